@@ -1,0 +1,237 @@
+"""Synthetic structured blocks for the residual/smoother hot path.
+
+The reference's regression meshes (CGNS) are downloaded at test time and are
+absent here, so parity and benchmarks run on analytic
+curvilinear blocks.  Arrays carry exactly the bounds the
+reference allocates in Fortran (column-major) order:
+
+    w,dw      (0:ib,0:jb,0:kb,1:nw)     p,gamma,rlv,rev,vol,iblank (0:ib,0:jb,0:kb)
+    x         (0:ie,0:je,0:ke,3)        sI (0:ie,1:je,1:ke,3)  sJ (1:ie,0:je,1:ke,3)
+    sK        (1:ie,1:je,0:ke,3)        porI (1:il,2:jl,2:kl)  porJ (2:il,1:jl,2:kl)
+    porK      (2:il,2:jl,1:kl)          d2Wall (2:il,2:jl,2:kl)
+
+Face metrics and volumes follow the reference's formulas
+(`src/adjoint/adjointExtra.F90:5-178` volume_block, `:179-300` metric_block),
+written here as whole-array numpy expressions.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict
+
+import numpy as np
+
+from .params import FlowParams, normalFlux, boundFlux, noFlux
+
+
+@dataclass
+class Block:
+    nx: int
+    ny: int
+    nz: int
+    nw: int
+    a: Dict[str, np.ndarray] = field(default_factory=dict)
+
+    # index helpers (reference naming)
+    @property
+    def il(self): return self.nx + 1
+    @property
+    def jl(self): return self.ny + 1
+    @property
+    def kl(self): return self.nz + 1
+    @property
+    def ie(self): return self.nx + 2
+    @property
+    def je(self): return self.ny + 2
+    @property
+    def ke(self): return self.nz + 2
+    @property
+    def ib(self): return self.nx + 3
+    @property
+    def jb(self): return self.ny + 3
+    @property
+    def kb(self): return self.nz + 3
+    @property
+    def ncells(self): return self.nx * self.ny * self.nz
+
+    def __getitem__(self, k):
+        return self.a[k]
+
+    def __setitem__(self, k, v):
+        self.a[k] = v
+
+    def owned(self, name):
+        """View of the owned cells (2:il,2:jl,2:kl[,:]) of a (0:ib,..) array."""
+        return self.a[name][2:self.il + 1, 2:self.jl + 1, 2:self.kl + 1]
+
+    def copy(self) -> "Block":
+        return Block(self.nx, self.ny, self.nz, self.nw, {k: v.copy(order="F") for k, v in self.a.items()})
+
+
+def F(shape, dtype=np.float64):
+    return np.zeros(shape, dtype=dtype, order="F")
+
+
+# ----------------------------------------------------------------------------
+# geometry
+# ----------------------------------------------------------------------------
+def make_nodes(nx, ny, nz, lengths=(1.0, 1.0, 1.0), amp=0.02, stretch_k=1.0, origin=(0.0, 0.0, 0.0)):
+    """Nodes x(0:ie,0:je,0:ke,3): smooth non-orthogonal right-handed map of the
+    unit cube (node 1 -> 0, node il -> 1; halo nodes 0 and ie continue the map)."""
+    ie, je, ke = nx + 2, ny + 2, nz + 2
+    xi = (np.arange(ie + 1) - 1.0) / nx
+    et = (np.arange(je + 1) - 1.0) / ny
+    ze = (np.arange(ke + 1) - 1.0) / nz
+    if stretch_k != 1.0:
+        # geometric-like clustering towards the k=kmin plane (wall)
+        s = stretch_k
+        ze = np.sign(ze) * (np.expm1(s * np.abs(ze)) / math.expm1(s))
+    X, E, Z = np.meshgrid(xi, et, ze, indexing="ij")
+    tp = 2.0 * math.pi
+    x = F((ie + 1, je + 1, ke + 1, 3))
+    x[..., 0] = origin[0] + lengths[0] * (X + amp * np.sin(tp * E) * np.sin(tp * Z))
+    x[..., 1] = origin[1] + lengths[1] * (E + amp * np.sin(tp * X) * np.sin(tp * Z + 0.3))
+    x[..., 2] = origin[2] + lengths[2] * (Z + amp * np.sin(tp * X + 0.7) * np.sin(tp * E))
+    return x
+
+
+def _cross(a, b):
+    c = np.empty_like(a)
+    c[..., 0] = a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1]
+    c[..., 1] = a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2]
+    c[..., 2] = a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+    return c
+
+
+def face_metrics(x):
+    """sI(0:ie,1:je,1:ke,3), sJ(1:ie,0:je,1:ke,3), sK(1:ie,1:je,0:ke,3) — half the
+    cross product of the face diagonals (metric_block, adjointExtra.F90:212-300)."""
+    # i-faces: v1 = x(i,j,n) - x(i,m,k), v2 = x(i,j,k) - x(i,m,n), m=j-1, n=k-1
+    v1 = x[:, 1:, :-1] - x[:, :-1, 1:]
+    v2 = x[:, 1:, 1:] - x[:, :-1, :-1]
+    sI = np.asfortranarray(0.5 * _cross(v1, v2))
+    # j-faces: v1 = x(i,j,n) - x(l,j,k), v2 = x(l,j,n) - x(i,j,k), l=i-1
+    v1 = x[1:, :, :-1] - x[:-1, :, 1:]
+    v2 = x[:-1, :, :-1] - x[1:, :, 1:]
+    sJ = np.asfortranarray(0.5 * _cross(v1, v2))
+    # k-faces: v1 = x(i,j,k) - x(l,m,k), v2 = x(l,j,k) - x(i,m,k)
+    v1 = x[1:, 1:, :] - x[:-1, :-1, :]
+    v2 = x[:-1, 1:, :] - x[1:, :-1, :]
+    sK = np.asfortranarray(0.5 * _cross(v1, v2))
+    return sI, sJ, sK
+
+
+def cell_volumes(x):
+    """vol(0:ib,0:jb,0:kb) — six-pyramid split about the cell centroid
+    (volume_block, adjointExtra.F90:40-110); 2nd-halo entries stay zero."""
+    ie, je, ke = x.shape[0] - 1, x.shape[1] - 1, x.shape[2] - 1
+    # corner views for cells 1..ie: (i or l=i-1, j or m=j-1, k or n=k-1)
+    c = {}
+    for a, sa in (("i", slice(1, None)), ("l", slice(0, -1))):
+        for b, sb in (("j", slice(1, None)), ("m", slice(0, -1))):
+            for d, sd in (("k", slice(1, None)), ("n", slice(0, -1))):
+                c[a + b + d] = x[sa, sb, sd]
+    cg = 0.125 * sum(c.values())
+
+    def volpym(a, b, cc, d):
+        q = 0.25 * (a + b + cc + d)
+        ac = a - cc
+        bd = b - d
+        return ((cg[..., 0] - q[..., 0]) * (ac[..., 1] * bd[..., 2] - ac[..., 2] * bd[..., 1])
+                + (cg[..., 1] - q[..., 1]) * (ac[..., 2] * bd[..., 0] - ac[..., 0] * bd[..., 2])
+                + (cg[..., 2] - q[..., 2]) * (ac[..., 0] * bd[..., 1] - ac[..., 1] * bd[..., 0]))
+
+    vp = (volpym(c["ijk"], c["ijn"], c["imn"], c["imk"])
+          + volpym(c["ljk"], c["lmk"], c["lmn"], c["ljn"])
+          + volpym(c["ijk"], c["ljk"], c["ljn"], c["ijn"])
+          + volpym(c["imk"], c["imn"], c["lmn"], c["lmk"])
+          + volpym(c["ijk"], c["imk"], c["lmk"], c["ljk"])
+          + volpym(c["ijn"], c["ljn"], c["lmn"], c["imn"]))
+    vol = F((ie + 2, je + 2, ke + 2))
+    vol[1:ie + 1, 1:je + 1, 1:ke + 1] = np.abs(vp / 6.0)
+    return vol
+
+
+# ----------------------------------------------------------------------------
+# state
+# ----------------------------------------------------------------------------
+def sutherland(prm: FlowParams, rho, p):
+    """computeLamViscosity, flowUtils.F90:1201-1300 (no k correction for SA)."""
+    muSuth = prm.muSuthDim / prm.muRef
+    TSuth = prm.TSuthDim / prm.TRef
+    SSuth = prm.SSuthDim / prm.TRef
+    T = p / (prm.RGas * rho)
+    return muSuth * ((TSuth + SSuth) / (T + SSuth)) * (T / TSuth) ** 1.5
+
+
+def sa_eddy_viscosity(prm: FlowParams, rho, nut, rlv):
+    """saEddyViscosity, turbUtils.F90:657-720: rev = rho*nuTilde*fv1."""
+    cv13 = prm.SAcv1 ** 3
+    chi = rho * nut / rlv
+    chi3 = chi ** 3
+    return rho * nut * chi3 / (chi3 + cv13)
+
+
+def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.0), amp=0.02,
+               stretch_k=1.0, wall_kmin=None, noise=0.02, wave=0.05, origin=(0.0, 0.0, 0.0)) -> Block:
+    """Analytic curvilinear block + perturbed free-stream state."""
+    rng = np.random.default_rng(seed)
+    nw = prm.nw
+    b = Block(nx, ny, nz, nw)
+    ib, jb, kb = b.ib, b.jb, b.kb
+    x = make_nodes(nx, ny, nz, lengths, amp, stretch_k, origin)
+    sI, sJ, sK = face_metrics(x)
+    vol = cell_volumes(x)
+    b["x"], b["sI"], b["sJ"], b["sK"], b["vol"] = x, sI, sJ, sK, vol
+    b["volRef"] = vol.copy(order="F")
+
+    # cell-centre parametric coordinates for all cells 0..ib
+    ci = (np.arange(ib + 1) - 1.5) / nx
+    cj = (np.arange(jb + 1) - 1.5) / ny
+    ck = (np.arange(kb + 1) - 1.5) / nz
+    X, E, Z = np.meshgrid(ci, cj, ck, indexing="ij")
+    tp = 2.0 * math.pi
+    winf = prm.wInf()
+    gam = prm.gammaConstant
+
+    def pert(phase):
+        return 1.0 + wave * np.sin(tp * (3 * X + 2 * E + Z) + phase) + noise * rng.uniform(-1.0, 1.0, X.shape)
+
+    w = F((ib + 1, jb + 1, kb + 1, nw))
+    w[..., 0] = winf[0] * pert(0.0)
+    w[..., 1] = winf[1] * pert(0.4)
+    w[..., 2] = winf[1] * 0.1 * (pert(1.1) - 0.95) + winf[2] * pert(0.9)
+    w[..., 3] = winf[1] * 0.1 * (pert(2.3) - 1.0)
+    pr = prm.pInf * pert(1.7)
+    v2 = w[..., 1] ** 2 + w[..., 2] ** 2 + w[..., 3] ** 2
+    w[..., 4] = pr / (gam - 1.0) + 0.5 * w[..., 0] * v2
+    b["w"] = w
+    b["p"] = np.asfortranarray(pr)
+    b["gamma"] = np.full((ib + 1, jb + 1, kb + 1), gam, order="F")
+    b["iblank"] = np.ones((ib + 1, jb + 1, kb + 1), dtype=np.int32, order="F")
+
+    porI = np.full((nx + 1, ny, nz), normalFlux, dtype=np.int8, order="F")
+    porJ = np.full((nx, ny + 1, nz), normalFlux, dtype=np.int8, order="F")
+    porK = np.full((nx, ny, nz + 1), normalFlux, dtype=np.int8, order="F")
+    if wall_kmin is None:
+        wall_kmin = prm.viscous
+    if wall_kmin:
+        porK[:, :, 0] = boundFlux  # solid wall on the k = kmin face
+    b["porI"], b["porJ"], b["porK"] = porI, porJ, porK
+
+    if prm.viscous:
+        b["rlv"] = np.asfortranarray(sutherland(prm, w[..., 0], pr))
+    else:
+        b["rlv"] = F((ib + 1, jb + 1, kb + 1))
+    b["rev"] = F((ib + 1, jb + 1, kb + 1))
+    if nw > 5:
+        nu_inf = prm.muInf / prm.rhoInf
+        w[..., 5] = 3.0 * nu_inf * (1.0 + 0.5 * rng.uniform(0.0, 1.0, X.shape)) * (1.0 + 40.0 * np.clip(Z, 0, 1) * np.exp(-4 * np.clip(Z, 0, 1)))
+        b["rev"] = np.asfortranarray(sa_eddy_viscosity(prm, w[..., 0], w[..., 5], b["rlv"]))
+    # wall distance: distance from the cell centre to the k=kmin plane (>= 1e-6)
+    xc = 0.125 * (x[1:, 1:, 1:] + x[:-1, 1:, 1:] + x[1:, :-1, 1:] + x[:-1, :-1, 1:]
+                  + x[1:, 1:, :-1] + x[:-1, 1:, :-1] + x[1:, :-1, :-1] + x[:-1, :-1, :-1])
+    d = xc[1:nx + 1, 1:ny + 1, 1:nz + 1, 2] - origin[2]
+    b["d2Wall"] = np.asfortranarray(np.maximum(d, 1e-6))
+    return b

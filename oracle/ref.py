@@ -1,0 +1,137 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+
+ctypes front-end to oracle/_ref/libadflow_ref.so: the reference's OWN Fortran
+hot-path routines (fluxes.F90, solverUtils.F90, residuals.F90, flowUtils.F90,
+sa.F90, adjointExtra.F90) compiled unchanged with amdflang; see
+oracle/refbuild/{Makefile,ref_driver.F90}.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB: Optional[ctypes.CDLL] = None
+
+
+def lib_path(fast: bool = False) -> str:
+    return os.path.join(_HERE, "_ref", "libadflow_ref_fast.so" if fast else "libadflow_ref.so")
+
+
+def available(fast: bool = False) -> bool:
+    return os.path.exists(lib_path(fast))
+
+
+def load(fast: bool = False) -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        lib = ctypes.CDLL(lib_path(fast), mode=ctypes.RTLD_GLOBAL)
+        lib.ref_set_dims.argtypes = [ctypes.c_int] * 5
+        lib.ref_set_ptr.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+        lib.ref_set_int.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        lib.ref_set_real.argtypes = [ctypes.c_char_p, ctypes.c_double]
+        lib.ref_set_vec.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int]
+        lib.ref_call.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        lib.ref_block_res_core.argtypes = [ctypes.c_int] * 3
+        _LIB = lib
+    return _LIB
+
+
+_INT_PARAMS = ["equations", "spaceDiscr", "spaceDiscrCoarse", "limiter", "orderTurb", "turbModel", "turbProd",
+               "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb"]
+_BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA"]
+_REAL_PARAMS = ["vis2", "vis4", "vis2Coarse", "adis", "acousticScaleFactor", "kappaCoef", "sigma", "cfl",
+                "cflCoarse", "cflLimit", "fcoll", "smoop", "alfaTurb", "betaTurb", "rFil", "gammaConstant",
+                "gammaInf", "pInf", "pInfCorr", "rhoInf", "uInf", "RGas", "muInf", "muRef", "TRef", "timeRef",
+                "prandtl", "prandtlTurb", "SSuthDim", "muSuthDim", "TSuthDim", "SAKappa", "SAcb1", "SAcb2",
+                "SAsigma", "SAcv1", "SAcw1", "SAcw2", "SAcw3", "SAct1", "SAct2", "SAct3", "SAct4", "SAcrot",
+                "eddyVisInfRatio"]
+
+
+def set_params(prm) -> None:
+    """Assign the reference's module variables from a FlowParams record (what
+    pyADflow does through f2py, pyADflow.py:5463-5630)."""
+    lib = load()
+    for n in _INT_PARAMS:
+        lib.ref_set_int(n.encode(), int(getattr(prm, n)))
+    for n in _BOOL_PARAMS:
+        lib.ref_set_int(n.encode(), int(bool(getattr(prm, n))))
+    for n in _REAL_PARAMS:
+        lib.ref_set_real(n.encode(), float(getattr(prm, n)))
+    # fixed settings of every BASELINE config: steady, calorically perfect gas,
+    # no preconditioner, no wall functions, no dissipation continuation
+    for n, v in (("equationMode", 1), ("cpModel", 1), ("precond", 1), ("kPresent", 0), ("lumpedDiss", 0),
+                 ("approxSA", 0), ("radiiNeededFine", 1), ("radiiNeededCoarse", 1), ("lowSpeedPreconditioner", 0),
+                 ("wallFunctions", 0), ("useDissContinuation", 0), ("nTimeIntervalsSpectral", 1),
+                 ("vortexCorr", 0), ("riemann", 1), ("riemannCoarse", 1), ("turbTreatment", 1), ("turbRelax", 1)):
+        lib.ref_set_int(n.encode(), v)
+    for n, v in (("totalR", 0.0), ("totalR0", 0.0), ("pRef", prm.pInfDim), ("rhoRef", prm.rhoInfDim)):
+        lib.ref_set_real(n.encode(), v)
+    for n in ("etaRK", "cdisRK"):
+        v = np.ascontiguousarray(getattr(prm, n), dtype=np.float64)
+        lib.ref_set_vec(n.encode(), v.ctypes.data, v.size)
+    w = np.zeros(10)
+    wi = prm.wInf()
+    w[:len(wi)] = wi
+    lib.ref_set_vec(b"wInf", w.ctypes.data, 10)
+    t = np.full(4, float(prm.turbResScale))
+    lib.ref_set_vec(b"turbResScale", t.ctypes.data, 4)
+
+
+_WORK3_CELL = ["aa"]
+_WORK3_IE = ["dtl", "radI", "radJ", "radK"]
+_GRADS = ["ux", "uy", "uz", "vx", "vy", "vz", "wx", "wy", "wz", "qx", "qy", "qz"]
+
+
+def bind_block(blk, prm) -> None:
+    """Aim the reference's blockPointers at `blk`'s arrays, creating the work
+    arrays (dw, fw, dtl, radI/J/K, aa, nodal gradients, scratch, wn, pn) it owns
+    in the reference with the reference's bounds."""
+    lib = load()
+    set_params(prm)
+    lib.ref_set_dims(blk.nx, blk.ny, blk.nz, blk.nw, 5)
+    ib, jb, kb = blk.ib, blk.jb, blk.kb
+    ie, je, ke = blk.ie, blk.je, blk.ke
+    a = blk.a
+
+    def need(name, shape, dtype=np.float64):
+        if name not in a:
+            a[name] = np.zeros(shape, dtype=dtype, order="F")
+
+    need("dw", (ib + 1, jb + 1, kb + 1, blk.nw))
+    need("fw", (ib + 1, jb + 1, kb + 1, 5))
+    need("scratch", (ib + 1, jb + 1, kb + 1, 10))
+    need("aa", (ib + 1, jb + 1, kb + 1))
+    for n in _WORK3_IE:
+        need(n, (ie, je, ke))
+    for n in _GRADS:
+        need(n, (blk.il, blk.jl, blk.kl))
+    need("wn", (blk.nx, blk.ny, blk.nz, 5))
+    need("pn", (blk.nx, blk.ny, blk.nz))
+    need("wr", (blk.nx, blk.ny, blk.nz, 5))
+    need("w1", (ie, je, ke, 5))
+    need("p1", (ie, je, ke))
+    for nm, shp in (("bmti1", (je, ke, 1, 1)), ("bmti2", (je, ke, 1, 1)), ("bmtj1", (ie, ke, 1, 1)),
+                    ("bmtj2", (ie, ke, 1, 1)), ("bmtk1", (ie, je, 1, 1)), ("bmtk2", (ie, je, 1, 1)),
+                    ("bvti1", (je, ke, 1)), ("bvti2", (je, ke, 1)), ("bvtj1", (ie, ke, 1)),
+                    ("bvtj2", (ie, ke, 1)), ("bvtk1", (ie, je, 1)), ("bvtk2", (ie, je, 1))):
+        need(nm, shp)
+    for name in ["w", "p", "gamma", "rlv", "rev", "vol", "volRef", "iblank", "x", "sI", "sJ", "sK",
+                 "porI", "porJ", "porK", "d2Wall", "dw", "fw", "scratch", "aa", "wn", "pn", "wr", "w1", "p1",
+                 "bmti1", "bmti2", "bmtj1", "bmtj2", "bmtk1", "bmtk2",
+                 "bvti1", "bvti2", "bvtj1", "bvtj2", "bvtk1", "bvtk2"] + _WORK3_IE + _GRADS:
+        arr = a[name]
+        assert arr.flags["F_CONTIGUOUS"], name
+        lib.ref_set_ptr(name.encode(), arr.ctypes.data)
+
+
+def call(name: str, iarg: int = 0) -> None:
+    load().ref_call(name.encode(), int(iarg))
+
+
+def block_res_core(update_intermed=True, flow_res=True, turb_res=True) -> None:
+    """blockette::blockResCore (blockette.F90:755-852) call sequence."""
+    load().ref_block_res_core(int(update_intermed), int(flow_res), int(turb_res))

@@ -1,0 +1,463 @@
+! TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+!
+! bind(C) driver around the reference's own per-block hot-path routines
+! (compiled in place from /root/reference by oracle/refbuild/Makefile).  It
+! aims the reference's module-global `blockPointers` at caller-owned buffers
+! (numpy arrays, Fortran order, bounds exactly as the reference allocates them:
+! SURVEY.md §8(a) row T) and calls the reference routine unchanged.  Nothing of
+! the reference's arithmetic is restated here.
+!
+! Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+! the resulting oracle/_ref/libadflow_ref.so.
+module ref_driver
+    use iso_c_binding
+    use constants
+    implicit none
+
+    ! scratch arrays the reference expects to be allocated but that carry no
+    ! information for a steady single-section block
+    integer(kind=intType), dimension(:, :, :), allocatable, target :: indFamI, indFamJ, indFamK
+    integer(kind=intType), dimension(:, :, :), allocatable, target :: facFamI, facFamJ, facFamK
+
+contains
+
+    function cstr(s) result(f)
+        character(kind=c_char), dimension(*), intent(in) :: s
+        character(len=64) :: f
+        integer :: i
+        f = ' '
+        do i = 1, 64
+            if (s(i) == c_null_char) exit
+            f(i:i) = s(i)
+        end do
+    end function cstr
+
+    ! ------------------------------------------------------------------ dims
+    subroutine ref_set_dims(nx_, ny_, nz_, nw_, nwf_) bind(C, name="ref_set_dims")
+        use blockPointers
+        use flowVarRefState, only: nw, nwf, nwt, nt1, nt2, wInf
+        use cgnsGrid, only: massFlowFamilyInv, massFlowFamilyDiss
+        integer(c_int), value :: nx_, ny_, nz_, nw_, nwf_
+        nx = nx_; ny = ny_; nz = nz_
+        il = nx + 1; jl = ny + 1; kl = nz + 1
+        ie = nx + 2; je = ny + 2; ke = nz + 2
+        ib = nx + 3; jb = ny + 3; kb = nz + 3
+        nw = nw_; nwf = nwf_; nwt = nw - nwf; nt1 = nwf + 1; nt2 = nw
+        spectralSol = 1; sectionID = 1; nbkLocal = 1; nbkGlobal = 1
+        rightHanded = .true.
+        blockIsMoving = .false.; addGridVelocities = .false.
+        nBocos = 0; nViscBocos = 0; nSubface = 0; n1to1 = 0
+        if (allocated(indFamI)) deallocate (indFamI, indFamJ, indFamK, facFamI, facFamJ, facFamK)
+        allocate (indFamI(1:il, 2:jl, 2:kl), indFamJ(2:il, 1:jl, 2:kl), indFamK(2:il, 2:jl, 1:kl))
+        allocate (facFamI(1:il, 2:jl, 2:kl), facFamJ(2:il, 1:jl, 2:kl), facFamK(2:il, 2:jl, 1:kl))
+        indFamI = 0; indFamJ = 0; indFamK = 0; facFamI = 0; facFamJ = 0; facFamK = 0
+        indFamilyI => indFamI; indFamilyJ => indFamJ; indFamilyK => indFamK
+        factFamilyI => facFamI; factFamilyJ => facFamJ; factFamilyK => facFamK
+        if (.not. allocated(massFlowFamilyInv)) then
+            allocate (massFlowFamilyInv(0:0, 1), massFlowFamilyDiss(0:0, 1))
+        end if
+        massFlowFamilyInv = zero; massFlowFamilyDiss = zero
+        if (.not. allocated(wInf)) then
+            allocate (wInf(10)); wInf = zero
+        end if
+    end subroutine ref_set_dims
+
+    ! -------------------------------------------------------------- pointers
+    subroutine ref_set_ptr(name, ptr) bind(C, name="ref_set_ptr")
+        use blockPointers
+        character(kind=c_char), dimension(*), intent(in) :: name
+        type(c_ptr), value :: ptr
+        real(kind=realType), dimension(:, :, :), pointer :: t3
+        real(kind=realType), dimension(:, :, :, :), pointer :: t4
+        integer(kind=intType), dimension(:, :, :), pointer :: i3
+        integer(kind=porType), dimension(:, :, :), pointer :: b3
+        integer(kind=intType) :: nwl
+        character(len=64) :: n
+        n = cstr(name)
+        select case (trim(n))
+        case ('w', 'dw')
+            nwl = ref_nw()
+            call c_f_pointer(ptr, t4, [ib + 1, jb + 1, kb + 1, nwl])
+            select case (trim(n))
+            case ('w'); w(0:, 0:, 0:, 1:) => t4
+            case ('dw'); dw(0:, 0:, 0:, 1:) => t4
+            end select
+        case ('wn', 'wr')
+            call c_f_pointer(ptr, t4, [nx, ny, nz, ref_nwf()])
+            select case (trim(n))
+            case ('wn'); wn(2:, 2:, 2:, 1:) => t4
+            case ('wr'); wr(2:, 2:, 2:, 1:) => t4
+            end select
+        case ('w1')
+            call c_f_pointer(ptr, t4, [ie, je, ke, ref_nwf()])
+            w1(1:, 1:, 1:, 1:) => t4
+        case ('bmti1', 'bmti2')
+            call c_f_pointer(ptr, t4, [je, ke, 1, 1])
+            if (trim(n) == 'bmti1') bmti1(1:, 1:, ref_nt1():, ref_nt1():) => t4
+            if (trim(n) == 'bmti2') bmti2(1:, 1:, ref_nt1():, ref_nt1():) => t4
+        case ('bmtj1', 'bmtj2')
+            call c_f_pointer(ptr, t4, [ie, ke, 1, 1])
+            if (trim(n) == 'bmtj1') bmtj1(1:, 1:, ref_nt1():, ref_nt1():) => t4
+            if (trim(n) == 'bmtj2') bmtj2(1:, 1:, ref_nt1():, ref_nt1():) => t4
+        case ('bmtk1', 'bmtk2')
+            call c_f_pointer(ptr, t4, [ie, je, 1, 1])
+            if (trim(n) == 'bmtk1') bmtk1(1:, 1:, ref_nt1():, ref_nt1():) => t4
+            if (trim(n) == 'bmtk2') bmtk2(1:, 1:, ref_nt1():, ref_nt1():) => t4
+        case ('bvti1', 'bvti2')
+            call c_f_pointer(ptr, t3, [je, ke, 1])
+            if (trim(n) == 'bvti1') bvti1(1:, 1:, ref_nt1():) => t3
+            if (trim(n) == 'bvti2') bvti2(1:, 1:, ref_nt1():) => t3
+        case ('bvtj1', 'bvtj2')
+            call c_f_pointer(ptr, t3, [ie, ke, 1])
+            if (trim(n) == 'bvtj1') bvtj1(1:, 1:, ref_nt1():) => t3
+            if (trim(n) == 'bvtj2') bvtj2(1:, 1:, ref_nt1():) => t3
+        case ('bvtk1', 'bvtk2')
+            call c_f_pointer(ptr, t3, [ie, je, 1])
+            if (trim(n) == 'bvtk1') bvtk1(1:, 1:, ref_nt1():) => t3
+            if (trim(n) == 'bvtk2') bvtk2(1:, 1:, ref_nt1():) => t3
+        case ('fw')
+            call c_f_pointer(ptr, t4, [ib + 1, jb + 1, kb + 1, ref_nwf()])
+            fw(0:, 0:, 0:, 1:) => t4
+        case ('scratch')
+            call c_f_pointer(ptr, t4, [ib + 1, jb + 1, kb + 1, 10])
+            scratch(0:, 0:, 0:, 1:) => t4
+        case ('p', 'gamma', 'rlv', 'rev', 'aa', 'vol', 'volRef', 'shockSensor')
+            call c_f_pointer(ptr, t3, [ib + 1, jb + 1, kb + 1])
+            select case (trim(n))
+            case ('p'); p(0:, 0:, 0:) => t3
+            case ('gamma'); gamma(0:, 0:, 0:) => t3
+            case ('rlv'); rlv(0:, 0:, 0:) => t3
+            case ('rev'); rev(0:, 0:, 0:) => t3
+            case ('aa'); aa(0:, 0:, 0:) => t3
+            case ('vol'); vol(0:, 0:, 0:) => t3
+            case ('volRef'); volRef(0:, 0:, 0:) => t3
+            case ('shockSensor'); shockSensor(0:, 0:, 0:) => t3
+            end select
+        case ('iblank')
+            call c_f_pointer(ptr, i3, [ib + 1, jb + 1, kb + 1])
+            iblank(0:, 0:, 0:) => i3
+        case ('x')
+            call c_f_pointer(ptr, t4, [ie + 1, je + 1, ke + 1, 3])
+            x(0:, 0:, 0:, 1:) => t4
+        case ('sI')
+            call c_f_pointer(ptr, t4, [ie + 1, je, ke, 3])
+            sI(0:, 1:, 1:, 1:) => t4
+        case ('sJ')
+            call c_f_pointer(ptr, t4, [ie, je + 1, ke, 3])
+            sJ(1:, 0:, 1:, 1:) => t4
+        case ('sK')
+            call c_f_pointer(ptr, t4, [ie, je, ke + 1, 3])
+            sK(1:, 1:, 0:, 1:) => t4
+        case ('porI')
+            call c_f_pointer(ptr, b3, [il, ny, nz])
+            porI(1:, 2:, 2:) => b3
+        case ('porJ')
+            call c_f_pointer(ptr, b3, [nx, jl, nz])
+            porJ(2:, 1:, 2:) => b3
+        case ('porK')
+            call c_f_pointer(ptr, b3, [nx, ny, kl])
+            porK(2:, 2:, 1:) => b3
+        case ('dtl', 'radI', 'radJ', 'radK')
+            call c_f_pointer(ptr, t3, [ie, je, ke])
+            select case (trim(n))
+            case ('dtl'); dtl(1:, 1:, 1:) => t3
+            case ('radI'); radI(1:, 1:, 1:) => t3
+            case ('radJ'); radJ(1:, 1:, 1:) => t3
+            case ('radK'); radK(1:, 1:, 1:) => t3
+            end select
+        case ('d2Wall')
+            call c_f_pointer(ptr, t3, [nx, ny, nz])
+            d2Wall(2:, 2:, 2:) => t3
+        case ('pn')
+            call c_f_pointer(ptr, t3, [nx, ny, nz])
+            pn(2:, 2:, 2:) => t3
+        case ('p1')
+            call c_f_pointer(ptr, t3, [ie, je, ke])
+            p1(1:, 1:, 1:) => t3
+        case ('ux', 'uy', 'uz', 'vx', 'vy', 'vz', 'wx', 'wy', 'wz', 'qx', 'qy', 'qz')
+            call c_f_pointer(ptr, t3, [il, jl, kl])
+            select case (trim(n))
+            case ('ux'); ux => t3
+            case ('uy'); uy => t3
+            case ('uz'); uz => t3
+            case ('vx'); vx => t3
+            case ('vy'); vy => t3
+            case ('vz'); vz => t3
+            case ('wx'); wx => t3
+            case ('wy'); wy => t3
+            case ('wz'); wz => t3
+            case ('qx'); qx => t3
+            case ('qy'); qy => t3
+            case ('qz'); qz => t3
+            end select
+        case default
+            print *, 'ref_set_ptr: unknown array ', trim(n)
+            stop 1
+        end select
+    end subroutine ref_set_ptr
+
+    integer function ref_nw()
+        use flowVarRefState, only: nw
+        ref_nw = nw
+    end function ref_nw
+
+    integer function ref_nwf()
+        use flowVarRefState, only: nwf
+        ref_nwf = nwf
+    end function ref_nwf
+
+    integer function ref_nt1()
+        use flowVarRefState, only: nt1
+        ref_nt1 = nt1
+    end function ref_nt1
+
+    ! --------------------------------------------------------------- scalars
+    subroutine ref_set_int(name, v) bind(C, name="ref_set_int")
+        use inputDiscretization
+        use inputIteration
+        use inputPhysics
+        use iteration
+        use flowVarRefState, only: viscous, eddyModel, kPresent
+        use inputTimeSpectral, only: nTimeIntervalsSpectral
+        use inputUnsteady, only: timeIntegrationScheme
+        character(kind=c_char), dimension(*), intent(in) :: name
+        integer(c_int), value :: v
+        character(len=64) :: n
+        n = cstr(name)
+        select case (trim(n))
+        case ('equations'); equations = v
+        case ('equationMode'); equationMode = v
+        case ('spaceDiscr'); spaceDiscr = v
+        case ('spaceDiscrCoarse'); spaceDiscrCoarse = v
+        case ('limiter'); limiter = v
+        case ('precond'); precond = v
+        case ('orderTurb'); orderTurb = v
+        case ('riemann'); riemann = v
+        case ('riemannCoarse'); riemannCoarse = v
+        case ('turbModel'); turbModel = v
+        case ('turbProd'); turbProd = v
+        case ('cpModel'); cpModel = v
+        case ('smoother'); smoother = v
+        case ('nRKStages'); nRKStages = v
+        case ('rkStage'); rkStage = v
+        case ('currentLevel'); currentLevel = v
+        case ('groundLevel'); groundLevel = v
+        case ('resAveraging'); resAveraging = v
+        case ('turbTreatment'); turbTreatment = v
+        case ('turbRelax'); turbRelax = v
+        case ('nSubIterTurb'); nSubIterTurb = v
+        case ('nTimeIntervalsSpectral'); nTimeIntervalsSpectral = v
+        case ('timeIntegrationScheme'); timeIntegrationScheme = v
+        case ('viscous'); viscous = (v /= 0)
+        case ('eddyModel'); eddyModel = (v /= 0)
+        case ('kPresent'); kPresent = (v /= 0)
+        case ('dirScaling'); dirScaling = (v /= 0)
+        case ('lumpedDiss'); lumpedDiss = (v /= 0)
+        case ('approxSA'); approxSA = (v /= 0)
+        case ('radiiNeededFine'); radiiNeededFine = (v /= 0)
+        case ('radiiNeededCoarse'); radiiNeededCoarse = (v /= 0)
+        case ('lowSpeedPreconditioner'); lowSpeedPreconditioner = (v /= 0)
+        case ('useQCR'); useQCR = (v /= 0)
+        case ('useRotationSA'); useRotationSA = (v /= 0)
+        case ('useft2SA'); useft2SA = (v /= 0)
+        case ('wallFunctions'); wallFunctions = (v /= 0)
+        case ('useDissContinuation'); useDissContinuation = (v /= 0)
+        case ('vortexCorr'); vortexCorr = (v /= 0)
+        case default
+            print *, 'ref_set_int: unknown name ', trim(n)
+            stop 1
+        end select
+    end subroutine ref_set_int
+
+    subroutine ref_set_real(name, v) bind(C, name="ref_set_real")
+        use inputDiscretization
+        use inputIteration
+        use inputPhysics
+        use iteration
+        use flowVarRefState
+        use paramTurb, only: rsaCw1
+        character(kind=c_char), dimension(*), intent(in) :: name
+        real(c_double), value :: v
+        character(len=64) :: n
+        n = cstr(name)
+        select case (trim(n))
+        case ('vis2'); vis2 = v
+        case ('vis4'); vis4 = v
+        case ('vis2Coarse'); vis2Coarse = v
+        case ('adis'); adis = v
+        case ('acousticScaleFactor'); acousticScaleFactor = v
+        case ('kappaCoef'); kappaCoef = v
+        case ('sigma'); sigma = v
+        case ('cfl'); cfl = v
+        case ('cflCoarse'); cflCoarse = v
+        case ('cflLimit'); cflLimit = v
+        case ('fcoll'); fcoll = v
+        case ('smoop'); smoop = v
+        case ('alfaTurb'); alfaTurb = v
+        case ('betaTurb'); betaTurb = v
+        case ('rFil'); rFil = v
+        case ('totalR'); totalR = v
+        case ('totalR0'); totalR0 = v
+        case ('gammaConstant'); gammaConstant = v
+        case ('gammaInf'); gammaInf = v
+        case ('pInf'); pInf = v
+        case ('pInfCorr'); pInfCorr = v
+        case ('rhoInf'); rhoInf = v
+        case ('uInf'); uInf = v
+        case ('RGas'); RGas = v
+        case ('muInf'); muInf = v
+        case ('muRef'); muRef = v
+        case ('TRef'); TRef = v
+        case ('pRef'); pRef = v
+        case ('rhoRef'); rhoRef = v
+        case ('timeRef'); timeRef = v
+        case ('prandtl'); prandtl = v
+        case ('prandtlTurb'); prandtlTurb = v
+        case ('SSuthDim'); SSuthDim = v
+        case ('muSuthDim'); muSuthDim = v
+        case ('TSuthDim'); TSuthDim = v
+        case ('SAKappa'); SAKappa = v
+        case ('SAcb1'); SAcb1 = v
+        case ('SAcb2'); SAcb2 = v
+        case ('SAsigma'); SAsigma = v
+        case ('SAcv1'); SAcv1 = v
+        case ('SAcw1'); rsaCw1 = v
+        case ('SAcw2'); SAcw2 = v
+        case ('SAcw3'); SAcw3 = v
+        case ('SAct1'); SAct1 = v
+        case ('SAct2'); SAct2 = v
+        case ('SAct3'); SAct3 = v
+        case ('SAct4'); SAct4 = v
+        case ('SAcrot'); SAcrot = v
+        case ('eddyVisInfRatio'); eddyVisInfRatio = v
+        case ('wallOffset'); wallOffset = v
+        case ('pklim'); pklim = v
+        case ('dissContMagnitude'); dissContMagnitude = v
+        case ('dissContMidpoint'); dissContMidpoint = v
+        case ('dissContSharpness'); dissContSharpness = v
+        case default
+            print *, 'ref_set_real: unknown name ', trim(n)
+            stop 1
+        end select
+    end subroutine ref_set_real
+
+    subroutine ref_set_vec(name, v, nv) bind(C, name="ref_set_vec")
+        use inputIteration, only: etaRK, cdisRK, turbResScale
+        use flowVarRefState, only: wInf
+        character(kind=c_char), dimension(*), intent(in) :: name
+        integer(c_int), value :: nv
+        real(c_double), dimension(nv), intent(in) :: v
+        character(len=64) :: n
+        n = cstr(name)
+        select case (trim(n))
+        case ('etaRK')
+            if (allocated(etaRK)) deallocate (etaRK)
+            allocate (etaRK(nv)); etaRK = v
+        case ('cdisRK')
+            if (allocated(cdisRK)) deallocate (cdisRK)
+            allocate (cdisRK(nv)); cdisRK = v
+        case ('wInf')
+            if (allocated(wInf)) deallocate (wInf)
+            allocate (wInf(nv)); wInf = v
+        case ('turbResScale')
+            turbResScale(1:nv) = v
+        case default
+            print *, 'ref_set_vec: unknown name ', trim(n)
+            stop 1
+        end select
+    end subroutine ref_set_vec
+
+    ! ----------------------------------------------------------------- calls
+    ! Each entry calls ONE reference routine, unchanged, on the current block.
+    subroutine ref_call(name, iarg) bind(C, name="ref_call")
+        use blockPointers
+        use flowVarRefState, only: nw, nwf, nt1, nt2
+        use solverUtils, only: timeStep_block
+        use fluxes
+        use residuals, only: residual_block, initres_block, computedwDADI, residualAveraging
+        use flowUtils, only: computeSpeedOfSoundSquared, allNodalGradients, computeEtotBlock, &
+                             computePressureSimple, computeLamViscosity
+        use turbUtils, only: computeEddyViscosity
+        use sa, only: sa_block
+        use adjointExtra, only: volume_block, metric_block, sumDwAndFw
+        character(kind=c_char), dimension(*), intent(in) :: name
+        integer(c_int), value :: iarg
+        character(len=64) :: n
+        n = cstr(name)
+        select case (trim(n))
+        case ('timeStep_block'); call timeStep_block(iarg /= 0)          ! solverUtils.F90:43
+        case ('initres_flow'); call initres_block(1_intType, nwf, 1_intType, 1_intType)   ! residuals.F90:427
+        case ('initres_all'); call initres_block(1_intType, nw, 1_intType, 1_intType)
+        case ('initres_turb'); call initres_block(nt1, nt2, 1_intType, 1_intType)
+        case ('inviscidCentralFlux'); call inviscidCentralFlux             ! fluxes.F90:4
+        case ('inviscidDissFluxScalar'); call inviscidDissFluxScalar       ! fluxes.F90:1049
+        case ('inviscidDissFluxMatrix'); call inviscidDissFluxMatrix       ! fluxes.F90:403
+        case ('inviscidUpwindFlux'); call inviscidUpwindFlux(iarg /= 0)    ! fluxes.F90:1438
+        case ('inviscidDissFluxScalarCoarse'); call inviscidDissFluxScalarCoarse
+        case ('inviscidDissFluxMatrixCoarse'); call inviscidDissFluxMatrixCoarse
+        case ('computeSpeedOfSoundSquared'); call computeSpeedOfSoundSquared
+        case ('allNodalGradients'); call allNodalGradients
+        case ('viscousFlux'); call viscousFlux                             ! fluxes.F90:2534
+        case ('residual_block'); call residual_block                       ! residuals.F90:4
+        case ('sumDwAndFw'); call sumDwAndFw
+        case ('sa_block'); call sa_block(iarg /= 0)                        ! sa.F90:16
+        case ('computedwDADI'); call computedwDADI                         ! residuals.F90:1062
+        case ('residualAveraging'); call residualAveraging                 ! residuals.F90:1785
+        case ('computeEtotBlock'); call computeEtotBlock(2_intType, il, 2_intType, jl, 2_intType, kl, iarg /= 0)
+        case ('computePressureSimple'); call computePressureSimple(iarg /= 0)
+        case ('computeLamViscosity'); call computeLamViscosity(iarg /= 0)
+        case ('computeEddyViscosity'); call computeEddyViscosity(iarg /= 0)
+        case ('volume_block'); call volume_block
+        case ('metric_block'); call metric_block
+        case ('zero_fw'); fw = zero
+        case default
+            print *, 'ref_call: unknown routine ', trim(n)
+            stop 1
+        end select
+    end subroutine ref_call
+
+    ! blockette::blockResCore (blockette.F90:755-852) cannot be linked here
+    ! (module blockette pulls in haloExchange/BC data/PETSc); this entry
+    ! issues the same sequence of reference calls in the same order.
+    subroutine ref_block_res_core(updateIntermed, flowRes, turbRes) bind(C, name="ref_block_res_core")
+        use blockPointers
+        use flowVarRefState, only: nw, nwf, nt1, nt2, viscous
+        use inputPhysics, only: equations, turbModel
+        use inputDiscretization, only: spaceDiscr
+        use solverUtils, only: timeStep_block
+        use fluxes
+        use residuals, only: initres_block
+        use flowUtils, only: computeSpeedOfSoundSquared, allNodalGradients
+        use sa, only: sa_block
+        use adjointExtra, only: sumDwAndFw
+        integer(c_int), value :: updateIntermed, flowRes, turbRes
+        integer(kind=intType) :: lStart, lEnd
+        lStart = 1; lEnd = nw
+        if (flowRes /= 0 .and. turbRes == 0) then
+            lEnd = nwf
+        else if (flowRes == 0 .and. turbRes /= 0) then
+            lStart = nt1; lEnd = nt2
+        end if
+        call timeStep_block(updateIntermed == 0)
+        call initres_block(lStart, lEnd, 1_intType, 1_intType)
+        fw = zero
+        if (equations == RANSEquations .and. turbRes /= 0) then
+            if (turbModel == spalartAllmaras) call sa_block(.true.)
+        end if
+        if (flowRes /= 0) then
+            call inviscidCentralFlux
+            select case (spaceDiscr)
+            case (dissScalar); call inviscidDissFluxScalar
+            case (dissMatrix); call inviscidDissFluxMatrix
+            case (upwind); call inviscidUpwindFlux(.true.)
+            end select
+            if (viscous) then
+                call computeSpeedOfSoundSquared
+                call allNodalGradients
+                call viscousFlux
+            end if
+            call sumDwAndFw
+        end if
+    end subroutine ref_block_res_core
+
+end module ref_driver
