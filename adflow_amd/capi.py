@@ -1,0 +1,164 @@
+"""ctypes binding of the C-ABI in include/adflow_gpu.h.
+
+This is the Python twin of the ISO_C_BINDING interface module a Fortran host
+uses (adflow_amd/fortran/adflow_gpu_shim.F90); it exists so that the parity
+tests and the benchmark drive exactly the entry points the reference's shell
+routines would call.  There is NO CPU fallback: if the HIP library is missing
+or no GPU is visible every call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int8, c_int32, c_uint, c_void_p
+from typing import Optional
+
+import numpy as np
+
+from . import params as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libadflow_gpu.so")
+MAX_RK = 8
+
+
+class AdflowOpts(ctypes.Structure):
+    _fields_ = [
+        ("equations", c_int32), ("turbModel", c_int32), ("turbProd", c_int32),
+        ("useQCR", c_int32), ("useRotationSA", c_int32), ("useft2SA", c_int32),
+        ("spaceDiscr", c_int32), ("spaceDiscrCoarse", c_int32), ("limiter", c_int32), ("orderTurb", c_int32),
+        ("dirScaling", c_int32),
+        ("smoother", c_int32), ("nRKStages", c_int32), ("resAveraging", c_int32), ("nSubiterations", c_int32),
+        ("nSubIterTurb", c_int32),
+        ("groundLevel", c_int32),
+        ("reserved_i", c_int32 * 3),
+        ("gammaConstant", c_double), ("prandtl", c_double), ("prandtlTurb", c_double),
+        ("SSuthDim", c_double), ("muSuthDim", c_double), ("TSuthDim", c_double),
+        ("SAKappa", c_double), ("SAcb1", c_double), ("SAcb2", c_double), ("SAsigma", c_double), ("SAcv1", c_double),
+        ("SAcw1", c_double), ("SAcw2", c_double), ("SAcw3", c_double), ("SAct1", c_double), ("SAct2", c_double),
+        ("SAct3", c_double), ("SAct4", c_double), ("SAcrot", c_double),
+        ("vis2", c_double), ("vis4", c_double), ("vis2Coarse", c_double), ("adis", c_double),
+        ("acousticScaleFactor", c_double), ("kappaCoef", c_double),
+        ("cfl", c_double), ("cflCoarse", c_double), ("cflLimit", c_double), ("fcoll", c_double), ("smoop", c_double),
+        ("alfaTurb", c_double), ("betaTurb", c_double), ("turbResScale", c_double),
+        ("etaRK", c_double * MAX_RK), ("cdisRK", c_double * MAX_RK),
+        ("gammaInf", c_double), ("pInf", c_double), ("pInfCorr", c_double), ("rhoInf", c_double), ("uInf", c_double),
+        ("RGas", c_double), ("muInf", c_double), ("muRef", c_double), ("TRef", c_double), ("timeRef", c_double),
+        ("wInf", c_double * 10),
+        ("reserved_d", c_double * 8),
+    ]
+
+
+class AdflowBlockDesc(ctypes.Structure):
+    _fields_ = [
+        ("nx", c_int32), ("ny", c_int32), ("nz", c_int32), ("nw", c_int32), ("rightHanded", c_int32),
+        ("reserved", c_int32),
+        ("w", c_void_p), ("p", c_void_p), ("gamma", c_void_p), ("rlv", c_void_p), ("rev", c_void_p),
+        ("x", c_void_p), ("sI", c_void_p), ("sJ", c_void_p), ("sK", c_void_p),
+        ("vol", c_void_p), ("volRef", c_void_p), ("d2Wall", c_void_p),
+        ("porI", c_void_p), ("porJ", c_void_p), ("porK", c_void_p), ("iblank", c_void_p),
+        ("dw", c_void_p), ("fw", c_void_p), ("dtl", c_void_p), ("radI", c_void_p), ("radJ", c_void_p),
+        ("radK", c_void_p),
+        ("w1", c_void_p), ("p1", c_void_p), ("wr", c_void_p),
+    ]
+
+
+# array identifiers (include/adflow_gpu.h)
+(ARR_W, ARR_P, ARR_GAMMA, ARR_RLV, ARR_REV, ARR_DW, ARR_FW, ARR_DTL, ARR_RADI, ARR_RADJ, ARR_RADK, ARR_AA,
+ ARR_NODAL_GRADS, ARR_WN, ARR_PN, ARR_W1, ARR_P1, ARR_WR, ARR_VOL, ARR_SI, ARR_SJ, ARR_SK) = range(1, 23)
+
+RES_UPDATE_INTERMED, RES_FLOW, RES_TURB = 1, 2, 4
+
+EXPORTS = [
+    "adflow_gpu_init", "adflow_gpu_finalize", "adflow_gpu_last_error", "adflow_gpu_device_name",
+    "adflow_gpu_comm_unique_id", "adflow_gpu_comm_init",
+    "adflow_gpu_block_register", "adflow_gpu_upload_geometry", "adflow_gpu_upload_state",
+    "adflow_gpu_download_state", "adflow_gpu_download_residual", "adflow_gpu_download_array",
+    "adflow_gpu_upload_array", "adflow_gpu_set_options",
+    "adflow_gpu_time_step", "adflow_gpu_initres", "adflow_gpu_residual", "adflow_gpu_block_res",
+    "adflow_gpu_rk_smooth", "adflow_gpu_dadi_smooth", "adflow_gpu_halo_exchange", "adflow_gpu_res_norms",
+    "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
+    "adflow_gpu_abi_sizes",
+]
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class AdflowGpuError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the HIP library; raises (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdflowGpuError(f"{LIB_PATH} not built: run `python -m adflow_amd.build` (no CPU fallback exists)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.adflow_gpu_last_error.restype = c_char_p
+    lib.adflow_gpu_init.argtypes = [c_int]
+    lib.adflow_gpu_device_name.argtypes = [c_char_p, c_int]
+    lib.adflow_gpu_block_register.argtypes = [c_int, c_int, c_int, POINTER(AdflowBlockDesc)]
+    for n in ("adflow_gpu_upload_geometry", "adflow_gpu_upload_state", "adflow_gpu_download_state",
+              "adflow_gpu_download_residual"):
+        getattr(lib, n).argtypes = [c_int, c_int, c_int]
+    lib.adflow_gpu_download_array.argtypes = [c_int, c_int, c_int, c_int, c_void_p]
+    lib.adflow_gpu_upload_array.argtypes = [c_int, c_int, c_int, c_int, c_void_p]
+    lib.adflow_gpu_set_options.argtypes = [POINTER(AdflowOpts)]
+    lib.adflow_gpu_time_step.argtypes = [c_int, c_int]
+    lib.adflow_gpu_initres.argtypes = [c_int, c_int, c_int]
+    lib.adflow_gpu_residual.argtypes = [c_int, c_int]
+    lib.adflow_gpu_block_res.argtypes = [c_int, c_uint]
+    lib.adflow_gpu_set_async.argtypes = [c_int]
+    lib.adflow_gpu_abi_sizes.argtypes = [POINTER(c_int), POINTER(c_int)]
+    lib.adflow_gpu_rk_smooth.argtypes = [c_int]
+    lib.adflow_gpu_dadi_smooth.argtypes = [c_int]
+    lib.adflow_gpu_halo_exchange.argtypes = [c_int] * 6
+    lib.adflow_gpu_res_norms.argtypes = [c_int, c_void_p, c_int]
+    lib.adflow_gpu_comm_unique_id.argtypes = [c_void_p]
+    lib.adflow_gpu_comm_init.argtypes = [c_int, c_int, c_void_p]
+    lib.adflow_gpu_event_record.argtypes = [c_int]
+    lib.adflow_gpu_event_elapsed_ms.argtypes = [c_int, c_int, POINTER(c_double)]
+    so, sd = c_int(), c_int()
+    lib.adflow_gpu_abi_sizes(ctypes.byref(so), ctypes.byref(sd))
+    if so.value != ctypes.sizeof(AdflowOpts) or sd.value != ctypes.sizeof(AdflowBlockDesc):
+        raise AdflowGpuError("ctypes mirror of adflow_opts/adflow_block_desc is out of date with include/adflow_gpu.h")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise AdflowGpuError(load().adflow_gpu_last_error().decode())
+
+
+def opts_from_params(prm: P.FlowParams) -> AdflowOpts:
+    o = AdflowOpts()
+    for name, _ in AdflowOpts._fields_:
+        if name.startswith("reserved") or name in ("etaRK", "cdisRK", "wInf"):
+            continue
+        setattr(o, name, type(getattr(o, name))(getattr(prm, name)))
+    for i, v in enumerate(prm.etaRK):
+        o.etaRK[i] = v
+    for i, v in enumerate(prm.cdisRK):
+        o.cdisRK[i] = v
+    for i, v in enumerate(prm.wInf()):
+        o.wInf[i] = v
+    return o
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.flags["F_CONTIGUOUS"], "host arrays must be Fortran-ordered"
+    return a.ctypes.data
+
+
+def desc_from_block(blk) -> AdflowBlockDesc:
+    d = AdflowBlockDesc()
+    d.nx, d.ny, d.nz, d.nw, d.rightHanded = blk.nx, blk.ny, blk.nz, blk.nw, 1
+    for name in ("w", "p", "gamma", "rlv", "rev", "x", "sI", "sJ", "sK", "vol", "volRef", "d2Wall",
+                 "porI", "porJ", "porK", "iblank", "dw", "fw", "dtl", "radI", "radJ", "radK", "w1", "p1", "wr"):
+        setattr(d, name, _ptr(blk.a.get(name)))
+    return d

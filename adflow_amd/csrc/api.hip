@@ -1,0 +1,557 @@
+// C-ABI entry points (include/adflow_gpu.h): block registry, HBM mirrors,
+// host<->device transfers and the launch sequences of the hot path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+std::string g_err;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+adflow_opts g_opts;
+bool g_have_opts = false;
+hipEvent_t g_events[64];
+bool g_events_ready = false;
+bool g_async = false;   // adflow_gpu_set_async: entry points enqueue only
+
+int fail(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevArr {
+    double* base = nullptr;   // hipMalloc pointer
+    int ncomp = 0;
+};
+
+struct Block {
+    adflow_block_desc d;
+    BlkView v;
+    long boxsize = 0;         // ldi*(jb+1)*(kb+1)
+    std::vector<void*> allocs;
+    bool geom_uploaded = false;
+};
+
+typedef std::tuple<int, int, int> Key;   // (level, sps, nn): iteration order = level, sps, nn
+std::map<Key, Block*> g_blocks;
+
+Block* find_block(int nn, int level, int sps)
+{
+    auto it = g_blocks.find(Key(level, sps, nn));
+    return it == g_blocks.end() ? nullptr : it->second;
+}
+
+int alloc_arr(Block* b, double** p, int ncomp)
+{
+    size_t bytes = (size_t)b->v.nbox * ncomp * sizeof(double) + 256;
+    void* raw = nullptr;
+    HIPCHK(hipMalloc(&raw, bytes));
+    HIPCHK(hipMemsetAsync(raw, 0, bytes, g_stream));
+    b->allocs.push_back(raw);
+    *p = (double*)raw + ADF_PAD0;
+    return 0;
+}
+
+// host sub-box (lo..lo+n-1 in each direction, column-major, ncomp components)
+// <-> device box component(s)
+int copy_box(Block* b, double* dev, const double* host, int ncomp, int lo_i, int n_i, int lo_j, int n_j, int lo_k, int n_k,
+             bool to_device)
+{
+    if (!host) return 0;
+    for (int c = 0; c < ncomp; ++c) {
+        hipMemcpy3DParms p;
+        memset(&p, 0, sizeof p);
+        double* dptr = dev + (size_t)c * b->v.nbox + b->v.idx(lo_i, lo_j, lo_k);
+        const double* hptr = host + (size_t)c * n_i * n_j * n_k;
+        hipPitchedPtr hp = make_hipPitchedPtr((void*)hptr, (size_t)n_i * 8, (size_t)n_i, (size_t)n_j);
+        hipPitchedPtr dp = make_hipPitchedPtr((void*)dptr, (size_t)b->v.ldi * 8, (size_t)b->v.ldi, (size_t)(b->v.jb + 1));
+        p.extent = make_hipExtent((size_t)n_i * 8, (size_t)n_j, (size_t)n_k);
+        if (to_device) {
+            p.srcPtr = hp;
+            p.dstPtr = dp;
+            p.kind = hipMemcpyHostToDevice;
+        } else {
+            p.srcPtr = dp;
+            p.dstPtr = hp;
+            p.kind = hipMemcpyDeviceToHost;
+        }
+        HIPCHK(hipMemcpy3DAsync(&p, g_stream));
+    }
+    return 0;
+}
+
+KParams make_kparams(int level, double rFil, int fwMode)
+{
+    const adflow_opts& o = g_opts;
+    KParams k;
+    memset(&k, 0, sizeof k);
+    k.equations = o.equations;
+    k.spaceDiscr = (level == 1) ? o.spaceDiscr : o.spaceDiscrCoarse;
+    k.limiter = o.limiter;
+    k.orderTurb = o.orderTurb;
+    k.turbProd = o.turbProd;
+    k.viscous = (o.equations == ADFLOW_NS || o.equations == ADFLOW_RANS);
+    k.eddyModel = (o.equations == ADFLOW_RANS);
+    k.dirScaling = o.dirScaling;
+    k.useQCR = o.useQCR;
+    k.useRotationSA = o.useRotationSA;
+    k.useft2SA = o.useft2SA;
+    k.fineGrid = (level == o.groundLevel);
+    k.doScaling = (o.dirScaling && level <= o.groundLevel);
+    k.coarseInit = (level != o.groundLevel);
+    k.fwMode = fwMode;
+    k.rFil = rFil;
+    k.sfil = 1.0 - rFil;
+    k.vis2 = o.vis2; k.vis4 = o.vis4; k.vis2Coarse = o.vis2Coarse; k.adis = o.adis;
+    k.acousticScaleFactor = o.acousticScaleFactor; k.kappaCoef = o.kappaCoef;
+    k.gammaInf = o.gammaInf; k.pInfCorr = o.pInfCorr; k.rhoInf = o.rhoInf; k.RGas = o.RGas;
+    k.muRef = o.muRef; k.TRef = o.TRef; k.timeRef = o.timeRef;
+    k.prandtl = o.prandtl; k.prandtlTurb = o.prandtlTurb;
+    k.SSuthDim = o.SSuthDim; k.muSuthDim = o.muSuthDim; k.TSuthDim = o.TSuthDim;
+    k.sa_k = o.SAKappa; k.sa_cb1 = o.SAcb1; k.sa_cb2 = o.SAcb2; k.sa_cb3 = o.SAsigma; k.sa_cv1 = o.SAcv1;
+    k.sa_cw1 = o.SAcw1; k.sa_cw2 = o.SAcw2; k.sa_cw3 = o.SAcw3; k.sa_ct3 = o.SAct3; k.sa_ct4 = o.SAct4;
+    k.sa_crot = o.SAcrot;
+    k.cfl = (level == 1) ? o.cfl : o.cflCoarse;
+    k.cflLimit = o.cflLimit; k.smoop = o.smoop; k.fcoll = o.fcoll; k.turbResScale = o.turbResScale;
+    for (int i = 0; i < 10; ++i) k.wInf[i] = o.wInf[i];
+    return k;
+}
+
+int need_ready(void)
+{
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    if (!g_have_opts) return fail("adflow_gpu_set_options has not been called");
+    return 0;
+}
+
+template <typename Fn>
+int for_level(int level, Fn fn)
+{
+    bool any = false;
+    for (auto& kv : g_blocks) {
+        if (std::get<0>(kv.first) != level) continue;
+        any = true;
+        int rc = fn(kv.second);
+        if (rc) return rc;
+    }
+    if (!any) return fail("no block registered on level %d", level);
+    return 0;
+}
+
+int sync_and_check(void)
+{
+    HIPCHK(hipGetLastError());
+    if (!g_async) HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* adflow_gpu_last_error(void) { return g_err.c_str(); }
+
+int adflow_gpu_init(int device_ordinal)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail("no HIP device visible: the MI355X engine has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail("device ordinal %d out of range (%d devices)", device_ordinal, n);
+    HIPCHK(hipSetDevice(device_ordinal));
+    if (!g_stream) HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_events_ready) {
+        for (int i = 0; i < 64; ++i) HIPCHK(hipEventCreate(&g_events[i]));
+        g_events_ready = true;
+    }
+    g_device = device_ordinal;
+    return 0;
+}
+
+int adflow_gpu_device_name(char* buf, int len)
+{
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g_device));
+    snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int adflow_gpu_finalize(void)
+{
+    for (auto& kv : g_blocks) {
+        for (void* p : kv.second->allocs) (void)hipFree(p);
+        delete kv.second;
+    }
+    g_blocks.clear();
+    if (g_events_ready) {
+        for (int i = 0; i < 64; ++i) (void)hipEventDestroy(g_events[i]);
+        g_events_ready = false;
+    }
+    if (g_stream) {
+        (void)hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    g_device = -1;
+    g_have_opts = false;
+    return 0;
+}
+
+int adflow_gpu_set_options(const adflow_opts* o)
+{
+    if (!o) return fail("null options");
+    if (o->equations < ADFLOW_EULER || o->equations > ADFLOW_RANS) return fail("equations=%d not supported", o->equations);
+    if (o->nRKStages < 1 || o->nRKStages > ADFLOW_MAX_RK_STAGES) return fail("nRKStages=%d out of range", o->nRKStages);
+    g_opts = *o;
+    g_have_opts = true;
+    return 0;
+}
+
+int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_desc* d)
+{
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    if (!d) return fail("null block descriptor");
+    if (d->nx < 1 || d->ny < 1 || d->nz < 1) return fail("block %d: bad dimensions %d %d %d", nn, d->nx, d->ny, d->nz);
+    if (d->nw != 5 && d->nw != 6) return fail("block %d: nw=%d not supported (5, or 6 with SA)", nn, d->nw);
+    if (find_block(nn, level, sps)) return fail("block (%d,%d,%d) already registered", nn, level, sps);
+    Block* b = new Block;
+    b->d = *d;
+    BlkView& v = b->v;
+    memset(&v, 0, sizeof v);
+    v.nx = d->nx; v.ny = d->ny; v.nz = d->nz; v.nw = d->nw;
+    v.il = v.nx + 1; v.jl = v.ny + 1; v.kl = v.nz + 1;
+    v.ie = v.nx + 2; v.je = v.ny + 2; v.ke = v.nz + 2;
+    v.ib = v.nx + 3; v.jb = v.ny + 3; v.kb = v.nz + 3;
+    v.ldi = ((v.ib + 1 + 15) / 16) * 16;
+    v.ldk = v.ldi * (v.jb + 1);
+    b->boxsize = (long)v.ldk * (v.kb + 1);
+    v.nbox = ((b->boxsize + 15) / 16) * 16 + 16;
+    int rc = 0;
+    rc |= alloc_arr(b, &v.w, v.nw);
+    rc |= alloc_arr(b, &v.p, 1);
+    rc |= alloc_arr(b, &v.gamma, 1);
+    rc |= alloc_arr(b, &v.rlv, 1);
+    rc |= alloc_arr(b, &v.rev, 1);
+    rc |= alloc_arr(b, &v.x, 3);
+    rc |= alloc_arr(b, &v.sI, 3);
+    rc |= alloc_arr(b, &v.sJ, 3);
+    rc |= alloc_arr(b, &v.sK, 3);
+    rc |= alloc_arr(b, &v.vol, 1);
+    rc |= alloc_arr(b, &v.volRef, 1);
+    rc |= alloc_arr(b, &v.d2wall, 1);
+    rc |= alloc_arr(b, &v.dw, v.nw);
+    rc |= alloc_arr(b, &v.fw, 5);
+    rc |= alloc_arr(b, &v.dtl, 1);
+    rc |= alloc_arr(b, &v.radI, 1);
+    rc |= alloc_arr(b, &v.radJ, 1);
+    rc |= alloc_arr(b, &v.radK, 1);
+    rc |= alloc_arr(b, &v.ss, 1);
+    rc |= alloc_arr(b, &v.aa, 1);
+    rc |= alloc_arr(b, &v.grad, 12);
+    rc |= alloc_arr(b, &v.scratch, 10);
+    rc |= alloc_arr(b, &v.wn, 5);
+    rc |= alloc_arr(b, &v.pn, 1);
+    rc |= alloc_arr(b, &v.w1, 5);
+    rc |= alloc_arr(b, &v.p1, 1);
+    rc |= alloc_arr(b, &v.wr, 5);
+    if (rc) return rc;
+    {
+        void* raw = nullptr;
+        HIPCHK(hipMalloc(&raw, (size_t)v.nbox + 256));
+        HIPCHK(hipMemsetAsync(raw, 0, (size_t)v.nbox + 256, g_stream));
+        b->allocs.push_back(raw);
+        v.flags = (uint8_t*)raw + 16;
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));
+    g_blocks[Key(level, sps, nn)] = b;
+    return 0;
+}
+
+int adflow_gpu_upload_geometry(int nn, int level, int sps)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    const adflow_block_desc& d = b->d;
+    BlkView& v = b->v;
+    int rc = 0;
+    rc |= copy_box(b, v.x, d.x, 3, 0, v.ie + 1, 0, v.je + 1, 0, v.ke + 1, true);
+    rc |= copy_box(b, v.sI, d.sI, 3, 0, v.ie + 1, 1, v.je, 1, v.ke, true);
+    rc |= copy_box(b, v.sJ, d.sJ, 3, 1, v.ie, 0, v.je + 1, 1, v.ke, true);
+    rc |= copy_box(b, v.sK, d.sK, 3, 1, v.ie, 1, v.je, 0, v.ke + 1, true);
+    rc |= copy_box(b, v.vol, d.vol, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
+    rc |= copy_box(b, v.volRef, d.volRef ? d.volRef : d.vol, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
+    rc |= copy_box(b, v.d2wall, d.d2Wall, 1, 2, v.nx, 2, v.ny, 2, v.nz, true);
+    if (rc) return rc;
+    // pack porosities + iblank into one byte per cell (internal.h)
+    std::vector<uint8_t> f((size_t)v.nbox, 0);
+    auto at = [&](int i, int j, int k) -> uint8_t& { return f[(size_t)v.idx(i, j, k)]; };
+    if (d.porI)
+        for (int k = 2; k <= v.kl; ++k)
+            for (int j = 2; j <= v.jl; ++j)
+                for (int i = 1; i <= v.il; ++i)
+                    at(i, j, k) |= (uint8_t)((d.porI[(size_t)(i - 1) + (size_t)v.il * ((j - 2) + (size_t)v.ny * (k - 2))] + 1) & 3);
+    if (d.porJ)
+        for (int k = 2; k <= v.kl; ++k)
+            for (int j = 1; j <= v.jl; ++j)
+                for (int i = 2; i <= v.il; ++i)
+                    at(i, j, k) |= (uint8_t)(((d.porJ[(size_t)(i - 2) + (size_t)v.nx * ((j - 1) + (size_t)v.jl * (k - 2))] + 1) & 3) << 2);
+    if (d.porK)
+        for (int k = 1; k <= v.kl; ++k)
+            for (int j = 2; j <= v.jl; ++j)
+                for (int i = 2; i <= v.il; ++i)
+                    at(i, j, k) |= (uint8_t)(((d.porK[(size_t)(i - 2) + (size_t)v.nx * ((j - 2) + (size_t)v.ny * (k - 1))] + 1) & 3) << 4);
+    for (int k = 0; k <= v.kb; ++k)
+        for (int j = 0; j <= v.jb; ++j)
+            for (int i = 0; i <= v.ib; ++i) {
+                int ibl = d.iblank ? d.iblank[(size_t)i + (size_t)(v.ib + 1) * (j + (size_t)(v.jb + 1) * k)] : 1;
+                if (ibl > 0) at(i, j, k) |= 64;
+            }
+    HIPCHK(hipMemcpyAsync(v.flags, f.data(), (size_t)b->boxsize, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    b->geom_uploaded = true;
+    return 0;
+}
+
+int adflow_gpu_upload_state(int nn, int level, int sps)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    const adflow_block_desc& d = b->d;
+    BlkView& v = b->v;
+    if (!d.w || !d.p || !d.gamma) return fail("block (%d,%d,%d): w, p and gamma host arrays are required", nn, level, sps);
+    int rc = 0;
+    rc |= copy_box(b, v.w, d.w, v.nw, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
+    rc |= copy_box(b, v.p, d.p, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
+    rc |= copy_box(b, v.gamma, d.gamma, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
+    rc |= copy_box(b, v.rlv, d.rlv, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
+    rc |= copy_box(b, v.rev, d.rev, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+int adflow_gpu_download_state(int nn, int level, int sps)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    const adflow_block_desc& d = b->d;
+    BlkView& v = b->v;
+    int rc = 0;
+    rc |= copy_box(b, v.w, d.w, v.nw, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, false);
+    rc |= copy_box(b, v.p, d.p, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, false);
+    rc |= copy_box(b, v.rlv, d.rlv, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, false);
+    rc |= copy_box(b, v.rev, d.rev, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, false);
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+int adflow_gpu_download_residual(int nn, int level, int sps)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (!b->d.dw) return fail("block (%d,%d,%d): no host dw array registered", nn, level, sps);
+    BlkView& v = b->v;
+    int rc = copy_box(b, v.dw, b->d.dw, v.nw, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, false);
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+static int array_spec(Block* b, int which, double** dev, int* nc, int lo[3], int n[3])
+{
+    BlkView& v = b->v;
+    auto cell = [&]() { lo[0] = lo[1] = lo[2] = 0; n[0] = v.ib + 1; n[1] = v.jb + 1; n[2] = v.kb + 1; };
+    auto halo1 = [&]() { lo[0] = lo[1] = lo[2] = 1; n[0] = v.ie; n[1] = v.je; n[2] = v.ke; };
+    auto owned = [&]() { lo[0] = lo[1] = lo[2] = 2; n[0] = v.nx; n[1] = v.ny; n[2] = v.nz; };
+    *nc = 1;
+    switch (which) {
+    case ADFLOW_ARR_W: *dev = v.w; *nc = v.nw; cell(); break;
+    case ADFLOW_ARR_P: *dev = v.p; cell(); break;
+    case ADFLOW_ARR_GAMMA: *dev = v.gamma; cell(); break;
+    case ADFLOW_ARR_RLV: *dev = v.rlv; cell(); break;
+    case ADFLOW_ARR_REV: *dev = v.rev; cell(); break;
+    case ADFLOW_ARR_DW: *dev = v.dw; *nc = v.nw; cell(); break;
+    case ADFLOW_ARR_FW: *dev = v.fw; *nc = 5; cell(); break;
+    case ADFLOW_ARR_AA: *dev = v.aa; cell(); break;
+    case ADFLOW_ARR_VOL: *dev = v.vol; cell(); break;
+    case ADFLOW_ARR_DTL: *dev = v.dtl; halo1(); break;
+    case ADFLOW_ARR_RADI: *dev = v.radI; halo1(); break;
+    case ADFLOW_ARR_RADJ: *dev = v.radJ; halo1(); break;
+    case ADFLOW_ARR_RADK: *dev = v.radK; halo1(); break;
+    case ADFLOW_ARR_P1: *dev = v.p1; halo1(); break;
+    case ADFLOW_ARR_W1: *dev = v.w1; *nc = 5; halo1(); break;
+    case ADFLOW_ARR_WN: *dev = v.wn; *nc = 5; owned(); break;
+    case ADFLOW_ARR_PN: *dev = v.pn; owned(); break;
+    case ADFLOW_ARR_WR: *dev = v.wr; *nc = 5; owned(); break;
+    case ADFLOW_ARR_NODAL_GRADS:
+        *dev = v.grad; *nc = 12; lo[0] = lo[1] = lo[2] = 1; n[0] = v.il; n[1] = v.jl; n[2] = v.kl; break;
+    case ADFLOW_ARR_SI: *dev = v.sI; *nc = 3; lo[0] = 0; lo[1] = lo[2] = 1; n[0] = v.ie + 1; n[1] = v.je; n[2] = v.ke; break;
+    case ADFLOW_ARR_SJ: *dev = v.sJ; *nc = 3; lo[1] = 0; lo[0] = lo[2] = 1; n[0] = v.ie; n[1] = v.je + 1; n[2] = v.ke; break;
+    case ADFLOW_ARR_SK: *dev = v.sK; *nc = 3; lo[2] = 0; lo[0] = lo[1] = 1; n[0] = v.ie; n[1] = v.je; n[2] = v.ke + 1; break;
+    default: return fail("unknown array id %d", which);
+    }
+    return 0;
+}
+
+int adflow_gpu_download_array(int nn, int level, int sps, int which, double* host)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (!host) return fail("null host pointer");
+    double* dev; int nc, lo[3], n[3];
+    if (array_spec(b, which, &dev, &nc, lo, n)) return 1;
+    if (copy_box(b, dev, host, nc, lo[0], n[0], lo[1], n[1], lo[2], n[2], false)) return 1;
+    return sync_and_check();
+}
+
+int adflow_gpu_upload_array(int nn, int level, int sps, int which, const double* host)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (!host) return fail("null host pointer");
+    double* dev; int nc, lo[3], n[3];
+    if (array_spec(b, which, &dev, &nc, lo, n)) return 1;
+    if (copy_box(b, dev, host, nc, lo[0], n[0], lo[1], n[1], lo[2], n[2], true)) return 1;
+    return sync_and_check();
+}
+
+// ---------------------------------------------------------------- hot path
+int adflow_gpu_time_step(int level, int onlyRadii)
+{
+    if (need_ready()) return 1;
+    KParams kp = make_kparams(level, 1.0, 0);
+    kp.onlyRadii = onlyRadii;
+    int rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kp, g_stream); return 0; });
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+int adflow_gpu_initres(int level, int varStart, int varEnd)
+{
+    if (need_ready()) return 1;
+    if (varEnd < varStart) return 0;
+    KParams kp = make_kparams(level, 1.0, 0);
+    int rc = for_level(level, [&](Block* b) {
+        if (varStart < 1 || varEnd > b->v.nw) return fail("initres: variable range %d..%d outside 1..%d", varStart, varEnd, b->v.nw);
+        launch_initres(b->v, kp, varStart - 1, varEnd - 1, g_stream);
+        return 0;
+    });
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+static int enqueue_flow_residual(int level, const KParams& kp)
+{
+    return for_level(level, [&](Block* b) {
+        if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
+        if (kp.spaceDiscr != ADFLOW_DISS_SCALAR) return fail("spaceDiscr=%d not implemented yet", kp.spaceDiscr);
+        launch_inviscid(b->v, kp, g_stream);
+        return 0;
+    });
+}
+
+int adflow_gpu_residual(int level, int rkStage)
+{
+    if (need_ready()) return 1;
+    double rFil = 1.0;
+    int fwMode = 0;
+    if (g_opts.smoother == ADFLOW_RUNGE_KUTTA) {
+        if (rkStage < 0 || rkStage >= g_opts.nRKStages) return fail("rkStage=%d outside 0..%d", rkStage, g_opts.nRKStages - 1);
+        rFil = g_opts.cdisRK[rkStage];   // cdisRK(rkStage+1), residuals.F90:61-65
+        fwMode = 1;
+    }
+    KParams kp = make_kparams(level, rFil, fwMode);
+    int rc = enqueue_flow_residual(level, kp);
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+static int block_res_enqueue(int level, unsigned flags)
+{
+    if (need_ready()) return 1;
+    KParams kp = make_kparams(level, 1.0, 0);
+    kp.onlyRadii = !(flags & ADFLOW_RES_UPDATE_INTERMED);
+    kp.coarseInit = 0;
+    int rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kp, g_stream); return 0; });
+    if (rc) return rc;
+    if (flags & ADFLOW_RES_FLOW) {
+        rc = enqueue_flow_residual(level, kp);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int adflow_gpu_block_res(int level, unsigned flags)
+{
+    int rc = block_res_enqueue(level, flags);
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+int adflow_gpu_rk_smooth(int) { return fail("adflow_gpu_rk_smooth: not implemented yet"); }
+int adflow_gpu_dadi_smooth(int) { return fail("adflow_gpu_dadi_smooth: not implemented yet"); }
+int adflow_gpu_halo_exchange(int, int, int, int, int, int) { return fail("adflow_gpu_halo_exchange: not implemented yet"); }
+int adflow_gpu_res_norms(int, double*, int) { return fail("adflow_gpu_res_norms: not implemented yet"); }
+int adflow_gpu_comm_unique_id(void*) { return fail("adflow_gpu_comm_unique_id: not implemented yet"); }
+int adflow_gpu_comm_init(int, int, const void*) { return fail("adflow_gpu_comm_init: not implemented yet"); }
+
+// --------------------------------------------------------- instrumentation
+int adflow_gpu_event_record(int slot)
+{
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    if (slot < 0 || slot >= 64) return fail("event slot %d out of range", slot);
+    HIPCHK(hipEventRecord(g_events[slot], g_stream));
+    return 0;
+}
+
+int adflow_gpu_event_elapsed_ms(int a, int b, double* ms)
+{
+    if (a < 0 || a >= 64 || b < 0 || b >= 64 || !ms) return fail("bad event arguments");
+    HIPCHK(hipEventSynchronize(g_events[b]));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, g_events[a], g_events[b]));
+    *ms = f;
+    return 0;
+}
+
+int adflow_gpu_sync(void)
+{
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+int adflow_gpu_set_async(int on)
+{
+    g_async = (on != 0);
+    return 0;
+}
+
+int adflow_gpu_abi_sizes(int* opts_bytes, int* desc_bytes)
+{
+    if (opts_bytes) *opts_bytes = (int)sizeof(adflow_opts);
+    if (desc_bytes) *desc_bytes = (int)sizeof(adflow_block_desc);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Internal device data model of the MI355X residual engine (not part of the ABI).
+//
+// HBM layout: every per-cell, per-face and per-node array of a
+// block lives in ONE uniform index box (0:ib,0:jb,0:kb), i fastest, SoA with the
+// variable index slowest.  One linear offset  idx = i + j*ldi + k*ldk  addresses
+// every array, and the six neighbours are idx±1, ±ldi, ±ldk.  Rows are padded to
+// ldi (multiple of 16 doubles) and the box origin is shifted by PAD0 doubles so
+// that the first OWNED cell of every row (i=2) starts a 128-byte line: a
+// wavefront whose lane l handles cell i=2+l issues fully aligned 512-byte loads.
+//   face arrays : sI(i,j,k,:) (face between cells i and i+1) stored at cell idx
+//   node arrays : x(i,j,k,:), nodal gradients stored at cell idx (node = upper
+//                 corner of cell (i,j,k), as in the reference, block.F90:363)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/adflow_gpu.h"
+
+#define ADF_PAD0 14   // (PAD0 + 2) % 16 == 0
+
+struct BlkView {
+    int nx, ny, nz, nw;
+    int il, jl, kl, ie, je, ke, ib, jb, kb;
+    int ldi;        // j-stride (doubles)
+    int ldk;        // k-stride
+    long nbox;      // stride between variables of a multi-component array
+    // state
+    double *w, *p, *gamma, *rlv, *rev;
+    // geometry
+    double *x, *sI, *sJ, *sK, *vol, *volRef, *d2wall;
+    uint8_t* flags;  // bits 0-1 porI+1, 2-3 porJ+1, 4-5 porK+1, bit 6 iblank>0
+    // residual + work
+    double *dw, *fw, *dtl, *radI, *radJ, *radK;
+    double *ss;      // JST sensor variable (entropy p/rho^gamma) for NS/RANS
+    double *aa;      // speed of sound squared
+    double *grad;    // 12 nodal gradients ux,uy,uz,vx,...,qz
+    double *scratch; // nscratch work arrays
+    double *wn, *pn; // RK stage-0 state
+    double *w1, *p1, *wr; // multigrid
+    __host__ __device__ inline long idx(int i, int j, int k) const { return (long)i + (long)j * ldi + (long)k * ldk; }
+};
+
+// porosity codes after the +1 shift used in `flags`
+#define ADF_POR_NOFLUX 0
+#define ADF_POR_BOUND 1
+#define ADF_POR_NORMAL 2
+__device__ __forceinline__ int flg_porI(uint8_t f) { return f & 3; }
+__device__ __forceinline__ int flg_porJ(uint8_t f) { return (f >> 2) & 3; }
+__device__ __forceinline__ int flg_porK(uint8_t f) { return (f >> 4) & 3; }
+__device__ __forceinline__ double flg_blank(uint8_t f) { return (f & 64) ? 1.0 : 0.0; }
+
+// per-call scalar parameters derived from adflow_opts on the host
+struct KParams {
+    int equations, spaceDiscr, limiter, orderTurb, turbProd;
+    int viscous, eddyModel, dirScaling, useQCR, useRotationSA, useft2SA;
+    int fineGrid;          // currentLevel == groundLevel
+    int doScaling;         // dirScaling && currentLevel <= groundLevel
+    int onlyRadii;
+    int coarseInit;        // initres: dw = wr instead of 0
+    int fwMode;            // 0: fw not persistent (rFil==1, sfil==0, no store)  1: persistent fw
+    int storeIntermed;     // store dtl / radii
+    double rFil, sfil;
+    double vis2, vis4, vis2Coarse, adis, acousticScaleFactor, kappaCoef;
+    double gammaInf, pInfCorr, rhoInf, RGas, muRef, TRef, timeRef;
+    double prandtl, prandtlTurb, SSuthDim, muSuthDim, TSuthDim;
+    double sa_k, sa_cb1, sa_cb2, sa_cb3, sa_cv1, sa_cw1, sa_cw2, sa_cw3, sa_ct3, sa_ct4, sa_crot;
+    double cfl, cflLimit, smoop, fcoll, turbResScale;
+    double wInf[10];
+};
+
+// ---- kernel launchers (one translation unit per kernel family) -------------
+void launch_time_step(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
+void launch_sum_dw_fw(const BlkView& b, const KParams& kp, hipStream_t s);

@@ -1,0 +1,118 @@
+"""Host-side mirror of the reference's operator surface for the hot path.
+
+Method names follow the reference's shell routines:
+`timeStep`, `initres`, `residual`, `blocketteRes`, `RungeKuttaSmoother`,
+`DADISmoother`, `whalo2`; each forwards to the C-ABI of include/adflow_gpu.h.
+Blocks are addressed like `flowDoms(nn, level, sps)` (1-based).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Tuple
+
+import numpy as np
+
+from . import capi
+from .params import FlowParams
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.lib = capi.load()
+        capi.check(self.lib.adflow_gpu_init(device))
+        self.blocks: Dict[Tuple[int, int, int], object] = {}
+        self._descs = {}
+        self.prm = None
+
+    # ---- lifetime ---------------------------------------------------------
+    def close(self):
+        if self.lib is not None:
+            self.lib.adflow_gpu_finalize()
+            self.lib = None
+
+    def device_name(self) -> str:
+        buf = ctypes.create_string_buffer(256)
+        capi.check(self.lib.adflow_gpu_device_name(buf, 256))
+        return buf.value.decode()
+
+    # ---- data model -------------------------------------------------------
+    def set_options(self, prm: FlowParams):
+        self.prm = prm
+        o = capi.opts_from_params(prm)
+        capi.check(self.lib.adflow_gpu_set_options(ctypes.byref(o)))
+
+    def register(self, blk, nn: int = 1, level: int = 1, sps: int = 1, upload: bool = True):
+        """flowDoms(nn,level,sps) <- blk ; host arrays stay owned by `blk`."""
+        a = blk.a
+        ib, jb, kb, ie, je, ke = blk.ib, blk.jb, blk.kb, blk.ie, blk.je, blk.ke
+        for name, shape in (("dw", (ib + 1, jb + 1, kb + 1, blk.nw)), ("fw", (ib + 1, jb + 1, kb + 1, 5)),
+                            ("dtl", (ie, je, ke)), ("radI", (ie, je, ke)), ("radJ", (ie, je, ke)),
+                            ("radK", (ie, je, ke))):
+            if name not in a:
+                a[name] = np.zeros(shape, order="F")
+        d = capi.desc_from_block(blk)
+        self._descs[(nn, level, sps)] = d
+        self.blocks[(nn, level, sps)] = blk
+        capi.check(self.lib.adflow_gpu_block_register(nn, level, sps, ctypes.byref(d)))
+        if upload:
+            self.upload_geometry(nn, level, sps)
+            self.upload_state(nn, level, sps)
+
+    def upload_geometry(self, nn=1, level=1, sps=1):
+        capi.check(self.lib.adflow_gpu_upload_geometry(nn, level, sps))
+
+    def upload_state(self, nn=1, level=1, sps=1):
+        capi.check(self.lib.adflow_gpu_upload_state(nn, level, sps))
+
+    def download_state(self, nn=1, level=1, sps=1):
+        capi.check(self.lib.adflow_gpu_download_state(nn, level, sps))
+
+    def download_residual(self, nn=1, level=1, sps=1):
+        capi.check(self.lib.adflow_gpu_download_residual(nn, level, sps))
+        return self.blocks[(nn, level, sps)]["dw"]
+
+    def download_array(self, which: int, out: np.ndarray, nn=1, level=1, sps=1):
+        assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
+        capi.check(self.lib.adflow_gpu_download_array(nn, level, sps, which, out.ctypes.data))
+        return out
+
+    def upload_array(self, which: int, src: np.ndarray, nn=1, level=1, sps=1):
+        assert src.flags["F_CONTIGUOUS"] and src.dtype == np.float64
+        capi.check(self.lib.adflow_gpu_upload_array(nn, level, sps, which, src.ctypes.data))
+
+    # ---- the hot path (reference shell-routine names) -----------------------
+    def timeStep(self, level=1, onlyRadii=False):
+        capi.check(self.lib.adflow_gpu_time_step(level, int(onlyRadii)))
+
+    def initres(self, level, varStart, varEnd):
+        capi.check(self.lib.adflow_gpu_initres(level, varStart, varEnd))
+
+    def residual(self, level=1, rkStage=0):
+        capi.check(self.lib.adflow_gpu_residual(level, rkStage))
+
+    def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True):
+        flags = (capi.RES_UPDATE_INTERMED if updateIntermed else 0) | (capi.RES_FLOW if flowRes else 0) \
+            | (capi.RES_TURB if turbRes else 0)
+        capi.check(self.lib.adflow_gpu_block_res(level, flags))
+
+    def set_async(self, on: bool):
+        """Entry points only enqueue on the library stream; order with sync()."""
+        capi.check(self.lib.adflow_gpu_set_async(int(on)))
+
+    def RungeKuttaSmoother(self, level=1):
+        capi.check(self.lib.adflow_gpu_rk_smooth(level))
+
+    def DADISmoother(self, level=1):
+        capi.check(self.lib.adflow_gpu_dadi_smooth(level))
+
+    # ---- instrumentation ----------------------------------------------------
+    def event_record(self, slot: int):
+        capi.check(self.lib.adflow_gpu_event_record(slot))
+
+    def event_elapsed_ms(self, a: int, b: int) -> float:
+        ms = ctypes.c_double()
+        capi.check(self.lib.adflow_gpu_event_elapsed_ms(a, b, ctypes.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        capi.check(self.lib.adflow_gpu_sync())

@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Benchmark of the residual-evaluation hot path on MI355X.
+
+`python bench.py --gpus N --steps K --warmup W` — one "step" is ONE residual
+evaluation (blockette::blocketteRes core: time step + inviscid [+ viscous + SA]
++ final sum) over every block of the workload, state resident in HBM.
+
+metric  : Mcells*residual-evals/s  (BASELINE.json)
+roofline: HBM-bound; algorithmic bytes/cell/eval from SURVEY.md §8(d)
+          (Euler 175 B, RANS-SA 255 B) over the live HIP-event duration of the
+          dominant kernel on the library's own stream.
+cpu_baseline: the reference's own Fortran (oracle/_ref, "reference") timed on
+          the host cores of this box on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: tutorial-wing multiblock Euler, JST scalar, roofline size
+    "euler_jst_8x128": dict(equations=1, spaceDiscr=1, nblocks=8, dims=(128, 128, 128), bytes_per_cell=175.0),
+}
+
+
+def _cpu_worker(args):
+    """One host core: the reference's blockResCore sequence on one block."""
+    dims, equations, seconds, seed = args
+    from adflow_amd.params import FlowParams
+    from adflow_amd.synth import make_block
+    from oracle import ref
+    prm = FlowParams(equations=equations)
+    blk = make_block(*dims, prm, seed=seed)
+    ref.bind_block(blk, prm)
+    ref.block_res_core(True, True, equations == 3)   # warm-up
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        ref.block_res_core(True, True, equations == 3)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return blk.ncells * n / dt
+
+
+def cpu_baseline(equations, seconds=12.0):
+    from oracle import ref
+    if not ref.available():
+        return None
+    cores = len(os.sched_getaffinity(0))
+    cores = max(1, min(cores, 64))
+    dims = (64, 64, 64)
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        rates = pool.map(_cpu_worker, [(dims, equations, seconds, 100 + i) for i in range(cores)])
+    return {"value": sum(rates) / 1e6, "unit": "Mcells*residual-evals/s", "cores": cores, "kind": "reference",
+            "sample": f"{cores} concurrent processes x one {dims[0]}^3 block each, ~{seconds:.0f} s of "
+                      "blockResCore evaluations of the reference Fortran (amdflang -O3 -fdefault-real-8); no MPI halo exchange",
+            "per_core": sum(rates) / cores / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="euler_jst_8x128")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from adflow_amd.engine import Engine
+    from adflow_amd.params import FlowParams
+    from adflow_amd.synth import make_block
+
+    wl = WORKLOADS[a.workload]
+    prm = FlowParams(equations=wl["equations"], spaceDiscr=wl["spaceDiscr"])
+    eng = Engine(local_rank)
+    eng.set_options(prm)
+    # weak scaling: every GPU owns `nblocks` blocks of the workload
+    nb = wl["nblocks"]
+    cells_local = 0
+    for n in range(nb):
+        blk = make_block(*wl["dims"], prm, seed=20260925 + rank * nb + n)
+        eng.register(blk, nn=n + 1, level=1)
+        cells_local += blk.ncells
+        # host copies are no longer needed by the timed loop
+        for k in list(blk.a.keys()):
+            if k not in ("dw",):
+                del blk.a[k]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    eng.set_async(True)
+    for _ in range(a.warmup):
+        eng.blocketteRes(1, True, True, wl["equations"] == 3)
+    barrier()
+    t0 = time.perf_counter()
+    eng.event_record(0)
+    for _ in range(a.steps):
+        eng.blocketteRes(1, True, True, wl["equations"] == 3)
+    eng.event_record(1)
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = eng.event_elapsed_ms(0, 1)
+
+    # dominant kernel alone (flux kernel: `residual` entry = initres+residual_block), live HIP events
+    from adflow_amd.params import DADI
+    eng.set_options(prm.replace(smoother=DADI))   # rFil = 1, non-persistent fw: the variant blocketteRes launches
+    for _ in range(2):
+        eng.residual(1, 0)
+    eng.event_record(2)
+    for _ in range(a.steps):
+        eng.residual(1, 0)
+    eng.event_record(3)
+    eng.sync()
+    k_ms = eng.event_elapsed_ms(2, 3) / (a.steps * nb)   # per launch (one launch = one block)
+    eng.set_async(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    cells_total = cells_local * world
+    value = cells_total * a.steps / dt / 1e6
+
+    out = None
+    if rank == 0:
+        cells_per_launch = cells_local / nb
+        alg_bytes = wl["bytes_per_cell"] * cells_per_launch
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mcells*residual-evals/s", "value": value, "unit": "Mcells*residual-evals/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {nb} blocks x {wl['dims'][0]}x{wl['dims'][1]}x{wl['dims'][2]} cells per GPU, "
+                                   "Euler, central + scalar JST, one residual evaluation per step (blocketteRes core)",
+                       "cells_per_gpu": cells_local, "device": eng.device_name()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_inviscid_scalar", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "whole_eval": {"event_ms_per_step": ev_ms / a.steps,
+                           "hbm_frac": wl["bytes_per_cell"] * cells_local / (ev_ms / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl["equations"])
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

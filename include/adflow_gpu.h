@@ -1,0 +1,169 @@
+/*
+ * adflow_gpu.h — C-ABI of the MI355X residual / smoother engine.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  The reference has no
+ * plugin registry: its hot path is a set of Fortran module procedures that act
+ * on module-global block pointers.  A maintainer keeps all host Fortran and
+ * replaces the BODIES of the shell routines listed next to each entry point by
+ * a call through an ISO_C_BINDING interface to the function below
+ * (INTEGRATION.md shows the Fortran side; adflow_amd/fortran/adflow_gpu_shim.F90
+ * is that interface module).
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 on success, nonzero on error
+ *    (adflow_gpu_last_error() gives the text; the Fortran shim forwards it to
+ *    utils::terminate, src/utils/utils.F90:501).
+ *  - host arrays are the reference's own Fortran arrays, column-major, with the
+ *    bounds the reference allocates (SURVEY.md §8(a) row "T"); the library
+ *    NEVER takes ownership — it only keeps device mirrors.
+ *  - (nn, level, sps) identify a block exactly like flowDoms(nn,level,sps)
+ *    (src/modules/block.F90:760-775); all three are 1-based.
+ *  - reals are double (realType, src/modules/precision.F90:77-81), integers
+ *    int32 (intType), porosities int8 (porType, precision.F90:110-111).
+ *  - single host thread per process; all work is issued on one HIP stream per
+ *    process and every entry point is synchronous on return unless stated.
+ */
+#ifndef ADFLOW_GPU_H
+#define ADFLOW_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enumerations: values of src/modules/constants.F90 */
+enum { ADFLOW_EULER = 1, ADFLOW_NS = 2, ADFLOW_RANS = 3 };
+enum { ADFLOW_DISS_SCALAR = 1, ADFLOW_DISS_MATRIX = 2, ADFLOW_UPWIND = 9 };
+enum { ADFLOW_LIM_FIRST_ORDER = 1, ADFLOW_LIM_NONE = 2, ADFLOW_LIM_VANALBADA = 3, ADFLOW_LIM_MINMOD = 4 };
+enum { ADFLOW_RUNGE_KUTTA = 1, ADFLOW_DADI = 2 };
+enum { ADFLOW_TURBPROD_STRAIN = 1, ADFLOW_TURBPROD_VORTICITY = 2 };
+enum { ADFLOW_RESAVG_NEVER = 0, ADFLOW_RESAVG_ALWAYS = 1, ADFLOW_RESAVG_ALTERNATE = 2 };
+
+#define ADFLOW_MAX_RK_STAGES 8
+
+/* Options: snapshot of the Fortran module variables the hot path reads.
+ * Refreshed by the shim at every entry (Python may assign them between calls,
+ * adflow/pyADflow.py:5463-5630).  Field names are the reference's. */
+typedef struct adflow_opts {
+    /* inputPhysics (src/modules/inputParam.F90:507-635) */
+    int32_t equations, turbModel, turbProd;
+    int32_t useQCR, useRotationSA, useft2SA;
+    /* inputDiscretization (inputParam.F90:1-97) */
+    int32_t spaceDiscr, spaceDiscrCoarse, limiter, orderTurb;
+    int32_t dirScaling;
+    /* inputIteration (inputParam.F90:183-299) */
+    int32_t smoother, nRKStages, resAveraging, nSubiterations, nSubIterTurb;
+    /* iteration (src/modules/iteration.f90) */
+    int32_t groundLevel;
+    int32_t reserved_i[3];
+    double gammaConstant, prandtl, prandtlTurb;
+    double SSuthDim, muSuthDim, TSuthDim;
+    double SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot;
+    double vis2, vis4, vis2Coarse, adis, acousticScaleFactor, kappaCoef;
+    double cfl, cflCoarse, cflLimit, fcoll, smoop, alfaTurb, betaTurb, turbResScale;
+    double etaRK[ADFLOW_MAX_RK_STAGES], cdisRK[ADFLOW_MAX_RK_STAGES];
+    /* flowVarRefState (src/modules/flowVarRefState.F90) */
+    double gammaInf, pInf, pInfCorr, rhoInf, uInf, RGas, muInf, muRef, TRef, timeRef;
+    double wInf[10];
+    double reserved_d[8];
+} adflow_opts;
+
+/* Host arrays of one block, flowDoms(nn,level,sps)%... .  NULL = not present
+ * (e.g. rev for Euler).  Bounds in comments are the reference's allocation. */
+typedef struct adflow_block_desc {
+    int32_t nx, ny, nz;       /* owned cells: il=nx+1, ie=nx+2, ib=nx+3 (block.F90:363-390) */
+    int32_t nw;               /* 5, or 6 with Spalart-Allmaras */
+    int32_t rightHanded;      /* blockType%rightHanded */
+    int32_t reserved;
+    /* state (initializeFlow.F90:457-529) */
+    double *w;                /* (0:ib,0:jb,0:kb,1:nw)  rho,u,v,w,rhoE[,nuTilde] */
+    double *p, *gamma;        /* (0:ib,0:jb,0:kb) */
+    double *rlv, *rev;        /* (0:ib,0:jb,0:kb) */
+    /* geometry */
+    double *x;                /* (0:ie,0:je,0:ke,3)  partitioning.F90:1761 */
+    double *sI, *sJ, *sK;     /* (0:ie,1:je,1:ke,3) (1:ie,0:je,1:ke,3) (1:ie,1:je,0:ke,3) */
+    double *vol, *volRef;     /* (0:ib,0:jb,0:kb) */
+    double *d2Wall;           /* (2:il,2:jl,2:kl)  wallDistance.F90:503 */
+    int8_t *porI, *porJ, *porK; /* (1:il,2:jl,2:kl) (2:il,1:jl,2:kl) (2:il,2:jl,1:kl) preprocessingAPI.F90:567 */
+    int32_t *iblank;          /* (0:ib,0:jb,0:kb) */
+    /* residual / work arrays the host may want back (utils.F90:3969-3974) */
+    double *dw;               /* (0:ib,0:jb,0:kb,1:nw) */
+    double *fw;               /* (0:ib,0:jb,0:kb,1:5) */
+    double *dtl, *radI, *radJ, *radK; /* (1:ie,1:je,1:ke) */
+    /* multigrid work (coarse levels, initializeFlow.F90:746-748) */
+    double *w1, *p1, *wr;     /* (1:ie,1:je,1:ke,1:5) (1:ie,1:je,1:ke) (2:il,2:jl,2:kl,1:5) */
+} adflow_block_desc;
+
+/* identifiers for adflow_gpu_download_array / adflow_gpu_upload_array */
+enum {
+    ADFLOW_ARR_W = 1, ADFLOW_ARR_P, ADFLOW_ARR_GAMMA, ADFLOW_ARR_RLV, ADFLOW_ARR_REV,
+    ADFLOW_ARR_DW, ADFLOW_ARR_FW, ADFLOW_ARR_DTL, ADFLOW_ARR_RADI, ADFLOW_ARR_RADJ, ADFLOW_ARR_RADK,
+    ADFLOW_ARR_AA, ADFLOW_ARR_NODAL_GRADS, ADFLOW_ARR_WN, ADFLOW_ARR_PN, ADFLOW_ARR_W1, ADFLOW_ARR_P1,
+    ADFLOW_ARR_WR, ADFLOW_ARR_VOL, ADFLOW_ARR_SI, ADFLOW_ARR_SJ, ADFLOW_ARR_SK
+};
+
+/* flags of adflow_gpu_block_res: the logical arguments of blockette::blocketteRes
+ * (src/NKSolver/blockette.F90:70-120) */
+enum {
+    ADFLOW_RES_UPDATE_INTERMED = 1u,   /* also store dtl, radI/J/K */
+    ADFLOW_RES_FLOW = 2u,              /* useFlowRes  */
+    ADFLOW_RES_TURB = 4u               /* useTurbRes  */
+};
+
+/* ---- lifetime ---------------------------------------------------------- */
+int adflow_gpu_init(int device_ordinal);
+int adflow_gpu_finalize(void);
+const char* adflow_gpu_last_error(void);
+int adflow_gpu_device_name(char* buf, int len);
+
+/* ---- multi-GPU (RCCL over xGMI) replaces the MPI path of
+ *      src/utils/haloExchange.F90:553-719 ------------------------------------ */
+int adflow_gpu_comm_unique_id(void* id128);                       /* rank 0: create id (128 bytes) */
+int adflow_gpu_comm_init(int rank, int nranks, const void* id128); /* all ranks */
+
+/* ---- data model -------------------------------------------------------- */
+int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_desc* d);
+int adflow_gpu_upload_geometry(int nn, int level, int sps);   /* x,sI,sJ,sK,vol,volRef,d2Wall,por*,iblank */
+int adflow_gpu_upload_state(int nn, int level, int sps);      /* w,p,gamma,rlv,rev incl. both halo layers */
+int adflow_gpu_download_state(int nn, int level, int sps);
+int adflow_gpu_download_residual(int nn, int level, int sps); /* dw -> desc.dw */
+int adflow_gpu_download_array(int nn, int level, int sps, int which, double* host);
+int adflow_gpu_upload_array(int nn, int level, int sps, int which, const double* host);
+int adflow_gpu_set_options(const adflow_opts* o);
+
+/* ---- the hot path; each acts on ALL registered blocks of `level`, like the
+ *      reference's shell loops over nDom -------------------------------------- */
+/* solverUtils::timeStep (src/solver/solverUtils.F90:4-41, block body :43-356) */
+int adflow_gpu_time_step(int level, int onlyRadii);
+/* residuals::initres (src/solver/residuals.F90:964-1026, block body :427-955), 1-based var range */
+int adflow_gpu_initres(int level, int varStart, int varEnd);
+/* residuals::residual (src/solver/residuals.F90:1028-1060, block body :4-346);
+ * rkStage selects rFil = cdisRK(rkStage+1) for the Runge-Kutta smoother */
+int adflow_gpu_residual(int level, int rkStage);
+/* blockette::blocketteRes main loop (src/NKSolver/blockette.F90:266-283):
+ * timeStep + initres + [SA] + inviscid + [viscous] + dw=(dw+fw)*iblank, rFil=1 */
+int adflow_gpu_block_res(int level, unsigned flags);
+/* smoothers::RungeKuttaSmoother / DADISmoother (src/solver/smoothers.F90:4,383) */
+int adflow_gpu_rk_smooth(int level);
+int adflow_gpu_dadi_smooth(int level);
+/* haloExchange::whalo1 / whalo2 (src/utils/haloExchange.F90:5,109) */
+int adflow_gpu_halo_exchange(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers);
+/* sum over owned cells of (dw(:,l)/vol)^2, l=1..n  (solvers.F90:1538) */
+int adflow_gpu_res_norms(int level, double* sums, int n);
+
+/* ---- instrumentation: HIP events on the library's own stream ------------ */
+int adflow_gpu_event_record(int slot);                   /* slot in [0,64) */
+int adflow_gpu_event_elapsed_ms(int slot_start, int slot_stop, double* ms);
+int adflow_gpu_sync(void);
+/* on != 0: hot-path entry points only ENQUEUE on the library stream (no host
+ * sync at return); the caller orders with adflow_gpu_sync().  Default off. */
+int adflow_gpu_set_async(int on);
+/* sizeof(adflow_opts), sizeof(adflow_block_desc) as compiled: lets a foreign-
+ * language binding verify its mirror of the two structs */
+int adflow_gpu_abi_sizes(int* opts_bytes, int* desc_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADFLOW_GPU_H */
