@@ -74,30 +74,57 @@ int alloc_arr(Block* b, double** p, int ncomp)
     return 0;
 }
 
+// pinned staging buffer (grown on demand) for host <-> device box transfers
+double* g_stage = nullptr;
+size_t g_stage_elems = 0;
+
+int stage_reserve(size_t elems)
+{
+    if (elems <= g_stage_elems) return 0;
+    if (g_stage) (void)hipHostFree(g_stage);
+    g_stage = nullptr;
+    g_stage_elems = 0;
+    HIPCHK(hipHostMalloc((void**)&g_stage, elems * sizeof(double), hipHostMallocDefault));
+    g_stage_elems = elems;
+    return 0;
+}
+
 // host sub-box (lo..lo+n-1 in each direction, column-major, ncomp components)
-// <-> device box component(s)
-int copy_box(Block* b, double* dev, const double* host, int ncomp, int lo_i, int n_i, int lo_j, int n_j, int lo_k, int n_k,
+// <-> device box component(s).  The host side is the reference's pageable
+// Fortran array; rows are (un)packed through one pinned buffer holding the
+// k-slab range of the padded device box, moved with a single DMA per component.
+int copy_box(Block* b, double* dev, const double* host_c, int ncomp, int lo_i, int n_i, int lo_j, int n_j, int lo_k, int n_k,
              bool to_device)
 {
-    if (!host) return 0;
+    if (!host_c) return 0;
+    double* host = const_cast<double*>(host_c);
+    const BlkView& v = b->v;
+    const size_t slab = (size_t)v.ldk * n_k;            // padded elements covering k = lo_k .. lo_k+n_k-1
+    if (stage_reserve(slab)) return 1;
     for (int c = 0; c < ncomp; ++c) {
-        hipMemcpy3DParms p;
-        memset(&p, 0, sizeof p);
-        double* dptr = dev + (size_t)c * b->v.nbox + b->v.idx(lo_i, lo_j, lo_k);
-        const double* hptr = host + (size_t)c * n_i * n_j * n_k;
-        hipPitchedPtr hp = make_hipPitchedPtr((void*)hptr, (size_t)n_i * 8, (size_t)n_i, (size_t)n_j);
-        hipPitchedPtr dp = make_hipPitchedPtr((void*)dptr, (size_t)b->v.ldi * 8, (size_t)b->v.ldi, (size_t)(b->v.jb + 1));
-        p.extent = make_hipExtent((size_t)n_i * 8, (size_t)n_j, (size_t)n_k);
+        double* dptr = dev + (size_t)c * v.nbox + v.idx(0, 0, lo_k);
+        double* hcomp = host + (size_t)c * n_i * n_j * n_k;
         if (to_device) {
-            p.srcPtr = hp;
-            p.dstPtr = dp;
-            p.kind = hipMemcpyHostToDevice;
+            // read-modify-write of the slab keeps device values outside the sub-box
+            const bool partial = (lo_i != 0 || lo_j != 0 || n_i != v.ib + 1 || n_j != v.jb + 1);
+            if (partial) {
+                HIPCHK(hipMemcpyAsync(g_stage, dptr, slab * 8, hipMemcpyDeviceToHost, g_stream));
+                HIPCHK(hipStreamSynchronize(g_stream));
+            }
+            for (int k = 0; k < n_k; ++k)
+                for (int j = 0; j < n_j; ++j)
+                    memcpy(g_stage + (size_t)k * v.ldk + (size_t)(j + lo_j) * v.ldi + lo_i,
+                           hcomp + ((size_t)k * n_j + j) * n_i, (size_t)n_i * 8);
+            HIPCHK(hipMemcpyAsync(dptr, g_stage, slab * 8, hipMemcpyHostToDevice, g_stream));
+            HIPCHK(hipStreamSynchronize(g_stream));
         } else {
-            p.srcPtr = dp;
-            p.dstPtr = hp;
-            p.kind = hipMemcpyDeviceToHost;
+            HIPCHK(hipMemcpyAsync(g_stage, dptr, slab * 8, hipMemcpyDeviceToHost, g_stream));
+            HIPCHK(hipStreamSynchronize(g_stream));
+            for (int k = 0; k < n_k; ++k)
+                for (int j = 0; j < n_j; ++j)
+                    memcpy(hcomp + ((size_t)k * n_j + j) * n_i,
+                           g_stage + (size_t)k * v.ldk + (size_t)(j + lo_j) * v.ldi + lo_i, (size_t)n_i * 8);
         }
-        HIPCHK(hipMemcpy3DAsync(&p, g_stream));
     }
     return 0;
 }
@@ -208,6 +235,11 @@ int adflow_gpu_finalize(void)
     if (g_events_ready) {
         for (int i = 0; i < 64; ++i) (void)hipEventDestroy(g_events[i]);
         g_events_ready = false;
+    }
+    if (g_stage) {
+        (void)hipHostFree(g_stage);
+        g_stage = nullptr;
+        g_stage_elems = 0;
     }
     if (g_stream) {
         (void)hipStreamDestroy(g_stream);

@@ -14,7 +14,6 @@ cpu_baseline: the reference's own Fortran (oracle/_ref, "reference") timed on
 """
 import argparse
 import json
-import multiprocessing as mp
 import os
 import sys
 import time
@@ -30,41 +29,56 @@ WORKLOADS = {
 }
 
 
-def _cpu_worker(args):
-    """One host core: the reference's blockResCore sequence on one block."""
-    dims, equations, seconds, seed = args
-    from adflow_amd.params import FlowParams
-    from adflow_amd.synth import make_block
-    from oracle import ref
-    prm = FlowParams(equations=equations)
-    blk = make_block(*dims, prm, seed=seed)
-    ref.bind_block(blk, prm)
-    ref.block_res_core(True, True, equations == 3)   # warm-up
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        ref.block_res_core(True, True, equations == 3)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
-    return blk.ncells * n / dt
+CPU_WORKER = r"""
+import sys, json
+sys.path.insert(0, sys.argv[1])
+from adflow_amd.params import FlowParams
+from adflow_amd.synth import make_block
+from oracle import ref
+n1, n2, n3, equations, seconds, seed = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]), int(sys.argv[7])
+prm = FlowParams(equations=equations)
+blk = make_block(n1, n2, n3, prm, seed=seed)
+ref.bind_block(blk, prm)
+n, dt = ref.time_block_res_core(seconds, True, True, equations == 3)
+print(json.dumps({"rate": blk.ncells * n / dt}))
+"""
 
 
-def cpu_baseline(equations, seconds=12.0):
+def cpu_baseline(equations, seconds=12.0, max_cores=32, dims=(64, 64, 64)):
+    """The reference's own Fortran (oracle/_ref) on this box's host cores: one
+    pinned process per core, each repeating blockResCore on its own block."""
+    import subprocess
     from oracle import ref
     if not ref.available():
         return None
-    cores = len(os.sched_getaffinity(0))
-    cores = max(1, min(cores, 64))
-    dims = (64, 64, 64)
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        rates = pool.map(_cpu_worker, [(dims, equations, seconds, 100 + i) for i in range(cores)])
-    return {"value": sum(rates) / 1e6, "unit": "Mcells*residual-evals/s", "cores": cores, "kind": "reference",
-            "sample": f"{cores} concurrent processes x one {dims[0]}^3 block each, ~{seconds:.0f} s of "
+    avail = sorted(os.sched_getaffinity(0))
+    cores = max(1, min(len(avail), max_cores))
+    procs = []
+    for i in range(cores):
+        cmd = ["taskset", "-c", str(avail[i]), sys.executable, "-c", CPU_WORKER, ROOT,
+               str(dims[0]), str(dims[1]), str(dims[2]), str(equations), str(seconds), str(100 + i)]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    rates = []
+    deadline = time.time() + seconds + 120.0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+            rates.append(json.loads(out.strip().splitlines()[-1])["rate"])
+        except Exception:
+            pr.kill()
+    if not rates:
+        return None
+    return {"value": sum(rates) / 1e6, "unit": "Mcells*residual-evals/s", "cores": len(rates), "kind": "reference",
+            "sample": f"{len(rates)} pinned processes x one {dims[0]}x{dims[1]}x{dims[2]} block each, ~{seconds:.0f} s of "
                       "blockResCore evaluations of the reference Fortran (amdflang -O3 -fdefault-real-8); no MPI halo exchange",
-            "per_core": sum(rates) / cores / 1e6}
+            "per_core": sum(rates) / len(rates) / 1e6}
+
+
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -84,6 +98,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    log("torch imported")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -104,6 +119,7 @@ def main():
         blk = make_block(*wl["dims"], prm, seed=20260925 + rank * nb + n)
         eng.register(blk, nn=n + 1, level=1)
         cells_local += blk.ncells
+        log(f"block {n + 1}/{nb} generated and uploaded")
         # host copies are no longer needed by the timed loop
         for k in list(blk.a.keys()):
             if k not in ("dw",):
@@ -127,6 +143,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ev_ms = eng.event_elapsed_ms(0, 1)
+    log(f"timed loop done: {dt / a.steps * 1e3:.3f} ms/step")
 
     # dominant kernel alone (flux kernel: `residual` entry = initres+residual_block), live HIP events
     from adflow_amd.params import DADI
@@ -172,7 +189,9 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline (reference Fortran on the host cores) ...")
             out["cpu_baseline"] = cpu_baseline(wl["equations"])
+            log("cpu baseline done")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -128,10 +128,55 @@ def bind_block(blk, prm) -> None:
         lib.ref_set_ptr(name.encode(), arr.ctypes.data)
 
 
+def _big_stack(fn, *args):
+    """The reference keeps block-sized automatic arrays on the stack (e.g. dss, ss
+    in fluxes.F90:1079-1080): run its routines on a thread with a 2 GiB stack
+    instead of the 8 MiB main-thread default."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn(*args)
+        except BaseException as e:  # pragma: no cover
+            box["e"] = e
+
+    old = threading.stack_size(2 << 30)
+    try:
+        t = threading.Thread(target=run)
+        t.start()
+    finally:
+        threading.stack_size(old)
+    t.join()
+    if "e" in box:
+        raise box["e"]
+    return box.get("r")
+
+
 def call(name: str, iarg: int = 0) -> None:
-    load().ref_call(name.encode(), int(iarg))
+    _big_stack(load().ref_call, name.encode(), int(iarg))
 
 
 def block_res_core(update_intermed=True, flow_res=True, turb_res=True) -> None:
     """blockette::blockResCore (blockette.F90:755-852) call sequence."""
-    load().ref_block_res_core(int(update_intermed), int(flow_res), int(turb_res))
+    _big_stack(load().ref_block_res_core, int(update_intermed), int(flow_res), int(turb_res))
+
+
+def time_block_res_core(seconds: float, update_intermed=True, flow_res=True, turb_res=True):
+    """Repeat the blockResCore sequence for ~`seconds`; returns (evals, elapsed)."""
+    import time
+    fn = load().ref_block_res_core
+    a = (int(update_intermed), int(flow_res), int(turb_res))
+
+    def loop():
+        fn(*a)   # warm-up
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            fn(*a)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                return n, dt
+
+    return _big_stack(loop)
