@@ -153,7 +153,7 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.sfil = 1.0 - rFil;
     k.vis2 = o.vis2; k.vis4 = o.vis4; k.vis2Coarse = o.vis2Coarse; k.adis = o.adis;
     k.acousticScaleFactor = o.acousticScaleFactor; k.kappaCoef = o.kappaCoef;
-    k.gammaInf = o.gammaInf; k.pInfCorr = o.pInfCorr; k.rhoInf = o.rhoInf; k.RGas = o.RGas;
+    k.gammaConstant = o.gammaConstant; k.gammaInf = o.gammaInf; k.pInfCorr = o.pInfCorr; k.rhoInf = o.rhoInf; k.RGas = o.RGas;
     k.muRef = o.muRef; k.TRef = o.TRef; k.timeRef = o.timeRef;
     k.prandtl = o.prandtl; k.prandtlTurb = o.prandtlTurb;
     k.SSuthDim = o.SSuthDim; k.muSuthDim = o.muSuthDim; k.TSuthDim = o.TSuthDim;
@@ -495,7 +495,8 @@ static int enqueue_flow_residual(int level, const KParams& kp)
 {
     return for_level(level, [&](Block* b) {
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
-        if (kp.spaceDiscr != ADFLOW_DISS_SCALAR) return fail("spaceDiscr=%d not implemented yet", kp.spaceDiscr);
+        if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
+            return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
         launch_inviscid(b->v, kp, g_stream);
         return 0;
     });

@@ -60,7 +60,7 @@ struct KParams {
     int storeIntermed;     // store dtl / radii
     double rFil, sfil;
     double vis2, vis4, vis2Coarse, adis, acousticScaleFactor, kappaCoef;
-    double gammaInf, pInfCorr, rhoInf, RGas, muRef, TRef, timeRef;
+    double gammaConstant, gammaInf, pInfCorr, rhoInf, RGas, muRef, TRef, timeRef;
     double prandtl, prandtlTurb, SSuthDim, muSuthDim, TSuthDim;
     double sa_k, sa_cb1, sa_cb2, sa_cb3, sa_cv1, sa_cw1, sa_cw2, sa_cw3, sa_ct3, sa_ct4, sa_crot;
     double cfl, cflLimit, smoop, fcoll, turbResScale;

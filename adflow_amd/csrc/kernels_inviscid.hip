@@ -95,11 +95,187 @@ __device__ __forceinline__ double jst_sensor(double sm, double s0, double sp, do
     return fabs((sp - 2.0 * s0 + sm) / (sp + 2.0 * s0 + sm + sslim));
 }
 
-// one index direction of the scalar scheme for the cell at line position 2
-template <bool VISC>
-__device__ __forceinline__ void dir_scalar(const BlkView& b, const KParams& kp, long c, long s, const double* __restrict__ sN,
-                                           const double* __restrict__ rad, int porM, int porP, double sslim,
-                                           double fis2, double fis4, bool doDiss, double dwc[5], double fwd[5])
+// matrix JST sensor (pressure, omega = 0.5 blending; fluxes.F90:495-508)
+__device__ __forceinline__ double mat_sensor(double pm, double p0, double pp, double plim)
+{
+    return fabs((pp - 2.0 * p0 + pm) /
+                (0.5 * (pp + 2.0 * p0 + pm) + 0.5 * (fabs(pp - p0) + fabs(p0 - pm)) + plim));
+}
+
+// shared tail of the matrix-dissipation and Roe fluxes: |A| applied to the
+// conservative difference (dr,dru,drv,drw,dre)  (fluxes.F90:626-690, 2469-2501)
+__device__ __forceinline__ void absA_times_dw(double lam1, double lam2, double lam3, double gm1, double alphaAvg,
+                                              double uAvg, double vAvg, double wAvg, double hAvg, double unAvg,
+                                              double ovaAvg, double ova2Avg, double sx, double sy, double sz,
+                                              double dr, double dru, double drv, double drw, double dre, double f[5])
+{
+    const double abv1 = 0.5 * (lam1 + lam2);
+    const double abv2 = 0.5 * (lam1 - lam2);
+    const double abv3 = abv1 - lam3;
+    const double abv4 = gm1 * (alphaAvg * dr - uAvg * dru - vAvg * drv - wAvg * drw + dre);   // - gm53*drk, drk = 0 (SA)
+    const double abv5 = sx * dru + sy * drv + sz * drw - unAvg * dr;
+    const double abv6 = abv3 * abv4 * ova2Avg + abv2 * abv5 * ovaAvg;
+    const double abv7 = abv2 * abv4 * ovaAvg + abv3 * abv5;
+    f[0] = lam3 * dr + abv6;
+    f[1] = lam3 * dru + uAvg * abv6 + sx * abv7;
+    f[2] = lam3 * drv + vAvg * abv6 + sy * abv7;
+    f[3] = lam3 * drw + wAvg * abv6 + sz * abv7;
+    f[4] = lam3 * dre + hAvg * abv6 + unAvg * abv7;
+}
+
+// matrix JST dissipative flux through face (l | l+1)  (fluxes.F90:523-690)
+__device__ __forceinline__ void jst_matrix_face(const Line& L, const double gam[5], int l, double nx, double ny, double nz,
+                                                int por, double dssL, double dssR, double fis2, double fis4, double sign,
+                                                double acc[5])
+{
+    const int r = l + 1, ll = l - 1, rr = l + 2;
+    const double ppor = (por == ADF_POR_NORMAL) ? 1.0 : 0.0;
+    const double dis2 = ppor * fis2 * fmin(0.25, fmax(dssL, dssR));
+    const double dis4 = fmax(ppor * fis4 - dis2, 0.0);
+    double ddw;
+    ddw = L.rho[r] - L.rho[l];
+    const double dr = dis2 * ddw - dis4 * (L.rho[rr] - L.rho[ll] - 3.0 * ddw);
+    ddw = L.rho[r] * L.u[r] - L.rho[l] * L.u[l];
+    const double dru = dis2 * ddw - dis4 * (L.rho[rr] * L.u[rr] - L.rho[ll] * L.u[ll] - 3.0 * ddw);
+    ddw = L.rho[r] * L.v[r] - L.rho[l] * L.v[l];
+    const double drv = dis2 * ddw - dis4 * (L.rho[rr] * L.v[rr] - L.rho[ll] * L.v[ll] - 3.0 * ddw);
+    ddw = L.rho[r] * L.w[r] - L.rho[l] * L.w[l];
+    const double drw = dis2 * ddw - dis4 * (L.rho[rr] * L.w[rr] - L.rho[ll] * L.w[ll] - 3.0 * ddw);
+    ddw = L.e[r] - L.e[l];
+    const double dre = dis2 * ddw - dis4 * (L.e[rr] - L.e[ll] - 3.0 * ddw);
+
+    const double gammaAvg = 0.5 * (gam[r] + gam[l]);
+    const double gm1 = gammaAvg - 1.0;
+    const double ovgm1 = 1.0 / gm1;
+    const double uAvg = 0.5 * (L.u[r] + L.u[l]);
+    const double vAvg = 0.5 * (L.v[r] + L.v[l]);
+    const double wAvg = 0.5 * (L.w[r] + L.w[l]);
+    const double a2Avg = 0.5 * (gam[r] * L.p[r] / L.rho[r] + gam[l] * L.p[l] / L.rho[l]);
+    const double area = sqrt(nx * nx + ny * ny + nz * nz);
+    const double tmp = 1.0 / fmax(1.e-25, area);
+    const double sx = nx * tmp, sy = ny * tmp, sz = nz * tmp;
+    const double alphaAvg = 0.5 * (uAvg * uAvg + vAvg * vAvg + wAvg * wAvg);
+    const double hAvg = alphaAvg + ovgm1 * a2Avg;
+    const double aAvg = sqrt(a2Avg);
+    const double unAvg = uAvg * sx + vAvg * sy + wAvg * sz;
+    const double ovaAvg = 1.0 / aAvg, ova2Avg = 1.0 / a2Avg;
+    double lam1 = fabs(unAvg + aAvg), lam2 = fabs(unAvg - aAvg), lam3 = fabs(unAvg);
+    const double rrad = lam3 + aAvg;
+    lam1 = fmax(lam1, 0.25 * rrad) * area;    // epsAcoustic
+    lam2 = fmax(lam2, 0.25 * rrad) * area;
+    lam3 = fmax(lam3, 0.025 * rrad) * area;   // epsShear
+    double f[5];
+    absA_times_dw(lam1, lam2, lam3, gm1, alphaAvg, uAvg, vAvg, wAvg, hAvg, unAvg, ovaAvg, ova2Avg, sx, sy, sz, dr, dru,
+                  drv, drw, dre, f);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) acc[m] += sign * f[m];
+}
+
+// MUSCL left/right state corrections (fluxes.F90:2103-2294 leftRightState)
+__device__ __forceinline__ void muscl(int lim, double omk, double opk, double factMinmod, double du1, double du2, double du3,
+                                      double& left, double& right)
+{
+    if (lim == ADFLOW_LIM_NONE) {
+        left = omk * du1 + opk * du2;
+        right = -omk * du3 - opk * du2;
+        return;
+    }
+    const double epsLim = 1.e-10;
+    const double tmp = 1.0 / copysign(fmax(fabs(du2), epsLim), du2);
+    double rl1 = fmax(0.0, du2 / copysign(fmax(fabs(du1), epsLim), du1));
+    double rl2 = fmax(0.0, du1 * tmp);
+    double rr1 = fmax(0.0, du3 * tmp);
+    double rr2 = fmax(0.0, du2 / copysign(fmax(fabs(du3), epsLim), du3));
+    if (lim == ADFLOW_LIM_VANALBADA) {
+        rl1 = rl1 * (rl1 + 1.0) / (rl1 * rl1 + 1.0);
+        rl2 = rl2 * (rl2 + 1.0) / (rl2 * rl2 + 1.0);
+        rr1 = rr1 * (rr1 + 1.0) / (rr1 * rr1 + 1.0);
+        rr2 = rr2 * (rr2 + 1.0) / (rr2 * rr2 + 1.0);
+    } else {   // minmod
+        rl1 = fmin(1.0, factMinmod * rl1);
+        rl2 = fmin(1.0, factMinmod * rl2);
+        rr1 = fmin(1.0, factMinmod * rr1);
+        rr2 = fmin(1.0, factMinmod * rr2);
+    }
+    left = omk * rl1 * du1 + opk * rl2 * du2;
+    right = -opk * rr1 * du2 - omk * rr2 * du3;
+}
+
+// Roe dissipation flux through face (l | l+1) from MUSCL-reconstructed
+// primitive states (rho,u,v,w,p); fw(left) += flux, fw(right) -= flux
+// (fluxes.F90:1790-1889 + riemannFlux :2296-2532)
+__device__ __forceinline__ void roe_face(const Line& L, const double gam[5], int l, double nx, double ny, double nz, int por,
+                                         int lim, double kappaCoef, double rFil, double gammaConstant, double sign,
+                                         double acc[5])
+{
+    const int r = l + 1, ll = l - 1, rr = l + 2;
+    double left[5], right[5];
+    if (lim == ADFLOW_LIM_FIRST_ORDER) {
+        left[0] = L.rho[l]; left[1] = L.u[l]; left[2] = L.v[l]; left[3] = L.w[l]; left[4] = L.p[l];
+        right[0] = L.rho[r]; right[1] = L.u[r]; right[2] = L.v[r]; right[3] = L.w[r]; right[4] = L.p[r];
+    } else {
+        const double omk = 0.25 * (1.0 - kappaCoef), opk = 0.25 * (1.0 + kappaCoef);
+        const double factMinmod = (3.0 - kappaCoef) / fmax(1.e-10, 1.0 - kappaCoef);
+        const double* q[5] = {L.rho, L.u, L.v, L.w, L.p};
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const double du1 = q[m][l] - q[m][ll];
+            const double du2 = q[m][r] - q[m][l];
+            const double du3 = q[m][rr] - q[m][r];
+            double dl, dr_;
+            muscl(lim, omk, opk, factMinmod, du1, du2, du3, dl, dr_);
+            left[m] = dl + q[m][l];
+            right[m] = dr_ + q[m][r];
+        }
+    }
+    double porFlux = 0.5 * rFil;
+    if (por == ADF_POR_NOFLUX || por == ADF_POR_BOUND) porFlux = 0.0;
+    const double gammaFace = 0.5 * (gam[l] + gam[r]);
+    const double gm1 = gammaFace - 1.0;
+    const double z1l = sqrt(left[0]), z1r = sqrt(right[0]);
+    double tmp = 1.0 / (z1l + z1r);
+    const double ovgm1 = 1.0 / (gammaConstant - 1.0);   // flowUtils::etot/eint, cpConstant
+    const double Etl = left[0] * (ovgm1 * left[4] / left[0] + 0.5 * (left[1] * left[1] + left[2] * left[2] + left[3] * left[3]));
+    const double Etr = right[0] * (ovgm1 * right[4] / right[0] + 0.5 * (right[1] * right[1] + right[2] * right[2] + right[3] * right[3]));
+    const double dr = right[0] - left[0];
+    const double dru = right[0] * right[1] - left[0] * left[1];
+    const double drv = right[0] * right[2] - left[0] * left[2];
+    const double drw = right[0] * right[3] - left[0] * left[3];
+    const double drE = Etr - Etl;
+    const double uAvg = tmp * (z1l * left[1] + z1r * right[1]);
+    const double vAvg = tmp * (z1l * left[2] + z1r * right[2]);
+    const double wAvg = tmp * (z1l * left[3] + z1r * right[3]);
+    const double hAvg = tmp * ((Etl + left[4]) / z1l + (Etr + right[4]) / z1r);
+    const double area = sqrt(nx * nx + ny * ny + nz * nz);
+    tmp = 1.0 / fmax(1.e-25, area);
+    const double sx = nx * tmp, sy = ny * tmp, sz = nz * tmp;
+    const double alphaAvg = 0.5 * (uAvg * uAvg + vAvg * vAvg + wAvg * wAvg);
+    const double a2Avg = fabs(gm1 * (hAvg - alphaAvg));
+    const double aAvg = sqrt(a2Avg);
+    double unAvg = uAvg * sx + vAvg * sy + wAvg * sz;
+    const double ovaAvg = 1.0 / aAvg, ova2Avg = 1.0 / a2Avg;
+    if (por == ADF_POR_BOUND) unAvg = 0.0;   // rFace = 0 (no grid velocity)
+    const double eta = 0.5 * (fabs((left[1] - right[1]) * sx + (left[2] - right[2]) * sy + (left[3] - right[3]) * sz) +
+                              fabs(sqrt(gammaFace * left[4] / left[0]) - sqrt(gammaFace * right[4] / right[0])));
+    double lam1 = fabs(unAvg + aAvg), lam2 = fabs(unAvg - aAvg), lam3 = fabs(unAvg);
+    tmp = 2.0 * eta;
+    if (lam1 < tmp) lam1 = eta + 0.25 * lam1 * lam1 / eta;
+    if (lam2 < tmp) lam2 = eta + 0.25 * lam2 * lam2 / eta;
+    if (lam3 < tmp) lam3 = eta + 0.25 * lam3 * lam3 / eta;
+    lam1 *= area; lam2 *= area; lam3 *= area;
+    double f[5];
+    absA_times_dw(lam1, lam2, lam3, gm1, alphaAvg, uAvg, vAvg, wAvg, hAvg, unAvg, ovaAvg, ova2Avg, sx, sy, sz, dr, dru,
+                  drv, drw, drE, f);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) acc[m] += sign * (-porFlux * f[m]);
+}
+
+// one index direction for the cell at line position 2: central flux through
+// both faces + the selected dissipation
+template <int SCHEME, bool VISC>
+__device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, long c, long s, const double* __restrict__ sN,
+                                         const double* __restrict__ rad, int porM, int porP, double sslim,
+                                         double fis2, double fis4, bool doDiss, int lim, double dwc[5], double fwd[5])
 {
     Line L;
     load_line(b, c, s, L);
@@ -109,7 +285,8 @@ __device__ __forceinline__ void dir_scalar(const BlkView& b, const KParams& kp, 
     const double px = sN[c], py = sN[c + nb], pz = sN[c + 2 * nb];
     central_face(L, 1, mx, my, mz, porM, -1.0, dwc);
     central_face(L, 2, px, py, pz, porP, +1.0, dwc);
-    if (doDiss) {
+    if (!doDiss) return;
+    if (SCHEME == ADFLOW_DISS_SCALAR) {
         double ssv[5];
         if (VISC) {
 #pragma unroll
@@ -126,13 +303,28 @@ __device__ __forceinline__ void dir_scalar(const BlkView& b, const KParams& kp, 
         const double rrP = (porP == ADF_POR_NORMAL ? 0.5 : 0.0) * (r0 + rad[c + s]);
         jst_scalar_face(L, 1, rrM, dm, d0, fis2, fis4, +1.0, fwd);   // cell is the right cell
         jst_scalar_face(L, 2, rrP, d0, dp, fis2, fis4, -1.0, fwd);   // cell is the left cell
+    } else {
+        double gam[5];
+        gam[0] = gam[4] = 0.0;
+#pragma unroll
+        for (int m = 1; m < 4; ++m) gam[m] = b.gamma[c + (m - 2) * s];
+        if (SCHEME == ADFLOW_DISS_MATRIX) {
+            const double dm = mat_sensor(L.p[0], L.p[1], L.p[2], sslim);
+            const double d0 = mat_sensor(L.p[1], L.p[2], L.p[3], sslim);
+            const double dp = mat_sensor(L.p[2], L.p[3], L.p[4], sslim);
+            jst_matrix_face(L, gam, 1, mx, my, mz, porM, dm, d0, fis2, fis4, +1.0, fwd);
+            jst_matrix_face(L, gam, 2, px, py, pz, porP, d0, dp, fis2, fis4, -1.0, fwd);
+        } else {   // Roe upwind: fw(left) += flux, fw(right) -= flux
+            roe_face(L, gam, 1, mx, my, mz, porM, lim, kp.kappaCoef, kp.rFil, kp.gammaConstant, -1.0, fwd);
+            roe_face(L, gam, 2, px, py, pz, porP, lim, kp.kappaCoef, kp.rFil, kp.gammaConstant, +1.0, fwd);
+        }
     }
 }
 
 // FINAL: dw = (init + central + fw) * iblank written; otherwise dw = init + central
 // and fw stored for the viscous kernel to complete.
-template <bool VISC, bool FINAL>
-__global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid_scalar(BlkView b, KParams kp)
+template <int SCHEME, bool VISC, bool FINAL>
+__global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid(BlkView b, KParams kp)
 {
     const int i = blockIdx.x * IV_BX + threadIdx.x + 2;
     const int j = blockIdx.y * IV_BY + threadIdx.y + 2;
@@ -145,17 +337,19 @@ __global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid_scalar(BlkView b, KPa
     const uint8_t fi = b.flags[c - 1], fj = b.flags[c - b.ldi], fk = b.flags[c - b.ldk];
 
     double sslim;
-    if (VISC)
+    if (SCHEME == ADFLOW_DISS_SCALAR && VISC)
         sslim = 0.001 * kp.pInfCorr / pow(kp.rhoInf, kp.gammaInf);
     else
-        sslim = 0.001 * kp.pInfCorr;
+        sslim = 0.001 * kp.pInfCorr;   // scalar-Euler sslim / matrix plim
     const double fis2 = kp.rFil * kp.vis2, fis4 = kp.rFil * kp.vis4;
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
+    // limiter actually used: first order off the fine grid (fluxes.F90:1531-1538)
+    const int lim = kp.fineGrid ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;
 
     double dwc[5] = {0, 0, 0, 0, 0}, fwd[5] = {0, 0, 0, 0, 0};
-    dir_scalar<VISC>(b, kp, c, 1, b.sI, b.radI, flg_porI(fi), flg_porI(f0), sslim, fis2, fis4, doDiss, dwc, fwd);
-    dir_scalar<VISC>(b, kp, c, b.ldi, b.sJ, b.radJ, flg_porJ(fj), flg_porJ(f0), sslim, fis2, fis4, doDiss, dwc, fwd);
-    dir_scalar<VISC>(b, kp, c, b.ldk, b.sK, b.radK, flg_porK(fk), flg_porK(f0), sslim, fis2, fis4, doDiss, dwc, fwd);
+    dir_flux<SCHEME, VISC>(b, kp, c, 1, b.sI, b.radI, flg_porI(fi), flg_porI(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd);
+    dir_flux<SCHEME, VISC>(b, kp, c, b.ldi, b.sJ, b.radJ, flg_porJ(fj), flg_porJ(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd);
+    dir_flux<SCHEME, VISC>(b, kp, c, b.ldk, b.sK, b.radK, flg_porK(fk), flg_porK(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd);
 
     const double blank = flg_blank(f0);
 #pragma unroll
@@ -179,20 +373,23 @@ __global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid_scalar(BlkView b, KPa
     }
 }
 
+template <int SCHEME>
+static void launch_scheme(const BlkView& b, const KParams& kp, dim3 grd, dim3 blk, hipStream_t s)
+{
+    if (kp.viscous)
+        hipLaunchKernelGGL((k_inviscid<SCHEME, true, false>), grd, blk, 0, s, b, kp);
+    else
+        hipLaunchKernelGGL((k_inviscid<SCHEME, false, true>), grd, blk, 0, s, b, kp);
+}
+
 void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s)
 {
     dim3 blk(IV_BX, IV_BY, 1);
     dim3 grd((b.nx + IV_BX - 1) / IV_BX, (b.ny + IV_BY - 1) / IV_BY, b.nz);
-    const bool final = !kp.viscous;
-    if (kp.spaceDiscr == ADFLOW_DISS_SCALAR) {
-        if (kp.viscous) {
-            if (final)
-                hipLaunchKernelGGL((k_inviscid_scalar<true, true>), grd, blk, 0, s, b, kp);
-            else
-                hipLaunchKernelGGL((k_inviscid_scalar<true, false>), grd, blk, 0, s, b, kp);
-        } else {
-            hipLaunchKernelGGL((k_inviscid_scalar<false, true>), grd, blk, 0, s, b, kp);
-        }
+    switch (kp.spaceDiscr) {
+    case ADFLOW_DISS_SCALAR: launch_scheme<ADFLOW_DISS_SCALAR>(b, kp, grd, blk, s); break;
+    case ADFLOW_DISS_MATRIX: launch_scheme<ADFLOW_DISS_MATRIX>(b, kp, grd, blk, s); break;
+    case ADFLOW_UPWIND: launch_scheme<ADFLOW_UPWIND>(b, kp, grd, blk, s); break;
     }
 }
 
