@@ -72,7 +72,7 @@ RES_UPDATE_INTERMED, RES_FLOW, RES_TURB = 1, 2, 4
 EXPORTS = [
     "adflow_gpu_init", "adflow_gpu_finalize", "adflow_gpu_last_error", "adflow_gpu_device_name",
     "adflow_gpu_comm_unique_id", "adflow_gpu_comm_init",
-    "adflow_gpu_block_register", "adflow_gpu_upload_geometry", "adflow_gpu_upload_state",
+    "adflow_gpu_block_register", "adflow_gpu_block_release", "adflow_gpu_release_all", "adflow_gpu_upload_geometry", "adflow_gpu_upload_state",
     "adflow_gpu_download_state", "adflow_gpu_download_residual", "adflow_gpu_download_array",
     "adflow_gpu_upload_array", "adflow_gpu_set_options",
     "adflow_gpu_time_step", "adflow_gpu_initres", "adflow_gpu_residual", "adflow_gpu_block_res",
@@ -81,26 +81,27 @@ EXPORTS = [
     "adflow_gpu_abi_sizes",
 ]
 
-_lib: Optional[ctypes.CDLL] = None
+_libs = {}
 
 
 class AdflowGpuError(RuntimeError):
     pass
 
 
-def load() -> ctypes.CDLL:
-    """dlopen the HIP library; raises (never falls back) if it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise AdflowGpuError(f"{LIB_PATH} not built: run `python -m adflow_amd.build` (no CPU fallback exists)")
-    lib = ctypes.CDLL(LIB_PATH)
+def load(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the HIP library; raises (never falls back) if it is absent.
+    `path` is only ever passed by the test-suite (kernel-logic emulator)."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise AdflowGpuError(f"{path} not built: run `python -m adflow_amd.build` (no CPU fallback exists)")
+    lib = ctypes.CDLL(path)
     lib.adflow_gpu_last_error.restype = c_char_p
     lib.adflow_gpu_init.argtypes = [c_int]
     lib.adflow_gpu_device_name.argtypes = [c_char_p, c_int]
     lib.adflow_gpu_block_register.argtypes = [c_int, c_int, c_int, POINTER(AdflowBlockDesc)]
-    for n in ("adflow_gpu_upload_geometry", "adflow_gpu_upload_state", "adflow_gpu_download_state",
+    for n in ("adflow_gpu_block_release", "adflow_gpu_upload_geometry", "adflow_gpu_upload_state", "adflow_gpu_download_state",
               "adflow_gpu_download_residual"):
         getattr(lib, n).argtypes = [c_int, c_int, c_int]
     lib.adflow_gpu_download_array.argtypes = [c_int, c_int, c_int, c_int, c_void_p]
@@ -124,13 +125,13 @@ def load() -> ctypes.CDLL:
     lib.adflow_gpu_abi_sizes(ctypes.byref(so), ctypes.byref(sd))
     if so.value != ctypes.sizeof(AdflowOpts) or sd.value != ctypes.sizeof(AdflowBlockDesc):
         raise AdflowGpuError("ctypes mirror of adflow_opts/adflow_block_desc is out of date with include/adflow_gpu.h")
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
-def check(rc: int) -> None:
+def check(rc: int, lib: Optional[ctypes.CDLL] = None) -> None:
     if rc != 0:
-        raise AdflowGpuError(load().adflow_gpu_last_error().decode())
+        raise AdflowGpuError((lib or load()).adflow_gpu_last_error().decode())
 
 
 def opts_from_params(prm: P.FlowParams) -> AdflowOpts:

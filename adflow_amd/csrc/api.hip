@@ -320,6 +320,28 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     return 0;
 }
 
+int adflow_gpu_block_release(int nn, int level, int sps)
+{
+    auto it = g_blocks.find(Key(level, sps, nn));
+    if (it == g_blocks.end()) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (void* p : it->second->allocs) (void)hipFree(p);
+    delete it->second;
+    g_blocks.erase(it);
+    return 0;
+}
+
+int adflow_gpu_release_all(void)
+{
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (auto& kv : g_blocks) {
+        for (void* p : kv.second->allocs) (void)hipFree(p);
+        delete kv.second;
+    }
+    g_blocks.clear();
+    return 0;
+}
+
 int adflow_gpu_upload_geometry(int nn, int level, int sps)
 {
     Block* b = find_block(nn, level, sps);

@@ -17,12 +17,15 @@ from .params import FlowParams
 
 
 class Engine:
-    def __init__(self, device: int = 0):
-        self.lib = capi.load()
-        capi.check(self.lib.adflow_gpu_init(device))
+    def __init__(self, device: int = 0, _lib_path=None):
+        self.lib = capi.load(_lib_path)
+        self._chk(self.lib.adflow_gpu_init(device))
         self.blocks: Dict[Tuple[int, int, int], object] = {}
         self._descs = {}
         self.prm = None
+
+    def _chk(self, rc):
+        capi.check(rc, self.lib)
 
     # ---- lifetime ---------------------------------------------------------
     def close(self):
@@ -32,14 +35,14 @@ class Engine:
 
     def device_name(self) -> str:
         buf = ctypes.create_string_buffer(256)
-        capi.check(self.lib.adflow_gpu_device_name(buf, 256))
+        self._chk(self.lib.adflow_gpu_device_name(buf, 256))
         return buf.value.decode()
 
     # ---- data model -------------------------------------------------------
     def set_options(self, prm: FlowParams):
         self.prm = prm
         o = capi.opts_from_params(prm)
-        capi.check(self.lib.adflow_gpu_set_options(ctypes.byref(o)))
+        self._chk(self.lib.adflow_gpu_set_options(ctypes.byref(o)))
 
     def register(self, blk, nn: int = 1, level: int = 1, sps: int = 1, upload: bool = True):
         """flowDoms(nn,level,sps) <- blk ; host arrays stay owned by `blk`."""
@@ -53,66 +56,76 @@ class Engine:
         d = capi.desc_from_block(blk)
         self._descs[(nn, level, sps)] = d
         self.blocks[(nn, level, sps)] = blk
-        capi.check(self.lib.adflow_gpu_block_register(nn, level, sps, ctypes.byref(d)))
+        self._chk(self.lib.adflow_gpu_block_register(nn, level, sps, ctypes.byref(d)))
         if upload:
             self.upload_geometry(nn, level, sps)
             self.upload_state(nn, level, sps)
 
+    def release(self, nn=1, level=1, sps=1):
+        self._chk(self.lib.adflow_gpu_block_release(nn, level, sps))
+        self.blocks.pop((nn, level, sps), None)
+        self._descs.pop((nn, level, sps), None)
+
+    def release_all(self):
+        self._chk(self.lib.adflow_gpu_release_all())
+        self.blocks.clear()
+        self._descs.clear()
+
     def upload_geometry(self, nn=1, level=1, sps=1):
-        capi.check(self.lib.adflow_gpu_upload_geometry(nn, level, sps))
+        self._chk(self.lib.adflow_gpu_upload_geometry(nn, level, sps))
 
     def upload_state(self, nn=1, level=1, sps=1):
-        capi.check(self.lib.adflow_gpu_upload_state(nn, level, sps))
+        self._chk(self.lib.adflow_gpu_upload_state(nn, level, sps))
 
     def download_state(self, nn=1, level=1, sps=1):
-        capi.check(self.lib.adflow_gpu_download_state(nn, level, sps))
+        self._chk(self.lib.adflow_gpu_download_state(nn, level, sps))
 
     def download_residual(self, nn=1, level=1, sps=1):
-        capi.check(self.lib.adflow_gpu_download_residual(nn, level, sps))
+        self._chk(self.lib.adflow_gpu_download_residual(nn, level, sps))
         return self.blocks[(nn, level, sps)]["dw"]
 
     def download_array(self, which: int, out: np.ndarray, nn=1, level=1, sps=1):
         assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
-        capi.check(self.lib.adflow_gpu_download_array(nn, level, sps, which, out.ctypes.data))
+        self._chk(self.lib.adflow_gpu_download_array(nn, level, sps, which, out.ctypes.data))
         return out
 
     def upload_array(self, which: int, src: np.ndarray, nn=1, level=1, sps=1):
         assert src.flags["F_CONTIGUOUS"] and src.dtype == np.float64
-        capi.check(self.lib.adflow_gpu_upload_array(nn, level, sps, which, src.ctypes.data))
+        self._chk(self.lib.adflow_gpu_upload_array(nn, level, sps, which, src.ctypes.data))
 
     # ---- the hot path (reference shell-routine names) -----------------------
     def timeStep(self, level=1, onlyRadii=False):
-        capi.check(self.lib.adflow_gpu_time_step(level, int(onlyRadii)))
+        self._chk(self.lib.adflow_gpu_time_step(level, int(onlyRadii)))
 
     def initres(self, level, varStart, varEnd):
-        capi.check(self.lib.adflow_gpu_initres(level, varStart, varEnd))
+        self._chk(self.lib.adflow_gpu_initres(level, varStart, varEnd))
 
     def residual(self, level=1, rkStage=0):
-        capi.check(self.lib.adflow_gpu_residual(level, rkStage))
+        self._chk(self.lib.adflow_gpu_residual(level, rkStage))
 
     def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True):
         flags = (capi.RES_UPDATE_INTERMED if updateIntermed else 0) | (capi.RES_FLOW if flowRes else 0) \
             | (capi.RES_TURB if turbRes else 0)
-        capi.check(self.lib.adflow_gpu_block_res(level, flags))
+        self._chk(self.lib.adflow_gpu_block_res(level, flags))
 
     def set_async(self, on: bool):
         """Entry points only enqueue on the library stream; order with sync()."""
-        capi.check(self.lib.adflow_gpu_set_async(int(on)))
+        self._chk(self.lib.adflow_gpu_set_async(int(on)))
 
     def RungeKuttaSmoother(self, level=1):
-        capi.check(self.lib.adflow_gpu_rk_smooth(level))
+        self._chk(self.lib.adflow_gpu_rk_smooth(level))
 
     def DADISmoother(self, level=1):
-        capi.check(self.lib.adflow_gpu_dadi_smooth(level))
+        self._chk(self.lib.adflow_gpu_dadi_smooth(level))
 
     # ---- instrumentation ----------------------------------------------------
     def event_record(self, slot: int):
-        capi.check(self.lib.adflow_gpu_event_record(slot))
+        self._chk(self.lib.adflow_gpu_event_record(slot))
 
     def event_elapsed_ms(self, a: int, b: int) -> float:
         ms = ctypes.c_double()
-        capi.check(self.lib.adflow_gpu_event_elapsed_ms(a, b, ctypes.byref(ms)))
+        self._chk(self.lib.adflow_gpu_event_elapsed_ms(a, b, ctypes.byref(ms)))
         return ms.value
 
     def sync(self):
-        capi.check(self.lib.adflow_gpu_sync())
+        self._chk(self.lib.adflow_gpu_sync())

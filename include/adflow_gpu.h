@@ -124,6 +124,10 @@ int adflow_gpu_comm_init(int rank, int nranks, const void* id128); /* all ranks 
 
 /* ---- data model -------------------------------------------------------- */
 int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_desc* d);
+/* free the device mirrors of one block / of every block (utils::releaseMemoryPart1/2,
+ * src/utils/utils.F90:4253,4732); host arrays are untouched */
+int adflow_gpu_block_release(int nn, int level, int sps);
+int adflow_gpu_release_all(void);
 int adflow_gpu_upload_geometry(int nn, int level, int sps);   /* x,sI,sJ,sK,vol,volRef,d2Wall,por*,iblank */
 int adflow_gpu_upload_state(int nn, int level, int sps);      /* w,p,gamma,rlv,rev incl. both halo layers */
 int adflow_gpu_download_state(int nn, int level, int sps);

@@ -6,16 +6,37 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--hostsim", action="store_true", default=False,
+                     help="developer aid: run the -m gpu tests against the host emulation of the kernels")
+
+
 @pytest.fixture(scope="session")
-def engine():
-    """One HIP engine per test session (C-ABI of include/adflow_gpu.h)."""
+def engine(request):
+    """The HIP engine through the C-ABI of include/adflow_gpu.h (real MI355X)."""
     from adflow_amd.engine import Engine
-    eng = Engine(0)
+    if request.config.getoption("--hostsim"):
+        from hostsim.build import build
+        eng = Engine(0, _lib_path=build())
+    else:
+        eng = Engine(0)
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="session")
+def hostsim_engine():
+    """Kernel-logic emulator (tests/hostsim): the same kernel sources compiled
+    with g++; CPU-only CI coverage of the kernel arithmetic.  Never timed."""
+    from adflow_amd.engine import Engine
+    from hostsim.build import build
+    eng = Engine(0, _lib_path=build())
     yield eng
     eng.close()

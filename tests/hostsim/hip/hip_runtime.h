@@ -1,0 +1,109 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+//
+// Host emulation of the small HIP surface the kernels in adflow_amd/csrc use, so
+// that the *same kernel sources* can be compiled with g++ and exercised by the
+// CPU-only CI (`pytest -m "not gpu"`) against the oracle.  It exists to check
+// kernel LOGIC without a GPU; it is never loaded by adflow_amd (the product has
+// no CPU path and fails loudly without the HIP library) and is never timed.
+//
+// Model: one OS thread runs the blocks of a grid (OpenMP across blocks); the
+// threads of a block are ucontext fibers scheduled round-robin, so
+// __syncthreads() and the wave shuffles (which are modelled as block-convergent
+// exchanges) behave deterministically.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define __shared__ static thread_local
+#define HOSTSIM 1
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_ { unsigned x, y, z; };
+extern thread_local uint3_ threadIdx, blockIdx;
+extern thread_local dim3 blockDim, gridDim;
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef struct hostsim_event* hipEvent_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; };
+
+inline const char* hipGetErrorString(hipError_t) { return "hostsim"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    std::snprintf(p->name, 256, "hostsim (CPU emulation of the HIP kernels, test only)");
+    std::snprintf(p->gcnArchName, 256, "host");
+    p->multiProcessorCount = 0;
+    return hipSuccess;
+}
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : 1; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n); return *p ? hipSuccess : 1; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+
+namespace hostsim {
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void syncthreads();
+double shfl_exchange(double v, int srcLaneInBlock);   // block-convergent
+}  // namespace hostsim
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hostsim::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { hostsim::syncthreads(); }
+inline int hostsim_lane() { return (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)); }
+inline double __shfl(double v, int srcLane, int width = 64) {
+    const int me = hostsim_lane();
+    const int base = (me / width) * width;
+    return hostsim::shfl_exchange(v, base + (srcLane % width));
+}
+inline double __shfl_up(double v, unsigned delta, int width = 64) {
+    const int me = hostsim_lane();
+    const int l = me % width;
+    const int src = (l >= (int)delta) ? me - (int)delta : me;
+    return hostsim::shfl_exchange(v, src);
+}
+inline double __shfl_down(double v, unsigned delta, int width = 64) {
+    const int me = hostsim_lane();
+    const int l = me % width;
+    const int src = (l + (int)delta < width) ? me + (int)delta : me;
+    return hostsim::shfl_exchange(v, src);
+}
+inline double __shfl_xor(double v, int mask, int width = 64) {
+    const int me = hostsim_lane();
+    const int base = (me / width) * width;
+    return hostsim::shfl_exchange(v, base + ((me % width) ^ mask));
+}
