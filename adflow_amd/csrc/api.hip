@@ -520,6 +520,7 @@ static int enqueue_flow_residual(int level, const KParams& kp)
         if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
             return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
         launch_inviscid(b->v, kp, g_stream);
+        if (kp.viscous && fabs(kp.rFil) >= 1.e-10) launch_viscous(b->v, kp, g_stream);
         return 0;
     });
 }

@@ -71,4 +71,4 @@ struct KParams {
 void launch_time_step(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
-void launch_sum_dw_fw(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);

@@ -376,10 +376,17 @@ __global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid(BlkView b, KParams kp
 template <int SCHEME>
 static void launch_scheme(const BlkView& b, const KParams& kp, dim3 grd, dim3 blk, hipStream_t s)
 {
-    if (kp.viscous)
-        hipLaunchKernelGGL((k_inviscid<SCHEME, true, false>), grd, blk, 0, s, b, kp);
-    else
+    // the viscous kernel completes the sum unless rFil == 0 (viscousFlux returns
+    // early, fluxes.F90:2585: the stored fw already holds the viscous part)
+    const bool doDiss = fabs(kp.rFil) >= 1.e-10;
+    if (kp.viscous) {
+        if (doDiss)
+            hipLaunchKernelGGL((k_inviscid<SCHEME, true, false>), grd, blk, 0, s, b, kp);
+        else
+            hipLaunchKernelGGL((k_inviscid<SCHEME, true, true>), grd, blk, 0, s, b, kp);
+    } else {
         hipLaunchKernelGGL((k_inviscid<SCHEME, false, true>), grd, blk, 0, s, b, kp);
+    }
 }
 
 void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s)

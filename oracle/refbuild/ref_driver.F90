@@ -18,6 +18,8 @@ module ref_driver
     ! information for a steady single-section block
     integer(kind=intType), dimension(:, :, :), allocatable, target :: indFamI, indFamJ, indFamK
     integer(kind=intType), dimension(:, :, :), allocatable, target :: facFamI, facFamJ, facFamK
+    ! no viscous subfaces in the synthetic blocks: all pointers 0 (preprocessingAPI.F90:2481-2486)
+    integer(kind=intType), dimension(:, :), allocatable, target :: vIminP, vImaxP, vJminP, vJmaxP, vKminP, vKmaxP
 
 contains
 
@@ -53,6 +55,13 @@ contains
         indFamI = 0; indFamJ = 0; indFamK = 0; facFamI = 0; facFamJ = 0; facFamK = 0
         indFamilyI => indFamI; indFamilyJ => indFamJ; indFamilyK => indFamK
         factFamilyI => facFamI; factFamilyJ => facFamJ; factFamilyK => facFamK
+        if (allocated(vIminP)) deallocate (vIminP, vImaxP, vJminP, vJmaxP, vKminP, vKmaxP)
+        allocate (vIminP(2:jl, 2:kl), vImaxP(2:jl, 2:kl), vJminP(2:il, 2:kl), vJmaxP(2:il, 2:kl), &
+                  vKminP(2:il, 2:jl), vKmaxP(2:il, 2:jl))
+        vIminP = 0; vImaxP = 0; vJminP = 0; vJmaxP = 0; vKminP = 0; vKmaxP = 0
+        viscIminPointer => vIminP; viscImaxPointer => vImaxP
+        viscJminPointer => vJminP; viscJmaxPointer => vJmaxP
+        viscKminPointer => vKminP; viscKmaxPointer => vKmaxP
         if (.not. allocated(massFlowFamilyInv)) then
             allocate (massFlowFamilyInv(0:0, 1), massFlowFamilyDiss(0:0, 1))
         end if
