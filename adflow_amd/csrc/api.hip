@@ -52,6 +52,7 @@ struct Block {
     long boxsize = 0;         // ldi*(jb+1)*(kb+1)
     std::vector<void*> allocs;
     bool geom_uploaded = false;
+    bool ss_valid = false;    // entropy sensor variable matches the current state
 };
 
 typedef std::tuple<int, int, int> Key;   // (level, sps, nn): iteration order = level, sps, nn
@@ -146,6 +147,7 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.useRotationSA = o.useRotationSA;
     k.useft2SA = o.useft2SA;
     k.fineGrid = (level == o.groundLevel);
+    k.groundLevelIsOne = (o.groundLevel == 1);
     k.doScaling = (o.dirScaling && level <= o.groundLevel);
     k.coarseInit = (level != o.groundLevel);
     k.fwMode = fwMode;
@@ -401,6 +403,7 @@ int adflow_gpu_upload_state(int nn, int level, int sps)
     rc |= copy_box(b, v.rlv, d.rlv, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
     rc |= copy_box(b, v.rev, d.rev, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
     if (rc) return rc;
+    b->ss_valid = false;
     return sync_and_check();
 }
 
@@ -485,6 +488,7 @@ int adflow_gpu_upload_array(int nn, int level, int sps, int which, const double*
     double* dev; int nc, lo[3], n[3];
     if (array_spec(b, which, &dev, &nc, lo, n)) return 1;
     if (copy_box(b, dev, host, nc, lo[0], n[0], lo[1], n[1], lo[2], n[2], true)) return 1;
+    if (which == ADFLOW_ARR_W || which == ADFLOW_ARR_P || which == ADFLOW_ARR_GAMMA) b->ss_valid = false;
     return sync_and_check();
 }
 
@@ -494,7 +498,11 @@ int adflow_gpu_time_step(int level, int onlyRadii)
     if (need_ready()) return 1;
     KParams kp = make_kparams(level, 1.0, 0);
     kp.onlyRadii = onlyRadii;
-    int rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kp, g_stream); return 0; });
+    int rc = for_level(level, [&](Block* b) {
+        launch_time_step(b->v, kp, g_stream);
+        b->ss_valid = true;
+        return 0;
+    });
     if (rc) return rc;
     return sync_and_check();
 }
@@ -519,6 +527,10 @@ static int enqueue_flow_residual(int level, const KParams& kp)
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
         if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
             return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
+        if (kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && !b->ss_valid && fabs(kp.rFil) >= 1.e-10) {
+            launch_entropy(b->v, g_stream);
+            b->ss_valid = true;
+        }
         launch_inviscid(b->v, kp, g_stream);
         if (kp.viscous && fabs(kp.rFil) >= 1.e-10) launch_viscous(b->v, kp, g_stream);
         return 0;
@@ -547,8 +559,21 @@ static int block_res_enqueue(int level, unsigned flags)
     KParams kp = make_kparams(level, 1.0, 0);
     kp.onlyRadii = !(flags & ADFLOW_RES_UPDATE_INTERMED);
     kp.coarseInit = 0;
-    int rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kp, g_stream); return 0; });
+    int rc = for_level(level, [&](Block* b) {
+        launch_time_step(b->v, kp, g_stream);
+        b->ss_valid = true;
+        return 0;
+    });
     if (rc) return rc;
+    // blockResCore order: SA residual first, then the mean-flow fluxes (blockette.F90:806-851)
+    if ((flags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
+        rc = for_level(level, [&](Block* b) {
+            if (b->v.nw < 6) return fail("RANS/SA needs nw = 6 (block has %d)", b->v.nw);
+            launch_sa_residual(b->v, kp, g_stream);
+            return 0;
+        });
+        if (rc) return rc;
+    }
     if (flags & ADFLOW_RES_FLOW) {
         rc = enqueue_flow_residual(level, kp);
         if (rc) return rc;

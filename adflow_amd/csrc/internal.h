@@ -53,6 +53,7 @@ struct KParams {
     int equations, spaceDiscr, limiter, orderTurb, turbProd;
     int viscous, eddyModel, dirScaling, useQCR, useRotationSA, useft2SA;
     int fineGrid;          // currentLevel == groundLevel
+    int groundLevelIsOne;  // groundLevel == 1 (second-order turbulence advection only then)
     int doScaling;         // dirScaling && currentLevel <= groundLevel
     int onlyRadii;
     int coarseInit;        // initres: dw = wr instead of 0
@@ -69,6 +70,8 @@ struct KParams {
 
 // ---- kernel launchers (one translation unit per kernel family) -------------
 void launch_time_step(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_entropy(const BlkView& b, hipStream_t s);
 void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_sa_residual(const BlkView& b, const KParams& kp, hipStream_t s);

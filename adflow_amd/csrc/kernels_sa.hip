@@ -1,0 +1,188 @@
+// Spalart-Allmaras residual, fused per cell: source + upwind advection +
+// diffusion + scaling -> dw(:,:,:,itu1).
+//
+// Reference semantics (block path, resOnly):
+//   sa_block        src/turbulence/sa.F90:16-86
+//   saSource        src/turbulence/sa.F90:89-344
+//   turbAdvection   src/turbulence/turbUtils.F90:828-1561
+//   saViscous       src/turbulence/sa.F90:346-676
+//   saResScale      src/turbulence/sa.F90:678-715
+// The reference accumulates in scratch(idvt) over four sweeps; here the value
+// lives in a register.  Roofline: HBM; no MFMA.
+#include "internal.h"
+
+#define SA_BX 64
+#define SA_BY 4
+
+// minmod-limited fully-upwind (kappa=-1) difference, or first order
+// (turbUtils.F90:917-958 for uu>0, :1007-1047 for uu<=0)
+__device__ __forceinline__ double upwind_diff(bool secondOrd, bool positive, double wm2, double wm1, double w0, double wp1,
+                                              double wp2)
+{
+    if (positive) {
+        if (!secondOrd) return w0 - wm1;
+        const double dwtm1 = wm1 - wm2, dwt = w0 - wm1, dwtp1 = wp1 - w0;
+        double d = dwt;
+        if (dwt * dwtp1 > 0.0) d += (fabs(dwt) < fabs(dwtp1)) ? 0.5 * dwt : 0.5 * dwtp1;
+        if (dwt * dwtm1 > 0.0) d -= (fabs(dwt) < fabs(dwtm1)) ? 0.5 * dwt : 0.5 * dwtm1;
+        return d;
+    } else {
+        if (!secondOrd) return wp1 - w0;
+        const double dwtm1 = w0 - wm1, dwt = wp1 - w0, dwtp1 = wp2 - wp1;
+        double d = dwt;
+        if (dwt * dwtp1 > 0.0) d -= (fabs(dwt) < fabs(dwtp1)) ? 0.5 * dwt : 0.5 * dwtp1;
+        if (dwt * dwtm1 > 0.0) d += (fabs(dwt) < fabs(dwtm1)) ? 0.5 * dwt : 0.5 * dwtm1;
+        return d;
+    }
+}
+
+struct SaDir {   // per-direction data of one cell
+    double sm[3], sp[3];      // normals of the minus / plus face
+    double volm, volp;        // volumes of the minus / plus neighbour
+    double nt[5];             // nuTilde at -2..+2
+    double num, nup;          // laminar kinematic viscosity of the minus / plus neighbour
+};
+
+__device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const double* __restrict__ sN, SaDir& d)
+{
+    const long nb = b.nbox;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        d.sm[m] = sN[c - s + m * nb];
+        d.sp[m] = sN[c + m * nb];
+    }
+    d.volm = b.vol[c - s];
+    d.volp = b.vol[c + s];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) d.nt[m] = b.w[c + (m - 2) * s + 5 * nb];
+    d.num = b.rlv[c - s] / b.w[c - s];
+    d.nup = b.rlv[c + s] / b.w[c + s];
+}
+
+// advection in one direction (turbUtils.F90:886-1070)
+__device__ __forceinline__ double sa_advect(const SaDir& d, double vol0, double u, double v, double w, bool secondOrd)
+{
+    const double voli = 0.5 / vol0;
+    const double xa = (d.sp[0] + d.sm[0]) * voli, ya = (d.sp[1] + d.sm[1]) * voli, za = (d.sp[2] + d.sm[2]) * voli;
+    const double uu = xa * u + ya * v + za * w;
+    const double dwt = upwind_diff(secondOrd, uu > 0.0, d.nt[0], d.nt[1], d.nt[2], d.nt[3], d.nt[4]);
+    return -uu * dwt;
+}
+
+// diffusion in one direction (sa.F90:385-450)
+__device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double nu, double cb2, double cb3Inv)
+{
+    const double voli = 1.0 / vol0;
+    const double volmi = 2.0 / (vol0 + d.volm), volpi = 2.0 / (vol0 + d.volp);
+    const double xm = d.sm[0] * volmi, ym = d.sm[1] * volmi, zm = d.sm[2] * volmi;
+    const double xp = d.sp[0] * volpi, yp = d.sp[1] * volpi, zp = d.sp[2] * volpi;
+    const double xa = 0.5 * (d.sp[0] + d.sm[0]) * voli, ya = 0.5 * (d.sp[1] + d.sm[1]) * voli,
+                 za = 0.5 * (d.sp[2] + d.sm[2]) * voli;
+    const double ttm = xm * xa + ym * ya + zm * za;
+    const double ttp = xp * xa + yp * ya + zp * za;
+    const double cnud = -cb2 * d.nt[2] * cb3Inv;
+    const double cam = ttm * cnud, cap = ttp * cnud;
+    const double nutm = 0.5 * (d.nt[1] + d.nt[2]), nutp = 0.5 * (d.nt[3] + d.nt[2]);
+    const double num = 0.5 * (d.num + nu), nup = 0.5 * (d.nup + nu);
+    const double cdm = (num + (1.0 + cb2) * nutm) * ttm * cb3Inv;
+    const double cdp = (nup + (1.0 + cb2) * nutp) * ttp * cb3Inv;
+    const double c1m = fmax(cdm + cam, 0.0), c1p = fmax(cdp + cap, 0.0);
+    const double c10 = c1m + c1p;
+    return c1m * d.nt[1] - c10 * d.nt[2] + c1p * d.nt[3];
+}
+
+__global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(BlkView b, KParams kp)
+{
+    const int i = blockIdx.x * SA_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SA_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+
+    SaDir di, dj, dk;
+    load_dir(b, c, si, b.sI, di);
+    load_dir(b, c, sj, b.sJ, dj);
+    load_dir(b, c, sk, b.sK, dk);
+
+    const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    const double nut = dk.nt[2];
+    const double vol0 = b.vol[c];
+
+    // ---- source (sa.F90:133-300): velocity gradient * 2 vol from the six neighbours
+    double gu[3][3];   // gu[comp][xyz]
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const long off = (m + 1) * nb;
+        const double qip = b.w[c + si + off], qim = b.w[c - si + off];
+        const double qjp = b.w[c + sj + off], qjm = b.w[c - sj + off];
+        const double qkp = b.w[c + sk + off], qkm = b.w[c - sk + off];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            gu[m][d] = qip * di.sp[d] - qim * di.sm[d] + qjp * dj.sp[d] - qjm * dj.sm[d] + qkp * dk.sp[d] - qkm * dk.sm[d];
+    }
+    const double fact = 0.25 / vol0;
+    double ss, strainMag2 = 0.0;
+    if (kp.turbProd == ADFLOW_TURBPROD_STRAIN) {
+        const double sxx = 2.0 * fact * gu[0][0], syy = 2.0 * fact * gu[1][1], szz = 2.0 * fact * gu[2][2];
+        const double sxy = fact * (gu[0][1] + gu[1][0]), sxz = fact * (gu[0][2] + gu[2][0]), syz = fact * (gu[1][2] + gu[2][1]);
+        const double tr = sxx + syy + szz;
+        const double div2 = (2.0 * (1.0 / 3.0)) * (tr * tr);
+        strainMag2 = 2.0 * (sxy * sxy + sxz * sxz + syz * syz) + sxx * sxx + syy * syy + szz * szz;
+        ss = sqrt(2.0 * strainMag2 - div2);
+    } else {
+        const double vortx = 2.0 * fact * (gu[2][1] - gu[1][2]);   // wheel speed omega = 0 (non-rotating sections)
+        const double vorty = 2.0 * fact * (gu[0][2] - gu[2][0]);
+        const double vortz = 2.0 * fact * (gu[1][0] - gu[0][1]);
+        ss = sqrt(vortx * vortx + vorty * vorty + vortz * vortz);
+    }
+    const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
+    const double kar2Inv = 1.0 / (kp.sa_k * kp.sa_k);
+    const double cw3_2 = kp.sa_cw3 * kp.sa_cw3;
+    const double cw36 = cw3_2 * cw3_2 * cw3_2;
+    const double cb3Inv = 1.0 / kp.sa_cb3;
+    const double nu = b.rlv[c] / rho;
+    const double d2 = b.d2wall[c];
+    const double dist2Inv = 1.0 / (d2 * d2);
+    const double chi = nut / nu;
+    const double chi2 = chi * chi, chi3 = chi * chi2;
+    const double fv1 = chi3 / (chi3 + cv13);
+    const double fv2 = 1.0 - chi / (1.0 + chi * fv1);
+    const double ft2 = kp.useft2SA ? kp.sa_ct3 * exp(-kp.sa_ct4 * chi2) : 0.0;
+    double sst = ss + nut * fv2 * kar2Inv * dist2Inv;
+    if (kp.useRotationSA) sst = sst + kp.sa_crot * fmin(0.0, sqrt(2.0 * strainMag2));
+    sst = fmax(sst, 1.e-10);
+    double rr = nut * kar2Inv * dist2Inv / sst;
+    rr = fmin(rr, 10.0);
+    const double rr2 = rr * rr;
+    const double gg = rr + kp.sa_cw2 * (rr2 * rr2 * rr2 - rr);
+    const double gg2 = gg * gg;
+    const double gg6 = gg2 * gg2 * gg2;
+    const double termFw = pow((1.0 + cw36) / (gg6 + cw36), 1.0 / 6.0);
+    const double fwSa = gg * termFw;
+    const double term1 = kp.sa_cb1 * (1.0 - ft2) * ss;
+    const double term2 = dist2Inv * (kar2Inv * kp.sa_cb1 * ((1.0 - ft2) * fv2 + ft2) - kp.sa_cw1 * fwSa);
+    double dvt = (term1 + term2 * nut) * nut;
+
+    // ---- advection, sweeps k, j, i (turbUtils.F90:886, 1118, 1349)
+    const bool secondOrd = (kp.orderTurb == 2) && kp.groundLevelIsOne;
+    dvt += sa_advect(dk, vol0, u, v, w, secondOrd);
+    dvt += sa_advect(dj, vol0, u, v, w, secondOrd);
+    dvt += sa_advect(di, vol0, u, v, w, secondOrd);
+
+    // ---- diffusion, sweeps k, j, i (sa.F90:371, 473, 572)
+    dvt += sa_diffuse(dk, vol0, nu, kp.sa_cb2, cb3Inv);
+    dvt += sa_diffuse(dj, vol0, nu, kp.sa_cb2, cb3Inv);
+    dvt += sa_diffuse(di, vol0, nu, kp.sa_cb2, cb3Inv);
+
+    // ---- scale (sa.F90:702-706)
+    b.dw[c + 5 * nb] = -b.volRef[c] * dvt * flg_blank(b.flags[c]);
+}
+
+void launch_sa_residual(const BlkView& b, const KParams& kp, hipStream_t s)
+{
+    dim3 blk(SA_BX, SA_BY, 1);
+    dim3 grd((b.nx + SA_BX - 1) / SA_BX, (b.ny + SA_BY - 1) / SA_BY, b.nz);
+    hipLaunchKernelGGL(k_sa_residual, grd, blk, 0, s, b, kp);
+}

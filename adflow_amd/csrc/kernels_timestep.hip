@@ -103,6 +103,25 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(BlkView b, KParams k
     b.dtl[c] = dt;
 }
 
+// JST entropy sensor variable alone, all cells 0..ib (fluxes.F90:1126-1136):
+// used when the state changed since the last time-step pass.
+__global__ __launch_bounds__(TS_BX* TS_BY) void k_entropy(BlkView b)
+{
+    const int i = blockIdx.x * TS_BX + threadIdx.x + (2 - 16);
+    const int j = blockIdx.y * TS_BY + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i < 0 || i > b.ib || j > b.jb) return;
+    const long c = b.idx(i, j, k);
+    b.ss[c] = b.p[c] / pow(b.w[c], b.gamma[c]);
+}
+
+void launch_entropy(const BlkView& b, hipStream_t s)
+{
+    dim3 blk(TS_BX, TS_BY, 1);
+    dim3 grd((b.ib + 1 + 14 + TS_BX - 1) / TS_BX, (b.jb + 1 + TS_BY - 1) / TS_BY, b.kb + 1);
+    hipLaunchKernelGGL(k_entropy, grd, blk, 0, s, b);
+}
+
 void launch_time_step(const BlkView& b, const KParams& kp, hipStream_t s)
 {
     dim3 blk(TS_BX, TS_BY, 1);

@@ -39,6 +39,7 @@ contains
         use blockPointers
         use flowVarRefState, only: nw, nwf, nwt, nt1, nt2, wInf
         use cgnsGrid, only: massFlowFamilyInv, massFlowFamilyDiss
+        use section, only: sections, nSections
         integer(c_int), value :: nx_, ny_, nz_, nw_, nwf_
         nx = nx_; ny = ny_; nz = nz_
         il = nx + 1; jl = ny + 1; kl = nz + 1
@@ -68,6 +69,14 @@ contains
         massFlowFamilyInv = zero; massFlowFamilyDiss = zero
         if (.not. allocated(wInf)) then
             allocate (wInf(10)); wInf = zero
+        end if
+        if (.not. allocated(sections)) then
+            ! one steady, non-rotating, non-periodic section
+            nSections = 1
+            allocate (sections(1))
+            sections(1)%periodic = .false.; sections(1)%rotating = .false.; sections(1)%nSlices = 1
+            sections(1)%timePeriod = one; sections(1)%rotCenter = zero; sections(1)%translation = zero
+            sections(1)%rotAxis = zero; sections(1)%rotRate = zero; sections(1)%rotMatrix = zero
         end if
     end subroutine ref_set_dims
 

@@ -1,0 +1,41 @@
+"""GPU parity (real MI355X, through the C-ABI): laminar NS and RANS-SA residuals —
+nodal gradients, viscous flux, SA source/advection/diffusion — against the
+reference's own Fortran (oracle/_ref).  BASELINE configs 3-4 parity sizes."""
+import pytest
+
+import checks
+from adflow_amd.params import (FlowParams, dissScalar, dissMatrix, upwind, NSEquations, RANSEquations, secondOrder,
+                               vorticity)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dims", [(16, 12, 8), (5, 3, 2)])
+def test_laminar_ns(engine, dims):
+    checks.check_block_res(engine, dims, FlowParams(equations=NSEquations), seed=4, stretch_k=2.0)
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_rans_sa_crm_parity_size(engine, sd):
+    # BASELINE config 4 parity size: 24x20x10 blocks, 4a upwind / 4b matrix
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156)
+    checks.check_block_res(engine, (24, 20, 10), prm, seed=sd, stretch_k=3.0)
+
+
+def test_rans_sa_tutorial_wing_parity_size(engine):
+    # BASELINE config 3 parity size: 24 192 cells
+    checks.check_block_res(engine, (48, 28, 18), FlowParams(equations=RANSEquations), seed=11, stretch_k=3.0)
+
+
+def test_rans_sa_options(engine):
+    prm = FlowParams(equations=RANSEquations, orderTurb=secondOrder, turbProd=vorticity, useQCR=True, useft2SA=False)
+    checks.check_block_res(engine, (17, 9, 5), prm, seed=8, stretch_k=2.0)
+
+
+def test_ns_rk_stage_residuals(engine):
+    checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations), stretch_k=2.0)
+
+
+def test_rans_full_size_block_vs_reference(engine):
+    """BASELINE config 3 roofline-size block (128x128x96) against the reference itself."""
+    checks.check_block_res(engine, (128, 128, 96), FlowParams(equations=RANSEquations), seed=5, stretch_k=3.0)

@@ -5,7 +5,8 @@ and indexing without a GPU; the -m gpu suite repeats the checks on the MI355X.""
 import pytest
 
 import checks
-from adflow_amd.params import (FlowParams, dissScalar, dissMatrix, upwind, noLimiter, vanAlbeda, minmod)
+from adflow_amd.params import (FlowParams, dissScalar, dissMatrix, upwind, noLimiter, vanAlbeda, minmod, NSEquations,
+                               RANSEquations, secondOrder, vorticity)
 from oracle import ref
 
 pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
@@ -33,3 +34,22 @@ def test_wall_porosity(hostsim_engine):
 @pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
 def test_rk_stage_residuals(hostsim_engine, sd):
     checks.check_rk_residual_sequence(hostsim_engine, (10, 8, 6), FlowParams(spaceDiscr=sd))
+
+
+def test_laminar_ns(hostsim_engine):
+    checks.check_block_res(hostsim_engine, (8, 6, 5), FlowParams(equations=NSEquations), seed=4, stretch_k=2.0)
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_rans_sa(hostsim_engine, sd):
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156)
+    checks.check_block_res(hostsim_engine, (10, 8, 6), prm, seed=sd, stretch_k=2.5)
+
+
+def test_rans_sa_options(hostsim_engine):
+    prm = FlowParams(equations=RANSEquations, orderTurb=secondOrder, turbProd=vorticity, useQCR=True, useft2SA=False)
+    checks.check_block_res(hostsim_engine, (7, 9, 5), prm, seed=8, stretch_k=2.0)
+
+
+def test_rans_rk_stage_residuals(hostsim_engine):
+    checks.check_rk_residual_sequence(hostsim_engine, (8, 6, 5), FlowParams(equations=NSEquations), stretch_k=2.0)
