@@ -63,6 +63,19 @@ class AdflowBlockDesc(ctypes.Structure):
     ]
 
 
+class AdflowCommPattern(ctypes.Structure):
+    _fields_ = [
+        ("ncopy", c_int32),
+        ("donorBlock", c_void_p), ("donorIndices", c_void_p), ("haloBlock", c_void_p), ("haloIndices", c_void_p),
+        ("nProcSend", c_int32), ("sendProc", c_void_p), ("nsendCum", c_void_p), ("sendBlock", c_void_p),
+        ("sendIndices", c_void_p),
+        ("nProcRecv", c_int32), ("recvProc", c_void_p), ("nrecvCum", c_void_p), ("recvBlock", c_void_p),
+        ("recvIndices", c_void_p),
+    ]
+
+
+BC_CALLBACK = ctypes.CFUNCTYPE(None, c_int, c_int)
+
 # array identifiers (include/adflow_gpu.h)
 (ARR_W, ARR_P, ARR_GAMMA, ARR_RLV, ARR_REV, ARR_DW, ARR_FW, ARR_DTL, ARR_RADI, ARR_RADJ, ARR_RADK, ARR_AA,
  ARR_NODAL_GRADS, ARR_WN, ARR_PN, ARR_W1, ARR_P1, ARR_WR, ARR_VOL, ARR_SI, ARR_SJ, ARR_SK) = range(1, 23)
@@ -77,6 +90,8 @@ EXPORTS = [
     "adflow_gpu_upload_array", "adflow_gpu_set_options",
     "adflow_gpu_time_step", "adflow_gpu_initres", "adflow_gpu_residual", "adflow_gpu_block_res",
     "adflow_gpu_rk_smooth", "adflow_gpu_dadi_smooth", "adflow_gpu_halo_exchange", "adflow_gpu_res_norms",
+    "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
+    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes",
 ]
@@ -117,6 +132,12 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_dadi_smooth.argtypes = [c_int]
     lib.adflow_gpu_halo_exchange.argtypes = [c_int] * 6
     lib.adflow_gpu_res_norms.argtypes = [c_int, c_void_p, c_int]
+    lib.adflow_gpu_comm_register.argtypes = [c_int, c_int, POINTER(AdflowCommPattern)]
+    lib.adflow_gpu_halo_slot_info.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]
+    lib.adflow_gpu_halo_pack.argtypes = [c_int] * 7 + [c_void_p]
+    lib.adflow_gpu_halo_unpack.argtypes = [c_int] * 7 + [c_void_p]
+    lib.adflow_gpu_halo_local_copy.argtypes = [c_int] * 6
+    lib.adflow_gpu_set_bc_callback.argtypes = [c_void_p]
     lib.adflow_gpu_comm_unique_id.argtypes = [c_void_p]
     lib.adflow_gpu_comm_init.argtypes = [c_int, c_int, c_void_p]
     lib.adflow_gpu_event_record.argtypes = [c_int]
@@ -163,3 +184,17 @@ def desc_from_block(blk) -> AdflowBlockDesc:
                  "porI", "porJ", "porK", "iblank", "dw", "fw", "dtl", "radI", "radJ", "radK", "w1", "p1", "wr"):
         setattr(d, name, _ptr(blk.a.get(name)))
     return d
+
+
+def comm_pattern_struct(cp) -> AdflowCommPattern:
+    """adflow_amd.topology.CommPattern -> C struct (arrays must outlive the call)."""
+    c = AdflowCommPattern()
+    c.ncopy = cp.ncopy
+    for n in ("donorBlock", "donorIndices", "haloBlock", "haloIndices", "sendProc", "nsendCum", "sendBlock",
+              "sendIndices", "recvProc", "nrecvCum", "recvBlock", "recvIndices"):
+        a = getattr(cp, n)
+        assert a.dtype == np.int32 and (a.ndim == 1 or a.flags["F_CONTIGUOUS"]), n
+        setattr(c, n, a.ctypes.data if a.size else None)
+    c.nProcSend = int(cp.sendProc.size)
+    c.nProcRecv = int(cp.recvProc.size)
+    return c

@@ -2,6 +2,7 @@
 // host<->device transfers and the launch sequences of the hot path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -57,6 +58,60 @@ struct Block {
 
 typedef std::tuple<int, int, int> Key;   // (level, sps, nn): iteration order = level, sps, nn
 std::map<Key, Block*> g_blocks;
+
+struct CommList {          // device index lists of one message / of the local copies
+    int n = 0;
+    int *blkA = nullptr, *blkB = nullptr;     // donor/halo block slots (pack/unpack use blkA only)
+    long *offA = nullptr, *offB = nullptr;
+    int peer = -1;
+    double* buf = nullptr;                    // device message buffer (11 variables max)
+};
+
+struct CommPattern {
+    bool present = false;
+    CommList local;
+    std::vector<CommList> sends, recvs;
+    // host copies of the index triples until the block table is known
+    std::vector<int32_t> h_donorBlock, h_donorIdx, h_haloBlock, h_haloIdx;
+    std::vector<int32_t> h_sendProc, h_nsendCum, h_sendBlock, h_sendIdx;
+    std::vector<int32_t> h_recvProc, h_nrecvCum, h_recvBlock, h_recvIdx;
+    bool built = false;
+};
+
+std::map<std::pair<int, int>, CommPattern> g_comm;   // (level, nLayers)
+std::map<int, BlkView*> g_tab;                        // level -> device table indexed by nn
+std::map<int, int> g_tab_size;
+adflow_bc_callback g_bc_callback = nullptr;
+double* g_norm_dev = nullptr;
+
+void free_list(CommList& l)
+{
+    if (l.blkA) (void)hipFree(l.blkA);
+    if (l.blkB) (void)hipFree(l.blkB);
+    if (l.offA) (void)hipFree(l.offA);
+    if (l.offB) (void)hipFree(l.offB);
+    if (l.buf) (void)hipFree(l.buf);
+    l = CommList();
+}
+
+void invalidate_comm_level(int level)
+{
+    for (auto& kv : g_comm)
+        if (kv.first.first == level) {
+            free_list(kv.second.local);
+            for (auto& l : kv.second.sends) free_list(l);
+            for (auto& l : kv.second.recvs) free_list(l);
+            kv.second.sends.clear();
+            kv.second.recvs.clear();
+            kv.second.built = false;
+        }
+    auto it = g_tab.find(level);
+    if (it != g_tab.end()) {
+        (void)hipFree(it->second);
+        g_tab.erase(it);
+    }
+}
+
 
 Block* find_block(int nn, int level, int sps)
 {
@@ -151,11 +206,12 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.doScaling = (o.dirScaling && level <= o.groundLevel);
     k.coarseInit = (level != o.groundLevel);
     k.fwMode = fwMode;
+    k.updateEddy = (level <= o.groundLevel);
     k.rFil = rFil;
     k.sfil = 1.0 - rFil;
     k.vis2 = o.vis2; k.vis4 = o.vis4; k.vis2Coarse = o.vis2Coarse; k.adis = o.adis;
     k.acousticScaleFactor = o.acousticScaleFactor; k.kappaCoef = o.kappaCoef;
-    k.gammaConstant = o.gammaConstant; k.gammaInf = o.gammaInf; k.pInfCorr = o.pInfCorr; k.rhoInf = o.rhoInf; k.RGas = o.RGas;
+    k.gammaConstant = o.gammaConstant; k.gammaInf = o.gammaInf; k.pInf = o.pInf; k.pInfCorr = o.pInfCorr; k.rhoInf = o.rhoInf; k.RGas = o.RGas;
     k.muRef = o.muRef; k.TRef = o.TRef; k.timeRef = o.timeRef;
     k.prandtl = o.prandtl; k.prandtlTurb = o.prandtlTurb;
     k.SSuthDim = o.SSuthDim; k.muSuthDim = o.muSuthDim; k.TSuthDim = o.TSuthDim;
@@ -319,6 +375,7 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     }
     HIPCHK(hipStreamSynchronize(g_stream));
     g_blocks[Key(level, sps, nn)] = b;
+    invalidate_comm_level(level);
     return 0;
 }
 
@@ -330,6 +387,7 @@ int adflow_gpu_block_release(int nn, int level, int sps)
     for (void* p : it->second->allocs) (void)hipFree(p);
     delete it->second;
     g_blocks.erase(it);
+    invalidate_comm_level(level);
     return 0;
 }
 
@@ -341,6 +399,12 @@ int adflow_gpu_release_all(void)
         delete kv.second;
     }
     g_blocks.clear();
+    {
+        std::vector<int> levels;
+        for (auto& kv : g_tab) levels.push_back(kv.first);
+        for (int l : levels) invalidate_comm_level(l);
+        g_comm.clear();
+    }
     return 0;
 }
 
@@ -588,12 +652,400 @@ int adflow_gpu_block_res(int level, unsigned flags)
     return sync_and_check();
 }
 
-int adflow_gpu_rk_smooth(int) { return fail("adflow_gpu_rk_smooth: not implemented yet"); }
-int adflow_gpu_dadi_smooth(int) { return fail("adflow_gpu_dadi_smooth: not implemented yet"); }
-int adflow_gpu_halo_exchange(int, int, int, int, int, int) { return fail("adflow_gpu_halo_exchange: not implemented yet"); }
-int adflow_gpu_res_norms(int, double*, int) { return fail("adflow_gpu_res_norms: not implemented yet"); }
-int adflow_gpu_comm_unique_id(void*) { return fail("adflow_gpu_comm_unique_id: not implemented yet"); }
-int adflow_gpu_comm_init(int, int, const void*) { return fail("adflow_gpu_comm_init: not implemented yet"); }
+}  // extern "C"
+
+// ------------------------------------------------------------ halo exchange
+namespace {
+
+int ensure_table(int level)
+{
+    if (g_tab.count(level)) return 0;
+    int maxnn = 0;
+    for (auto& kv : g_blocks)
+        if (std::get<0>(kv.first) == level) maxnn = std::max(maxnn, std::get<2>(kv.first));
+    if (maxnn == 0) return fail("no block registered on level %d", level);
+    std::vector<BlkView> h(maxnn + 1);
+    memset(h.data(), 0, sizeof(BlkView) * h.size());
+    for (auto& kv : g_blocks)
+        if (std::get<0>(kv.first) == level && std::get<1>(kv.first) == 1) h[std::get<2>(kv.first)] = kv.second->v;
+    BlkView* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(BlkView) * h.size()));
+    HIPCHK(hipMemcpy(d, h.data(), sizeof(BlkView) * h.size(), hipMemcpyHostToDevice));
+    g_tab[level] = d;
+    g_tab_size[level] = maxnn;
+    return 0;
+}
+
+int make_list(int level, const int32_t* blk, const int32_t* idx, int ld, int first, int n, int** d_blk, long** d_off)
+{
+    std::vector<int> hb(n);
+    std::vector<long> ho(n);
+    for (int t = 0; t < n; ++t) {
+        const int nn = blk[first + t];
+        Block* b = find_block(nn, level, 1);
+        if (!b) return fail("comm pattern of level %d references unregistered block %d", level, nn);
+        const int i = idx[first + t], j = idx[ld + first + t], k = idx[2 * ld + first + t];
+        if (i < 0 || i > b->v.ib || j < 0 || j > b->v.jb || k < 0 || k > b->v.kb)
+            return fail("comm pattern of level %d: cell (%d,%d,%d) outside block %d", level, i, j, k, nn);
+        hb[t] = nn;
+        ho[t] = b->v.idx(i, j, k);
+    }
+    *d_blk = nullptr;
+    *d_off = nullptr;
+    if (n == 0) return 0;
+    HIPCHK(hipMalloc((void**)d_blk, sizeof(int) * n));
+    HIPCHK(hipMalloc((void**)d_off, sizeof(long) * n));
+    HIPCHK(hipMemcpy(*d_blk, hb.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*d_off, ho.data(), sizeof(long) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int build_comm(int level, int nLayers, CommPattern** out)
+{
+    auto it = g_comm.find(std::make_pair(level, nLayers));
+    if (it == g_comm.end()) return fail("no %d-layer comm pattern registered for level %d", nLayers, level);
+    CommPattern& cp = it->second;
+    *out = &cp;
+    if (ensure_table(level)) return 1;
+    if (cp.built) return 0;
+    const int nc = (int)cp.h_donorBlock.size();
+    cp.local.n = nc;
+    if (make_list(level, cp.h_donorBlock.data(), cp.h_donorIdx.data(), nc, 0, nc, &cp.local.blkA, &cp.local.offA)) return 1;
+    if (make_list(level, cp.h_haloBlock.data(), cp.h_haloIdx.data(), nc, 0, nc, &cp.local.blkB, &cp.local.offB)) return 1;
+    const int ns = (int)cp.h_sendProc.size(), nr = (int)cp.h_recvProc.size();
+    const int nst = ns ? cp.h_nsendCum[ns] : 0, nrt = nr ? cp.h_nrecvCum[nr] : 0;
+    cp.sends.resize(ns);
+    cp.recvs.resize(nr);
+    for (int i = 0; i < ns; ++i) {
+        CommList& l = cp.sends[i];
+        l.peer = cp.h_sendProc[i];
+        l.n = cp.h_nsendCum[i + 1] - cp.h_nsendCum[i];
+        if (make_list(level, cp.h_sendBlock.data(), cp.h_sendIdx.data(), nst, cp.h_nsendCum[i], l.n, &l.blkA, &l.offA)) return 1;
+        HIPCHK(hipMalloc((void**)&l.buf, sizeof(double) * 11 * (size_t)std::max(l.n, 1)));
+    }
+    for (int i = 0; i < nr; ++i) {
+        CommList& l = cp.recvs[i];
+        l.peer = cp.h_recvProc[i];
+        l.n = cp.h_nrecvCum[i + 1] - cp.h_nrecvCum[i];
+        if (make_list(level, cp.h_recvBlock.data(), cp.h_recvIdx.data(), nrt, cp.h_nrecvCum[i], l.n, &l.blkA, &l.offA)) return 1;
+        HIPCHK(hipMalloc((void**)&l.buf, sizeof(double) * 11 * (size_t)std::max(l.n, 1)));
+    }
+    cp.built = true;
+    return 0;
+}
+
+// setCommPointers (haloExchange.F90:392-415): which variables travel
+int halo_mask(int varStart, int varEnd, int commPressure, int commVisc, unsigned* mask, int* nvar)
+{
+    if (varStart < 1 || varEnd > 6) return fail("halo exchange: variable range %d..%d outside 1..6", varStart, varEnd);
+    unsigned m = 0;
+    int n = 0;
+    for (int l = varStart; l <= varEnd; ++l) { m |= 1u << (l - 1); ++n; }
+    if (commPressure) { m |= 1u << 8; ++n; }
+    const bool visc = (g_opts.equations == ADFLOW_NS || g_opts.equations == ADFLOW_RANS);
+    if (visc && commVisc) { m |= 1u << 9; ++n; }
+    if (g_opts.equations == ADFLOW_RANS && commVisc) { m |= 1u << 10; ++n; }
+    *mask = m;
+    *nvar = n;
+    return 0;
+}
+
+}  // namespace
+
+#ifndef ADFLOW_NO_RCCL
+#include <rccl/rccl.h>
+namespace {
+ncclComm_t g_nccl = nullptr;
+int g_rank = 0, g_nranks = 1;
+}
+#define NCCLCHK(expr)                                                                          \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess) return fail("%s failed: %s", #expr, ncclGetErrorString(r_));    \
+    } while (0)
+#endif
+
+extern "C" {
+
+int adflow_gpu_set_bc_callback(adflow_bc_callback fn)
+{
+    g_bc_callback = fn;
+    return 0;
+}
+
+int adflow_gpu_comm_unique_id(void* id128)
+{
+#ifndef ADFLOW_NO_RCCL
+    if (!id128) return fail("null id buffer");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return 0;
+#else
+    (void)id128;
+    return fail("built without RCCL");
+#endif
+}
+
+int adflow_gpu_comm_init(int rank, int nranks, const void* id128)
+{
+#ifndef ADFLOW_NO_RCCL
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    if (!id128) return fail("null id buffer");
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCLCHK(ncclCommInitRank(&g_nccl, nranks, id, rank));
+    g_rank = rank;
+    g_nranks = nranks;
+    return 0;
+#else
+    (void)rank; (void)nranks; (void)id128;
+    return fail("built without RCCL");
+#endif
+}
+
+int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* p)
+{
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    if (!p) return fail("null comm pattern");
+    if (nLayers != 1 && nLayers != 2) return fail("nLayers must be 1 or 2");
+    auto key = std::make_pair(level, nLayers);
+    if (g_comm.count(key)) {
+        CommPattern& old = g_comm[key];
+        free_list(old.local);
+        for (auto& l : old.sends) free_list(l);
+        for (auto& l : old.recvs) free_list(l);
+    }
+    CommPattern cp;
+    cp.present = true;
+    const int nc = p->ncopy;
+    if (nc < 0 || p->nProcSend < 0 || p->nProcRecv < 0) return fail("negative count in comm pattern");
+    if (nc > 0) {
+        cp.h_donorBlock.assign(p->donorBlock, p->donorBlock + nc);
+        cp.h_haloBlock.assign(p->haloBlock, p->haloBlock + nc);
+        cp.h_donorIdx.assign(p->donorIndices, p->donorIndices + 3 * (size_t)nc);
+        cp.h_haloIdx.assign(p->haloIndices, p->haloIndices + 3 * (size_t)nc);
+    }
+    if (p->nProcSend > 0) {
+        cp.h_sendProc.assign(p->sendProc, p->sendProc + p->nProcSend);
+        cp.h_nsendCum.assign(p->nsendCum, p->nsendCum + p->nProcSend + 1);
+        const int nt = cp.h_nsendCum[p->nProcSend];
+        cp.h_sendBlock.assign(p->sendBlock, p->sendBlock + nt);
+        cp.h_sendIdx.assign(p->sendIndices, p->sendIndices + 3 * (size_t)nt);
+    }
+    if (p->nProcRecv > 0) {
+        cp.h_recvProc.assign(p->recvProc, p->recvProc + p->nProcRecv);
+        cp.h_nrecvCum.assign(p->nrecvCum, p->nrecvCum + p->nProcRecv + 1);
+        const int nt = cp.h_nrecvCum[p->nProcRecv];
+        cp.h_recvBlock.assign(p->recvBlock, p->recvBlock + nt);
+        cp.h_recvIdx.assign(p->recvIndices, p->recvIndices + 3 * (size_t)nt);
+    }
+    g_comm[key] = cp;
+    return 0;
+}
+
+int adflow_gpu_halo_local_copy(int level, int nLayers, int varStart, int varEnd, int commPressure, int commVisc)
+{
+    if (need_ready()) return 1;
+    CommPattern* cp;
+    if (build_comm(level, nLayers, &cp)) return 1;
+    unsigned mask; int nvar;
+    if (halo_mask(varStart, varEnd, commPressure, commVisc, &mask, &nvar)) return 1;
+    launch_halo_copy(g_tab[level], cp->local.blkA, cp->local.offA, cp->local.blkB, cp->local.offB, cp->local.n, mask, g_stream);
+    for_level(level, [&](Block* b) { b->ss_valid = false; return 0; });
+    return sync_and_check();
+}
+
+int adflow_gpu_halo_slot_info(int level, int nLayers, int isSend, int islot, int* peer, int* count)
+{
+    CommPattern* cp;
+    if (build_comm(level, nLayers, &cp)) return 1;
+    std::vector<CommList>& v = isSend ? cp->sends : cp->recvs;
+    if (islot < 0 || islot >= (int)v.size()) {
+        if (peer) *peer = -1;
+        if (count) *count = 0;
+        return 0;   // past the last slot: count 0
+    }
+    if (peer) *peer = v[islot].peer;
+    if (count) *count = v[islot].n;
+    return 0;
+}
+
+int adflow_gpu_halo_pack(int level, int nLayers, int islot, int varStart, int varEnd, int commPressure, int commVisc, double* buf)
+{
+    if (need_ready()) return 1;
+    CommPattern* cp;
+    if (build_comm(level, nLayers, &cp)) return 1;
+    if (islot < 0 || islot >= (int)cp->sends.size()) return fail("send slot %d out of range", islot);
+    unsigned mask; int nvar;
+    if (halo_mask(varStart, varEnd, commPressure, commVisc, &mask, &nvar)) return 1;
+    CommList& l = cp->sends[islot];
+    launch_halo_pack(g_tab[level], l.blkA, l.offA, l.n, mask, l.buf, g_stream);
+    HIPCHK(hipMemcpyAsync(buf, l.buf, sizeof(double) * (size_t)nvar * l.n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+int adflow_gpu_halo_unpack(int level, int nLayers, int islot, int varStart, int varEnd, int commPressure, int commVisc,
+                           const double* buf)
+{
+    if (need_ready()) return 1;
+    CommPattern* cp;
+    if (build_comm(level, nLayers, &cp)) return 1;
+    if (islot < 0 || islot >= (int)cp->recvs.size()) return fail("recv slot %d out of range", islot);
+    unsigned mask; int nvar;
+    if (halo_mask(varStart, varEnd, commPressure, commVisc, &mask, &nvar)) return 1;
+    CommList& l = cp->recvs[islot];
+    HIPCHK(hipMemcpyAsync(l.buf, buf, sizeof(double) * (size_t)nvar * l.n, hipMemcpyHostToDevice, g_stream));
+    launch_halo_unpack(g_tab[level], l.blkA, l.offA, l.n, mask, l.buf, g_stream);
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for_level(level, [&](Block* b) { b->ss_valid = false; return 0; });
+    return 0;
+}
+
+static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers)
+{
+    CommPattern* cp;
+    if (build_comm(level, nLayers, &cp)) return 1;
+    unsigned mask; int nvar;
+    if (halo_mask(varStart, varEnd, commPressure, commVisc, &mask, &nvar)) return 1;
+    if (nvar == 0) return 0;
+    BlkView* tab = g_tab[level];
+    // pack every outgoing message, then one grouped RCCL send/recv over xGMI,
+    // with the same-GPU copies enqueued behind the packs (they only read owned cells)
+    for (auto& l : cp->sends) launch_halo_pack(tab, l.blkA, l.offA, l.n, mask, l.buf, g_stream);
+    if (!cp->sends.empty() || !cp->recvs.empty()) {
+#ifndef ADFLOW_NO_RCCL
+        if (!g_nccl) return fail("halo exchange needs other ranks but adflow_gpu_comm_init was not called");
+        NCCLCHK(ncclGroupStart());
+        for (auto& l : cp->sends)
+            if (l.n > 0) NCCLCHK(ncclSend(l.buf, (size_t)nvar * l.n, ncclDouble, l.peer, g_nccl, g_stream));
+        for (auto& l : cp->recvs)
+            if (l.n > 0) NCCLCHK(ncclRecv(l.buf, (size_t)nvar * l.n, ncclDouble, l.peer, g_nccl, g_stream));
+        NCCLCHK(ncclGroupEnd());
+#else
+        return fail("built without RCCL: use adflow_gpu_halo_pack/unpack with an external transport");
+#endif
+    }
+    launch_halo_copy(tab, cp->local.blkA, cp->local.offA, cp->local.blkB, cp->local.offB, cp->local.n, mask, g_stream);
+    for (auto& l : cp->recvs) launch_halo_unpack(tab, l.blkA, l.offA, l.n, mask, l.buf, g_stream);
+    // whalo2 closes by recomputing the total energy of the owned cells from p when
+    // both travelled (haloExchange.F90:178-196)
+    const bool bothPAndE = commPressure && varStart <= 5 && varEnd >= 5;
+    for_level(level, [&](Block* b) {
+        if (nLayers == 2 && bothPAndE) launch_etot_owned(b->v, g_opts.gammaConstant, g_stream);
+        b->ss_valid = false;
+        return 0;
+    });
+    return 0;
+}
+
+int adflow_gpu_halo_exchange(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers)
+{
+    if (need_ready()) return 1;
+    if (halo_exchange_enqueue(level, varStart, varEnd, commPressure, commVisc, nLayers)) return 1;
+    return sync_and_check();
+}
+
+// ----------------------------------------------------------------- smoothers
+// one stage of either smoother after dw holds the scaled update: state update,
+// boundary-condition hook, halo exchange (smoothers.F90:292-380, 600-691)
+static int finish_stage(int level, const KParams& kp, double scale, int fromWn)
+{
+    int rc = for_level(level, [&](Block* b) {
+        launch_stage_update(b->v, kp, scale, fromWn, g_stream);
+        b->ss_valid = false;
+        return 0;
+    });
+    if (rc) return rc;
+    const int secondHalo = (level <= g_opts.groundLevel);
+    if (g_bc_callback) {
+        HIPCHK(hipStreamSynchronize(g_stream));
+        g_bc_callback(level, secondHalo);
+    }
+    const int nLayers = secondHalo ? 2 : 1;
+    if (g_comm.count(std::make_pair(level, nLayers)))
+        if (halo_exchange_enqueue(level, 1, 5, 1, 1, nLayers)) return 1;
+    return 0;
+}
+
+static bool smooth_residual(int rkStage)
+{
+    if (g_opts.resAveraging == ADFLOW_RESAVG_NEVER) return false;
+    if (g_opts.resAveraging == ADFLOW_RESAVG_ALWAYS) return true;
+    return (rkStage % 2) == 1;
+}
+
+int adflow_gpu_rk_smooth(int level)
+{
+    if (need_ready()) return 1;
+    if (g_opts.smoother != ADFLOW_RUNGE_KUTTA) return fail("adflow_gpu_rk_smooth called with smoother=%d", g_opts.smoother);
+    int rc = for_level(level, [&](Block* b) { launch_rk_save(b->v, g_stream); return 0; });
+    if (rc) return rc;
+    const int nst = g_opts.nRKStages;
+    for (int stage = 1; stage <= nst; ++stage) {
+        KParams kp = make_kparams(level, 1.0, 1);
+        const double scale = kp.cfl * g_opts.etaRK[stage - 1];
+        if (smooth_residual(stage)) {
+            rc = for_level(level, [&](Block* b) {
+                launch_scale_dw(b->v, scale, 0, g_stream);
+                launch_res_averaging(b->v, kp, g_stream);
+                return 0;
+            });
+            if (rc) return rc;
+            if (finish_stage(level, kp, 0.0, 1)) return 1;
+        } else {
+            if (finish_stage(level, kp, scale, 1)) return 1;
+        }
+        if (stage < nst) {
+            // residual of the next stage: rkStage = stage -> rFil = cdisRK(stage+1)
+            KParams kr = make_kparams(level, g_opts.cdisRK[stage], 1);
+            if (enqueue_flow_residual(level, kr)) return 1;
+        }
+    }
+    return sync_and_check();
+}
+
+int adflow_gpu_dadi_smooth(int level)
+{
+    if (need_ready()) return 1;
+    if (g_opts.smoother != ADFLOW_DADI) return fail("adflow_gpu_dadi_smooth called with smoother=%d", g_opts.smoother);
+    const int nsub = (g_opts.groundLevel == 1) ? std::max(1, (int)g_opts.nSubiterations) : 1;
+    for (int it = 1; it <= nsub; ++it) {
+        KParams kp = make_kparams(level, 1.0, 0);
+        int rc = for_level(level, [&](Block* b) {
+            launch_dadi(b->v, kp, g_stream);
+            if (smooth_residual(0)) launch_res_averaging(b->v, kp, g_stream);   // rkStage stays 0 under DADI
+            return 0;
+        });
+        if (rc) return rc;
+        if (finish_stage(level, kp, 0.0, 0)) return 1;
+        if (it < nsub) {
+            if (enqueue_flow_residual(level, kp)) return 1;
+        }
+    }
+    return sync_and_check();
+}
+
+int adflow_gpu_res_norms(int level, double* sums, int n)
+{
+    if (need_ready()) return 1;
+    if (!sums || n < 1 || n > 6) return fail("res_norms: n must be 1..6");
+    if (!g_norm_dev) HIPCHK(hipMalloc((void**)&g_norm_dev, sizeof(double) * 8));
+    HIPCHK(hipMemsetAsync(g_norm_dev, 0, sizeof(double) * 8, g_stream));
+    int rc = for_level(level, [&](Block* b) {
+        if (n > b->v.nw) return fail("res_norms: n=%d exceeds nw=%d", n, b->v.nw);
+        launch_res_norms(b->v, n, g_norm_dev, g_stream);
+        return 0;
+    });
+    if (rc) return rc;
+#ifndef ADFLOW_NO_RCCL
+    if (g_nccl && g_nranks > 1) NCCLCHK(ncclAllReduce(g_norm_dev, g_norm_dev, n, ncclDouble, ncclSum, g_nccl, g_stream));
+#endif
+    HIPCHK(hipMemcpyAsync(sums, g_norm_dev, sizeof(double) * n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
+}
 
 // --------------------------------------------------------- instrumentation
 int adflow_gpu_event_record(int slot)

@@ -57,11 +57,12 @@ struct KParams {
     int doScaling;         // dirScaling && currentLevel <= groundLevel
     int onlyRadii;
     int coarseInit;        // initres: dw = wr instead of 0
+    int updateEddy;        // currentLevel <= groundLevel: recompute rev in the stage update
     int fwMode;            // 0: fw not persistent (rFil==1, sfil==0, no store)  1: persistent fw
     int storeIntermed;     // store dtl / radii
     double rFil, sfil;
     double vis2, vis4, vis2Coarse, adis, acousticScaleFactor, kappaCoef;
-    double gammaConstant, gammaInf, pInfCorr, rhoInf, RGas, muRef, TRef, timeRef;
+    double gammaConstant, gammaInf, pInf, pInfCorr, rhoInf, RGas, muRef, TRef, timeRef;
     double prandtl, prandtlTurb, SSuthDim, muSuthDim, TSuthDim;
     double sa_k, sa_cb1, sa_cb2, sa_cb3, sa_cv1, sa_cw1, sa_cw2, sa_cw3, sa_ct3, sa_ct4, sa_crot;
     double cfl, cflLimit, smoop, fcoll, turbResScale;
@@ -75,3 +76,15 @@ void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_sa_residual(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_rk_save(const BlkView& b, hipStream_t s);
+void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s);
+void launch_scale_dw(const BlkView& b, double factor, int timesVol, hipStream_t s);
+void launch_stage_update(const BlkView& b, const KParams& kp, double scale, int fromWn, hipStream_t s);
+void launch_res_averaging(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_dadi(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_halo_copy(const BlkView* tab, const int* donorBlk, const long* donorOff, const int* haloBlk, const long* haloOff,
+                      int n, unsigned mask, hipStream_t s);
+void launch_halo_pack(const BlkView* tab, const int* blk, const long* off, int n, unsigned mask, double* buf, hipStream_t s);
+void launch_halo_unpack(const BlkView* tab, const int* blk, const long* off, int n, unsigned mask, const double* buf,
+                        hipStream_t s);
+void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);

@@ -1,0 +1,512 @@
+// Smoother kernels: Runge-Kutta stage update, implicit residual averaging and
+// the diagonalised ADI (D-ADI) factorisation.
+//
+// Reference semantics:
+//   RungeKuttaSmoother / executeRkStage   src/solver/smoothers.F90:4-382
+//   DADISmoother / executeDADIStep        src/solver/smoothers.F90:383-693
+//   computedwDADI, tridiagsolve           src/solver/residuals.F90:1062-1783
+//   residualAveraging                     src/solver/residuals.F90:1785-2082
+//   computeEtotBlock                      src/utils/flowUtils.F90:551-672
+//   computeLamViscosity                   src/utils/flowUtils.F90:1201-1300
+//   saEddyViscosity                       src/turbulence/turbUtils.F90:657-720
+//
+// All pointwise work of a stage (dt scaling, conservative update with the
+// density/pressure clipping, total energy, Sutherland viscosity, SA eddy
+// viscosity) is ONE kernel.  Line solves along j and k map lanes to i
+// (coalesced); lines along i are solved one line per lane.
+// Roofline: HBM; no MFMA.
+#include "internal.h"
+
+#define SM_BX 64
+#define SM_BY 4
+
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_rk_save(BlkView b)
+{
+    const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+#pragma unroll
+    for (int l = 0; l < 5; ++l) b.wn[c + l * b.nbox] = b.w[c + l * b.nbox];
+    b.pn[c] = b.p[c];
+}
+
+void launch_rk_save(const BlkView& b, hipStream_t s)
+{
+    dim3 blk(SM_BX, SM_BY, 1);
+    dim3 grd((b.nx + SM_BX - 1) / SM_BX, (b.ny + SM_BY - 1) / SM_BY, b.nz);
+    hipLaunchKernelGGL(k_rk_save, grd, blk, 0, s, b);
+}
+
+// computeEtotBlock on the owned cells (flowUtils.F90:551-672, cpConstant): the
+// closing step of whalo2 when both p and rhoE were exchanged (haloExchange.F90:178-196)
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned(BlkView b, double gammaConstant)
+{
+    const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    const double ovgm1 = 1.0 / (gammaConstant - 1.0);
+    const double u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    b.w[c + 4 * nb] = ovgm1 * b.p[c] + 0.5 * b.w[c] * (u * u + v * v + w * w);
+}
+
+void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s)
+{
+    dim3 blk(SM_BX, SM_BY, 1);
+    dim3 grd((b.nx + SM_BX - 1) / SM_BX, (b.ny + SM_BY - 1) / SM_BY, b.nz);
+    hipLaunchKernelGGL(k_etot_owned, grd, blk, 0, s, b, gammaConstant);
+}
+
+// dw *= factor * dtl  [* vol]  (smoothers.F90:196-218 RK, :514-532 DADI)
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_scale_dw(BlkView b, double factor, int timesVol)
+{
+    const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    double dt = factor * b.dtl[c];
+    if (timesVol) dt *= b.vol[c];
+#pragma unroll
+    for (int l = 0; l < 5; ++l) b.dw[c + l * b.nbox] *= dt;
+}
+
+void launch_scale_dw(const BlkView& b, double factor, int timesVol, hipStream_t s)
+{
+    dim3 blk(SM_BX, SM_BY, 1);
+    dim3 grd((b.nx + SM_BX - 1) / SM_BX, (b.ny + SM_BY - 1) / SM_BY, b.nz);
+    hipLaunchKernelGGL(k_scale_dw, grd, blk, 0, s, b, factor, timesVol);
+}
+
+// State update of one stage.  FROM_WN: Runge-Kutta (new = stage-0 state - dw),
+// otherwise D-ADI (new = current - dw).  scale != 0: dw is first multiplied by
+// scale*dtl (fused k_scale_dw when no residual averaging sits in between).
+template <bool FROM_WN>
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_stage_update(BlkView b, KParams kp, double scale)
+{
+    const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    double d[5];
+#pragma unroll
+    for (int l = 0; l < 5; ++l) d[l] = b.dw[c + l * nb];
+    if (scale != 0.0) {
+        const double dt = scale * b.dtl[c];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) d[l] *= dt;
+    }
+    const double gam = b.gamma[c];
+    const double gm1 = gam - 1.0;
+    const double rho0 = b.w[c], u0 = b.w[c + nb], v0 = b.w[c + 2 * nb], w0 = b.w[c + 3 * nb], e0 = b.w[c + 4 * nb];
+    const double p0 = b.p[c];
+    double ovr = 1.0 / rho0;
+    const double v2 = u0 * u0 + v0 * v0 + w0 * w0;
+    const double dp = (ovr * p0 - gm1 * (ovr * e0 - v2)) * d[0] + gm1 * (d[4] - u0 * d[1] - v0 * d[2] - w0 * d[3]);
+    double rhoB, uB, vB, wB, pB;
+    if (FROM_WN) {
+        rhoB = b.wn[c]; uB = b.wn[c + nb]; vB = b.wn[c + 2 * nb]; wB = b.wn[c + 3 * nb]; pB = b.pn[c];
+    } else {
+        rhoB = rho0; uB = u0; vB = v0; wB = w0; pB = p0;
+    }
+    const double ru = rhoB * uB - d[1], rv = rhoB * vB - d[2], rw = rhoB * wB - d[3];
+    double rho = rhoB - d[0];
+    rho = fmax(rho, 1.e-4 * kp.rhoInf);
+    ovr = 1.0 / rho;
+    const double u = ovr * ru, v = ovr * rv, w = ovr * rw;
+    double p = pB - dp;
+    p = fmax(p, 1.e-4 * kp.pInfCorr);
+    b.w[c] = rho;
+    b.w[c + nb] = u;
+    b.w[c + 2 * nb] = v;
+    b.w[c + 3 * nb] = w;
+    b.p[c] = p;
+    // computeEtotBlock, cpConstant
+    const double ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
+    b.w[c + 4 * nb] = ovgm1 * p + 0.5 * rho * (u * u + v * v + w * w);
+    if (kp.viscous) {
+        // computeLamViscosity (Sutherland)
+        const double muSuth = kp.muSuthDim / kp.muRef, TSuth = kp.TSuthDim / kp.TRef, SSuth = kp.SSuthDim / kp.TRef;
+        const double T = p / (kp.RGas * rho);
+        const double tt = T / TSuth;
+        const double rlv = muSuth * ((TSuth + SSuth) / (T + SSuth)) * (tt * sqrt(tt));
+        b.rlv[c] = rlv;
+        if (kp.eddyModel && kp.updateEddy) {
+            const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
+            const double rnuSA = b.w[c + 5 * nb] * rho;
+            const double chi = rnuSA / rlv;
+            const double chi3 = chi * chi * chi;
+            b.rev[c] = chi3 / (chi3 + cv13) * rnuSA;
+        }
+    }
+}
+
+void launch_stage_update(const BlkView& b, const KParams& kp, double scale, int fromWn, hipStream_t s)
+{
+    dim3 blk(SM_BX, SM_BY, 1);
+    dim3 grd((b.nx + SM_BX - 1) / SM_BX, (b.ny + SM_BY - 1) / SM_BY, b.nz);
+    if (fromWn)
+        hipLaunchKernelGGL((k_stage_update<true>), grd, blk, 0, s, b, kp, scale);
+    else
+        hipLaunchKernelGGL((k_stage_update<false>), grd, blk, 0, s, b, kp, scale);
+}
+
+// ---------------------------------------------------------------------------
+// implicit residual averaging (residuals.F90:1856-2080): one line per lane.
+// DIR 0: lines along i (lanes over j), DIR 1: along j (lanes over i),
+// DIR 2: along k (lanes over i).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double ra_rfl(const BlkView& b, long c, double plim)
+{
+    const double p0 = b.p[c];
+    double pa = b.p[c + 1], pb = b.p[c - 1];
+    const double dpi = fabs(pa - 2.0 * p0 + pb) / (pa + 2.0 * p0 + pb + plim);
+    pa = b.p[c + b.ldi]; pb = b.p[c - b.ldi];
+    const double dpj = fabs(pa - 2.0 * p0 + pb) / (pa + 2.0 * p0 + pb + plim);
+    pa = b.p[c + b.ldk]; pb = b.p[c - b.ldk];
+    const double dpk = fabs(pa - 2.0 * p0 + pb) / (pa + 2.0 * p0 + pb + plim);
+    return 1.0 / (1.0 + 2.0 * (dpi + dpj + dpk));
+}
+
+template <int DIR>
+__global__ __launch_bounds__(64) void k_res_averaging(BlkView b, KParams kp)
+{
+    // line coordinates (a fastest): DIR0 -> (j,k), DIR1 -> (i,k), DIR2 -> (i,j)
+    const int a = blockIdx.x * 64 + threadIdx.x + 2;
+    const int bb = blockIdx.y + 2;
+    int n, amax;
+    long c0, s;
+    if (DIR == 0) { amax = b.jl; n = b.nx; c0 = b.idx(2, a, bb); s = 1; }
+    else if (DIR == 1) { amax = b.il; n = b.ny; c0 = b.idx(a, 2, bb); s = b.ldi; }
+    else { amax = b.il; n = b.nz; c0 = b.idx(a, bb, 2); s = b.ldk; }
+    if (a > amax) return;
+    const long nb = b.nbox;
+    const double rfl0 = 0.5 * kp.cfl / kp.cflLimit;
+    const double plim = 0.001 * kp.pInfCorr;
+    // forward elimination; d(m) kept in the scratch array (component 0)
+    double epzm = 0.0, dm = 0.0;          // epz(m-1), d(m-1) ; epz(1) = d(1) = 0
+    double prev[5] = {0, 0, 0, 0, 0};     // transformed dw(m-1)
+    double rflc = ra_rfl(b, c0, plim);
+    for (int m = 0; m < n; ++m) {         // cell index 2+m along the line
+        const long c = c0 + m * s;
+        double epz = 0.0;
+        double rfln = 0.0;
+        if (m < n - 1) {                  // epz defined for 2..n (index il gets 0)
+            rfln = ra_rfl(b, c + s, plim);
+            const double r = rfl0 * (rflc + rfln);
+            epz = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * flg_blank(b.flags[c]);
+        }
+        const double t = 1.0 / (1.0 + epz + epzm - epzm * dm);
+        const double d = t * epz;
+        b.scratch[c] = d;
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            const double v = t * (b.dw[c + l * nb] + epzm * prev[l]);
+            b.dw[c + l * nb] = v;
+            prev[l] = v;
+        }
+        epzm = epz;
+        dm = d;
+        rflc = rfln;
+    }
+    // back substitution from index nx down to 2 (residuals.F90:1897-1905)
+    for (int m = n - 2; m >= 0; --m) {
+        const long c = c0 + m * s;
+        const double d = b.scratch[c];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            const double v = b.dw[c + l * nb] + d * prev[l];
+            b.dw[c + l * nb] = v;
+            prev[l] = v;
+        }
+    }
+}
+
+void launch_res_averaging(const BlkView& b, const KParams& kp, hipStream_t s)
+{
+    dim3 blk(64, 1, 1);
+    if (b.nx > 1) hipLaunchKernelGGL((k_res_averaging<0>), dim3((b.ny + 63) / 64, b.nz, 1), blk, 0, s, b, kp);
+    if (b.ny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3((b.nx + 63) / 64, b.nz, 1), blk, 0, s, b, kp);
+    if (b.nz > 1) hipLaunchKernelGGL((k_res_averaging<2>), dim3((b.nx + 63) / 64, b.ny, 1), blk, 0, s, b, kp);
+}
+
+// ---------------------------------------------------------------------------
+// D-ADI (residuals.F90:1062-1748)
+// ---------------------------------------------------------------------------
+struct DadiCell {          // per-cell coefficients of one direction
+    double dP[3], dM[3];   // diagPlus / diagMinus for eigenvalue groups {1,2,3}, 4, 5
+    double vt1, vt3;       // viscTerm1 (face m), viscTerm3 (face m-1)
+    double ddt;            // dual_dt * max(iblank,0)
+};
+
+// DIR: 0 = i, 1 = j, 2 = k.  Coefficients of cell c (residuals.F90:1349-1376 for j)
+template <int DIR>
+__device__ __forceinline__ void dadi_cell(const BlkView& b, const KParams& kp, long c, long s, const double* __restrict__ sN,
+                                          DadiCell& o)
+{
+    const long nb = b.nbox;
+    const double vol = b.vol[c], rho = b.w[c];
+    const double u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    const double volhalf = 0.5 / vol;
+    // mean normal of the two faces (velocity part)
+    const double r1 = volhalf * (sN[c] + sN[c - s]);
+    const double r2 = volhalf * (sN[c + nb] + sN[c - s + nb]);
+    const double r3 = volhalf * (sN[c + 2 * nb] + sN[c - s + 2 * nb]);
+    const double qq = r1 * u + r2 * v + r3 * w;
+    const double cijk = sqrt(b.gamma[c] * b.p[c] / rho);
+    const double cc = cijk * sqrt(r1 * r1 + r2 * r2 + r3 * r3);
+    // metric used in eps2: the k-direction mixes sK(k) with sJ(k-1) in the
+    // reference (residuals.F90:1625-1627) and that is reproduced here
+    double m1 = r1, m2 = r2, m3 = r3;
+    if (DIR == 2) {
+        m1 = volhalf * (b.sK[c] + b.sJ[c - s]);
+        m2 = volhalf * (b.sK[c + nb] + b.sJ[c - s + nb]);
+        m3 = volhalf * (b.sK[c + 2 * nb] + b.sJ[c - s + 2 * nb]);
+    }
+    const double epsval = 0.08, fac = 1.05;
+    const double cInf2 = kp.gammaInf * kp.pInf / kp.rhoInf;
+    const double eps2 = epsval * epsval * cInf2 * (m1 * m1 + m2 * m2 + m3 * m3);
+    o.dP[0] = 0.5 * (qq + fac * sqrt(qq * qq + eps2));
+    o.dP[1] = 0.5 * (qq + cc + fac * sqrt((qq + cc) * (qq + cc) + eps2));
+    o.dP[2] = 0.5 * (qq - cc + fac * sqrt((qq - cc) * (qq - cc) + eps2));
+    o.dM[0] = 0.5 * (qq - fac * sqrt(qq * qq + eps2));
+    o.dM[1] = 0.5 * (qq + cc - fac * sqrt((qq + cc) * (qq + cc) + eps2));
+    o.dM[2] = 0.5 * (qq - cc - fac * sqrt((qq - cc) * (qq - cc) + eps2));
+    // viscous terms: metterm(face) = |S|^2 * mut / (vol_m + vol_m+1)
+    double mtP = 0.0, mtM = 0.0;
+    if (kp.viscous) {
+        double mutP = b.rlv[c] + b.rlv[c + s], mutM = b.rlv[c - s] + b.rlv[c];
+        if (kp.eddyModel) {
+            mutP += b.rev[c] + b.rev[c + s];
+            mutM += b.rev[c - s] + b.rev[c];
+        }
+        const double sp = sN[c] * sN[c] + sN[c + nb] * sN[c + nb] + sN[c + 2 * nb] * sN[c + 2 * nb];
+        const double sm = sN[c - s] * sN[c - s] + sN[c - s + nb] * sN[c - s + nb] + sN[c - s + 2 * nb] * sN[c - s + 2 * nb];
+        mtP = sp * mutP * (1.0 / (vol + b.vol[c + s]));
+        mtM = sm * mutM * (1.0 / (b.vol[c - s] + vol));
+    }
+    o.vt1 = mtP / vol / rho;
+    o.vt3 = mtM / vol / rho;
+    o.ddt = kp.cfl * b.dtl[c] * vol * flg_blank(b.flags[c]);
+}
+
+// T_eta^-1 applied to the physical update (residuals.F90:1276-1331)
+__device__ __forceinline__ void dadi_pre_j(const BlkView& b, long c, double d[5])
+{
+    const long nb = b.nbox;
+    const double rho = b.w[c], uvel = b.w[c + nb], vvel = b.w[c + 2 * nb], wvel = b.w[c + 3 * nb];
+    const double gm1 = b.gamma[c] - 1.0;
+    const double cijk = sqrt(b.gamma[c] * b.p[c] / rho);
+    const double c2inv = 1.0 / (cijk * cijk);
+    const double xfact = 2.0 * cijk;
+    const double alphinv = sqrt(2.0) * cijk / rho;
+    const double uvw = 0.5 * (uvel * uvel + vvel * vvel + wvel * wvel);
+    const long s = b.ldi;
+    double rj1 = 0.5 * (b.sJ[c] + b.sJ[c - s]), rj2 = 0.5 * (b.sJ[c + nb] + b.sJ[c - s + nb]),
+           rj3 = 0.5 * (b.sJ[c + 2 * nb] + b.sJ[c - s + 2 * nb]);
+    const double rj = sqrt(rj1 * rj1 + rj2 * rj2 + rj3 * rj3);
+    const double uu = uvel * rj1 + vvel * rj2 + wvel * rj3;
+    rj1 /= rj; rj2 /= rj; rj3 /= rj;
+    const double dw1 = d[0], dw2 = d[1], dw3 = d[2], dw4 = d[3], dw5 = d[4];
+    double a1 = dw2 * uvel + dw3 * vvel + dw4 * wvel - dw5;
+    a1 = a1 * gm1 * c2inv + dw1 * (1.0 - uvw * gm1 * c2inv);
+    const double a2 = (rj2 * wvel - rj3 * vvel) * dw1 + rj3 * dw3 - rj2 * dw4;
+    const double a3 = (rj3 * uvel - rj1 * wvel) * dw1 + rj1 * dw4 - rj3 * dw2;
+    const double a4 = (rj1 * vvel - rj2 * uvel) * dw1 + rj2 * dw2 - rj1 * dw3;
+    double a5 = uvw * dw1 - uvel * dw2 - vvel * dw3 - wvel * dw4 + dw5;
+    a5 = a5 * gm1 * c2inv;
+    const double a6 = uu * dw1 / rj - rj1 * dw2 - rj2 * dw3 - rj3 * dw4;
+    d[0] = a1 * rj1 + a2 / rho;
+    d[1] = a1 * rj2 + a3 / rho;
+    d[2] = a1 * rj3 + a4 / rho;
+    d[3] = (0.5 * a5 - a6 / xfact) * alphinv;
+    d[4] = (0.5 * a5 + a6 / xfact) * alphinv;
+}
+
+// T_A^-1 T_B between two directions given their unit mean normals
+// (residuals.F90:1404-1446 with (ri,rj); :1540-1583 with (rk,ri) in swapped roles)
+__device__ __forceinline__ void dadi_rotate(const double a1, const double a2, const double a3, const double a4, double d[5])
+{
+    const double sqrt2inv = 1.0 / sqrt(2.0);
+    const double dw1 = d[0], dw2 = d[1], dw3 = d[2], dw4 = d[3], dw5 = d[4];
+    const double a5 = (dw4 - dw5) * sqrt2inv;
+    const double a6 = (dw4 + dw5) * 0.5;
+    const double a7 = (a3 * dw1 + a4 * dw2 - a2 * dw3 - a5 * a1) * sqrt2inv;
+    d[0] = a1 * dw1 + a2 * dw2 + a4 * dw3 + a5 * a3;
+    d[1] = -a2 * dw1 + a1 * dw2 - a3 * dw3 + a5 * a4;
+    d[2] = -a4 * dw1 + a3 * dw2 + a1 * dw3 - a5 * a2;
+    d[3] = -a7 + a6;
+    d[4] = a7 + a6;
+}
+
+__device__ __forceinline__ void unit_mean_normal(const double* __restrict__ sN, long c, long s, long nb, double r[3])
+{
+    r[0] = 0.5 * (sN[c] + sN[c - s]);
+    r[1] = 0.5 * (sN[c + nb] + sN[c - s + nb]);
+    r[2] = 0.5 * (sN[c + 2 * nb] + sN[c - s + 2 * nb]);
+    const double rr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    r[0] /= rr; r[1] /= rr; r[2] /= rr;
+}
+
+// after the j-solve: T_xi^-1 T_eta (residuals.F90:1404-1446)
+__device__ __forceinline__ void dadi_post_j(const BlkView& b, long c, double d[5])
+{
+    double ri[3], rj[3];
+    unit_mean_normal(b.sI, c, 1, b.nbox, ri);
+    unit_mean_normal(b.sJ, c, b.ldi, b.nbox, rj);
+    const double a1 = ri[0] * rj[0] + ri[1] * rj[1] + ri[2] * rj[2];
+    const double a2 = ri[0] * rj[1] - rj[0] * ri[1];
+    const double a3 = ri[2] * rj[1] - rj[2] * ri[1];
+    const double a4 = ri[0] * rj[2] - rj[0] * ri[2];
+    dadi_rotate(a1, a2, a3, a4, d);
+}
+
+// after the i-solve: T_zeta^-1 T_xi (residuals.F90:1540-1583)
+__device__ __forceinline__ void dadi_post_i(const BlkView& b, long c, double d[5])
+{
+    double ri[3], rk[3];
+    unit_mean_normal(b.sI, c, 1, b.nbox, ri);
+    unit_mean_normal(b.sK, c, b.ldk, b.nbox, rk);
+    const double a1 = ri[0] * rk[0] + ri[1] * rk[1] + ri[2] * rk[2];
+    const double a2 = rk[0] * ri[1] - ri[0] * rk[1];
+    const double a3 = rk[2] * ri[1] - ri[2] * rk[1];
+    const double a4 = rk[0] * ri[2] - ri[0] * rk[2];
+    dadi_rotate(a1, a2, a3, a4, d);
+}
+
+// after the k-solve: T_zeta and the -1/vol scaling (residuals.F90:1676-1745)
+__device__ __forceinline__ void dadi_post_k(const BlkView& b, long c, double d[5])
+{
+    const long nb = b.nbox;
+    const double rho = b.w[c], uvel = b.w[c + nb], vvel = b.w[c + 2 * nb], wvel = b.w[c + 3 * nb];
+    const double gam = b.gamma[c];
+    const long s = b.ldk;
+    double rk1 = 0.5 * (b.sK[c] + b.sK[c - s]), rk2 = 0.5 * (b.sK[c + nb] + b.sK[c - s + nb]),
+           rk3 = 0.5 * (b.sK[c + 2 * nb] + b.sK[c - s + 2 * nb]);
+    const double rk = sqrt(rk1 * rk1 + rk2 * rk2 + rk3 * rk3);
+    const double uu = uvel * rk1 + vvel * rk2 + wvel * rk3;
+    rk1 /= rk; rk2 /= rk; rk3 /= rk;
+    const double uvw = 0.5 * (uvel * uvel + vvel * vvel + wvel * wvel);
+    const double cijkinv = sqrt(rho / gam / b.p[c]);
+    const double alph = rho * cijkinv * (1.0 / sqrt(2.0));
+    const double xfact = 2.0 / cijkinv;
+    const double ge = gam * b.w[c + 4 * nb] / rho - (gam - 1.0) * uvw;
+    const double dw1 = d[0], dw2 = d[1], dw3 = d[2];
+    const double dw4 = d[3] * alph, dw5 = d[4] * alph;
+    const double a1 = dw1 * rk1 + dw2 * rk2 + dw3 * rk3 + dw4 + dw5;
+    const double a2 = 0.5 * xfact * (dw4 - dw5);
+    const double a3 = uvw * (rk1 * dw1 + rk2 * dw2 + rk3 * dw3);
+    const double volfact = -1.0 / b.vol[c];
+    d[0] = a1 * volfact;
+    d[1] = (a1 * uvel - rho * (rk3 * dw2 - rk2 * dw3) + a2 * rk1) * volfact;
+    d[2] = (a1 * vvel - rho * (rk1 * dw3 - rk3 * dw1) + a2 * rk2) * volfact;
+    d[3] = (a1 * wvel - rho * (rk2 * dw1 - rk1 * dw2) + a2 * rk3) * volfact;
+    d[4] = (a3 + rho * ((vvel * rk3 - wvel * rk2) * dw1 + (wvel * rk1 - uvel * rk3) * dw2 + (uvel * rk2 - vvel * rk1) * dw3) +
+            (ge + 0.5 * xfact * uu / rk) * dw4 + (ge - 0.5 * xfact * uu / rk) * dw5) * volfact;
+}
+
+// One direction of the D-ADI sweep, one line per lane.
+//  DIR 1 (j): pre-transform T_eta^-1, solve along j, post-transform T_xi^-1 T_eta
+//  DIR 0 (i): solve along i, post T_zeta^-1 T_xi
+//  DIR 2 (k): solve along k, post T_zeta * (-1/vol)
+// scale: factor applied to the incoming dw on load (DIR 1 only: -cfl*dtl*vol of
+// executeDADIStep, smoothers.F90:514-532)
+template <int DIR>
+__global__ __launch_bounds__(64) void k_dadi_sweep(BlkView b, KParams kp)
+{
+    const int a = blockIdx.x * 64 + threadIdx.x + 2;
+    const int bb = blockIdx.y + 2;
+    int n, amax;
+    long c0, s;
+    const double* sN;
+    if (DIR == 0) { amax = b.jl; n = b.nx; c0 = b.idx(2, a, bb); s = 1; sN = b.sI; }
+    else if (DIR == 1) { amax = b.il; n = b.ny; c0 = b.idx(a, 2, bb); s = b.ldi; sN = b.sJ; }
+    else { amax = b.il; n = b.nz; c0 = b.idx(a, bb, 2); s = b.ldk; sN = b.sK; }
+    if (a > amax) return;
+    const long nb = b.nbox;
+    double* sc = b.scratch;   // components 0..2: modified super-diagonals of the three eigenvalue groups
+    const bool solve = (n > 1);   // "if (jl > 2)" etc.: skip the inversion for one-cell lines
+    static const int grp[5] = {0, 0, 0, 1, 2};
+
+    DadiCell cur, nxt, prv;
+    if (solve) dadi_cell<DIR>(b, kp, c0, s, sN, cur);
+    double ddp[3] = {0, 0, 0};          // dd'(m-1)
+    double fprev[5] = {0, 0, 0, 0, 0};  // ff'(m-1)
+    for (int m = 0; m < n; ++m) {
+        const long c = c0 + m * s;
+        double d[5];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) d[l] = b.dw[c + l * nb];
+        if (DIR == 1) {
+            const double sc0 = -kp.cfl * b.dtl[c] * b.vol[c];   // executeDADIStep scaling
+#pragma unroll
+            for (int l = 0; l < 5; ++l) d[l] *= sc0;
+            dadi_pre_j(b, c, d);
+        }
+        if (solve) {
+            if (m < n - 1) dadi_cell<DIR>(b, kp, c + s, s, sN, nxt);
+            double ddn[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                // row m: sub-diagonal from cell m-1, super-diagonal from cell m+1, both scaled with ddt(m)
+                const double bbv = (m > 0) ? (-prv.vt1 - prv.dP[g]) * cur.ddt : 0.0;
+                const double ddv = (m < n - 1) ? (-nxt.vt3 + nxt.dM[g]) * cur.ddt : 0.0;
+                const double ccv = 1.0 + (cur.vt1 + cur.vt3 + cur.dP[g] - cur.dM[g]) * cur.ddt;
+                const double d0 = 1.0 / (ccv - bbv * ddp[g]);
+                ddn[g] = ddv * d0;
+                sc[c + g * nb] = ddn[g];
+#pragma unroll
+                for (int l = 0; l < 5; ++l)
+                    if (grp[l] == g) d[l] = (d[l] - bbv * fprev[l]) * d0;
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ddp[g] = ddn[g];
+#pragma unroll
+            for (int l = 0; l < 5; ++l) fprev[l] = d[l];
+            prv = cur;
+            cur = nxt;
+#pragma unroll
+            for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
+        } else {
+            if (DIR == 0) dadi_post_i(b, c, d);
+            else if (DIR == 1) dadi_post_j(b, c, d);
+            else dadi_post_k(b, c, d);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
+        }
+    }
+    if (!solve) return;
+    // back substitution + post-transform
+    for (int m = n - 1; m >= 0; --m) {
+        const long c = c0 + m * s;
+        double d[5];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) d[l] = b.dw[c + l * nb];
+        if (m < n - 1) {
+#pragma unroll
+            for (int l = 0; l < 5; ++l) d[l] -= sc[c + grp[l] * nb] * fprev[l];
+        }
+#pragma unroll
+        for (int l = 0; l < 5; ++l) fprev[l] = d[l];
+        if (DIR == 0) dadi_post_i(b, c, d);
+        else if (DIR == 1) dadi_post_j(b, c, d);
+        else dadi_post_k(b, c, d);
+#pragma unroll
+        for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
+    }
+}
+
+// computedwDADI incl. the -cfl*dtl*vol scaling of executeDADIStep
+void launch_dadi(const BlkView& b, const KParams& kp, hipStream_t s)
+{
+    dim3 blk(64, 1, 1);
+    hipLaunchKernelGGL((k_dadi_sweep<1>), dim3((b.nx + 63) / 64, b.nz, 1), blk, 0, s, b, kp);
+    hipLaunchKernelGGL((k_dadi_sweep<0>), dim3((b.ny + 63) / 64, b.nz, 1), blk, 0, s, b, kp);
+    hipLaunchKernelGGL((k_dadi_sweep<2>), dim3((b.nx + 63) / 64, b.ny, 1), blk, 0, s, b, kp);
+}

@@ -118,6 +118,23 @@ class Engine:
     def DADISmoother(self, level=1):
         self._chk(self.lib.adflow_gpu_dadi_smooth(level))
 
+    # ---- halo exchange ------------------------------------------------------
+    def comm_register(self, level: int, nLayers: int, cp):
+        """commPatternCell_{1st,2nd}(level) + internalCell_{1st,2nd}(level)."""
+        c = capi.comm_pattern_struct(cp)
+        self._chk(self.lib.adflow_gpu_comm_register(level, nLayers, ctypes.byref(c)))
+
+    def whalo1(self, level, start, end, commPressure=True, commGamma=True, commViscous=True):
+        self._chk(self.lib.adflow_gpu_halo_exchange(level, start, end, int(commPressure), int(commViscous), 1))
+
+    def whalo2(self, level, start, end, commPressure=True, commGamma=True, commViscous=True):
+        self._chk(self.lib.adflow_gpu_halo_exchange(level, start, end, int(commPressure), int(commViscous), 2))
+
+    def res_norms(self, level=1, n=5):
+        out = np.zeros(n)
+        self._chk(self.lib.adflow_gpu_res_norms(level, out.ctypes.data, n))
+        return out
+
     # ---- instrumentation ----------------------------------------------------
     def event_record(self, slot: int):
         self._chk(self.lib.adflow_gpu_event_record(slot))

@@ -1,0 +1,164 @@
+"""Block topologies and 1-to-1 halo communication patterns.
+
+Builds, for synthetic multi-block cases, exactly the data the reference's
+preprocessing produces for the hot path: `internalCell_{1st,2nd}(level)` and
+`commPatternCell_{1st,2nd}(level)` (src/modules/communication.F90, built in
+src/preprocessing/pointMatchedCommPattern.F90 — out of scope).
+Cell indices are 0..ib as the reference stores them; block ids are local and
+1-based; ranks are 0-based.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Tuple
+
+import numpy as np
+
+
+@dataclass
+class CommPattern:
+    """Flattened pattern of ONE rank, one level, one halo depth."""
+    donorBlock: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    donorIndices: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.int32, order="F"))
+    haloBlock: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    haloIndices: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.int32, order="F"))
+    sendProc: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    nsendCum: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
+    sendBlock: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    sendIndices: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.int32, order="F"))
+    recvProc: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    nrecvCum: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
+    recvBlock: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    recvIndices: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.int32, order="F"))
+
+    @property
+    def ncopy(self):
+        return int(self.donorBlock.size)
+
+
+@dataclass
+class BrickTopology:
+    """Bi x Bj x Bk equal blocks of nx x ny x nz cells, periodic in all three
+    index directions; block g (0-based, i fastest) lives on rank owner(g)."""
+    Bi: int
+    Bj: int
+    Bk: int
+    nx: int
+    ny: int
+    nz: int
+    owner: Callable[[int], int] = lambda g: 0
+
+    @property
+    def nblocks(self):
+        return self.Bi * self.Bj * self.Bk
+
+    def gid(self, bi, bj, bk):
+        return bi + self.Bi * (bj + self.Bj * bk)
+
+    def coords(self, g):
+        return g % self.Bi, (g // self.Bi) % self.Bj, g // (self.Bi * self.Bj)
+
+    def local_ids(self) -> Dict[int, int]:
+        """global block id -> local 1-based block number nn on its owner."""
+        cnt: Dict[int, int] = {}
+        out = {}
+        for g in range(self.nblocks):
+            r = self.owner(g)
+            cnt[r] = cnt.get(r, 0) + 1
+            out[g] = cnt[r]
+        return out
+
+    def blocks_of(self, rank) -> List[int]:
+        return [g for g in range(self.nblocks) if self.owner(g) == rank]
+
+    def patterns(self, nLayers: int) -> Dict[int, CommPattern]:
+        """CommPattern per rank for halo depth nLayers (1: cells 1..ie, 2: 0..ib),
+        faces, edges and corners included."""
+        nx, ny, nz = self.nx, self.ny, self.nz
+        lo = 2 - nLayers
+        ii = np.arange(lo, nx + 2 + nLayers)
+        jj = np.arange(lo, ny + 2 + nLayers)
+        kk = np.arange(lo, nz + 2 + nLayers)
+        I, J, K = np.meshgrid(ii, jj, kk, indexing="ij")
+        halo = ~((I >= 2) & (I <= nx + 1) & (J >= 2) & (J <= ny + 1) & (K >= 2) & (K <= nz + 1))
+        hi, hj, hk = I[halo], J[halo], K[halo]        # canonical order: k slowest? (C order of the mask)
+        lid = self.local_ids()
+        ranks = sorted({self.owner(g) for g in range(self.nblocks)})
+        loc = {r: [[], [], [], []] for r in ranks}            # donorBlk, donorIdx, haloBlk, haloIdx
+        msg: Dict[Tuple[int, int], List] = {}                  # (src rank, dst rank) -> [sendBlk, sendIdx, recvBlk, recvIdx]
+        for g in range(self.nblocks):
+            bi, bj, bk = self.coords(g)
+            gi = (bi * nx + hi - 2) % (self.Bi * nx)
+            gj = (bj * ny + hj - 2) % (self.Bj * ny)
+            gk = (bk * nz + hk - 2) % (self.Bk * nz)
+            dg = (gi // nx) + self.Bi * ((gj // ny) + self.Bj * (gk // nz))
+            di, dj, dk = gi % nx + 2, gj % ny + 2, gk % nz + 2
+            rh = self.owner(g)
+            downers = np.array([self.owner(int(x)) for x in np.unique(dg)])
+            for dgu, rd in zip(np.unique(dg), downers):
+                m = dg == dgu
+                didx = np.stack([di[m], dj[m], dk[m]], axis=1)
+                hidx = np.stack([hi[m], hj[m], hk[m]], axis=1)
+                n = int(m.sum())
+                if rd == rh:
+                    L = loc[rh]
+                    L[0].append(np.full(n, lid[int(dgu)])); L[1].append(didx)
+                    L[2].append(np.full(n, lid[g])); L[3].append(hidx)
+                else:
+                    M = msg.setdefault((int(rd), int(rh)), [[], [], [], []])
+                    M[0].append(np.full(n, lid[int(dgu)])); M[1].append(didx)
+                    M[2].append(np.full(n, lid[g])); M[3].append(hidx)
+        out = {}
+        for r in ranks:
+            cp = CommPattern()
+            L = loc[r]
+            if L[0]:
+                cp.donorBlock = np.concatenate(L[0]).astype(np.int32)
+                cp.donorIndices = np.asfortranarray(np.concatenate(L[1]).astype(np.int32))
+                cp.haloBlock = np.concatenate(L[2]).astype(np.int32)
+                cp.haloIndices = np.asfortranarray(np.concatenate(L[3]).astype(np.int32))
+            sp, sc, sb, si_ = [], [0], [], []
+            rp, rc, rb, ri_ = [], [0], [], []
+            for (src, dst), M in sorted(msg.items()):
+                if src == r:
+                    sp.append(dst); sb.append(np.concatenate(M[0])); si_.append(np.concatenate(M[1]))
+                    sc.append(sc[-1] + sb[-1].size)
+                if dst == r:
+                    rp.append(src); rb.append(np.concatenate(M[2])); ri_.append(np.concatenate(M[3]))
+                    rc.append(rc[-1] + rb[-1].size)
+            if sp:
+                cp.sendProc = np.array(sp, np.int32); cp.nsendCum = np.array(sc, np.int32)
+                cp.sendBlock = np.concatenate(sb).astype(np.int32)
+                cp.sendIndices = np.asfortranarray(np.concatenate(si_).astype(np.int32))
+            if rp:
+                cp.recvProc = np.array(rp, np.int32); cp.nrecvCum = np.array(rc, np.int32)
+                cp.recvBlock = np.concatenate(rb).astype(np.int32)
+                cp.recvIndices = np.asfortranarray(np.concatenate(ri_).astype(np.int32))
+            out[r] = cp
+        return out
+
+
+def apply_local_copies(blocks: Dict[int, object], cp: CommPattern, names=("w", "p", "rlv", "rev")):
+    """numpy statement of the same-process copies (haloExchange.F90:657-678) used
+    to give synthetic multi-block states consistent halos before the first step."""
+    for t in range(cp.ncopy):
+        db, hb = blocks[int(cp.donorBlock[t])], blocks[int(cp.haloBlock[t])]
+        di, dj, dk = cp.donorIndices[t]
+        hi, hj, hk = cp.haloIndices[t]
+        for n in names:
+            if n in db.a and n in hb.a:
+                hb.a[n][hi, hj, hk] = db.a[n][di, dj, dk]
+
+
+def apply_local_copies_fast(blocks: Dict[int, object], cp: CommPattern, names=("w", "p", "rlv", "rev")):
+    """Vectorised version of apply_local_copies (grouped by block pair)."""
+    if cp.ncopy == 0:
+        return
+    key = cp.donorBlock.astype(np.int64) * 100000 + cp.haloBlock
+    for kv in np.unique(key):
+        m = key == kv
+        db, hb = blocks[int(kv // 100000)], blocks[int(kv % 100000)]
+        d, h = cp.donorIndices[m], cp.haloIndices[m]
+        for n in names:
+            if n in db.a and n in hb.a:
+                hb.a[n][h[:, 0], h[:, 1], h[:, 2]] = db.a[n][d[:, 0], d[:, 1], d[:, 2]]

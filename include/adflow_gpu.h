@@ -95,6 +95,28 @@ typedef struct adflow_block_desc {
     double *w1, *p1, *wr;     /* (1:ie,1:je,1:ke,1:5) (1:ie,1:je,1:ke) (2:il,2:jl,2:kl,1:5) */
 } adflow_block_desc;
 
+/* 1-to-1 halo communication pattern of one level and one halo depth: the
+ * reference's internalCell_{1st,2nd}(level) and commPatternCell_{1st,2nd}(level)
+ * (src/modules/communication.F90 internalCommType / commType), flattened.  Cell
+ * indices are the values the reference stores (actual cell indices 0..ib; its
+ * "+1" at use, haloExchange.F90:605-607, only undoes a pointer rebasing).
+ * Index arrays are column-major (n,3) like the Fortran ones; block ids are the
+ * local block numbers nn (1-based).  Entry order inside a message must match on
+ * sender and receiver, which the reference's preprocessing guarantees. */
+typedef struct adflow_comm_pattern {
+    int32_t ncopy;                       /* internal%ncopy: same-process copies */
+    const int32_t *donorBlock, *donorIndices;   /* (ncopy), (ncopy,3) */
+    const int32_t *haloBlock, *haloIndices;     /* (ncopy), (ncopy,3) */
+    int32_t nProcSend;                   /* commPattern%nProcSend */
+    const int32_t *sendProc;             /* (nProcSend) ranks */
+    const int32_t *nsendCum;             /* (0:nProcSend) cumulative cell counts, nsendCum[0] = 0 */
+    const int32_t *sendBlock, *sendIndices;     /* (nsendCum[nProcSend]), (..,3): sendList(i)%block / %indices concatenated */
+    int32_t nProcRecv;
+    const int32_t *recvProc;
+    const int32_t *nrecvCum;
+    const int32_t *recvBlock, *recvIndices;
+} adflow_comm_pattern;
+
 /* identifiers for adflow_gpu_download_array / adflow_gpu_upload_array */
 enum {
     ADFLOW_ARR_W = 1, ADFLOW_ARR_P, ADFLOW_ARR_GAMMA, ADFLOW_ARR_RLV, ADFLOW_ARR_REV,
@@ -151,8 +173,26 @@ int adflow_gpu_block_res(int level, unsigned flags);
 /* smoothers::RungeKuttaSmoother / DADISmoother (src/solver/smoothers.F90:4,383) */
 int adflow_gpu_rk_smooth(int level);
 int adflow_gpu_dadi_smooth(int level);
-/* haloExchange::whalo1 / whalo2 (src/utils/haloExchange.F90:5,109) */
+/* register the 1-to-1 pattern of (level, nLayers = 1 | 2); lists are copied */
+int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* p);
+/* haloExchange::whalo1 (nLayers=1) / whalo2 (nLayers=2) (src/utils/haloExchange.F90:5,109):
+ * w(varStart:varEnd) [+ p] [+ rlv, rev when viscous / eddy model]; 1-based variable range;
+ * same-process copies on the device, other ranks through RCCL send/recv */
 int adflow_gpu_halo_exchange(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers);
+/* split form of the inter-process part, for a caller-owned transport (used by the
+ * CPU multi-process tests; the product path is adflow_gpu_halo_exchange):
+ * pack the message for send slot `islot` (0-based) into `buf` (host or device
+ * memory of nvar*count doubles, variable-major); unpack recv slot `islot` from `buf`;
+ * *_count return the number of cells of the slot and the peer rank */
+int adflow_gpu_halo_slot_info(int level, int nLayers, int isSend, int islot, int* peer, int* count);
+int adflow_gpu_halo_pack(int level, int nLayers, int islot, int varStart, int varEnd, int commPressure, int commVisc, double* buf);
+int adflow_gpu_halo_unpack(int level, int nLayers, int islot, int varStart, int varEnd, int commPressure, int commVisc, const double* buf);
+int adflow_gpu_halo_local_copy(int level, int nLayers, int varStart, int varEnd, int commPressure, int commVisc);
+/* host hook called between the state update and the halo exchange of every
+ * smoother stage, where the reference applies boundary conditions
+ * (applyAllBC, smoothers.F90:369,680).  NULL (default) = no physical boundaries. */
+typedef void (*adflow_bc_callback)(int level, int secondHalo);
+int adflow_gpu_set_bc_callback(adflow_bc_callback fn);
 /* sum over owned cells of (dw(:,l)/vol)^2, l=1..n  (solvers.F90:1538) */
 int adflow_gpu_res_norms(int level, double* sums, int n);
 

@@ -36,12 +36,16 @@ def load(fast: bool = False) -> ctypes.CDLL:
         lib.ref_set_vec.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int]
         lib.ref_call.argtypes = [ctypes.c_char_p, ctypes.c_int]
         lib.ref_block_res_core.argtypes = [ctypes.c_int] * 3
+        lib.ref_alloc_doms.argtypes = [ctypes.c_int] * 2
+        lib.ref_commit_block.argtypes = [ctypes.c_int] * 2
+        lib.ref_set_internal_comm.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+        lib.ref_call_level.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _LIB = lib
     return _LIB
 
 
 _INT_PARAMS = ["equations", "spaceDiscr", "spaceDiscrCoarse", "limiter", "orderTurb", "turbModel", "turbProd",
-               "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb"]
+               "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb", "nSubiterations"]
 _BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA"]
 _REAL_PARAMS = ["vis2", "vis4", "vis2Coarse", "adis", "acousticScaleFactor", "kappaCoef", "sigma", "cfl",
                 "cflCoarse", "cflLimit", "fcoll", "smoop", "alfaTurb", "betaTurb", "rFil", "gammaConstant",
@@ -83,6 +87,7 @@ def set_params(prm) -> None:
 
 _WORK3_CELL = ["aa"]
 _WORK3_IE = ["dtl", "radI", "radJ", "radK"]
+_MG = ["mgIFine", "mgJFine", "mgKFine", "mgICoarse", "mgJCoarse", "mgKCoarse", "mgIWeight", "mgJWeight", "mgKWeight"]
 _GRADS = ["ux", "uy", "uz", "vx", "vy", "vz", "wx", "wy", "wz", "qx", "qy", "qz"]
 
 
@@ -114,6 +119,13 @@ def bind_block(blk, prm) -> None:
     need("wr", (blk.nx, blk.ny, blk.nz, 5))
     need("w1", (ie, je, ke, 5))
     need("p1", (ie, je, ke))
+    for nm, shp in (("indFamilyI", (blk.il, blk.ny, blk.nz)), ("indFamilyJ", (blk.nx, blk.jl, blk.nz)),
+                    ("indFamilyK", (blk.nx, blk.ny, blk.kl)), ("factFamilyI", (blk.il, blk.ny, blk.nz)),
+                    ("factFamilyJ", (blk.nx, blk.jl, blk.nz)), ("factFamilyK", (blk.nx, blk.ny, blk.kl)),
+                    ("viscIminPointer", (blk.ny, blk.nz)), ("viscImaxPointer", (blk.ny, blk.nz)),
+                    ("viscJminPointer", (blk.nx, blk.nz)), ("viscJmaxPointer", (blk.nx, blk.nz)),
+                    ("viscKminPointer", (blk.nx, blk.ny)), ("viscKmaxPointer", (blk.nx, blk.ny))):
+        need(nm, shp, np.int32)
     for nm, shp in (("bmti1", (je, ke, 1, 1)), ("bmti2", (je, ke, 1, 1)), ("bmtj1", (ie, ke, 1, 1)),
                     ("bmtj2", (ie, ke, 1, 1)), ("bmtk1", (ie, je, 1, 1)), ("bmtk2", (ie, je, 1, 1)),
                     ("bvti1", (je, ke, 1)), ("bvti2", (je, ke, 1)), ("bvtj1", (ie, ke, 1)),
@@ -122,7 +134,10 @@ def bind_block(blk, prm) -> None:
     for name in ["w", "p", "gamma", "rlv", "rev", "vol", "volRef", "iblank", "x", "sI", "sJ", "sK",
                  "porI", "porJ", "porK", "d2Wall", "dw", "fw", "scratch", "aa", "wn", "pn", "wr", "w1", "p1",
                  "bmti1", "bmti2", "bmtj1", "bmtj2", "bmtk1", "bmtk2",
-                 "bvti1", "bvti2", "bvtj1", "bvtj2", "bvtk1", "bvtk2"] + _WORK3_IE + _GRADS:
+                 "bvti1", "bvti2", "bvtj1", "bvtj2", "bvtk1", "bvtk2",
+                 "indFamilyI", "indFamilyJ", "indFamilyK", "factFamilyI", "factFamilyJ", "factFamilyK",
+                 "viscIminPointer", "viscImaxPointer", "viscJminPointer", "viscJmaxPointer", "viscKminPointer",
+                 "viscKmaxPointer"] + _WORK3_IE + _GRADS + [n for n in _MG if n in a]:
         arr = a[name]
         assert arr.flags["F_CONTIGUOUS"], name
         lib.ref_set_ptr(name.encode(), arr.ctypes.data)
@@ -180,3 +195,36 @@ def time_block_res_core(seconds: float, update_intermed=True, flow_res=True, tur
                 return n, dt
 
     return _big_stack(loop)
+
+
+# ---- multi-block mode: the reference's shell routines over flowDoms ---------------
+def alloc_doms(ndom: int, nlevels: int = 1) -> None:
+    load().ref_alloc_doms(ndom, nlevels)
+
+
+def commit_block(nn: int, level: int = 1) -> None:
+    """flowDoms(nn,level,1) <- the block currently bound by bind_block."""
+    load().ref_commit_block(nn, level)
+
+
+_keep = []
+
+
+def set_internal_comm(level: int, nLayers: int, cp) -> None:
+    """internalCell_{1st,2nd}(level) from an adflow_amd.topology.CommPattern."""
+    arrs = [np.ascontiguousarray(cp.donorBlock, np.int32), np.asfortranarray(cp.donorIndices, np.int32),
+            np.ascontiguousarray(cp.haloBlock, np.int32), np.asfortranarray(cp.haloIndices, np.int32)]
+    _keep.append(arrs)
+    load().ref_set_internal_comm(level, nLayers, cp.ncopy, *[a.ctypes.data for a in arrs])
+
+
+def call_level(name: str, level: int = 1, i1: int = 0, i2: int = 0) -> None:
+    _big_stack(load().ref_call_level, name.encode(), level, int(i1), int(i2))
+
+
+def bind_blocks(blocks, prm, level: int = 1, nlevels: int = 1) -> None:
+    """blocks: {nn: Block}; binds each and commits it to flowDoms(nn,level,1)."""
+    alloc_doms(max(blocks), nlevels)
+    for nn, b in sorted(blocks.items()):
+        bind_block(b, prm)
+        commit_block(nn, level)

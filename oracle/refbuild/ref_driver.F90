@@ -14,12 +14,6 @@ module ref_driver
     use constants
     implicit none
 
-    ! scratch arrays the reference expects to be allocated but that carry no
-    ! information for a steady single-section block
-    integer(kind=intType), dimension(:, :, :), allocatable, target :: indFamI, indFamJ, indFamK
-    integer(kind=intType), dimension(:, :, :), allocatable, target :: facFamI, facFamJ, facFamK
-    ! no viscous subfaces in the synthetic blocks: all pointers 0 (preprocessingAPI.F90:2481-2486)
-    integer(kind=intType), dimension(:, :), allocatable, target :: vIminP, vImaxP, vJminP, vJmaxP, vKminP, vKmaxP
 
 contains
 
@@ -50,19 +44,6 @@ contains
         rightHanded = .true.
         blockIsMoving = .false.; addGridVelocities = .false.
         nBocos = 0; nViscBocos = 0; nSubface = 0; n1to1 = 0
-        if (allocated(indFamI)) deallocate (indFamI, indFamJ, indFamK, facFamI, facFamJ, facFamK)
-        allocate (indFamI(1:il, 2:jl, 2:kl), indFamJ(2:il, 1:jl, 2:kl), indFamK(2:il, 2:jl, 1:kl))
-        allocate (facFamI(1:il, 2:jl, 2:kl), facFamJ(2:il, 1:jl, 2:kl), facFamK(2:il, 2:jl, 1:kl))
-        indFamI = 0; indFamJ = 0; indFamK = 0; facFamI = 0; facFamJ = 0; facFamK = 0
-        indFamilyI => indFamI; indFamilyJ => indFamJ; indFamilyK => indFamK
-        factFamilyI => facFamI; factFamilyJ => facFamJ; factFamilyK => facFamK
-        if (allocated(vIminP)) deallocate (vIminP, vImaxP, vJminP, vJmaxP, vKminP, vKmaxP)
-        allocate (vIminP(2:jl, 2:kl), vImaxP(2:jl, 2:kl), vJminP(2:il, 2:kl), vJmaxP(2:il, 2:kl), &
-                  vKminP(2:il, 2:jl), vKmaxP(2:il, 2:jl))
-        vIminP = 0; vImaxP = 0; vJminP = 0; vJmaxP = 0; vKminP = 0; vKmaxP = 0
-        viscIminPointer => vIminP; viscImaxPointer => vImaxP
-        viscJminPointer => vJminP; viscJmaxPointer => vJmaxP
-        viscKminPointer => vKminP; viscKmaxPointer => vKmaxP
         if (.not. allocated(massFlowFamilyInv)) then
             allocate (massFlowFamilyInv(0:0, 1), massFlowFamilyDiss(0:0, 1))
         end if
@@ -88,6 +69,8 @@ contains
         real(kind=realType), dimension(:, :, :), pointer :: t3
         real(kind=realType), dimension(:, :, :, :), pointer :: t4
         integer(kind=intType), dimension(:, :, :), pointer :: i3
+        integer(kind=intType), dimension(:, :), pointer :: i2
+        real(kind=realType), dimension(:), pointer :: t1
         integer(kind=porType), dimension(:, :, :), pointer :: b3
         integer(kind=intType) :: nwl
         character(len=64) :: n
@@ -154,6 +137,48 @@ contains
         case ('iblank')
             call c_f_pointer(ptr, i3, [ib + 1, jb + 1, kb + 1])
             iblank(0:, 0:, 0:) => i3
+        case ('indFamilyI', 'factFamilyI')
+            call c_f_pointer(ptr, i3, [il, ny, nz])
+            if (trim(n) == 'indFamilyI') indFamilyI(1:, 2:, 2:) => i3
+            if (trim(n) == 'factFamilyI') factFamilyI(1:, 2:, 2:) => i3
+        case ('indFamilyJ', 'factFamilyJ')
+            call c_f_pointer(ptr, i3, [nx, jl, nz])
+            if (trim(n) == 'indFamilyJ') indFamilyJ(2:, 1:, 2:) => i3
+            if (trim(n) == 'factFamilyJ') factFamilyJ(2:, 1:, 2:) => i3
+        case ('indFamilyK', 'factFamilyK')
+            call c_f_pointer(ptr, i3, [nx, ny, kl])
+            if (trim(n) == 'indFamilyK') indFamilyK(2:, 2:, 1:) => i3
+            if (trim(n) == 'factFamilyK') factFamilyK(2:, 2:, 1:) => i3
+        case ('viscIminPointer', 'viscImaxPointer')
+            call c_f_pointer(ptr, i2, [ny, nz])
+            if (trim(n) == 'viscIminPointer') viscIminPointer(2:, 2:) => i2
+            if (trim(n) == 'viscImaxPointer') viscImaxPointer(2:, 2:) => i2
+        case ('viscJminPointer', 'viscJmaxPointer')
+            call c_f_pointer(ptr, i2, [nx, nz])
+            if (trim(n) == 'viscJminPointer') viscJminPointer(2:, 2:) => i2
+            if (trim(n) == 'viscJmaxPointer') viscJmaxPointer(2:, 2:) => i2
+        case ('viscKminPointer', 'viscKmaxPointer')
+            call c_f_pointer(ptr, i2, [nx, ny])
+            if (trim(n) == 'viscKminPointer') viscKminPointer(2:, 2:) => i2
+            if (trim(n) == 'viscKmaxPointer') viscKmaxPointer(2:, 2:) => i2
+        case ('mgIFine')   ! (1:ie,2) on the COARSE block (coarseUtils.F90:254)
+            call c_f_pointer(ptr, i2, [ie, 2]); mgIFine(1:, 1:) => i2
+        case ('mgJFine')
+            call c_f_pointer(ptr, i2, [je, 2]); mgJFine(1:, 1:) => i2
+        case ('mgKFine')
+            call c_f_pointer(ptr, i2, [ke, 2]); mgKFine(1:, 1:) => i2
+        case ('mgICoarse')  ! (2:il,2) on the FINE block
+            call c_f_pointer(ptr, i2, [nx, 2]); mgICoarse(2:, 1:) => i2
+        case ('mgJCoarse')
+            call c_f_pointer(ptr, i2, [ny, 2]); mgJCoarse(2:, 1:) => i2
+        case ('mgKCoarse')
+            call c_f_pointer(ptr, i2, [nz, 2]); mgKCoarse(2:, 1:) => i2
+        case ('mgIWeight')
+            call c_f_pointer(ptr, t1, [nx]); mgIWeight(2:) => t1
+        case ('mgJWeight')
+            call c_f_pointer(ptr, t1, [ny]); mgJWeight(2:) => t1
+        case ('mgKWeight')
+            call c_f_pointer(ptr, t1, [nz]); mgKWeight(2:) => t1
         case ('x')
             call c_f_pointer(ptr, t4, [ie + 1, je + 1, ke + 1, 3])
             x(0:, 0:, 0:, 1:) => t4
@@ -264,6 +289,7 @@ contains
         case ('turbTreatment'); turbTreatment = v
         case ('turbRelax'); turbRelax = v
         case ('nSubIterTurb'); nSubIterTurb = v
+        case ('nSubiterations'); nSubiterations = v
         case ('nTimeIntervalsSpectral'); nTimeIntervalsSpectral = v
         case ('timeIntegrationScheme'); timeIntegrationScheme = v
         case ('viscous'); viscous = (v /= 0)
@@ -477,5 +503,140 @@ contains
             call sumDwAndFw
         end if
     end subroutine ref_block_res_core
+
+
+    ! ===================================================================
+    ! multi-block mode: the reference's SHELL routines (smoothers, halo
+    ! exchange, multigrid) loop over flowDoms(nn,level,sps) and re-aim
+    ! blockPointers with utils::setPointers (utils.F90:3236).  ref_commit_block
+    ! stores the current blockPointers association into flowDoms(nn,level,1).
+    ! ===================================================================
+    subroutine ref_alloc_doms(nDom_, nLevels_) bind(C, name="ref_alloc_doms")
+        use block, only: flowDoms, nDom
+        use communication
+        use inputTimeSpectral, only: nTimeIntervalsSpectral
+        use inputIteration, only: nMGLevels
+        integer(c_int), value :: nDom_, nLevels_
+        integer :: l
+        if (allocated(flowDoms)) deallocate (flowDoms)
+        allocate (flowDoms(nDom_, nLevels_, 1))
+        nDom = nDom_
+        nTimeIntervalsSpectral = 1
+        nMGLevels = nLevels_
+        myID = 0; nProc = 1
+        if (allocated(commPatternCell_1st)) deallocate (commPatternCell_1st, commPatternCell_2nd, &
+                                                        internalCell_1st, internalCell_2nd)
+        allocate (commPatternCell_1st(nLevels_), commPatternCell_2nd(nLevels_), &
+                  internalCell_1st(nLevels_), internalCell_2nd(nLevels_))
+        if (allocated(commPatternOverset)) deallocate (commPatternOverset, internalOverset)
+        allocate (commPatternOverset(nLevels_, 1), internalOverset(nLevels_, 1))
+        do l = 1, nLevels_
+            commPatternCell_1st(l)%nProcSend = 0; commPatternCell_1st(l)%nProcRecv = 0; commPatternCell_1st(l)%nPeriodic = 0
+            commPatternCell_2nd(l)%nProcSend = 0; commPatternCell_2nd(l)%nProcRecv = 0; commPatternCell_2nd(l)%nPeriodic = 0
+            internalCell_1st(l)%ncopy = 0; internalCell_1st(l)%nPeriodic = 0
+            internalCell_2nd(l)%ncopy = 0; internalCell_2nd(l)%nPeriodic = 0
+            commPatternOverset(l, 1)%nProcSend = 0; commPatternOverset(l, 1)%nProcRecv = 0
+            commPatternOverset(l, 1)%nPeriodic = 0
+            internalOverset(l, 1)%ncopy = 0; internalOverset(l, 1)%nPeriodic = 0
+        end do
+        if (.not. allocated(sendBuffer)) then
+            allocate (sendBuffer(1), recvBuffer(1), sendRequests(1), recvRequests(1))
+        end if
+    end subroutine ref_alloc_doms
+
+    subroutine ref_commit_block(nn, level) bind(C, name="ref_commit_block")
+        use block, only: flowDoms
+        use blockPointers
+        integer(c_int), value :: nn, level
+        associate (d => flowDoms(nn, level, 1))
+            d%nx = nx; d%ny = ny; d%nz = nz
+            d%il = il; d%jl = jl; d%kl = kl
+            d%ie = ie; d%je = je; d%ke = ke
+            d%ib = ib; d%jb = jb; d%kb = kb
+            d%cgnsBlockID = 1
+            d%rightHanded = .true.
+            d%iBegor = 1; d%iEndor = il; d%jBegor = 1; d%jEndor = jl; d%kBegor = 1; d%kEndor = kl
+            d%nSubface = 0; d%n1to1 = 0; d%nBocos = 0; d%nViscBocos = 0
+            d%nOrphans = 0
+            d%blockIsMoving = .false.; d%addGridVelocities = .false.
+            d%iblank => iblank
+            d%viscIminPointer => viscIminPointer; d%viscImaxPointer => viscImaxPointer
+            d%viscJminPointer => viscJminPointer; d%viscJmaxPointer => viscJmaxPointer
+            d%viscKminPointer => viscKminPointer; d%viscKmaxPointer => viscKmaxPointer
+            d%x => x; d%si => si; d%sj => sj; d%sk => sk; d%vol => vol; d%volRef => volRef
+            d%porI => porI; d%porJ => porJ; d%porK => porK
+            d%indFamilyI => indFamilyI; d%indFamilyJ => indFamilyJ; d%indFamilyK => indFamilyK
+            d%factFamilyI => factFamilyI; d%factFamilyJ => factFamilyJ; d%factFamilyK => factFamilyK
+            d%w => w; d%p => p; d%aa => aa; d%gamma => gamma; d%rlv => rlv; d%rev => rev
+            d%ux => ux; d%uy => uy; d%uz => uz; d%vx => vx; d%vy => vy; d%vz => vz
+            d%wx => wx; d%wy => wy; d%wz => wz; d%qx => qx; d%qy => qy; d%qz => qz
+            d%dw => dw; d%fw => fw; d%scratch => scratch
+            d%p1 => p1; d%w1 => w1; d%wr => wr
+            d%wn => wn; d%pn => pn; d%dtl => dtl; d%radI => radI; d%radJ => radJ; d%radK => radK
+            d%d2Wall => d2Wall
+            d%bmti1 => bmti1; d%bmti2 => bmti2; d%bmtj1 => bmtj1; d%bmtj2 => bmtj2; d%bmtk1 => bmtk1; d%bmtk2 => bmtk2
+            d%bvti1 => bvti1; d%bvti2 => bvti2; d%bvtj1 => bvtj1; d%bvtj2 => bvtj2; d%bvtk1 => bvtk1; d%bvtk2 => bvtk2
+            d%mgIFine => mgIFine; d%mgJFine => mgJFine; d%mgKFine => mgKFine
+            d%mgIWeight => mgIWeight; d%mgJWeight => mgJWeight; d%mgKWeight => mgKWeight
+            d%mgICoarse => mgICoarse; d%mgJCoarse => mgJCoarse; d%mgKCoarse => mgKCoarse
+        end associate
+    end subroutine ref_commit_block
+
+    ! same-process 1-to-1 halo copy lists (communication.F90 internalCommType):
+    ! indices are 0-based cell indices exactly as the reference stores them
+    ! (the +1 offset is applied at use, haloExchange.F90:605-607)
+    subroutine ref_set_internal_comm(level, nLayers, ncopy, donorBlock, donorIdx, haloBlock, haloIdx) &
+        bind(C, name="ref_set_internal_comm")
+        use communication
+        integer(c_int), value :: level, nLayers, ncopy
+        integer(c_int), dimension(ncopy), intent(in) :: donorBlock, haloBlock
+        integer(c_int), dimension(ncopy, 3), intent(in) :: donorIdx, haloIdx
+        if (nLayers == 1) then
+            call fill(internalCell_1st(level))
+        else
+            call fill(internalCell_2nd(level))
+        end if
+    contains
+        subroutine fill(ic)
+            type(internalCommType), intent(inout) :: ic
+            ic%ncopy = ncopy
+            ic%nPeriodic = 0
+            allocate (ic%donorBlock(ncopy), ic%haloBlock(ncopy), ic%donorIndices(ncopy, 3), ic%haloIndices(ncopy, 3))
+            ic%donorBlock = donorBlock; ic%haloBlock = haloBlock
+            ic%donorIndices = donorIdx; ic%haloIndices = haloIdx
+        end subroutine fill
+    end subroutine ref_set_internal_comm
+
+    ! shell routines acting on every committed block of `level`
+    subroutine ref_call_level(name, level, i1, i2) bind(C, name="ref_call_level")
+        use iteration, only: currentLevel, groundLevel, rkStage
+        use flowVarRefState, only: nwf, nw, nt1, nt2
+        use haloExchange, only: whalo1, whalo2
+        use smoothers, only: RungeKuttaSmoother, DADISmoother
+        use solverUtils, only: timeStep
+        use residuals, only: initres, residual
+        use multiGrid, only: transferToCoarseGrid, transferToFineGrid
+        use utils, only: setPointers
+        character(kind=c_char), dimension(*), intent(in) :: name
+        integer(c_int), value :: level, i1, i2
+        character(len=64) :: n
+        n = cstr(name)
+        currentLevel = level
+        select case (trim(n))
+        case ('setPointers'); call setPointers(i1, level, 1_intType)
+        case ('whalo2'); call whalo2(level, i1, i2, .true., .true., .true.)         ! haloExchange.F90:109
+        case ('whalo1'); call whalo1(level, i1, i2, .true., .true., .true.)         ! haloExchange.F90:5
+        case ('timeStep'); call timeStep(i1 /= 0)                                     ! solverUtils.F90:4
+        case ('initres'); call initres(i1, i2)                                        ! residuals.F90:964
+        case ('residual'); call residual                                              ! residuals.F90:1028
+        case ('RungeKuttaSmoother'); call RungeKuttaSmoother                          ! smoothers.F90:4
+        case ('DADISmoother'); call DADISmoother                                      ! smoothers.F90:383
+        case ('transferToCoarseGrid'); call transferToCoarseGrid                      ! multiGrid.F90:5
+        case ('transferToFineGrid'); call transferToFineGrid(i1 /= 0)                 ! multiGrid.F90:326
+        case default
+            print *, 'ref_call_level: unknown routine ', trim(n)
+            stop 1
+        end select
+    end subroutine ref_call_level
 
 end module ref_driver

@@ -84,6 +84,12 @@ double shfl_exchange(double v, int srcLaneInBlock);   // block-convergent
     hostsim::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
 
 inline void __syncthreads() { hostsim::syncthreads(); }
+inline double atomicAdd(double* p, double v) {
+    double old;
+#pragma omp critical(hostsim_atomic)
+    { old = *p; *p = old + v; }
+    return old;
+}
 inline int hostsim_lane() { return (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)); }
 inline double __shfl(double v, int srcLane, int width = 64) {
     const int me = hostsim_lane();

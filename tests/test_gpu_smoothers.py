@@ -1,0 +1,57 @@
+"""GPU parity (real MI355X, through the C-ABI): halo exchange, Runge-Kutta and
+D-ADI smoother sweeps against the reference's own shell routines
+(haloExchange.F90 whalo1/whalo2, smoothers.F90 RungeKuttaSmoother/DADISmoother)
+on periodic bricks of blocks (no physical boundaries)."""
+import pytest
+
+import checks
+from adflow_amd.params import (FlowParams, NSEquations, RANSEquations, noResAveraging, alternateResAveraging,
+                               alwaysResAveraging, dissMatrix, upwind)
+from adflow_amd.topology import BrickTopology
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nLayers", [1, 2])
+def test_halo_exchange_same_gpu(engine, nLayers):
+    checks.check_halo_exchange(engine, BrickTopology(2, 2, 1, 8, 6, 5), FlowParams(equations=RANSEquations), nLayers)
+
+
+def test_halo_exchange_self_periodic_single_block(engine):
+    checks.check_halo_exchange(engine, BrickTopology(1, 1, 1, 7, 5, 3), FlowParams(), 2)
+
+
+@pytest.mark.parametrize("resavg", [noResAveraging, alternateResAveraging, alwaysResAveraging])
+def test_rk_smoother_euler(engine, resavg):
+    checks.check_rk_smoother(engine, BrickTopology(2, 1, 1, 16, 12, 8), FlowParams(resAveraging=resavg), nsweeps=2)
+
+
+def test_rk_smoother_multiblock_tutorial_wing_size(engine):
+    # BASELINE config 2 parity size: 6 blocks, ~12 096 cells
+    checks.check_rk_smoother(engine, BrickTopology(3, 2, 1, 16, 14, 9), FlowParams(), nsweeps=2)
+
+
+@pytest.mark.parametrize("sd", [dissMatrix, upwind])
+def test_rk_smoother_other_schemes(engine, sd):
+    checks.check_rk_smoother(engine, BrickTopology(2, 1, 1, 10, 8, 6), FlowParams(spaceDiscr=sd, resAveraging=noResAveraging))
+
+
+def test_rk_smoother_rans(engine):
+    checks.check_rk_smoother(engine, BrickTopology(2, 1, 1, 12, 10, 8),
+                             FlowParams(equations=RANSEquations, resAveraging=noResAveraging), stretch_k=2.0)
+
+
+def test_dadi_smoother_euler(engine):
+    checks.check_dadi_smoother(engine, BrickTopology(2, 1, 1, 12, 10, 8), FlowParams(resAveraging=noResAveraging, cfl=1.5),
+                               nsweeps=2)
+
+
+def test_dadi_smoother_rans_tutorial_wing_config(engine):
+    # BASELINE config 3: RANS-SA, D-ADI, nSubiter = 3, cfl 1.5, no residual averaging
+    prm = FlowParams(equations=RANSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=3)
+    checks.check_dadi_smoother(engine, BrickTopology(2, 2, 1, 12, 10, 8), prm, stretch_k=2.5)
+
+
+def test_dadi_degenerate_lines(engine):
+    prm = FlowParams(equations=NSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2)
+    checks.check_dadi_smoother(engine, BrickTopology(1, 1, 2, 5, 1, 4), prm, stretch_k=2.0)

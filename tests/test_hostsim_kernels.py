@@ -53,3 +53,29 @@ def test_rans_sa_options(hostsim_engine):
 
 def test_rans_rk_stage_residuals(hostsim_engine):
     checks.check_rk_residual_sequence(hostsim_engine, (8, 6, 5), FlowParams(equations=NSEquations), stretch_k=2.0)
+
+
+# ---- shell routines: halo exchange and smoothers on periodic bricks -------------
+from adflow_amd.params import noResAveraging, alternateResAveraging  # noqa: E402
+from adflow_amd.topology import BrickTopology  # noqa: E402
+
+
+@pytest.mark.parametrize("nLayers", [1, 2])
+def test_halo_exchange(hostsim_engine, nLayers):
+    checks.check_halo_exchange(hostsim_engine, BrickTopology(2, 2, 1, 5, 4, 3), FlowParams(equations=RANSEquations), nLayers)
+
+
+@pytest.mark.parametrize("resavg", [noResAveraging, alternateResAveraging])
+def test_rk_smoother(hostsim_engine, resavg):
+    checks.check_rk_smoother(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams(resAveraging=resavg))
+
+
+def test_rk_smoother_rans(hostsim_engine):
+    checks.check_rk_smoother(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
+                             FlowParams(equations=RANSEquations, resAveraging=noResAveraging), stretch_k=2.0)
+
+
+def test_dadi_smoother(hostsim_engine):
+    checks.check_dadi_smoother(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams(resAveraging=noResAveraging, cfl=1.5))
+    prm = FlowParams(equations=RANSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=3)
+    checks.check_dadi_smoother(hostsim_engine, BrickTopology(1, 1, 2, 5, 1, 4), prm, stretch_k=2.0)
