@@ -93,7 +93,7 @@ EXPORTS = [
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
     "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
-    "adflow_gpu_abi_sizes",
+    "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
 ]
 
 _libs = {}
@@ -127,6 +127,7 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_residual.argtypes = [c_int, c_int]
     lib.adflow_gpu_block_res.argtypes = [c_int, c_uint]
     lib.adflow_gpu_set_async.argtypes = [c_int]
+    lib.adflow_gpu_set_tuning.argtypes = [c_char_p, c_int]
     lib.adflow_gpu_abi_sizes.argtypes = [POINTER(c_int), POINTER(c_int)]
     lib.adflow_gpu_rk_smooth.argtypes = [c_int]
     lib.adflow_gpu_dadi_smooth.argtypes = [c_int]

@@ -14,6 +14,8 @@
 
 #include "internal.h"
 
+extern int g_march_minw;
+
 namespace {
 
 std::string g_err;
@@ -81,6 +83,8 @@ struct CommPattern {
 std::map<std::pair<int, int>, CommPattern> g_comm;   // (level, nLayers)
 std::map<int, BlkView*> g_tab;                        // level -> device table indexed by nn
 std::map<int, int> g_tab_size;
+std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
+bool g_use_march = true;                               // tuning: adflow_gpu_set_tuning("euler_march", 0|1)
 adflow_bc_callback g_bc_callback = nullptr;
 double* g_norm_dev = nullptr;
 
@@ -110,8 +114,16 @@ void invalidate_comm_level(int level)
         (void)hipFree(it->second);
         g_tab.erase(it);
     }
+    auto jt = g_tiles.find(level);
+    if (jt != g_tiles.end()) {
+        (void)hipFree(jt->second.first);
+        g_tiles.erase(jt);
+    }
 }
 
+
+int ensure_table(int level);
+int ensure_tiles(int level);
 
 Block* find_block(int nn, int level, int sps)
 {
@@ -587,6 +599,17 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
 
 static int enqueue_flow_residual(int level, const KParams& kp)
 {
+    if (g_use_march && !kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR) {
+        // Euler + scalar JST: one k-marching launch over every block of the level
+        int rc = for_level(level, [&](Block* b) {
+            if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
+            return 0;
+        });
+        if (rc) return rc;
+        if (ensure_tiles(level)) return 1;
+        launch_euler_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
+        return 0;
+    }
     return for_level(level, [&](Block* b) {
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
         if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
@@ -673,6 +696,43 @@ int ensure_table(int level)
     HIPCHK(hipMemcpy(d, h.data(), sizeof(BlkView) * h.size(), hipMemcpyHostToDevice));
     g_tab[level] = d;
     g_tab_size[level] = maxnn;
+    return 0;
+}
+
+// tile table of the k-marching Euler kernel for every block of a level.  The
+// dispatcher places workgroup p on XCD p % 8 (MI355X_MICROARCH.md): entry p holds
+// the tile  (p % 8) * ceil(n/8) + p / 8  of the natural order (i-tile fastest, then
+// j, k, block) so that each XCD owns one contiguous slab and j/k-neighbouring tiles
+// share its 4 MiB L2.
+int ensure_tiles(int level)
+{
+    if (g_tiles.count(level)) return 0;
+    if (ensure_table(level)) return 1;
+    std::vector<int4> nat;
+    for (auto& kv : g_blocks) {
+        if (std::get<0>(kv.first) != level || std::get<1>(kv.first) != 1) continue;
+        int ntx, nty, ntz;
+        euler_march_tiles(kv.second->v, &ntx, &nty, &ntz);
+        for (int tz = 0; tz < ntz; ++tz)
+            for (int ty = 0; ty < nty; ++ty)
+                for (int tx = 0; tx < ntx; ++tx) {
+                    int4 t;
+                    t.x = std::get<2>(kv.first); t.y = tx; t.z = ty; t.w = tz;
+                    nat.push_back(t);
+                }
+    }
+    const int n = (int)nat.size();
+    const int per = (n + 7) / 8;
+    std::vector<int4> phys((size_t)per * 8);
+    for (int p = 0; p < per * 8; ++p) {
+        const int L = (p % 8) * per + p / 8;
+        if (L < n) phys[p] = nat[L];
+        else { phys[p].x = -1; phys[p].y = phys[p].z = phys[p].w = 0; }
+    }
+    int4* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(int4) * phys.size()));
+    HIPCHK(hipMemcpy(d, phys.data(), sizeof(int4) * phys.size(), hipMemcpyHostToDevice));
+    g_tiles[level] = std::make_pair(d, (int)phys.size());
     return 0;
 }
 
@@ -1072,6 +1132,14 @@ int adflow_gpu_sync(void)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g_stream));
     return 0;
+}
+
+int adflow_gpu_set_tuning(const char* key, int value)
+{
+    if (!key) return fail("null tuning key");
+    if (!strcmp(key, "euler_march")) { g_use_march = (value != 0); return 0; }
+    if (!strcmp(key, "march_minw")) { g_march_minw = value; return 0; }
+    return fail("unknown tuning key '%s'", key);
 }
 
 int adflow_gpu_set_async(int on)

@@ -17,6 +17,28 @@
 
 #define ADF_PAD0 14   // (PAD0 + 2) % 16 == 0
 
+// pointer into HBM with an explicit global address space: pointers that reach a
+// kernel through a table in memory are "generic" to the compiler and would be
+// accessed with the slower flat_load/flat_store forms.
+#ifdef HOSTSIM
+#define GPTR(T) T*
+#else
+#define GPTR(T) T __attribute__((address_space(1)))*
+#endif
+
+// element access through a uniform base pointer and a 32-bit BYTE offset: the
+// form `global_load v, v_off, s[base]` (scalar base + 32-bit vector offset) that
+// needs no 64-bit address arithmetic per access.  Valid while one component of
+// one block stays below 4 GiB (512 M doubles).
+__device__ __forceinline__ double ldg(GPTR(const double) base, unsigned byteoff)
+{
+    return *(GPTR(const double))((GPTR(const char))base + byteoff);
+}
+__device__ __forceinline__ void stg(GPTR(double) base, unsigned byteoff, double v)
+{
+    *(GPTR(double))((GPTR(char))base + byteoff) = v;
+}
+
 struct BlkView {
     int nx, ny, nz, nw;
     int il, jl, kl, ie, je, ke, ib, jb, kb;
@@ -87,4 +109,6 @@ void launch_halo_copy(const BlkView* tab, const int* donorBlk, const long* donor
 void launch_halo_pack(const BlkView* tab, const int* blk, const long* off, int n, unsigned mask, double* buf, hipStream_t s);
 void launch_halo_unpack(const BlkView* tab, const int* blk, const long* off, int n, unsigned mask, const double* buf,
                         hipStream_t s);
+void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);

@@ -62,9 +62,13 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(BlkView b, KParams k
         ri = fmax(ri, epsr);
         rj = fmax(rj, epsr);
         rk = fmax(rk, epsr);
-        const double rij = pow(ri / rj, kp.adis);
-        const double rjk = pow(rj / rk, kp.adis);
-        const double rki = pow(rk / ri, kp.adis);
+        // (ri/rj)**adis etc. (solverUtils.F90:187-199) through one logarithm per
+        // radius: x**a = exp(a (log xi - log xj)); the three FP64 pow calls of the
+        // straightforward form made this kernel VALU-bound (profiles/r01_b_*).
+        const double li = log(ri), lj = log(rj), lk = log(rk);
+        const double rij = exp(kp.adis * (li - lj));
+        const double rjk = exp(kp.adis * (lj - lk));
+        const double rki = exp(kp.adis * (lk - li));
         b.radI[c] = ri * (1.0 + 1.0 / rij + rki);
         b.radJ[c] = rj * (1.0 + 1.0 / rjk + rij);
         b.radK[c] = rk * (1.0 + 1.0 / rki + rjk);

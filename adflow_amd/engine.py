@@ -108,6 +108,9 @@ class Engine:
             | (capi.RES_TURB if turbRes else 0)
         self._chk(self.lib.adflow_gpu_block_res(level, flags))
 
+    def set_tuning(self, key: str, value: int):
+        self._chk(self.lib.adflow_gpu_set_tuning(key.encode(), int(value)))
+
     def set_async(self, on: bool):
         """Entry points only enqueue on the library stream; order with sync()."""
         self._chk(self.lib.adflow_gpu_set_async(int(on)))

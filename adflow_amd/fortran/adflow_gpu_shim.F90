@@ -1,0 +1,265 @@
+! adflow_gpu_shim.F90 — ISO_C_BINDING interface to the C-ABI of include/adflow_gpu.h
+! plus the glue that fills its two structs from the reference's own modules.
+!
+! This file is what a maintainer ADDS to the reference tree (src/gpu/, listed in
+! src/build/fileList after modules/ and utils/); it `use`s the reference's
+! modules and therefore only compiles inside that tree (oracle/refbuild proves
+! it does: `make -C oracle/refbuild shim` compiles it against the reference's
+! .mod files with amdflang).  INTEGRATION.md shows the call-site edits.
+module adflowGpuShim
+    use iso_c_binding
+    use constants
+    implicit none
+
+    ! ---- mirror of adflow_opts (include/adflow_gpu.h) -----------------------
+    type, bind(C) :: adflow_opts
+        integer(c_int32_t) :: equations, turbModel, turbProd
+        integer(c_int32_t) :: useQCR, useRotationSA, useft2SA
+        integer(c_int32_t) :: spaceDiscr, spaceDiscrCoarse, limiter, orderTurb
+        integer(c_int32_t) :: dirScaling
+        integer(c_int32_t) :: smoother, nRKStages, resAveraging, nSubiterations, nSubIterTurb
+        integer(c_int32_t) :: groundLevel
+        integer(c_int32_t) :: reserved_i(3)
+        real(c_double) :: gammaConstant, prandtl, prandtlTurb
+        real(c_double) :: SSuthDim, muSuthDim, TSuthDim
+        real(c_double) :: SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot
+        real(c_double) :: vis2, vis4, vis2Coarse, adis, acousticScaleFactor, kappaCoef
+        real(c_double) :: cfl, cflCoarse, cflLimit, fcoll, smoop, alfaTurb, betaTurb, turbResScale
+        real(c_double) :: etaRK(8), cdisRK(8)
+        real(c_double) :: gammaInf, pInf, pInfCorr, rhoInf, uInf, RGas, muInf, muRef, TRef, timeRef
+        real(c_double) :: wInf(10)
+        real(c_double) :: reserved_d(8)
+    end type adflow_opts
+
+    ! ---- mirror of adflow_block_desc ----------------------------------------
+    type, bind(C) :: adflow_block_desc
+        integer(c_int32_t) :: nx, ny, nz, nw, rightHanded, reserved
+        type(c_ptr) :: w, p, gamma, rlv, rev
+        type(c_ptr) :: x, sI, sJ, sK, vol, volRef, d2Wall
+        type(c_ptr) :: porI, porJ, porK, iblank
+        type(c_ptr) :: dw, fw, dtl, radI, radJ, radK
+        type(c_ptr) :: w1, p1, wr
+    end type adflow_block_desc
+
+    ! ---- mirror of adflow_comm_pattern ---------------------------------------
+    type, bind(C) :: adflow_comm_pattern
+        integer(c_int32_t) :: ncopy
+        type(c_ptr) :: donorBlock, donorIndices, haloBlock, haloIndices
+        integer(c_int32_t) :: nProcSend
+        type(c_ptr) :: sendProc, nsendCum, sendBlock, sendIndices
+        integer(c_int32_t) :: nProcRecv
+        type(c_ptr) :: recvProc, nrecvCum, recvBlock, recvIndices
+    end type adflow_comm_pattern
+
+    interface
+        integer(c_int) function adflow_gpu_comm_register(level, nLayers, p) bind(C, name="adflow_gpu_comm_register")
+            import :: c_int, adflow_comm_pattern
+            integer(c_int), value :: level, nLayers
+            type(adflow_comm_pattern), intent(in) :: p
+        end function
+        integer(c_int) function adflow_gpu_init(device) bind(C, name="adflow_gpu_init")
+            import :: c_int
+            integer(c_int), value :: device
+        end function
+        integer(c_int) function adflow_gpu_finalize() bind(C, name="adflow_gpu_finalize")
+            import :: c_int
+        end function
+        type(c_ptr) function adflow_gpu_last_error() bind(C, name="adflow_gpu_last_error")
+            import :: c_ptr
+        end function
+        integer(c_int) function adflow_gpu_set_options(o) bind(C, name="adflow_gpu_set_options")
+            import :: c_int, adflow_opts
+            type(adflow_opts), intent(in) :: o
+        end function
+        integer(c_int) function adflow_gpu_block_register(nn, level, sps, d) bind(C, name="adflow_gpu_block_register")
+            import :: c_int, adflow_block_desc
+            integer(c_int), value :: nn, level, sps
+            type(adflow_block_desc), intent(in) :: d
+        end function
+        integer(c_int) function adflow_gpu_upload_geometry(nn, level, sps) bind(C, name="adflow_gpu_upload_geometry")
+            import :: c_int
+            integer(c_int), value :: nn, level, sps
+        end function
+        integer(c_int) function adflow_gpu_upload_state(nn, level, sps) bind(C, name="adflow_gpu_upload_state")
+            import :: c_int
+            integer(c_int), value :: nn, level, sps
+        end function
+        integer(c_int) function adflow_gpu_download_state(nn, level, sps) bind(C, name="adflow_gpu_download_state")
+            import :: c_int
+            integer(c_int), value :: nn, level, sps
+        end function
+        integer(c_int) function adflow_gpu_download_residual(nn, level, sps) bind(C, name="adflow_gpu_download_residual")
+            import :: c_int
+            integer(c_int), value :: nn, level, sps
+        end function
+        integer(c_int) function adflow_gpu_time_step(level, onlyRadii) bind(C, name="adflow_gpu_time_step")
+            import :: c_int
+            integer(c_int), value :: level, onlyRadii
+        end function
+        integer(c_int) function adflow_gpu_initres(level, varStart, varEnd) bind(C, name="adflow_gpu_initres")
+            import :: c_int
+            integer(c_int), value :: level, varStart, varEnd
+        end function
+        integer(c_int) function adflow_gpu_residual(level, rkStage) bind(C, name="adflow_gpu_residual")
+            import :: c_int
+            integer(c_int), value :: level, rkStage
+        end function
+        integer(c_int) function adflow_gpu_block_res(level, flags) bind(C, name="adflow_gpu_block_res")
+            import :: c_int
+            integer(c_int), value :: level, flags
+        end function
+        integer(c_int) function adflow_gpu_rk_smooth(level) bind(C, name="adflow_gpu_rk_smooth")
+            import :: c_int
+            integer(c_int), value :: level
+        end function
+        integer(c_int) function adflow_gpu_dadi_smooth(level) bind(C, name="adflow_gpu_dadi_smooth")
+            import :: c_int
+            integer(c_int), value :: level
+        end function
+        integer(c_int) function adflow_gpu_halo_exchange(level, varStart, varEnd, commPressure, commVisc, nLayers) &
+            bind(C, name="adflow_gpu_halo_exchange")
+            import :: c_int
+            integer(c_int), value :: level, varStart, varEnd, commPressure, commVisc, nLayers
+        end function
+        integer(c_int) function adflow_gpu_res_norms(level, sums, n) bind(C, name="adflow_gpu_res_norms")
+            import :: c_int, c_double
+            integer(c_int), value :: level, n
+            real(c_double), intent(out) :: sums(*)
+        end function
+    end interface
+
+contains
+
+    ! forward a library error to the reference's own error path (utils.F90:501)
+    subroutine gpuCheck(ierr, routine)
+        use utils, only: terminate
+        integer(c_int), intent(in) :: ierr
+        character(len=*), intent(in) :: routine
+        character(kind=c_char), pointer :: cmsg(:)
+        character(len=512) :: msg
+        integer :: i
+        if (ierr == 0) return
+        call c_f_pointer(adflow_gpu_last_error(), cmsg, [512])
+        msg = ' '
+        do i = 1, 512
+            if (cmsg(i) == c_null_char) exit
+            msg(i:i) = cmsg(i)
+        end do
+        call terminate(routine, trim(msg))
+    end subroutine gpuCheck
+
+    ! snapshot of the module variables the hot path reads (what Python may have
+    ! reassigned through f2py since the last call, pyADflow.py:5463-5630)
+    subroutine gpuRefreshOptions()
+        use inputPhysics
+        use inputDiscretization
+        use inputIteration
+        use iteration, only: groundLevel
+        use flowVarRefState
+        use paramTurb, only: rsaCw1
+        type(adflow_opts) :: o
+        integer :: n
+        o%equations = equations; o%turbModel = turbModel; o%turbProd = turbProd
+        o%useQCR = merge(1, 0, useQCR); o%useRotationSA = merge(1, 0, useRotationSA); o%useft2SA = merge(1, 0, useft2SA)
+        o%spaceDiscr = spaceDiscr; o%spaceDiscrCoarse = spaceDiscrCoarse; o%limiter = limiter; o%orderTurb = orderTurb
+        o%dirScaling = merge(1, 0, dirScaling)
+        o%smoother = smoother; o%nRKStages = nRKStages; o%resAveraging = resAveraging
+        o%nSubiterations = nSubiterations; o%nSubIterTurb = nSubIterTurb
+        o%groundLevel = groundLevel
+        o%reserved_i = 0
+        o%gammaConstant = gammaConstant; o%prandtl = prandtl; o%prandtlTurb = prandtlTurb
+        o%SSuthDim = SSuthDim; o%muSuthDim = muSuthDim; o%TSuthDim = TSuthDim
+        o%SAKappa = SAKappa; o%SAcb1 = SAcb1; o%SAcb2 = SAcb2; o%SAsigma = SAsigma; o%SAcv1 = SAcv1
+        o%SAcw1 = rsaCw1; o%SAcw2 = SAcw2; o%SAcw3 = SAcw3
+        o%SAct1 = SAct1; o%SAct2 = SAct2; o%SAct3 = SAct3; o%SAct4 = SAct4; o%SAcrot = SAcrot
+        o%vis2 = vis2; o%vis4 = vis4; o%vis2Coarse = vis2Coarse; o%adis = adis
+        o%acousticScaleFactor = acousticScaleFactor; o%kappaCoef = kappaCoef
+        o%cfl = cfl; o%cflCoarse = cflCoarse; o%cflLimit = cflLimit; o%fcoll = fcoll; o%smoop = smoop
+        o%alfaTurb = alfaTurb; o%betaTurb = betaTurb; o%turbResScale = turbResScale(1)
+        o%etaRK = zero; o%cdisRK = zero
+        n = min(nRKStages, 8)
+        if (allocated(etaRK)) o%etaRK(1:n) = etaRK(1:n)
+        if (allocated(cdisRK)) o%cdisRK(1:n) = cdisRK(1:n)
+        o%gammaInf = gammaInf; o%pInf = pInf; o%pInfCorr = pInfCorr; o%rhoInf = rhoInf; o%uInf = uInf
+        o%RGas = RGas; o%muInf = muInf; o%muRef = muRef; o%TRef = TRef; o%timeRef = timeRef
+        o%wInf = zero
+        if (allocated(wInf)) o%wInf(1:size(wInf)) = wInf
+        o%reserved_d = zero
+        call gpuCheck(adflow_gpu_set_options(o), "gpuRefreshOptions")
+    end subroutine gpuRefreshOptions
+
+    ! flowDoms(nn,level,sps) -> device mirror.  All targets are contiguous
+    ! `allocate`d arrays (SURVEY.md §8(a) row T) so c_loc is legal.
+    subroutine gpuRegisterBlock(nn, level, sps)
+        use block, only: flowDoms
+        use flowVarRefState, only: nw
+        integer(kind=intType), intent(in) :: nn, level, sps
+        type(adflow_block_desc) :: d
+        associate (b => flowDoms(nn, level, sps), b1 => flowDoms(nn, 1, sps), g => flowDoms(nn, level, 1))
+            d%nx = b%nx; d%ny = b%ny; d%nz = b%nz; d%nw = nw
+            d%rightHanded = merge(1, 0, b%rightHanded); d%reserved = 0
+            d%w = c_loc(b%w); d%p = c_loc(b%p)
+            d%gamma = c_loc(b1%gamma); d%rlv = c_loc(b1%rlv); d%rev = c_null_ptr
+            if (associated(b%rev)) d%rev = c_loc(b%rev)
+            d%x = c_loc(b%x); d%sI = c_loc(b%sI); d%sJ = c_loc(b%sJ); d%sK = c_loc(b%sK)
+            d%vol = c_loc(b%vol); d%volRef = c_null_ptr; d%d2Wall = c_null_ptr
+            if (associated(b%volRef)) d%volRef = c_loc(b%volRef)
+            if (associated(b%d2Wall)) d%d2Wall = c_loc(b%d2Wall)
+            d%porI = c_loc(g%porI); d%porJ = c_loc(g%porJ); d%porK = c_loc(g%porK)
+            d%iblank = c_loc(b%iblank)
+            d%dw = c_loc(b1%dw); d%fw = c_loc(b1%fw); d%dtl = c_loc(b1%dtl)
+            d%radI = c_loc(b1%radI); d%radJ = c_loc(b1%radJ); d%radK = c_loc(b1%radK)
+            d%w1 = c_null_ptr; d%p1 = c_null_ptr; d%wr = c_null_ptr
+            if (level > 1) then
+                d%w1 = c_loc(b%w1); d%p1 = c_loc(b%p1); d%wr = c_loc(b%wr)
+            end if
+        end associate
+        call gpuCheck(adflow_gpu_block_register(int(nn, c_int), int(level, c_int), int(sps, c_int), d), "gpuRegisterBlock")
+        call gpuCheck(adflow_gpu_upload_geometry(int(nn, c_int), int(level, c_int), int(sps, c_int)), "gpuRegisterBlock")
+    end subroutine gpuRegisterBlock
+
+    ! commPatternCell_{1st,2nd}(level) + internalCell_{1st,2nd}(level) -> adflow_comm_pattern
+    ! (src/modules/communication.F90).  Pure flattening: index values are passed as stored.
+    subroutine gpuRegisterComm(level, nLayers, cp, ic)
+        use communication, only: commType, internalCommType
+        integer(kind=intType), intent(in) :: level, nLayers
+        type(commType), intent(in) :: cp
+        type(internalCommType), intent(in) :: ic
+        type(adflow_comm_pattern) :: p
+        integer(c_int32_t), allocatable, target :: sendBlock(:), sendIdx(:, :), recvBlock(:), recvIdx(:, :)
+        integer(c_int32_t), allocatable, target :: nsc(:), nrc(:), sp(:), rp(:)
+        integer(c_int32_t), allocatable, target :: dB(:), dI(:, :), hB(:), hI(:, :)
+        integer :: i, n0, n1, nst, nrt
+        nst = 0; nrt = 0
+        if (cp%nProcSend > 0) nst = cp%nsendCum(cp%nProcSend)
+        if (cp%nProcRecv > 0) nrt = cp%nrecvCum(cp%nProcRecv)
+        allocate (sendBlock(nst), sendIdx(nst, 3), recvBlock(nrt), recvIdx(nrt, 3))
+        allocate (nsc(0:cp%nProcSend), nrc(0:cp%nProcRecv), sp(cp%nProcSend), rp(cp%nProcRecv))
+        nsc(0) = 0; nrc(0) = 0
+        do i = 1, cp%nProcSend
+            n0 = cp%nsendCum(i - 1); n1 = cp%nsendCum(i)
+            sp(i) = cp%sendProc(i); nsc(i) = n1
+            sendBlock(n0 + 1:n1) = cp%sendList(i)%block(1:n1 - n0)
+            sendIdx(n0 + 1:n1, :) = cp%sendList(i)%indices(1:n1 - n0, :)
+        end do
+        do i = 1, cp%nProcRecv
+            n0 = cp%nrecvCum(i - 1); n1 = cp%nrecvCum(i)
+            rp(i) = cp%recvProc(i); nrc(i) = n1
+            recvBlock(n0 + 1:n1) = cp%recvList(i)%block(1:n1 - n0)
+            recvIdx(n0 + 1:n1, :) = cp%recvList(i)%indices(1:n1 - n0, :)
+        end do
+        allocate (dB(ic%ncopy), dI(ic%ncopy, 3), hB(ic%ncopy), hI(ic%ncopy, 3))
+        if (ic%ncopy > 0) then
+            dB = ic%donorBlock(1:ic%ncopy); dI = ic%donorIndices(1:ic%ncopy, :)
+            hB = ic%haloBlock(1:ic%ncopy); hI = ic%haloIndices(1:ic%ncopy, :)
+        end if
+        p%ncopy = ic%ncopy
+        p%donorBlock = c_loc(dB); p%donorIndices = c_loc(dI); p%haloBlock = c_loc(hB); p%haloIndices = c_loc(hI)
+        p%nProcSend = cp%nProcSend; p%sendProc = c_loc(sp); p%nsendCum = c_loc(nsc)
+        p%sendBlock = c_loc(sendBlock); p%sendIndices = c_loc(sendIdx)
+        p%nProcRecv = cp%nProcRecv; p%recvProc = c_loc(rp); p%nrecvCum = c_loc(nrc)
+        p%recvBlock = c_loc(recvBlock); p%recvIndices = c_loc(recvIdx)
+        call gpuCheck(adflow_gpu_comm_register(int(level, c_int), int(nLayers, c_int), p), "gpuRegisterComm")
+    end subroutine gpuRegisterComm
+
+end module adflowGpuShim

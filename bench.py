@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="euler_jst_8x128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +113,10 @@ def main():
     prm = FlowParams(equations=wl["equations"], spaceDiscr=wl["spaceDiscr"])
     eng = Engine(local_rank)
     eng.set_options(prm)
+    tuning = dict(kv.split("=") for kv in a.tuning)
+    for k_, v_ in tuning.items():
+        eng.set_tuning(k_, int(v_))
+    march = int(tuning.get("euler_march", 1)) and wl["equations"] == 1 and wl["spaceDiscr"] == 1
     # weak scaling: every GPU owns `nblocks` blocks of the workload
     nb = wl["nblocks"]
     cells_local = 0
@@ -155,7 +160,9 @@ def main():
         eng.residual(1, 0)
     eng.event_record(3)
     eng.sync()
-    k_ms = eng.event_elapsed_ms(2, 3) / (a.steps * nb)   # per launch (one launch = one block)
+    # the k-marching Euler kernel covers all blocks of the level in ONE launch
+    launches_per_step = 1 if march else nb
+    k_ms = eng.event_elapsed_ms(2, 3) / (a.steps * launches_per_step)
     eng.set_async(False)
 
     if world > 1:
@@ -167,7 +174,7 @@ def main():
 
     out = None
     if rank == 0:
-        cells_per_launch = cells_local / nb
+        cells_per_launch = cells_local / launches_per_step
         alg_bytes = wl["bytes_per_cell"] * cells_per_launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
@@ -179,7 +186,7 @@ def main():
                        "cells_per_gpu": cells_local, "device": eng.device_name()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_inviscid_scalar", "kernel_ms": k_ms,
+                         "kernel": "k_euler_march" if march else "k_inviscid", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "whole_eval": {"event_ms_per_step": ev_ms / a.steps,
                            "hbm_frac": wl["bytes_per_cell"] * cells_local / (ev_ms / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS},

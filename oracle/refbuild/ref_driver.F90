@@ -639,4 +639,16 @@ contains
         end select
     end subroutine ref_call_level
 
+
+    ! sizes of the ISO_C_BINDING mirrors in adflow_amd/fortran/adflow_gpu_shim.F90
+    ! (compiled here against the reference's modules) for the ABI cross-check
+    subroutine ref_shim_sizes(opts_bytes, desc_bytes) bind(C, name="ref_shim_sizes")
+        use adflowGpuShim, only: adflow_opts, adflow_block_desc
+        integer(c_int), intent(out) :: opts_bytes, desc_bytes
+        type(adflow_opts) :: o
+        type(adflow_block_desc) :: d
+        opts_bytes = int(c_sizeof(o), c_int)
+        desc_bytes = int(c_sizeof(d), c_int)
+    end subroutine ref_shim_sizes
+
 end module ref_driver

@@ -36,6 +36,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint3_ { unsigned x, y, z; };
+struct int4 { int x, y, z, w; };
 extern thread_local uint3_ threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
 
@@ -108,6 +109,8 @@ inline double __shfl_down(double v, unsigned delta, int width = 64) {
     const int src = (l + (int)delta < width) ? me + (int)delta : me;
     return hostsim::shfl_exchange(v, src);
 }
+inline int __shfl_up(int v, unsigned delta, int width = 64) { return (int)__shfl_up((double)v, delta, width); }
+inline int __shfl_down(int v, unsigned delta, int width = 64) { return (int)__shfl_down((double)v, delta, width); }
 inline double __shfl_xor(double v, int mask, int width = 64) {
     const int me = hostsim_lane();
     const int base = (me / width) * width;

@@ -79,3 +79,20 @@ def test_dadi_smoother(hostsim_engine):
     checks.check_dadi_smoother(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams(resAveraging=noResAveraging, cfl=1.5))
     prm = FlowParams(equations=RANSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=3)
     checks.check_dadi_smoother(hostsim_engine, BrickTopology(1, 1, 2, 5, 1, 4), prm, stretch_k=2.0)
+
+
+from golden_cases import CASES as _GOLD, load_case as _load_case  # noqa: E402
+from util import TOL as _TOL, rel_err as _rel_err  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(_GOLD))
+def test_kernels_vs_golden(hostsim_engine, name):
+    prm, blk, gold, turb = _load_case(name)
+    hostsim_engine.release_all()
+    hostsim_engine.set_options(prm)
+    hostsim_engine.register(blk)
+    hostsim_engine.blocketteRes(1, True, True, turb)
+    dw = hostsim_engine.download_residual()
+    s = (slice(2, blk.il + 1), slice(2, blk.jl + 1), slice(2, blk.kl + 1))
+    for l in range(blk.nw):
+        assert _rel_err(dw[s][..., l], gold["dw"][..., l]) <= _TOL, (name, l)

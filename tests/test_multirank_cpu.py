@@ -1,0 +1,36 @@
+"""CPU-only, world_size 2 (gloo): the N>1 halo-exchange path — pattern split
+over ranks, pack, transport, unpack, same-process copies — against the
+single-rank result.  Kernels run on the tests/hostsim emulator."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("nLayers", [1, 2])
+def test_two_rank_halo_exchange_gloo(nLayers):
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_halo_worker.py"), str(r), "2", str(port), str(nLayers)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o = "TIMEOUT"
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} OK" in o, o[-2000:]
