@@ -56,6 +56,7 @@ struct Block {
     std::vector<void*> allocs;
     bool geom_uploaded = false;
     bool ss_valid = false;    // entropy sensor variable matches the current state
+    bool etot_consistent = false;   // owned-cell rhoE already equals computeEtotBlock(p, rho, v)
 };
 
 typedef std::tuple<int, int, int> Key;   // (level, sps, nn): iteration order = level, sps, nn
@@ -480,6 +481,7 @@ int adflow_gpu_upload_state(int nn, int level, int sps)
     rc |= copy_box(b, v.rev, d.rev, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
     if (rc) return rc;
     b->ss_valid = false;
+    b->etot_consistent = false;
     return sync_and_check();
 }
 
@@ -564,7 +566,10 @@ int adflow_gpu_upload_array(int nn, int level, int sps, int which, const double*
     double* dev; int nc, lo[3], n[3];
     if (array_spec(b, which, &dev, &nc, lo, n)) return 1;
     if (copy_box(b, dev, host, nc, lo[0], n[0], lo[1], n[1], lo[2], n[2], true)) return 1;
-    if (which == ADFLOW_ARR_W || which == ADFLOW_ARR_P || which == ADFLOW_ARR_GAMMA) b->ss_valid = false;
+    if (which == ADFLOW_ARR_W || which == ADFLOW_ARR_P || which == ADFLOW_ARR_GAMMA) {
+        b->ss_valid = false;
+        b->etot_consistent = false;
+    }
     return sync_and_check();
 }
 
@@ -993,7 +998,12 @@ static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPr
     // both travelled (haloExchange.F90:178-196)
     const bool bothPAndE = commPressure && varStart <= 5 && varEnd >= 5;
     for_level(level, [&](Block* b) {
-        if (nLayers == 2 && bothPAndE) launch_etot_owned(b->v, g_opts.gammaConstant, g_stream);
+        // the exchange never touches owned cells: when their rhoE was produced by
+        // computeEtotBlock already (stage update, or a previous whalo2) the pass is an identity
+        if (nLayers == 2 && bothPAndE && !b->etot_consistent) {
+            launch_etot_owned(b->v, g_opts.gammaConstant, g_stream);
+            b->etot_consistent = true;
+        }
         b->ss_valid = false;
         return 0;
     });
@@ -1015,6 +1025,7 @@ static int finish_stage(int level, const KParams& kp, double scale, int fromWn)
     int rc = for_level(level, [&](Block* b) {
         launch_stage_update(b->v, kp, scale, fromWn, g_stream);
         b->ss_valid = false;
+        b->etot_consistent = true;
         return 0;
     });
     if (rc) return rc;

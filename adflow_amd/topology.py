@@ -71,9 +71,10 @@ class BrickTopology:
     def blocks_of(self, rank) -> List[int]:
         return [g for g in range(self.nblocks) if self.owner(g) == rank]
 
-    def patterns(self, nLayers: int) -> Dict[int, CommPattern]:
+    def patterns(self, nLayers: int, only_rank=None) -> Dict[int, CommPattern]:
         """CommPattern per rank for halo depth nLayers (1: cells 1..ie, 2: 0..ib),
-        faces, edges and corners included."""
+        faces, edges and corners included.  only_rank: build just that rank's
+        pattern (skips block pairs that do not involve it)."""
         nx, ny, nz = self.nx, self.ny, self.nz
         lo = 2 - nLayers
         ii = np.arange(lo, nx + 2 + nLayers)
@@ -94,8 +95,11 @@ class BrickTopology:
             dg = (gi // nx) + self.Bi * ((gj // ny) + self.Bj * (gk // nz))
             di, dj, dk = gi % nx + 2, gj % ny + 2, gk % nz + 2
             rh = self.owner(g)
-            downers = np.array([self.owner(int(x)) for x in np.unique(dg)])
-            for dgu, rd in zip(np.unique(dg), downers):
+            udg = np.unique(dg)
+            downers = np.array([self.owner(int(x)) for x in udg])
+            for dgu, rd in zip(udg, downers):
+                if only_rank is not None and rh != only_rank and rd != only_rank:
+                    continue
                 m = dg == dgu
                 didx = np.stack([di[m], dj[m], dk[m]], axis=1)
                 hidx = np.stack([hi[m], hj[m], hk[m]], axis=1)
@@ -110,6 +114,8 @@ class BrickTopology:
                     M[2].append(np.full(n, lid[g])); M[3].append(hidx)
         out = {}
         for r in ranks:
+            if only_rank is not None and r != only_rank:
+                continue
             cp = CommPattern()
             L = loc[r]
             if L[0]:
