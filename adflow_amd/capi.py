@@ -60,6 +60,9 @@ class AdflowBlockDesc(ctypes.Structure):
         ("dw", c_void_p), ("fw", c_void_p), ("dtl", c_void_p), ("radI", c_void_p), ("radJ", c_void_p),
         ("radK", c_void_p),
         ("w1", c_void_p), ("p1", c_void_p), ("wr", c_void_p),
+        ("mgIFine", c_void_p), ("mgJFine", c_void_p), ("mgKFine", c_void_p),
+        ("mgIWeight", c_void_p), ("mgJWeight", c_void_p), ("mgKWeight", c_void_p),
+        ("mgICoarse", c_void_p), ("mgJCoarse", c_void_p), ("mgKCoarse", c_void_p),
     ]
 
 
@@ -90,6 +93,7 @@ EXPORTS = [
     "adflow_gpu_upload_array", "adflow_gpu_set_options",
     "adflow_gpu_time_step", "adflow_gpu_initres", "adflow_gpu_residual", "adflow_gpu_block_res",
     "adflow_gpu_rk_smooth", "adflow_gpu_dadi_smooth", "adflow_gpu_halo_exchange", "adflow_gpu_res_norms",
+    "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
     "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
@@ -133,6 +137,9 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_dadi_smooth.argtypes = [c_int]
     lib.adflow_gpu_halo_exchange.argtypes = [c_int] * 6
     lib.adflow_gpu_res_norms.argtypes = [c_int, c_void_p, c_int]
+    lib.adflow_gpu_transfer_to_coarse.argtypes = [c_int]
+    lib.adflow_gpu_transfer_to_fine.argtypes = [c_int]
+    lib.adflow_gpu_mg_cycle.argtypes = [c_void_p, c_int]
     lib.adflow_gpu_comm_register.argtypes = [c_int, c_int, POINTER(AdflowCommPattern)]
     lib.adflow_gpu_halo_slot_info.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]
     lib.adflow_gpu_halo_pack.argtypes = [c_int] * 7 + [c_void_p]
@@ -182,7 +189,9 @@ def desc_from_block(blk) -> AdflowBlockDesc:
     d = AdflowBlockDesc()
     d.nx, d.ny, d.nz, d.nw, d.rightHanded = blk.nx, blk.ny, blk.nz, blk.nw, 1
     for name in ("w", "p", "gamma", "rlv", "rev", "x", "sI", "sJ", "sK", "vol", "volRef", "d2Wall",
-                 "porI", "porJ", "porK", "iblank", "dw", "fw", "dtl", "radI", "radJ", "radK", "w1", "p1", "wr"):
+                 "porI", "porJ", "porK", "iblank", "dw", "fw", "dtl", "radI", "radJ", "radK", "w1", "p1", "wr",
+                 "mgIFine", "mgJFine", "mgKFine", "mgIWeight", "mgJWeight", "mgKWeight", "mgICoarse", "mgJCoarse",
+                 "mgKCoarse"):
         setattr(d, name, _ptr(blk.a.get(name)))
     return d
 

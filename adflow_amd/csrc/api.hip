@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <tuple>
@@ -386,6 +387,40 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
         b->allocs.push_back(raw);
         v.flags = (uint8_t*)raw + 16;
     }
+    // multigrid maps: small index arrays, re-laid out as [2*m + q]
+    {
+        auto up_pair = [&](const int32_t* h, int lo, int n, int** dev) -> int {
+            *dev = nullptr;
+            if (!h) return 0;
+            std::vector<int> t((size_t)2 * (lo + n + 1), 0);
+            for (int m = 0; m < n; ++m)
+                for (int q = 0; q < 2; ++q) t[(size_t)2 * (lo + m) + q] = h[(size_t)m + (size_t)n * q];
+            void* raw = nullptr;
+            HIPCHK(hipMalloc(&raw, sizeof(int) * t.size()));
+            HIPCHK(hipMemcpy(raw, t.data(), sizeof(int) * t.size(), hipMemcpyHostToDevice));
+            b->allocs.push_back(raw);
+            *dev = (int*)raw;
+            return 0;
+        };
+        auto up_w = [&](const double* h, int lo, int n, double** dev) -> int {
+            *dev = nullptr;
+            if (!h) return 0;
+            std::vector<double> t((size_t)(lo + n + 1), 0.0);
+            for (int m = 0; m < n; ++m) t[(size_t)lo + m] = h[m];
+            void* raw = nullptr;
+            HIPCHK(hipMalloc(&raw, sizeof(double) * t.size()));
+            HIPCHK(hipMemcpy(raw, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+            b->allocs.push_back(raw);
+            *dev = (double*)raw;
+            return 0;
+        };
+        if (up_pair(d->mgIFine, 1, v.ie, &v.mgIFine) || up_pair(d->mgJFine, 1, v.je, &v.mgJFine) ||
+            up_pair(d->mgKFine, 1, v.ke, &v.mgKFine) || up_w(d->mgIWeight, 2, v.nx, &v.mgIWeight) ||
+            up_w(d->mgJWeight, 2, v.ny, &v.mgJWeight) || up_w(d->mgKWeight, 2, v.nz, &v.mgKWeight) ||
+            up_pair(d->mgICoarse, 2, v.nx, &v.mgICoarse) || up_pair(d->mgJCoarse, 2, v.ny, &v.mgJCoarse) ||
+            up_pair(d->mgKCoarse, 2, v.nz, &v.mgKCoarse))
+            return 1;
+    }
     HIPCHK(hipStreamSynchronize(g_stream));
     g_blocks[Key(level, sps, nn)] = b;
     invalidate_comm_level(level);
@@ -604,7 +639,7 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
 
 static int enqueue_flow_residual(int level, const KParams& kp)
 {
-    if (g_use_march && !kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR) {
+    if (g_use_march && !kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.fineGrid) {
         // Euler + scalar JST: one k-marching launch over every block of the level
         int rc = for_level(level, [&](Block* b) {
             if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
@@ -619,6 +654,9 @@ static int enqueue_flow_residual(int level, const KParams& kp)
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
         if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
             return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
+        if (kp.spaceDiscr == ADFLOW_DISS_MATRIX && !kp.fineGrid)
+            return fail("matrix dissipation on coarse multigrid levels (inviscidDissFluxMatrixCoarse) is not implemented: "
+                        "use coarseDiscretization = scalar or upwind");
         if (kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && !b->ss_valid && fabs(kp.rFil) >= 1.e-10) {
             launch_entropy(b->v, g_stream);
             b->ss_valid = true;
@@ -1095,6 +1133,159 @@ int adflow_gpu_dadi_smooth(int level)
             if (enqueue_flow_residual(level, kp)) return 1;
         }
     }
+    return sync_and_check();
+}
+
+// ---------------------------------------------------------------- multigrid
+static int for_level_pairs(int fineLevel, const std::function<int(Block*, Block*)>& fn)
+{
+    bool any = false;
+    for (auto& kv : g_blocks) {
+        if (std::get<0>(kv.first) != fineLevel) continue;
+        Block* c = find_block(std::get<2>(kv.first), fineLevel + 1, std::get<1>(kv.first));
+        if (!c) return fail("block %d has no level-%d counterpart", std::get<2>(kv.first), fineLevel + 1);
+        any = true;
+        int rc = fn(kv.second, c);
+        if (rc) return rc;
+    }
+    if (!any) return fail("no block registered on level %d", fineLevel);
+    return 0;
+}
+
+static int exchange_if_registered(int level, int nLayers)
+{
+    if (g_comm.count(std::make_pair(level, nLayers))) return halo_exchange_enqueue(level, 1, 5, 1, 1, nLayers);
+    return 0;
+}
+
+static double rfil_stage0(int* fwMode)
+{
+    *fwMode = (g_opts.smoother == ADFLOW_RUNGE_KUTTA) ? 1 : 0;
+    return (g_opts.smoother == ADFLOW_RUNGE_KUTTA) ? g_opts.cdisRK[0] : 1.0;
+}
+
+static int transfer_to_coarse_enqueue(int level)
+{
+    const int cl = level + 1;
+    int fwMode;
+    const double rFil = rfil_stage0(&fwMode);
+    // residual of the fine level with rkStage = 0 (multiGrid.F90:62-70)
+    KParams kf = make_kparams(level, rFil, fwMode);
+    kf.onlyRadii = 1;
+    int rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kf, g_stream); b->ss_valid = true; return 0; });
+    if (rc) return rc;
+    if (enqueue_flow_residual(level, kf)) return 1;
+    // restriction + closures on the coarse level
+    KParams kc = make_kparams(cl, rFil, fwMode);
+    rc = for_level_pairs(level, [&](Block* f, Block* c) {
+        if (!c->v.mgIFine || !c->v.mgIWeight) return fail("coarse block has no mgIFine/mgIWeight maps");
+        if (!c->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", cl);
+        launch_restrict(c->v, f->v, kc, g_stream);
+        c->ss_valid = false;
+        c->etot_consistent = true;
+        return 0;
+    });
+    if (rc) return rc;
+    // applyAllBC(.false.) ; whalo1 (multiGrid.F90:236-241)
+    if (g_bc_callback) {
+        HIPCHK(hipStreamSynchronize(g_stream));
+        g_bc_callback(cl, 0);
+    }
+    if (exchange_if_registered(cl, 1)) return 1;
+    // time step, entry state, coarse residual from zero, forcing term (multiGrid.F90:246-320)
+    kc.onlyRadii = 0;
+    rc = for_level(cl, [&](Block* b) {
+        launch_time_step(b->v, kc, g_stream);
+        b->ss_valid = true;
+        launch_store_entry_state(b->v, g_stream);
+        return 0;
+    });
+    if (rc) return rc;
+    KParams kz = kc;
+    kz.coarseInit = 0;
+    if (enqueue_flow_residual(cl, kz)) return 1;
+    return for_level(cl, [&](Block* b) { launch_forcing(b->v, g_opts.fcoll, g_stream); return 0; });
+}
+
+static int transfer_to_fine_enqueue(int level)
+{
+    KParams kf = make_kparams(level, 1.0, 0);
+    int rc = for_level_pairs(level, [&](Block* f, Block* c) {
+        if (!f->v.mgICoarse) return fail("fine block has no mgICoarse map");
+        launch_corrections(c->v, g_stream);
+        launch_prolong_update(f->v, c->v, kf, g_stream);
+        f->ss_valid = false;
+        f->etot_consistent = true;
+        return 0;
+    });
+    if (rc) return rc;
+    const int secondHalo = (level <= g_opts.groundLevel);
+    if (g_bc_callback) {
+        HIPCHK(hipStreamSynchronize(g_stream));
+        g_bc_callback(level, secondHalo);
+    }
+    return exchange_if_registered(level, secondHalo ? 2 : 1);
+}
+
+int adflow_gpu_transfer_to_coarse(int level)
+{
+    if (need_ready()) return 1;
+    if (transfer_to_coarse_enqueue(level)) return 1;
+    return sync_and_check();
+}
+
+int adflow_gpu_transfer_to_fine(int level)
+{
+    if (need_ready()) return 1;
+    if (transfer_to_fine_enqueue(level)) return 1;
+    return sync_and_check();
+}
+
+int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
+{
+    if (need_ready()) return 1;
+    if (!cycling || nSteps < 1) return fail("mg_cycle: empty cycling strategy");
+    const bool was_async = g_async;
+    g_async = true;                 // the whole cycle is enqueued, one sync at the end
+    int level = g_opts.groundLevel;
+    int rc = 0;
+    for (int n = 0; n < nSteps && !rc; ++n) {
+        switch (cycling[n]) {
+        case -1:
+            level -= 1;
+            rc = transfer_to_fine_enqueue(level);
+            break;
+        case 0: {
+            if (n > 0 && cycling[n - 1] != 1) {
+                // time step + residual with rkStage = 0 (multiGrid.F90:880-888)
+                int fwMode;
+                const double rFil = rfil_stage0(&fwMode);
+                KParams kp = make_kparams(level, rFil, fwMode);
+                rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kp, g_stream); b->ss_valid = true; return 0; });
+                if (!rc) rc = enqueue_flow_residual(level, kp);
+            }
+            if (!rc) rc = (g_opts.smoother == ADFLOW_RUNGE_KUTTA) ? adflow_gpu_rk_smooth(level) : adflow_gpu_dadi_smooth(level);
+            break;
+        }
+        case 1:
+            rc = transfer_to_coarse_enqueue(level);
+            level += 1;
+            break;
+        default:
+            rc = fail("mg_cycle: cycling(%d) = %d is not -1, 0 or 1", n + 1, cycling[n]);
+        }
+    }
+    if (!rc) {
+        // closing time step + residual on the ground level (multiGrid.F90:944-950)
+        level = g_opts.groundLevel;
+        int fwMode;
+        const double rFil = rfil_stage0(&fwMode);
+        KParams kp = make_kparams(level, rFil, fwMode);
+        rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kp, g_stream); b->ss_valid = true; return 0; });
+        if (!rc) rc = enqueue_flow_residual(level, kp);
+    }
+    g_async = was_async;
+    if (rc) return rc;
     return sync_and_check();
 }
 

@@ -58,6 +58,10 @@ struct BlkView {
     double *scratch; // nscratch work arrays
     double *wn, *pn; // RK stage-0 state
     double *w1, *p1, *wr; // multigrid
+    // multigrid maps (device copies of coarseUtils.F90:254-262): index 2*m+{0,1} for coarse/fine cell m
+    int *mgIFine, *mgJFine, *mgKFine;        // coarse block: (1:ie,2) stored [m*2+q], m = 0..ie
+    double *mgIWeight, *mgJWeight, *mgKWeight;  // coarse block, indexed by cell index
+    int *mgICoarse, *mgJCoarse, *mgKCoarse;  // fine block, indexed [i*2+q]
     __host__ __device__ inline long idx(int i, int j, int k) const { return (long)i + (long)j * ldi + (long)k * ldk; }
 };
 
@@ -111,4 +115,9 @@ void launch_halo_unpack(const BlkView* tab, const int* blk, const long* off, int
                         hipStream_t s);
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
+void launch_restrict(const BlkView& c, const BlkView& f, const KParams& kp, hipStream_t s);
+void launch_store_entry_state(const BlkView& c, hipStream_t s);
+void launch_forcing(const BlkView& c, double fcoll, hipStream_t s);
+void launch_corrections(const BlkView& c, hipStream_t s);
+void launch_prolong_update(const BlkView& f, const BlkView& c, const KParams& kp, hipStream_t s);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);

@@ -286,7 +286,20 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
     central_face(L, 1, mx, my, mz, porM, -1.0, dwc);
     central_face(L, 2, px, py, pz, porP, +1.0, dwc);
     if (!doDiss) return;
-    if (SCHEME == ADFLOW_DISS_SCALAR) {
+    if (SCHEME == ADFLOW_DISS_SCALAR && !kp.fineGrid) {
+        // coarse multigrid levels: first-order scalar dissipation
+        // (fluxes::inviscidDissFluxScalarCoarse, fluxes.F90:4977-5203): fs = dis0 (W_R - W_L)
+        const double fis0 = kp.rFil * kp.vis2Coarse;
+        const double r0 = rad[c];
+        const double d0M = fis0 * (porM == ADF_POR_NORMAL ? 0.5 : 0.0) * (rad[c - s] + r0);
+        const double d0P = fis0 * (porP == ADF_POR_NORMAL ? 0.5 : 0.0) * (r0 + rad[c + s]);
+        double Wm[5], W0[5], Wp[5];
+        Wm[0] = L.rho[1]; Wm[1] = L.rho[1] * L.u[1]; Wm[2] = L.rho[1] * L.v[1]; Wm[3] = L.rho[1] * L.w[1]; Wm[4] = L.e[1] + L.p[1];
+        W0[0] = L.rho[2]; W0[1] = L.rho[2] * L.u[2]; W0[2] = L.rho[2] * L.v[2]; W0[3] = L.rho[2] * L.w[2]; W0[4] = L.e[2] + L.p[2];
+        Wp[0] = L.rho[3]; Wp[1] = L.rho[3] * L.u[3]; Wp[2] = L.rho[3] * L.v[3]; Wp[3] = L.rho[3] * L.w[3]; Wp[4] = L.e[3] + L.p[3];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) fwd[l] += d0M * (W0[l] - Wm[l]) - d0P * (Wp[l] - W0[l]);
+    } else if (SCHEME == ADFLOW_DISS_SCALAR) {
         double ssv[5];
         if (VISC) {
 #pragma unroll

@@ -121,6 +121,17 @@ class Engine:
     def DADISmoother(self, level=1):
         self._chk(self.lib.adflow_gpu_dadi_smooth(level))
 
+    # ---- multigrid ----------------------------------------------------------
+    def transferToCoarseGrid(self, level=1):
+        self._chk(self.lib.adflow_gpu_transfer_to_coarse(level))
+
+    def transferToFineGrid(self, level=1):
+        self._chk(self.lib.adflow_gpu_transfer_to_fine(level))
+
+    def executeMGCycle(self, cycling):
+        c = np.ascontiguousarray(cycling, np.int32)
+        self._chk(self.lib.adflow_gpu_mg_cycle(c.ctypes.data, c.size))
+
     # ---- halo exchange ------------------------------------------------------
     def comm_register(self, level: int, nLayers: int, cp):
         """commPatternCell_{1st,2nd}(level) + internalCell_{1st,2nd}(level)."""

@@ -39,6 +39,8 @@ module adflowGpuShim
         type(c_ptr) :: porI, porJ, porK, iblank
         type(c_ptr) :: dw, fw, dtl, radI, radJ, radK
         type(c_ptr) :: w1, p1, wr
+        type(c_ptr) :: mgIFine, mgJFine, mgKFine, mgIWeight, mgJWeight, mgKWeight
+        type(c_ptr) :: mgICoarse, mgJCoarse, mgKCoarse
     end type adflow_block_desc
 
     ! ---- mirror of adflow_comm_pattern ---------------------------------------
@@ -210,8 +212,16 @@ contains
             d%dw = c_loc(b1%dw); d%fw = c_loc(b1%fw); d%dtl = c_loc(b1%dtl)
             d%radI = c_loc(b1%radI); d%radJ = c_loc(b1%radJ); d%radK = c_loc(b1%radK)
             d%w1 = c_null_ptr; d%p1 = c_null_ptr; d%wr = c_null_ptr
+            d%mgIFine = c_null_ptr; d%mgJFine = c_null_ptr; d%mgKFine = c_null_ptr
+            d%mgIWeight = c_null_ptr; d%mgJWeight = c_null_ptr; d%mgKWeight = c_null_ptr
+            d%mgICoarse = c_null_ptr; d%mgJCoarse = c_null_ptr; d%mgKCoarse = c_null_ptr
             if (level > 1) then
                 d%w1 = c_loc(b%w1); d%p1 = c_loc(b%p1); d%wr = c_loc(b%wr)
+                d%mgIFine = c_loc(g%mgIFine); d%mgJFine = c_loc(g%mgJFine); d%mgKFine = c_loc(g%mgKFine)
+                d%mgIWeight = c_loc(g%mgIWeight); d%mgJWeight = c_loc(g%mgJWeight); d%mgKWeight = c_loc(g%mgKWeight)
+            end if
+            if (associated(g%mgICoarse)) then
+                d%mgICoarse = c_loc(g%mgICoarse); d%mgJCoarse = c_loc(g%mgJCoarse); d%mgKCoarse = c_loc(g%mgKCoarse)
             end if
         end associate
         call gpuCheck(adflow_gpu_block_register(int(nn, c_int), int(level, c_int), int(sps, c_int), d), "gpuRegisterBlock")

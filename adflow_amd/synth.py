@@ -235,3 +235,41 @@ def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.
     d = xc[1:nx + 1, 1:ny + 1, 1:nz + 1, 2] - origin[2]
     b["d2Wall"] = np.asfortranarray(np.maximum(d, 1e-6))
     return b
+
+
+# ----------------------------------------------------------------------------
+# multigrid: regular 2:1 coarsening maps (src/preprocessing/coarseUtils.F90:254-420)
+# ----------------------------------------------------------------------------
+def mg_maps_1d(nf: int):
+    """Maps of one direction for nf fine cells (nf even) -> nc = nf/2 coarse cells.
+    Returns (mgFine (1:ie_c,2), mgWeight (2:il_c), mgCoarse (2:il_f,2))."""
+    assert nf % 2 == 0 and nf >= 2
+    nc = nf // 2
+    ie_c = nc + 2
+    ie_f, ib_f = nf + 2, nf + 3
+    fine = np.zeros((ie_c, 2), np.int32, order="F")
+    fine[0] = (0, 1)
+    fine[ie_c - 1] = (ie_f, ib_f)
+    for ii in range(2, nc + 2):                 # coarse cell ii covers fine cells 2ii-2, 2ii-1
+        fine[ii - 1] = (2 * ii - 2, 2 * ii - 1)
+    weight = np.ones(nc, np.float64)
+    coarse = np.zeros((nf, 2), np.int32, order="F")
+    for i in range(2, nf + 2):                  # fine cell i: nearest / next-nearest coarse cell
+        ii = i // 2 + 1
+        coarse[i - 2] = (ii, ii - 1) if i % 2 == 0 else (ii, ii + 1)
+    return fine, weight, coarse
+
+
+def make_coarse_block(fine: Block, prm: FlowParams, **mk) -> Block:
+    """Level+1 block of `fine` (same analytic map at half resolution) with the
+    transfer maps attached to both blocks."""
+    c = make_block(fine.nx // 2, fine.ny // 2, fine.nz // 2, prm, **mk)
+    for d, nf in (("I", fine.nx), ("J", fine.ny), ("K", fine.nz)):
+        f, wgt, co = mg_maps_1d(nf)
+        c["mg%sFine" % d], c["mg%sWeight" % d] = f, wgt
+        fine["mg%sCoarse" % d] = co
+    ie, je, ke = c.ie, c.je, c.ke
+    c["w1"] = F((ie, je, ke, 5))
+    c["p1"] = F((ie, je, ke))
+    c["wr"] = F((c.nx, c.ny, c.nz, 5))
+    return c

@@ -93,6 +93,12 @@ typedef struct adflow_block_desc {
     double *dtl, *radI, *radJ, *radK; /* (1:ie,1:je,1:ke) */
     /* multigrid work (coarse levels, initializeFlow.F90:746-748) */
     double *w1, *p1, *wr;     /* (1:ie,1:je,1:ke,1:5) (1:ie,1:je,1:ke) (2:il,2:jl,2:kl,1:5) */
+    /* multigrid transfer maps (src/preprocessing/coarseUtils.F90:254-262), NULL when absent.
+     * On a COARSE block: the two fine cells of each coarse cell and the restriction weights */
+    int32_t *mgIFine, *mgJFine, *mgKFine;       /* (1:ie,2) (1:je,2) (1:ke,2) */
+    double *mgIWeight, *mgJWeight, *mgKWeight;  /* (2:il) (2:jl) (2:kl) */
+    /* on a FINE block: nearest and next-nearest coarse cell of each fine cell */
+    int32_t *mgICoarse, *mgJCoarse, *mgKCoarse; /* (2:il,2) (2:jl,2) (2:kl,2) */
 } adflow_block_desc;
 
 /* 1-to-1 halo communication pattern of one level and one halo depth: the
@@ -173,6 +179,17 @@ int adflow_gpu_block_res(int level, unsigned flags);
 /* smoothers::RungeKuttaSmoother / DADISmoother (src/solver/smoothers.F90:4,383) */
 int adflow_gpu_rk_smooth(int level);
 int adflow_gpu_dadi_smooth(int level);
+/* multigrid::transferToCoarseGrid (src/solver/multiGrid.F90:5-324): residual on `level`,
+ * volume-weighted restriction to level+1, coarse residual, forcing term wr */
+int adflow_gpu_transfer_to_coarse(int level);
+/* multigrid::transferToFineGrid(.true.) (multiGrid.F90:326-652): prolongation of the
+ * corrections of level+1 to `level`, state update, halo exchange */
+int adflow_gpu_transfer_to_fine(int level);
+/* multigrid::executeMGCycle (multiGrid.F90:825-955): `cycling` as produced by
+ * setCycleStrategy (:957-1030): -1 prolongate, 0 smooth, +1 restrict; ends with the
+ * ground-level time step + residual.  The SA DDADI solve between is the host's until
+ * adflow_gpu_sa_solve exists. */
+int adflow_gpu_mg_cycle(const int32_t* cycling, int nStepsCycling);
 /* register the 1-to-1 pattern of (level, nLayers = 1 | 2); lists are copied */
 int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* p);
 /* haloExchange::whalo1 (nLayers=1) / whalo2 (nLayers=2) (src/utils/haloExchange.F90:5,109):

@@ -39,6 +39,7 @@ def load(fast: bool = False) -> ctypes.CDLL:
         lib.ref_alloc_doms.argtypes = [ctypes.c_int] * 2
         lib.ref_commit_block.argtypes = [ctypes.c_int] * 2
         lib.ref_set_internal_comm.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+        lib.ref_set_cycling.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ref_call_level.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _LIB = lib
     return _LIB
@@ -218,13 +219,19 @@ def set_internal_comm(level: int, nLayers: int, cp) -> None:
     load().ref_set_internal_comm(level, nLayers, cp.ncopy, *[a.ctypes.data for a in arrs])
 
 
+def set_cycling(cycling) -> None:
+    c = np.ascontiguousarray(cycling, np.int32)
+    load().ref_set_cycling(c.ctypes.data, c.size)
+
+
 def call_level(name: str, level: int = 1, i1: int = 0, i2: int = 0) -> None:
     _big_stack(load().ref_call_level, name.encode(), level, int(i1), int(i2))
 
 
-def bind_blocks(blocks, prm, level: int = 1, nlevels: int = 1) -> None:
+def bind_blocks(blocks, prm, level: int = 1, nlevels: int = 1, alloc: bool = True) -> None:
     """blocks: {nn: Block}; binds each and commits it to flowDoms(nn,level,1)."""
-    alloc_doms(max(blocks), nlevels)
+    if alloc:
+        alloc_doms(max(blocks), nlevels)
     for nn, b in sorted(blocks.items()):
         bind_block(b, prm)
         commit_block(nn, level)

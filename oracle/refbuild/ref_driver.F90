@@ -411,6 +411,16 @@ contains
         end select
     end subroutine ref_set_vec
 
+    subroutine ref_set_cycling(c, n) bind(C, name="ref_set_cycling")
+        use iteration, only: cycling, nStepsCycling
+        integer(c_int), value :: n
+        integer(c_int), dimension(n), intent(in) :: c
+        if (allocated(cycling)) deallocate (cycling)
+        allocate (cycling(n))
+        cycling = c
+        nStepsCycling = n
+    end subroutine ref_set_cycling
+
     ! ----------------------------------------------------------------- calls
     ! Each entry calls ONE reference routine, unchanged, on the current block.
     subroutine ref_call(name, iarg) bind(C, name="ref_call")
@@ -615,7 +625,7 @@ contains
         use smoothers, only: RungeKuttaSmoother, DADISmoother
         use solverUtils, only: timeStep
         use residuals, only: initres, residual
-        use multiGrid, only: transferToCoarseGrid, transferToFineGrid
+        use multiGrid, only: transferToCoarseGrid, transferToFineGrid, executeMGCycle
         use utils, only: setPointers
         character(kind=c_char), dimension(*), intent(in) :: name
         integer(c_int), value :: level, i1, i2
@@ -633,6 +643,7 @@ contains
         case ('DADISmoother'); call DADISmoother                                      ! smoothers.F90:383
         case ('transferToCoarseGrid'); call transferToCoarseGrid                      ! multiGrid.F90:5
         case ('transferToFineGrid'); call transferToFineGrid(i1 /= 0)                 ! multiGrid.F90:326
+        case ('executeMGCycle'); call executeMGCycle                                  ! multiGrid.F90:825
         case default
             print *, 'ref_call_level: unknown routine ', trim(n)
             stop 1

@@ -196,3 +196,78 @@ def check_dadi_smoother(engine, topo, prm, seed=9, nsweeps=1, **mk):
         engine.residual(1, 0)
         engine.DADISmoother(1)
         assert_state(engine, blocks, rblocks, prm, f"DADI sweep {sweep}")
+
+
+def setup_two_level_brick(engine, topo, prm, seed=1, **mk):
+    """Fine (level 1) + coarse (level 2) periodic bricks on the engine and in the
+    reference's flowDoms, with 1-to-1 patterns on both levels."""
+    from oracle import ref
+    from adflow_amd.synth import make_coarse_block
+    from adflow_amd.topology import BrickTopology, apply_local_copies_fast
+    engine.release_all()
+    fine = make_brick(topo, prm, seed, **mk)
+    ctopo = BrickTopology(topo.Bi, topo.Bj, topo.Bk, topo.nx // 2, topo.ny // 2, topo.nz // 2)
+    coarse = {nn: make_coarse_block(b, prm, seed=seed + 1000 + nn, **mk) for nn, b in fine.items()}
+    fp = {L: topo.patterns(L)[0] for L in (1, 2)}
+    cpat = {L: ctopo.patterns(L)[0] for L in (1, 2)}
+    apply_local_copies_fast(fine, fp[2])
+    rfine = {nn: b.copy() for nn, b in fine.items()}
+    rcoarse = {nn: b.copy() for nn, b in coarse.items()}
+    p1 = prm.replace(currentLevel=1, groundLevel=1)
+    ref.bind_blocks(rfine, p1, level=1, nlevels=2)
+    ref.bind_blocks(rcoarse, p1, level=2, nlevels=2, alloc=False)
+    for L in (1, 2):
+        ref.set_internal_comm(1, L, fp[L])
+        ref.set_internal_comm(2, L, cpat[L])
+    engine.set_options(prm)
+    for nn in fine:
+        engine.register(fine[nn], nn=nn, level=1)
+        engine.register(coarse[nn], nn=nn, level=2)
+    for L in (1, 2):
+        engine.comm_register(1, L, fp[L])
+        engine.comm_register(2, L, cpat[L])
+    return fine, coarse, rfine, rcoarse
+
+
+def check_mg_transfer(engine, topo, prm, seed=11, **mk):
+    """transferToCoarseGrid then transferToFineGrid (multiGrid.F90:5-652)."""
+    from oracle import ref
+    fine, coarse, rfine, rcoarse = setup_two_level_brick(engine, topo, prm, seed, **mk)
+    ref.load().ref_set_int(b"rkStage", 0)
+    ref.call_level("transferToCoarseGrid", 1)
+    engine.transferToCoarseGrid(1)
+    assert_state(engine, coarse, rcoarse, prm, "restricted state", level=2)
+    for nn, c in coarse.items():
+        for which, name in ((capi.ARR_WR, "wr"), (capi.ARR_W1, "w1"), (capi.ARR_P1, "p1")):
+            out = np.zeros_like(rcoarse[nn][name])
+            engine.download_array(which, out, nn, 2)
+            e = rel_err(out, rcoarse[nn][name])
+            assert e <= TOL, ("coarse", nn, name, e)
+    # a coarse-level smoothing sweep changes the coarse state, then prolongate the corrections
+    ref.call_level("RungeKuttaSmoother" if prm.smoother == RungeKutta else "DADISmoother", 2)
+    (engine.RungeKuttaSmoother if prm.smoother == RungeKutta else engine.DADISmoother)(2)
+    assert_state(engine, coarse, rcoarse, prm, "coarse smoothing", level=2)
+    ref.call_level("transferToFineGrid", 1, 1)
+    engine.transferToFineGrid(1)
+    assert_state(engine, fine, rfine, prm, "prolongated state", level=1)
+
+
+def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, **mk):
+    """executeMGCycle (multiGrid.F90:825-955) for a given cycling strategy."""
+    from oracle import ref
+    fine, coarse, rfine, rcoarse = setup_two_level_brick(engine, topo, prm, seed, **mk)
+    ref.set_cycling(cycling)
+    # entry condition of the cycle: time step and residual of the ground level are known
+    ref.load().ref_set_int(b"rkStage", 0)
+    ref.call_level("timeStep", 1, 0)
+    ref.call_level("initres", 1, 1, 5)
+    ref.call_level("residual", 1)
+    engine.timeStep(1, False)
+    engine.residual(1, 0)
+    for n in range(ncycles):
+        ref.call_level("executeMGCycle", 1)
+        engine.executeMGCycle(cycling)
+        assert_state(engine, fine, rfine, prm, f"MG cycle {n}", level=1)
+        for nn, b in fine.items():
+            dw = engine.download_residual(nn, 1)
+            assert_dw(b, dw, rfine[nn]["dw"], 5, what=f"residual after cycle {n}")

@@ -1,0 +1,36 @@
+"""GPU parity (real MI355X, through the C-ABI): multigrid restriction /
+prolongation and full cycles against the reference's own transferToCoarseGrid,
+transferToFineGrid and executeMGCycle (src/solver/multiGrid.F90) on two-level
+periodic bricks (BASELINE config 2: multiblock Euler, RK multigrid)."""
+import pytest
+
+import checks
+from adflow_amd.params import FlowParams, NSEquations, DADI, noResAveraging, upwind
+from adflow_amd.topology import BrickTopology
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mg_transfer_operators(engine):
+    checks.check_mg_transfer(engine, BrickTopology(2, 1, 1, 16, 12, 8), FlowParams(resAveraging=noResAveraging))
+
+
+@pytest.mark.parametrize("cycling", [[0, 1, 0, -1], [0, 1, 0, 0, -1, 0]])
+def test_mg_cycle_euler_rk_tutorial_wing_size(engine, cycling):
+    # 6 blocks x (16x14x8): BASELINE config 2 parity size, default alternate residual averaging
+    checks.check_mg_cycle(engine, BrickTopology(3, 2, 1, 16, 14, 8), FlowParams(), cycling)
+
+
+def test_mg_cycle_laminar(engine):
+    checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 12, 8, 8), FlowParams(equations=NSEquations, resAveraging=noResAveraging),
+                          [0, 1, 0, -1], stretch_k=2.0)
+
+
+def test_mg_cycle_dadi(engine):
+    checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 12, 8, 8), FlowParams(smoother=DADI, resAveraging=noResAveraging, cfl=1.5),
+                          [0, 1, 0, -1])
+
+
+def test_mg_cycle_upwind(engine):
+    prm = FlowParams(spaceDiscr=upwind, spaceDiscrCoarse=upwind, resAveraging=noResAveraging)
+    checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 12, 8, 8), prm, [0, 1, 0, -1])

@@ -96,3 +96,12 @@ def test_kernels_vs_golden(hostsim_engine, name):
     s = (slice(2, blk.il + 1), slice(2, blk.jl + 1), slice(2, blk.kl + 1))
     for l in range(blk.nw):
         assert _rel_err(dw[s][..., l], gold["dw"][..., l]) <= _TOL, (name, l)
+
+
+def test_mg_transfer(hostsim_engine):
+    checks.check_mg_transfer(hostsim_engine, BrickTopology(2, 1, 1, 8, 6, 4), FlowParams(resAveraging=noResAveraging))
+
+
+@pytest.mark.parametrize("cycling", [[0, 1, 0, -1], [0, 1, 0, 0, -1, 0]])
+def test_mg_cycle(hostsim_engine, cycling):
+    checks.check_mg_cycle(hostsim_engine, BrickTopology(2, 1, 1, 8, 6, 4), FlowParams(), cycling)
