@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="euler_jst_8x128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mg", action="store_true", help="skip the MG-cycles/s measurement")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
     a = ap.parse_args()
 
@@ -128,15 +129,23 @@ def main():
     topo = BrickTopology(2 * world, 2, 2, *dims, owner=lambda g: (g % (2 * world)) // 2)
     lid = topo.local_ids()
     cells_local = 0
+    from adflow_amd.synth import make_coarse_block
     for g in topo.blocks_of(rank):
         blk = make_block(*dims, prm, seed=20260925 + g)
+        both = [blk]
+        if not a.no_mg:
+            cblk = make_coarse_block(blk, prm, seed=777 + g)   # also attaches mgI/J/KCoarse to blk
+            both.append(cblk)
         eng.register(blk, nn=lid[g], level=1)
+        if not a.no_mg:
+            eng.register(cblk, nn=lid[g], level=2)
         cells_local += blk.ncells
         log(f"block {lid[g]}/{nb} generated and uploaded")
         # host copies are no longer needed by the timed loop
-        for k in list(blk.a.keys()):
-            if k not in ("dw",):
-                del blk.a[k]
+        for b_ in both:
+            for k in list(b_.a.keys()):
+                if k not in ("dw",):
+                    del b_.a[k]
     halo = "off"
     try:
         cp = topo.patterns(2, only_rank=rank)[rank]
@@ -203,6 +212,42 @@ def main():
     k_ms = eng.event_elapsed_ms(2, 3) / (a.steps * launches_per_step)
     eng.set_async(False)
 
+    # ---- second headline metric: multigrid cycles / s (2-level V cycle, RK smoother) ----
+    mg = None
+    if not a.no_mg:
+        try:
+            from adflow_amd.params import RungeKutta
+            eng.set_options(prm.replace(smoother=RungeKutta))
+            ctopo = BrickTopology(2 * world, 2, 2, dims[0] // 2, dims[1] // 2, dims[2] // 2, owner=topo.owner)
+            if do_halo:
+                eng.comm_register(1, 2, cp)
+                eng.comm_register(2, 1, ctopo.patterns(1, only_rank=rank)[rank])
+            log("multigrid levels registered")
+            cyc = [0, 1, 0, -1]
+            eng.set_async(False)
+            eng.timeStep(1, False)
+            eng.residual(1, 0)
+            for _ in range(2):
+                eng.executeMGCycle(cyc)
+            barrier()
+            ncyc = max(5, a.steps // 5)
+            t1 = time.perf_counter()
+            for _ in range(ncyc):
+                eng.executeMGCycle(cyc)
+            barrier()
+            dt_mg = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([dt_mg], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt_mg = float(tt.item())
+            mg = {"cycles_per_s": ncyc / dt_mg, "ms_per_cycle": dt_mg / ncyc * 1e3, "cycles_timed": ncyc,
+                  "cycle": "2-level V: smooth(RK5, alternate residual averaging) / restrict / smooth / prolong + closing residual",
+                  "fine_cells_per_gpu": cells_local}
+            log(f"MG: {mg['ms_per_cycle']:.3f} ms/cycle")
+        except Exception as e:
+            mg = {"error": str(e)}
+            log("MG benchmark failed: " + str(e))
+
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -227,6 +272,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_euler_march" if march else "k_inviscid", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
+            "mg": mg,
             "whole_eval": {"event_ms_per_step": ev_ms / a.steps,
                            "hbm_frac": wl["bytes_per_cell"] * cells_local / (ev_ms / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }

@@ -18,6 +18,17 @@ def pytest_addoption(parser):
                      help="developer aid: run the -m gpu tests against the host emulation of the kernels")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _fresh_hip_library():
+    """(Re)build libadflow_gpu.so when its sources are newer (hipcc cross-compiles
+    without a GPU) so the ABI tests never look at a stale library."""
+    import shutil
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        from adflow_amd.build import build_lib
+        build_lib(verbose=False)
+    yield
+
+
 @pytest.fixture(scope="session")
 def engine(request):
     """The HIP engine through the C-ABI of include/adflow_gpu.h (real MI355X)."""
