@@ -176,13 +176,20 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous(BlkView b, KParams kp)
     const uint8_t f0 = b.flags[c];
     const uint8_t fi = b.flags[c - si], fj = b.flags[c - sj], fk = b.flags[c - sk];
     double acc[5] = {0, 0, 0, 0, 0};
-    // reference sweep order k, j, i (fluxes.F90:2610, 2903, 3197)
-    visc_face(b, kp, c - sk, sk, si, sj, b.sK, flg_porK(fk), +1.0, acc);
-    visc_face(b, kp, c, sk, si, sj, b.sK, flg_porK(f0), -1.0, acc);
-    visc_face(b, kp, c - sj, sj, si, sk, b.sJ, flg_porJ(fj), +1.0, acc);
-    visc_face(b, kp, c, sj, si, sk, b.sJ, flg_porJ(f0), -1.0, acc);
-    visc_face(b, kp, c - si, si, sj, sk, b.sI, flg_porI(fi), +1.0, acc);
-    visc_face(b, kp, c, si, sj, sk, b.sI, flg_porI(f0), -1.0, acc);
+    // reference sweep order k, j, i (fluxes.F90:2610, 2903, 3197).  The three
+    // directions run as a rolled loop: unrolled, the six inlined face evaluations
+    // need > 256 VGPRs and spill.
+    const long sd3[3] = {sk, sj, si};
+    const long s13[3] = {si, si, sj};
+    const long s23[3] = {sj, sk, sk};
+    const double* sN3[3] = {b.sK, b.sJ, b.sI};
+    const int porM3[3] = {flg_porK(fk), flg_porJ(fj), flg_porI(fi)};
+    const int porP3[3] = {flg_porK(f0), flg_porJ(f0), flg_porI(f0)};
+#pragma unroll 1
+    for (int d = 0; d < 3; ++d) {
+        visc_face(b, kp, c - sd3[d], sd3[d], s13[d], s23[d], sN3[d], porM3[d], +1.0, acc);
+        visc_face(b, kp, c, sd3[d], s13[d], s23[d], sN3[d], porP3[d], -1.0, acc);
+    }
     const double blank = flg_blank(f0);
 #pragma unroll
     for (int l = 0; l < 5; ++l) {

@@ -26,6 +26,11 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 WORKLOADS = {
     # BASELINE.json configs[1]: tutorial-wing multiblock Euler, JST scalar, roofline size
     "euler_jst_8x128": dict(equations=1, spaceDiscr=1, nblocks=8, dims=(128, 128, 128), bytes_per_cell=175.0),
+    # BASELINE.json configs[2]/[3] at roofline size (not the headline line; `--workload ...`):
+    # RANS + SA, viscous flux + SA residual, scalar JST / Roe upwind / matrix dissipation
+    "rans_sa_jst_8x128x128x96": dict(equations=3, spaceDiscr=1, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
+    "rans_sa_upwind_8x128x128x96": dict(equations=3, spaceDiscr=9, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
+    "rans_sa_matrix_8x128x128x96": dict(equations=3, spaceDiscr=2, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
 }
 
 
@@ -111,7 +116,8 @@ def main():
     from adflow_amd.synth import make_block
 
     wl = WORKLOADS[a.workload]
-    prm = FlowParams(equations=wl["equations"], spaceDiscr=wl["spaceDiscr"])
+    prm = FlowParams(equations=wl["equations"], spaceDiscr=wl["spaceDiscr"],
+                     vis4=0.1 if wl["spaceDiscr"] == 2 else 0.0156)
     eng = Engine(local_rank)
     eng.set_options(prm)
     tuning = dict(kv.split("=") for kv in a.tuning)
@@ -131,7 +137,7 @@ def main():
     cells_local = 0
     from adflow_amd.synth import make_coarse_block
     for g in topo.blocks_of(rank):
-        blk = make_block(*dims, prm, seed=20260925 + g)
+        blk = make_block(*dims, prm, seed=20260925 + g, stretch_k=3.0 if wl["equations"] == 3 else 1.0)
         both = [blk]
         if not a.no_mg:
             cblk = make_coarse_block(blk, prm, seed=777 + g)   # also attaches mgI/J/KCoarse to blk
@@ -165,7 +171,7 @@ def main():
             idbuf = idg.cpu()
         from adflow_amd import capi
         capi.check(eng.lib.adflow_gpu_comm_init(rank, world, idbuf.numpy().tobytes()), eng.lib)
-        eng.whalo2(1, 1, 5)
+        eng.whalo2(1, 1, prm.nw)
         halo = "whalo2 every step: same-GPU copies" + (" + RCCL send/recv over xGMI" if world > 1 else "")
     except Exception as e:  # the evaluation of independent shards is still a valid measurement
         halo = f"FAILED ({e}); shards evaluated without exchange"
@@ -174,7 +180,7 @@ def main():
 
     def step():
         if do_halo:
-            eng.whalo2(1, 1, 5)
+            eng.whalo2(1, 1, prm.nw)
         eng.blocketteRes(1, True, True, wl["equations"] == 3)
 
     def barrier():
@@ -265,12 +271,15 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {nb} blocks x {wl['dims'][0]}x{wl['dims'][1]}x{wl['dims'][2]} cells per GPU, "
-                                   "Euler, central + scalar JST, one residual evaluation per step (whalo2 + blocketteRes core)",
+                                   + ("Euler, central + scalar JST" if wl["equations"] == 1 else "RANS-SA, spaceDiscr=%d" % wl["spaceDiscr"])
+                                   + ", one residual evaluation per step (whalo2 + blocketteRes core)",
                        "halo_exchange": halo,
                        "cells_per_gpu": cells_local, "device": eng.device_name()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_euler_march" if march else "k_inviscid", "kernel_ms": k_ms,
+                         "kernel": "k_euler_march" if march else ("k_inviscid" if wl["equations"] == 1 else
+                                                                   "k_inviscid + k_nodal_gradients + k_viscous (one block)"),
+                         "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "mg": mg,
             "whole_eval": {"event_ms_per_step": ev_ms / a.steps,
@@ -289,9 +298,11 @@ def main():
         print(json.dumps(out))
     sys.stdout.flush()
     sys.stderr.flush()
-    # RCCL prints a banner through C stdio at process exit; leave without running
-    # C atexit handlers so the JSON line stays the last line of stdout
-    os._exit(0)
+    # RCCL prints a banner through buffered C stdio that is flushed at process exit:
+    # point fd 1 at /dev/null from here on so the JSON line stays the last line of
+    # stdout (normal exit still runs atexit handlers, e.g. rocprofv3's writer)
+    dn = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(dn, 1)
 
 
 if __name__ == "__main__":
