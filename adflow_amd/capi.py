@@ -83,7 +83,7 @@ BC_CALLBACK = ctypes.CFUNCTYPE(None, c_int, c_int)
 (ARR_W, ARR_P, ARR_GAMMA, ARR_RLV, ARR_REV, ARR_DW, ARR_FW, ARR_DTL, ARR_RADI, ARR_RADJ, ARR_RADK, ARR_AA,
  ARR_NODAL_GRADS, ARR_WN, ARR_PN, ARR_W1, ARR_P1, ARR_WR, ARR_VOL, ARR_SI, ARR_SJ, ARR_SK) = range(1, 23)
 
-RES_UPDATE_INTERMED, RES_FLOW, RES_TURB = 1, 2, 4
+RES_UPDATE_INTERMED, RES_FLOW, RES_TURB, RES_CLOSURES, RES_HALO = 1, 2, 4, 8, 16
 
 EXPORTS = [
     "adflow_gpu_init", "adflow_gpu_finalize", "adflow_gpu_last_error", "adflow_gpu_device_name",
@@ -93,6 +93,8 @@ EXPORTS = [
     "adflow_gpu_upload_array", "adflow_gpu_set_options",
     "adflow_gpu_time_step", "adflow_gpu_initres", "adflow_gpu_residual", "adflow_gpu_block_res",
     "adflow_gpu_rk_smooth", "adflow_gpu_dadi_smooth", "adflow_gpu_halo_exchange", "adflow_gpu_res_norms",
+    "adflow_gpu_set_w_vec", "adflow_gpu_get_r_vec", "adflow_gpu_get_res", "adflow_gpu_nk_residual",
+    "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
     "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback",
@@ -137,6 +139,11 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_dadi_smooth.argtypes = [c_int]
     lib.adflow_gpu_halo_exchange.argtypes = [c_int] * 6
     lib.adflow_gpu_res_norms.argtypes = [c_int, c_void_p, c_int]
+    lib.adflow_gpu_set_w_vec.argtypes = [c_void_p, ctypes.c_long]
+    lib.adflow_gpu_get_r_vec.argtypes = [c_void_p, ctypes.c_long, c_void_p]
+    lib.adflow_gpu_get_res.argtypes = [c_void_p, ctypes.c_long]
+    lib.adflow_gpu_nk_residual.argtypes = [c_void_p, c_void_p, ctypes.c_long]
+    lib.adflow_gpu_nk_residual_dev.argtypes = [c_void_p, c_void_p, ctypes.c_long]
     lib.adflow_gpu_transfer_to_coarse.argtypes = [c_int]
     lib.adflow_gpu_transfer_to_fine.argtypes = [c_int]
     lib.adflow_gpu_mg_cycle.argtypes = [c_void_p, c_int]

@@ -683,13 +683,38 @@ int adflow_gpu_residual(int level, int rkStage)
     return sync_and_check();
 }
 
+static int block_res_enqueue(int level, unsigned flags);
+static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers);
+
 static int block_res_enqueue(int level, unsigned flags)
 {
     if (need_ready()) return 1;
     KParams kp = make_kparams(level, 1.0, 0);
     kp.onlyRadii = !(flags & ADFLOW_RES_UPDATE_INTERMED);
     kp.coarseInit = 0;
-    int rc = for_level(level, [&](Block* b) {
+    int rc = 0;
+    if (flags & ADFLOW_RES_CLOSURES) {
+        // computePressureSimple / computeLamViscosity / computeEddyViscosity (blockette.F90:199-203)
+        rc = for_level(level, [&](Block* b) {
+            launch_closures(b->v, kp, g_stream);
+            b->ss_valid = false;
+            b->etot_consistent = false;
+            return 0;
+        });
+        if (rc) return rc;
+    }
+    if (flags & ADFLOW_RES_HALO) {
+        if (g_bc_callback) {
+            HIPCHK(hipStreamSynchronize(g_stream));
+            g_bc_callback(level, 1);
+        }
+        int lStart = 1, lEnd = (g_opts.equations == ADFLOW_RANS) ? 6 : 5;
+        if ((flags & ADFLOW_RES_FLOW) && !(flags & ADFLOW_RES_TURB)) lEnd = 5;
+        if (!(flags & ADFLOW_RES_FLOW) && (flags & ADFLOW_RES_TURB)) lStart = 6;
+        if (g_comm.count(std::make_pair(level, 2)))
+            if (halo_exchange_enqueue(level, lStart, lEnd, 1, 1, 2)) return 1;
+    }
+    rc = for_level(level, [&](Block* b) {
         launch_time_step(b->v, kp, g_stream);
         b->ss_valid = true;
         return 0;
@@ -1287,6 +1312,127 @@ int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
     g_async = was_async;
     if (rc) return rc;
     return sync_and_check();
+}
+
+// --------------------------------------------------------- Newton-Krylov glue
+namespace {
+double* g_vec_dev = nullptr;     // device staging of the PETSc-layout vectors
+size_t g_vec_elems = 0;
+
+int vec_reserve(size_t n)
+{
+    if (n <= g_vec_elems) return 0;
+    if (g_vec_dev) (void)hipFree(g_vec_dev);
+    g_vec_dev = nullptr;
+    g_vec_elems = 0;
+    HIPCHK(hipMalloc((void**)&g_vec_dev, n * sizeof(double)));
+    g_vec_elems = n;
+    return 0;
+}
+
+long level1_dof(void)
+{
+    long n = 0;
+    for (auto& kv : g_blocks)
+        if (std::get<0>(kv.first) == 1) n += (long)kv.second->v.nx * kv.second->v.ny * kv.second->v.nz * kv.second->v.nw;
+    return n;
+}
+
+// blocks in the reference's vector order: nn ascending (sps = 1)
+int for_level1_in_order(const std::function<int(Block*, long)>& fn)
+{
+    std::map<int, Block*> byNN;
+    for (auto& kv : g_blocks)
+        if (std::get<0>(kv.first) == 1 && std::get<1>(kv.first) == 1) byNN[std::get<2>(kv.first)] = kv.second;
+    if (byNN.empty()) return fail("no block registered on level 1");
+    long off = 0;
+    for (auto& kv : byNN) {
+        int rc = fn(kv.second, off);
+        if (rc) return rc;
+        off += (long)kv.second->v.nx * kv.second->v.ny * kv.second->v.nz * kv.second->v.nw;
+    }
+    return 0;
+}
+
+int set_w_dev(const double* d_vec)
+{
+    const double turbFloor = 1e-6 * g_opts.wInf[5];
+    return for_level1_in_order([&](Block* b, long off) {
+        launch_set_w(b->v, d_vec + off, turbFloor, g_stream);
+        b->ss_valid = false;
+        b->etot_consistent = false;
+        return 0;
+    });
+}
+
+int get_r_dev(double* d_vec, double turbScale, double* d_sums)
+{
+    return for_level1_in_order([&](Block* b, long off) {
+        launch_get_r(b->v, d_vec + off, turbScale, d_sums, g_stream);
+        return 0;
+    });
+}
+}  // namespace
+
+int adflow_gpu_set_w_vec(const double* wVec, long n)
+{
+    if (need_ready()) return 1;
+    if (!wVec || n != level1_dof()) return fail("set_w_vec: n=%ld but the level-1 blocks hold %ld DOF", n, level1_dof());
+    if (vec_reserve((size_t)n)) return 1;
+    HIPCHK(hipMemcpyAsync(g_vec_dev, wVec, sizeof(double) * n, hipMemcpyHostToDevice, g_stream));
+    if (set_w_dev(g_vec_dev)) return 1;
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+static int get_vec_common(double* out, long n, double turbScale, double* sumsq2)
+{
+    if (need_ready()) return 1;
+    if (!out || n != level1_dof()) return fail("get_r_vec: n=%ld but the level-1 blocks hold %ld DOF", n, level1_dof());
+    if (vec_reserve((size_t)n)) return 1;
+    if (!g_norm_dev) HIPCHK(hipMalloc((void**)&g_norm_dev, sizeof(double) * 8));
+    HIPCHK(hipMemsetAsync(g_norm_dev, 0, sizeof(double) * 8, g_stream));
+    if (get_r_dev(g_vec_dev, turbScale, sumsq2 ? g_norm_dev : nullptr)) return 1;
+    HIPCHK(hipMemcpyAsync(out, g_vec_dev, sizeof(double) * n, hipMemcpyDeviceToHost, g_stream));
+    if (sumsq2) HIPCHK(hipMemcpyAsync(sumsq2, g_norm_dev, sizeof(double) * 2, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+int adflow_gpu_get_r_vec(double* rVec, long n, double* sumsq2) { return get_vec_common(rVec, n, g_opts.turbResScale, sumsq2); }
+int adflow_gpu_get_res(double* res, long n) { return get_vec_common(res, n, 1.0, nullptr); }
+
+static int nk_core_enqueue(void)
+{
+    // blocketteRes with its default arguments (blockette.F90:130-160): exact residual,
+    // flow + turbulence, no intermediate update
+    unsigned flags = ADFLOW_RES_CLOSURES | ADFLOW_RES_HALO | ADFLOW_RES_FLOW;
+    if (g_opts.equations == ADFLOW_RANS) flags |= ADFLOW_RES_TURB;
+    return block_res_enqueue(1, flags);
+}
+
+int adflow_gpu_nk_residual_dev(const double* d_wVec, double* d_rVec, long n)
+{
+    if (need_ready()) return 1;
+    if (!d_wVec || !d_rVec || n != level1_dof()) return fail("nk_residual: n=%ld but the level-1 blocks hold %ld DOF", n, level1_dof());
+    if (set_w_dev(d_wVec)) return 1;
+    if (nk_core_enqueue()) return 1;
+    if (get_r_dev(d_rVec, g_opts.turbResScale, nullptr)) return 1;
+    return sync_and_check();
+}
+
+int adflow_gpu_nk_residual(const double* wVec, double* rVec, long n)
+{
+    if (need_ready()) return 1;
+    if (!wVec || !rVec || n != level1_dof()) return fail("nk_residual: n=%ld but the level-1 blocks hold %ld DOF", n, level1_dof());
+    if (vec_reserve((size_t)n)) return 1;
+    HIPCHK(hipMemcpyAsync(g_vec_dev, wVec, sizeof(double) * n, hipMemcpyHostToDevice, g_stream));
+    if (set_w_dev(g_vec_dev)) return 1;
+    if (nk_core_enqueue()) return 1;
+    if (get_r_dev(g_vec_dev, g_opts.turbResScale, nullptr)) return 1;
+    HIPCHK(hipMemcpyAsync(rVec, g_vec_dev, sizeof(double) * n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
 }
 
 int adflow_gpu_res_norms(int level, double* sums, int n)

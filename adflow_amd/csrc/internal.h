@@ -120,4 +120,7 @@ void launch_store_entry_state(const BlkView& c, hipStream_t s);
 void launch_forcing(const BlkView& c, double fcoll, hipStream_t s);
 void launch_corrections(const BlkView& c, hipStream_t s);
 void launch_prolong_update(const BlkView& f, const BlkView& c, const KParams& kp, hipStream_t s);
+void launch_set_w(const BlkView& b, const double* vec, double turbFloor, hipStream_t s);
+void launch_get_r(const BlkView& b, double* vec, double turbScale, double* sums, hipStream_t s);
+void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);

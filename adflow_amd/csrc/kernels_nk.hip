@@ -1,0 +1,116 @@
+// Newton-Krylov glue: PETSc state/residual vectors <-> block arrays, and the
+// pointwise state closures that open blockette::blocketteRes.
+//
+// Reference semantics:
+//   NKSolvers::setW      src/NKSolver/NKSolvers.F90:1331-1376  (AoS vector -> w, turbulence clipped at 1e-6*wInf)
+//   NKSolvers::setRVec   src/NKSolver/NKSolvers.F90:1262-1329  (dw/volRef, turbulence * turbResScale, AoS)
+//   nksolver::getRes     src/NKSolver/NKSolvers.F90:1413-1450  (same without turbResScale)
+//   computePressureSimple / computeLamViscosity / computeEddyViscosity on the owned cells
+//                        src/NKSolver/blockette.F90:199-203, flowUtils.F90:867-925,1201-1300, turbUtils.F90:657-720
+// Vector order: block, k, j, i, variable fastest (NKSolvers.F90:1240-1253).
+#include "internal.h"
+
+#define NK_BX 64
+#define NK_BY 4
+
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_set_w(BlkView b, const double* __restrict__ vec, double turbFloor)
+{
+    const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * NK_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long m = (((long)(k - 2) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw;
+    for (int l = 0; l < 5; ++l) b.w[c + l * b.nbox] = vec[m + l];
+    if (b.nw > 5) b.w[c + 5 * b.nbox] = fmax(turbFloor, vec[m + 5]);
+}
+
+// scale != 0: turbulence residual multiplied by `turbScale`; sums[0] += flow^2, sums[1] += turb^2
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_get_r(BlkView b, double* __restrict__ vec, double turbScale,
+                                                        double* __restrict__ sums)
+{
+    __shared__ double red[2][NK_BX * NK_BY];
+    const int tid = threadIdx.x + NK_BX * threadIdx.y;
+    const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * NK_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    double sf = 0.0, st = 0.0;
+    if (i <= b.il && j <= b.jl) {
+        const long c = b.idx(i, j, k);
+        const long m = (((long)(k - 2) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw;
+        const double ovv = 1.0 / b.volRef[c];
+        for (int l = 0; l < 5; ++l) {
+            const double t = b.dw[c + l * b.nbox] * ovv;
+            vec[m + l] = t;
+            sf += t * t;
+        }
+        if (b.nw > 5) {
+            const double t = b.dw[c + 5 * b.nbox] * ovv * turbScale;
+            vec[m + 5] = t;
+            st += t * t;
+        }
+    }
+    if (!sums) return;
+    red[0][tid] = sf;
+    red[1][tid] = st;
+    __syncthreads();
+    for (int s = NK_BX * NK_BY / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] += red[0][tid + s];
+            red[1][tid] += red[1][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        atomicAdd(&sums[0], red[0][0]);
+        atomicAdd(&sums[1], red[1][0]);
+    }
+}
+
+// owned cells: p from (rho, v, rhoE) with the 1e-4*pInfCorr floor, Sutherland, SA eddy viscosity
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_closures(BlkView b, KParams kp)
+{
+    const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * NK_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    const double gm1 = kp.gammaConstant - 1.0;
+    const double v2 = u * u + v * v + w * w;
+    double p = gm1 * (b.w[c + 4 * nb] - 0.5 * rho * v2);
+    p = fmax(p, 1.e-4 * kp.pInfCorr);
+    b.p[c] = p;
+    if (kp.viscous) {
+        const double muSuth = kp.muSuthDim / kp.muRef, TSuth = kp.TSuthDim / kp.TRef, SSuth = kp.SSuthDim / kp.TRef;
+        const double T = p / (kp.RGas * rho);
+        const double tt = T / TSuth;
+        const double rlv = muSuth * ((TSuth + SSuth) / (T + SSuth)) * (tt * sqrt(tt));
+        b.rlv[c] = rlv;
+        if (kp.eddyModel && kp.updateEddy) {
+            const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
+            const double rnuSA = b.w[c + 5 * nb] * rho;
+            const double chi = rnuSA / rlv;
+            const double chi3 = chi * chi * chi;
+            b.rev[c] = chi3 / (chi3 + cv13) * rnuSA;
+        }
+    }
+}
+
+static dim3 nk_grid(const BlkView& b) { return dim3((b.nx + NK_BX - 1) / NK_BX, (b.ny + NK_BY - 1) / NK_BY, b.nz); }
+
+void launch_set_w(const BlkView& b, const double* vec, double turbFloor, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_set_w, nk_grid(b), dim3(NK_BX, NK_BY, 1), 0, s, b, vec, turbFloor);
+}
+
+void launch_get_r(const BlkView& b, double* vec, double turbScale, double* sums, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_get_r, nk_grid(b), dim3(NK_BX, NK_BY, 1), 0, s, b, vec, turbScale, sums);
+}
+
+void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_closures, nk_grid(b), dim3(NK_BX, NK_BY, 1), 0, s, b, kp);
+}

@@ -121,6 +121,30 @@ class Engine:
     def DADISmoother(self, level=1):
         self._chk(self.lib.adflow_gpu_dadi_smooth(level))
 
+    # ---- Newton-Krylov glue (nksolver.* of src/f2py/adflow.pyf:394-421) -----
+    def setW(self, wVec: np.ndarray):
+        assert wVec.dtype == np.float64 and wVec.flags["C_CONTIGUOUS"]
+        self._chk(self.lib.adflow_gpu_set_w_vec(wVec.ctypes.data, wVec.size))
+
+    def setRVec(self, n: int):
+        """-> (rVec, sum flow^2, sum turb^2)"""
+        r = np.zeros(n)
+        s2 = np.zeros(2)
+        self._chk(self.lib.adflow_gpu_get_r_vec(r.ctypes.data, n, s2.ctypes.data))
+        return r, s2[0], s2[1]
+
+    def getRes(self, n: int):
+        r = np.zeros(n)
+        self._chk(self.lib.adflow_gpu_get_res(r.ctypes.data, n))
+        return r
+
+    def FormFunction_mf(self, wVec: np.ndarray):
+        """setW + blocketteRes + setRVec (NKSolvers.F90:437-461)."""
+        assert wVec.dtype == np.float64 and wVec.flags["C_CONTIGUOUS"]
+        r = np.zeros_like(wVec)
+        self._chk(self.lib.adflow_gpu_nk_residual(wVec.ctypes.data, r.ctypes.data, wVec.size))
+        return r
+
     # ---- multigrid ----------------------------------------------------------
     def transferToCoarseGrid(self, level=1):
         self._chk(self.lib.adflow_gpu_transfer_to_coarse(level))

@@ -136,7 +136,10 @@ enum {
 enum {
     ADFLOW_RES_UPDATE_INTERMED = 1u,   /* also store dtl, radI/J/K */
     ADFLOW_RES_FLOW = 2u,              /* useFlowRes  */
-    ADFLOW_RES_TURB = 4u               /* useTurbRes  */
+    ADFLOW_RES_TURB = 4u,              /* useTurbRes  */
+    /* the part of blocketteRes in front of the core (blockette.F90:195-246): */
+    ADFLOW_RES_CLOSURES = 8u,          /* computePressureSimple + laminar/eddy viscosity, owned cells */
+    ADFLOW_RES_HALO = 16u              /* boundary-condition hook + whalo2(1, lStart, lEnd, T,T,T) */
 };
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -212,6 +215,17 @@ typedef void (*adflow_bc_callback)(int level, int secondHalo);
 int adflow_gpu_set_bc_callback(adflow_bc_callback fn);
 /* sum over owned cells of (dw(:,l)/vol)^2, l=1..n  (solvers.F90:1538) */
 int adflow_gpu_res_norms(int level, double* sums, int n);
+
+/* ---- Newton-Krylov glue (src/NKSolver/NKSolvers.F90) -----------------------
+ * vectors are the PETSc layout: block, k, j, i, variable fastest; n = total DOF of
+ * the level-1 blocks of this process (nw * owned cells).  Host-pointer forms copy
+ * through PCIe; *_dev forms take device pointers (PETSc VECHIP). */
+int adflow_gpu_set_w_vec(const double* wVec, long n);                 /* setW :1331 (turbulence clipped at 1e-6*wInf) */
+int adflow_gpu_get_r_vec(double* rVec, long n, double* sumsq2);        /* setRVec :1262: dw/volRef, turb*turbResScale; sumsq2[0..1] = sum flow^2, turb^2 (may be NULL) */
+int adflow_gpu_get_res(double* res, long n);                           /* nksolver::getRes :1413: no turbResScale */
+/* FormFunction_mf (:437-461): setW + blocketteRes(all defaults) + setRVec */
+int adflow_gpu_nk_residual(const double* wVec, double* rVec, long n);
+int adflow_gpu_nk_residual_dev(const double* d_wVec, double* d_rVec, long n);
 
 /* ---- instrumentation: HIP events on the library's own stream ------------ */
 int adflow_gpu_event_record(int slot);                   /* slot in [0,64) */

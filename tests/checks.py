@@ -271,3 +271,64 @@ def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, **mk):
         for nn, b in fine.items():
             dw = engine.download_residual(nn, 1)
             assert_dw(b, dw, rfine[nn]["dw"], 5, what=f"residual after cycle {n}")
+
+
+def check_nk_residual(engine, topo, prm, seed=21, **mk):
+    """FormFunction_mf = setW + blocketteRes + setRVec (NKSolvers.F90:437-461,1262-1376):
+    the vector glue is restated in numpy (NKSolvers.F90 needs PETSc), every
+    arithmetic step in between is the reference's own routine."""
+    from oracle import ref
+    blocks, rblocks = setup_brick(engine, topo, prm, seed, **mk)
+    rng = np.random.default_rng(seed)
+    nw = prm.nw
+    # state vector in PETSc order: block, k, j, i, variable fastest
+    parts = []
+    for nn in sorted(blocks):
+        b = blocks[nn]
+        wv = np.ascontiguousarray(np.transpose(b.owned("w"), (2, 1, 0, 3))).reshape(-1, nw).copy()
+        wv *= 1.0 + 1e-3 * rng.uniform(-1, 1, wv.shape)
+        if nw > 5:
+            wv[::7, 5] = 0.0       # exercises the 1e-6*wInf clipping of setW
+        parts.append(wv.reshape(-1))
+    wVec = np.concatenate(parts)
+    # --- reference side
+    winf = prm.wInf()
+    off = 0
+    for nn in sorted(rblocks):
+        r = rblocks[nn]
+        n = r.ncells * nw
+        wv = wVec[off:off + n].reshape(r.nz, r.ny, r.nx, nw)
+        off += n
+        r.owned("w")[...] = np.transpose(wv, (2, 1, 0, 3))
+        if nw > 5:
+            r.owned("w")[..., 5] = np.maximum(1e-6 * winf[5], r.owned("w")[..., 5])
+        ref.call_level("setPointers", 1, nn)
+        ref.call("computePressureSimple", 0)
+        ref.call("computeLamViscosity", 0)
+        ref.call("computeEddyViscosity", 0)
+    ref.call_level("whalo2", 1, 1, nw)
+    rparts = []
+    for nn in sorted(rblocks):
+        r = rblocks[nn]
+        ref.call_level("setPointers", 1, nn)
+        ref.block_res_core(False, True, prm.eddyModel)
+        res = r.owned("dw") / r.owned("volRef")[..., None]
+        if nw > 5:
+            res[..., 5] *= prm.turbResScale
+        rparts.append(np.ascontiguousarray(np.transpose(res, (2, 1, 0, 3))).reshape(-1))
+    rRef = np.concatenate(rparts)
+    # --- GPU side
+    rGpu = engine.FormFunction_mf(wVec)
+    rr = rGpu.reshape(-1, nw)
+    rf = rRef.reshape(-1, nw)
+    for l in range(nw):
+        e = rel_err(rr[:, l], rf[:, l])
+        assert e <= TOL, ("rVec", l, e)
+    # getRes (no turbResScale) and setRVec norms
+    r2, sf, st = engine.setRVec(wVec.size)
+    assert rel_err(r2, rGpu) == 0.0
+    assert abs(sf - (rf[:, :5] ** 2).sum()) <= 1e-9 * sf
+    if nw > 5:
+        assert abs(st - (rf[:, 5] ** 2).sum()) <= 1e-9 * max(st, 1e-300)
+        g = engine.getRes(wVec.size).reshape(-1, nw)
+        assert rel_err(g[:, 5] * prm.turbResScale, rr[:, 5]) <= 1e-14

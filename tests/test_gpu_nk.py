@@ -1,0 +1,42 @@
+"""GPU parity (real MI355X, through the C-ABI): the Newton-Krylov residual
+function FormFunction_mf = setW + blocketteRes + setRVec (BASELINE config 5;
+src/NKSolver/NKSolvers.F90:437-461) on multi-block bricks, and a matrix-free
+matvec proxy (finite difference of the residual along a random direction)."""
+import numpy as np
+import pytest
+
+import checks
+from adflow_amd.params import FlowParams, RANSEquations, upwind, dissMatrix
+from adflow_amd.topology import BrickTopology
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nk_residual_euler(engine):
+    checks.check_nk_residual(engine, BrickTopology(2, 2, 1, 12, 10, 8), FlowParams())
+
+
+@pytest.mark.parametrize("sd", [upwind, dissMatrix])
+def test_nk_residual_crm_rans_parity_size(engine, sd):
+    # BASELINE configs 4/5 parity size: 8 blocks of 24x20x10, RANS-SA, 4a upwind / 4b matrix
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156)
+    checks.check_nk_residual(engine, BrickTopology(2, 2, 2, 24, 20, 10), prm, stretch_k=3.0)
+
+
+def test_matrix_free_matvec_is_linear(engine):
+    """(R(w + h v) - R(w)) / h is linear in v to O(h): the property PETSc's MFFD relies on."""
+    prm = FlowParams()
+    topo = BrickTopology(2, 1, 1, 10, 8, 6)
+    blocks, _ = checks.setup_brick(engine, topo, prm, 3)
+    w0 = np.concatenate([np.ascontiguousarray(np.transpose(blocks[nn].owned("w"), (2, 1, 0, 3))).reshape(-1)
+                         for nn in sorted(blocks)])
+    rng = np.random.default_rng(0)
+    v1, v2 = rng.standard_normal(w0.size), rng.standard_normal(w0.size)
+    v1 /= np.linalg.norm(v1)
+    v2 /= np.linalg.norm(v2)
+    h = 1e-7
+    r0 = engine.FormFunction_mf(w0)
+    j1 = (engine.FormFunction_mf(w0 + h * v1) - r0) / h
+    j2 = (engine.FormFunction_mf(w0 + h * v2) - r0) / h
+    j12 = (engine.FormFunction_mf(w0 + h * (v1 + v2)) - r0) / h
+    assert np.linalg.norm(j12 - j1 - j2) <= 1e-5 * np.linalg.norm(j12)

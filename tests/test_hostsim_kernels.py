@@ -105,3 +105,9 @@ def test_mg_transfer(hostsim_engine):
 @pytest.mark.parametrize("cycling", [[0, 1, 0, -1], [0, 1, 0, 0, -1, 0]])
 def test_mg_cycle(hostsim_engine, cycling):
     checks.check_mg_cycle(hostsim_engine, BrickTopology(2, 1, 1, 8, 6, 4), FlowParams(), cycling)
+
+
+def test_nk_residual(hostsim_engine):
+    checks.check_nk_residual(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams())
+    checks.check_nk_residual(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
+                             FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
