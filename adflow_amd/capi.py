@@ -31,7 +31,8 @@ class AdflowOpts(ctypes.Structure):
         ("smoother", c_int32), ("nRKStages", c_int32), ("resAveraging", c_int32), ("nSubiterations", c_int32),
         ("nSubIterTurb", c_int32),
         ("groundLevel", c_int32),
-        ("reserved_i", c_int32 * 3),
+        ("turbRelax", c_int32),
+        ("reserved_i", c_int32 * 2),
         ("gammaConstant", c_double), ("prandtl", c_double), ("prandtlTurb", c_double),
         ("SSuthDim", c_double), ("muSuthDim", c_double), ("TSuthDim", c_double),
         ("SAKappa", c_double), ("SAcb1", c_double), ("SAcb2", c_double), ("SAsigma", c_double), ("SAcv1", c_double),
@@ -93,6 +94,7 @@ EXPORTS = [
     "adflow_gpu_upload_array", "adflow_gpu_set_options",
     "adflow_gpu_time_step", "adflow_gpu_initres", "adflow_gpu_residual", "adflow_gpu_block_res",
     "adflow_gpu_rk_smooth", "adflow_gpu_dadi_smooth", "adflow_gpu_halo_exchange", "adflow_gpu_res_norms",
+    "adflow_gpu_sa_solve", "adflow_gpu_set_turb_bc_callback",
     "adflow_gpu_set_w_vec", "adflow_gpu_get_r_vec", "adflow_gpu_get_res", "adflow_gpu_nk_residual",
     "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
@@ -139,6 +141,8 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_dadi_smooth.argtypes = [c_int]
     lib.adflow_gpu_halo_exchange.argtypes = [c_int] * 6
     lib.adflow_gpu_res_norms.argtypes = [c_int, c_void_p, c_int]
+    lib.adflow_gpu_sa_solve.argtypes = [c_int]
+    lib.adflow_gpu_set_turb_bc_callback.argtypes = [c_void_p]
     lib.adflow_gpu_set_w_vec.argtypes = [c_void_p, ctypes.c_long]
     lib.adflow_gpu_get_r_vec.argtypes = [c_void_p, ctypes.c_long, c_void_p]
     lib.adflow_gpu_get_res.argtypes = [c_void_p, ctypes.c_long]

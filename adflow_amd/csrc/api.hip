@@ -88,6 +88,7 @@ std::map<int, int> g_tab_size;
 std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
 bool g_use_march = true;                               // tuning: adflow_gpu_set_tuning("euler_march", 0|1)
 adflow_bc_callback g_bc_callback = nullptr;
+adflow_bc_callback g_turb_bc_callback = nullptr;
 double* g_norm_dev = nullptr;
 
 void free_list(CommList& l)
@@ -232,6 +233,8 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.sa_k = o.SAKappa; k.sa_cb1 = o.SAcb1; k.sa_cb2 = o.SAcb2; k.sa_cb3 = o.SAsigma; k.sa_cv1 = o.SAcv1;
     k.sa_cw1 = o.SAcw1; k.sa_cw2 = o.SAcw2; k.sa_cw3 = o.SAcw3; k.sa_ct3 = o.SAct3; k.sa_ct4 = o.SAct4;
     k.sa_crot = o.SAcrot;
+    k.sa_qqFactor = (o.turbRelax == 2) ? 1.0 + (1.0 - o.alfaTurb) / o.alfaTurb : 1.0;
+    k.sa_updFactor = (o.turbRelax == 1) ? o.alfaTurb : 1.0;
     k.cfl = (level == 1) ? o.cfl : o.cflCoarse;
     k.cflLimit = o.cflLimit; k.smoop = o.smoop; k.fcoll = o.fcoll; k.turbResScale = o.turbResScale;
     for (int i = 0; i < 10; ++i) k.wInf[i] = o.wInf[i];
@@ -1300,6 +1303,10 @@ int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
             rc = fail("mg_cycle: cycling(%d) = %d is not -1, 0 or 1", n + 1, cycling[n]);
         }
     }
+    if (!rc && g_opts.equations == ADFLOW_RANS) {
+        // turbSolveDDADI on the ground level (multiGrid.F90:938)
+        rc = adflow_gpu_sa_solve(g_opts.groundLevel);
+    }
     if (!rc) {
         // closing time step + residual on the ground level (multiGrid.F90:944-950)
         level = g_opts.groundLevel;
@@ -1432,6 +1439,37 @@ int adflow_gpu_nk_residual(const double* wVec, double* rVec, long n)
     if (get_r_dev(g_vec_dev, g_opts.turbResScale, nullptr)) return 1;
     HIPCHK(hipMemcpyAsync(rVec, g_vec_dev, sizeof(double) * n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+// turbAPI::turbSolveDDADI (src/turbulence/turbAPI.F90:4-95) for Spalart-Allmaras:
+// nSubIterTurb x [ sa_block(.false.) on every block ; whalo2(nt1:nt2, no p, viscosities) ]
+int adflow_gpu_sa_solve(int level)
+{
+    if (need_ready()) return 1;
+    if (g_opts.equations != ADFLOW_RANS) return fail("adflow_gpu_sa_solve needs equations = RANS");
+    const int nit = std::max(1, (int)g_opts.nSubIterTurb);
+    for (int it = 0; it < nit; ++it) {
+        KParams kp = make_kparams(level, 1.0, 0);
+        int rc = for_level(level, [&](Block* b) {
+            if (b->v.nw < 6) return fail("RANS/SA needs nw = 6 (block has %d)", b->v.nw);
+            launch_sa_solve(b->v, kp, g_stream);
+            return 0;
+        });
+        if (rc) return rc;
+        if (g_turb_bc_callback) {
+            HIPCHK(hipStreamSynchronize(g_stream));
+            g_turb_bc_callback(level, 1);
+        }
+        if (g_comm.count(std::make_pair(level, 2)))
+            if (halo_exchange_enqueue(level, 6, 6, 0, 1, 2)) return 1;
+    }
+    return sync_and_check();
+}
+
+int adflow_gpu_set_turb_bc_callback(adflow_bc_callback fn)
+{
+    g_turb_bc_callback = fn;
     return 0;
 }
 

@@ -91,6 +91,8 @@ struct KParams {
     double gammaConstant, gammaInf, pInf, pInfCorr, rhoInf, RGas, muRef, TRef, timeRef;
     double prandtl, prandtlTurb, SSuthDim, muSuthDim, TSuthDim;
     double sa_k, sa_cb1, sa_cb2, sa_cb3, sa_cv1, sa_cw1, sa_cw2, sa_cw3, sa_ct3, sa_ct4, sa_crot;
+    double sa_qqFactor;    // 1 + (1-alfaTurb)/alfaTurb for implicit relaxation, else 1
+    double sa_updFactor;   // alfaTurb for explicit relaxation, else 1
     double cfl, cflLimit, smoop, fcoll, turbResScale;
     double wInf[10];
 };
@@ -102,6 +104,7 @@ void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_sa_residual(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_sa_solve(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_rk_save(const BlkView& b, hipStream_t s);
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s);
 void launch_scale_dw(const BlkView& b, double factor, int timesVol, hipStream_t s);

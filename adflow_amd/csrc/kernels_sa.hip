@@ -60,17 +60,20 @@ __device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const
 }
 
 // advection in one direction (turbUtils.F90:886-1070)
-__device__ __forceinline__ double sa_advect(const SaDir& d, double vol0, double u, double v, double w, bool secondOrd)
+__device__ __forceinline__ double sa_advect(const SaDir& d, double vol0, double u, double v, double w, bool secondOrd,
+                                            double* uuOut = nullptr)
 {
     const double voli = 0.5 / vol0;
     const double xa = (d.sp[0] + d.sm[0]) * voli, ya = (d.sp[1] + d.sm[1]) * voli, za = (d.sp[2] + d.sm[2]) * voli;
     const double uu = xa * u + ya * v + za * w;
     const double dwt = upwind_diff(secondOrd, uu > 0.0, d.nt[0], d.nt[1], d.nt[2], d.nt[3], d.nt[4]);
+    if (uuOut) *uuOut = uu;
     return -uu * dwt;
 }
 
 // diffusion in one direction (sa.F90:385-450)
-__device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double nu, double cb2, double cb3Inv)
+__device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double nu, double cb2, double cb3Inv,
+                                             double* c1mOut = nullptr, double* c1pOut = nullptr)
 {
     const double voli = 1.0 / vol0;
     const double volmi = 2.0 / (vol0 + d.volm), volpi = 2.0 / (vol0 + d.volp);
@@ -88,9 +91,13 @@ __device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double
     const double cdp = (nup + (1.0 + cb2) * nutp) * ttp * cb3Inv;
     const double c1m = fmax(cdm + cam, 0.0), c1p = fmax(cdp + cap, 0.0);
     const double c10 = c1m + c1p;
+    if (c1mOut) { *c1mOut = c1m; *c1pOut = c1p; }
     return c1m * d.nt[1] - c10 * d.nt[2] + c1p * d.nt[3];
 }
 
+// SOLVE: additionally store the right-hand side (scratch 0) and the central
+// jacobian qq (scratch 1) for the DDADI line solves of saSolve
+template <bool SOLVE>
 __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(BlkView b, KParams kp)
 {
     const int i = blockIdx.x * SA_BX + threadIdx.x + 2;
@@ -164,25 +171,132 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(BlkView b, KParams
     const double term1 = kp.sa_cb1 * (1.0 - ft2) * ss;
     const double term2 = dist2Inv * (kar2Inv * kp.sa_cb1 * ((1.0 - ft2) * fv2 + ft2) - kp.sa_cw1 * fwSa);
     double dvt = (term1 + term2 * nut) * nut;
+    double qq = 0.0;
+    if (SOLVE) {
+        // -d(source)/d(nuTilde), clipped at zero (sa.F90:306-332)
+        const double t1 = chi3 + cv13;
+        const double dfv1 = 3.0 * chi2 * cv13 / (t1 * t1);
+        const double t2 = 1.0 + chi * fv1;
+        const double dfv2 = (chi2 * dfv1 - 1.0) / (nu * (t2 * t2));
+        const double dft2 = -2.0 * kp.sa_ct4 * chi * ft2 / nu;
+        const double drr = (1.0 - rr * (fv2 + nut * dfv2)) * kar2Inv * dist2Inv / sst;
+        const double dgg = (1.0 - kp.sa_cw2 + 6.0 * kp.sa_cw2 * (rr2 * rr2 * rr)) * drr;
+        const double dfw = (cw36 / (gg6 + cw36)) * termFw * dgg;
+        qq = -2.0 * term2 * nut - dist2Inv * nut * nut * (kp.sa_cb1 * kar2Inv * (dfv2 - ft2 * dfv2 - fv2 * dft2 + dft2) - kp.sa_cw1 * dfw);
+        qq = fmax(qq, 0.0);
+    }
 
     // ---- advection, sweeps k, j, i (turbUtils.F90:886, 1118, 1349)
     const bool secondOrd = (kp.orderTurb == 2) && kp.groundLevelIsOne;
-    dvt += sa_advect(dk, vol0, u, v, w, secondOrd);
-    dvt += sa_advect(dj, vol0, u, v, w, secondOrd);
-    dvt += sa_advect(di, vol0, u, v, w, secondOrd);
+    double uu, c1m, c1p;
+    dvt += sa_advect(dk, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu);   // central jacobian: +uu or -uu (turbUtils.F90:972,1060)
+    dvt += sa_advect(dj, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu);
+    dvt += sa_advect(di, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu);
 
     // ---- diffusion, sweeps k, j, i (sa.F90:371, 473, 572)
-    dvt += sa_diffuse(dk, vol0, nu, kp.sa_cb2, cb3Inv);
-    dvt += sa_diffuse(dj, vol0, nu, kp.sa_cb2, cb3Inv);
-    dvt += sa_diffuse(di, vol0, nu, kp.sa_cb2, cb3Inv);
+    dvt += sa_diffuse(dk, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p;
+    dvt += sa_diffuse(dj, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p;
+    dvt += sa_diffuse(di, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p;
 
     // ---- scale (sa.F90:702-706)
     b.dw[c + 5 * nb] = -b.volRef[c] * dvt * flg_blank(b.flags[c]);
+    if (SOLVE) {
+        b.scratch[c] = dvt;
+        // saSolve scales the central jacobian by 1 + (1-alfa)/alfa for implicit relaxation (sa.F90:830-836)
+        b.scratch[c + nb] = kp.sa_qqFactor * qq;
+    }
+}
+
+// One direction of saSolve (sa.F90:858-1240): per line  bb = (-c1m - max(uu,0)) rblank,
+// dd = (-c1p + min(uu,0)) rblank, cc = qq, ff = rhs rblank; elimination from the END of
+// the line towards index 2, then forward substitution.  scratch: 0 rhs/solution, 1 qq,
+// 2 modified cc, 3 bb.  LAST: the k sweep, followed by the update of nuTilde and rev.
+template <int DIR>
+__global__ __launch_bounds__(64) void k_sa_sweep(BlkView b, KParams kp)
+{
+    const int a = blockIdx.x * 64 + threadIdx.x + 2;
+    const int bbi = blockIdx.y + 2;
+    int n, amax;
+    long c0, s;
+    const double* sN;
+    if (DIR == 0) { amax = b.jl; n = b.nx; c0 = b.idx(2, a, bbi); s = 1; sN = b.sI; }
+    else if (DIR == 1) { amax = b.il; n = b.ny; c0 = b.idx(a, 2, bbi); s = b.ldi; sN = b.sJ; }
+    else { amax = b.il; n = b.nz; c0 = b.idx(a, bbi, 2); s = b.ldk; sN = b.sK; }
+    if (a > amax) return;
+    const long nb = b.nbox;
+    const double cb3Inv = 1.0 / kp.sa_cb3;
+    double* rhs = b.scratch;
+    double* qqA = b.scratch + nb;
+    double* ccA = b.scratch + 2 * nb;
+    double* bbA = b.scratch + 3 * nb;
+    // backward elimination: m = n-1 (index jl) down to 0 (index 2)
+    double ccN = 1.0, bbN = 0.0, ffN = 0.0;   // values of row m+1
+    for (int m = n - 1; m >= 0; --m) {
+        const long c = c0 + m * s;
+        SaDir d;
+        load_dir(b, c, s, sN, d);
+        const double vol0 = b.vol[c];
+        const double nu = b.rlv[c] / b.w[c];
+        double c1m, c1p, uu;
+        (void)sa_diffuse(d, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p);
+        (void)sa_advect(d, vol0, b.w[c + nb], b.w[c + 2 * nb], b.w[c + 3 * nb], false, &uu);
+        const double rblank = flg_blank(b.flags[c]);
+        const double um = (uu < 0.0) ? uu : 0.0, up = (uu > 0.0) ? uu : 0.0;
+        const double bb = (-c1m - up) * rblank;
+        const double dd = (-c1p + um) * rblank;
+        double cc = qqA[c];
+        double ff = rhs[c] * rblank;
+        if (m < n - 1) {
+            const double f = dd / ccN;
+            cc = cc - f * bbN;
+            ff = ff - f * ffN;
+        }
+        ccA[c] = cc;
+        bbA[c] = bb;
+        rhs[c] = ff;
+        ccN = cc; bbN = bb; ffN = ff;
+    }
+    // forward substitution
+    double fprev = 0.0;
+    for (int m = 0; m < n; ++m) {
+        const long c = c0 + m * s;
+        double ff = rhs[c];
+        if (m > 0) ff = ff - bbA[c] * fprev;
+        ff = ff / ccA[c];
+        fprev = ff;
+        if (DIR == 2) {
+            // last sweep: update nuTilde (explicit relaxation factor) and the eddy viscosity
+            // (sa.F90:1248-1262, saEddyViscosity turbUtils.F90:657-720)
+            double nut = b.w[c + 5 * nb] + kp.sa_updFactor * ff;
+            nut = fmax(nut, 0.0);
+            b.w[c + 5 * nb] = nut;
+            rhs[c] = ff;
+            const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
+            const double rnuSA = nut * b.w[c];
+            const double chi = rnuSA / b.rlv[c];
+            const double chi3 = chi * chi * chi;
+            b.rev[c] = chi3 / (chi3 + cv13) * rnuSA;
+        } else {
+            rhs[c] = ff * qqA[c];   // right-hand side of the next direction
+        }
+    }
+}
+
+void launch_sa_solve(const BlkView& b, const KParams& kp, hipStream_t s)
+{
+    dim3 blk(SA_BX, SA_BY, 1);
+    dim3 grd((b.nx + SA_BX - 1) / SA_BX, (b.ny + SA_BY - 1) / SA_BY, b.nz);
+    hipLaunchKernelGGL((k_sa_residual<true>), grd, blk, 0, s, b, kp);
+    dim3 l64(64, 1, 1);
+    // sweep order of the reference: j, i, k
+    hipLaunchKernelGGL((k_sa_sweep<1>), dim3((b.nx + 63) / 64, b.nz, 1), l64, 0, s, b, kp);
+    hipLaunchKernelGGL((k_sa_sweep<0>), dim3((b.ny + 63) / 64, b.nz, 1), l64, 0, s, b, kp);
+    hipLaunchKernelGGL((k_sa_sweep<2>), dim3((b.nx + 63) / 64, b.ny, 1), l64, 0, s, b, kp);
 }
 
 void launch_sa_residual(const BlkView& b, const KParams& kp, hipStream_t s)
 {
     dim3 blk(SA_BX, SA_BY, 1);
     dim3 grd((b.nx + SA_BX - 1) / SA_BX, (b.ny + SA_BY - 1) / SA_BY, b.nz);
-    hipLaunchKernelGGL(k_sa_residual, grd, blk, 0, s, b, kp);
+    hipLaunchKernelGGL((k_sa_residual<false>), grd, blk, 0, s, b, kp);
 }

@@ -121,6 +121,9 @@ class Engine:
     def DADISmoother(self, level=1):
         self._chk(self.lib.adflow_gpu_dadi_smooth(level))
 
+    def turbSolveDDADI(self, level=1):
+        self._chk(self.lib.adflow_gpu_sa_solve(level))
+
     # ---- Newton-Krylov glue (nksolver.* of src/f2py/adflow.pyf:394-421) -----
     def setW(self, wVec: np.ndarray):
         assert wVec.dtype == np.float64 and wVec.flags["C_CONTIGUOUS"]

@@ -19,7 +19,8 @@ module adflowGpuShim
         integer(c_int32_t) :: dirScaling
         integer(c_int32_t) :: smoother, nRKStages, resAveraging, nSubiterations, nSubIterTurb
         integer(c_int32_t) :: groundLevel
-        integer(c_int32_t) :: reserved_i(3)
+        integer(c_int32_t) :: turbRelax
+        integer(c_int32_t) :: reserved_i(2)
         real(c_double) :: gammaConstant, prandtl, prandtlTurb
         real(c_double) :: SSuthDim, muSuthDim, TSuthDim
         real(c_double) :: SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot
@@ -168,6 +169,7 @@ contains
         o%smoother = smoother; o%nRKStages = nRKStages; o%resAveraging = resAveraging
         o%nSubiterations = nSubiterations; o%nSubIterTurb = nSubIterTurb
         o%groundLevel = groundLevel
+        o%turbRelax = turbRelax
         o%reserved_i = 0
         o%gammaConstant = gammaConstant; o%prandtl = prandtl; o%prandtlTurb = prandtlTurb
         o%SSuthDim = SSuthDim; o%muSuthDim = muSuthDim; o%TSuthDim = TSuthDim

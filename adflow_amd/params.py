@@ -81,6 +81,7 @@ class FlowParams:
     turbResScale: float = 10000.0
     nSubiterations: int = 1
     nSubIterTurb: int = 3
+    turbRelax: int = 2          # turbRelaxImplicit (SA default)
     alfaTurb: float = 0.8
     betaTurb: float = -1.0
     # --- iteration

@@ -42,6 +42,9 @@ enum { ADFLOW_RESAVG_NEVER = 0, ADFLOW_RESAVG_ALWAYS = 1, ADFLOW_RESAVG_ALTERNAT
 
 #define ADFLOW_MAX_RK_STAGES 8
 
+/* host hook type: see adflow_gpu_set_bc_callback */
+typedef void (*adflow_bc_callback)(int level, int secondHalo);
+
 /* Options: snapshot of the Fortran module variables the hot path reads.
  * Refreshed by the shim at every entry (Python may assign them between calls,
  * adflow/pyADflow.py:5463-5630).  Field names are the reference's. */
@@ -56,7 +59,8 @@ typedef struct adflow_opts {
     int32_t smoother, nRKStages, resAveraging, nSubiterations, nSubIterTurb;
     /* iteration (src/modules/iteration.f90) */
     int32_t groundLevel;
-    int32_t reserved_i[3];
+    int32_t turbRelax;        /* inputIteration: 1 explicit, 2 implicit (default for SA, inputParamRoutines.F90:3402) */
+    int32_t reserved_i[2];
     double gammaConstant, prandtl, prandtlTurb;
     double SSuthDim, muSuthDim, TSuthDim;
     double SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot;
@@ -182,6 +186,11 @@ int adflow_gpu_block_res(int level, unsigned flags);
 /* smoothers::RungeKuttaSmoother / DADISmoother (src/solver/smoothers.F90:4,383) */
 int adflow_gpu_rk_smooth(int level);
 int adflow_gpu_dadi_smooth(int level);
+/* turbAPI::turbSolveDDADI for Spalart-Allmaras (src/turbulence/turbAPI.F90:4-95, sa.F90:16-86,717-1268):
+ * nSubIterTurb x [SA residual + central jacobian, DDADI line solves j,i,k, update of
+ * nuTilde and rev, turbulent-BC hook, whalo2(nt1:nt2)] */
+int adflow_gpu_sa_solve(int level);
+int adflow_gpu_set_turb_bc_callback(adflow_bc_callback fn);   /* applyAllTurbBCThisBlock stays on the host */
 /* multigrid::transferToCoarseGrid (src/solver/multiGrid.F90:5-324): residual on `level`,
  * volume-weighted restriction to level+1, coarse residual, forcing term wr */
 int adflow_gpu_transfer_to_coarse(int level);
@@ -190,8 +199,7 @@ int adflow_gpu_transfer_to_coarse(int level);
 int adflow_gpu_transfer_to_fine(int level);
 /* multigrid::executeMGCycle (multiGrid.F90:825-955): `cycling` as produced by
  * setCycleStrategy (:957-1030): -1 prolongate, 0 smooth, +1 restrict; ends with the
- * ground-level time step + residual.  The SA DDADI solve between is the host's until
- * adflow_gpu_sa_solve exists. */
+ * turbSolveDDADI (RANS) and the ground-level time step + residual. */
 int adflow_gpu_mg_cycle(const int32_t* cycling, int nStepsCycling);
 /* register the 1-to-1 pattern of (level, nLayers = 1 | 2); lists are copied */
 int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* p);
@@ -211,7 +219,6 @@ int adflow_gpu_halo_local_copy(int level, int nLayers, int varStart, int varEnd,
 /* host hook called between the state update and the halo exchange of every
  * smoother stage, where the reference applies boundary conditions
  * (applyAllBC, smoothers.F90:369,680).  NULL (default) = no physical boundaries. */
-typedef void (*adflow_bc_callback)(int level, int secondHalo);
 int adflow_gpu_set_bc_callback(adflow_bc_callback fn);
 /* sum over owned cells of (dw(:,l)/vol)^2, l=1..n  (solvers.F90:1538) */
 int adflow_gpu_res_norms(int level, double* sums, int n);

@@ -46,7 +46,7 @@ def load(fast: bool = False) -> ctypes.CDLL:
 
 
 _INT_PARAMS = ["equations", "spaceDiscr", "spaceDiscrCoarse", "limiter", "orderTurb", "turbModel", "turbProd",
-               "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb", "nSubiterations"]
+               "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb", "nSubiterations", "turbRelax"]
 _BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA"]
 _REAL_PARAMS = ["vis2", "vis4", "vis2Coarse", "adis", "acousticScaleFactor", "kappaCoef", "sigma", "cfl",
                 "cflCoarse", "cflLimit", "fcoll", "smoop", "alfaTurb", "betaTurb", "rFil", "gammaConstant",
@@ -71,7 +71,7 @@ def set_params(prm) -> None:
     for n, v in (("equationMode", 1), ("cpModel", 1), ("precond", 1), ("kPresent", 0), ("lumpedDiss", 0),
                  ("approxSA", 0), ("radiiNeededFine", 1), ("radiiNeededCoarse", 1), ("lowSpeedPreconditioner", 0),
                  ("wallFunctions", 0), ("useDissContinuation", 0), ("nTimeIntervalsSpectral", 1),
-                 ("vortexCorr", 0), ("riemann", 1), ("riemannCoarse", 1), ("turbTreatment", 1), ("turbRelax", 1)):
+                 ("vortexCorr", 0), ("riemann", 1), ("riemannCoarse", 1), ("turbTreatment", 1)):
         lib.ref_set_int(n.encode(), v)
     for n, v in (("totalR", 0.0), ("totalR0", 0.0), ("pRef", prm.pInfDim), ("rhoRef", prm.rhoInfDim)):
         lib.ref_set_real(n.encode(), v)

@@ -636,6 +636,7 @@ contains
         case ('setPointers'); call setPointers(i1, level, 1_intType)
         case ('whalo2'); call whalo2(level, i1, i2, .true., .true., .true.)         ! haloExchange.F90:109
         case ('whalo1'); call whalo1(level, i1, i2, .true., .true., .true.)         ! haloExchange.F90:5
+        case ('whalo2_turb'); call whalo2(level, i1, i2, .false., .false., .true.)   ! turbAPI.F90:92
         case ('timeStep'); call timeStep(i1 /= 0)                                     ! solverUtils.F90:4
         case ('initres'); call initres(i1, i2)                                        ! residuals.F90:964
         case ('residual'); call residual                                              ! residuals.F90:1028

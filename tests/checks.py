@@ -332,3 +332,17 @@ def check_nk_residual(engine, topo, prm, seed=21, **mk):
         assert abs(st - (rf[:, 5] ** 2).sum()) <= 1e-9 * max(st, 1e-300)
         g = engine.getRes(wVec.size).reshape(-1, nw)
         assert rel_err(g[:, 5] * prm.turbResScale, rr[:, 5]) <= 1e-14
+
+
+def check_sa_solve(engine, topo, prm, seed=31, **mk):
+    """turbSolveDDADI: nSubIterTurb x [sa_block(.false.) ; whalo2(nt1:nt2)]
+    (turbAPI.F90:4-95, sa.F90:16-86,717-1268) on a periodic brick."""
+    from oracle import ref
+    blocks, rblocks = setup_brick(engine, topo, prm, seed, **mk)
+    for it in range(prm.nSubIterTurb):
+        for nn in sorted(rblocks):
+            ref.call_level("setPointers", 1, nn)
+            ref.call("sa_block", 0)
+        ref.load().ref_call_level(b"whalo2_turb", 1, 6, 6)
+    engine.turbSolveDDADI(1)
+    assert_state(engine, blocks, rblocks, prm, "SA DDADI solve")

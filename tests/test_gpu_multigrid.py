@@ -34,3 +34,11 @@ def test_mg_cycle_dadi(engine):
 def test_mg_cycle_upwind(engine):
     prm = FlowParams(spaceDiscr=upwind, spaceDiscrCoarse=upwind, resAveraging=noResAveraging)
     checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 12, 8, 8), prm, [0, 1, 0, -1])
+
+
+def test_mg_cycle_rans_dadi_with_sa_solve(engine):
+    # BASELINE config 3: RANS-SA, D-ADI smoother, turbSolveDDADI closing the cycle
+    from adflow_amd.params import RANSEquations
+    prm = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=3,
+                     nSubIterTurb=3)
+    checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 12, 8, 8), prm, [0], ncycles=2, stretch_k=2.5)

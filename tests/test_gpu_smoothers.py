@@ -55,3 +55,9 @@ def test_dadi_smoother_rans_tutorial_wing_config(engine):
 def test_dadi_degenerate_lines(engine):
     prm = FlowParams(equations=NSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2)
     checks.check_dadi_smoother(engine, BrickTopology(1, 1, 2, 5, 1, 4), prm, stretch_k=2.0)
+
+
+@pytest.mark.parametrize("nsub,order", [(1, 1), (3, 2)])
+def test_sa_ddadi_solve(engine, nsub, order):
+    prm = FlowParams(equations=RANSEquations, nSubIterTurb=nsub, orderTurb=order)
+    checks.check_sa_solve(engine, BrickTopology(2, 2, 1, 12, 10, 8), prm, stretch_k=2.5)

@@ -111,3 +111,15 @@ def test_nk_residual(hostsim_engine):
     checks.check_nk_residual(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams())
     checks.check_nk_residual(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
                              FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+
+
+def test_sa_ddadi_solve(hostsim_engine):
+    prm = FlowParams(equations=RANSEquations, nSubIterTurb=2, orderTurb=secondOrder)
+    checks.check_sa_solve(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), prm, stretch_k=2.0)
+
+
+def test_mg_cycle_rans_single_grid(hostsim_engine):
+    from adflow_amd.params import DADI
+    prm = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2,
+                     nSubIterTurb=2)
+    checks.check_mg_cycle(hostsim_engine, BrickTopology(2, 1, 1, 8, 6, 4), prm, [0], ncycles=1, stretch_k=2.0)
