@@ -39,6 +39,27 @@ __device__ __forceinline__ void stg(GPTR(double) base, unsigned byteoff, double 
     *(GPTR(double))((GPTR(char))base + byteoff) = v;
 }
 
+// value of the neighbouring lane of the 64-wide wavefront: lane_up1 = lane-1
+// (__shfl_up by 1), lane_dn1 = lane+1.  On gfx950 these are single DPP moves
+// (v_mov_b32_dpp wave_shr:1 / wave_shl:1) per 32-bit half instead of a
+// ds_bpermute through the LDS crossbar.  Lane 0 / 63 receive garbage.
+#ifdef HOSTSIM
+__device__ __forceinline__ double lane_up1(double v) { return __shfl_up(v, 1); }
+__device__ __forceinline__ double lane_dn1(double v) { return __shfl_down(v, 1); }
+__device__ __forceinline__ int lane_up1(int v) { return __shfl_up(v, 1); }
+#else
+__device__ __forceinline__ int lane_up1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_dn1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ double lane_up1(double v)
+{
+    return __hiloint2double(lane_up1(__double2hiint(v)), lane_up1(__double2loint(v)));
+}
+__device__ __forceinline__ double lane_dn1(double v)
+{
+    return __hiloint2double(lane_dn1(__double2hiint(v)), lane_dn1(__double2loint(v)));
+}
+#endif
+
 struct BlkView {
     int nx, ny, nz, nw;
     int il, jl, kl, ie, je, ke, ib, jb, kb;

@@ -49,20 +49,22 @@ __device__ __forceinline__ Cons cons_of(const Cell& q)
 __device__ __forceinline__ Cell shfl_cell_up(const Cell& q, int d)
 {
     Cell r;
-    r.rho = __shfl_up(q.rho, d); r.u = __shfl_up(q.u, d); r.v = __shfl_up(q.v, d);
-    r.w = __shfl_up(q.w, d); r.e = __shfl_up(q.e, d); r.p = __shfl_up(q.p, d);
+    (void)d;   // d == 1
+    r.rho = lane_up1(q.rho); r.u = lane_up1(q.u); r.v = lane_up1(q.v);
+    r.w = lane_up1(q.w); r.e = lane_up1(q.e); r.p = lane_up1(q.p);
     return r;
 }
 
 __device__ __forceinline__ Cons shfl_cons(const Cons& q, int d, bool up)
 {
     Cons r;
-    if (up) {
-        r.r = __shfl_up(q.r, d); r.ru = __shfl_up(q.ru, d); r.rv = __shfl_up(q.rv, d);
-        r.rw = __shfl_up(q.rw, d); r.ep = __shfl_up(q.ep, d);
-    } else {
-        r.r = __shfl_down(q.r, d); r.ru = __shfl_down(q.ru, d); r.rv = __shfl_down(q.rv, d);
-        r.rw = __shfl_down(q.rw, d); r.ep = __shfl_down(q.ep, d);
+    if (up) {   // d == 2: two single-lane shifts
+        (void)d;
+        r.r = lane_up1(lane_up1(q.r)); r.ru = lane_up1(lane_up1(q.ru)); r.rv = lane_up1(lane_up1(q.rv));
+        r.rw = lane_up1(lane_up1(q.rw)); r.ep = lane_up1(lane_up1(q.ep));
+    } else {    // d == 1
+        r.r = lane_dn1(q.r); r.ru = lane_dn1(q.ru); r.rv = lane_dn1(q.rv);
+        r.rw = lane_dn1(q.rw); r.ep = lane_dn1(q.ep);
     }
     return r;
 }
@@ -107,7 +109,8 @@ __device__ __forceinline__ double em_sensor(double sm, double s0, double sp, dou
 
 // MINW: minimum waves per SIMD requested from the register allocator (2: 256
 // VGPRs, no spills; 3: 168 VGPRs; 4: 128 VGPRs) — selectable for A/B runs
-template <int MINW>
+// FW: persistent dissipation residual fw of the Runge-Kutta scheme is read/written
+template <int MINW, bool FW>
 __global__ __launch_bounds__(64 * EM_BY, MINW) void k_euler_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
                                                            KParams kp)
 {
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(64 * EM_BY, MINW) void k_euler_march(const BlkView*
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 double fwn = accD[l] - fd[l];
-                if (kp.fwMode) {
+                if (FW) {
                     const double old = ldg(fw + l * nb, cw);
                     fwn = doDiss ? (kp.sfil * old + fwn) : old;
                     if (doDiss) stg(fw + l * nb, cw, fwn);
@@ -198,25 +201,32 @@ __global__ __launch_bounds__(64 * EM_BY, MINW) void k_euler_march(const BlkView*
             const Cons WLL = shfl_cons(W0, 2, true);
             const Cons WR = shfl_cons(W0, 1, false);
             const double sx = ldg(sIx, c - 8u), sy = ldg(sIy, c - 8u), sz = ldg(sIz, c - 8u);
-            const int flagL = __shfl_up(flag0, 1);
+            const int flagL = lane_up1(flag0);
             const int por = flg_porI((uint8_t)flagL);
             double gc[5], gd[5] = {0, 0, 0, 0, 0};
             em_central(qL, q0, sx, sy, sz, por, gc);
             if (doDiss) {
-                const double pR = __shfl_down(q0.p, 1);
+                const double pR = lane_dn1(q0.p);
                 const double d0 = em_sensor(qL.p, q0.p, pR, sslim);
-                const double dL = __shfl_up(d0, 1);
+                const double dL = lane_up1(d0);
                 const double rad0 = ldg(radI, c);
-                const double radL = __shfl_up(rad0, 1);
+                const double radL = lane_up1(rad0);
                 const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * (radL + rad0);
                 em_jst(WLL, WL, W0, WR, rrad, dL, d0, fis2, fis4, gd);
             }
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
-                const double gcP = __shfl_down(gc[l], 1);
-                const double gdP = __shfl_down(gd[l], 1);
-                accC[l] += gcP - gc[l];      // + plus face, - minus face
-                accD[l] += gd[l] - gdP;      // fw(R) += f : minus face adds, plus face subtracts
+                if (FW) {
+                    const double gcP = lane_dn1(gc[l]);
+                    const double gdP = lane_dn1(gd[l]);
+                    accC[l] += gcP - gc[l];      // + plus face, - minus face
+                    accD[l] += gd[l] - gdP;      // fw(R) += f : minus face adds, plus face subtracts
+                } else {
+                    // no persistent fw: only the net contribution N = D - F matters
+                    // (right cell += N, left cell -= N): one hand-over per component
+                    const double n = gd[l] - gc[l];
+                    accD[l] += n - lane_dn1(n);
+                }
             }
         }
         // ---- j-direction: both faces of the cell, neighbours through L1/L2
@@ -260,12 +270,14 @@ int g_march_minw = 2;
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;
-    if (g_march_minw >= 4)
-        hipLaunchKernelGGL((k_euler_march<4>), dim3(ntiles), dim3(64, EM_BY, 1), 0, s, tab, tiles, kp);
-    else if (g_march_minw == 3)
-        hipLaunchKernelGGL((k_euler_march<3>), dim3(ntiles), dim3(64, EM_BY, 1), 0, s, tab, tiles, kp);
-    else
-        hipLaunchKernelGGL((k_euler_march<2>), dim3(ntiles), dim3(64, EM_BY, 1), 0, s, tab, tiles, kp);
+    const dim3 blk(64, EM_BY, 1);
+    if (kp.fwMode) {
+        hipLaunchKernelGGL((k_euler_march<2, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp);
+    } else if (g_march_minw >= 3) {
+        hipLaunchKernelGGL((k_euler_march<3, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp);
+    } else {
+        hipLaunchKernelGGL((k_euler_march<2, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp);
+    }
 }
 
 // tile decomposition of one block for the table built by the host
