@@ -657,9 +657,6 @@ static int enqueue_flow_residual(int level, const KParams& kp)
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
         if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
             return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
-        if (kp.spaceDiscr == ADFLOW_DISS_MATRIX && !kp.fineGrid)
-            return fail("matrix dissipation on coarse multigrid levels (inviscidDissFluxMatrixCoarse) is not implemented: "
-                        "use coarseDiscretization = scalar or upwind");
         if (kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && !b->ss_valid && fabs(kp.rFil) >= 1.e-10) {
             launch_entropy(b->v, g_stream);
             b->ss_valid = true;

@@ -126,12 +126,14 @@ __device__ __forceinline__ void absA_times_dw(double lam1, double lam2, double l
 // matrix JST dissipative flux through face (l | l+1)  (fluxes.F90:523-690)
 __device__ __forceinline__ void jst_matrix_face(const Line& L, const double gam[5], int l, double nx, double ny, double nz,
                                                 int por, double dssL, double dssR, double fis2, double fis4, double sign,
-                                                double acc[5])
+                                                double acc[5], bool coarse = false)
 {
     const int r = l + 1, ll = l - 1, rr = l + 2;
     const double ppor = (por == ADF_POR_NORMAL) ? 1.0 : 0.0;
-    const double dis2 = ppor * fis2 * fmin(0.25, fmax(dssL, dssR));
-    const double dis4 = fmax(ppor * fis4 - dis2, 0.0);
+    // coarse multigrid levels (inviscidDissFluxMatrixCoarse, fluxes.F90:5205-5430): first
+    // differences only, dis0 = rFil*vis2Coarse*ppor passed in fis2, no sensor
+    const double dis2 = coarse ? ppor * fis2 : ppor * fis2 * fmin(0.25, fmax(dssL, dssR));
+    const double dis4 = coarse ? 0.0 : fmax(ppor * fis4 - dis2, 0.0);
     double ddw;
     ddw = L.rho[r] - L.rho[l];
     const double dr = dis2 * ddw - dis4 * (L.rho[rr] - L.rho[ll] - 3.0 * ddw);
@@ -321,7 +323,11 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
         gam[0] = gam[4] = 0.0;
 #pragma unroll
         for (int m = 1; m < 4; ++m) gam[m] = b.gamma[c + (m - 2) * s];
-        if (SCHEME == ADFLOW_DISS_MATRIX) {
+        if (SCHEME == ADFLOW_DISS_MATRIX && !kp.fineGrid) {
+            const double fis0 = kp.rFil * kp.vis2Coarse;
+            jst_matrix_face(L, gam, 1, mx, my, mz, porM, 0.0, 0.0, fis0, 0.0, +1.0, fwd, true);
+            jst_matrix_face(L, gam, 2, px, py, pz, porP, 0.0, 0.0, fis0, 0.0, -1.0, fwd, true);
+        } else if (SCHEME == ADFLOW_DISS_MATRIX) {
             const double dm = mat_sensor(L.p[0], L.p[1], L.p[2], sslim);
             const double d0 = mat_sensor(L.p[1], L.p[2], L.p[3], sslim);
             const double dp = mat_sensor(L.p[2], L.p[3], L.p[4], sslim);

@@ -174,7 +174,8 @@ def sa_eddy_viscosity(prm: FlowParams, rho, nut, rlv):
 
 
 def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.0), amp=0.02,
-               stretch_k=1.0, wall_kmin=None, noise=0.02, wave=0.05, origin=(0.0, 0.0, 0.0)) -> Block:
+               stretch_k=1.0, wall_kmin=None, noise=0.02, wave=0.05, origin=(0.0, 0.0, 0.0), holes=0.0,
+               noflux_jmax=False) -> Block:
     """Analytic curvilinear block + perturbed free-stream state."""
     rng = np.random.default_rng(seed)
     nw = prm.nw
@@ -218,7 +219,14 @@ def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.
         wall_kmin = prm.viscous
     if wall_kmin:
         porK[:, :, 0] = boundFlux  # solid wall on the k = kmin face
+    if noflux_jmax:
+        porJ[:, ny, :] = noFlux     # conservative non-matching boundary on the j = jmax face
     b["porI"], b["porJ"], b["porK"] = porI, porJ, porK
+    if holes > 0.0:
+        # overset-style blanking: iblank 0 (hole) and -1 (fringe) cells, halos included
+        r = rng.uniform(0.0, 1.0, b["iblank"].shape)
+        b["iblank"][r < holes] = 0
+        b["iblank"][(r >= holes) & (r < 1.5 * holes)] = -1
 
     if prm.viscous:
         b["rlv"] = np.asfortranarray(sutherland(prm, w[..., 0], pr))

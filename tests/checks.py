@@ -198,35 +198,40 @@ def check_dadi_smoother(engine, topo, prm, seed=9, nsweeps=1, **mk):
         assert_state(engine, blocks, rblocks, prm, f"DADI sweep {sweep}")
 
 
-def setup_two_level_brick(engine, topo, prm, seed=1, **mk):
-    """Fine (level 1) + coarse (level 2) periodic bricks on the engine and in the
-    reference's flowDoms, with 1-to-1 patterns on both levels."""
+def setup_multilevel_brick(engine, topo, prm, nlevels=2, seed=1, **mk):
+    """Periodic bricks on levels 1..nlevels (2:1 coarsening) on the engine and in the
+    reference's flowDoms, with 1-to-1 patterns on every level.
+    Returns (levels, rlevels): lists of {nn: Block}, index 0 = level 1."""
     from oracle import ref
     from adflow_amd.synth import make_coarse_block
     from adflow_amd.topology import BrickTopology, apply_local_copies_fast
     engine.release_all()
-    fine = make_brick(topo, prm, seed, **mk)
-    ctopo = BrickTopology(topo.Bi, topo.Bj, topo.Bk, topo.nx // 2, topo.ny // 2, topo.nz // 2)
-    coarse = {nn: make_coarse_block(b, prm, seed=seed + 1000 + nn, **mk) for nn, b in fine.items()}
-    fp = {L: topo.patterns(L)[0] for L in (1, 2)}
-    cpat = {L: ctopo.patterns(L)[0] for L in (1, 2)}
-    apply_local_copies_fast(fine, fp[2])
-    rfine = {nn: b.copy() for nn, b in fine.items()}
-    rcoarse = {nn: b.copy() for nn, b in coarse.items()}
+    levels = [make_brick(topo, prm, seed, **mk)]
+    topos = [topo]
+    for lv in range(2, nlevels + 1):
+        t = topos[-1]
+        topos.append(BrickTopology(t.Bi, t.Bj, t.Bk, t.nx // 2, t.ny // 2, t.nz // 2))
+        levels.append({nn: make_coarse_block(b, prm, seed=seed + 1000 * lv + nn, **mk) for nn, b in levels[-1].items()})
+    pats = [{L: t.patterns(L)[0] for L in (1, 2)} for t in topos]
+    apply_local_copies_fast(levels[0], pats[0][2])
+    rlevels = [{nn: b.copy() for nn, b in lev.items()} for lev in levels]
     p1 = prm.replace(currentLevel=1, groundLevel=1)
-    ref.bind_blocks(rfine, p1, level=1, nlevels=2)
-    ref.bind_blocks(rcoarse, p1, level=2, nlevels=2, alloc=False)
-    for L in (1, 2):
-        ref.set_internal_comm(1, L, fp[L])
-        ref.set_internal_comm(2, L, cpat[L])
+    for lv, rl in enumerate(rlevels, start=1):
+        ref.bind_blocks(rl, p1, level=lv, nlevels=nlevels, alloc=(lv == 1))
     engine.set_options(prm)
-    for nn in fine:
-        engine.register(fine[nn], nn=nn, level=1)
-        engine.register(coarse[nn], nn=nn, level=2)
-    for L in (1, 2):
-        engine.comm_register(1, L, fp[L])
-        engine.comm_register(2, L, cpat[L])
-    return fine, coarse, rfine, rcoarse
+    for lv, lev in enumerate(levels, start=1):
+        for nn, b in lev.items():
+            engine.register(b, nn=nn, level=lv)
+    for lv in range(1, nlevels + 1):
+        for L in (1, 2):
+            ref.set_internal_comm(lv, L, pats[lv - 1][L])
+            engine.comm_register(lv, L, pats[lv - 1][L])
+    return levels, rlevels
+
+
+def setup_two_level_brick(engine, topo, prm, seed=1, **mk):
+    levels, rlevels = setup_multilevel_brick(engine, topo, prm, 2, seed, **mk)
+    return levels[0], levels[1], rlevels[0], rlevels[1]
 
 
 def check_mg_transfer(engine, topo, prm, seed=11, **mk):
@@ -252,10 +257,11 @@ def check_mg_transfer(engine, topo, prm, seed=11, **mk):
     assert_state(engine, fine, rfine, prm, "prolongated state", level=1)
 
 
-def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, **mk):
+def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, nlevels=2, **mk):
     """executeMGCycle (multiGrid.F90:825-955) for a given cycling strategy."""
     from oracle import ref
-    fine, coarse, rfine, rcoarse = setup_two_level_brick(engine, topo, prm, seed, **mk)
+    levels, rlevels = setup_multilevel_brick(engine, topo, prm, nlevels, seed, **mk)
+    fine, rfine = levels[0], rlevels[0]
     ref.set_cycling(cycling)
     # entry condition of the cycle: time step and residual of the ground level are known
     ref.load().ref_set_int(b"rkStage", 0)

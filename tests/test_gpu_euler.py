@@ -41,3 +41,11 @@ def test_rk_stage_residuals_persistent_fw(engine, sd):
 def test_full_size_block_vs_reference(engine):
     """BASELINE roofline-size block (128^3) against the reference itself."""
     checks.check_block_res(engine, (128, 128, 128), FlowParams(spaceDiscr=dissScalar), seed=5)
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_blanked_cells_and_noflux_faces(engine, sd):
+    """iblank = 0 / -1 (overset holes, fringes) and noFlux porosity (conservative
+    non-matching boundary): residual_block's max(iblank,0) and porFlux = 0 paths."""
+    checks.check_block_res(engine, (33, 12, 9), FlowParams(spaceDiscr=sd), seed=40 + sd, holes=0.08, noflux_jmax=True,
+                           wall_kmin=True)

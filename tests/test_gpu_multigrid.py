@@ -42,3 +42,20 @@ def test_mg_cycle_rans_dadi_with_sa_solve(engine):
     prm = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=3,
                      nSubIterTurb=3)
     checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 12, 8, 8), prm, [0], ncycles=2, stretch_k=2.5)
+
+
+def test_mg_cycle_matrix_dissipation_on_coarse_level(engine):
+    from adflow_amd.params import dissMatrix
+    prm = FlowParams(spaceDiscr=dissMatrix, spaceDiscrCoarse=dissMatrix, vis4=0.1, resAveraging=noResAveraging)
+    checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 12, 8, 8), prm, [0, 1, 0, -1])
+
+
+def test_mg_cycle_three_levels_v(engine):
+    """3-level V cycle (mgStartlevel 1, cycle strategy "3v"-like)"""
+    checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 16, 8, 8), FlowParams(), [0, 1, 0, 1, 0, -1, 0, -1], nlevels=3)
+
+
+def test_mg_cycle_three_levels_w(engine):
+    """3-level W cycle: the coarsest level is visited twice"""
+    checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 16, 8, 8), FlowParams(),
+                          [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0], nlevels=3)

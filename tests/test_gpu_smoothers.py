@@ -61,3 +61,10 @@ def test_dadi_degenerate_lines(engine):
 def test_sa_ddadi_solve(engine, nsub, order):
     prm = FlowParams(equations=RANSEquations, nSubIterTurb=nsub, orderTurb=order)
     checks.check_sa_solve(engine, BrickTopology(2, 2, 1, 12, 10, 8), prm, stretch_k=2.5)
+
+
+def test_smoothers_with_blanked_cells(engine):
+    topo = BrickTopology(2, 1, 1, 12, 10, 8)
+    checks.check_rk_smoother(engine, topo, FlowParams(), holes=0.1)
+    checks.check_dadi_smoother(engine, topo, FlowParams(resAveraging=noResAveraging, cfl=1.5), holes=0.1)
+    checks.check_sa_solve(engine, topo, FlowParams(equations=RANSEquations, nSubIterTurb=2), holes=0.1, stretch_k=2.0)

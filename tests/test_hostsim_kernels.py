@@ -123,3 +123,24 @@ def test_mg_cycle_rans_single_grid(hostsim_engine):
     prm = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2,
                      nSubIterTurb=2)
     checks.check_mg_cycle(hostsim_engine, BrickTopology(2, 1, 1, 8, 6, 4), prm, [0], ncycles=1, stretch_k=2.0)
+
+
+# ---- edge cases the reference handles: blanked (overset) cells, noFlux faces --------
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_blanked_cells_and_noflux_faces(hostsim_engine, sd):
+    prm = FlowParams(spaceDiscr=sd)
+    checks.check_block_res(hostsim_engine, (9, 7, 6), prm, seed=40 + sd, holes=0.08, noflux_jmax=True, wall_kmin=True)
+
+
+def test_blanked_cells_rans_and_smoothers(hostsim_engine):
+    prm = FlowParams(equations=RANSEquations)
+    checks.check_block_res(hostsim_engine, (9, 7, 6), prm, seed=50, holes=0.08, noflux_jmax=True, stretch_k=2.0)
+    topo = BrickTopology(2, 1, 1, 6, 5, 4)
+    checks.check_rk_smoother(hostsim_engine, topo, FlowParams(), holes=0.1)
+    checks.check_dadi_smoother(hostsim_engine, topo, FlowParams(resAveraging=noResAveraging, cfl=1.5), holes=0.1)
+    checks.check_sa_solve(hostsim_engine, topo, FlowParams(equations=RANSEquations, nSubIterTurb=2), holes=0.1, stretch_k=2.0)
+
+
+def test_mg_cycle_three_levels(hostsim_engine):
+    checks.check_mg_cycle(hostsim_engine, BrickTopology(1, 1, 1, 8, 8, 8), FlowParams(),
+                          [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0], ncycles=1, nlevels=3)
