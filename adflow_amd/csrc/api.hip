@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw;
+extern int g_march_minw, g_march_kch, g_march_pipe;
 
 namespace {
 
@@ -1522,6 +1522,14 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!key) return fail("null tuning key");
     if (!strcmp(key, "euler_march")) { g_use_march = (value != 0); return 0; }
     if (!strcmp(key, "march_minw")) { g_march_minw = value; return 0; }
+    if (!strcmp(key, "march_pipe")) { g_march_pipe = value; return 0; }
+    if (!strcmp(key, "march_kch")) {
+        if (value < 4) return fail("march_kch must be >= 4");
+        g_march_kch = value;
+        for (auto& kv : g_tiles) hipFree(kv.second.first);   // tile tables depend on the chunk length
+        g_tiles.clear();
+        return 0;
+    }
     return fail("unknown tuning key '%s'", key);
 }
 

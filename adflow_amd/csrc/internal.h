@@ -48,8 +48,8 @@ __device__ __forceinline__ double lane_up1(double v) { return __shfl_up(v, 1); }
 __device__ __forceinline__ double lane_dn1(double v) { return __shfl_down(v, 1); }
 __device__ __forceinline__ int lane_up1(int v) { return __shfl_up(v, 1); }
 #else
-__device__ __forceinline__ int lane_up1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int lane_dn1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_up1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int lane_dn1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
 __device__ __forceinline__ double lane_up1(double v)
 {
     return __hiloint2double(lane_up1(__double2hiint(v)), lane_up1(__double2loint(v)));

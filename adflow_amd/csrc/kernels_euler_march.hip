@@ -69,6 +69,13 @@ __device__ __forceinline__ Cons shfl_cons(const Cons& q, int d, bool up)
     return r;
 }
 
+__device__ __forceinline__ Cons shfl_cons_up1(const Cons& q)
+{
+    Cons r;
+    r.r = lane_up1(q.r); r.ru = lane_up1(q.ru); r.rv = lane_up1(q.rv); r.rw = lane_up1(q.rw); r.ep = lane_up1(q.ep);
+    return r;
+}
+
 // central flux through the face between L and R (fluxes.F90:52-129);  dw(L) += f, dw(R) -= f
 __device__ __forceinline__ void em_central(const Cell& L, const Cell& R, double sx, double sy, double sz, int por, double f[5])
 {
@@ -112,7 +119,7 @@ __device__ __forceinline__ double em_sensor(double sm, double s0, double sp, dou
 // FW: persistent dissipation residual fw of the Runge-Kutta scheme is read/written
 template <int MINW, bool FW>
 __global__ __launch_bounds__(64 * EM_BY, MINW) void k_euler_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
-                                                           KParams kp)
+                                                           KParams kp, int kch)
 {
     const int4 t = tiles[blockIdx.x];           // x: block slot, y/z/w: tile coordinates
     if (t.x < 0) return;                        // padding entry of the XCD-ordered table
@@ -120,8 +127,8 @@ __global__ __launch_bounds__(64 * EM_BY, MINW) void k_euler_march(const BlkView*
     const int lane = threadIdx.x;
     const int i = t.y * EM_OUT + lane;          // columns i0-2 .. i0+61, i0 = 2 + 60*tx
     const int j = 2 + t.z * EM_BY + (int)threadIdx.y;
-    const int k0 = 2 + t.w * EM_KCH;
-    const int k1 = (k0 + EM_KCH - 1 < b.kl) ? k0 + EM_KCH - 1 : b.kl;
+    const int k0 = 2 + t.w * kch;
+    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
     const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
     const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jl) ? j : b.jl;   // clamped: every lane takes part in the shuffles
     const long nb = b.nbox;
@@ -265,18 +272,318 @@ __global__ __launch_bounds__(64 * EM_BY, MINW) void k_euler_march(const BlkView*
     }
 }
 
+// ---------------------------------------------------------------------------
+// Software-pipelined form of the same march.  One plane of the march is split
+// in two phases, each with its own set of global loads:
+//   A(k): k-face (k-1|k), finish + store cell k-1, i-face   (16 loads)
+//   B(k): both j-faces of cell k                               (32 loads)
+// and the loads of a phase are issued BEFORE the arithmetic of the other
+// phase, so every load has ~half an iteration of FP64 work (plus the other
+// waves of the SIMD) to hide its latency instead of being waited for
+// immediately.  The register allocator gets the full 256-VGPR budget (2 waves
+// per SIMD); latency hiding comes from the pipeline, not from occupancy.
+// ---------------------------------------------------------------------------
+struct InA {      // loads of phase A of plane k (the state of cell k+1 goes straight into the window)
+    double radK0;             // radK(k)
+    double sKx, sKy, sKz;     // normal of the face k-1|k (stored at k-1)
+    double sIx, sIy, sIz;     // normal of the face i-1|i (stored at i-1)
+    double radI0;             // radI(i)
+    double fwOld[5];          // FW only: fw of cell k-1
+    int flag0;                // flags of cell k
+};
+struct InB {      // loads of phase B of plane k
+    Cell qa, qb, qc, qd;      // j-2, j-1, j+1, j+2
+    double sMx, sMy, sMz;     // normal of the face j-1|j
+    double sPx, sPy, sPz;     // normal of the face j|j+1
+    double rJm, rJ0, rJp;     // radJ at j-1, j, j+1
+    int flagJm;               // flags of cell j-1
+};
+
+// LDSJ: the state rows j0-2 .. j0+EM_BY+1 of a plane are fetched ONCE per workgroup
+// (16-byte loads, two rows per wave instruction) into a 3-slot LDS ring and shared by
+// the EM_BY waves: 6 wide loads per wave and plane replace 30 narrow ones, which takes
+// the texture-address unit (the measured bottleneck of the register-only form:
+// TA busy 83-95 % of the kernel) out of the critical path.  One barrier per plane.
+#define EL_ROWS (EM_BY + 4)
+#define EL_PANEL (EL_ROWS * 64)          // doubles of one quantity in one slot
+#define EL_SLOT (6 * EL_PANEL)           // doubles of one slot (24 KiB)
+typedef double d2_t __attribute__((vector_size(16)));
+__device__ __forceinline__ d2_t ldg2(GPTR(const double) base, unsigned byteoff)
+{
+    return *(GPTR(const d2_t))((GPTR(const char))base + byteoff);
+}
+
+template <bool FW, bool LDSJ>
+__global__ __launch_bounds__(64 * EM_BY, 2) void k_euler_march_p(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
+                                                                 KParams kp, int kch)
+{
+    __shared__ __attribute__((aligned(16))) double lds[LDSJ ? 3 * EL_SLOT : 2];
+    const int4 t = tiles[blockIdx.x];
+    if (t.x < 0) return;
+    const BlkView& b = tab[t.x];
+    const int lane = threadIdx.x;
+    const int i = t.y * EM_OUT + lane;
+    const int j = 2 + t.z * EM_BY + (int)threadIdx.y;
+    const int k0 = 2 + t.w * kch;
+    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
+    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
+    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jl) ? j : b.jl;
+    const long nb = b.nbox;
+    const unsigned sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
+
+    EmPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w4 = m.w3 + nb;
+    m.p = (GPTR(const double))b.p;
+    GPTR(const double) radI = (GPTR(const double))b.radI;
+    GPTR(const double) radJ = (GPTR(const double))b.radJ;
+    GPTR(const double) radK = (GPTR(const double))b.radK;
+    GPTR(const double) sIx = (GPTR(const double))b.sI; GPTR(const double) sIy = sIx + nb; GPTR(const double) sIz = sIy + nb;
+    GPTR(const double) sJx = (GPTR(const double))b.sJ; GPTR(const double) sJy = sJx + nb; GPTR(const double) sJz = sJy + nb;
+    GPTR(const double) sKx = (GPTR(const double))b.sK; GPTR(const double) sKy = sKx + nb; GPTR(const double) sKz = sKy + nb;
+    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
+    GPTR(double) dw = (GPTR(double))b.dw;
+    GPTR(double) fw = (GPTR(double))b.fw;
+    GPTR(const double) wr = (GPTR(const double))b.wr;
+
+    const double sslim = 0.001 * kp.pInfCorr;
+    const double fis2 = kp.rFil * kp.vis2, fis4 = kp.rFil * kp.vis4;
+    const bool doDiss = fabs(kp.rFil) >= 1.e-10;
+
+    InA a;
+    // phase-A loads of the plane at byte offset cc; the state of the cell above it lands in `up`
+    auto loadA = [&](unsigned cc, Cell& up) {
+        if (!LDSJ) up = ld_cell(m, cc + sk);
+        a.flag0 = flags[cc >> 3];
+        a.radK0 = ldg(radK, cc);
+        a.sKx = ldg(sKx, cc - sk); a.sKy = ldg(sKy, cc - sk); a.sKz = ldg(sKz, cc - sk);
+        a.sIx = ldg(sIx, cc - 8u); a.sIy = ldg(sIy, cc - 8u); a.sIz = ldg(sIz, cc - 8u);
+        a.radI0 = ldg(radI, cc);
+        if (FW) {
+#pragma unroll
+            for (int l = 0; l < 5; ++l) a.fwOld[l] = ldg(fw + l * nb, cc - sk);
+        }
+    };
+    auto loadB = [&](unsigned cc, InB& q) {
+        if (!LDSJ) {
+            q.qb = ld_cell(m, cc - sj); q.qc = ld_cell(m, cc + sj);
+            q.qa = ld_cell(m, cc - 2 * sj); q.qd = ld_cell(m, cc + 2 * sj);
+        }
+        q.flagJm = flags[(cc - sj) >> 3];
+        q.sMx = ldg(sJx, cc - sj); q.sMy = ldg(sJy, cc - sj); q.sMz = ldg(sJz, cc - sj);
+        q.sPx = ldg(sJx, cc); q.sPy = ldg(sJy, cc); q.sPz = ldg(sJz, cc);
+        q.rJm = ldg(radJ, cc - sj); q.rJ0 = ldg(radJ, cc); q.rJp = ldg(radJ, cc + sj);
+    };
+
+    // ---- LDS ring (LDSJ): slot of plane k0+n is n % 3.  This wave stages rows 2*ty and
+    //      2*ty+1 of the 8-row panel: lanes 0-31 the first, lanes 32-63 the second row,
+    //      two adjacent cells per lane.
+    const int ty = threadIdx.y;
+    const int hrow = 2 * ty + (lane >> 5), xp = 2 * (lane & 31);
+    unsigned cs = 0;            // byte offset of this lane's pair in the plane being staged
+    int splane = k0;            // plane index of the next staging load
+    d2_t st[6];
+    if (LDSJ) {
+        int jr = t.z * EM_BY + hrow;                  // j0 - 2 + hrow
+        if (jr > b.jb) jr = b.jb;
+        int ip = t.y * EM_OUT + xp;                   // even; the last pair may run one cell past ib (row padding)
+        if (ip > (b.ib & ~1)) ip = b.ib & ~1;         // stays 16-byte aligned
+        cs = 8u * (unsigned)(ip + jr * b.ldi);
+    }
+    const int ldsW = hrow * 64 + xp;                  // position inside a panel
+    auto stage_load = [&]() {
+        const int pl = (splane < b.kb) ? splane : b.kb;
+        const unsigned o = cs + (unsigned)pl * sk;
+        st[0] = ldg2(m.w0, o); st[1] = ldg2(m.w1, o); st[2] = ldg2(m.w2, o); st[3] = ldg2(m.w3, o); st[4] = ldg2(m.w4, o);
+        st[5] = ldg2(m.p, o);
+        ++splane;
+    };
+    auto stage_store = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) *(d2_t*)&lds[slot * EL_SLOT + q * EL_PANEL + ldsW] = st[q];
+    };
+    auto lds_cell = [&](int slot, int row) {
+        const double* __restrict__ r = &lds[slot * EL_SLOT + row * 64 + lane];
+        Cell q;
+        q.rho = r[0]; q.u = r[EL_PANEL]; q.v = r[2 * EL_PANEL]; q.w = r[3 * EL_PANEL]; q.e = r[4 * EL_PANEL];
+        q.p = r[5 * EL_PANEL];
+        return q;
+    };
+    int sl0 = 0, sl1 = 1, sl2 = 2;   // slots of the planes k, k+1, k+2
+
+    // prologue: window k-2 .. k of the own column, phase-A loads of the first plane
+    Cell S0 = ld_cell(m, c - 2 * sk), S1 = ld_cell(m, c - sk), S2 = ld_cell(m, c), S3;
+    double radKm = ldg(radK, c - sk);
+    int flagm = flags[(c - sk) >> 3];
+    if (LDSJ) {
+        stage_load(); stage_store(0);
+        stage_load(); stage_store(1);
+        stage_load();                 // plane k0+2: stays in flight until the first step stores it
+    }
+    loadA(c, S3);
+    if (LDSJ) {
+        __syncthreads();
+        S3 = lds_cell(1, ty + 2);
+    }
+    double dssKm = em_sensor(S0.p, S1.p, S2.p, sslim);
+    double accC[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};
+    double dssK0;
+
+    // k-face (k-1|k) from the phase-A loads; finishes and stores cell k-1, starts cell k
+    auto kface = [&](bool store, const Cell& qm2, const Cell& qm1, const Cell& q0, const Cell& qp1) {
+        dssK0 = em_sensor(qm1.p, q0.p, qp1.p, sslim);
+        double fc[5], fd[5] = {0, 0, 0, 0, 0};
+        const int por = flg_porK((uint8_t)flagm);
+        em_central(qm1, q0, a.sKx, a.sKy, a.sKz, por, fc);
+        if (doDiss) {
+            const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * (radKm + a.radK0);
+            em_jst(cons_of(qm2), cons_of(qm1), cons_of(q0), cons_of(qp1), rrad, dssKm, dssK0, fis2, fis4, fd);
+        }
+        if (store && out) {
+            const unsigned cw = c - sk;
+            const double blank = flg_blank((uint8_t)flagm);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                double fwn = accD[l] - fd[l];
+                if (FW) {
+                    const double old = a.fwOld[l];
+                    fwn = doDiss ? (kp.sfil * old + fwn) : old;
+                    if (doDiss) stg(fw + l * nb, cw, fwn);
+                }
+                double d = accC[l] + fc[l];
+                if (kp.coarseInit) d += ldg(wr + l * nb, cw);
+                stg(dw + l * nb, cw, (d + fwn) * blank);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 5; ++l) { accC[l] = -fc[l]; accD[l] = fd[l]; }
+    };
+
+    // one plane of the march; qm2's slot receives the state of cell k+2 (phase-A loads of plane k+1)
+    auto plane = [&](bool first, Cell& qm2, const Cell& qm1, const Cell& q0, const Cell& qp1) {
+        // ---- issue the loads of phase B(k); they complete under the arithmetic of A(k)
+        InB q;
+        if (LDSJ) {
+            stage_store(sl2);         // plane k+2 (loaded during the previous step)
+            stage_load();             // plane k+3
+        }
+        loadB(c, q);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ================= phase A(k) =================
+        kface(!first, qm2, qm1, q0, qp1);
+        const int flag0 = a.flag0;
+        const double radK0 = a.radK0;
+        {
+            const Cell qL = shfl_cell_up(q0, 1);
+            const Cons W0 = cons_of(q0);
+            const Cons WL = cons_of(qL);
+            const Cons WLL = shfl_cons_up1(WL);
+            const Cons WR = shfl_cons(W0, 1, false);
+            const int flagL = lane_up1(flag0);
+            const int por = flg_porI((uint8_t)flagL);
+            double gc[5], gd[5] = {0, 0, 0, 0, 0};
+            em_central(qL, q0, a.sIx, a.sIy, a.sIz, por, gc);
+            if (doDiss) {
+                const double pR = lane_dn1(q0.p);
+                const double d0 = em_sensor(qL.p, q0.p, pR, sslim);
+                const double dL = lane_up1(d0);
+                const double rad0 = a.radI0;
+                const double radL = lane_up1(rad0);
+                const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * (radL + rad0);
+                em_jst(WLL, WL, W0, WR, rrad, dL, d0, fis2, fis4, gd);
+            }
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                if (FW) {
+                    const double gcP = lane_dn1(gc[l]);
+                    const double gdP = lane_dn1(gd[l]);
+                    accC[l] += gcP - gc[l];      // + plus face, - minus face
+                    accD[l] += gd[l] - gdP;      // fw(R) += f : minus face adds, plus face subtracts
+                } else {
+                    // no persistent fw: only the net contribution N = D - F matters
+                    const double n = gd[l] - gc[l];
+                    accD[l] += n - lane_dn1(n);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- issue the loads of phase A(k+1); they complete under the arithmetic of B(k)
+        loadA(c + sk, qm2);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ================= phase B(k) =================
+        if (LDSJ) {
+            q.qa = lds_cell(sl0, ty); q.qb = lds_cell(sl0, ty + 1); q.qc = lds_cell(sl0, ty + 3); q.qd = lds_cell(sl0, ty + 4);
+        }
+        {
+            const int porM = flg_porJ((uint8_t)q.flagJm), porP = flg_porJ((uint8_t)flag0);
+            double hc[5], hd[5];
+            em_central(q.qb, q0, q.sMx, q.sMy, q.sMz, porM, hc);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) accC[l] -= hc[l];
+            em_central(q0, q.qc, q.sPx, q.sPy, q.sPz, porP, hc);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) accC[l] += hc[l];
+            if (doDiss) {
+                const double dm = em_sensor(q.qa.p, q.qb.p, q0.p, sslim), d0 = em_sensor(q.qb.p, q0.p, q.qc.p, sslim),
+                             dp = em_sensor(q0.p, q.qc.p, q.qd.p, sslim);
+                const double rrM = (porM == ADF_POR_NORMAL ? 0.5 : 0.0) * (q.rJm + q.rJ0);
+                const double rrP = (porP == ADF_POR_NORMAL ? 0.5 : 0.0) * (q.rJ0 + q.rJp);
+                const Cons Wa = cons_of(q.qa), Wb = cons_of(q.qb), W0 = cons_of(q0), Wc = cons_of(q.qc), Wd = cons_of(q.qd);
+                em_jst(Wa, Wb, W0, Wc, rrM, dm, d0, fis2, fis4, hd);
+#pragma unroll
+                for (int l = 0; l < 5; ++l) accD[l] += hd[l];
+                em_jst(Wb, W0, Wc, Wd, rrP, d0, dp, fis2, fis4, hd);
+#pragma unroll
+                for (int l = 0; l < 5; ++l) accD[l] -= hd[l];
+            }
+        }
+        radKm = radK0;
+        dssKm = dssK0;
+        flagm = flag0;
+        c += sk;
+        if (LDSJ) {
+            // plane k+2 is complete in LDS, plane k is no longer read: its slot takes plane k+3
+            __syncthreads();
+            qm2 = lds_cell(sl2, ty + 2);      // own column at k+2: the next step's qp1
+            const int s = sl0; sl0 = sl1; sl1 = sl2; sl2 = s;
+        }
+    };
+
+    for (int k = k0; k <= k1; ++k) {
+        plane(k == k0, S0, S1, S2, S3);
+        const Cell nxt = S0;
+        S0 = S1; S1 = S2; S2 = S3; S3 = nxt;
+    }
+    // epilogue: face k1|k1+1 closes the last cell of the chunk
+    kface(true, S0, S1, S2, S3);
+}
+
 int g_march_minw = 2;
+int g_march_kch = EM_KCH;      // k-chunk length of a tile (tuning "march_kch")
+int g_march_pipe = 2;          // tuning "march_pipe": 0 plain, 1 software-pipelined, 2 pipelined + state rows shared through LDS
 
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;
     const dim3 blk(64, EM_BY, 1);
-    if (kp.fwMode) {
-        hipLaunchKernelGGL((k_euler_march<2, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp);
+    if (g_march_pipe) {
+        if (g_march_pipe >= 2) {
+            if (kp.fwMode)
+                hipLaunchKernelGGL((k_euler_march_p<true, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+            else
+                hipLaunchKernelGGL((k_euler_march_p<false, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+        } else if (kp.fwMode)
+            hipLaunchKernelGGL((k_euler_march_p<true, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+        else
+            hipLaunchKernelGGL((k_euler_march_p<false, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+    } else if (kp.fwMode) {
+        hipLaunchKernelGGL((k_euler_march<2, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
     } else if (g_march_minw >= 3) {
-        hipLaunchKernelGGL((k_euler_march<3, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp);
+        hipLaunchKernelGGL((k_euler_march<3, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
     } else {
-        hipLaunchKernelGGL((k_euler_march<2, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp);
+        hipLaunchKernelGGL((k_euler_march<2, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
     }
 }
 
@@ -285,5 +592,5 @@ void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz)
 {
     *ntx = (b.nx + EM_OUT - 1) / EM_OUT;
     *nty = (b.ny + EM_BY - 1) / EM_BY;
-    *ntz = (b.nz + EM_KCH - 1) / EM_KCH;
+    *ntz = (b.nz + g_march_kch - 1) / g_march_kch;
 }

@@ -116,3 +116,4 @@ inline double __shfl_xor(double v, int mask, int width = 64) {
     const int base = (me / width) * width;
     return hostsim::shfl_exchange(v, base + ((me % width) ^ mask));
 }
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)

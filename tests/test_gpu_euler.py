@@ -49,3 +49,16 @@ def test_blanked_cells_and_noflux_faces(engine, sd):
     non-matching boundary): residual_block's max(iblank,0) and porFlux = 0 paths."""
     checks.check_block_res(engine, (33, 12, 9), FlowParams(spaceDiscr=sd), seed=40 + sd, holes=0.08, noflux_jmax=True,
                            wall_kmin=True)
+
+
+@pytest.mark.parametrize("pipe,kch", [(2, 4), (2, 5), (2, 64), (1, 4), (0, 4), (1, 64), (0, 32)])
+def test_euler_march_variants(engine, pipe, kch):
+    """marching kernel: k-chunk boundaries, software-pipelined and plain form"""
+    engine.set_tuning("march_pipe", pipe)
+    engine.set_tuning("march_kch", kch)
+    try:
+        checks.check_block_res(engine, (70, 9, 11), FlowParams(spaceDiscr=dissScalar), seed=77, wall_kmin=True)
+        checks.check_rk_residual_sequence(engine, (20, 6, 7), FlowParams(spaceDiscr=dissScalar), seed=78)
+    finally:
+        engine.set_tuning("march_pipe", 2)
+        engine.set_tuning("march_kch", 32)

@@ -144,3 +144,17 @@ def test_blanked_cells_rans_and_smoothers(hostsim_engine):
 def test_mg_cycle_three_levels(hostsim_engine):
     checks.check_mg_cycle(hostsim_engine, BrickTopology(1, 1, 1, 8, 8, 8), FlowParams(),
                           [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0], ncycles=1, nlevels=3)
+
+
+@pytest.mark.parametrize("pipe,kch", [(2, 4), (2, 5), (2, 32), (1, 4), (0, 4), (1, 5)])
+def test_euler_march_variants(hostsim_engine, pipe, kch):
+    """marching kernel: chunk boundaries (k-chunks of 4/5 planes on an 11-plane block) for the
+    software-pipelined and the plain form"""
+    hostsim_engine.set_tuning("march_pipe", pipe)
+    hostsim_engine.set_tuning("march_kch", kch)
+    try:
+        checks.check_block_res(hostsim_engine, (13, 6, 11), FlowParams(spaceDiscr=dissScalar), seed=77, wall_kmin=True)
+        checks.check_rk_residual_sequence(hostsim_engine, (9, 5, 7), FlowParams(spaceDiscr=dissScalar), seed=78)
+    finally:
+        hostsim_engine.set_tuning("march_pipe", 2)
+        hostsim_engine.set_tuning("march_kch", 32)
