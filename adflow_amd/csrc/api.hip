@@ -126,6 +126,7 @@ void invalidate_comm_level(int level)
 
 
 int ensure_table(int level);
+int res_averaging_level(int level, const KParams& kp);
 int ensure_tiles(int level);
 
 Block* find_block(int nn, int level, int sps)
@@ -748,6 +749,9 @@ int adflow_gpu_block_res(int level, unsigned flags)
 // ------------------------------------------------------------ halo exchange
 namespace {
 
+struct LevelDims { int nx, ny, nz; };
+std::map<int, LevelDims> g_tab_dims;                   // largest block extents of a level (grid of the batched launches)
+
 int ensure_table(int level)
 {
     if (g_tab.count(level)) return 0;
@@ -764,6 +768,18 @@ int ensure_table(int level)
     HIPCHK(hipMemcpy(d, h.data(), sizeof(BlkView) * h.size(), hipMemcpyHostToDevice));
     g_tab[level] = d;
     g_tab_size[level] = maxnn;
+    LevelDims ld = {0, 0, 0};
+    for (auto& v : h) { ld.nx = std::max(ld.nx, v.nx); ld.ny = std::max(ld.ny, v.ny); ld.nz = std::max(ld.nz, v.nz); }
+    g_tab_dims[level] = ld;
+    return 0;
+}
+
+// implicit residual averaging of every block of the level (one launch per direction)
+int res_averaging_level(int level, const KParams& kp)
+{
+    if (ensure_table(level)) return 1;
+    const LevelDims& ld = g_tab_dims[level];
+    launch_res_averaging_level(g_tab[level], g_tab_size[level], ld.nx, ld.ny, ld.nz, kp, g_stream);
     return 0;
 }
 
@@ -804,10 +820,11 @@ int ensure_tiles(int level)
     return 0;
 }
 
-int make_list(int level, const int32_t* blk, const int32_t* idx, int ld, int first, int n, int** d_blk, long** d_off)
+int make_list_host(int level, const int32_t* blk, const int32_t* idx, int ld, int first, int n, std::vector<int>& hb,
+                   std::vector<long>& ho)
 {
-    std::vector<int> hb(n);
-    std::vector<long> ho(n);
+    hb.resize(n);
+    ho.resize(n);
     for (int t = 0; t < n; ++t) {
         const int nn = blk[first + t];
         Block* b = find_block(nn, level, 1);
@@ -818,6 +835,12 @@ int make_list(int level, const int32_t* blk, const int32_t* idx, int ld, int fir
         hb[t] = nn;
         ho[t] = b->v.idx(i, j, k);
     }
+    return 0;
+}
+
+int upload_list(const std::vector<int>& hb, const std::vector<long>& ho, int** d_blk, long** d_off)
+{
+    const size_t n = hb.size();
     *d_blk = nullptr;
     *d_off = nullptr;
     if (n == 0) return 0;
@@ -826,6 +849,14 @@ int make_list(int level, const int32_t* blk, const int32_t* idx, int ld, int fir
     HIPCHK(hipMemcpy(*d_blk, hb.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(*d_off, ho.data(), sizeof(long) * n, hipMemcpyHostToDevice));
     return 0;
+}
+
+int make_list(int level, const int32_t* blk, const int32_t* idx, int ld, int first, int n, int** d_blk, long** d_off)
+{
+    std::vector<int> hb;
+    std::vector<long> ho;
+    if (make_list_host(level, blk, idx, ld, first, n, hb, ho)) return 1;
+    return upload_list(hb, ho, d_blk, d_off);
 }
 
 int build_comm(int level, int nLayers, CommPattern** out)
@@ -838,8 +869,23 @@ int build_comm(int level, int nLayers, CommPattern** out)
     if (cp.built) return 0;
     const int nc = (int)cp.h_donorBlock.size();
     cp.local.n = nc;
-    if (make_list(level, cp.h_donorBlock.data(), cp.h_donorIdx.data(), nc, 0, nc, &cp.local.blkA, &cp.local.offA)) return 1;
-    if (make_list(level, cp.h_haloBlock.data(), cp.h_haloIdx.data(), nc, 0, nc, &cp.local.blkB, &cp.local.offB)) return 1;
+    {
+        // same-GPU copies: the (donor, halo) pairs are independent (donors are owned cells), so they are
+        // re-ordered by halo address: consecutive lanes then write - and for 1-to-1 matching blocks also
+        // read - consecutive memory whatever order the host's commPattern lists them in
+        std::vector<int> db, hb;
+        std::vector<long> dof, hof;
+        if (make_list_host(level, cp.h_donorBlock.data(), cp.h_donorIdx.data(), nc, 0, nc, db, dof)) return 1;
+        if (make_list_host(level, cp.h_haloBlock.data(), cp.h_haloIdx.data(), nc, 0, nc, hb, hof)) return 1;
+        std::vector<int> perm(nc);
+        for (int t = 0; t < nc; ++t) perm[t] = t;
+        std::sort(perm.begin(), perm.end(), [&](int a, int c) { return hb[a] != hb[c] ? hb[a] < hb[c] : hof[a] < hof[c]; });
+        std::vector<int> db2(nc), hb2(nc);
+        std::vector<long> dof2(nc), hof2(nc);
+        for (int t = 0; t < nc; ++t) { db2[t] = db[perm[t]]; dof2[t] = dof[perm[t]]; hb2[t] = hb[perm[t]]; hof2[t] = hof[perm[t]]; }
+        if (upload_list(db2, dof2, &cp.local.blkA, &cp.local.offA)) return 1;
+        if (upload_list(hb2, hof2, &cp.local.blkB, &cp.local.offB)) return 1;
+    }
     const int ns = (int)cp.h_sendProc.size(), nr = (int)cp.h_recvProc.size();
     const int nst = ns ? cp.h_nsendCum[ns] : 0, nrt = nr ? cp.h_nrecvCum[nr] : 0;
     cp.sends.resize(ns);
@@ -1123,10 +1169,10 @@ int adflow_gpu_rk_smooth(int level)
         if (smooth_residual(stage)) {
             rc = for_level(level, [&](Block* b) {
                 launch_scale_dw(b->v, scale, 0, g_stream);
-                launch_res_averaging(b->v, kp, g_stream);
                 return 0;
             });
             if (rc) return rc;
+            if (res_averaging_level(level, kp)) return 1;
             if (finish_stage(level, kp, 0.0, 1)) return 1;
         } else {
             if (finish_stage(level, kp, scale, 1)) return 1;
@@ -1149,10 +1195,10 @@ int adflow_gpu_dadi_smooth(int level)
         KParams kp = make_kparams(level, 1.0, 0);
         int rc = for_level(level, [&](Block* b) {
             launch_dadi(b->v, kp, g_stream);
-            if (smooth_residual(0)) launch_res_averaging(b->v, kp, g_stream);   // rkStage stays 0 under DADI
             return 0;
         });
         if (rc) return rc;
+        if (smooth_residual(0) && res_averaging_level(level, kp)) return 1;   // rkStage stays 0 under DADI
         if (finish_stage(level, kp, 0.0, 0)) return 1;
         if (it < nsub) {
             if (enqueue_flow_residual(level, kp)) return 1;

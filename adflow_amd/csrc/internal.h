@@ -130,7 +130,7 @@ void launch_rk_save(const BlkView& b, hipStream_t s);
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s);
 void launch_scale_dw(const BlkView& b, double factor, int timesVol, hipStream_t s);
 void launch_stage_update(const BlkView& b, const KParams& kp, double scale, int fromWn, hipStream_t s);
-void launch_res_averaging(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_dadi(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_halo_copy(const BlkView* tab, const int* donorBlk, const long* donorOff, const int* haloBlk, const long* haloOff,
                       int n, unsigned mask, hipStream_t s);

@@ -174,43 +174,61 @@ __device__ __forceinline__ double ra_rfl(const BlkView& b, long c, double plim)
     return 1.0 / (1.0 + 2.0 * (dpi + dpj + dpk));
 }
 
-template <int DIR>
-__global__ __launch_bounds__(64) void k_res_averaging(BlkView b, KParams kp)
+// Level-batched form: ONE launch per direction covers every block of the level and
+// each of the 5 equations of a line is its own thread (the tridiagonal factor depends
+// only on p, so the equations are independent): 5 x nBlocks x more lines in flight
+// than one-line-per-lane-per-block, which is what hides the latency of the serial
+// Thomas recurrences.  The pressure switch rfl is evaluated once per cell by a
+// pointwise pre-pass (scratch 0) instead of once per cell, direction and sweep.
+// scratch 1..5: the eliminated super-diagonal d of each equation's own solve.
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_ra_rfl(const BlkView* __restrict__ tab, KParams kp, int maxnz)
 {
+    const BlkView& b = tab[blockIdx.z / maxnz + 1];
+    const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
+    const int k = blockIdx.z % maxnz + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
+    const long c = b.idx(i, j, k);
+    b.scratch[c] = ra_rfl(b, c, 0.001 * kp.pInfCorr);
+}
+
+template <int DIR>
+__global__ __launch_bounds__(64) void k_res_averaging(const BlkView* __restrict__ tab, KParams kp)
+{
+    const BlkView& b = tab[blockIdx.z / 5 + 1];
+    const int l = blockIdx.z % 5;
     // line coordinates (a fastest): DIR0 -> (j,k), DIR1 -> (i,k), DIR2 -> (i,j)
     const int a = blockIdx.x * 64 + threadIdx.x + 2;
     const int bb = blockIdx.y + 2;
-    int n, amax;
+    int n, amax, bmax;
     long c0, s;
-    if (DIR == 0) { amax = b.jl; n = b.nx; c0 = b.idx(2, a, bb); s = 1; }
-    else if (DIR == 1) { amax = b.il; n = b.ny; c0 = b.idx(a, 2, bb); s = b.ldi; }
-    else { amax = b.il; n = b.nz; c0 = b.idx(a, bb, 2); s = b.ldk; }
-    if (a > amax) return;
-    const long nb = b.nbox;
+    if (DIR == 0) { amax = b.jl; bmax = b.kl; n = b.nx; c0 = b.idx(2, a, bb); s = 1; }
+    else if (DIR == 1) { amax = b.il; bmax = b.kl; n = b.ny; c0 = b.idx(a, 2, bb); s = b.ldi; }
+    else { amax = b.il; bmax = b.jl; n = b.nz; c0 = b.idx(a, bb, 2); s = b.ldk; }
+    if (a > amax || bb > bmax || n <= 1) return;
     const double rfl0 = 0.5 * kp.cfl / kp.cflLimit;
-    const double plim = 0.001 * kp.pInfCorr;
-    // forward elimination; d(m) kept in the scratch array (component 0)
+    const double* __restrict__ R = b.scratch;
+    double* __restrict__ D = b.scratch + (1 + l) * b.nbox;
+    double* __restrict__ dw = b.dw + l * b.nbox;
+    // forward elimination (residuals.F90:1873-1895)
     double epzm = 0.0, dm = 0.0;          // epz(m-1), d(m-1) ; epz(1) = d(1) = 0
-    double prev[5] = {0, 0, 0, 0, 0};     // transformed dw(m-1)
-    double rflc = ra_rfl(b, c0, plim);
+    double prev = 0.0;                    // transformed dw(m-1)
+    double rflc = R[c0];
     for (int m = 0; m < n; ++m) {         // cell index 2+m along the line
         const long c = c0 + m * s;
         double epz = 0.0;
         double rfln = 0.0;
         if (m < n - 1) {                  // epz defined for 2..n (index il gets 0)
-            rfln = ra_rfl(b, c + s, plim);
+            rfln = R[c + s];
             const double r = rfl0 * (rflc + rfln);
             epz = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * flg_blank(b.flags[c]);
         }
         const double t = 1.0 / (1.0 + epz + epzm - epzm * dm);
         const double d = t * epz;
-        b.scratch[c] = d;
-#pragma unroll
-        for (int l = 0; l < 5; ++l) {
-            const double v = t * (b.dw[c + l * nb] + epzm * prev[l]);
-            b.dw[c + l * nb] = v;
-            prev[l] = v;
-        }
+        D[c] = d;
+        const double v = t * (dw[c] + epzm * prev);
+        dw[c] = v;
+        prev = v;
         epzm = epz;
         dm = d;
         rflc = rfln;
@@ -218,22 +236,132 @@ __global__ __launch_bounds__(64) void k_res_averaging(BlkView b, KParams kp)
     // back substitution from index nx down to 2 (residuals.F90:1897-1905)
     for (int m = n - 2; m >= 0; --m) {
         const long c = c0 + m * s;
-        const double d = b.scratch[c];
-#pragma unroll
-        for (int l = 0; l < 5; ++l) {
-            const double v = b.dw[c + l * nb] + d * prev[l];
-            b.dw[c + l * nb] = v;
-            prev[l] = v;
-        }
+        const double v = dw[c] + D[c] * prev;
+        dw[c] = v;
+        prev = v;
     }
 }
 
-void launch_res_averaging(const BlkView& b, const KParams& kp, hipStream_t s)
+// Lines along i are contiguous in memory: with lanes over j a wave would touch 64
+// different rows per access.  Here the 64 lines of a workgroup are processed in
+// chunks of RA_CH cells that travel through an LDS tile: global loads / stores move
+// 128-byte row segments (4 lines x 16 cells per wave access), the serial recurrence
+// of line `lane` runs on the tile.  Same arithmetic as k_res_averaging<0>.
+#define RA_CH 16
+#define RA_LD (RA_CH + 1)
+__global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restrict__ tab, KParams kp)
 {
-    dim3 blk(64, 1, 1);
-    if (b.nx > 1) hipLaunchKernelGGL((k_res_averaging<0>), dim3((b.ny + 63) / 64, b.nz, 1), blk, 0, s, b, kp);
-    if (b.ny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3((b.nx + 63) / 64, b.nz, 1), blk, 0, s, b, kp);
-    if (b.nz > 1) hipLaunchKernelGGL((k_res_averaging<2>), dim3((b.nx + 63) / 64, b.ny, 1), blk, 0, s, b, kp);
+    __shared__ double tv[64 * RA_LD];     // dw of the chunk
+    __shared__ double tr[64 * RA_LD];     // forward: rfl of the right neighbour, then d;  backward: d
+    __shared__ uint8_t tf[64 * RA_LD];    // iblank > 0
+    const BlkView& b = tab[blockIdx.z / 5 + 1];
+    const int l = blockIdx.z % 5;
+    const int lane = threadIdx.x;
+    const int j0 = blockIdx.x * 64 + 2;
+    const int k = blockIdx.y + 2;
+    const int n = b.nx;
+    if (j0 > b.jl || k > b.kl || n <= 1) return;
+    const double rfl0 = 0.5 * kp.cfl / kp.cflLimit;
+    const double* __restrict__ R = b.scratch;
+    double* __restrict__ D = b.scratch + (1 + l) * b.nbox;
+    double* __restrict__ dw = b.dw + l * b.nbox;
+    const int sub = lane >> 4, col = lane & 15;       // tile transfer role: 4 lines x 16 cells per access
+    const bool lineOk = (j0 + lane <= b.jl);
+    const int nch = (n + RA_CH - 1) / RA_CH;
+
+    double epzm = 0.0, dm = 0.0, prev = 0.0;
+    double rflc = lineOk ? R[b.idx(2, j0 + lane, k)] : 0.0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int i0 = 2 + ch * RA_CH;
+        const int i = i0 + col;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = 4 * q + sub;
+            double v = 0.0, rr = 0.0;
+            uint8_t f = 0;
+            if (j0 + r <= b.jl && i <= b.il) {
+                const long c = b.idx(i, j0 + r, k);
+                v = dw[c]; rr = R[c + 1]; f = b.flags[c];
+            }
+            tv[r * RA_LD + col] = v; tr[r * RA_LD + col] = rr; tf[r * RA_LD + col] = f;
+        }
+        __syncthreads();
+        if (lineOk) {
+            const int mEnd = (n - ch * RA_CH < RA_CH) ? n - ch * RA_CH : RA_CH;
+            for (int m = 0; m < mEnd; ++m) {
+                const int o = lane * RA_LD + m;
+                double epz = 0.0, rfln = 0.0;
+                if (ch * RA_CH + m < n - 1) {
+                    rfln = tr[o];
+                    const double r = rfl0 * (rflc + rfln);
+                    epz = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * flg_blank(tf[o]);
+                }
+                const double t = 1.0 / (1.0 + epz + epzm - epzm * dm);
+                const double d = t * epz;
+                tr[o] = d;
+                const double v = t * (tv[o] + epzm * prev);
+                tv[o] = v;
+                prev = v;
+                epzm = epz;
+                dm = d;
+                rflc = rfln;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = 4 * q + sub;
+            if (j0 + r <= b.jl && i <= b.il) {
+                const long c = b.idx(i, j0 + r, k);
+                dw[c] = tv[r * RA_LD + col]; D[c] = tr[r * RA_LD + col];
+            }
+        }
+        __syncthreads();
+    }
+    // back substitution: cells n-2 .. 0, chunks right to left
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        const int i0 = 2 + ch * RA_CH;
+        const int i = i0 + col;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = 4 * q + sub;
+            double v = 0.0, dd = 0.0;
+            if (j0 + r <= b.jl && i <= b.il) {
+                const long c = b.idx(i, j0 + r, k);
+                v = dw[c]; dd = D[c];
+            }
+            tv[r * RA_LD + col] = v; tr[r * RA_LD + col] = dd;
+        }
+        __syncthreads();
+        if (lineOk) {
+            int mTop = n - 2 - ch * RA_CH;              // last cell that is updated
+            if (mTop > RA_CH - 1) mTop = RA_CH - 1;
+            for (int m = mTop; m >= 0; --m) {
+                const int o = lane * RA_LD + m;
+                const double v = tv[o] + tr[o] * prev;
+                tv[o] = v;
+                prev = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = 4 * q + sub;
+            if (j0 + r <= b.jl && i <= b.il) dw[b.idx(i, j0 + r, k)] = tv[r * RA_LD + col];
+        }
+        __syncthreads();
+    }
+}
+
+void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_ra_rfl, dim3((maxnx + SM_BX - 1) / SM_BX, (maxny + SM_BY - 1) / SM_BY, maxnz * nslots),
+                       dim3(SM_BX, SM_BY, 1), 0, s, tab, kp, maxnz);
+    const dim3 blk(64, 1, 1);
+    if (maxnx > 1) hipLaunchKernelGGL(k_res_averaging_i, dim3((maxny + 63) / 64, maxnz, 5 * nslots), blk, 0, s, tab, kp);
+    if (maxny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3((maxnx + 63) / 64, maxnz, 5 * nslots), blk, 0, s, tab, kp);
+    if (maxnz > 1) hipLaunchKernelGGL((k_res_averaging<2>), dim3((maxnx + 63) / 64, maxny, 5 * nslots), blk, 0, s, tab, kp);
 }
 
 // ---------------------------------------------------------------------------

@@ -222,8 +222,9 @@ def main():
     mg = None
     if not a.no_mg:
         try:
-            from adflow_amd.params import RungeKutta
-            eng.set_options(prm.replace(smoother=RungeKutta))
+            from adflow_amd.params import RungeKutta, alternateResAveraging
+            # pyADflow defaults (pyADflow.py:5697-5731): RK smoother, "alternate" residual averaging
+            eng.set_options(prm.replace(smoother=RungeKutta, resAveraging=alternateResAveraging))
             ctopo = BrickTopology(2 * world, 2, 2, dims[0] // 2, dims[1] // 2, dims[2] // 2, owner=topo.owner)
             if do_halo:
                 eng.comm_register(1, 2, cp)
@@ -263,6 +264,17 @@ def main():
 
     out = None
     if rank == 0:
+        # HBM-side bytes per launch of the dominant kernel from the PMC passes over this very command
+        # (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 correction of
+        # MI355X_MICROARCH.md applied; tools/pmc_traffic.py writes the file, the raw summary sits beside it)
+        traffic, traffic_src = None, None
+        try:
+            tf = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ent = tf.get(a.workload)
+            if ent and not a.tuning:
+                traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         cells_per_launch = cells_local / launches_per_step
         alg_bytes = wl["bytes_per_cell"] * cells_per_launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
@@ -276,8 +288,8 @@ def main():
                        "halo_exchange": halo,
                        "cells_per_gpu": cells_local, "device": eng.device_name()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_euler_march" if march else ("k_inviscid" if wl["equations"] == 1 else
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_euler_march_p" if march else ("k_inviscid" if wl["equations"] == 1 else
                                                                    "k_inviscid + k_nodal_gradients + k_viscous (one block)"),
                          "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
