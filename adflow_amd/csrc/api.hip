@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_viscous_tiled;
 
 namespace {
 
@@ -56,6 +56,7 @@ struct Block {
     long boxsize = 0;         // ldi*(jb+1)*(kb+1)
     std::vector<void*> allocs;
     bool geom_uploaded = false;
+    bool face_vectors_valid = false;   // dI/dJ/dK derived from x
     bool ss_valid = false;    // entropy sensor variable matches the current state
     bool etot_consistent = false;   // owned-cell rhoE already equals computeEtotBlock(p, rho, v)
 };
@@ -368,6 +369,9 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     rc |= alloc_arr(b, &v.vol, 1);
     rc |= alloc_arr(b, &v.volRef, 1);
     rc |= alloc_arr(b, &v.d2wall, 1);
+    rc |= alloc_arr(b, &v.dI, 3);
+    rc |= alloc_arr(b, &v.dJ, 3);
+    rc |= alloc_arr(b, &v.dK, 3);
     rc |= alloc_arr(b, &v.dw, v.nw);
     rc |= alloc_arr(b, &v.fw, 5);
     rc |= alloc_arr(b, &v.dtl, 1);
@@ -502,6 +506,7 @@ int adflow_gpu_upload_geometry(int nn, int level, int sps)
     HIPCHK(hipMemcpyAsync(v.flags, f.data(), (size_t)b->boxsize, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     b->geom_uploaded = true;
+    b->face_vectors_valid = false;
     return 0;
 }
 
@@ -663,7 +668,13 @@ static int enqueue_flow_residual(int level, const KParams& kp)
             b->ss_valid = true;
         }
         launch_inviscid(b->v, kp, g_stream);
-        if (kp.viscous && fabs(kp.rFil) >= 1.e-10) launch_viscous(b->v, kp, g_stream);
+        if (kp.viscous && fabs(kp.rFil) >= 1.e-10) {
+            if (!b->face_vectors_valid) {
+                launch_face_vectors(b->v, g_stream);
+                b->face_vectors_valid = true;
+            }
+            launch_viscous(b->v, kp, g_stream);
+        }
         return 0;
     });
 }
@@ -1569,6 +1580,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "euler_march")) { g_use_march = (value != 0); return 0; }
     if (!strcmp(key, "march_minw")) { g_march_minw = value; return 0; }
     if (!strcmp(key, "march_pipe")) { g_march_pipe = value; return 0; }
+    if (!strcmp(key, "viscous_tiled")) { g_viscous_tiled = value; return 0; }
     if (!strcmp(key, "march_kch")) {
         if (value < 4) return fail("march_kch must be >= 4");
         g_march_kch = value;

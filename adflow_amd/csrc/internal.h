@@ -70,6 +70,7 @@ struct BlkView {
     double *w, *p, *gamma, *rlv, *rev;
     // geometry
     double *x, *sI, *sJ, *sK, *vol, *volRef, *d2wall;
+    double *dI, *dJ, *dK;   // derived geometry: vector between the two cell centres of a face (viscous normal correction)
     uint8_t* flags;  // bits 0-1 porI+1, 2-3 porJ+1, 4-5 porK+1, bit 6 iblank>0
     // residual + work
     double *dw, *fw, *dtl, *radI, *radJ, *radK;
@@ -124,6 +125,7 @@ void launch_entropy(const BlkView& b, hipStream_t s);
 void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_face_vectors(const BlkView& b, hipStream_t s);
 void launch_sa_residual(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_sa_solve(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_rk_save(const BlkView& b, hipStream_t s);

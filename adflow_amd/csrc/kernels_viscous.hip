@@ -18,36 +18,56 @@
 
 __device__ __forceinline__ double aa_at(const BlkView& b, long q) { return b.gamma[q] * b.p[q] / b.w[q]; }
 
-// one integration point of the dual-cell surface integral (flowUtils.F90:1712-1791):
-// cells c0, c0+s1, c0+s2, c0+s1+s2 (a 2x2 patch normal to direction d) and the
-// normals of the faces below (c-sd) and above (c) each of those four cells.
-__device__ __forceinline__ void grad_point(const BlkView& b, long c0, long sd, long s1, long s2,
-                                           const double* __restrict__ sN, double sign, double g[12])
+struct NCell { double u, v, w, aa; };
+
+// The two integration points of one direction of the dual-cell surface integral
+// (flowUtils.F90:1712-1791 for k).  The point below the node (sign -) uses the 2x2
+// patch of cells m[0..3] and the face normals at index-1 and index of those cells,
+// the point above it (sign +) the patch p[0..3] and the normals at index and
+// index+1: the normals at `index` are shared, every cell value is loaded once by
+// the caller.  Summation order as in the reference: the four faces at the lower
+// index first, then the four at the upper one.
+__device__ __forceinline__ void grad_dir(const BlkView& b, long c, long sd, long s1, long s2, const double* __restrict__ sN,
+                                         const NCell& m0, const NCell& m1, const NCell& m2, const NCell& m3, const NCell& p0,
+                                         const NCell& p1, const NCell& p2, const NCell& p3, double g[12])
 {
     const long nb = b.nbox;
-    const long cc[4] = {c0, c0 + s1, c0 + s2, c0 + s1 + s2};
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    // reference summation order: the four faces at index-1 first, then the four at index
+    const long cc[4] = {c, c + s1, c + s2, c + s1 + s2};
+    double lo[3] = {0.0, 0.0, 0.0}, mid[4][3], hi[4][3];
+    double sm[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        sx += sN[cc[m] - sd];
-        sy += sN[cc[m] - sd + nb];
-        sz += sN[cc[m] - sd + 2 * nb];
-    }
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        sx += sN[cc[m]];
-        sy += sN[cc[m] + nb];
-        sz += sN[cc[m] + 2 * nb];
+        for (int d = 0; d < 3; ++d) {
+            sm[d] += sN[cc[q] - sd + d * nb];
+            mid[q][d] = sN[cc[q] + d * nb];
+            hi[q][d] = sN[cc[q] + sd + d * nb];
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sm[d] += mid[q][d]; sp[d] += mid[q][d]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) sp[d] += hi[q][d];
+    (void)lo;
+    {
+        const double ubar = 0.25 * (m0.u + m1.u + m2.u + m3.u), vbar = 0.25 * (m0.v + m1.v + m2.v + m3.v);
+        const double wbar = 0.25 * (m0.w + m1.w + m2.w + m3.w), a2 = 0.25 * (m0.aa + m1.aa + m2.aa + m3.aa);
+        g[0] += -1.0 * ubar * sm[0]; g[1] += -1.0 * ubar * sm[1]; g[2] += -1.0 * ubar * sm[2];
+        g[3] += -1.0 * vbar * sm[0]; g[4] += -1.0 * vbar * sm[1]; g[5] += -1.0 * vbar * sm[2];
+        g[6] += -1.0 * wbar * sm[0]; g[7] += -1.0 * wbar * sm[1]; g[8] += -1.0 * wbar * sm[2];
+        g[9] -= -1.0 * a2 * sm[0]; g[10] -= -1.0 * a2 * sm[1]; g[11] -= -1.0 * a2 * sm[2];
     }
-    const double ubar = 0.25 * (b.w[cc[0] + nb] + b.w[cc[1] + nb] + b.w[cc[2] + nb] + b.w[cc[3] + nb]);
-    const double vbar = 0.25 * (b.w[cc[0] + 2 * nb] + b.w[cc[1] + 2 * nb] + b.w[cc[2] + 2 * nb] + b.w[cc[3] + 2 * nb]);
-    const double wbar = 0.25 * (b.w[cc[0] + 3 * nb] + b.w[cc[1] + 3 * nb] + b.w[cc[2] + 3 * nb] + b.w[cc[3] + 3 * nb]);
-    const double a2 = 0.25 * (aa_at(b, cc[0]) + aa_at(b, cc[1]) + aa_at(b, cc[2]) + aa_at(b, cc[3]));
-    g[0] += sign * ubar * sx; g[1] += sign * ubar * sy; g[2] += sign * ubar * sz;
-    g[3] += sign * vbar * sx; g[4] += sign * vbar * sy; g[5] += sign * vbar * sz;
-    g[6] += sign * wbar * sx; g[7] += sign * wbar * sy; g[8] += sign * wbar * sz;
-    g[9] -= sign * a2 * sx; g[10] -= sign * a2 * sy; g[11] -= sign * a2 * sz;
+    {
+        const double ubar = 0.25 * (p0.u + p1.u + p2.u + p3.u), vbar = 0.25 * (p0.v + p1.v + p2.v + p3.v);
+        const double wbar = 0.25 * (p0.w + p1.w + p2.w + p3.w), a2 = 0.25 * (p0.aa + p1.aa + p2.aa + p3.aa);
+        g[0] += ubar * sp[0]; g[1] += ubar * sp[1]; g[2] += ubar * sp[2];
+        g[3] += vbar * sp[0]; g[4] += vbar * sp[1]; g[5] += vbar * sp[2];
+        g[6] += wbar * sp[0]; g[7] += wbar * sp[1]; g[8] += wbar * sp[2];
+        g[9] -= a2 * sp[0]; g[10] -= a2 * sp[1]; g[11] -= a2 * sp[2];
+    }
 }
 
 // nodes 1..il x 1..jl x 1..kl ; node (i,j,k) is stored at cell index (i,j,k)
@@ -58,23 +78,29 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
     const int k = blockIdx.z + 1;
     if (i < 1 || i > b.il || j > b.jl) return;
     const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
     const long si = 1, sj = b.ldi, sk = b.ldk;
+    // the eight cells around the node, index di + 2 dj + 4 dk
+    NCell q[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const long cq = c + (n & 1) * si + ((n >> 1) & 1) * sj + (n >> 2) * sk;
+        q[n].u = b.w[cq + nb]; q[n].v = b.w[cq + 2 * nb]; q[n].w = b.w[cq + 3 * nb];
+        q[n].aa = aa_at(b, cq);
+    }
     double g[12];
 #pragma unroll
     for (int m = 0; m < 12; ++m) g[m] = 0.0;
-    // k-direction: point k gives "-", point k+1 gives "+" (flowUtils.F90:1759-1791)
-    grad_point(b, c, sk, si, sj, b.sK, -1.0, g);
-    grad_point(b, c + sk, sk, si, sj, b.sK, +1.0, g);
-    // j-direction (cells (i..i+1, j, k..k+1); flowUtils.F90:1805-1892)
-    grad_point(b, c, sj, si, sk, b.sJ, -1.0, g);
-    grad_point(b, c + sj, sj, si, sk, b.sJ, +1.0, g);
-    // i-direction (cells (i, j..j+1, k..k+1); flowUtils.F90:1894-1979)
-    grad_point(b, c, si, sj, sk, b.sI, -1.0, g);
-    grad_point(b, c + si, si, sj, sk, b.sI, +1.0, g);
+    // k-direction (flowUtils.F90:1759-1791): patches (i..i+1, j..j+1) at k and k+1
+    grad_dir(b, c, sk, si, sj, b.sK, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], g);
+    // j-direction (:1805-1892): patches (i..i+1, k..k+1) at j and j+1
+    grad_dir(b, c, sj, si, sk, b.sJ, q[0], q[1], q[4], q[5], q[2], q[3], q[6], q[7], g);
+    // i-direction (:1894-1979): patches (j..j+1, k..k+1) at i and i+1
+    grad_dir(b, c, si, sj, sk, b.sI, q[0], q[2], q[4], q[6], q[1], q[3], q[5], q[7], g);
     const double oneOverV = 1.0 / (b.vol[c] + b.vol[c + sk] + b.vol[c + si] + b.vol[c + si + sk] + b.vol[c + sj] +
                                    b.vol[c + sj + sk] + b.vol[c + si + sj] + b.vol[c + si + sj + sk]);
 #pragma unroll
-    for (int m = 0; m < 12; ++m) b.grad[c + m * b.nbox] = g[m] * oneOverV;
+    for (int m = 0; m < 12; ++m) b.grad[c + m * nb] = g[m] * oneOverV;
 }
 
 // viscous flux through the face between cells cL and cL+sd (fluxes.F90:2610-2860);
@@ -199,11 +225,220 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous(BlkView b, KParams kp)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Tiled form of the face-flux kernel.  The gather form above issues ~560 loads
+// per cell (48 nodal gradients + 24 node coordinates per face, six faces): the
+// texture-address unit, not HBM, bounds it.  Here
+//   * the vector between the two cell centres of every face (the only use of
+//     the node coordinates x, fluxes.F90:2660-2676) is static geometry, formed
+//     once per mesh by k_face_vectors with the reference's summation order;
+//   * the nodal gradients of the two node planes a workgroup's 64x4 cells touch
+//     are staged ONCE through LDS by coalesced row loads (120 rows of 65 nodes)
+//     and the 4-node averages of the six faces read them from there;
+//   * the state of a neighbour cell is loaded once per direction, not per face.
+// ~125 global loads per cell remain.  Arithmetic (and its order) is unchanged.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(VS_BX* VS_BY) void k_face_vectors(BlkView b)
+{
+    const int i = blockIdx.x * VS_BX + threadIdx.x + 1;
+    const int j = blockIdx.y * VS_BY + threadIdx.y + 1;
+    const int k = blockIdx.z + 1;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+    const long sd3[3] = {si, sj, sk};
+    const long s13[3] = {sj, si, si};
+    const long s23[3] = {sk, sk, sj};
+    double* out3[3] = {b.dI, b.dJ, b.dK};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const long sd = sd3[d], s1 = s13[d], s2 = s23[d];
+        const long n0 = c - s1 - s2, n1 = c - s2, n2 = c - s1, n3 = c;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const double* xx = b.x + m * nb;
+            out3[d][c + m * nb] = 0.125 * (xx[n0 + sd] - xx[n0 - sd] + xx[n2 + sd] - xx[n2 - sd] + xx[n1 + sd] - xx[n1 - sd] +
+                                           xx[n3 + sd] - xx[n3 - sd]);
+        }
+    }
+}
+
+void launch_face_vectors(const BlkView& b, hipStream_t s)
+{
+    dim3 blk(VS_BX, VS_BY, 1);
+    dim3 g((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
+    hipLaunchKernelGGL(k_face_vectors, g, blk, 0, s, b);
+}
+
+#define VT_LDX 66                       // 65 nodes per row (+1 pad)
+#define VT_ROWS (VS_BY + 1)             // node rows j0-1 .. j0+VS_BY-1
+#define VT_COMP (VT_ROWS * VT_LDX)      // doubles of one gradient component in one node plane
+#define VT_PLANE (12 * VT_COMP)
+
+struct VCell { double u, v, w, aa, rlv, rev, gam; };
+
+__device__ __forceinline__ VCell vcell_at(const BlkView& b, const KParams& kp, long q)
+{
+    const long nb = b.nbox;
+    VCell c;
+    c.u = b.w[q + nb]; c.v = b.w[q + 2 * nb]; c.w = b.w[q + 3 * nb];
+    c.gam = b.gamma[q];
+    c.aa = c.gam * b.p[q] / b.w[q];
+    c.rlv = b.rlv[q];
+    c.rev = kp.eddyModel ? b.rev[q] : 0.0;
+    return c;
+}
+
+// face between L and R; o0..o3: LDS offsets (component 0) of the face nodes in the reference order
+// (-s1-s2), (-s2), (-s1), (0); fN/dN: normal and centre-to-centre vector of the face
+__device__ __forceinline__ void visc_face_t(const KParams& kp, const double* __restrict__ gl, int o0, int o1, int o2, int o3,
+                                            const VCell& L, const VCell& R, const double fN[3], const double dN[3], int por_code,
+                                            double sign, double acc[5])
+{
+    double por = 0.5 * kp.rFil;
+    if (por_code == ADF_POR_NOFLUX) por = 0.0;
+    const double mul = por * (L.rlv + R.rlv);
+    double mue = 0.0;
+    if (kp.eddyModel) mue = por * (L.rev + R.rev);
+    const double mut = mul + mue;
+    const double gm1 = 0.5 * (L.gam + R.gam) - 1.0;
+    const double heatCoef = mul * (1.0 / (kp.prandtl * gm1)) + mue * (1.0 / (kp.prandtlTurb * gm1));
+    double gr[12];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+        const double* g = gl + m * VT_COMP;
+        gr[m] = 0.25 * (g[o0] + g[o1] + g[o2] + g[o3]);
+    }
+    const double ss = 1.0 / sqrt(dN[0] * dN[0] + dN[1] * dN[1] + dN[2] * dN[2]);
+    const double ssx = ss * dN[0], ssy = ss * dN[1], ssz = ss * dN[2];
+    double corr;
+    corr = gr[0] * ssx + gr[1] * ssy + gr[2] * ssz - (R.u - L.u) * ss;
+    double u_x = gr[0] - corr * ssx, u_y = gr[1] - corr * ssy, u_z = gr[2] - corr * ssz;
+    corr = gr[3] * ssx + gr[4] * ssy + gr[5] * ssz - (R.v - L.v) * ss;
+    double v_x = gr[3] - corr * ssx, v_y = gr[4] - corr * ssy, v_z = gr[5] - corr * ssz;
+    corr = gr[6] * ssx + gr[7] * ssy + gr[8] * ssz - (R.w - L.w) * ss;
+    double w_x = gr[6] - corr * ssx, w_y = gr[7] - corr * ssy, w_z = gr[8] - corr * ssz;
+    corr = gr[9] * ssx + gr[10] * ssy + gr[11] * ssz + (R.aa - L.aa) * ss;
+    double q_x = gr[9] - corr * ssx, q_y = gr[10] - corr * ssy, q_z = gr[11] - corr * ssz;
+
+    const double fracDiv = (2.0 * (1.0 / 3.0)) * (u_x + v_y + w_z);
+    const double tauxxS = 2.0 * u_x - fracDiv, tauyyS = 2.0 * v_y - fracDiv, tauzzS = 2.0 * w_z - fracDiv;
+    const double tauxyS = u_y + v_x, tauxzS = u_z + w_x, tauyzS = v_z + w_y;
+    q_x *= heatCoef; q_y *= heatCoef; q_z *= heatCoef;
+    double tauxx, tauyy, tauzz, tauxy, tauxz, tauyz;
+    if (kp.useQCR) {
+        double den = sqrt(u_x * u_x + u_y * u_y + u_z * u_z + v_x * v_x + v_y * v_y + v_z * v_z + w_x * w_x + w_y * w_y +
+                          w_z * w_z);
+        den = fmax(den, 1.e-14);
+        const double fact = mue * 0.3 / den;
+        const double Wxy = u_y - v_x, Wxz = u_z - w_x, Wyz = v_z - w_y;
+        const double Wyx = -Wxy, Wzx = -Wxz, Wzy = -Wyz;
+        const double exx = fact * (Wxy * tauxyS + Wxz * tauxzS) * 2.0;
+        const double eyy = fact * (Wyx * tauxyS + Wyz * tauyzS) * 2.0;
+        const double ezz = fact * (Wzx * tauxzS + Wzy * tauyzS) * 2.0;
+        const double exy = fact * (Wxy * tauyyS + Wxz * tauyzS + Wyx * tauxxS + Wyz * tauxzS);
+        const double exz = fact * (Wxy * tauyzS + Wxz * tauzzS + Wzx * tauxxS + Wzy * tauxyS);
+        const double eyz = fact * (Wyx * tauxzS + Wyz * tauzzS + Wzx * tauxyS + Wzy * tauyyS);
+        tauxx = mut * tauxxS - exx; tauyy = mut * tauyyS - eyy; tauzz = mut * tauzzS - ezz;
+        tauxy = mut * tauxyS - exy; tauxz = mut * tauxzS - exz; tauyz = mut * tauyzS - eyz;
+    } else {
+        tauxx = mut * tauxxS; tauyy = mut * tauyyS; tauzz = mut * tauzzS;
+        tauxy = mut * tauxyS; tauxz = mut * tauxzS; tauyz = mut * tauyzS;
+    }
+    const double ubar = 0.5 * (L.u + R.u), vbar = 0.5 * (L.v + R.v), wbar = 0.5 * (L.w + R.w);
+    const double nx = fN[0], ny = fN[1], nz = fN[2];
+    const double fmx = tauxx * nx + tauxy * ny + tauxz * nz;
+    const double fmy = tauxy * nx + tauyy * ny + tauyz * nz;
+    const double fmz = tauxz * nx + tauyz * ny + tauzz * nz;
+    double frhoE = (ubar * tauxx + vbar * tauxy + wbar * tauxz) * nx;
+    frhoE = frhoE + (ubar * tauxy + vbar * tauyy + wbar * tauyz) * ny;
+    frhoE = frhoE + (ubar * tauxz + vbar * tauyz + wbar * tauzz) * nz;
+    frhoE = frhoE - q_x * nx - q_y * ny - q_z * nz;
+    acc[1] += sign * fmx;
+    acc[2] += sign * fmy;
+    acc[3] += sign * fmz;
+    acc[4] += sign * frhoE;
+}
+
+__global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(BlkView b, KParams kp)
+{
+    __shared__ double gl[2 * VT_PLANE];     // node planes k-1 and k, 12 components, VT_ROWS x 65 nodes
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i0 = blockIdx.x * VS_BX + 2, j0 = blockIdx.y * VS_BY + 2;
+    const int i = i0 + tx, j = j0 + ty, k = blockIdx.z + 2;
+    const long nb = b.nbox;
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+    // ---- stage the nodal gradients: row = (plane, component, node row); nodes i0-1 .. i0+63
+    {
+        int in = i0 - 1 + tx;
+        if (in > b.ib) in = b.ib;
+        for (int it = 0; it < (2 * 12 * VT_ROWS) / VS_BY; ++it) {
+            const int row = ty * ((2 * 12 * VT_ROWS) / VS_BY) + it;
+            const int pl = row / (12 * VT_ROWS), m = (row / VT_ROWS) % 12, r = row % VT_ROWS;
+            int jn = j0 - 1 + r;
+            if (jn > b.jb) jn = b.jb;
+            gl[row * VT_LDX + tx] = b.grad[m * nb + b.idx(in, jn, k - 1 + pl)];
+        }
+        const int t = ty * VS_BX + tx;      // the 65th node of every row
+        if (t < 2 * 12 * VT_ROWS) {
+            const int pl = t / (12 * VT_ROWS), m = (t / VT_ROWS) % 12, r = t % VT_ROWS;
+            int jn = j0 - 1 + r;
+            if (jn > b.jb) jn = b.jb;
+            int in2 = i0 + VS_BX - 1;
+            if (in2 > b.ib) in2 = b.ib;
+            gl[t * VT_LDX + VS_BX] = b.grad[m * nb + b.idx(in2, jn, k - 1 + pl)];
+        }
+    }
+    __syncthreads();
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const uint8_t f0 = b.flags[c];
+    double acc[5] = {0, 0, 0, 0, 0};
+    const VCell C = vcell_at(b, kp, c);
+    // LDS offset (component 0) of this cell's corner node (i-1, j-1, k-1); +1 / +VT_LDX / +VT_PLANE step to i, j, k.
+    // Face nodes in the reference order (-s1-s2), (-s2), (-s1), (0) = base, base+D1, base+D2, base+D1+D2.
+    const int o000 = ty * VT_LDX + tx;
+    // reference sweep order k, j, i (fluxes.F90:2610, 2903, 3197); rolled: six inlined faces would not fit 256 VGPRs
+    const long sd3[3] = {sk, sj, si};
+    const int Dd3[3] = {VT_PLANE, VT_LDX, 1};
+    const int D13[3] = {1, 1, VT_LDX};            // s1 = si, si, sj
+    const int D23[3] = {VT_LDX, VT_PLANE, VT_PLANE};   // s2 = sj, sk, sk
+    const double* sN3[3] = {b.sK, b.sJ, b.sI};
+    const double* dN3[3] = {b.dK, b.dJ, b.dI};
+    const int shift3[3] = {4, 2, 0};              // porosity bits of the direction inside the flag byte
+#pragma unroll 1
+    for (int d = 0; d < 3; ++d) {
+        const long sd = sd3[d], cm = c - sd;
+        const double* __restrict__ sN = sN3[d];
+        const double* __restrict__ dN = dN3[d];
+        const VCell M = vcell_at(b, kp, cm), P = vcell_at(b, kp, c + sd);
+        const double nM[3] = {sN[cm], sN[cm + nb], sN[cm + 2 * nb]}, nP[3] = {sN[c], sN[c + nb], sN[c + 2 * nb]};
+        const double dM[3] = {dN[cm], dN[cm + nb], dN[cm + 2 * nb]}, dP[3] = {dN[c], dN[c + nb], dN[c + 2 * nb]};
+        const int porM = (b.flags[cm] >> shift3[d]) & 3, porP = (f0 >> shift3[d]) & 3;
+        const int D1 = D13[d], D2 = D23[d], oP = o000 + Dd3[d];
+        visc_face_t(kp, gl, o000, o000 + D1, o000 + D2, o000 + D1 + D2, M, C, nM, dM, porM, +1.0, acc);
+        visc_face_t(kp, gl, oP, oP + D1, oP + D2, oP + D1 + D2, C, P, nP, dP, porP, -1.0, acc);
+    }
+    const double blank = flg_blank(f0);
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        const double fwn = b.fw[c + l * nb] + acc[l];
+        if (kp.fwMode) b.fw[c + l * nb] = fwn;
+        b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
+    }
+}
+
+int g_viscous_tiled = 1;   // tuning "viscous_tiled"
+
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
 {
     dim3 blk(VS_BX, VS_BY, 1);
     dim3 gn((b.il + 15 + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
     hipLaunchKernelGGL(k_nodal_gradients, gn, blk, 0, s, b);
     dim3 gc((b.nx + VS_BX - 1) / VS_BX, (b.ny + VS_BY - 1) / VS_BY, b.nz);
-    hipLaunchKernelGGL(k_viscous, gc, blk, 0, s, b, kp);
+    if (g_viscous_tiled)
+        hipLaunchKernelGGL(k_viscous_t, gc, blk, 0, s, b, kp);
+    else
+        hipLaunchKernelGGL(k_viscous, gc, blk, 0, s, b, kp);
 }
