@@ -32,7 +32,10 @@ class AdflowOpts(ctypes.Structure):
         ("nSubIterTurb", c_int32),
         ("groundLevel", c_int32),
         ("turbRelax", c_int32),
-        ("reserved_i", c_int32 * 2),
+        ("eulerWallBCTreatment", c_int32),
+        ("viscWallBCTreatment", c_int32),
+        ("outflowTreatment", c_int32),
+        ("reserved_i", c_int32),
         ("gammaConstant", c_double), ("prandtl", c_double), ("prandtlTurb", c_double),
         ("SSuthDim", c_double), ("muSuthDim", c_double), ("TSuthDim", c_double),
         ("SAKappa", c_double), ("SAcb1", c_double), ("SAcb2", c_double), ("SAsigma", c_double), ("SAcv1", c_double),
@@ -48,6 +51,22 @@ class AdflowOpts(ctypes.Structure):
         ("wInf", c_double * 10),
         ("reserved_d", c_double * 8),
     ]
+
+
+class AdflowBcSubface(ctypes.Structure):
+    """adflow_bc_subface (include/adflow_gpu.h): BCType/BCFaceID + the BCData members the flow BCs read"""
+    _fields_ = [
+        ("bcType", c_int32), ("faceID", c_int32),
+        ("icBeg", c_int32), ("icEnd", c_int32), ("jcBeg", c_int32), ("jcEnd", c_int32),
+        ("norm", c_void_p), ("rface", c_void_p), ("uSlip", c_void_p), ("TNS_Wall", c_void_p),
+        ("rho", c_void_p), ("velx", c_void_p), ("vely", c_void_p), ("velz", c_void_p), ("ps", c_void_p),
+    ]
+
+
+# BCType / BCFaceID values (src/modules/constants.F90:257-297)
+BC_SYMM, BC_NSWALL_ADIABATIC, BC_NSWALL_ISOTHERMAL, BC_EULERWALL, BC_FARFIELD = -1, -3, -4, -5, -6
+BC_SUPERSONIC_INFLOW, BC_SUPERSONIC_OUTFLOW, BC_EXTRAP = -7, -9, -15
+IMIN, IMAX, JMIN, JMAX, KMIN, KMAX = 1, 2, 3, 4, 5, 6
 
 
 class AdflowBlockDesc(ctypes.Structure):
@@ -99,7 +118,7 @@ EXPORTS = [
     "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
-    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback",
+    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
 ]
@@ -135,6 +154,8 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_residual.argtypes = [c_int, c_int]
     lib.adflow_gpu_block_res.argtypes = [c_int, c_uint]
     lib.adflow_gpu_set_async.argtypes = [c_int]
+    lib.adflow_gpu_bc_register.argtypes = [c_int, c_int, c_int, c_int, c_int, POINTER(AdflowBcSubface)]
+    lib.adflow_gpu_apply_all_bc.argtypes = [c_int, c_int]
     lib.adflow_gpu_set_tuning.argtypes = [c_char_p, c_int]
     lib.adflow_gpu_abi_sizes.argtypes = [POINTER(c_int), POINTER(c_int)]
     lib.adflow_gpu_rk_smooth.argtypes = [c_int]

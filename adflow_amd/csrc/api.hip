@@ -59,6 +59,8 @@ struct Block {
     bool face_vectors_valid = false;   // dI/dJ/dK derived from x
     bool ss_valid = false;    // entropy sensor variable matches the current state
     bool etot_consistent = false;   // owned-cell rhoE already equals computeEtotBlock(p, rho, v)
+    std::vector<BcFaceDev> bc;      // boundary subfaces (device BCData), first nViscBocos = viscous walls
+    int nViscBocos = 0;
 };
 
 typedef std::tuple<int, int, int> Key;   // (level, sps, nn): iteration order = level, sps, nn
@@ -696,6 +698,8 @@ int adflow_gpu_residual(int level, int rkStage)
 }
 
 static int block_res_enqueue(int level, unsigned flags);
+static int apply_bc_enqueue(int level, int secondHalo);
+static int apply_turb_bc_enqueue(int level, int secondHalo);
 static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers);
 
 static int block_res_enqueue(int level, unsigned flags)
@@ -716,6 +720,9 @@ static int block_res_enqueue(int level, unsigned flags)
         if (rc) return rc;
     }
     if (flags & ADFLOW_RES_HALO) {
+        // BCTurbTreatment + applyAllTurbBCThisBlock(.true.) before applyAllBC_block(.true.) (blockette.F90:220-226)
+        if ((flags & ADFLOW_RES_TURB) && apply_turb_bc_enqueue(level, 1)) return 1;
+        if (apply_bc_enqueue(level, 1)) return 1;
         if (g_bc_callback) {
             HIPCHK(hipStreamSynchronize(g_stream));
             g_bc_callback(level, 1);
@@ -958,6 +965,112 @@ int adflow_gpu_set_bc_callback(adflow_bc_callback fn)
     return 0;
 }
 
+int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBocos, const adflow_bc_subface* faces)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (nBocos < 0 || nViscBocos < 0 || nViscBocos > nBocos) return fail("bc_register: nBocos=%d nViscBocos=%d", nBocos, nViscBocos);
+    if (nBocos > 0 && !faces) return fail("bc_register: null subface list");
+    const BlkView& v = b->v;
+    std::vector<BcFaceDev> out;
+    for (int m = 0; m < nBocos; ++m) {
+        const adflow_bc_subface& f = faces[m];
+        switch (f.bcType) {
+        case ADFLOW_BC_SYMM: case ADFLOW_BC_NSWALL_ADIABATIC: case ADFLOW_BC_NSWALL_ISOTHERMAL: case ADFLOW_BC_EULERWALL:
+        case ADFLOW_BC_FARFIELD: case ADFLOW_BC_SUPERSONIC_INFLOW: case ADFLOW_BC_SUPERSONIC_OUTFLOW: case ADFLOW_BC_EXTRAP:
+            break;
+        default:
+            return fail("bc_register: block %d subface %d: BCType %d is not implemented on the device "
+                        "(symmPolar, subsonic in/outflow, bleeds stay with the host callback)", nn, m + 1, f.bcType);
+        }
+        if (f.faceID < ADFLOW_IMIN || f.faceID > ADFLOW_KMAX) return fail("bc_register: block %d subface %d: BCFaceID %d", nn, m + 1, f.faceID);
+        // generic subface indices run over the two in-plane directions of the block face (utils.F90:881-1175)
+        const int amax = (f.faceID <= ADFLOW_IMAX) ? v.jb : v.ib;
+        const int bmax = (f.faceID <= ADFLOW_JMAX) ? v.kb : v.jb;
+        if (f.icBeg < 0 || f.icEnd > amax || f.jcBeg < 0 || f.jcEnd > bmax || f.icEnd < f.icBeg || f.jcEnd < f.jcBeg)
+            return fail("bc_register: block %d subface %d: cell range %d:%d x %d:%d outside the block face", nn, m + 1, f.icBeg,
+                        f.icEnd, f.jcBeg, f.jcEnd);
+        const bool needNorm = (f.bcType == ADFLOW_BC_SYMM || f.bcType == ADFLOW_BC_EULERWALL || f.bcType == ADFLOW_BC_FARFIELD);
+        if (needNorm && !f.norm) return fail("bc_register: block %d subface %d: BCData%%norm is required", nn, m + 1);
+        if (f.bcType == ADFLOW_BC_NSWALL_ISOTHERMAL && !f.TNS_Wall) return fail("bc_register: block %d subface %d: TNS_Wall is required", nn, m + 1);
+        if (f.bcType == ADFLOW_BC_SUPERSONIC_INFLOW && !(f.rho && f.velx && f.vely && f.velz && f.ps))
+            return fail("bc_register: block %d subface %d: rho, velx, vely, velz, ps are required", nn, m + 1);
+        const size_t n = (size_t)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
+        auto up = [&](const double* h, int nc, const double** dev) -> int {
+            *dev = nullptr;
+            if (!h) return 0;
+            void* raw = nullptr;
+            HIPCHK(hipMalloc(&raw, sizeof(double) * n * nc));
+            HIPCHK(hipMemcpy(raw, h, sizeof(double) * n * nc, hipMemcpyHostToDevice));
+            b->allocs.push_back(raw);
+            *dev = (const double*)raw;
+            return 0;
+        };
+        BcFaceDev d;
+        d.type = f.bcType; d.faceID = f.faceID; d.icBeg = f.icBeg; d.icEnd = f.icEnd; d.jcBeg = f.jcBeg; d.jcEnd = f.jcEnd;
+        if (up(f.norm, 3, &d.norm) || up(f.rface, 1, &d.rface) || up(f.uSlip, 3, &d.uslip) || up(f.TNS_Wall, 1, &d.tns) ||
+            up(f.rho, 1, &d.rho) || up(f.velx, 1, &d.vx) || up(f.vely, 1, &d.vy) || up(f.velz, 1, &d.vz) || up(f.ps, 1, &d.ps))
+            return 1;
+        out.push_back(d);
+    }
+    b->bc = out;
+    b->nViscBocos = nViscBocos;
+    if (v.nw > 5 && !v.bmt[0]) {
+        // face arrays of the implicit turbulence boundary treatment (bmt/bvt of blockPointers, one turbulence variable)
+        const size_t nf[3] = {(size_t)v.je * v.ke, (size_t)v.ie * v.ke, (size_t)v.ie * v.je};
+        for (int f6 = 0; f6 < 6; ++f6)
+            for (int which = 0; which < 2; ++which) {
+                void* raw = nullptr;
+                HIPCHK(hipMalloc(&raw, sizeof(double) * nf[f6 / 2]));
+                HIPCHK(hipMemsetAsync(raw, 0, sizeof(double) * nf[f6 / 2], g_stream));
+                b->allocs.push_back(raw);
+                (which ? b->v.bvt : b->v.bmt)[f6] = (double*)raw;
+            }
+        invalidate_comm_level(level);   // the device block table holds copies of BlkView
+    }
+    return 0;
+}
+
+// bcTurbTreatment + applyAllTurbBCThisBlock(secondHalo) for the blocks of `level` with registered subfaces
+static int apply_turb_bc_enqueue(int level, int secondHalo)
+{
+    if (g_opts.equations != ADFLOW_RANS) return 0;
+    KParams kp = make_kparams(level, 1.0, 0);
+    return for_level(level, [&](Block* b) {
+        if (b->bc.empty()) return 0;
+        launch_turb_bc_treatment(b->v, b->bc.data(), (int)b->bc.size(), kp, g_stream);
+        launch_apply_turb_bc(b->v, b->bc.data(), (int)b->bc.size(), kp, secondHalo, g_stream);
+        return 0;
+    });
+}
+
+// applyAllBC (BCRoutines.F90:15-54) for the blocks of `level` that registered subfaces
+static int apply_bc_enqueue(int level, int secondHalo)
+{
+    KParams kp = make_kparams(level, 1.0, 0);
+    if (g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_NORMAL_MOMENTUM || g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_QUADRATIC) {
+        bool any = false;
+        for (auto& kv : g_blocks)
+            if (std::get<0>(kv.first) == level)
+                for (auto& f : kv.second->bc) any = any || f.type == ADFLOW_BC_EULERWALL;
+        if (any) return fail("eulerWallBCTreatment=%d is not implemented on the device (1 constant, 2 linear)", g_opts.eulerWallBCTreatment);
+    }
+    return for_level(level, [&](Block* b) {
+        if (b->bc.empty()) return 0;
+        launch_apply_all_bc(b->v, b->bc.data(), (int)b->bc.size(), b->nViscBocos, kp, secondHalo, g_opts.eulerWallBCTreatment,
+                            g_opts.viscWallBCTreatment, g_opts.outflowTreatment, g_stream);
+        b->ss_valid = false;
+        return 0;
+    });
+}
+
+int adflow_gpu_apply_all_bc(int level, int secondHalo)
+{
+    if (need_ready()) return 1;
+    if (apply_bc_enqueue(level, secondHalo)) return 1;
+    return sync_and_check();
+}
+
 int adflow_gpu_comm_unique_id(void* id128)
 {
 #ifndef ADFLOW_NO_RCCL
@@ -1150,6 +1263,7 @@ static int finish_stage(int level, const KParams& kp, double scale, int fromWn)
     });
     if (rc) return rc;
     const int secondHalo = (level <= g_opts.groundLevel);
+    if (apply_bc_enqueue(level, secondHalo)) return 1;
     if (g_bc_callback) {
         HIPCHK(hipStreamSynchronize(g_stream));
         g_bc_callback(level, secondHalo);
@@ -1263,12 +1377,14 @@ static int transfer_to_coarse_enqueue(int level)
         if (!c->v.mgIFine || !c->v.mgIWeight) return fail("coarse block has no mgIFine/mgIWeight maps");
         if (!c->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", cl);
         launch_restrict(c->v, f->v, kc, g_stream);
+        launch_corner_row_halos(c->v, kc, g_stream);      // setCornerRowHalos(nwf) (multiGrid.F90:229)
         c->ss_valid = false;
         c->etot_consistent = true;
         return 0;
     });
     if (rc) return rc;
     // applyAllBC(.false.) ; whalo1 (multiGrid.F90:236-241)
+    if (apply_bc_enqueue(cl, 0)) return 1;
     if (g_bc_callback) {
         HIPCHK(hipStreamSynchronize(g_stream));
         g_bc_callback(cl, 0);
@@ -1295,6 +1411,8 @@ static int transfer_to_fine_enqueue(int level)
     int rc = for_level_pairs(level, [&](Block* f, Block* c) {
         if (!f->v.mgICoarse) return fail("fine block has no mgICoarse map");
         launch_corrections(c->v, g_stream);
+        // setCorrectionsCoarseHalos (multiGrid.F90:472): fact = 0, mgBoundCorr = bcDirichlet0 (inputParamRoutines.F90:3923)
+        if (!c->bc.empty()) launch_bc_coarse_corrections(c->v, c->bc.data(), (int)c->bc.size(), 0.0, g_stream);
         launch_prolong_update(f->v, c->v, kf, g_stream);
         f->ss_valid = false;
         f->etot_consistent = true;
@@ -1302,6 +1420,7 @@ static int transfer_to_fine_enqueue(int level)
     });
     if (rc) return rc;
     const int secondHalo = (level <= g_opts.groundLevel);
+    if (apply_bc_enqueue(level, secondHalo)) return 1;
     if (g_bc_callback) {
         HIPCHK(hipStreamSynchronize(g_stream));
         g_bc_callback(level, secondHalo);
@@ -1507,7 +1626,10 @@ int adflow_gpu_sa_solve(int level)
         KParams kp = make_kparams(level, 1.0, 0);
         int rc = for_level(level, [&](Block* b) {
             if (b->v.nw < 6) return fail("RANS/SA needs nw = 6 (block has %d)", b->v.nw);
+            // sa_block(.false.): bcTurbTreatment first, applyAllTurbBCThisBlock(.true.) last (sa.F90:40-84)
+            if (!b->bc.empty()) launch_turb_bc_treatment(b->v, b->bc.data(), (int)b->bc.size(), kp, g_stream);
             launch_sa_solve(b->v, kp, g_stream);
+            if (!b->bc.empty()) launch_apply_turb_bc(b->v, b->bc.data(), (int)b->bc.size(), kp, 1, g_stream);
             return 0;
         });
         if (rc) return rc;
@@ -1584,7 +1706,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "march_kch")) {
         if (value < 4) return fail("march_kch must be >= 4");
         g_march_kch = value;
-        for (auto& kv : g_tiles) hipFree(kv.second.first);   // tile tables depend on the chunk length
+        for (auto& kv : g_tiles) (void)hipFree(kv.second.first);   // tile tables depend on the chunk length
         g_tiles.clear();
         return 0;
     }

@@ -71,6 +71,10 @@ struct BlkView {
     // geometry
     double *x, *sI, *sJ, *sK, *vol, *volRef, *d2wall;
     double *dI, *dJ, *dK;   // derived geometry: vector between the two cell centres of a face (viscous normal correction)
+    // implicit turbulence boundary treatment of Spalart-Allmaras (turbBCRoutines.F90:662-798): halo = bvt - bmt * interior.
+    // Index 0..5 = iMin,iMax,jMin,jMax,kMin,kMax; entry (a,b) at (a-1) + A*(b-1), A = je (i faces) or ie (j,k faces).
+    // NULL until a block registers boundary subfaces (= all zero, the periodic / internal case).
+    double *bmt[6], *bvt[6];
     uint8_t* flags;  // bits 0-1 porI+1, 2-3 porJ+1, 4-5 porK+1, bit 6 iblank>0
     // residual + work
     double *dw, *fw, *dtl, *radI, *radJ, *radK;
@@ -85,6 +89,12 @@ struct BlkView {
     double *mgIWeight, *mgJWeight, *mgKWeight;  // coarse block, indexed by cell index
     int *mgICoarse, *mgJCoarse, *mgKCoarse;  // fine block, indexed [i*2+q]
     __host__ __device__ inline long idx(int i, int j, int k) const { return (long)i + (long)j * ldi + (long)k * ldk; }
+};
+
+// one boundary subface on the device (adflow_bc_subface with device copies of the BCData members)
+struct BcFaceDev {
+    int type, faceID, icBeg, icEnd, jcBeg, jcEnd;
+    const double *norm, *rface, *uslip, *tns, *rho, *vx, *vy, *vz, *ps;
 };
 
 // porosity codes after the +1 shift used in `flags`
@@ -150,3 +160,9 @@ void launch_set_w(const BlkView& b, const double* vec, double turbFloor, hipStre
 void launch_get_r(const BlkView& b, double* vec, double turbScale, double* sums, hipStream_t s);
 void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);
+void launch_turb_bc_treatment(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, hipStream_t s);
+void launch_apply_turb_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, int second, hipStream_t s);
+void launch_corner_row_halos(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_bc_coarse_corrections(const BlkView& b, const BcFaceDev* faces, int nBocos, double fact, hipStream_t s);
+void launch_apply_all_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, int nVisc, const KParams& kp, int second,
+                         int eulerWallTreatment, int viscWallTreatment, int outflowTreatment, hipStream_t s);

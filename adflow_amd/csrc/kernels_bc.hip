@@ -1,0 +1,473 @@
+// Flow boundary conditions on the device (SURVEY.md §8f "next" row 1).
+//
+// Reference semantics (src/solver/BCRoutines.F90):
+//   applyAllBC_block      :57-221   order of the kinds, subfaces in index order
+//   bcSymm1stHalo/2ndHalo :223-330
+//   bcNSWallAdiabatic     :489-577
+//   bcNSWallIsoThermal    :579-691
+//   bcEulerWall           :1063-1280 (constant / linear pressure extrapolation)
+//   bcFarfield            :1282-1409
+//   bcSupersonicInflow    :1411-1477
+//   bcExtrap              :1479-1570
+//   computeEtot           :1816-1868 (cpConstant, no k correction: SA carries no k)
+//   extrapolate2ndHalo    :1870-1918
+//   setBCPointers         src/utils/utils.F90:881-1175 (ww0..ww3 = 2nd halo, 1st halo,
+//                         1st and 2nd interior slab of the block face)
+// One thread per cell (i,j) of the subface range icBeg..icEnd x jcBeg..jcEnd.  A subface
+// is a 2-D slab: its cost is O(N^2) against the O(N^3) residual, so the kernels are
+// written for clarity; lanes run along the first face index (i for j/k faces: coalesced).
+// Subfaces that share halo cells along block edges read what earlier subfaces wrote, so
+// they are separate launches in the reference's order.
+#include <algorithm>
+
+#include "internal.h"
+
+struct BcSlab {            // cell offsets of the four slabs and the BCData index of one (i,j)
+    long c0, c1, c2, c3;   // 2nd halo, 1st halo, 1st interior, 2nd interior
+    long f;                // (i - icBeg) + isize * (j - jcBeg)
+    long fn;               // stride between components of norm / uSlip
+};
+
+__device__ __forceinline__ bool bc_slab(const BlkView& b, const BcFaceDev& f, BcSlab& s)
+{
+    const int isize = f.icEnd - f.icBeg + 1, jsize = f.jcEnd - f.jcBeg + 1;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)isize * jsize) return false;
+    const int i = f.icBeg + (int)(t % isize), j = f.jcBeg + (int)(t / isize);
+    long base, step;
+    switch (f.faceID) {
+    case ADFLOW_IMIN: base = b.idx(0, i, j); step = 1; break;
+    case ADFLOW_IMAX: base = b.idx(b.ib, i, j); step = -1; break;
+    case ADFLOW_JMIN: base = b.idx(i, 0, j); step = b.ldi; break;
+    case ADFLOW_JMAX: base = b.idx(i, b.jb, j); step = -(long)b.ldi; break;
+    case ADFLOW_KMIN: base = b.idx(i, j, 0); step = b.ldk; break;
+    default: base = b.idx(i, j, b.kb); step = -(long)b.ldk; break;
+    }
+    s.c0 = base; s.c1 = base + step; s.c2 = base + 2 * step; s.c3 = base + 3 * step;
+    s.f = t;
+    s.fn = (long)isize * jsize;
+    return true;
+}
+
+// computeEtot (BCRoutines.F90:1816-1868)
+__device__ __forceinline__ void bc_etot(const BlkView& b, const KParams& kp, long c)
+{
+    const long nb = b.nbox;
+    const double ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
+    const double u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    b.w[c + 4 * nb] = ovgm1 * b.p[c] + 0.5 * b.w[c] * (u * u + v * v + w * w);
+}
+
+// extrapolate2ndHalo (BCRoutines.F90:1870-1918)
+__device__ __forceinline__ void bc_second_halo(const BlkView& b, const KParams& kp, const BcSlab& s)
+{
+    const long nb = b.nbox;
+    const double factor = 0.5;
+    double r = 2.0 * b.w[s.c1] - b.w[s.c2];
+    r = fmax(factor * b.w[s.c1], r);
+    b.w[s.c0] = r;
+#pragma unroll
+    for (int l = 1; l <= 3; ++l) b.w[s.c0 + l * nb] = 2.0 * b.w[s.c1 + l * nb] - b.w[s.c2 + l * nb];
+    b.p[s.c0] = fmax(factor * b.p[s.c1], 2.0 * b.p[s.c1] - b.p[s.c2]);
+    if (kp.viscous) b.rlv[s.c0] = b.rlv[s.c1];
+    if (kp.eddyModel) b.rev[s.c0] = b.rev[s.c1];
+    bc_etot(b, kp, s.c0);
+}
+
+// symmetry: layer 1 mirrors slab 2, layer 0 mirrors slab 3 (two separate passes in the reference)
+__global__ __launch_bounds__(256) void k_bc_symm(BlkView b, BcFaceDev f, KParams kp, int second)
+{
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    const long ch = second ? s.c0 : s.c1, cd = second ? s.c3 : s.c2;
+    const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
+    const double u = b.w[cd + nb], v = b.w[cd + 2 * nb], w = b.w[cd + 3 * nb];
+    const double vn = 2.0 * (u * nx + v * ny + w * nz);
+    b.w[ch] = b.w[cd];
+    b.w[ch + nb] = u - vn * nx;
+    b.w[ch + 2 * nb] = v - vn * ny;
+    b.w[ch + 3 * nb] = w - vn * nz;
+    b.w[ch + 4 * nb] = b.w[cd + 4 * nb];
+    b.gamma[ch] = b.gamma[cd];
+    b.p[ch] = b.p[cd];
+    if (kp.viscous) b.rlv[ch] = b.rlv[cd];
+    if (kp.eddyModel) b.rev[ch] = b.rev[cd];
+}
+
+// viscous walls; ISO: isothermal (wall temperature TNS_Wall)
+template <bool ISO>
+__global__ __launch_bounds__(256) void k_bc_nswall(BlkView b, BcFaceDev f, KParams kp, int second, int wallTreatment)
+{
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    const double rhok = 0.0;     // correctForK = .false. (no k equation)
+    double p1;
+    if (wallTreatment == ADFLOW_WALLBC_CONSTANT) {
+        p1 = b.p[s.c2] - 4.0 * (1.0 / 3.0) * rhok;
+    } else {
+        p1 = 2 * b.p[s.c2] - b.p[s.c3];
+        if (p1 <= 0.0) p1 = b.p[s.c2];
+    }
+    b.p[s.c1] = p1;
+    if (ISO) {
+        const double tw = f.tns[s.f];
+        const double t2 = b.p[s.c2] / (kp.RGas * b.w[s.c2]);
+        double t1 = 2.0 * tw - t2;
+        t1 = fmax(0.5 * tw, t1);
+        t1 = fmin(2.0 * tw, t1);
+        b.w[s.c1] = p1 / (kp.RGas * t1);
+    } else {
+        b.w[s.c1] = b.w[s.c2];
+    }
+#pragma unroll
+    for (int l = 1; l <= 3; ++l) {
+        const double us = f.uslip ? f.uslip[s.f + (l - 1) * s.fn] : 0.0;
+        b.w[s.c1 + l * nb] = -b.w[s.c2 + l * nb] + 2.0 * us;
+    }
+    b.rlv[s.c1] = b.rlv[s.c2];
+    if (kp.eddyModel) b.rev[s.c1] = -b.rev[s.c2];
+    bc_etot(b, kp, s.c1);
+    if (second) bc_second_halo(b, kp, s);
+}
+
+// myDim (utils): max(x - y, 0)
+__device__ __forceinline__ double bc_mydim(double x, double y) { return fmax(x - y, 0.0); }
+
+__global__ __launch_bounds__(256) void k_bc_eulerwall(BlkView b, BcFaceDev f, KParams kp, int second, int wallTreatment)
+{
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    double grad = 0.0;
+    if (wallTreatment == ADFLOW_WALLBC_LINEAR) grad = b.p[s.c3] - b.p[s.c2];
+    const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
+    const double rface = f.rface ? f.rface[s.f] : 0.0;
+    const double u = b.w[s.c2 + nb], v = b.w[s.c2 + 2 * nb], w = b.w[s.c2 + 3 * nb];
+    b.p[s.c1] = bc_mydim(b.p[s.c2], grad);
+    const double vn = 2.0 * (rface - u * nx - v * ny - w * nz);
+    b.w[s.c1] = b.w[s.c2];
+    b.w[s.c1 + nb] = u + vn * nx;
+    b.w[s.c1 + 2 * nb] = v + vn * ny;
+    b.w[s.c1 + 3 * nb] = w + vn * nz;
+    if (kp.viscous) b.rlv[s.c1] = b.rlv[s.c2];
+    if (kp.eddyModel) b.rev[s.c1] = b.rev[s.c2];
+    bc_etot(b, kp, s.c1);
+    if (second) bc_second_halo(b, kp, s);
+}
+
+__global__ __launch_bounds__(256) void k_bc_farfield(BlkView b, BcFaceDev f, KParams kp, int second)
+{
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    const double gm1 = kp.gammaInf - 1.0;
+    const double ovgm1 = 1.0 / gm1;
+    const double r0 = 1.0 / kp.wInf[0];
+    const double u0 = kp.wInf[1], v0 = kp.wInf[2], w0 = kp.wInf[3];
+    const double c0 = sqrt(kp.gammaInf * kp.pInfCorr * r0);
+    const double s0 = pow(kp.wInf[0], kp.gammaInf) / kp.pInfCorr;
+    const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
+    const double rface = f.rface ? f.rface[s.f] : 0.0;
+    const double qn0 = u0 * nx + v0 * ny + w0 * nz;
+    const double vn0 = qn0 - rface;
+    const double rho2 = b.w[s.c2], gam2 = b.gamma[s.c2], p2 = b.p[s.c2];
+    const double re = 1.0 / rho2;
+    const double ue = b.w[s.c2 + nb], ve = b.w[s.c2 + 2 * nb], we = b.w[s.c2 + 3 * nb];
+    const double qne = ue * nx + ve * ny + we * nz;
+    const double ce = sqrt(gam2 * p2 * re);
+    double ac1, ac2;
+    if (vn0 > -c0) ac1 = qne + 2.0 * ovgm1 * ce;      // outflow or subsonic inflow
+    else ac1 = qn0 + 2.0 * ovgm1 * c0;                // supersonic inflow
+    if (vn0 > c0) ac2 = qne - 2.0 * ovgm1 * ce;       // supersonic outflow
+    else ac2 = qn0 - 2.0 * ovgm1 * c0;                // inflow or subsonic outflow
+    const double qnf = 0.5 * (ac1 + ac2);
+    const double cf = 0.25 * (ac1 - ac2) * gm1;
+    double uf, vf, wf, sf;
+    if (vn0 > 0.0) {                                  // outflow
+        uf = ue + (qnf - qne) * nx;
+        vf = ve + (qnf - qne) * ny;
+        wf = we + (qnf - qne) * nz;
+        sf = pow(rho2, gam2) / p2;
+    } else {                                          // inflow
+        uf = u0 + (qnf - qn0) * nx;
+        vf = v0 + (qnf - qn0) * ny;
+        wf = w0 + (qnf - qn0) * nz;
+        sf = s0;
+    }
+    const double cc = cf * cf / gam2;
+    const double rho1 = pow(sf * cc, ovgm1);
+    b.w[s.c1] = rho1;
+    b.w[s.c1 + nb] = uf;
+    b.w[s.c1 + 2 * nb] = vf;
+    b.w[s.c1 + 3 * nb] = wf;
+    b.p[s.c1] = rho1 * cc;
+    if (kp.viscous) b.rlv[s.c1] = b.rlv[s.c2];
+    if (kp.eddyModel) b.rev[s.c1] = b.rev[s.c2];
+    bc_etot(b, kp, s.c1);
+    if (second) bc_second_halo(b, kp, s);
+}
+
+// extrap / supersonic outflow: fw2, fw3 = weights of slab 2 and 3
+__global__ __launch_bounds__(256) void k_bc_extrap(BlkView b, BcFaceDev f, KParams kp, int second, double fw2, double fw3)
+{
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    const double factor = 0.5;
+    double r = fw2 * b.w[s.c2] + fw3 * b.w[s.c3];
+    r = fmax(factor * b.w[s.c2], r);
+    b.w[s.c1] = r;
+#pragma unroll
+    for (int l = 1; l <= 3; ++l) b.w[s.c1 + l * nb] = fw2 * b.w[s.c2 + l * nb] + fw3 * b.w[s.c3 + l * nb];
+    double p1 = fw2 * b.p[s.c2] + fw3 * b.p[s.c3];
+    p1 = fmax(factor * b.p[s.c2], p1);
+    b.p[s.c1] = p1;
+    if (kp.viscous) b.rlv[s.c1] = b.rlv[s.c2];
+    if (kp.eddyModel) b.rev[s.c1] = b.rev[s.c2];
+    bc_etot(b, kp, s.c1);
+    if (second) bc_second_halo(b, kp, s);
+}
+
+// supersonic inflow (BCRoutines.F90:1411-1477): both halo layers take the prescribed state
+__global__ __launch_bounds__(256) void k_bc_supersonic_inflow(BlkView b, BcFaceDev f, KParams kp, int second)
+{
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    b.w[s.c1] = f.rho[s.f];
+    b.w[s.c1 + nb] = f.vx[s.f];
+    b.w[s.c1 + 2 * nb] = f.vy[s.f];
+    b.w[s.c1 + 3 * nb] = f.vz[s.f];
+    b.p[s.c1] = f.ps[s.f];
+    if (kp.viscous) b.rlv[s.c1] = b.rlv[s.c2];
+    if (kp.eddyModel) b.rev[s.c1] = b.rev[s.c2];
+    bc_etot(b, kp, s.c1);
+    if (second) {
+        b.w[s.c0] = b.w[s.c1];
+        b.w[s.c0 + nb] = b.w[s.c1 + nb];
+        b.w[s.c0 + 2 * nb] = b.w[s.c1 + 2 * nb];
+        b.w[s.c0 + 3 * nb] = b.w[s.c1 + 3 * nb];
+        b.p[s.c0] = b.p[s.c1];
+        if (kp.viscous) b.rlv[s.c0] = b.rlv[s.c1];
+        if (kp.eddyModel) b.rev[s.c0] = b.rev[s.c1];
+        bc_etot(b, kp, s.c0);
+    }
+}
+
+static dim3 bc_grid(const BcFaceDev& f)
+{
+    const long n = (long)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
+    return dim3((unsigned)((n + 255) / 256), 1, 1);
+}
+
+// applyAllBC_block for one block: `faces` in registration order, the first nVisc are the viscous walls
+void launch_apply_all_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, int nVisc, const KParams& kp, int second,
+                         int eulerWallTreatment, int viscWallTreatment, int outflowTreatment, hipStream_t s)
+{
+    const dim3 blk(256, 1, 1);
+    // coarse levels force the constant-pressure wall treatment (BCRoutines.F90:552-553, 1098-1099)
+    if (!kp.fineGrid) { eulerWallTreatment = ADFLOW_WALLBC_CONSTANT; viscWallTreatment = ADFLOW_WALLBC_CONSTANT; }
+    for (int m = 0; m < nBocos; ++m)
+        if (faces[m].type == ADFLOW_BC_SYMM) hipLaunchKernelGGL(k_bc_symm, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, 0);
+    if (second)
+        for (int m = 0; m < nBocos; ++m)
+            if (faces[m].type == ADFLOW_BC_SYMM) hipLaunchKernelGGL(k_bc_symm, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, 1);
+    for (int m = 0; m < nVisc; ++m)
+        if (faces[m].type == ADFLOW_BC_NSWALL_ADIABATIC)
+            hipLaunchKernelGGL((k_bc_nswall<false>), bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second, viscWallTreatment);
+    for (int m = 0; m < nVisc; ++m)
+        if (faces[m].type == ADFLOW_BC_NSWALL_ISOTHERMAL)
+            hipLaunchKernelGGL((k_bc_nswall<true>), bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second, viscWallTreatment);
+    for (int m = 0; m < nBocos; ++m)
+        if (faces[m].type == ADFLOW_BC_FARFIELD) hipLaunchKernelGGL(k_bc_farfield, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second);
+    for (int m = 0; m < nBocos; ++m)
+        if (faces[m].type == ADFLOW_BC_EXTRAP || faces[m].type == ADFLOW_BC_SUPERSONIC_OUTFLOW) {
+            double fw2 = 2.0, fw3 = -1.0;
+            if (faces[m].type == ADFLOW_BC_SUPERSONIC_OUTFLOW && outflowTreatment == 1) { fw2 = 1.0; fw3 = 0.0; }
+            hipLaunchKernelGGL(k_bc_extrap, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second, fw2, fw3);
+        }
+    for (int m = 0; m < nBocos; ++m)
+        if (faces[m].type == ADFLOW_BC_EULERWALL)
+            hipLaunchKernelGGL(k_bc_eulerwall, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second, eulerWallTreatment);
+    for (int m = 0; m < nBocos; ++m)
+        if (faces[m].type == ADFLOW_BC_SUPERSONIC_INFLOW)
+            hipLaunchKernelGGL(k_bc_supersonic_inflow, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second);
+}
+
+// ---------------------------------------------------------------------------
+// Turbulence boundary conditions of Spalart-Allmaras (src/turbulence/turbBCRoutines.F90)
+//   bcTurbTreatment           :662-798  bmt/bvt of every face: zero, then per subface
+//     bcTurbWall (SA)         :799-870  bmt = 1      (nuTilde_halo = -nuTilde_interior)
+//     bcTurbSymm / outflow    :614-660, 564-613  bmt = -1 (copy)
+//     bcTurbFarfield          :373-459  outflow: bmt = -1, inflow: bvt = wInf(itu1)
+//   applyAllTurbBCThisBlock   :49-236   halo = bvt - bmt * interior; eddy viscosity
+//                                       -rev (walls) / +rev (others); turb2ndHalo copies
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ long bc_face_entry(const BlkView& b, const BcFaceDev& f, long t, int* fidx)
+{
+    const int isize = f.icEnd - f.icBeg + 1;
+    const int i = f.icBeg + (int)(t % isize), j = f.jcBeg + (int)(t / isize);
+    const int A = (f.faceID <= ADFLOW_IMAX) ? b.je : b.ie;
+    *fidx = f.faceID - 1;
+    return (long)(i - 1) + (long)A * (j - 1);
+}
+
+__global__ __launch_bounds__(256) void k_turb_bc_zero(BlkView b)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n[3] = {(long)b.je * b.ke, (long)b.ie * b.ke, (long)b.ie * b.je};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (t < n[d]) {
+            b.bmt[2 * d][t] = 0.0; b.bmt[2 * d + 1][t] = 0.0;
+            b.bvt[2 * d][t] = 0.0; b.bvt[2 * d + 1][t] = 0.0;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_turb_bc_treatment(BlkView b, BcFaceDev f, KParams kp)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
+    if (t >= n) return;
+    // the face arrays only cover 1..ie x 1..je (turbBCRoutines.F90:684-735): skip range cells outside
+    const int isize = f.icEnd - f.icBeg + 1;
+    const int i = f.icBeg + (int)(t % isize), j = f.jcBeg + (int)(t / isize);
+    const int A = (f.faceID <= ADFLOW_IMAX) ? b.je : b.ie;
+    const int B = (f.faceID <= ADFLOW_JMAX) ? b.ke : b.je;
+    if (i < 1 || i > A || j < 1 || j > B) return;
+    int fi;
+    const long e = bc_face_entry(b, f, t, &fi);
+    switch (f.type) {
+    case ADFLOW_BC_NSWALL_ADIABATIC: case ADFLOW_BC_NSWALL_ISOTHERMAL:
+        b.bmt[fi][e] = 1.0;
+        break;
+    case ADFLOW_BC_SYMM: case ADFLOW_BC_EULERWALL: case ADFLOW_BC_SUPERSONIC_OUTFLOW: case ADFLOW_BC_EXTRAP:
+        b.bmt[fi][e] = -1.0;
+        break;
+    case ADFLOW_BC_FARFIELD: {
+        const double dot = f.norm[t] * kp.wInf[1] + f.norm[t + n] * kp.wInf[2] + f.norm[t + 2 * n] * kp.wInf[3] -
+                           (f.rface ? f.rface[t] : 0.0);
+        if (dot > 0.0) b.bmt[fi][e] = -1.0;
+        else b.bvt[fi][e] = kp.wInf[5];
+        break;
+    }
+    default: break;   // supersonic inflow: prescribed turbulence (BCData%turbInlet) is not carried: left as is
+    }
+}
+
+__global__ __launch_bounds__(256) void k_apply_turb_bc(BlkView b, BcFaceDev f, KParams kp, int second)
+{
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    int fi;
+    const long e = bc_face_entry(b, f, s.f, &fi);
+    const long nt = 5 * b.nbox;
+    b.w[s.c1 + nt] = b.bvt[fi][e] - b.bmt[fi][e] * b.w[s.c2 + nt];
+    if (kp.eddyModel) {
+        const bool wall = (f.type == ADFLOW_BC_NSWALL_ADIABATIC || f.type == ADFLOW_BC_NSWALL_ISOTHERMAL);
+        b.rev[s.c1] = wall ? -b.rev[s.c2] : b.rev[s.c2];
+    }
+    if (second) {
+        b.w[s.c0 + nt] = b.w[s.c1 + nt];
+        if (kp.eddyModel) b.rev[s.c0] = b.rev[s.c1];
+    }
+}
+
+void launch_turb_bc_treatment(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, hipStream_t s)
+{
+    if (!b.bmt[0]) return;
+    const long nmax = std::max(std::max((long)b.je * b.ke, (long)b.ie * b.ke), (long)b.ie * b.je);
+    hipLaunchKernelGGL(k_turb_bc_zero, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, b);
+    for (int m = 0; m < nBocos; ++m) hipLaunchKernelGGL(k_turb_bc_treatment, bc_grid(faces[m]), dim3(256), 0, s, b, faces[m], kp);
+}
+
+void launch_apply_turb_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, int second, hipStream_t s)
+{
+    if (!b.bmt[0]) return;
+    for (int m = 0; m < nBocos; ++m) hipLaunchKernelGGL(k_apply_turb_bc, bc_grid(faces[m]), dim3(256), 0, s, b, faces[m], kp, second);
+}
+
+// ---------------------------------------------------------------------------
+// Multigrid pieces that touch boundary halos (src/solver/multiGrid.F90)
+//   setCornerRowHalos         :1032-1357  after the restriction: first-halo cells next to the block edges take
+//                                         the value of their interior neighbour so that boundary conditions that
+//                                         read them find defined data.  Six loops, each reading what earlier
+//                                         ones wrote: one workgroup walks them in order.
+//   setCorrectionsCoarseHalos :1359-1503  corrections in the boundary halos of the coarse block before the
+//                                         prolongation: symmetry mirrors them, every other kind scales them by
+//                                         fact (0 for mgBoundCorr = bcDirichlet0, the only value the reference sets)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void crh_copy(const BlkView& b, const KParams& kp, long dst, long src)
+{
+#pragma unroll
+    for (int l = 0; l < 5; ++l) b.w[dst + l * b.nbox] = b.w[src + l * b.nbox];
+    b.p[dst] = b.p[src];
+    if (kp.viscous) b.rlv[dst] = b.rlv[src];
+    if (kp.eddyModel) b.rev[dst] = b.rev[src];
+}
+
+__global__ __launch_bounds__(256) void k_corner_row_halos(BlkView b, KParams kp)
+{
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int il = b.il, jl = b.jl, kl = b.kl, ie = b.ie, je = b.je, ke = b.ke;
+    const int J4[4] = {2, (3 < jl) ? 3 : jl, jl, (2 > b.ny) ? 2 : b.ny};
+    const int K4[4] = {2, (3 < kl) ? 3 : kl, kl, (2 > b.nz) ? 2 : b.nz};
+    const int I4[4] = {2, (3 < il) ? 3 : il, il, (2 > b.nx) ? 2 : b.nx};
+    // 1: k = 2..kl, i halos at j in J4
+    for (int k = 2 + t; k <= kl; k += nt)
+        for (int q = 0; q < 4; ++q) { crh_copy(b, kp, b.idx(1, J4[q], k), b.idx(2, J4[q], k)); crh_copy(b, kp, b.idx(ie, J4[q], k), b.idx(il, J4[q], k)); }
+    __syncthreads();
+    // 2: j = 3..ny, i halos at k in K4
+    for (int j = 3 + t; j <= b.ny; j += nt)
+        for (int q = 0; q < 4; ++q) { crh_copy(b, kp, b.idx(1, j, K4[q]), b.idx(2, j, K4[q])); crh_copy(b, kp, b.idx(ie, j, K4[q]), b.idx(il, j, K4[q])); }
+    __syncthreads();
+    // 3: k = 3..nz, j halos at i in I4
+    for (int k = 3 + t; k <= b.nz; k += nt)
+        for (int q = 0; q < 4; ++q) { crh_copy(b, kp, b.idx(I4[q], 1, k), b.idx(I4[q], 2, k)); crh_copy(b, kp, b.idx(I4[q], je, k), b.idx(I4[q], jl, k)); }
+    __syncthreads();
+    // 4: i = 1..ie, j halos at k in K4
+    for (int i = 1 + t; i <= ie; i += nt)
+        for (int q = 0; q < 4; ++q) { crh_copy(b, kp, b.idx(i, 1, K4[q]), b.idx(i, 2, K4[q])); crh_copy(b, kp, b.idx(i, je, K4[q]), b.idx(i, jl, K4[q])); }
+    __syncthreads();
+    // 5: j = 1..je, k halos at i in I4
+    for (int j = 1 + t; j <= je; j += nt)
+        for (int q = 0; q < 4; ++q) { crh_copy(b, kp, b.idx(I4[q], j, 1), b.idx(I4[q], j, 2)); crh_copy(b, kp, b.idx(I4[q], j, ke), b.idx(I4[q], j, kl)); }
+    __syncthreads();
+    // 6: i = 1..ie, k halos at j in J4
+    for (int i = 1 + t; i <= ie; i += nt)
+        for (int q = 0; q < 4; ++q) { crh_copy(b, kp, b.idx(i, J4[q], 1), b.idx(i, J4[q], 2)); crh_copy(b, kp, b.idx(i, J4[q], ke), b.idx(i, J4[q], kl)); }
+}
+
+void launch_corner_row_halos(const BlkView& b, const KParams& kp, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_corner_row_halos, dim3(1), dim3(256), 0, s, b, kp);
+}
+
+// corrections live in scratch(:,:,:,0:4) = d(rho), d(u), d(v), d(w), d(p) of the coarse block (kernels_mg.hip)
+__global__ __launch_bounds__(256) void k_bc_coarse_corrections(BlkView b, BcFaceDev f, double fact)
+{
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    double* __restrict__ q = b.scratch;
+    if (f.type == ADFLOW_BC_SYMM) {
+        const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
+        const double u = q[s.c2 + nb], v = q[s.c2 + 2 * nb], w = q[s.c2 + 3 * nb];
+        const double vn = 2.0 * (u * nx + v * ny + w * nz);
+        q[s.c1] = q[s.c2];
+        q[s.c1 + nb] = u - vn * nx;
+        q[s.c1 + 2 * nb] = v - vn * ny;
+        q[s.c1 + 3 * nb] = w - vn * nz;
+        q[s.c1 + 4 * nb] = q[s.c2 + 4 * nb];
+    } else {
+#pragma unroll
+        for (int l = 0; l < 5; ++l) q[s.c1 + l * nb] = fact * q[s.c2 + l * nb];
+    }
+}
+
+void launch_bc_coarse_corrections(const BlkView& b, const BcFaceDev* faces, int nBocos, double fact, hipStream_t s)
+{
+    for (int m = 0; m < nBocos; ++m) hipLaunchKernelGGL(k_bc_coarse_corrections, bc_grid(faces[m]), dim3(256), 0, s, b, faces[m], fact);
+}

@@ -189,14 +189,27 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(BlkView b, KParams
     // ---- advection, sweeps k, j, i (turbUtils.F90:886, 1118, 1349)
     const bool secondOrd = (kp.orderTurb == 2) && kp.groundLevelIsOne;
     double uu, c1m, c1p;
-    dvt += sa_advect(dk, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu);   // central jacobian: +uu or -uu (turbUtils.F90:972,1060)
-    dvt += sa_advect(dj, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu);
-    dvt += sa_advect(di, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu);
+    // implicit boundary treatment (only where it adds diagonal dominance): max(bmt, 0) of the face behind a
+    // boundary cell, zero elsewhere (turbUtils.F90:986-1004,1074-1092; sa.F90:452-468)
+    double bmK1 = 0.0, bmK2 = 0.0, bmJ1 = 0.0, bmJ2 = 0.0, bmI1 = 0.0, bmI2 = 0.0;
+    if (SOLVE && b.bmt[0]) {
+        if (i == 2) bmI1 = fmax(b.bmt[0][(j - 1) + (long)b.je * (k - 1)], 0.0);
+        if (i == b.il) bmI2 = fmax(b.bmt[1][(j - 1) + (long)b.je * (k - 1)], 0.0);
+        if (j == 2) bmJ1 = fmax(b.bmt[2][(i - 1) + (long)b.ie * (k - 1)], 0.0);
+        if (j == b.jl) bmJ2 = fmax(b.bmt[3][(i - 1) + (long)b.ie * (k - 1)], 0.0);
+        if (k == 2) bmK1 = fmax(b.bmt[4][(i - 1) + (long)b.ie * (j - 1)], 0.0);
+        if (k == b.kl) bmK2 = fmax(b.bmt[5][(i - 1) + (long)b.ie * (j - 1)], 0.0);
+    }
+    // central jacobian of the advection: +uu (uu > 0) or -uu, plus the boundary part (turbUtils.F90:972-1004,1060-1092)
+    dvt += sa_advect(dk, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu) + ((uu > 0.0) ? uu * bmK1 : -uu * bmK2);
+    dvt += sa_advect(dj, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu) + ((uu > 0.0) ? uu * bmJ1 : -uu * bmJ2);
+    dvt += sa_advect(di, vol0, u, v, w, secondOrd, &uu); qq += fabs(uu) + ((uu > 0.0) ? uu * bmI1 : -uu * bmI2);
 
-    // ---- diffusion, sweeps k, j, i (sa.F90:371, 473, 572)
-    dvt += sa_diffuse(dk, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p;
-    dvt += sa_diffuse(dj, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p;
-    dvt += sa_diffuse(di, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p;
+    // ---- diffusion, sweeps k, j, i (sa.F90:371, 473, 572); boundary cells: c1 - b1 max(bmt1,0) at index 2,
+    //      else c1 - d1 max(bmt2,0) at the last index
+    dvt += sa_diffuse(dk, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p + ((k == 2) ? c1m * bmK1 : c1p * bmK2);
+    dvt += sa_diffuse(dj, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p + ((j == 2) ? c1m * bmJ1 : c1p * bmJ2);
+    dvt += sa_diffuse(di, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qq += c1m + c1p + ((i == 2) ? c1m * bmI1 : c1p * bmI2);
 
     // ---- scale (sa.F90:702-706)
     b.dw[c + 5 * nb] = -b.volRef[c] * dvt * flg_blank(b.flags[c]);

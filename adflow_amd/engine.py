@@ -108,6 +108,23 @@ class Engine:
             | (capi.RES_TURB if turbRes else 0)
         self._chk(self.lib.adflow_gpu_block_res(level, flags))
 
+    def bc_register(self, faces, nViscBocos: int = 0, nn: int = 1, level: int = 1, sps: int = 1):
+        """flowDoms(nn,level,sps)%BCType/BCFaceID/BCData -> device.  `faces`: list of dicts with bcType, faceID,
+        icBeg, icEnd, jcBeg, jcEnd and the BCData members (Fortran-order float64 arrays) the kind needs."""
+        arr = (capi.AdflowBcSubface * max(len(faces), 1))()
+        for m, f in enumerate(faces):
+            for k in ("bcType", "faceID", "icBeg", "icEnd", "jcBeg", "jcEnd"):
+                setattr(arr[m], k, int(f[k]))
+            for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps"):
+                a = f.get(k)
+                if a is not None:
+                    assert a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, k
+                    setattr(arr[m], k, a.ctypes.data)
+        self._chk(self.lib.adflow_gpu_bc_register(nn, level, sps, len(faces), int(nViscBocos), arr))
+
+    def applyAllBC(self, level=1, secondHalo=True):
+        self._chk(self.lib.adflow_gpu_apply_all_bc(level, int(secondHalo)))
+
     def set_tuning(self, key: str, value: int):
         self._chk(self.lib.adflow_gpu_set_tuning(key.encode(), int(value)))
 

@@ -20,7 +20,8 @@ module adflowGpuShim
         integer(c_int32_t) :: smoother, nRKStages, resAveraging, nSubiterations, nSubIterTurb
         integer(c_int32_t) :: groundLevel
         integer(c_int32_t) :: turbRelax
-        integer(c_int32_t) :: reserved_i(2)
+        integer(c_int32_t) :: eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment
+        integer(c_int32_t) :: reserved_i
         real(c_double) :: gammaConstant, prandtl, prandtlTurb
         real(c_double) :: SSuthDim, muSuthDim, TSuthDim
         real(c_double) :: SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot
@@ -54,7 +55,25 @@ module adflowGpuShim
         type(c_ptr) :: recvProc, nrecvCum, recvBlock, recvIndices
     end type adflow_comm_pattern
 
+    ! ---- mirror of adflow_bc_subface ------------------------------------------
+    type, bind(C) :: adflow_bc_subface
+        integer(c_int32_t) :: bcType, faceID
+        integer(c_int32_t) :: icBeg, icEnd, jcBeg, jcEnd
+        type(c_ptr) :: norm, rface, uSlip, TNS_Wall
+        type(c_ptr) :: rho, velx, vely, velz, ps
+    end type adflow_bc_subface
+
     interface
+        integer(c_int) function adflow_gpu_bc_register(nn, level, sps, nBocos, nViscBocos, faces) &
+            bind(C, name="adflow_gpu_bc_register")
+            import :: c_int, adflow_bc_subface
+            integer(c_int), value :: nn, level, sps, nBocos, nViscBocos
+            type(adflow_bc_subface), intent(in) :: faces(*)
+        end function
+        integer(c_int) function adflow_gpu_apply_all_bc(level, secondHalo) bind(C, name="adflow_gpu_apply_all_bc")
+            import :: c_int
+            integer(c_int), value :: level, secondHalo
+        end function
         integer(c_int) function adflow_gpu_comm_register(level, nLayers, p) bind(C, name="adflow_gpu_comm_register")
             import :: c_int, adflow_comm_pattern
             integer(c_int), value :: level, nLayers
@@ -170,6 +189,8 @@ contains
         o%nSubiterations = nSubiterations; o%nSubIterTurb = nSubIterTurb
         o%groundLevel = groundLevel
         o%turbRelax = turbRelax
+        o%eulerWallBCTreatment = eulerWallBCTreatment; o%viscWallBCTreatment = viscWallBCTreatment
+        o%outflowTreatment = outflowTreatment
         o%reserved_i = 0
         o%gammaConstant = gammaConstant; o%prandtl = prandtl; o%prandtlTurb = prandtlTurb
         o%SSuthDim = SSuthDim; o%muSuthDim = muSuthDim; o%TSuthDim = TSuthDim
@@ -273,5 +294,37 @@ contains
         p%recvBlock = c_loc(recvBlock); p%recvIndices = c_loc(recvIdx)
         call gpuCheck(adflow_gpu_comm_register(int(level, c_int), int(nLayers, c_int), p), "gpuRegisterComm")
     end subroutine gpuRegisterComm
+
+    ! flowDoms(nn,level,sps)%BCType / BCFaceID / BCData(:) -> device (BCRoutines on the device).  Call again after
+    ! anything that changes BCData (setBCDataFineGrid / boundary normals after a mesh warp): the data are copied.
+    subroutine gpuRegisterBocos(nn, level, sps)
+        use block, only: flowDoms
+        integer(kind=intType), intent(in) :: nn, level, sps
+        type(adflow_bc_subface), allocatable :: f(:)
+        integer :: mm, nb
+        nb = flowDoms(nn, level, sps)%nBocos
+        allocate (f(max(nb, 1)))
+        do mm = 1, nb
+            associate (d => flowDoms(nn, level, sps)%BCData(mm))
+                f(mm)%bcType = flowDoms(nn, level, sps)%BCType(mm)
+                f(mm)%faceID = flowDoms(nn, level, sps)%BCFaceID(mm)
+                f(mm)%icBeg = d%icBeg; f(mm)%icEnd = d%icEnd; f(mm)%jcBeg = d%jcBeg; f(mm)%jcEnd = d%jcEnd
+                f(mm)%norm = c_null_ptr; f(mm)%rface = c_null_ptr; f(mm)%uSlip = c_null_ptr; f(mm)%TNS_Wall = c_null_ptr
+                f(mm)%rho = c_null_ptr; f(mm)%velx = c_null_ptr; f(mm)%vely = c_null_ptr; f(mm)%velz = c_null_ptr
+                f(mm)%ps = c_null_ptr
+                if (associated(d%norm)) f(mm)%norm = c_loc(d%norm)
+                if (associated(d%rface)) f(mm)%rface = c_loc(d%rface)
+                if (associated(d%uSlip)) f(mm)%uSlip = c_loc(d%uSlip)
+                if (associated(d%TNS_Wall)) f(mm)%TNS_Wall = c_loc(d%TNS_Wall)
+                if (associated(d%rho)) f(mm)%rho = c_loc(d%rho)
+                if (associated(d%velx)) f(mm)%velx = c_loc(d%velx)
+                if (associated(d%vely)) f(mm)%vely = c_loc(d%vely)
+                if (associated(d%velz)) f(mm)%velz = c_loc(d%velz)
+                if (associated(d%ps)) f(mm)%ps = c_loc(d%ps)
+            end associate
+        end do
+        call gpuCheck(adflow_gpu_bc_register(int(nn, c_int), int(level, c_int), int(sps, c_int), int(nb, c_int), &
+                                             int(flowDoms(nn, level, sps)%nViscBocos, c_int), f), "gpuRegisterBocos")
+    end subroutine gpuRegisterBocos
 
 end module adflowGpuShim

@@ -82,6 +82,10 @@ class FlowParams:
     nSubiterations: int = 1
     nSubIterTurb: int = 3
     turbRelax: int = 2          # turbRelaxImplicit (SA default)
+    # --- boundary treatment (inputDiscretization; pyADflow defaults: linear / constant / constant)
+    eulerWallBCTreatment: int = 2
+    viscWallBCTreatment: int = 1
+    outflowTreatment: int = 1
     alfaTurb: float = 0.8
     betaTurb: float = -1.0
     # --- iteration

@@ -246,6 +246,52 @@ def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.
 
 
 # ----------------------------------------------------------------------------
+# boundary subfaces: BCType / BCFaceID / BCData of a block whose six faces are physical
+# boundaries (one subface per face, cell range including the first halo ring as the
+# reference's preprocessing builds it).  Viscous walls come first (nViscBocos).
+# ----------------------------------------------------------------------------
+def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7):
+    """spec: {faceID (1..6 = iMin,iMax,jMin,jMax,kMin,kMax): BCType}.  Returns (faces, nViscBocos)."""
+    rng = np.random.default_rng(seed)
+    ie, je, ke = blk.ie, blk.je, blk.ke
+    sI, sJ, sK = blk["sI"], blk["sJ"], blk["sK"]
+    winf = prm.wInf()
+    faces = []
+    order = sorted(spec.items(), key=lambda kv: (0 if kv[1] in (-3, -4) else 1, kv[0]))
+    for fid, typ in order:
+        if fid in (1, 2):
+            n = sI[1 if fid == 1 else blk.il, :, :, :]            # (je, ke, 3)
+            rngs = (1, je, 1, ke)
+        elif fid in (3, 4):
+            n = sJ[:, 1 if fid == 3 else blk.jl, :, :]            # (ie, ke, 3)
+            rngs = (1, ie, 1, ke)
+        else:
+            n = sK[:, :, 1 if fid == 5 else blk.kl, :]            # (ie, je, 3)
+            rngs = (1, ie, 1, je)
+        sgn = -1.0 if fid in (1, 3, 5) else 1.0                    # outward
+        mag = np.sqrt((n ** 2).sum(axis=-1, keepdims=True))
+        norm = np.asfortranarray(sgn * n / mag)
+        shp = norm.shape[:2]
+        f = dict(bcType=int(typ), faceID=int(fid), icBeg=rngs[0], icEnd=rngs[1], jcBeg=rngs[2], jcEnd=rngs[3], norm=norm)
+        if typ in (-5, -6):
+            f["rface"] = np.asfortranarray(0.01 * rng.uniform(-1, 1, shp))
+        if typ in (-3, -4):
+            f["uSlip"] = np.asfortranarray(0.02 * rng.uniform(-1, 1, shp + (3,)))
+        if typ == -4:
+            tinf = prm.pInf / (prm.RGas * prm.rhoInf)
+            f["TNS_Wall"] = np.asfortranarray(tinf * (1.0 + 0.05 * rng.uniform(-1, 1, shp)))
+        if typ == -7:
+            f["rho"] = np.asfortranarray(winf[0] * (1.0 + 0.02 * rng.uniform(-1, 1, shp)))
+            f["velx"] = np.asfortranarray(winf[1] * (1.0 + 0.02 * rng.uniform(-1, 1, shp)))
+            f["vely"] = np.asfortranarray(winf[1] * 0.05 * rng.uniform(-1, 1, shp))
+            f["velz"] = np.asfortranarray(winf[1] * 0.05 * rng.uniform(-1, 1, shp))
+            f["ps"] = np.asfortranarray(prm.pInf * (1.0 + 0.02 * rng.uniform(-1, 1, shp)))
+        faces.append(f)
+    nvisc = sum(1 for _, t in order if t in (-3, -4))
+    return faces, nvisc
+
+
+# ----------------------------------------------------------------------------
 # multigrid: regular 2:1 coarsening maps (src/preprocessing/coarseUtils.F90:254-420)
 # ----------------------------------------------------------------------------
 def mg_maps_1d(nf: int):

@@ -45,6 +45,32 @@ enum { ADFLOW_RESAVG_NEVER = 0, ADFLOW_RESAVG_ALWAYS = 1, ADFLOW_RESAVG_ALTERNAT
 /* host hook type: see adflow_gpu_set_bc_callback */
 typedef void (*adflow_bc_callback)(int level, int secondHalo);
 
+/* boundary subfaces: BCType and BCFaceID values of src/modules/constants.F90:257-297 */
+enum {
+    ADFLOW_BC_SYMM = -1, ADFLOW_BC_NSWALL_ADIABATIC = -3, ADFLOW_BC_NSWALL_ISOTHERMAL = -4, ADFLOW_BC_EULERWALL = -5,
+    ADFLOW_BC_FARFIELD = -6, ADFLOW_BC_SUPERSONIC_INFLOW = -7, ADFLOW_BC_SUPERSONIC_OUTFLOW = -9, ADFLOW_BC_EXTRAP = -15
+};
+enum { ADFLOW_IMIN = 1, ADFLOW_IMAX = 2, ADFLOW_JMIN = 3, ADFLOW_JMAX = 4, ADFLOW_KMIN = 5, ADFLOW_KMAX = 6 };
+enum { ADFLOW_WALLBC_CONSTANT = 1, ADFLOW_WALLBC_LINEAR = 2, ADFLOW_WALLBC_QUADRATIC = 3, ADFLOW_WALLBC_NORMAL_MOMENTUM = 4 };
+
+/* One boundary subface of a block: flowDoms(nn,level,sps)%BCType(mm), %BCFaceID(mm) and the
+ * members of %BCData(mm) the flow boundary conditions read (block.F90 BCDataType).  Every array
+ * has the bounds (icBeg:icEnd, jcBeg:jcEnd [,3]) of the reference, Fortran order; NULL where the
+ * boundary type does not use it (rface NULL = zero grid velocity). */
+typedef struct adflow_bc_subface {
+    int32_t bcType, faceID;
+    int32_t icBeg, icEnd, jcBeg, jcEnd;
+    const double* norm;       /* unit outward normal, 3 components                                       */
+    const double* rface;      /* normal grid velocity (EulerWall, farField)                              */
+    const double* uSlip;      /* wall velocity, 3 components (NSWall*)                                   */
+    const double* TNS_Wall;   /* wall temperature (NSWallIsothermal)                                     */
+    const double* rho;        /* prescribed state (SupersonicInflow): rho, velx, vely, velz, ps          */
+    const double* velx;
+    const double* vely;
+    const double* velz;
+    const double* ps;
+} adflow_bc_subface;
+
 /* Options: snapshot of the Fortran module variables the hot path reads.
  * Refreshed by the shim at every entry (Python may assign them between calls,
  * adflow/pyADflow.py:5463-5630).  Field names are the reference's. */
@@ -60,7 +86,10 @@ typedef struct adflow_opts {
     /* iteration (src/modules/iteration.f90) */
     int32_t groundLevel;
     int32_t turbRelax;        /* inputIteration: 1 explicit, 2 implicit (default for SA, inputParamRoutines.F90:3402) */
-    int32_t reserved_i[2];
+    /* inputDiscretization: boundary treatment (constants.F90:170-178): 1 constant, 2 linear, 4 normal momentum;
+     * outflowTreatment 1 constant, 2 linear extrapolation */
+    int32_t eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment;
+    int32_t reserved_i;
     double gammaConstant, prandtl, prandtlTurb;
     double SSuthDim, muSuthDim, TSuthDim;
     double SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot;
@@ -220,6 +249,18 @@ int adflow_gpu_halo_local_copy(int level, int nLayers, int varStart, int varEnd,
  * smoother stage, where the reference applies boundary conditions
  * (applyAllBC, smoothers.F90:369,680).  NULL (default) = no physical boundaries. */
 int adflow_gpu_set_bc_callback(adflow_bc_callback fn);
+/* Boundary conditions on the device ("next" row 1 of SURVEY.md §8f).
+ * adflow_gpu_bc_register copies the subfaces of one block (the first nViscBocos are the viscous
+ * walls, as in the reference) to the device; adflow_gpu_apply_all_bc is BCRoutines::applyAllBC
+ * (src/solver/BCRoutines.F90:15-221: symm -> adiabatic wall -> isothermal wall -> farfield ->
+ * extrap / supersonic outflow -> Euler wall -> supersonic inflow, subfaces in index order inside
+ * each kind, computeEtot + extrapolate2ndHalo as there) for every registered block of the level.
+ * Once a level has registered subfaces the smoothers, the multigrid transfers and the NK residual
+ * apply them on the device at the points where the reference calls applyAllBC; the host callback
+ * (if any) still runs afterwards for kinds that are not implemented here (symmPolar, subsonic
+ * in/outflow, normal-momentum Euler wall: registration of those returns an error). */
+int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBocos, const adflow_bc_subface* faces);
+int adflow_gpu_apply_all_bc(int level, int secondHalo);
 /* sum over owned cells of (dw(:,l)/vol)^2, l=1..n  (solvers.F90:1538) */
 int adflow_gpu_res_norms(int level, double* sums, int n);
 

@@ -41,12 +41,15 @@ def load(fast: bool = False) -> ctypes.CDLL:
         lib.ref_set_internal_comm.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
         lib.ref_set_cycling.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ref_call_level.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.ref_set_bocos.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ref_set_bcdata.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p]
         _LIB = lib
     return _LIB
 
 
 _INT_PARAMS = ["equations", "spaceDiscr", "spaceDiscrCoarse", "limiter", "orderTurb", "turbModel", "turbProd",
-               "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb", "nSubiterations", "turbRelax"]
+               "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb", "nSubiterations", "turbRelax",
+               "eulerWallBCTreatment", "viscWallBCTreatment", "outflowTreatment"]
 _BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA"]
 _REAL_PARAMS = ["vis2", "vis4", "vis2Coarse", "adis", "acousticScaleFactor", "kappaCoef", "sigma", "cfl",
                 "cflCoarse", "cflLimit", "fcoll", "smoop", "alfaTurb", "betaTurb", "rFil", "gammaConstant",
@@ -144,6 +147,25 @@ def bind_block(blk, prm) -> None:
         lib.ref_set_ptr(name.encode(), arr.ctypes.data)
 
 
+def set_bocos(faces, nViscBocos=0) -> None:
+    """blockPointers%BCType/BCFaceID/BCData for the currently bound block (before commit_block):
+    `faces` as in Engine.bc_register.  The arrays stay owned by the caller."""
+    lib = load()
+    n = len(faces)
+    types = np.array([f["bcType"] for f in faces] or [0], dtype=np.int32)
+    fids = np.array([f["faceID"] for f in faces] or [0], dtype=np.int32)
+    rng = np.asfortranarray(np.array([[f["icBeg"], f["icEnd"], f["jcBeg"], f["jcEnd"]] for f in faces] or [[0, 0, 0, 0]],
+                                     dtype=np.int32).T)
+    lib.ref_set_bocos(n, int(nViscBocos), types.ctypes.data, fids.ctypes.data, rng.ctypes.data)
+    _keep.append(faces)     # the reference points INTO these arrays
+    for m, f in enumerate(faces):
+        for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps"):
+            a = f.get(k)
+            if a is not None:
+                assert a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, k
+                lib.ref_set_bcdata(m + 1, k.encode(), a.ctypes.data)
+
+
 def _big_stack(fn, *args):
     """The reference keeps block-sized automatic arrays on the stack (e.g. dss, ss
     in fluxes.F90:1079-1080): run its routines on a thread with a 2 GiB stack
@@ -228,10 +250,13 @@ def call_level(name: str, level: int = 1, i1: int = 0, i2: int = 0) -> None:
     _big_stack(load().ref_call_level, name.encode(), level, int(i1), int(i2))
 
 
-def bind_blocks(blocks, prm, level: int = 1, nlevels: int = 1, alloc: bool = True) -> None:
-    """blocks: {nn: Block}; binds each and commits it to flowDoms(nn,level,1)."""
+def bind_blocks(blocks, prm, level: int = 1, nlevels: int = 1, alloc: bool = True, bocos=None) -> None:
+    """blocks: {nn: Block}; binds each and commits it to flowDoms(nn,level,1).
+    bocos: optional {nn: (faces, nViscBocos)} boundary subfaces (set_bocos)."""
     if alloc:
         alloc_doms(max(blocks), nlevels)
     for nn, b in sorted(blocks.items()):
         bind_block(b, prm)
+        if bocos and nn in bocos:
+            set_bocos(*bocos[nn])
         commit_block(nn, level)

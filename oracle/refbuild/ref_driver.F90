@@ -288,6 +288,9 @@ contains
         case ('resAveraging'); resAveraging = v
         case ('turbTreatment'); turbTreatment = v
         case ('turbRelax'); turbRelax = v
+        case ('eulerWallBCTreatment'); eulerWallBCTreatment = v
+        case ('viscWallBCTreatment'); viscWallBCTreatment = v
+        case ('outflowTreatment'); outflowTreatment = v
         case ('nSubIterTurb'); nSubIterTurb = v
         case ('nSubiterations'); nSubiterations = v
         case ('nTimeIntervalsSpectral'); nTimeIntervalsSpectral = v
@@ -421,6 +424,64 @@ contains
         nStepsCycling = n
     end subroutine ref_set_cycling
 
+    ! --------------------------------------------------- boundary subfaces
+    ! blockPointers%nBocos/BCType/BCFaceID/BCData(:)%{icBeg..jcEnd} for the block the
+    ! pointers currently describe.  ranges(1:4, mm) = icBeg, icEnd, jcBeg, jcEnd.
+    ! Fresh storage per call: committed blocks keep theirs.
+    subroutine ref_set_bocos(nBocos_, nViscBocos_, types, faceIDs, ranges) bind(C, name="ref_set_bocos")
+        use blockPointers
+        integer(c_int), value :: nBocos_, nViscBocos_
+        integer(c_int), intent(in) :: types(*), faceIDs(*), ranges(4, *)
+        integer :: mm
+        nBocos = nBocos_; nViscBocos = nViscBocos_
+        nullify (BCType, BCFaceID, BCData, globalCell, s)
+        allocate (BCType(max(nBocos, 1)), BCFaceID(max(nBocos, 1)), BCData(max(nBocos, 1)))
+        allocate (globalCell(0:ib, 0:jb, 0:kb), s(0:ie, 0:je, 0:ke, 3))
+        globalCell = 0; s = zero
+        do mm = 1, nBocos
+            BCType(mm) = types(mm); BCFaceID(mm) = faceIDs(mm)
+            BCData(mm)%icBeg = ranges(1, mm); BCData(mm)%icEnd = ranges(2, mm)
+            BCData(mm)%jcBeg = ranges(3, mm); BCData(mm)%jcEnd = ranges(4, mm)
+            BCData(mm)%subsonicInletTreatment = 0
+            nullify (BCData(mm)%norm, BCData(mm)%rface, BCData(mm)%uSlip, BCData(mm)%TNS_Wall, BCData(mm)%rho, &
+                     BCData(mm)%velx, BCData(mm)%vely, BCData(mm)%velz, BCData(mm)%ps)
+        end do
+    end subroutine ref_set_bocos
+
+    ! member `name` of BCData(mm) => caller-owned array with the reference's bounds
+    subroutine ref_set_bcdata(mm, name, ptr) bind(C, name="ref_set_bcdata")
+        use blockPointers
+        integer(c_int), value :: mm
+        character(kind=c_char), dimension(*), intent(in) :: name
+        type(c_ptr), value :: ptr
+        real(kind=realType), dimension(:, :, :), pointer :: t3
+        real(kind=realType), dimension(:, :), pointer :: t2
+        integer(kind=intType) :: i0, i1, j0, j1
+        character(len=64) :: n
+        n = cstr(name)
+        i0 = BCData(mm)%icBeg; i1 = BCData(mm)%icEnd; j0 = BCData(mm)%jcBeg; j1 = BCData(mm)%jcEnd
+        select case (trim(n))
+        case ('norm', 'uSlip')
+            call c_f_pointer(ptr, t3, [i1 - i0 + 1, j1 - j0 + 1, 3])
+            if (trim(n) == 'norm') BCData(mm)%norm(i0:, j0:, 1:) => t3
+            if (trim(n) == 'uSlip') BCData(mm)%uSlip(i0:, j0:, 1:) => t3
+        case ('rface', 'TNS_Wall', 'rho', 'velx', 'vely', 'velz', 'ps')
+            call c_f_pointer(ptr, t2, [i1 - i0 + 1, j1 - j0 + 1])
+            select case (trim(n))
+            case ('rface'); BCData(mm)%rface(i0:, j0:) => t2
+            case ('TNS_Wall'); BCData(mm)%TNS_Wall(i0:, j0:) => t2
+            case ('rho'); BCData(mm)%rho(i0:, j0:) => t2
+            case ('velx'); BCData(mm)%velx(i0:, j0:) => t2
+            case ('vely'); BCData(mm)%vely(i0:, j0:) => t2
+            case ('velz'); BCData(mm)%velz(i0:, j0:) => t2
+            case ('ps'); BCData(mm)%ps(i0:, j0:) => t2
+            end select
+        case default
+            print *, 'ref_set_bcdata: unknown member ', trim(n)
+            stop 1
+        end select
+    end subroutine ref_set_bcdata
+
     ! ----------------------------------------------------------------- calls
     ! Each entry calls ONE reference routine, unchanged, on the current block.
     subroutine ref_call(name, iarg) bind(C, name="ref_call")
@@ -434,6 +495,8 @@ contains
         use turbUtils, only: computeEddyViscosity
         use sa, only: sa_block
         use adjointExtra, only: volume_block, metric_block, sumDwAndFw
+        use BCRoutines, only: applyAllBC_block
+        use turbBCRoutines, only: bcTurbTreatment, applyAllTurbBCThisBlock
         character(kind=c_char), dimension(*), intent(in) :: name
         integer(c_int), value :: iarg
         character(len=64) :: n
@@ -463,6 +526,9 @@ contains
         case ('computeEddyViscosity'); call computeEddyViscosity(iarg /= 0)
         case ('volume_block'); call volume_block
         case ('metric_block'); call metric_block
+        case ('applyAllBC_block'); call applyAllBC_block(iarg /= 0)         ! BCRoutines.F90:57
+        case ('bcTurbTreatment'); call bcTurbTreatment                       ! turbBCRoutines.F90:662
+        case ('applyAllTurbBCThisBlock'); call applyAllTurbBCThisBlock(iarg /= 0)   ! turbBCRoutines.F90:49
         case ('zero_fw'); fw = zero
         case default
             print *, 'ref_call: unknown routine ', trim(n)
@@ -566,7 +632,9 @@ contains
             d%cgnsBlockID = 1
             d%rightHanded = .true.
             d%iBegor = 1; d%iEndor = il; d%jBegor = 1; d%jEndor = jl; d%kBegor = 1; d%kEndor = kl
-            d%nSubface = 0; d%n1to1 = 0; d%nBocos = 0; d%nViscBocos = 0
+            d%nSubface = 0; d%n1to1 = 0; d%nBocos = nBocos; d%nViscBocos = nViscBocos
+            d%BCType => BCType; d%BCFaceID => BCFaceID; d%BCData => BCData
+            d%globalCell => globalCell; d%s => s
             d%nOrphans = 0
             d%blockIsMoving = .false.; d%addGridVelocities = .false.
             d%iblank => iblank
@@ -627,6 +695,7 @@ contains
         use residuals, only: initres, residual
         use multiGrid, only: transferToCoarseGrid, transferToFineGrid, executeMGCycle
         use utils, only: setPointers
+        use BCRoutines, only: applyAllBC
         character(kind=c_char), dimension(*), intent(in) :: name
         integer(c_int), value :: level, i1, i2
         character(len=64) :: n
@@ -645,6 +714,7 @@ contains
         case ('transferToCoarseGrid'); call transferToCoarseGrid                      ! multiGrid.F90:5
         case ('transferToFineGrid'); call transferToFineGrid(i1 /= 0)                 ! multiGrid.F90:326
         case ('executeMGCycle'); call executeMGCycle                                  ! multiGrid.F90:825
+        case ('applyAllBC'); call applyAllBC(i1 /= 0)                                 ! BCRoutines.F90:15
         case default
             print *, 'ref_call_level: unknown routine ', trim(n)
             stop 1

@@ -1,0 +1,101 @@
+"""GPU parity (real MI355X, through the C-ABI): boundary conditions on the device
+(SURVEY.md §8f "next" row 1) against the reference's own BCRoutines / turbBCRoutines:
+applyAllBC_block on all six faces of a block, the smoothers, the SA solve, the multigrid
+cycle and the NK residual with physical boundaries."""
+import pytest
+
+import checks
+from adflow_amd.params import (FlowParams, NSEquations, RANSEquations, DADI, RungeKutta, noResAveraging, secondOrder,
+                               alternateResAveraging)
+from adflow_amd.topology import BrickTopology
+
+pytestmark = pytest.mark.gpu
+
+# BCType: -1 symm, -3 adiabatic wall, -4 isothermal wall, -5 Euler wall, -6 farfield, -7 supersonic inflow,
+# -9 supersonic outflow, -15 extrap ; faces 1..6 = iMin, iMax, jMin, jMax, kMin, kMax
+EULER_SPECS = [{1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}, {1: -7, 2: -6, 3: -5, 4: -5, 5: -1, 6: -1},
+               {1: -6, 2: -6, 3: -6, 4: -6, 5: -5, 6: -6}]
+VISC_SPECS = [{1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, {1: -9, 2: -7, 3: -3, 4: -1, 5: -4, 6: -15}]
+
+
+@pytest.mark.parametrize("spec", EULER_SPECS)
+@pytest.mark.parametrize("second", [True, False])
+def test_apply_all_bc_euler(engine, spec, second):
+    checks.check_apply_bc(engine, (70, 9, 11), FlowParams(), spec, secondHalo=second)
+
+
+@pytest.mark.parametrize("treat", [1, 2])
+def test_apply_all_bc_wall_and_outflow_treatments(engine, treat):
+    prm = FlowParams(eulerWallBCTreatment=treat, outflowTreatment=treat)
+    checks.check_apply_bc(engine, (12, 10, 6), prm, EULER_SPECS[0])
+    prm = FlowParams(equations=NSEquations, viscWallBCTreatment=treat)
+    checks.check_apply_bc(engine, (12, 10, 6), prm, VISC_SPECS[0], stretch_k=2.0)
+
+
+@pytest.mark.parametrize("spec", VISC_SPECS)
+def test_apply_all_bc_rans(engine, spec):
+    checks.check_apply_bc(engine, (20, 7, 6), FlowParams(equations=RANSEquations), spec, stretch_k=2.0)
+
+
+def test_apply_all_bc_two_dimensional_block_between_symmetry_planes(engine):
+    """one cell between two symmetry planes: the reason the reference runs the 2nd-halo symmetry pass separately"""
+    checks.check_apply_bc(engine, (16, 8, 1), FlowParams(), {1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
+
+
+def test_apply_all_bc_coarse_level_forces_constant_pressure_walls(engine):
+    checks.check_apply_bc(engine, (12, 10, 6), FlowParams(eulerWallBCTreatment=2), EULER_SPECS[0], secondHalo=False, level=2)
+
+
+def test_rk_smoother_with_bc(engine):
+    checks.check_smoother_with_bc(engine, (24, 10, 6), FlowParams(smoother=RungeKutta, resAveraging=alternateResAveraging),
+                                  {1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
+    checks.check_smoother_with_bc(engine, (12, 8, 6), FlowParams(equations=NSEquations, smoother=RungeKutta),
+                                  {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}, stretch_k=2.0)
+
+
+def test_dadi_smoother_with_bc_rans(engine):
+    prm = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2)
+    checks.check_smoother_with_bc(engine, (12, 8, 6), prm, {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}, stretch_k=2.0)
+
+
+@pytest.mark.parametrize("order", [1, secondOrder])
+def test_sa_solve_with_turbulence_bc(engine, order):
+    prm = FlowParams(equations=RANSEquations, nSubIterTurb=2, orderTurb=order)
+    checks.check_sa_solve_with_bc(engine, (12, 8, 6), prm, {1: -6, 2: -15, 3: -1, 4: -4, 5: -3, 6: -9}, stretch_k=2.0)
+    checks.check_sa_solve_with_bc(engine, (8, 6, 5), prm, {1: -6, 2: -6, 3: -1, 4: -5, 5: -3, 6: -6}, stretch_k=2.0)
+
+
+def test_mg_cycle_with_bc(engine):
+    checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 16, 8, 8), FlowParams(), [0, 1, 0, -1],
+                          bc_spec={1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
+    prm = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2,
+                     nSubIterTurb=2)
+    checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 8, 8, 4), prm, [0, 1, 0, -1], ncycles=2,
+                          bc_spec={1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}, stretch_k=2.0)
+
+
+def test_mg_cycle_three_levels_with_bc(engine):
+    checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 8, 8, 8), FlowParams(equations=NSEquations),
+                          [0, 1, 0, 1, 0, -1, 0, -1], ncycles=2, nlevels=3,
+                          bc_spec={1: -6, 2: -9, 3: -1, 4: -15, 5: -4, 6: -6}, stretch_k=2.0)
+
+
+def test_nk_residual_with_bc(engine):
+    checks.check_nk_residual(engine, BrickTopology(1, 1, 1, 12, 8, 6), FlowParams(equations=RANSEquations),
+                             bc_spec={1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}, stretch_k=2.0)
+    checks.check_nk_residual(engine, BrickTopology(1, 1, 1, 12, 8, 6), FlowParams(),
+                             bc_spec={1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
+
+
+def test_unsupported_bc_kinds_are_refused(engine):
+    from adflow_amd.capi import AdflowGpuError
+    from adflow_amd.synth import make_block, make_bocos
+    engine.release_all()
+    prm = FlowParams()
+    engine.set_options(prm)
+    blk = make_block(6, 5, 4, prm)
+    engine.register(blk)
+    faces, nv = make_bocos(blk, prm, {1: -6})
+    faces[0]["bcType"] = -8          # subsonic inflow
+    with pytest.raises(AdflowGpuError):
+        engine.bc_register(faces, nv)

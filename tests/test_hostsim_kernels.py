@@ -158,3 +158,36 @@ def test_euler_march_variants(hostsim_engine, pipe, kch):
     finally:
         hostsim_engine.set_tuning("march_pipe", 2)
         hostsim_engine.set_tuning("march_kch", 32)
+
+
+# ---- boundary conditions on the device ("next" row 1): same checks as tests/test_gpu_bc.py, small sizes ----
+@pytest.mark.parametrize("spec", [{1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}, {1: -7, 2: -6, 3: -5, 4: -5, 5: -1, 6: -1}])
+@pytest.mark.parametrize("second", [True, False])
+def test_apply_all_bc_euler(hostsim_engine, spec, second):
+    checks.check_apply_bc(hostsim_engine, (6, 5, 4), FlowParams(), spec, secondHalo=second)
+    checks.check_apply_bc(hostsim_engine, (6, 5, 1), FlowParams(eulerWallBCTreatment=1, outflowTreatment=2), spec, secondHalo=second)
+
+
+def test_apply_all_bc_viscous(hostsim_engine):
+    checks.check_apply_bc(hostsim_engine, (5, 4, 3), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6},
+                          stretch_k=2.0)
+    checks.check_apply_bc(hostsim_engine, (5, 4, 3), FlowParams(equations=NSEquations, viscWallBCTreatment=2),
+                          {1: -9, 2: -7, 3: -3, 4: -1, 5: -4, 6: -15}, stretch_k=2.0)
+    checks.check_apply_bc(hostsim_engine, (6, 4, 4), FlowParams(equations=NSEquations, viscWallBCTreatment=2),
+                          {1: -6, 2: -6, 3: -3, 4: -1, 5: -5, 6: -6}, secondHalo=False, level=2, stretch_k=2.0)
+
+
+def test_smoothers_sa_solve_mg_nk_with_bc(hostsim_engine):
+    from adflow_amd.params import DADI, RungeKutta, alternateResAveraging
+    e = hostsim_engine
+    checks.check_smoother_with_bc(e, (8, 6, 4), FlowParams(smoother=RungeKutta, resAveraging=alternateResAveraging),
+                                  {1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
+    rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=2)
+    wall = {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}
+    checks.check_smoother_with_bc(e, (6, 5, 4), rans, wall, stretch_k=2.0)
+    checks.check_sa_solve_with_bc(e, (6, 5, 4), rans.replace(orderTurb=secondOrder), {1: -6, 2: -15, 3: -1, 4: -4, 5: -3, 6: -9},
+                                  stretch_k=2.0)
+    checks.check_mg_cycle(e, BrickTopology(1, 1, 1, 8, 8, 4), FlowParams(), [0, 1, 0, -1],
+                          bc_spec={1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
+    checks.check_mg_cycle(e, BrickTopology(1, 1, 1, 8, 4, 4), rans, [0, 1, 0, -1], ncycles=1, bc_spec=wall, stretch_k=2.0)
+    checks.check_nk_residual(e, BrickTopology(1, 1, 1, 6, 5, 4), FlowParams(equations=RANSEquations), bc_spec=wall, stretch_k=2.0)
