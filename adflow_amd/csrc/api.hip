@@ -512,6 +512,33 @@ int adflow_gpu_upload_geometry(int nn, int level, int sps)
     return 0;
 }
 
+// x only; adflow_gpu_update_geometry derives the rest on the device
+int adflow_gpu_upload_coordinates(int nn, int level, int sps)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (!b->d.x) return fail("block (%d,%d,%d): no coordinate array", nn, level, sps);
+    if (copy_box(b, b->v.x, b->d.x, 3, 0, b->v.ie + 1, 0, b->v.je + 1, 0, b->v.ke + 1, true)) return 1;
+    b->face_vectors_valid = false;
+    return sync_and_check();
+}
+
+// volume_block + metric_block + boundaryNormals (adjointExtra.F90:5-364) for every block of the level:
+// the `useSpatial` branch of blocketteRes (blockette.F90:203-211) after the mesh moved
+int adflow_gpu_update_geometry(int level)
+{
+    if (need_ready()) return 1;
+    int rc = for_level(level, [&](Block* b) {
+        if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
+        launch_volume_metric(b->v, b->d.rightHanded, g_stream);
+        if (!b->bc.empty()) launch_boundary_normals(b->v, b->bc.data(), (int)b->bc.size(), g_stream);
+        b->face_vectors_valid = false;
+        return 0;
+    });
+    if (rc) return rc;
+    return sync_and_check();
+}
+
 int adflow_gpu_upload_state(int nn, int level, int sps)
 {
     Block* b = find_block(nn, level, sps);

@@ -164,5 +164,7 @@ void launch_turb_bc_treatment(const BlkView& b, const BcFaceDev* faces, int nBoc
 void launch_apply_turb_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, int second, hipStream_t s);
 void launch_corner_row_halos(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_bc_coarse_corrections(const BlkView& b, const BcFaceDev* faces, int nBocos, double fact, hipStream_t s);
+void launch_volume_metric(const BlkView& b, int rightHanded, hipStream_t s);
+void launch_boundary_normals(const BlkView& b, const BcFaceDev* faces, int nBocos, hipStream_t s);
 void launch_apply_all_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, int nVisc, const KParams& kp, int second,
                          int eulerWallTreatment, int viscWallTreatment, int outflowTreatment, hipStream_t s);

@@ -1,0 +1,156 @@
+// Geometry pipeline on the device (SURVEY.md §8f "next" row 3): cell volumes, face
+// normals and boundary normals from the node coordinates, for the mesh-warping
+// (`useSpatial`) branch of blocketteRes (src/NKSolver/blockette.F90:203-211).
+//
+// Reference semantics (src/adjoint/adjointExtra.F90):
+//   volume_block     :5-178    six pyramids per cell around the cell centre, |.|, then the
+//                              halo-volume repair (a collapsed halo takes its neighbour's volume)
+//   metric_block     :179-268  face normal = fact * (diagonal x diagonal), fact = +-1/2
+//   boundaryNormals  :270-364  unit outward normal of every boundary-subface cell
+// Pointwise gathers over nodes; roofline: HBM.
+#include "internal.h"
+
+#define GM_BX 64
+#define GM_BY 4
+
+struct P3 { double x, y, z; };
+
+__device__ __forceinline__ P3 node(const BlkView& b, long n)
+{
+    P3 p;
+    p.x = b.x[n]; p.y = b.x[n + b.nbox]; p.z = b.x[n + 2 * b.nbox];
+    return p;
+}
+
+// volpym (adjointExtra.F90:157-176); (xp,yp,zp) = cell centre
+__device__ __forceinline__ double volpym(const P3& c, const P3& a, const P3& b, const P3& cc, const P3& d)
+{
+    return (c.x - 0.25 * (a.x + b.x + cc.x + d.x)) * ((a.y - cc.y) * (b.z - d.z) - (a.z - cc.z) * (b.y - d.y)) +
+           (c.y - 0.25 * (a.y + b.y + cc.y + d.y)) * ((a.z - cc.z) * (b.x - d.x) - (a.x - cc.x) * (b.z - d.z)) +
+           (c.z - 0.25 * (a.z + b.z + cc.z + d.z)) * ((a.x - cc.x) * (b.y - d.y) - (a.y - cc.y) * (b.x - d.x));
+}
+
+// all box cells: vol = 0 outside 1..ie x 1..je x 1..ke
+__global__ __launch_bounds__(GM_BX* GM_BY) void k_volume(BlkView b)
+{
+    const int i = blockIdx.x * GM_BX + threadIdx.x;
+    const int j = blockIdx.y * GM_BY + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i > b.ib || j > b.jb) return;
+    const long c = b.idx(i, j, k);
+    if (i < 1 || i > b.ie || j < 1 || j > b.je || k < 1 || k > b.ke) { b.vol[c] = 0.0; return; }
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+    // nodes: (i|l, j|m, k|n) with l = i-1, m = j-1, n = k-1
+    const P3 ijk = node(b, c), imk = node(b, c - sj), imn = node(b, c - sj - sk), ijn = node(b, c - sk);
+    const P3 ljk = node(b, c - si), lmk = node(b, c - si - sj), lmn = node(b, c - si - sj - sk), ljn = node(b, c - si - sk);
+    P3 ctr;
+    ctr.x = 0.125 * (ijk.x + imk.x + imn.x + ijn.x + ljk.x + lmk.x + lmn.x + ljn.x);
+    ctr.y = 0.125 * (ijk.y + imk.y + imn.y + ijn.y + ljk.y + lmk.y + lmn.y + ljn.y);
+    ctr.z = 0.125 * (ijk.z + imk.z + imn.z + ijn.z + ljk.z + lmk.z + lmn.z + ljn.z);
+    const double vp1 = volpym(ctr, ijk, ijn, imn, imk);
+    const double vp2 = volpym(ctr, ljk, lmk, lmn, ljn);
+    const double vp3 = volpym(ctr, ijk, ljk, ljn, ijn);
+    const double vp4 = volpym(ctr, imk, imn, lmn, lmk);
+    const double vp5 = volpym(ctr, ijk, imk, lmk, ljk);
+    const double vp6 = volpym(ctr, ijn, ljn, lmn, imn);
+    b.vol[c] = fabs((1.0 / 6.0) * (vp1 + vp2 + vp3 + vp4 + vp5 + vp6));
+}
+
+// halo-volume repair, one direction per launch (the later directions read what the earlier ones wrote)
+template <int DIR>
+__global__ __launch_bounds__(256) void k_volume_halo(BlkView b)
+{
+    const double haloCellRatio = 1e-10;
+    const int a = blockIdx.x * 256 + threadIdx.x, bb = blockIdx.y;
+    int lo, hi, lo2, hi2;
+    long h1, n1, h2, n2;
+    if (DIR == 0) {          // i faces: j = 2..jl, k = 2..kl
+        const int j = a + 2, k = bb + 2;
+        if (j > b.jl || k > b.kl) return;
+        h1 = b.idx(1, j, k); n1 = b.idx(2, j, k); h2 = b.idx(b.ie, j, k); n2 = b.idx(b.il, j, k);
+    } else if (DIR == 1) {   // j faces: i = 1..ie, k = 2..kl
+        const int i = a + 1, k = bb + 2;
+        if (i > b.ie || k > b.kl) return;
+        h1 = b.idx(i, 1, k); n1 = b.idx(i, 2, k); h2 = b.idx(i, b.je, k); n2 = b.idx(i, b.jl, k);
+    } else {                 // k faces: i = 1..ie, j = 1..je
+        const int i = a + 1, j = bb + 1;
+        if (i > b.ie || j > b.je) return;
+        h1 = b.idx(i, j, 1); n1 = b.idx(i, j, 2); h2 = b.idx(i, j, b.ke); n2 = b.idx(i, j, b.kl);
+    }
+    (void)lo; (void)hi; (void)lo2; (void)hi2;
+    if (b.vol[h1] / b.vol[n1] < haloCellRatio) b.vol[h1] = b.vol[n1];
+    if (b.vol[h2] / b.vol[n2] < haloCellRatio) b.vol[h2] = b.vol[n2];
+}
+
+__device__ __forceinline__ void cross_store(double* __restrict__ s, long c, long nb, double fact, const P3& p1, const P3& p2,
+                                            const P3& q1, const P3& q2)
+{
+    const double v1x = p1.x - p2.x, v1y = p1.y - p2.y, v1z = p1.z - p2.z;
+    const double v2x = q1.x - q2.x, v2y = q1.y - q2.y, v2z = q1.z - q2.z;
+    s[c] = fact * (v1y * v2z - v1z * v2y);
+    s[c + nb] = fact * (v1z * v2x - v1x * v2z);
+    s[c + 2 * nb] = fact * (v1x * v2y - v1y * v2x);
+}
+
+// sI (i = 0..ie, j = 1..je, k = 1..ke), sJ (1..ie, 0..je, 1..ke), sK (1..ie, 1..je, 0..ke)
+__global__ __launch_bounds__(GM_BX* GM_BY) void k_metric(BlkView b, double fact)
+{
+    const int i = blockIdx.x * GM_BX + threadIdx.x;
+    const int j = blockIdx.y * GM_BY + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i > b.ie || j > b.je || k > b.ke) return;
+    const long c = b.idx(i, j, k), nb = b.nbox;
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+    if (j >= 1 && k >= 1)    // v1 = x(i,j,n) - x(i,m,k) ; v2 = x(i,j,k) - x(i,m,n)
+        cross_store(b.sI, c, nb, fact, node(b, c - sk), node(b, c - sj), node(b, c), node(b, c - sj - sk));
+    if (i >= 1 && k >= 1)    // v1 = x(i,j,n) - x(l,j,k) ; v2 = x(l,j,n) - x(i,j,k)
+        cross_store(b.sJ, c, nb, fact, node(b, c - sk), node(b, c - si), node(b, c - si - sk), node(b, c));
+    if (i >= 1 && j >= 1)    // v1 = x(i,j,k) - x(l,m,k) ; v2 = x(l,j,k) - x(i,m,k)
+        cross_store(b.sK, c, nb, fact, node(b, c), node(b, c - si - sj), node(b, c - si), node(b, c - sj));
+}
+
+__global__ __launch_bounds__(256) void k_boundary_normals(BlkView b, BcFaceDev f, double* __restrict__ norm)
+{
+    const int isize = f.icEnd - f.icBeg + 1, jsize = f.jcEnd - f.jcBeg + 1;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, n = (long)isize * jsize;
+    if (t >= n) return;
+    const int i = f.icBeg + (int)(t % isize), j = f.jcBeg + (int)(t / isize);
+    const double* s;
+    long c;
+    double mult;
+    switch (f.faceID) {
+    case ADFLOW_IMIN: mult = -1.0; s = b.sI; c = b.idx(1, i, j); break;
+    case ADFLOW_IMAX: mult = 1.0; s = b.sI; c = b.idx(b.il, i, j); break;
+    case ADFLOW_JMIN: mult = -1.0; s = b.sJ; c = b.idx(i, 1, j); break;
+    case ADFLOW_JMAX: mult = 1.0; s = b.sJ; c = b.idx(i, b.jl, j); break;
+    case ADFLOW_KMIN: mult = -1.0; s = b.sK; c = b.idx(i, j, 1); break;
+    default: mult = 1.0; s = b.sK; c = b.idx(i, j, b.kl); break;
+    }
+    const double xxp = s[c], yyp = s[c + b.nbox], zzp = s[c + 2 * b.nbox];
+    double fact = sqrt(xxp * xxp + yyp * yyp + zzp * zzp);
+    if (fact > 0.0) fact = mult / fact;
+    norm[t] = fact * xxp;
+    norm[t + n] = fact * yyp;
+    norm[t + 2 * n] = fact * zzp;
+}
+
+void launch_volume_metric(const BlkView& b, int rightHanded, hipStream_t s)
+{
+    const dim3 blk(GM_BX, GM_BY, 1);
+    hipLaunchKernelGGL(k_volume, dim3((b.ib + GM_BX) / GM_BX, (b.jb + GM_BY) / GM_BY, b.kb + 1), blk, 0, s, b);
+    hipLaunchKernelGGL((k_volume_halo<0>), dim3((b.ny + 255) / 256, b.nz), dim3(256), 0, s, b);
+    hipLaunchKernelGGL((k_volume_halo<1>), dim3((b.ie + 255) / 256, b.nz), dim3(256), 0, s, b);
+    hipLaunchKernelGGL((k_volume_halo<2>), dim3((b.ie + 255) / 256, b.je), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_metric, dim3((b.ie + GM_BX) / GM_BX, (b.je + GM_BY) / GM_BY, b.ke + 1), blk, 0, s, b,
+                       rightHanded ? 0.5 : -0.5);
+}
+
+void launch_boundary_normals(const BlkView& b, const BcFaceDev* faces, int nBocos, hipStream_t s)
+{
+    for (int m = 0; m < nBocos; ++m) {
+        if (!faces[m].norm) continue;
+        const long n = (long)(faces[m].icEnd - faces[m].icBeg + 1) * (faces[m].jcEnd - faces[m].jcBeg + 1);
+        hipLaunchKernelGGL(k_boundary_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b, faces[m],
+                           const_cast<double*>(faces[m].norm));
+    }
+}

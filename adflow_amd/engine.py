@@ -122,6 +122,13 @@ class Engine:
                     setattr(arr[m], k, a.ctypes.data)
         self._chk(self.lib.adflow_gpu_bc_register(nn, level, sps, len(faces), int(nViscBocos), arr))
 
+    def upload_coordinates(self, nn=1, level=1, sps=1):
+        self._chk(self.lib.adflow_gpu_upload_coordinates(nn, level, sps))
+
+    def update_geometry(self, level=1):
+        """volume_block + metric_block + boundaryNormals on the device"""
+        self._chk(self.lib.adflow_gpu_update_geometry(level))
+
     def applyAllBC(self, level=1, secondHalo=True):
         self._chk(self.lib.adflow_gpu_apply_all_bc(level, int(secondHalo)))
 

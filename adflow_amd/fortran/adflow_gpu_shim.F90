@@ -70,6 +70,14 @@ module adflowGpuShim
             integer(c_int), value :: nn, level, sps, nBocos, nViscBocos
             type(adflow_bc_subface), intent(in) :: faces(*)
         end function
+        integer(c_int) function adflow_gpu_upload_coordinates(nn, level, sps) bind(C, name="adflow_gpu_upload_coordinates")
+            import :: c_int
+            integer(c_int), value :: nn, level, sps
+        end function
+        integer(c_int) function adflow_gpu_update_geometry(level) bind(C, name="adflow_gpu_update_geometry")
+            import :: c_int
+            integer(c_int), value :: level
+        end function
         integer(c_int) function adflow_gpu_apply_all_bc(level, secondHalo) bind(C, name="adflow_gpu_apply_all_bc")
             import :: c_int
             integer(c_int), value :: level, secondHalo

@@ -193,6 +193,11 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
 int adflow_gpu_block_release(int nn, int level, int sps);
 int adflow_gpu_release_all(void);
 int adflow_gpu_upload_geometry(int nn, int level, int sps);   /* x,sI,sJ,sK,vol,volRef,d2Wall,por*,iblank */
+/* Mesh warping ("next" row 3 of SURVEY.md 8f): upload the node coordinates only, then derive cell volumes, face
+ * normals and the unit normals of the registered boundary subfaces on the device = volume_block + metric_block +
+ * boundaryNormals (src/adjoint/adjointExtra.F90:5-364), the `useSpatial` branch of blocketteRes (blockette.F90:203-211) */
+int adflow_gpu_upload_coordinates(int nn, int level, int sps);
+int adflow_gpu_update_geometry(int level);
 int adflow_gpu_upload_state(int nn, int level, int sps);      /* w,p,gamma,rlv,rev incl. both halo layers */
 int adflow_gpu_download_state(int nn, int level, int sps);
 int adflow_gpu_download_residual(int nn, int level, int sps); /* dw -> desc.dw */

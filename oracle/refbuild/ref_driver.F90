@@ -494,7 +494,7 @@ contains
                              computePressureSimple, computeLamViscosity
         use turbUtils, only: computeEddyViscosity
         use sa, only: sa_block
-        use adjointExtra, only: volume_block, metric_block, sumDwAndFw
+        use adjointExtra, only: volume_block, metric_block, boundaryNormals, sumDwAndFw
         use BCRoutines, only: applyAllBC_block
         use turbBCRoutines, only: bcTurbTreatment, applyAllTurbBCThisBlock
         character(kind=c_char), dimension(*), intent(in) :: name
@@ -526,6 +526,7 @@ contains
         case ('computeEddyViscosity'); call computeEddyViscosity(iarg /= 0)
         case ('volume_block'); call volume_block
         case ('metric_block'); call metric_block
+        case ('boundaryNormals'); call boundaryNormals                      ! adjointExtra.F90:270
         case ('applyAllBC_block'); call applyAllBC_block(iarg /= 0)         ! BCRoutines.F90:57
         case ('bcTurbTreatment'); call bcTurbTreatment                       ! turbBCRoutines.F90:662
         case ('applyAllTurbBCThisBlock'); call applyAllTurbBCThisBlock(iarg /= 0)   ! turbBCRoutines.F90:49

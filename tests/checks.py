@@ -121,6 +121,45 @@ def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, *
     return blk, r
 
 
+def check_update_geometry(engine, dims, prm, spec, seed=81, **mk):
+    """volume_block + metric_block + boundaryNormals (adjointExtra.F90:5-364) after the nodes moved: vol, sI/sJ/sK
+    and - through a boundary-condition pass that reads them - the unit normals of the boundary subfaces."""
+    from oracle import ref
+    from adflow_amd.synth import make_bocos
+    new_level(engine)
+    prm = prm.replace(currentLevel=1, groundLevel=1)
+    blk = make_block(*dims, prm, seed=seed, **mk)
+    faces, nvisc = make_bocos(blk, prm, spec, seed=seed + 1)
+    engine.set_options(prm)
+    engine.register(blk, nn=1, level=1)
+    engine.bc_register(faces, nvisc, nn=1, level=1)
+    # warp the mesh (same on both sides), then derive the metrics
+    rng = np.random.default_rng(seed)
+    h = 1.0 / max(dims)
+    blk["x"] += 0.05 * h * rng.uniform(-1, 1, blk["x"].shape)
+    r = blk.copy()
+    rfaces = [dict(f, norm=f["norm"].copy(order="F")) for f in faces]
+    ref.bind_block(r, prm)
+    ref.set_bocos(rfaces, nvisc)
+    ref.call("volume_block")
+    ref.call("metric_block")
+    ref.call("boundaryNormals")
+    engine.upload_coordinates(1, 1)
+    engine.update_geometry(1)
+    for which, name in ((capi.ARR_VOL, "vol"), (capi.ARR_SI, "sI"), (capi.ARR_SJ, "sJ"), (capi.ARR_SK, "sK")):
+        out = np.zeros_like(r[name])
+        engine.download_array(which, out, 1, 1)
+        ref_arr = r[name]
+        if name == "vol":      # the reference's loops leave the outermost ring at the `vol = zero` it starts from
+            assert np.all(out[0] == 0.0) and np.all(out[:, 0] == 0.0) and np.all(out[:, :, 0] == 0.0)
+            out, ref_arr = out[1:-1, 1:-1, 1:-1], ref_arr[1:-1, 1:-1, 1:-1]
+        e = rel_err(out, ref_arr)
+        assert e <= TOL, (name, e)
+    ref.call("applyAllBC_block", 1)
+    engine.applyAllBC(1, True)
+    assert_state(engine, {1: blk}, {1: r}, prm, "BCs with the recomputed boundary normals")
+
+
 def check_smoother_with_bc(engine, dims, prm, spec, seed=61, nsweeps=2, **mk):
     """RungeKuttaSmoother / DADISmoother on ONE block whose six faces are physical boundaries: the device
     applies applyAllBC between update and halo exchange (smoothers.F90:369,680) exactly where the reference does."""

@@ -99,3 +99,11 @@ def test_unsupported_bc_kinds_are_refused(engine):
     faces[0]["bcType"] = -8          # subsonic inflow
     with pytest.raises(AdflowGpuError):
         engine.bc_register(faces, nv)
+
+
+@pytest.mark.parametrize("dims", [(70, 9, 11), (16, 8, 1)])
+def test_update_geometry_after_mesh_warp(engine, dims):
+    """"next" row 3: volume_block + metric_block + boundaryNormals on the device"""
+    checks.check_update_geometry(engine, dims, FlowParams(), {1: -1, 2: -6, 3: -5, 4: -5, 5: -1, 6: -6})
+    checks.check_update_geometry(engine, dims, FlowParams(equations=NSEquations), {1: -6, 2: -6, 3: -3, 4: -6, 5: -1, 6: -1},
+                                 stretch_k=2.0)

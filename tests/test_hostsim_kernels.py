@@ -191,3 +191,9 @@ def test_smoothers_sa_solve_mg_nk_with_bc(hostsim_engine):
                           bc_spec={1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
     checks.check_mg_cycle(e, BrickTopology(1, 1, 1, 8, 4, 4), rans, [0, 1, 0, -1], ncycles=1, bc_spec=wall, stretch_k=2.0)
     checks.check_nk_residual(e, BrickTopology(1, 1, 1, 6, 5, 4), FlowParams(equations=RANSEquations), bc_spec=wall, stretch_k=2.0)
+
+
+def test_update_geometry_after_mesh_warp(hostsim_engine):
+    checks.check_update_geometry(hostsim_engine, (7, 5, 4), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -5, 5: -1, 6: -6})
+    checks.check_update_geometry(hostsim_engine, (5, 4, 1), FlowParams(equations=NSEquations), {1: -6, 2: -6, 3: -3, 4: -6, 5: -1, 6: -1},
+                                 stretch_k=2.0)
