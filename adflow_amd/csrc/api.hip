@@ -130,6 +130,9 @@ void invalidate_comm_level(int level)
 
 int ensure_table(int level);
 int res_averaging_level(int level, const KParams& kp);
+int time_step_level(int level, const KParams& kp);
+struct LevelTab { const BlkView* tab; int n, nx, ny, nz; };
+int level_tab(int level, LevelTab* t);
 int ensure_tiles(int level);
 
 Block* find_block(int nn, int level, int sps)
@@ -652,12 +655,7 @@ int adflow_gpu_time_step(int level, int onlyRadii)
     if (need_ready()) return 1;
     KParams kp = make_kparams(level, 1.0, 0);
     kp.onlyRadii = onlyRadii;
-    int rc = for_level(level, [&](Block* b) {
-        launch_time_step(b->v, kp, g_stream);
-        b->ss_valid = true;
-        return 0;
-    });
-    if (rc) return rc;
+    if (time_step_level(level, kp)) return 1;
     return sync_and_check();
 }
 
@@ -688,22 +686,28 @@ static int enqueue_flow_residual(int level, const KParams& kp)
         launch_euler_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
         return 0;
     }
-    return for_level(level, [&](Block* b) {
+    if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
+        return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
+    int rc = for_level(level, [&](Block* b) {
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
-        if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
-            return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
         if (kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && !b->ss_valid && fabs(kp.rFil) >= 1.e-10) {
             launch_entropy(b->v, g_stream);
             b->ss_valid = true;
         }
-        launch_inviscid(b->v, kp, g_stream);
-        if (kp.viscous && fabs(kp.rFil) >= 1.e-10) {
-            if (!b->face_vectors_valid) {
-                launch_face_vectors(b->v, g_stream);
-                b->face_vectors_valid = true;
-            }
-            launch_viscous(b->v, kp, g_stream);
+        return 0;
+    });
+    if (rc) return rc;
+    // inviscid part: one launch for every block of the level (blocks are independent given their halos)
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_inviscid_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
+    return for_level(level, [&](Block* b) {
+        if (!b->face_vectors_valid) {
+            launch_face_vectors(b->v, g_stream);
+            b->face_vectors_valid = true;
         }
+        launch_viscous(b->v, kp, g_stream);
         return 0;
     });
 }
@@ -760,11 +764,7 @@ static int block_res_enqueue(int level, unsigned flags)
         if (g_comm.count(std::make_pair(level, 2)))
             if (halo_exchange_enqueue(level, lStart, lEnd, 1, 1, 2)) return 1;
     }
-    rc = for_level(level, [&](Block* b) {
-        launch_time_step(b->v, kp, g_stream);
-        b->ss_valid = true;
-        return 0;
-    });
+    rc = time_step_level(level, kp);
     if (rc) return rc;
     // blockResCore order: SA residual first, then the mean-flow fluxes (blockette.F90:806-851)
     if ((flags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
@@ -816,6 +816,25 @@ int ensure_table(int level)
     LevelDims ld = {0, 0, 0};
     for (auto& v : h) { ld.nx = std::max(ld.nx, v.nx); ld.ny = std::max(ld.ny, v.ny); ld.nz = std::max(ld.nz, v.nz); }
     g_tab_dims[level] = ld;
+    return 0;
+}
+
+// level-batched pointwise launches: device block table + the largest block extents of the level
+int level_tab(int level, LevelTab* t)
+{
+    if (ensure_table(level)) return 1;
+    const LevelDims& ld = g_tab_dims[level];
+    t->tab = g_tab[level]; t->n = g_tab_size[level]; t->nx = ld.nx; t->ny = ld.ny; t->nz = ld.nz;
+    return 0;
+}
+
+int time_step_level(int level, const KParams& kp)
+{
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_time_step_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    for (auto& kv : g_blocks)
+        if (std::get<0>(kv.first) == level) kv.second->ss_valid = true;
     return 0;
 }
 
@@ -1282,8 +1301,10 @@ int adflow_gpu_halo_exchange(int level, int varStart, int varEnd, int commPressu
 // boundary-condition hook, halo exchange (smoothers.F90:292-380, 600-691)
 static int finish_stage(int level, const KParams& kp, double scale, int fromWn)
 {
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_stage_update_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, scale, fromWn, g_stream);
     int rc = for_level(level, [&](Block* b) {
-        launch_stage_update(b->v, kp, scale, fromWn, g_stream);
         b->ss_valid = false;
         b->etot_consistent = true;
         return 0;
@@ -1312,18 +1333,15 @@ int adflow_gpu_rk_smooth(int level)
 {
     if (need_ready()) return 1;
     if (g_opts.smoother != ADFLOW_RUNGE_KUTTA) return fail("adflow_gpu_rk_smooth called with smoother=%d", g_opts.smoother);
-    int rc = for_level(level, [&](Block* b) { launch_rk_save(b->v, g_stream); return 0; });
-    if (rc) return rc;
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_rk_save_level(t.tab, t.n, t.nx, t.ny, t.nz, g_stream);
     const int nst = g_opts.nRKStages;
     for (int stage = 1; stage <= nst; ++stage) {
         KParams kp = make_kparams(level, 1.0, 1);
         const double scale = kp.cfl * g_opts.etaRK[stage - 1];
         if (smooth_residual(stage)) {
-            rc = for_level(level, [&](Block* b) {
-                launch_scale_dw(b->v, scale, 0, g_stream);
-                return 0;
-            });
-            if (rc) return rc;
+            launch_scale_dw_level(t.tab, t.n, t.nx, t.ny, t.nz, scale, 0, g_stream);
             if (res_averaging_level(level, kp)) return 1;
             if (finish_stage(level, kp, 0.0, 1)) return 1;
         } else {
@@ -1395,7 +1413,7 @@ static int transfer_to_coarse_enqueue(int level)
     // residual of the fine level with rkStage = 0 (multiGrid.F90:62-70)
     KParams kf = make_kparams(level, rFil, fwMode);
     kf.onlyRadii = 1;
-    int rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kf, g_stream); b->ss_valid = true; return 0; });
+    int rc = time_step_level(level, kf);
     if (rc) return rc;
     if (enqueue_flow_residual(level, kf)) return 1;
     // restriction + closures on the coarse level
@@ -1403,13 +1421,15 @@ static int transfer_to_coarse_enqueue(int level)
     rc = for_level_pairs(level, [&](Block* f, Block* c) {
         if (!c->v.mgIFine || !c->v.mgIWeight) return fail("coarse block has no mgIFine/mgIWeight maps");
         if (!c->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", cl);
-        launch_restrict(c->v, f->v, kc, g_stream);
-        launch_corner_row_halos(c->v, kc, g_stream);      // setCornerRowHalos(nwf) (multiGrid.F90:229)
         c->ss_valid = false;
         c->etot_consistent = true;
         return 0;
     });
     if (rc) return rc;
+    LevelTab tf, tc;
+    if (level_tab(level, &tf) || level_tab(cl, &tc)) return 1;
+    launch_restrict_level(tc.tab, tf.tab, tc.n, tc.nx, tc.ny, tc.nz, kc, g_stream);
+    launch_corner_row_halos_level(tc.tab, tc.n, kc, g_stream);      // setCornerRowHalos(nwf) (multiGrid.F90:229)
     // applyAllBC(.false.) ; whalo1 (multiGrid.F90:236-241)
     if (apply_bc_enqueue(cl, 0)) return 1;
     if (g_bc_callback) {
@@ -1419,33 +1439,33 @@ static int transfer_to_coarse_enqueue(int level)
     if (exchange_if_registered(cl, 1)) return 1;
     // time step, entry state, coarse residual from zero, forcing term (multiGrid.F90:246-320)
     kc.onlyRadii = 0;
-    rc = for_level(cl, [&](Block* b) {
-        launch_time_step(b->v, kc, g_stream);
-        b->ss_valid = true;
-        launch_store_entry_state(b->v, g_stream);
-        return 0;
-    });
+    rc = time_step_level(cl, kc);
     if (rc) return rc;
+    if (level_tab(cl, &tc)) return 1;       // BC registration may have rebuilt the table
+    launch_store_entry_state_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, g_stream);
     KParams kz = kc;
     kz.coarseInit = 0;
     if (enqueue_flow_residual(cl, kz)) return 1;
-    return for_level(cl, [&](Block* b) { launch_forcing(b->v, g_opts.fcoll, g_stream); return 0; });
+    launch_forcing_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, g_opts.fcoll, g_stream);
+    return 0;
 }
 
 static int transfer_to_fine_enqueue(int level)
 {
     KParams kf = make_kparams(level, 1.0, 0);
+    LevelTab tf, tc;
+    if (level_tab(level, &tf) || level_tab(level + 1, &tc)) return 1;
+    launch_corrections_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, g_stream);
     int rc = for_level_pairs(level, [&](Block* f, Block* c) {
         if (!f->v.mgICoarse) return fail("fine block has no mgICoarse map");
-        launch_corrections(c->v, g_stream);
         // setCorrectionsCoarseHalos (multiGrid.F90:472): fact = 0, mgBoundCorr = bcDirichlet0 (inputParamRoutines.F90:3923)
         if (!c->bc.empty()) launch_bc_coarse_corrections(c->v, c->bc.data(), (int)c->bc.size(), 0.0, g_stream);
-        launch_prolong_update(f->v, c->v, kf, g_stream);
         f->ss_valid = false;
         f->etot_consistent = true;
         return 0;
     });
     if (rc) return rc;
+    launch_prolong_update_level(tf.tab, tc.tab, tc.n, tf.nx, tf.ny, tf.nz, kf, g_stream);
     const int secondHalo = (level <= g_opts.groundLevel);
     if (apply_bc_enqueue(level, secondHalo)) return 1;
     if (g_bc_callback) {
@@ -1489,7 +1509,7 @@ int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
                 int fwMode;
                 const double rFil = rfil_stage0(&fwMode);
                 KParams kp = make_kparams(level, rFil, fwMode);
-                rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kp, g_stream); b->ss_valid = true; return 0; });
+                rc = time_step_level(level, kp);
                 if (!rc) rc = enqueue_flow_residual(level, kp);
             }
             if (!rc) rc = (g_opts.smoother == ADFLOW_RUNGE_KUTTA) ? adflow_gpu_rk_smooth(level) : adflow_gpu_dadi_smooth(level);
@@ -1513,7 +1533,7 @@ int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
         int fwMode;
         const double rFil = rfil_stage0(&fwMode);
         KParams kp = make_kparams(level, rFil, fwMode);
-        rc = for_level(level, [&](Block* b) { launch_time_step(b->v, kp, g_stream); b->ss_valid = true; return 0; });
+        rc = time_step_level(level, kp);
         if (!rc) rc = enqueue_flow_residual(level, kp);
     }
     g_async = was_async;

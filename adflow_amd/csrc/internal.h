@@ -130,18 +130,19 @@ struct KParams {
 };
 
 // ---- kernel launchers (one translation unit per kernel family) -------------
-void launch_time_step(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_time_step_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_entropy(const BlkView& b, hipStream_t s);
-void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_inviscid_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_face_vectors(const BlkView& b, hipStream_t s);
 void launch_sa_residual(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_sa_solve(const BlkView& b, const KParams& kp, hipStream_t s);
-void launch_rk_save(const BlkView& b, hipStream_t s);
+void launch_rk_save_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s);
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s);
-void launch_scale_dw(const BlkView& b, double factor, int timesVol, hipStream_t s);
-void launch_stage_update(const BlkView& b, const KParams& kp, double scale, int fromWn, hipStream_t s);
+void launch_scale_dw_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double factor, int timesVol, hipStream_t s);
+void launch_stage_update_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, double scale,
+                               int fromWn, hipStream_t s);
 void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_dadi(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_halo_copy(const BlkView* tab, const int* donorBlk, const long* donorOff, const int* haloBlk, const long* haloOff,
@@ -151,18 +152,19 @@ void launch_halo_unpack(const BlkView* tab, const int* blk, const long* off, int
                         hipStream_t s);
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
-void launch_restrict(const BlkView& c, const BlkView& f, const KParams& kp, hipStream_t s);
-void launch_store_entry_state(const BlkView& c, hipStream_t s);
-void launch_forcing(const BlkView& c, double fcoll, hipStream_t s);
-void launch_corrections(const BlkView& c, hipStream_t s);
-void launch_prolong_update(const BlkView& f, const BlkView& c, const KParams& kp, hipStream_t s);
+void launch_restrict_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void launch_store_entry_state_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, hipStream_t s);
+void launch_forcing_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, double fcoll, hipStream_t s);
+void launch_corrections_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, hipStream_t s);
+void launch_prolong_update_level(const BlkView* ftab, const BlkView* ctab, int nslots, int nx, int ny, int nz, const KParams& kp,
+                                 hipStream_t s);
 void launch_set_w(const BlkView& b, const double* vec, double turbFloor, hipStream_t s);
 void launch_get_r(const BlkView& b, double* vec, double turbScale, double* sums, hipStream_t s);
 void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);
 void launch_turb_bc_treatment(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, hipStream_t s);
 void launch_apply_turb_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, int second, hipStream_t s);
-void launch_corner_row_halos(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_corner_row_halos_level(const BlkView* tab, int nslots, const KParams& kp, hipStream_t s);
 void launch_bc_coarse_corrections(const BlkView& b, const BcFaceDev* faces, int nBocos, double fact, hipStream_t s);
 void launch_volume_metric(const BlkView& b, int rightHanded, hipStream_t s);
 void launch_boundary_normals(const BlkView& b, const BcFaceDev* faces, int nBocos, hipStream_t s);

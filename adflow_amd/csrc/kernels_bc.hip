@@ -408,8 +408,10 @@ __device__ __forceinline__ void crh_copy(const BlkView& b, const KParams& kp, lo
     if (kp.eddyModel) b.rev[dst] = b.rev[src];
 }
 
-__global__ __launch_bounds__(256) void k_corner_row_halos(BlkView b, KParams kp)
+__global__ __launch_bounds__(256) void k_corner_row_halos(const BlkView* __restrict__ tab, KParams kp)
 {
+    const BlkView& b = tab[blockIdx.x + 1];     // one workgroup per block of the level
+    if (b.nx == 0) return;
     const int t = threadIdx.x, nt = blockDim.x;
     const int il = b.il, jl = b.jl, kl = b.kl, ie = b.ie, je = b.je, ke = b.ke;
     const int J4[4] = {2, (3 < jl) ? 3 : jl, jl, (2 > b.ny) ? 2 : b.ny};
@@ -440,9 +442,10 @@ __global__ __launch_bounds__(256) void k_corner_row_halos(BlkView b, KParams kp)
         for (int q = 0; q < 4; ++q) { crh_copy(b, kp, b.idx(i, J4[q], 1), b.idx(i, J4[q], 2)); crh_copy(b, kp, b.idx(i, J4[q], ke), b.idx(i, J4[q], kl)); }
 }
 
-void launch_corner_row_halos(const BlkView& b, const KParams& kp, hipStream_t s)
+void launch_corner_row_halos_level(const BlkView* tab, int nslots, const KParams& kp, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_corner_row_halos, dim3(1), dim3(256), 0, s, b, kp);
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_corner_row_halos, dim3(nslots), dim3(256), 0, s, tab, kp);
 }
 
 // corrections live in scratch(:,:,:,0:4) = d(rho), d(u), d(v), d(w), d(p) of the coarse block (kernels_mg.hip)

@@ -343,12 +343,14 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
 // FINAL: dw = (init + central + fw) * iblank written; otherwise dw = init + central
 // and fw stored for the viscous kernel to complete.
 template <int SCHEME, bool VISC, bool FINAL>
-__global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid(BlkView b, KParams kp)
+__global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
+    // level-batched: blockIdx.z = block slot * nzb + plane
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * IV_BX + threadIdx.x + 2;
     const int j = blockIdx.y * IV_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > b.il || j > b.jl) return;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
     const long c = b.idx(i, j, k);
     const long nb = b.nbox;
 
@@ -393,29 +395,30 @@ __global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid(BlkView b, KParams kp
 }
 
 template <int SCHEME>
-static void launch_scheme(const BlkView& b, const KParams& kp, dim3 grd, dim3 blk, hipStream_t s)
+static void launch_scheme(const BlkView* b, int nzb, const KParams& kp, dim3 grd, dim3 blk, hipStream_t s)
 {
     // the viscous kernel completes the sum unless rFil == 0 (viscousFlux returns
     // early, fluxes.F90:2585: the stored fw already holds the viscous part)
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
     if (kp.viscous) {
         if (doDiss)
-            hipLaunchKernelGGL((k_inviscid<SCHEME, true, false>), grd, blk, 0, s, b, kp);
+            hipLaunchKernelGGL((k_inviscid<SCHEME, true, false>), grd, blk, 0, s, b, nzb, kp);
         else
-            hipLaunchKernelGGL((k_inviscid<SCHEME, true, true>), grd, blk, 0, s, b, kp);
+            hipLaunchKernelGGL((k_inviscid<SCHEME, true, true>), grd, blk, 0, s, b, nzb, kp);
     } else {
-        hipLaunchKernelGGL((k_inviscid<SCHEME, false, true>), grd, blk, 0, s, b, kp);
+        hipLaunchKernelGGL((k_inviscid<SCHEME, false, true>), grd, blk, 0, s, b, nzb, kp);
     }
 }
 
-void launch_inviscid(const BlkView& b, const KParams& kp, hipStream_t s)
+void launch_inviscid_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
 {
+    if (nslots <= 0) return;
     dim3 blk(IV_BX, IV_BY, 1);
-    dim3 grd((b.nx + IV_BX - 1) / IV_BX, (b.ny + IV_BY - 1) / IV_BY, b.nz);
+    dim3 grd((maxnx + IV_BX - 1) / IV_BX, (maxny + IV_BY - 1) / IV_BY, maxnz * nslots);
     switch (kp.spaceDiscr) {
-    case ADFLOW_DISS_SCALAR: launch_scheme<ADFLOW_DISS_SCALAR>(b, kp, grd, blk, s); break;
-    case ADFLOW_DISS_MATRIX: launch_scheme<ADFLOW_DISS_MATRIX>(b, kp, grd, blk, s); break;
-    case ADFLOW_UPWIND: launch_scheme<ADFLOW_UPWIND>(b, kp, grd, blk, s); break;
+    case ADFLOW_DISS_SCALAR: launch_scheme<ADFLOW_DISS_SCALAR>(tab, maxnz, kp, grd, blk, s); break;
+    case ADFLOW_DISS_MATRIX: launch_scheme<ADFLOW_DISS_MATRIX>(tab, maxnz, kp, grd, blk, s); break;
+    case ADFLOW_UPWIND: launch_scheme<ADFLOW_UPWIND>(tab, maxnz, kp, grd, blk, s); break;
     }
 }
 

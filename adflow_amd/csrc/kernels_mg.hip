@@ -16,12 +16,14 @@
 // coarse owned cells: wr = weighted sum of the 8 fine residuals; w, p, rev =
 // volume-weighted averages; then Etot and the laminar viscosity of the coarse
 // state (multiGrid.F90:92-226).  rev keeps the restricted value on coarse levels.
-__global__ __launch_bounds__(MG_BX* MG_BY) void k_restrict(BlkView c, BlkView f, KParams kp)
+__global__ __launch_bounds__(MG_BX* MG_BY) void k_restrict(const BlkView* __restrict__ ctab, const BlkView* __restrict__ ftab, int nzb, KParams kp)
 {
+    const BlkView& c = ctab[blockIdx.z / nzb + 1];
+    const BlkView& f = ftab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * MG_BX + threadIdx.x + 2;
     const int j = blockIdx.y * MG_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > c.il || j > c.jl) return;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > c.il || j > c.jl || k > c.kl) return;
     const long cc = c.idx(i, j, k);
     const int ii = c.mgIFine[2 * i], ii1 = c.mgIFine[2 * i + 1];
     const int jj = c.mgJFine[2 * j], jj1 = c.mgJFine[2 * j + 1];
@@ -73,12 +75,13 @@ __global__ __launch_bounds__(MG_BX* MG_BY) void k_restrict(BlkView c, BlkView f,
 }
 
 // cells 1..ie: w1 = w, p1 = p  (multiGrid.F90:258-276)
-__global__ __launch_bounds__(MG_BX* MG_BY) void k_store_entry_state(BlkView c)
+__global__ __launch_bounds__(MG_BX* MG_BY) void k_store_entry_state(const BlkView* __restrict__ ctab, int nzb)
 {
+    const BlkView& c = ctab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * MG_BX + threadIdx.x + (2 - 16);
     const int j = blockIdx.y * MG_BY + threadIdx.y + 1;
-    const int k = blockIdx.z + 1;
-    if (i < 1 || i > c.ie || j > c.je) return;
+    const int k = blockIdx.z % nzb + 1;
+    if (c.nx == 0 || i < 1 || i > c.ie || j > c.je || k > c.ke) return;
     const long cc = c.idx(i, j, k);
 #pragma unroll
     for (int l = 0; l < 5; ++l) c.w1[cc + l * c.nbox] = c.w[cc + l * c.nbox];
@@ -86,12 +89,13 @@ __global__ __launch_bounds__(MG_BX* MG_BY) void k_store_entry_state(BlkView c)
 }
 
 // forcing term: tmp = fcoll*wr ; wr = tmp - dw ; dw = tmp  (multiGrid.F90:302-320)
-__global__ __launch_bounds__(MG_BX* MG_BY) void k_forcing(BlkView c, double fcoll)
+__global__ __launch_bounds__(MG_BX* MG_BY) void k_forcing(const BlkView* __restrict__ ctab, int nzb, double fcoll)
 {
+    const BlkView& c = ctab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * MG_BX + threadIdx.x + 2;
     const int j = blockIdx.y * MG_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > c.il || j > c.jl) return;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > c.il || j > c.jl || k > c.kl) return;
     const long cc = c.idx(i, j, k);
 #pragma unroll
     for (int l = 0; l < 5; ++l) {
@@ -103,12 +107,13 @@ __global__ __launch_bounds__(MG_BX* MG_BY) void k_forcing(BlkView c, double fcol
 
 // corrections on the coarse block, cells 1..ie, into scratch(0:4):
 // (rho,u,v,w) - w1 and p - p1  (multiGrid.F90:392-404; the reference overwrites w)
-__global__ __launch_bounds__(MG_BX* MG_BY) void k_corrections(BlkView c)
+__global__ __launch_bounds__(MG_BX* MG_BY) void k_corrections(const BlkView* __restrict__ ctab, int nzb)
 {
+    const BlkView& c = ctab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * MG_BX + threadIdx.x + (2 - 16);
     const int j = blockIdx.y * MG_BY + threadIdx.y + 1;
-    const int k = blockIdx.z + 1;
-    if (i < 1 || i > c.ie || j > c.je) return;
+    const int k = blockIdx.z % nzb + 1;
+    if (c.nx == 0 || i < 1 || i > c.ie || j > c.je || k > c.ke) return;
     const long cc = c.idx(i, j, k);
 #pragma unroll
     for (int l = 0; l < 4; ++l) c.scratch[cc + l * c.nbox] = c.w[cc + l * c.nbox] - c.w1[cc + l * c.nbox];
@@ -117,12 +122,14 @@ __global__ __launch_bounds__(MG_BX* MG_BY) void k_corrections(BlkView c)
 
 // fine owned cells: trilinear (27,9,3,1)/64 interpolation of the coarse corrections,
 // state update with clipping, Etot, viscosities (multiGrid.F90:481-575)
-__global__ __launch_bounds__(MG_BX* MG_BY) void k_prolong_update(BlkView f, BlkView c, KParams kp)
+__global__ __launch_bounds__(MG_BX* MG_BY) void k_prolong_update(const BlkView* __restrict__ ftab, const BlkView* __restrict__ ctab, int nzb, KParams kp)
 {
+    const BlkView& f = ftab[blockIdx.z / nzb + 1];
+    const BlkView& c = ctab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * MG_BX + threadIdx.x + 2;
     const int j = blockIdx.y * MG_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > f.il || j > f.jl) return;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > f.il || j > f.jl || k > f.kl) return;
     const long cf = f.idx(i, j, k);
     const int ii = f.mgICoarse[2 * i], ii1 = f.mgICoarse[2 * i + 1];
     const int jj = f.mgJCoarse[2 * j], jj1 = f.mgJCoarse[2 * j + 1];
@@ -163,37 +170,43 @@ __global__ __launch_bounds__(MG_BX* MG_BY) void k_prolong_update(BlkView f, BlkV
     }
 }
 
-void launch_restrict(const BlkView& c, const BlkView& f, const KParams& kp, hipStream_t s)
+// Level-batched launchers: one launch covers every block (pair) of the level, blockIdx.z = slot * nzb + plane;
+// nx, ny, nz = the largest extents of the blocks the grid runs over (coarse blocks unless stated otherwise).
+void launch_restrict_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
-    dim3 blk(MG_BX, MG_BY, 1);
-    dim3 grd((c.nx + MG_BX - 1) / MG_BX, (c.ny + MG_BY - 1) / MG_BY, c.nz);
-    hipLaunchKernelGGL(k_restrict, grd, blk, 0, s, c, f, kp);
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_restrict, dim3((nx + MG_BX - 1) / MG_BX, (ny + MG_BY - 1) / MG_BY, nz * nslots), dim3(MG_BX, MG_BY, 1), 0, s,
+                       ctab, ftab, nz, kp);
 }
 
-void launch_store_entry_state(const BlkView& c, hipStream_t s)
+void launch_store_entry_state_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, hipStream_t s)
 {
-    dim3 blk(MG_BX, MG_BY, 1);
-    dim3 grd((c.ie + 15 + MG_BX - 1) / MG_BX, (c.je + MG_BY - 1) / MG_BY, c.ke);
-    hipLaunchKernelGGL(k_store_entry_state, grd, blk, 0, s, c);
+    if (nslots <= 0) return;
+    const int nzb = nz + 2;
+    hipLaunchKernelGGL(k_store_entry_state, dim3((nx + 2 + 15 + MG_BX - 1) / MG_BX, (ny + 2 + MG_BY - 1) / MG_BY, nzb * nslots),
+                       dim3(MG_BX, MG_BY, 1), 0, s, ctab, nzb);
 }
 
-void launch_forcing(const BlkView& c, double fcoll, hipStream_t s)
+void launch_forcing_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, double fcoll, hipStream_t s)
 {
-    dim3 blk(MG_BX, MG_BY, 1);
-    dim3 grd((c.nx + MG_BX - 1) / MG_BX, (c.ny + MG_BY - 1) / MG_BY, c.nz);
-    hipLaunchKernelGGL(k_forcing, grd, blk, 0, s, c, fcoll);
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_forcing, dim3((nx + MG_BX - 1) / MG_BX, (ny + MG_BY - 1) / MG_BY, nz * nslots), dim3(MG_BX, MG_BY, 1), 0, s,
+                       ctab, nz, fcoll);
 }
 
-void launch_corrections(const BlkView& c, hipStream_t s)
+void launch_corrections_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, hipStream_t s)
 {
-    dim3 blk(MG_BX, MG_BY, 1);
-    dim3 grd((c.ie + 15 + MG_BX - 1) / MG_BX, (c.je + MG_BY - 1) / MG_BY, c.ke);
-    hipLaunchKernelGGL(k_corrections, grd, blk, 0, s, c);
+    if (nslots <= 0) return;
+    const int nzb = nz + 2;
+    hipLaunchKernelGGL(k_corrections, dim3((nx + 2 + 15 + MG_BX - 1) / MG_BX, (ny + 2 + MG_BY - 1) / MG_BY, nzb * nslots),
+                       dim3(MG_BX, MG_BY, 1), 0, s, ctab, nzb);
 }
 
-void launch_prolong_update(const BlkView& f, const BlkView& c, const KParams& kp, hipStream_t s)
+// nx, ny, nz: largest FINE block
+void launch_prolong_update_level(const BlkView* ftab, const BlkView* ctab, int nslots, int nx, int ny, int nz, const KParams& kp,
+                                 hipStream_t s)
 {
-    dim3 blk(MG_BX, MG_BY, 1);
-    dim3 grd((f.nx + MG_BX - 1) / MG_BX, (f.ny + MG_BY - 1) / MG_BY, f.nz);
-    hipLaunchKernelGGL(k_prolong_update, grd, blk, 0, s, f, c, kp);
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_prolong_update, dim3((nx + MG_BX - 1) / MG_BX, (ny + MG_BY - 1) / MG_BY, nz * nslots), dim3(MG_BX, MG_BY, 1), 0,
+                       s, ftab, ctab, nz, kp);
 }

@@ -20,23 +20,29 @@
 #define SM_BX 64
 #define SM_BY 4
 
-__global__ __launch_bounds__(SM_BX* SM_BY) void k_rk_save(BlkView b)
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_rk_save(const BlkView* __restrict__ tab, int nzb)
 {
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
     const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > b.il || j > b.jl) return;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
     const long c = b.idx(i, j, k);
 #pragma unroll
     for (int l = 0; l < 5; ++l) b.wn[c + l * b.nbox] = b.w[c + l * b.nbox];
     b.pn[c] = b.p[c];
 }
 
-void launch_rk_save(const BlkView& b, hipStream_t s)
+static dim3 level_grid(int nslots, int maxnx, int maxny, int maxnz)
 {
-    dim3 blk(SM_BX, SM_BY, 1);
-    dim3 grd((b.nx + SM_BX - 1) / SM_BX, (b.ny + SM_BY - 1) / SM_BY, b.nz);
-    hipLaunchKernelGGL(k_rk_save, grd, blk, 0, s, b);
+    return dim3((maxnx + SM_BX - 1) / SM_BX, (maxny + SM_BY - 1) / SM_BY, maxnz * nslots);
+}
+
+// the pointwise smoother kernels cover every block of a level in one launch (blockIdx.z = slot * maxnz + plane)
+void launch_rk_save_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_rk_save, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz);
 }
 
 // computeEtotBlock on the owned cells (flowUtils.F90:551-672, cpConstant): the
@@ -62,12 +68,13 @@ void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s)
 }
 
 // dw *= factor * dtl  [* vol]  (smoothers.F90:196-218 RK, :514-532 DADI)
-__global__ __launch_bounds__(SM_BX* SM_BY) void k_scale_dw(BlkView b, double factor, int timesVol)
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_scale_dw(const BlkView* __restrict__ tab, int nzb, double factor, int timesVol)
 {
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
     const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > b.il || j > b.jl) return;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
     const long c = b.idx(i, j, k);
     double dt = factor * b.dtl[c];
     if (timesVol) dt *= b.vol[c];
@@ -75,23 +82,23 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_scale_dw(BlkView b, double fac
     for (int l = 0; l < 5; ++l) b.dw[c + l * b.nbox] *= dt;
 }
 
-void launch_scale_dw(const BlkView& b, double factor, int timesVol, hipStream_t s)
+void launch_scale_dw_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double factor, int timesVol, hipStream_t s)
 {
-    dim3 blk(SM_BX, SM_BY, 1);
-    dim3 grd((b.nx + SM_BX - 1) / SM_BX, (b.ny + SM_BY - 1) / SM_BY, b.nz);
-    hipLaunchKernelGGL(k_scale_dw, grd, blk, 0, s, b, factor, timesVol);
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_scale_dw, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, factor, timesVol);
 }
 
 // State update of one stage.  FROM_WN: Runge-Kutta (new = stage-0 state - dw),
 // otherwise D-ADI (new = current - dw).  scale != 0: dw is first multiplied by
 // scale*dtl (fused k_scale_dw when no residual averaging sits in between).
 template <bool FROM_WN>
-__global__ __launch_bounds__(SM_BX* SM_BY) void k_stage_update(BlkView b, KParams kp, double scale)
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_stage_update(const BlkView* __restrict__ tab, int nzb, KParams kp, double scale)
 {
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
     const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > b.il || j > b.jl) return;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
     const long c = b.idx(i, j, k);
     const long nb = b.nbox;
     double d[5];
@@ -147,14 +154,15 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_stage_update(BlkView b, KParam
     }
 }
 
-void launch_stage_update(const BlkView& b, const KParams& kp, double scale, int fromWn, hipStream_t s)
+void launch_stage_update_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, double scale,
+                               int fromWn, hipStream_t s)
 {
-    dim3 blk(SM_BX, SM_BY, 1);
-    dim3 grd((b.nx + SM_BX - 1) / SM_BX, (b.ny + SM_BY - 1) / SM_BY, b.nz);
+    if (nslots <= 0) return;
+    const dim3 grd = level_grid(nslots, maxnx, maxny, maxnz), blk(SM_BX, SM_BY, 1);
     if (fromWn)
-        hipLaunchKernelGGL((k_stage_update<true>), grd, blk, 0, s, b, kp, scale);
+        hipLaunchKernelGGL((k_stage_update<true>), grd, blk, 0, s, tab, maxnz, kp, scale);
     else
-        hipLaunchKernelGGL((k_stage_update<false>), grd, blk, 0, s, b, kp, scale);
+        hipLaunchKernelGGL((k_stage_update<false>), grd, blk, 0, s, tab, maxnz, kp, scale);
 }
 
 // ---------------------------------------------------------------------------

@@ -10,13 +10,17 @@
 #define TS_BY 4
 
 template <bool VISC, bool SCALING>
-__global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(BlkView b, KParams kp)
+__global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
+    // level-batched: blockIdx.z = (block slot, plane); slots the level does not use hold an all-zero view
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    if (b.nx == 0) return;
     // lane 0 of the first block sits at i = 2-16 so that every wavefront load
     // starts on a 128-byte line (see internal.h)
     const int i = blockIdx.x * TS_BX + threadIdx.x + (2 - 16);
     const int j = blockIdx.y * TS_BY + threadIdx.y;
-    const int k = blockIdx.z;
+    const int k = blockIdx.z % nzb;
+    if (k > b.kb) return;
     if (i < 0 || i > b.ib || j > b.jb) return;
     const long c = b.idx(i, j, k);
     const long nb = b.nbox;
@@ -126,19 +130,21 @@ void launch_entropy(const BlkView& b, hipStream_t s)
     hipLaunchKernelGGL(k_entropy, grd, blk, 0, s, b);
 }
 
-void launch_time_step(const BlkView& b, const KParams& kp, hipStream_t s)
+void launch_time_step_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
 {
+    if (nslots <= 0) return;
     dim3 blk(TS_BX, TS_BY, 1);
-    dim3 grd((b.ib + 1 + 14 + TS_BX - 1) / TS_BX, (b.jb + 1 + TS_BY - 1) / TS_BY, b.kb + 1);
+    const int nzb = maxnz + 4;
+    dim3 grd((maxnx + 4 + 14 + TS_BX - 1) / TS_BX, (maxny + 4 + TS_BY - 1) / TS_BY, nzb * nslots);
     if (kp.viscous) {
         if (kp.doScaling)
-            hipLaunchKernelGGL((k_time_step<true, true>), grd, blk, 0, s, b, kp);
+            hipLaunchKernelGGL((k_time_step<true, true>), grd, blk, 0, s, tab, nzb, kp);
         else
-            hipLaunchKernelGGL((k_time_step<true, false>), grd, blk, 0, s, b, kp);
+            hipLaunchKernelGGL((k_time_step<true, false>), grd, blk, 0, s, tab, nzb, kp);
     } else {
         if (kp.doScaling)
-            hipLaunchKernelGGL((k_time_step<false, true>), grd, blk, 0, s, b, kp);
+            hipLaunchKernelGGL((k_time_step<false, true>), grd, blk, 0, s, tab, nzb, kp);
         else
-            hipLaunchKernelGGL((k_time_step<false, false>), grd, blk, 0, s, b, kp);
+            hipLaunchKernelGGL((k_time_step<false, false>), grd, blk, 0, s, tab, nzb, kp);
     }
 }

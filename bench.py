@@ -31,6 +31,9 @@ WORKLOADS = {
     "rans_sa_jst_8x128x128x96": dict(equations=3, spaceDiscr=1, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
     "rans_sa_upwind_8x128x128x96": dict(equations=3, spaceDiscr=9, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
     "rans_sa_matrix_8x128x128x96": dict(equations=3, spaceDiscr=2, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
+    # same cell count as the headline, cut into 512 blocks of 32^3 (what a production multiblock mesh looks like per GPU):
+    # measures how much of the rate survives small blocks (level-batched launches)
+    "euler_jst_512x32": dict(equations=1, spaceDiscr=1, nblocks=512, dims=(32, 32, 32), bytes_per_cell=175.0),
 }
 
 
@@ -130,9 +133,10 @@ def main():
     # blocketteRes performs (whalo2, blockette.F90:246): same-GPU copies + RCCL p2p
     from adflow_amd.topology import BrickTopology
     nb = wl["nblocks"]
-    assert nb == 8
     dims = wl["dims"]
-    topo = BrickTopology(2 * world, 2, 2, *dims, owner=lambda g: (g % (2 * world)) // 2)
+    e = round(nb ** (1.0 / 3.0))                 # per-GPU brick of e x e x e blocks
+    assert e ** 3 == nb
+    topo = BrickTopology(e * world, e, e, *dims, owner=lambda g: (g % (e * world)) // e)
     lid = topo.local_ids()
     cells_local = 0
     from adflow_amd.synth import make_coarse_block
@@ -225,7 +229,7 @@ def main():
             from adflow_amd.params import RungeKutta, alternateResAveraging
             # pyADflow defaults (pyADflow.py:5697-5731): RK smoother, "alternate" residual averaging
             eng.set_options(prm.replace(smoother=RungeKutta, resAveraging=alternateResAveraging))
-            ctopo = BrickTopology(2 * world, 2, 2, dims[0] // 2, dims[1] // 2, dims[2] // 2, owner=topo.owner)
+            ctopo = BrickTopology(e * world, e, e, dims[0] // 2, dims[1] // 2, dims[2] // 2, owner=topo.owner)
             if do_halo:
                 eng.comm_register(1, 2, cp)
                 eng.comm_register(2, 1, ctopo.patterns(1, only_rank=rank)[rank])
