@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_viscous_tiled;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_viscous_tiled, g_lines_i_tiled;
 
 namespace {
 
@@ -770,10 +770,12 @@ static int block_res_enqueue(int level, unsigned flags)
     if ((flags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
         rc = for_level(level, [&](Block* b) {
             if (b->v.nw < 6) return fail("RANS/SA needs nw = 6 (block has %d)", b->v.nw);
-            launch_sa_residual(b->v, kp, g_stream);
             return 0;
         });
         if (rc) return rc;
+        LevelTab t;
+        if (level_tab(level, &t)) return 1;
+        launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
     if (flags & ADFLOW_RES_FLOW) {
         rc = enqueue_flow_residual(level, kp);
@@ -1363,11 +1365,9 @@ int adflow_gpu_dadi_smooth(int level)
     const int nsub = (g_opts.groundLevel == 1) ? std::max(1, (int)g_opts.nSubiterations) : 1;
     for (int it = 1; it <= nsub; ++it) {
         KParams kp = make_kparams(level, 1.0, 0);
-        int rc = for_level(level, [&](Block* b) {
-            launch_dadi(b->v, kp, g_stream);
-            return 0;
-        });
-        if (rc) return rc;
+        LevelTab t;
+        if (level_tab(level, &t)) return 1;
+        launch_dadi_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
         if (smooth_residual(0) && res_averaging_level(level, kp)) return 1;   // rkStage stays 0 under DADI
         if (finish_stage(level, kp, 0.0, 0)) return 1;
         if (it < nsub) {
@@ -1671,11 +1671,17 @@ int adflow_gpu_sa_solve(int level)
     const int nit = std::max(1, (int)g_opts.nSubIterTurb);
     for (int it = 0; it < nit; ++it) {
         KParams kp = make_kparams(level, 1.0, 0);
+        // sa_block(.false.) of every block: bcTurbTreatment first, applyAllTurbBCThisBlock(.true.) last (sa.F90:40-84)
         int rc = for_level(level, [&](Block* b) {
             if (b->v.nw < 6) return fail("RANS/SA needs nw = 6 (block has %d)", b->v.nw);
-            // sa_block(.false.): bcTurbTreatment first, applyAllTurbBCThisBlock(.true.) last (sa.F90:40-84)
             if (!b->bc.empty()) launch_turb_bc_treatment(b->v, b->bc.data(), (int)b->bc.size(), kp, g_stream);
-            launch_sa_solve(b->v, kp, g_stream);
+            return 0;
+        });
+        if (rc) return rc;
+        LevelTab t;
+        if (level_tab(level, &t)) return 1;
+        launch_sa_solve_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        rc = for_level(level, [&](Block* b) {
             if (!b->bc.empty()) launch_apply_turb_bc(b->v, b->bc.data(), (int)b->bc.size(), kp, 1, g_stream);
             return 0;
         });
@@ -1750,6 +1756,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "march_minw")) { g_march_minw = value; return 0; }
     if (!strcmp(key, "march_pipe")) { g_march_pipe = value; return 0; }
     if (!strcmp(key, "viscous_tiled")) { g_viscous_tiled = value; return 0; }
+    if (!strcmp(key, "lines_i_tiled")) { g_lines_i_tiled = value; return 0; }
     if (!strcmp(key, "march_kch")) {
         if (value < 4) return fail("march_kch must be >= 4");
         g_march_kch = value;

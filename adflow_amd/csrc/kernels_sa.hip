@@ -98,12 +98,13 @@ __device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double
 // SOLVE: additionally store the right-hand side (scratch 0) and the central
 // jacobian qq (scratch 1) for the DDADI line solves of saSolve
 template <bool SOLVE>
-__global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(BlkView b, KParams kp)
+__global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
+    const BlkView& b = tab[blockIdx.z / nzb + 1];     // level-batched: blockIdx.z = slot * nzb + plane
     const int i = blockIdx.x * SA_BX + threadIdx.x + 2;
     const int j = blockIdx.y * SA_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > b.il || j > b.jl) return;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
     const long c = b.idx(i, j, k);
     const long nb = b.nbox;
     const long si = 1, sj = b.ldi, sk = b.ldk;
@@ -225,17 +226,18 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(BlkView b, KParams
 // the line towards index 2, then forward substitution.  scratch: 0 rhs/solution, 1 qq,
 // 2 modified cc, 3 bb.  LAST: the k sweep, followed by the update of nuTilde and rev.
 template <int DIR>
-__global__ __launch_bounds__(64) void k_sa_sweep(BlkView b, KParams kp)
+__global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab, KParams kp, int slot0)
 {
+    const BlkView& b = tab[slot0 + blockIdx.z + 1];
     const int a = blockIdx.x * 64 + threadIdx.x + 2;
     const int bbi = blockIdx.y + 2;
-    int n, amax;
+    int n, amax, bmax;
     long c0, s;
     const double* sN;
-    if (DIR == 0) { amax = b.jl; n = b.nx; c0 = b.idx(2, a, bbi); s = 1; sN = b.sI; }
-    else if (DIR == 1) { amax = b.il; n = b.ny; c0 = b.idx(a, 2, bbi); s = b.ldi; sN = b.sJ; }
-    else { amax = b.il; n = b.nz; c0 = b.idx(a, bbi, 2); s = b.ldk; sN = b.sK; }
-    if (a > amax) return;
+    if (DIR == 0) { amax = b.jl; bmax = b.kl; n = b.nx; c0 = b.idx(2, a, bbi); s = 1; sN = b.sI; }
+    else if (DIR == 1) { amax = b.il; bmax = b.kl; n = b.ny; c0 = b.idx(a, 2, bbi); s = b.ldi; sN = b.sJ; }
+    else { amax = b.il; bmax = b.jl; n = b.nz; c0 = b.idx(a, bbi, 2); s = b.ldk; sN = b.sK; }
+    if (b.nx == 0 || a > amax || bbi > bmax) return;
     const long nb = b.nbox;
     const double cb3Inv = 1.0 / kp.sa_cb3;
     double* rhs = b.scratch;
@@ -295,21 +297,153 @@ __global__ __launch_bounds__(64) void k_sa_sweep(BlkView b, KParams kp)
     }
 }
 
-void launch_sa_solve(const BlkView& b, const KParams& kp, hipStream_t s)
+// ---------------------------------------------------------------------------
+// i-direction sweep of saSolve in coalesced pieces (same arithmetic as k_sa_sweep<0>; see the
+// D-ADI counterpart in kernels_smooth.hip):
+//   k_sa_rows_i   pointwise, lanes over i: bb (scratch 3), dd (scratch 4), ff = rhs * rblank (scratch 0)
+//   k_sa_solve_i  one thread per line: elimination from the end of the line, forward substitution,
+//                 rhs of the next direction = solution * qq; 64-line x 16-cell LDS tiles
+// ---------------------------------------------------------------------------
+#define SI_CH 16
+#define SI_LD (SI_CH + 1)
+
+__device__ __forceinline__ void sa_tile_load(const BlkView& b, const double* __restrict__ arr, double* __restrict__ tile, int j0, int k,
+                                             int i0, int lane)
 {
-    dim3 blk(SA_BX, SA_BY, 1);
-    dim3 grd((b.nx + SA_BX - 1) / SA_BX, (b.ny + SA_BY - 1) / SA_BY, b.nz);
-    hipLaunchKernelGGL((k_sa_residual<true>), grd, blk, 0, s, b, kp);
-    dim3 l64(64, 1, 1);
-    // sweep order of the reference: j, i, k
-    hipLaunchKernelGGL((k_sa_sweep<1>), dim3((b.nx + 63) / 64, b.nz, 1), l64, 0, s, b, kp);
-    hipLaunchKernelGGL((k_sa_sweep<0>), dim3((b.ny + 63) / 64, b.nz, 1), l64, 0, s, b, kp);
-    hipLaunchKernelGGL((k_sa_sweep<2>), dim3((b.nx + 63) / 64, b.ny, 1), l64, 0, s, b, kp);
+    const int sub = lane >> 4, col = lane & 15, i = i0 + col;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = 4 * q + sub;
+        tile[r * SI_LD + col] = (j0 + r <= b.jl && i <= b.il) ? arr[b.idx(i, j0 + r, k)] : 1.0;
+    }
 }
 
-void launch_sa_residual(const BlkView& b, const KParams& kp, hipStream_t s)
+__device__ __forceinline__ void sa_tile_store(const BlkView& b, double* __restrict__ arr, const double* __restrict__ tile, int j0, int k,
+                                              int i0, int lane)
 {
+    const int sub = lane >> 4, col = lane & 15, i = i0 + col;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = 4 * q + sub;
+        if (j0 + r <= b.jl && i <= b.il) arr[b.idx(i, j0 + r, k)] = tile[r * SI_LD + col];
+    }
+}
+
+__global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_rows_i(const BlkView* __restrict__ tab, int nzb, KParams kp)
+{
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    const int i = blockIdx.x * SA_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SA_BY + threadIdx.y + 2;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
+    const long c = b.idx(i, j, k), nb = b.nbox;
+    const double cb3Inv = 1.0 / kp.sa_cb3;
+    SaDir d;
+    load_dir(b, c, 1, b.sI, d);
+    const double vol0 = b.vol[c];
+    const double nu = b.rlv[c] / b.w[c];
+    double c1m, c1p, uu;
+    (void)sa_diffuse(d, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p);
+    (void)sa_advect(d, vol0, b.w[c + nb], b.w[c + 2 * nb], b.w[c + 3 * nb], false, &uu);
+    const double rblank = flg_blank(b.flags[c]);
+    const double um = (uu < 0.0) ? uu : 0.0, up = (uu > 0.0) ? uu : 0.0;
+    b.scratch[c + 3 * nb] = (-c1m - up) * rblank;
+    b.scratch[c + 4 * nb] = (-c1p + um) * rblank;
+    b.scratch[c] = b.scratch[c] * rblank;
+}
+
+__global__ __launch_bounds__(64) void k_sa_solve_i(const BlkView* __restrict__ tab)
+{
+    __shared__ double tb[64 * SI_LD], tc[64 * SI_LD], td[64 * SI_LD], tf[64 * SI_LD];
+    const BlkView& b = tab[blockIdx.z + 1];
+    const int lane = threadIdx.x;
+    const int j0 = blockIdx.x * 64 + 2, k = blockIdx.y + 2;
+    const int n = b.nx;
+    if (b.nx == 0 || j0 > b.jl || k > b.kl) return;
+    const long nb = b.nbox;
+    double* __restrict__ rhs = b.scratch;
+    const double* __restrict__ qqA = b.scratch + nb;
+    double* __restrict__ ccA = b.scratch + 2 * nb;
+    const double* __restrict__ bbA = b.scratch + 3 * nb;
+    const double* __restrict__ ddA = b.scratch + 4 * nb;
+    const bool lineOk = (j0 + lane <= b.jl);
+    const int nch = (n + SI_CH - 1) / SI_CH;
+    // elimination from the end of the line: chunks right to left
+    double ccN = 1.0, bbN = 0.0, ffN = 0.0;
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        const int i0 = 2 + ch * SI_CH;
+        sa_tile_load(b, bbA, tb, j0, k, i0, lane); sa_tile_load(b, qqA, tc, j0, k, i0, lane);
+        sa_tile_load(b, ddA, td, j0, k, i0, lane); sa_tile_load(b, rhs, tf, j0, k, i0, lane);
+        __syncthreads();
+        if (lineOk) {
+            int mTop = n - 1 - ch * SI_CH;
+            if (mTop > SI_CH - 1) mTop = SI_CH - 1;
+            for (int m = mTop; m >= 0; --m) {
+                const int o = lane * SI_LD + m;
+                double cc = tc[o], ff = tf[o];
+                const double bb = tb[o];
+                if (ch * SI_CH + m < n - 1) {
+                    const double f = td[o] / ccN;
+                    cc = cc - f * bbN;
+                    ff = ff - f * ffN;
+                }
+                tc[o] = cc; tf[o] = ff;
+                ccN = cc; bbN = bb; ffN = ff;
+            }
+        }
+        __syncthreads();
+        sa_tile_store(b, ccA, tc, j0, k, i0, lane); sa_tile_store(b, rhs, tf, j0, k, i0, lane);
+        __syncthreads();
+    }
+    // forward substitution, then the right-hand side of the next direction
+    double fprev = 0.0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int i0 = 2 + ch * SI_CH;
+        sa_tile_load(b, bbA, tb, j0, k, i0, lane); sa_tile_load(b, ccA, tc, j0, k, i0, lane);
+        sa_tile_load(b, qqA, td, j0, k, i0, lane); sa_tile_load(b, rhs, tf, j0, k, i0, lane);
+        __syncthreads();
+        if (lineOk) {
+            const int mEnd = (n - ch * SI_CH < SI_CH) ? n - ch * SI_CH : SI_CH;
+            for (int m = 0; m < mEnd; ++m) {
+                const int o = lane * SI_LD + m;
+                double ff = tf[o];
+                if (ch * SI_CH + m > 0) ff = ff - tb[o] * fprev;
+                ff = ff / tc[o];
+                fprev = ff;
+                tf[o] = ff * td[o];
+            }
+        }
+        __syncthreads();
+        sa_tile_store(b, rhs, tf, j0, k, i0, lane);
+        __syncthreads();
+    }
+}
+
+extern int g_lines_i_tiled;
+
+void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
     dim3 blk(SA_BX, SA_BY, 1);
-    dim3 grd((b.nx + SA_BX - 1) / SA_BX, (b.ny + SA_BY - 1) / SA_BY, b.nz);
-    hipLaunchKernelGGL((k_sa_residual<false>), grd, blk, 0, s, b, kp);
+    dim3 grd((nx + SA_BX - 1) / SA_BX, (ny + SA_BY - 1) / SA_BY, nz * nslots);
+    hipLaunchKernelGGL((k_sa_residual<true>), grd, blk, 0, s, tab, nz, kp);
+    dim3 l64(64, 1, 1);
+    // sweep order of the reference: j, i, k
+    hipLaunchKernelGGL((k_sa_sweep<1>), dim3((nx + 63) / 64, nz, nslots), l64, 0, s, tab, kp, 0);
+    if (g_lines_i_tiled) {
+        hipLaunchKernelGGL(k_sa_rows_i, grd, blk, 0, s, tab, nz, kp);
+        hipLaunchKernelGGL(k_sa_solve_i, dim3((ny + 63) / 64, nz, nslots), l64, 0, s, tab);
+    } else {
+        // i lines one block at a time (uncoalesced, see launch_dadi_level)
+        for (int m = 0; m < nslots; ++m) hipLaunchKernelGGL((k_sa_sweep<0>), dim3((ny + 63) / 64, nz, 1), l64, 0, s, tab, kp, m);
+    }
+    hipLaunchKernelGGL((k_sa_sweep<2>), dim3((nx + 63) / 64, ny, nslots), l64, 0, s, tab, kp, 0);
+}
+
+void launch_sa_residual_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    dim3 blk(SA_BX, SA_BY, 1);
+    dim3 grd((nx + SA_BX - 1) / SA_BX, (ny + SA_BY - 1) / SA_BY, nz * nslots);
+    hipLaunchKernelGGL((k_sa_residual<false>), grd, blk, 0, s, tab, nz, kp);
 }

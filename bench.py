@@ -143,11 +143,11 @@ def main():
     for g in topo.blocks_of(rank):
         blk = make_block(*dims, prm, seed=20260925 + g, stretch_k=3.0 if wl["equations"] == 3 else 1.0)
         both = [blk]
-        if not a.no_mg:
+        if not a.no_mg and wl["equations"] != 3:     # RANS workloads time a single-grid iteration (config 3)
             cblk = make_coarse_block(blk, prm, seed=777 + g)   # also attaches mgI/J/KCoarse to blk
             both.append(cblk)
         eng.register(blk, nn=lid[g], level=1)
-        if not a.no_mg:
+        if len(both) > 1:
             eng.register(cblk, nn=lid[g], level=2)
         cells_local += blk.ncells
         log(f"block {lid[g]}/{nb} generated and uploaded")
@@ -226,15 +226,24 @@ def main():
     mg = None
     if not a.no_mg:
         try:
-            from adflow_amd.params import RungeKutta, alternateResAveraging
-            # pyADflow defaults (pyADflow.py:5697-5731): RK smoother, "alternate" residual averaging
-            eng.set_options(prm.replace(smoother=RungeKutta, resAveraging=alternateResAveraging))
+            from adflow_amd.params import RungeKutta, DADI, alternateResAveraging, noResAveraging
+            rans = wl["equations"] == 3
+            if rans:
+                # BASELINE config 3 (test_functionals.py:136-160): single grid, D-ADI with 3 sub-iterations,
+                # 3 SA DDADI sub-iterations, cfl 1.5, no residual averaging: one "cycle" = one solver iteration
+                eng.set_options(prm.replace(smoother=DADI, nSubiterations=3, nSubIterTurb=3, cfl=1.5, resAveraging=noResAveraging))
+                cyc_desc = "single grid: D-ADI x3 sub-iterations + SA DDADI x3 (BASELINE config 3)"
+            else:
+                # pyADflow defaults (pyADflow.py:5697-5731): RK smoother, "alternate" residual averaging
+                eng.set_options(prm.replace(smoother=RungeKutta, resAveraging=alternateResAveraging))
+                cyc_desc = "2-level V: smooth(RK5, alternate residual averaging) / restrict / smooth / prolong + closing residual"
             ctopo = BrickTopology(e * world, e, e, dims[0] // 2, dims[1] // 2, dims[2] // 2, owner=topo.owner)
             if do_halo:
                 eng.comm_register(1, 2, cp)
-                eng.comm_register(2, 1, ctopo.patterns(1, only_rank=rank)[rank])
+                if not rans:
+                    eng.comm_register(2, 1, ctopo.patterns(1, only_rank=rank)[rank])
             log("multigrid levels registered")
-            cyc = [0, 1, 0, -1]
+            cyc = [0] if rans else [0, 1, 0, -1]
             eng.set_async(False)
             eng.timeStep(1, False)
             eng.residual(1, 0)
@@ -252,7 +261,7 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt_mg = float(tt.item())
             mg = {"cycles_per_s": ncyc / dt_mg, "ms_per_cycle": dt_mg / ncyc * 1e3, "cycles_timed": ncyc,
-                  "cycle": "2-level V: smooth(RK5, alternate residual averaging) / restrict / smooth / prolong + closing residual",
+                  "cycle": cyc_desc,
                   "fine_cells_per_gpu": cells_local}
             log(f"MG: {mg['ms_per_cycle']:.3f} ms/cycle")
         except Exception as e:
