@@ -377,6 +377,7 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     rc |= alloc_arr(b, &v.dI, 3);
     rc |= alloc_arr(b, &v.dJ, 3);
     rc |= alloc_arr(b, &v.dK, 3);
+    rc |= alloc_arr(b, &v.nsum, 19);
     rc |= alloc_arr(b, &v.dw, v.nw);
     rc |= alloc_arr(b, &v.fw, 5);
     rc |= alloc_arr(b, &v.dtl, 1);

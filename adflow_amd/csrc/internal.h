@@ -71,6 +71,7 @@ struct BlkView {
     // geometry
     double *x, *sI, *sJ, *sK, *vol, *volRef, *d2wall;
     double *dI, *dJ, *dK;   // derived geometry: vector between the two cell centres of a face (viscous normal correction)
+    double *nsum;           // derived geometry: 18 summed normals of a node's dual cell + 1/sum(vol) (nodal gradients)
     // implicit turbulence boundary treatment of Spalart-Allmaras (turbBCRoutines.F90:662-798): halo = bvt - bmt * interior.
     // Index 0..5 = iMin,iMax,jMin,jMax,kMin,kMax; entry (a,b) at (a-1) + A*(b-1), A = je (i faces) or ie (j,k faces).
     // NULL until a block registers boundary subfaces (= all zero, the periodic / internal case).

@@ -16,6 +16,8 @@
 #define VS_BX 64
 #define VS_BY 4
 
+int g_viscous_tiled = 1;   // tuning "viscous_tiled": 1 = LDS-tiled nodal-gradient and face-flux kernels
+
 __device__ __forceinline__ double aa_at(const BlkView& b, long q) { return b.gamma[q] * b.p[q] / b.w[q]; }
 
 struct NCell { double u, v, w, aa; };
@@ -99,6 +101,118 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
     grad_dir(b, c, si, sj, sk, b.sI, q[0], q[2], q[4], q[6], q[1], q[3], q[5], q[7], g);
     const double oneOverV = 1.0 / (b.vol[c] + b.vol[c + sk] + b.vol[c + si] + b.vol[c + si + sk] + b.vol[c + sj] +
                                    b.vol[c + sj + sk] + b.vol[c + si + sj] + b.vol[c + si + sj + sk]);
+#pragma unroll
+    for (int m = 0; m < 12; ++m) b.grad[c + m * nb] = g[m] * oneOverV;
+}
+
+// ---------------------------------------------------------------------------
+// Tiled form of the nodal-gradient kernel.  k_nodal_gradients issues ~164 loads per node (8 cells x 6
+// values + 108 face-normal components + 8 volumes) and is bound by the texture-address unit.  Here
+//   * the six summed normal vectors of a node's dual cell and 1/sum(vol) are static geometry: formed once
+//     per mesh by k_node_sums with exactly the summation order of grad_dir (19 values per node);
+//   * u, v, w, a^2 of the 65 x 5 x 2 cells a workgroup's 64 x 4 nodes touch are staged once through LDS
+//     (a^2 = gamma p / rho evaluated once per cell instead of three times per node and cell).
+// 19 + ~18 global loads per node remain.  Arithmetic and its order are unchanged.
+// ---------------------------------------------------------------------------
+#define NS_NCOMP 19
+__global__ __launch_bounds__(VS_BX* VS_BY) void k_node_sums(BlkView b)
+{
+    const int i = blockIdx.x * VS_BX + threadIdx.x + 1;
+    const int j = blockIdx.y * VS_BY + threadIdx.y + 1;
+    const int k = blockIdx.z + 1;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k), nb = b.nbox;
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+    const long sd3[3] = {sk, sj, si};
+    const long s13[3] = {si, si, sj};
+    const long s23[3] = {sj, sk, sk};
+    const double* sN3[3] = {b.sK, b.sJ, b.sI};
+#pragma unroll
+    for (int dir = 0; dir < 3; ++dir) {
+        const long sd = sd3[dir], s1 = s13[dir], s2 = s23[dir];
+        const double* __restrict__ sN = sN3[dir];
+        const long cc[4] = {c, c + s1, c + s2, c + s1 + s2};
+        double mid[4][3], hi[4][3];
+        double sm[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                sm[d] += sN[cc[q] - sd + d * nb];
+                mid[q][d] = sN[cc[q] + d * nb];
+                hi[q][d] = sN[cc[q] + sd + d * nb];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { sm[d] += mid[q][d]; sp[d] += mid[q][d]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sp[d] += hi[q][d];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            b.nsum[c + (6 * dir + d) * nb] = sm[d];
+            b.nsum[c + (6 * dir + 3 + d) * nb] = sp[d];
+        }
+    }
+    b.nsum[c + 18 * nb] = 1.0 / (b.vol[c] + b.vol[c + sk] + b.vol[c + si] + b.vol[c + si + sk] + b.vol[c + sj] +
+                                 b.vol[c + sj + sk] + b.vol[c + si + sj] + b.vol[c + si + sj + sk]);
+}
+
+#define NT_LDX 66
+#define NT_ROWS (VS_BY + 1)
+#define NT_PLANE (NT_ROWS * NT_LDX)
+
+__device__ __forceinline__ void grad_acc(const double* __restrict__ ns, long c, long nb, int off, double sign, double ubar, double vbar,
+                                         double wbar, double a2, double g[12])
+{
+    const double sx = ns[c + off * nb], sy = ns[c + (off + 1) * nb], sz = ns[c + (off + 2) * nb];
+    g[0] += sign * ubar * sx; g[1] += sign * ubar * sy; g[2] += sign * ubar * sz;
+    g[3] += sign * vbar * sx; g[4] += sign * vbar * sy; g[5] += sign * vbar * sz;
+    g[6] += sign * wbar * sx; g[7] += sign * wbar * sy; g[8] += sign * wbar * sz;
+    g[9] -= sign * a2 * sx; g[10] -= sign * a2 * sy; g[11] -= sign * a2 * sz;
+}
+
+__global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients_t(BlkView b)
+{
+    __shared__ double cu[2 * NT_PLANE], cv[2 * NT_PLANE], cw[2 * NT_PLANE], ca[2 * NT_PLANE];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i0 = blockIdx.x * VS_BX + 1, j0 = blockIdx.y * VS_BY + 1;
+    const int i = i0 + tx, j = j0 + ty, k = blockIdx.z + 1;
+    const long nb = b.nbox;
+    // ---- stage u, v, w, a^2 of cells (i0..i0+64, j0..j0+4, k..k+1)
+    for (int e = ty * VS_BX + tx; e < 2 * NT_ROWS * 65; e += VS_BX * VS_BY) {
+        const int row = e / 65, x = e % 65;
+        const int pl = row / NT_ROWS, r = row % NT_ROWS;
+        int ic = i0 + x, jc = j0 + r;
+        if (ic > b.ib) ic = b.ib;
+        if (jc > b.jb) jc = b.jb;
+        const long q = b.idx(ic, jc, k + pl);
+        const int o = pl * NT_PLANE + r * NT_LDX + x;
+        cu[o] = b.w[q + nb]; cv[o] = b.w[q + 2 * nb]; cw[o] = b.w[q + 3 * nb];
+        ca[o] = aa_at(b, q);
+    }
+    __syncthreads();
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    // LDS offsets of the eight cells, index di + 2 dj + 4 dk
+    int o[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) o[n] = (n >> 2) * NT_PLANE + (ty + ((n >> 1) & 1)) * NT_LDX + tx + (n & 1);
+    double g[12];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) g[m] = 0.0;
+#define NT_BAR(arr, a, bq, cq, d) (0.25 * (arr[o[a]] + arr[o[bq]] + arr[o[cq]] + arr[o[d]]))
+    // k-direction: patches (di, dj) at dk = 0 / 1 ; j-direction: (di, dk) at dj = 0 / 1 ; i-direction: (dj, dk) at di = 0 / 1
+    grad_acc(b.nsum, c, nb, 0, -1.0, NT_BAR(cu, 0, 1, 2, 3), NT_BAR(cv, 0, 1, 2, 3), NT_BAR(cw, 0, 1, 2, 3), NT_BAR(ca, 0, 1, 2, 3), g);
+    grad_acc(b.nsum, c, nb, 3, +1.0, NT_BAR(cu, 4, 5, 6, 7), NT_BAR(cv, 4, 5, 6, 7), NT_BAR(cw, 4, 5, 6, 7), NT_BAR(ca, 4, 5, 6, 7), g);
+    grad_acc(b.nsum, c, nb, 6, -1.0, NT_BAR(cu, 0, 1, 4, 5), NT_BAR(cv, 0, 1, 4, 5), NT_BAR(cw, 0, 1, 4, 5), NT_BAR(ca, 0, 1, 4, 5), g);
+    grad_acc(b.nsum, c, nb, 9, +1.0, NT_BAR(cu, 2, 3, 6, 7), NT_BAR(cv, 2, 3, 6, 7), NT_BAR(cw, 2, 3, 6, 7), NT_BAR(ca, 2, 3, 6, 7), g);
+    grad_acc(b.nsum, c, nb, 12, -1.0, NT_BAR(cu, 0, 2, 4, 6), NT_BAR(cv, 0, 2, 4, 6), NT_BAR(cw, 0, 2, 4, 6), NT_BAR(ca, 0, 2, 4, 6), g);
+    grad_acc(b.nsum, c, nb, 15, +1.0, NT_BAR(cu, 1, 3, 5, 7), NT_BAR(cv, 1, 3, 5, 7), NT_BAR(cw, 1, 3, 5, 7), NT_BAR(ca, 1, 3, 5, 7), g);
+#undef NT_BAR
+    const double oneOverV = b.nsum[c + 18 * nb];
 #pragma unroll
     for (int m = 0; m < 12; ++m) b.grad[c + m * nb] = g[m] * oneOverV;
 }
@@ -264,11 +378,13 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_face_vectors(BlkView b)
     }
 }
 
+// derived static geometry of the viscous path: face vectors + the normal sums / inverse volume sums of the nodes
 void launch_face_vectors(const BlkView& b, hipStream_t s)
 {
     dim3 blk(VS_BX, VS_BY, 1);
     dim3 g((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
     hipLaunchKernelGGL(k_face_vectors, g, blk, 0, s, b);
+    hipLaunchKernelGGL(k_node_sums, g, blk, 0, s, b);
 }
 
 #define VT_LDX 66                       // 65 nodes per row (+1 pad)
@@ -429,13 +545,15 @@ __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(BlkView b, KParam
     }
 }
 
-int g_viscous_tiled = 1;   // tuning "viscous_tiled"
 
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
 {
     dim3 blk(VS_BX, VS_BY, 1);
     dim3 gn((b.il + 15 + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
-    hipLaunchKernelGGL(k_nodal_gradients, gn, blk, 0, s, b);
+    if (g_viscous_tiled)
+        hipLaunchKernelGGL(k_nodal_gradients_t, dim3((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl), blk, 0, s, b);
+    else
+        hipLaunchKernelGGL(k_nodal_gradients, gn, blk, 0, s, b);
     dim3 gc((b.nx + VS_BX - 1) / VS_BX, (b.ny + VS_BY - 1) / VS_BY, b.nz);
     if (g_viscous_tiled)
         hipLaunchKernelGGL(k_viscous_t, gc, blk, 0, s, b, kp);
