@@ -203,10 +203,12 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_ra_rfl(const BlkView* __restri
 template <int DIR>
 __global__ __launch_bounds__(64) void k_res_averaging(const BlkView* __restrict__ tab, KParams kp)
 {
-    const BlkView& b = tab[blockIdx.z / 5 + 1];
-    const int l = blockIdx.z % 5;
+    // the five equations of a line set are neighbouring workgroups (blockIdx.x fastest): they share rfl and flags
+    // through the L2 instead of fetching them five times
+    const BlkView& b = tab[blockIdx.z + 1];
+    const int l = blockIdx.x % 5;
     // line coordinates (a fastest): DIR0 -> (j,k), DIR1 -> (i,k), DIR2 -> (i,j)
-    const int a = blockIdx.x * 64 + threadIdx.x + 2;
+    const int a = (blockIdx.x / 5) * 64 + threadIdx.x + 2;
     const int bb = blockIdx.y + 2;
     int n, amax, bmax;
     long c0, s;
@@ -262,10 +264,10 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
     __shared__ double tv[64 * RA_LD];     // dw of the chunk
     __shared__ double tr[64 * RA_LD];     // forward: rfl of the right neighbour, then d;  backward: d
     __shared__ uint8_t tf[64 * RA_LD];    // iblank > 0
-    const BlkView& b = tab[blockIdx.z / 5 + 1];
-    const int l = blockIdx.z % 5;
+    const BlkView& b = tab[blockIdx.z + 1];
+    const int l = blockIdx.x % 5;
     const int lane = threadIdx.x;
-    const int j0 = blockIdx.x * 64 + 2;
+    const int j0 = (blockIdx.x / 5) * 64 + 2;
     const int k = blockIdx.y + 2;
     const int n = b.nx;
     if (j0 > b.jl || k > b.kl || n <= 1) return;
@@ -367,9 +369,9 @@ void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int m
     hipLaunchKernelGGL(k_ra_rfl, dim3((maxnx + SM_BX - 1) / SM_BX, (maxny + SM_BY - 1) / SM_BY, maxnz * nslots),
                        dim3(SM_BX, SM_BY, 1), 0, s, tab, kp, maxnz);
     const dim3 blk(64, 1, 1);
-    if (maxnx > 1) hipLaunchKernelGGL(k_res_averaging_i, dim3((maxny + 63) / 64, maxnz, 5 * nslots), blk, 0, s, tab, kp);
-    if (maxny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3((maxnx + 63) / 64, maxnz, 5 * nslots), blk, 0, s, tab, kp);
-    if (maxnz > 1) hipLaunchKernelGGL((k_res_averaging<2>), dim3((maxnx + 63) / 64, maxny, 5 * nslots), blk, 0, s, tab, kp);
+    if (maxnx > 1) hipLaunchKernelGGL(k_res_averaging_i, dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
+    if (maxny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3(5 * ((maxnx + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
+    if (maxnz > 1) hipLaunchKernelGGL((k_res_averaging<2>), dim3(5 * ((maxnx + 63) / 64), maxny, nslots), blk, 0, s, tab, kp);
 }
 
 // ---------------------------------------------------------------------------
@@ -703,11 +705,11 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_dadi_rows_i(const BlkView* __r
 __global__ __launch_bounds__(64) void k_dadi_solve_i(const BlkView* __restrict__ tab, KParams kp)
 {
     __shared__ double tb[64 * TI_LD], tc[64 * TI_LD], td[64 * TI_LD], tf[64 * TI_LD];
-    const BlkView& b = tab[blockIdx.z / 5 + 1];
-    const int l = blockIdx.z % 5;
+    const BlkView& b = tab[blockIdx.z + 1];
+    const int l = blockIdx.x % 5;               // equation fastest: the three equations of group 0 share their rows in L2
     const int g = (l < 3) ? 0 : l - 2;
     const int lane = threadIdx.x;
-    const int j0 = blockIdx.x * 64 + 2, k = blockIdx.y + 2;
+    const int j0 = (blockIdx.x / 5) * 64 + 2, k = blockIdx.y + 2;
     const int n = b.nx;
     if (b.nx == 0 || j0 > b.jl || k > b.kl || n <= 1) return;
     const long nb = b.nbox;
@@ -790,7 +792,7 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
         const dim3 pg((nx + SM_BX - 1) / SM_BX, (ny + SM_BY - 1) / SM_BY, nz * nslots), pb(SM_BX, SM_BY, 1);
         if (nx > 1) {
             hipLaunchKernelGGL(k_dadi_rows_i, pg, pb, 0, s, tab, nz, kp);
-            hipLaunchKernelGGL(k_dadi_solve_i, dim3((ny + 63) / 64, nz, 5 * nslots), blk, 0, s, tab, kp);
+            hipLaunchKernelGGL(k_dadi_solve_i, dim3(5 * ((ny + 63) / 64), nz, nslots), blk, 0, s, tab, kp);
         }
         hipLaunchKernelGGL(k_dadi_post_i, pg, pb, 0, s, tab, nz);
     } else {

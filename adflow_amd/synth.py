@@ -250,8 +250,10 @@ def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.
 # boundaries (one subface per face, cell range including the first halo ring as the
 # reference's preprocessing builds it).  Viscous walls come first (nViscBocos).
 # ----------------------------------------------------------------------------
-def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7):
-    """spec: {faceID (1..6 = iMin,iMax,jMin,jMax,kMin,kMax): BCType}.  Returns (faces, nViscBocos)."""
+def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7, split=()):
+    """spec: {faceID (1..6 = iMin,iMax,jMin,jMax,kMin,kMax): BCType}.  Returns (faces, nViscBocos).
+    split: {faceID: BCType of the second half}: the face is cut in two subfaces along its first index (the lower
+    half keeps spec's kind), as block faces that are only partly a wall / partly farfield are in real meshes."""
     rng = np.random.default_rng(seed)
     ie, je, ke = blk.ie, blk.je, blk.ke
     sI, sJ, sK = blk["sI"], blk["sJ"], blk["sK"]
@@ -287,7 +289,30 @@ def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7):
             f["velz"] = np.asfortranarray(winf[1] * 0.05 * rng.uniform(-1, 1, shp))
             f["ps"] = np.asfortranarray(prm.pInf * (1.0 + 0.02 * rng.uniform(-1, 1, shp)))
         faces.append(f)
-    nvisc = sum(1 for _, t in order if t in (-3, -4))
+    # cut the requested faces in two subfaces (ranges 1..h and h+1..end of the first index)
+    for fid, typ2 in dict(split).items():
+        m = next(ix for ix, f in enumerate(faces) if f["faceID"] == fid)
+        f = faces[m]
+        h = (f["icBeg"] + f["icEnd"]) // 2
+        lo, hi = dict(f), dict(f)
+        lo["icEnd"], hi["icBeg"], hi["bcType"] = h, h + 1, int(typ2)
+        n0 = h - f["icBeg"] + 1
+        for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps"):
+            if f.get(k) is not None:
+                lo[k] = np.asfortranarray(f[k][:n0])
+                hi[k] = np.asfortranarray(f[k][n0:])
+        shp = hi["norm"].shape[:2]
+        if typ2 in (-5, -6) and hi.get("rface") is None:
+            hi["rface"] = np.asfortranarray(0.01 * rng.uniform(-1, 1, shp))
+        if typ2 in (-3, -4) and hi.get("uSlip") is None:
+            hi["uSlip"] = np.asfortranarray(0.02 * rng.uniform(-1, 1, shp + (3,)))
+        if typ2 == -4 and hi.get("TNS_Wall") is None:
+            tinf = prm.pInf / (prm.RGas * prm.rhoInf)
+            hi["TNS_Wall"] = np.asfortranarray(tinf * (1.0 + 0.05 * rng.uniform(-1, 1, shp)))
+        faces[m:m + 1] = [lo, hi]
+    # viscous walls first (stable), as the reference orders the subfaces of a block
+    faces.sort(key=lambda f: 0 if f["bcType"] in (-3, -4) else 1)
+    nvisc = sum(1 for f in faces if f["bcType"] in (-3, -4))
     return faces, nvisc
 
 

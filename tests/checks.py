@@ -96,7 +96,7 @@ def check_rk_residual_sequence(engine, dims, prm, seed=3, **mk):
 # multi-block checks against the reference's SHELL routines (smoothers.F90,
 # haloExchange.F90) on periodic bricks of blocks
 # ---------------------------------------------------------------------------
-def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, **mk):
+def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, split=(), **mk):
     """applyAllBC_block (BCRoutines.F90:57-221) on a block whose six faces are physical boundaries:
     every halo value the reference's routine writes (w, p, gamma, rlv, rev on both halo rings,
     edges and corners included, where later subfaces read what earlier ones wrote)."""
@@ -105,7 +105,7 @@ def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, *
     new_level(engine)
     prm = prm.replace(currentLevel=level, groundLevel=1)
     blk = make_block(*dims, prm, seed=seed, **mk)
-    faces, nvisc = make_bocos(blk, prm, spec, seed=seed + 1)
+    faces, nvisc = make_bocos(blk, prm, spec, seed=seed + 1, split=split)
     r = blk.copy()
     ref.bind_block(r, prm)
     ref.set_bocos(faces, nvisc)

@@ -107,3 +107,10 @@ def test_update_geometry_after_mesh_warp(engine, dims):
     checks.check_update_geometry(engine, dims, FlowParams(), {1: -1, 2: -6, 3: -5, 4: -5, 5: -1, 6: -6})
     checks.check_update_geometry(engine, dims, FlowParams(equations=NSEquations), {1: -6, 2: -6, 3: -3, 4: -6, 5: -1, 6: -1},
                                  stretch_k=2.0)
+
+
+def test_apply_all_bc_split_faces(engine):
+    """block faces cut into two subfaces of different kinds (wall + farfield, symmetry + Euler wall)"""
+    checks.check_apply_bc(engine, (40, 9, 6), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}, split={3: -6, 6: -5, 1: -6})
+    checks.check_apply_bc(engine, (24, 8, 6), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6},
+                          split={5: -6, 4: -3}, stretch_k=2.0)
