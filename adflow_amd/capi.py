@@ -49,7 +49,8 @@ class AdflowOpts(ctypes.Structure):
         ("gammaInf", c_double), ("pInf", c_double), ("pInfCorr", c_double), ("rhoInf", c_double), ("uInf", c_double),
         ("RGas", c_double), ("muInf", c_double), ("muRef", c_double), ("TRef", c_double), ("timeRef", c_double),
         ("wInf", c_double * 10),
-        ("reserved_d", c_double * 8),
+        ("sigma", c_double),
+        ("reserved_d", c_double * 7),
     ]
 
 
@@ -119,7 +120,7 @@ EXPORTS = [
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
     "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc",
-    "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry",
+    "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
 ]
@@ -159,6 +160,7 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_apply_all_bc.argtypes = [c_int, c_int]
     lib.adflow_gpu_upload_coordinates.argtypes = [c_int, c_int, c_int]
     lib.adflow_gpu_update_geometry.argtypes = [c_int]
+    lib.adflow_gpu_reference_shock_sensor.argtypes = [c_int]
     lib.adflow_gpu_set_tuning.argtypes = [c_char_p, c_int]
     lib.adflow_gpu_abi_sizes.argtypes = [POINTER(c_int), POINTER(c_int)]
     lib.adflow_gpu_rk_smooth.argtypes = [c_int]

@@ -220,6 +220,7 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.viscous = (o.equations == ADFLOW_NS || o.equations == ADFLOW_RANS);
     k.eddyModel = (o.equations == ADFLOW_RANS);
     k.dirScaling = o.dirScaling;
+    k.sigma = o.sigma;
     k.useQCR = o.useQCR;
     k.useRotationSA = o.useRotationSA;
     k.useft2SA = o.useft2SA;
@@ -674,9 +675,9 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
     return sync_and_check();
 }
 
-static int enqueue_flow_residual(int level, const KParams& kp)
+static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false)
 {
-    if (g_use_march && !kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.fineGrid) {
+    if (g_use_march && !kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.fineGrid && !kp.dissApprox) {
         // Euler + scalar JST: one k-marching launch over every block of the level
         int rc = for_level(level, [&](Block* b) {
             if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
@@ -691,7 +692,7 @@ static int enqueue_flow_residual(int level, const KParams& kp)
         return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
     int rc = for_level(level, [&](Block* b) {
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
-        if (kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && !b->ss_valid && fabs(kp.rFil) >= 1.e-10) {
+        if (kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && !b->ss_valid && fabs(kp.rFil) >= 1.e-10 && !kp.dissApprox) {
             launch_entropy(b->v, g_stream);
             b->ss_valid = true;
         }
@@ -708,7 +709,8 @@ static int enqueue_flow_residual(int level, const KParams& kp)
             launch_face_vectors(b->v, g_stream);
             b->face_vectors_valid = true;
         }
-        launch_viscous(b->v, kp, g_stream);
+        if (viscApprox) launch_viscous_approx(b->v, kp, g_stream);   // viscousFluxApprox instead of gradients + viscousFlux
+        else launch_viscous(b->v, kp, g_stream);
         return 0;
     });
 }
@@ -740,6 +742,8 @@ static int block_res_enqueue(int level, unsigned flags)
     KParams kp = make_kparams(level, 1.0, 0);
     kp.onlyRadii = !(flags & ADFLOW_RES_UPDATE_INTERMED);
     kp.coarseInit = 0;
+    kp.dissApprox = (flags & ADFLOW_RES_DISS_APPROX) ? 1 : 0;
+    const bool viscApprox = (flags & ADFLOW_RES_VISC_APPROX) != 0;
     int rc = 0;
     if (flags & ADFLOW_RES_CLOSURES) {
         // computePressureSimple / computeLamViscosity / computeEddyViscosity (blockette.F90:199-203)
@@ -779,10 +783,28 @@ static int block_res_enqueue(int level, unsigned flags)
         launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
     if (flags & ADFLOW_RES_FLOW) {
-        rc = enqueue_flow_residual(level, kp);
+        rc = enqueue_flow_residual(level, kp, viscApprox);
         if (rc) return rc;
     }
     return 0;
+}
+
+// referenceShockSensor (adjointUtils.F90:1909-1969): pressure (Euler or matrix dissipation) or entropy
+int adflow_gpu_reference_shock_sensor(int level)
+{
+    if (need_ready()) return 1;
+    const bool pressure = (g_opts.equations == ADFLOW_EULER) || (g_opts.spaceDiscr == ADFLOW_DISS_MATRIX);
+    int rc = for_level(level, [&](Block* b) {
+        if (pressure) {
+            HIPCHK(hipMemcpyAsync(b->v.ss, b->v.p, sizeof(double) * (size_t)b->boxsize, hipMemcpyDeviceToDevice, g_stream));
+        } else {
+            launch_entropy(b->v, g_stream);
+        }
+        b->ss_valid = false;    // the exact viscous kernel recomputes its own sensor after an approximate pass
+        return 0;
+    });
+    if (rc) return rc;
+    return sync_and_check();
 }
 
 int adflow_gpu_block_res(int level, unsigned flags)

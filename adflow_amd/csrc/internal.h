@@ -119,6 +119,8 @@ struct KParams {
     int updateEddy;        // currentLevel <= groundLevel: recompute rev in the stage update
     int fwMode;            // 0: fw not persistent (rFil==1, sfil==0, no store)  1: persistent fw
     int storeIntermed;     // store dtl / radii
+    int dissApprox;        // lumped dissipation with the frozen sensor in b.ss (inviscidDissFlux*Approx)
+    double sigma;
     double rFil, sfil;
     double vis2, vis4, vis2Coarse, adis, acousticScaleFactor, kappaCoef;
     double gammaConstant, gammaInf, pInf, pInfCorr, rhoInf, RGas, muRef, TRef, timeRef;
@@ -136,6 +138,7 @@ void launch_entropy(const BlkView& b, hipStream_t s);
 void launch_inviscid_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_face_vectors(const BlkView& b, hipStream_t s);
 void launch_sa_residual_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

@@ -66,12 +66,15 @@ __device__ __forceinline__ void central_face(const Line& L, int l, double sx, do
 
 // scalar JST dissipative flux through face (l | l+1); needs line entries
 // l-1..l+2.  fw(right) += fs, fw(left) -= fs  (fluxes.F90:1204-1272)
+// approx: inviscidDissFluxScalarApprox (fluxes.F90:3861-4342): dis2 + sigma*fis4*rrad on the first difference only
 __device__ __forceinline__ void jst_scalar_face(const Line& L, int l, double rrad, double dssL, double dssR,
-                                                double fis2, double fis4, double sign, double acc[5])
+                                                double fis2, double fis4, double sign, double acc[5], bool approx = false,
+                                                double sigma = 0.0)
 {
     const int r = l + 1, ll = l - 1, rr = l + 2;
-    const double dis2 = fis2 * rrad * fmin(0.25, fmax(dssL, dssR));
-    const double dis4 = fmax(fis4 * rrad - dis2, 0.0);   // myDim, utils.F90:470-480
+    double dis2 = fis2 * rrad * fmin(0.25, fmax(dssL, dssR));
+    double dis4 = fmax(fis4 * rrad - dis2, 0.0);   // myDim, utils.F90:470-480
+    if (approx) { dis2 = dis2 + sigma * fis4 * rrad; dis4 = 0.0; }
     double ddw, fs;
     ddw = L.rho[r] - L.rho[l];
     fs = dis2 * ddw - dis4 * (L.rho[rr] - L.rho[ll] - 3.0 * ddw);
@@ -126,14 +129,15 @@ __device__ __forceinline__ void absA_times_dw(double lam1, double lam2, double l
 // matrix JST dissipative flux through face (l | l+1)  (fluxes.F90:523-690)
 __device__ __forceinline__ void jst_matrix_face(const Line& L, const double gam[5], int l, double nx, double ny, double nz,
                                                 int por, double dssL, double dssR, double fis2, double fis4, double sign,
-                                                double acc[5], bool coarse = false)
+                                                double acc[5], bool coarse = false, bool approx = false, double sigma = 0.0)
 {
     const int r = l + 1, ll = l - 1, rr = l + 2;
     const double ppor = (por == ADF_POR_NORMAL) ? 1.0 : 0.0;
     // coarse multigrid levels (inviscidDissFluxMatrixCoarse, fluxes.F90:5205-5430): first
     // differences only, dis0 = rFil*vis2Coarse*ppor passed in fis2, no sensor
-    const double dis2 = coarse ? ppor * fis2 : ppor * fis2 * fmin(0.25, fmax(dssL, dssR));
-    const double dis4 = coarse ? 0.0 : fmax(ppor * fis4 - dis2, 0.0);
+    double dis2 = coarse ? ppor * fis2 : ppor * fis2 * fmin(0.25, fmax(dssL, dssR));
+    double dis4 = coarse ? 0.0 : fmax(ppor * fis4 - dis2, 0.0);
+    if (approx) { dis2 = dis2 + sigma * fis4 * ppor; dis4 = 0.0; }   // inviscidDissFluxMatrixApprox (fluxes.F90:4462)
     double ddw;
     ddw = L.rho[r] - L.rho[l];
     const double dr = dis2 * ddw - dis4 * (L.rho[rr] - L.rho[ll] - 3.0 * ddw);
@@ -303,7 +307,8 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
         for (int l = 0; l < 5; ++l) fwd[l] += d0M * (W0[l] - Wm[l]) - d0P * (Wp[l] - W0[l]);
     } else if (SCHEME == ADFLOW_DISS_SCALAR) {
         double ssv[5];
-        if (VISC) {
+        const bool approx = kp.dissApprox != 0;
+        if (VISC || approx) {      // approx: the frozen sensor (adflow_gpu_reference_shock_sensor) for Euler too
 #pragma unroll
             for (int m = 0; m < 5; ++m) ssv[m] = b.ss[c + (m - 2) * s];
         } else {
@@ -316,8 +321,8 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
         const double r0 = rad[c];
         const double rrM = (porM == ADF_POR_NORMAL ? 0.5 : 0.0) * (rad[c - s] + r0);
         const double rrP = (porP == ADF_POR_NORMAL ? 0.5 : 0.0) * (r0 + rad[c + s]);
-        jst_scalar_face(L, 1, rrM, dm, d0, fis2, fis4, +1.0, fwd);   // cell is the right cell
-        jst_scalar_face(L, 2, rrP, d0, dp, fis2, fis4, -1.0, fwd);   // cell is the left cell
+        jst_scalar_face(L, 1, rrM, dm, d0, fis2, fis4, +1.0, fwd, approx, kp.sigma);   // cell is the right cell
+        jst_scalar_face(L, 2, rrP, d0, dp, fis2, fis4, -1.0, fwd, approx, kp.sigma);   // cell is the left cell
     } else {
         double gam[5];
         gam[0] = gam[4] = 0.0;
@@ -328,11 +333,15 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
             jst_matrix_face(L, gam, 1, mx, my, mz, porM, 0.0, 0.0, fis0, 0.0, +1.0, fwd, true);
             jst_matrix_face(L, gam, 2, px, py, pz, porP, 0.0, 0.0, fis0, 0.0, -1.0, fwd, true);
         } else if (SCHEME == ADFLOW_DISS_MATRIX) {
-            const double dm = mat_sensor(L.p[0], L.p[1], L.p[2], sslim);
-            const double d0 = mat_sensor(L.p[1], L.p[2], L.p[3], sslim);
-            const double dp = mat_sensor(L.p[2], L.p[3], L.p[4], sslim);
-            jst_matrix_face(L, gam, 1, mx, my, mz, porM, dm, d0, fis2, fis4, +1.0, fwd);
-            jst_matrix_face(L, gam, 2, px, py, pz, porP, d0, dp, fis2, fis4, -1.0, fwd);
+            const bool approx = kp.dissApprox != 0;
+            double sv[5];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) sv[m] = approx ? b.ss[c + (m - 2) * s] : L.p[m];   // frozen pressure when approx
+            const double dm = mat_sensor(sv[0], sv[1], sv[2], sslim);
+            const double d0 = mat_sensor(sv[1], sv[2], sv[3], sslim);
+            const double dp = mat_sensor(sv[2], sv[3], sv[4], sslim);
+            jst_matrix_face(L, gam, 1, mx, my, mz, porM, dm, d0, fis2, fis4, +1.0, fwd, false, approx, kp.sigma);
+            jst_matrix_face(L, gam, 2, px, py, pz, porP, d0, dp, fis2, fis4, -1.0, fwd, false, approx, kp.sigma);
         } else {   // Roe upwind: fw(left) += flux, fw(right) -= flux
             roe_face(L, gam, 1, mx, my, mz, porM, lim, kp.kappaCoef, kp.rFil, kp.gammaConstant, -1.0, fwd);
             roe_face(L, gam, 2, px, py, pz, porP, lim, kp.kappaCoef, kp.rFil, kp.gammaConstant, +1.0, fwd);

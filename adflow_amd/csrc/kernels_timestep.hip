@@ -29,8 +29,8 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(const BlkView* __res
     const double pp = b.p[c];
     const double gam = b.gamma[c];
 
-    if (VISC) {
-        // entropy-like sensor variable, all cells 0..ib (fluxes.F90:1126-1136)
+    if (VISC && !kp.dissApprox) {
+        // entropy-like sensor variable, all cells 0..ib (fluxes.F90:1126-1136); left alone while the sensor is frozen
         b.ss[c] = pp / pow(rho, gam);
     }
     if (i < 1 || i > b.ie || j < 1 || j > b.je || k < 1 || k > b.ke) return;

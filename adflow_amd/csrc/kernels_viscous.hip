@@ -546,6 +546,94 @@ __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(BlkView b, KParam
 }
 
 
+// ---------------------------------------------------------------------------
+// viscousFluxApprox (fluxes.F90:3487-3859): thin-layer form for the preconditioner assembly.  The gradient on a
+// face is the difference of the two cell values along the centre-to-centre vector d (no nodal gradients):
+// grad(q) = (q_R - q_L) d / |d|^2.  d is the static face vector of k_face_vectors (same node order).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void visc_face_approx(const KParams& kp, const VCell& L, const VCell& R, const double fN[3],
+                                                 const double dN[3], int por_code, double sign, double acc[5])
+{
+    double ss = 1.0 / (dN[0] * dN[0] + dN[1] * dN[1] + dN[2] * dN[2]);
+    const double ssx = ss * dN[0], ssy = ss * dN[1], ssz = ss * dN[2];
+    double dd;
+    dd = R.u - L.u;
+    const double u_x = dd * ssx, u_y = dd * ssy, u_z = dd * ssz;
+    dd = R.v - L.v;
+    const double v_x = dd * ssx, v_y = dd * ssy, v_z = dd * ssz;
+    dd = R.w - L.w;
+    const double w_x = dd * ssx, w_y = dd * ssy, w_z = dd * ssz;
+    dd = R.aa - L.aa;
+    double q_x = -dd * ssx, q_y = -dd * ssy, q_z = -dd * ssz;
+    double por = 0.5 * kp.rFil;
+    if (por_code == ADF_POR_NOFLUX) por = 0.0;
+    const double mul = por * (L.rlv + R.rlv);
+    double mue = 0.0;
+    if (kp.eddyModel) mue = por * (L.rev + R.rev);
+    const double mut = mul + mue;
+    const double gm1 = 0.5 * (L.gam + R.gam) - 1.0;
+    const double factLamHeat = 1.0 / (kp.prandtl * gm1), factTurbHeat = 1.0 / (kp.prandtlTurb * gm1);
+    const double heatCoef = mul * factLamHeat + mue * factTurbHeat;
+    const double fracDiv = (2.0 * (1.0 / 3.0)) * (u_x + v_y + w_z);
+    const double tauxx = mut * (2.0 * u_x - fracDiv), tauyy = mut * (2.0 * v_y - fracDiv), tauzz = mut * (2.0 * w_z - fracDiv);
+    const double tauxy = mut * (u_y + v_x), tauxz = mut * (u_z + w_x), tauyz = mut * (v_z + w_y);
+    q_x = heatCoef * q_x; q_y = heatCoef * q_y; q_z = heatCoef * q_z;
+    const double ubar = 0.5 * (L.u + R.u), vbar = 0.5 * (L.v + R.v), wbar = 0.5 * (L.w + R.w);
+    const double nx = fN[0], ny = fN[1], nz = fN[2];
+    const double fmx = tauxx * nx + tauxy * ny + tauxz * nz;
+    const double fmy = tauxy * nx + tauyy * ny + tauyz * nz;
+    const double fmz = tauxz * nx + tauyz * ny + tauzz * nz;
+    const double frhoE = (ubar * tauxx + vbar * tauxy + wbar * tauxz) * nx + (ubar * tauxy + vbar * tauyy + wbar * tauyz) * ny +
+                         (ubar * tauxz + vbar * tauyz + wbar * tauzz) * nz - q_x * nx - q_y * ny - q_z * nz;
+    acc[1] += sign * fmx;
+    acc[2] += sign * fmy;
+    acc[3] += sign * fmz;
+    acc[4] += sign * frhoE;
+}
+
+__global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous_approx(BlkView b, KParams kp)
+{
+    const int i = blockIdx.x * VS_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * VS_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k), nb = b.nbox;
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+    const uint8_t f0 = b.flags[c];
+    double acc[5] = {0, 0, 0, 0, 0};
+    const VCell C = vcell_at(b, kp, c);
+    // reference sweep order i, j, k (fluxes.F90:3520, 3666, 3762)
+    const long sd3[3] = {si, sj, sk};
+    const double* sN3[3] = {b.sI, b.sJ, b.sK};
+    const double* dN3[3] = {b.dI, b.dJ, b.dK};
+    const int shift3[3] = {0, 2, 4};
+#pragma unroll 1
+    for (int d = 0; d < 3; ++d) {
+        const long sd = sd3[d], cm = c - sd;
+        const double* __restrict__ sN = sN3[d];
+        const double* __restrict__ dN = dN3[d];
+        const VCell M = vcell_at(b, kp, cm), P = vcell_at(b, kp, c + sd);
+        const double nM[3] = {sN[cm], sN[cm + nb], sN[cm + 2 * nb]}, nP[3] = {sN[c], sN[c + nb], sN[c + 2 * nb]};
+        const double dM[3] = {dN[cm], dN[cm + nb], dN[cm + 2 * nb]}, dP[3] = {dN[c], dN[c + nb], dN[c + 2 * nb]};
+        visc_face_approx(kp, M, C, nM, dM, (b.flags[cm] >> shift3[d]) & 3, +1.0, acc);
+        visc_face_approx(kp, C, P, nP, dP, (f0 >> shift3[d]) & 3, -1.0, acc);
+    }
+    const double blank = flg_blank(f0);
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        const double fwn = b.fw[c + l * nb] + acc[l];
+        if (kp.fwMode) b.fw[c + l * nb] = fwn;
+        b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
+    }
+}
+
+void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s)
+{
+    dim3 blk(VS_BX, VS_BY, 1);
+    dim3 gc((b.nx + VS_BX - 1) / VS_BX, (b.ny + VS_BY - 1) / VS_BY, b.nz);
+    hipLaunchKernelGGL(k_viscous_approx, gc, blk, 0, s, b, kp);
+}
+
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
 {
     dim3 blk(VS_BX, VS_BY, 1);

@@ -103,9 +103,12 @@ class Engine:
     def residual(self, level=1, rkStage=0):
         self._chk(self.lib.adflow_gpu_residual(level, rkStage))
 
-    def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True):
+    def referenceShockSensor(self, level=1):
+        self._chk(self.lib.adflow_gpu_reference_shock_sensor(level))
+
+    def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True, dissApprox=False, viscApprox=False):
         flags = (capi.RES_UPDATE_INTERMED if updateIntermed else 0) | (capi.RES_FLOW if flowRes else 0) \
-            | (capi.RES_TURB if turbRes else 0)
+            | (capi.RES_TURB if turbRes else 0) | (32 if dissApprox else 0) | (64 if viscApprox else 0)
         self._chk(self.lib.adflow_gpu_block_res(level, flags))
 
     def bc_register(self, faces, nViscBocos: int = 0, nn: int = 1, level: int = 1, sps: int = 1):

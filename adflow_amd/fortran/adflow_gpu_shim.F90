@@ -30,7 +30,8 @@ module adflowGpuShim
         real(c_double) :: etaRK(8), cdisRK(8)
         real(c_double) :: gammaInf, pInf, pInfCorr, rhoInf, uInf, RGas, muInf, muRef, TRef, timeRef
         real(c_double) :: wInf(10)
-        real(c_double) :: reserved_d(8)
+        real(c_double) :: sigma
+        real(c_double) :: reserved_d(7)
     end type adflow_opts
 
     ! ---- mirror of adflow_block_desc ----------------------------------------
@@ -217,6 +218,7 @@ contains
         o%RGas = RGas; o%muInf = muInf; o%muRef = muRef; o%TRef = TRef; o%timeRef = timeRef
         o%wInf = zero
         if (allocated(wInf)) o%wInf(1:size(wInf)) = wInf
+        o%sigma = sigma
         o%reserved_d = zero
         call gpuCheck(adflow_gpu_set_options(o), "gpuRefreshOptions")
     end subroutine gpuRefreshOptions

@@ -99,7 +99,8 @@ typedef struct adflow_opts {
     /* flowVarRefState (src/modules/flowVarRefState.F90) */
     double gammaInf, pInf, pInfCorr, rhoInf, uInf, RGas, muInf, muRef, TRef, timeRef;
     double wInf[10];
-    double reserved_d[8];
+    double sigma;             /* inputDiscretization: lumped-dissipation coefficient of the approximate residual */
+    double reserved_d[7];
 } adflow_opts;
 
 /* Host arrays of one block, flowDoms(nn,level,sps)%... .  NULL = not present
@@ -172,7 +173,11 @@ enum {
     ADFLOW_RES_TURB = 4u,              /* useTurbRes  */
     /* the part of blocketteRes in front of the core (blockette.F90:195-246): */
     ADFLOW_RES_CLOSURES = 8u,          /* computePressureSimple + laminar/eddy viscosity, owned cells */
-    ADFLOW_RES_HALO = 16u              /* boundary-condition hook + whalo2(1, lStart, lEnd, T,T,T) */
+    ADFLOW_RES_HALO = 16u,             /* boundary-condition hook + whalo2(1, lStart, lEnd, T,T,T) */
+    /* approximate residual of the preconditioner assembly (blockette.F90:755-852, fluxes.F90:3487-4975): */
+    ADFLOW_RES_DISS_APPROX = 32u,      /* useDissApprox: inviscidDissFluxScalarApprox / MatrixApprox (lumped 2nd-difference
+                                          dissipation with the FROZEN sensor of adflow_gpu_reference_shock_sensor) */
+    ADFLOW_RES_VISC_APPROX = 64u       /* useViscApprox: viscousFluxApprox (thin-layer normal differences) */
 };
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -217,6 +222,10 @@ int adflow_gpu_residual(int level, int rkStage);
 /* blockette::blocketteRes main loop (src/NKSolver/blockette.F90:266-283):
  * timeStep + initres + [SA] + inviscid + [viscous] + dw=(dw+fw)*iblank, rFil=1 */
 int adflow_gpu_block_res(int level, unsigned flags);
+/* adjointUtils::referenceShockSensor (src/adjoint/adjointUtils.F90:1909-1969): freeze the shock sensor of every
+ * level-1 block at the current state (pressure for Euler / matrix dissipation, entropy p/rho^gamma otherwise) for
+ * the following ADFLOW_RES_DISS_APPROX evaluations */
+int adflow_gpu_reference_shock_sensor(int level);
 /* smoothers::RungeKuttaSmoother / DADISmoother (src/solver/smoothers.F90:4,383) */
 int adflow_gpu_rk_smooth(int level);
 int adflow_gpu_dadi_smooth(int level);

@@ -36,6 +36,7 @@ def load(fast: bool = False) -> ctypes.CDLL:
         lib.ref_set_vec.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int]
         lib.ref_call.argtypes = [ctypes.c_char_p, ctypes.c_int]
         lib.ref_block_res_core.argtypes = [ctypes.c_int] * 3
+        lib.ref_block_res_core2.argtypes = [ctypes.c_int] * 5
         lib.ref_alloc_doms.argtypes = [ctypes.c_int] * 2
         lib.ref_commit_block.argtypes = [ctypes.c_int] * 2
         lib.ref_set_internal_comm.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
@@ -195,9 +196,13 @@ def call(name: str, iarg: int = 0) -> None:
     _big_stack(load().ref_call, name.encode(), int(iarg))
 
 
-def block_res_core(update_intermed=True, flow_res=True, turb_res=True) -> None:
+def block_res_core(update_intermed=True, flow_res=True, turb_res=True, diss_approx=False, visc_approx=False) -> None:
     """blockette::blockResCore (blockette.F90:755-852) call sequence."""
-    _big_stack(load().ref_block_res_core, int(update_intermed), int(flow_res), int(turb_res))
+    if diss_approx or visc_approx:
+        _big_stack(load().ref_block_res_core2, int(update_intermed), int(flow_res), int(turb_res), int(diss_approx),
+                   int(visc_approx))
+    else:
+        _big_stack(load().ref_block_res_core, int(update_intermed), int(flow_res), int(turb_res))
 
 
 def time_block_res_core(seconds: float, update_intermed=True, flow_res=True, turb_res=True):

@@ -581,6 +581,61 @@ contains
         end if
     end subroutine ref_block_res_core
 
+    ! the same sequence with the approximate-residual switches of blockResCore (blockette.F90:755-852)
+    subroutine ref_block_res_core2(updateIntermed, flowRes, turbRes, dissApprox, viscApprox) &
+        bind(C, name="ref_block_res_core2")
+        use blockPointers
+        use flowVarRefState, only: nw, nwf, nt1, nt2, viscous
+        use inputPhysics, only: equations, turbModel
+        use inputDiscretization, only: spaceDiscr
+        use solverUtils, only: timeStep_block
+        use fluxes
+        use residuals, only: initres_block
+        use flowUtils, only: computeSpeedOfSoundSquared, allNodalGradients
+        use sa, only: sa_block
+        use adjointExtra, only: sumDwAndFw
+        integer(c_int), value :: updateIntermed, flowRes, turbRes, dissApprox, viscApprox
+        integer(kind=intType) :: lStart, lEnd
+        lStart = 1; lEnd = nw
+        if (flowRes /= 0 .and. turbRes == 0) then
+            lEnd = nwf
+        else if (flowRes == 0 .and. turbRes /= 0) then
+            lStart = nt1; lEnd = nt2
+        end if
+        call timeStep_block(updateIntermed == 0)
+        call initres_block(lStart, lEnd, 1_intType, 1_intType)
+        fw = zero
+        if (equations == RANSEquations .and. turbRes /= 0) then
+            if (turbModel == spalartAllmaras) call sa_block(.true.)
+        end if
+        if (flowRes /= 0) then
+            call inviscidCentralFlux
+            if (dissApprox /= 0) then          ! blockette.F90:808-817
+                select case (spaceDiscr)
+                case (dissScalar); call inviscidDissFluxScalarApprox
+                case (dissMatrix); call inviscidDissFluxMatrixApprox
+                case (upwind); call inviscidUpwindFlux(.true.)
+                end select
+            else
+                select case (spaceDiscr)
+                case (dissScalar); call inviscidDissFluxScalar
+                case (dissMatrix); call inviscidDissFluxMatrix
+                case (upwind); call inviscidUpwindFlux(.true.)
+                end select
+            end if
+            if (viscous) then
+                call computeSpeedOfSoundSquared
+                if (viscApprox /= 0) then
+                    call viscousFluxApprox
+                else
+                    call allNodalGradients
+                    call viscousFlux
+                end if
+            end if
+            call sumDwAndFw
+        end if
+    end subroutine ref_block_res_core2
+
 
     ! ===================================================================
     ! multi-block mode: the reference's SHELL routines (smoothers, halo

@@ -58,6 +58,45 @@ def check_block_res(engine, dims, prm, seed=1, **mk):
     return blk, r
 
 
+def check_block_res_approx(engine, dims, prm, diss_approx=True, visc_approx=True, seed=91, **mk):
+    """blockResCore with dissApprox / viscApprox (blockette.F90:755-852): the lumped-dissipation and thin-layer
+    residual of the preconditioner assembly, sensor FROZEN at a reference state that differs from the state the
+    residual is evaluated at (as in the finite-difference Jacobian, adjointUtils.F90:1909-1969)."""
+    from oracle import ref
+    lvl = new_level(engine)
+    prm = prm.replace(currentLevel=lvl, groundLevel=lvl)
+    blk = make_block(*dims, prm, seed=seed, **mk)
+    r = ref_bind(blk, prm)
+    turb = prm.equations == RANSEquations
+    engine.set_options(prm)
+    engine.register(blk, nn=1, level=lvl)
+    # reference state -> frozen sensor (referenceShockSensor restated: pressure, or entropy for NS/RANS scalar JST)
+    if prm.equations == EulerEquations or prm.spaceDiscr == dissMatrix:
+        sens = r["p"].copy(order="F")
+    else:
+        sens = np.asfortranarray(r["p"] / r["w"][..., 0] ** r["gamma"])
+    r.a["shockSensor"] = sens
+    ref.load().ref_set_ptr(b"shockSensor", sens.ctypes.data)
+    engine.referenceShockSensor(lvl)
+    # perturbed state (what the coloured finite differences do)
+    rng = np.random.default_rng(seed)
+    fac = 1.0 + 1e-2 * rng.uniform(-1, 1, blk["w"].shape[:3])
+    for a in (blk, r):
+        a["w"][..., 0] *= fac
+        a["w"][..., 4] *= fac
+        a["p"][...] *= fac
+    engine.upload_state(1, lvl)
+    ref.block_res_core(True, True, turb, diss_approx=diss_approx, visc_approx=visc_approx)
+    engine.blocketteRes(level=lvl, updateIntermed=True, flowRes=True, turbRes=turb, dissApprox=diss_approx, viscApprox=visc_approx)
+    dw = engine.download_residual(1, lvl)
+    assert_dw(blk, dw, r["dw"], blk.nw, what=f"approx residual diss={diss_approx} visc={visc_approx}")
+    # an exact evaluation afterwards must not be affected by the frozen sensor
+    ref.block_res_core(True, True, turb)
+    engine.blocketteRes(level=lvl, updateIntermed=True, flowRes=True, turbRes=turb)
+    dw = engine.download_residual(1, lvl)
+    assert_dw(blk, dw, r["dw"], blk.nw, what="exact residual after an approximate one")
+
+
 def check_rk_residual_sequence(engine, dims, prm, seed=3, **mk):
     """residual() inside the RK smoother: rFil = cdisRK(stage+1) with the
     dissipation residual fw PERSISTENT between stages (residuals.F90:61-65,

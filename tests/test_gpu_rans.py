@@ -39,3 +39,17 @@ def test_ns_rk_stage_residuals(engine):
 def test_rans_full_size_block_vs_reference(engine):
     """BASELINE config 3 roofline-size block (128x128x96) against the reference itself."""
     checks.check_block_res(engine, (128, 128, 96), FlowParams(equations=RANSEquations), seed=5, stretch_k=3.0)
+
+
+# ---- approximate residual of the preconditioner assembly (blocketteRes useDissApprox / useViscApprox) ----
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_block_res_approx(engine, sd):
+    checks.check_block_res_approx(engine, (40, 12, 7), FlowParams(spaceDiscr=sd, sigma=0.2, vis4=0.05), visc_approx=False)
+    checks.check_block_res_approx(engine, (24, 20, 10), FlowParams(equations=RANSEquations, spaceDiscr=sd, sigma=0.3, vis4=0.05),
+                                  stretch_k=2.0)
+
+
+def test_block_res_visc_approx_only(engine):
+    from adflow_amd.params import NSEquations
+    checks.check_block_res_approx(engine, (24, 20, 10), FlowParams(equations=NSEquations, sigma=0.3), diss_approx=False,
+                                  visc_approx=True, stretch_k=2.0)

@@ -205,3 +205,16 @@ def test_apply_all_bc_split_faces(hostsim_engine):
                           split={3: -6, 6: -5, 1: -6})
     checks.check_apply_bc(hostsim_engine, (8, 6, 4), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6},
                           split={5: -6, 4: -3}, stretch_k=2.0)
+
+
+# ---- approximate residual of the preconditioner assembly (blocketteRes useDissApprox / useViscApprox) ----
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_block_res_approx(hostsim_engine, sd):
+    checks.check_block_res_approx(hostsim_engine, (9, 7, 5), FlowParams(spaceDiscr=sd, sigma=0.2, vis4=0.05), visc_approx=False)
+    checks.check_block_res_approx(hostsim_engine, (8, 6, 5), FlowParams(equations=RANSEquations, spaceDiscr=sd, sigma=0.3, vis4=0.05),
+                                  stretch_k=2.0)
+
+
+def test_block_res_visc_approx_only(hostsim_engine):
+    checks.check_block_res_approx(hostsim_engine, (8, 6, 5), FlowParams(equations=NSEquations, sigma=0.3), diss_approx=False,
+                                  visc_approx=True, stretch_k=2.0)
