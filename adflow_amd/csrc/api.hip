@@ -704,15 +704,19 @@ static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox =
     if (level_tab(level, &t)) return 1;
     launch_inviscid_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
-    return for_level(level, [&](Block* b) {
+    const bool batched = !viscApprox && viscous_is_tiled();
+    rc = for_level(level, [&](Block* b) {
         if (!b->face_vectors_valid) {
             launch_face_vectors(b->v, g_stream);
             b->face_vectors_valid = true;
         }
         if (viscApprox) launch_viscous_approx(b->v, kp, g_stream);   // viscousFluxApprox instead of gradients + viscousFlux
-        else launch_viscous(b->v, kp, g_stream);
+        else if (!batched) launch_viscous(b->v, kp, g_stream);
         return 0;
     });
+    if (rc) return rc;
+    if (batched) launch_viscous_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    return 0;
 }
 
 int adflow_gpu_residual(int level, int rkStage)

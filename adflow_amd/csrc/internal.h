@@ -138,6 +138,8 @@ void launch_entropy(const BlkView& b, hipStream_t s);
 void launch_inviscid_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+int viscous_is_tiled();
 void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_face_vectors(const BlkView& b, hipStream_t s);
 void launch_sa_residual_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

@@ -304,16 +304,18 @@ __global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab
 //   k_sa_solve_i  one thread per line: elimination from the end of the line, forward substitution,
 //                 rhs of the next direction = solution * qq; 64-line x 16-cell LDS tiles
 // ---------------------------------------------------------------------------
-#define SI_CH 16
+#define SI_SH 3
+#define SI_CH (1 << SI_SH)
 #define SI_LD (SI_CH + 1)
+#define SI_LPA (64 >> SI_SH)
 
 __device__ __forceinline__ void sa_tile_load(const BlkView& b, const double* __restrict__ arr, double* __restrict__ tile, int j0, int k,
                                              int i0, int lane)
 {
-    const int sub = lane >> 4, col = lane & 15, i = i0 + col;
+    const int sub = lane >> SI_SH, col = lane & (SI_CH - 1), i = i0 + col;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = 4 * q + sub;
+    for (int q = 0; q < SI_CH; ++q) {
+        const int r = SI_LPA * q + sub;
         tile[r * SI_LD + col] = (j0 + r <= b.jl && i <= b.il) ? arr[b.idx(i, j0 + r, k)] : 1.0;
     }
 }
@@ -321,10 +323,10 @@ __device__ __forceinline__ void sa_tile_load(const BlkView& b, const double* __r
 __device__ __forceinline__ void sa_tile_store(const BlkView& b, double* __restrict__ arr, const double* __restrict__ tile, int j0, int k,
                                               int i0, int lane)
 {
-    const int sub = lane >> 4, col = lane & 15, i = i0 + col;
+    const int sub = lane >> SI_SH, col = lane & (SI_CH - 1), i = i0 + col;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = 4 * q + sub;
+    for (int q = 0; q < SI_CH; ++q) {
+        const int r = SI_LPA * q + sub;
         if (j0 + r <= b.jl && i <= b.il) arr[b.idx(i, j0 + r, k)] = tile[r * SI_LD + col];
     }
 }

@@ -652,17 +652,19 @@ __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ t
 // The one-line-per-lane form reads ~25 arrays with a stride of one row per lane: 0.9 ms per
 // 128x128x96 block against 0.15 ms for the j sweep.
 // ---------------------------------------------------------------------------
-#define TI_CH 16
+#define TI_SH 3                 // log2 of the chunk length: 8 cells -> 18 KB of LDS per workgroup, 8 workgroups per CU
+#define TI_CH (1 << TI_SH)
 #define TI_LD (TI_CH + 1)
+#define TI_LPA (64 >> TI_SH)    // lines moved per wave access
 
-// 64 lines (j0..j0+63) x TI_CH cells (i0..) of one array <-> LDS tile; lane -> (line 4q + lane/16, cell lane%16)
+// 64 lines (j0..j0+63) x TI_CH cells (i0..) of one array <-> LDS tile; lane -> (line TI_LPA*q + lane/TI_CH, cell lane%TI_CH)
 __device__ __forceinline__ void tile_load(const BlkView& b, const double* __restrict__ arr, double* __restrict__ tile, int j0, int k,
                                           int i0, int lane)
 {
-    const int sub = lane >> 4, col = lane & 15, i = i0 + col;
+    const int sub = lane >> TI_SH, col = lane & (TI_CH - 1), i = i0 + col;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = 4 * q + sub;
+    for (int q = 0; q < TI_CH; ++q) {
+        const int r = TI_LPA * q + sub;
         tile[r * TI_LD + col] = (j0 + r <= b.jl && i <= b.il) ? arr[b.idx(i, j0 + r, k)] : 0.0;
     }
 }
@@ -670,10 +672,10 @@ __device__ __forceinline__ void tile_load(const BlkView& b, const double* __rest
 __device__ __forceinline__ void tile_store(const BlkView& b, double* __restrict__ arr, const double* __restrict__ tile, int j0, int k,
                                            int i0, int lane)
 {
-    const int sub = lane >> 4, col = lane & 15, i = i0 + col;
+    const int sub = lane >> TI_SH, col = lane & (TI_CH - 1), i = i0 + col;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = 4 * q + sub;
+    for (int q = 0; q < TI_CH; ++q) {
+        const int r = TI_LPA * q + sub;
         if (j0 + r <= b.jl && i <= b.il) arr[b.idx(i, j0 + r, k)] = tile[r * TI_LD + col];
     }
 }

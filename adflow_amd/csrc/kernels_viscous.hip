@@ -174,12 +174,14 @@ __device__ __forceinline__ void grad_acc(const double* __restrict__ ns, long c, 
     g[9] -= sign * a2 * sx; g[10] -= sign * a2 * sy; g[11] -= sign * a2 * sz;
 }
 
-__global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients_t(BlkView b)
+__global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients_t(const BlkView* __restrict__ tab, int nzb)
 {
     __shared__ double cu[2 * NT_PLANE], cv[2 * NT_PLANE], cw[2 * NT_PLANE], ca[2 * NT_PLANE];
+    const BlkView& b = tab[blockIdx.z / nzb + 1];      // level-batched: blockIdx.z = slot * nzb + node plane
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int i0 = blockIdx.x * VS_BX + 1, j0 = blockIdx.y * VS_BY + 1;
-    const int i = i0 + tx, j = j0 + ty, k = blockIdx.z + 1;
+    const int i = i0 + tx, j = j0 + ty, k = blockIdx.z % nzb + 1;
+    if (b.nx == 0 || k > b.kl || i0 > b.il || j0 > b.jl) return;      // uniform per workgroup
     const long nb = b.nbox;
     // ---- stage u, v, w, a^2 of cells (i0..i0+64, j0..j0+4, k..k+1)
     for (int e = ty * VS_BX + tx; e < 2 * NT_ROWS * 65; e += VS_BX * VS_BY) {
@@ -477,71 +479,92 @@ __device__ __forceinline__ void visc_face_t(const KParams& kp, const double* __r
     acc[4] += sign * frhoE;
 }
 
-__global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(BlkView b, KParams kp)
+#define VT_KCH 8      // planes marched by one workgroup: each new plane stages ONE node plane (the other is reused)
+
+__device__ __forceinline__ void vt_stage_plane(const BlkView& b, double* __restrict__ gl, int slot, int i0, int j0, int kn, int tx,
+                                               int ty)
 {
-    __shared__ double gl[2 * VT_PLANE];     // node planes k-1 and k, 12 components, VT_ROWS x 65 nodes
+    const long nb = b.nbox;
+    int in = i0 - 1 + tx;
+    if (in > b.ib) in = b.ib;
+    // rows = (component, node row) of node plane kn; nodes i0-1 .. i0+63
+    for (int it = 0; it < (12 * VT_ROWS) / VS_BY; ++it) {
+        const int row = ty * ((12 * VT_ROWS) / VS_BY) + it;
+        const int m = row / VT_ROWS, r = row % VT_ROWS;
+        int jn = j0 - 1 + r;
+        if (jn > b.jb) jn = b.jb;
+        gl[slot * VT_PLANE + row * VT_LDX + tx] = b.grad[m * nb + b.idx(in, jn, kn)];
+    }
+    const int t = ty * VS_BX + tx;      // the 65th node of every row
+    if (t < 12 * VT_ROWS) {
+        const int m = t / VT_ROWS, r = t % VT_ROWS;
+        int jn = j0 - 1 + r;
+        if (jn > b.jb) jn = b.jb;
+        int in2 = i0 + VS_BX - 1;
+        if (in2 > b.ib) in2 = b.ib;
+        gl[slot * VT_PLANE + t * VT_LDX + VS_BX] = b.grad[m * nb + b.idx(in2, jn, kn)];
+    }
+}
+
+__global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __restrict__ tab, int nzb, KParams kp)
+{
+    __shared__ double gl[2 * VT_PLANE];     // two node planes (ring), 12 components, VT_ROWS x 65 nodes
+    const BlkView& b = tab[blockIdx.z / nzb + 1];      // level-batched: blockIdx.z = slot * nzb + k chunk
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int i0 = blockIdx.x * VS_BX + 2, j0 = blockIdx.y * VS_BY + 2;
-    const int i = i0 + tx, j = j0 + ty, k = blockIdx.z + 2;
+    const int i = i0 + tx, j = j0 + ty;
+    const int k0 = (blockIdx.z % nzb) * VT_KCH + 2;
+    if (b.nx == 0 || k0 > b.kl || i0 > b.il || j0 > b.jl) return;     // uniform per workgroup
+    const int k1 = (k0 + VT_KCH - 1 < b.kl) ? k0 + VT_KCH - 1 : b.kl;
     const long nb = b.nbox;
     const long si = 1, sj = b.ldi, sk = b.ldk;
-    // ---- stage the nodal gradients: row = (plane, component, node row); nodes i0-1 .. i0+63
-    {
-        int in = i0 - 1 + tx;
-        if (in > b.ib) in = b.ib;
-        for (int it = 0; it < (2 * 12 * VT_ROWS) / VS_BY; ++it) {
-            const int row = ty * ((2 * 12 * VT_ROWS) / VS_BY) + it;
-            const int pl = row / (12 * VT_ROWS), m = (row / VT_ROWS) % 12, r = row % VT_ROWS;
-            int jn = j0 - 1 + r;
-            if (jn > b.jb) jn = b.jb;
-            gl[row * VT_LDX + tx] = b.grad[m * nb + b.idx(in, jn, k - 1 + pl)];
-        }
-        const int t = ty * VS_BX + tx;      // the 65th node of every row
-        if (t < 2 * 12 * VT_ROWS) {
-            const int pl = t / (12 * VT_ROWS), m = (t / VT_ROWS) % 12, r = t % VT_ROWS;
-            int jn = j0 - 1 + r;
-            if (jn > b.jb) jn = b.jb;
-            int in2 = i0 + VS_BX - 1;
-            if (in2 > b.ib) in2 = b.ib;
-            gl[t * VT_LDX + VS_BX] = b.grad[m * nb + b.idx(in2, jn, k - 1 + pl)];
-        }
-    }
-    __syncthreads();
-    if (i > b.il || j > b.jl) return;
-    const long c = b.idx(i, j, k);
-    const uint8_t f0 = b.flags[c];
-    double acc[5] = {0, 0, 0, 0, 0};
-    const VCell C = vcell_at(b, kp, c);
-    // LDS offset (component 0) of this cell's corner node (i-1, j-1, k-1); +1 / +VT_LDX / +VT_PLANE step to i, j, k.
-    // Face nodes in the reference order (-s1-s2), (-s2), (-s1), (0) = base, base+D1, base+D2, base+D1+D2.
-    const int o000 = ty * VT_LDX + tx;
+    const bool valid = (i <= b.il && j <= b.jl);
     // reference sweep order k, j, i (fluxes.F90:2610, 2903, 3197); rolled: six inlined faces would not fit 256 VGPRs
     const long sd3[3] = {sk, sj, si};
-    const int Dd3[3] = {VT_PLANE, VT_LDX, 1};
     const int D13[3] = {1, 1, VT_LDX};            // s1 = si, si, sj
-    const int D23[3] = {VT_LDX, VT_PLANE, VT_PLANE};   // s2 = sj, sk, sk
     const double* sN3[3] = {b.sK, b.sJ, b.sI};
     const double* dN3[3] = {b.dK, b.dJ, b.dI};
     const int shift3[3] = {4, 2, 0};              // porosity bits of the direction inside the flag byte
+    int pLo = 0;                                   // slot of node plane k-1
+    vt_stage_plane(b, gl, pLo, i0, j0, k0 - 1, tx, ty);
+    for (int k = k0; k <= k1; ++k) {
+        const int pHi = 1 - pLo;
+        vt_stage_plane(b, gl, pHi, i0, j0, k, tx, ty);
+        __syncthreads();
+        if (valid) {
+            const long c = b.idx(i, j, k);
+            const uint8_t f0 = b.flags[c];
+            double acc[5] = {0, 0, 0, 0, 0};
+            const VCell C = vcell_at(b, kp, c);
+            // LDS offset (component 0) of this cell's corner node (i-1, j-1, k-1); +1 / +VT_LDX step to i, j; the k step
+            // goes to the other slot.  Face nodes in the reference order (-s1-s2), (-s2), (-s1), (0).
+            const int o000 = pLo * VT_PLANE + ty * VT_LDX + tx;
+            const int Dk = (pHi - pLo) * VT_PLANE;
+            const int Dd3[3] = {Dk, VT_LDX, 1};
+            const int D23[3] = {VT_LDX, Dk, Dk};  // s2 = sj, sk, sk
 #pragma unroll 1
-    for (int d = 0; d < 3; ++d) {
-        const long sd = sd3[d], cm = c - sd;
-        const double* __restrict__ sN = sN3[d];
-        const double* __restrict__ dN = dN3[d];
-        const VCell M = vcell_at(b, kp, cm), P = vcell_at(b, kp, c + sd);
-        const double nM[3] = {sN[cm], sN[cm + nb], sN[cm + 2 * nb]}, nP[3] = {sN[c], sN[c + nb], sN[c + 2 * nb]};
-        const double dM[3] = {dN[cm], dN[cm + nb], dN[cm + 2 * nb]}, dP[3] = {dN[c], dN[c + nb], dN[c + 2 * nb]};
-        const int porM = (b.flags[cm] >> shift3[d]) & 3, porP = (f0 >> shift3[d]) & 3;
-        const int D1 = D13[d], D2 = D23[d], oP = o000 + Dd3[d];
-        visc_face_t(kp, gl, o000, o000 + D1, o000 + D2, o000 + D1 + D2, M, C, nM, dM, porM, +1.0, acc);
-        visc_face_t(kp, gl, oP, oP + D1, oP + D2, oP + D1 + D2, C, P, nP, dP, porP, -1.0, acc);
-    }
-    const double blank = flg_blank(f0);
+            for (int d = 0; d < 3; ++d) {
+                const long sd = sd3[d], cm = c - sd;
+                const double* __restrict__ sN = sN3[d];
+                const double* __restrict__ dN = dN3[d];
+                const VCell M = vcell_at(b, kp, cm), P = vcell_at(b, kp, c + sd);
+                const double nM[3] = {sN[cm], sN[cm + nb], sN[cm + 2 * nb]}, nP[3] = {sN[c], sN[c + nb], sN[c + 2 * nb]};
+                const double dM[3] = {dN[cm], dN[cm + nb], dN[cm + 2 * nb]}, dP[3] = {dN[c], dN[c + nb], dN[c + 2 * nb]};
+                const int porM = (b.flags[cm] >> shift3[d]) & 3, porP = (f0 >> shift3[d]) & 3;
+                const int D1 = D13[d], D2 = D23[d], oP = o000 + Dd3[d];
+                visc_face_t(kp, gl, o000, o000 + D1, o000 + D2, o000 + D1 + D2, M, C, nM, dM, porM, +1.0, acc);
+                visc_face_t(kp, gl, oP, oP + D1, oP + D2, oP + D1 + D2, C, P, nP, dP, porP, -1.0, acc);
+            }
+            const double blank = flg_blank(f0);
 #pragma unroll
-    for (int l = 0; l < 5; ++l) {
-        const double fwn = b.fw[c + l * nb] + acc[l];
-        if (kp.fwMode) b.fw[c + l * nb] = fwn;
-        b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
+            for (int l = 0; l < 5; ++l) {
+                const double fwn = b.fw[c + l * nb] + acc[l];
+                if (kp.fwMode) b.fw[c + l * nb] = fwn;
+                b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
+            }
+        }
+        __syncthreads();        // every wave is done with plane k-1 before its slot takes plane k+1
+        pLo = pHi;
     }
 }
 
@@ -634,17 +657,26 @@ void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s)
     hipLaunchKernelGGL(k_viscous_approx, gc, blk, 0, s, b, kp);
 }
 
+// gather forms, one block per launch (tuning "viscous_tiled" = 0, kept for A/B measurements)
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
 {
     dim3 blk(VS_BX, VS_BY, 1);
     dim3 gn((b.il + 15 + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
-    if (g_viscous_tiled)
-        hipLaunchKernelGGL(k_nodal_gradients_t, dim3((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl), blk, 0, s, b);
-    else
-        hipLaunchKernelGGL(k_nodal_gradients, gn, blk, 0, s, b);
+    hipLaunchKernelGGL(k_nodal_gradients, gn, blk, 0, s, b);
     dim3 gc((b.nx + VS_BX - 1) / VS_BX, (b.ny + VS_BY - 1) / VS_BY, b.nz);
-    if (g_viscous_tiled)
-        hipLaunchKernelGGL(k_viscous_t, gc, blk, 0, s, b, kp);
-    else
-        hipLaunchKernelGGL(k_viscous, gc, blk, 0, s, b, kp);
+    hipLaunchKernelGGL(k_viscous, gc, blk, 0, s, b, kp);
 }
+
+// tiled forms, every block of the level in one launch each
+void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    dim3 blk(VS_BX, VS_BY, 1);
+    const int nzn = nz + 1;                              // node planes 1..kl
+    hipLaunchKernelGGL(k_nodal_gradients_t, dim3((nx + 1 + VS_BX - 1) / VS_BX, (ny + 1 + VS_BY - 1) / VS_BY, nzn * nslots), blk, 0, s,
+                       tab, nzn);
+    const int nch = (nz + VT_KCH - 1) / VT_KCH;
+    hipLaunchKernelGGL(k_viscous_t, dim3((nx + VS_BX - 1) / VS_BX, (ny + VS_BY - 1) / VS_BY, nch * nslots), blk, 0, s, tab, nch, kp);
+}
+
+int viscous_is_tiled() { return g_viscous_tiled; }
