@@ -442,11 +442,15 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     return 0;
 }
 
+static void bc_plan_drop(int level);
+static void bc_plan_drop_all();
+
 int adflow_gpu_block_release(int nn, int level, int sps)
 {
     auto it = g_blocks.find(Key(level, sps, nn));
     if (it == g_blocks.end()) return fail("block (%d,%d,%d) not registered", nn, level, sps);
     if (g_stream) (void)hipStreamSynchronize(g_stream);
+    bc_plan_drop(level);
     for (void* p : it->second->allocs) (void)hipFree(p);
     delete it->second;
     g_blocks.erase(it);
@@ -457,6 +461,7 @@ int adflow_gpu_block_release(int nn, int level, int sps)
 int adflow_gpu_release_all(void)
 {
     if (g_stream) (void)hipStreamSynchronize(g_stream);
+    bc_plan_drop_all();
     for (auto& kv : g_blocks) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
         delete kv.second;
@@ -738,6 +743,10 @@ int adflow_gpu_residual(int level, int rkStage)
 static int block_res_enqueue(int level, unsigned flags);
 static int apply_bc_enqueue(int level, int secondHalo);
 static int apply_turb_bc_enqueue(int level, int secondHalo);
+static int turb_bc_treatment_enqueue(int level, const KParams& kp);
+static int turb_bc_apply_enqueue(int level, const KParams& kp, int secondHalo);
+static int bc_coarse_corrections_enqueue(int coarseLevel, double fact);
+static void bc_plan_drop(int level);
 static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers);
 
 static int block_res_enqueue(int level, unsigned flags)
@@ -1090,6 +1099,7 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
     }
     b->bc = out;
     b->nViscBocos = nViscBocos;
+    bc_plan_drop(level);
     if (v.nw > 5 && !v.bmt[0]) {
         // face arrays of the implicit turbulence boundary treatment (bmt/bvt of blockPointers, one turbulence variable)
         const size_t nf[3] = {(size_t)v.je * v.ke, (size_t)v.ie * v.ke, (size_t)v.ie * v.je};
@@ -1106,37 +1116,166 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
     return 0;
 }
 
+// ---- launch plan of the boundary subfaces of a level (kernels_bc.hip): every subface of every block in one device
+// array; `flow` lists the launches of applyAllBC in the reference's order, `ordinal` the r-th subfaces of all blocks
+struct BcPlan {
+    BcEntry* d_ent = nullptr;
+    int* d_order = nullptr;
+    std::vector<BcPhase> flow, ordinal;
+    long maxFace = 0;
+    bool anyEulerWall = false;
+    int nent = 0;
+};
+static std::map<int, BcPlan> g_bcplan;
+
+static void bc_plan_drop(int level)
+{
+    auto it = g_bcplan.find(level);
+    if (it == g_bcplan.end()) return;
+    if (it->second.d_ent) (void)hipFree(it->second.d_ent);
+    if (it->second.d_order) (void)hipFree(it->second.d_order);
+    g_bcplan.erase(it);
+}
+
+static void bc_plan_drop_all()
+{
+    std::vector<int> levels;
+    for (auto& kv : g_bcplan) levels.push_back(kv.first);
+    for (int l : levels) bc_plan_drop(l);
+}
+
+static int bc_plan(int level, BcPlan** out)
+{
+    auto it = g_bcplan.find(level);
+    if (it != g_bcplan.end()) { *out = &it->second; return 0; }
+    BcPlan pl;
+    std::vector<BcEntry> ent;
+    struct Ref { int first, n, nVisc; };      // entries of one block: ent[first .. first+n)
+    std::vector<Ref> blocks;
+    for (auto& kv : g_blocks) {
+        if (std::get<0>(kv.first) != level || std::get<1>(kv.first) != 1) continue;
+        Block* b = kv.second;
+        if (b->bc.empty()) continue;
+        Ref r = {(int)ent.size(), (int)b->bc.size(), b->nViscBocos};
+        for (auto& f : b->bc) {
+            BcEntry e;
+            e.slot = std::get<2>(kv.first); e.pad = 0; e.f = f;
+            ent.push_back(e);
+            pl.anyEulerWall = pl.anyEulerWall || f.type == ADFLOW_BC_EULERWALL;
+        }
+        blocks.push_back(r);
+        const BlkView& v = b->v;
+        pl.maxFace = std::max(pl.maxFace, std::max(std::max((long)v.je * v.ke, (long)v.ie * v.ke), (long)v.ie * v.je));
+    }
+    pl.nent = (int)ent.size();
+    std::vector<int> order;
+    auto cells = [&](int e) { const BcFaceDev& f = ent[e].f; return (long)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1); };
+    // kinds in the order of applyAllBC_block (BCRoutines.F90:75-216); walls only among the first nViscBocos subfaces
+    auto match = [&](int kind, const BcFaceDev& f, bool inVisc) {
+        switch (kind) {
+        case BCP_SYMM1: case BCP_SYMM2: return f.type == ADFLOW_BC_SYMM;
+        case BCP_WALL_ADIABATIC: return inVisc && f.type == ADFLOW_BC_NSWALL_ADIABATIC;
+        case BCP_WALL_ISOTHERMAL: return inVisc && f.type == ADFLOW_BC_NSWALL_ISOTHERMAL;
+        case BCP_FARFIELD: return f.type == ADFLOW_BC_FARFIELD;
+        case BCP_EXTRAP: return f.type == ADFLOW_BC_EXTRAP || f.type == ADFLOW_BC_SUPERSONIC_OUTFLOW;
+        case BCP_EULERWALL: return f.type == ADFLOW_BC_EULERWALL;
+        case BCP_SUPERSONIC_INFLOW: return f.type == ADFLOW_BC_SUPERSONIC_INFLOW;
+        default: return true;
+        }
+    };
+    auto add_kind = [&](int kind, std::vector<BcPhase>& dst) {
+        for (int r = 0;; ++r) {       // r-th matching subface of every block: never two subfaces of one block together
+            BcPhase ph = {kind, (int)order.size(), 0, 0};
+            for (auto& rb : blocks) {
+                int seen = 0;
+                for (int m = 0; m < rb.n; ++m)
+                    if (match(kind, ent[rb.first + m].f, m < rb.nVisc)) {
+                        if (seen == r) { order.push_back(rb.first + m); ph.count++; ph.maxCells = std::max(ph.maxCells, cells(rb.first + m)); break; }
+                        ++seen;
+                    }
+            }
+            if (ph.count == 0) break;
+            dst.push_back(ph);
+        }
+    };
+    for (int kind : {BCP_SYMM1, BCP_SYMM2, BCP_WALL_ADIABATIC, BCP_WALL_ISOTHERMAL, BCP_FARFIELD, BCP_EXTRAP, BCP_EULERWALL,
+                     BCP_SUPERSONIC_INFLOW})
+        add_kind(kind, pl.flow);
+    add_kind(BCP_ORDINAL, pl.ordinal);
+    if (pl.nent > 0) {
+        HIPCHK(hipMalloc((void**)&pl.d_ent, sizeof(BcEntry) * ent.size()));
+        HIPCHK(hipMemcpy(pl.d_ent, ent.data(), sizeof(BcEntry) * ent.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&pl.d_order, sizeof(int) * order.size()));
+        HIPCHK(hipMemcpy(pl.d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
+    }
+    g_bcplan[level] = pl;
+    *out = &g_bcplan[level];
+    return 0;
+}
+
+// bcTurbTreatment of every block of the level with registered subfaces
+static int turb_bc_treatment_enqueue(int level, const KParams& kp)
+{
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return 1;
+    if (pl->nent == 0) return 0;
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_turb_bc_treatment(t.tab, t.n, pl->maxFace, pl->d_ent, pl->d_order, pl->ordinal, kp, g_stream);
+    return 0;
+}
+
+// applyAllTurbBCThisBlock(secondHalo) of every block of the level
+static int turb_bc_apply_enqueue(int level, const KParams& kp, int secondHalo)
+{
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return 1;
+    if (pl->nent == 0) return 0;
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_apply_turb_bc(t.tab, pl->d_ent, pl->d_order, pl->ordinal, kp, secondHalo, g_stream);
+    return 0;
+}
+
 // bcTurbTreatment + applyAllTurbBCThisBlock(secondHalo) for the blocks of `level` with registered subfaces
 static int apply_turb_bc_enqueue(int level, int secondHalo)
 {
     if (g_opts.equations != ADFLOW_RANS) return 0;
     KParams kp = make_kparams(level, 1.0, 0);
-    return for_level(level, [&](Block* b) {
-        if (b->bc.empty()) return 0;
-        launch_turb_bc_treatment(b->v, b->bc.data(), (int)b->bc.size(), kp, g_stream);
-        launch_apply_turb_bc(b->v, b->bc.data(), (int)b->bc.size(), kp, secondHalo, g_stream);
-        return 0;
-    });
+    if (turb_bc_treatment_enqueue(level, kp)) return 1;
+    return turb_bc_apply_enqueue(level, kp, secondHalo);
 }
 
 // applyAllBC (BCRoutines.F90:15-54) for the blocks of `level` that registered subfaces
 static int apply_bc_enqueue(int level, int secondHalo)
 {
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return 1;
+    if (pl->nent == 0) return 0;
     KParams kp = make_kparams(level, 1.0, 0);
-    if (g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_NORMAL_MOMENTUM || g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_QUADRATIC) {
-        bool any = false;
-        for (auto& kv : g_blocks)
-            if (std::get<0>(kv.first) == level)
-                for (auto& f : kv.second->bc) any = any || f.type == ADFLOW_BC_EULERWALL;
-        if (any) return fail("eulerWallBCTreatment=%d is not implemented on the device (1 constant, 2 linear)", g_opts.eulerWallBCTreatment);
-    }
+    if (pl->anyEulerWall &&
+        (g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_NORMAL_MOMENTUM || g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_QUADRATIC))
+        return fail("eulerWallBCTreatment=%d is not implemented on the device (1 constant, 2 linear)", g_opts.eulerWallBCTreatment);
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_apply_all_bc(t.tab, pl->d_ent, pl->d_order, pl->flow, kp, secondHalo, g_opts.eulerWallBCTreatment,
+                        g_opts.viscWallBCTreatment, g_opts.outflowTreatment, g_stream);
     return for_level(level, [&](Block* b) {
-        if (b->bc.empty()) return 0;
-        launch_apply_all_bc(b->v, b->bc.data(), (int)b->bc.size(), b->nViscBocos, kp, secondHalo, g_opts.eulerWallBCTreatment,
-                            g_opts.viscWallBCTreatment, g_opts.outflowTreatment, g_stream);
-        b->ss_valid = false;
+        if (!b->bc.empty()) b->ss_valid = false;
         return 0;
     });
+}
+
+// setCorrectionsCoarseHalos of every coarse block with subfaces (multiGrid.F90:472)
+static int bc_coarse_corrections_enqueue(int coarseLevel, double fact)
+{
+    BcPlan* pl;
+    if (bc_plan(coarseLevel, &pl)) return 1;
+    if (pl->nent == 0) return 0;
+    LevelTab t;
+    if (level_tab(coarseLevel, &t)) return 1;
+    launch_bc_coarse_corrections(t.tab, pl->d_ent, pl->d_order, pl->ordinal, fact, g_stream);
+    return 0;
 }
 
 int adflow_gpu_apply_all_bc(int level, int secondHalo)
@@ -1485,13 +1624,13 @@ static int transfer_to_fine_enqueue(int level)
     launch_corrections_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, g_stream);
     int rc = for_level_pairs(level, [&](Block* f, Block* c) {
         if (!f->v.mgICoarse) return fail("fine block has no mgICoarse map");
-        // setCorrectionsCoarseHalos (multiGrid.F90:472): fact = 0, mgBoundCorr = bcDirichlet0 (inputParamRoutines.F90:3923)
-        if (!c->bc.empty()) launch_bc_coarse_corrections(c->v, c->bc.data(), (int)c->bc.size(), 0.0, g_stream);
         f->ss_valid = false;
         f->etot_consistent = true;
         return 0;
     });
     if (rc) return rc;
+    // setCorrectionsCoarseHalos (multiGrid.F90:472): fact = 0, mgBoundCorr = bcDirichlet0 (inputParamRoutines.F90:3923)
+    if (bc_coarse_corrections_enqueue(level + 1, 0.0)) return 1;
     launch_prolong_update_level(tf.tab, tc.tab, tc.n, tf.nx, tf.ny, tf.nz, kf, g_stream);
     const int secondHalo = (level <= g_opts.groundLevel);
     if (apply_bc_enqueue(level, secondHalo)) return 1;
@@ -1701,18 +1840,14 @@ int adflow_gpu_sa_solve(int level)
         // sa_block(.false.) of every block: bcTurbTreatment first, applyAllTurbBCThisBlock(.true.) last (sa.F90:40-84)
         int rc = for_level(level, [&](Block* b) {
             if (b->v.nw < 6) return fail("RANS/SA needs nw = 6 (block has %d)", b->v.nw);
-            if (!b->bc.empty()) launch_turb_bc_treatment(b->v, b->bc.data(), (int)b->bc.size(), kp, g_stream);
             return 0;
         });
         if (rc) return rc;
+        if (turb_bc_treatment_enqueue(level, kp)) return 1;
         LevelTab t;
         if (level_tab(level, &t)) return 1;
         launch_sa_solve_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
-        rc = for_level(level, [&](Block* b) {
-            if (!b->bc.empty()) launch_apply_turb_bc(b->v, b->bc.data(), (int)b->bc.size(), kp, 1, g_stream);
-            return 0;
-        });
-        if (rc) return rc;
+        if (turb_bc_apply_enqueue(level, kp, 1)) return 1;
         if (g_turb_bc_callback) {
             HIPCHK(hipStreamSynchronize(g_stream));
             g_turb_bc_callback(level, 1);

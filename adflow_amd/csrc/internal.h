@@ -98,6 +98,11 @@ struct BcFaceDev {
     const double *norm, *rface, *uslip, *tns, *rho, *vx, *vy, *vz, *ps;
 };
 
+struct BcEntry { int slot, pad; BcFaceDev f; };     // one subface of the block in table slot `slot`
+enum { BCP_SYMM1, BCP_SYMM2, BCP_WALL_ADIABATIC, BCP_WALL_ISOTHERMAL, BCP_FARFIELD, BCP_EXTRAP, BCP_EULERWALL,
+       BCP_SUPERSONIC_INFLOW, BCP_ORDINAL };
+struct BcPhase { int kind, first, count; long maxCells; };   // one launch: entries order[first .. first+count)
+
 // porosity codes after the +1 shift used in `flags`
 #define ADF_POR_NOFLUX 0
 #define ADF_POR_BOUND 1
@@ -168,11 +173,16 @@ void launch_set_w(const BlkView& b, const double* vec, double turbFloor, hipStre
 void launch_get_r(const BlkView& b, double* vec, double turbScale, double* sums, hipStream_t s);
 void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);
-void launch_turb_bc_treatment(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, hipStream_t s);
-void launch_apply_turb_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, int second, hipStream_t s);
+#include <vector>
+void launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& flow,
+                         const KParams& kp, int second, int eulerWallTreatment, int viscWallTreatment, int outflowTreatment,
+                         hipStream_t s);
+void launch_turb_bc_treatment(const BlkView* tab, int nslots, long maxFace, const BcEntry* ent, const int* order,
+                              const std::vector<BcPhase>& ordinal, const KParams& kp, hipStream_t s);
+void launch_apply_turb_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& ordinal,
+                          const KParams& kp, int second, hipStream_t s);
+void launch_bc_coarse_corrections(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& ordinal,
+                                  double fact, hipStream_t s);
 void launch_corner_row_halos_level(const BlkView* tab, int nslots, const KParams& kp, hipStream_t s);
-void launch_bc_coarse_corrections(const BlkView& b, const BcFaceDev* faces, int nBocos, double fact, hipStream_t s);
 void launch_volume_metric(const BlkView& b, int rightHanded, hipStream_t s);
 void launch_boundary_normals(const BlkView& b, const BcFaceDev* faces, int nBocos, hipStream_t s);
-void launch_apply_all_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, int nVisc, const KParams& kp, int second,
-                         int eulerWallTreatment, int viscWallTreatment, int outflowTreatment, hipStream_t s);

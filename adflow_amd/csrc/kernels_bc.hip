@@ -19,8 +19,17 @@
 // Subfaces that share halo cells along block edges read what earlier subfaces wrote, so
 // they are separate launches in the reference's order.
 #include <algorithm>
+#include <vector>
 
 #include "internal.h"
+
+// Level-batched launches: the subfaces of every block of a level sit in one device array; a launch runs over a
+// list of entries (blockIdx.y) that may execute concurrently - never two overlapping subfaces of one block.
+#define BC_ARGS const BlkView* __restrict__ tab, const BcEntry* __restrict__ ent, const int* __restrict__ order
+#define BC_PROLOGUE                                   \
+    const BcEntry& e_ = ent[order[blockIdx.y]];       \
+    const BlkView& b = tab[e_.slot];                  \
+    const BcFaceDev& f = e_.f;
 
 struct BcSlab {            // cell offsets of the four slabs and the BCData index of one (i,j)
     long c0, c1, c2, c3;   // 2nd halo, 1st halo, 1st interior, 2nd interior
@@ -75,8 +84,9 @@ __device__ __forceinline__ void bc_second_halo(const BlkView& b, const KParams& 
 }
 
 // symmetry: layer 1 mirrors slab 2, layer 0 mirrors slab 3 (two separate passes in the reference)
-__global__ __launch_bounds__(256) void k_bc_symm(BlkView b, BcFaceDev f, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_bc_symm(BC_ARGS, KParams kp, int second)
 {
+    BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
@@ -97,8 +107,9 @@ __global__ __launch_bounds__(256) void k_bc_symm(BlkView b, BcFaceDev f, KParams
 
 // viscous walls; ISO: isothermal (wall temperature TNS_Wall)
 template <bool ISO>
-__global__ __launch_bounds__(256) void k_bc_nswall(BlkView b, BcFaceDev f, KParams kp, int second, int wallTreatment)
+__global__ __launch_bounds__(256) void k_bc_nswall(BC_ARGS, KParams kp, int second, int wallTreatment)
 {
+    BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
@@ -135,8 +146,9 @@ __global__ __launch_bounds__(256) void k_bc_nswall(BlkView b, BcFaceDev f, KPara
 // myDim (utils): max(x - y, 0)
 __device__ __forceinline__ double bc_mydim(double x, double y) { return fmax(x - y, 0.0); }
 
-__global__ __launch_bounds__(256) void k_bc_eulerwall(BlkView b, BcFaceDev f, KParams kp, int second, int wallTreatment)
+__global__ __launch_bounds__(256) void k_bc_eulerwall(BC_ARGS, KParams kp, int second, int wallTreatment)
 {
+    BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
@@ -157,8 +169,9 @@ __global__ __launch_bounds__(256) void k_bc_eulerwall(BlkView b, BcFaceDev f, KP
     if (second) bc_second_halo(b, kp, s);
 }
 
-__global__ __launch_bounds__(256) void k_bc_farfield(BlkView b, BcFaceDev f, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_bc_farfield(BC_ARGS, KParams kp, int second)
 {
+    BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
@@ -210,8 +223,12 @@ __global__ __launch_bounds__(256) void k_bc_farfield(BlkView b, BcFaceDev f, KPa
 }
 
 // extrap / supersonic outflow: fw2, fw3 = weights of slab 2 and 3
-__global__ __launch_bounds__(256) void k_bc_extrap(BlkView b, BcFaceDev f, KParams kp, int second, double fw2, double fw3)
+__global__ __launch_bounds__(256) void k_bc_extrap(BC_ARGS, KParams kp, int second, int outflowTreatment)
 {
+    BC_PROLOGUE
+    // extrap: linear; supersonic outflow: constant or linear (BCRoutines.F90:1512-1531)
+    double fw2 = 2.0, fw3 = -1.0;
+    if (f.type == ADFLOW_BC_SUPERSONIC_OUTFLOW && outflowTreatment == 1) { fw2 = 1.0; fw3 = 0.0; }
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
@@ -231,8 +248,9 @@ __global__ __launch_bounds__(256) void k_bc_extrap(BlkView b, BcFaceDev f, KPara
 }
 
 // supersonic inflow (BCRoutines.F90:1411-1477): both halo layers take the prescribed state
-__global__ __launch_bounds__(256) void k_bc_supersonic_inflow(BlkView b, BcFaceDev f, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_bc_supersonic_inflow(BC_ARGS, KParams kp, int second)
 {
+    BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
@@ -256,44 +274,32 @@ __global__ __launch_bounds__(256) void k_bc_supersonic_inflow(BlkView b, BcFaceD
     }
 }
 
-static dim3 bc_grid(const BcFaceDev& f)
-{
-    const long n = (long)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
-    return dim3((unsigned)((n + 255) / 256), 1, 1);
-}
+static dim3 bc_grid(const BcPhase& ph) { return dim3((unsigned)((ph.maxCells + 255) / 256), (unsigned)ph.count, 1); }
 
-// applyAllBC_block for one block: `faces` in registration order, the first nVisc are the viscous walls
-void launch_apply_all_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, int nVisc, const KParams& kp, int second,
-                         int eulerWallTreatment, int viscWallTreatment, int outflowTreatment, hipStream_t s)
+// applyAllBC for every block of the level: `flow` = launch plan in the reference's order (symm, symm 2nd halo pass,
+// adiabatic walls, isothermal walls, farfield, extrap / supersonic outflow, Euler wall, supersonic inflow; inside a
+// kind one launch per ordinal of the subface within its block)
+void launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& flow,
+                         const KParams& kp, int second, int eulerWallTreatment, int viscWallTreatment, int outflowTreatment,
+                         hipStream_t s)
 {
     const dim3 blk(256, 1, 1);
     // coarse levels force the constant-pressure wall treatment (BCRoutines.F90:552-553, 1098-1099)
     if (!kp.fineGrid) { eulerWallTreatment = ADFLOW_WALLBC_CONSTANT; viscWallTreatment = ADFLOW_WALLBC_CONSTANT; }
-    for (int m = 0; m < nBocos; ++m)
-        if (faces[m].type == ADFLOW_BC_SYMM) hipLaunchKernelGGL(k_bc_symm, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, 0);
-    if (second)
-        for (int m = 0; m < nBocos; ++m)
-            if (faces[m].type == ADFLOW_BC_SYMM) hipLaunchKernelGGL(k_bc_symm, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, 1);
-    for (int m = 0; m < nVisc; ++m)
-        if (faces[m].type == ADFLOW_BC_NSWALL_ADIABATIC)
-            hipLaunchKernelGGL((k_bc_nswall<false>), bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second, viscWallTreatment);
-    for (int m = 0; m < nVisc; ++m)
-        if (faces[m].type == ADFLOW_BC_NSWALL_ISOTHERMAL)
-            hipLaunchKernelGGL((k_bc_nswall<true>), bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second, viscWallTreatment);
-    for (int m = 0; m < nBocos; ++m)
-        if (faces[m].type == ADFLOW_BC_FARFIELD) hipLaunchKernelGGL(k_bc_farfield, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second);
-    for (int m = 0; m < nBocos; ++m)
-        if (faces[m].type == ADFLOW_BC_EXTRAP || faces[m].type == ADFLOW_BC_SUPERSONIC_OUTFLOW) {
-            double fw2 = 2.0, fw3 = -1.0;
-            if (faces[m].type == ADFLOW_BC_SUPERSONIC_OUTFLOW && outflowTreatment == 1) { fw2 = 1.0; fw3 = 0.0; }
-            hipLaunchKernelGGL(k_bc_extrap, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second, fw2, fw3);
+    for (const BcPhase& ph : flow) {
+        const int* o = order + ph.first;
+        switch (ph.kind) {
+        case BCP_SYMM1: hipLaunchKernelGGL(k_bc_symm, bc_grid(ph), blk, 0, s, tab, ent, o, kp, 0); break;
+        case BCP_SYMM2: if (second) hipLaunchKernelGGL(k_bc_symm, bc_grid(ph), blk, 0, s, tab, ent, o, kp, 1); break;
+        case BCP_WALL_ADIABATIC: hipLaunchKernelGGL((k_bc_nswall<false>), bc_grid(ph), blk, 0, s, tab, ent, o, kp, second, viscWallTreatment); break;
+        case BCP_WALL_ISOTHERMAL: hipLaunchKernelGGL((k_bc_nswall<true>), bc_grid(ph), blk, 0, s, tab, ent, o, kp, second, viscWallTreatment); break;
+        case BCP_FARFIELD: hipLaunchKernelGGL(k_bc_farfield, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second); break;
+        case BCP_EXTRAP: hipLaunchKernelGGL(k_bc_extrap, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second, outflowTreatment); break;
+        case BCP_EULERWALL: hipLaunchKernelGGL(k_bc_eulerwall, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second, eulerWallTreatment); break;
+        case BCP_SUPERSONIC_INFLOW: hipLaunchKernelGGL(k_bc_supersonic_inflow, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second); break;
+        default: break;
         }
-    for (int m = 0; m < nBocos; ++m)
-        if (faces[m].type == ADFLOW_BC_EULERWALL)
-            hipLaunchKernelGGL(k_bc_eulerwall, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second, eulerWallTreatment);
-    for (int m = 0; m < nBocos; ++m)
-        if (faces[m].type == ADFLOW_BC_SUPERSONIC_INFLOW)
-            hipLaunchKernelGGL(k_bc_supersonic_inflow, bc_grid(faces[m]), blk, 0, s, b, faces[m], kp, second);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -314,8 +320,10 @@ __device__ __forceinline__ long bc_face_entry(const BlkView& b, const BcFaceDev&
     return (long)(i - 1) + (long)A * (j - 1);
 }
 
-__global__ __launch_bounds__(256) void k_turb_bc_zero(BlkView b)
+__global__ __launch_bounds__(256) void k_turb_bc_zero(const BlkView* __restrict__ tab)
 {
+    const BlkView& b = tab[blockIdx.y + 1];
+    if (b.nx == 0 || !b.bmt[0]) return;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n[3] = {(long)b.je * b.ke, (long)b.ie * b.ke, (long)b.ie * b.je};
 #pragma unroll
@@ -326,11 +334,12 @@ __global__ __launch_bounds__(256) void k_turb_bc_zero(BlkView b)
         }
 }
 
-__global__ __launch_bounds__(256) void k_turb_bc_treatment(BlkView b, BcFaceDev f, KParams kp)
+__global__ __launch_bounds__(256) void k_turb_bc_treatment(BC_ARGS, KParams kp)
 {
+    BC_PROLOGUE
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n = (long)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
-    if (t >= n) return;
+    if (t >= n || !b.bmt[0]) return;
     // the face arrays only cover 1..ie x 1..je (turbBCRoutines.F90:684-735): skip range cells outside
     const int isize = f.icEnd - f.icBeg + 1;
     const int i = f.icBeg + (int)(t % isize), j = f.jcBeg + (int)(t / isize);
@@ -357,10 +366,11 @@ __global__ __launch_bounds__(256) void k_turb_bc_treatment(BlkView b, BcFaceDev 
     }
 }
 
-__global__ __launch_bounds__(256) void k_apply_turb_bc(BlkView b, BcFaceDev f, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_apply_turb_bc(BC_ARGS, KParams kp, int second)
 {
+    BC_PROLOGUE
     BcSlab s;
-    if (!bc_slab(b, f, s)) return;
+    if (!bc_slab(b, f, s) || !b.bmt[0]) return;
     int fi;
     const long e = bc_face_entry(b, f, s.f, &fi);
     const long nt = 5 * b.nbox;
@@ -375,18 +385,20 @@ __global__ __launch_bounds__(256) void k_apply_turb_bc(BlkView b, BcFaceDev f, K
     }
 }
 
-void launch_turb_bc_treatment(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, hipStream_t s)
+// `ordinal`: one launch per ordinal of a subface within its block (the r-th subfaces of all blocks together)
+void launch_turb_bc_treatment(const BlkView* tab, int nslots, long maxFace, const BcEntry* ent, const int* order,
+                              const std::vector<BcPhase>& ordinal, const KParams& kp, hipStream_t s)
 {
-    if (!b.bmt[0]) return;
-    const long nmax = std::max(std::max((long)b.je * b.ke, (long)b.ie * b.ke), (long)b.ie * b.je);
-    hipLaunchKernelGGL(k_turb_bc_zero, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, b);
-    for (int m = 0; m < nBocos; ++m) hipLaunchKernelGGL(k_turb_bc_treatment, bc_grid(faces[m]), dim3(256), 0, s, b, faces[m], kp);
+    hipLaunchKernelGGL(k_turb_bc_zero, dim3((unsigned)((maxFace + 255) / 256), nslots), dim3(256), 0, s, tab);
+    for (const BcPhase& ph : ordinal)
+        hipLaunchKernelGGL(k_turb_bc_treatment, bc_grid(ph), dim3(256), 0, s, tab, ent, order + ph.first, kp);
 }
 
-void launch_apply_turb_bc(const BlkView& b, const BcFaceDev* faces, int nBocos, const KParams& kp, int second, hipStream_t s)
+void launch_apply_turb_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& ordinal,
+                          const KParams& kp, int second, hipStream_t s)
 {
-    if (!b.bmt[0]) return;
-    for (int m = 0; m < nBocos; ++m) hipLaunchKernelGGL(k_apply_turb_bc, bc_grid(faces[m]), dim3(256), 0, s, b, faces[m], kp, second);
+    for (const BcPhase& ph : ordinal)
+        hipLaunchKernelGGL(k_apply_turb_bc, bc_grid(ph), dim3(256), 0, s, tab, ent, order + ph.first, kp, second);
 }
 
 // ---------------------------------------------------------------------------
@@ -449,8 +461,9 @@ void launch_corner_row_halos_level(const BlkView* tab, int nslots, const KParams
 }
 
 // corrections live in scratch(:,:,:,0:4) = d(rho), d(u), d(v), d(w), d(p) of the coarse block (kernels_mg.hip)
-__global__ __launch_bounds__(256) void k_bc_coarse_corrections(BlkView b, BcFaceDev f, double fact)
+__global__ __launch_bounds__(256) void k_bc_coarse_corrections(BC_ARGS, double fact)
 {
+    BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
@@ -470,7 +483,9 @@ __global__ __launch_bounds__(256) void k_bc_coarse_corrections(BlkView b, BcFace
     }
 }
 
-void launch_bc_coarse_corrections(const BlkView& b, const BcFaceDev* faces, int nBocos, double fact, hipStream_t s)
+void launch_bc_coarse_corrections(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& ordinal,
+                                  double fact, hipStream_t s)
 {
-    for (int m = 0; m < nBocos; ++m) hipLaunchKernelGGL(k_bc_coarse_corrections, bc_grid(faces[m]), dim3(256), 0, s, b, faces[m], fact);
+    for (const BcPhase& ph : ordinal)
+        hipLaunchKernelGGL(k_bc_coarse_corrections, bc_grid(ph), dim3(256), 0, s, tab, ent, order + ph.first, fact);
 }

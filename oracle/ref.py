@@ -262,6 +262,6 @@ def bind_blocks(blocks, prm, level: int = 1, nlevels: int = 1, alloc: bool = Tru
         alloc_doms(max(blocks), nlevels)
     for nn, b in sorted(blocks.items()):
         bind_block(b, prm)
-        if bocos and nn in bocos:
-            set_bocos(*bocos[nn])
+        if bocos is not None:
+            set_bocos(*bocos.get(nn, ([], 0)))
         commit_block(nn, level)

@@ -516,6 +516,66 @@ def setup_block_with_bc(engine, dims, prm, spec, seed, **mk):
     return blk, r, prm
 
 
+def setup_blocks_with_bc(engine, prm, blocks_spec, seed=91, **mk):
+    """Several unconnected blocks of different sizes on ONE level, each with its own set of boundary subfaces
+    ({nn: (dims, spec, split)}; spec None = a block without subfaces, slot numbers may have gaps): what the
+    level-batched boundary-condition launches see on a production multiblock mesh."""
+    from oracle import ref
+    from adflow_amd.synth import make_bocos
+    from adflow_amd.topology import CommPattern
+    engine.release_all()
+    prm = prm.replace(currentLevel=1, groundLevel=1)
+    blocks, bocos = {}, {}
+    for nn, (dims, spec, split) in blocks_spec.items():
+        blocks[nn] = make_block(*dims, prm, seed=seed + 13 * nn, **mk)
+        if spec:
+            bocos[nn] = make_bocos(blocks[nn], prm, spec, seed=seed + 13 * nn + 1, split=split)
+    rblocks = {nn: b.copy() for nn, b in blocks.items()}
+    ref.alloc_doms(max(blocks), 1)
+    ref.bind_blocks(rblocks, prm, level=1, nlevels=1, alloc=False, bocos=bocos)
+    empty = CommPattern()
+    engine.set_options(prm)
+    for nn, b in blocks.items():
+        engine.register(b, nn=nn, level=1)
+        if nn in bocos:
+            engine.bc_register(*bocos[nn], nn=nn, level=1)
+    for L in (1, 2):
+        ref.set_internal_comm(1, L, empty)
+        engine.comm_register(1, L, empty)
+    return blocks, rblocks, prm
+
+
+def check_multiblock_bc(engine, prm, blocks_spec, seed=91, **mk):
+    """applyAllBC over a level of several blocks with different subface lists, then (RANS) the SA solve and one
+    smoother sweep on them: the device groups the subfaces of all blocks by kind / position in the block's list,
+    the reference walks block by block."""
+    from oracle import ref
+    blocks, rblocks, prm = setup_blocks_with_bc(engine, prm, blocks_spec, seed, **mk)
+    for nn in sorted(rblocks):
+        ref.call_level("setPointers", 1, nn)
+        ref.call("applyAllBC_block", 1)
+    engine.applyAllBC(1, True)
+    assert_state(engine, blocks, rblocks, prm, "multiblock applyAllBC")
+    if prm.equations == RANSEquations:
+        for it in range(prm.nSubIterTurb):
+            for nn in sorted(rblocks):
+                ref.call_level("setPointers", 1, nn)
+                ref.call("sa_block", 0)
+            ref.load().ref_call_level(b"whalo2_turb", 1, 6, 6)
+        engine.turbSolveDDADI(1)
+        assert_state(engine, blocks, rblocks, prm, "multiblock SA DDADI solve with BCs")
+    name = "RungeKuttaSmoother" if prm.smoother == RungeKutta else "DADISmoother"
+    ref.load().ref_set_int(b"rkStage", 0)
+    ref.call_level("timeStep", 1, 0)
+    ref.call_level("initres", 1, 1, 5)
+    ref.call_level("residual", 1)
+    ref.call_level(name, 1)
+    engine.timeStep(1, False)
+    engine.residual(1, 0)
+    getattr(engine, name)(1)
+    assert_state(engine, blocks, rblocks, prm, f"multiblock {name} with BCs")
+
+
 def check_sa_solve_with_bc(engine, dims, prm, spec, seed=71, **mk):
     """turbSolveDDADI on a block with physical boundaries: bcTurbTreatment (bmt/bvt), their implicit part in the
     central jacobian (sa.F90:452-468, turbUtils.F90:986-1004) and applyAllTurbBCThisBlock(.true.) on the device."""

@@ -114,3 +114,16 @@ def test_apply_all_bc_split_faces(engine):
     checks.check_apply_bc(engine, (40, 9, 6), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}, split={3: -6, 6: -5, 1: -6})
     checks.check_apply_bc(engine, (24, 8, 6), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6},
                           split={5: -6, 4: -3}, stretch_k=2.0)
+
+
+def test_multiblock_bc(engine):
+    """several blocks with different subface lists: the level-batched BC launches against the reference's block loop"""
+    checks.check_multiblock_bc(engine, FlowParams(), {
+        1: ((40, 9, 6), {1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}, {3: -6, 6: -5}),
+        2: ((70, 7, 5), None, ()),
+        3: ((12, 10, 8), {2: -6, 3: -5, 6: -7}, ()),
+        4: ((9, 8, 8), {1: -5, 2: -5, 3: -5, 4: -5, 5: -5, 6: -5}, {1: -6})})
+    checks.check_multiblock_bc(engine, FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging), {
+        1: ((24, 8, 6), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, {5: -6, 4: -3}),
+        2: ((70, 6, 6), {3: -3, 4: -6}, ()),
+        3: ((10, 12, 8), {1: -6, 2: -9, 3: -3, 4: -6, 5: -1, 6: -1}, ())}, stretch_k=2.0)
