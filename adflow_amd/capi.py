@@ -35,7 +35,7 @@ class AdflowOpts(ctypes.Structure):
         ("eulerWallBCTreatment", c_int32),
         ("viscWallBCTreatment", c_int32),
         ("outflowTreatment", c_int32),
-        ("reserved_i", c_int32),
+        ("lowSpeedPreconditioner", c_int32),
         ("gammaConstant", c_double), ("prandtl", c_double), ("prandtlTurb", c_double),
         ("SSuthDim", c_double), ("muSuthDim", c_double), ("TSuthDim", c_double),
         ("SAKappa", c_double), ("SAcb1", c_double), ("SAcb2", c_double), ("SAsigma", c_double), ("SAcv1", c_double),
@@ -119,7 +119,7 @@ EXPORTS = [
     "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
-    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc",
+    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress",
     "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
@@ -158,6 +158,7 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_set_async.argtypes = [c_int]
     lib.adflow_gpu_bc_register.argtypes = [c_int, c_int, c_int, c_int, c_int, POINTER(AdflowBcSubface)]
     lib.adflow_gpu_apply_all_bc.argtypes = [c_int, c_int]
+    lib.adflow_gpu_download_wall_stress.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.adflow_gpu_upload_coordinates.argtypes = [c_int, c_int, c_int]
     lib.adflow_gpu_update_geometry.argtypes = [c_int]
     lib.adflow_gpu_reference_shock_sensor.argtypes = [c_int]

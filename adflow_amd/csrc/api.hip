@@ -680,7 +680,28 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
     return sync_and_check();
 }
 
-static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false)
+static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox);
+
+// residual (residuals.F90:1028) = residual_block of every block; blockResCore (blockette.F90:755) is the same sum of
+// fluxes WITHOUT the low-speed preconditioner of residual_block (residuals.F90:172-331) -> lowSpeed = false there.
+static int wall_stress_enqueue(int level, const KParams& kp);
+
+// stage0: the reference's rkStage is 0 at this call -> on the ground level viscousFlux also stores the wall stress tensor
+// and heat flux of the viscous subfaces (storeWallTensor, fluxes.F90:2586-2592)
+static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false, bool lowSpeed = true, bool stage0 = true)
+{
+    if (enqueue_flow_fluxes(level, kp, viscApprox)) return 1;
+    if (stage0 && !viscApprox && kp.viscous && level == g_opts.groundLevel && fabs(kp.rFil) >= 1.e-10)
+        if (wall_stress_enqueue(level, kp)) return 1;
+    if (lowSpeed && g_opts.lowSpeedPreconditioner) {
+        LevelTab t;
+        if (level_tab(level, &t)) return 1;
+        launch_low_speed_precond_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    }
+    return 0;
+}
+
+static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox)
 {
     if (g_use_march && !kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.fineGrid && !kp.dissApprox) {
         // Euler + scalar JST: one k-marching launch over every block of the level
@@ -735,7 +756,7 @@ int adflow_gpu_residual(int level, int rkStage)
         fwMode = 1;
     }
     KParams kp = make_kparams(level, rFil, fwMode);
-    int rc = enqueue_flow_residual(level, kp);
+    int rc = enqueue_flow_residual(level, kp, false, true, rkStage == 0);
     if (rc) return rc;
     return sync_and_check();
 }
@@ -796,7 +817,7 @@ static int block_res_enqueue(int level, unsigned flags)
         launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
     if (flags & ADFLOW_RES_FLOW) {
-        rc = enqueue_flow_residual(level, kp, viscApprox);
+        rc = enqueue_flow_residual(level, kp, viscApprox, false);
         if (rc) return rc;
     }
     return 0;
@@ -1095,6 +1116,19 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
         if (up(f.norm, 3, &d.norm) || up(f.rface, 1, &d.rface) || up(f.uSlip, 3, &d.uslip) || up(f.TNS_Wall, 1, &d.tns) ||
             up(f.rho, 1, &d.rho) || up(f.velx, 1, &d.vx) || up(f.vely, 1, &d.vy) || up(f.velz, 1, &d.vz) || up(f.ps, 1, &d.ps))
             return 1;
+        d.tauq = nullptr;
+        if (m < nViscBocos) {
+            int r[4];
+            bc_owned_range(f.faceID, f.icBeg, f.icEnd, f.jcBeg, f.jcEnd, v.il, v.jl, v.kl, r);
+            const long no = (long)std::max(0, r[1] - r[0] + 1) * std::max(0, r[3] - r[2] + 1);
+            if (no > 0) {
+                void* raw = nullptr;
+                HIPCHK(hipMalloc(&raw, sizeof(double) * 9 * no));
+                HIPCHK(hipMemsetAsync(raw, 0, sizeof(double) * 9 * no, g_stream));
+                b->allocs.push_back(raw);
+                d.tauq = (double*)raw;
+            }
+        }
         out.push_back(d);
     }
     b->bc = out;
@@ -1122,6 +1156,7 @@ struct BcPlan {
     BcEntry* d_ent = nullptr;
     int* d_order = nullptr;
     std::vector<BcPhase> flow, ordinal;
+    BcPhase wall = {0, 0, 0, 0};   // the viscous subfaces (wall stress storage), any order
     long maxFace = 0;
     bool anyEulerWall = false;
     int nent = 0;
@@ -1202,6 +1237,13 @@ static int bc_plan(int level, BcPlan** out)
                      BCP_SUPERSONIC_INFLOW})
         add_kind(kind, pl.flow);
     add_kind(BCP_ORDINAL, pl.ordinal);
+    pl.wall.first = (int)order.size();
+    for (int e = 0; e < (int)ent.size(); ++e)
+        if (ent[e].f.tauq) {
+            order.push_back(e);
+            pl.wall.count++;
+            pl.wall.maxCells = std::max(pl.wall.maxCells, cells(e));
+        }
     if (pl.nent > 0) {
         HIPCHK(hipMalloc((void**)&pl.d_ent, sizeof(BcEntry) * ent.size()));
         HIPCHK(hipMemcpy(pl.d_ent, ent.data(), sizeof(BcEntry) * ent.size(), hipMemcpyHostToDevice));
@@ -1264,6 +1306,34 @@ static int apply_bc_enqueue(int level, int secondHalo)
         if (!b->bc.empty()) b->ss_valid = false;
         return 0;
     });
+}
+
+// viscSubface(:)%tau / %q of every viscous subface of the level, from the nodal gradients the viscous kernels just used
+static int wall_stress_enqueue(int level, const KParams& kp)
+{
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return 1;
+    if (pl->wall.count == 0) return 0;
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_wall_stress(t.tab, pl->d_ent, pl->d_order, pl->wall, kp, g_stream);
+    return 0;
+}
+
+int adflow_gpu_download_wall_stress(int nn, int level, int sps, int mm, double* tau, double* q)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (mm < 1 || mm > b->nViscBocos || mm > (int)b->bc.size()) return fail("download_wall_stress: subface %d is not a viscous subface of block %d", mm, nn);
+    const BcFaceDev& f = b->bc[mm - 1];
+    int r[4];
+    bc_owned_range(f.faceID, f.icBeg, f.icEnd, f.jcBeg, f.jcEnd, b->v.il, b->v.jl, b->v.kl, r);
+    const long no = (long)std::max(0, r[1] - r[0] + 1) * std::max(0, r[3] - r[2] + 1);
+    if (no == 0 || !f.tauq) return 0;
+    HIPCHK(hipStreamSynchronize(g_stream));
+    if (tau) HIPCHK(hipMemcpy(tau, f.tauq, sizeof(double) * 6 * no, hipMemcpyDeviceToHost));
+    if (q) HIPCHK(hipMemcpy(q, f.tauq + 6 * no, sizeof(double) * 3 * no, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // setCorrectionsCoarseHalos of every coarse block with subfaces (multiGrid.F90:472)
@@ -1507,7 +1577,7 @@ int adflow_gpu_rk_smooth(int level)
     const int nst = g_opts.nRKStages;
     for (int stage = 1; stage <= nst; ++stage) {
         KParams kp = make_kparams(level, 1.0, 1);
-        const double scale = kp.cfl * g_opts.etaRK[stage - 1];
+        const double scale = (g_opts.lowSpeedPreconditioner ? 0.8 : 1.0) * kp.cfl * g_opts.etaRK[stage - 1];   // smoothers.F90:202
         if (smooth_residual(stage)) {
             launch_scale_dw_level(t.tab, t.n, t.nx, t.ny, t.nz, scale, 0, g_stream);
             if (res_averaging_level(level, kp)) return 1;
@@ -1518,7 +1588,7 @@ int adflow_gpu_rk_smooth(int level)
         if (stage < nst) {
             // residual of the next stage: rkStage = stage -> rFil = cdisRK(stage+1)
             KParams kr = make_kparams(level, g_opts.cdisRK[stage], 1);
-            if (enqueue_flow_residual(level, kr)) return 1;
+            if (enqueue_flow_residual(level, kr, false, true, false)) return 1;
         }
     }
     return sync_and_check();

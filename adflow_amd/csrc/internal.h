@@ -96,7 +96,18 @@ struct BlkView {
 struct BcFaceDev {
     int type, faceID, icBeg, icEnd, jcBeg, jcEnd;
     const double *norm, *rface, *uslip, *tns, *rho, *vx, *vy, *vz, *ps;
+    double* tauq;          // viscous subfaces: viscSubface%tau(:,:,1:6), %q(:,:,1:3) over the OWNED face cells, component-major
 };
+
+// owned face cells of a subface (the node range inBeg+1..inEnd of viscSubfaceInfo, preprocessingAPI.F90:2520-2524)
+__host__ __device__ inline void bc_owned_range(int faceID, int icBeg, int icEnd, int jcBeg, int jcEnd, int il, int jl, int kl, int r[4])
+{
+    const int amax = (faceID <= 2) ? jl : il, bmax = (faceID <= 4) ? kl : jl;
+    r[0] = icBeg > 2 ? icBeg : 2;
+    r[1] = icEnd < amax ? icEnd : amax;
+    r[2] = jcBeg > 2 ? jcBeg : 2;
+    r[3] = jcEnd < bmax ? jcEnd : bmax;
+}
 
 struct BcEntry { int slot, pad; BcFaceDev f; };     // one subface of the block in table slot `slot`
 enum { BCP_SYMM1, BCP_SYMM2, BCP_WALL_ADIABATIC, BCP_WALL_ISOTHERMAL, BCP_FARFIELD, BCP_EXTRAP, BCP_EULERWALL,
@@ -145,6 +156,7 @@ void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStre
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 int viscous_is_tiled();
+void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, const KParams& kp, hipStream_t s);
 void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_face_vectors(const BlkView& b, hipStream_t s);
 void launch_sa_residual_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
@@ -152,6 +164,7 @@ void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int n
 void launch_rk_save_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s);
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s);
 void launch_scale_dw_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double factor, int timesVol, hipStream_t s);
+void launch_low_speed_precond_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_stage_update_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, double scale,
                                int fromWn, hipStream_t s);
 void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);

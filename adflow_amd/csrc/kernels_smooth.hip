@@ -88,6 +88,56 @@ void launch_scale_dw_level(const BlkView* tab, int nslots, int maxnx, int maxny,
     hipLaunchKernelGGL(k_scale_dw, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, factor, timesVol);
 }
 
+// Low-speed preconditioner of residual_block (residuals.F90:172-331): dw <- B(w,p,gamma) * dw on the owned cells, with B the
+// 5x5 product of the conservative->primitive jacobian and the low-Mach matrix A of that routine (K1, K2, M0 as there).
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_low_speed_precond(const BlkView* __restrict__ tab, int nzb, double uInf2)
+{
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
+    const long c = b.idx(i, j, k), nb = b.nbox;
+    constexpr double K1 = 1.05, K2 = 0.6, M0 = 0.2;
+    const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    const double gam = b.gamma[c], g1 = gam - 1.0;
+    const double SoS = sqrt(gam * b.p[c] / rho), a2 = SoS * SoS, a4 = a2 * a2;
+    const double q = u * u + v * v + w * w;
+    const double resM = sqrt(q) / SoS, M2 = resM * resM;
+    const double K3 = K1 * (1.0 + ((1.0 - K1 * M0 * M0) * M2) / (K1 * M0 * M0 * M0 * M0));
+    const double betaMr2 = fmin(fmax(K3 * q, K2 * uInf2), a2);
+    // rows of A: only columns 1, the diagonal and 5 are populated
+    const double A1[5] = {betaMr2 * (1.0 / a4), 0.0, 0.0, 0.0, -betaMr2 / a4};
+    const double A2[5] = {u / a2, rho, 0.0, 0.0, -u / a2};
+    const double A3[5] = {v / a2, 0.0, rho, 0.0, -v / a2};
+    const double A4[5] = {w / a2, 0.0, 0.0, rho, -w / a2};
+    const double A5[5] = {1.0 / g1 + M2 / 2.0, rho * u, rho * v, rho * w, -M2 / 2.0};
+    double d[5];
+#pragma unroll
+    for (int l = 0; l < 5; ++l) d[l] = b.dw[c + l * nb];
+    const double h = g1 * q / 2.0, omg = 1.0 - gam;
+    auto row = [&](const double* A) {
+        const double B1 = A[0] * h + A[1] * (-u) / rho + A[2] * (-v) / rho + A[3] * (-w) / rho + A[4] * (h - a2);
+        const double B2 = A[0] * omg * u + A[1] / rho + A[4] * omg * u;
+        const double B3 = A[0] * omg * v + A[2] / rho + A[4] * omg * v;
+        const double B4 = A[0] * omg * w + A[3] / rho + A[4] * omg * w;
+        const double B5 = A[0] * g1 + A[4] * g1;
+        return B1 * d[0] + B2 * d[1] + B3 * d[2] + B4 * d[3] + B5 * d[4];
+    };
+    b.dw[c] = row(A1);
+    b.dw[c + nb] = row(A2);
+    b.dw[c + 2 * nb] = row(A3);
+    b.dw[c + 3 * nb] = row(A4);
+    b.dw[c + 4 * nb] = row(A5);
+}
+
+void launch_low_speed_precond_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    const double uInf2 = kp.wInf[1] * kp.wInf[1] + kp.wInf[2] * kp.wInf[2] + kp.wInf[3] * kp.wInf[3];
+    hipLaunchKernelGGL(k_low_speed_precond, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, uInf2);
+}
+
 // State update of one stage.  FROM_WN: Runge-Kutta (new = stage-0 state - dw),
 // otherwise D-ADI (new = current - dw).  scale != 0: dw is first multiplied by
 // scale*dtl (fused k_scale_dw when no residual averaging sits in between).

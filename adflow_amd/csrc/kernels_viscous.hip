@@ -222,7 +222,8 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients_t(const BlkVie
 // viscous flux through the face between cells cL and cL+sd (fluxes.F90:2610-2860);
 // the four face nodes are cL, cL-s1, cL-s2, cL-s1-s2.
 __device__ __forceinline__ void visc_face(const BlkView& b, const KParams& kp, long cL, long sd, long s1, long s2,
-                                          const double* __restrict__ sN, int por_code, double sign, double acc[5])
+                                          const double* __restrict__ sN, int por_code, double sign, double acc[5],
+                                          double* tq = nullptr)
 {
     const long nb = b.nbox;
     const long cR = cL + sd;
@@ -289,6 +290,11 @@ __device__ __forceinline__ void visc_face(const BlkView& b, const KParams& kp, l
         tauxx = mut * tauxxS; tauyy = mut * tauyyS; tauzz = mut * tauzzS;
         tauxy = mut * tauxyS; tauxz = mut * tauxzS; tauyz = mut * tauyzS;
     }
+    if (tq) {   // wall stress tensor / heat flux of a viscous subface (fluxes.F90:2861-2892)
+        tq[0] = tauxx; tq[1] = tauyy; tq[2] = tauzz; tq[3] = tauxy; tq[4] = tauxz; tq[5] = tauyz;
+        tq[6] = q_x; tq[7] = q_y; tq[8] = q_z;
+        return;
+    }
     const double ubar = 0.5 * (uL + uR), vbar = 0.5 * (vL + vR), wbar = 0.5 * (wL + wR);
     const double nx = sN[cL], ny = sN[cL + nb], nz = sN[cL + 2 * nb];
     const double fmx = tauxx * nx + tauxy * ny + tauxz * nz;
@@ -339,6 +345,51 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous(BlkView b, KParams kp)
         if (kp.fwMode) b.fw[c + l * nb] = fwn;
         b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
     }
+}
+
+// Stress tensor and heat flux vector on the faces of the viscous-wall subfaces: what viscousFlux stores in
+// viscSubface(:)%tau / %q when storeWallTensor is set (rkStage == 0 on the ground level, fluxes.F90:2586-2592,
+// 2861-2892, 3155-3185, 3450-3480).  Same face evaluation as the flux kernels, from the nodal gradients they left in
+// b.grad; blockIdx.y = subface entry of the level's boundary plan.
+__global__ __launch_bounds__(256) void k_wall_stress(const BlkView* __restrict__ tab, const BcEntry* __restrict__ ent,
+                                                     const int* __restrict__ order, KParams kp)
+{
+    const BcEntry& e = ent[order[blockIdx.y]];
+    const BcFaceDev& f = e.f;
+    if (!f.tauq) return;
+    const BlkView& b = tab[e.slot];
+    int r[4];
+    bc_owned_range(f.faceID, f.icBeg, f.icEnd, f.jcBeg, f.jcEnd, b.il, b.jl, b.kl, r);
+    const int na = r[1] - r[0] + 1, nbb = r[3] - r[2] + 1;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (na <= 0 || nbb <= 0 || t >= (long)na * nbb) return;
+    const int a = r[0] + (int)(t % na), bb = r[2] + (int)(t / na);
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+    long cL, sd, s1, s2;
+    const double* sN;
+    int por;
+    switch (f.faceID) {
+    case ADFLOW_IMIN: case ADFLOW_IMAX:
+        cL = b.idx(f.faceID == ADFLOW_IMIN ? 1 : b.il, a, bb); sd = si; s1 = sj; s2 = sk; sN = b.sI; por = flg_porI(b.flags[cL]);
+        break;
+    case ADFLOW_JMIN: case ADFLOW_JMAX:
+        cL = b.idx(a, f.faceID == ADFLOW_JMIN ? 1 : b.jl, bb); sd = sj; s1 = si; s2 = sk; sN = b.sJ; por = flg_porJ(b.flags[cL]);
+        break;
+    default:
+        cL = b.idx(a, bb, f.faceID == ADFLOW_KMIN ? 1 : b.kl); sd = sk; s1 = si; s2 = sj; sN = b.sK; por = flg_porK(b.flags[cL]);
+    }
+    double tq[9], acc[5];
+    visc_face(b, kp, cL, sd, s1, s2, sN, por, 1.0, acc, tq);
+    const long n = (long)na * nbb;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) f.tauq[m * n + t] = tq[m];
+}
+
+void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, const KParams& kp, hipStream_t s)
+{
+    if (ph.count <= 0 || ph.maxCells <= 0) return;
+    hipLaunchKernelGGL(k_wall_stress, dim3((unsigned)((ph.maxCells + 255) / 256), ph.count, 1), dim3(256, 1, 1), 0, s, tab, ent,
+                       order + ph.first, kp);
 }
 
 // ---------------------------------------------------------------------------

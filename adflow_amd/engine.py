@@ -125,6 +125,13 @@ class Engine:
                     setattr(arr[m], k, a.ctypes.data)
         self._chk(self.lib.adflow_gpu_bc_register(nn, level, sps, len(faces), int(nViscBocos), arr))
 
+    def wall_stress(self, shape, mm: int, nn: int = 1, level: int = 1, sps: int = 1):
+        """viscSubface(mm)%tau, %q of viscous subface mm (1-based) over its owned face cells `shape` = (n1, n2)"""
+        tau = np.zeros(tuple(shape) + (6,), order="F")
+        q = np.zeros(tuple(shape) + (3,), order="F")
+        self._chk(self.lib.adflow_gpu_download_wall_stress(nn, level, sps, mm, tau.ctypes.data, q.ctypes.data))
+        return tau, q
+
     def upload_coordinates(self, nn=1, level=1, sps=1):
         self._chk(self.lib.adflow_gpu_upload_coordinates(nn, level, sps))
 

@@ -21,7 +21,7 @@ module adflowGpuShim
         integer(c_int32_t) :: groundLevel
         integer(c_int32_t) :: turbRelax
         integer(c_int32_t) :: eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment
-        integer(c_int32_t) :: reserved_i
+        integer(c_int32_t) :: lowSpeedPreconditioner
         real(c_double) :: gammaConstant, prandtl, prandtlTurb
         real(c_double) :: SSuthDim, muSuthDim, TSuthDim
         real(c_double) :: SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot
@@ -82,6 +82,12 @@ module adflowGpuShim
         integer(c_int) function adflow_gpu_apply_all_bc(level, secondHalo) bind(C, name="adflow_gpu_apply_all_bc")
             import :: c_int
             integer(c_int), value :: level, secondHalo
+        end function
+        integer(c_int) function adflow_gpu_download_wall_stress(nn, level, sps, mm, tau, q) &
+            bind(C, name="adflow_gpu_download_wall_stress")
+            import :: c_int, c_ptr
+            integer(c_int), value :: nn, level, sps, mm
+            type(c_ptr), value :: tau, q
         end function
         integer(c_int) function adflow_gpu_comm_register(level, nLayers, p) bind(C, name="adflow_gpu_comm_register")
             import :: c_int, adflow_comm_pattern
@@ -200,7 +206,7 @@ contains
         o%turbRelax = turbRelax
         o%eulerWallBCTreatment = eulerWallBCTreatment; o%viscWallBCTreatment = viscWallBCTreatment
         o%outflowTreatment = outflowTreatment
-        o%reserved_i = 0
+        o%lowSpeedPreconditioner = merge(1, 0, lowSpeedPreconditioner)
         o%gammaConstant = gammaConstant; o%prandtl = prandtl; o%prandtlTurb = prandtlTurb
         o%SSuthDim = SSuthDim; o%muSuthDim = muSuthDim; o%TSuthDim = TSuthDim
         o%SAKappa = SAKappa; o%SAcb1 = SAcb1; o%SAcb2 = SAcb2; o%SAsigma = SAsigma; o%SAcv1 = SAcv1
@@ -336,5 +342,18 @@ contains
         call gpuCheck(adflow_gpu_bc_register(int(nn, c_int), int(level, c_int), int(sps, c_int), int(nb, c_int), &
                                              int(flowDoms(nn, level, sps)%nViscBocos, c_int), f), "gpuRegisterBocos")
     end subroutine gpuRegisterBocos
+
+    ! viscSubface(:)%tau / %q of a block <- device (what viscousFlux stored with storeWallTensor); call before the host's
+    ! force integration (surfaceIntegrations.F90:718) or computeUtau
+    subroutine gpuDownloadWallStress(nn, level, sps)
+        use block, only: flowDoms
+        integer(kind=intType), intent(in) :: nn, level, sps
+        integer :: mm
+        do mm = 1, flowDoms(nn, level, sps)%nViscBocos
+            call gpuCheck(adflow_gpu_download_wall_stress(int(nn, c_int), int(level, c_int), int(sps, c_int), int(mm, c_int), &
+                                                          c_loc(flowDoms(nn, level, sps)%viscSubface(mm)%tau), &
+                                                          c_loc(flowDoms(nn, level, sps)%viscSubface(mm)%q)), "gpuDownloadWallStress")
+        end do
+    end subroutine gpuDownloadWallStress
 
 end module adflowGpuShim

@@ -86,6 +86,7 @@ class FlowParams:
     eulerWallBCTreatment: int = 2
     viscWallBCTreatment: int = 1
     outflowTreatment: int = 1
+    lowSpeedPreconditioner: bool = False
     alfaTurb: float = 0.8
     betaTurb: float = -1.0
     # --- iteration

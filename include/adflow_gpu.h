@@ -89,7 +89,7 @@ typedef struct adflow_opts {
     /* inputDiscretization: boundary treatment (constants.F90:170-178): 1 constant, 2 linear, 4 normal momentum;
      * outflowTreatment 1 constant, 2 linear extrapolation */
     int32_t eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment;
-    int32_t reserved_i;
+    int32_t lowSpeedPreconditioner;   /* inputDiscretization: residual_block's 5x5 low-Mach transform (residuals.F90:172-331) + the 0.8 RK step factor (smoothers.F90:202) */
     double gammaConstant, prandtl, prandtlTurb;
     double SSuthDim, muSuthDim, TSuthDim;
     double SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot;
@@ -275,6 +275,13 @@ int adflow_gpu_set_bc_callback(adflow_bc_callback fn);
  * in/outflow, normal-momentum Euler wall: registration of those returns an error). */
 int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBocos, const adflow_bc_subface* faces);
 int adflow_gpu_apply_all_bc(int level, int secondHalo);
+/* viscSubface(mm)%tau(:,:,1:6) and %q(:,:,1:3) of viscous subface mm (1-based, mm <= nViscBocos): the wall stress tensor and
+ * heat flux that viscousFlux stores when rkStage == 0 on the ground level (storeWallTensor, fluxes.F90:2586-2592, 2861-2892)
+ * and that the host's force integration reads (surfaceIntegrations.F90:718).  The arrays cover the owned face cells
+ * inBeg+1:inEnd x jnBeg+1:jnEnd as allocated by viscSubfaceInfo (preprocessingAPI.F90:2520-2541); either may be NULL.
+ * The device stores them after every such residual evaluation (adflow_gpu_residual with rkStage 0, the D-ADI smoother,
+ * the multigrid cycle's closing residual, adflow_gpu_block_res). */
+int adflow_gpu_download_wall_stress(int nn, int level, int sps, int mm, double* tau, double* q);
 /* sum over owned cells of (dw(:,l)/vol)^2, l=1..n  (solvers.F90:1538) */
 int adflow_gpu_res_norms(int level, double* sums, int n);
 

@@ -51,7 +51,7 @@ def load(fast: bool = False) -> ctypes.CDLL:
 _INT_PARAMS = ["equations", "spaceDiscr", "spaceDiscrCoarse", "limiter", "orderTurb", "turbModel", "turbProd",
                "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb", "nSubiterations", "turbRelax",
                "eulerWallBCTreatment", "viscWallBCTreatment", "outflowTreatment"]
-_BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA"]
+_BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA", "lowSpeedPreconditioner"]
 _REAL_PARAMS = ["vis2", "vis4", "vis2Coarse", "adis", "acousticScaleFactor", "kappaCoef", "sigma", "cfl",
                 "cflCoarse", "cflLimit", "fcoll", "smoop", "alfaTurb", "betaTurb", "rFil", "gammaConstant",
                 "gammaInf", "pInf", "pInfCorr", "rhoInf", "uInf", "RGas", "muInf", "muRef", "TRef", "timeRef",
@@ -71,9 +71,9 @@ def set_params(prm) -> None:
     for n in _REAL_PARAMS:
         lib.ref_set_real(n.encode(), float(getattr(prm, n)))
     # fixed settings of every BASELINE config: steady, calorically perfect gas,
-    # no preconditioner, no wall functions, no dissipation continuation
+    # no time-derivative preconditioner (precond), no wall functions, no dissipation continuation
     for n, v in (("equationMode", 1), ("cpModel", 1), ("precond", 1), ("kPresent", 0), ("lumpedDiss", 0),
-                 ("approxSA", 0), ("radiiNeededFine", 1), ("radiiNeededCoarse", 1), ("lowSpeedPreconditioner", 0),
+                 ("approxSA", 0), ("radiiNeededFine", 1), ("radiiNeededCoarse", 1),
                  ("wallFunctions", 0), ("useDissContinuation", 0), ("nTimeIntervalsSpectral", 1),
                  ("vortexCorr", 0), ("riemann", 1), ("riemannCoarse", 1), ("turbTreatment", 1)):
         lib.ref_set_int(n.encode(), v)
@@ -165,6 +165,19 @@ def set_bocos(faces, nViscBocos=0) -> None:
             if a is not None:
                 assert a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, k
                 lib.ref_set_bcdata(m + 1, k.encode(), a.ctypes.data)
+
+
+def wall_stress(mm: int):
+    """viscSubface(mm)%tau (n1,n2,6), %q (n1,n2,3) of the currently bound block (mm 1-based)"""
+    lib = load()
+    dims = (ctypes.c_int * 2)()
+    big = 1 << 16
+    tau = np.zeros(6 * big)
+    q = np.zeros(3 * big)
+    lib.ref_get_wall_stress(ctypes.c_int(mm), tau.ctypes.data_as(ctypes.c_void_p), q.ctypes.data_as(ctypes.c_void_p), dims)
+    n1, n2 = dims[0], dims[1]
+    assert n1 * n2 <= big
+    return (tau[:6 * n1 * n2].reshape((n1, n2, 6), order="F").copy(), q[:3 * n1 * n2].reshape((n1, n2, 3), order="F").copy())
 
 
 def _big_stack(fn, *args):

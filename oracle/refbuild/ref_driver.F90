@@ -432,7 +432,7 @@ contains
         use blockPointers
         integer(c_int), value :: nBocos_, nViscBocos_
         integer(c_int), intent(in) :: types(*), faceIDs(*), ranges(4, *)
-        integer :: mm
+        integer :: mm, n1, n2, iBeg, iEnd, jBeg, jEnd
         nBocos = nBocos_; nViscBocos = nViscBocos_
         nullify (BCType, BCFaceID, BCData, globalCell, s)
         allocate (BCType(max(nBocos, 1)), BCFaceID(max(nBocos, 1)), BCData(max(nBocos, 1)))
@@ -446,7 +446,50 @@ contains
             nullify (BCData(mm)%norm, BCData(mm)%rface, BCData(mm)%uSlip, BCData(mm)%TNS_Wall, BCData(mm)%rho, &
                      BCData(mm)%velx, BCData(mm)%vely, BCData(mm)%velz, BCData(mm)%ps)
         end do
+        ! what preprocessingAPI.F90:2430-2581 (viscSubfaceInfo) sets up: storage of the wall stress tensor / heat flux
+        ! of the viscous subfaces (their owned face cells) and the visc*Pointer maps into it
+        nullify (viscSubface)
+        allocate (viscSubface(max(nViscBocos, 1)))
+        if (associated(viscIminPointer)) then
+            viscIminPointer = 0; viscImaxPointer = 0; viscJminPointer = 0
+            viscJmaxPointer = 0; viscKminPointer = 0; viscKmaxPointer = 0
+        end if
+        do mm = 1, nViscBocos
+            select case (BCFaceID(mm))
+            case (iMin, iMax); n1 = jl; n2 = kl
+            case (jMin, jMax); n1 = il; n2 = kl
+            case default; n1 = il; n2 = jl
+            end select
+            iBeg = max(BCData(mm)%icBeg, 2); iEnd = min(BCData(mm)%icEnd, n1)
+            jBeg = max(BCData(mm)%jcBeg, 2); jEnd = min(BCData(mm)%jcEnd, n2)
+            BCData(mm)%inBeg = iBeg - 1; BCData(mm)%inEnd = iEnd
+            BCData(mm)%jnBeg = jBeg - 1; BCData(mm)%jnEnd = jEnd
+            allocate (viscSubface(mm)%tau(iBeg:iEnd, jBeg:jEnd, 6), viscSubface(mm)%q(iBeg:iEnd, jBeg:jEnd, 3), &
+                      viscSubface(mm)%utau(iBeg:iEnd, jBeg:jEnd))
+            viscSubface(mm)%tau = zero; viscSubface(mm)%q = zero; viscSubface(mm)%utau = zero
+            select case (BCFaceID(mm))
+            case (iMin); viscIminPointer(iBeg:iEnd, jBeg:jEnd) = mm
+            case (iMax); viscImaxPointer(iBeg:iEnd, jBeg:jEnd) = mm
+            case (jMin); viscJminPointer(iBeg:iEnd, jBeg:jEnd) = mm
+            case (jMax); viscJmaxPointer(iBeg:iEnd, jBeg:jEnd) = mm
+            case (kMin); viscKminPointer(iBeg:iEnd, jBeg:jEnd) = mm
+            case (kMax); viscKmaxPointer(iBeg:iEnd, jBeg:jEnd) = mm
+            end select
+        end do
     end subroutine ref_set_bocos
+
+    ! viscSubface(mm)%tau / %q of the current block -> caller arrays (n1, n2, 6) / (n1, n2, 3); dims returns n1, n2
+    subroutine ref_get_wall_stress(mm, tau, q, dims) bind(C, name="ref_get_wall_stress")
+        use blockPointers
+        integer(c_int), value :: mm
+        real(c_double), intent(out) :: tau(*), q(*)
+        integer(c_int), intent(out) :: dims(2)
+        integer :: n
+        dims(1) = size(viscSubface(mm)%tau, 1); dims(2) = size(viscSubface(mm)%tau, 2)
+        n = dims(1) * dims(2)
+        tau(1:6 * n) = reshape(viscSubface(mm)%tau, [6 * n])
+        q(1:3 * n) = reshape(viscSubface(mm)%q, [3 * n])
+    end subroutine ref_get_wall_stress
 
     ! member `name` of BCData(mm) => caller-owned array with the reference's bounds
     subroutine ref_set_bcdata(mm, name, ptr) bind(C, name="ref_set_bcdata")
@@ -690,7 +733,7 @@ contains
             d%iBegor = 1; d%iEndor = il; d%jBegor = 1; d%jEndor = jl; d%kBegor = 1; d%kEndor = kl
             d%nSubface = 0; d%n1to1 = 0; d%nBocos = nBocos; d%nViscBocos = nViscBocos
             d%BCType => BCType; d%BCFaceID => BCFaceID; d%BCData => BCData
-            d%globalCell => globalCell; d%s => s
+            d%globalCell => globalCell; d%s => s; d%viscSubface => viscSubface
             d%nOrphans = 0
             d%blockIsMoving = .false.; d%addGridVelocities = .false.
             d%iblank => iblank

@@ -160,6 +160,40 @@ def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, s
     return blk, r
 
 
+def check_wall_stress(engine, dims, prm, spec, split=(), seed=57, dadi=False, **mk):
+    """viscSubface(:)%tau / %q: the wall stress tensor and heat flux viscousFlux stores for the viscous subfaces when
+    rkStage == 0 on the ground level (fluxes.F90:2586-2592, 2861-2892 k, 3155-3185 j, 3450-3480 i)."""
+    from oracle import ref
+    from adflow_amd.synth import make_bocos
+    new_level(engine)
+    prm = prm.replace(currentLevel=1, groundLevel=1)
+    blk = make_block(*dims, prm, seed=seed, **mk)
+    faces, nvisc = make_bocos(blk, prm, spec, seed=seed + 1, split=split)
+    assert nvisc > 0
+    r = blk.copy()
+    ref.bind_block(r, prm)
+    ref.set_bocos(faces, nvisc)
+    ref.call("applyAllBC_block", 1)
+    ref.load().ref_set_int(b"rkStage", 0)
+    ref.call("timeStep_block", 0)
+    ref.call("initres_flow")
+    ref.call("residual_block")
+    engine.set_options(prm)
+    engine.register(blk, nn=1, level=1)
+    engine.bc_register(faces, nvisc, nn=1, level=1)
+    engine.applyAllBC(1, True)
+    engine.timeStep(1, False)
+    engine.residual(1, 0)
+    for mm in range(1, nvisc + 1):
+        tau_r, q_r = ref.wall_stress(mm)
+        tau, q = engine.wall_stress(tau_r.shape[:2], mm)
+        assert np.abs(tau_r).max() > 0
+        e = max(rel_err(tau, tau_r), rel_err(q, q_r))
+        assert e <= TOL, (mm, faces[mm - 1]["faceID"], e)
+    dw = engine.download_residual(1, 1)
+    assert_dw(blk, dw, r["dw"], 5, what="dw with wall stress storage")
+
+
 def check_update_geometry(engine, dims, prm, spec, seed=81, **mk):
     """volume_block + metric_block + boundaryNormals (adjointExtra.F90:5-364) after the nodes moved: vol, sI/sJ/sK
     and - through a boundary-condition pass that reads them - the unit normals of the boundary subfaces."""

@@ -53,3 +53,12 @@ def test_block_res_visc_approx_only(engine):
     from adflow_amd.params import NSEquations
     checks.check_block_res_approx(engine, (24, 20, 10), FlowParams(equations=NSEquations, sigma=0.3), diss_approx=False,
                                   visc_approx=True, stretch_k=2.0)
+
+
+def test_wall_stress_storage(engine):
+    """a7 / a17 useStoreWall: viscSubface%tau, %q on all six block faces, split subfaces, QCR"""
+    from adflow_amd.params import NSEquations
+    checks.check_wall_stress(engine, (70, 9, 8), FlowParams(equations=NSEquations), {1: -3, 2: -4, 3: -3, 4: -6, 5: -4, 6: -3},
+                             stretch_k=2.0)
+    checks.check_wall_stress(engine, (24, 10, 8), FlowParams(equations=RANSEquations, useQCR=True),
+                             {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, split={5: -6, 4: -3}, stretch_k=2.0)

@@ -68,3 +68,16 @@ def test_smoothers_with_blanked_cells(engine):
     checks.check_rk_smoother(engine, topo, FlowParams(), holes=0.1)
     checks.check_dadi_smoother(engine, topo, FlowParams(resAveraging=noResAveraging, cfl=1.5), holes=0.1)
     checks.check_sa_solve(engine, topo, FlowParams(equations=RANSEquations, nSubIterTurb=2), holes=0.1, stretch_k=2.0)
+
+
+def test_low_speed_preconditioner(engine):
+    """residual_block's 5x5 low-Mach transform (residuals.F90:172-331) and the 0.8 RK step factor (smoothers.F90:202);
+    blocketteRes does not apply it (blockette.F90:755-852)"""
+    from adflow_amd.params import DADI, upwind
+    lo = dict(lowSpeedPreconditioner=True, Mach=0.15)
+    checks.check_rk_residual_sequence(engine, (70, 9, 7), FlowParams(**lo))
+    checks.check_rk_residual_sequence(engine, (24, 10, 8), FlowParams(equations=RANSEquations, spaceDiscr=upwind, **lo), stretch_k=2.0)
+    checks.check_rk_smoother(engine, BrickTopology(2, 1, 1, 20, 9, 8), FlowParams(resAveraging=alternateResAveraging, **lo))
+    checks.check_dadi_smoother(engine, BrickTopology(1, 2, 1, 16, 8, 8),
+                               FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, **lo), stretch_k=2.0)
+    checks.check_block_res(engine, (20, 10, 8), FlowParams(**lo), seed=5)

@@ -207,6 +207,26 @@ def test_apply_all_bc_split_faces(hostsim_engine):
                           split={5: -6, 4: -3}, stretch_k=2.0)
 
 
+def test_low_speed_preconditioner(hostsim_engine):
+    """residual_block's 5x5 low-Mach transform (residuals.F90:172-331) and the 0.8 RK step factor (smoothers.F90:202);
+    blocketteRes does not apply it (blockette.F90:755-852)"""
+    lo = dict(lowSpeedPreconditioner=True, Mach=0.15)
+    checks.check_rk_residual_sequence(hostsim_engine, (9, 7, 5), FlowParams(**lo))
+    checks.check_rk_residual_sequence(hostsim_engine, (8, 6, 5), FlowParams(equations=RANSEquations, spaceDiscr=upwind, **lo), stretch_k=2.0)
+    checks.check_rk_smoother(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams(resAveraging=alternateResAveraging, **lo))
+    checks.check_dadi_smoother(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
+                               FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, **lo), stretch_k=2.0)
+    checks.check_block_res(hostsim_engine, (8, 6, 5), FlowParams(**lo), seed=5)
+
+
+def test_wall_stress_storage(hostsim_engine):
+    """a7 / a17 useStoreWall: viscSubface%tau, %q on all six block faces, split subfaces, QCR"""
+    checks.check_wall_stress(hostsim_engine, (6, 5, 4), FlowParams(equations=NSEquations), {1: -3, 2: -4, 3: -3, 4: -6, 5: -4, 6: -3},
+                             stretch_k=2.0)
+    checks.check_wall_stress(hostsim_engine, (7, 5, 4), FlowParams(equations=RANSEquations, useQCR=True),
+                             {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, split={5: -6, 4: -3}, stretch_k=2.0)
+
+
 def test_multiblock_bc(hostsim_engine):
     """several blocks with different subface lists: the level-batched BC launches against the reference's block loop"""
     checks.check_multiblock_bc(hostsim_engine, FlowParams(), {
