@@ -35,7 +35,7 @@ class AdflowOpts(ctypes.Structure):
         ("eulerWallBCTreatment", c_int32),
         ("viscWallBCTreatment", c_int32),
         ("outflowTreatment", c_int32),
-        ("lowSpeedPreconditioner", c_int32),
+        ("hScalingInlet", c_int32), ("reserved_i", c_int32), ("lowSpeedPreconditioner", c_int32),
         ("gammaConstant", c_double), ("prandtl", c_double), ("prandtlTurb", c_double),
         ("SSuthDim", c_double), ("muSuthDim", c_double), ("TSuthDim", c_double),
         ("SAKappa", c_double), ("SAcb1", c_double), ("SAcb2", c_double), ("SAsigma", c_double), ("SAcv1", c_double),
@@ -59,14 +59,22 @@ class AdflowBcSubface(ctypes.Structure):
     _fields_ = [
         ("bcType", c_int32), ("faceID", c_int32),
         ("icBeg", c_int32), ("icEnd", c_int32), ("jcBeg", c_int32), ("jcEnd", c_int32),
+        ("subsonicInletTreatment", c_int32), ("reserved", c_int32),
         ("norm", c_void_p), ("rface", c_void_p), ("uSlip", c_void_p), ("TNS_Wall", c_void_p),
         ("rho", c_void_p), ("velx", c_void_p), ("vely", c_void_p), ("velz", c_void_p), ("ps", c_void_p),
+        ("ptInlet", c_void_p), ("ttInlet", c_void_p), ("htInlet", c_void_p),
+        ("flowXdirInlet", c_void_p), ("flowYdirInlet", c_void_p), ("flowZdirInlet", c_void_p), ("turbInlet", c_void_p),
     ]
+
+
+BC_ARRAYS = ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps", "ptInlet", "ttInlet", "htInlet",
+             "flowXdirInlet", "flowYdirInlet", "flowZdirInlet", "turbInlet")
 
 
 # BCType / BCFaceID values (src/modules/constants.F90:257-297)
 BC_SYMM, BC_NSWALL_ADIABATIC, BC_NSWALL_ISOTHERMAL, BC_EULERWALL, BC_FARFIELD = -1, -3, -4, -5, -6
 BC_SUPERSONIC_INFLOW, BC_SUPERSONIC_OUTFLOW, BC_EXTRAP = -7, -9, -15
+BC_SYMM_POLAR, BC_SUBSONIC_INFLOW, BC_SUBSONIC_OUTFLOW, BC_MASSBLEED_OUTFLOW = -2, -8, -10, -12
 IMIN, IMAX, JMIN, JMAX, KMIN, KMAX = 1, 2, 3, 4, 5, 6
 
 
@@ -119,7 +127,7 @@ EXPORTS = [
     "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
-    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress",
+    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2",
     "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",

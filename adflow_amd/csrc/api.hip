@@ -1083,10 +1083,11 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
         switch (f.bcType) {
         case ADFLOW_BC_SYMM: case ADFLOW_BC_NSWALL_ADIABATIC: case ADFLOW_BC_NSWALL_ISOTHERMAL: case ADFLOW_BC_EULERWALL:
         case ADFLOW_BC_FARFIELD: case ADFLOW_BC_SUPERSONIC_INFLOW: case ADFLOW_BC_SUPERSONIC_OUTFLOW: case ADFLOW_BC_EXTRAP:
+        case ADFLOW_BC_SYMM_POLAR: case ADFLOW_BC_SUBSONIC_INFLOW: case ADFLOW_BC_SUBSONIC_OUTFLOW: case ADFLOW_BC_MASSBLEED_OUTFLOW:
             break;
         default:
             return fail("bc_register: block %d subface %d: BCType %d is not implemented on the device "
-                        "(symmPolar, subsonic in/outflow, bleeds stay with the host callback)", nn, m + 1, f.bcType);
+                        "(inflow bleeds, mDot / thrust, domain and sliding interfaces stay with the host callback)", nn, m + 1, f.bcType);
         }
         if (f.faceID < ADFLOW_IMIN || f.faceID > ADFLOW_KMAX) return fail("bc_register: block %d subface %d: BCFaceID %d", nn, m + 1, f.faceID);
         // generic subface indices run over the two in-plane directions of the block face (utils.F90:881-1175)
@@ -1095,7 +1096,23 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
         if (f.icBeg < 0 || f.icEnd > amax || f.jcBeg < 0 || f.jcEnd > bmax || f.icEnd < f.icBeg || f.jcEnd < f.jcBeg)
             return fail("bc_register: block %d subface %d: cell range %d:%d x %d:%d outside the block face", nn, m + 1, f.icBeg,
                         f.icEnd, f.jcBeg, f.jcEnd);
-        const bool needNorm = (f.bcType == ADFLOW_BC_SYMM || f.bcType == ADFLOW_BC_EULERWALL || f.bcType == ADFLOW_BC_FARFIELD);
+        const bool subOut = (f.bcType == ADFLOW_BC_SUBSONIC_OUTFLOW || f.bcType == ADFLOW_BC_MASSBLEED_OUTFLOW);
+        const bool subIn = (f.bcType == ADFLOW_BC_SUBSONIC_INFLOW);
+        const bool needNorm = (f.bcType == ADFLOW_BC_SYMM || f.bcType == ADFLOW_BC_EULERWALL || f.bcType == ADFLOW_BC_FARFIELD || subOut || subIn);
+        if (subOut && !f.ps) return fail("bc_register: block %d subface %d: BCData%%ps is required", nn, m + 1);
+        if (subIn) {
+            if (f.subsonicInletTreatment == ADFLOW_INLET_TOTAL_CONDITIONS) {
+                if (!(f.ptInlet && f.ttInlet && f.htInlet && f.flowXdirInlet && f.flowYdirInlet && f.flowZdirInlet))
+                    return fail("bc_register: block %d subface %d: ptInlet, ttInlet, htInlet, flow[XYZ]dirInlet are required", nn, m + 1);
+            } else if (f.subsonicInletTreatment == ADFLOW_INLET_MASS_FLOW) {
+                if (!(f.rho && f.velx && f.vely && f.velz)) return fail("bc_register: block %d subface %d: rho, velx, vely, velz are required", nn, m + 1);
+            } else
+                return fail("bc_register: block %d subface %d: subsonicInletTreatment=%d (1 total conditions, 2 mass flow)", nn, m + 1,
+                            f.subsonicInletTreatment);
+        }
+        if (f.bcType == ADFLOW_BC_SYMM_POLAR && !v.x) return fail("bc_register: block %d subface %d: symmPolar needs the node coordinates x", nn, m + 1);
+        if ((subIn || f.bcType == ADFLOW_BC_SUPERSONIC_INFLOW) && v.nw > 5 && !f.turbInlet)
+            return fail("bc_register: block %d subface %d: BCData%%turbInlet is required for an inflow subface of a RANS block", nn, m + 1);
         if (needNorm && !f.norm) return fail("bc_register: block %d subface %d: BCData%%norm is required", nn, m + 1);
         if (f.bcType == ADFLOW_BC_NSWALL_ISOTHERMAL && !f.TNS_Wall) return fail("bc_register: block %d subface %d: TNS_Wall is required", nn, m + 1);
         if (f.bcType == ADFLOW_BC_SUPERSONIC_INFLOW && !(f.rho && f.velx && f.vely && f.velz && f.ps))
@@ -1114,8 +1131,11 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
         BcFaceDev d;
         d.type = f.bcType; d.faceID = f.faceID; d.icBeg = f.icBeg; d.icEnd = f.icEnd; d.jcBeg = f.jcBeg; d.jcEnd = f.jcEnd;
         if (up(f.norm, 3, &d.norm) || up(f.rface, 1, &d.rface) || up(f.uSlip, 3, &d.uslip) || up(f.TNS_Wall, 1, &d.tns) ||
-            up(f.rho, 1, &d.rho) || up(f.velx, 1, &d.vx) || up(f.vely, 1, &d.vy) || up(f.velz, 1, &d.vz) || up(f.ps, 1, &d.ps))
+            up(f.rho, 1, &d.rho) || up(f.velx, 1, &d.vx) || up(f.vely, 1, &d.vy) || up(f.velz, 1, &d.vz) || up(f.ps, 1, &d.ps) ||
+            up(f.ptInlet, 1, &d.pt) || up(f.ttInlet, 1, &d.tt) || up(f.htInlet, 1, &d.ht) || up(f.flowXdirInlet, 1, &d.fdx) ||
+            up(f.flowYdirInlet, 1, &d.fdy) || up(f.flowZdirInlet, 1, &d.fdz) || up(v.nw > 5 ? f.turbInlet : nullptr, 1, &d.turbInlet))
             return 1;
+        d.inletTreatment = f.subsonicInletTreatment; d.pad = 0;
         d.tauq = nullptr;
         if (m < nViscBocos) {
             int r[4];
@@ -1215,6 +1235,9 @@ static int bc_plan(int level, BcPlan** out)
         case BCP_EXTRAP: return f.type == ADFLOW_BC_EXTRAP || f.type == ADFLOW_BC_SUPERSONIC_OUTFLOW;
         case BCP_EULERWALL: return f.type == ADFLOW_BC_EULERWALL;
         case BCP_SUPERSONIC_INFLOW: return f.type == ADFLOW_BC_SUPERSONIC_INFLOW;
+        case BCP_SYMMPOLAR1: case BCP_SYMMPOLAR2: return f.type == ADFLOW_BC_SYMM_POLAR;
+        case BCP_SUBSONIC_OUTFLOW: return f.type == ADFLOW_BC_SUBSONIC_OUTFLOW || f.type == ADFLOW_BC_MASSBLEED_OUTFLOW;
+        case BCP_SUBSONIC_INFLOW: return f.type == ADFLOW_BC_SUBSONIC_INFLOW;
         default: return true;
         }
     };
@@ -1233,8 +1256,8 @@ static int bc_plan(int level, BcPlan** out)
             dst.push_back(ph);
         }
     };
-    for (int kind : {BCP_SYMM1, BCP_SYMM2, BCP_WALL_ADIABATIC, BCP_WALL_ISOTHERMAL, BCP_FARFIELD, BCP_EXTRAP, BCP_EULERWALL,
-                     BCP_SUPERSONIC_INFLOW})
+    for (int kind : {BCP_SYMM1, BCP_SYMM2, BCP_SYMMPOLAR1, BCP_SYMMPOLAR2, BCP_WALL_ADIABATIC, BCP_WALL_ISOTHERMAL, BCP_FARFIELD,
+                     BCP_SUBSONIC_OUTFLOW, BCP_SUBSONIC_INFLOW, BCP_EXTRAP, BCP_EULERWALL, BCP_SUPERSONIC_INFLOW})
         add_kind(kind, pl.flow);
     add_kind(BCP_ORDINAL, pl.ordinal);
     pl.wall.first = (int)order.size();
@@ -1301,7 +1324,7 @@ static int apply_bc_enqueue(int level, int secondHalo)
     LevelTab t;
     if (level_tab(level, &t)) return 1;
     launch_apply_all_bc(t.tab, pl->d_ent, pl->d_order, pl->flow, kp, secondHalo, g_opts.eulerWallBCTreatment,
-                        g_opts.viscWallBCTreatment, g_opts.outflowTreatment, g_stream);
+                        g_opts.viscWallBCTreatment, g_opts.outflowTreatment, g_opts.hScalingInlet, g_stream);
     return for_level(level, [&](Block* b) {
         if (!b->bc.empty()) b->ss_valid = false;
         return 0;
@@ -2009,6 +2032,13 @@ int adflow_gpu_abi_sizes(int* opts_bytes, int* desc_bytes)
 {
     if (opts_bytes) *opts_bytes = (int)sizeof(adflow_opts);
     if (desc_bytes) *desc_bytes = (int)sizeof(adflow_block_desc);
+    return 0;
+}
+
+int adflow_gpu_abi_sizes2(int* bc_subface_bytes, int* comm_pattern_bytes)
+{
+    if (bc_subface_bytes) *bc_subface_bytes = (int)sizeof(adflow_bc_subface);
+    if (comm_pattern_bytes) *comm_pattern_bytes = (int)sizeof(adflow_comm_pattern);
     return 0;
 }
 

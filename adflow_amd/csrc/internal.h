@@ -96,6 +96,9 @@ struct BlkView {
 struct BcFaceDev {
     int type, faceID, icBeg, icEnd, jcBeg, jcEnd;
     const double *norm, *rface, *uslip, *tns, *rho, *vx, *vy, *vz, *ps;
+    const double *pt, *tt, *ht, *fdx, *fdy, *fdz;   // subsonic inflow with total conditions
+    const double* turbInlet;                       // prescribed turbulence variable of inflow subfaces
+    int inletTreatment, pad;
     double* tauq;          // viscous subfaces: viscSubface%tau(:,:,1:6), %q(:,:,1:3) over the OWNED face cells, component-major
 };
 
@@ -111,7 +114,7 @@ __host__ __device__ inline void bc_owned_range(int faceID, int icBeg, int icEnd,
 
 struct BcEntry { int slot, pad; BcFaceDev f; };     // one subface of the block in table slot `slot`
 enum { BCP_SYMM1, BCP_SYMM2, BCP_WALL_ADIABATIC, BCP_WALL_ISOTHERMAL, BCP_FARFIELD, BCP_EXTRAP, BCP_EULERWALL,
-       BCP_SUPERSONIC_INFLOW, BCP_ORDINAL };
+       BCP_SUPERSONIC_INFLOW, BCP_SYMMPOLAR1, BCP_SYMMPOLAR2, BCP_SUBSONIC_OUTFLOW, BCP_SUBSONIC_INFLOW, BCP_ORDINAL };
 struct BcPhase { int kind, first, count; long maxCells; };   // one launch: entries order[first .. first+count)
 
 // porosity codes after the +1 shift used in `flags`
@@ -188,7 +191,7 @@ void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);
 #include <vector>
 void launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& flow,
-                         const KParams& kp, int second, int eulerWallTreatment, int viscWallTreatment, int outflowTreatment,
+                         const KParams& kp, int second, int eulerWallTreatment, int viscWallTreatment, int outflowTreatment, int hScalingInlet,
                          hipStream_t s);
 void launch_turb_bc_treatment(const BlkView* tab, int nslots, long maxFace, const BcEntry* ent, const int* order,
                               const std::vector<BcPhase>& ordinal, const KParams& kp, hipStream_t s);

@@ -3,6 +3,9 @@
 // Reference semantics (src/solver/BCRoutines.F90):
 //   applyAllBC_block      :57-221   order of the kinds, subfaces in index order
 //   bcSymm1stHalo/2ndHalo :223-330
+//   bcSymmPolar1st/2ndHalo:332-487
+//   bcSubsonicOutflow     :693-802  (also outflow mass bleeds)
+//   bcSubsonicInflow      :804-1061 (total conditions / mass flow; cpConstant)
 //   bcNSWallAdiabatic     :489-577
 //   bcNSWallIsoThermal    :579-691
 //   bcEulerWall           :1063-1280 (constant / linear pressure extrapolation)
@@ -103,6 +106,135 @@ __global__ __launch_bounds__(256) void k_bc_symm(BC_ARGS, KParams kp, int second
     b.p[ch] = b.p[cd];
     if (kp.viscous) b.rlv[ch] = b.rlv[cd];
     if (kp.eddyModel) b.rev[ch] = b.rev[cd];
+}
+
+// polar symmetry: the mirror direction is the diagonal of the face cell (degenerate "axis" faces), xx(i+1,j+1) - xx(i,j)
+// of the face's node plane (BCRoutines.F90:370-379, setBCPointers utils.F90:1103-1133)
+__global__ __launch_bounds__(256) void k_bc_symm_polar(BC_ARGS, KParams kp, int second)
+{
+    BC_PROLOGUE
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    const int isize = f.icEnd - f.icBeg + 1;
+    const int i = f.icBeg + (int)(s.f % isize), j = f.jcBeg + (int)(s.f / isize);
+    long nA, nB;
+    switch (f.faceID) {
+    case ADFLOW_IMIN: case ADFLOW_IMAX: { const int P = (f.faceID == ADFLOW_IMIN) ? 1 : b.il; nA = b.idx(P, i - 1, j - 1); nB = b.idx(P, i, j); break; }
+    case ADFLOW_JMIN: case ADFLOW_JMAX: { const int P = (f.faceID == ADFLOW_JMIN) ? 1 : b.jl; nA = b.idx(i - 1, P, j - 1); nB = b.idx(i, P, j); break; }
+    default: { const int P = (f.faceID == ADFLOW_KMIN) ? 1 : b.kl; nA = b.idx(i - 1, j - 1, P); nB = b.idx(i, j, P); }
+    }
+    double nx = b.x[nB] - b.x[nA], ny = b.x[nB + nb] - b.x[nA + nb], nz = b.x[nB + 2 * nb] - b.x[nA + 2 * nb];
+    const double tmp = 1.0 / sqrt(nx * nx + ny * ny + nz * nz);
+    nx *= tmp; ny *= tmp; nz *= tmp;
+    const long ch = second ? s.c0 : s.c1, cd = second ? s.c3 : s.c2;
+    const double u = b.w[cd + nb], v = b.w[cd + 2 * nb], w = b.w[cd + 3 * nb];
+    const double t2 = 2.0 * (u * nx + v * ny + w * nz);
+    b.w[ch] = b.w[cd];
+    b.w[ch + nb] = t2 * nx - u;
+    b.w[ch + 2 * nb] = t2 * ny - v;
+    b.w[ch + 3 * nb] = t2 * nz - w;
+    b.w[ch + 4 * nb] = b.w[cd + 4 * nb];
+    b.p[ch] = b.p[cd];
+    if (kp.viscous) b.rlv[ch] = b.rlv[cd];
+    if (kp.eddyModel) b.rev[ch] = b.rev[cd];
+}
+
+// subsonic outflow / outflow mass bleed: static pressure prescribed, entropy, tangential velocity and the outgoing
+// acoustic Riemann variable extrapolated
+__global__ __launch_bounds__(256) void k_bc_subsonic_outflow(BC_ARGS, KParams kp, int second)
+{
+    BC_PROLOGUE
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    const double pExit = f.ps[s.f];
+    const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
+    const double gam2 = b.gamma[s.c2];
+    const double ovg = 1.0 / gam2, ovgm1 = 1.0 / (gam2 - 1.0);
+    const double pInt = b.p[s.c2];
+    const double r = 1.0 / b.w[s.c2];
+    double a = sqrt(gam2 * pInt * r);
+    const double ue = b.w[s.c2 + nb], ve = b.w[s.c2 + 2 * nb], we = b.w[s.c2 + 3 * nb];
+    const double qne = ue * nx + ve * ny + we * nz;
+    const double ss = pInt * pow(r, gam2);
+    const double ac = qne + 2.0 * a * ovgm1;
+    const double rho1 = pow(pExit / ss, ovg);
+    b.w[s.c1] = rho1;
+    b.p[s.c1] = pExit;
+    a = sqrt(gam2 * pExit / rho1);
+    const double qnh = ac - 2.0 * a * ovgm1;
+    b.w[s.c1 + nb] = ue + (qnh - qne) * nx;
+    b.w[s.c1 + 2 * nb] = ve + (qnh - qne) * ny;
+    b.w[s.c1 + 3 * nb] = we + (qnh - qne) * nz;
+    if (kp.viscous) b.rlv[s.c1] = b.rlv[s.c2];
+    if (kp.eddyModel) b.rev[s.c1] = b.rev[s.c2];
+    bc_etot(b, kp, s.c1);
+    if (second) bc_second_halo(b, kp, s);
+}
+
+// subsonic inflow: total conditions + flow direction, or density + velocity prescribed; the outgoing acoustic
+// Riemann variable comes from the interior
+__global__ __launch_bounds__(256) void k_bc_subsonic_inflow(BC_ARGS, KParams kp, int second, int hScalingInlet)
+{
+    BC_PROLOGUE
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    const long nb = b.nbox;
+    const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
+    const double gam2 = b.gamma[s.c2];
+    const double gm1 = gam2 - 1.0, ovgm1 = 1.0 / gm1;
+    const double r = 1.0 / b.w[s.c2];
+    const double u2 = b.w[s.c2 + nb], v2 = b.w[s.c2 + 2 * nb], w2 = b.w[s.c2 + 3 * nb];
+    double a2 = gam2 * b.p[s.c2] * r;
+    double beta = u2 * nx + v2 * ny + w2 * nz + 2.0 * ovgm1 * sqrt(a2);
+    if (f.inletTreatment == ADFLOW_INLET_TOTAL_CONDITIONS) {
+        const double govgm1 = kp.gammaConstant / (kp.gammaConstant - 1.0);
+        const double ptot = f.pt[s.f], ttot = f.tt[s.f], htot = f.ht[s.f];
+        const double ssx = f.fdx[s.f], ssy = f.fdy[s.f], ssz = f.fdz[s.f];
+        const double h2 = r * (b.w[s.c2 + 4 * nb] + b.p[s.c2]);
+        double scaleFact = 1.0;
+        if (hScalingInlet) scaleFact = sqrt(htot / h2);
+        beta = beta * scaleFact;
+        double q2 = u2 * u2 + v2 * v2 + w2 * w2;
+        const double a2tot = gm1 * (htot - h2 + 0.5 * q2) + a2;
+        const double alpha = nx * ssx + ny * ssy + nz * ssz;
+        const double aa2 = 0.5 * gm1 * alpha * alpha + 1.0;
+        const double bb = -gm1 * alpha * beta;
+        const double cc = 0.5 * gm1 * beta * beta - 2.0 * ovgm1 * a2tot;
+        double dd = bb * bb - 4.0 * aa2 * cc;
+        dd = sqrt(fmax(0.0, dd));
+        double q = (-bb + dd) / (2.0 * aa2);
+        q = fmax(0.0, q);
+        q2 = q * q;
+        a2 = a2tot - 0.5 * gm1 * q2;
+        double m2 = q2 / a2;
+        m2 = fmin(1.0, m2);
+        q2 = m2 * a2;
+        q = sqrt(q2);
+        a2 = a2tot - 0.5 * gm1 * q2;
+        b.w[s.c1 + nb] = q * ssx;
+        b.w[s.c1 + 2 * nb] = q * ssy;
+        b.w[s.c1 + 3 * nb] = q * ssz;
+        const double ts = a2 / (gam2 * kp.RGas);
+        const double ratio = pow(ts / ttot, govgm1);
+        b.p[s.c1] = ptot * ratio;
+        b.w[s.c1] = (ptot * ratio) / (kp.RGas * ts);
+    } else {
+        const double rho = f.rho[s.f], velx = f.vx[s.f], vely = f.vy[s.f], velz = f.vz[s.f];
+        a2 = 0.5 * gm1 * (beta - velx * nx - vely * ny - velz * nz);
+        a2 = fmax(0.0, a2);
+        a2 = a2 * a2;
+        b.p[s.c1] = rho * a2 / gam2;
+        b.w[s.c1] = rho;
+        b.w[s.c1 + nb] = velx;
+        b.w[s.c1 + 2 * nb] = vely;
+        b.w[s.c1 + 3 * nb] = velz;
+    }
+    if (kp.viscous) b.rlv[s.c1] = b.rlv[s.c2];
+    if (kp.eddyModel) b.rev[s.c1] = b.rev[s.c2];
+    bc_etot(b, kp, s.c1);
+    if (second) bc_second_halo(b, kp, s);
 }
 
 // viscous walls; ISO: isothermal (wall temperature TNS_Wall)
@@ -281,7 +413,7 @@ static dim3 bc_grid(const BcPhase& ph) { return dim3((unsigned)((ph.maxCells + 2
 // kind one launch per ordinal of the subface within its block)
 void launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& flow,
                          const KParams& kp, int second, int eulerWallTreatment, int viscWallTreatment, int outflowTreatment,
-                         hipStream_t s)
+                         int hScalingInlet, hipStream_t s)
 {
     const dim3 blk(256, 1, 1);
     // coarse levels force the constant-pressure wall treatment (BCRoutines.F90:552-553, 1098-1099)
@@ -297,6 +429,10 @@ void launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* orde
         case BCP_EXTRAP: hipLaunchKernelGGL(k_bc_extrap, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second, outflowTreatment); break;
         case BCP_EULERWALL: hipLaunchKernelGGL(k_bc_eulerwall, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second, eulerWallTreatment); break;
         case BCP_SUPERSONIC_INFLOW: hipLaunchKernelGGL(k_bc_supersonic_inflow, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second); break;
+        case BCP_SYMMPOLAR1: hipLaunchKernelGGL(k_bc_symm_polar, bc_grid(ph), blk, 0, s, tab, ent, o, kp, 0); break;
+        case BCP_SYMMPOLAR2: if (second) hipLaunchKernelGGL(k_bc_symm_polar, bc_grid(ph), blk, 0, s, tab, ent, o, kp, 1); break;
+        case BCP_SUBSONIC_OUTFLOW: hipLaunchKernelGGL(k_bc_subsonic_outflow, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second); break;
+        case BCP_SUBSONIC_INFLOW: hipLaunchKernelGGL(k_bc_subsonic_inflow, bc_grid(ph), blk, 0, s, tab, ent, o, kp, second, hScalingInlet); break;
         default: break;
         }
     }
@@ -307,6 +443,7 @@ void launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* orde
 //   bcTurbTreatment           :662-798  bmt/bvt of every face: zero, then per subface
 //     bcTurbWall (SA)         :799-870  bmt = 1      (nuTilde_halo = -nuTilde_interior)
 //     bcTurbSymm / outflow    :614-660, 564-613  bmt = -1 (copy)
+//     bcTurbInflow            :460-515  bvt = 2 turbInlet, bmt = 1 (face value = turbInlet)
 //     bcTurbFarfield          :373-459  outflow: bmt = -1, inflow: bvt = wInf(itu1)
 //   applyAllTurbBCThisBlock   :49-236   halo = bvt - bmt * interior; eddy viscosity
 //                                       -rev (walls) / +rev (others); turb2ndHalo copies
@@ -352,8 +489,15 @@ __global__ __launch_bounds__(256) void k_turb_bc_treatment(BC_ARGS, KParams kp)
     case ADFLOW_BC_NSWALL_ADIABATIC: case ADFLOW_BC_NSWALL_ISOTHERMAL:
         b.bmt[fi][e] = 1.0;
         break;
-    case ADFLOW_BC_SYMM: case ADFLOW_BC_EULERWALL: case ADFLOW_BC_SUPERSONIC_OUTFLOW: case ADFLOW_BC_EXTRAP:
+    case ADFLOW_BC_SYMM: case ADFLOW_BC_SYMM_POLAR: case ADFLOW_BC_EULERWALL: case ADFLOW_BC_SUPERSONIC_OUTFLOW: case ADFLOW_BC_EXTRAP:
+    case ADFLOW_BC_SUBSONIC_OUTFLOW: case ADFLOW_BC_MASSBLEED_OUTFLOW:
         b.bmt[fi][e] = -1.0;
+        break;
+    case ADFLOW_BC_SUPERSONIC_INFLOW: case ADFLOW_BC_SUBSONIC_INFLOW:     // bcTurbInflow (turbBCRoutines.F90:460-515)
+        if (f.turbInlet) {
+            b.bvt[fi][e] = 2.0 * f.turbInlet[t];
+            b.bmt[fi][e] = 1.0;
+        }
         break;
     case ADFLOW_BC_FARFIELD: {
         const double dot = f.norm[t] * kp.wInf[1] + f.norm[t + n] * kp.wInf[2] + f.norm[t + 2 * n] * kp.wInf[3] -
@@ -362,7 +506,7 @@ __global__ __launch_bounds__(256) void k_turb_bc_treatment(BC_ARGS, KParams kp)
         else b.bvt[fi][e] = kp.wInf[5];
         break;
     }
-    default: break;   // supersonic inflow: prescribed turbulence (BCData%turbInlet) is not carried: left as is
+    default: break;
     }
 }
 

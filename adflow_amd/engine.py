@@ -118,7 +118,8 @@ class Engine:
         for m, f in enumerate(faces):
             for k in ("bcType", "faceID", "icBeg", "icEnd", "jcBeg", "jcEnd"):
                 setattr(arr[m], k, int(f[k]))
-            for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps"):
+            arr[m].subsonicInletTreatment = int(f.get("subsonicInletTreatment", 0))
+            for k in capi.BC_ARRAYS:
                 a = f.get(k)
                 if a is not None:
                     assert a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, k

@@ -21,6 +21,7 @@ module adflowGpuShim
         integer(c_int32_t) :: groundLevel
         integer(c_int32_t) :: turbRelax
         integer(c_int32_t) :: eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment
+        integer(c_int32_t) :: hScalingInlet, reserved_i
         integer(c_int32_t) :: lowSpeedPreconditioner
         real(c_double) :: gammaConstant, prandtl, prandtlTurb
         real(c_double) :: SSuthDim, muSuthDim, TSuthDim
@@ -60,8 +61,10 @@ module adflowGpuShim
     type, bind(C) :: adflow_bc_subface
         integer(c_int32_t) :: bcType, faceID
         integer(c_int32_t) :: icBeg, icEnd, jcBeg, jcEnd
+        integer(c_int32_t) :: subsonicInletTreatment, reserved
         type(c_ptr) :: norm, rface, uSlip, TNS_Wall
         type(c_ptr) :: rho, velx, vely, velz, ps
+        type(c_ptr) :: ptInlet, ttInlet, htInlet, flowXdirInlet, flowYdirInlet, flowZdirInlet, turbInlet
     end type adflow_bc_subface
 
     interface
@@ -206,6 +209,7 @@ contains
         o%turbRelax = turbRelax
         o%eulerWallBCTreatment = eulerWallBCTreatment; o%viscWallBCTreatment = viscWallBCTreatment
         o%outflowTreatment = outflowTreatment
+        o%hScalingInlet = merge(1, 0, hScalingInlet); o%reserved_i = 0
         o%lowSpeedPreconditioner = merge(1, 0, lowSpeedPreconditioner)
         o%gammaConstant = gammaConstant; o%prandtl = prandtl; o%prandtlTurb = prandtlTurb
         o%SSuthDim = SSuthDim; o%muSuthDim = muSuthDim; o%TSuthDim = TSuthDim
@@ -328,6 +332,10 @@ contains
                 f(mm)%norm = c_null_ptr; f(mm)%rface = c_null_ptr; f(mm)%uSlip = c_null_ptr; f(mm)%TNS_Wall = c_null_ptr
                 f(mm)%rho = c_null_ptr; f(mm)%velx = c_null_ptr; f(mm)%vely = c_null_ptr; f(mm)%velz = c_null_ptr
                 f(mm)%ps = c_null_ptr
+                f(mm)%ptInlet = c_null_ptr; f(mm)%ttInlet = c_null_ptr; f(mm)%htInlet = c_null_ptr
+                f(mm)%flowXdirInlet = c_null_ptr; f(mm)%flowYdirInlet = c_null_ptr; f(mm)%flowZdirInlet = c_null_ptr
+                f(mm)%turbInlet = c_null_ptr
+                f(mm)%subsonicInletTreatment = int(d%subsonicInletTreatment, c_int32_t); f(mm)%reserved = 0
                 if (associated(d%norm)) f(mm)%norm = c_loc(d%norm)
                 if (associated(d%rface)) f(mm)%rface = c_loc(d%rface)
                 if (associated(d%uSlip)) f(mm)%uSlip = c_loc(d%uSlip)
@@ -337,6 +345,13 @@ contains
                 if (associated(d%vely)) f(mm)%vely = c_loc(d%vely)
                 if (associated(d%velz)) f(mm)%velz = c_loc(d%velz)
                 if (associated(d%ps)) f(mm)%ps = c_loc(d%ps)
+                if (associated(d%ptInlet)) f(mm)%ptInlet = c_loc(d%ptInlet)
+                if (associated(d%ttInlet)) f(mm)%ttInlet = c_loc(d%ttInlet)
+                if (associated(d%htInlet)) f(mm)%htInlet = c_loc(d%htInlet)
+                if (associated(d%flowXdirInlet)) f(mm)%flowXdirInlet = c_loc(d%flowXdirInlet)
+                if (associated(d%flowYdirInlet)) f(mm)%flowYdirInlet = c_loc(d%flowYdirInlet)
+                if (associated(d%flowZdirInlet)) f(mm)%flowZdirInlet = c_loc(d%flowZdirInlet)
+                if (associated(d%turbInlet)) f(mm)%turbInlet = c_loc(d%turbInlet)
             end associate
         end do
         call gpuCheck(adflow_gpu_bc_register(int(nn, c_int), int(level, c_int), int(sps, c_int), int(nb, c_int), &

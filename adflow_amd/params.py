@@ -87,6 +87,7 @@ class FlowParams:
     viscWallBCTreatment: int = 1
     outflowTreatment: int = 1
     lowSpeedPreconditioner: bool = False
+    hScalingInlet: bool = False
     alfaTurb: float = 0.8
     betaTurb: float = -1.0
     # --- iteration

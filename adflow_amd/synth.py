@@ -282,6 +282,33 @@ def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7, split=()):
         if typ == -4:
             tinf = prm.pInf / (prm.RGas * prm.rhoInf)
             f["TNS_Wall"] = np.asfortranarray(tinf * (1.0 + 0.05 * rng.uniform(-1, 1, shp)))
+        if typ in (-10, -12):       # subsonic outflow / outflow bleed: static pressure
+            f["ps"] = np.asfortranarray(prm.pInf * (1.0 + 0.03 * rng.uniform(-1, 1, shp)))
+        if typ == -8:               # subsonic inflow: total conditions on min faces, mass flow on max faces
+            gam, R = prm.gammaConstant, prm.RGas
+            tinf = prm.pInf / (R * prm.rhoInf)
+            m2 = prm.Mach ** 2
+            if fid in (1, 3, 5):
+                f["subsonicInletTreatment"] = 1
+                tt = tinf * (1.0 + 0.5 * (gam - 1.0) * m2) * (1.0 + 0.02 * rng.uniform(-1, 1, shp))
+                pt = prm.pInf * (1.0 + 0.5 * (gam - 1.0) * m2) ** (gam / (gam - 1.0)) * (1.0 + 0.02 * rng.uniform(-1, 1, shp))
+                f["ptInlet"] = np.asfortranarray(pt)
+                f["ttInlet"] = np.asfortranarray(tt)
+                f["htInlet"] = np.asfortranarray(gam / (gam - 1.0) * R * tt)
+                d = -norm + 0.1 * rng.uniform(-1, 1, shp + (3,))          # roughly into the domain
+                d /= np.sqrt((d ** 2).sum(axis=-1, keepdims=True))
+                f["flowXdirInlet"] = np.asfortranarray(d[..., 0])
+                f["flowYdirInlet"] = np.asfortranarray(d[..., 1])
+                f["flowZdirInlet"] = np.asfortranarray(d[..., 2])
+            else:
+                f["subsonicInletTreatment"] = 2
+                f["rho"] = np.asfortranarray(winf[0] * (1.0 + 0.02 * rng.uniform(-1, 1, shp)))
+                vin = -0.5 * winf[1] * norm * (1.0 + 0.05 * rng.uniform(-1, 1, shp + (1,)))
+                f["velx"] = np.asfortranarray(vin[..., 0])
+                f["vely"] = np.asfortranarray(vin[..., 1])
+                f["velz"] = np.asfortranarray(vin[..., 2])
+        if typ in (-7, -8) and blk.nw > 5:
+            f["turbInlet"] = np.asfortranarray(winf[5] * (1.0 + 0.3 * rng.uniform(0, 1, shp + (1,))))
         if typ == -7:
             f["rho"] = np.asfortranarray(winf[0] * (1.0 + 0.02 * rng.uniform(-1, 1, shp)))
             f["velx"] = np.asfortranarray(winf[1] * (1.0 + 0.02 * rng.uniform(-1, 1, shp)))
@@ -297,7 +324,8 @@ def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7, split=()):
         lo, hi = dict(f), dict(f)
         lo["icEnd"], hi["icBeg"], hi["bcType"] = h, h + 1, int(typ2)
         n0 = h - f["icBeg"] + 1
-        for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps"):
+        for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps", "ptInlet", "ttInlet", "htInlet",
+                  "flowXdirInlet", "flowYdirInlet", "flowZdirInlet", "turbInlet"):
             if f.get(k) is not None:
                 lo[k] = np.asfortranarray(f[k][:n0])
                 hi[k] = np.asfortranarray(f[k][n0:])

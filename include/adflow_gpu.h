@@ -47,9 +47,12 @@ typedef void (*adflow_bc_callback)(int level, int secondHalo);
 
 /* boundary subfaces: BCType and BCFaceID values of src/modules/constants.F90:257-297 */
 enum {
-    ADFLOW_BC_SYMM = -1, ADFLOW_BC_NSWALL_ADIABATIC = -3, ADFLOW_BC_NSWALL_ISOTHERMAL = -4, ADFLOW_BC_EULERWALL = -5,
-    ADFLOW_BC_FARFIELD = -6, ADFLOW_BC_SUPERSONIC_INFLOW = -7, ADFLOW_BC_SUPERSONIC_OUTFLOW = -9, ADFLOW_BC_EXTRAP = -15
+    ADFLOW_BC_SYMM = -1, ADFLOW_BC_SYMM_POLAR = -2, ADFLOW_BC_NSWALL_ADIABATIC = -3, ADFLOW_BC_NSWALL_ISOTHERMAL = -4,
+    ADFLOW_BC_EULERWALL = -5, ADFLOW_BC_FARFIELD = -6, ADFLOW_BC_SUPERSONIC_INFLOW = -7, ADFLOW_BC_SUBSONIC_INFLOW = -8,
+    ADFLOW_BC_SUPERSONIC_OUTFLOW = -9, ADFLOW_BC_SUBSONIC_OUTFLOW = -10, ADFLOW_BC_MASSBLEED_OUTFLOW = -12,
+    ADFLOW_BC_EXTRAP = -15
 };
+enum { ADFLOW_INLET_TOTAL_CONDITIONS = 1, ADFLOW_INLET_MASS_FLOW = 2 };   /* BCData%subsonicInletTreatment, constants.F90:237 */
 enum { ADFLOW_IMIN = 1, ADFLOW_IMAX = 2, ADFLOW_JMIN = 3, ADFLOW_JMAX = 4, ADFLOW_KMIN = 5, ADFLOW_KMAX = 6 };
 enum { ADFLOW_WALLBC_CONSTANT = 1, ADFLOW_WALLBC_LINEAR = 2, ADFLOW_WALLBC_QUADRATIC = 3, ADFLOW_WALLBC_NORMAL_MOMENTUM = 4 };
 
@@ -60,15 +63,24 @@ enum { ADFLOW_WALLBC_CONSTANT = 1, ADFLOW_WALLBC_LINEAR = 2, ADFLOW_WALLBC_QUADR
 typedef struct adflow_bc_subface {
     int32_t bcType, faceID;
     int32_t icBeg, icEnd, jcBeg, jcEnd;
+    int32_t subsonicInletTreatment;   /* SubsonicInflow: 1 total conditions, 2 mass flow                 */
+    int32_t reserved;
     const double* norm;       /* unit outward normal, 3 components                                       */
     const double* rface;      /* normal grid velocity (EulerWall, farField)                              */
     const double* uSlip;      /* wall velocity, 3 components (NSWall*)                                   */
     const double* TNS_Wall;   /* wall temperature (NSWallIsothermal)                                     */
-    const double* rho;        /* prescribed state (SupersonicInflow): rho, velx, vely, velz, ps          */
+    const double* rho;        /* prescribed state (SupersonicInflow; SubsonicInflow with mass flow): rho, velx, vely, velz */
     const double* velx;
     const double* vely;
     const double* velz;
-    const double* ps;
+    const double* ps;         /* static pressure (SupersonicInflow, SubsonicOutflow, MassBleedOutflow)   */
+    const double* ptInlet;    /* SubsonicInflow with total conditions: total pressure, temperature, enthalpy, */
+    const double* ttInlet;    /* unit flow direction                                                     */
+    const double* htInlet;
+    const double* flowXdirInlet;
+    const double* flowYdirInlet;
+    const double* flowZdirInlet;
+    const double* turbInlet;  /* prescribed turbulence variable(s) of inflow subfaces (RANS), (:,:,nt1:nt2) */
 } adflow_bc_subface;
 
 /* Options: snapshot of the Fortran module variables the hot path reads.
@@ -89,6 +101,8 @@ typedef struct adflow_opts {
     /* inputDiscretization: boundary treatment (constants.F90:170-178): 1 constant, 2 linear, 4 normal momentum;
      * outflowTreatment 1 constant, 2 linear extrapolation */
     int32_t eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment;
+    int32_t hScalingInlet;            /* inputDiscretization: total-enthalpy scaling of the subsonic-inflow Riemann invariant */
+    int32_t reserved_i;
     int32_t lowSpeedPreconditioner;   /* inputDiscretization: residual_block's 5x5 low-Mach transform (residuals.F90:172-331) + the 0.8 RK step factor (smoothers.F90:202) */
     double gammaConstant, prandtl, prandtlTurb;
     double SSuthDim, muSuthDim, TSuthDim;
@@ -271,8 +285,8 @@ int adflow_gpu_set_bc_callback(adflow_bc_callback fn);
  * each kind, computeEtot + extrapolate2ndHalo as there) for every registered block of the level.
  * Once a level has registered subfaces the smoothers, the multigrid transfers and the NK residual
  * apply them on the device at the points where the reference calls applyAllBC; the host callback
- * (if any) still runs afterwards for kinds that are not implemented here (symmPolar, subsonic
- * in/outflow, normal-momentum Euler wall: registration of those returns an error). */
+ * (if any) still runs afterwards for kinds that are not implemented here (bleed inflow, mDot / thrust,
+ * domain interfaces, sliding interfaces; normal-momentum Euler wall: registration of those returns an error). */
 int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBocos, const adflow_bc_subface* faces);
 int adflow_gpu_apply_all_bc(int level, int secondHalo);
 /* viscSubface(mm)%tau(:,:,1:6) and %q(:,:,1:3) of viscous subface mm (1-based, mm <= nViscBocos): the wall stress tensor and
@@ -309,6 +323,8 @@ int adflow_gpu_set_async(int on);
 /* sizeof(adflow_opts), sizeof(adflow_block_desc) as compiled: lets a foreign-
  * language binding verify its mirror of the two structs */
 int adflow_gpu_abi_sizes(int* opts_bytes, int* desc_bytes);
+/* the same for adflow_bc_subface and adflow_comm_pattern */
+int adflow_gpu_abi_sizes2(int* bc_subface_bytes, int* comm_pattern_bytes);
 
 #ifdef __cplusplus
 }

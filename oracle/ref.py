@@ -51,7 +51,7 @@ def load(fast: bool = False) -> ctypes.CDLL:
 _INT_PARAMS = ["equations", "spaceDiscr", "spaceDiscrCoarse", "limiter", "orderTurb", "turbModel", "turbProd",
                "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb", "nSubiterations", "turbRelax",
                "eulerWallBCTreatment", "viscWallBCTreatment", "outflowTreatment"]
-_BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA", "lowSpeedPreconditioner"]
+_BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA", "lowSpeedPreconditioner", "hScalingInlet"]
 _REAL_PARAMS = ["vis2", "vis4", "vis2Coarse", "adis", "acousticScaleFactor", "kappaCoef", "sigma", "cfl",
                 "cflCoarse", "cflLimit", "fcoll", "smoop", "alfaTurb", "betaTurb", "rFil", "gammaConstant",
                 "gammaInf", "pInf", "pInfCorr", "rhoInf", "uInf", "RGas", "muInf", "muRef", "TRef", "timeRef",
@@ -160,7 +160,10 @@ def set_bocos(faces, nViscBocos=0) -> None:
     lib.ref_set_bocos(n, int(nViscBocos), types.ctypes.data, fids.ctypes.data, rng.ctypes.data)
     _keep.append(faces)     # the reference points INTO these arrays
     for m, f in enumerate(faces):
-        for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps"):
+        if f.get("subsonicInletTreatment"):
+            lib.ref_set_inlet_treatment(m + 1, int(f["subsonicInletTreatment"]))
+        for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps", "ptInlet", "ttInlet", "htInlet",
+                  "flowXdirInlet", "flowYdirInlet", "flowZdirInlet", "turbInlet"):
             a = f.get(k)
             if a is not None:
                 assert a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, k

@@ -304,6 +304,7 @@ contains
         case ('radiiNeededFine'); radiiNeededFine = (v /= 0)
         case ('radiiNeededCoarse'); radiiNeededCoarse = (v /= 0)
         case ('lowSpeedPreconditioner'); lowSpeedPreconditioner = (v /= 0)
+        case ('hScalingInlet'); hScalingInlet = (v /= 0)
         case ('useQCR'); useQCR = (v /= 0)
         case ('useRotationSA'); useRotationSA = (v /= 0)
         case ('useft2SA'); useft2SA = (v /= 0)
@@ -444,7 +445,9 @@ contains
             BCData(mm)%jcBeg = ranges(3, mm); BCData(mm)%jcEnd = ranges(4, mm)
             BCData(mm)%subsonicInletTreatment = 0
             nullify (BCData(mm)%norm, BCData(mm)%rface, BCData(mm)%uSlip, BCData(mm)%TNS_Wall, BCData(mm)%rho, &
-                     BCData(mm)%velx, BCData(mm)%vely, BCData(mm)%velz, BCData(mm)%ps)
+                     BCData(mm)%velx, BCData(mm)%vely, BCData(mm)%velz, BCData(mm)%ps, BCData(mm)%ptInlet, &
+                     BCData(mm)%ttInlet, BCData(mm)%htInlet, BCData(mm)%flowXdirInlet, BCData(mm)%flowYdirInlet, &
+                     BCData(mm)%flowZdirInlet, BCData(mm)%turbInlet)
         end do
         ! what preprocessingAPI.F90:2430-2581 (viscSubfaceInfo) sets up: storage of the wall stress tensor / heat flux
         ! of the viscous subfaces (their owned face cells) and the visc*Pointer maps into it
@@ -491,9 +494,16 @@ contains
         q(1:3 * n) = reshape(viscSubface(mm)%q, [3 * n])
     end subroutine ref_get_wall_stress
 
+    subroutine ref_set_inlet_treatment(mm, v) bind(C, name="ref_set_inlet_treatment")
+        use blockPointers
+        integer(c_int), value :: mm, v
+        BCData(mm)%subsonicInletTreatment = v
+    end subroutine ref_set_inlet_treatment
+
     ! member `name` of BCData(mm) => caller-owned array with the reference's bounds
     subroutine ref_set_bcdata(mm, name, ptr) bind(C, name="ref_set_bcdata")
         use blockPointers
+        use flowVarRefState, only: nt1, nt2
         integer(c_int), value :: mm
         character(kind=c_char), dimension(*), intent(in) :: name
         type(c_ptr), value :: ptr
@@ -508,9 +518,19 @@ contains
             call c_f_pointer(ptr, t3, [i1 - i0 + 1, j1 - j0 + 1, 3])
             if (trim(n) == 'norm') BCData(mm)%norm(i0:, j0:, 1:) => t3
             if (trim(n) == 'uSlip') BCData(mm)%uSlip(i0:, j0:, 1:) => t3
-        case ('rface', 'TNS_Wall', 'rho', 'velx', 'vely', 'velz', 'ps')
+        case ('turbInlet')
+            call c_f_pointer(ptr, t3, [i1 - i0 + 1, j1 - j0 + 1, nt2 - nt1 + 1])
+            BCData(mm)%turbInlet(i0:, j0:, nt1:) => t3
+        case ('rface', 'TNS_Wall', 'rho', 'velx', 'vely', 'velz', 'ps', 'ptInlet', 'ttInlet', 'htInlet', 'flowXdirInlet', &
+              'flowYdirInlet', 'flowZdirInlet')
             call c_f_pointer(ptr, t2, [i1 - i0 + 1, j1 - j0 + 1])
             select case (trim(n))
+            case ('ptInlet'); BCData(mm)%ptInlet(i0:, j0:) => t2
+            case ('ttInlet'); BCData(mm)%ttInlet(i0:, j0:) => t2
+            case ('htInlet'); BCData(mm)%htInlet(i0:, j0:) => t2
+            case ('flowXdirInlet'); BCData(mm)%flowXdirInlet(i0:, j0:) => t2
+            case ('flowYdirInlet'); BCData(mm)%flowYdirInlet(i0:, j0:) => t2
+            case ('flowZdirInlet'); BCData(mm)%flowZdirInlet(i0:, j0:) => t2
             case ('rface'); BCData(mm)%rface(i0:, j0:) => t2
             case ('TNS_Wall'); BCData(mm)%TNS_Wall(i0:, j0:) => t2
             case ('rho'); BCData(mm)%rho(i0:, j0:) => t2
@@ -831,5 +851,14 @@ contains
         opts_bytes = int(c_sizeof(o), c_int)
         desc_bytes = int(c_sizeof(d), c_int)
     end subroutine ref_shim_sizes
+
+    subroutine ref_shim_sizes2(bc_bytes, comm_bytes) bind(C, name="ref_shim_sizes2")
+        use adflowGpuShim, only: adflow_bc_subface, adflow_comm_pattern
+        integer(c_int), intent(out) :: bc_bytes, comm_bytes
+        type(adflow_bc_subface) :: f
+        type(adflow_comm_pattern) :: p
+        bc_bytes = int(c_sizeof(f), c_int)
+        comm_bytes = int(c_sizeof(p), c_int)
+    end subroutine ref_shim_sizes2
 
 end module ref_driver

@@ -34,6 +34,9 @@ def test_struct_layouts_agree():
     assert lib.adflow_gpu_abi_sizes(ctypes.byref(so), ctypes.byref(sd)) == 0
     assert so.value == ctypes.sizeof(capi.AdflowOpts)
     assert sd.value == ctypes.sizeof(capi.AdflowBlockDesc)
+    assert lib.adflow_gpu_abi_sizes2(ctypes.byref(so), ctypes.byref(sd)) == 0
+    assert so.value == ctypes.sizeof(capi.AdflowBcSubface)
+    assert sd.value == ctypes.sizeof(capi.AdflowCommPattern)
 
 
 def test_fortran_shim_mirrors_agree():
@@ -46,6 +49,8 @@ def test_fortran_shim_mirrors_agree():
     a, b = ctypes.c_int(), ctypes.c_int()
     lib.ref_shim_sizes(ctypes.byref(a), ctypes.byref(b))
     assert (a.value, b.value) == (ctypes.sizeof(capi.AdflowOpts), ctypes.sizeof(capi.AdflowBlockDesc))
+    lib.ref_shim_sizes2(ctypes.byref(a), ctypes.byref(b))
+    assert (a.value, b.value) == (ctypes.sizeof(capi.AdflowBcSubface), ctypes.sizeof(capi.AdflowCommPattern))
 
 
 def test_no_cpu_fallback():

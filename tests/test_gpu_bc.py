@@ -127,3 +127,17 @@ def test_multiblock_bc(engine):
         1: ((24, 8, 6), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, {5: -6, 4: -3}),
         2: ((70, 6, 6), {3: -3, 4: -6}, ()),
         3: ((10, 12, 8), {1: -6, 2: -9, 3: -3, 4: -6, 5: -1, 6: -1}, ())}, stretch_k=2.0)
+
+
+def test_apply_all_bc_subsonic_and_polar(engine):
+    """symmPolar, subsonic inflow (total conditions on min faces, mass flow on max faces, hScalingInlet), subsonic
+    outflow / outflow bleed, with the turbulence inflow / outflow treatment for RANS"""
+    lo = dict(Mach=0.3)
+    spec = {1: -8, 2: -10, 3: -2, 4: -8, 5: -12, 6: -6}
+    for second in (True, False):
+        checks.check_apply_bc(engine, (70, 9, 7), FlowParams(**lo), spec, secondHalo=second)
+    checks.check_apply_bc(engine, (20, 12, 8), FlowParams(hScalingInlet=True, **lo), {1: -10, 2: -8, 3: -8, 4: -2, 5: -1, 6: -5})
+    rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, **lo)
+    checks.check_multiblock_bc(engine, rans, {
+        1: ((24, 8, 6), {1: -8, 2: -10, 3: -3, 4: -6, 5: -2, 6: -7}, ()),
+        2: ((70, 6, 8), {1: -12, 2: -8, 3: -3, 4: -6}, {3: -6})}, stretch_k=2.0)

@@ -227,6 +227,20 @@ def test_wall_stress_storage(hostsim_engine):
                              {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, split={5: -6, 4: -3}, stretch_k=2.0)
 
 
+def test_apply_all_bc_subsonic_and_polar(hostsim_engine):
+    """symmPolar, subsonic inflow (total conditions on min faces, mass flow on max faces, hScalingInlet), subsonic
+    outflow / outflow bleed, with the turbulence inflow / outflow treatment for RANS"""
+    lo = dict(Mach=0.3)
+    spec = {1: -8, 2: -10, 3: -2, 4: -8, 5: -12, 6: -6}
+    for second in (True, False):
+        checks.check_apply_bc(hostsim_engine, (6, 5, 4), FlowParams(**lo), spec, secondHalo=second)
+    checks.check_apply_bc(hostsim_engine, (6, 5, 4), FlowParams(hScalingInlet=True, **lo), {1: -10, 2: -8, 3: -8, 4: -2, 5: -1, 6: -5})
+    rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, **lo)
+    checks.check_multiblock_bc(hostsim_engine, rans, {
+        1: ((6, 5, 4), {1: -8, 2: -10, 3: -3, 4: -6, 5: -2, 6: -7}, ()),
+        2: ((5, 4, 6), {1: -12, 2: -8, 3: -3, 4: -6}, {3: -6})}, stretch_k=2.0)
+
+
 def test_multiblock_bc(hostsim_engine):
     """several blocks with different subface lists: the level-batched BC launches against the reference's block loop"""
     checks.check_multiblock_bc(hostsim_engine, FlowParams(), {
