@@ -92,6 +92,8 @@ class AdflowBlockDesc(ctypes.Structure):
         ("mgIFine", c_void_p), ("mgJFine", c_void_p), ("mgKFine", c_void_p),
         ("mgIWeight", c_void_p), ("mgJWeight", c_void_p), ("mgKWeight", c_void_p),
         ("mgICoarse", c_void_p), ("mgJCoarse", c_void_p), ("mgKCoarse", c_void_p),
+        ("sFaceI", c_void_p), ("sFaceJ", c_void_p), ("sFaceK", c_void_p),
+        ("rotRate", c_double * 3), ("addGridVelocities", c_int32), ("blockIsMoving", c_int32),
     ]
 
 
@@ -237,8 +239,13 @@ def desc_from_block(blk) -> AdflowBlockDesc:
     for name in ("w", "p", "gamma", "rlv", "rev", "x", "sI", "sJ", "sK", "vol", "volRef", "d2Wall",
                  "porI", "porJ", "porK", "iblank", "dw", "fw", "dtl", "radI", "radJ", "radK", "w1", "p1", "wr",
                  "mgIFine", "mgJFine", "mgKFine", "mgIWeight", "mgJWeight", "mgKWeight", "mgICoarse", "mgJCoarse",
-                 "mgKCoarse"):
+                 "mgKCoarse", "sFaceI", "sFaceJ", "sFaceK"):
         setattr(d, name, _ptr(blk.a.get(name)))
+    d.addGridVelocities = int(blk.a.get("sFaceI") is not None)
+    rot = getattr(blk, "rotRate", None)
+    d.blockIsMoving = int(rot is not None)
+    for m in range(3):
+        d.rotRate[m] = float(rot[m]) if rot is not None else 0.0
     return d
 
 

@@ -375,6 +375,12 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     rc |= alloc_arr(b, &v.vol, 1);
     rc |= alloc_arr(b, &v.volRef, 1);
     rc |= alloc_arr(b, &v.d2wall, 1);
+    if (d->addGridVelocities) {
+        if (!(d->sFaceI && d->sFaceJ && d->sFaceK)) return fail("block (%d,%d,%d): addGridVelocities without sFaceI/J/K", nn, level, sps);
+        rc |= alloc_arr(b, &v.sFace, 3);
+    }
+    v.moving = d->blockIsMoving ? 1 : 0;
+    for (int m = 0; m < 3; ++m) v.rot[m] = d->rotRate[m];
     rc |= alloc_arr(b, &v.dI, 3);
     rc |= alloc_arr(b, &v.dJ, 3);
     rc |= alloc_arr(b, &v.dK, 3);
@@ -487,6 +493,11 @@ int adflow_gpu_upload_geometry(int nn, int level, int sps)
     rc |= copy_box(b, v.sI, d.sI, 3, 0, v.ie + 1, 1, v.je, 1, v.ke, true);
     rc |= copy_box(b, v.sJ, d.sJ, 3, 1, v.ie, 0, v.je + 1, 1, v.ke, true);
     rc |= copy_box(b, v.sK, d.sK, 3, 1, v.ie, 1, v.je, 0, v.ke + 1, true);
+    if (v.sFace) {
+        rc |= copy_box(b, v.sFace, d.sFaceI, 1, 0, v.ie + 1, 1, v.je, 1, v.ke, true);
+        rc |= copy_box(b, v.sFace + v.nbox, d.sFaceJ, 1, 1, v.ie, 0, v.je + 1, 1, v.ke, true);
+        rc |= copy_box(b, v.sFace + 2 * v.nbox, d.sFaceK, 1, 1, v.ie, 1, v.je, 0, v.ke + 1, true);
+    }
     rc |= copy_box(b, v.vol, d.vol, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
     rc |= copy_box(b, v.volRef, d.volRef ? d.volRef : d.vol, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
     rc |= copy_box(b, v.d2wall, d.d2Wall, 1, 2, v.nx, 2, v.ny, 2, v.nz, true);
@@ -703,7 +714,9 @@ static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox =
 
 static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox)
 {
-    if (g_use_march && !kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.fineGrid && !kp.dissApprox) {
+    bool anyMoving = false;     // grid velocities / rotational source: the generic kernels carry them
+    for_level(level, [&](Block* b) { anyMoving = anyMoving || b->v.sFace || b->v.moving; return 0; });
+    if (g_use_march && !kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.fineGrid && !kp.dissApprox && !anyMoving) {
         // Euler + scalar JST: one k-marching launch over every block of the level
         int rc = for_level(level, [&](Block* b) {
             if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);

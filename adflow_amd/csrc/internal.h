@@ -70,6 +70,9 @@ struct BlkView {
     double *w, *p, *gamma, *rlv, *rev;
     // geometry
     double *x, *sI, *sJ, *sK, *vol, *volRef, *d2wall;
+    double* sFace;          // moving blocks: sFaceI/J/K as components 0..2 (entry at the left cell of the face); NULL at rest
+    int moving;             // blockIsMoving: rotational source with rot = cgnsDoms%rotRate (fluxes.F90:372-397)
+    double rot[3];
     double *dI, *dJ, *dK;   // derived geometry: vector between the two cell centres of a face (viscous normal correction)
     double *nsum;           // derived geometry: 18 summed normals of a node's dual cell + 1/sum(vol) (nodal gradients)
     // implicit turbulence boundary treatment of Spalart-Allmaras (turbBCRoutines.F90:662-798): halo = bvt - bmt * interior.

@@ -40,8 +40,9 @@ __device__ __forceinline__ void load_line(const BlkView& b, long c, long s, Line
 // face normal (sx,sy,sz) and porosity code `por`; adds +F to acc when the cell
 // is the left one (sign=+1) and -F when it is the right one (sign=-1).
 // fluxes.F90:52-129
+// sFace: grid velocity through the face (moving blocks), 0 at rest
 __device__ __forceinline__ void central_face(const Line& L, int l, double sx, double sy, double sz, int por,
-                                             double sign, double acc[5])
+                                             double sign, double acc[5], double sFace = 0.0)
 {
     const int r = l + 1;
     double vnp = L.u[r] * sx + L.v[r] * sy + L.w[r] * sz;
@@ -50,11 +51,11 @@ __device__ __forceinline__ void central_face(const Line& L, int l, double sx, do
     if (por == ADF_POR_NOFLUX) porFlux = 0.0;
     if (por == ADF_POR_BOUND) {
         porVel = 0.0;
-        vnp = 0.0;   // sFace == 0: steady, non-moving blocks
-        vnm = 0.0;
+        vnp = sFace;
+        vnm = sFace;
     }
     porVel *= porFlux;
-    const double qsp = vnp * porVel, qsm = vnm * porVel;
+    const double qsp = (vnp - sFace) * porVel, qsm = (vnm - sFace) * porVel;
     const double rqsp = qsp * L.rho[r], rqsm = qsm * L.rho[l];
     const double pa = porFlux * (L.p[r] + L.p[l]);
     acc[0] += sign * (rqsp + rqsm);
@@ -129,7 +130,8 @@ __device__ __forceinline__ void absA_times_dw(double lam1, double lam2, double l
 // matrix JST dissipative flux through face (l | l+1)  (fluxes.F90:523-690)
 __device__ __forceinline__ void jst_matrix_face(const Line& L, const double gam[5], int l, double nx, double ny, double nz,
                                                 int por, double dssL, double dssR, double fis2, double fis4, double sign,
-                                                double acc[5], bool coarse = false, bool approx = false, double sigma = 0.0)
+                                                double acc[5], bool coarse = false, bool approx = false, double sigma = 0.0,
+                                                double sFace = 0.0)
 {
     const int r = l + 1, ll = l - 1, rr = l + 2;
     const double ppor = (por == ADF_POR_NORMAL) ? 1.0 : 0.0;
@@ -165,7 +167,8 @@ __device__ __forceinline__ void jst_matrix_face(const Line& L, const double gam[
     const double aAvg = sqrt(a2Avg);
     const double unAvg = uAvg * sx + vAvg * sy + wAvg * sz;
     const double ovaAvg = 1.0 / aAvg, ova2Avg = 1.0 / a2Avg;
-    double lam1 = fabs(unAvg + aAvg), lam2 = fabs(unAvg - aAvg), lam3 = fabs(unAvg);
+    const double sface = sFace * tmp;         // fluxes.F90:616
+    double lam1 = fabs(unAvg - sface + aAvg), lam2 = fabs(unAvg - sface - aAvg), lam3 = fabs(unAvg - sface);
     const double rrad = lam3 + aAvg;
     lam1 = fmax(lam1, 0.25 * rrad) * area;    // epsAcoustic
     lam2 = fmax(lam2, 0.25 * rrad) * area;
@@ -212,7 +215,7 @@ __device__ __forceinline__ void muscl(int lim, double omk, double opk, double fa
 // (fluxes.F90:1790-1889 + riemannFlux :2296-2532)
 __device__ __forceinline__ void roe_face(const Line& L, const double gam[5], int l, double nx, double ny, double nz, int por,
                                          int lim, double kappaCoef, double rFil, double gammaConstant, double sign,
-                                         double acc[5])
+                                         double acc[5], double sFace = 0.0)
 {
     const int r = l + 1, ll = l - 1, rr = l + 2;
     double left[5], right[5];
@@ -260,10 +263,11 @@ __device__ __forceinline__ void roe_face(const Line& L, const double gam[5], int
     const double aAvg = sqrt(a2Avg);
     double unAvg = uAvg * sx + vAvg * sy + wAvg * sz;
     const double ovaAvg = 1.0 / aAvg, ova2Avg = 1.0 / a2Avg;
-    if (por == ADF_POR_BOUND) unAvg = 0.0;   // rFace = 0 (no grid velocity)
+    const double rFace = sFace * tmp;          // fluxes.F90:2420
+    if (por == ADF_POR_BOUND) unAvg = rFace;
     const double eta = 0.5 * (fabs((left[1] - right[1]) * sx + (left[2] - right[2]) * sy + (left[3] - right[3]) * sz) +
                               fabs(sqrt(gammaFace * left[4] / left[0]) - sqrt(gammaFace * right[4] / right[0])));
-    double lam1 = fabs(unAvg + aAvg), lam2 = fabs(unAvg - aAvg), lam3 = fabs(unAvg);
+    double lam1 = fabs(unAvg - rFace + aAvg), lam2 = fabs(unAvg - rFace - aAvg), lam3 = fabs(unAvg - rFace);
     tmp = 2.0 * eta;
     if (lam1 < tmp) lam1 = eta + 0.25 * lam1 * lam1 / eta;
     if (lam2 < tmp) lam2 = eta + 0.25 * lam2 * lam2 / eta;
@@ -281,7 +285,8 @@ __device__ __forceinline__ void roe_face(const Line& L, const double gam[5], int
 template <int SCHEME, bool VISC>
 __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, long c, long s, const double* __restrict__ sN,
                                          const double* __restrict__ rad, int porM, int porP, double sslim,
-                                         double fis2, double fis4, bool doDiss, int lim, double dwc[5], double fwd[5])
+                                         double fis2, double fis4, bool doDiss, int lim, double dwc[5], double fwd[5],
+                                         const double* __restrict__ sF)
 {
     Line L;
     load_line(b, c, s, L);
@@ -289,8 +294,10 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
     // minus face: normal stored at the left cell c-s ; plus face at c
     const double mx = sN[c - s], my = sN[c - s + nb], mz = sN[c - s + 2 * nb];
     const double px = sN[c], py = sN[c + nb], pz = sN[c + 2 * nb];
-    central_face(L, 1, mx, my, mz, porM, -1.0, dwc);
-    central_face(L, 2, px, py, pz, porP, +1.0, dwc);
+    // grid velocity through the two faces (sFaceI/J/K of a moving block)
+    const double sfM = sF ? sF[c - s] : 0.0, sfP = sF ? sF[c] : 0.0;
+    central_face(L, 1, mx, my, mz, porM, -1.0, dwc, sfM);
+    central_face(L, 2, px, py, pz, porP, +1.0, dwc, sfP);
     if (!doDiss) return;
     if (SCHEME == ADFLOW_DISS_SCALAR && !kp.fineGrid) {
         // coarse multigrid levels: first-order scalar dissipation
@@ -330,8 +337,8 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
         for (int m = 1; m < 4; ++m) gam[m] = b.gamma[c + (m - 2) * s];
         if (SCHEME == ADFLOW_DISS_MATRIX && !kp.fineGrid) {
             const double fis0 = kp.rFil * kp.vis2Coarse;
-            jst_matrix_face(L, gam, 1, mx, my, mz, porM, 0.0, 0.0, fis0, 0.0, +1.0, fwd, true);
-            jst_matrix_face(L, gam, 2, px, py, pz, porP, 0.0, 0.0, fis0, 0.0, -1.0, fwd, true);
+            jst_matrix_face(L, gam, 1, mx, my, mz, porM, 0.0, 0.0, fis0, 0.0, +1.0, fwd, true, false, 0.0, sfM);
+            jst_matrix_face(L, gam, 2, px, py, pz, porP, 0.0, 0.0, fis0, 0.0, -1.0, fwd, true, false, 0.0, sfP);
         } else if (SCHEME == ADFLOW_DISS_MATRIX) {
             const bool approx = kp.dissApprox != 0;
             double sv[5];
@@ -340,11 +347,11 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
             const double dm = mat_sensor(sv[0], sv[1], sv[2], sslim);
             const double d0 = mat_sensor(sv[1], sv[2], sv[3], sslim);
             const double dp = mat_sensor(sv[2], sv[3], sv[4], sslim);
-            jst_matrix_face(L, gam, 1, mx, my, mz, porM, dm, d0, fis2, fis4, +1.0, fwd, false, approx, kp.sigma);
-            jst_matrix_face(L, gam, 2, px, py, pz, porP, d0, dp, fis2, fis4, -1.0, fwd, false, approx, kp.sigma);
+            jst_matrix_face(L, gam, 1, mx, my, mz, porM, dm, d0, fis2, fis4, +1.0, fwd, false, approx, kp.sigma, sfM);
+            jst_matrix_face(L, gam, 2, px, py, pz, porP, d0, dp, fis2, fis4, -1.0, fwd, false, approx, kp.sigma, sfP);
         } else {   // Roe upwind: fw(left) += flux, fw(right) -= flux
-            roe_face(L, gam, 1, mx, my, mz, porM, lim, kp.kappaCoef, kp.rFil, kp.gammaConstant, -1.0, fwd);
-            roe_face(L, gam, 2, px, py, pz, porP, lim, kp.kappaCoef, kp.rFil, kp.gammaConstant, +1.0, fwd);
+            roe_face(L, gam, 1, mx, my, mz, porM, lim, kp.kappaCoef, kp.rFil, kp.gammaConstant, -1.0, fwd, sfM);
+            roe_face(L, gam, 2, px, py, pz, porP, lim, kp.kappaCoef, kp.rFil, kp.gammaConstant, +1.0, fwd, sfP);
         }
     }
 }
@@ -377,9 +384,22 @@ __global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid(const BlkView* __rest
     const int lim = kp.fineGrid ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;
 
     double dwc[5] = {0, 0, 0, 0, 0}, fwd[5] = {0, 0, 0, 0, 0};
-    dir_flux<SCHEME, VISC>(b, kp, c, 1, b.sI, b.radI, flg_porI(fi), flg_porI(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd);
-    dir_flux<SCHEME, VISC>(b, kp, c, b.ldi, b.sJ, b.radJ, flg_porJ(fj), flg_porJ(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd);
-    dir_flux<SCHEME, VISC>(b, kp, c, b.ldk, b.sK, b.radK, flg_porK(fk), flg_porK(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd);
+    const double* sF = b.sFace;
+    dir_flux<SCHEME, VISC>(b, kp, c, 1, b.sI, b.radI, flg_porI(fi), flg_porI(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd, sF);
+    dir_flux<SCHEME, VISC>(b, kp, c, b.ldi, b.sJ, b.radJ, flg_porJ(fj), flg_porJ(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd,
+                           sF ? sF + nb : nullptr);
+    dir_flux<SCHEME, VISC>(b, kp, c, b.ldk, b.sK, b.radK, flg_porK(fk), flg_porK(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd,
+                           sF ? sF + 2 * nb : nullptr);
+    if (b.moving) {
+        // rotational source of the momentum equations, steady mode: the equations are solved in the inertial frame
+        // (inviscidCentralFlux, fluxes.F90:372-397)
+        const double wwx = kp.timeRef * b.rot[0], wwy = kp.timeRef * b.rot[1], wwz = kp.timeRef * b.rot[2];
+        const double rvol = b.w[c] * b.vol[c];
+        const double u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+        dwc[1] += rvol * (wwy * w - wwz * v);
+        dwc[2] += rvol * (wwz * u - wwx * w);
+        dwc[3] += rvol * (wwx * v - wwy * u);
+    }
 
     const double blank = flg_blank(f0);
 #pragma unroll

@@ -41,11 +41,14 @@ struct SaDir {   // per-direction data of one cell
     double volm, volp;        // volumes of the minus / plus neighbour
     double nt[5];             // nuTilde at -2..+2
     double num, nup;          // laminar kinematic viscosity of the minus / plus neighbour
+    double qsf;               // grid velocity of a moving block: sFace(minus face) + sFace(plus face), else 0
 };
 
-__device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const double* __restrict__ sN, SaDir& d)
+// dirc: 0, 1, 2 = i, j, k (component of b.sFace)
+__device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const double* __restrict__ sN, SaDir& d, int dirc)
 {
     const long nb = b.nbox;
+    d.qsf = b.sFace ? b.sFace[c + dirc * nb] + b.sFace[c - s + dirc * nb] : 0.0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         d.sm[m] = sN[c - s + m * nb];
@@ -65,7 +68,7 @@ __device__ __forceinline__ double sa_advect(const SaDir& d, double vol0, double 
 {
     const double voli = 0.5 / vol0;
     const double xa = (d.sp[0] + d.sm[0]) * voli, ya = (d.sp[1] + d.sm[1]) * voli, za = (d.sp[2] + d.sm[2]) * voli;
-    const double uu = xa * u + ya * v + za * w;
+    const double uu = xa * u + ya * v + za * w - d.qsf * voli;       // qs = (sFace(m) + sFace(m-1)) voli, turbUtils.F90:906
     const double dwt = upwind_diff(secondOrd, uu > 0.0, d.nt[0], d.nt[1], d.nt[2], d.nt[3], d.nt[4]);
     if (uuOut) *uuOut = uu;
     return -uu * dwt;
@@ -110,9 +113,9 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(const BlkView* __r
     const long si = 1, sj = b.ldi, sk = b.ldk;
 
     SaDir di, dj, dk;
-    load_dir(b, c, si, b.sI, di);
-    load_dir(b, c, sj, b.sJ, dj);
-    load_dir(b, c, sk, b.sK, dk);
+    load_dir(b, c, si, b.sI, di, 0);
+    load_dir(b, c, sj, b.sJ, dj, 1);
+    load_dir(b, c, sk, b.sK, dk, 2);
 
     const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
     const double nut = dk.nt[2];
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab
     for (int m = n - 1; m >= 0; --m) {
         const long c = c0 + m * s;
         SaDir d;
-        load_dir(b, c, s, sN, d);
+        load_dir(b, c, s, sN, d, DIR);
         const double vol0 = b.vol[c];
         const double nu = b.rlv[c] / b.w[c];
         double c1m, c1p, uu;
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_rows_i(const BlkView* __res
     const long c = b.idx(i, j, k), nb = b.nbox;
     const double cb3Inv = 1.0 / kp.sa_cb3;
     SaDir d;
-    load_dir(b, c, 1, b.sI, d);
+    load_dir(b, c, 1, b.sI, d, 0);
     const double vol0 = b.vol[c];
     const double nu = b.rlv[c] / b.w[c];
     double c1m, c1p, uu;

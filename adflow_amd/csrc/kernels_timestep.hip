@@ -45,19 +45,24 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(const BlkView* __res
     double sy = b.sI[c - 1 + nb] + b.sI[c + nb];
     double sz = b.sI[c - 1 + 2 * nb] + b.sI[c + 2 * nb];
     const double si2 = sx * sx + sy * sy + sz * sz;
-    double ri = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz) + kp.acousticScaleFactor * sqrt(cc2 * si2));
+    // grid velocity of a moving block: sum over the two faces (solverUtils.F90:147-181)
+    const double* sF = b.sFace;
+    double sFace = sF ? sF[c - 1] + sF[c] : 0.0;
+    double ri = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * si2));
 
     sx = b.sJ[c - b.ldi] + b.sJ[c];
     sy = b.sJ[c - b.ldi + nb] + b.sJ[c + nb];
     sz = b.sJ[c - b.ldi + 2 * nb] + b.sJ[c + 2 * nb];
     const double sj2 = sx * sx + sy * sy + sz * sz;
-    double rj = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz) + kp.acousticScaleFactor * sqrt(cc2 * sj2));
+    sFace = sF ? sF[c - b.ldi + nb] + sF[c + nb] : 0.0;
+    double rj = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * sj2));
 
     sx = b.sK[c - b.ldk] + b.sK[c];
     sy = b.sK[c - b.ldk + nb] + b.sK[c + nb];
     sz = b.sK[c - b.ldk + 2 * nb] + b.sK[c + 2 * nb];
     const double sk2 = sx * sx + sy * sy + sz * sz;
-    double rk = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz) + kp.acousticScaleFactor * sqrt(cc2 * sk2));
+    sFace = sF ? sF[c - b.ldk + 2 * nb] + sF[c + 2 * nb] : 0.0;
+    double rk = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * sk2));
 
     const double rsum = ri + rj + rk;   // inviscid part of 1/dt (before scaling)
 

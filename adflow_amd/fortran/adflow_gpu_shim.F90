@@ -45,6 +45,9 @@ module adflowGpuShim
         type(c_ptr) :: w1, p1, wr
         type(c_ptr) :: mgIFine, mgJFine, mgKFine, mgIWeight, mgJWeight, mgKWeight
         type(c_ptr) :: mgICoarse, mgJCoarse, mgKCoarse
+        type(c_ptr) :: sFaceI, sFaceJ, sFaceK
+        real(c_double) :: rotRate(3)
+        integer(c_int32_t) :: addGridVelocities, blockIsMoving
     end type adflow_block_desc
 
     ! ---- mirror of adflow_comm_pattern ---------------------------------------
@@ -237,6 +240,7 @@ contains
     ! `allocate`d arrays (SURVEY.md §8(a) row T) so c_loc is legal.
     subroutine gpuRegisterBlock(nn, level, sps)
         use block, only: flowDoms
+        use cgnsGrid, only: cgnsDoms
         use flowVarRefState, only: nw
         integer(kind=intType), intent(in) :: nn, level, sps
         type(adflow_block_desc) :: d
@@ -266,6 +270,12 @@ contains
             if (associated(g%mgICoarse)) then
                 d%mgICoarse = c_loc(g%mgICoarse); d%mgJCoarse = c_loc(g%mgJCoarse); d%mgKCoarse = c_loc(g%mgKCoarse)
             end if
+            d%sFaceI = c_null_ptr; d%sFaceJ = c_null_ptr; d%sFaceK = c_null_ptr; d%rotRate = 0.0_c_double
+            d%addGridVelocities = merge(1, 0, b%addGridVelocities); d%blockIsMoving = merge(1, 0, b%blockIsMoving)
+            if (b%addGridVelocities) then
+                d%sFaceI = c_loc(b%sFaceI); d%sFaceJ = c_loc(b%sFaceJ); d%sFaceK = c_loc(b%sFaceK)
+            end if
+            if (b%blockIsMoving) d%rotRate = cgnsDoms(b%cgnsBlockID)%rotRate
         end associate
         call gpuCheck(adflow_gpu_block_register(int(nn, c_int), int(level, c_int), int(sps, c_int), d), "gpuRegisterBlock")
         call gpuCheck(adflow_gpu_upload_geometry(int(nn, c_int), int(level, c_int), int(sps, c_int)), "gpuRegisterBlock")

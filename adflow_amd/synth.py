@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -32,6 +32,7 @@ class Block:
     nz: int
     nw: int
     a: Dict[str, np.ndarray] = field(default_factory=dict)
+    rotRate: Optional[tuple] = None      # cgnsDoms%rotRate of a moving block (blockIsMoving), None at rest
 
     # index helpers (reference naming)
     @property
@@ -66,7 +67,29 @@ class Block:
         return self.a[name][2:self.il + 1, 2:self.jl + 1, 2:self.kl + 1]
 
     def copy(self) -> "Block":
-        return Block(self.nx, self.ny, self.nz, self.nw, {k: v.copy(order="F") for k, v in self.a.items()})
+        return Block(self.nx, self.ny, self.nz, self.nw, {k: v.copy(order="F") for k, v in self.a.items()}, self.rotRate)
+
+
+def add_grid_velocities(blk: "Block", prm, rotRate=(0.05, -0.03, 0.12), rotCenter=(0.3, -0.2, 0.1)):
+    """Make `blk` a block of a steadily rotating frame: sFaceI/J/K = (timeRef * rotRate x (face centre - rotCenter)) . S
+    (what gridVelocitiesFineLevel + normalVelocitiesAllLevels leave in the block, solverUtils.F90:672-1190, 2063-2260)
+    and blockIsMoving with cgnsDoms%rotRate for the rotational source term."""
+    x = blk["x"]
+    om = prm.timeRef * np.asarray(rotRate, float)
+    c0 = np.asarray(rotCenter, float)
+
+    def face(xs, S):
+        v = np.cross(np.broadcast_to(om, xs.shape), xs - c0)
+        return np.asfortranarray((v * S).sum(axis=-1))
+    # face centre = mean of the four nodes of the face; node (i,j,k) of x(0:ie,0:je,0:ke) is x[i,j,k]
+    xi = 0.25 * (x[:, :-1, :-1] + x[:, 1:, :-1] + x[:, :-1, 1:] + x[:, 1:, 1:])     # (0:ie, 1:je, 1:ke)
+    xj = 0.25 * (x[:-1, :, :-1] + x[1:, :, :-1] + x[:-1, :, 1:] + x[1:, :, 1:])     # (1:ie, 0:je, 1:ke)
+    xk = 0.25 * (x[:-1, :-1, :] + x[1:, :-1, :] + x[:-1, 1:, :] + x[1:, 1:, :])     # (1:ie, 1:je, 0:ke)
+    blk["sFaceI"] = face(xi, blk["sI"])
+    blk["sFaceJ"] = face(xj, blk["sJ"])
+    blk["sFaceK"] = face(xk, blk["sK"])
+    blk.rotRate = tuple(float(r) for r in rotRate)
+    return blk
 
 
 def F(shape, dtype=np.float64):
@@ -175,8 +198,9 @@ def sa_eddy_viscosity(prm: FlowParams, rho, nut, rlv):
 
 def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.0), amp=0.02,
                stretch_k=1.0, wall_kmin=None, noise=0.02, wave=0.05, origin=(0.0, 0.0, 0.0), holes=0.0,
-               noflux_jmax=False) -> Block:
-    """Analytic curvilinear block + perturbed free-stream state."""
+               noflux_jmax=False, moving=False) -> Block:
+    """Analytic curvilinear block + perturbed free-stream state.
+    moving: a block of a steadily rotating frame (add_grid_velocities)."""
     rng = np.random.default_rng(seed)
     nw = prm.nw
     b = Block(nx, ny, nz, nw)
@@ -242,6 +266,8 @@ def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.
                   + x[1:, 1:, :-1] + x[:-1, 1:, :-1] + x[1:, :-1, :-1] + x[:-1, :-1, :-1])
     d = xc[1:nx + 1, 1:ny + 1, 1:nz + 1, 2] - origin[2]
     b["d2Wall"] = np.asfortranarray(np.maximum(d, 1e-6))
+    if moving:
+        add_grid_velocities(b, prm)
     return b
 
 

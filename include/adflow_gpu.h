@@ -147,6 +147,12 @@ typedef struct adflow_block_desc {
     double *mgIWeight, *mgJWeight, *mgKWeight;  /* (2:il) (2:jl) (2:kl) */
     /* on a FINE block: nearest and next-nearest coarse cell of each fine cell */
     int32_t *mgICoarse, *mgJCoarse, *mgKCoarse; /* (2:il,2) (2:jl,2) (2:kl,2) */
+    /* moving blocks (rotating frame / ALE, block.F90 sFaceI/J/K, addGridVelocities, blockIsMoving): dot product of the
+     * face velocity with the face normal; NULL / 0 for a block at rest.  rotRate = cgnsDoms(nbkGlobal)%rotRate, used by
+     * the rotational source of inviscidCentralFlux (fluxes.F90:372-397) when blockIsMoving in steady mode */
+    double *sFaceI, *sFaceJ, *sFaceK;           /* (0:ie,1:je,1:ke) (1:ie,0:je,1:ke) (1:ie,1:je,0:ke) */
+    double rotRate[3];
+    int32_t addGridVelocities, blockIsMoving;
 } adflow_block_desc;
 
 /* 1-to-1 halo communication pattern of one level and one halo depth: the

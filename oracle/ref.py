@@ -44,6 +44,7 @@ def load(fast: bool = False) -> ctypes.CDLL:
         lib.ref_call_level.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         lib.ref_set_bocos.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.ref_set_bcdata.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p]
+        lib.ref_set_moving.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         _LIB = lib
     return _LIB
 
@@ -136,7 +137,10 @@ def bind_block(blk, prm) -> None:
                     ("bvti1", (je, ke, 1)), ("bvti2", (je, ke, 1)), ("bvtj1", (ie, ke, 1)),
                     ("bvtj2", (ie, ke, 1)), ("bvtk1", (ie, je, 1)), ("bvtk2", (ie, je, 1))):
         need(nm, shp)
-    for name in ["w", "p", "gamma", "rlv", "rev", "vol", "volRef", "iblank", "x", "sI", "sJ", "sK",
+    rot = np.asarray(blk.rotRate if getattr(blk, "rotRate", None) is not None else (0.0, 0.0, 0.0), dtype=np.float64)
+    lib.ref_set_moving(int("sFaceI" in a), int(getattr(blk, "rotRate", None) is not None), rot.ctypes.data)
+    for name in [n for n in ("sFaceI", "sFaceJ", "sFaceK") if n in a] + \
+                ["w", "p", "gamma", "rlv", "rev", "vol", "volRef", "iblank", "x", "sI", "sJ", "sK",
                  "porI", "porJ", "porK", "d2Wall", "dw", "fw", "scratch", "aa", "wn", "pn", "wr", "w1", "p1",
                  "bmti1", "bmti2", "bmtj1", "bmtj2", "bmtk1", "bmtk2",
                  "bvti1", "bvti2", "bvtj1", "bvtj2", "bvtk1", "bvtk2",

@@ -182,6 +182,12 @@ contains
         case ('x')
             call c_f_pointer(ptr, t4, [ie + 1, je + 1, ke + 1, 3])
             x(0:, 0:, 0:, 1:) => t4
+        case ('sFaceI')
+            call c_f_pointer(ptr, t3, [ie + 1, je, ke]); sFaceI(0:, 1:, 1:) => t3
+        case ('sFaceJ')
+            call c_f_pointer(ptr, t3, [ie, je + 1, ke]); sFaceJ(1:, 0:, 1:) => t3
+        case ('sFaceK')
+            call c_f_pointer(ptr, t3, [ie, je, ke + 1]); sFaceK(1:, 1:, 0:) => t3
         case ('sI')
             call c_f_pointer(ptr, t4, [ie + 1, je, ke, 3])
             sI(0:, 1:, 1:, 1:) => t4
@@ -494,6 +500,19 @@ contains
         q(1:3 * n) = reshape(viscSubface(mm)%q, [3 * n])
     end subroutine ref_get_wall_stress
 
+    ! blockPointers%addGridVelocities / %blockIsMoving and cgnsDoms(nbkGlobal)%rotRate of the bound block
+    subroutine ref_set_moving(addGridVel, isMoving, rotRate) bind(C, name="ref_set_moving")
+        use blockPointers
+        use cgnsGrid, only: cgnsDoms, cgnsNDom
+        integer(c_int), value :: addGridVel, isMoving
+        real(c_double), intent(in) :: rotRate(3)
+        addGridVelocities = (addGridVel /= 0); blockIsMoving = (isMoving /= 0)
+        if (.not. allocated(cgnsDoms)) then
+            allocate (cgnsDoms(1)); cgnsNDom = 1
+        end if
+        cgnsDoms(1)%rotRate = rotRate; cgnsDoms(1)%rotCenter = zero; cgnsDoms(1)%rotatingFrameSpecified = (isMoving /= 0)
+    end subroutine ref_set_moving
+
     subroutine ref_set_inlet_treatment(mm, v) bind(C, name="ref_set_inlet_treatment")
         use blockPointers
         integer(c_int), value :: mm, v
@@ -755,7 +774,10 @@ contains
             d%BCType => BCType; d%BCFaceID => BCFaceID; d%BCData => BCData
             d%globalCell => globalCell; d%s => s; d%viscSubface => viscSubface
             d%nOrphans = 0
-            d%blockIsMoving = .false.; d%addGridVelocities = .false.
+            d%blockIsMoving = blockIsMoving; d%addGridVelocities = addGridVelocities
+            if (addGridVelocities) then
+                d%sFaceI => sFaceI; d%sFaceJ => sFaceJ; d%sFaceK => sFaceK
+            end if
             d%iblank => iblank
             d%viscIminPointer => viscIminPointer; d%viscImaxPointer => viscImaxPointer
             d%viscJminPointer => viscJminPointer; d%viscJmaxPointer => viscJmaxPointer

@@ -62,3 +62,23 @@ def test_euler_march_variants(engine, pipe, kch):
     finally:
         engine.set_tuning("march_pipe", 2)
         engine.set_tuning("march_kch", 32)
+
+
+def test_moving_blocks(engine):
+    """grid velocities sFaceI/J/K and the rotational source of a steadily rotating block in the central flux, matrix /
+    Roe dissipation, spectral radii, SA advection + DDADI coefficients and the D-ADI diagonals
+    (fluxes.F90:50,372-397,616,2420; solverUtils.F90:147-181; turbUtils.F90:906; residuals.F90:1192)"""
+    from adflow_amd.params import (RANSEquations, DADI, noResAveraging, alternateResAveraging, secondOrder, dissScalar, dissMatrix,
+                                   upwind)
+    from adflow_amd.topology import BrickTopology
+    mv = dict(moving=True)
+    for sd in (dissScalar, dissMatrix, upwind):
+        checks.check_block_res(engine, (70, 9, 8), FlowParams(spaceDiscr=sd), seed=sd, wall_kmin=True, **mv)
+    checks.check_rk_residual_sequence(engine, (24, 10, 8), FlowParams(), **mv)
+    checks.check_block_res(engine, (24, 10, 8), FlowParams(equations=RANSEquations, orderTurb=secondOrder), seed=4, stretch_k=2.0, **mv)
+    checks.check_rk_smoother(engine, BrickTopology(2, 1, 1, 20, 9, 8), FlowParams(resAveraging=alternateResAveraging), **mv)
+    checks.check_dadi_smoother(engine, BrickTopology(1, 2, 1, 16, 8, 8),
+                               FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging), stretch_k=2.0, **mv)
+    checks.check_sa_solve(engine, BrickTopology(1, 1, 2, 12, 8, 8), FlowParams(equations=RANSEquations, nSubIterTurb=2),
+                          stretch_k=2.0, **mv)
+    checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 16, 8, 8), FlowParams(), [0, 1, 0, -1], ncycles=1, **mv)

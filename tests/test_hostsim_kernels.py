@@ -241,6 +241,23 @@ def test_apply_all_bc_subsonic_and_polar(hostsim_engine):
         2: ((5, 4, 6), {1: -12, 2: -8, 3: -3, 4: -6}, {3: -6})}, stretch_k=2.0)
 
 
+def test_moving_blocks(hostsim_engine):
+    """grid velocities sFaceI/J/K and the rotational source of a steadily rotating block in the central flux, matrix /
+    Roe dissipation, spectral radii, SA advection + DDADI coefficients and the D-ADI diagonals
+    (fluxes.F90:50,372-397,616,2420; solverUtils.F90:147-181; turbUtils.F90:906; residuals.F90:1192)"""
+    mv = dict(moving=True)
+    for sd in (dissScalar, dissMatrix, upwind):
+        checks.check_block_res(hostsim_engine, (8, 6, 5), FlowParams(spaceDiscr=sd), seed=sd, wall_kmin=True, **mv)
+    checks.check_rk_residual_sequence(hostsim_engine, (9, 7, 5), FlowParams(), **mv)
+    checks.check_block_res(hostsim_engine, (8, 6, 5), FlowParams(equations=RANSEquations, orderTurb=secondOrder), seed=4, stretch_k=2.0, **mv)
+    checks.check_rk_smoother(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams(resAveraging=alternateResAveraging), **mv)
+    checks.check_dadi_smoother(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
+                               FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging), stretch_k=2.0, **mv)
+    checks.check_sa_solve(hostsim_engine, BrickTopology(1, 1, 2, 5, 4, 4), FlowParams(equations=RANSEquations, nSubIterTurb=2),
+                          stretch_k=2.0, **mv)
+    checks.check_mg_cycle(hostsim_engine, BrickTopology(1, 1, 1, 8, 8, 4), FlowParams(), [0, 1, 0, -1], ncycles=1, **mv)
+
+
 def test_multiblock_bc(hostsim_engine):
     """several blocks with different subface lists: the level-batched BC launches against the reference's block loop"""
     checks.check_multiblock_bc(hostsim_engine, FlowParams(), {
