@@ -64,6 +64,7 @@ class AdflowBcSubface(ctypes.Structure):
         ("rho", c_void_p), ("velx", c_void_p), ("vely", c_void_p), ("velz", c_void_p), ("ps", c_void_p),
         ("ptInlet", c_void_p), ("ttInlet", c_void_p), ("htInlet", c_void_p),
         ("flowXdirInlet", c_void_p), ("flowYdirInlet", c_void_p), ("flowZdirInlet", c_void_p), ("turbInlet", c_void_p),
+        ("symNorm", c_double * 3),
     ]
 
 
@@ -112,7 +113,7 @@ BC_CALLBACK = ctypes.CFUNCTYPE(None, c_int, c_int)
 
 # array identifiers (include/adflow_gpu.h)
 (ARR_W, ARR_P, ARR_GAMMA, ARR_RLV, ARR_REV, ARR_DW, ARR_FW, ARR_DTL, ARR_RADI, ARR_RADJ, ARR_RADK, ARR_AA,
- ARR_NODAL_GRADS, ARR_WN, ARR_PN, ARR_W1, ARR_P1, ARR_WR, ARR_VOL, ARR_SI, ARR_SJ, ARR_SK) = range(1, 23)
+ ARR_NODAL_GRADS, ARR_WN, ARR_PN, ARR_W1, ARR_P1, ARR_WR, ARR_VOL, ARR_SI, ARR_SJ, ARR_SK, ARR_X) = range(1, 24)
 
 RES_UPDATE_INTERMED, RES_FLOW, RES_TURB, RES_CLOSURES, RES_HALO = 1, 2, 4, 8, 16
 
@@ -129,7 +130,7 @@ EXPORTS = [
     "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
-    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2",
+    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2", "adflow_gpu_xhalo", "adflow_gpu_exchange_coor",
     "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
@@ -171,6 +172,8 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_download_wall_stress.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.adflow_gpu_upload_coordinates.argtypes = [c_int, c_int, c_int]
     lib.adflow_gpu_update_geometry.argtypes = [c_int]
+    lib.adflow_gpu_xhalo.argtypes = [c_int]
+    lib.adflow_gpu_exchange_coor.argtypes = [c_int]
     lib.adflow_gpu_reference_shock_sensor.argtypes = [c_int]
     lib.adflow_gpu_set_tuning.argtypes = [c_char_p, c_int]
     lib.adflow_gpu_abi_sizes.argtypes = [POINTER(c_int), POINTER(c_int)]

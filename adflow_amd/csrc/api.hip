@@ -633,6 +633,7 @@ static int array_spec(Block* b, int which, double** dev, int* nc, int lo[3], int
     case ADFLOW_ARR_WR: *dev = v.wr; *nc = 5; owned(); break;
     case ADFLOW_ARR_NODAL_GRADS:
         *dev = v.grad; *nc = 12; lo[0] = lo[1] = lo[2] = 1; n[0] = v.il; n[1] = v.jl; n[2] = v.kl; break;
+    case ADFLOW_ARR_X: *dev = v.x; *nc = 3; lo[0] = lo[1] = lo[2] = 0; n[0] = v.ie + 1; n[1] = v.je + 1; n[2] = v.ke + 1; break;
     case ADFLOW_ARR_SI: *dev = v.sI; *nc = 3; lo[0] = 0; lo[1] = lo[2] = 1; n[0] = v.ie + 1; n[1] = v.je; n[2] = v.ke; break;
     case ADFLOW_ARR_SJ: *dev = v.sJ; *nc = 3; lo[1] = 0; lo[0] = lo[2] = 1; n[0] = v.ie; n[1] = v.je + 1; n[2] = v.ke; break;
     case ADFLOW_ARR_SK: *dev = v.sK; *nc = 3; lo[2] = 0; lo[0] = lo[1] = 1; n[0] = v.ie; n[1] = v.je; n[2] = v.ke + 1; break;
@@ -1149,6 +1150,7 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
             up(f.flowYdirInlet, 1, &d.fdy) || up(f.flowZdirInlet, 1, &d.fdz) || up(v.nw > 5 ? f.turbInlet : nullptr, 1, &d.turbInlet))
             return 1;
         d.inletTreatment = f.subsonicInletTreatment; d.pad = 0;
+        for (int q = 0; q < 3; ++q) d.symNorm[q] = f.symNorm[q];
         d.tauq = nullptr;
         if (m < nViscBocos) {
             int r[4];
@@ -1426,7 +1428,7 @@ int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* 
 {
     if (g_device < 0) return fail("adflow_gpu_init has not been called");
     if (!p) return fail("null comm pattern");
-    if (nLayers != 1 && nLayers != 2) return fail("nLayers must be 1 or 2");
+    if (nLayers < 0 || nLayers > 2) return fail("nLayers must be 1 or 2 (cell halos) or 0 (the node pattern of exchangeCoor)");
     auto key = std::make_pair(level, nLayers);
     if (g_comm.count(key)) {
         CommPattern& old = g_comm[key];
@@ -1521,6 +1523,8 @@ int adflow_gpu_halo_unpack(int level, int nLayers, int islot, int varStart, int 
     return 0;
 }
 
+static int comm_exchange_enqueue(CommPattern* cp, BlkView* tab, unsigned mask, int nvar);
+
 static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers)
 {
     CommPattern* cp;
@@ -1528,7 +1532,26 @@ static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPr
     unsigned mask; int nvar;
     if (halo_mask(varStart, varEnd, commPressure, commVisc, &mask, &nvar)) return 1;
     if (nvar == 0) return 0;
-    BlkView* tab = g_tab[level];
+    if (comm_exchange_enqueue(cp, g_tab[level], mask, nvar)) return 1;
+    // whalo2 closes by recomputing the total energy of the owned cells from p when
+    // both travelled (haloExchange.F90:178-196)
+    const bool bothPAndE = commPressure && varStart <= 5 && varEnd >= 5;
+    for_level(level, [&](Block* b) {
+        // the exchange never touches owned cells: when their rhoE was produced by
+        // computeEtotBlock already (stage update, or a previous whalo2) the pass is an identity
+        if (nLayers == 2 && bothPAndE && !b->etot_consistent) {
+            launch_etot_owned(b->v, g_opts.gammaConstant, g_stream);
+            b->etot_consistent = true;
+        }
+        b->ss_valid = false;
+        return 0;
+    });
+    return 0;
+}
+
+// pack -> grouped RCCL send/recv -> same-GPU copies -> unpack of the variables in `mask` over one pattern
+static int comm_exchange_enqueue(CommPattern* cp, BlkView* tab, unsigned mask, int nvar)
+{
     // pack every outgoing message, then one grouped RCCL send/recv over xGMI,
     // with the same-GPU copies enqueued behind the packs (they only read owned cells)
     for (auto& l : cp->sends) launch_halo_pack(tab, l.blkA, l.offA, l.n, mask, l.buf, g_stream);
@@ -1547,20 +1570,32 @@ static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPr
     }
     launch_halo_copy(tab, cp->local.blkA, cp->local.offA, cp->local.blkB, cp->local.offB, cp->local.n, mask, g_stream);
     for (auto& l : cp->recvs) launch_halo_unpack(tab, l.blkA, l.offA, l.n, mask, l.buf, g_stream);
-    // whalo2 closes by recomputing the total energy of the owned cells from p when
-    // both travelled (haloExchange.F90:178-196)
-    const bool bothPAndE = commPressure && varStart <= 5 && varEnd >= 5;
-    for_level(level, [&](Block* b) {
-        // the exchange never touches owned cells: when their rhoE was produced by
-        // computeEtotBlock already (stage update, or a previous whalo2) the pass is an identity
-        if (nLayers == 2 && bothPAndE && !b->etot_consistent) {
-            launch_etot_owned(b->v, g_opts.gammaConstant, g_stream);
-            b->etot_consistent = true;
-        }
-        b->ss_valid = false;
-        return 0;
-    });
     return 0;
+}
+
+// exchangeCoor (haloExchange.F90:2456-2640): the three coordinates over the node pattern (nLayers key 0)
+int adflow_gpu_exchange_coor(int level)
+{
+    if (need_ready()) return 1;
+    CommPattern* cp;
+    if (build_comm(level, 0, &cp)) return 1;
+    if (comm_exchange_enqueue(cp, g_tab[level], 7u << 11, 3)) return 1;
+    for_level(level, [&](Block* b) { b->face_vectors_valid = false; return 0; });
+    return sync_and_check();
+}
+
+// xhalo_block (adjointExtra.F90:365-599) of every block of the level
+int adflow_gpu_xhalo(int level)
+{
+    if (need_ready()) return 1;
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_xhalo_level(t.tab, t.n, t.nx, t.ny, t.nz, g_stream);
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return 1;
+    for (const BcPhase& ph : pl->ordinal) launch_xhalo_symm(t.tab, pl->d_ent, pl->d_order, ph, g_stream);
+    for_level(level, [&](Block* b) { b->face_vectors_valid = false; return 0; });
+    return sync_and_check();
 }
 
 int adflow_gpu_halo_exchange(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers)

@@ -102,6 +102,7 @@ struct BcFaceDev {
     const double *pt, *tt, *ht, *fdx, *fdy, *fdz;   // subsonic inflow with total conditions
     const double* turbInlet;                       // prescribed turbulence variable of inflow subfaces
     int inletTreatment, pad;
+    double symNorm[3];     // BCData%symNorm of a symmetry plane (xhalo_block)
     double* tauq;          // viscous subfaces: viscSubface%tau(:,:,1:6), %q(:,:,1:3) over the OWNED face cells, component-major
 };
 
@@ -162,6 +163,8 @@ void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStre
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 int viscous_is_tiled();
+void launch_xhalo_level(const BlkView* tab, int nslots, int nx, int ny, int nz, hipStream_t s);
+void launch_xhalo_symm(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, hipStream_t s);
 void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, const KParams& kp, hipStream_t s);
 void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_face_vectors(const BlkView& b, hipStream_t s);

@@ -134,6 +134,103 @@ __global__ __launch_bounds__(256) void k_boundary_normals(BlkView b, BcFaceDev f
     norm[t + 2 * n] = fact * zzp;
 }
 
+// ---------------------------------------------------------------------------
+// xhalo_block (adjointExtra.F90:365-599): halo nodes by linear extrapolation, three ordered passes
+//   0: i = 0 / ie   for j = 1..jl, k = 1..kl
+//   1: j = 0 / je   for i = 0..ie, k = 1..kl   (reads what pass 0 wrote)
+//   2: k = 0 / ke   for i = 0..ie, j = 0..je   (reads passes 0 and 1)
+// then the mirror image in symmetry planes.  Level-batched: blockIdx.z = block slot.
+// ---------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(256) void k_xhalo(const BlkView* __restrict__ tab)
+{
+    const BlkView& b = tab[blockIdx.z + 1];
+    if (b.nx == 0) return;
+    const int a = blockIdx.x * 64 + threadIdx.x, c2 = blockIdx.y * 4 + threadIdx.y;
+    const long nb = b.nbox;
+    long h0, s0, h1, s1;     // halo node + step towards the interior, on the min and on the max side
+    if (PASS == 0) {
+        const int j = a + 1, k = c2 + 1;
+        if (j > b.jl || k > b.kl) return;
+        h0 = b.idx(0, j, k); s0 = 1; h1 = b.idx(b.ie, j, k); s1 = -1;
+    } else if (PASS == 1) {
+        const int i = a, k = c2 + 1;
+        if (i > b.ie || k > b.kl) return;
+        h0 = b.idx(i, 0, k); s0 = b.ldi; h1 = b.idx(i, b.je, k); s1 = -(long)b.ldi;
+    } else {
+        const int i = a, j = c2;
+        if (i > b.ie || j > b.je) return;
+        h0 = b.idx(i, j, 0); s0 = b.ldk; h1 = b.idx(i, j, b.ke); s1 = -(long)b.ldk;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        double* x = b.x + m * nb;
+        x[h0] = 2.0 * x[h0 + s0] - x[h0 + 2 * s0];
+        x[h1] = 2.0 * x[h1 + s1] - x[h1 + 2 * s1];
+    }
+}
+
+void launch_xhalo_level(const BlkView* tab, int nslots, int nx, int ny, int nz, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    const int ie = nx + 2, je = ny + 2, jl = ny + 1, kl = nz + 1;
+    dim3 blk(64, 4, 1);
+    hipLaunchKernelGGL(k_xhalo<0>, dim3((jl + 63) / 64, (kl + 3) / 4, nslots), blk, 0, s, tab);
+    hipLaunchKernelGGL(k_xhalo<1>, dim3((ie + 64) / 64, (kl + 3) / 4, nslots), blk, 0, s, tab);
+    hipLaunchKernelGGL(k_xhalo<2>, dim3((ie + 64) / 64, (je + 4) / 4, nslots), blk, 0, s, tab);
+}
+
+// symmetry planes: halo node = mirror image of the second node plane, x(0) = x(2) + 2 ((x(1) - x(2)) . n) n, over the
+// node range of the subface extended to 0 / max+1 where it reaches the edge of the block face (adjointExtra.F90:431-597)
+__global__ __launch_bounds__(256) void k_xhalo_symm(const BlkView* __restrict__ tab, const BcEntry* __restrict__ ent,
+                                                    const int* __restrict__ order)
+{
+    const BcEntry& e = ent[order[blockIdx.y]];
+    const BcFaceDev& f = e.f;
+    if (f.type != ADFLOW_BC_SYMM) return;
+    const BlkView& b = tab[e.slot];
+    double nx = f.symNorm[0], ny = f.symNorm[1], nz = f.symNorm[2];
+    const double length = sqrt(nx * nx + ny * ny + nz * nz);
+    nx /= length; ny /= length; nz /= length;
+    if (!(length > 1.e-25)) return;          // eps of constants.F90: singular (collapsed) symmetry plane
+    int r[4];
+    bc_owned_range(f.faceID, f.icBeg, f.icEnd, f.jcBeg, f.jcEnd, b.il, b.jl, b.kl, r);
+    const int iiMax = (f.faceID <= ADFLOW_IMAX) ? b.jl : b.il, jjMax = (f.faceID <= ADFLOW_JMAX) ? b.kl : b.jl;
+    int iBeg = r[0] - 1, iEnd = r[1], jBeg = r[2] - 1, jEnd = r[3];      // node range of the subface
+    if (iBeg == 1) iBeg = 0;
+    if (iEnd == iiMax) iEnd = iiMax + 1;
+    if (jBeg == 1) jBeg = 0;
+    if (jEnd == jjMax) jEnd = jjMax + 1;
+    const int na = iEnd - iBeg + 1, nbb = jEnd - jBeg + 1;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (na <= 0 || nbb <= 0 || t >= (long)na * nbb) return;
+    const int a = iBeg + (int)(t % na), c2 = jBeg + (int)(t / na);
+    long h, s;
+    switch (f.faceID) {
+    case ADFLOW_IMIN: h = b.idx(0, a, c2); s = 1; break;
+    case ADFLOW_IMAX: h = b.idx(b.ie, a, c2); s = -1; break;
+    case ADFLOW_JMIN: h = b.idx(a, 0, c2); s = b.ldi; break;
+    case ADFLOW_JMAX: h = b.idx(a, b.je, c2); s = -(long)b.ldi; break;
+    case ADFLOW_KMIN: h = b.idx(a, c2, 0); s = b.ldk; break;
+    default: h = b.idx(a, c2, b.ke); s = -(long)b.ldk;
+    }
+    const long nb = b.nbox;
+    const long n1 = h + s, n2 = h + 2 * s;
+    const double v1 = b.x[n1] - b.x[n2], v2 = b.x[n1 + nb] - b.x[n2 + nb], v3 = b.x[n1 + 2 * nb] - b.x[n2 + 2 * nb];
+    const double dot = 2.0 * (v1 * nx + v2 * ny + v3 * nz);
+    b.x[h] = b.x[n2] + dot * nx;
+    b.x[h + nb] = b.x[n2 + nb] + dot * ny;
+    b.x[h + 2 * nb] = b.x[n2 + 2 * nb] + dot * nz;
+}
+
+void launch_xhalo_symm(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, hipStream_t s)
+{
+    if (ph.count <= 0) return;
+    // the node range is at most (cells + 3) per direction: bound it by (sqrt(maxCells) + 3)^2 generously via maxCells * 4 + 64
+    const long maxNodes = ph.maxCells * 4 + 64;
+    hipLaunchKernelGGL(k_xhalo_symm, dim3((unsigned)((maxNodes + 255) / 256), ph.count, 1), dim3(256), 0, s, tab, ent, order + ph.first);
+}
+
 void launch_volume_metric(const BlkView& b, int rightHanded, hipStream_t s)
 {
     const dim3 blk(GM_BX, GM_BY, 1);

@@ -10,13 +10,16 @@
 // store and the unpack load are coalesced; the reference packs cell-major.
 #include "internal.h"
 
-// variable selector: bit l (0..5) = w(:,:,:,l+1), bit 8 = p, bit 9 = rlv, bit 10 = rev
+// variable selector: bit l (0..5) = w(:,:,:,l+1), bit 8 = p, bit 9 = rlv, bit 10 = rev, bits 11..13 = x(:,:,:,1:3)
+// (node coordinates: the entries of a NODE pattern, exchangeCoor)
+#define HALO_NVAR 14
 __device__ __forceinline__ double* halo_var(const BlkView& b, int v)
 {
     if (v < 8) return b.w + (long)v * b.nbox;
     if (v == 8) return b.p;
     if (v == 9) return b.rlv;
-    return b.rev;
+    if (v == 10) return b.rev;
+    return b.x + (long)(v - 11) * b.nbox;
 }
 
 __global__ void k_halo_copy(const BlkView* __restrict__ tab, const int* __restrict__ donorBlk,
@@ -28,7 +31,7 @@ __global__ void k_halo_copy(const BlkView* __restrict__ tab, const int* __restri
     const BlkView& db = tab[donorBlk[t]];
     const BlkView& hb = tab[haloBlk[t]];
     const long dof = donorOff[t], hof = haloOff[t];
-    for (int v = 0; v < 11; ++v)
+    for (int v = 0; v < HALO_NVAR; ++v)
         if (mask & (1u << v)) halo_var(hb, v)[hof] = halo_var(db, v)[dof];
 }
 
@@ -40,7 +43,7 @@ __global__ void k_halo_pack(const BlkView* __restrict__ tab, const int* __restri
     const BlkView& b = tab[blk[t]];
     const long o = off[t];
     int q = 0;
-    for (int v = 0; v < 11; ++v)
+    for (int v = 0; v < HALO_NVAR; ++v)
         if (mask & (1u << v)) {
             buf[(long)q * n + t] = halo_var(b, v)[o];
             ++q;
@@ -55,7 +58,7 @@ __global__ void k_halo_unpack(const BlkView* __restrict__ tab, const int* __rest
     const BlkView& b = tab[blk[t]];
     const long o = off[t];
     int q = 0;
-    for (int v = 0; v < 11; ++v)
+    for (int v = 0; v < HALO_NVAR; ++v)
         if (mask & (1u << v)) {
             halo_var(b, v)[o] = buf[(long)q * n + t];
             ++q;

@@ -119,6 +119,9 @@ class Engine:
             for k in ("bcType", "faceID", "icBeg", "icEnd", "jcBeg", "jcEnd"):
                 setattr(arr[m], k, int(f[k]))
             arr[m].subsonicInletTreatment = int(f.get("subsonicInletTreatment", 0))
+            if f.get("symNorm") is not None:
+                for q in range(3):
+                    arr[m].symNorm[q] = float(f["symNorm"][q])
             for k in capi.BC_ARRAYS:
                 a = f.get(k)
                 if a is not None:
@@ -139,6 +142,13 @@ class Engine:
     def update_geometry(self, level=1):
         """volume_block + metric_block + boundaryNormals on the device"""
         self._chk(self.lib.adflow_gpu_update_geometry(level))
+
+    def xhalo(self, level=1):
+        """xhalo_block of every block of the level"""
+        self._chk(self.lib.adflow_gpu_xhalo(level))
+
+    def exchangeCoor(self, level=1):
+        self._chk(self.lib.adflow_gpu_exchange_coor(level))
 
     def applyAllBC(self, level=1, secondHalo=True):
         self._chk(self.lib.adflow_gpu_apply_all_bc(level, int(secondHalo)))

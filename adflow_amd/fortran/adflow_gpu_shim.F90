@@ -68,6 +68,7 @@ module adflowGpuShim
         type(c_ptr) :: norm, rface, uSlip, TNS_Wall
         type(c_ptr) :: rho, velx, vely, velz, ps
         type(c_ptr) :: ptInlet, ttInlet, htInlet, flowXdirInlet, flowYdirInlet, flowZdirInlet, turbInlet
+        real(c_double) :: symNorm(3)
     end type adflow_bc_subface
 
     interface
@@ -88,6 +89,14 @@ module adflowGpuShim
         integer(c_int) function adflow_gpu_apply_all_bc(level, secondHalo) bind(C, name="adflow_gpu_apply_all_bc")
             import :: c_int
             integer(c_int), value :: level, secondHalo
+        end function
+        integer(c_int) function adflow_gpu_xhalo(level) bind(C, name="adflow_gpu_xhalo")
+            import :: c_int
+            integer(c_int), value :: level
+        end function
+        integer(c_int) function adflow_gpu_exchange_coor(level) bind(C, name="adflow_gpu_exchange_coor")
+            import :: c_int
+            integer(c_int), value :: level
         end function
         integer(c_int) function adflow_gpu_download_wall_stress(nn, level, sps, mm, tau, q) &
             bind(C, name="adflow_gpu_download_wall_stress")
@@ -346,6 +355,7 @@ contains
                 f(mm)%flowXdirInlet = c_null_ptr; f(mm)%flowYdirInlet = c_null_ptr; f(mm)%flowZdirInlet = c_null_ptr
                 f(mm)%turbInlet = c_null_ptr
                 f(mm)%subsonicInletTreatment = int(d%subsonicInletTreatment, c_int32_t); f(mm)%reserved = 0
+                f(mm)%symNorm = d%symNorm
                 if (associated(d%norm)) f(mm)%norm = c_loc(d%norm)
                 if (associated(d%rface)) f(mm)%rface = c_loc(d%rface)
                 if (associated(d%uSlip)) f(mm)%uSlip = c_loc(d%uSlip)

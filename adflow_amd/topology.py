@@ -74,26 +74,47 @@ class BrickTopology:
     def patterns(self, nLayers: int, only_rank=None) -> Dict[int, CommPattern]:
         """CommPattern per rank for halo depth nLayers (1: cells 1..ie, 2: 0..ib),
         faces, edges and corners included.  only_rank: build just that rank's
-        pattern (skips block pairs that do not involve it)."""
+        pattern (skips block pairs that do not involve it).
+        nLayers = 0: the NODE pattern (commPatternNode_1st / internalNode_1st): halo nodes 0 and ie/je/ke take the
+        coordinates of the neighbour's interior nodes nx / 2 (exchangeCoor, haloExchange.F90:2456)."""
         nx, ny, nz = self.nx, self.ny, self.nz
-        lo = 2 - nLayers
-        ii = np.arange(lo, nx + 2 + nLayers)
-        jj = np.arange(lo, ny + 2 + nLayers)
-        kk = np.arange(lo, nz + 2 + nLayers)
-        I, J, K = np.meshgrid(ii, jj, kk, indexing="ij")
-        halo = ~((I >= 2) & (I <= nx + 1) & (J >= 2) & (J <= ny + 1) & (K >= 2) & (K <= nz + 1))
+        nodes = nLayers == 0
+        if nodes:
+            ii, jj, kk = np.arange(0, nx + 3), np.arange(0, ny + 3), np.arange(0, nz + 3)
+            I, J, K = np.meshgrid(ii, jj, kk, indexing="ij")
+            halo = (I == 0) | (I == nx + 2) | (J == 0) | (J == ny + 2) | (K == 0) | (K == nz + 2)
+        else:
+            lo = 2 - nLayers
+            ii = np.arange(lo, nx + 2 + nLayers)
+            jj = np.arange(lo, ny + 2 + nLayers)
+            kk = np.arange(lo, nz + 2 + nLayers)
+            I, J, K = np.meshgrid(ii, jj, kk, indexing="ij")
+            halo = ~((I >= 2) & (I <= nx + 1) & (J >= 2) & (J <= ny + 1) & (K >= 2) & (K <= nz + 1))
         hi, hj, hk = I[halo], J[halo], K[halo]        # canonical order: k slowest? (C order of the mask)
         lid = self.local_ids()
         ranks = sorted({self.owner(g) for g in range(self.nblocks)})
         loc = {r: [[], [], [], []] for r in ranks}            # donorBlk, donorIdx, haloBlk, haloIdx
         msg: Dict[Tuple[int, int], List] = {}                  # (src rank, dst rank) -> [sendBlk, sendIdx, recvBlk, recvIdx]
+
+        def node_map(b, idx, n, B):
+            # node idx of block b in one direction: halo nodes 0 / n+2 are nodes n / 2 of the previous / next block
+            g_ = (b * n + idx - 1) % (B * n)
+            keep = (idx >= 1) & (idx <= n + 1)
+            return np.where(keep, b, g_ // n), np.where(keep, idx, g_ % n + 1)
+
         for g in range(self.nblocks):
             bi, bj, bk = self.coords(g)
-            gi = (bi * nx + hi - 2) % (self.Bi * nx)
-            gj = (bj * ny + hj - 2) % (self.Bj * ny)
-            gk = (bk * nz + hk - 2) % (self.Bk * nz)
-            dg = (gi // nx) + self.Bi * ((gj // ny) + self.Bj * (gk // nz))
-            di, dj, dk = gi % nx + 2, gj % ny + 2, gk % nz + 2
+            if nodes:
+                dbi, di = node_map(bi, hi, nx, self.Bi)
+                dbj, dj = node_map(bj, hj, ny, self.Bj)
+                dbk, dk = node_map(bk, hk, nz, self.Bk)
+                dg = dbi + self.Bi * (dbj + self.Bj * dbk)
+            else:
+                gi = (bi * nx + hi - 2) % (self.Bi * nx)
+                gj = (bj * ny + hj - 2) % (self.Bj * ny)
+                gk = (bk * nz + hk - 2) % (self.Bk * nz)
+                dg = (gi // nx) + self.Bi * ((gj // ny) + self.Bj * (gk // nz))
+                di, dj, dk = gi % nx + 2, gj % ny + 2, gk % nz + 2
             rh = self.owner(g)
             udg = np.unique(dg)
             downers = np.array([self.owner(int(x)) for x in udg])

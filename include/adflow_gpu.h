@@ -81,6 +81,7 @@ typedef struct adflow_bc_subface {
     const double* flowYdirInlet;
     const double* flowZdirInlet;
     const double* turbInlet;  /* prescribed turbulence variable(s) of inflow subfaces (RANS), (:,:,nt1:nt2) */
+    double symNorm[3];        /* BCData%symNorm: the (constant) normal of a symmetry plane, read by xhalo_block */
 } adflow_bc_subface;
 
 /* Options: snapshot of the Fortran module variables the hot path reads.
@@ -182,7 +183,7 @@ enum {
     ADFLOW_ARR_W = 1, ADFLOW_ARR_P, ADFLOW_ARR_GAMMA, ADFLOW_ARR_RLV, ADFLOW_ARR_REV,
     ADFLOW_ARR_DW, ADFLOW_ARR_FW, ADFLOW_ARR_DTL, ADFLOW_ARR_RADI, ADFLOW_ARR_RADJ, ADFLOW_ARR_RADK,
     ADFLOW_ARR_AA, ADFLOW_ARR_NODAL_GRADS, ADFLOW_ARR_WN, ADFLOW_ARR_PN, ADFLOW_ARR_W1, ADFLOW_ARR_P1,
-    ADFLOW_ARR_WR, ADFLOW_ARR_VOL, ADFLOW_ARR_SI, ADFLOW_ARR_SJ, ADFLOW_ARR_SK
+    ADFLOW_ARR_WR, ADFLOW_ARR_VOL, ADFLOW_ARR_SI, ADFLOW_ARR_SJ, ADFLOW_ARR_SK, ADFLOW_ARR_X
 };
 
 /* flags of adflow_gpu_block_res: the logical arguments of blockette::blocketteRes
@@ -223,6 +224,17 @@ int adflow_gpu_upload_geometry(int nn, int level, int sps);   /* x,sI,sJ,sK,vol,
  * boundaryNormals (src/adjoint/adjointExtra.F90:5-364), the `useSpatial` branch of blocketteRes (blockette.F90:203-211) */
 int adflow_gpu_upload_coordinates(int nn, int level, int sps);
 int adflow_gpu_update_geometry(int level);
+/* Halo node coordinates after the owned nodes moved, the two steps that precede volume / metric in the `useSpatial`
+ * branch of blocketteRes (blockette.F90:181-187):
+ *   adflow_gpu_xhalo          adjointExtra::xhalo_block (adjointExtra.F90:365-599) of every block of the level: linear
+ *                             extrapolation of the halo nodes 0 / ie, je, ke, then the mirror image in symmetry planes
+ *                             (subfaces of kind symm with their BCData%symNorm);
+ *   adflow_gpu_exchange_coor  haloExchange::exchangeCoor (haloExchange.F90:2456-2640): halo nodes of 1-to-1 interfaces
+ *                             from the neighbours' interior nodes, using the NODE pattern commPatternNode_1st(level) /
+ *                             internalNode_1st(level) registered with adflow_gpu_comm_register(level, 0, pattern)
+ *                             (same-GPU copies + RCCL send/recv; periodic translations / rotations are not applied). */
+int adflow_gpu_xhalo(int level);
+int adflow_gpu_exchange_coor(int level);
 int adflow_gpu_upload_state(int nn, int level, int sps);      /* w,p,gamma,rlv,rev incl. both halo layers */
 int adflow_gpu_download_state(int nn, int level, int sps);
 int adflow_gpu_download_residual(int nn, int level, int sps); /* dw -> desc.dw */

@@ -45,6 +45,8 @@ def load(fast: bool = False) -> ctypes.CDLL:
         lib.ref_set_bocos.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.ref_set_bcdata.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p]
         lib.ref_set_moving.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.ref_set_sym_norm.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        lib.ref_set_inlet_treatment.argtypes = [ctypes.c_int, ctypes.c_int]
         _LIB = lib
     return _LIB
 
@@ -164,6 +166,9 @@ def set_bocos(faces, nViscBocos=0) -> None:
     lib.ref_set_bocos(n, int(nViscBocos), types.ctypes.data, fids.ctypes.data, rng.ctypes.data)
     _keep.append(faces)     # the reference points INTO these arrays
     for m, f in enumerate(faces):
+        if f.get("symNorm") is not None:
+            v = np.ascontiguousarray(f["symNorm"], dtype=np.float64)
+            lib.ref_set_sym_norm(m + 1, v.ctypes.data)
         if f.get("subsonicInletTreatment"):
             lib.ref_set_inlet_treatment(m + 1, int(f["subsonicInletTreatment"]))
         for k in ("norm", "rface", "uSlip", "TNS_Wall", "rho", "velx", "vely", "velz", "ps", "ptInlet", "ttInlet", "htInlet",

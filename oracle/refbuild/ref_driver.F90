@@ -455,6 +455,32 @@ contains
                      BCData(mm)%ttInlet, BCData(mm)%htInlet, BCData(mm)%flowXdirInlet, BCData(mm)%flowYdirInlet, &
                      BCData(mm)%flowZdirInlet, BCData(mm)%turbInlet)
         end do
+        ! node ranges of the subfaces: BCData%inBeg.. (face-local) and the block-level inBeg/jnBeg/knBeg arrays
+        ! (blockPointers) that xhalo_block reads
+        nSubface = nBocos
+        nullify (inBeg, inEnd, jnBeg, jnEnd, knBeg, knEnd)
+        allocate (inBeg(max(nBocos, 1)), inEnd(max(nBocos, 1)), jnBeg(max(nBocos, 1)), jnEnd(max(nBocos, 1)), &
+                  knBeg(max(nBocos, 1)), knEnd(max(nBocos, 1)))
+        do mm = 1, nBocos
+            select case (BCFaceID(mm))
+            case (iMin, iMax); n1 = jl; n2 = kl
+            case (jMin, jMax); n1 = il; n2 = kl
+            case default; n1 = il; n2 = jl
+            end select
+            iBeg = max(BCData(mm)%icBeg, 2); iEnd = min(BCData(mm)%icEnd, n1)
+            jBeg = max(BCData(mm)%jcBeg, 2); jEnd = min(BCData(mm)%jcEnd, n2)
+            BCData(mm)%inBeg = iBeg - 1; BCData(mm)%inEnd = iEnd
+            BCData(mm)%jnBeg = jBeg - 1; BCData(mm)%jnEnd = jEnd
+            BCData(mm)%symNorm = zero; BCData(mm)%symNormSet = .true.
+            select case (BCFaceID(mm))
+            case (iMin); inBeg(mm) = 1; inEnd(mm) = 1; jnBeg(mm) = iBeg - 1; jnEnd(mm) = iEnd; knBeg(mm) = jBeg - 1; knEnd(mm) = jEnd
+            case (iMax); inBeg(mm) = il; inEnd(mm) = il; jnBeg(mm) = iBeg - 1; jnEnd(mm) = iEnd; knBeg(mm) = jBeg - 1; knEnd(mm) = jEnd
+            case (jMin); jnBeg(mm) = 1; jnEnd(mm) = 1; inBeg(mm) = iBeg - 1; inEnd(mm) = iEnd; knBeg(mm) = jBeg - 1; knEnd(mm) = jEnd
+            case (jMax); jnBeg(mm) = jl; jnEnd(mm) = jl; inBeg(mm) = iBeg - 1; inEnd(mm) = iEnd; knBeg(mm) = jBeg - 1; knEnd(mm) = jEnd
+            case (kMin); knBeg(mm) = 1; knEnd(mm) = 1; inBeg(mm) = iBeg - 1; inEnd(mm) = iEnd; jnBeg(mm) = jBeg - 1; jnEnd(mm) = jEnd
+            case (kMax); knBeg(mm) = kl; knEnd(mm) = kl; inBeg(mm) = iBeg - 1; inEnd(mm) = iEnd; jnBeg(mm) = jBeg - 1; jnEnd(mm) = jEnd
+            end select
+        end do
         ! what preprocessingAPI.F90:2430-2581 (viscSubfaceInfo) sets up: storage of the wall stress tensor / heat flux
         ! of the viscous subfaces (their owned face cells) and the visc*Pointer maps into it
         nullify (viscSubface)
@@ -512,6 +538,13 @@ contains
         end if
         cgnsDoms(1)%rotRate = rotRate; cgnsDoms(1)%rotCenter = zero; cgnsDoms(1)%rotatingFrameSpecified = (isMoving /= 0)
     end subroutine ref_set_moving
+
+    subroutine ref_set_sym_norm(mm, v) bind(C, name="ref_set_sym_norm")
+        use blockPointers
+        integer(c_int), value :: mm
+        real(c_double), intent(in) :: v(3)
+        BCData(mm)%symNorm = v; BCData(mm)%symNormSet = .true.
+    end subroutine ref_set_sym_norm
 
     subroutine ref_set_inlet_treatment(mm, v) bind(C, name="ref_set_inlet_treatment")
         use blockPointers
@@ -576,7 +609,7 @@ contains
                              computePressureSimple, computeLamViscosity
         use turbUtils, only: computeEddyViscosity
         use sa, only: sa_block
-        use adjointExtra, only: volume_block, metric_block, boundaryNormals, sumDwAndFw
+        use adjointExtra, only: volume_block, metric_block, boundaryNormals, sumDwAndFw, xhalo_block
         use BCRoutines, only: applyAllBC_block
         use turbBCRoutines, only: bcTurbTreatment, applyAllTurbBCThisBlock
         character(kind=c_char), dimension(*), intent(in) :: name
@@ -609,6 +642,7 @@ contains
         case ('volume_block'); call volume_block
         case ('metric_block'); call metric_block
         case ('boundaryNormals'); call boundaryNormals                      ! adjointExtra.F90:270
+        case ('xhalo_block'); call xhalo_block                              ! adjointExtra.F90:365
         case ('applyAllBC_block'); call applyAllBC_block(iarg /= 0)         ! BCRoutines.F90:57
         case ('bcTurbTreatment'); call bcTurbTreatment                       ! turbBCRoutines.F90:662
         case ('applyAllTurbBCThisBlock'); call applyAllTurbBCThisBlock(iarg /= 0)   ! turbBCRoutines.F90:49
@@ -742,6 +776,12 @@ contains
                                                         internalCell_1st, internalCell_2nd)
         allocate (commPatternCell_1st(nLevels_), commPatternCell_2nd(nLevels_), &
                   internalCell_1st(nLevels_), internalCell_2nd(nLevels_))
+        if (allocated(commPatternNode_1st)) deallocate (commPatternNode_1st, internalNode_1st)
+        allocate (commPatternNode_1st(nLevels_), internalNode_1st(nLevels_))
+        do l = 1, nLevels_
+            commPatternNode_1st(l)%nProcSend = 0; commPatternNode_1st(l)%nProcRecv = 0; commPatternNode_1st(l)%nPeriodic = 0
+            internalNode_1st(l)%ncopy = 0; internalNode_1st(l)%nPeriodic = 0
+        end do
         if (allocated(commPatternOverset)) deallocate (commPatternOverset, internalOverset)
         allocate (commPatternOverset(nLevels_, 1), internalOverset(nLevels_, 1))
         do l = 1, nLevels_
@@ -770,9 +810,10 @@ contains
             d%cgnsBlockID = 1
             d%rightHanded = .true.
             d%iBegor = 1; d%iEndor = il; d%jBegor = 1; d%jEndor = jl; d%kBegor = 1; d%kEndor = kl
-            d%nSubface = 0; d%n1to1 = 0; d%nBocos = nBocos; d%nViscBocos = nViscBocos
+            d%nSubface = nBocos; d%n1to1 = 0; d%nBocos = nBocos; d%nViscBocos = nViscBocos
             d%BCType => BCType; d%BCFaceID => BCFaceID; d%BCData => BCData
             d%globalCell => globalCell; d%s => s; d%viscSubface => viscSubface
+            d%inBeg => inBeg; d%inEnd => inEnd; d%jnBeg => jnBeg; d%jnEnd => jnEnd; d%knBeg => knBeg; d%knEnd => knEnd
             d%nOrphans = 0
             d%blockIsMoving = blockIsMoving; d%addGridVelocities = addGridVelocities
             if (addGridVelocities) then
@@ -810,7 +851,9 @@ contains
         integer(c_int), value :: level, nLayers, ncopy
         integer(c_int), dimension(ncopy), intent(in) :: donorBlock, haloBlock
         integer(c_int), dimension(ncopy, 3), intent(in) :: donorIdx, haloIdx
-        if (nLayers == 1) then
+        if (nLayers == 0) then
+            call fill(internalNode_1st(level))      ! node pattern of exchangeCoor
+        else if (nLayers == 1) then
             call fill(internalCell_1st(level))
         else
             call fill(internalCell_2nd(level))
@@ -830,7 +873,7 @@ contains
     subroutine ref_call_level(name, level, i1, i2) bind(C, name="ref_call_level")
         use iteration, only: currentLevel, groundLevel, rkStage
         use flowVarRefState, only: nwf, nw, nt1, nt2
-        use haloExchange, only: whalo1, whalo2
+        use haloExchange, only: whalo1, whalo2, exchangeCoor
         use smoothers, only: RungeKuttaSmoother, DADISmoother
         use solverUtils, only: timeStep
         use residuals, only: initres, residual
@@ -856,6 +899,7 @@ contains
         case ('transferToFineGrid'); call transferToFineGrid(i1 /= 0)                 ! multiGrid.F90:326
         case ('executeMGCycle'); call executeMGCycle                                  ! multiGrid.F90:825
         case ('applyAllBC'); call applyAllBC(i1 /= 0)                                 ! BCRoutines.F90:15
+        case ('exchangeCoor'); call exchangeCoor(level)                               ! haloExchange.F90:2456
         case default
             print *, 'ref_call_level: unknown routine ', trim(n)
             stop 1

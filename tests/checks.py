@@ -160,6 +160,84 @@ def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, s
     return blk, r
 
 
+def _warp_owned_nodes(blocks, seed):
+    """move the nodes 1..il x 1..jl x 1..kl of every block (the halo nodes are what xhalo / exchangeCoor rebuild)"""
+    rng = np.random.default_rng(seed)
+    for nn in sorted(blocks):
+        b = blocks[nn]
+        h = 1.0 / max(b.nx, b.ny, b.nz)
+        d = 0.05 * h * rng.uniform(-1, 1, b["x"][1:-1, 1:-1, 1:-1].shape)
+        b["x"][1:-1, 1:-1, 1:-1] += d
+        # poison the halo nodes so that a missing update cannot pass
+        for sl in ((0,), (-1,)):
+            b["x"][sl[0], :, :] = 7.0; b["x"][:, sl[0], :] = 7.0; b["x"][:, :, sl[0]] = 7.0
+
+
+def _assert_geometry(engine, blocks, rblocks, what, names=("x", "vol", "sI", "sJ", "sK")):
+    ids = {"x": capi.ARR_X, "vol": capi.ARR_VOL, "sI": capi.ARR_SI, "sJ": capi.ARR_SJ, "sK": capi.ARR_SK}
+    for nn in sorted(blocks):
+        for name in names:
+            out = np.zeros_like(rblocks[nn][name])
+            engine.download_array(ids[name], out, nn, 1)
+            ref_arr = rblocks[nn][name]
+            if name == "vol":
+                out, ref_arr = out[1:-1, 1:-1, 1:-1], ref_arr[1:-1, 1:-1, 1:-1]
+            e = rel_err(out, ref_arr)
+            assert e <= TOL, (what, nn, name, e)
+
+
+def check_coordinate_halos_brick(engine, topo, prm, seed=83, **mk):
+    """xhalo_block (adjointExtra.F90:365-599) + exchangeCoor (haloExchange.F90:2456-2640) + volume / metric on a periodic
+    brick of blocks after the owned nodes moved: the front part of the `useSpatial` branch of blocketteRes."""
+    from oracle import ref
+    blocks, rblocks = setup_brick(engine, topo, prm, seed, **mk)
+    npat = topo.patterns(0)[0]
+    ref.set_internal_comm(1, 0, npat)
+    engine.comm_register(1, 0, npat)
+    _warp_owned_nodes(blocks, seed)
+    for nn in blocks:
+        rblocks[nn]["x"][...] = blocks[nn]["x"]
+    for nn in sorted(rblocks):
+        ref.call_level("setPointers", 1, nn)
+        ref.call("xhalo_block")
+    ref.call_level("exchangeCoor", 1)
+    for nn in sorted(rblocks):
+        ref.call_level("setPointers", 1, nn)
+        ref.call("volume_block")
+        ref.call("metric_block")
+    for nn in sorted(blocks):
+        engine.upload_coordinates(nn, 1)
+    engine.xhalo(1)
+    engine.exchangeCoor(1)
+    engine.update_geometry(1)
+    _assert_geometry(engine, blocks, rblocks, "xhalo + exchangeCoor + metrics")
+
+
+def check_xhalo_symmetry(engine, dims, prm, spec, split=(), seed=85, **mk):
+    """xhalo_block on a block with symmetry planes (mirror image of the second node plane about BCData%symNorm, node
+    ranges extended over the block edges) and other subfaces (plain extrapolation)."""
+    from oracle import ref
+    from adflow_amd.synth import make_bocos
+    new_level(engine)
+    prm = prm.replace(currentLevel=1, groundLevel=1)
+    blk = make_block(*dims, prm, seed=seed, **mk)
+    faces, nvisc = make_bocos(blk, prm, spec, seed=seed + 1, split=split)
+    for f in faces:
+        if f["bcType"] == -1:      # plane normal: mean of the face normals, deliberately not of unit length
+            f["symNorm"] = 1.7 * f["norm"].reshape(-1, 3).mean(axis=0)
+    engine.set_options(prm)
+    engine.register(blk, nn=1, level=1)
+    engine.bc_register(faces, nvisc, nn=1, level=1)
+    _warp_owned_nodes({1: blk}, seed)
+    r = blk.copy()
+    ref.bind_block(r, prm)
+    ref.set_bocos(faces, nvisc)
+    ref.call("xhalo_block")
+    engine.upload_coordinates(1, 1)
+    engine.xhalo(1)
+    _assert_geometry(engine, {1: blk}, {1: r}, f"xhalo with symmetry planes {spec}", names=("x",))
+
+
 def check_wall_stress(engine, dims, prm, spec, split=(), seed=57, dadi=False, **mk):
     """viscSubface(:)%tau / %q: the wall stress tensor and heat flux viscousFlux stores for the viscous subfaces when
     rkStage == 0 on the ground level (fluxes.F90:2586-2592, 2861-2892 k, 3155-3185 j, 3450-3480 i)."""

@@ -141,3 +141,11 @@ def test_apply_all_bc_subsonic_and_polar(engine):
     checks.check_multiblock_bc(engine, rans, {
         1: ((24, 8, 6), {1: -8, 2: -10, 3: -3, 4: -6, 5: -2, 6: -7}, ()),
         2: ((70, 6, 8), {1: -12, 2: -8, 3: -3, 4: -6}, {3: -6})}, stretch_k=2.0)
+
+
+def test_coordinate_halos(engine):
+    """"next" row 3: xhalo_block + exchangeCoor (node pattern) + metrics after a mesh warp"""
+    checks.check_coordinate_halos_brick(engine, BrickTopology(2, 2, 1, 20, 9, 8), FlowParams())
+    checks.check_coordinate_halos_brick(engine, BrickTopology(1, 1, 2, 70, 6, 4), FlowParams(equations=NSEquations), stretch_k=2.0)
+    checks.check_xhalo_symmetry(engine, (70, 9, 8), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -1, 5: -1, 6: -6})
+    checks.check_xhalo_symmetry(engine, (24, 10, 8), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5})

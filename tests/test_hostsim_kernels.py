@@ -258,6 +258,14 @@ def test_moving_blocks(hostsim_engine):
     checks.check_mg_cycle(hostsim_engine, BrickTopology(1, 1, 1, 8, 8, 4), FlowParams(), [0, 1, 0, -1], ncycles=1, **mv)
 
 
+def test_coordinate_halos(hostsim_engine):
+    """"next" row 3: xhalo_block + exchangeCoor (node pattern) + metrics after a mesh warp"""
+    checks.check_coordinate_halos_brick(hostsim_engine, BrickTopology(2, 2, 1, 5, 4, 3), FlowParams())
+    checks.check_coordinate_halos_brick(hostsim_engine, BrickTopology(1, 1, 2, 4, 4, 2), FlowParams(equations=NSEquations), stretch_k=2.0)
+    checks.check_xhalo_symmetry(hostsim_engine, (6, 5, 4), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -1, 5: -1, 6: -6})
+    checks.check_xhalo_symmetry(hostsim_engine, (7, 5, 4), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5})
+
+
 def test_multiblock_bc(hostsim_engine):
     """several blocks with different subface lists: the level-batched BC launches against the reference's block loop"""
     checks.check_multiblock_bc(hostsim_engine, FlowParams(), {
