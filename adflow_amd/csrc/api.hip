@@ -1796,6 +1796,24 @@ int adflow_gpu_transfer_to_fine(int level)
     return sync_and_check();
 }
 
+// coarseOwnedCoordinates(coarseLevel) (coarseUtils.F90:780-858) for every block pair (coarseLevel-1, coarseLevel)
+int adflow_gpu_coarse_coordinates(int coarseLevel)
+{
+    if (need_ready()) return 1;
+    if (coarseLevel < 2) return fail("coarse_coordinates: level %d has no finer level", coarseLevel);
+    int rc = for_level_pairs(coarseLevel - 1, [&](Block* f, Block* c) {
+        (void)f;
+        if (!c->v.mgIFine) return fail("coarse block has no mgIFine maps");
+        c->face_vectors_valid = false;
+        return 0;
+    });
+    if (rc) return rc;
+    LevelTab tf, tc;
+    if (level_tab(coarseLevel - 1, &tf) || level_tab(coarseLevel, &tc)) return 1;
+    launch_coarse_coordinates_level(tc.tab, tf.tab, tc.n, tc.nx, tc.ny, tc.nz, g_stream);
+    return sync_and_check();
+}
+
 int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
 {
     if (need_ready()) return 1;

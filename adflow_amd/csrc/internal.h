@@ -163,6 +163,7 @@ void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStre
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 int viscous_is_tiled();
+void launch_coarse_coordinates_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, hipStream_t s);
 void launch_xhalo_level(const BlkView* tab, int nslots, int nx, int ny, int nz, hipStream_t s);
 void launch_xhalo_symm(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, hipStream_t s);
 void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, const KParams& kp, hipStream_t s);

@@ -231,6 +231,32 @@ void launch_xhalo_symm(const BlkView* tab, const BcEntry* ent, const int* order,
     hipLaunchKernelGGL(k_xhalo_symm, dim3((unsigned)((maxNodes + 255) / 256), ph.count, 1), dim3(256), 0, s, tab, ent, order + ph.first);
 }
 
+// coarseOwnedCoordinates (coarseUtils.F90:780-858): the nodes 1..il of a coarse block are the fine nodes kept by the
+// coarsening.  With the transfer maps: coarse node m >= 2 closes coarse cell m, whose last fine cell is mgFine(m,2),
+// so it is fine node mgFine(m,2); node 1 is fine node 1.
+__global__ __launch_bounds__(256) void k_coarse_coordinates(const BlkView* __restrict__ ctab, const BlkView* __restrict__ ftab)
+{
+    const BlkView& c = ctab[blockIdx.z + 1];
+    const BlkView& f = ftab[blockIdx.z + 1];
+    if (c.nx == 0) return;
+    const int i = blockIdx.x * 64 + threadIdx.x + 1;
+    const int jk = blockIdx.y * 4 + threadIdx.y;
+    const int j = jk % c.jl + 1, k = jk / c.jl + 1;
+    if (i > c.il || k > c.kl) return;
+    const int fi = (i == 1) ? 1 : c.mgIFine[2 * i + 1], fj = (j == 1) ? 1 : c.mgJFine[2 * j + 1],
+              fk = (k == 1) ? 1 : c.mgKFine[2 * k + 1];
+    const long cn = c.idx(i, j, k), fn = f.idx(fi, fj, fk);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) c.x[cn + m * c.nbox] = f.x[fn + m * f.nbox];
+}
+
+void launch_coarse_coordinates_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    const int il = nx + 1, jl = ny + 1, kl = nz + 1;
+    hipLaunchKernelGGL(k_coarse_coordinates, dim3((il + 63) / 64, (jl * kl + 3) / 4, nslots), dim3(64, 4, 1), 0, s, ctab, ftab);
+}
+
 void launch_volume_metric(const BlkView& b, int rightHanded, hipStream_t s)
 {
     const dim3 blk(GM_BX, GM_BY, 1);

@@ -147,6 +147,9 @@ class Engine:
         """xhalo_block of every block of the level"""
         self._chk(self.lib.adflow_gpu_xhalo(level))
 
+    def coarseOwnedCoordinates(self, coarseLevel):
+        self._chk(self.lib.adflow_gpu_coarse_coordinates(coarseLevel))
+
     def exchangeCoor(self, level=1):
         self._chk(self.lib.adflow_gpu_exchange_coor(level))
 

@@ -94,6 +94,10 @@ module adflowGpuShim
             import :: c_int
             integer(c_int), value :: level
         end function
+        integer(c_int) function adflow_gpu_coarse_coordinates(coarseLevel) bind(C, name="adflow_gpu_coarse_coordinates")
+            import :: c_int
+            integer(c_int), value :: coarseLevel
+        end function
         integer(c_int) function adflow_gpu_exchange_coor(level) bind(C, name="adflow_gpu_exchange_coor")
             import :: c_int
             integer(c_int), value :: level

@@ -234,6 +234,11 @@ int adflow_gpu_update_geometry(int level);
  *                             internalNode_1st(level) registered with adflow_gpu_comm_register(level, 0, pattern)
  *                             (same-GPU copies + RCCL send/recv; periodic translations / rotations are not applied). */
 int adflow_gpu_xhalo(int level);
+/* coarseUtils::coarseOwnedCoordinates(coarseLevel) (coarseUtils.F90:780-858): the owned nodes of the coarse blocks from
+ * the level above, through the registered mgI/J/KFine maps.  updateCoordinatesAllLevels / updateMetricsAllLevels
+ * (preprocessingAPI.F90:3945-4017) on the device = for every coarse level: this, adflow_gpu_xhalo,
+ * adflow_gpu_exchange_coor, adflow_gpu_update_geometry. */
+int adflow_gpu_coarse_coordinates(int coarseLevel);
 int adflow_gpu_exchange_coor(int level);
 int adflow_gpu_upload_state(int nn, int level, int sps);      /* w,p,gamma,rlv,rev incl. both halo layers */
 int adflow_gpu_download_state(int nn, int level, int sps);

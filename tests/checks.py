@@ -213,6 +213,51 @@ def check_coordinate_halos_brick(engine, topo, prm, seed=83, **mk):
     _assert_geometry(engine, blocks, rblocks, "xhalo + exchangeCoor + metrics")
 
 
+def check_coarse_level_geometry(engine, topo, prm, seed=87, **mk):
+    """updateCoordinatesAllLevels / updateMetricsAllLevels on the device (preprocessingAPI.F90:3945-4017): owned coarse
+    nodes by injection (coarseOwnedCoordinates, coarseUtils.F90:780-858, restated with numpy: a pure copy of every
+    second node), then xhalo + exchangeCoor + volume / metric of the coarse level against the reference's routines."""
+    from oracle import ref
+    levels, rlevels = setup_multilevel_brick(engine, topo, prm, nlevels=2, seed=seed, **mk)
+    t2 = type(topo)(topo.Bi, topo.Bj, topo.Bk, topo.nx // 2, topo.ny // 2, topo.nz // 2)
+    for lv, t in ((1, topo), (2, t2)):
+        npat = t.patterns(0)[0]
+        ref.set_internal_comm(lv, 0, npat)
+        engine.comm_register(lv, 0, npat)
+    _warp_owned_nodes(levels[0], seed)
+    for nn, b in levels[0].items():
+        engine.upload_coordinates(nn, 1)
+        # numpy statement of coarseOwnedCoordinates: coarse node ii = fine node 2 ii - 1
+        rc = rlevels[1][nn]
+        rc["x"][...] = 7.0
+        rc["x"][1:-1, 1:-1, 1:-1] = b["x"][1:-1:2, 1:-1:2, 1:-1:2]
+    p2 = prm.replace(currentLevel=2, groundLevel=1)
+    for nn in sorted(rlevels[1]):
+        ref.call_level("setPointers", 2, nn)
+        ref.call("xhalo_block")
+    ref.call_level("exchangeCoor", 2)
+    for nn in sorted(rlevels[1]):
+        ref.call_level("setPointers", 2, nn)
+        ref.call("volume_block")
+        ref.call("metric_block")
+    engine.xhalo(1)
+    engine.exchangeCoor(1)
+    engine.coarseOwnedCoordinates(2)
+    engine.xhalo(2)
+    engine.exchangeCoor(2)
+    engine.update_geometry(2)
+    ids = {"x": capi.ARR_X, "vol": capi.ARR_VOL, "sI": capi.ARR_SI, "sJ": capi.ARR_SJ, "sK": capi.ARR_SK}
+    for nn in sorted(levels[1]):
+        for name in ("x", "vol", "sI", "sJ", "sK"):
+            out = np.zeros_like(rlevels[1][nn][name])
+            engine.download_array(ids[name], out, nn, 2)
+            ref_arr = rlevels[1][nn][name]
+            if name == "vol":
+                out, ref_arr = out[1:-1, 1:-1, 1:-1], ref_arr[1:-1, 1:-1, 1:-1]
+            e = rel_err(out, ref_arr)
+            assert e <= TOL, ("coarse level geometry", nn, name, e)
+
+
 def check_xhalo_symmetry(engine, dims, prm, spec, split=(), seed=85, **mk):
     """xhalo_block on a block with symmetry planes (mirror image of the second node plane about BCData%symNorm, node
     ranges extended over the block edges) and other subfaces (plain extrapolation)."""

@@ -264,6 +264,7 @@ def test_coordinate_halos(hostsim_engine):
     checks.check_coordinate_halos_brick(hostsim_engine, BrickTopology(1, 1, 2, 4, 4, 2), FlowParams(equations=NSEquations), stretch_k=2.0)
     checks.check_xhalo_symmetry(hostsim_engine, (6, 5, 4), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -1, 5: -1, 6: -6})
     checks.check_xhalo_symmetry(hostsim_engine, (7, 5, 4), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5})
+    checks.check_coarse_level_geometry(hostsim_engine, BrickTopology(2, 1, 1, 8, 6, 4), FlowParams())
 
 
 def test_multiblock_bc(hostsim_engine):
