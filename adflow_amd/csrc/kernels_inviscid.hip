@@ -295,7 +295,8 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
     const double mx = sN[c - s], my = sN[c - s + nb], mz = sN[c - s + 2 * nb];
     const double px = sN[c], py = sN[c + nb], pz = sN[c + 2 * nb];
     // grid velocity through the two faces (sFaceI/J/K of a moving block)
-    const double sfM = sF ? sF[c - s] : 0.0, sfP = sF ? sF[c] : 0.0;
+    double sfM = 0.0, sfP = 0.0;
+    if (sF) { sfM = sF[c - s]; sfP = sF[c]; }     // uniform branch
     central_face(L, 1, mx, my, mz, porM, -1.0, dwc, sfM);
     central_face(L, 2, px, py, pz, porP, +1.0, dwc, sfP);
     if (!doDiss) return;

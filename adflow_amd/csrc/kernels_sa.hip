@@ -48,7 +48,8 @@ struct SaDir {   // per-direction data of one cell
 __device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const double* __restrict__ sN, SaDir& d, int dirc)
 {
     const long nb = b.nbox;
-    d.qsf = b.sFace ? b.sFace[c + dirc * nb] + b.sFace[c - s + dirc * nb] : 0.0;
+    d.qsf = 0.0;
+    if (b.sFace) d.qsf = b.sFace[c + dirc * nb] + b.sFace[c - s + dirc * nb];     // uniform branch
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         d.sm[m] = sN[c - s + m * nb];

@@ -447,7 +447,8 @@ __device__ __forceinline__ void dadi_cell(const BlkView& b, const KParams& kp, l
     const double r2 = volhalf * (sN[c + nb] + sN[c - s + nb]);
     const double r3 = volhalf * (sN[c + 2 * nb] + sN[c - s + 2 * nb]);
     // grid velocity of a moving block (residuals.F90:1192-1196)
-    const double qs = b.sFace ? (b.sFace[c - s + DIR * nb] + b.sFace[c + DIR * nb]) * volhalf : 0.0;
+    double qs = 0.0;
+    if (b.sFace) qs = (b.sFace[c - s + DIR * nb] + b.sFace[c + DIR * nb]) * volhalf;     // uniform branch
     const double qq = r1 * u + r2 * v + r3 * w - qs;
     const double cijk = sqrt(b.gamma[c] * b.p[c] / rho);
     const double cc = cijk * sqrt(r1 * r1 + r2 * r2 + r3 * r3);

@@ -46,22 +46,27 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(const BlkView* __res
     double sz = b.sI[c - 1 + 2 * nb] + b.sI[c + 2 * nb];
     const double si2 = sx * sx + sy * sy + sz * sz;
     // grid velocity of a moving block: sum over the two faces (solverUtils.F90:147-181)
-    const double* sF = b.sFace;
-    double sFace = sF ? sF[c - 1] + sF[c] : 0.0;
+    double sFace = 0.0, sFaceJ = 0.0, sFaceK = 0.0;
+    if (b.sFace) {      // uniform branch: no loads at all for blocks at rest
+        const double* sF = b.sFace;
+        sFace = sF[c - 1] + sF[c];
+        sFaceJ = sF[c - b.ldi + nb] + sF[c + nb];
+        sFaceK = sF[c - b.ldk + 2 * nb] + sF[c + 2 * nb];
+    }
     double ri = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * si2));
 
     sx = b.sJ[c - b.ldi] + b.sJ[c];
     sy = b.sJ[c - b.ldi + nb] + b.sJ[c + nb];
     sz = b.sJ[c - b.ldi + 2 * nb] + b.sJ[c + 2 * nb];
     const double sj2 = sx * sx + sy * sy + sz * sz;
-    sFace = sF ? sF[c - b.ldi + nb] + sF[c + nb] : 0.0;
+    sFace = sFaceJ;
     double rj = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * sj2));
 
     sx = b.sK[c - b.ldk] + b.sK[c];
     sy = b.sK[c - b.ldk + nb] + b.sK[c + nb];
     sz = b.sK[c - b.ldk + 2 * nb] + b.sK[c + 2 * nb];
     const double sk2 = sx * sx + sy * sy + sz * sz;
-    sFace = sF ? sF[c - b.ldk + 2 * nb] + sF[c + 2 * nb] : 0.0;
+    sFace = sFaceK;
     double rk = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * sk2));
 
     const double rsum = ri + rj + rk;   // inviscid part of 1/dt (before scaling)

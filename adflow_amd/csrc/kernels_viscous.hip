@@ -463,7 +463,7 @@ __device__ __forceinline__ VCell vcell_at(const BlkView& b, const KParams& kp, l
 // (-s1-s2), (-s2), (-s1), (0); fN/dN: normal and centre-to-centre vector of the face
 __device__ __forceinline__ void visc_face_t(const KParams& kp, const double* __restrict__ gl, int o0, int o1, int o2, int o3,
                                             const VCell& L, const VCell& R, const double fN[3], const double dN[3], int por_code,
-                                            double sign, double acc[5])
+                                            double f[4])
 {
     double por = 0.5 * kp.rFil;
     if (por_code == ADF_POR_NOFLUX) por = 0.0;
@@ -524,10 +524,7 @@ __device__ __forceinline__ void visc_face_t(const KParams& kp, const double* __r
     frhoE = frhoE + (ubar * tauxy + vbar * tauyy + wbar * tauyz) * ny;
     frhoE = frhoE + (ubar * tauxz + vbar * tauyz + wbar * tauzz) * nz;
     frhoE = frhoE - q_x * nx - q_y * ny - q_z * nz;
-    acc[1] += sign * fmx;
-    acc[2] += sign * fmy;
-    acc[3] += sign * fmz;
-    acc[4] += sign * frhoE;
+    f[0] = fmx; f[1] = fmy; f[2] = fmz; f[3] = frhoE;
 }
 
 #define VT_KCH 8      // planes marched by one workgroup: each new plane stages ONE node plane (the other is reused)
@@ -578,6 +575,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __
     const int shift3[3] = {4, 2, 0};              // porosity bits of the direction inside the flag byte
     int pLo = 0;                                   // slot of node plane k-1
     vt_stage_plane(b, gl, pLo, i0, j0, k0 - 1, tx, ty);
+    double fk[4] = {0, 0, 0, 0};                   // flux through the k face below the cell: the upper face of the previous plane
     for (int k = k0; k <= k1; ++k) {
         const int pHi = 1 - pLo;
         vt_stage_plane(b, gl, pHi, i0, j0, k, tx, ty);
@@ -598,13 +596,33 @@ __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __
                 const long sd = sd3[d], cm = c - sd;
                 const double* __restrict__ sN = sN3[d];
                 const double* __restrict__ dN = dN3[d];
-                const VCell M = vcell_at(b, kp, cm), P = vcell_at(b, kp, c + sd);
-                const double nM[3] = {sN[cm], sN[cm + nb], sN[cm + 2 * nb]}, nP[3] = {sN[c], sN[c + nb], sN[c + 2 * nb]};
-                const double dM[3] = {dN[cm], dN[cm + nb], dN[cm + 2 * nb]}, dP[3] = {dN[c], dN[c + nb], dN[c + 2 * nb]};
-                const int porM = (b.flags[cm] >> shift3[d]) & 3, porP = (f0 >> shift3[d]) & 3;
                 const int D1 = D13[d], D2 = D23[d], oP = o000 + Dd3[d];
-                visc_face_t(kp, gl, o000, o000 + D1, o000 + D2, o000 + D1 + D2, M, C, nM, dM, porM, +1.0, acc);
-                visc_face_t(kp, gl, oP, oP + D1, oP + D2, oP + D1 + D2, C, P, nP, dP, porP, -1.0, acc);
+                double fM[4], fP[4];
+                if (d == 0 && k > k0) {
+                    // the face below was the upper k face of the previous plane: same inputs, same flux
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) fM[m] = fk[m];
+                } else {
+                    const VCell M = vcell_at(b, kp, cm);
+                    const double nM[3] = {sN[cm], sN[cm + nb], sN[cm + 2 * nb]};
+                    const double dM[3] = {dN[cm], dN[cm + nb], dN[cm + 2 * nb]};
+                    const int porM = (b.flags[cm] >> shift3[d]) & 3;
+                    visc_face_t(kp, gl, o000, o000 + D1, o000 + D2, o000 + D1 + D2, M, C, nM, dM, porM, fM);
+                }
+                const VCell P = vcell_at(b, kp, c + sd);
+                const double nP[3] = {sN[c], sN[c + nb], sN[c + 2 * nb]};
+                const double dP[3] = {dN[c], dN[c + nb], dN[c + 2 * nb]};
+                const int porP = (f0 >> shift3[d]) & 3;
+                visc_face_t(kp, gl, oP, oP + D1, oP + D2, oP + D1 + D2, C, P, nP, dP, porP, fP);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    acc[m + 1] += fM[m];
+                    acc[m + 1] -= fP[m];
+                }
+                if (d == 0) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) fk[m] = fP[m];
+                }
             }
             const double blank = flg_blank(f0);
 #pragma unroll
