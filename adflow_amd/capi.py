@@ -98,6 +98,14 @@ class AdflowBlockDesc(ctypes.Structure):
     ]
 
 
+class AdflowPeriodicData(ctypes.Structure):
+    """adflow_periodic_data: periodicDataType of communication.F90"""
+    _fields_ = [
+        ("rotMatrix", c_double * 9), ("rotCenter", c_double * 3), ("translation", c_double * 3),
+        ("nHalos", c_int32), ("reserved", c_int32), ("block", c_void_p), ("indices", c_void_p),
+    ]
+
+
 class AdflowCommPattern(ctypes.Structure):
     _fields_ = [
         ("ncopy", c_int32),
@@ -130,7 +138,7 @@ EXPORTS = [
     "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
-    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2", "adflow_gpu_xhalo", "adflow_gpu_coarse_coordinates", "adflow_gpu_exchange_coor",
+    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2", "adflow_gpu_xhalo", "adflow_gpu_comm_register_periodic", "adflow_gpu_coarse_coordinates", "adflow_gpu_exchange_coor",
     "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
@@ -173,6 +181,7 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_upload_coordinates.argtypes = [c_int, c_int, c_int]
     lib.adflow_gpu_update_geometry.argtypes = [c_int]
     lib.adflow_gpu_xhalo.argtypes = [c_int]
+    lib.adflow_gpu_comm_register_periodic.argtypes = [c_int, c_int, c_int, POINTER(AdflowPeriodicData)]
     lib.adflow_gpu_coarse_coordinates.argtypes = [c_int]
     lib.adflow_gpu_exchange_coor.argtypes = [c_int]
     lib.adflow_gpu_reference_shock_sensor.argtypes = [c_int]

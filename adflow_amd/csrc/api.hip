@@ -82,6 +82,13 @@ struct CommPattern {
     std::vector<int32_t> h_donorBlock, h_donorIdx, h_haloBlock, h_haloIdx;
     std::vector<int32_t> h_sendProc, h_nsendCum, h_sendBlock, h_sendIdx;
     std::vector<int32_t> h_recvProc, h_nrecvCum, h_recvBlock, h_recvIdx;
+    // periodic transformations (periodicDataType): halos they apply to
+    struct Periodic {
+        double rotMatrix[9], rotCenter[3], translation[3];
+        std::vector<int32_t> h_block, h_idx;
+        CommList list;
+    };
+    std::vector<Periodic> periodic;
     bool built = false;
 };
 
@@ -104,17 +111,22 @@ void free_list(CommList& l)
     l = CommList();
 }
 
+// device lists of a pattern: rebuilt from the host copies at the next exchange
+void drop_comm_lists(CommPattern& cp)
+{
+    free_list(cp.local);
+    for (auto& l : cp.sends) free_list(l);
+    for (auto& l : cp.recvs) free_list(l);
+    for (auto& pd : cp.periodic) free_list(pd.list);
+    cp.sends.clear();
+    cp.recvs.clear();
+    cp.built = false;
+}
+
 void invalidate_comm_level(int level)
 {
     for (auto& kv : g_comm)
-        if (kv.first.first == level) {
-            free_list(kv.second.local);
-            for (auto& l : kv.second.sends) free_list(l);
-            for (auto& l : kv.second.recvs) free_list(l);
-            kv.second.sends.clear();
-            kv.second.recvs.clear();
-            kv.second.built = false;
-        }
+        if (kv.first.first == level) drop_comm_lists(kv.second);
     auto it = g_tab.find(level);
     if (it != g_tab.end()) {
         (void)hipFree(it->second);
@@ -1041,6 +1053,12 @@ int build_comm(int level, int nLayers, CommPattern** out)
         if (make_list(level, cp.h_recvBlock.data(), cp.h_recvIdx.data(), nrt, cp.h_nrecvCum[i], l.n, &l.blkA, &l.offA)) return 1;
         HIPCHK(hipMalloc((void**)&l.buf, sizeof(double) * 11 * (size_t)std::max(l.n, 1)));
     }
+    for (auto& pd : cp.periodic) {
+        free_list(pd.list);
+        pd.list.n = (int)pd.h_block.size();
+        if (pd.list.n > 0 && make_list(level, pd.h_block.data(), pd.h_idx.data(), pd.list.n, 0, pd.list.n, &pd.list.blkA, &pd.list.offA))
+            return 1;
+    }
     cp.built = true;
     return 0;
 }
@@ -1431,10 +1449,7 @@ int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* 
     if (nLayers < 0 || nLayers > 2) return fail("nLayers must be 1 or 2 (cell halos) or 0 (the node pattern of exchangeCoor)");
     auto key = std::make_pair(level, nLayers);
     if (g_comm.count(key)) {
-        CommPattern& old = g_comm[key];
-        free_list(old.local);
-        for (auto& l : old.sends) free_list(l);
-        for (auto& l : old.recvs) free_list(l);
+        drop_comm_lists(g_comm[key]);     // a re-registration also drops the periodic transformations
     }
     CommPattern cp;
     cp.present = true;
@@ -1461,6 +1476,28 @@ int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* 
         cp.h_recvIdx.assign(p->recvIndices, p->recvIndices + 3 * (size_t)nt);
     }
     g_comm[key] = cp;
+    return 0;
+}
+
+int adflow_gpu_comm_register_periodic(int level, int nLayers, int nPeriodic, const adflow_periodic_data* pd)
+{
+    auto it = g_comm.find(std::make_pair(level, nLayers));
+    if (it == g_comm.end()) return fail("comm_register_periodic: no pattern registered for level %d, nLayers %d", level, nLayers);
+    if (nPeriodic < 0 || (nPeriodic > 0 && !pd)) return fail("comm_register_periodic: nPeriodic=%d", nPeriodic);
+    CommPattern& cp = it->second;
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    drop_comm_lists(cp);
+    cp.periodic.clear();
+    for (int m = 0; m < nPeriodic; ++m) {
+        CommPattern::Periodic q;
+        for (int a = 0; a < 9; ++a) q.rotMatrix[a] = pd[m].rotMatrix[a];
+        for (int a = 0; a < 3; ++a) { q.rotCenter[a] = pd[m].rotCenter[a]; q.translation[a] = pd[m].translation[a]; }
+        const int n = pd[m].nHalos;
+        if (n < 0 || (n > 0 && (!pd[m].block || !pd[m].indices))) return fail("comm_register_periodic: entry %d: nHalos=%d", m + 1, n);
+        q.h_block.assign(pd[m].block, pd[m].block + n);
+        q.h_idx.assign(pd[m].indices, pd[m].indices + (size_t)3 * n);
+        cp.periodic.push_back(q);
+    }
     return 0;
 }
 
@@ -1570,6 +1607,13 @@ static int comm_exchange_enqueue(CommPattern* cp, BlkView* tab, unsigned mask, i
     }
     launch_halo_copy(tab, cp->local.blkA, cp->local.offA, cp->local.blkB, cp->local.offB, cp->local.n, mask, g_stream);
     for (auto& l : cp->recvs) launch_halo_unpack(tab, l.blkA, l.offA, l.n, mask, l.buf, g_stream);
+    // periodic transformations of the halos that crossed a periodic interface: coordinates for the node pattern,
+    // velocities when all three travelled (haloExchange.F90:456-457)
+    const bool coor = (mask & (7u << 11)) != 0;
+    const bool vel = (mask & 0xEu) == 0xEu;
+    if (coor || vel)
+        for (auto& pd : cp->periodic)
+            launch_periodic(tab, pd.list.blkA, pd.list.offA, pd.list.n, pd.rotMatrix, pd.rotCenter, pd.translation, coor ? 1 : 0, g_stream);
     return 0;
 }
 

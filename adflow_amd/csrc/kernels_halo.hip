@@ -65,6 +65,46 @@ __global__ void k_halo_unpack(const BlkView* __restrict__ tab, const int* __rest
         }
 }
 
+// periodic transformations on the receiving side (haloExchange.F90:487-551 velocities, :2644-2712 coordinates)
+struct Rot3 { double m[9]; double c[3], t[3]; };    // m column-major
+
+__global__ void k_periodic_velocity(const BlkView* __restrict__ tab, const int* __restrict__ blk, const long* __restrict__ off, int n,
+                                    Rot3 r)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const BlkView& b = tab[blk[t]];
+    const long o = off[t], nb = b.nbox;
+    const double vx = b.w[o + nb], vy = b.w[o + 2 * nb], vz = b.w[o + 3 * nb];
+    b.w[o + nb] = r.m[0] * vx + r.m[3] * vy + r.m[6] * vz;
+    b.w[o + 2 * nb] = r.m[1] * vx + r.m[4] * vy + r.m[7] * vz;
+    b.w[o + 3 * nb] = r.m[2] * vx + r.m[5] * vy + r.m[8] * vz;
+}
+
+__global__ void k_periodic_coor(const BlkView* __restrict__ tab, const int* __restrict__ blk, const long* __restrict__ off, int n, Rot3 r)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const BlkView& b = tab[blk[t]];
+    const long o = off[t], nb = b.nbox;
+    const double dx = b.x[o] - r.c[0], dy = b.x[o + nb] - r.c[1], dz = b.x[o + 2 * nb] - r.c[2];
+    b.x[o] = r.m[0] * dx + r.m[3] * dy + r.m[6] * dz + r.t[0];
+    b.x[o + nb] = r.m[1] * dx + r.m[4] * dy + r.m[7] * dz + r.t[1];
+    b.x[o + 2 * nb] = r.m[2] * dx + r.m[5] * dy + r.m[8] * dz + r.t[2];
+}
+
+// coor: node pattern (translation already holds periodicData%translation + rotCenter)
+void launch_periodic(const BlkView* tab, const int* blk, const long* off, int n, const double rotMatrix[9], const double rotCenter[3],
+                     const double translation[3], int coor, hipStream_t s)
+{
+    if (n <= 0) return;
+    Rot3 r;
+    for (int q = 0; q < 9; ++q) r.m[q] = rotMatrix[q];
+    for (int q = 0; q < 3; ++q) { r.c[q] = rotCenter[q]; r.t[q] = translation[q] + rotCenter[q]; }
+    if (coor) hipLaunchKernelGGL(k_periodic_coor, dim3((n + 255) / 256), dim3(256), 0, s, tab, blk, off, n, r);
+    else hipLaunchKernelGGL(k_periodic_velocity, dim3((n + 255) / 256), dim3(256), 0, s, tab, blk, off, n, r);
+}
+
 void launch_halo_copy(const BlkView* tab, const int* donorBlk, const long* donorOff, const int* haloBlk, const long* haloOff,
                       int n, unsigned mask, hipStream_t s)
 {

@@ -143,6 +143,25 @@ class Engine:
         """volume_block + metric_block + boundaryNormals on the device"""
         self._chk(self.lib.adflow_gpu_update_geometry(level))
 
+    def comm_register_periodic(self, level, nLayers, periodic):
+        """periodic: list of dicts rotMatrix (3,3), rotCenter (3), translation (3), block (n) int32, indices (n,3) int32 F-order"""
+        arr = (capi.AdflowPeriodicData * max(len(periodic), 1))()
+        keep = []
+        for m, pd in enumerate(periodic):
+            R = np.asfortranarray(pd["rotMatrix"], dtype=np.float64)
+            for q in range(9):
+                arr[m].rotMatrix[q] = float(R.ravel(order="F")[q])
+            for q in range(3):
+                arr[m].rotCenter[q] = float(pd["rotCenter"][q])
+                arr[m].translation[q] = float(pd["translation"][q])
+            blk = np.ascontiguousarray(pd["block"], np.int32)
+            idx = np.asfortranarray(pd["indices"], np.int32)
+            keep += [blk, idx]
+            arr[m].nHalos = int(blk.size)
+            arr[m].block = blk.ctypes.data
+            arr[m].indices = idx.ctypes.data
+        self._chk(self.lib.adflow_gpu_comm_register_periodic(level, nLayers, len(periodic), arr))
+
     def xhalo(self, level=1):
         """xhalo_block of every block of the level"""
         self._chk(self.lib.adflow_gpu_xhalo(level))

@@ -60,6 +60,17 @@ module adflowGpuShim
         type(c_ptr) :: recvProc, nrecvCum, recvBlock, recvIndices
     end type adflow_comm_pattern
 
+    type intBuf
+        integer(c_int32_t), allocatable :: v(:)
+    end type intBuf
+
+    ! ---- mirror of adflow_periodic_data ----------------------------------------
+    type, bind(C) :: adflow_periodic_data
+        real(c_double) :: rotMatrix(9), rotCenter(3), translation(3)
+        integer(c_int32_t) :: nHalos, reserved
+        type(c_ptr) :: block, indices
+    end type adflow_periodic_data
+
     ! ---- mirror of adflow_bc_subface ------------------------------------------
     type, bind(C) :: adflow_bc_subface
         integer(c_int32_t) :: bcType, faceID
@@ -89,6 +100,12 @@ module adflowGpuShim
         integer(c_int) function adflow_gpu_apply_all_bc(level, secondHalo) bind(C, name="adflow_gpu_apply_all_bc")
             import :: c_int
             integer(c_int), value :: level, secondHalo
+        end function
+        integer(c_int) function adflow_gpu_comm_register_periodic(level, nLayers, nPeriodic, pd) &
+            bind(C, name="adflow_gpu_comm_register_periodic")
+            import :: c_int, adflow_periodic_data
+            integer(c_int), value :: level, nLayers, nPeriodic
+            type(adflow_periodic_data), intent(in) :: pd(*)
         end function
         integer(c_int) function adflow_gpu_xhalo(level) bind(C, name="adflow_gpu_xhalo")
             import :: c_int
@@ -336,6 +353,49 @@ contains
         p%nProcRecv = cp%nProcRecv; p%recvProc = c_loc(rp); p%nrecvCum = c_loc(nrc)
         p%recvBlock = c_loc(recvBlock); p%recvIndices = c_loc(recvIdx)
         call gpuCheck(adflow_gpu_comm_register(int(level, c_int), int(nLayers, c_int), p), "gpuRegisterComm")
+        call registerPeriodic()
+    contains
+        ! periodicData of the internal and of the inter-processor pattern, concatenated (disjoint halos)
+        subroutine registerPeriodic()
+            type(adflow_periodic_data), allocatable :: pd(:)
+            type(intBuf), allocatable, target :: bb(:), ii(:)
+            integer :: np, m, k, n
+            np = ic%nPeriodic + cp%nPeriodic
+            allocate (pd(max(np, 1)), bb(max(np, 1)), ii(max(np, 1)))
+            do m = 1, np
+                if (m <= ic%nPeriodic) then
+                    associate (q => ic%periodicData(m))
+                        n = q%nHalos
+                        pd(m)%rotMatrix = reshape(q%rotMatrix, [9]); pd(m)%rotCenter = q%rotCenter
+                        pd(m)%translation = q%translation
+                        allocate (bb(m)%v(max(n, 1)), ii(m)%v(3 * max(n, 1)))
+                        do k = 1, n
+                            bb(m)%v(k) = int(q%block(k), c_int32_t)
+                            ii(m)%v(k) = int(q%indices(k, 1), c_int32_t)
+                            ii(m)%v(n + k) = int(q%indices(k, 2), c_int32_t)
+                            ii(m)%v(2 * n + k) = int(q%indices(k, 3), c_int32_t)
+                        end do
+                    end associate
+                else
+                    associate (q => cp%periodicData(m - ic%nPeriodic))
+                        n = q%nHalos
+                        pd(m)%rotMatrix = reshape(q%rotMatrix, [9]); pd(m)%rotCenter = q%rotCenter
+                        pd(m)%translation = q%translation
+                        allocate (bb(m)%v(max(n, 1)), ii(m)%v(3 * max(n, 1)))
+                        do k = 1, n
+                            bb(m)%v(k) = int(q%block(k), c_int32_t)
+                            ii(m)%v(k) = int(q%indices(k, 1), c_int32_t)
+                            ii(m)%v(n + k) = int(q%indices(k, 2), c_int32_t)
+                            ii(m)%v(2 * n + k) = int(q%indices(k, 3), c_int32_t)
+                        end do
+                    end associate
+                end if
+                pd(m)%nHalos = int(n, c_int32_t); pd(m)%reserved = 0
+                pd(m)%block = c_loc(bb(m)%v); pd(m)%indices = c_loc(ii(m)%v)
+            end do
+            call gpuCheck(adflow_gpu_comm_register_periodic(int(level, c_int), int(nLayers, c_int), int(np, c_int), pd), &
+                          "gpuRegisterComm (periodic)")
+        end subroutine registerPeriodic
     end subroutine gpuRegisterComm
 
     ! flowDoms(nn,level,sps)%BCType / BCFaceID / BCData(:) -> device (BCRoutines on the device).  Call again after

@@ -30,6 +30,8 @@ class CommPattern:
     nrecvCum: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
     recvBlock: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     recvIndices: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.int32, order="F"))
+    # per same-process copy: -1 / +1 when the halo wraps around the brick in i (a periodic interface), else 0
+    wrapI: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
 
     @property
     def ncopy(self):
@@ -93,7 +95,7 @@ class BrickTopology:
         hi, hj, hk = I[halo], J[halo], K[halo]        # canonical order: k slowest? (C order of the mask)
         lid = self.local_ids()
         ranks = sorted({self.owner(g) for g in range(self.nblocks)})
-        loc = {r: [[], [], [], []] for r in ranks}            # donorBlk, donorIdx, haloBlk, haloIdx
+        loc = {r: [[], [], [], [], []] for r in ranks}        # donorBlk, donorIdx, haloBlk, haloIdx, wrapI
         msg: Dict[Tuple[int, int], List] = {}                  # (src rank, dst rank) -> [sendBlk, sendIdx, recvBlk, recvIdx]
 
         def node_map(b, idx, n, B):
@@ -105,11 +107,15 @@ class BrickTopology:
         for g in range(self.nblocks):
             bi, bj, bk = self.coords(g)
             if nodes:
+                gw = bi * nx + hi - 1
+                wrap = np.where((hi >= 1) & (hi <= nx + 1), 0, np.where(gw < 0, -1, np.where(gw >= self.Bi * nx, 1, 0)))
                 dbi, di = node_map(bi, hi, nx, self.Bi)
                 dbj, dj = node_map(bj, hj, ny, self.Bj)
                 dbk, dk = node_map(bk, hk, nz, self.Bk)
                 dg = dbi + self.Bi * (dbj + self.Bj * dbk)
             else:
+                gw = bi * nx + hi - 2
+                wrap = np.where(gw < 0, -1, np.where(gw >= self.Bi * nx, 1, 0))
                 gi = (bi * nx + hi - 2) % (self.Bi * nx)
                 gj = (bj * ny + hj - 2) % (self.Bj * ny)
                 gk = (bk * nz + hk - 2) % (self.Bk * nz)
@@ -128,7 +134,7 @@ class BrickTopology:
                 if rd == rh:
                     L = loc[rh]
                     L[0].append(np.full(n, lid[int(dgu)])); L[1].append(didx)
-                    L[2].append(np.full(n, lid[g])); L[3].append(hidx)
+                    L[2].append(np.full(n, lid[g])); L[3].append(hidx); L[4].append(wrap[m])
                 else:
                     M = msg.setdefault((int(rd), int(rh)), [[], [], [], []])
                     M[0].append(np.full(n, lid[int(dgu)])); M[1].append(didx)
@@ -144,6 +150,7 @@ class BrickTopology:
                 cp.donorIndices = np.asfortranarray(np.concatenate(L[1]).astype(np.int32))
                 cp.haloBlock = np.concatenate(L[2]).astype(np.int32)
                 cp.haloIndices = np.asfortranarray(np.concatenate(L[3]).astype(np.int32))
+                cp.wrapI = np.concatenate(L[4]).astype(np.int32)
             sp, sc, sb, si_ = [], [0], [], []
             rp, rc, rb, ri_ = [], [0], [], []
             for (src, dst), M in sorted(msg.items()):

@@ -232,7 +232,8 @@ int adflow_gpu_update_geometry(int level);
  *   adflow_gpu_exchange_coor  haloExchange::exchangeCoor (haloExchange.F90:2456-2640): halo nodes of 1-to-1 interfaces
  *                             from the neighbours' interior nodes, using the NODE pattern commPatternNode_1st(level) /
  *                             internalNode_1st(level) registered with adflow_gpu_comm_register(level, 0, pattern)
- *                             (same-GPU copies + RCCL send/recv; periodic translations / rotations are not applied). */
+ *                             (same-GPU copies + RCCL send/recv; periodic transformations as registered with
+ *                             adflow_gpu_comm_register_periodic). */
 int adflow_gpu_xhalo(int level);
 /* coarseUtils::coarseOwnedCoordinates(coarseLevel) (coarseUtils.F90:780-858): the owned nodes of the coarse blocks from
  * the level above, through the registered mgI/J/KFine maps.  updateCoordinatesAllLevels / updateMetricsAllLevels
@@ -283,6 +284,19 @@ int adflow_gpu_transfer_to_fine(int level);
 int adflow_gpu_mg_cycle(const int32_t* cycling, int nStepsCycling);
 /* register the 1-to-1 pattern of (level, nLayers = 1 | 2); lists are copied */
 int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* p);
+/* Periodic transformations of a registered pattern: the periodicData(:) of internalCell_*(level) AND commPatternCell_*(level)
+ * (communication.F90 periodicDataType) concatenated - they address disjoint halos.  Applied on the receiving side after the
+ * exchange: velocities of the listed halo cells rotated by rotMatrix when the exchanged range covers ivx..ivz
+ * (correctPeriodicVelocity, haloExchange.F90:456-551); for the node pattern (nLayers = 0) the halo node coordinates become
+ * rotMatrix (x - rotCenter) + translation + rotCenter (correctPeriodicCoor, haloExchange.F90:2644-2712).
+ * Call after adflow_gpu_comm_register of the same (level, nLayers); nPeriodic = 0 removes them. */
+typedef struct adflow_periodic_data {
+    double rotMatrix[9];            /* (3,3) column-major, as stored */
+    double rotCenter[3], translation[3];
+    int32_t nHalos, reserved;
+    const int32_t *block, *indices; /* (nHalos), (nHalos,3) column-major */
+} adflow_periodic_data;
+int adflow_gpu_comm_register_periodic(int level, int nLayers, int nPeriodic, const adflow_periodic_data* pd);
 /* haloExchange::whalo1 (nLayers=1) / whalo2 (nLayers=2) (src/utils/haloExchange.F90:5,109):
  * w(varStart:varEnd) [+ p] [+ rlv, rev when viscous / eddy model]; 1-based variable range;
  * same-process copies on the device, other ranks through RCCL send/recv */

@@ -271,6 +271,26 @@ def set_internal_comm(level: int, nLayers: int, cp) -> None:
     load().ref_set_internal_comm(level, nLayers, cp.ncopy, *[a.ctypes.data for a in arrs])
 
 
+def set_periodic(level: int, nLayers: int, periodic) -> None:
+    """internal*(level)%periodicData from a list of dicts (rotMatrix, rotCenter, translation, block, indices); call after
+    set_internal_comm of the same pattern"""
+    lib = load()
+    lib.ref_set_periodic.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    if not periodic:
+        z = np.zeros(9)
+        zi = np.zeros(3, np.int32)
+        lib.ref_set_periodic(level, nLayers, 1, 0, z.ctypes.data, z.ctypes.data, z.ctypes.data, 0, zi.ctypes.data, zi.ctypes.data)
+        return
+    for m, pd in enumerate(periodic, start=1):
+        R = np.asfortranarray(pd["rotMatrix"], dtype=np.float64)
+        c = np.ascontiguousarray(pd["rotCenter"], dtype=np.float64)
+        t = np.ascontiguousarray(pd["translation"], dtype=np.float64)
+        blk = np.ascontiguousarray(pd["block"], np.int32)
+        idx = np.asfortranarray(pd["indices"], np.int32)
+        lib.ref_set_periodic(level, nLayers, m, len(periodic), R.ctypes.data, c.ctypes.data, t.ctypes.data, int(blk.size),
+                             blk.ctypes.data, idx.ctypes.data)
+
+
 def set_cycling(cycling) -> None:
     c = np.ascontiguousarray(cycling, np.int32)
     load().ref_set_cycling(c.ctypes.data, c.size)

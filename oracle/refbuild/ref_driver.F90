@@ -869,6 +869,39 @@ contains
         end subroutine fill
     end subroutine ref_set_internal_comm
 
+    ! periodicData(nn) of internalNode_1st / internalCell_1st / internalCell_2nd(level) (nLayers = 0 / 1 / 2); the first call
+    ! (nn = 1) sizes the list
+    subroutine ref_set_periodic(level, nLayers, nn, nPeriodic, rotMatrix, rotCenter, translation, nHalos, blk, idx) &
+        bind(C, name="ref_set_periodic")
+        use communication
+        integer(c_int), value :: level, nLayers, nn, nPeriodic, nHalos
+        real(c_double), intent(in) :: rotMatrix(3, 3), rotCenter(3), translation(3)
+        integer(c_int), intent(in) :: blk(nHalos), idx(nHalos, 3)
+        if (nLayers == 0) then
+            call fill(internalNode_1st(level))
+        else if (nLayers == 1) then
+            call fill(internalCell_1st(level))
+        else
+            call fill(internalCell_2nd(level))
+        end if
+    contains
+        subroutine fill(ic)
+            type(internalCommType), intent(inout) :: ic
+            if (nn == 1) then
+                ic%nPeriodic = nPeriodic
+                allocate (ic%periodicData(max(nPeriodic, 1)))
+            end if
+            if (nPeriodic == 0) return
+            ic%periodicData(nn)%rotMatrix = rotMatrix
+            ic%periodicData(nn)%rotCenter = rotCenter
+            ic%periodicData(nn)%translation = translation
+            ic%periodicData(nn)%nHalos = nHalos
+            allocate (ic%periodicData(nn)%block(nHalos), ic%periodicData(nn)%indices(nHalos, 3))
+            ic%periodicData(nn)%block = blk
+            ic%periodicData(nn)%indices = idx
+        end subroutine fill
+    end subroutine ref_set_periodic
+
     ! shell routines acting on every committed block of `level`
     subroutine ref_call_level(name, level, i1, i2) bind(C, name="ref_call_level")
         use iteration, only: currentLevel, groundLevel, rkStage

@@ -213,6 +213,55 @@ def check_coordinate_halos_brick(engine, topo, prm, seed=83, **mk):
     _assert_geometry(engine, blocks, rblocks, "xhalo + exchangeCoor + metrics")
 
 
+def periodic_lists(cp, angle=0.3, translation=(0.0, 0.0, 0.4), center=(0.1, -0.2, 0.0)):
+    """periodicData of a pattern whose i direction wraps around a rotationally periodic sector: halos that crossed the
+    low-i side take the rotation about z by -angle, those that crossed the high-i side by +angle"""
+    out = []
+    for sign in (-1, 1):
+        m = cp.wrapI == sign
+        if not m.any():
+            continue
+        a = sign * angle
+        R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+        out.append(dict(rotMatrix=R, rotCenter=np.array(center), translation=sign * np.array(translation),
+                        block=cp.haloBlock[m].copy(), indices=np.asfortranarray(cp.haloIndices[m])))
+    return out
+
+
+def check_periodic_halos(engine, topo, prm, seed=89, **mk):
+    """periodic interfaces: correctPeriodicVelocity after whalo1 / whalo2 (haloExchange.F90:456-551) and
+    correctPeriodicCoor after exchangeCoor (:2644-2712), applied to the halos listed in periodicData"""
+    from oracle import ref
+    blocks, rblocks = setup_brick(engine, topo, prm, seed, **mk)
+    pats = {L: topo.patterns(L)[0] for L in (0, 1, 2)}
+    ref.set_internal_comm(1, 0, pats[0])
+    engine.comm_register(1, 0, pats[0])
+    for L in (0, 1, 2):
+        pl = periodic_lists(pats[L])
+        assert pl, "the brick must wrap in i"
+        ref.set_periodic(1, L, pl)
+        engine.comm_register_periodic(1, L, pl)
+    rng = np.random.default_rng(seed)
+    for nn in sorted(blocks):
+        f = 1.0 + 0.01 * rng.uniform(-1, 1, blocks[nn]["w"].shape)
+        for b in (blocks[nn], rblocks[nn]):
+            b["w"] *= f
+        engine.upload_state(nn, 1)
+    for nLayers, name in ((2, "whalo2"), (1, "whalo1")):
+        ref.call_level(name, 1, 1, prm.nw)
+        getattr(engine, name)(1, 1, prm.nw)
+        assert_state(engine, blocks, rblocks, prm, f"{name} with periodic velocity rotation")
+    # density only: no rotation (haloExchange.F90:457)
+    ref.call_level("whalo2", 1, 1, 1)
+    engine.whalo2(1, 1, 1)
+    assert_state(engine, blocks, rblocks, prm, "whalo2 of rho only: no periodic correction")
+    ref.call_level("exchangeCoor", 1)
+    engine.exchangeCoor(1)
+    _assert_geometry(engine, blocks, rblocks, "exchangeCoor with periodic transformation", names=("x",))
+    for L in (0, 1, 2):        # leave the reference's patterns clean for the next test
+        ref.set_periodic(1, L, [])
+
+
 def check_coarse_level_geometry(engine, topo, prm, seed=87, **mk):
     """updateCoordinatesAllLevels / updateMetricsAllLevels on the device (preprocessingAPI.F90:3945-4017): owned coarse
     nodes by injection (coarseOwnedCoordinates, coarseUtils.F90:780-858, restated with numpy: a pure copy of every

@@ -81,3 +81,9 @@ def test_low_speed_preconditioner(engine):
     checks.check_dadi_smoother(engine, BrickTopology(1, 2, 1, 16, 8, 8),
                                FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, **lo), stretch_k=2.0)
     checks.check_block_res(engine, (20, 10, 8), FlowParams(**lo), seed=5)
+
+
+def test_periodic_halos(engine):
+    """a18: periodic transformations of the halo exchange (velocities) and of exchangeCoor (coordinates)"""
+    checks.check_periodic_halos(engine, BrickTopology(2, 1, 1, 20, 9, 8), FlowParams())
+    checks.check_periodic_halos(engine, BrickTopology(1, 2, 1, 70, 6, 4), FlowParams(equations=RANSEquations), stretch_k=2.0)

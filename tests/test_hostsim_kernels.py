@@ -267,6 +267,12 @@ def test_coordinate_halos(hostsim_engine):
     checks.check_coarse_level_geometry(hostsim_engine, BrickTopology(2, 1, 1, 8, 6, 4), FlowParams())
 
 
+def test_periodic_halos(hostsim_engine):
+    """a18: periodic transformations of the halo exchange (velocities) and of exchangeCoor (coordinates)"""
+    checks.check_periodic_halos(hostsim_engine, BrickTopology(2, 1, 1, 5, 4, 3), FlowParams())
+    checks.check_periodic_halos(hostsim_engine, BrickTopology(1, 2, 1, 4, 4, 2), FlowParams(equations=RANSEquations), stretch_k=2.0)
+
+
 def test_multiblock_bc(hostsim_engine):
     """several blocks with different subface lists: the level-batched BC launches against the reference's block loop"""
     checks.check_multiblock_bc(hostsim_engine, FlowParams(), {
