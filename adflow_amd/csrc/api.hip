@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_viscous_tiled, g_lines_i_tiled;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled;
 
 namespace {
 
@@ -2119,7 +2119,17 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!key) return fail("null tuning key");
     if (!strcmp(key, "euler_march")) { g_use_march = (value != 0); return 0; }
     if (!strcmp(key, "march_minw")) { g_march_minw = value; return 0; }
-    if (!strcmp(key, "march_pipe")) { g_march_pipe = value; return 0; }
+    if (!strcmp(key, "march_pipe") || !strcmp(key, "march_by")) {
+        if (!strcmp(key, "march_by")) {
+            if (value != 4 && value != 8) return fail("march_by must be 4 or 8");
+            g_march_by = value;
+        } else
+            g_march_pipe = value;
+        if (g_stream) (void)hipStreamSynchronize(g_stream);
+        for (auto& kv : g_tiles) (void)hipFree(kv.second.first);   // tile tables depend on the rows per workgroup
+        g_tiles.clear();
+        return 0;
+    }
     if (!strcmp(key, "viscous_tiled")) { g_viscous_tiled = value; return 0; }
     if (!strcmp(key, "lines_i_tiled")) { g_lines_i_tiled = value; return 0; }
     if (!strcmp(key, "march_kch")) {

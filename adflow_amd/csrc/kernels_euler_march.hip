@@ -304,26 +304,25 @@ struct InB {      // loads of phase B of plane k
 // the EM_BY waves: 6 wide loads per wave and plane replace 30 narrow ones, which takes
 // the texture-address unit (the measured bottleneck of the register-only form:
 // TA busy 83-95 % of the kernel) out of the critical path.  One barrier per plane.
-#define EL_ROWS (EM_BY + 4)
-#define EL_PANEL (EL_ROWS * 64)          // doubles of one quantity in one slot
-#define EL_SLOT (6 * EL_PANEL)           // doubles of one slot (24 KiB)
 typedef double d2_t __attribute__((vector_size(16)));
 __device__ __forceinline__ d2_t ldg2(GPTR(const double) base, unsigned byteoff)
 {
     return *(GPTR(const d2_t))((GPTR(const char))base + byteoff);
 }
 
-template <bool FW, bool LDSJ>
-__global__ __launch_bounds__(64 * EM_BY, 2) void k_euler_march_p(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
+template <bool FW, bool LDSJ, int BY>
+__global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
                                                                  KParams kp, int kch)
 {
+    // BY rows of cells per workgroup (4: two workgroups per CU; 8: one, with 12 instead of 2 x 8 staged rows per 8 produced)
+    constexpr int EL_ROWS = BY + 4, EL_PANEL = EL_ROWS * 64, EL_SLOT = 6 * EL_PANEL;
     __shared__ __attribute__((aligned(16))) double lds[LDSJ ? 3 * EL_SLOT : 2];
     const int4 t = tiles[blockIdx.x];
     if (t.x < 0) return;
     const BlkView& b = tab[t.x];
     const int lane = threadIdx.x;
     const int i = t.y * EM_OUT + lane;
-    const int j = 2 + t.z * EM_BY + (int)threadIdx.y;
+    const int j = 2 + t.z * BY + (int)threadIdx.y;
     const int k0 = 2 + t.w * kch;
     const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
     const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
@@ -384,14 +383,16 @@ __global__ __launch_bounds__(64 * EM_BY, 2) void k_euler_march_p(const BlkView* 
     int splane = k0;            // plane index of the next staging load
     d2_t st[6];
     if (LDSJ) {
-        int jr = t.z * EM_BY + hrow;                  // j0 - 2 + hrow
+        int jr = t.z * BY + hrow;                  // j0 - 2 + hrow
         if (jr > b.jb) jr = b.jb;
         int ip = t.y * EM_OUT + xp;                   // even; the last pair may run one cell past ib (row padding)
         if (ip > (b.ib & ~1)) ip = b.ib & ~1;         // stays 16-byte aligned
         cs = 8u * (unsigned)(ip + jr * b.ldi);
     }
     const int ldsW = hrow * 64 + xp;                  // position inside a panel
+    const bool stager = hrow < EL_ROWS;               // BY = 8: the waves 6 and 7 have no rows to stage
     auto stage_load = [&]() {
+        if (!stager) return;
         const int pl = (splane < b.kb) ? splane : b.kb;
         const unsigned o = cs + (unsigned)pl * sk;
         st[0] = ldg2(m.w0, o); st[1] = ldg2(m.w1, o); st[2] = ldg2(m.w2, o); st[3] = ldg2(m.w3, o); st[4] = ldg2(m.w4, o);
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(64 * EM_BY, 2) void k_euler_march_p(const BlkView* 
         ++splane;
     };
     auto stage_store = [&](int slot) {
+        if (!stager) return;
 #pragma unroll
         for (int q = 0; q < 6; ++q) *(d2_t*)&lds[slot * EL_SLOT + q * EL_PANEL + ldsW] = st[q];
     };
@@ -563,21 +565,29 @@ __global__ __launch_bounds__(64 * EM_BY, 2) void k_euler_march_p(const BlkView* 
 int g_march_minw = 2;
 int g_march_kch = EM_KCH;      // k-chunk length of a tile (tuning "march_kch")
 int g_march_pipe = 2;          // tuning "march_pipe": 0 plain, 1 software-pipelined, 2 pipelined + state rows shared through LDS
+int g_march_by = EM_BY;        // tuning "march_by": 4 or 8 rows of cells per workgroup (8 only with march_pipe = 2)
+static int march_rows() { return (g_march_pipe >= 2 && g_march_by == 8) ? 8 : EM_BY; }
 
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;
     const dim3 blk(64, EM_BY, 1);
     if (g_march_pipe) {
-        if (g_march_pipe >= 2) {
+        if (g_march_pipe >= 2 && march_rows() == 8) {
+            const dim3 blk8(64, 8, 1);
             if (kp.fwMode)
-                hipLaunchKernelGGL((k_euler_march_p<true, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+                hipLaunchKernelGGL((k_euler_march_p<true, true, 8>), dim3(ntiles), blk8, 0, s, tab, tiles, kp, g_march_kch);
             else
-                hipLaunchKernelGGL((k_euler_march_p<false, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+                hipLaunchKernelGGL((k_euler_march_p<false, true, 8>), dim3(ntiles), blk8, 0, s, tab, tiles, kp, g_march_kch);
+        } else if (g_march_pipe >= 2) {
+            if (kp.fwMode)
+                hipLaunchKernelGGL((k_euler_march_p<true, true, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+            else
+                hipLaunchKernelGGL((k_euler_march_p<false, true, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
         } else if (kp.fwMode)
-            hipLaunchKernelGGL((k_euler_march_p<true, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+            hipLaunchKernelGGL((k_euler_march_p<true, false, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
         else
-            hipLaunchKernelGGL((k_euler_march_p<false, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+            hipLaunchKernelGGL((k_euler_march_p<false, false, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
     } else if (kp.fwMode) {
         hipLaunchKernelGGL((k_euler_march<2, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
     } else if (g_march_minw >= 3) {
@@ -591,6 +601,6 @@ void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz)
 {
     *ntx = (b.nx + EM_OUT - 1) / EM_OUT;
-    *nty = (b.ny + EM_BY - 1) / EM_BY;
+    *nty = (b.ny + march_rows() - 1) / march_rows();
     *ntz = (b.nz + g_march_kch - 1) / g_march_kch;
 }

@@ -160,6 +160,19 @@ def test_euler_march_variants(hostsim_engine, pipe, kch):
         hostsim_engine.set_tuning("march_kch", 32)
 
 
+def test_euler_march_eight_rows(hostsim_engine):
+    """marching kernel with 8 rows of cells per workgroup (tuning march_by = 8): ragged j extents, chunk boundaries"""
+    hostsim_engine.set_tuning("march_by", 8)
+    hostsim_engine.set_tuning("march_kch", 5)
+    try:
+        checks.check_block_res(hostsim_engine, (13, 11, 9), FlowParams(spaceDiscr=dissScalar), seed=79, wall_kmin=True)
+        checks.check_block_res(hostsim_engine, (7, 3, 4), FlowParams(spaceDiscr=dissScalar), seed=80)
+        checks.check_rk_residual_sequence(hostsim_engine, (9, 17, 7), FlowParams(spaceDiscr=dissScalar), seed=81)
+    finally:
+        hostsim_engine.set_tuning("march_by", 4)
+        hostsim_engine.set_tuning("march_kch", 32)
+
+
 # ---- boundary conditions on the device ("next" row 1): same checks as tests/test_gpu_bc.py, small sizes ----
 @pytest.mark.parametrize("spec", [{1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}, {1: -7, 2: -6, 3: -5, 4: -5, 5: -1, 6: -1}])
 @pytest.mark.parametrize("second", [True, False])

@@ -28,10 +28,10 @@ for nn in range(1, nblk + 1):
 eng.timeStep(1, False)
 ncell = nblk * nx * ny * nz
 CONFIGS = [
-    dict(march_pipe=2, march_kch=32, march_nt=0),
-    dict(march_pipe=2, march_kch=32, march_nt=1),
-    dict(march_pipe=2, march_kch=16, march_nt=1),
-    dict(march_pipe=2, march_kch=32, march_nt=0),
+    dict(march_pipe=2, march_kch=32, march_by=4),
+    dict(march_pipe=2, march_kch=32, march_by=8),
+    dict(march_pipe=2, march_kch=64, march_by=8),
+    dict(march_pipe=2, march_kch=32, march_by=4),
 ]
 if only:
     CONFIGS = [dict(march_pipe=only[0], march_kch=only[1])]
