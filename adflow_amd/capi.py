@@ -50,7 +50,8 @@ class AdflowOpts(ctypes.Structure):
         ("RGas", c_double), ("muInf", c_double), ("muRef", c_double), ("TRef", c_double), ("timeRef", c_double),
         ("wInf", c_double * 10),
         ("sigma", c_double),
-        ("reserved_d", c_double * 7),
+        ("pRef", c_double), ("uRef", c_double), ("LRef", c_double), ("ordersConverged", c_double),
+        ("reserved_d", c_double * 3),
     ]
 
 
@@ -98,6 +99,14 @@ class AdflowBlockDesc(ctypes.Structure):
     ]
 
 
+class AdflowActuatorRegion(ctypes.Structure):
+    """adflow_actuator_region: actuatorRegionType of actuatorRegionData.F90"""
+    _fields_ = [
+        ("nCellIDs", c_int32), ("reserved", c_int32), ("block", c_void_p), ("cellIDs", c_void_p),
+        ("force", c_double * 3), ("heat", c_double), ("volume", c_double), ("relaxStart", c_double), ("relaxEnd", c_double),
+    ]
+
+
 class AdflowPeriodicData(ctypes.Structure):
     """adflow_periodic_data: periodicDataType of communication.F90"""
     _fields_ = [
@@ -138,7 +147,7 @@ EXPORTS = [
     "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
-    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2", "adflow_gpu_xhalo", "adflow_gpu_comm_register_periodic", "adflow_gpu_coarse_coordinates", "adflow_gpu_exchange_coor",
+    "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2", "adflow_gpu_xhalo", "adflow_gpu_actuator_register", "adflow_gpu_comm_register_periodic", "adflow_gpu_coarse_coordinates", "adflow_gpu_exchange_coor",
     "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
@@ -181,6 +190,7 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_upload_coordinates.argtypes = [c_int, c_int, c_int]
     lib.adflow_gpu_update_geometry.argtypes = [c_int]
     lib.adflow_gpu_xhalo.argtypes = [c_int]
+    lib.adflow_gpu_actuator_register.argtypes = [c_int, POINTER(AdflowActuatorRegion)]
     lib.adflow_gpu_comm_register_periodic.argtypes = [c_int, c_int, c_int, POINTER(AdflowPeriodicData)]
     lib.adflow_gpu_coarse_coordinates.argtypes = [c_int]
     lib.adflow_gpu_exchange_coor.argtypes = [c_int]

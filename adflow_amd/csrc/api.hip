@@ -92,6 +92,14 @@ struct CommPattern {
     bool built = false;
 };
 
+struct ActRegion {       // one actuator region (actuatorRegionData.F90); the cell list addresses level-1 blocks
+    std::vector<int32_t> h_block, h_idx;      // h_idx (n,3) column-major as make_list expects
+    double force[3], heat, volume, relaxStart, relaxEnd;
+    CommList list;
+    bool built = false;
+};
+std::vector<ActRegion> g_act;
+
 std::map<std::pair<int, int>, CommPattern> g_comm;   // (level, nLayers)
 std::map<int, BlkView*> g_tab;                        // level -> device table indexed by nn
 std::map<int, int> g_tab_size;
@@ -125,6 +133,8 @@ void drop_comm_lists(CommPattern& cp)
 
 void invalidate_comm_level(int level)
 {
+    if (level == 1)
+        for (auto& r : g_act) r.built = false;      // cell offsets depend on the registered blocks
     for (auto& kv : g_comm)
         if (kv.first.first == level) drop_comm_lists(kv.second);
     auto it = g_tab.find(level);
@@ -146,6 +156,7 @@ int time_step_level(int level, const KParams& kp);
 struct LevelTab { const BlkView* tab; int n, nx, ny, nz; };
 int level_tab(int level, LevelTab* t);
 int ensure_tiles(int level);
+int make_list(int level, const int32_t* blk, const int32_t* idx, int ld, int first, int n, int** d_blk, long** d_off);
 
 Block* find_block(int nn, int level, int sps)
 {
@@ -705,6 +716,7 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
 }
 
 static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox);
+static int source_terms_enqueue(int withBlank);
 
 // residual (residuals.F90:1028) = residual_block of every block; blockResCore (blockette.F90:755) is the same sum of
 // fluxes WITHOUT the low-speed preconditioner of residual_block (residuals.F90:172-331) -> lowSpeed = false there.
@@ -717,6 +729,8 @@ static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox =
     if (enqueue_flow_fluxes(level, kp, viscApprox)) return 1;
     if (stage0 && !viscApprox && kp.viscous && level == g_opts.groundLevel && fabs(kp.rFil) >= 1.e-10)
         if (wall_stress_enqueue(level, kp)) return 1;
+    // sourceTerms() of the call sites of `residual` (smoothers.F90:74,409, multiGrid.F90:52,887,949): fine level only
+    if (lowSpeed && level == 1 && source_terms_enqueue(1)) return 1;
     if (lowSpeed && g_opts.lowSpeedPreconditioner) {
         LevelTab t;
         if (level_tab(level, &t)) return 1;
@@ -845,6 +859,59 @@ static int block_res_enqueue(int level, unsigned flags)
     if (flags & ADFLOW_RES_FLOW) {
         rc = enqueue_flow_residual(level, kp, viscApprox, false);
         if (rc) return rc;
+    }
+    // actuator-region sources after the core, fine level only and without the iblank factor (blockette.F90:276-281)
+    if (level == 1 && source_terms_enqueue(0)) return 1;
+    return 0;
+}
+
+// ---- actuator regions (actuatorRegionData.F90) -----------------------------------------------------------------------
+int adflow_gpu_actuator_register(int nRegions, const adflow_actuator_region* regions)
+{
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    if (nRegions < 0 || (nRegions > 0 && !regions)) return fail("actuator_register: nRegions=%d", nRegions);
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (auto& r : g_act) free_list(r.list);
+    g_act.clear();
+    for (int m = 0; m < nRegions; ++m) {
+        const adflow_actuator_region& in = regions[m];
+        const int n = in.nCellIDs;
+        if (n < 0 || (n > 0 && (!in.block || !in.cellIDs))) return fail("actuator_register: region %d: nCellIDs=%d", m + 1, n);
+        if (!(in.volume > 0.0)) return fail("actuator_register: region %d: volume must be positive", m + 1);
+        ActRegion r;
+        r.h_block.assign(in.block, in.block + n);
+        r.h_idx.resize((size_t)3 * n);
+        for (int t = 0; t < n; ++t)
+            for (int q = 0; q < 3; ++q) r.h_idx[(size_t)q * n + t] = in.cellIDs[(size_t)3 * t + q];   // (3,n) -> (n,3)
+        for (int q = 0; q < 3; ++q) r.force[q] = in.force[q];
+        r.heat = in.heat; r.volume = in.volume; r.relaxStart = in.relaxStart; r.relaxEnd = in.relaxEnd;
+        g_act.push_back(r);
+    }
+    return 0;
+}
+
+static int source_terms_enqueue(int withBlank)
+{
+    if (g_act.empty()) return 0;
+    if (ensure_table(1)) return 1;
+    for (auto& r : g_act) {
+        const int n = (int)r.h_block.size();
+        if (!r.built) {
+            free_list(r.list);
+            r.list.n = n;
+            if (n > 0 && make_list(1, r.h_block.data(), r.h_idx.data(), n, 0, n, &r.list.blkA, &r.list.offA)) return 1;
+            r.built = true;
+        }
+        // relaxation factor and the non-dimensional scales (residuals.F90:367-385)
+        double factor;
+        const double oc = g_opts.ordersConverged;
+        if (oc < r.relaxStart) factor = 0.0;
+        else if (oc > r.relaxEnd) factor = 1.0;
+        else factor = (oc - r.relaxStart) / (r.relaxEnd - r.relaxStart);
+        double Ff[3];
+        for (int q = 0; q < 3; ++q) Ff[q] = factor * r.force[q] / r.volume / g_opts.pRef;
+        const double Qf = factor * r.heat / r.volume / (g_opts.pRef * g_opts.uRef * g_opts.LRef * g_opts.LRef);
+        launch_source_terms(g_tab[1], r.list.blkA, r.list.offA, n, Ff, Qf, withBlank, g_stream);
     }
     return 0;
 }

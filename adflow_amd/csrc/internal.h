@@ -174,6 +174,8 @@ void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int n
 void launch_rk_save_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s);
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s);
 void launch_scale_dw_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double factor, int timesVol, hipStream_t s);
+void launch_source_terms(const BlkView* tab, const int* blk, const long* off, int n, const double Ffact[3], double Qfact, int withBlank,
+                         hipStream_t s);
 void launch_low_speed_precond_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_stage_update_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, double scale,
                                int fromWn, hipStream_t s);

@@ -88,6 +88,35 @@ void launch_scale_dw_level(const BlkView* tab, int nslots, int maxnx, int maxny,
     hipLaunchKernelGGL(k_scale_dw, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, factor, timesVol);
 }
 
+// sourceTerms_block (residuals.F90:348-425): body force and heat source of the cells of an actuator region.
+// withBlank: applied to the finished residual of residual_block, i.e. times max(iblank, 0) as the sum there; without it
+// the form blocketteRes applies after its core (blockette.F90:276-281).
+__global__ __launch_bounds__(256) void k_source_terms(const BlkView* __restrict__ tab, const int* __restrict__ blk,
+                                                      const long* __restrict__ off, int n, double fx, double fy, double fz, double qf,
+                                                      int withBlank)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const BlkView& b = tab[blk[t]];
+    const long c = off[t], nb = b.nbox;
+    const double vol = b.vol[c];
+    const double f1 = vol * fx, f2 = vol * fy, f3 = vol * fz, q = vol * qf;
+    const double vx = b.w[c + nb], vy = b.w[c + 2 * nb], vz = b.w[c + 3 * nb];
+    const double s = withBlank ? flg_blank(b.flags[c]) : 1.0;
+    b.dw[c + nb] -= s * f1;
+    b.dw[c + 2 * nb] -= s * f2;
+    b.dw[c + 3 * nb] -= s * f3;
+    b.dw[c + 4 * nb] -= s * (f1 * vx + f2 * vy + f3 * vz + q);
+}
+
+void launch_source_terms(const BlkView* tab, const int* blk, const long* off, int n, const double Ffact[3], double Qfact, int withBlank,
+                         hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_source_terms, dim3((n + 255) / 256), dim3(256), 0, s, tab, blk, off, n, Ffact[0], Ffact[1], Ffact[2], Qfact,
+                       withBlank);
+}
+
 // Low-speed preconditioner of residual_block (residuals.F90:172-331): dw <- B(w,p,gamma) * dw on the owned cells, with B the
 // 5x5 product of the conservative->primitive jacobian and the low-Mach matrix A of that routine (K1, K2, M0 as there).
 __global__ __launch_bounds__(SM_BX* SM_BY) void k_low_speed_precond(const BlkView* __restrict__ tab, int nzb, double uInf2)

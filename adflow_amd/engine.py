@@ -162,6 +162,22 @@ class Engine:
             arr[m].indices = idx.ctypes.data
         self._chk(self.lib.adflow_gpu_comm_register_periodic(level, nLayers, len(periodic), arr))
 
+    def actuator_register(self, regions):
+        """regions: list of dicts block (n) int32, cellIDs (3,n) int32 F-order, force (3), heat, volume, relaxStart, relaxEnd"""
+        arr = (capi.AdflowActuatorRegion * max(len(regions), 1))()
+        keep = []
+        for m, r in enumerate(regions):
+            blk = np.ascontiguousarray(r["block"], np.int32)
+            ids = np.asfortranarray(r["cellIDs"], np.int32)
+            keep += [blk, ids]
+            arr[m].nCellIDs = int(blk.size)
+            arr[m].block, arr[m].cellIDs = blk.ctypes.data, ids.ctypes.data
+            for q in range(3):
+                arr[m].force[q] = float(r["force"][q])
+            arr[m].heat, arr[m].volume = float(r["heat"]), float(r["volume"])
+            arr[m].relaxStart, arr[m].relaxEnd = float(r.get("relaxStart", -1.0)), float(r.get("relaxEnd", -1.0))
+        self._chk(self.lib.adflow_gpu_actuator_register(len(regions), arr))
+
     def xhalo(self, level=1):
         """xhalo_block of every block of the level"""
         self._chk(self.lib.adflow_gpu_xhalo(level))

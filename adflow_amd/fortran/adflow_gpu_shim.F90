@@ -32,7 +32,8 @@ module adflowGpuShim
         real(c_double) :: gammaInf, pInf, pInfCorr, rhoInf, uInf, RGas, muInf, muRef, TRef, timeRef
         real(c_double) :: wInf(10)
         real(c_double) :: sigma
-        real(c_double) :: reserved_d(7)
+        real(c_double) :: pRef, uRef, LRef, ordersConverged
+        real(c_double) :: reserved_d(3)
     end type adflow_opts
 
     ! ---- mirror of adflow_block_desc ----------------------------------------
@@ -59,6 +60,13 @@ module adflowGpuShim
         integer(c_int32_t) :: nProcRecv
         type(c_ptr) :: recvProc, nrecvCum, recvBlock, recvIndices
     end type adflow_comm_pattern
+
+    ! ---- mirror of adflow_actuator_region --------------------------------------
+    type, bind(C) :: adflow_actuator_region
+        integer(c_int32_t) :: nCellIDs, reserved
+        type(c_ptr) :: block, cellIDs
+        real(c_double) :: force(3), heat, volume, relaxStart, relaxEnd
+    end type adflow_actuator_region
 
     type intBuf
         integer(c_int32_t), allocatable :: v(:)
@@ -106,6 +114,11 @@ module adflowGpuShim
             import :: c_int, adflow_periodic_data
             integer(c_int), value :: level, nLayers, nPeriodic
             type(adflow_periodic_data), intent(in) :: pd(*)
+        end function
+        integer(c_int) function adflow_gpu_actuator_register(nRegions, regions) bind(C, name="adflow_gpu_actuator_register")
+            import :: c_int, adflow_actuator_region
+            integer(c_int), value :: nRegions
+            type(adflow_actuator_region), intent(in) :: regions(*)
         end function
         integer(c_int) function adflow_gpu_xhalo(level) bind(C, name="adflow_gpu_xhalo")
             import :: c_int
@@ -227,7 +240,7 @@ contains
         use inputPhysics
         use inputDiscretization
         use inputIteration
-        use iteration, only: groundLevel
+        use iteration, only: groundLevel, ordersConverged
         use flowVarRefState
         use paramTurb, only: rsaCw1
         type(adflow_opts) :: o
@@ -262,6 +275,7 @@ contains
         o%wInf = zero
         if (allocated(wInf)) o%wInf(1:size(wInf)) = wInf
         o%sigma = sigma
+        o%pRef = pRef; o%uRef = uRef; o%LRef = LRef; o%ordersConverged = ordersConverged
         o%reserved_d = zero
         call gpuCheck(adflow_gpu_set_options(o), "gpuRefreshOptions")
     end subroutine gpuRefreshOptions
@@ -441,6 +455,34 @@ contains
         call gpuCheck(adflow_gpu_bc_register(int(nn, c_int), int(level, c_int), int(sps, c_int), int(nb, c_int), &
                                              int(flowDoms(nn, level, sps)%nViscBocos, c_int), f), "gpuRegisterBocos")
     end subroutine gpuRegisterBocos
+
+    ! actuatorRegions(1:nActuatorRegions) -> device (after addActuatorRegion; again when force / heat change)
+    subroutine gpuRegisterActuatorRegions()
+        use actuatorRegionData, only: actuatorRegions, nActuatorRegions
+        use block, only: nDom
+        type(adflow_actuator_region), allocatable :: r(:)
+        type(intBuf), allocatable, target :: bb(:), cc(:)
+        integer :: m, nn, ii, n
+        allocate (r(max(nActuatorRegions, 1)), bb(max(nActuatorRegions, 1)), cc(max(nActuatorRegions, 1)))
+        do m = 1, nActuatorRegions
+            n = actuatorRegions(m)%nCellIDs
+            allocate (bb(m)%v(max(n, 1)), cc(m)%v(3 * max(n, 1)))
+            do nn = 1, nDom
+                do ii = actuatorRegions(m)%blkPtr(nn - 1) + 1, actuatorRegions(m)%blkPtr(nn)
+                    bb(m)%v(ii) = int(nn, c_int32_t)
+                end do
+            end do
+            do ii = 1, n
+                cc(m)%v(3 * ii - 2:3 * ii) = int(actuatorRegions(m)%cellIDs(1:3, ii), c_int32_t)
+            end do
+            r(m)%nCellIDs = int(n, c_int32_t); r(m)%reserved = 0
+            r(m)%block = c_loc(bb(m)%v); r(m)%cellIDs = c_loc(cc(m)%v)
+            r(m)%force = actuatorRegions(m)%force; r(m)%heat = actuatorRegions(m)%heat
+            r(m)%volume = actuatorRegions(m)%volume
+            r(m)%relaxStart = actuatorRegions(m)%relaxStart; r(m)%relaxEnd = actuatorRegions(m)%relaxEnd
+        end do
+        call gpuCheck(adflow_gpu_actuator_register(int(nActuatorRegions, c_int), r), "gpuRegisterActuatorRegions")
+    end subroutine gpuRegisterActuatorRegions
 
     ! viscSubface(:)%tau / %q of a block <- device (what viscousFlux stored with storeWallTensor); call before the host's
     ! force integration (surfaceIntegrations.F90:718) or computeUtau

@@ -88,6 +88,8 @@ class FlowParams:
     outflowTreatment: int = 1
     lowSpeedPreconditioner: bool = False
     hScalingInlet: bool = False
+    LRef: float = 1.0
+    ordersConverged: float = 16.0
     alfaTurb: float = 0.8
     betaTurb: float = -1.0
     # --- iteration
@@ -161,6 +163,14 @@ class FlowParams:
     @property
     def muInf(self) -> float:
         return self.muInfDim / self.muRef
+
+    @property
+    def pRef(self) -> float:
+        return self.pInfDim
+
+    @property
+    def uRef(self) -> float:
+        return math.sqrt(self.pInfDim / self.rhoInfDim)
 
     @property
     def timeRef(self) -> float:

@@ -260,9 +260,24 @@ def main():
                 tt = torch.tensor([dt_mg], dtype=torch.float64, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt_mg = float(tt.item())
+            # algorithmic bytes of one cycle: sum over levels of n_smooth x nStages x (B_res + B_upd)
+            # + the residuals of the transfers + restriction / prolongation, level l holding N / 8^l cells
+            if rans:
+                b_res, b_dadi, b_upd = 255.0 + 32.0, 244.0, 224.0
+                per_cell = 3 * (b_res + b_dadi + b_upd)            # SA DDADI sweeps not in the §8(d) table: left out
+                formula = "3 x (B_res 287 + B_dadi 244 + B_upd 224) B per cell, SA solve not counted"
+            else:
+                b_res, b_upd, b_ts, b_tr = 175.0, 200.0, 32.0, 8.0 * (2 * 5 + 2)
+                smooth = 5 * (b_res + b_upd)
+                per_cell = smooth + (b_res + b_ts) + (b_res + smooth) / 8.0 + b_tr + (b_res + b_ts)
+                formula = ("fine RK5 5 x (175 + 200) + restriction residual (175 + 32) + coarse [forcing residual 175 + RK5] / 8 "
+                           "+ transfers 96 + closing residual (175 + 32) B per fine cell")
+            alg_cycle = per_cell * cells_local * world
             mg = {"cycles_per_s": ncyc / dt_mg, "ms_per_cycle": dt_mg / ncyc * 1e3, "cycles_timed": ncyc,
                   "cycle": cyc_desc,
-                  "fine_cells_per_gpu": cells_local}
+                  "fine_cells_per_gpu": cells_local,
+                  "algorithmic_bytes_per_cycle": alg_cycle, "algorithmic_bytes_formula": formula,
+                  "hbm_frac": alg_cycle / (dt_mg / ncyc) / (8.0e12 * world)}
             log(f"MG: {mg['ms_per_cycle']:.3f} ms/cycle")
         except Exception as e:
             mg = {"error": str(e)}

@@ -115,7 +115,9 @@ typedef struct adflow_opts {
     double gammaInf, pInf, pInfCorr, rhoInf, uInf, RGas, muInf, muRef, TRef, timeRef;
     double wInf[10];
     double sigma;             /* inputDiscretization: lumped-dissipation coefficient of the approximate residual */
-    double reserved_d[7];
+    double pRef, uRef, LRef;  /* flowVarRefState: scales of the actuator-region source terms (residuals.F90:370-385) */
+    double ordersConverged;   /* iteration: relaxation of the actuator source between relaxStart and relaxEnd */
+    double reserved_d[3];
 } adflow_opts;
 
 /* Host arrays of one block, flowDoms(nn,level,sps)%... .  NULL = not present
@@ -333,6 +335,19 @@ int adflow_gpu_apply_all_bc(int level, int secondHalo);
  * The device stores them after every such residual evaluation (adflow_gpu_residual with rkStage 0, the D-ADI smoother,
  * the multigrid cycle's closing residual, adflow_gpu_block_res). */
 int adflow_gpu_download_wall_stress(int nn, int level, int sps, int mm, double* tau, double* q);
+/* Actuator regions (actuatorRegionData.F90): residuals::sourceTerms_block (residuals.F90:348-425) adds the body force and
+ * heat source of every listed cell to dw of the FINE level: -vol * force / volume / pRef on the momentum residuals,
+ * -(F . v) - vol * heat / volume / (pRef uRef LRef^2) on the energy residual, ramped by ordersConverged between
+ * relaxStart and relaxEnd.  Once regions are registered every level-1 residual evaluation of the library includes
+ * them where the reference calls sourceTerms (smoothers.F90:74,409, multiGrid.F90:52,887,949, blockette.F90:278);
+ * the body of the host's `sourceTerms` shell becomes a no-op like `initres`.  block(:) = local block nn of each cell
+ * (what blkPtr encodes), cellIDs (3,nCellIDs) column-major.  nRegions = 0 removes them. */
+typedef struct adflow_actuator_region {
+    int32_t nCellIDs, reserved;
+    const int32_t *block, *cellIDs;
+    double force[3], heat, volume, relaxStart, relaxEnd;
+} adflow_actuator_region;
+int adflow_gpu_actuator_register(int nRegions, const adflow_actuator_region* regions);
 /* sum over owned cells of (dw(:,l)/vol)^2, l=1..n  (solvers.F90:1538) */
 int adflow_gpu_res_norms(int level, double* sums, int n);
 

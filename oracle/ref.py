@@ -80,7 +80,8 @@ def set_params(prm) -> None:
                  ("wallFunctions", 0), ("useDissContinuation", 0), ("nTimeIntervalsSpectral", 1),
                  ("vortexCorr", 0), ("riemann", 1), ("riemannCoarse", 1), ("turbTreatment", 1)):
         lib.ref_set_int(n.encode(), v)
-    for n, v in (("totalR", 0.0), ("totalR0", 0.0), ("pRef", prm.pInfDim), ("rhoRef", prm.rhoInfDim)):
+    for n, v in (("totalR", 0.0), ("totalR0", 0.0), ("pRef", prm.pInfDim), ("rhoRef", prm.rhoInfDim), ("uRef", prm.uRef),
+                 ("LRef", prm.LRef), ("ordersConverged", prm.ordersConverged)):
         lib.ref_set_real(n.encode(), v)
     for n in ("etaRK", "cdisRK"):
         v = np.ascontiguousarray(getattr(prm, n), dtype=np.float64)
@@ -269,6 +270,22 @@ def set_internal_comm(level: int, nLayers: int, cp) -> None:
             np.ascontiguousarray(cp.haloBlock, np.int32), np.asfortranarray(cp.haloIndices, np.int32)]
     _keep.append(arrs)
     load().ref_set_internal_comm(level, nLayers, cp.ncopy, *[a.ctypes.data for a in arrs])
+
+
+def set_actuator_regions(regions) -> None:
+    """actuatorRegions(:) of the single bound block from Engine.actuator_register's list of dicts"""
+    lib = load()
+    lib.ref_set_actuator.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_double] * 4
+    if not regions:
+        z = np.zeros(3)
+        zi = np.zeros(3, np.int32)
+        lib.ref_set_actuator(1, 0, 0, zi.ctypes.data, z.ctypes.data, 0.0, 1.0, -1.0, -1.0)
+        return
+    for m, r in enumerate(regions, start=1):
+        ids = np.asfortranarray(r["cellIDs"], np.int32)
+        f = np.ascontiguousarray(r["force"], dtype=np.float64)
+        lib.ref_set_actuator(m, len(regions), int(ids.shape[1]), ids.ctypes.data, f.ctypes.data, float(r["heat"]), float(r["volume"]),
+                             float(r.get("relaxStart", -1.0)), float(r.get("relaxEnd", -1.0)))
 
 
 def set_periodic(level: int, nLayers: int, periodic) -> None:

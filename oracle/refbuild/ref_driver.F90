@@ -363,6 +363,9 @@ contains
         case ('muRef'); muRef = v
         case ('TRef'); TRef = v
         case ('pRef'); pRef = v
+        case ('uRef'); uRef = v
+        case ('LRef'); LRef = v
+        case ('ordersConverged'); ordersConverged = v
         case ('rhoRef'); rhoRef = v
         case ('timeRef'); timeRef = v
         case ('prandtl'); prandtl = v
@@ -539,6 +542,26 @@ contains
         cgnsDoms(1)%rotRate = rotRate; cgnsDoms(1)%rotCenter = zero; cgnsDoms(1)%rotatingFrameSpecified = (isMoving /= 0)
     end subroutine ref_set_moving
 
+    ! actuatorRegions(iRegion) for the single bound block (blkPtr(0:1) = 0, n)
+    subroutine ref_set_actuator(iRegion, nRegions, n, cellIDs, force, heat, volume, relaxStart, relaxEnd) &
+        bind(C, name="ref_set_actuator")
+        use actuatorRegionData
+        integer(c_int), value :: iRegion, nRegions, n
+        integer(c_int), intent(in) :: cellIDs(3, n)
+        real(c_double), intent(in) :: force(3)
+        real(c_double), value :: heat, volume, relaxStart, relaxEnd
+        nActuatorRegions = nRegions
+        if (nRegions == 0) return
+        associate (r => actuatorRegions(iRegion))
+            r%nCellIDs = n
+            allocate (r%cellIDs(3, max(n, 1)))
+            r%cellIDs(:, 1:n) = cellIDs
+            if (allocated(r%blkPtr)) deallocate (r%blkPtr)
+            allocate (r%blkPtr(0:1)); r%blkPtr(0) = 0; r%blkPtr(1) = n
+            r%force = force; r%heat = heat; r%volume = volume; r%relaxStart = relaxStart; r%relaxEnd = relaxEnd
+        end associate
+    end subroutine ref_set_actuator
+
     subroutine ref_set_sym_norm(mm, v) bind(C, name="ref_set_sym_norm")
         use blockPointers
         integer(c_int), value :: mm
@@ -604,7 +627,7 @@ contains
         use flowVarRefState, only: nw, nwf, nt1, nt2
         use solverUtils, only: timeStep_block
         use fluxes
-        use residuals, only: residual_block, initres_block, computedwDADI, residualAveraging
+        use residuals, only: residual_block, initres_block, computedwDADI, residualAveraging, sourceTerms_block
         use flowUtils, only: computeSpeedOfSoundSquared, allNodalGradients, computeEtotBlock, &
                              computePressureSimple, computeLamViscosity
         use turbUtils, only: computeEddyViscosity
@@ -615,6 +638,7 @@ contains
         character(kind=c_char), dimension(*), intent(in) :: name
         integer(c_int), value :: iarg
         character(len=64) :: n
+        real(kind=realType) :: dummyReal
         n = cstr(name)
         select case (trim(n))
         case ('timeStep_block'); call timeStep_block(iarg /= 0)          ! solverUtils.F90:43
@@ -643,6 +667,7 @@ contains
         case ('metric_block'); call metric_block
         case ('boundaryNormals'); call boundaryNormals                      ! adjointExtra.F90:270
         case ('xhalo_block'); call xhalo_block                              ! adjointExtra.F90:365
+        case ('sourceTerms_block'); call sourceTerms_block(1_intType, .true., int(iarg, intType), dummyReal)   ! residuals.F90:348
         case ('applyAllBC_block'); call applyAllBC_block(iarg /= 0)         ! BCRoutines.F90:57
         case ('bcTurbTreatment'); call bcTurbTreatment                       ! turbBCRoutines.F90:662
         case ('applyAllTurbBCThisBlock'); call applyAllTurbBCThisBlock(iarg /= 0)   ! turbBCRoutines.F90:49

@@ -332,6 +332,54 @@ def check_xhalo_symmetry(engine, dims, prm, spec, split=(), seed=85, **mk):
     _assert_geometry(engine, {1: blk}, {1: r}, f"xhalo with symmetry planes {spec}", names=("x",))
 
 
+def check_actuator_regions(engine, dims, prm, seed=93, **mk):
+    """sourceTerms_block (residuals.F90:348-425): body force + heat source of actuator regions in `residual`
+    (initres; sourceTerms; residual, smoothers.F90:72-75) and after the core of blocketteRes (blockette.F90:276-281),
+    with the relaxation ramp between relaxStart and relaxEnd."""
+    from oracle import ref
+    new_level(engine)
+    prm = prm.replace(currentLevel=1, groundLevel=1, ordersConverged=2.5)
+    blk = make_block(*dims, prm, seed=seed, **mk)
+    rng = np.random.default_rng(seed)
+    regions = []
+    for m in range(2):
+        n = 7 + 5 * m
+        ids = np.asfortranarray(np.stack([rng.integers(2, blk.il + 1, n), rng.integers(2, blk.jl + 1, n),
+                                          rng.integers(2, blk.kl + 1, n)]).astype(np.int32))
+        ids = np.asfortranarray(np.unique(ids, axis=1))          # a cell appears once per region
+        regions.append(dict(block=np.ones(ids.shape[1], np.int32), cellIDs=ids, force=prm.pInfDim * rng.uniform(-1, 1, 3),
+                            heat=prm.pInfDim * prm.uRef * 0.3, volume=float(blk["vol"][2:-2, 2:-2, 2:-2].sum() * 0.1),
+                            relaxStart=(2.0 if m else -1.0), relaxEnd=(3.0 if m else -1.0)))
+    r = blk.copy()
+    ref.bind_block(r, prm)
+    ref.set_actuator_regions(regions)
+    engine.set_options(prm)
+    engine.register(blk, nn=1, level=1)
+    engine.actuator_register(regions)
+    try:
+        # residual path
+        ref.load().ref_set_int(b"rkStage", 0)
+        ref.call("timeStep_block", 0)
+        ref.call("initres_flow")
+        base = r["dw"].copy()
+        for m in (1, 2):
+            ref.call("sourceTerms_block", m)
+        assert np.abs(r["dw"] - base).max() > 0
+        ref.call("residual_block")
+        engine.timeStep(1, False)
+        engine.residual(1, 0)
+        assert_dw(blk, engine.download_residual(1, 1), r["dw"], 5, what="residual with actuator sources")
+        # blocketteRes path: core, then the sources
+        ref.block_res_core(True, True, prm.equations == RANSEquations)
+        for m in (1, 2):
+            ref.call("sourceTerms_block", m)
+        engine.blocketteRes(1, True, True, prm.equations == RANSEquations)
+        assert_dw(blk, engine.download_residual(1, 1), r["dw"], blk.nw, what="blocketteRes with actuator sources")
+    finally:
+        engine.actuator_register([])
+        ref.set_actuator_regions([])
+
+
 def check_wall_stress(engine, dims, prm, spec, split=(), seed=57, dadi=False, **mk):
     """viscSubface(:)%tau / %q: the wall stress tensor and heat flux viscousFlux stores for the viscous subfaces when
     rkStage == 0 on the ground level (fluxes.F90:2586-2592, 2861-2892 k, 3155-3185 j, 3450-3480 i)."""

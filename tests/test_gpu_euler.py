@@ -82,3 +82,11 @@ def test_moving_blocks(engine):
     checks.check_sa_solve(engine, BrickTopology(1, 1, 2, 12, 8, 8), FlowParams(equations=RANSEquations, nSubIterTurb=2),
                           stretch_k=2.0, **mv)
     checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 16, 8, 8), FlowParams(), [0, 1, 0, -1], ncycles=1, **mv)
+
+
+def test_actuator_regions(engine):
+    """a8: actuator-zone source terms in `residual` and after the blocketteRes core"""
+    from adflow_amd.params import RANSEquations
+    checks.check_actuator_regions(engine, (70, 9, 8), FlowParams())
+    checks.check_actuator_regions(engine, (24, 10, 8), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+    checks.check_actuator_regions(engine, (20, 10, 8), FlowParams(), holes=0.1)

@@ -286,6 +286,13 @@ def test_periodic_halos(hostsim_engine):
     checks.check_periodic_halos(hostsim_engine, BrickTopology(1, 2, 1, 4, 4, 2), FlowParams(equations=RANSEquations), stretch_k=2.0)
 
 
+def test_actuator_regions(hostsim_engine):
+    """a8: actuator-zone source terms in `residual` and after the blocketteRes core"""
+    checks.check_actuator_regions(hostsim_engine, (8, 6, 5), FlowParams())
+    checks.check_actuator_regions(hostsim_engine, (7, 6, 5), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+    checks.check_actuator_regions(hostsim_engine, (7, 6, 5), FlowParams(), holes=0.1)
+
+
 def test_multiblock_bc(hostsim_engine):
     """several blocks with different subface lists: the level-batched BC launches against the reference's block loop"""
     checks.check_multiblock_bc(hostsim_engine, FlowParams(), {
