@@ -60,6 +60,7 @@ struct Block {
     bool ss_valid = false;    // entropy sensor variable matches the current state
     bool etot_consistent = false;   // owned-cell rhoE already equals computeEtotBlock(p, rho, v)
     std::vector<BcFaceDev> bc;      // boundary subfaces (device BCData), first nViscBocos = viscous walls
+    std::vector<void*> bc_allocs;   // device copies of the BCData members: replaced at every bc_register
     int nViscBocos = 0;
 };
 
@@ -335,6 +336,7 @@ int adflow_gpu_finalize(void)
 {
     for (auto& kv : g_blocks) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
+        for (void* p : kv.second->bc_allocs) (void)hipFree(p);
         delete kv.second;
     }
     g_blocks.clear();
@@ -481,6 +483,7 @@ int adflow_gpu_block_release(int nn, int level, int sps)
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     bc_plan_drop(level);
     for (void* p : it->second->allocs) (void)hipFree(p);
+    for (void* p : it->second->bc_allocs) (void)hipFree(p);
     delete it->second;
     g_blocks.erase(it);
     invalidate_comm_level(level);
@@ -493,6 +496,7 @@ int adflow_gpu_release_all(void)
     bc_plan_drop_all();
     for (auto& kv : g_blocks) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
+        for (void* p : kv.second->bc_allocs) (void)hipFree(p);
         delete kv.second;
     }
     g_blocks.clear();
@@ -1177,6 +1181,8 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
     if (nBocos > 0 && !faces) return fail("bc_register: null subface list");
     const BlkView& v = b->v;
     std::vector<BcFaceDev> out;
+    std::vector<void*> fresh;       // device arrays of this registration
+    auto drop_fresh = [&]() { for (void* q : fresh) (void)hipFree(q); };
     for (int m = 0; m < nBocos; ++m) {
         const adflow_bc_subface& f = faces[m];
         switch (f.bcType) {
@@ -1185,37 +1191,37 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
         case ADFLOW_BC_SYMM_POLAR: case ADFLOW_BC_SUBSONIC_INFLOW: case ADFLOW_BC_SUBSONIC_OUTFLOW: case ADFLOW_BC_MASSBLEED_OUTFLOW:
             break;
         default:
-            return fail("bc_register: block %d subface %d: BCType %d is not implemented on the device "
+            return drop_fresh(), fail("bc_register: block %d subface %d: BCType %d is not implemented on the device "
                         "(inflow bleeds, mDot / thrust, domain and sliding interfaces stay with the host callback)", nn, m + 1, f.bcType);
         }
-        if (f.faceID < ADFLOW_IMIN || f.faceID > ADFLOW_KMAX) return fail("bc_register: block %d subface %d: BCFaceID %d", nn, m + 1, f.faceID);
+        if (f.faceID < ADFLOW_IMIN || f.faceID > ADFLOW_KMAX) return drop_fresh(), fail("bc_register: block %d subface %d: BCFaceID %d", nn, m + 1, f.faceID);
         // generic subface indices run over the two in-plane directions of the block face (utils.F90:881-1175)
         const int amax = (f.faceID <= ADFLOW_IMAX) ? v.jb : v.ib;
         const int bmax = (f.faceID <= ADFLOW_JMAX) ? v.kb : v.jb;
         if (f.icBeg < 0 || f.icEnd > amax || f.jcBeg < 0 || f.jcEnd > bmax || f.icEnd < f.icBeg || f.jcEnd < f.jcBeg)
-            return fail("bc_register: block %d subface %d: cell range %d:%d x %d:%d outside the block face", nn, m + 1, f.icBeg,
+            return drop_fresh(), fail("bc_register: block %d subface %d: cell range %d:%d x %d:%d outside the block face", nn, m + 1, f.icBeg,
                         f.icEnd, f.jcBeg, f.jcEnd);
         const bool subOut = (f.bcType == ADFLOW_BC_SUBSONIC_OUTFLOW || f.bcType == ADFLOW_BC_MASSBLEED_OUTFLOW);
         const bool subIn = (f.bcType == ADFLOW_BC_SUBSONIC_INFLOW);
         const bool needNorm = (f.bcType == ADFLOW_BC_SYMM || f.bcType == ADFLOW_BC_EULERWALL || f.bcType == ADFLOW_BC_FARFIELD || subOut || subIn);
-        if (subOut && !f.ps) return fail("bc_register: block %d subface %d: BCData%%ps is required", nn, m + 1);
+        if (subOut && !f.ps) return drop_fresh(), fail("bc_register: block %d subface %d: BCData%%ps is required", nn, m + 1);
         if (subIn) {
             if (f.subsonicInletTreatment == ADFLOW_INLET_TOTAL_CONDITIONS) {
                 if (!(f.ptInlet && f.ttInlet && f.htInlet && f.flowXdirInlet && f.flowYdirInlet && f.flowZdirInlet))
-                    return fail("bc_register: block %d subface %d: ptInlet, ttInlet, htInlet, flow[XYZ]dirInlet are required", nn, m + 1);
+                    return drop_fresh(), fail("bc_register: block %d subface %d: ptInlet, ttInlet, htInlet, flow[XYZ]dirInlet are required", nn, m + 1);
             } else if (f.subsonicInletTreatment == ADFLOW_INLET_MASS_FLOW) {
-                if (!(f.rho && f.velx && f.vely && f.velz)) return fail("bc_register: block %d subface %d: rho, velx, vely, velz are required", nn, m + 1);
+                if (!(f.rho && f.velx && f.vely && f.velz)) return drop_fresh(), fail("bc_register: block %d subface %d: rho, velx, vely, velz are required", nn, m + 1);
             } else
-                return fail("bc_register: block %d subface %d: subsonicInletTreatment=%d (1 total conditions, 2 mass flow)", nn, m + 1,
+                return drop_fresh(), fail("bc_register: block %d subface %d: subsonicInletTreatment=%d (1 total conditions, 2 mass flow)", nn, m + 1,
                             f.subsonicInletTreatment);
         }
-        if (f.bcType == ADFLOW_BC_SYMM_POLAR && !v.x) return fail("bc_register: block %d subface %d: symmPolar needs the node coordinates x", nn, m + 1);
+        if (f.bcType == ADFLOW_BC_SYMM_POLAR && !v.x) return drop_fresh(), fail("bc_register: block %d subface %d: symmPolar needs the node coordinates x", nn, m + 1);
         if ((subIn || f.bcType == ADFLOW_BC_SUPERSONIC_INFLOW) && v.nw > 5 && !f.turbInlet)
-            return fail("bc_register: block %d subface %d: BCData%%turbInlet is required for an inflow subface of a RANS block", nn, m + 1);
-        if (needNorm && !f.norm) return fail("bc_register: block %d subface %d: BCData%%norm is required", nn, m + 1);
-        if (f.bcType == ADFLOW_BC_NSWALL_ISOTHERMAL && !f.TNS_Wall) return fail("bc_register: block %d subface %d: TNS_Wall is required", nn, m + 1);
+            return drop_fresh(), fail("bc_register: block %d subface %d: BCData%%turbInlet is required for an inflow subface of a RANS block", nn, m + 1);
+        if (needNorm && !f.norm) return drop_fresh(), fail("bc_register: block %d subface %d: BCData%%norm is required", nn, m + 1);
+        if (f.bcType == ADFLOW_BC_NSWALL_ISOTHERMAL && !f.TNS_Wall) return drop_fresh(), fail("bc_register: block %d subface %d: TNS_Wall is required", nn, m + 1);
         if (f.bcType == ADFLOW_BC_SUPERSONIC_INFLOW && !(f.rho && f.velx && f.vely && f.velz && f.ps))
-            return fail("bc_register: block %d subface %d: rho, velx, vely, velz, ps are required", nn, m + 1);
+            return drop_fresh(), fail("bc_register: block %d subface %d: rho, velx, vely, velz, ps are required", nn, m + 1);
         const size_t n = (size_t)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
         auto up = [&](const double* h, int nc, const double** dev) -> int {
             *dev = nullptr;
@@ -1223,7 +1229,7 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
             void* raw = nullptr;
             HIPCHK(hipMalloc(&raw, sizeof(double) * n * nc));
             HIPCHK(hipMemcpy(raw, h, sizeof(double) * n * nc, hipMemcpyHostToDevice));
-            b->allocs.push_back(raw);
+            fresh.push_back(raw);
             *dev = (const double*)raw;
             return 0;
         };
@@ -1245,15 +1251,19 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
                 void* raw = nullptr;
                 HIPCHK(hipMalloc(&raw, sizeof(double) * 9 * no));
                 HIPCHK(hipMemsetAsync(raw, 0, sizeof(double) * 9 * no, g_stream));
-                b->allocs.push_back(raw);
+                fresh.push_back(raw);
                 d.tauq = (double*)raw;
             }
         }
         out.push_back(d);
     }
+    // the previous registration's device data is no longer referenced once the plan is dropped
+    bc_plan_drop(level);
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (void* q : b->bc_allocs) (void)hipFree(q);
+    b->bc_allocs = fresh;
     b->bc = out;
     b->nViscBocos = nViscBocos;
-    bc_plan_drop(level);
     if (v.nw > 5 && !v.bmt[0]) {
         // face arrays of the implicit turbulence boundary treatment (bmt/bvt of blockPointers, one turbulence variable)
         const size_t nf[3] = {(size_t)v.je * v.ke, (size_t)v.ie * v.ke, (size_t)v.ie * v.je};
