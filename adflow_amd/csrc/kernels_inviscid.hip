@@ -154,19 +154,19 @@ __device__ __forceinline__ void jst_matrix_face(const Line& L, const double gam[
 
     const double gammaAvg = 0.5 * (gam[r] + gam[l]);
     const double gm1 = gammaAvg - 1.0;
-    const double ovgm1 = 1.0 / gm1;
+    const double ovgm1 = fastdiv(1.0, gm1);
     const double uAvg = 0.5 * (L.u[r] + L.u[l]);
     const double vAvg = 0.5 * (L.v[r] + L.v[l]);
     const double wAvg = 0.5 * (L.w[r] + L.w[l]);
-    const double a2Avg = 0.5 * (gam[r] * L.p[r] / L.rho[r] + gam[l] * L.p[l] / L.rho[l]);
+    const double a2Avg = 0.5 * (fastdiv(gam[r] * L.p[r], L.rho[r]) + fastdiv(gam[l] * L.p[l], L.rho[l]));
     const double area = sqrt(nx * nx + ny * ny + nz * nz);
-    const double tmp = 1.0 / fmax(1.e-25, area);
+    const double tmp = fastdiv(1.0, fmax(1.e-25, area));
     const double sx = nx * tmp, sy = ny * tmp, sz = nz * tmp;
     const double alphaAvg = 0.5 * (uAvg * uAvg + vAvg * vAvg + wAvg * wAvg);
     const double hAvg = alphaAvg + ovgm1 * a2Avg;
     const double aAvg = sqrt(a2Avg);
     const double unAvg = uAvg * sx + vAvg * sy + wAvg * sz;
-    const double ovaAvg = 1.0 / aAvg, ova2Avg = 1.0 / a2Avg;
+    const double ovaAvg = fastdiv(1.0, aAvg), ova2Avg = fastdiv(1.0, a2Avg);
     const double sface = sFace * tmp;         // fluxes.F90:616
     double lam1 = fabs(unAvg - sface + aAvg), lam2 = fabs(unAvg - sface - aAvg), lam3 = fabs(unAvg - sface);
     const double rrad = lam3 + aAvg;
@@ -190,21 +190,23 @@ __device__ __forceinline__ void muscl(int lim, double omk, double opk, double fa
         return;
     }
     const double epsLim = 1.e-10;
-    const double tmp = 1.0 / copysign(fmax(fabs(du2), epsLim), du2);
-    double rl1 = fmax(0.0, du2 / copysign(fmax(fabs(du1), epsLim), du1));
-    double rl2 = fmax(0.0, du1 * tmp);
-    double rr1 = fmax(0.0, du3 * tmp);
-    double rr2 = fmax(0.0, du2 / copysign(fmax(fabs(du3), epsLim), du3));
+    // clamped denominators of the four slope ratios r = a / b (fluxes.F90:2167-2190)
+    const double d1 = copysign(fmax(fabs(du1), epsLim), du1), d2 = copysign(fmax(fabs(du2), epsLim), du2),
+                 d3 = copysign(fmax(fabs(du3), epsLim), du3);
+    double rl1, rl2, rr1, rr2;
     if (lim == ADFLOW_LIM_VANALBADA) {
-        rl1 = rl1 * (rl1 + 1.0) / (rl1 * rl1 + 1.0);
-        rl2 = rl2 * (rl2 + 1.0) / (rl2 * rl2 + 1.0);
-        rr1 = rr1 * (rr1 + 1.0) / (rr1 * rr1 + 1.0);
-        rr2 = rr2 * (rr2 + 1.0) / (rr2 * rr2 + 1.0);
+        // r (r + 1) / (r^2 + 1) with r = max(0, a / b) is a (a + b) / (a^2 + b^2) for a b > 0 and 0 otherwise: one
+        // division per ratio instead of two (the kernel is bound by FP64 divisions)
+        auto phi = [](double a, double b) { return (a * b > 0.0) ? fastdiv(a * (a + b), a * a + b * b) : 0.0; };
+        rl1 = phi(du2, d1);
+        rl2 = phi(du1, d2);
+        rr1 = phi(du3, d2);
+        rr2 = phi(du2, d3);
     } else {   // minmod
-        rl1 = fmin(1.0, factMinmod * rl1);
-        rl2 = fmin(1.0, factMinmod * rl2);
-        rr1 = fmin(1.0, factMinmod * rr1);
-        rr2 = fmin(1.0, factMinmod * rr2);
+        rl1 = fmin(1.0, factMinmod * fmax(0.0, fastdiv(du2, d1)));
+        rl2 = fmin(1.0, factMinmod * fmax(0.0, fastdiv(du1, d2)));
+        rr1 = fmin(1.0, factMinmod * fmax(0.0, fastdiv(du3, d2)));
+        rr2 = fmin(1.0, factMinmod * fmax(0.0, fastdiv(du2, d3)));
     }
     left = omk * rl1 * du1 + opk * rl2 * du2;
     right = -opk * rr1 * du2 - omk * rr2 * du3;
@@ -242,10 +244,10 @@ __device__ __forceinline__ void roe_face(const Line& L, const double gam[5], int
     const double gammaFace = 0.5 * (gam[l] + gam[r]);
     const double gm1 = gammaFace - 1.0;
     const double z1l = sqrt(left[0]), z1r = sqrt(right[0]);
-    double tmp = 1.0 / (z1l + z1r);
-    const double ovgm1 = 1.0 / (gammaConstant - 1.0);   // flowUtils::etot/eint, cpConstant
-    const double Etl = left[0] * (ovgm1 * left[4] / left[0] + 0.5 * (left[1] * left[1] + left[2] * left[2] + left[3] * left[3]));
-    const double Etr = right[0] * (ovgm1 * right[4] / right[0] + 0.5 * (right[1] * right[1] + right[2] * right[2] + right[3] * right[3]));
+    double tmp = fastdiv(1.0, z1l + z1r);
+    const double ovgm1 = 1.0 / (gammaConstant - 1.0);   // flowUtils::etot/eint, cpConstant (uniform: scalar unit)
+    const double Etl = left[0] * (fastdiv(ovgm1 * left[4], left[0]) + 0.5 * (left[1] * left[1] + left[2] * left[2] + left[3] * left[3]));
+    const double Etr = right[0] * (fastdiv(ovgm1 * right[4], right[0]) + 0.5 * (right[1] * right[1] + right[2] * right[2] + right[3] * right[3]));
     const double dr = right[0] - left[0];
     const double dru = right[0] * right[1] - left[0] * left[1];
     const double drv = right[0] * right[2] - left[0] * left[2];
@@ -254,24 +256,24 @@ __device__ __forceinline__ void roe_face(const Line& L, const double gam[5], int
     const double uAvg = tmp * (z1l * left[1] + z1r * right[1]);
     const double vAvg = tmp * (z1l * left[2] + z1r * right[2]);
     const double wAvg = tmp * (z1l * left[3] + z1r * right[3]);
-    const double hAvg = tmp * ((Etl + left[4]) / z1l + (Etr + right[4]) / z1r);
+    const double hAvg = tmp * (fastdiv(Etl + left[4], z1l) + fastdiv(Etr + right[4], z1r));
     const double area = sqrt(nx * nx + ny * ny + nz * nz);
-    tmp = 1.0 / fmax(1.e-25, area);
+    tmp = fastdiv(1.0, fmax(1.e-25, area));
     const double sx = nx * tmp, sy = ny * tmp, sz = nz * tmp;
     const double alphaAvg = 0.5 * (uAvg * uAvg + vAvg * vAvg + wAvg * wAvg);
     const double a2Avg = fabs(gm1 * (hAvg - alphaAvg));
     const double aAvg = sqrt(a2Avg);
     double unAvg = uAvg * sx + vAvg * sy + wAvg * sz;
-    const double ovaAvg = 1.0 / aAvg, ova2Avg = 1.0 / a2Avg;
+    const double ovaAvg = fastdiv(1.0, aAvg), ova2Avg = fastdiv(1.0, a2Avg);
     const double rFace = sFace * tmp;          // fluxes.F90:2420
     if (por == ADF_POR_BOUND) unAvg = rFace;
     const double eta = 0.5 * (fabs((left[1] - right[1]) * sx + (left[2] - right[2]) * sy + (left[3] - right[3]) * sz) +
-                              fabs(sqrt(gammaFace * left[4] / left[0]) - sqrt(gammaFace * right[4] / right[0])));
+                              fabs(sqrt(fastdiv(gammaFace * left[4], left[0])) - sqrt(fastdiv(gammaFace * right[4], right[0]))));
     double lam1 = fabs(unAvg - rFace + aAvg), lam2 = fabs(unAvg - rFace - aAvg), lam3 = fabs(unAvg - rFace);
     tmp = 2.0 * eta;
-    if (lam1 < tmp) lam1 = eta + 0.25 * lam1 * lam1 / eta;
-    if (lam2 < tmp) lam2 = eta + 0.25 * lam2 * lam2 / eta;
-    if (lam3 < tmp) lam3 = eta + 0.25 * lam3 * lam3 / eta;
+    if (lam1 < tmp) lam1 = eta + fastdiv(0.25 * lam1 * lam1, eta);
+    if (lam2 < tmp) lam2 = eta + fastdiv(0.25 * lam2 * lam2, eta);
+    if (lam3 < tmp) lam3 = eta + fastdiv(0.25 * lam3 * lam3, eta);
     lam1 *= area; lam2 *= area; lam3 *= area;
     double f[5];
     absA_times_dw(lam1, lam2, lam3, gm1, alphaAvg, uAvg, vAvg, wAvg, hAvg, unAvg, ovaAvg, ova2Avg, sx, sy, sz, dr, dru,
@@ -360,7 +362,7 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
 // FINAL: dw = (init + central + fw) * iblank written; otherwise dw = init + central
 // and fw stored for the viscous kernel to complete.
 template <int SCHEME, bool VISC, bool FINAL>
-__global__ __launch_bounds__(IV_BX* IV_BY) void k_inviscid(const BlkView* __restrict__ tab, int nzb, KParams kp)
+__global__ __launch_bounds__(IV_BX* IV_BY, (SCHEME == ADFLOW_UPWIND ? 2 : 1)) void k_inviscid(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
     // level-batched: blockIdx.z = block slot * nzb + plane
     const BlkView& b = tab[blockIdx.z / nzb + 1];
