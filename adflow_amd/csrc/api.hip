@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march;
 
 namespace {
 
@@ -772,7 +772,13 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox)
     // inviscid part: one launch for every block of the level (blocks are independent given their halos)
     LevelTab t;
     if (level_tab(level, &t)) return 1;
-    launch_inviscid_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    if (inviscid_march_enabled() && kp.spaceDiscr != ADFLOW_DISS_SCALAR && !kp.dissApprox && !anyMoving) {
+        // matrix dissipation / Roe upwind: k-marching kernel over the level's tile table (every face once in k and i)
+        if (ensure_tiles(level)) return 1;
+        launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
+    } else {
+        launch_inviscid_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    }
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
     const bool batched = !viscApprox && viscous_is_tiled();
     rc = for_level(level, [&](Block* b) {
@@ -2208,6 +2214,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         return 0;
     }
     if (!strcmp(key, "viscous_tiled")) { g_viscous_tiled = value; return 0; }
+    if (!strcmp(key, "inviscid_march")) { g_inviscid_march = value; return 0; }
     if (!strcmp(key, "lines_i_tiled")) { g_lines_i_tiled = value; return 0; }
     if (!strcmp(key, "march_kch")) {
         if (value < 4) return fail("march_kch must be >= 4");

@@ -207,6 +207,8 @@ void launch_periodic(const BlkView* tab, const int* blk, const long* off, int n,
 void launch_halo_pack(const BlkView* tab, const int* blk, const long* off, int n, unsigned mask, double* buf, hipStream_t s);
 void launch_halo_unpack(const BlkView* tab, const int* blk, const long* off, int n, unsigned mask, const double* buf,
                         hipStream_t s);
+void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+int inviscid_march_enabled();
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
 void launch_restrict_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

@@ -1,0 +1,249 @@
+// k-marching inviscid residual for MATRIX dissipation and ROE UPWIND (Euler, laminar, RANS; fine and coarse levels).
+//
+// The cell-gather kernel (kernels_inviscid.hip) evaluates the six faces of every cell, i.e. every face twice.  These
+// two schemes are bound by FP64 arithmetic (eigenvalue scaling, MUSCL limiter: ~300 divisions per cell in the gather
+// form), so the gather form pays twice.  Here the march of the Euler / scalar-JST kernel (kernels_euler_march.hip) is
+// reused:
+//   * a workgroup is 64 lanes (i) x 4 rows (j); every thread marches along k with a 4-cell register window, so a
+//     k-face is evaluated once and closes the cell below / opens the cell above;
+//   * a 64-lane wavefront covers the columns i0-2 .. i0+61 and produces 60 of them: the lane evaluates the face
+//     (i-1 | i) from its neighbours' state (DPP lane shifts) and hands the flux of (i | i+1) over from lane+1, so an
+//     i-face is evaluated once;
+//   * both j-faces of a cell are evaluated by the cell (rows are different waves).
+// Four face evaluations per cell instead of six, and ~45 instead of ~100 loads per cell.  The face functions are the
+// ones of the gather kernel (flux_faces.h): same arithmetic, same order inside a face.
+//
+// gamma: the reference reads gamma(i,j,k); with the calorically perfect gas (cpConstant, the only cp model of the
+// path) that array holds gammaConstant everywhere, which is what the faces use here.
+//
+// Reference semantics: fluxes.F90:4-401 (central), :403-1047 (matrix), :1438-2532 (upwind), :5205-5430 (matrix,
+// coarse levels), residuals.F90:334-344 (final sum).  Roofline: FP64 VALU for upwind, HBM for matrix.
+#include "flux_faces.h"
+
+#define IM_OUT 60          // must match EM_OUT / EM_BY of kernels_euler_march.hip: the tile table is shared
+#define IM_BY 4
+
+struct MCell { double rho, u, v, w, e, p; };
+
+struct ImPtrs {
+    GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) w4;
+    GPTR(const double) p;
+};
+
+__device__ __forceinline__ MCell im_ld(const ImPtrs& m, unsigned o)
+{
+    MCell q;
+    q.rho = ldg(m.w0, o); q.u = ldg(m.w1, o); q.v = ldg(m.w2, o); q.w = ldg(m.w3, o); q.e = ldg(m.w4, o);
+    q.p = ldg(m.p, o);
+    return q;
+}
+
+__device__ __forceinline__ MCell im_up1(const MCell& q)
+{
+    MCell r;
+    r.rho = lane_up1(q.rho); r.u = lane_up1(q.u); r.v = lane_up1(q.v); r.w = lane_up1(q.w); r.e = lane_up1(q.e); r.p = lane_up1(q.p);
+    return r;
+}
+
+__device__ __forceinline__ MCell im_dn1(const MCell& q)
+{
+    MCell r;
+    r.rho = lane_dn1(q.rho); r.u = lane_dn1(q.u); r.v = lane_dn1(q.v); r.w = lane_dn1(q.w); r.e = lane_dn1(q.e); r.p = lane_dn1(q.p);
+    return r;
+}
+
+// the four cells around a face as positions 0..3 of a Line; the face is between positions 1 and 2
+__device__ __forceinline__ void im_line(const MCell& a, const MCell& b, const MCell& c, const MCell& d, Line& L)
+{
+    const MCell* q[4] = {&a, &b, &c, &d};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        L.rho[m] = q[m]->rho; L.u[m] = q[m]->u; L.v[m] = q[m]->v; L.w[m] = q[m]->w; L.e[m] = q[m]->e; L.p[m] = q[m]->p;
+    }
+    L.rho[4] = L.u[4] = L.v[4] = L.w[4] = L.e[4] = L.p[4] = 0.0;
+}
+
+struct ImFace {          // scalars of the dissipation shared by all faces of a launch
+    double fis2, fis4, plim, gam;
+    int lim, coarse, doDiss;
+    double kappaCoef, rFil, gammaConstant;
+};
+
+// fluxes through the face between b and c (stencil a b | c d) with normal (sx,sy,sz): central fc (dw(b) += fc,
+// dw(c) -= fc) and dissipation fd in the convention fw(c) += fd, fw(b) -= fd.  dssB / dssC: matrix sensors of b and c.
+template <int SCHEME>
+__device__ __forceinline__ void im_face(const ImFace& F, const MCell& a, const MCell& b, const MCell& c, const MCell& d, double sx,
+                                        double sy, double sz, int por, double dssB, double dssC, double fc[5], double fd[5])
+{
+    Line L;
+    im_line(a, b, c, d, L);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) { fc[m] = 0.0; fd[m] = 0.0; }
+    central_face(L, 1, sx, sy, sz, por, +1.0, fc);
+    if (!F.doDiss) return;
+    const double gam[5] = {F.gam, F.gam, F.gam, F.gam, F.gam};
+    if (SCHEME == ADFLOW_DISS_MATRIX) {
+        if (F.coarse) jst_matrix_face(L, gam, 1, sx, sy, sz, por, 0.0, 0.0, F.fis2, 0.0, +1.0, fd, true);
+        else jst_matrix_face(L, gam, 1, sx, sy, sz, por, dssB, dssC, F.fis2, F.fis4, +1.0, fd);
+    } else {
+        // roe_face: fw(left) += flux, fw(right) -= flux with flux = -porFlux |A| dW; sign -1 gives the (right += ) form
+        roe_face(L, gam, 1, sx, sy, sz, por, F.lim, F.kappaCoef, F.rFil, F.gammaConstant, -1.0, fd);
+    }
+}
+
+// FW: persistent dissipation residual of the Runge-Kutta scheme; FINAL: dw = (dw + fw) iblank written here, otherwise dw and
+// fw are left for the viscous kernel to complete (residual_block, residuals.F90:334-344)
+template <int SCHEME, bool FW, bool FINAL>
+__global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
+                                                                  KParams kp, int kch)
+{
+    const int4 t = tiles[blockIdx.x];
+    if (t.x < 0) return;
+    const BlkView& b = tab[t.x];
+    const int lane = threadIdx.x;
+    const int i = t.y * IM_OUT + lane;          // columns i0-2 .. i0+61
+    const int j = 2 + t.z * IM_BY + (int)threadIdx.y;
+    const int k0 = 2 + t.w * kch;
+    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
+    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
+    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jl) ? j : b.jl;
+    const long nb = b.nbox;
+    const unsigned sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
+
+    ImPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w4 = m.w3 + nb;
+    m.p = (GPTR(const double))b.p;
+    GPTR(const double) sIx = (GPTR(const double))b.sI; GPTR(const double) sIy = sIx + nb; GPTR(const double) sIz = sIy + nb;
+    GPTR(const double) sJx = (GPTR(const double))b.sJ; GPTR(const double) sJy = sJx + nb; GPTR(const double) sJz = sJy + nb;
+    GPTR(const double) sKx = (GPTR(const double))b.sK; GPTR(const double) sKy = sKx + nb; GPTR(const double) sKz = sKy + nb;
+    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
+    GPTR(double) dw = (GPTR(double))b.dw;
+    GPTR(double) fw = (GPTR(double))b.fw;
+    GPTR(const double) wr = (GPTR(const double))b.wr;
+
+    ImFace F;
+    F.doDiss = fabs(kp.rFil) >= 1.e-10;
+    F.coarse = !kp.fineGrid;
+    F.fis2 = F.coarse ? kp.rFil * kp.vis2Coarse : kp.rFil * kp.vis2;     // coarse: dis0 of inviscidDissFluxMatrixCoarse
+    F.fis4 = kp.rFil * kp.vis4;
+    F.plim = 0.001 * kp.pInfCorr;
+    F.gam = kp.gammaConstant;
+    F.lim = kp.fineGrid ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;           // fluxes.F90:1531-1538
+    F.kappaCoef = kp.kappaCoef; F.rFil = kp.rFil; F.gammaConstant = kp.gammaConstant;
+    const bool sens = (SCHEME == ADFLOW_DISS_MATRIX) && F.doDiss && !F.coarse;
+
+    // window k-2 .. k+1 of the own column
+    MCell qm2 = im_ld(m, c - 2 * sk), qm1 = im_ld(m, c - sk), q0 = im_ld(m, c);
+    int flagm = flags[(c - sk) >> 3];
+    double dssKm = sens ? mat_sensor(qm2.p, qm1.p, q0.p, F.plim) : 0.0;
+    double accC[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};
+
+    for (int k = k0; k <= k1 + 1; ++k) {
+        const MCell qp1 = im_ld(m, c + sk);
+        const int flag0 = flags[c >> 3];
+        const double dssK0 = sens ? mat_sensor(qm1.p, q0.p, qp1.p, F.plim) : 0.0;
+        // ---- k-face between cells k-1 and k (normal and porosity stored at cell k-1)
+        double fc[5], fd[5];
+        im_face<SCHEME>(F, qm2, qm1, q0, qp1, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), dssKm,
+                        dssK0, fc, fd);
+        // ---- finish cell k-1 and write it
+        if (k > k0 && out) {
+            const unsigned cw = c - sk;
+            const double blank = flg_blank((uint8_t)flagm);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                double fwn = accD[l] - fd[l];
+                if (FW) {
+                    const double old = ldg(fw + l * nb, cw);
+                    fwn = F.doDiss ? (kp.sfil * old + fwn) : old;
+                }
+                double d = accC[l] + fc[l];
+                if (kp.coarseInit) d += ldg(wr + l * nb, cw);
+                if (FINAL) {
+                    if (FW && F.doDiss) stg(fw + l * nb, cw, fwn);
+                    stg(dw + l * nb, cw, (d + fwn) * blank);
+                } else {
+                    stg(fw + l * nb, cw, fwn);
+                    stg(dw + l * nb, cw, d);
+                }
+            }
+        }
+        if (k > k1) break;
+        // ---- start cell k
+#pragma unroll
+        for (int l = 0; l < 5; ++l) { accC[l] = -fc[l]; accD[l] = fd[l]; }
+
+        // ---- i-direction: this lane evaluates the face (i-1 | i); the face (i | i+1) comes from lane+1
+        {
+            const MCell qL = im_up1(q0), qLL = im_up1(qL), qR = im_dn1(q0);
+            const int por = flg_porI((uint8_t)lane_up1(flag0));
+            double d0 = 0.0, dL = 0.0;
+            if (sens) {
+                d0 = mat_sensor(qL.p, q0.p, qR.p, F.plim);
+                dL = lane_up1(d0);
+            }
+            double gc[5], gd[5];
+            im_face<SCHEME>(F, qLL, qL, q0, qR, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, dL, d0, gc, gd);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                accC[l] += lane_dn1(gc[l]) - gc[l];     // + plus face, - minus face
+                accD[l] += gd[l] - lane_dn1(gd[l]);     // minus face adds, plus face subtracts
+            }
+        }
+        // ---- j-direction: both faces of the cell
+        {
+            const MCell qa = im_ld(m, c - 2 * sj), qb = im_ld(m, c - sj), qc = im_ld(m, c + sj), qd = im_ld(m, c + 2 * sj);
+            const int porM = flg_porJ(flags[(c - sj) >> 3]), porP = flg_porJ((uint8_t)flag0);
+            double dm = 0.0, d0 = 0.0, dp = 0.0;
+            if (sens) {
+                dm = mat_sensor(qa.p, qb.p, q0.p, F.plim);
+                d0 = mat_sensor(qb.p, q0.p, qc.p, F.plim);
+                dp = mat_sensor(q0.p, qc.p, qd.p, F.plim);
+            }
+            double hc[5], hd[5];
+            im_face<SCHEME>(F, qa, qb, q0, qc, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, dm, d0, hc, hd);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) { accC[l] -= hc[l]; accD[l] += hd[l]; }
+            im_face<SCHEME>(F, qb, q0, qc, qd, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, d0, dp, hc, hd);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) { accC[l] += hc[l]; accD[l] -= hd[l]; }
+        }
+        // ---- advance the window
+        qm2 = qm1; qm1 = q0; q0 = qp1;
+        dssKm = dssK0;
+        flagm = flag0;
+        c += sk;
+    }
+}
+
+int g_inviscid_march = 1;      // tuning "inviscid_march": 0 = cell-gather kernel for matrix / upwind too
+
+template <int SCHEME>
+static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)
+{
+    const dim3 blk(64, IM_BY, 1), grd(ntiles);
+    const bool doDiss = fabs(kp.rFil) >= 1.e-10;
+    const bool final_ = !(kp.viscous && doDiss);       // as launch_scheme of the gather kernel
+    if (kp.fwMode) {
+        if (final_) hipLaunchKernelGGL((k_inviscid_march<SCHEME, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL((k_inviscid_march<SCHEME, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
+    } else {
+        if (final_) hipLaunchKernelGGL((k_inviscid_march<SCHEME, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL((k_inviscid_march<SCHEME, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
+    }
+}
+
+extern int g_march_kch;
+
+// matrix dissipation / Roe upwind over the tile table of the level (the table of the Euler marching kernel)
+void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    if (ntiles <= 0) return;
+    if (kp.spaceDiscr == ADFLOW_DISS_MATRIX) launch_im<ADFLOW_DISS_MATRIX>(tab, tiles, ntiles, kp, g_march_kch, s);
+    else launch_im<ADFLOW_UPWIND>(tab, tiles, ntiles, kp, g_march_kch, s);
+}
+
+extern int g_march_by, g_march_pipe;
+// the shared tile table has IM_BY rows per tile unless the Euler kernel was switched to 8 rows (tuning march_by)
+int inviscid_march_enabled() { return g_inviscid_march && !(g_march_pipe >= 2 && g_march_by == 8); }
