@@ -1,4 +1,5 @@
-// k-marching inviscid residual for MATRIX dissipation and ROE UPWIND (Euler, laminar, RANS; fine and coarse levels).
+// k-marching inviscid residual for MATRIX dissipation and ROE UPWIND (Euler, laminar, RANS; fine and coarse levels) and
+// for scalar JST with the entropy sensor (laminar / RANS, fine level; Euler + scalar JST has its own pipelined kernel).
 //
 // The cell-gather kernel (kernels_inviscid.hip) evaluates the six faces of every cell, i.e. every face twice.  These
 // two schemes are bound by FP64 arithmetic (eigenvalue scaling, MUSCL limiter: ~300 divisions per cell in the gather
@@ -23,18 +24,21 @@
 #define IM_OUT 60          // must match EM_OUT / EM_BY of kernels_euler_march.hip: the tile table is shared
 #define IM_BY 4
 
-struct MCell { double rho, u, v, w, e, p; };
+struct MCell { double rho, u, v, w, e, p, s; };     // s: sensor variable of the scalar JST scheme (entropy for NS / RANS)
 
 struct ImPtrs {
     GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) w4;
     GPTR(const double) p;
+    GPTR(const double) ss;      // scalar JST only
 };
 
+template <bool SCAL>
 __device__ __forceinline__ MCell im_ld(const ImPtrs& m, unsigned o)
 {
     MCell q;
     q.rho = ldg(m.w0, o); q.u = ldg(m.w1, o); q.v = ldg(m.w2, o); q.w = ldg(m.w3, o); q.e = ldg(m.w4, o);
     q.p = ldg(m.p, o);
+    q.s = SCAL ? ldg(m.ss, o) : 0.0;
     return q;
 }
 
@@ -42,6 +46,7 @@ __device__ __forceinline__ MCell im_up1(const MCell& q)
 {
     MCell r;
     r.rho = lane_up1(q.rho); r.u = lane_up1(q.u); r.v = lane_up1(q.v); r.w = lane_up1(q.w); r.e = lane_up1(q.e); r.p = lane_up1(q.p);
+    r.s = lane_up1(q.s);
     return r;
 }
 
@@ -49,6 +54,7 @@ __device__ __forceinline__ MCell im_dn1(const MCell& q)
 {
     MCell r;
     r.rho = lane_dn1(q.rho); r.u = lane_dn1(q.u); r.v = lane_dn1(q.v); r.w = lane_dn1(q.w); r.e = lane_dn1(q.e); r.p = lane_dn1(q.p);
+    r.s = lane_dn1(q.s);
     return r;
 }
 
@@ -73,7 +79,8 @@ struct ImFace {          // scalars of the dissipation shared by all faces of a 
 // dw(c) -= fc) and dissipation fd in the convention fw(c) += fd, fw(b) -= fd.  dssB / dssC: matrix sensors of b and c.
 template <int SCHEME>
 __device__ __forceinline__ void im_face(const ImFace& F, const MCell& a, const MCell& b, const MCell& c, const MCell& d, double sx,
-                                        double sy, double sz, int por, double dssB, double dssC, double fc[5], double fd[5])
+                                        double sy, double sz, int por, double dssB, double dssC, double fc[5], double fd[5],
+                                        double radSum = 0.0)
 {
     Line L;
     im_line(a, b, c, d, L);
@@ -82,7 +89,11 @@ __device__ __forceinline__ void im_face(const ImFace& F, const MCell& a, const M
     central_face(L, 1, sx, sy, sz, por, +1.0, fc);
     if (!F.doDiss) return;
     const double gam[5] = {F.gam, F.gam, F.gam, F.gam, F.gam};
-    if (SCHEME == ADFLOW_DISS_MATRIX) {
+    if (SCHEME == ADFLOW_DISS_SCALAR) {
+        // scalar JST on the fine level: radSum = spectral radii of b and c in the direction of the face (fluxes.F90:1204-1272)
+        const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * radSum;
+        jst_scalar_face(L, 1, rrad, dssB, dssC, F.fis2, F.fis4, +1.0, fd);
+    } else if (SCHEME == ADFLOW_DISS_MATRIX) {
         if (F.coarse) jst_matrix_face(L, gam, 1, sx, sy, sz, por, 0.0, 0.0, F.fis2, 0.0, +1.0, fd, true);
         else jst_matrix_face(L, gam, 1, sx, sy, sz, por, dssB, dssC, F.fis2, F.fis4, +1.0, fd);
     } else {
@@ -114,6 +125,11 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
     ImPtrs m;
     m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w4 = m.w3 + nb;
     m.p = (GPTR(const double))b.p;
+    m.ss = (GPTR(const double))b.ss;
+    constexpr bool SCAL = (SCHEME == ADFLOW_DISS_SCALAR);       // NS / RANS, fine level: entropy sensor from b.ss, radii from the time step
+    GPTR(const double) radI = (GPTR(const double))b.radI;
+    GPTR(const double) radJ = (GPTR(const double))b.radJ;
+    GPTR(const double) radK = (GPTR(const double))b.radK;
     GPTR(const double) sIx = (GPTR(const double))b.sI; GPTR(const double) sIy = sIx + nb; GPTR(const double) sIz = sIy + nb;
     GPTR(const double) sJx = (GPTR(const double))b.sJ; GPTR(const double) sJy = sJx + nb; GPTR(const double) sJz = sJy + nb;
     GPTR(const double) sKx = (GPTR(const double))b.sK; GPTR(const double) sKy = sKx + nb; GPTR(const double) sKz = sKy + nb;
@@ -127,26 +143,31 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
     F.coarse = !kp.fineGrid;
     F.fis2 = F.coarse ? kp.rFil * kp.vis2Coarse : kp.rFil * kp.vis2;     // coarse: dis0 of inviscidDissFluxMatrixCoarse
     F.fis4 = kp.rFil * kp.vis4;
-    F.plim = 0.001 * kp.pInfCorr;
+    F.plim = SCAL ? 0.001 * kp.pInfCorr / pow(kp.rhoInf, kp.gammaInf) : 0.001 * kp.pInfCorr;   // sslim of the entropy sensor / plim
     F.gam = kp.gammaConstant;
     F.lim = kp.fineGrid ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;           // fluxes.F90:1531-1538
     F.kappaCoef = kp.kappaCoef; F.rFil = kp.rFil; F.gammaConstant = kp.gammaConstant;
-    const bool sens = (SCHEME == ADFLOW_DISS_MATRIX) && F.doDiss && !F.coarse;
+    const bool sens = (SCHEME != ADFLOW_UPWIND) && F.doDiss && !F.coarse;
+    auto sensor = [&](const MCell& a, const MCell& q, const MCell& d) {
+        return SCAL ? jst_sensor(a.s, q.s, d.s, F.plim) : mat_sensor(a.p, q.p, d.p, F.plim);
+    };
 
     // window k-2 .. k+1 of the own column
-    MCell qm2 = im_ld(m, c - 2 * sk), qm1 = im_ld(m, c - sk), q0 = im_ld(m, c);
+    MCell qm2 = im_ld<SCAL>(m, c - 2 * sk), qm1 = im_ld<SCAL>(m, c - sk), q0 = im_ld<SCAL>(m, c);
     int flagm = flags[(c - sk) >> 3];
-    double dssKm = sens ? mat_sensor(qm2.p, qm1.p, q0.p, F.plim) : 0.0;
+    double dssKm = sens ? sensor(qm2, qm1, q0) : 0.0;
+    double radKm = SCAL ? ldg(radK, c - sk) : 0.0;
     double accC[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};
 
     for (int k = k0; k <= k1 + 1; ++k) {
-        const MCell qp1 = im_ld(m, c + sk);
+        const MCell qp1 = im_ld<SCAL>(m, c + sk);
         const int flag0 = flags[c >> 3];
-        const double dssK0 = sens ? mat_sensor(qm1.p, q0.p, qp1.p, F.plim) : 0.0;
+        const double dssK0 = sens ? sensor(qm1, q0, qp1) : 0.0;
+        const double radK0 = SCAL ? ldg(radK, c) : 0.0;
         // ---- k-face between cells k-1 and k (normal and porosity stored at cell k-1)
         double fc[5], fd[5];
         im_face<SCHEME>(F, qm2, qm1, q0, qp1, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), dssKm,
-                        dssK0, fc, fd);
+                        dssK0, fc, fd, radKm + radK0);
         // ---- finish cell k-1 and write it
         if (k > k0 && out) {
             const unsigned cw = c - sk;
@@ -180,11 +201,16 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
             const int por = flg_porI((uint8_t)lane_up1(flag0));
             double d0 = 0.0, dL = 0.0;
             if (sens) {
-                d0 = mat_sensor(qL.p, q0.p, qR.p, F.plim);
+                d0 = sensor(qL, q0, qR);
                 dL = lane_up1(d0);
             }
+            double radSum = 0.0;
+            if (SCAL) {
+                const double rad0 = ldg(radI, c);
+                radSum = lane_up1(rad0) + rad0;
+            }
             double gc[5], gd[5];
-            im_face<SCHEME>(F, qLL, qL, q0, qR, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, dL, d0, gc, gd);
+            im_face<SCHEME>(F, qLL, qL, q0, qR, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, dL, d0, gc, gd, radSum);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 accC[l] += lane_dn1(gc[l]) - gc[l];     // + plus face, - minus face
@@ -193,31 +219,39 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
         }
         // ---- j-direction: both faces of the cell
         {
-            const MCell qa = im_ld(m, c - 2 * sj), qb = im_ld(m, c - sj), qc = im_ld(m, c + sj), qd = im_ld(m, c + 2 * sj);
+            const MCell qa = im_ld<SCAL>(m, c - 2 * sj), qb = im_ld<SCAL>(m, c - sj), qc = im_ld<SCAL>(m, c + sj),
+                        qd = im_ld<SCAL>(m, c + 2 * sj);
             const int porM = flg_porJ(flags[(c - sj) >> 3]), porP = flg_porJ((uint8_t)flag0);
             double dm = 0.0, d0 = 0.0, dp = 0.0;
             if (sens) {
-                dm = mat_sensor(qa.p, qb.p, q0.p, F.plim);
-                d0 = mat_sensor(qb.p, q0.p, qc.p, F.plim);
-                dp = mat_sensor(q0.p, qc.p, qd.p, F.plim);
+                dm = sensor(qa, qb, q0);
+                d0 = sensor(qb, q0, qc);
+                dp = sensor(q0, qc, qd);
+            }
+            double rM = 0.0, rP = 0.0;
+            if (SCAL) {
+                const double r0 = ldg(radJ, c);
+                rM = ldg(radJ, c - sj) + r0;
+                rP = r0 + ldg(radJ, c + sj);
             }
             double hc[5], hd[5];
-            im_face<SCHEME>(F, qa, qb, q0, qc, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, dm, d0, hc, hd);
+            im_face<SCHEME>(F, qa, qb, q0, qc, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, dm, d0, hc, hd, rM);
 #pragma unroll
             for (int l = 0; l < 5; ++l) { accC[l] -= hc[l]; accD[l] += hd[l]; }
-            im_face<SCHEME>(F, qb, q0, qc, qd, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, d0, dp, hc, hd);
+            im_face<SCHEME>(F, qb, q0, qc, qd, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, d0, dp, hc, hd, rP);
 #pragma unroll
             for (int l = 0; l < 5; ++l) { accC[l] += hc[l]; accD[l] -= hd[l]; }
         }
         // ---- advance the window
         qm2 = qm1; qm1 = q0; q0 = qp1;
+        radKm = radK0;
         dssKm = dssK0;
         flagm = flag0;
         c += sk;
     }
 }
 
-int g_inviscid_march = 1;      // tuning "inviscid_march": 0 = cell-gather kernel for matrix / upwind too
+int g_inviscid_march = 1;      // tuning "inviscid_march": 0 = cell-gather kernel for matrix / upwind too, 2 = marching form for NS / RANS scalar JST as well
 
 template <int SCHEME>
 static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)
@@ -241,9 +275,10 @@ void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, co
 {
     if (ntiles <= 0) return;
     if (kp.spaceDiscr == ADFLOW_DISS_MATRIX) launch_im<ADFLOW_DISS_MATRIX>(tab, tiles, ntiles, kp, g_march_kch, s);
-    else launch_im<ADFLOW_UPWIND>(tab, tiles, ntiles, kp, g_march_kch, s);
+    else if (kp.spaceDiscr == ADFLOW_UPWIND) launch_im<ADFLOW_UPWIND>(tab, tiles, ntiles, kp, g_march_kch, s);
+    else launch_im<ADFLOW_DISS_SCALAR>(tab, tiles, ntiles, kp, g_march_kch, s);     // NS / RANS on the fine level only (caller)
 }
 
 extern int g_march_by, g_march_pipe;
 // the shared tile table has IM_BY rows per tile unless the Euler kernel was switched to 8 rows (tuning march_by)
-int inviscid_march_enabled() { return g_inviscid_march && !(g_march_pipe >= 2 && g_march_by == 8); }
+int inviscid_march_enabled() { return (g_march_pipe >= 2 && g_march_by == 8) ? 0 : g_inviscid_march; }

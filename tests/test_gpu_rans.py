@@ -62,3 +62,19 @@ def test_wall_stress_storage(engine):
                              stretch_k=2.0)
     checks.check_wall_stress(engine, (24, 10, 8), FlowParams(equations=RANSEquations, useQCR=True),
                              {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, split={5: -6, 4: -3}, stretch_k=2.0)
+
+
+def test_inviscid_march_variants(engine):
+    """tuning inviscid_march: 0 = cell-gather kernel for matrix / upwind, 2 = marching form for NS / RANS scalar JST too"""
+    from adflow_amd.params import NSEquations
+    try:
+        engine.set_tuning("inviscid_march", 0)
+        for sd in (dissMatrix, upwind):
+            checks.check_block_res(engine, (70, 9, 8), FlowParams(equations=RANSEquations, spaceDiscr=sd), seed=sd, stretch_k=2.0)
+        engine.set_tuning("inviscid_march", 2)
+        engine.set_tuning("march_kch", 5)
+        checks.check_block_res(engine, (70, 9, 12), FlowParams(equations=RANSEquations), seed=6, stretch_k=2.0)
+        checks.check_rk_residual_sequence(engine, (24, 10, 8), FlowParams(equations=NSEquations), stretch_k=2.0)
+    finally:
+        engine.set_tuning("inviscid_march", 1)
+        engine.set_tuning("march_kch", 32)
