@@ -554,6 +554,45 @@ __device__ __forceinline__ void vt_stage_plane(const BlkView& b, double* __restr
     }
 }
 
+// The same node plane in two steps: global loads into registers (issued before the faces of the current plane are
+// evaluated, so their latency hides under that arithmetic), LDS stores after the barrier that frees the slot.
+#define VT_NPRE ((12 * VT_ROWS) / VS_BY + 1)
+__device__ __forceinline__ void vt_prefetch_plane(const BlkView& b, double pre[VT_NPRE], int i0, int j0, int kn, int tx, int ty)
+{
+    const long nb = b.nbox;
+    int in = i0 - 1 + tx;
+    if (in > b.ib) in = b.ib;
+#pragma unroll
+    for (int it = 0; it < (12 * VT_ROWS) / VS_BY; ++it) {
+        const int row = ty * ((12 * VT_ROWS) / VS_BY) + it;
+        const int m = row / VT_ROWS, r = row % VT_ROWS;
+        int jn = j0 - 1 + r;
+        if (jn > b.jb) jn = b.jb;
+        pre[it] = b.grad[m * nb + b.idx(in, jn, kn)];
+    }
+    const int t = ty * VS_BX + tx;
+    pre[VT_NPRE - 1] = 0.0;
+    if (t < 12 * VT_ROWS) {
+        const int m = t / VT_ROWS, r = t % VT_ROWS;
+        int jn = j0 - 1 + r;
+        if (jn > b.jb) jn = b.jb;
+        int in2 = i0 + VS_BX - 1;
+        if (in2 > b.ib) in2 = b.ib;
+        pre[VT_NPRE - 1] = b.grad[m * nb + b.idx(in2, jn, kn)];
+    }
+}
+
+__device__ __forceinline__ void vt_store_plane(double* __restrict__ gl, int slot, const double pre[VT_NPRE], int tx, int ty)
+{
+#pragma unroll
+    for (int it = 0; it < (12 * VT_ROWS) / VS_BY; ++it) {
+        const int row = ty * ((12 * VT_ROWS) / VS_BY) + it;
+        gl[slot * VT_PLANE + row * VT_LDX + tx] = pre[it];
+    }
+    const int t = ty * VS_BX + tx;
+    if (t < 12 * VT_ROWS) gl[slot * VT_PLANE + t * VT_LDX + VS_BX] = pre[VT_NPRE - 1];
+}
+
 __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
     __shared__ double gl[2 * VT_PLANE];     // two node planes (ring), 12 components, VT_ROWS x 65 nodes
@@ -575,11 +614,13 @@ __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __
     const int shift3[3] = {4, 2, 0};              // porosity bits of the direction inside the flag byte
     int pLo = 0;                                   // slot of node plane k-1
     vt_stage_plane(b, gl, pLo, i0, j0, k0 - 1, tx, ty);
+    vt_stage_plane(b, gl, 1 - pLo, i0, j0, k0, tx, ty);
+    __syncthreads();
     double fk[4] = {0, 0, 0, 0};                   // flux through the k face below the cell: the upper face of the previous plane
     for (int k = k0; k <= k1; ++k) {
         const int pHi = 1 - pLo;
-        vt_stage_plane(b, gl, pHi, i0, j0, k, tx, ty);
-        __syncthreads();
+        double pre[VT_NPRE];
+        if (k < k1) vt_prefetch_plane(b, pre, i0, j0, k + 1, tx, ty);     // node plane of the NEXT step: in flight under the faces
         if (valid) {
             const long c = b.idx(i, j, k);
             const uint8_t f0 = b.flags[c];
@@ -633,6 +674,10 @@ __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __
             }
         }
         __syncthreads();        // every wave is done with plane k-1 before its slot takes plane k+1
+        if (k < k1) {
+            vt_store_plane(gl, pLo, pre, tx, ty);
+            __syncthreads();
+        }
         pLo = pHi;
     }
 }
