@@ -786,9 +786,47 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_dadi_rows_i(const BlkView* __r
     }
 }
 
+// Register form of the tile transposition: the global loads of a 64-line x TI_CH-cell tile land in registers
+// (coalesced: lane -> (line TI_LPA*q + lane/TI_CH, cell lane%TI_CH)), pass through ONE LDS tile and come back as the
+// TI_CH cells of the lane's own line.  All arrays of a chunk are fetched before the first transposition, so their
+// latencies overlap, and a workgroup (one wave) needs 4.6 KB of LDS instead of one tile per array (18 KB: 8 waves per CU;
+// the PMC counters showed 93 % of the wave cycles waiting).
+__device__ __forceinline__ void tile_fetch(const BlkView& b, const double* __restrict__ arr, int j0, int k, int i0, int lane,
+                                           double raw[TI_CH])
+{
+    const int sub = lane >> TI_SH, col = lane & (TI_CH - 1), i = i0 + col;
+#pragma unroll
+    for (int q = 0; q < TI_CH; ++q) {
+        const int r = TI_LPA * q + sub;
+        raw[q] = (j0 + r <= b.jl && i <= b.il) ? arr[b.idx(i, j0 + r, k)] : 0.0;
+    }
+}
+
+// raw (coalesced order) -> v (cells 0..TI_CH-1 of the lane's line); one wave per workgroup: the barriers only order LDS
+__device__ __forceinline__ void tile_to_line(double* __restrict__ tile, int lane, const double raw[TI_CH], double v[TI_CH])
+{
+    const int sub = lane >> TI_SH, col = lane & (TI_CH - 1);
+#pragma unroll
+    for (int q = 0; q < TI_CH; ++q) tile[(TI_LPA * q + sub) * TI_LD + col] = raw[q];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < TI_CH; ++m) v[m] = tile[lane * TI_LD + m];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void line_to_global(const BlkView& b, double* __restrict__ arr, double* __restrict__ tile, int j0, int k,
+                                               int i0, int lane, const double v[TI_CH])
+{
+#pragma unroll
+    for (int m = 0; m < TI_CH; ++m) tile[lane * TI_LD + m] = v[m];
+    __syncthreads();
+    tile_store(b, arr, tile, j0, k, i0, lane);
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void k_dadi_solve_i(const BlkView* __restrict__ tab, KParams kp)
 {
-    __shared__ double tb[64 * TI_LD], tc[64 * TI_LD], td[64 * TI_LD], tf[64 * TI_LD];
+    __shared__ double tile[64 * TI_LD];
     const BlkView& b = tab[blockIdx.z + 1];
     const int l = blockIdx.x % 5;               // equation fastest: the three equations of group 0 share their rows in L2
     const int g = (l < 3) ? 0 : l - 2;
@@ -802,49 +840,49 @@ __global__ __launch_bounds__(64) void k_dadi_solve_i(const BlkView* __restrict__
     const double* __restrict__ Dd = b.grad + (3 * g + 2) * nb;
     double* __restrict__ Dp = b.scratch + l * nb;       // eliminated super-diagonal of this equation's solve
     double* __restrict__ F = b.dw + l * nb;
-    const bool lineOk = (j0 + lane <= b.jl);
     const int nch = (n + TI_CH - 1) / TI_CH;
     double ddp = 0.0, fprev = 0.0;
     for (int ch = 0; ch < nch; ++ch) {
         const int i0 = 2 + ch * TI_CH;
-        tile_load(b, Bb, tb, j0, k, i0, lane); tile_load(b, Cc, tc, j0, k, i0, lane);
-        tile_load(b, Dd, td, j0, k, i0, lane); tile_load(b, F, tf, j0, k, i0, lane);
-        __syncthreads();
-        if (lineOk) {
-            const int mEnd = (n - ch * TI_CH < TI_CH) ? n - ch * TI_CH : TI_CH;
-            for (int m = 0; m < mEnd; ++m) {
-                const int o = lane * TI_LD + m;
-                const double bbv = tb[o];
-                const double d0 = 1.0 / (tc[o] - bbv * ddp);
-                const double ddn = td[o] * d0;
-                td[o] = ddn;
-                const double f = (tf[o] - bbv * fprev) * d0;
-                tf[o] = f;
+        double rb[TI_CH], rc[TI_CH], rd[TI_CH], rf[TI_CH];
+        tile_fetch(b, Bb, j0, k, i0, lane, rb); tile_fetch(b, Cc, j0, k, i0, lane, rc);
+        tile_fetch(b, Dd, j0, k, i0, lane, rd); tile_fetch(b, F, j0, k, i0, lane, rf);
+        double vb[TI_CH], vc[TI_CH], vd[TI_CH], vf[TI_CH];
+        tile_to_line(tile, lane, rb, vb); tile_to_line(tile, lane, rc, vc);
+        tile_to_line(tile, lane, rd, vd); tile_to_line(tile, lane, rf, vf);
+        const int mEnd = (n - ch * TI_CH < TI_CH) ? n - ch * TI_CH : TI_CH;
+#pragma unroll
+        for (int m = 0; m < TI_CH; ++m) {
+            if (m < mEnd) {
+                const double bbv = vb[m];
+                const double d0 = 1.0 / (vc[m] - bbv * ddp);
+                const double ddn = vd[m] * d0;
+                vd[m] = ddn;
+                const double f = (vf[m] - bbv * fprev) * d0;
+                vf[m] = f;
                 ddp = ddn; fprev = f;
             }
         }
-        __syncthreads();
-        tile_store(b, Dp, td, j0, k, i0, lane); tile_store(b, F, tf, j0, k, i0, lane);
-        __syncthreads();
+        line_to_global(b, Dp, tile, j0, k, i0, lane, vd);
+        line_to_global(b, F, tile, j0, k, i0, lane, vf);
     }
     // back substitution: rows n-2 .. 0 (row n-1 keeps its value = fprev)
     for (int ch = nch - 1; ch >= 0; --ch) {
         const int i0 = 2 + ch * TI_CH;
-        tile_load(b, Dp, td, j0, k, i0, lane); tile_load(b, F, tf, j0, k, i0, lane);
-        __syncthreads();
-        if (lineOk) {
-            int mTop = n - 2 - ch * TI_CH;
-            if (mTop > TI_CH - 1) mTop = TI_CH - 1;
-            for (int m = mTop; m >= 0; --m) {
-                const int o = lane * TI_LD + m;
-                const double f = tf[o] - td[o] * fprev;
-                tf[o] = f;
+        double rd[TI_CH], rf[TI_CH], vd[TI_CH], vf[TI_CH];
+        tile_fetch(b, Dp, j0, k, i0, lane, rd); tile_fetch(b, F, j0, k, i0, lane, rf);
+        tile_to_line(tile, lane, rd, vd); tile_to_line(tile, lane, rf, vf);
+        int mTop = n - 2 - ch * TI_CH;
+        if (mTop > TI_CH - 1) mTop = TI_CH - 1;
+#pragma unroll
+        for (int m = TI_CH - 1; m >= 0; --m) {
+            if (m <= mTop) {
+                const double f = vf[m] - vd[m] * fprev;
+                vf[m] = f;
                 fprev = f;
             }
         }
-        __syncthreads();
-        tile_store(b, F, tf, j0, k, i0, lane);
-        __syncthreads();
+        line_to_global(b, F, tile, j0, k, i0, lane, vf);
     }
 }
 
