@@ -358,9 +358,43 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_rows_i(const BlkView* __res
     b.scratch[c] = b.scratch[c] * rblank;
 }
 
+// register form of the tile transposition (see k_dadi_solve_i, kernels_smooth.hip): coalesced global loads into registers,
+// one LDS tile per workgroup (one wave), all arrays of a chunk in flight before the first transposition
+__device__ __forceinline__ void sa_tile_fetch(const BlkView& b, const double* __restrict__ arr, int j0, int k, int i0, int lane,
+                                              double raw[SI_CH])
+{
+    const int sub = lane >> SI_SH, col = lane & (SI_CH - 1), i = i0 + col;
+#pragma unroll
+    for (int q = 0; q < SI_CH; ++q) {
+        const int r = SI_LPA * q + sub;
+        raw[q] = (j0 + r <= b.jl && i <= b.il) ? arr[b.idx(i, j0 + r, k)] : 1.0;
+    }
+}
+
+__device__ __forceinline__ void sa_tile_to_line(double* __restrict__ tile, int lane, const double raw[SI_CH], double v[SI_CH])
+{
+    const int sub = lane >> SI_SH, col = lane & (SI_CH - 1);
+#pragma unroll
+    for (int q = 0; q < SI_CH; ++q) tile[(SI_LPA * q + sub) * SI_LD + col] = raw[q];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < SI_CH; ++m) v[m] = tile[lane * SI_LD + m];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void sa_line_to_global(const BlkView& b, double* __restrict__ arr, double* __restrict__ tile, int j0, int k,
+                                                  int i0, int lane, const double v[SI_CH])
+{
+#pragma unroll
+    for (int m = 0; m < SI_CH; ++m) tile[lane * SI_LD + m] = v[m];
+    __syncthreads();
+    sa_tile_store(b, arr, tile, j0, k, i0, lane);
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void k_sa_solve_i(const BlkView* __restrict__ tab)
 {
-    __shared__ double tb[64 * SI_LD], tc[64 * SI_LD], td[64 * SI_LD], tf[64 * SI_LD];
+    __shared__ double tile[64 * SI_LD];
     const BlkView& b = tab[blockIdx.z + 1];
     const int lane = threadIdx.x;
     const int j0 = blockIdx.x * 64 + 2, k = blockIdx.y + 2;
@@ -372,56 +406,56 @@ __global__ __launch_bounds__(64) void k_sa_solve_i(const BlkView* __restrict__ t
     double* __restrict__ ccA = b.scratch + 2 * nb;
     const double* __restrict__ bbA = b.scratch + 3 * nb;
     const double* __restrict__ ddA = b.scratch + 4 * nb;
-    const bool lineOk = (j0 + lane <= b.jl);
     const int nch = (n + SI_CH - 1) / SI_CH;
     // elimination from the end of the line: chunks right to left
     double ccN = 1.0, bbN = 0.0, ffN = 0.0;
     for (int ch = nch - 1; ch >= 0; --ch) {
         const int i0 = 2 + ch * SI_CH;
-        sa_tile_load(b, bbA, tb, j0, k, i0, lane); sa_tile_load(b, qqA, tc, j0, k, i0, lane);
-        sa_tile_load(b, ddA, td, j0, k, i0, lane); sa_tile_load(b, rhs, tf, j0, k, i0, lane);
-        __syncthreads();
-        if (lineOk) {
-            int mTop = n - 1 - ch * SI_CH;
-            if (mTop > SI_CH - 1) mTop = SI_CH - 1;
-            for (int m = mTop; m >= 0; --m) {
-                const int o = lane * SI_LD + m;
-                double cc = tc[o], ff = tf[o];
-                const double bb = tb[o];
+        double rb[SI_CH], rc[SI_CH], rd[SI_CH], rf[SI_CH], vb[SI_CH], vc[SI_CH], vd[SI_CH], vf[SI_CH];
+        sa_tile_fetch(b, bbA, j0, k, i0, lane, rb); sa_tile_fetch(b, qqA, j0, k, i0, lane, rc);
+        sa_tile_fetch(b, ddA, j0, k, i0, lane, rd); sa_tile_fetch(b, rhs, j0, k, i0, lane, rf);
+        sa_tile_to_line(tile, lane, rb, vb); sa_tile_to_line(tile, lane, rc, vc);
+        sa_tile_to_line(tile, lane, rd, vd); sa_tile_to_line(tile, lane, rf, vf);
+        int mTop = n - 1 - ch * SI_CH;
+        if (mTop > SI_CH - 1) mTop = SI_CH - 1;
+#pragma unroll
+        for (int m = SI_CH - 1; m >= 0; --m) {
+            if (m <= mTop) {
+                double cc = vc[m], ff = vf[m];
+                const double bb = vb[m];
                 if (ch * SI_CH + m < n - 1) {
-                    const double f = td[o] / ccN;
+                    const double f = vd[m] / ccN;
                     cc = cc - f * bbN;
                     ff = ff - f * ffN;
                 }
-                tc[o] = cc; tf[o] = ff;
+                vc[m] = cc; vf[m] = ff;
                 ccN = cc; bbN = bb; ffN = ff;
             }
         }
-        __syncthreads();
-        sa_tile_store(b, ccA, tc, j0, k, i0, lane); sa_tile_store(b, rhs, tf, j0, k, i0, lane);
-        __syncthreads();
+        sa_line_to_global(b, ccA, tile, j0, k, i0, lane, vc);
+        sa_line_to_global(b, rhs, tile, j0, k, i0, lane, vf);
     }
     // forward substitution, then the right-hand side of the next direction
     double fprev = 0.0;
     for (int ch = 0; ch < nch; ++ch) {
         const int i0 = 2 + ch * SI_CH;
-        sa_tile_load(b, bbA, tb, j0, k, i0, lane); sa_tile_load(b, ccA, tc, j0, k, i0, lane);
-        sa_tile_load(b, qqA, td, j0, k, i0, lane); sa_tile_load(b, rhs, tf, j0, k, i0, lane);
-        __syncthreads();
-        if (lineOk) {
-            const int mEnd = (n - ch * SI_CH < SI_CH) ? n - ch * SI_CH : SI_CH;
-            for (int m = 0; m < mEnd; ++m) {
-                const int o = lane * SI_LD + m;
-                double ff = tf[o];
-                if (ch * SI_CH + m > 0) ff = ff - tb[o] * fprev;
-                ff = ff / tc[o];
+        double rb[SI_CH], rc[SI_CH], rd[SI_CH], rf[SI_CH], vb[SI_CH], vc[SI_CH], vd[SI_CH], vf[SI_CH];
+        sa_tile_fetch(b, bbA, j0, k, i0, lane, rb); sa_tile_fetch(b, ccA, j0, k, i0, lane, rc);
+        sa_tile_fetch(b, qqA, j0, k, i0, lane, rd); sa_tile_fetch(b, rhs, j0, k, i0, lane, rf);
+        sa_tile_to_line(tile, lane, rb, vb); sa_tile_to_line(tile, lane, rc, vc);
+        sa_tile_to_line(tile, lane, rd, vd); sa_tile_to_line(tile, lane, rf, vf);
+        const int mEnd = (n - ch * SI_CH < SI_CH) ? n - ch * SI_CH : SI_CH;
+#pragma unroll
+        for (int m = 0; m < SI_CH; ++m) {
+            if (m < mEnd) {
+                double ff = vf[m];
+                if (ch * SI_CH + m > 0) ff = ff - vb[m] * fprev;
+                ff = ff / vc[m];
                 fprev = ff;
-                tf[o] = ff * td[o];
+                vf[m] = ff * vd[m];
             }
         }
-        __syncthreads();
-        sa_tile_store(b, rhs, tf, j0, k, i0, lane);
-        __syncthreads();
+        sa_line_to_global(b, rhs, tile, j0, k, i0, lane, vf);
     }
 }
 

@@ -334,15 +334,19 @@ __global__ __launch_bounds__(64) void k_res_averaging(const BlkView* __restrict_
 // Lines along i are contiguous in memory: with lanes over j a wave would touch 64
 // different rows per access.  Here the 64 lines of a workgroup are processed in
 // chunks of RA_CH cells that travel through an LDS tile: global loads / stores move
-// 128-byte row segments (4 lines x 16 cells per wave access), the serial recurrence
+// 64-byte row segments (8 lines x 8 cells per wave access), the serial recurrence
 // of line `lane` runs on the tile.  Same arithmetic as k_res_averaging<0>.
-#define RA_CH 16
+#define RA_SH 3
+#define RA_CH (1 << RA_SH)
 #define RA_LD (RA_CH + 1)
+#define RA_LPA (64 >> RA_SH)     // lines moved per wave access
+
+// The tile transposition runs through registers and ONE LDS tile per workgroup (one wave): the coalesced global loads of
+// all arrays of a chunk are in flight together, and 4.6 KB of LDS per wave leave the occupancy to the registers
+// (three tiles = 18.5 KB held it at 8 waves per CU; the kernel is bound by load latency).
 __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restrict__ tab, KParams kp)
 {
-    __shared__ double tv[64 * RA_LD];     // dw of the chunk
-    __shared__ double tr[64 * RA_LD];     // forward: rfl of the right neighbour, then d;  backward: d
-    __shared__ uint8_t tf[64 * RA_LD];    // iblank > 0
+    __shared__ double tile[64 * RA_LD];
     const BlkView& b = tab[blockIdx.z + 1];
     const int l = blockIdx.x % 5;
     const int lane = threadIdx.x;
@@ -354,91 +358,99 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
     const double* __restrict__ R = b.scratch;
     double* __restrict__ D = b.scratch + (1 + l) * b.nbox;
     double* __restrict__ dw = b.dw + l * b.nbox;
-    const int sub = lane >> 4, col = lane & 15;       // tile transfer role: 4 lines x 16 cells per access
+    const int sub = lane >> RA_SH, col = lane & (RA_CH - 1);   // tile transfer role: RA_LPA lines x RA_CH cells per access
     const bool lineOk = (j0 + lane <= b.jl);
     const int nch = (n + RA_CH - 1) / RA_CH;
+    // raw (coalesced order) -> the RA_CH cells of the lane's own line
+    auto to_line = [&](const double raw[RA_CH], double v[RA_CH]) {
+#pragma unroll
+        for (int q = 0; q < RA_CH; ++q) tile[(RA_LPA * q + sub) * RA_LD + col] = raw[q];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < RA_CH; ++m) v[m] = tile[lane * RA_LD + m];
+        __syncthreads();
+    };
+    auto to_global = [&](double* __restrict__ arr, int i0, const double v[RA_CH]) {
+#pragma unroll
+        for (int m = 0; m < RA_CH; ++m) tile[lane * RA_LD + m] = v[m];
+        __syncthreads();
+        const int i = i0 + col;
+#pragma unroll
+        for (int q = 0; q < RA_CH; ++q) {
+            const int r = RA_LPA * q + sub;
+            if (j0 + r <= b.jl && i <= b.il) arr[b.idx(i, j0 + r, k)] = tile[r * RA_LD + col];
+        }
+        __syncthreads();
+    };
 
     double epzm = 0.0, dm = 0.0, prev = 0.0;
     double rflc = lineOk ? R[b.idx(2, j0 + lane, k)] : 0.0;
     for (int ch = 0; ch < nch; ++ch) {
         const int i0 = 2 + ch * RA_CH;
         const int i = i0 + col;
+        double rv[RA_CH], rr[RA_CH], rf[RA_CH];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = 4 * q + sub;
-            double v = 0.0, rr = 0.0;
-            uint8_t f = 0;
+        for (int q = 0; q < RA_CH; ++q) {
+            const int r = RA_LPA * q + sub;
+            rv[q] = 0.0; rr[q] = 0.0; rf[q] = 0.0;
             if (j0 + r <= b.jl && i <= b.il) {
                 const long c = b.idx(i, j0 + r, k);
-                v = dw[c]; rr = R[c + 1]; f = b.flags[c];
+                rv[q] = dw[c]; rr[q] = R[c + 1]; rf[q] = flg_blank(b.flags[c]);
             }
-            tv[r * RA_LD + col] = v; tr[r * RA_LD + col] = rr; tf[r * RA_LD + col] = f;
         }
-        __syncthreads();
-        if (lineOk) {
-            const int mEnd = (n - ch * RA_CH < RA_CH) ? n - ch * RA_CH : RA_CH;
-            for (int m = 0; m < mEnd; ++m) {
-                const int o = lane * RA_LD + m;
+        double tv[RA_CH], tr[RA_CH], tb[RA_CH];
+        to_line(rv, tv); to_line(rr, tr); to_line(rf, tb);
+        const int mEnd = (n - ch * RA_CH < RA_CH) ? n - ch * RA_CH : RA_CH;
+#pragma unroll
+        for (int m = 0; m < RA_CH; ++m) {
+            if (m < mEnd) {
                 double epz = 0.0, rfln = 0.0;
                 if (ch * RA_CH + m < n - 1) {
-                    rfln = tr[o];
+                    rfln = tr[m];
                     const double r = rfl0 * (rflc + rfln);
-                    epz = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * flg_blank(tf[o]);
+                    epz = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * tb[m];
                 }
                 const double t = 1.0 / (1.0 + epz + epzm - epzm * dm);
                 const double d = t * epz;
-                tr[o] = d;
-                const double v = t * (tv[o] + epzm * prev);
-                tv[o] = v;
+                tr[m] = d;
+                const double v = t * (tv[m] + epzm * prev);
+                tv[m] = v;
                 prev = v;
                 epzm = epz;
                 dm = d;
                 rflc = rfln;
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = 4 * q + sub;
-            if (j0 + r <= b.jl && i <= b.il) {
-                const long c = b.idx(i, j0 + r, k);
-                dw[c] = tv[r * RA_LD + col]; D[c] = tr[r * RA_LD + col];
-            }
-        }
-        __syncthreads();
+        to_global(dw, i0, tv);
+        to_global(D, i0, tr);
     }
     // back substitution: cells n-2 .. 0, chunks right to left
     for (int ch = nch - 1; ch >= 0; --ch) {
         const int i0 = 2 + ch * RA_CH;
         const int i = i0 + col;
+        double rv[RA_CH], rd[RA_CH];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = 4 * q + sub;
-            double v = 0.0, dd = 0.0;
+        for (int q = 0; q < RA_CH; ++q) {
+            const int r = RA_LPA * q + sub;
+            rv[q] = 0.0; rd[q] = 0.0;
             if (j0 + r <= b.jl && i <= b.il) {
                 const long c = b.idx(i, j0 + r, k);
-                v = dw[c]; dd = D[c];
+                rv[q] = dw[c]; rd[q] = D[c];
             }
-            tv[r * RA_LD + col] = v; tr[r * RA_LD + col] = dd;
         }
-        __syncthreads();
-        if (lineOk) {
-            int mTop = n - 2 - ch * RA_CH;              // last cell that is updated
-            if (mTop > RA_CH - 1) mTop = RA_CH - 1;
-            for (int m = mTop; m >= 0; --m) {
-                const int o = lane * RA_LD + m;
-                const double v = tv[o] + tr[o] * prev;
-                tv[o] = v;
+        double tv[RA_CH], tr[RA_CH];
+        to_line(rv, tv); to_line(rd, tr);
+        int mTop = n - 2 - ch * RA_CH;              // last cell that is updated
+        if (mTop > RA_CH - 1) mTop = RA_CH - 1;
+#pragma unroll
+        for (int m = RA_CH - 1; m >= 0; --m) {
+            if (m <= mTop) {
+                const double v = tv[m] + tr[m] * prev;
+                tv[m] = v;
                 prev = v;
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = 4 * q + sub;
-            if (j0 + r <= b.jl && i <= b.il) dw[b.idx(i, j0 + r, k)] = tv[r * RA_LD + col];
-        }
-        __syncthreads();
+        to_global(dw, i0, tv);
     }
 }
 
