@@ -279,49 +279,57 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_ra_rfl(const BlkView* __restri
     b.scratch[c] = ra_rfl(b, c, 0.001 * kp.pInfCorr);
 }
 
+// A workgroup = 64 lines x the 5 equations (threadIdx.y): the tridiagonal factor depends only on the pressure switch, so
+// every equation forms the same epz / t / d in registers, but only the wave of equation 0 STORES the eliminated
+// super-diagonal d (scratch 1); after the workgroup barrier that follows the forward sweeps all five waves read it in
+// their back substitution.  One d array instead of five: 184 instead of 320 B per cell and direction of HBM traffic with
+// the parallelism of one thread per (line, equation) kept; rfl and the flags are shared through the CU's L1.
 template <int DIR>
-__global__ __launch_bounds__(64) void k_res_averaging(const BlkView* __restrict__ tab, KParams kp)
+__global__ __launch_bounds__(64 * 5) void k_res_averaging(const BlkView* __restrict__ tab, KParams kp)
 {
-    // the five equations of a line set are neighbouring workgroups (blockIdx.x fastest): they share rfl and flags
-    // through the L2 instead of fetching them five times
     const BlkView& b = tab[blockIdx.z + 1];
-    const int l = blockIdx.x % 5;
+    const int l = threadIdx.y;
     // line coordinates (a fastest): DIR0 -> (j,k), DIR1 -> (i,k), DIR2 -> (i,j)
-    const int a = (blockIdx.x / 5) * 64 + threadIdx.x + 2;
+    const int a = blockIdx.x * 64 + threadIdx.x + 2;
     const int bb = blockIdx.y + 2;
     int n, amax, bmax;
     long c0, s;
     if (DIR == 0) { amax = b.jl; bmax = b.kl; n = b.nx; c0 = b.idx(2, a, bb); s = 1; }
     else if (DIR == 1) { amax = b.il; bmax = b.kl; n = b.ny; c0 = b.idx(a, 2, bb); s = b.ldi; }
     else { amax = b.il; bmax = b.jl; n = b.nz; c0 = b.idx(a, bb, 2); s = b.ldk; }
-    if (a > amax || bb > bmax || n <= 1) return;
+    if (b.nx == 0 || bb > bmax || n <= 1) return;        // uniform per workgroup
+    const bool active = (a <= amax);
     const double rfl0 = 0.5 * kp.cfl / kp.cflLimit;
     const double* __restrict__ R = b.scratch;
-    double* __restrict__ D = b.scratch + (1 + l) * b.nbox;
+    double* __restrict__ D = b.scratch + b.nbox;
     double* __restrict__ dw = b.dw + l * b.nbox;
-    // forward elimination (residuals.F90:1873-1895)
-    double epzm = 0.0, dm = 0.0;          // epz(m-1), d(m-1) ; epz(1) = d(1) = 0
     double prev = 0.0;                    // transformed dw(m-1)
-    double rflc = R[c0];
-    for (int m = 0; m < n; ++m) {         // cell index 2+m along the line
-        const long c = c0 + m * s;
-        double epz = 0.0;
-        double rfln = 0.0;
-        if (m < n - 1) {                  // epz defined for 2..n (index il gets 0)
-            rfln = R[c + s];
-            const double r = rfl0 * (rflc + rfln);
-            epz = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * flg_blank(b.flags[c]);
+    if (active) {
+        // forward elimination (residuals.F90:1873-1895)
+        double epzm = 0.0, dm = 0.0;          // epz(m-1), d(m-1) ; epz(1) = d(1) = 0
+        double rflc = R[c0];
+        for (int m = 0; m < n; ++m) {         // cell index 2+m along the line
+            const long c = c0 + m * s;
+            double epz = 0.0;
+            double rfln = 0.0;
+            if (m < n - 1) {                  // epz defined for 2..n (index il gets 0)
+                rfln = R[c + s];
+                const double r = rfl0 * (rflc + rfln);
+                epz = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * flg_blank(b.flags[c]);
+            }
+            const double t = 1.0 / (1.0 + epz + epzm - epzm * dm);
+            const double d = t * epz;
+            if (l == 0) D[c] = d;
+            const double v = t * (dw[c] + epzm * prev);
+            dw[c] = v;
+            prev = v;
+            epzm = epz;
+            dm = d;
+            rflc = rfln;
         }
-        const double t = 1.0 / (1.0 + epz + epzm - epzm * dm);
-        const double d = t * epz;
-        D[c] = d;
-        const double v = t * (dw[c] + epzm * prev);
-        dw[c] = v;
-        prev = v;
-        epzm = epz;
-        dm = d;
-        rflc = rfln;
     }
+    __syncthreads();       // d of the whole line set is in memory (written by the equation-0 wave of this workgroup)
+    if (!active) return;
     // back substitution from index nx down to 2 (residuals.F90:1897-1905)
     for (int m = n - 2; m >= 0; --m) {
         const long c = c0 + m * s;
@@ -461,8 +469,9 @@ void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int m
                        dim3(SM_BX, SM_BY, 1), 0, s, tab, kp, maxnz);
     const dim3 blk(64, 1, 1);
     if (maxnx > 1) hipLaunchKernelGGL(k_res_averaging_i, dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
-    if (maxny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3(5 * ((maxnx + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
-    if (maxnz > 1) hipLaunchKernelGGL((k_res_averaging<2>), dim3(5 * ((maxnx + 63) / 64), maxny, nslots), blk, 0, s, tab, kp);
+    const dim3 blk5(64, 5, 1);        // 64 lines x 5 equations
+    if (maxny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3((maxnx + 63) / 64, maxnz, nslots), blk5, 0, s, tab, kp);
+    if (maxnz > 1) hipLaunchKernelGGL((k_res_averaging<2>), dim3((maxnx + 63) / 64, maxny, nslots), blk5, 0, s, tab, kp);
 }
 
 // ---------------------------------------------------------------------------
