@@ -212,6 +212,63 @@ module adflowGpuShim
             integer(c_int), value :: level, n
             real(c_double), intent(out) :: sums(*)
         end function
+        integer(c_int) function adflow_gpu_mg_cycle(cycling, nStepsCycling) bind(C, name="adflow_gpu_mg_cycle")
+            import :: c_int, c_int32_t
+            integer(c_int32_t), intent(in) :: cycling(*)
+            integer(c_int), value :: nStepsCycling
+        end function
+        integer(c_int) function adflow_gpu_transfer_to_coarse(level) bind(C, name="adflow_gpu_transfer_to_coarse")
+            import :: c_int
+            integer(c_int), value :: level
+        end function
+        integer(c_int) function adflow_gpu_transfer_to_fine(level) bind(C, name="adflow_gpu_transfer_to_fine")
+            import :: c_int
+            integer(c_int), value :: level
+        end function
+        integer(c_int) function adflow_gpu_sa_solve(level) bind(C, name="adflow_gpu_sa_solve")
+            import :: c_int
+            integer(c_int), value :: level
+        end function
+        integer(c_int) function adflow_gpu_reference_shock_sensor(level) bind(C, name="adflow_gpu_reference_shock_sensor")
+            import :: c_int
+            integer(c_int), value :: level
+        end function
+        integer(c_int) function adflow_gpu_set_w_vec(wVec, n) bind(C, name="adflow_gpu_set_w_vec")
+            import :: c_int, c_long, c_double
+            real(c_double), intent(in) :: wVec(*)
+            integer(c_long), value :: n
+        end function
+        integer(c_int) function adflow_gpu_get_r_vec(rVec, n, sumsq2) bind(C, name="adflow_gpu_get_r_vec")
+            import :: c_int, c_long, c_double, c_ptr
+            real(c_double), intent(out) :: rVec(*)
+            integer(c_long), value :: n
+            type(c_ptr), value :: sumsq2
+        end function
+        integer(c_int) function adflow_gpu_get_res(res, n) bind(C, name="adflow_gpu_get_res")
+            import :: c_int, c_long, c_double
+            real(c_double), intent(out) :: res(*)
+            integer(c_long), value :: n
+        end function
+        integer(c_int) function adflow_gpu_nk_residual(wVec, rVec, n) bind(C, name="adflow_gpu_nk_residual")
+            import :: c_int, c_long, c_double
+            real(c_double), intent(in) :: wVec(*)
+            real(c_double), intent(out) :: rVec(*)
+            integer(c_long), value :: n
+        end function
+        integer(c_int) function adflow_gpu_block_release(nn, level, sps) bind(C, name="adflow_gpu_block_release")
+            import :: c_int
+            integer(c_int), value :: nn, level, sps
+        end function
+        integer(c_int) function adflow_gpu_release_all() bind(C, name="adflow_gpu_release_all")
+            import :: c_int
+        end function
+        integer(c_int) function adflow_gpu_sync() bind(C, name="adflow_gpu_sync")
+            import :: c_int
+        end function
+        integer(c_int) function adflow_gpu_set_async(on) bind(C, name="adflow_gpu_set_async")
+            import :: c_int
+            integer(c_int), value :: on
+        end function
     end interface
 
 contains
