@@ -352,6 +352,9 @@ __global__ __launch_bounds__(64 * 5) void k_res_averaging(const BlkView* __restr
 // The tile transposition runs through registers and ONE LDS tile per workgroup (one wave): the coalesced global loads of
 // all arrays of a chunk are in flight together, and 4.6 KB of LDS per wave leave the occupancy to the registers
 // (three tiles = 18.5 KB held it at 8 waves per CU; the kernel is bound by load latency).
+// PASS 0: forward elimination (the eliminated diagonal d is the same for the five equations: only the equation-0 workgroups
+// store it, scratch 1); PASS 1: back substitution in a second launch, whose boundary orders it after every d store.
+template <int PASS>
 __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restrict__ tab, KParams kp)
 {
     __shared__ double tile[64 * RA_LD];
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
     if (j0 > b.jl || k > b.kl || n <= 1) return;
     const double rfl0 = 0.5 * kp.cfl / kp.cflLimit;
     const double* __restrict__ R = b.scratch;
-    double* __restrict__ D = b.scratch + (1 + l) * b.nbox;
+    double* __restrict__ D = b.scratch + b.nbox;
     double* __restrict__ dw = b.dw + l * b.nbox;
     const int sub = lane >> RA_SH, col = lane & (RA_CH - 1);   // tile transfer role: RA_LPA lines x RA_CH cells per access
     const bool lineOk = (j0 + lane <= b.jl);
@@ -392,8 +395,8 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
     };
 
     double epzm = 0.0, dm = 0.0, prev = 0.0;
-    double rflc = lineOk ? R[b.idx(2, j0 + lane, k)] : 0.0;
-    for (int ch = 0; ch < nch; ++ch) {
+    double rflc = (PASS == 0 && lineOk) ? R[b.idx(2, j0 + lane, k)] : 0.0;
+    for (int ch = 0; PASS == 0 && ch < nch; ++ch) {
         const int i0 = 2 + ch * RA_CH;
         const int i = i0 + col;
         double rv[RA_CH], rr[RA_CH], rf[RA_CH];
@@ -430,8 +433,9 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
             }
         }
         to_global(dw, i0, tv);
-        to_global(D, i0, tr);
+        if (l == 0) to_global(D, i0, tr);        // uniform per workgroup (one wave)
     }
+    if (PASS == 0) return;
     // back substitution: cells n-2 .. 0, chunks right to left
     for (int ch = nch - 1; ch >= 0; --ch) {
         const int i0 = 2 + ch * RA_CH;
@@ -448,6 +452,13 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
         }
         double tv[RA_CH], tr[RA_CH];
         to_line(rv, tv); to_line(rd, tr);
+        if (ch == nch - 1) {
+            // the last cell of the line keeps its forward value: the start of the substitution
+            const int mLast = n - 1 - ch * RA_CH;
+#pragma unroll
+            for (int m = 0; m < RA_CH; ++m)
+                if (m == mLast) prev = tv[m];
+        }
         int mTop = n - 2 - ch * RA_CH;              // last cell that is updated
         if (mTop > RA_CH - 1) mTop = RA_CH - 1;
 #pragma unroll
@@ -468,7 +479,10 @@ void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int m
     hipLaunchKernelGGL(k_ra_rfl, dim3((maxnx + SM_BX - 1) / SM_BX, (maxny + SM_BY - 1) / SM_BY, maxnz * nslots),
                        dim3(SM_BX, SM_BY, 1), 0, s, tab, kp, maxnz);
     const dim3 blk(64, 1, 1);
-    if (maxnx > 1) hipLaunchKernelGGL(k_res_averaging_i, dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
+    if (maxnx > 1) {
+        hipLaunchKernelGGL((k_res_averaging_i<0>), dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
+        hipLaunchKernelGGL((k_res_averaging_i<1>), dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
+    }
     const dim3 blk5(64, 5, 1);        // 64 lines x 5 equations
     if (maxny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3((maxnx + 63) / 64, maxnz, nslots), blk5, 0, s, tab, kp);
     if (maxnz > 1) hipLaunchKernelGGL((k_res_averaging<2>), dim3((maxnx + 63) / 64, maxny, nslots), blk5, 0, s, tab, kp);
