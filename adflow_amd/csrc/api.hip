@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march;
 
 namespace {
 
@@ -105,6 +105,8 @@ std::map<std::pair<int, int>, CommPattern> g_comm;   // (level, nLayers)
 std::map<int, BlkView*> g_tab;                        // level -> device table indexed by nn
 std::map<int, int> g_tab_size;
 std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
+int g_skip_unused_radii = 1;                             // tuning "skip_unused_radii"
+int g_phase_base = 0;                                    // tuning "phase_events": first of 8 event slots, 0 = off
 bool g_use_march = true;                               // tuning: adflow_gpu_set_tuning("euler_march", 0|1)
 adflow_bc_callback g_bc_callback = nullptr;
 adflow_bc_callback g_turb_bc_callback = nullptr;
@@ -293,6 +295,16 @@ int for_level(int level, Fn fn)
     if (!any) return fail("no block registered on level %d", level);
     return 0;
 }
+
+}  // namespace
+// instrumentation of blocketteRes (tuning "phase_events" = first event slot): marks 0 entry, 1 closures / BCs / halos done,
+// 2 time step, 3 SA residual, 4 inviscid fluxes, 5 nodal gradients, 6 viscous fluxes + sources (end)
+void adf_phase_mark(int i)
+{
+    if (g_phase_base > 0 && g_stream) (void)hipEventRecord(g_events[g_phase_base + i], g_stream);
+}
+namespace {
+inline void phase_mark(int i) { adf_phase_mark(i); }
 
 int sync_and_check(void)
 {
@@ -778,10 +790,14 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox)
     if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) && !kp.dissApprox && !anyMoving) {
         // matrix dissipation / Roe upwind: k-marching kernel over the level's tile table (every face once in k and i)
         if (ensure_tiles(level)) return 1;
-        launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
+        // second-order Roe upwind on the fine level: the per-cell reconstruction kernel; everything else (matrix, first order)
+        // stays with the per-face kernel
+        if (!launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream))
+            launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
     } else {
         launch_inviscid_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
+    phase_mark(4);
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
     const bool batched = !viscApprox && viscous_is_tiled();
     rc = for_level(level, [&](Block* b) {
@@ -826,6 +842,7 @@ static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPr
 static int block_res_enqueue(int level, unsigned flags)
 {
     if (need_ready()) return 1;
+    phase_mark(0);
     KParams kp = make_kparams(level, 1.0, 0);
     kp.onlyRadii = !(flags & ADFLOW_RES_UPDATE_INTERMED);
     kp.coarseInit = 0;
@@ -856,8 +873,16 @@ static int block_res_enqueue(int level, unsigned flags)
         if (g_comm.count(std::make_pair(level, 2)))
             if (halo_exchange_enqueue(level, lStart, lEnd, 1, 1, 2)) return 1;
     }
-    rc = time_step_level(level, kp);
-    if (rc) return rc;
+    phase_mark(1);
+    // timeStep_block(onlyRadii): with matrix dissipation / Roe upwind nothing in the residual reads the spectral radii, and
+    // without updateIntermed the reference's default path (blocketteResCore, blockette.F90:299-753) keeps them in the
+    // blockette's private arrays: they are not an output of the evaluation.  Only scalar JST needs them (and the entropy
+    // sensor the same kernel leaves in ss).
+    if (!(g_skip_unused_radii && kp.onlyRadii && kp.spaceDiscr != ADFLOW_DISS_SCALAR)) {
+        rc = time_step_level(level, kp);
+        if (rc) return rc;
+    }
+    phase_mark(2);
     // blockResCore order: SA residual first, then the mean-flow fluxes (blockette.F90:806-851)
     if ((flags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
         rc = for_level(level, [&](Block* b) {
@@ -869,10 +894,12 @@ static int block_res_enqueue(int level, unsigned flags)
         if (level_tab(level, &t)) return 1;
         launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
+    phase_mark(3);
     if (flags & ADFLOW_RES_FLOW) {
         rc = enqueue_flow_residual(level, kp, viscApprox, false);
         if (rc) return rc;
     }
+    phase_mark(6);
     // actuator-region sources after the core, fine level only and without the iblank factor (blockette.F90:276-281)
     if (level == 1 && source_terms_enqueue(0)) return 1;
     return 0;
@@ -2218,6 +2245,13 @@ int adflow_gpu_set_tuning(const char* key, int value)
     }
     if (!strcmp(key, "viscous_tiled")) { g_viscous_tiled = value; return 0; }
     if (!strcmp(key, "inviscid_march")) { g_inviscid_march = value; return 0; }
+    if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
+    if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
+    if (!strcmp(key, "phase_events")) {
+        if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");
+        g_phase_base = value;
+        return 0;
+    }
     if (!strcmp(key, "lines_i_tiled")) { g_lines_i_tiled = value; return 0; }
     if (!strcmp(key, "march_kch")) {
         if (value < 4) return fail("march_kch must be >= 4");

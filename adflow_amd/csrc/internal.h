@@ -58,6 +58,39 @@ __device__ __forceinline__ double fastdiv(double a, double b)
 }
 #endif
 
+// 1 / b and 1 / sqrt(x) for operands in the normal range: the hardware seed (v_rcp_f64 / v_rsq_f64, quarter rate) refined
+// by ADF_NR Newton steps in FMA form, without the range handling, final residual correction and denormal scaling of the
+// compiler's division / sqrt.  Callers multiply by the result; the flux kernels that use them are bound by FP64 issue.
+#ifndef ADF_NR
+#define ADF_NR 2
+#endif
+#ifdef HOSTSIM
+__device__ __forceinline__ double rcp_nr(double b) { return 1.0 / b; }
+__device__ __forceinline__ double rsq_nr(double x) { return 1.0 / sqrt(x); }
+#else
+__device__ __forceinline__ double rcp_nr(double b)
+{
+    double x = __builtin_amdgcn_rcp(b);
+#pragma unroll
+    for (int it = 0; it < ADF_NR; ++it) {
+        const double e = __builtin_fma(-b, x, 1.0);
+        x = __builtin_fma(x, e, x);
+    }
+    return x;
+}
+__device__ __forceinline__ double rsq_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < ADF_NR; ++it) {
+        const double t = x * y;
+        const double e = __builtin_fma(-t, y, 1.0);      // 1 - x y^2
+        y = __builtin_fma(0.5 * y, e, y);
+    }
+    return y;
+}
+#endif
+
 // value of the neighbouring lane of the 64-wide wavefront: lane_up1 = lane-1
 // (__shfl_up by 1), lane_dn1 = lane+1.  On gfx950 these are single DPP moves
 // (v_mov_b32_dpp wave_shr:1 / wave_shl:1) per 32-bit half instead of a
@@ -182,6 +215,7 @@ void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStre
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 int viscous_is_tiled();
+void adf_phase_mark(int i);    // api.hip: optional HIP event between the phases of blocketteRes
 void launch_coarse_coordinates_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, hipStream_t s);
 void launch_xhalo_level(const BlkView* tab, int nslots, int nx, int ny, int nz, hipStream_t s);
 void launch_xhalo_symm(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, hipStream_t s);
@@ -209,6 +243,7 @@ void launch_halo_unpack(const BlkView* tab, const int* blk, const long* off, int
                         hipStream_t s);
 void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 int inviscid_march_enabled();
+bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
 void launch_restrict_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

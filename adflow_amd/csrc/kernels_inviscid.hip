@@ -95,8 +95,8 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
     }
 }
 
-// FINAL: dw = (init + central + fw) * iblank written; otherwise dw = init + central
-// and fw stored for the viscous kernel to complete.
+// FINAL: dw = (init + central + fw) * iblank written; otherwise the viscous kernel completes the sum: with the persistent
+// fw of the Runge-Kutta scheme (fwMode) dw = init + central and fw are stored, else only dw = init + central + fw.
 template <int SCHEME, bool VISC, bool FINAL>
 __global__ __launch_bounds__(IV_BX* IV_BY, (SCHEME == ADFLOW_UPWIND ? 2 : 1)) void k_inviscid(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
@@ -155,9 +155,11 @@ __global__ __launch_bounds__(IV_BX* IV_BY, (SCHEME == ADFLOW_UPWIND ? 2 : 1)) vo
         if (FINAL) {
             if (kp.fwMode && doDiss) b.fw[c + l * nb] = fwn;
             b.dw[c + l * nb] = (d + fwn) * blank;
-        } else {
+        } else if (kp.fwMode) {
             b.fw[c + l * nb] = fwn;
             b.dw[c + l * nb] = d;
+        } else {
+            b.dw[c + l * nb] = d + fwn;      // fw not persistent: the viscous kernel adds its part to the sum
         }
     }
 }

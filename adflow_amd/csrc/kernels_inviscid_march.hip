@@ -184,9 +184,11 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
                 if (FINAL) {
                     if (FW && F.doDiss) stg(fw + l * nb, cw, fwn);
                     stg(dw + l * nb, cw, (d + fwn) * blank);
-                } else {
+                } else if (FW) {
                     stg(fw + l * nb, cw, fwn);
                     stg(dw + l * nb, cw, d);
+                } else {
+                    stg(dw + l * nb, cw, d + fwn);      // fw not persistent: the viscous kernel adds its part to the sum
                 }
             }
         }

@@ -1,0 +1,396 @@
+// k-marching inviscid residual for the second-order ROE UPWIND scheme on the fine level: central flux + MUSCL
+// reconstruction (no limiter / van Albada / minmod) + Roe flux with the 1-D entropy fix, every face evaluated ONCE in i
+// and k, the reconstruction evaluated once per CELL and direction.
+//
+// Reference semantics: fluxes::inviscidCentralFlux  src/solver/fluxes.F90:4-401
+//                      fluxes::inviscidUpwindFlux   src/solver/fluxes.F90:1438-2532 (leftRightState :2103-2294,
+//                      riemannFlux :2296-2532), final sum residuals.F90:334-344.
+//
+// Why a second kernel next to k_inviscid_march<upwind>: that one evaluates leftRightState per FACE as the reference does
+// (20 limiter divisions per face, four faces per cell) and measures ~4400 FP64 issue slots per cell -- it is bound by
+// FP64 issue, not by HBM.  Here the algebra is regrouped (results agree to rounding, not bitwise):
+//   * leftRightState of face (c | c+1) gives  left  = w_c     + omk A_c     + opk B_c
+//                                             right = w_{c+1} - opk A_{c+1} - omk B_{c+1}
+//     with A_c = f(d+ / d-) d-,  B_c = f(d- / d+) d+  and d-, d+ the two differences of cell c in that direction: both
+//     states of a cell are functions of (w_{c-1}, w_c, w_{c+1}) only.  A thread therefore reconstructs ITS cell once per
+//     direction (two limiter values per variable instead of four per face and variable) and the face takes the left
+//     state from the cell below (k: carried in registers; i: DPP lane shift; j: exchanged through LDS);
+//   * the two limiter denominators of a variable share one reciprocal (1/x = y / (x y));
+//   * riemannFlux: 1/sqrt(rho) from v_rsq_f64 serves z1, 1/z1 and the sound speeds of the entropy fix; E_t =
+//     p/(gamma-1) + rho q^2/2 without the division by rho; 1/a, 1/a^2 and a from one v_rsq_f64; unit normal and area
+//     from one v_rsq_f64.  8 transcendental seeds per face instead of 14 divisions + 7 square roots.
+// Mapping as in kernels_inviscid_march.hip: workgroup = 64 lanes (i) x 4 rows (j) marching in k over the level's XCD-ordered
+// tile table; a wavefront covers columns i0-2 .. i0+61 and produces 60 of them.
+//
+// gamma: calorically perfect gas (cpConstant, the only cp model of the path): gamma(i,j,k) = gammaConstant.
+// Roofline: FP64 VALU issue (~1500 slots per cell), then HBM.
+#include "internal.h"
+
+#define RM_OUT 60          // must match EM_OUT / EM_BY of kernels_euler_march.hip: the tile table is shared
+#define RM_BY 4
+
+struct RCell { double rho, u, v, w, p, e; };
+
+struct RmPtrs {
+    GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) w4;
+    GPTR(const double) p;
+};
+
+__device__ __forceinline__ RCell rm_ld(const RmPtrs& m, unsigned o)
+{
+    RCell q;
+    q.rho = ldg(m.w0, o); q.u = ldg(m.w1, o); q.v = ldg(m.w2, o); q.w = ldg(m.w3, o); q.e = ldg(m.w4, o);
+    q.p = ldg(m.p, o);
+    return q;
+}
+
+__device__ __forceinline__ RCell rm_up1(const RCell& q)
+{
+    RCell r;
+    r.rho = lane_up1(q.rho); r.u = lane_up1(q.u); r.v = lane_up1(q.v); r.w = lane_up1(q.w); r.p = lane_up1(q.p); r.e = lane_up1(q.e);
+    return r;
+}
+
+__device__ __forceinline__ RCell rm_dn1(const RCell& q)
+{
+    RCell r;
+    r.rho = lane_dn1(q.rho); r.u = lane_dn1(q.u); r.v = lane_dn1(q.v); r.w = lane_dn1(q.w); r.p = lane_dn1(q.p); r.e = lane_dn1(q.e);
+    return r;
+}
+
+struct RmK {              // uniform scalars of a launch
+    double omk, opk, factMinmod, gam, gm1, ovgm1, porDiss;
+    bool doDiss;
+};
+
+// MUSCL states of ONE cell along one direction for one variable (leftRightState regrouped per cell, see the header):
+// plus = left state of the face above the cell, minus = right state of the face below it.
+template <int LIM>
+__device__ __forceinline__ void rm_recon1(const RmK& K, double qm, double q0, double qp, double& plus, double& minus)
+{
+    const double dm = q0 - qm, dp = qp - q0;
+    double A, B;
+    if (LIM == ADFLOW_LIM_NONE) {
+        A = dm; B = dp;
+    } else {
+        const double epsLim = 1.e-10;
+        const double cm = copysign(fmax(fabs(dm), epsLim), dm), cp = copysign(fmax(fabs(dp), epsLim), dp);
+        if (LIM == ADFLOW_LIM_VANALBADA) {
+            // f(r) = r (r + 1) / (r^2 + 1) with r = max(0, a / b)  ==  a (a + b) / (a^2 + b^2) for a b > 0, else 0
+            const double dA = dp * dp + cm * cm, dB = dm * dm + cp * cp;
+            const double r = rcp_nr(dA * dB);
+            A = (dp * cm > 0.0) ? (dp * (dp + cm)) * (r * dB) * dm : 0.0;
+            B = (dm * cp > 0.0) ? (dm * (dm + cp)) * (r * dA) * dp : 0.0;
+        } else {   // minmod: f(r) = min(1, factMinmod max(0, r))
+            const double r = rcp_nr(cm * cp);
+            A = fmin(1.0, K.factMinmod * fmax(0.0, dp * (r * cp))) * dm;
+            B = fmin(1.0, K.factMinmod * fmax(0.0, dm * (r * cm))) * dp;
+        }
+    }
+    plus = q0 + (K.omk * A + K.opk * B);
+    minus = q0 - (K.opk * A + K.omk * B);
+}
+
+template <int LIM>
+__device__ __forceinline__ void rm_recon(const RmK& K, const RCell& a, const RCell& b, const RCell& c, double plus[5], double minus[5])
+{
+    rm_recon1<LIM>(K, a.rho, b.rho, c.rho, plus[0], minus[0]);
+    rm_recon1<LIM>(K, a.u, b.u, c.u, plus[1], minus[1]);
+    rm_recon1<LIM>(K, a.v, b.v, c.v, plus[2], minus[2]);
+    rm_recon1<LIM>(K, a.w, b.w, c.w, plus[3], minus[3]);
+    rm_recon1<LIM>(K, a.p, b.p, c.p, plus[4], minus[4]);
+}
+
+// Fluxes through the face between cells b and c (normal S = (nx,ny,nz) pointing from b to c, porosity code por):
+//   fc: central flux, dw(b) += fc, dw(c) -= fc                              (fluxes.F90:52-129)
+//   fd: Roe dissipation flux = -porFlux |A| (W_R - W_L), fw(b) += fd, fw(c) -= fd   (riemannFlux, fluxes.F90:2296-2501)
+// L / R: reconstructed primitive states (rho, u, v, w, p) on the two sides of the face.
+__device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCell& c, const double L[5], const double R[5], double nx,
+                                        double ny, double nz, int por, double fc[5], double fd[5])
+{
+    // ---- central
+    {
+        double vnp = c.u * nx + c.v * ny + c.w * nz;
+        double vnm = b.u * nx + b.v * ny + b.w * nz;
+        double porVel = 1.0, porFlux = 0.5;
+        if (por == ADF_POR_NOFLUX) porFlux = 0.0;
+        if (por == ADF_POR_BOUND) { porVel = 0.0; vnp = 0.0; vnm = 0.0; }
+        porVel *= porFlux;
+        const double qsp = vnp * porVel, qsm = vnm * porVel;
+        const double rqsp = qsp * c.rho, rqsm = qsm * b.rho;
+        const double pa = porFlux * (c.p + b.p);
+        fc[0] = rqsp + rqsm;
+        fc[1] = rqsp * c.u + rqsm * b.u + pa * nx;
+        fc[2] = rqsp * c.v + rqsm * b.v + pa * ny;
+        fc[3] = rqsp * c.w + rqsm * b.w + pa * nz;
+        fc[4] = qsp * c.e + qsm * b.e + porFlux * (vnp * c.p + vnm * b.p);
+    }
+    if (!K.doDiss) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) fd[m] = 0.0;
+        return;
+    }
+    // ---- Roe
+    double porFlux = K.porDiss;                                // 0.5 rFil
+    if (por == ADF_POR_NOFLUX || por == ADF_POR_BOUND) porFlux = 0.0;
+    const double rsl = rsq_nr(L[0]), rsr = rsq_nr(R[0]);       // 1 / z1l, 1 / z1r
+    const double z1l = L[0] * rsl, z1r = R[0] * rsr;
+    const double tmp = rcp_nr(z1l + z1r);
+    const double kl = 0.5 * (L[1] * L[1] + L[2] * L[2] + L[3] * L[3]), kr = 0.5 * (R[1] * R[1] + R[2] * R[2] + R[3] * R[3]);
+    const double Etl = K.ovgm1 * L[4] + L[0] * kl, Etr = K.ovgm1 * R[4] + R[0] * kr;   // etot, cpConstant (flowUtils.F90:551-640)
+    const double dr = R[0] - L[0];
+    const double dru = R[0] * R[1] - L[0] * L[1];
+    const double drv = R[0] * R[2] - L[0] * L[2];
+    const double drw = R[0] * R[3] - L[0] * L[3];
+    const double drE = Etr - Etl;
+    const double wl = z1l * tmp, wr = z1r * tmp;
+    const double uAvg = wl * L[1] + wr * R[1];
+    const double vAvg = wl * L[2] + wr * R[2];
+    const double wAvg = wl * L[3] + wr * R[3];
+    const double hAvg = tmp * ((Etl + L[4]) * rsl + (Etr + R[4]) * rsr);
+    const double a2n = nx * nx + ny * ny + nz * nz;
+    const double ra = rsq_nr(fmax(a2n, 1.e-50));               // 1 / max(1e-25, area)
+    const double area = a2n * ra;
+    const double sx = nx * ra, sy = ny * ra, sz = nz * ra;
+    const double alphaAvg = 0.5 * (uAvg * uAvg + vAvg * vAvg + wAvg * wAvg);
+    const double a2Avg = fabs(K.gm1 * (hAvg - alphaAvg));
+    const double ovaAvg = rsq_nr(a2Avg), ova2Avg = ovaAvg * ovaAvg, aAvg = a2Avg * ovaAvg;
+    double unAvg = uAvg * sx + vAvg * sy + wAvg * sz;
+    if (por == ADF_POR_BOUND) unAvg = 0.0;                     // rFace = 0: blocks at rest (moving blocks use the gather kernel)
+    // sound speeds of the two states for the entropy fix: sqrt(gamma p / rho) = sqrt(gamma p) / sqrt(rho)
+    const double gpl = K.gam * L[4], gpr = K.gam * R[4];
+    const double cl = gpl * rsq_nr(gpl) * rsl, cr = gpr * rsq_nr(gpr) * rsr;
+    const double eta = 0.5 * (fabs((L[1] - R[1]) * sx + (L[2] - R[2]) * sy + (L[3] - R[3]) * sz) + fabs(cl - cr));
+    double lam1 = fabs(unAvg + aAvg), lam2 = fabs(unAvg - aAvg), lam3 = fabs(unAvg);
+    const double two_eta = 2.0 * eta;
+    const double q4eta = 0.25 * rcp_nr(fmax(eta, 1.e-300));    // only used where lam < 2 eta, i.e. eta > 0
+    if (lam1 < two_eta) lam1 = eta + lam1 * lam1 * q4eta;
+    if (lam2 < two_eta) lam2 = eta + lam2 * lam2 * q4eta;
+    if (lam3 < two_eta) lam3 = eta + lam3 * lam3 * q4eta;
+    lam1 *= area; lam2 *= area; lam3 *= area;
+    const double abv1 = 0.5 * (lam1 + lam2);
+    const double abv2 = 0.5 * (lam1 - lam2);
+    const double abv3 = abv1 - lam3;
+    const double abv4 = K.gm1 * (alphaAvg * dr - uAvg * dru - vAvg * drv - wAvg * drw + drE);
+    const double abv5 = sx * dru + sy * drv + sz * drw - unAvg * dr;
+    const double abv6 = abv3 * abv4 * ova2Avg + abv2 * abv5 * ovaAvg;
+    const double abv7 = abv2 * abv4 * ovaAvg + abv3 * abv5;
+    fd[0] = -porFlux * (lam3 * dr + abv6);
+    fd[1] = -porFlux * (lam3 * dru + uAvg * abv6 + sx * abv7);
+    fd[2] = -porFlux * (lam3 * drv + vAvg * abv6 + sy * abv7);
+    fd[3] = -porFlux * (lam3 * drw + wAvg * abv6 + sz * abv7);
+    fd[4] = -porFlux * (lam3 * drE + hAvg * abv6 + unAvg * abv7);
+}
+
+// LDS exchange of the j-direction states: UL of rows -1..2 (slots 0..3) and UR of rows 1..4 (slots 4..7) of the tile
+#define RM_XJ (8 * 5 * 64)
+
+// FW: persistent dissipation residual of the Runge-Kutta scheme (fw kept between the stages); FINAL: dw = (dw + fw) iblank
+// written here, otherwise the sum dw + fw is left in dw for the viscous kernel to complete (residuals.F90:334-344)
+template <int LIM, bool FW, bool FINAL>
+__global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
+                                                             int kch)
+{
+    __shared__ double xj[2 * RM_XJ];
+    const int4 t = tiles[blockIdx.x];
+    if (t.x < 0) return;
+    const BlkView& b = tab[t.x];
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int i = t.y * RM_OUT + lane;          // columns i0-2 .. i0+61
+    const int j = 2 + t.z * RM_BY + row;
+    const int k0 = 2 + t.w * kch;
+    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
+    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
+    const int ic = (i < b.ib) ? i : b.ib;
+    // rows beyond the block: clamped to the first halo row so that a valid row's upper neighbour is the true cell j+1
+    const int jc = (j < b.je) ? j : b.je;
+    const int jp2 = (jc + 2 < b.jb) ? jc + 2 : b.jb;
+    const long nb = b.nbox;
+    const unsigned sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
+    const unsigned oj2 = 8u * (unsigned)((jp2 - jc) * b.ldi);   // offset to row j+2 (clamped)
+
+    RmPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w4 = m.w3 + nb;
+    m.p = (GPTR(const double))b.p;
+    GPTR(const double) sIx = (GPTR(const double))b.sI; GPTR(const double) sIy = sIx + nb; GPTR(const double) sIz = sIy + nb;
+    GPTR(const double) sJx = (GPTR(const double))b.sJ; GPTR(const double) sJy = sJx + nb; GPTR(const double) sJz = sJy + nb;
+    GPTR(const double) sKx = (GPTR(const double))b.sK; GPTR(const double) sKy = sKx + nb; GPTR(const double) sKz = sKy + nb;
+    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
+    GPTR(double) dw = (GPTR(double))b.dw;
+    GPTR(double) fw = (GPTR(double))b.fw;
+    GPTR(const double) wr = (GPTR(const double))b.wr;
+
+    RmK K;
+    K.doDiss = fabs(kp.rFil) >= 1.e-10;
+    K.omk = 0.25 * (1.0 - kp.kappaCoef); K.opk = 0.25 * (1.0 + kp.kappaCoef);
+    K.factMinmod = (3.0 - kp.kappaCoef) / fmax(1.e-10, 1.0 - kp.kappaCoef);
+    K.gam = kp.gammaConstant; K.gm1 = kp.gammaConstant - 1.0; K.ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
+    K.porDiss = 0.5 * kp.rFil;
+
+    // window k-1 .. k+1 of the own column; left state of the face above cell k-1
+    RCell qm1, q0;
+    double ULk[5];
+    {
+        const RCell qm2 = rm_ld(m, c - 2 * sk);
+        qm1 = rm_ld(m, c - sk);
+        q0 = rm_ld(m, c);
+        double dummy[5];
+        rm_recon<LIM>(K, qm2, qm1, q0, ULk, dummy);
+    }
+    int flagm = flags[(c - sk) >> 3];
+    double acc[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};   // accD: dissipation part, kept apart only when FW
+
+    for (int k = k0; k <= k1 + 1; ++k) {
+        const RCell qp1 = rm_ld(m, c + sk);
+        const int flag0 = flags[c >> 3];
+        double* __restrict__ xb = xj + ((k - k0) & 1) * RM_XJ;
+        const bool body = (k <= k1);
+        RCell qjm, qjp;
+        double ULj[5], URj[5];
+        if (body) {
+            // ---- j-direction, first half: reconstruct the own cell (+ the cell outside the tile for the edge rows) and
+            //      publish the states the neighbouring rows need
+            qjm = rm_ld(m, c - sj);
+            qjp = rm_ld(m, c + sj);
+            rm_recon<LIM>(K, qjm, q0, qjp, ULj, URj);
+            if (row < RM_BY - 1) {
+#pragma unroll
+                for (int l = 0; l < 5; ++l) xb[((row + 1) * 5 + l) * 64 + lane] = ULj[l];
+            }
+            if (row > 0) {
+#pragma unroll
+                for (int l = 0; l < 5; ++l) xb[((4 + row - 1) * 5 + l) * 64 + lane] = URj[l];
+            }
+            if (row == 0) {
+                const RCell qjm2 = rm_ld(m, c - 2 * sj);
+                double pl[5], mi[5];
+                rm_recon<LIM>(K, qjm2, qjm, q0, pl, mi);
+#pragma unroll
+                for (int l = 0; l < 5; ++l) xb[(0 * 5 + l) * 64 + lane] = pl[l];
+            }
+            if (row == RM_BY - 1) {
+                const RCell qjp2 = rm_ld(m, c + oj2);
+                double pl[5], mi[5];
+                rm_recon<LIM>(K, q0, qjp, qjp2, pl, mi);
+#pragma unroll
+                for (int l = 0; l < 5; ++l) xb[(7 * 5 + l) * 64 + lane] = mi[l];
+            }
+        }
+        // ---- k-face between cells k-1 and k (normal and porosity stored at cell k-1)
+        double ULk0[5], URk0[5];
+        rm_recon<LIM>(K, qm1, q0, qp1, ULk0, URk0);
+        double fc[5], fd[5];
+        rm_face(K, qm1, q0, ULk, URk0, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), fc, fd);
+        // ---- finish cell k-1 and write it
+        if (k > k0 && out) {
+            const unsigned cw = c - sk;
+            const double blank = flg_blank((uint8_t)flagm);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                double d = acc[l] + fc[l];
+                if (kp.coarseInit) d += ldg(wr + l * nb, cw);
+                if (FW) {
+                    double fwn = accD[l] + fd[l];
+                    const double old = ldg(fw + l * nb, cw);
+                    fwn = K.doDiss ? (kp.sfil * old + fwn) : old;
+                    if (K.doDiss || !FINAL) stg(fw + l * nb, cw, fwn);
+                    stg(dw + l * nb, cw, FINAL ? (d + fwn) * blank : d);
+                } else {
+                    d += fd[l];
+                    stg(dw + l * nb, cw, FINAL ? d * blank : d);
+                }
+            }
+        }
+        if (!body) break;
+        // ---- start cell k
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            ULk[l] = ULk0[l];
+            if (FW) { acc[l] = -fc[l]; accD[l] = -fd[l]; }
+            else acc[l] = -(fc[l] + fd[l]);
+        }
+        // ---- i-direction: this lane evaluates the face (i-1 | i); the face (i | i+1) comes from lane+1
+        {
+            const RCell qL = rm_up1(q0), qR = rm_dn1(q0);
+            double ULi[5], URi[5], ULm[5];
+            rm_recon<LIM>(K, qL, q0, qR, ULi, URi);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) ULm[l] = lane_up1(ULi[l]);
+            const int por = flg_porI((uint8_t)lane_up1(flag0));
+            double gc[5], gd[5];
+            rm_face(K, qL, q0, ULm, URi, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, gc, gd);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                if (FW) {
+                    acc[l] += lane_dn1(gc[l]) - gc[l];
+                    accD[l] += lane_dn1(gd[l]) - gd[l];
+                } else {
+                    const double g = gc[l] + gd[l];
+                    acc[l] += lane_dn1(g) - g;
+                }
+            }
+        }
+        // ---- j-direction, second half: both faces of the cell with the neighbours' states
+        __syncthreads();
+        {
+            double Lm[5], Rp[5];
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                Lm[l] = xb[(row * 5 + l) * 64 + lane];            // left state of face (j-1 | j): UL of row-1
+                Rp[l] = xb[((4 + row) * 5 + l) * 64 + lane];      // right state of face (j | j+1): UR of row+1
+            }
+            const int porM = flg_porJ(flags[(c - sj) >> 3]), porP = flg_porJ((uint8_t)flag0);
+            double hc[5], hd[5];
+            rm_face(K, qjm, q0, Lm, URj, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, hc, hd);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                if (FW) { acc[l] -= hc[l]; accD[l] -= hd[l]; }
+                else acc[l] -= hc[l] + hd[l];
+            }
+            rm_face(K, q0, qjp, ULj, Rp, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, hc, hd);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                if (FW) { acc[l] += hc[l]; accD[l] += hd[l]; }
+                else acc[l] += hc[l] + hd[l];
+            }
+        }
+        // ---- advance the window
+        qm1 = q0; q0 = qp1;
+        flagm = flag0;
+        c += sk;
+    }
+}
+
+int g_roe_march = 1;       // tuning "roe_march": 0 = k_inviscid_march<upwind> (reconstruction per face) on the fine level too
+
+extern int g_march_kch;
+
+template <int LIM>
+static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    const dim3 blk(64, RM_BY, 1), grd(ntiles);
+    const bool doDiss = fabs(kp.rFil) >= 1.e-10;
+    const bool final_ = !(kp.viscous && doDiss);
+    const int kch = g_march_kch;
+    if (kp.fwMode) {
+        if (final_) hipLaunchKernelGGL((k_roe_march<LIM, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL((k_roe_march<LIM, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
+    } else {
+        if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
+    }
+}
+
+// true when the launch was taken: second-order Roe upwind on the fine level of blocks at rest
+bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    if (!g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid || kp.dissApprox) return false;
+    if (ntiles <= 0) return true;
+    switch (kp.limiter) {
+    case ADFLOW_LIM_NONE: launch_rm<ADFLOW_LIM_NONE>(tab, tiles, ntiles, kp, s); return true;
+    case ADFLOW_LIM_VANALBADA: launch_rm<ADFLOW_LIM_VANALBADA>(tab, tiles, ntiles, kp, s); return true;
+    case ADFLOW_LIM_MINMOD: launch_rm<ADFLOW_LIM_MINMOD>(tab, tiles, ntiles, kp, s); return true;
+    default: return false;      // first order: k_inviscid_march
+    }
+}

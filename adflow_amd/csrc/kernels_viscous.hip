@@ -341,7 +341,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous(BlkView b, KParams kp)
     const double blank = flg_blank(f0);
 #pragma unroll
     for (int l = 0; l < 5; ++l) {
-        const double fwn = b.fw[c + l * nb] + acc[l];
+        const double fwn = (kp.fwMode ? b.fw[c + l * nb] : 0.0) + acc[l];   // without fwMode dw already holds dw + fw
         if (kp.fwMode) b.fw[c + l * nb] = fwn;
         b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
     }
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __
             const double blank = flg_blank(f0);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
-                const double fwn = b.fw[c + l * nb] + acc[l];
+                const double fwn = (kp.fwMode ? b.fw[c + l * nb] : 0.0) + acc[l];   // without fwMode dw already holds dw + fw
                 if (kp.fwMode) b.fw[c + l * nb] = fwn;
                 b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
             }
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous_approx(BlkView b, KPar
     const double blank = flg_blank(f0);
 #pragma unroll
     for (int l = 0; l < 5; ++l) {
-        const double fwn = b.fw[c + l * nb] + acc[l];
+        const double fwn = (kp.fwMode ? b.fw[c + l * nb] : 0.0) + acc[l];   // without fwMode dw already holds dw + fw
         if (kp.fwMode) b.fw[c + l * nb] = fwn;
         b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
     }
@@ -789,6 +789,7 @@ void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz
     const int nzn = nz + 1;                              // node planes 1..kl
     hipLaunchKernelGGL(k_nodal_gradients_t, dim3((nx + 1 + VS_BX - 1) / VS_BX, (ny + 1 + VS_BY - 1) / VS_BY, nzn * nslots), blk, 0, s,
                        tab, nzn);
+    adf_phase_mark(5);
     const int nch = (nz + VT_KCH - 1) / VT_KCH;
     hipLaunchKernelGGL(k_viscous_t, dim3((nx + VS_BX - 1) / VS_BX, (ny + VS_BY - 1) / VS_BY, nch * nslots), blk, 0, s, tab, nch, kp);
 }
