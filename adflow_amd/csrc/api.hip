@@ -301,7 +301,14 @@ int for_level(int level, Fn fn)
 // 2 time step, 3 SA residual, 4 inviscid fluxes, 5 nodal gradients, 6 viscous fluxes + sources (end)
 void adf_phase_mark(int i)
 {
-    if (g_phase_base > 0 && g_stream) (void)hipEventRecord(g_events[g_phase_base + i], g_stream);
+    static unsigned hit = 0;
+    if (g_phase_base <= 0 || !g_stream) return;
+    if (i == 0) hit = 0;
+    if (i == 6)      // phases this configuration does not have (no viscous part, fused kernels): zero-length, closed here
+        for (int m = 1; m < 6; ++m)
+            if (!(hit & (1u << m))) (void)hipEventRecord(g_events[g_phase_base + m], g_stream);
+    hit |= 1u << i;
+    (void)hipEventRecord(g_events[g_phase_base + i], g_stream);
 }
 namespace {
 inline void phase_mark(int i) { adf_phase_mark(i); }

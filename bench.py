@@ -1,20 +1,30 @@
 #!/usr/bin/env python
 """Benchmark of the residual-evaluation hot path on MI355X.
 
-`python bench.py --gpus N --steps K --warmup W` — one "step" is ONE residual
-evaluation (blockette::blocketteRes core: time step + inviscid [+ viscous + SA]
-+ final sum) over every block of the workload, state resident in HBM.
+`python bench.py --gpus N --steps K --warmup W` -- one "step" is ONE residual
+evaluation over every block of the workload, state resident in HBM:
+whalo2 (2-layer ghost-cell exchange) + the blocketteRes core with its default
+flags (blockette.F90:118-140: exact residual, flow + turbulence, no
+intermediate update) -- what the NK matrix-free matvec, getResidual and the
+adjoint call.
+
+Default workload (BASELINE.json `metric` / configs[3]):
+CRM wing-body RANS-SA at roofline size, 8 blocks x 160x128x64 per GPU, Roe
+upwind with the van Albada limiter (kappa = 1/3).  Other configurations are
+reported under "extra" at N=1 (4b matrix dissipation, config 5 GMRES proxy,
+config 3 D-ADI iteration, config 2 Euler JST + 3-level W multigrid cycle).
 
 metric  : Mcells*residual-evals/s  (BASELINE.json)
 roofline: HBM-bound; algorithmic bytes/cell/eval from SURVEY.md §8(d)
-          (Euler 175 B, RANS-SA 255 B) over the live HIP-event duration of the
-          dominant kernel on the library's own stream.
+          (Euler 175 B, RANS-SA 255 B).  Per-kernel durations are measured live
+          with HIP events on the library's own stream (tuning "phase_events").
 cpu_baseline: the reference's own Fortran (oracle/_ref, "reference") timed on
           the host cores of this box on a bounded sample (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,17 +34,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: tutorial-wing multiblock Euler, JST scalar, roofline size (BASELINE.md §2)
-    "euler_jst_8x128": dict(equations=1, spaceDiscr=1, nblocks=8, dims=(128, 128, 128), bytes_per_cell=175.0),
-    # BASELINE.json configs[2]/[3] at roofline size (not the headline line; `--workload ...`):
-    # RANS + SA, viscous flux + SA residual, scalar JST / Roe upwind / matrix dissipation
-    "rans_sa_jst_8x128x128x96": dict(equations=3, spaceDiscr=1, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
-    "rans_sa_upwind_8x128x128x96": dict(equations=3, spaceDiscr=9, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
-    "rans_sa_matrix_8x128x128x96": dict(equations=3, spaceDiscr=2, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0),
-    # same cell count as the headline, cut into 512 blocks of 32^3 (what a production multiblock mesh looks like per GPU):
-    # measures how much of the rate survives small blocks (level-batched launches)
-    "euler_jst_512x32": dict(equations=1, spaceDiscr=1, nblocks=512, dims=(32, 32, 32), bytes_per_cell=175.0),
+    # BASELINE.json configs[3] (the configuration the metric is quoted on), SURVEY §8(d) rows 4a / 4b
+    "crm_rans_sa_upwind_8x160x128x64": dict(equations=3, spaceDiscr=9, nblocks=8, dims=(160, 128, 64), bytes_per_cell=255.0,
+                                            desc="RANS-SA, Roe upwind (van Albada, kappa=1/3)"),
+    "crm_rans_sa_matrix_8x160x128x64": dict(equations=3, spaceDiscr=2, nblocks=8, dims=(160, 128, 64), bytes_per_cell=255.0,
+                                            desc="RANS-SA, matrix dissipation (vis4=0.1)"),
+    # BASELINE.json configs[1]: tutorial-wing multiblock Euler, JST scalar, roofline size
+    "euler_jst_8x128": dict(equations=1, spaceDiscr=1, nblocks=8, dims=(128, 128, 128), bytes_per_cell=175.0,
+                            desc="Euler, central + scalar JST"),
+    # BASELINE.json configs[2] at roofline size
+    "rans_sa_jst_8x128x128x96": dict(equations=3, spaceDiscr=1, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0,
+                                     desc="RANS-SA, scalar JST"),
+    "rans_sa_upwind_8x128x128x96": dict(equations=3, spaceDiscr=9, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0,
+                                        desc="RANS-SA, Roe upwind (van Albada)"),
+    "rans_sa_matrix_8x128x128x96": dict(equations=3, spaceDiscr=2, nblocks=8, dims=(128, 128, 96), bytes_per_cell=255.0,
+                                        desc="RANS-SA, matrix dissipation (vis4=0.1)"),
+    # same cell count as the Euler workload, cut into 512 blocks of 32^3 (a production multiblock mesh per GPU)
+    "euler_jst_512x32": dict(equations=1, spaceDiscr=1, nblocks=512, dims=(32, 32, 32), bytes_per_cell=175.0,
+                             desc="Euler, central + scalar JST, 32^3 blocks"),
 }
+DEFAULT_WORKLOAD = "crm_rans_sa_upwind_8x160x128x64"
+PHASES = ["closures+bc", "time step", "SA residual", "inviscid", "nodal gradients", "viscous"]   # between marks 0..6 of api.hip
 
 
 CPU_WORKER = r"""
@@ -43,19 +63,19 @@ sys.path.insert(0, sys.argv[1])
 from adflow_amd.params import FlowParams
 from adflow_amd.synth import make_block
 from oracle import ref
-n1, n2, n3, equations, seconds, seed = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]), int(sys.argv[7])
-prm = FlowParams(equations=equations)
-blk = make_block(n1, n2, n3, prm, seed=seed)
+n1, n2, n3, equations, spaceDiscr, seconds, seed = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]),
+                                                    int(sys.argv[6]), float(sys.argv[7]), int(sys.argv[8]))
+prm = FlowParams(equations=equations, spaceDiscr=spaceDiscr, vis4=0.1 if spaceDiscr == 2 else 0.0156)
+blk = make_block(n1, n2, n3, prm, seed=seed, stretch_k=3.0 if equations == 3 else 1.0)
 ref.bind_block(blk, prm)
-n, dt = ref.time_block_res_core(seconds, True, True, equations == 3)
+n, dt = ref.time_block_res_core(seconds, False, True, equations == 3)
 print(json.dumps({"rate": blk.ncells * n / dt}))
 """
 
 
-def cpu_baseline(equations, seconds=12.0, max_cores=32, dims=(64, 64, 64)):
+def cpu_baseline(equations, spaceDiscr, seconds=12.0, max_cores=32, dims=(64, 64, 64)):
     """The reference's own Fortran (oracle/_ref) on this box's host cores: one
     pinned process per core, each repeating blockResCore on its own block."""
-    import subprocess
     from oracle import ref
     if not ref.available():
         return None
@@ -64,7 +84,7 @@ def cpu_baseline(equations, seconds=12.0, max_cores=32, dims=(64, 64, 64)):
     procs = []
     for i in range(cores):
         cmd = ["taskset", "-c", str(avail[i]), sys.executable, "-c", CPU_WORKER, ROOT,
-               str(dims[0]), str(dims[1]), str(dims[2]), str(equations), str(seconds), str(100 + i)]
+               str(dims[0]), str(dims[1]), str(dims[2]), str(equations), str(spaceDiscr), str(seconds), str(100 + i)]
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
     rates = []
     deadline = time.time() + seconds + 120.0
@@ -76,9 +96,11 @@ def cpu_baseline(equations, seconds=12.0, max_cores=32, dims=(64, 64, 64)):
             pr.kill()
     if not rates:
         return None
+    what = {1: "Euler", 2: "laminar NS", 3: "RANS-SA"}[equations] + {1: " scalar JST", 2: " matrix dissipation", 9: " Roe upwind"}[spaceDiscr]
     return {"value": sum(rates) / 1e6, "unit": "Mcells*residual-evals/s", "cores": len(rates), "kind": "reference",
-            "sample": f"{len(rates)} pinned processes x one {dims[0]}x{dims[1]}x{dims[2]} block each, ~{seconds:.0f} s of "
-                      "blockResCore evaluations of the reference Fortran (amdflang -O3 -fdefault-real-8); no MPI halo exchange",
+            "sample": f"{len(rates)} pinned processes x one {dims[0]}x{dims[1]}x{dims[2]} block each ({what}), ~{seconds:.0f} s of "
+                      "blockResCore evaluations (blockette.F90:755-852, updateIntermed=F) of the reference Fortran "
+                      "(amdflang -O3 -fdefault-real-8); no MPI halo exchange",
             "per_core": sum(rates) / len(rates) / 1e6}
 
 
@@ -89,21 +111,172 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def rank_grid(n):
+    """ranks as an rx x ry x rz grid, as cubic as possible (8 -> 2x2x2: three face peers + edge / corner peers per GPU)"""
+    g = [1, 1, 1]
+    d = 0
+    while n > 1:
+        f = 2 if n % 2 == 0 else n
+        g[d % 3] *= f
+        n //= f
+        d += 1
+    return tuple(g)
+
+
+def w_cycle(nlev):
+    """cycleStrategy of an `nlev`w cycle (inputParamRoutines.F90:1127-1180 setEntriesWcycle)"""
+    if nlev == 2:
+        return [0, 1, 0, -1]
+    return [0, 1] + w_cycle(nlev - 1) + w_cycle(nlev - 1) + [0, -1]
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible on this node")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Job:
+    """One workload resident on this rank's GPU."""
+
+    def __init__(self, a, name, eng, rank, world, levels=1, keep_w=False):
+        from adflow_amd.params import FlowParams
+        from adflow_amd.synth import make_block, make_coarse_block
+        from adflow_amd.topology import BrickTopology
+        import numpy as np
+        self.name, self.eng, self.rank, self.world = name, eng, rank, world
+        wl = self.wl = WORKLOADS[name]
+        self.prm = FlowParams(equations=wl["equations"], spaceDiscr=wl["spaceDiscr"], vis4=0.1 if wl["spaceDiscr"] == 2 else 0.0156)
+        eng.set_options(self.prm)
+        nb, dims = wl["nblocks"], wl["dims"]
+        e = round(nb ** (1.0 / 3.0))                 # per-GPU brick of e x e x e blocks
+        assert e ** 3 == nb
+        # weak scaling: every GPU owns an e^3 brick of blocks; the ranks form an rx x ry x rz grid of such bricks, periodic
+        # in all three directions, so every evaluation is preceded by the 2-layer exchange of blocketteRes (whalo2,
+        # blockette.F90:246): same-GPU copies + RCCL send/recv with up to 7 distinct peers at 8 ranks
+        rx, ry, rz = rank_grid(world)
+        self.grid = (rx, ry, rz)
+
+        def owner(g, Bi=e * rx, Bj=e * ry):
+            bi, bj, bk = g % Bi, (g // Bi) % Bj, g // (Bi * Bj)
+            return (bi // e) + rx * ((bj // e) + ry * (bk // e))
+        self.topo = [BrickTopology(e * rx, e * ry, e * rz, dims[0] >> l, dims[1] >> l, dims[2] >> l, owner=owner) for l in range(levels)]
+        lid = self.topo[0].local_ids()
+        self.cells_local = 0
+        self.wvec = []
+        for g in self.topo[0].blocks_of(rank):
+            blk = make_block(*dims, self.prm, seed=20260925 + g, stretch_k=3.0 if wl["equations"] == 3 else 1.0)
+            chain = [blk]
+            for l in range(1, levels):
+                chain.append(make_coarse_block(chain[-1], self.prm, seed=777 * l + g))   # also attaches the mg maps to the finer block
+            for l, b_ in enumerate(chain):
+                eng.register(b_, nn=lid[g], level=l + 1)
+            self.cells_local += blk.ncells
+            if keep_w:   # PETSc vector order: block, k, j, i, variable fastest (NKSolvers.F90:1240-1253)
+                wo = blk["w"][2:blk.il + 1, 2:blk.jl + 1, 2:blk.kl + 1, :]
+                self.wvec.append(np.ascontiguousarray(wo.transpose(2, 1, 0, 3)).ravel())
+            for b_ in chain:       # host copies are no longer needed by the timed loops
+                for k in list(b_.a.keys()):
+                    if k not in ("dw",):
+                        del b_.a[k]
+            log(f"{name}: block {lid[g]}/{nb} generated and uploaded")
+        self.halo = "off"
+        self.cp = []
+        try:
+            for l in range(levels):
+                cp = self.topo[l].patterns(2 if l == 0 else 1, only_rank=rank)[rank]
+                eng.comm_register(l + 1, 2 if l == 0 else 1, cp)
+                self.cp.append(cp)
+            cp = self.cp[0]
+            log(f"comm pattern: {cp.ncopy} local copies, {int(cp.nsendCum[-1])} cells sent to {cp.sendProc.size} peer ranks")
+            self.peers = int(cp.sendProc.size)
+            eng.whalo2(1, 1, self.prm.nw)
+            self.halo = "whalo2 every step: same-GPU copies" + (f" + RCCL send/recv over xGMI with {self.peers} peers" if world > 1 else "")
+        except Exception as ex:  # the evaluation of independent shards is still a valid measurement
+            self.halo = f"FAILED ({ex}); shards evaluated without exchange"
+            log("halo exchange unavailable: " + str(ex))
+        self.do_halo = not self.halo.startswith("FAILED")
+
+    def step(self):
+        if self.do_halo:
+            self.eng.whalo2(1, 1, self.prm.nw)
+        # blocketteRes core with the reference's default flags: updateIntermed = F, flowRes = T, turbRes = T
+        self.eng.blocketteRes(1, False, True, self.wl["equations"] == 3)
+
+
+def timed(eng, fn, steps, barrier, min_seconds=1.0, max_reps=2000):
+    """Time `steps` calls of fn, repeated until the region lasts >= min_seconds (the driver's busy sampler needs that);
+    returns (seconds per step, repeats, event ms per step)."""
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    probe = time.perf_counter() - t0
+    reps = int(min(max_reps, max(1, -(-min_seconds // max(probe, 1e-6)))))
+    barrier()
+    t0 = time.perf_counter()
+    eng.event_record(0)
+    for _ in range(reps):
+        for _ in range(steps):
+            fn()
+    eng.event_record(1)
+    barrier()
+    dt = time.perf_counter() - t0
+    return dt / (reps * steps), reps, eng.event_elapsed_ms(0, 1) / (reps * steps)
+
+
+def phase_times(eng, fn, n=10):
+    """live HIP-event durations (ms) between the phase marks of blocketteRes, averaged over n evaluations"""
+    base = 40
+    eng.set_tuning("phase_events", base)
+    acc = [0.0] * 6
+    ok = [0] * 6
+    for _ in range(n):
+        fn()
+        eng.sync()
+        last = 0
+        for m in range(1, 7):
+            try:
+                acc[m - 1] += eng.event_elapsed_ms(base + last, base + m)
+                ok[m - 1] += 1
+                last = m
+            except Exception:
+                pass        # mark not recorded by this configuration (e.g. no viscous part)
+    eng.set_tuning("phase_events", 0)
+    return {PHASES[m]: acc[m] / ok[m] for m in range(6) if ok[m]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="euler_jst_8x128")
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mg", action="store_true", help="skip the MG-cycles/s measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported under 'extra' (N=1)")
+    ap.add_argument("--no-mg", action="store_true", help="skip the config-2 multigrid cycle measurement")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K steps until the region lasts this long")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     import torch
@@ -114,78 +287,28 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
+    import numpy as np
+    from adflow_amd import capi
     from adflow_amd.engine import Engine
-    from adflow_amd.params import FlowParams
-    from adflow_amd.synth import make_block
+    from adflow_amd.params import DADI, RungeKutta, alternateResAveraging, noResAveraging
 
-    wl = WORKLOADS[a.workload]
-    prm = FlowParams(equations=wl["equations"], spaceDiscr=wl["spaceDiscr"],
-                     vis4=0.1 if wl["spaceDiscr"] == 2 else 0.0156)
     eng = Engine(local_rank)
-    eng.set_options(prm)
     tuning = dict(kv.split("=") for kv in a.tuning)
     for k_, v_ in tuning.items():
         eng.set_tuning(k_, int(v_))
-    march = int(tuning.get("euler_march", 1)) and wl["equations"] == 1 and wl["spaceDiscr"] == 1
-    # weak scaling: every GPU owns `nblocks` blocks (a 2x2x2 brick) of the workload; the
-    # ranks' bricks are chained along i into one periodic brick of (2N)x2x2 blocks, so
-    # every evaluation is preceded by the 2-layer halo exchange the reference's
-    # blocketteRes performs (whalo2, blockette.F90:246): same-GPU copies + RCCL p2p
-    from adflow_amd.topology import BrickTopology
-    nb = wl["nblocks"]
-    dims = wl["dims"]
-    e = round(nb ** (1.0 / 3.0))                 # per-GPU brick of e x e x e blocks
-    assert e ** 3 == nb
-    topo = BrickTopology(e * world, e, e, *dims, owner=lambda g: (g % (e * world)) // e)
-    lid = topo.local_ids()
-    cells_local = 0
-    from adflow_amd.synth import make_coarse_block
-    for g in topo.blocks_of(rank):
-        blk = make_block(*dims, prm, seed=20260925 + g, stretch_k=3.0 if wl["equations"] == 3 else 1.0)
-        both = [blk]
-        if not a.no_mg and wl["equations"] != 3:     # RANS workloads time a single-grid iteration (config 3)
-            cblk = make_coarse_block(blk, prm, seed=777 + g)   # also attaches mgI/J/KCoarse to blk
-            both.append(cblk)
-        eng.register(blk, nn=lid[g], level=1)
-        if len(both) > 1:
-            eng.register(cblk, nn=lid[g], level=2)
-        cells_local += blk.ncells
-        log(f"block {lid[g]}/{nb} generated and uploaded")
-        # host copies are no longer needed by the timed loop
-        for b_ in both:
-            for k in list(b_.a.keys()):
-                if k not in ("dw",):
-                    del b_.a[k]
-    halo = "off"
-    try:
-        cp = topo.patterns(2, only_rank=rank)[rank]
-        eng.comm_register(1, 2, cp)
-        log(f"comm pattern: {cp.ncopy} local copies, {int(cp.nsendCum[-1])} cells sent to {cp.sendProc.size} ranks")
-        # RCCL communicator of the library (also at N=1: exercises the bootstrap)
-        idbuf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            import ctypes
-            raw = (ctypes.c_char * 128)()
-            from adflow_amd import capi
-            capi.check(eng.lib.adflow_gpu_comm_unique_id(raw), eng.lib)
-            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-        if world > 1:
-            idg = idbuf.cuda()
-            dist.broadcast(idg, 0)
-            idbuf = idg.cpu()
-        from adflow_amd import capi
-        capi.check(eng.lib.adflow_gpu_comm_init(rank, world, idbuf.numpy().tobytes()), eng.lib)
-        eng.whalo2(1, 1, prm.nw)
-        halo = "whalo2 every step: same-GPU copies" + (" + RCCL send/recv over xGMI" if world > 1 else "")
-    except Exception as e:  # the evaluation of independent shards is still a valid measurement
-        halo = f"FAILED ({e}); shards evaluated without exchange"
-        log("halo exchange unavailable: " + str(e))
-    do_halo = not halo.startswith("FAILED")
 
-    def step():
-        if do_halo:
-            eng.whalo2(1, 1, prm.nw)
-        eng.blocketteRes(1, True, True, wl["equations"] == 3)
+    # RCCL communicator of the library (also at N=1: exercises the bootstrap)
+    import ctypes
+    idbuf = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        raw = (ctypes.c_char * 128)()
+        capi.check(eng.lib.adflow_gpu_comm_unique_id(raw), eng.lib)
+        idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+    if world > 1:
+        idg = idbuf.cuda()
+        dist.broadcast(idg, 0)
+        idbuf = idg.cpu()
+    capi.check(eng.lib.adflow_gpu_comm_init(rank, world, idbuf.numpy().tobytes()), eng.lib)
 
     def barrier():
         if world > 1:
@@ -193,145 +316,181 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
+    extras_on = (world == 1 and not a.no_extras and a.workload == DEFAULT_WORKLOAD and not a.tuning)
+    job = Job(a, a.workload, eng, rank, world, keep_w=extras_on)
+    wl, prm = job.wl, job.prm
     eng.set_async(True)
     for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    eng.event_record(0)
-    for _ in range(a.steps):
-        step()
-    eng.event_record(1)
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = eng.event_elapsed_ms(0, 1)
-    log(f"timed loop done: {dt / a.steps * 1e3:.3f} ms/step")
+        job.step()
+    sec_step, reps, ev_ms = timed(eng, job.step, a.steps, barrier, a.min_seconds)
+    log(f"timed loop done: {sec_step * 1e3:.3f} ms/step ({reps} x {a.steps} steps)")
+    if world > 1:
+        t = torch.tensor([sec_step], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec_step = float(t.item())
+    cells_total = job.cells_local * world
+    value = cells_total / sec_step / 1e6
 
-    # dominant kernel alone (flux kernel: `residual` entry = initres+residual_block), live HIP events
-    from adflow_amd.params import DADI
-    eng.set_options(prm.replace(smoother=DADI))   # rFil = 1, non-persistent fw: the variant blocketteRes launches
-    for _ in range(2):
-        eng.residual(1, 0)
-    eng.event_record(2)
-    for _ in range(a.steps):
-        eng.residual(1, 0)
-    eng.event_record(3)
-    eng.sync()
-    # the k-marching Euler kernel covers all blocks of the level in ONE launch
-    launches_per_step = 1 if march else nb
-    k_ms = eng.event_elapsed_ms(2, 3) / (a.steps * launches_per_step)
+    # ---- per-kernel durations of one evaluation, live HIP events on the library's stream
     eng.set_async(False)
+    ph = phase_times(eng, job.step)
+    log("phases (ms): " + ", ".join(f"{k} {v:.3f}" for k, v in ph.items()))
+    kern = {k: v for k, v in ph.items() if k != "closures+bc"}
+    dom = max(kern, key=kern.get)
 
-    # ---- second headline metric: multigrid cycles / s (2-level V cycle, RK smoother) ----
-    mg = None
-    if not a.no_mg:
+    extra = {}
+    if extras_on:
         try:
-            from adflow_amd.params import RungeKutta, DADI, alternateResAveraging, noResAveraging
-            rans = wl["equations"] == 3
-            if rans:
-                # BASELINE config 3 (test_functionals.py:136-160): single grid, D-ADI with 3 sub-iterations,
-                # 3 SA DDADI sub-iterations, cfl 1.5, no residual averaging: one "cycle" = one solver iteration
-                eng.set_options(prm.replace(smoother=DADI, nSubiterations=3, nSubIterTurb=3, cfl=1.5, resAveraging=noResAveraging))
-                cyc_desc = "single grid: D-ADI x3 sub-iterations + SA DDADI x3 (BASELINE config 3)"
-            else:
-                # pyADflow defaults (pyADflow.py:5697-5731): RK smoother, "alternate" residual averaging
-                eng.set_options(prm.replace(smoother=RungeKutta, resAveraging=alternateResAveraging))
-                cyc_desc = "2-level V: smooth(RK5, alternate residual averaging) / restrict / smooth / prolong + closing residual"
-            ctopo = BrickTopology(e * world, e, e, dims[0] // 2, dims[1] // 2, dims[2] // 2, owner=topo.owner)
-            if do_halo:
-                eng.comm_register(1, 2, cp)
-                if not rans:
-                    eng.comm_register(2, 1, ctopo.patterns(1, only_rank=rank)[rank])
-            log("multigrid levels registered")
-            cyc = [0] if rans else [0, 1, 0, -1]
+            # ---- config 4b: matrix dissipation on the same blocks
+            p4b = prm.replace(spaceDiscr=2, vis4=0.1)
+            eng.set_options(p4b)
+            eng.set_async(True)
+            for _ in range(3):
+                job.step()
+            s4b, r4b, e4b = timed(eng, job.step, a.steps, barrier, a.min_seconds)
             eng.set_async(False)
+            ph4b = phase_times(eng, job.step)
+            extra["crm_rans_sa_matrix_8x160x128x64"] = {
+                "value": job.cells_local / s4b / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_step": s4b * 1e3,
+                "whole_eval_hbm_frac": 255.0 * job.cells_local / s4b / 1e9 / HBM_PEAK_GBS, "phase_ms": ph4b}
+            log(f"4b matrix: {s4b * 1e3:.3f} ms/step")
+            eng.set_options(prm)
+            # ---- config 5: GMRES proxy, 30 matrix-free matvecs FormFunction_mf(w + h v_k) (NKSolvers.F90:437-461), vectors on the device
+            n = sum(v.size for v in job.wvec)
+            w0 = torch.from_numpy(np.concatenate(job.wvec)).cuda()
+            job.wvec = []
+            gen = torch.Generator(device="cuda").manual_seed(5)
+            vk = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 0.5
+            vk /= vk.norm()
+            wk = w0 + 1e-7 * vk
+            rv = torch.empty_like(w0)
+            torch.cuda.synchronize()
+
+            def matvec():
+                capi.check(eng.lib.adflow_gpu_nk_residual_dev(wk.data_ptr(), rv.data_ptr(), n), eng.lib)
+            eng.set_async(True)
+            for _ in range(3):
+                matvec()
+            s5, r5, e5 = timed(eng, matvec, 30, barrier, a.min_seconds)
+            eng.set_async(False)
+            extra["config5_gmres_proxy"] = {
+                "value": job.cells_local / s5 / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_matvec": s5 * 1e3,
+                "ms_per_30_matvecs": 30 * s5 * 1e3, "bytes_per_cell": 255.0 + 96.0,
+                "whole_eval_hbm_frac": (255.0 + 96.0) * job.cells_local / s5 / 1e9 / HBM_PEAK_GBS,
+                "what": "setW + blocketteRes(default flags: closures, BCs, whalo2, core) + setRVec at w + 1e-7 v, device vectors"}
+            log(f"config 5 proxy: {s5 * 1e3:.3f} ms/matvec")
+            del w0, vk, wk, rv
+            # restore the state (setW clipped / perturbed it by 1e-7) is not needed: the remaining extras re-time only
+            # ---- config 3: one solver iteration = D-ADI x3 sub-iterations + SA DDADI x3 (test_functionals.py:136-160)
+            eng.set_options(prm.replace(spaceDiscr=1, smoother=DADI, nSubiterations=3, nSubIterTurb=3, cfl=1.5, resAveraging=noResAveraging))
             eng.timeStep(1, False)
             eng.residual(1, 0)
             for _ in range(2):
-                eng.executeMGCycle(cyc)
-            barrier()
-            ncyc = max(5, a.steps // 5)
-            t1 = time.perf_counter()
-            for _ in range(ncyc):
-                eng.executeMGCycle(cyc)
-            barrier()
-            dt_mg = time.perf_counter() - t1
-            if world > 1:
-                tt = torch.tensor([dt_mg], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt_mg = float(tt.item())
-            # algorithmic bytes of one cycle: sum over levels of n_smooth x nStages x (B_res + B_upd)
-            # + the residuals of the transfers + restriction / prolongation, level l holding N / 8^l cells
-            if rans:
-                b_res, b_dadi, b_upd = 255.0 + 32.0, 244.0, 224.0
-                per_cell = 3 * (b_res + b_dadi + b_upd)            # SA DDADI sweeps not in the §8(d) table: left out
-                formula = "3 x (B_res 287 + B_dadi 244 + B_upd 224) B per cell, SA solve not counted"
-            else:
-                b_res, b_upd, b_ts, b_tr = 175.0, 200.0, 32.0, 8.0 * (2 * 5 + 2)
-                smooth = 5 * (b_res + b_upd)
-                per_cell = smooth + (b_res + b_ts) + (b_res + smooth) / 8.0 + b_tr + (b_res + b_ts)
-                formula = ("fine RK5 5 x (175 + 200) + restriction residual (175 + 32) + coarse [forcing residual 175 + RK5] / 8 "
-                           "+ transfers 96 + closing residual (175 + 32) B per fine cell")
-            alg_cycle = per_cell * cells_local * world
-            mg = {"cycles_per_s": ncyc / dt_mg, "ms_per_cycle": dt_mg / ncyc * 1e3, "cycles_timed": ncyc,
-                  "cycle": cyc_desc,
-                  "fine_cells_per_gpu": cells_local,
-                  "algorithmic_bytes_per_cycle": alg_cycle, "algorithmic_bytes_formula": formula,
-                  "hbm_frac": alg_cycle / (dt_mg / ncyc) / (8.0e12 * world)}
-            log(f"MG: {mg['ms_per_cycle']:.3f} ms/cycle")
-        except Exception as e:
-            mg = {"error": str(e)}
-            log("MG benchmark failed: " + str(e))
-
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    cells_total = cells_local * world
-    value = cells_total * a.steps / dt / 1e6
+                eng.executeMGCycle([0])
+            s3, r3, e3 = timed(eng, lambda: eng.executeMGCycle([0]), 5, barrier, a.min_seconds)
+            b_res, b_dadi, b_upd = 255.0 + 32.0, 244.0, 224.0
+            extra["config3_dadi_iteration"] = {
+                "iterations_per_s": 1.0 / s3, "ms_per_iteration": s3 * 1e3,
+                "what": "single grid on the same blocks with scalar JST: D-ADI x3 sub-iterations + SA DDADI x3",
+                "hbm_frac": 3 * (b_res + b_dadi + b_upd) * job.cells_local / s3 / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_formula": "3 x (B_res 287 + B_dadi 244 + B_upd 224) B per cell, SA solve not counted"}
+            log(f"config 3 iteration: {s3 * 1e3:.3f} ms")
+            eng.set_options(prm)
+        except Exception as ex:
+            extra["error_rans_extras"] = str(ex)
+            log("RANS extras failed: " + str(ex))
 
     out = None
     if rank == 0:
-        # HBM-side bytes per launch of the dominant kernel from the PMC passes over this very command
-        # (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 correction of
-        # MI355X_MICROARCH.md applied; tools/pmc_traffic.py writes the file, the raw summary sits beside it)
+        # HBM-side bytes per launch from the PMC passes (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs,
+        # tools/pmc_traffic.py writes the file with the git hash it was measured at; the raw summaries sit beside it)
         traffic, traffic_src = None, None
         try:
             tf = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             ent = tf.get(a.workload)
             if ent and not a.tuning:
-                traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
+                traffic, traffic_src = ent, ent.get("source")
         except (OSError, ValueError, KeyError):
             pass
-        cells_per_launch = cells_local / launches_per_step
-        alg_bytes = wl["bytes_per_cell"] * cells_per_launch
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        alg_bytes = wl["bytes_per_cell"] * job.cells_local
+        eval_ms = sum(kern.values())
+        dom_traffic = None
+        if traffic:
+            dom_traffic = traffic.get("kernels", {}).get(dom, {}).get("traffic_bytes_per_launch")
+        achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
         out = {
             "metric": "Mcells*residual-evals/s", "value": value, "unit": "Mcells*residual-evals/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec_step * 1e3, "repeats": reps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {nb} blocks x {wl['dims'][0]}x{wl['dims'][1]}x{wl['dims'][2]} cells per GPU, "
-                                   + ("Euler, central + scalar JST" if wl["equations"] == 1 else "RANS-SA, spaceDiscr=%d" % wl["spaceDiscr"])
-                                   + ", one residual evaluation per step (whalo2 + blocketteRes core)",
-                       "halo_exchange": halo,
-                       "cells_per_gpu": cells_local, "device": eng.device_name()},
+            "config": {"workload": f"{a.workload}: {wl['nblocks']} blocks x {wl['dims'][0]}x{wl['dims'][1]}x{wl['dims'][2]} cells per GPU, "
+                                   + wl["desc"] + ", one residual evaluation per step (whalo2 + blocketteRes core, default flags)",
+                       "halo_exchange": job.halo, "rank_grid": "x".join(map(str, job.grid)),
+                       "cells_per_gpu": job.cells_local, "device": eng.device_name()},
+            # the evaluation is several kernels (SA, inviscid, nodal gradients, viscous): `achieved` prices the WHOLE
+            # evaluation (sum of the kernels' live event durations) against the 255 / 175 B per cell of SURVEY §8(d);
+            # dominant_kernel is the longest of them
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_euler_march_p" if march else ("k_inviscid" if wl["equations"] == 1 else
-                                                                   "k_inviscid + k_nodal_gradients + k_viscous (one block)"),
-                         "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            "mg": mg,
-            "whole_eval": {"event_ms_per_step": ev_ms / a.steps,
-                           "hbm_frac": wl["bytes_per_cell"] * cells_local / (ev_ms / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic or {}).get("traffic_bytes_per_eval"), "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_eval": alg_bytes, "kernels_ms": kern, "eval_kernels_ms": eval_ms,
+                         "dominant_kernel": dom, "dominant_kernel_ms": kern[dom], "dominant_kernel_traffic": dom_traffic,
+                         "dominant_kernel_share": kern[dom] / eval_ms},
+            "whole_eval": {"event_ms_per_step": ev_ms, "halo_and_gaps_ms": ev_ms - eval_ms,
+                           "hbm_frac": alg_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+
+    # ---- config 2: Euler JST + 3-level W multigrid cycle (N=1 extras, or the workload itself when asked for)
+    if extras_on and not a.no_mg:
+        try:
+            eng.release_all()
+            del job
+            j2 = Job(a, "euler_jst_8x128", eng, rank, world, levels=3)
+            eng.set_async(True)
+            for _ in range(3):
+                j2.step()
+            s2, r2, e2 = timed(eng, j2.step, a.steps, barrier, a.min_seconds)
+            eng.set_async(False)
+            ph2 = phase_times(eng, j2.step)
+            extra["euler_jst_8x128"] = {"value": j2.cells_local / s2 / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_step": s2 * 1e3,
+                                        "whole_eval_hbm_frac": 175.0 * j2.cells_local / s2 / 1e9 / HBM_PEAK_GBS, "phase_ms": ph2}
+            log(f"config 2 Euler: {s2 * 1e3:.3f} ms/step")
+            # pyADflow defaults (pyADflow.py:5697-5731): RK smoother, "alternate" residual averaging, cflCoarse 1.0, fcoll 0.8
+            eng.set_options(j2.prm.replace(smoother=RungeKutta, resAveraging=alternateResAveraging))
+            cyc = w_cycle(3)
+            eng.timeStep(1, False)
+            eng.residual(1, 0)
+            for _ in range(2):
+                eng.executeMGCycle(cyc)
+            smg, rmg, emg = timed(eng, lambda: eng.executeMGCycle(cyc), 3, barrier, a.min_seconds)
+            # algorithmic bytes of the cycle: per level visit nStages x (B_res + B_upd); level l has N / 8^l cells
+            b_res, b_upd, b_ts, b_tr = 175.0, 200.0, 32.0, 8.0 * (2 * 5 + 2)
+            lvl, per_cell = 0, 0.0
+            for c_ in cyc:
+                if c_ == 0:
+                    per_cell += 5 * (b_res + b_upd) / 8 ** lvl
+                elif c_ == 1:
+                    per_cell += (b_res + b_ts + b_tr) / 8 ** lvl + b_res / 8 ** (lvl + 1)
+                    lvl += 1
+                else:
+                    lvl -= 1
+                    per_cell += b_tr / 8 ** lvl
+            per_cell += b_res + b_ts
+            extra["mg_3w_cycle"] = {"cycles_per_s": 1.0 / smg, "ms_per_cycle": smg * 1e3, "cycle": "3w: " + " ".join(map(str, cyc)),
+                                    "what": "RK5 + alternate residual averaging on every visit, cflCoarse 1.0, vis2Coarse 0.5, fcoll 0.8",
+                                    "fine_cells_per_gpu": j2.cells_local, "algorithmic_bytes_per_fine_cell": per_cell,
+                                    "hbm_frac": per_cell * j2.cells_local / smg / 1e9 / HBM_PEAK_GBS}
+            log(f"3w MG cycle: {smg * 1e3:.3f} ms")
+        except Exception as ex:
+            extra["error_config2"] = str(ex)
+            log("config 2 extras failed: " + str(ex))
     eng.close()
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
+        out["extra"] = extra or None
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (reference Fortran on the host cores) ...")
-            out["cpu_baseline"] = cpu_baseline(wl["equations"])
+            out["cpu_baseline"] = cpu_baseline(wl["equations"], wl["spaceDiscr"])
             log("cpu baseline done")
         else:
             out["cpu_baseline"] = None

@@ -1,0 +1,86 @@
+// Calibration helpers run on the GPU box next to the profiles (test / measurement infrastructure, not product code):
+//   copy8 / copy16 : streaming copies of a known byte count with 8-byte and 16-byte accesses per lane, so that the
+//                    FETCH_SIZE / WRITE_SIZE counters of rocprofv3 can be calibrated for the access widths the flux
+//                    kernels use (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own pattern");
+//   probe          : accuracy of the raw v_rcp_f64 / v_rsq_f64 seeds and of rcp_nr / rsq_nr after 1 and 2 Newton steps
+//                    (internal.h), which decides ADF_NR.
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/pmc_calib.bin tools/pmc_calib.hip
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+__global__ void copy8(double* __restrict__ d, const double* __restrict__ s, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+__global__ void copy16(double2* __restrict__ d, const double2* __restrict__ s, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+// five separate 8-byte streams read, one written (the access shape of the flux kernels: SoA components)
+__global__ void read5w1(double* __restrict__ d, const double* __restrict__ s, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        d[i] = s[i] + s[i + n] + s[i + 2 * n] + s[i + 3 * n] + s[i + 4 * n];
+}
+
+template <int NR>
+__global__ void probe(const double* __restrict__ x, double* __restrict__ rc, double* __restrict__ rs, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double b = x[i];
+    double r = __builtin_amdgcn_rcp(b);
+    for (int it = 0; it < NR; ++it) { const double e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r); }
+    double y = __builtin_amdgcn_rsq(b);
+    for (int it = 0; it < NR; ++it) { const double t = b * y; const double e = __builtin_fma(-t, y, 1.0); y = __builtin_fma(0.5 * y, e, y); }
+    rc[i] = r; rs[i] = y;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv)
+{
+    const char* mode = argc > 1 ? argv[1] : "all";
+    if (!strcmp(mode, "copy") || !strcmp(mode, "all")) {
+        const size_t n = (size_t)1 << 27;          // 128 Mi doubles = 1 GiB per stream: far beyond the 256 MiB Infinity Cache
+        double *s, *d;
+        CK(hipMalloc(&s, 5 * n * sizeof(double) / 4 + n * sizeof(double)));   // read5w1 reads 5 streams of n/4
+        CK(hipMalloc(&d, n * sizeof(double)));
+        CK(hipMemset(s, 0, 5 * n * sizeof(double) / 4 + n * sizeof(double)));
+        for (int it = 0; it < 5; ++it) {
+            hipLaunchKernelGGL(copy8, dim3(8192), dim3(256), 0, 0, d, s, n);
+            hipLaunchKernelGGL(copy16, dim3(8192), dim3(256), 0, 0, (double2*)d, (const double2*)s, n / 2);
+            hipLaunchKernelGGL(read5w1, dim3(8192), dim3(256), 0, 0, d, s, n / 4);
+        }
+        CK(hipDeviceSynchronize());
+        printf("copy8: reads %zu B writes %zu B per launch; copy16: the same; read5w1: reads %zu B writes %zu B\n", n * 8, n * 8,
+               5 * (n / 4) * 8, (n / 4) * 8);
+    }
+    if (!strcmp(mode, "probe") || !strcmp(mode, "all")) {
+        const size_t n = 1 << 22;
+        std::vector<double> hx(n), hr(n), hs(n);
+        srand(7);
+        for (size_t i = 0; i < n; ++i) hx[i] = exp(((double)rand() / RAND_MAX) * 92.0 - 46.0);   // 1e-20 .. 1e20
+        double *x, *rc, *rs;
+        CK(hipMalloc(&x, n * 8)); CK(hipMalloc(&rc, n * 8)); CK(hipMalloc(&rs, n * 8));
+        CK(hipMemcpy(x, hx.data(), n * 8, hipMemcpyHostToDevice));
+        for (int nr = 0; nr <= 2; ++nr) {
+            if (nr == 0) hipLaunchKernelGGL(probe<0>, dim3((n + 255) / 256), dim3(256), 0, 0, x, rc, rs, n);
+            if (nr == 1) hipLaunchKernelGGL(probe<1>, dim3((n + 255) / 256), dim3(256), 0, 0, x, rc, rs, n);
+            if (nr == 2) hipLaunchKernelGGL(probe<2>, dim3((n + 255) / 256), dim3(256), 0, 0, x, rc, rs, n);
+            CK(hipMemcpy(hr.data(), rc, n * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hs.data(), rs, n * 8, hipMemcpyDeviceToHost));
+            double er = 0, es = 0;
+            for (size_t i = 0; i < n; ++i) {
+                er = fmax(er, fabs(hr[i] * hx[i] - 1.0));
+                es = fmax(es, fabs(hs[i] * sqrt(hx[i]) - 1.0));
+            }
+            printf("NR=%d  max rel err  rcp %.3e   rsq %.3e\n", nr, er, es);
+        }
+    }
+    return 0;
+}

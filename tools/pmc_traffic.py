@@ -1,36 +1,86 @@
 #!/usr/bin/env python
-"""HBM-side traffic per launch of one kernel from two rocprofv3 --pmc passes
-(FETCH_SIZE in one, WRITE_SIZE in the other: they do not fit one pass, MI355X_MICROARCH.md
-"rocprofv3 PMC slots").  Units and corrections as that guide prescribes for gfx950:
-both counters are in KiB; FETCH_SIZE reports half of the bytes of a coalesced streaming
-read (TCC_EA0_RDREQ x 64 B while the requests are 128 B) and is doubled; WRITE_SIZE was
-calibrated here against the known store volume of the kernel (5 doubles per owned cell)
-and needs no correction.
+"""HBM-side traffic per launch of the kernels of one residual evaluation from two rocprofv3 --pmc passes
+(FETCH_SIZE in one, WRITE_SIZE in the other: they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC
+slots").  Both counters are reported in KiB.  On gfx950 FETCH_SIZE under-reports coalesced streaming reads
+(TCC_EA0_RDREQ x 64 B while the requests are 128 B); the factor depends on the access width, so it is CALIBRATED
+on the same box with tools/pmc_calib.bin (copies of a known byte count with 8-byte SoA streams -- the access
+shape of the flux kernels -- and with 16-byte accesses) and the 8-byte SoA factor is applied.
 
-usage: pmc_traffic.py <fetch.db> <write.db> <kernel substring> <workload> <out.json> <source note>"""
+usage:
+  pmc_traffic.py calib <fetch.db> <write.db> <out.json>
+  pmc_traffic.py bench <fetch.db> <write.db> <workload> <out.json> <git hash> <source note>
+"""
 import json
 import os
 import sqlite3
 import sys
 
+PHASE_OF = [("k_roe_march", "inviscid"), ("k_inviscid_march", "inviscid"), ("k_inviscid<", "inviscid"), ("k_euler_march", "inviscid"),
+            ("k_sa_residual", "SA residual"), ("k_nodal_gradients", "nodal gradients"), ("k_node_grad", "nodal gradients"),
+            ("k_viscous", "viscous"), ("k_time_step", "time step"), ("k_halo_copy", "halo copies"), ("k_entropy", "entropy sensor")]
 
-def avg(db, counter, kern):
+
+def per_kernel(db, counter):
     c = sqlite3.connect(db)
-    r = c.execute("select avg(value), count(*) from counters_collection where counter_name=? and kernel_name like ?",
-                  (counter, "%" + kern + "%")).fetchone()
-    return r[0], r[1]
+    out = {}
+    for name, v, n in c.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? "
+                                "group by kernel_name", (counter,)):
+        out[name] = (v, n)
+    return out
 
 
-fetch_db, write_db, kern, workload, out, src = sys.argv[1:7]
-f, nf = avg(fetch_db, "FETCH_SIZE", kern)
-w, nw = avg(write_db, "WRITE_SIZE", kern)
-ent = {"kernel": kern, "fetch_size_kib_raw": f, "write_size_kib_raw": w, "launches_averaged": [nf, nw],
-       "fetch_bytes": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
-       "traffic_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0,
-       "correction": "FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported", "source": src}
-tab = {}
-if os.path.exists(out):
-    tab = json.load(open(out))
-tab[workload] = ent
-json.dump(tab, open(out, "w"), indent=1)
-print(json.dumps(ent))
+def load(out):
+    return json.load(open(out)) if os.path.exists(out) else {}
+
+
+def main():
+    mode = sys.argv[1]
+    if mode == "calib":
+        fetch_db, write_db, out = sys.argv[2:5]
+        f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+        n = 1 << 27
+        true = {"copy8": (8 * n, 8 * n), "copy16": (8 * n, 8 * n), "read5w1": (5 * (n // 4) * 8, (n // 4) * 8)}
+        cal = {}
+        for k, (rb, wb) in true.items():
+            fk = [v for name, v in f.items() if name.startswith(k)]
+            wk = [v for name, v in w.items() if name.startswith(k)]
+            if fk and wk:
+                cal[k] = {"fetch_kib_raw": fk[0][0], "write_kib_raw": wk[0][0], "true_read_bytes": rb, "true_write_bytes": wb,
+                          "fetch_factor": rb / (fk[0][0] * 1024.0), "write_factor": wb / (wk[0][0] * 1024.0)}
+        tab = load(out)
+        tab["_calibration"] = cal
+        json.dump(tab, open(out, "w"), indent=1)
+        print(json.dumps(cal, indent=1))
+        return
+    fetch_db, write_db, workload, out, git, src = sys.argv[2:8]
+    tab = load(out)
+    cal = tab.get("_calibration", {}).get("read5w1")
+    ff = cal["fetch_factor"] if cal else 2.0
+    wf = cal["write_factor"] if cal else 1.0
+    f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    kernels = {}
+    for name in sorted(set(f) | set(w)):
+        phase = next((p for key, p in PHASE_OF if key in name), None)
+        if phase is None:
+            continue
+        fv, fn = f.get(name, (0.0, 0))
+        wv, wn = w.get(name, (0.0, 0))
+        e = kernels.setdefault(phase, {"kernel": name[:100], "fetch_kib_raw": 0.0, "write_kib_raw": 0.0, "launches_averaged": [fn, wn]})
+        e["fetch_kib_raw"] += fv
+        e["write_kib_raw"] += wv
+    for e in kernels.values():
+        e["fetch_bytes"] = ff * e["fetch_kib_raw"] * 1024.0
+        e["write_bytes"] = wf * e["write_kib_raw"] * 1024.0
+        e["traffic_bytes_per_launch"] = e["fetch_bytes"] + e["write_bytes"]
+    core = [p for p in kernels if p not in ("halo copies",)]
+    ent = {"git": git, "source": src, "kernels": kernels,
+           "traffic_bytes_per_eval": sum(kernels[p]["traffic_bytes_per_launch"] for p in core),
+           "correction": f"FETCH_SIZE x{ff:.3f}, WRITE_SIZE x{wf:.3f} ("
+                         + ("calibrated with tools/pmc_calib.bin read5w1 on the same box" if cal else "gfx950 note of MI355X_MICROARCH.md, uncalibrated") + ")"}
+    tab[workload] = ent
+    json.dump(tab, open(out, "w"), indent=1)
+    print(json.dumps(ent, indent=1))
+
+
+if __name__ == "__main__":
+    main()
