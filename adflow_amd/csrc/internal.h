@@ -61,8 +61,10 @@ __device__ __forceinline__ double fastdiv(double a, double b)
 // 1 / b and 1 / sqrt(x) for operands in the normal range: the hardware seed (v_rcp_f64 / v_rsq_f64, quarter rate) refined
 // by ADF_NR Newton steps in FMA form, without the range handling, final residual correction and denormal scaling of the
 // compiler's division / sqrt.  Callers multiply by the result; the flux kernels that use them are bound by FP64 issue.
+// Measured on MI355X (tools/pmc_calib.bin probe, profiles/r02_a_probe.txt): raw seeds 4.6e-8 / 5.2e-8 relative, one step
+// 2.1e-15 / 4.1e-15, two steps 1.1e-16 / 2.2e-16 -> ONE step is enough for the 1e-10 parity bar.
 #ifndef ADF_NR
-#define ADF_NR 2
+#define ADF_NR 1
 #endif
 #ifdef HOSTSIM
 __device__ __forceinline__ double rcp_nr(double b) { return 1.0 / b; }

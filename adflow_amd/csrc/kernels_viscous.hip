@@ -16,7 +16,7 @@
 #define VS_BX 64
 #define VS_BY 4
 
-int g_viscous_tiled = 1;   // tuning "viscous_tiled": 1 = LDS-tiled nodal-gradient and face-flux kernels
+int g_viscous_tiled = 2;   // tuning "viscous_tiled": 0 = gather kernels, 1 = LDS-tiled nodal-gradient and face-flux kernels, 2 = k-marching nodal gradients
 
 __device__ __forceinline__ double aa_at(const BlkView& b, long q) { return b.gamma[q] * b.p[q] / b.w[q]; }
 
@@ -217,6 +217,189 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients_t(const BlkVie
     const double oneOverV = b.nsum[c + 18 * nb];
 #pragma unroll
     for (int m = 0; m < 12; ++m) b.grad[c + m * nb] = g[m] * oneOverV;
+}
+
+// ---------------------------------------------------------------------------
+// k-marching form of the nodal-gradient kernel (tuning "viscous_tiled" >= 2).  k_nodal_gradients_t reads 19 static
+// sums per node (152 B) next to ~6 state values and is bound by that traffic.  The dual-cell surface integral factorises:
+// with the per-CELL vectors  tI = sI(i-1) + sI(i),  tJ = sJ(j-1) + sJ(j),  tK = sK(k-1) + sK(k)  the normal of the
+// integration point of direction k at cell plane m is the sum of tK over the 2 x 2 cells around the node column, the one of
+// direction j at cell row m the sum of tJ over (i..i+1) x (k..k+1), and likewise for i; the averaged state is the sum of
+// (u, v, w, -a^2) over the same four cells.  So a thread marching in k needs, per plane, ONE cell record (5 state values,
+// the 9 face normals stored at the cell, sJ(j-1), vol; sI(i-1) by a DPP lane shift, sK(k-1) carried) and the record of the
+// cell above it in j, which the neighbouring wave publishes through LDS; the i-neighbour comes by DPP, the k-neighbour is
+// the next plane.  ~19 loads and 12 stores per node instead of ~45 loads, no static nsum array (-152 B per node).
+// The sums are formed in a different order than the reference's (flowUtils.F90:1712-1979): results agree to rounding.
+// Mapping: workgroup = 64 lanes (cells i0-1 .. i0+62, producing nodes i0 .. i0+61) x 4 rows, NG_KCH node planes per march.
+// ---------------------------------------------------------------------------
+#define NG_OUT 62
+#define NG_BY 4
+#define NG_KCH 32
+#define NG_NV 14                        // published values per cell and plane
+#define NG_SLOT (NG_NV * 64)
+
+struct NgRec { double tI[3], phi[4], sTK[3], sV, sTJ[3]; };
+
+struct NgPtrs {
+    GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) p;
+    GPTR(const double) sI; GPTR(const double) sJ; GPTR(const double) sK; GPTR(const double) vol;
+    unsigned nb8;       // byte stride between the components of a vector array
+    unsigned sj;        // byte stride of one row
+};
+
+// record of the cell at byte offset c; sKp: sK of the plane below (in), of this plane (out)
+__device__ __forceinline__ void ng_record(const NgPtrs& m, unsigned c, double gam, double sKp[3], NgRec& R)
+{
+    const double rho = ldg(m.w0, c);
+    R.phi[0] = ldg(m.w1, c); R.phi[1] = ldg(m.w2, c); R.phi[2] = ldg(m.w3, c);
+    R.phi[3] = -(gam * ldg(m.p, c)) * rcp_nr(rho);              // minus the speed of sound squared (heat flux sign)
+    double tJ[3], tK[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double si = ldg(m.sI, c + d * m.nb8);
+        R.tI[d] = lane_up1(si) + si;
+        tJ[d] = ldg(m.sJ, c - m.sj + d * m.nb8) + ldg(m.sJ, c + d * m.nb8);
+        const double sk = ldg(m.sK, c + d * m.nb8);
+        tK[d] = sKp[d] + sk;
+        sKp[d] = sk;
+    }
+    const double vol = ldg(m.vol, c);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        R.sTJ[d] = tJ[d] + lane_dn1(tJ[d]);
+        R.sTK[d] = tK[d] + lane_dn1(tK[d]);
+    }
+    R.sV = vol + lane_dn1(vol);
+}
+
+__device__ __forceinline__ void ng_publish(double* __restrict__ x, int lane, const NgRec& R)
+{
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { x[d * 64 + lane] = R.tI[d]; x[(7 + d) * 64 + lane] = R.sTK[d]; x[(11 + d) * 64 + lane] = R.sTJ[d]; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) x[(3 + d) * 64 + lane] = R.phi[d];
+    x[10 * 64 + lane] = R.sV;
+}
+
+__device__ __forceinline__ void ng_fetch(const double* __restrict__ x, int lane, NgRec& R)
+{
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { R.tI[d] = x[d * 64 + lane]; R.sTK[d] = x[(7 + d) * 64 + lane]; R.sTJ[d] = x[(11 + d) * 64 + lane]; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) R.phi[d] = x[(3 + d) * 64 + lane];
+    R.sV = x[10 * 64 + lane];
+}
+
+// sums of one cell plane around the node column of the thread: P (direction k), Q0 / Q1 (direction j at the own row / the row
+// above), RI (direction i at the own column; the column i+1 comes by DPP when used), V (volumes)
+struct NgPlane { double Pt[3], Pp[4], Q0t[3], Q0p[4], Q1t[3], Q1p[4], RIt[3], RIp[4], V; };
+
+// g += sign * 0.25 * phi (x) t
+__device__ __forceinline__ void ng_outer(double g[12], double sign, const double ph[4], const double t[3])
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const double a = sign * 0.25 * ph[v];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[3 * v + d] += a * t[d];
+    }
+}
+
+__global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView* __restrict__ tab, int nzb, double gam)
+{
+    __shared__ double xr[2 * NG_BY * NG_SLOT];            // [parity][row slot 0..3 = cell rows j0+1 .. j0+4][value][lane]
+    const BlkView& b = tab[blockIdx.z / nzb + 1];         // level-batched: blockIdx.z = slot * nzb + k chunk
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int i0 = blockIdx.x * NG_OUT + 1, j0 = blockIdx.y * NG_BY + 1;      // first node of the tile
+    const int kn0 = (blockIdx.z % nzb) * NG_KCH + 1;
+    if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
+    const int kn1 = (kn0 + NG_KCH - 1 < b.kl) ? kn0 + NG_KCH - 1 : b.kl;
+    const int i = i0 - 1 + lane, j = j0 + row;
+    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
+    const int jx = (j0 + NG_BY < b.jb) ? j0 + NG_BY : b.jb;                    // cell row above the tile (record made by wave 0)
+    const bool out = (lane >= 1 && lane <= NG_OUT && i <= b.il && j <= b.jl);
+    const long nb = b.nbox;
+    NgPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
+    m.p = (GPTR(const double))b.p;
+    m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
+    m.vol = (GPTR(const double))b.vol;
+    m.nb8 = 8u * (unsigned)nb; m.sj = 8u * (unsigned)b.ldi;
+    GPTR(double) grad = (GPTR(double))b.grad;
+    const unsigned sk = 8u * (unsigned)b.ldk;
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + kn0 * b.ldk);
+    unsigned cx = 8u * (unsigned)(ic + jx * b.ldi + kn0 * b.ldk);
+    double sKp[3], sKpx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * m.nb8); sKpx[d] = ldg(m.sK, cx - sk + d * m.nb8); }
+    NgPlane S;       // sums of the previous cell plane
+    for (int mm = kn0; mm <= kn1 + 1; ++mm) {
+        double* __restrict__ xb = xr + ((mm - kn0) & 1) * (NG_BY * NG_SLOT);
+        NgRec R;
+        ng_record(m, c, gam, sKp, R);
+        if (row > 0) ng_publish(xb + (row - 1) * NG_SLOT, lane, R);
+        if (row == 0) {
+            NgRec X;
+            ng_record(m, cx, gam, sKpx, X);
+            ng_publish(xb + (NG_BY - 1) * NG_SLOT, lane, X);
+        }
+        __syncthreads();
+        NgRec U;                       // the cell above in j
+        ng_fetch(xb + row * NG_SLOT, lane, U);
+        NgPlane N;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            N.Pt[d] = R.sTK[d] + U.sTK[d];
+            N.Q0t[d] = R.sTJ[d]; N.Q1t[d] = U.sTJ[d];
+            N.RIt[d] = R.tI[d] + U.tI[d];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            N.Q0p[v] = R.phi[v] + lane_dn1(R.phi[v]);
+            N.Q1p[v] = U.phi[v] + lane_dn1(U.phi[v]);
+            N.Pp[v] = N.Q0p[v] + N.Q1p[v];
+            N.RIp[v] = R.phi[v] + U.phi[v];
+        }
+        N.V = R.sV + U.sV;
+        if (mm > kn0) {
+            // node plane mm-1 from the cell planes mm-1 (S) and mm (N)
+            double g[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) g[q] = 0.0;
+            ng_outer(g, -1.0, S.Pp, S.Pt);                    // k direction: below the node -, above +
+            ng_outer(g, +1.0, N.Pp, N.Pt);
+            double t[3], ph[4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t[d] = S.Q0t[d] + N.Q0t[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = S.Q0p[v] + N.Q0p[v];
+            ng_outer(g, -1.0, ph, t);                         // j direction: own row -, row above +
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t[d] = S.Q1t[d] + N.Q1t[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = S.Q1p[v] + N.Q1p[v];
+            ng_outer(g, +1.0, ph, t);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t[d] = S.RIt[d] + N.RIt[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = S.RIp[v] + N.RIp[v];
+            ng_outer(g, -1.0, ph, t);                         // i direction: own column -, column i+1 +
+            double t1[3], ph1[4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t[d]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
+            ng_outer(g, +1.0, ph1, t1);
+            const double oneOverV = rcp_nr(S.V + N.V);
+            if (out) {
+                const unsigned cn = c - sk;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cn, g[q] * oneOverV);
+            }
+        }
+        S = N;
+        c += sk; cx += sk;
+    }
 }
 
 // viscous flux through the face between cells cL and cL+sd (fluxes.F90:2610-2860);
@@ -787,8 +970,13 @@ void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz
     if (nslots <= 0) return;
     dim3 blk(VS_BX, VS_BY, 1);
     const int nzn = nz + 1;                              // node planes 1..kl
-    hipLaunchKernelGGL(k_nodal_gradients_t, dim3((nx + 1 + VS_BX - 1) / VS_BX, (ny + 1 + VS_BY - 1) / VS_BY, nzn * nslots), blk, 0, s,
-                       tab, nzn);
+    if (g_viscous_tiled >= 2) {
+        const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
+        hipLaunchKernelGGL(k_node_grad_march, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+    } else
+        hipLaunchKernelGGL(k_nodal_gradients_t, dim3((nx + 1 + VS_BX - 1) / VS_BX, (ny + 1 + VS_BY - 1) / VS_BY, nzn * nslots), blk, 0, s,
+                           tab, nzn);
     adf_phase_mark(5);
     const int nch = (nz + VT_KCH - 1) / VT_KCH;
     hipLaunchKernelGGL(k_viscous_t, dim3((nx + VS_BX - 1) / VS_BX, (ny + VS_BY - 1) / VS_BY, nch * nslots), blk, 0, s, tab, nch, kp);

@@ -33,6 +33,13 @@ struct BlockRun {
     int current = -1;
     const std::function<void()>* body = nullptr;
     std::vector<double> xchg;
+    // true barriers (threads of a block / lanes of a 64-wide wave may take different paths between two rendezvous,
+    // e.g. wave-specialised kernels): arrivals are counted against the threads that have not returned yet
+    int alive = 0;
+    long bar_gen = 0;
+    int bar_arrived = 0;
+    std::vector<int> wave_alive, wave_arrived;
+    std::vector<long> wave_gen;
 };
 thread_local BlockRun* g_run = nullptr;
 
@@ -52,16 +59,38 @@ void yield_to_sched()
 }
 }  // namespace
 
-void syncthreads() { yield_to_sched(); }
+void syncthreads()
+{
+    BlockRun* r = g_run;
+    const long gen = r->bar_gen;
+    r->bar_arrived++;
+    while (r->bar_gen == gen) {
+        if (r->bar_arrived >= r->alive) { r->bar_arrived = 0; r->bar_gen++; break; }
+        yield_to_sched();
+    }
+}
 
+namespace {
+void wave_barrier(BlockRun* r, int w)
+{
+    const long gen = r->wave_gen[w];
+    r->wave_arrived[w]++;
+    while (r->wave_gen[w] == gen) {
+        if (r->wave_arrived[w] >= r->wave_alive[w]) { r->wave_arrived[w] = 0; r->wave_gen[w]++; break; }
+        yield_to_sched();
+    }
+}
+}  // namespace
+
+// exchange between the lanes of ONE 64-wide wave (consecutive linear thread ids); src is a linear thread id of the block
 double shfl_exchange(double v, int src)
 {
     BlockRun* r = g_run;
-    const int me = r->current;
+    const int me = r->current, w = me / 64;
     r->xchg[me] = v;
-    yield_to_sched();            // everybody has published
+    wave_barrier(r, w);          // every live lane of the wave has published
     const double out = r->xchg[src];
-    yield_to_sched();            // everybody has read before the next publish
+    wave_barrier(r, w);          // every live lane has read before the next publish
     return out;
 }
 
@@ -96,16 +125,21 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
                 f.ctx.uc_link = nullptr;
                 makecontext(&f.ctx, fiber_entry, 0);
             }
-            int alive = nthreads;
-            while (alive > 0) {
-                alive = 0;
+            const int nwaves = (nthreads + 63) / 64;
+            run.alive = nthreads;
+            run.bar_arrived = 0;
+            run.wave_alive.assign(nwaves, 0);
+            run.wave_arrived.assign(nwaves, 0);
+            run.wave_gen.assign(nwaves, 0);
+            for (int t = 0; t < nthreads; ++t) run.wave_alive[t / 64]++;
+            while (run.alive > 0) {
                 for (int t = 0; t < nthreads; ++t) {
                     Fiber& f = run.fibers[t];
                     if (f.done) continue;
                     run.current = t;
                     threadIdx = f.tid;
                     swapcontext(&run.sched, &f.ctx);
-                    if (!f.done) ++alive;
+                    if (f.done) { run.alive--; run.wave_alive[t / 64]--; }
                 }
             }
         }

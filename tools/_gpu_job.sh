@@ -5,6 +5,7 @@ TAG=${TAG:-r02_a}
 ./tools/pmc_calib.bin probe > $O/${TAG}_probe.txt 2>&1; cat $O/${TAG}_probe.txt
 timeout 1200 python -m pytest tests -m gpu -x -q ${PYTEST_K:+-k "$PYTEST_K"} 2>&1 | tail -6 | tee $O/${TAG}_pytest.txt
 timeout 900 python bench.py ${BENCH_ARGS} > $O/${TAG}_bench.json 2> $O/${TAG}_bench.log; tail -c 1500 $O/${TAG}_bench.log; cut -c1-1200 $O/${TAG}_bench.json
+timeout 300 python bench.py --no-extras --no-cpu-baseline --tuning roe_march=0 2>/dev/null | tail -1 | cut -c1-900 > $O/${TAG}_bench_roe0.json; cut -c1-400 $O/${TAG}_bench_roe0.json
 B="python bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 2 --min-seconds 0.2"
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o t -- $B > $O/${TAG}_prof.log 2>&1
 python tools/rocpd_summary.py $O/prof/t_results.db $O/${TAG}_kernel_trace.md "($TAG: $B)" | head -14
