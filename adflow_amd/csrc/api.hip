@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb;
 
 namespace {
 
@@ -817,7 +817,14 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox)
         return 0;
     });
     if (rc) return rc;
-    if (batched) launch_viscous_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    if (batched && viscous_is_tiled() >= 2 && g_march_by == 4) {
+        // k-marching nodal gradients, then the k-marching face kernel over the level's tile table
+        launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        phase_mark(5);
+        if (ensure_tiles(level)) return 1;
+        launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
+    } else if (batched)
+        launch_viscous_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     return 0;
 }
 
@@ -2253,6 +2260,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "viscous_tiled")) { g_viscous_tiled = value; return 0; }
     if (!strcmp(key, "inviscid_march")) { g_inviscid_march = value; return 0; }
     if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
+    if (!strcmp(key, "visc_sb")) { g_visc_sb = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {
         if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(IV_BX* IV_BY, (SCHEME == ADFLOW_UPWIND ? 2 : 1)) vo
             b.fw[c + l * nb] = fwn;
             b.dw[c + l * nb] = d;
         } else {
-            b.dw[c + l * nb] = d + fwn;      // fw not persistent: the viscous kernel adds its part to the sum
+            b.dw[c + l * nb] = (d + fwn) * blank;      // fw not persistent: the viscous kernel adds its part to dw(2:5) and re-applies iblank
         }
     }
 }

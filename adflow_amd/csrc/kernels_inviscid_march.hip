@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
                     stg(fw + l * nb, cw, fwn);
                     stg(dw + l * nb, cw, d);
                 } else {
-                    stg(dw + l * nb, cw, d + fwn);      // fw not persistent: the viscous kernel adds its part to the sum
+                    stg(dw + l * nb, cw, (d + fwn) * blank);      // fw not persistent: the viscous kernel adds its part to dw(2:5) and re-applies iblank
                 }
             }
         }

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __re
                     stg(dw + l * nb, cw, FINAL ? (d + fwn) * blank : d);
                 } else {
                     d += fd[l];
-                    stg(dw + l * nb, cw, FINAL ? d * blank : d);
+                    stg(dw + l * nb, cw, d * blank);      // not FINAL: the viscous kernel adds its part to dw(2:5) and re-applies iblank
                 }
             }
         }

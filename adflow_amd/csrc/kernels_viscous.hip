@@ -867,6 +867,253 @@ __global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __
 
 
 // ---------------------------------------------------------------------------
+// k-marching form of the face-flux kernel (tuning "viscous_tiled" >= 2) over the level's XCD-ordered tile table (the table of
+// the inviscid marching kernels: 60 produced columns per 64-lane wavefront, 4 rows, march_kch planes).  k_viscous_t stages
+// the gradient planes in a separate phase between two barriers per plane, evaluates five faces per cell and loads the state
+// of every neighbour per face: it waits 70 % of its wave cycles (profiles/r02_a_pmc_sq.txt) and moves 660 B per cell.  Here
+//   * a thread loads the 12 gradients of ITS node (i, j, k) with plain coalesced loads and publishes them in LDS for the
+//     row above (one barrier per plane, double-buffered); the node plane below is carried in registers, the nodes at
+//     i-1 come by DPP lane shifts: no staging phase, no 65th column;
+//   * k faces are carried (once per face), i faces are evaluated by the left cell and handed to lane+1 by DPP (once per
+//     face), both j faces are evaluated by the cell (rows are different waves): 4 face evaluations per cell;
+//   * the own column's state is a two-plane window; the heat-conduction factors use the constant gamma of the path;
+//     1/|d| comes from v_rsq_f64; without the persistent fw of the RK scheme only dw is read and written.
+// Face arithmetic as visc_face_t (fluxes.F90:2610-2860); the 4-node average is formed from pair sums (rounding only).
+// ---------------------------------------------------------------------------
+#define VM_OUT 60          // tile table shared with the inviscid marching kernels
+#define VM_BY 4
+#define VM_G (12 * 64)     // one node row of one plane in LDS
+
+struct VmCell { double u, v, w, na, rlv, rev; };      // na = - gamma p / rho (minus the speed of sound squared)
+
+struct VmPtrs {
+    GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) p;
+    GPTR(const double) rlv; GPTR(const double) rev;
+};
+
+__device__ __forceinline__ VmCell vm_ld(const VmPtrs& m, unsigned o, double gam, bool eddy)
+{
+    VmCell q;
+    q.u = ldg(m.w1, o); q.v = ldg(m.w2, o); q.w = ldg(m.w3, o);
+    q.na = -(gam * ldg(m.p, o)) * rcp_nr(ldg(m.w0, o));
+    q.rlv = ldg(m.rlv, o);
+    q.rev = eddy ? ldg(m.rev, o) : 0.0;
+    return q;
+}
+
+__device__ __forceinline__ VmCell vm_dn1(const VmCell& q)
+{
+    VmCell r;
+    r.u = lane_dn1(q.u); r.v = lane_dn1(q.v); r.w = lane_dn1(q.w); r.na = lane_dn1(q.na); r.rlv = lane_dn1(q.rlv); r.rev = lane_dn1(q.rev);
+    return r;
+}
+
+struct VmK { double porV, hl, ht; bool eddy; };       // 0.5 rFil; 1 / (prandtl (gamma-1)); 1 / (prandtlTurb (gamma-1))
+
+// viscous flux through the face between L and R (normal fN pointing from L to R, centre-to-centre vector dN); gs: SUM of the
+// gradients of the four face nodes (the average is gs / 4)
+template <bool QCR>
+__device__ __forceinline__ void vm_face(const VmK& K, const double gs[12], const VmCell& L, const VmCell& R, const double fN[3],
+                                        const double dN[3], int por_code, double f[4])
+{
+    double por = K.porV;
+    if (por_code == ADF_POR_NOFLUX) por = 0.0;
+    const double mul = por * (L.rlv + R.rlv);
+    const double mue = K.eddy ? por * (L.rev + R.rev) : 0.0;
+    const double mut = mul + mue;
+    const double heatCoef = mul * K.hl + mue * K.ht;
+    const double ss = rsq_nr(dN[0] * dN[0] + dN[1] * dN[1] + dN[2] * dN[2]);
+    const double ssx = ss * dN[0], ssy = ss * dN[1], ssz = ss * dN[2];
+    double gr[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) gr[q] = 0.25 * gs[q];
+    double corr;
+    corr = gr[0] * ssx + gr[1] * ssy + gr[2] * ssz - (R.u - L.u) * ss;
+    const double u_x = gr[0] - corr * ssx, u_y = gr[1] - corr * ssy, u_z = gr[2] - corr * ssz;
+    corr = gr[3] * ssx + gr[4] * ssy + gr[5] * ssz - (R.v - L.v) * ss;
+    const double v_x = gr[3] - corr * ssx, v_y = gr[4] - corr * ssy, v_z = gr[5] - corr * ssz;
+    corr = gr[6] * ssx + gr[7] * ssy + gr[8] * ssz - (R.w - L.w) * ss;
+    const double w_x = gr[6] - corr * ssx, w_y = gr[7] - corr * ssy, w_z = gr[8] - corr * ssz;
+    corr = gr[9] * ssx + gr[10] * ssy + gr[11] * ssz - (R.na - L.na) * ss;
+    double q_x = gr[9] - corr * ssx, q_y = gr[10] - corr * ssy, q_z = gr[11] - corr * ssz;
+    const double fracDiv = (2.0 * (1.0 / 3.0)) * (u_x + v_y + w_z);
+    const double tauxxS = 2.0 * u_x - fracDiv, tauyyS = 2.0 * v_y - fracDiv, tauzzS = 2.0 * w_z - fracDiv;
+    const double tauxyS = u_y + v_x, tauxzS = u_z + w_x, tauyzS = v_z + w_y;
+    q_x *= heatCoef; q_y *= heatCoef; q_z *= heatCoef;
+    double tauxx = mut * tauxxS, tauyy = mut * tauyyS, tauzz = mut * tauzzS;
+    double tauxy = mut * tauxyS, tauxz = mut * tauxzS, tauyz = mut * tauyzS;
+    if (QCR) {
+        double den = sqrt(u_x * u_x + u_y * u_y + u_z * u_z + v_x * v_x + v_y * v_y + v_z * v_z + w_x * w_x + w_y * w_y + w_z * w_z);
+        den = fmax(den, 1.e-14);
+        const double fact = mue * 0.3 / den;
+        const double Wxy = u_y - v_x, Wxz = u_z - w_x, Wyz = v_z - w_y;
+        const double Wyx = -Wxy, Wzx = -Wxz, Wzy = -Wyz;
+        tauxx -= fact * (Wxy * tauxyS + Wxz * tauxzS) * 2.0;
+        tauyy -= fact * (Wyx * tauxyS + Wyz * tauyzS) * 2.0;
+        tauzz -= fact * (Wzx * tauxzS + Wzy * tauyzS) * 2.0;
+        tauxy -= fact * (Wxy * tauyyS + Wxz * tauyzS + Wyx * tauxxS + Wyz * tauxzS);
+        tauxz -= fact * (Wxy * tauyzS + Wxz * tauzzS + Wzx * tauxxS + Wzy * tauxyS);
+        tauyz -= fact * (Wyx * tauxzS + Wyz * tauzzS + Wzx * tauxyS + Wzy * tauyyS);
+    }
+    const double ubar = 0.5 * (L.u + R.u), vbar = 0.5 * (L.v + R.v), wbar = 0.5 * (L.w + R.w);
+    const double nx = fN[0], ny = fN[1], nz = fN[2];
+    f[0] = tauxx * nx + tauxy * ny + tauxz * nz;
+    f[1] = tauxy * nx + tauyy * ny + tauyz * nz;
+    f[2] = tauxz * nx + tauyz * ny + tauzz * nz;
+    double frhoE = (ubar * tauxx + vbar * tauxy + wbar * tauxz) * nx;
+    frhoE = frhoE + (ubar * tauxy + vbar * tauyy + wbar * tauyz) * ny;
+    frhoE = frhoE + (ubar * tauxz + vbar * tauyz + wbar * tauzz) * nz;
+    f[3] = frhoE - q_x * nx - q_y * ny - q_z * nz;
+}
+
+__device__ __forceinline__ void vm_ld3(GPTR(const double) a, unsigned o, unsigned nb8, double v[3])
+{
+    v[0] = ldg(a, o); v[1] = ldg(a, o + nb8); v[2] = ldg(a, o + 2 * nb8);
+}
+
+// SB: scheduling fences between the face blocks (limits how far the compiler hoists the loads of later faces: fewer live
+// registers, less latency overlap) -- tuning "visc_sb"
+template <bool QCR, int SB>
+__global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
+                                                              int kch)
+{
+    __shared__ double gx[2 * (VM_BY + 1) * VM_G];      // [parity][node row slot 0..4 = rows j0-1 .. j0+3][component][lane]
+    const int4 t = tiles[blockIdx.x];
+    if (t.x < 0) return;
+    const BlkView& b = tab[t.x];
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int i = t.y * VM_OUT + lane;          // columns i0-2 .. i0+61
+    const int j = 2 + t.z * VM_BY + row;
+    const int k0 = 2 + t.w * kch;
+    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
+    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
+    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.je) ? j : b.je;
+    const long nb = b.nbox;
+    const unsigned nb8 = 8u * (unsigned)nb, sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
+    VmPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
+    m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.rev = (GPTR(const double))b.rev;
+    GPTR(const double) sI = (GPTR(const double))b.sI; GPTR(const double) sJ = (GPTR(const double))b.sJ;
+    GPTR(const double) sK = (GPTR(const double))b.sK;
+    GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
+    GPTR(const double) dK = (GPTR(const double))b.dK;
+    GPTR(const double) grad = (GPTR(const double))b.grad;
+    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
+    GPTR(double) dw = (GPTR(double))b.dw;
+    GPTR(double) fw = (GPTR(double))b.fw;
+    VmK K;
+    K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
+    K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
+    const double gam = kp.gammaConstant;
+
+    // node plane k0-1 -> LDS buffer 1 (the march starts with buffer 0); cell planes k0-1 and k0 of the own column
+    {
+        double* __restrict__ xp = gx + (VM_BY + 1) * VM_G;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) xp[(row + 1) * VM_G + q * 64 + lane] = ldg(grad, c - sk + q * nb8);
+        if (row == 0) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) xp[q * 64 + lane] = ldg(grad, c - sk - sj + q * nb8);
+        }
+    }
+    const VmCell qm1 = vm_ld(m, c - sk, gam, K.eddy);
+    VmCell q0 = vm_ld(m, c, gam, K.eddy);
+    double fk[4];
+    __syncthreads();
+    {
+        // k face below the first plane of the march: nodes (i-1..i, j-1..j, k0-1)
+        const double* __restrict__ xp = gx + (VM_BY + 1) * VM_G;
+        double gs[12], nK[3], dKv[3];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) { const double s = xp[(row + 1) * VM_G + q * 64 + lane] + xp[row * VM_G + q * 64 + lane]; gs[q] = s + lane_up1(s); }
+        vm_ld3(sK, c - sk, nb8, nK); vm_ld3(dK, c - sk, nb8, dKv);
+        vm_face<QCR>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), fk);
+    }
+    for (int k = k0; k <= k1; ++k) {
+        double* __restrict__ xb = gx + ((k - k0) & 1) * ((VM_BY + 1) * VM_G);               // node plane k
+        const double* __restrict__ xp = gx + ((k - k0 + 1) & 1) * ((VM_BY + 1) * VM_G);     // node plane k-1
+        // ---- own node of plane k -> LDS; row 0 also fetches the node row below the tile.  Both node planes stay in LDS and
+        //      every face reads its four nodes from there (carried in registers they push the kernel over the 256 VGPRs of
+        //      two waves per SIMD and the spills serialise the loads)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) xb[(row + 1) * VM_G + q * 64 + lane] = ldg(grad, c + q * nb8);
+        if (row == 0) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) xb[q * 64 + lane] = ldg(grad, c - sj + q * nb8);
+        }
+        const VmCell qp1 = vm_ld(m, c + sk, gam, K.eddy);
+        const int flag0 = flags[c >> 3];
+        double acc[4];
+        __syncthreads();
+        const int oM = row * VM_G + lane, o0 = (row + 1) * VM_G + lane;       // node rows j-1 and j
+        // ---- j face (j-1 | j): nodes (i-1..i, j-1, k-1..k)
+        {
+            double gs[12], nJ[3], dJv[3], f[4];
+            const VmCell qjm = vm_ld(m, c - sj, gam, K.eddy);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
+            vm_ld3(sJ, c - sj, nb8, nJ); vm_ld3(dJ, c - sj, nb8, dJv);
+            vm_face<QCR>(K, gs, qjm, q0, nJ, dJv, flg_porJ(flags[(c - sj) >> 3]), f);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) acc[l] = fk[l] + f[l];
+        }
+        if (SB >= 1) __builtin_amdgcn_sched_barrier(0);
+        // ---- i face (i | i+1): nodes (i, j-1..j, k-1..k) of the own column; the face (i-1 | i) comes from lane-1
+        {
+            double gs[12], nI[3], dIv[3], f[4];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) gs[q] = (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
+            vm_ld3(sI, c, nb8, nI); vm_ld3(dI, c, nb8, dIv);
+            const VmCell qR = vm_dn1(q0);
+            vm_face<QCR>(K, gs, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
+        }
+        if (SB >= 1) __builtin_amdgcn_sched_barrier(0);
+        // ---- j face (j | j+1): nodes (i-1..i, j, k-1..k)
+        {
+            double gs[12], nJ[3], dJv[3], f[4];
+            const VmCell qjp = vm_ld(m, c + sj, gam, K.eddy);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
+            vm_ld3(sJ, c, nb8, nJ); vm_ld3(dJ, c, nb8, dJv);
+            vm_face<QCR>(K, gs, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), f);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) acc[l] -= f[l];
+        }
+        if (SB >= 1) __builtin_amdgcn_sched_barrier(0);
+        // ---- k face above the cell: nodes (i-1..i, j-1..j, k)
+        {
+            double gs[12], nK[3], dKv[3], f[4];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { const double s = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
+            vm_ld3(sK, c, nb8, nK); vm_ld3(dK, c, nb8, dKv);
+            vm_face<QCR>(K, gs, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), f);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) { acc[l] -= f[l]; fk[l] = f[l]; }
+        }
+        if (out) {
+            const double blank = flg_blank((uint8_t)flag0);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const unsigned o = c + (l + 1) * nb8;
+                double fwn = acc[l];
+                if (kp.fwMode) {
+                    fwn += ldg(fw, o);
+                    stg(fw, o, fwn);
+                }
+                stg(dw, o, (ldg(dw, o) + fwn) * blank);
+            }
+            if (kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
+        }
+        q0 = qp1;
+        c += sk;
+        __syncthreads();        // every wave is done with plane k-1 before its buffer takes plane k+1
+    }
+}
+
+// ---------------------------------------------------------------------------
 // viscousFluxApprox (fluxes.F90:3487-3859): thin-layer form for the preconditioner assembly.  The gradient on a
 // face is the difference of the two cell values along the centre-to-centre vector d (no nodal gradients):
 // grad(q) = (q_R - q_L) d / |d|^2.  d is the static face vector of k_face_vectors (same node order).
@@ -965,6 +1212,29 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
 }
 
 // tiled forms, every block of the level in one launch each
+extern int g_march_kch;
+int g_visc_sb = 0;
+
+// marching face-flux kernel over the tile table of the level (tuning viscous_tiled >= 2)
+void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    if (ntiles <= 0) return;
+    const dim3 blk(64, VM_BY, 1), grd(ntiles);
+    if (kp.useQCR) hipLaunchKernelGGL((k_visc_march<true, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+    else if (g_visc_sb == 0) hipLaunchKernelGGL((k_visc_march<false, 0>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+    else if (g_visc_sb == 1) hipLaunchKernelGGL((k_visc_march<false, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+    else hipLaunchKernelGGL((k_visc_march<false, 2>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+}
+
+void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    const int nzn = nz + 1;
+    const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
+    hipLaunchKernelGGL(k_node_grad_march, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                       dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+}
+
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
     if (nslots <= 0) return;

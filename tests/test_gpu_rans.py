@@ -78,3 +78,48 @@ def test_inviscid_march_variants(engine):
     finally:
         engine.set_tuning("inviscid_march", 1)
         engine.set_tuning("march_kch", 32)
+
+
+# ---- round 2: the synthetic states have a tiny viscous part (Re ~ 1e7: 1e-6 of dw); with muSuthDim = 1 the viscous flux is as
+#      large as the inviscid one, so an error in the nodal gradients / face fluxes cannot hide below the 1e-10 bar
+@pytest.mark.parametrize("eq,qcr", [(NSEquations, False), (RANSEquations, False), (RANSEquations, True)])
+def test_viscous_dominated(engine, eq, qcr):
+    for sd in (upwind, dissScalar):
+        prm = FlowParams(equations=eq, spaceDiscr=sd, useQCR=qcr, muSuthDim=1.0)
+        checks.check_block_res(engine, (70, 9, 12), prm, seed=21, stretch_k=2.0)
+    checks.check_rk_residual_sequence(engine, (24, 10, 8), FlowParams(equations=NSEquations, muSuthDim=1.0), stretch_k=2.0)
+
+
+def test_viscous_kernel_variants(engine):
+    """tuning viscous_tiled: 2 = k-marching gradient + face kernels (default), 1 = LDS-tiled pair, 0 = gather pair;
+    roe_march: 0 = per-face reconstruction kernel; partial tiles in i, j and the k chunk; blanked cells"""
+    try:
+        for vt in (2, 1, 0):
+            engine.set_tuning("viscous_tiled", vt)
+            prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
+            checks.check_block_res(engine, (63, 6, 35), prm, seed=vt, stretch_k=2.0, holes=0.05)
+        engine.set_tuning("viscous_tiled", 2)
+        engine.set_tuning("roe_march", 0)
+        checks.check_block_res(engine, (63, 6, 9), FlowParams(equations=RANSEquations, spaceDiscr=upwind), seed=3, stretch_k=2.0)
+    finally:
+        engine.set_tuning("viscous_tiled", 2)
+        engine.set_tuning("roe_march", 1)
+
+
+def test_block_res_without_intermediates(engine):
+    """default flags of blocketteRes (updateIntermed = F): dw only; the spectral radii are not an output"""
+    from oracle import ref
+    from util import owned, rel_err, TOL
+    from adflow_amd.synth import make_block
+    for sd in (upwind, dissMatrix, dissScalar):
+        prm = FlowParams(equations=RANSEquations, spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156)
+        engine.release_all()
+        blk = make_block(24, 10, 8, prm, seed=sd, stretch_k=2.0)
+        r = checks.ref_bind(blk, prm)
+        ref.block_res_core(False, True, True)
+        engine.set_options(prm)
+        engine.register(blk)
+        engine.blocketteRes(1, False, True, True)
+        dw = engine.download_residual()
+        for l in range(blk.nw):
+            assert rel_err(owned(blk, dw[..., l]), owned(blk, r["dw"][..., l])) <= TOL, (sd, l)

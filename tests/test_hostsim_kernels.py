@@ -332,3 +332,22 @@ def test_block_res_approx(hostsim_engine, sd):
 def test_block_res_visc_approx_only(hostsim_engine):
     checks.check_block_res_approx(hostsim_engine, (8, 6, 5), FlowParams(equations=NSEquations, sigma=0.3), diss_approx=False,
                                   visc_approx=True, stretch_k=2.0)
+
+
+# ---- round 2 kernels on the emulator: viscous-dominated states, kernel variants, default flags (GPU twins in test_gpu_rans.py)
+@pytest.mark.parametrize("eq,qcr", [(NSEquations, False), (RANSEquations, True)])
+def test_viscous_dominated(hostsim_engine, eq, qcr):
+    prm = FlowParams(equations=eq, spaceDiscr=upwind, useQCR=qcr, muSuthDim=1.0)
+    checks.check_block_res(hostsim_engine, (63, 6, 9), prm, seed=21, stretch_k=2.0)
+    checks.check_rk_residual_sequence(hostsim_engine, (12, 6, 5), FlowParams(equations=NSEquations, muSuthDim=1.0), stretch_k=2.0)
+
+
+def test_viscous_kernel_variants(hostsim_engine):
+    import test_gpu_rans
+    test_gpu_rans.test_viscous_kernel_variants.__wrapped__(hostsim_engine) if hasattr(test_gpu_rans.test_viscous_kernel_variants, "__wrapped__") \
+        else test_gpu_rans.test_viscous_kernel_variants(hostsim_engine)
+
+
+def test_block_res_without_intermediates(hostsim_engine):
+    import test_gpu_rans
+    test_gpu_rans.test_block_res_without_intermediates(hostsim_engine)
