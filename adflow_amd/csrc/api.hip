@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows;
 
 namespace {
 
@@ -738,7 +738,7 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
     return sync_and_check();
 }
 
-static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox);
+static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad);
 static int source_terms_enqueue(int withBlank);
 
 // residual (residuals.F90:1028) = residual_block of every block; blockResCore (blockette.F90:755) is the same sum of
@@ -747,10 +747,16 @@ static int wall_stress_enqueue(int level, const KParams& kp);
 
 // stage0: the reference's rkStage is 0 at this call -> on the ground level viscousFlux also stores the wall stress tensor
 // and heat flux of the viscous subfaces (storeWallTensor, fluxes.F90:2586-2592)
-static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false, bool lowSpeed = true, bool stage0 = true)
+static bool has_wall_subfaces(int level);
+
+// needGradHbm: the caller wants the nodal gradients in the block arrays (updateIntermed copy-out, blockette.F90:706-750)
+static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false, bool lowSpeed = true, bool stage0 = true,
+                                 bool needGradHbm = false)
 {
-    if (enqueue_flow_fluxes(level, kp, viscApprox)) return 1;
-    if (stage0 && !viscApprox && kp.viscous && level == g_opts.groundLevel && fabs(kp.rFil) >= 1.e-10)
+    const bool wallStress = stage0 && !viscApprox && kp.viscous && level == g_opts.groundLevel && fabs(kp.rFil) >= 1.e-10 &&
+                            has_wall_subfaces(level);
+    if (enqueue_flow_fluxes(level, kp, viscApprox, needGradHbm || wallStress)) return 1;
+    if (wallStress)
         if (wall_stress_enqueue(level, kp)) return 1;
     // sourceTerms() of the call sites of `residual` (smoothers.F90:74,409, multiGrid.F90:52,887,949): fine level only
     if (lowSpeed && level == 1 && source_terms_enqueue(1)) return 1;
@@ -762,7 +768,7 @@ static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox =
     return 0;
 }
 
-static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox)
+static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad)
 {
     bool anyMoving = false;     // grid velocities / rotational source: the generic kernels carry them
     for_level(level, [&](Block* b) { anyMoving = anyMoving || b->v.sFace || b->v.moving; return 0; });
@@ -817,7 +823,10 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox)
         return 0;
     });
     if (rc) return rc;
-    if (batched && viscous_is_tiled() >= 2 && g_march_by == 4) {
+    if (batched && viscous_is_tiled() >= 2 && (g_viscous_fused >= 2 || (g_viscous_fused == 1 && !needGrad))) {
+        // nodal gradients and face fluxes in one kernel: the gradients stay in LDS
+        launch_visc_fused_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    } else if (batched && viscous_is_tiled() >= 2 && g_march_by == 4) {
         // k-marching nodal gradients, then the k-marching face kernel over the level's tile table
         launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
         phase_mark(5);
@@ -910,7 +919,7 @@ static int block_res_enqueue(int level, unsigned flags)
     }
     phase_mark(3);
     if (flags & ADFLOW_RES_FLOW) {
-        rc = enqueue_flow_residual(level, kp, viscApprox, false);
+        rc = enqueue_flow_residual(level, kp, viscApprox, false, true, (flags & ADFLOW_RES_UPDATE_INTERMED) != 0);
         if (rc) return rc;
     }
     phase_mark(6);
@@ -1489,6 +1498,13 @@ static int apply_bc_enqueue(int level, int secondHalo)
         if (!b->bc.empty()) b->ss_valid = false;
         return 0;
     });
+}
+
+static bool has_wall_subfaces(int level)
+{
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return false;
+    return pl->wall.count > 0;
 }
 
 // viscSubface(:)%tau / %q of every viscous subface of the level, from the nodal gradients the viscous kernels just used
@@ -2261,6 +2277,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "inviscid_march")) { g_inviscid_march = value; return 0; }
     if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
     if (!strcmp(key, "visc_sb")) { g_visc_sb = value; return 0; }
+    if (!strcmp(key, "viscous_fused")) { g_viscous_fused = value; return 0; }
+    if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {
         if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");

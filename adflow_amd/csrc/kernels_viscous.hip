@@ -1114,6 +1114,230 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
 }
 
 // ---------------------------------------------------------------------------
+// FUSED nodal gradients + viscous fluxes (tuning "viscous_fused").  The two marching kernels above exchange the 12 nodal
+// gradients through HBM: 106 B per cell written, ~140 B read back, and the gradient kernel re-reads the state and the face
+// normals the flux kernel reads as well (344 + 487 B per cell measured, profiles/r02_c_pmc_traffic.txt; both kernels run at
+// ~5 TB/s, i.e. they are bound by that traffic).  Here one workgroup of 8 waves (64 lanes x 8 cell rows) marches in k and
+//   phase A  makes the cell record of plane m (ng_record: state, tI / tJ / tK, i-pair sums) and publishes it in LDS,
+//   phase B  forms the gradients of node plane m-1 from the records of planes m-1 (carried sums) and m (ng_* algebra of
+//            k_node_grad_march) and stores them in a two-plane LDS ring,
+//   phase C  evaluates the faces of cell plane m-1 from node planes m-2 and m-1 in that ring (vm_face of k_visc_march),
+// with two barriers per plane.  The gradients never leave the CU.  Rows: wave r owns cell row / node row j0-1+r; cell rows
+// 1..7 are produced (the j faces of a cell need node rows j-1 and j), wave 0 also makes the record of the cell row above
+// the tile.  LDS: records 8 x 14 x 512 B + gradient ring 2 x 8 x 12 x 512 B = 153 KB: one workgroup per CU.
+// k_wall_stress and the updateIntermed copy-out read the gradients from HBM: those callers run k_node_grad_march as well.
+// ---------------------------------------------------------------------------
+#define VF_OUT 60
+#define VF_KCH 32
+
+// VF_ROWS: waves per workgroup (VF_ROWS - 1 cell rows produced): 8 -> one workgroup per CU, 4 -> two
+template <bool QCR, int VF_ROWS>
+__global__ __launch_bounds__(64 * VF_ROWS, 2) void k_visc_fused(const BlkView* __restrict__ tab, int nzb, KParams kp)
+{
+    constexpr int VF_REC = VF_ROWS * NG_SLOT;      // doubles of the record exchange
+    constexpr int VF_GPL = VF_ROWS * VM_G;         // doubles of one node plane in the ring
+    __shared__ double vf_lds[VF_REC + 2 * VF_GPL];     // 8 rows: 155,648 B of the 160 KiB per CU; 4 rows: 77,824 B
+    double* __restrict__ xr = vf_lds;                     // records: slot s = cell row j0+s (s = 0..7), row 0 publishes slot 7
+    double* __restrict__ gx = vf_lds + VF_REC;            // gradient ring [parity][node row][component][lane]
+    const BlkView& b = tab[blockIdx.z / nzb + 1];         // level-batched: blockIdx.z = slot * nzb + k chunk
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int i0 = blockIdx.x * VF_OUT + 2, j0 = blockIdx.y * (VF_ROWS - 1) + 2;      // first produced cell
+    const int k0 = (blockIdx.z % nzb) * VF_KCH + 2;
+    if (b.nx == 0 || k0 > b.kl || i0 > b.il || j0 > b.jl) return;                      // uniform per workgroup
+    const int k1 = (k0 + VF_KCH - 1 < b.kl) ? k0 + VF_KCH - 1 : b.kl;
+    const int i = i0 - 2 + lane, j = j0 - 1 + row;
+    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.je) ? j : b.je;
+    const int jx = (j0 + VF_ROWS - 1 < b.jb) ? j0 + VF_ROWS - 1 : b.jb;               // cell row above the tile
+    const bool out = (row >= 1 && lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
+    const long nb = b.nbox;
+    const unsigned nb8 = 8u * (unsigned)nb, sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
+    NgPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
+    m.p = (GPTR(const double))b.p;
+    m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
+    m.vol = (GPTR(const double))b.vol;
+    m.nb8 = nb8; m.sj = sj;
+    VmPtrs vp;
+    vp.w0 = m.w0; vp.w1 = m.w1; vp.w2 = m.w2; vp.w3 = m.w3; vp.p = m.p;
+    vp.rlv = (GPTR(const double))b.rlv; vp.rev = (GPTR(const double))b.rev;
+    GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
+    GPTR(const double) dK = (GPTR(const double))b.dK;
+    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
+    GPTR(double) dw = (GPTR(double))b.dw;
+    GPTR(double) fw = (GPTR(double))b.fw;
+    VmK K;
+    K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
+    K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
+    const double gam = kp.gammaConstant;
+
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + (k0 - 1) * b.ldk);      // cell plane of the record made in this iteration
+    unsigned cx = 8u * (unsigned)(ic + jx * b.ldi + (k0 - 1) * b.ldk);
+    double sKp[3], sKpx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * nb8); sKpx[d] = ldg(m.sK, cx - sk + d * nb8); }
+    NgPlane S;                 // sums of the previous cell plane
+    VmCell q0;                 // state of the own cell in the previous plane (the plane whose faces are evaluated)
+    double fk[4] = {0, 0, 0, 0};
+    const int oM = (row - 1) * VM_G + lane, o0 = row * VM_G + lane;        // node rows j-1 and j of a ring plane
+    for (int mm = k0 - 1; mm <= k1 + 1; ++mm) {
+        // ---------------- phase A: record of cell plane mm
+        NgRec R;
+        ng_record(m, c, gam, sKp, R);
+        VmCell q1;             // the own cell in plane mm
+        q1.u = R.phi[0]; q1.v = R.phi[1]; q1.w = R.phi[2]; q1.na = R.phi[3];
+        q1.rlv = ldg(vp.rlv, c);
+        q1.rev = K.eddy ? ldg(vp.rev, c) : 0.0;
+        if (row > 0) ng_publish(xr + (row - 1) * NG_SLOT, lane, R);
+        if (row == 0) {
+            NgRec X;
+            ng_record(m, cx, gam, sKpx, X);
+            ng_publish(xr + (VF_ROWS - 1) * NG_SLOT, lane, X);
+        }
+        __syncthreads();
+        // ---------------- phase B: sums of plane mm; gradients of node plane mm-1 -> ring slot (mm-1) & 1
+        {
+            NgRec U;
+            ng_fetch(xr + row * NG_SLOT, lane, U);
+            NgPlane N;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                N.Pt[d] = R.sTK[d] + U.sTK[d];
+                N.Q0t[d] = R.sTJ[d]; N.Q1t[d] = U.sTJ[d];
+                N.RIt[d] = R.tI[d] + U.tI[d];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                N.Q0p[v] = R.phi[v] + lane_dn1(R.phi[v]);
+                N.Q1p[v] = U.phi[v] + lane_dn1(U.phi[v]);
+                N.Pp[v] = N.Q0p[v] + N.Q1p[v];
+                N.RIp[v] = R.phi[v] + U.phi[v];
+            }
+            N.V = R.sV + U.sV;
+            if (mm >= k0) {
+                double g[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) g[q] = 0.0;
+                ng_outer(g, -1.0, S.Pp, S.Pt);
+                ng_outer(g, +1.0, N.Pp, N.Pt);
+                double t[3], ph[4];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) t[d] = S.Q0t[d] + N.Q0t[d];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) ph[v] = S.Q0p[v] + N.Q0p[v];
+                ng_outer(g, -1.0, ph, t);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) t[d] = S.Q1t[d] + N.Q1t[d];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) ph[v] = S.Q1p[v] + N.Q1p[v];
+                ng_outer(g, +1.0, ph, t);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) t[d] = S.RIt[d] + N.RIt[d];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) ph[v] = S.RIp[v] + N.RIp[v];
+                ng_outer(g, -1.0, ph, t);
+                double t1[3], ph1[4];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t[d]);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
+                ng_outer(g, +1.0, ph1, t1);
+                const double oneOverV = rcp_nr(S.V + N.V);
+                double* __restrict__ gb = gx + ((mm - 1) & 1) * VF_GPL;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) gb[row * VM_G + q * 64 + lane] = g[q] * oneOverV;
+            }
+            S = N;
+        }
+        __syncthreads();
+        // ---------------- phase C: faces of cell plane mm-1 (node planes mm-2 and mm-1)
+        if (mm >= k0 + 1 && row >= 1) {
+            const unsigned cf = c - sk;                                        // the cell whose faces are evaluated
+            const double* __restrict__ xb = gx + ((mm - 1) & 1) * VF_GPL;      // node plane mm-1
+            const double* __restrict__ xp = gx + (mm & 1) * VF_GPL;            // node plane mm-2
+            const int flag0 = flags[cf >> 3];
+            double acc[4];
+            if (mm == k0 + 1) {
+                // k face below the first plane of the march: nodes (i-1..i, j-1..j, k0-1)
+                double gs[12], nK[3], dKv[3];
+                const VmCell qm1 = vm_ld(vp, cf - sk, gam, K.eddy);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { const double a = xp[oM + q * 64] + xp[o0 + q * 64]; gs[q] = a + lane_up1(a); }
+                vm_ld3(m.sK, cf - sk, nb8, nK); vm_ld3(dK, cf - sk, nb8, dKv);
+                vm_face<QCR>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(cf - sk) >> 3]), fk);
+            }
+            // ---- the four faces the cell evaluates, as a ROLLED loop (one inlined face evaluation: the sums of the gradient
+            //      phase stay in registers next to it; unrolled, the four evaluations spill 350 B per thread):
+            //        0: (j-1 | j)  nodes (i-1..i, j-1, k-1..k)     1: (i | i+1)  nodes (i, j-1..j, k-1..k), (i-1 | i) from lane-1
+            //        2: (j | j+1)  nodes (i-1..i, j,   k-1..k)     3: (k | k+1)  nodes (i-1..i, j-1..j, k)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) acc[l] = fk[l];
+#pragma unroll 1
+            for (int fc = 0; fc < 4; ++fc) {
+                double gs[12], fN[3], dN[3], f[4];
+                VmCell L, Rr;
+                int por;
+                if (fc == 0) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) { const double a = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = a + lane_up1(a); }
+                    L = vm_ld(vp, cf - sj, gam, K.eddy); Rr = q0;
+                    vm_ld3(m.sJ, cf - sj, nb8, fN); vm_ld3(dJ, cf - sj, nb8, dN);
+                    por = flg_porJ(flags[(cf - sj) >> 3]);
+                } else if (fc == 1) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) gs[q] = (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
+                    L = q0; Rr = vm_dn1(q0);
+                    vm_ld3(m.sI, cf, nb8, fN); vm_ld3(dI, cf, nb8, dN);
+                    por = flg_porI((uint8_t)flag0);
+                } else if (fc == 2) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) { const double a = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = a + lane_up1(a); }
+                    L = q0; Rr = vm_ld(vp, cf + sj, gam, K.eddy);
+                    vm_ld3(m.sJ, cf, nb8, fN); vm_ld3(dJ, cf, nb8, dN);
+                    por = flg_porJ((uint8_t)flag0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) { const double a = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = a + lane_up1(a); }
+                    L = q0; Rr = q1;
+                    vm_ld3(m.sK, cf, nb8, fN); vm_ld3(dK, cf, nb8, dN);
+                    por = flg_porK((uint8_t)flag0);
+                }
+                vm_face<QCR>(K, gs, L, Rr, fN, dN, por, f);
+                if (fc == 0) {
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) acc[l] += f[l];
+                } else if (fc == 1) {
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
+                } else {
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) acc[l] -= f[l];
+                    if (fc == 3) {
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) fk[l] = f[l];
+                    }
+                }
+            }
+            if (out) {
+                const double blank = flg_blank((uint8_t)flag0);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    const unsigned o = cf + (l + 1) * nb8;
+                    double fwn = acc[l];
+                    if (kp.fwMode) {
+                        fwn += ldg(fw, o);
+                        stg(fw, o, fwn);
+                    }
+                    stg(dw, o, (ldg(dw, o) + fwn) * blank);
+                }
+                if (kp.fwMode) stg(dw, cf, (ldg(dw, cf) + ldg(fw, cf)) * blank);
+            }
+        }
+        q0 = q1;
+        c += sk; cx += sk;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // viscousFluxApprox (fluxes.F90:3487-3859): thin-layer form for the preconditioner assembly.  The gradient on a
 // face is the difference of the two cell values along the centre-to-centre vector d (no nodal gradients):
 // grad(q) = (q_R - q_L) d / |d|^2.  d is the static face vector of k_face_vectors (same node order).
@@ -1224,6 +1448,25 @@ void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const 
     else if (g_visc_sb == 0) hipLaunchKernelGGL((k_visc_march<false, 0>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
     else if (g_visc_sb == 1) hipLaunchKernelGGL((k_visc_march<false, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
     else hipLaunchKernelGGL((k_visc_march<false, 2>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+}
+
+int g_viscous_fused_rows = 8;   // tuning "viscous_fused_rows": 8 or 4 waves per workgroup
+int g_viscous_fused = 0;    // tuning "viscous_fused": 0 = off, 1 = where the gradients need not reach HBM, 2 = always
+
+// fused nodal gradients + viscous fluxes (one launch for every block of the level)
+void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    const int nch = (nz + VF_KCH - 1) / VF_KCH;
+    const int rows = (g_viscous_fused_rows == 4) ? 4 : 8;
+    const dim3 blk(64, rows, 1), grd((nx + VF_OUT - 1) / VF_OUT, (ny + rows - 2) / (rows - 1), nch * nslots);
+    if (rows == 8) {
+        if (kp.useQCR) hipLaunchKernelGGL((k_visc_fused<true, 8>), grd, blk, 0, s, tab, nch, kp);
+        else hipLaunchKernelGGL((k_visc_fused<false, 8>), grd, blk, 0, s, tab, nch, kp);
+    } else {
+        if (kp.useQCR) hipLaunchKernelGGL((k_visc_fused<true, 4>), grd, blk, 0, s, tab, nch, kp);
+        else hipLaunchKernelGGL((k_visc_fused<false, 4>), grd, blk, 0, s, tab, nch, kp);
+    }
 }
 
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)

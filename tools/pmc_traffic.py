@@ -17,7 +17,7 @@ import sys
 
 PHASE_OF = [("k_roe_march", "inviscid"), ("k_inviscid_march", "inviscid"), ("k_inviscid<", "inviscid"), ("k_euler_march", "inviscid"),
             ("k_sa_residual", "SA residual"), ("k_nodal_gradients", "nodal gradients"), ("k_node_grad", "nodal gradients"),
-            ("k_viscous", "viscous"), ("k_time_step", "time step"), ("k_halo_copy", "halo copies"), ("k_entropy", "entropy sensor")]
+            ("k_viscous", "viscous"), ("k_visc_march", "viscous"), ("k_time_step", "time step"), ("k_halo_copy", "halo copies"), ("k_entropy", "entropy sensor")]
 
 
 def per_kernel(db, counter):
