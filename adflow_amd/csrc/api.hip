@@ -382,6 +382,12 @@ int adflow_gpu_set_options(const adflow_opts* o)
     if (!o) return fail("null options");
     if (o->equations < ADFLOW_EULER || o->equations > ADFLOW_RANS) return fail("equations=%d not supported", o->equations);
     if (o->nRKStages < 1 || o->nRKStages > ADFLOW_MAX_RK_STAGES) return fail("nRKStages=%d out of range", o->nRKStages);
+    if (o->unsupported)
+        return fail("configuration outside the GPU path:%s%s%s%s (this library computes the steady, constant-cp, 1-to-1 multiblock residual only)",
+                    (o->unsupported & 1) ? " unsteady / time-spectral equationMode;" : "", (o->unsupported & 2) ? " cpModel /= cpConstant;" : "",
+                    (o->unsupported & 4) ? " wall functions;" : "", (o->unsupported & 8) ? " overset blocks;" : "");
+    if (o->equations == ADFLOW_RANS && o->turbModel != 2)   // spalartAllmaras (constants.F90)
+        return fail("turbModel=%d not supported (Spalart-Allmaras only)", o->turbModel);
     g_opts = *o;
     g_have_opts = true;
     return 0;
@@ -394,6 +400,8 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     if (d->nx < 1 || d->ny < 1 || d->nz < 1) return fail("block %d: bad dimensions %d %d %d", nn, d->nx, d->ny, d->nz);
     if (d->nw != 5 && d->nw != 6) return fail("block %d: nw=%d not supported (5, or 6 with SA)", nn, d->nw);
     if (find_block(nn, level, sps)) return fail("block (%d,%d,%d) already registered", nn, level, sps);
+    // the level-batched kernels hold one spectral instance: a second one would silently keep stale dw / w
+    if (sps != 1) return fail("block (%d,%d,%d): only sps = 1 (steady, one spectral instance) is supported", nn, level, sps);
     Block* b = new Block;
     b->d = *d;
     BlkView& v = b->v;
@@ -612,8 +620,14 @@ int adflow_gpu_upload_state(int nn, int level, int sps)
     if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
     const adflow_block_desc& d = b->d;
     BlkView& v = b->v;
-    if (!d.w || !d.p || !d.gamma) return fail("block (%d,%d,%d): w, p and gamma host arrays are required", nn, level, sps);
+    if (!d.w || !d.p || (!d.gamma && level == 1))
+        return fail("block (%d,%d,%d): w, p and (on the finest level) gamma host arrays are required", nn, level, sps);
     int rc = 0;
+    if (!d.gamma) {
+        // coarse levels of the reference alias the fine level's gamma with fine strides (not handed over): constant gamma
+        std::vector<double> g((size_t)(v.ib + 1) * (v.jb + 1) * (v.kb + 1), g_opts.gammaConstant);
+        rc |= copy_box(b, v.gamma, g.data(), 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
+    }
     rc |= copy_box(b, v.w, d.w, v.nw, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
     rc |= copy_box(b, v.p, d.p, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
     rc |= copy_box(b, v.gamma, d.gamma, 1, 0, v.ib + 1, 0, v.jb + 1, 0, v.kb + 1, true);
@@ -1040,6 +1054,11 @@ int level_tab(int level, LevelTab* t)
     if (ensure_table(level)) return 1;
     const LevelDims& ld = g_tab_dims[level];
     t->tab = g_tab[level]; t->n = g_tab_size[level]; t->nx = ld.nx; t->ny = ld.ny; t->nz = ld.nz;
+    // the level-batched launches fold (block slot, k plane) into gridDim.z, which HIP limits to 65535
+    if ((long)(ld.nz + 4) * t->n > 65535)
+        return fail("level %d: %d block slots x %d k planes exceed the 65535 limit of gridDim.z of the level-batched launches "
+                    "(about %d blocks of this depth per rank): distribute the blocks over more ranks", level, t->n, ld.nz + 4,
+                    65535 / (ld.nz + 4));
     return 0;
 }
 
@@ -1048,8 +1067,10 @@ int time_step_level(int level, const KParams& kp)
     LevelTab t;
     if (level_tab(level, &t)) return 1;
     launch_time_step_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    // the NS / RANS kernel also leaves the entropy sensor in ss -- but not in a dissApprox pass (frozen sensor kept)
+    const bool wrote_ss = kp.viscous && !kp.dissApprox;
     for (auto& kv : g_blocks)
-        if (std::get<0>(kv.first) == level) kv.second->ss_valid = true;
+        if (std::get<0>(kv.first) == level) kv.second->ss_valid = wrote_ss;
     return 0;
 }
 
@@ -1836,6 +1857,7 @@ int adflow_gpu_rk_smooth(int level)
     for (int stage = 1; stage <= nst; ++stage) {
         KParams kp = make_kparams(level, 1.0, 1);
         const double scale = (g_opts.lowSpeedPreconditioner ? 0.8 : 1.0) * kp.cfl * g_opts.etaRK[stage - 1];   // smoothers.F90:202
+        if (level_tab(level, &t)) return 1;      // a BC callback of the previous stage may have rebuilt the device table
         if (smooth_residual(stage)) {
             launch_scale_dw_level(t.tab, t.n, t.nx, t.ny, t.nz, scale, 0, g_stream);
             if (res_averaging_level(level, kp)) return 1;

@@ -21,7 +21,7 @@ module adflowGpuShim
         integer(c_int32_t) :: groundLevel
         integer(c_int32_t) :: turbRelax
         integer(c_int32_t) :: eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment
-        integer(c_int32_t) :: hScalingInlet, reserved_i
+        integer(c_int32_t) :: hScalingInlet, unsupported
         integer(c_int32_t) :: lowSpeedPreconditioner
         real(c_double) :: gammaConstant, prandtl, prandtlTurb
         real(c_double) :: SSuthDim, muSuthDim, TSuthDim
@@ -300,6 +300,7 @@ contains
         use iteration, only: groundLevel, ordersConverged
         use flowVarRefState
         use paramTurb, only: rsaCw1
+        use oversetData, only: oversetPresent
         type(adflow_opts) :: o
         integer :: n
         o%equations = equations; o%turbModel = turbModel; o%turbProd = turbProd
@@ -312,7 +313,13 @@ contains
         o%turbRelax = turbRelax
         o%eulerWallBCTreatment = eulerWallBCTreatment; o%viscWallBCTreatment = viscWallBCTreatment
         o%outflowTreatment = outflowTreatment
-        o%hScalingInlet = merge(1, 0, hScalingInlet); o%reserved_i = 0
+        o%hScalingInlet = merge(1, 0, hScalingInlet)
+        ! configurations outside the path: refused by the library (adflow_gpu_set_options) instead of computed wrongly
+        o%unsupported = 0
+        if (equationMode /= steady) o%unsupported = ior(o%unsupported, 1)
+        if (cpModel /= cpConstant) o%unsupported = ior(o%unsupported, 2)
+        if (wallFunctions) o%unsupported = ior(o%unsupported, 4)
+        if (oversetPresent) o%unsupported = ior(o%unsupported, 8)
         o%lowSpeedPreconditioner = merge(1, 0, lowSpeedPreconditioner)
         o%gammaConstant = gammaConstant; o%prandtl = prandtl; o%prandtlTurb = prandtlTurb
         o%SSuthDim = SSuthDim; o%muSuthDim = muSuthDim; o%TSuthDim = TSuthDim
@@ -349,7 +356,14 @@ contains
             d%nx = b%nx; d%ny = b%ny; d%nz = b%nz; d%nw = nw
             d%rightHanded = merge(1, 0, b%rightHanded); d%reserved = 0
             d%w = c_loc(b%w); d%p = c_loc(b%p)
-            d%gamma = c_loc(b1%gamma); d%rlv = c_loc(b1%rlv); d%rev = c_null_ptr
+            ! gamma, rlv, dw, fw, dtl, radI/J/K exist on the finest level only; setPointers aims the coarse levels at the
+            ! FINE arrays and indexes them with coarse i,j,k (utils.F90:3310-3360), i.e. with the fine strides.  The library
+            ! copies contiguous level-shaped boxes, so the coarse levels do not hand these over (gamma is the constant of
+            ! the calorically perfect gas there, the others are device-only work arrays on coarse levels).
+            d%gamma = c_null_ptr; d%rlv = c_null_ptr; d%rev = c_null_ptr
+            if (level == 1) then
+                d%gamma = c_loc(b1%gamma); d%rlv = c_loc(b1%rlv)
+            end if
             if (associated(b%rev)) d%rev = c_loc(b%rev)
             d%x = c_loc(b%x); d%sI = c_loc(b%sI); d%sJ = c_loc(b%sJ); d%sK = c_loc(b%sK)
             d%vol = c_loc(b%vol); d%volRef = c_null_ptr; d%d2Wall = c_null_ptr
@@ -357,8 +371,12 @@ contains
             if (associated(b%d2Wall)) d%d2Wall = c_loc(b%d2Wall)
             d%porI = c_loc(g%porI); d%porJ = c_loc(g%porJ); d%porK = c_loc(g%porK)
             d%iblank = c_loc(b%iblank)
-            d%dw = c_loc(b1%dw); d%fw = c_loc(b1%fw); d%dtl = c_loc(b1%dtl)
-            d%radI = c_loc(b1%radI); d%radJ = c_loc(b1%radJ); d%radK = c_loc(b1%radK)
+            d%dw = c_null_ptr; d%fw = c_null_ptr; d%dtl = c_null_ptr
+            d%radI = c_null_ptr; d%radJ = c_null_ptr; d%radK = c_null_ptr
+            if (level == 1) then
+                d%dw = c_loc(b1%dw); d%fw = c_loc(b1%fw); d%dtl = c_loc(b1%dtl)
+                d%radI = c_loc(b1%radI); d%radJ = c_loc(b1%radJ); d%radK = c_loc(b1%radK)
+            end if
             d%w1 = c_null_ptr; d%p1 = c_null_ptr; d%wr = c_null_ptr
             d%mgIFine = c_null_ptr; d%mgJFine = c_null_ptr; d%mgKFine = c_null_ptr
             d%mgIWeight = c_null_ptr; d%mgJWeight = c_null_ptr; d%mgKWeight = c_null_ptr

@@ -91,6 +91,8 @@ class FlowParams:
     LRef: float = 1.0
     ordersConverged: float = 16.0
     alfaTurb: float = 0.8
+    # bit mask of reference features outside the GPU path (include/adflow_gpu.h adflow_opts::unsupported); 0 = none
+    unsupported: int = 0
     betaTurb: float = -1.0
     # --- iteration
     currentLevel: int = 1

@@ -103,7 +103,10 @@ typedef struct adflow_opts {
      * outflowTreatment 1 constant, 2 linear extrapolation */
     int32_t eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment;
     int32_t hScalingInlet;            /* inputDiscretization: total-enthalpy scaling of the subsonic-inflow Riemann invariant */
-    int32_t reserved_i;
+    /* features of the reference this library does NOT implement, as a bit mask the host fills from its option modules:
+     * 1 equationMode /= steady (unsteady / time spectral), 2 cpModel /= cpConstant, 4 wall functions, 8 overset blocks present.
+     * adflow_gpu_set_options refuses a non-zero mask instead of silently returning steady, constant-gamma, 1-to-1 results. */
+    int32_t unsupported;
     int32_t lowSpeedPreconditioner;   /* inputDiscretization: residual_block's 5x5 low-Mach transform (residuals.F90:172-331) + the 0.8 RK step factor (smoothers.F90:202) */
     double gammaConstant, prandtl, prandtlTurb;
     double SSuthDim, muSuthDim, TSuthDim;

@@ -37,6 +37,7 @@ def load(fast: bool = False) -> ctypes.CDLL:
         lib.ref_call.argtypes = [ctypes.c_char_p, ctypes.c_int]
         lib.ref_block_res_core.argtypes = [ctypes.c_int] * 3
         lib.ref_block_res_core2.argtypes = [ctypes.c_int] * 5
+        lib.ref_blockette_res_core.argtypes = [ctypes.c_int] * 5
         lib.ref_alloc_doms.argtypes = [ctypes.c_int] * 2
         lib.ref_commit_block.argtypes = [ctypes.c_int] * 2
         lib.ref_set_internal_comm.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
@@ -119,6 +120,7 @@ def bind_block(blk, prm) -> None:
     need("fw", (ib + 1, jb + 1, kb + 1, 5))
     need("scratch", (ib + 1, jb + 1, kb + 1, 10))
     need("aa", (ib + 1, jb + 1, kb + 1))
+    need("shockSensor", (ib + 1, jb + 1, kb + 1))      # read by blocketteResCore on the fine level (blockette.F90:387,475)
     for n in _WORK3_IE:
         need(n, (ie, je, ke))
     for n in _GRADS:
@@ -144,7 +146,7 @@ def bind_block(blk, prm) -> None:
     lib.ref_set_moving(int("sFaceI" in a), int(getattr(blk, "rotRate", None) is not None), rot.ctypes.data)
     for name in [n for n in ("sFaceI", "sFaceJ", "sFaceK") if n in a] + \
                 ["w", "p", "gamma", "rlv", "rev", "vol", "volRef", "iblank", "x", "sI", "sJ", "sK",
-                 "porI", "porJ", "porK", "d2Wall", "dw", "fw", "scratch", "aa", "wn", "pn", "wr", "w1", "p1",
+                 "porI", "porJ", "porK", "d2Wall", "dw", "fw", "scratch", "aa", "shockSensor", "wn", "pn", "wr", "w1", "p1",
                  "bmti1", "bmti2", "bmtj1", "bmtj2", "bmtk1", "bmtk2",
                  "bvti1", "bvti2", "bvtj1", "bvtj2", "bvtk1", "bvtk2",
                  "indFamilyI", "indFamilyJ", "indFamilyK", "factFamilyI", "factFamilyJ", "factFamilyK",
@@ -229,6 +231,12 @@ def block_res_core(update_intermed=True, flow_res=True, turb_res=True, diss_appr
                    int(visc_approx))
     else:
         _big_stack(load().ref_block_res_core, int(update_intermed), int(flow_res), int(turb_res))
+
+
+def blockette_res_core(update_intermed=False, flow_res=True, turb_res=True, diss_approx=False, visc_approx=False) -> None:
+    """blockette::blocketteResCore (blockette.F90:299-753): the reference's default (cache-blocked) residual path,
+    called unchanged on the bound block."""
+    _big_stack(load().ref_blockette_res_core, int(update_intermed), int(flow_res), int(turb_res), int(diss_approx), int(visc_approx))
 
 
 def time_block_res_core(seconds: float, update_intermed=True, flow_res=True, turb_res=True):

@@ -722,6 +722,18 @@ contains
         end if
     end subroutine ref_block_res_core
 
+    ! blockette::blocketteResCore (blockette.F90:299-753), the reference's DEFAULT residual path (useBlockettes = True,
+    ! pyADflow.py:5734), called unchanged: metrics recomputed from x per 8^3 tile, fused SA routines, its own time step.
+    ! blocketteRes sets rFil = one before the core (blockette.F90:270).
+    subroutine ref_blockette_res_core(updateIntermed, flowRes, turbRes, dissApprox, viscApprox) &
+        bind(C, name="ref_blockette_res_core")
+        use blockette, only: blocketteResCore
+        use iteration, only: rFil
+        integer(c_int), value :: updateIntermed, flowRes, turbRes, dissApprox, viscApprox
+        rFil = one
+        call blocketteResCore(dissApprox /= 0, viscApprox /= 0, updateIntermed /= 0, flowRes /= 0, turbRes /= 0, .true.)
+    end subroutine ref_blockette_res_core
+
     ! the same sequence with the approximate-residual switches of blockResCore (blockette.F90:755-852)
     subroutine ref_block_res_core2(updateIntermed, flowRes, turbRes, dissApprox, viscApprox) &
         bind(C, name="ref_block_res_core2")

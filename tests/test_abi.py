@@ -67,3 +67,29 @@ def test_no_cpu_fallback():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
     assert "rc 1" in out and "no CPU fallback" in out, out
     assert "rc2 1" in out, out
+
+
+def test_unsupported_configurations_are_refused():
+    """adflow_opts::unsupported (unsteady / time spectral, cp curve fits, wall functions, overset) and sps > 1 must be
+    refused instead of silently computed as steady, constant-gamma, 1-to-1 (round-1 advisor finding)."""
+    import ctypes
+    from adflow_amd.params import FlowParams
+    lib = capi.load()
+    for bit, word in ((1, "unsteady"), (2, "cpModel"), (4, "wall functions"), (8, "overset")):
+        o = capi.opts_from_params(FlowParams(unsupported=bit))
+        assert lib.adflow_gpu_set_options(ctypes.byref(o)) != 0
+        assert word in lib.adflow_gpu_last_error().decode()
+    o = capi.opts_from_params(FlowParams())
+    assert lib.adflow_gpu_set_options(ctypes.byref(o)) == 0
+
+
+def test_shim_hands_no_aliased_arrays_to_coarse_levels():
+    """gpuRegisterBlock: gamma, rlv, dw, fw, dtl, radI/J/K alias the finest level's storage on coarse levels (setPointers)
+    and must not be handed over with a coarse shape (round-1 advisor finding)."""
+    src = open(os.path.join(ROOT, "adflow_amd", "fortran", "adflow_gpu_shim.F90")).read()
+    blk = src[src.index("subroutine gpuRegisterBlock"):src.index("end subroutine gpuRegisterBlock")]
+    for name in ("gamma", "rlv", "dw", "fw", "dtl", "radI", "radJ", "radK"):
+        assert re.search(r"d%%%s = c_null_ptr" % name, blk), name
+        m = re.search(r"if \(level == 1\) then(.*?)end if", blk, flags=re.S)
+        assert m
+    assert "sps = 1" in open(os.path.join(ROOT, "adflow_amd", "csrc", "api.hip")).read()

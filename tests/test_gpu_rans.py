@@ -123,3 +123,12 @@ def test_block_res_without_intermediates(engine):
         dw = engine.download_residual()
         for l in range(blk.nw):
             assert rel_err(owned(blk, dw[..., l]), owned(blk, r["dw"][..., l])) <= TOL, (sd, l)
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+@pytest.mark.parametrize("update", [False, True])
+def test_block_res_vs_blockette_core(engine, sd, update):
+    """the reference's default residual path (blocketteResCore) on the config 3 / 4 parity sizes"""
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156)
+    checks.check_block_res_vs_blockette(engine, (24, 20, 10), prm, update, seed=sd, stretch_k=3.0)
+    checks.check_block_res_vs_blockette(engine, (17, 9, 11), FlowParams(spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156), update, seed=sd)

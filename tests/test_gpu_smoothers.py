@@ -17,6 +17,13 @@ def test_halo_exchange_same_gpu(engine, nLayers):
     checks.check_halo_exchange(engine, BrickTopology(2, 2, 1, 8, 6, 5), FlowParams(equations=RANSEquations), nLayers)
 
 
+@pytest.mark.parametrize("nLayers,nranks", [(2, 2), (1, 2), (2, 8)])
+def test_halo_pack_unpack_loopback(engine, nLayers, nranks):
+    """a18: the pack / unpack kernels of the inter-GPU path on the real device (2 and 8 virtual ranks of a 2x2x2 brick,
+    every rank with face, edge and corner peers) against the reference's whalo1 / whalo2 on the undivided brick"""
+    checks.check_halo_loopback(engine, BrickTopology(2, 2, 2, 8, 6, 5), nranks, FlowParams(equations=RANSEquations), nLayers)
+
+
 def test_halo_exchange_self_periodic_single_block(engine):
     checks.check_halo_exchange(engine, BrickTopology(1, 1, 1, 7, 5, 3), FlowParams(), 2)
 

@@ -351,3 +351,15 @@ def test_viscous_kernel_variants(hostsim_engine):
 def test_block_res_without_intermediates(hostsim_engine):
     import test_gpu_rans
     test_gpu_rans.test_block_res_without_intermediates(hostsim_engine)
+
+
+@pytest.mark.parametrize("nLayers,nranks", [(2, 2), (2, 8)])
+def test_halo_pack_unpack_loopback(hostsim_engine, nLayers, nranks):
+    checks.check_halo_loopback(hostsim_engine, BrickTopology(2, 2, 2, 5, 4, 3), nranks, FlowParams(equations=RANSEquations), nLayers)
+
+
+@pytest.mark.parametrize("sd", [dissScalar, upwind])
+def test_block_res_vs_blockette_core(hostsim_engine, sd):
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=sd)
+    checks.check_block_res_vs_blockette(hostsim_engine, (12, 10, 9), prm, False, seed=sd, stretch_k=3.0)
+    checks.check_block_res_vs_blockette(hostsim_engine, (12, 10, 9), prm, True, seed=sd, stretch_k=3.0)

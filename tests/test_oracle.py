@@ -52,3 +52,19 @@ def test_c_restatement_vs_reference_random_sizes():
         s = (slice(2, a.il + 1), slice(2, a.jl + 1), slice(2, a.kl + 1))
         for l in range(5):
             assert rel_err(a["dw"][s][..., l], b["dw"][s][..., l]) <= TOL
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_blockette_twin_agrees_with_block_path(name):
+    """blockette::blocketteResCore (the reference's default, cache-blocked residual path, blockette.F90:299-753) and the
+    blockResCore sequence the golden vectors were generated with must agree to round-off on every golden case (SURVEY.md
+    Appendix C: "a free cross-check for the oracle"); the golden vectors therefore pin BOTH twins."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    prm, blk, gold, turb = load_case(name)
+    ref.bind_block(blk, prm)
+    ref.blockette_res_core(False, True, turb)
+    s = (slice(2, blk.il + 1), slice(2, blk.jl + 1), slice(2, blk.kl + 1))
+    for l in range(blk.nw):
+        assert rel_err(blk["dw"][s][..., l], gold["dw"][..., l]) <= 1e-13, (name, l)
