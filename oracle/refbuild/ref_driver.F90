@@ -734,6 +734,44 @@ contains
         call blocketteResCore(dissApprox /= 0, viscApprox /= 0, updateIntermed /= 0, flowRes /= 0, turbRes /= 0, .true.)
     end subroutine ref_blockette_res_core
 
+    ! EXECUTES the ISO_C_BINDING host side of the drop-in boundary (adflow_amd/fortran/adflow_gpu_shim.F90) against the C-ABI
+    ! library that is loaded in this process: options from the reference's option modules, every block of the level from
+    ! flowDoms(nn,level,1) by c_loc, the boundary subfaces, the 1-to-1 patterns of communication.F90, then ONE blocketteRes
+    ! evaluation (flags of include/adflow_gpu.h) and the residual back into flowDoms(nn,1,1)%dw -- what the call-site edits of
+    ! INTEGRATION.md do inside blockette::blocketteRes.  nSmooth > 0 additionally runs that many smoother sweeps
+    ! (RungeKuttaSmoother / DADISmoother bodies) and brings the state back.
+    subroutine ref_shim_roundtrip(level, flags, withBocos, nSmooth) bind(C, name="ref_shim_roundtrip")
+        use adflowGpuShim
+        use block, only: nDom
+        use communication, only: commPatternCell_1st, commPatternCell_2nd, internalCell_1st, internalCell_2nd
+        use inputIteration, only: smoother
+        integer(c_int), value :: level, flags, withBocos, nSmooth
+        integer(kind=intType) :: nn, lev
+        integer :: it
+        lev = level
+        call gpuCheck(adflow_gpu_release_all(), "ref_shim_roundtrip")
+        call gpuRefreshOptions()
+        do nn = 1, nDom
+            call gpuRegisterBlock(nn, lev, 1_intType)
+            call gpuCheck(adflow_gpu_upload_state(int(nn, c_int), level, 1_c_int), "upload_state")
+            if (withBocos /= 0) call gpuRegisterBocos(nn, lev, 1_intType)
+        end do
+        call gpuRegisterComm(lev, 2_intType, commPatternCell_2nd(level), internalCell_2nd(level))
+        call gpuRegisterComm(lev, 1_intType, commPatternCell_1st(level), internalCell_1st(level))
+        call gpuCheck(adflow_gpu_block_res(level, flags), "block_res")
+        do it = 1, nSmooth
+            if (smoother == RungeKutta) then
+                call gpuCheck(adflow_gpu_rk_smooth(level), "rk_smooth")
+            else
+                call gpuCheck(adflow_gpu_dadi_smooth(level), "dadi_smooth")
+            end if
+        end do
+        do nn = 1, nDom
+            call gpuCheck(adflow_gpu_download_residual(int(nn, c_int), level, 1_c_int), "download_residual")
+            if (nSmooth > 0) call gpuCheck(adflow_gpu_download_state(int(nn, c_int), level, 1_c_int), "download_state")
+        end do
+    end subroutine ref_shim_roundtrip
+
     ! the same sequence with the approximate-residual switches of blockResCore (blockette.F90:755-852)
     subroutine ref_block_res_core2(updateIntermed, flowRes, turbRes, dissApprox, viscApprox) &
         bind(C, name="ref_block_res_core2")
