@@ -31,13 +31,14 @@ def assert_dw(blk, dw_gpu, dw_ref, nvar=5, tol=TOL, what="dw"):
         assert e <= tol, (what, l, e)
 
 
-def check_block_res(engine, dims, prm, seed=1, **mk):
+def check_block_res(engine, dims, prm, seed=1, blk=None, **mk):
     """blocketteRes core (timeStep + initres + fluxes + sum) vs blockResCore of
-    the reference (blockette.F90:755-852)."""
+    the reference (blockette.F90:755-852).  blk: a prepared block instead of make_block(dims, ...)."""
     from oracle import ref
     lvl = new_level(engine)
     prm = prm.replace(currentLevel=lvl, groundLevel=lvl)
-    blk = make_block(*dims, prm, seed=seed, **mk)
+    if blk is None:
+        blk = make_block(*dims, prm, seed=seed, **mk)
     r = ref_bind(blk, prm)
     turb = prm.equations == RANSEquations
     ref.block_res_core(True, True, turb)
@@ -160,7 +161,7 @@ def check_rk_residual_sequence(engine, dims, prm, seed=3, **mk):
 # multi-block checks against the reference's SHELL routines (smoothers.F90,
 # haloExchange.F90) on periodic bricks of blocks
 # ---------------------------------------------------------------------------
-def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, split=(), **mk):
+def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, split=(), mutate=None, **mk):
     """applyAllBC_block (BCRoutines.F90:57-221) on a block whose six faces are physical boundaries:
     every halo value the reference's routine writes (w, p, gamma, rlv, rev on both halo rings,
     edges and corners included, where later subfaces read what earlier ones wrote)."""
@@ -169,6 +170,8 @@ def check_apply_bc(engine, dims, prm, spec, secondHalo=True, seed=51, level=1, s
     new_level(engine)
     prm = prm.replace(currentLevel=level, groundLevel=1)
     blk = make_block(*dims, prm, seed=seed, **mk)
+    if mutate is not None:
+        mutate(blk)
     faces, nvisc = make_bocos(blk, prm, spec, seed=seed + 1, split=split)
     r = blk.copy()
     ref.bind_block(r, prm)
@@ -630,6 +633,45 @@ def check_halo_loopback(engine, topo, nranks, prm, nLayers=2, seed=5):
             assert buf.size == nvar * cnt.value
             capi.check(lib.adflow_gpu_halo_unpack(1, nLayers, q, *var, buf.ctypes.data), lib)
     assert_state(engine, blocks, rblocks, prm, f"whalo{nLayers} through pack / unpack of {nranks} virtual ranks", tol=1e-14)
+
+
+def check_vacuum_smoother(engine, topo, prm, seed=7, frac=2e-4, **mk):
+    """RungeKuttaSmoother on a brick whose blocks hold a near-vacuum pocket: the stage update must clip density and pressure
+    at 1e-4 of the free stream exactly as executeRkStage does (smoothers.F90:326, 342).  Returns the number of cells the
+    REFERENCE clipped (counted on its arrays after the sweep)."""
+    from oracle import ref
+    from adflow_amd.topology import apply_local_copies_fast
+    import adversarial
+    prm = prm.replace(smoother=RungeKutta)
+    lvl = new_level(engine)
+    blocks = make_brick(topo, prm, seed, **mk)
+    for b in blocks.values():
+        adversarial.vacuum_pocket(b, prm, frac)
+    pats = {L: topo.patterns(L)[0] for L in (1, 2)}
+    apply_local_copies_fast(blocks, pats[2])
+    rblocks = {nn: b.copy() for nn, b in blocks.items()}
+    ref.bind_blocks(rblocks, prm.replace(currentLevel=1, groundLevel=1))
+    engine.set_options(prm)
+    for L in (1, 2):
+        ref.set_internal_comm(1, L, pats[L])
+    for nn, b in blocks.items():
+        engine.register(b, nn=nn, level=lvl)
+    for L in (1, 2):
+        engine.comm_register(lvl, L, pats[L])
+    ref.load().ref_set_int(b"rkStage", 0)
+    ref.call_level("timeStep", 1, 0)
+    ref.call_level("initres", 1, 1, 5)
+    ref.call_level("residual", 1)
+    ref.call_level("RungeKuttaSmoother", 1)
+    engine.timeStep(1, False)
+    engine.residual(1, 0)
+    engine.RungeKuttaSmoother(1)
+    clipped = 0
+    for r in rblocks.values():
+        s = (slice(2, r.il + 1), slice(2, r.jl + 1), slice(2, r.kl + 1))
+        clipped += int((r["w"][s + (0,)] == 1.e-4 * prm.rhoInf).sum()) + int((r["p"][s] == 1.e-4 * prm.pInfCorr).sum())
+    assert_state(engine, blocks, rblocks, prm, "RK sweep over a near-vacuum pocket")
+    return clipped
 
 
 def check_rk_smoother(engine, topo, prm, seed=7, nsweeps=1, **mk):

@@ -363,3 +363,12 @@ def test_block_res_vs_blockette_core(hostsim_engine, sd):
     prm = FlowParams(equations=RANSEquations, spaceDiscr=sd)
     checks.check_block_res_vs_blockette(hostsim_engine, (12, 10, 9), prm, False, seed=sd, stretch_k=3.0)
     checks.check_block_res_vs_blockette(hostsim_engine, (12, 10, 9), prm, True, seed=sd, stretch_k=3.0)
+
+
+# ---- adversarial states (GPU twins in test_gpu_adversarial.py)
+def test_adversarial_states(hostsim_engine):
+    import test_gpu_adversarial as T
+    T.shock_cases(hostsim_engine, (24, 6, 5))
+    T.vacuum_cases(hostsim_engine)
+    T.wall_revert_case(hostsim_engine)
+    T.sa_cases(hostsim_engine, (16, 6, 12))
