@@ -55,7 +55,9 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
                     raise RuntimeError(f"hipcc failed for {s}:\n{out}")
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if jobs or force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+        # -Bsymbolic-functions: calls between the library's own entry points (adflow_gpu_mg_cycle -> adflow_gpu_rk_smooth ...) bind
+        # inside the library and cannot be interposed by another definition of the same name in the process
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)

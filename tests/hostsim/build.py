@@ -15,11 +15,11 @@ LIB = os.path.join(HERE, "libadflow_hostsim.so")
 
 def build(force=False):
     srcs = sorted(glob.glob(os.path.join(ROOT, "adflow_amd", "csrc", "*.hip"))) + [os.path.join(HERE, "hostsim.cpp")]
-    deps = srcs + glob.glob(os.path.join(ROOT, "adflow_amd", "csrc", "*.h")) + \
+    deps = srcs + [os.path.abspath(__file__)] + glob.glob(os.path.join(ROOT, "adflow_amd", "csrc", "*.h")) + \
         [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "adflow_gpu.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-I", HERE,
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-Wl,-Bsymbolic-functions", "-I", HERE,
            "-DADFLOW_NO_RCCL", "-Wno-unknown-pragmas", "-o", LIB]
     for s in srcs:
         cmd += ["-x", "c++", s]
