@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows, g_grad_sa_fused, g_sa_march;
 
 namespace {
 
@@ -752,7 +752,7 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
     return sync_and_check();
 }
 
-static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad);
+static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad, bool withSA = false);
 static int source_terms_enqueue(int withBlank);
 
 // residual (residuals.F90:1028) = residual_block of every block; blockResCore (blockette.F90:755) is the same sum of
@@ -765,11 +765,11 @@ static bool has_wall_subfaces(int level);
 
 // needGradHbm: the caller wants the nodal gradients in the block arrays (updateIntermed copy-out, blockette.F90:706-750)
 static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false, bool lowSpeed = true, bool stage0 = true,
-                                 bool needGradHbm = false)
+                                 bool needGradHbm = false, bool withSA = false)
 {
     const bool wallStress = stage0 && !viscApprox && kp.viscous && level == g_opts.groundLevel && fabs(kp.rFil) >= 1.e-10 &&
                             has_wall_subfaces(level);
-    if (enqueue_flow_fluxes(level, kp, viscApprox, needGradHbm || wallStress)) return 1;
+    if (enqueue_flow_fluxes(level, kp, viscApprox, needGradHbm || wallStress, withSA)) return 1;
     if (wallStress)
         if (wall_stress_enqueue(level, kp)) return 1;
     // sourceTerms() of the call sites of `residual` (smoothers.F90:74,409, multiGrid.F90:52,887,949): fine level only
@@ -782,7 +782,7 @@ static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox =
     return 0;
 }
 
-static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad)
+static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad, bool withSA)
 {
     bool anyMoving = false;     // grid velocities / rotational source: the generic kernels carry them
     for_level(level, [&](Block* b) { anyMoving = anyMoving || b->v.sFace || b->v.moving; return 0; });
@@ -841,8 +841,10 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         // nodal gradients and face fluxes in one kernel: the gradients stay in LDS
         launch_visc_fused_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     } else if (batched && viscous_is_tiled() >= 2 && g_march_by == 4) {
-        // k-marching nodal gradients, then the k-marching face kernel over the level's tile table
-        launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        // k-marching nodal gradients (with the SA residual when the caller left it to this kernel), then the k-marching face
+        // kernel over the level's tile table
+        if (withSA) launch_grad_sa_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        else launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
         phase_mark(5);
         if (ensure_tiles(level)) return 1;
         launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
@@ -921,19 +923,30 @@ static int block_res_enqueue(int level, unsigned flags)
     }
     phase_mark(2);
     // blockResCore order: SA residual first, then the mean-flow fluxes (blockette.F90:806-851)
+    // the SA residual rides on the nodal-gradient march when that kernel runs in this evaluation (exact viscous fluxes,
+    // marching kernels, blocks at rest); otherwise its own gather kernel
+    bool saFused = false;
     if ((flags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
+        bool moving = false;
         rc = for_level(level, [&](Block* b) {
             if (b->v.nw < 6) return fail("RANS/SA needs nw = 6 (block has %d)", b->v.nw);
+            moving = moving || b->v.sFace || b->v.moving;
             return 0;
         });
         if (rc) return rc;
-        LevelTab t;
-        if (level_tab(level, &t)) return 1;
-        launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        saFused = g_grad_sa_fused && (flags & ADFLOW_RES_FLOW) && !viscApprox && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !moving &&
+                  viscous_is_tiled() >= 2 && g_march_by == 4 && g_viscous_fused < 2 &&
+                  !(g_viscous_fused == 1 && !(flags & ADFLOW_RES_UPDATE_INTERMED));
+        if (!saFused) {
+            LevelTab t;
+            if (level_tab(level, &t)) return 1;
+            if (g_sa_march && !moving) launch_sa_march_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+            else launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        }
     }
     phase_mark(3);
     if (flags & ADFLOW_RES_FLOW) {
-        rc = enqueue_flow_residual(level, kp, viscApprox, false, true, (flags & ADFLOW_RES_UPDATE_INTERMED) != 0);
+        rc = enqueue_flow_residual(level, kp, viscApprox, false, true, (flags & ADFLOW_RES_UPDATE_INTERMED) != 0, saFused);
         if (rc) return rc;
     }
     phase_mark(6);
@@ -2300,6 +2313,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
     if (!strcmp(key, "visc_sb")) { g_visc_sb = value; return 0; }
     if (!strcmp(key, "viscous_fused")) { g_viscous_fused = value; return 0; }
+    if (!strcmp(key, "grad_sa_fused")) { g_grad_sa_fused = value; return 0; }
+    if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
     if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {

@@ -39,25 +39,6 @@ __device__ __forceinline__ void stg(GPTR(double) base, unsigned byteoff, double 
     *(GPTR(double))((GPTR(char))base + byteoff) = v;
 }
 
-// a / b for the arithmetic-bound flux kernels: v_rcp_f64 + two Newton steps + one residual correction, i.e. the
-// compiler's own FP64 division without its v_div_scale / v_div_fmas / v_div_fixup range handling (8 instead of 13
-// instructions).  Only for denominators in the normal range (clamped differences, densities, face areas, sound speeds).
-#ifdef HOSTSIM
-__device__ __forceinline__ double fastdiv(double a, double b) { return a / b; }
-#else
-__device__ __forceinline__ double fastdiv(double a, double b)
-{
-    double x = __builtin_amdgcn_rcp(b);
-    double e = __builtin_fma(-b, x, 1.0);
-    x = __builtin_fma(x, e, x);
-    e = __builtin_fma(-b, x, 1.0);
-    x = __builtin_fma(x, e, x);
-    const double q = a * x;
-    const double r = __builtin_fma(-b, q, a);
-    return __builtin_fma(r, x, q);
-}
-#endif
-
 // 1 / b and 1 / sqrt(x) for operands in the normal range: the hardware seed (v_rcp_f64 / v_rsq_f64, quarter rate) refined
 // by ADF_NR Newton steps in FMA form, without the range handling, final residual correction and denormal scaling of the
 // compiler's division / sqrt.  Callers multiply by the result; the flux kernels that use them are bound by FP64 issue.
@@ -90,6 +71,56 @@ __device__ __forceinline__ double rsq_nr(double x)
         y = __builtin_fma(0.5 * y, e, y);
     }
     return y;
+}
+#endif
+
+// a / b for denominators in the normal range (clamped differences, densities, volumes, sound speeds): a * rcp_nr(b),
+// 5 FP64 issue slots instead of the ~17 of the compiler's division (v_div_scale / v_div_fmas / v_div_fixup range handling)
+__device__ __forceinline__ double fastdiv(double a, double b) { return a * rcp_nr(b); }
+
+// sqrt(x) for x >= 0 in the normal range or exactly 0
+#ifdef HOSTSIM
+__device__ __forceinline__ double fastsqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double fast_root6(double x) { return pow(x, 1.0 / 6.0); }
+__device__ __forceinline__ double fast_exp_neg(double x) { return exp(x); }
+#else
+__device__ __forceinline__ double fastsqrt(double x) { return x * rsq_nr(fmax(x, 1.e-300)); }
+// x^(1/6) for x in the normal positive range: single-precision seed of z = x^(-1/6) (v_log_f32 / v_exp_f32), two Newton steps
+// z <- z (7 - x z^6) / 6 in FP64 (quadratic: 1e-7 -> 4e-14 -> 1e-26), result x z^5.  ~25 issue slots instead of ~150 of pow().
+__device__ __forceinline__ double fast_root6(double x)
+{
+    double z = (double)__builtin_amdgcn_exp2f(-(1.0f / 6.0f) * __builtin_amdgcn_logf((float)x));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double z2 = z * z, z6 = z2 * z2 * z2;
+        z = z * __builtin_fma(-x, z6, 7.0) * (1.0 / 6.0);
+    }
+    const double z2 = z * z;
+    return x * (z2 * z2 * z);
+}
+// exp(x) for x <= 0 (the ft2 term of Spalart-Allmaras): 0 below -700, else 2^k * P(r) with k = round(x log2 e), r = x - k ln 2
+// in two pieces, Taylor polynomial of degree 13 on |r| <= ln2 / 2 (truncation 1e-17), ldexp.  ~25 slots instead of ~60.
+__device__ __forceinline__ double fast_exp_neg(double x)
+{
+    if (x < -700.0) return 0.0;
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
 }
 #endif
 
@@ -218,6 +249,8 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 int viscous_is_tiled();
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void adf_phase_mark(int i);    // api.hip: optional HIP event between the phases of blocketteRes

@@ -9,95 +9,10 @@
 //   saResScale      src/turbulence/sa.F90:678-715
 // The reference accumulates in scratch(idvt) over four sweeps; here the value
 // lives in a register.  Roofline: HBM; no MFMA.
-#include "internal.h"
+#include "sa_core.h"
 
 #define SA_BX 64
 #define SA_BY 4
-
-// minmod-limited fully-upwind (kappa=-1) difference, or first order
-// (turbUtils.F90:917-958 for uu>0, :1007-1047 for uu<=0)
-__device__ __forceinline__ double upwind_diff(bool secondOrd, bool positive, double wm2, double wm1, double w0, double wp1,
-                                              double wp2)
-{
-    if (positive) {
-        if (!secondOrd) return w0 - wm1;
-        const double dwtm1 = wm1 - wm2, dwt = w0 - wm1, dwtp1 = wp1 - w0;
-        double d = dwt;
-        if (dwt * dwtp1 > 0.0) d += (fabs(dwt) < fabs(dwtp1)) ? 0.5 * dwt : 0.5 * dwtp1;
-        if (dwt * dwtm1 > 0.0) d -= (fabs(dwt) < fabs(dwtm1)) ? 0.5 * dwt : 0.5 * dwtm1;
-        return d;
-    } else {
-        if (!secondOrd) return wp1 - w0;
-        const double dwtm1 = w0 - wm1, dwt = wp1 - w0, dwtp1 = wp2 - wp1;
-        double d = dwt;
-        if (dwt * dwtp1 > 0.0) d -= (fabs(dwt) < fabs(dwtp1)) ? 0.5 * dwt : 0.5 * dwtp1;
-        if (dwt * dwtm1 > 0.0) d += (fabs(dwt) < fabs(dwtm1)) ? 0.5 * dwt : 0.5 * dwtm1;
-        return d;
-    }
-}
-
-struct SaDir {   // per-direction data of one cell
-    double sm[3], sp[3];      // normals of the minus / plus face
-    double volm, volp;        // volumes of the minus / plus neighbour
-    double nt[5];             // nuTilde at -2..+2
-    double num, nup;          // laminar kinematic viscosity of the minus / plus neighbour
-    double qsf;               // grid velocity of a moving block: sFace(minus face) + sFace(plus face), else 0
-};
-
-// dirc: 0, 1, 2 = i, j, k (component of b.sFace)
-__device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const double* __restrict__ sN, SaDir& d, int dirc)
-{
-    const long nb = b.nbox;
-    d.qsf = 0.0;
-    if (b.sFace) d.qsf = b.sFace[c + dirc * nb] + b.sFace[c - s + dirc * nb];     // uniform branch
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        d.sm[m] = sN[c - s + m * nb];
-        d.sp[m] = sN[c + m * nb];
-    }
-    d.volm = b.vol[c - s];
-    d.volp = b.vol[c + s];
-#pragma unroll
-    for (int m = 0; m < 5; ++m) d.nt[m] = b.w[c + (m - 2) * s + 5 * nb];
-    d.num = b.rlv[c - s] / b.w[c - s];
-    d.nup = b.rlv[c + s] / b.w[c + s];
-}
-
-// advection in one direction (turbUtils.F90:886-1070)
-__device__ __forceinline__ double sa_advect(const SaDir& d, double vol0, double u, double v, double w, bool secondOrd,
-                                            double* uuOut = nullptr)
-{
-    const double voli = 0.5 / vol0;
-    const double xa = (d.sp[0] + d.sm[0]) * voli, ya = (d.sp[1] + d.sm[1]) * voli, za = (d.sp[2] + d.sm[2]) * voli;
-    const double uu = xa * u + ya * v + za * w - d.qsf * voli;       // qs = (sFace(m) + sFace(m-1)) voli, turbUtils.F90:906
-    const double dwt = upwind_diff(secondOrd, uu > 0.0, d.nt[0], d.nt[1], d.nt[2], d.nt[3], d.nt[4]);
-    if (uuOut) *uuOut = uu;
-    return -uu * dwt;
-}
-
-// diffusion in one direction (sa.F90:385-450)
-__device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double nu, double cb2, double cb3Inv,
-                                             double* c1mOut = nullptr, double* c1pOut = nullptr)
-{
-    const double voli = 1.0 / vol0;
-    const double volmi = 2.0 / (vol0 + d.volm), volpi = 2.0 / (vol0 + d.volp);
-    const double xm = d.sm[0] * volmi, ym = d.sm[1] * volmi, zm = d.sm[2] * volmi;
-    const double xp = d.sp[0] * volpi, yp = d.sp[1] * volpi, zp = d.sp[2] * volpi;
-    const double xa = 0.5 * (d.sp[0] + d.sm[0]) * voli, ya = 0.5 * (d.sp[1] + d.sm[1]) * voli,
-                 za = 0.5 * (d.sp[2] + d.sm[2]) * voli;
-    const double ttm = xm * xa + ym * ya + zm * za;
-    const double ttp = xp * xa + yp * ya + zp * za;
-    const double cnud = -cb2 * d.nt[2] * cb3Inv;
-    const double cam = ttm * cnud, cap = ttp * cnud;
-    const double nutm = 0.5 * (d.nt[1] + d.nt[2]), nutp = 0.5 * (d.nt[3] + d.nt[2]);
-    const double num = 0.5 * (d.num + nu), nup = 0.5 * (d.nup + nu);
-    const double cdm = (num + (1.0 + cb2) * nutm) * ttm * cb3Inv;
-    const double cdp = (nup + (1.0 + cb2) * nutp) * ttp * cb3Inv;
-    const double c1m = fmax(cdm + cam, 0.0), c1p = fmax(cdp + cap, 0.0);
-    const double c10 = c1m + c1p;
-    if (c1mOut) { *c1mOut = c1m; *c1pOut = c1p; }
-    return c1m * d.nt[1] - c10 * d.nt[2] + c1p * d.nt[3];
-}
 
 // SOLVE: additionally store the right-hand side (scratch 0) and the central
 // jacobian qq (scratch 1) for the DDADI line solves of saSolve

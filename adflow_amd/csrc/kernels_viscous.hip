@@ -11,7 +11,7 @@
 // pure function of its surroundings, so the two adjacent cells agree bitwise).
 // a^2 is formed on the fly from (gamma, p, rho) instead of being stored.
 // Roofline: HBM (255 B/cell RANS); no MFMA.
-#include "internal.h"
+#include "sa_core.h"
 
 #define VS_BX 64
 #define VS_BY 4
@@ -399,6 +399,265 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView
         }
         S = N;
         c += sk; cx += sk;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Nodal gradients AND the Spalart-Allmaras residual in one march (tuning "grad_sa_fused").  k_sa_residual gathers 73 values per
+// cell (237 B per cell from HBM, 3.5 TB/s: bound by load latency) and 14 of its 19 distinct arrays -- rho, u, v, w, the nine face
+// normals, vol -- are exactly what the cell record of k_node_grad_march reads.  Here the gradient march also keeps a three-plane
+// window of its own column (u, v, w, nu = rlv / rho, vol; five planes of nuTilde), takes the i neighbours by DPP lane shifts
+// and loads only the j neighbours, d2Wall, volRef and the lower-j normal in addition: the SA residual of cell plane m is
+// evaluated right after the record of plane m (the plane above is the one loaded for the next record).
+// Tiles advance by 60: nodes of lanes 1..60 and cells of lanes 2..61 (second-order advection reaches i +- 2).
+// Arithmetic of the SA terms: sa_core.h (shared with k_sa_residual), same order of the sweeps (k, j, i).
+// ---------------------------------------------------------------------------
+#define GS_OUT 60
+
+__device__ __forceinline__ void vm_ld3(GPTR(const double) a, unsigned o, unsigned nb8, double v[3])
+{
+    v[0] = ldg(a, o); v[1] = ldg(a, o + nb8); v[2] = ldg(a, o + 2 * nb8);
+}
+
+
+struct GsCell { double u, v, w, rho, p, vol, rlv; };      // own column, one plane
+struct GsNbr { double u, v, w, nu, vol, nut; };           // what a neighbour contributes to the SA terms
+
+struct GsPtrs {
+    GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) w5;
+    GPTR(const double) p; GPTR(const double) rlv; GPTR(const double) vol;
+    GPTR(const double) sI; GPTR(const double) sJ; GPTR(const double) sK;
+    GPTR(const double) d2wall; GPTR(const double) volRef;
+    unsigned nb8, sj;
+};
+
+__device__ __forceinline__ GsCell gs_ld(const GsPtrs& m, unsigned c)
+{
+    GsCell q;
+    q.rho = ldg(m.w0, c); q.u = ldg(m.w1, c); q.v = ldg(m.w2, c); q.w = ldg(m.w3, c);
+    q.p = ldg(m.p, c); q.vol = ldg(m.vol, c); q.rlv = ldg(m.rlv, c);
+    return q;
+}
+
+__device__ __forceinline__ GsNbr gs_nbr_ld(const GsPtrs& m, unsigned c)
+{
+    GsNbr q;
+    q.u = ldg(m.w1, c); q.v = ldg(m.w2, c); q.w = ldg(m.w3, c);
+    q.nu = ldg(m.rlv, c) * rcp_nr(ldg(m.w0, c));
+    q.vol = ldg(m.vol, c);
+    q.nut = ldg(m.w5, c);
+    return q;
+}
+
+__device__ __forceinline__ GsNbr gs_up1(const GsNbr& q)
+{
+    GsNbr r;
+    r.u = lane_up1(q.u); r.v = lane_up1(q.v); r.w = lane_up1(q.w); r.nu = lane_up1(q.nu); r.vol = lane_up1(q.vol); r.nut = lane_up1(q.nut);
+    return r;
+}
+__device__ __forceinline__ GsNbr gs_dn1(const GsNbr& q)
+{
+    GsNbr r;
+    r.u = lane_dn1(q.u); r.v = lane_dn1(q.v); r.w = lane_dn1(q.w); r.nu = lane_dn1(q.nu); r.vol = lane_dn1(q.vol); r.nut = lane_dn1(q.nut);
+    return r;
+}
+
+// record of a cell from its preloaded state and the face normals of its plane; nI / nJm / nJ / nK: sI(c), sJ(c - sj), sJ(c),
+// sK(c) (kept by the caller for the SA terms); sKp: sK of the plane below (in), of this plane (out)
+__device__ __forceinline__ void gs_record(const GsCell& q, double gam, const double nI[3], const double nJm[3], const double nJ[3],
+                                          const double nK[3], double sKp[3], NgRec& R)
+{
+    R.phi[0] = q.u; R.phi[1] = q.v; R.phi[2] = q.w;
+    R.phi[3] = -(gam * q.p) * rcp_nr(q.rho);
+    double tJ[3], tK[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        R.tI[d] = lane_up1(nI[d]) + nI[d];
+        tJ[d] = nJm[d] + nJ[d];
+        tK[d] = sKp[d] + nK[d];
+        sKp[d] = nK[d];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        R.sTJ[d] = tJ[d] + lane_dn1(tJ[d]);
+        R.sTK[d] = tK[d] + lane_dn1(tK[d]);
+    }
+    R.sV = q.vol + lane_dn1(q.vol);
+}
+
+// GRAD = false: the Spalart-Allmaras residual alone as a k-march (no records, no LDS, no barrier)
+template <bool GRAD>
+__global__ __launch_bounds__(64 * NG_BY, 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp)
+{
+    __shared__ double xr[GRAD ? 2 * NG_BY * NG_SLOT : 1];
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int i0 = blockIdx.x * GS_OUT + 1, j0 = blockIdx.y * NG_BY + 1;      // first node of the tile
+    const int kn0 = (blockIdx.z % nzb) * NG_KCH + 1;
+    if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
+    const int kn1 = (kn0 + NG_KCH - 1 < b.kl) ? kn0 + NG_KCH - 1 : b.kl;
+    const int i = i0 - 1 + lane, j = j0 + row;
+    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
+    const int jx = (j0 + NG_BY < b.jb) ? j0 + NG_BY : b.jb;
+    const bool outN = (lane >= 1 && lane <= GS_OUT && i <= b.il && j <= b.jl);            // node produced
+    const bool outC = (lane >= 2 && lane <= GS_OUT + 1 && i <= b.il && j >= 2 && j <= b.jl);   // SA cell produced
+    const long nb = b.nbox;
+    const double gam = kp.gammaConstant;
+    GsPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w5 = m.w3 + 2 * nb;
+    m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.vol = (GPTR(const double))b.vol;
+    m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
+    m.d2wall = (GPTR(const double))b.d2wall; m.volRef = (GPTR(const double))b.volRef;
+    m.nb8 = 8u * (unsigned)nb; m.sj = 8u * (unsigned)b.ldi;
+    NgPtrs mx;                                            // record of the cell row above the tile (wave 0): plain loads
+    mx.w0 = m.w0; mx.w1 = m.w1; mx.w2 = m.w2; mx.w3 = m.w3; mx.p = m.p; mx.sI = m.sI; mx.sJ = m.sJ; mx.sK = m.sK; mx.vol = m.vol;
+    mx.nb8 = m.nb8; mx.sj = m.sj;
+    GPTR(double) grad = (GPTR(double))b.grad;
+    GPTR(double) dw5 = (GPTR(double))b.dw + 5 * nb;
+    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
+    const unsigned sk = 8u * (unsigned)b.ldk, sj = m.sj;
+    // rows j +- 2 of nuTilde, clamped into the box (only read for produced cells, where they are inside)
+    const unsigned ojm2 = (jc >= 2) ? 2 * sj : (unsigned)jc * sj, ojp2 = (jc + 2 <= b.jb) ? 2 * sj : (unsigned)(b.jb - jc) * sj;
+    const unsigned ojm1 = (jc >= 1) ? sj : 0u, ojp1 = (jc + 1 <= b.jb) ? sj : 0u;
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + kn0 * b.ldk);
+    unsigned cx = 8u * (unsigned)(ic + jx * b.ldi + kn0 * b.ldk);
+    const bool secondOrd = (kp.orderTurb == 2) && kp.groundLevelIsOne;
+    const double cb3Inv = 1.0 / kp.sa_cb3;
+    double sKp[3], sKpx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * m.nb8); sKpx[d] = GRAD ? ldg(mx.sK, cx - sk + d * m.nb8) : 0.0; }
+    // window of the own column: planes kn0-1 (SA neighbour below) and kn0; nuTilde of planes kn0-2 .. kn0+1
+    const unsigned ckm2 = (kn0 >= 2) ? 2 * sk : sk;       // plane kn0-2 clamped at 0 (kn0 = 1: not read by a produced cell)
+    GsCell s0 = gs_ld(m, c);
+    GsNbr sm1 = gs_nbr_ld(m, c - sk);
+    double n_m2 = ldg(m.w5, c - ckm2), n_0 = ldg(m.w5, c), n_p1 = ldg(m.w5, c + sk);
+    NgPlane S;
+    for (int mm = kn0; mm <= kn1 + 1; ++mm) {
+        double* __restrict__ xb = xr + ((mm - kn0) & 1) * (NG_BY * NG_SLOT);
+        const unsigned ckp2 = (mm + 2 <= b.kb) ? 2 * sk : ((mm + 1 <= b.kb) ? sk : 0u);
+        const unsigned ckp1 = (mm + 1 <= b.kb) ? sk : 0u;
+        // ---- loads of this plane: the four face-normal triples, the state of the plane above, nuTilde two planes above
+        double nI[3], nJm[3], nJ[3], nK[3];
+        vm_ld3(m.sI, c, m.nb8, nI); vm_ld3(m.sJ, c - ojm1, m.nb8, nJm); vm_ld3(m.sJ, c, m.nb8, nJ); vm_ld3(m.sK, c, m.nb8, nK);
+        const GsCell sp1 = gs_ld(m, c + ckp1);
+        const double n_p2 = ldg(m.w5, c + ckp2);
+        const double sKm[3] = {sKp[0], sKp[1], sKp[2]};    // sK of the plane below, before gs_record advances it
+        NgRec R;
+        if (GRAD) {
+            gs_record(s0, gam, nI, nJm, nJ, nK, sKp, R);
+            if (row > 0) ng_publish(xb + (row - 1) * NG_SLOT, lane, R);
+            if (row == 0) {
+                NgRec X;
+                ng_record(mx, cx, gam, sKpx, X);
+                ng_publish(xb + (NG_BY - 1) * NG_SLOT, lane, X);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sKp[d] = nK[d];
+        }
+        // ---- Spalart-Allmaras residual of cell (i, j, mm): sweeps k, j, i as the reference (sa.F90, turbUtils.F90)
+        const bool saPlane = (mm >= 2 && mm <= kn1);
+        if (saPlane) {
+            GsNbr q0;
+            q0.u = s0.u; q0.v = s0.v; q0.w = s0.w; q0.nu = s0.rlv * rcp_nr(s0.rho); q0.vol = s0.vol; q0.nut = n_0;
+            GsNbr qkp;
+            qkp.u = sp1.u; qkp.v = sp1.v; qkp.w = sp1.w; qkp.nu = sp1.rlv * rcp_nr(sp1.rho); qkp.vol = sp1.vol; qkp.nut = n_p1;
+            const GsNbr qim = gs_up1(q0), qip = gs_dn1(q0);
+            const double n_im2 = lane_up1(qim.nut), n_ip2 = lane_dn1(qip.nut);
+            const GsNbr qjm = gs_nbr_ld(m, c - ojm1), qjp = gs_nbr_ld(m, c + ojp1);
+            const double n_jm2 = ldg(m.w5, c - ojm2), n_jp2 = ldg(m.w5, c + ojp2);
+            const double nIm[3] = {lane_up1(nI[0]), lane_up1(nI[1]), lane_up1(nI[2])};
+            // velocity gradient * 2 vol from the six neighbours (sa.F90:133-190)
+            double gu[3][3];
+            const double qq[3][6] = {{qip.u, qim.u, qjp.u, qjm.u, qkp.u, sm1.u}, {qip.v, qim.v, qjp.v, qjm.v, qkp.v, sm1.v},
+                                     {qip.w, qim.w, qjp.w, qjm.w, qkp.w, sm1.w}};
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    gu[v][d] = qq[v][0] * nI[d] - qq[v][1] * nIm[d] + qq[v][2] * nJ[d] - qq[v][3] * nJm[d] + qq[v][4] * nK[d] - qq[v][5] * sKm[d];
+            double dvt = sa_source(kp, gu, s0.vol, q0.nu, n_0, ldg(m.d2wall, c));
+            SaDir dk, dj, di;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                dk.sm[d] = sKm[d]; dk.sp[d] = nK[d]; dj.sm[d] = nJm[d]; dj.sp[d] = nJ[d]; di.sm[d] = nIm[d]; di.sp[d] = nI[d];
+            }
+            dk.volm = sm1.vol; dk.volp = qkp.vol; dk.num = sm1.nu; dk.nup = qkp.nu; dk.qsf = 0.0;
+            dk.nt[0] = n_m2; dk.nt[1] = sm1.nut; dk.nt[2] = n_0; dk.nt[3] = n_p1; dk.nt[4] = n_p2;
+            dj.volm = qjm.vol; dj.volp = qjp.vol; dj.num = qjm.nu; dj.nup = qjp.nu; dj.qsf = 0.0;
+            dj.nt[0] = n_jm2; dj.nt[1] = qjm.nut; dj.nt[2] = n_0; dj.nt[3] = qjp.nut; dj.nt[4] = n_jp2;
+            di.volm = qim.vol; di.volp = qip.vol; di.num = qim.nu; di.nup = qip.nu; di.qsf = 0.0;
+            di.nt[0] = n_im2; di.nt[1] = qim.nut; di.nt[2] = n_0; di.nt[3] = qip.nut; di.nt[4] = n_ip2;
+            dvt += sa_advect(dk, s0.vol, s0.u, s0.v, s0.w, secondOrd);
+            dvt += sa_advect(dj, s0.vol, s0.u, s0.v, s0.w, secondOrd);
+            dvt += sa_advect(di, s0.vol, s0.u, s0.v, s0.w, secondOrd);
+            dvt += sa_diffuse(dk, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
+            dvt += sa_diffuse(dj, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
+            dvt += sa_diffuse(di, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
+            if (outC) stg(dw5, c, -ldg(m.volRef, c) * dvt * flg_blank(flags[c >> 3]));
+        }
+        if (GRAD) {
+        __syncthreads();
+        NgRec U;
+        ng_fetch(xb + row * NG_SLOT, lane, U);
+        NgPlane N;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            N.Pt[d] = R.sTK[d] + U.sTK[d];
+            N.Q0t[d] = R.sTJ[d]; N.Q1t[d] = U.sTJ[d];
+            N.RIt[d] = R.tI[d] + U.tI[d];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            N.Q0p[v] = R.phi[v] + lane_dn1(R.phi[v]);
+            N.Q1p[v] = U.phi[v] + lane_dn1(U.phi[v]);
+            N.Pp[v] = N.Q0p[v] + N.Q1p[v];
+            N.RIp[v] = R.phi[v] + U.phi[v];
+        }
+        N.V = R.sV + U.sV;
+        if (mm > kn0) {
+            double g[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) g[q] = 0.0;
+            ng_outer(g, -1.0, S.Pp, S.Pt);
+            ng_outer(g, +1.0, N.Pp, N.Pt);
+            double t[3], ph[4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t[d] = S.Q0t[d] + N.Q0t[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = S.Q0p[v] + N.Q0p[v];
+            ng_outer(g, -1.0, ph, t);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t[d] = S.Q1t[d] + N.Q1t[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = S.Q1p[v] + N.Q1p[v];
+            ng_outer(g, +1.0, ph, t);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t[d] = S.RIt[d] + N.RIt[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = S.RIp[v] + N.RIp[v];
+            ng_outer(g, -1.0, ph, t);
+            double t1[3], ph1[4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t[d]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
+            ng_outer(g, +1.0, ph1, t1);
+            const double oneOverV = rcp_nr(S.V + N.V);
+            if (outN) {
+                const unsigned cn = c - sk;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cn, g[q] * oneOverV);
+            }
+        }
+        S = N;
+        }
+        // ---- advance the window
+        n_m2 = sm1.nut;
+        sm1.u = s0.u; sm1.v = s0.v; sm1.w = s0.w; sm1.nu = s0.rlv * rcp_nr(s0.rho); sm1.vol = s0.vol; sm1.nut = n_0;
+        s0 = sp1;
+        n_0 = n_p1; n_p1 = n_p2;
+        c += ckp1; cx += sk;
     }
 }
 
@@ -966,11 +1225,6 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gs[12], const
     f[3] = frhoE - q_x * nx - q_y * ny - q_z * nz;
 }
 
-__device__ __forceinline__ void vm_ld3(GPTR(const double) a, unsigned o, unsigned nb8, double v[3])
-{
-    v[0] = ldg(a, o); v[1] = ldg(a, o + nb8); v[2] = ldg(a, o + 2 * nb8);
-}
-
 // SB: scheduling fences between the face blocks (limits how far the compiler hoists the loads of later faces: fewer live
 // registers, less latency overlap) -- tuning "visc_sb"
 template <bool QCR, int SB>
@@ -1467,6 +1721,29 @@ void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int
         if (kp.useQCR) hipLaunchKernelGGL((k_visc_fused<true, 4>), grd, blk, 0, s, tab, nch, kp);
         else hipLaunchKernelGGL((k_visc_fused<false, 4>), grd, blk, 0, s, tab, nch, kp);
     }
+}
+
+int g_sa_march = 1;         // tuning "sa_march": SA residual as its own k-march instead of the gather kernel
+int g_grad_sa_fused = 0;    // tuning "grad_sa_fused": SA residual evaluated inside the nodal-gradient march
+
+// nodal gradients + Spalart-Allmaras residual of every block of the level in one launch
+void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    const int nzn = nz + 1;
+    const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
+    hipLaunchKernelGGL((k_grad_sa_march<true>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                       dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
+}
+
+// the Spalart-Allmaras residual alone, as a k-march (blocks at rest)
+void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    const int nzn = nz + 1;
+    const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
+    hipLaunchKernelGGL((k_grad_sa_march<false>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                       dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
 }
 
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
