@@ -485,9 +485,11 @@ __device__ __forceinline__ void gs_record(const GsCell& q, double gam, const dou
     R.sV = q.vol + lane_dn1(q.vol);
 }
 
-// GRAD = false: the Spalart-Allmaras residual alone as a k-march (no records, no LDS, no barrier)
+// GRAD = false: the Spalart-Allmaras residual alone as a k-march (no records, no LDS, no barrier), the default.
+// GRAD = true needs ~310 registers: at two waves per SIMD it spills 300 B per thread (2.6 ms on config 4a), at one wave per SIMD it
+// runs 1.67 ms against 0.55 + 0.68 ms of the two separate kernels (profiles/r02_g, r02_j): kept as a tuning option only.
 template <bool GRAD>
-__global__ __launch_bounds__(64 * NG_BY, 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp)
+__global__ __launch_bounds__(64 * NG_BY, GRAD ? 1 : 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
     __shared__ double xr[GRAD ? 2 * NG_BY * NG_SLOT : 1];
     const BlkView& b = tab[blockIdx.z / nzb + 1];
