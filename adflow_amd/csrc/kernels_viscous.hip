@@ -488,19 +488,22 @@ __device__ __forceinline__ void gs_record(const GsCell& q, double gam, const dou
 // GRAD = false: the Spalart-Allmaras residual alone as a k-march (no records, no LDS, no barrier), the default.
 // GRAD = true needs ~310 registers: at two waves per SIMD it spills 300 B per thread (2.6 ms on config 4a), at one wave per SIMD it
 // runs 1.67 ms against 0.55 + 0.68 ms of the two separate kernels (profiles/r02_g, r02_j): kept as a tuning option only.
-template <bool GRAD>
-__global__ __launch_bounds__(64 * NG_BY, GRAD ? 1 : 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp)
+// ROWS: cell rows (waves) per workgroup; GRAD needs ROWS = NG_BY (the LDS record exchange); the SA-only march may run 8 rows: the
+// j neighbours are plain loads and the rows j0-2 .. j0+ROWS+1 a workgroup touches are re-read by the workgroups above and below
+// (349 B per cell at 4 rows, profiles/r02_k_pmc_traffic.txt, at 6.5 TB/s: the kernel is bound by exactly that traffic)
+template <bool GRAD, int ROWS>
+__global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
     __shared__ double xr[GRAD ? 2 * NG_BY * NG_SLOT : 1];
     const BlkView& b = tab[blockIdx.z / nzb + 1];
     const int lane = threadIdx.x, row = threadIdx.y;
-    const int i0 = blockIdx.x * GS_OUT + 1, j0 = blockIdx.y * NG_BY + 1;      // first node of the tile
+    const int i0 = blockIdx.x * GS_OUT + 1, j0 = blockIdx.y * ROWS + 1;      // first node of the tile
     const int kn0 = (blockIdx.z % nzb) * NG_KCH + 1;
     if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
     const int kn1 = (kn0 + NG_KCH - 1 < b.kl) ? kn0 + NG_KCH - 1 : b.kl;
     const int i = i0 - 1 + lane, j = j0 + row;
     const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
-    const int jx = (j0 + NG_BY < b.jb) ? j0 + NG_BY : b.jb;
+    const int jx = (j0 + ROWS < b.jb) ? j0 + ROWS : b.jb;
     const bool outN = (lane >= 1 && lane <= GS_OUT && i <= b.il && j <= b.jl);            // node produced
     const bool outC = (lane >= 2 && lane <= GS_OUT + 1 && i <= b.il && j >= 2 && j <= b.jl);   // SA cell produced
     const long nb = b.nbox;
@@ -1725,7 +1728,7 @@ void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int
     }
 }
 
-int g_sa_march = 1;         // tuning "sa_march": SA residual as its own k-march instead of the gather kernel
+int g_sa_march = 1;         // tuning "sa_march": 0 = gather kernel, 1 = k-march with 4 rows per workgroup, 2 = with 8 rows (no faster: 0.57 vs 0.54 ms, profiles/r02_l)
 int g_grad_sa_fused = 0;    // tuning "grad_sa_fused": SA residual evaluated inside the nodal-gradient march
 
 // nodal gradients + Spalart-Allmaras residual of every block of the level in one launch
@@ -1734,7 +1737,7 @@ void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz
     if (nslots <= 0) return;
     const int nzn = nz + 1;
     const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
-    hipLaunchKernelGGL((k_grad_sa_march<true>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+    hipLaunchKernelGGL((k_grad_sa_march<true, NG_BY>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
                        dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
 }
 
@@ -1744,8 +1747,12 @@ void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int n
     if (nslots <= 0) return;
     const int nzn = nz + 1;
     const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
-    hipLaunchKernelGGL((k_grad_sa_march<false>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                       dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
+    if (g_sa_march < 2)
+        hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
+    else
+        hipLaunchKernelGGL((k_grad_sa_march<false, 8>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + 7) / 8, nchn * nslots), dim3(64, 8, 1), 0, s,
+                           tab, nchn, kp);
 }
 
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
