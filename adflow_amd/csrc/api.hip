@@ -15,13 +15,18 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows, g_grad_sa_fused, g_sa_march;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows, g_grad_sa_fused, g_sa_march, g_roe_lds_pad, g_roe_grad_mix;
 
 namespace {
 
 std::string g_err;
 int g_device = -1;
 hipStream_t g_stream = nullptr;
+// side streams of blocketteRes: the SA residual and the nodal gradients are independent of the inviscid kernel (which is bound by
+// FP64 issue while they are bound by HBM): launched on their own queues they share the CUs with it (tuning "overlap")
+hipStream_t g_streamB = nullptr, g_streamC = nullptr;
+hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr;
+int g_overlap = 1;
 adflow_opts g_opts;
 bool g_have_opts = false;
 hipEvent_t g_events[64];
@@ -334,6 +339,11 @@ int adflow_gpu_init(int device_ordinal)
     if (device_ordinal < 0 || device_ordinal >= n) return fail("device ordinal %d out of range (%d devices)", device_ordinal, n);
     HIPCHK(hipSetDevice(device_ordinal));
     if (!g_stream) HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_streamB) {
+        HIPCHK(hipStreamCreateWithFlags(&g_streamB, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&g_streamC, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&g_evFork)); HIPCHK(hipEventCreate(&g_evB)); HIPCHK(hipEventCreate(&g_evC));
+    }
     if (!g_events_ready) {
         for (int i = 0; i < 64; ++i) HIPCHK(hipEventCreate(&g_events[i]));
         g_events_ready = true;
@@ -811,10 +821,27 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     // inviscid part: one launch for every block of the level (blocks are independent given their halos)
     LevelTab t;
     if (level_tab(level, &t)) return 1;
+    // the nodal-gradient march reads only the state and the metrics: forked onto its own queue BEFORE the inviscid kernel is
+    // enqueued, joined in front of the face-flux kernel
+    const bool viscMarch = kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2 && g_march_by == 4 &&
+                           !(g_viscous_fused >= 2 || (g_viscous_fused == 1 && !needGrad));
+    bool gradForked = false, mixed = false;
+    if (viscMarch && !withSA && g_phase_base <= 0 && inviscid_march_enabled() && kp.spaceDiscr == ADFLOW_UPWIND && !anyMoving) {
+        // Roe inviscid march and nodal-gradient march as ONE launch of interleaved workgroups
+        if (ensure_tiles(level)) return 1;
+        mixed = launch_roe_grad_mix(g_tab[level], g_tiles[level].first, g_tiles[level].second, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    }
+    if (viscMarch && !mixed && g_overlap && g_phase_base <= 0) {
+        HIPCHK(hipEventRecord(g_evFork, g_stream));
+        HIPCHK(hipStreamWaitEvent(g_streamC, g_evFork, 0));
+        gradForked = true;
+    }
     // scalar JST with the entropy sensor (NS / RANS, fine level) also has a marching form, but it is bound by memory like
     // the gather form (1.06 vs 1.10 ms on 8 x 128x128x96): only with tuning inviscid_march = 2
     const bool scalarVisc = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
-    if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) && !kp.dissApprox && !anyMoving) {
+    if (mixed) {
+        // inviscid part already enqueued
+    } else if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) && !kp.dissApprox && !anyMoving) {
         // matrix dissipation / Roe upwind: k-marching kernel over the level's tile table (every face once in k and i)
         if (ensure_tiles(level)) return 1;
         // second-order Roe upwind on the fine level: the per-cell reconstruction kernel; everything else (matrix, first order)
@@ -843,8 +870,14 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     } else if (batched && viscous_is_tiled() >= 2 && g_march_by == 4) {
         // k-marching nodal gradients (with the SA residual when the caller left it to this kernel), then the k-marching face
         // kernel over the level's tile table
-        if (withSA) launch_grad_sa_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
-        else launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        hipStream_t sg = gradForked ? g_streamC : g_stream;
+        if (mixed) { /* gradients came with the inviscid launch */ }
+        else if (withSA) launch_grad_sa_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, sg);
+        else launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, sg);
+        if (gradForked) {
+            HIPCHK(hipEventRecord(g_evC, g_streamC));
+            HIPCHK(hipStreamWaitEvent(g_stream, g_evC, 0));     // join: the face kernel needs the gradients and dw of the inviscid kernel
+        }
         phase_mark(5);
         if (ensure_tiles(level)) return 1;
         launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
@@ -925,7 +958,7 @@ static int block_res_enqueue(int level, unsigned flags)
     // blockResCore order: SA residual first, then the mean-flow fluxes (blockette.F90:806-851)
     // the SA residual rides on the nodal-gradient march when that kernel runs in this evaluation (exact viscous fluxes,
     // marching kernels, blocks at rest); otherwise its own gather kernel
-    bool saFused = false;
+    bool saFused = false, saForked = false;
     if ((flags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
         bool moving = false;
         rc = for_level(level, [&](Block* b) {
@@ -940,8 +973,17 @@ static int block_res_enqueue(int level, unsigned flags)
         if (!saFused) {
             LevelTab t;
             if (level_tab(level, &t)) return 1;
-            if (g_sa_march && !moving) launch_sa_march_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
-            else launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+            hipStream_t ss = g_stream;
+            if (g_overlap && g_phase_base <= 0 && (flags & ADFLOW_RES_FLOW)) {
+                // fork: the SA residual (writes dw(:,:,:,itu1) only) runs beside the mean-flow kernels; joined below
+                HIPCHK(hipEventRecord(g_evFork, g_stream));
+                HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
+                ss = g_streamB;
+                saForked = true;
+            }
+            if (g_sa_march && !moving) launch_sa_march_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, ss);
+            else launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, ss);
+            if (saForked) HIPCHK(hipEventRecord(g_evB, g_streamB));
         }
     }
     phase_mark(3);
@@ -949,6 +991,7 @@ static int block_res_enqueue(int level, unsigned flags)
         rc = enqueue_flow_residual(level, kp, viscApprox, false, true, (flags & ADFLOW_RES_UPDATE_INTERMED) != 0, saFused);
         if (rc) return rc;
     }
+    if (saForked) HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0));      // join
     phase_mark(6);
     // actuator-region sources after the core, fine level only and without the iblank factor (blockette.F90:276-281)
     if (level == 1 && source_terms_enqueue(0)) return 1;
@@ -2315,6 +2358,9 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "viscous_fused")) { g_viscous_fused = value; return 0; }
     if (!strcmp(key, "grad_sa_fused")) { g_grad_sa_fused = value; return 0; }
     if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
+    if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
+    if (!strcmp(key, "roe_grad_mix")) { g_roe_grad_mix = value; return 0; }
+    if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }
     if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {

@@ -249,6 +249,7 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 int viscous_is_tiled();
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

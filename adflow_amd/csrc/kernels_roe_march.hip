@@ -187,12 +187,13 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
 
 // FW: persistent dissipation residual of the Runge-Kutta scheme (fw kept between the stages); FINAL: dw = (dw + fw) iblank
 // written here, otherwise the sum dw + fw is left in dw for the viscous kernel to complete (residuals.F90:334-344)
+// body of the kernel for workgroup `bid` of the tile table; xj: 2 * RM_XJ doubles of LDS (the caller owns the allocation so that
+// the mixed kernel of kernels_viscous.hip can give the same bytes to either of its two bodies)
 template <int LIM, bool FW, bool FINAL>
-__global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
-                                                             int kch)
+__device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, const KParams& kp, int kch,
+                                               int bid, double* __restrict__ xj)
 {
-    __shared__ double xj[2 * RM_XJ];
-    const int4 t = tiles[blockIdx.x];
+    const int4 t = tiles[bid];
     if (t.x < 0) return;
     const BlkView& b = tab[t.x];
     const int lane = threadIdx.x, row = threadIdx.y;
@@ -362,14 +363,33 @@ __global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __re
     }
 }
 
+template <int LIM, bool FW, bool FINAL>
+__global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
+                                                             int kch)
+{
+    __shared__ double xj[2 * RM_XJ];
+    roe_march_body<LIM, FW, FINAL>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
+}
+
+#ifndef ADF_ROE_BODY_ONLY
 int g_roe_march = 1;       // tuning "roe_march": 0 = k_inviscid_march<upwind> (reconstruction per face) on the fine level too
 
 extern int g_march_kch;
+
+int g_roe_lds_pad = 0;     // tuning "roe_lds_pad": extra (unused) dynamic LDS bytes per workgroup: > 41 KB leaves one workgroup per CU,
+                           // i.e. half of the wave slots to the bandwidth-bound kernels running beside it on the side streams
 
 template <int LIM>
 static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     const dim3 blk(64, RM_BY, 1), grd(ntiles);
+    const size_t pad = (size_t)g_roe_lds_pad;
+#ifndef HOSTSIM
+    if (pad) {
+        (void)hipFuncSetAttribute((const void*)k_roe_march<LIM, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+        (void)hipFuncSetAttribute((const void*)k_roe_march<LIM, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    }
+#endif
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
     const bool final_ = !(kp.viscous && doDiss);
     const int kch = g_march_kch;
@@ -377,8 +397,8 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
         if (final_) hipLaunchKernelGGL((k_roe_march<LIM, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
-        if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
-        else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
+        if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, pad, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, pad, s, tab, tiles, kp, kch);
     }
 }
 
@@ -394,3 +414,4 @@ bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const K
     default: return false;      // first order: k_inviscid_march
     }
 }
+#endif   // ADF_ROE_BODY_ONLY

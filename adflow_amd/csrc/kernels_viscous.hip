@@ -13,6 +13,8 @@
 // Roofline: HBM (255 B/cell RANS); no MFMA.
 #include "sa_core.h"
 
+extern int g_march_kch;
+
 #define VS_BX 64
 #define VS_BY 4
 
@@ -305,13 +307,14 @@ __device__ __forceinline__ void ng_outer(double g[12], double sign, const double
     }
 }
 
-__global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView* __restrict__ tab, int nzb, double gam)
+// body of the kernel for the workgroup (bx, by, bz) of its grid; xr: 2 * NG_BY * NG_SLOT doubles of LDS owned by the caller
+__device__ __forceinline__ void node_grad_body(const BlkView* __restrict__ tab, int nzb, double gam, int bx, int by, int bz,
+                                               double* __restrict__ xr)
 {
-    __shared__ double xr[2 * NG_BY * NG_SLOT];            // [parity][row slot 0..3 = cell rows j0+1 .. j0+4][value][lane]
-    const BlkView& b = tab[blockIdx.z / nzb + 1];         // level-batched: blockIdx.z = slot * nzb + k chunk
+    const BlkView& b = tab[bz / nzb + 1];                 // level-batched: bz = slot * nzb + k chunk
     const int lane = threadIdx.x, row = threadIdx.y;
-    const int i0 = blockIdx.x * NG_OUT + 1, j0 = blockIdx.y * NG_BY + 1;      // first node of the tile
-    const int kn0 = (blockIdx.z % nzb) * NG_KCH + 1;
+    const int i0 = bx * NG_OUT + 1, j0 = by * NG_BY + 1;      // first node of the tile
+    const int kn0 = (bz % nzb) * NG_KCH + 1;
     if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
     const int kn1 = (kn0 + NG_KCH - 1 < b.kl) ? kn0 + NG_KCH - 1 : b.kl;
     const int i = i0 - 1 + lane, j = j0 + row;
@@ -399,6 +402,40 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView
         }
         S = N;
         c += sk; cx += sk;
+    }
+}
+
+__global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView* __restrict__ tab, int nzb, double gam)
+{
+    __shared__ double xr[2 * NG_BY * NG_SLOT];            // [parity][row slot 0..3 = cell rows j0+1 .. j0+4][value][lane]
+    node_grad_body(tab, nzb, gam, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, xr);
+}
+
+// ---------------------------------------------------------------------------
+// HORIZONTAL fusion of the Roe-upwind inviscid march (bound by FP64 issue: 76 % VALU busy, 2.4 TB/s) and the nodal-gradient
+// march (bound by HBM: 5.3 TB/s, 12 % VALU busy): one launch whose workgroups are roe tiles and gradient tiles interleaved in
+// proportion to their counts, so that every CU holds both kinds at any time and the gradient kernel's memory time hides under
+// the inviscid kernel's arithmetic.  The two bodies are the kernels above, unchanged; they share one LDS allocation
+// (max of the two) and the register allocation of the larger one.  Separate queues do not give this mixing: either kernel
+// alone fills every wave slot of the chip (profiles/r02_m: 2.94 vs 3.13 ms).
+// ---------------------------------------------------------------------------
+#define ADF_ROE_BODY_ONLY
+#include "kernels_roe_march.hip"
+#define MIX_LDS ((2 * RM_XJ) > (2 * NG_BY * NG_SLOT) ? (2 * RM_XJ) : (2 * NG_BY * NG_SLOT))
+
+template <int LIM>
+__global__ __launch_bounds__(256, 2) void k_roe_grad_mix(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, int nR, KParams kp,
+                                                         int kch, int gx, int gy, int nG, int nzb)
+{
+    __shared__ double lds[MIX_LDS];
+    // block b of nR + nG: the a-th roe tile with a = floor(b nR / (nR + nG)) if that quotient steps at b, else a gradient tile
+    const long tot = (long)nR + nG, bq = blockIdx.x;
+    const int a0 = (int)((bq * nR) / tot), a1 = (int)(((bq + 1) * nR) / tot);
+    if (a1 > a0) {
+        roe_march_body<LIM, false, false>(tab, tiles, kp, kch, a0, lds);
+    } else {
+        const int g = (int)bq - a0;          // gradient tiles before this block
+        node_grad_body(tab, nzb, kp.gammaConstant, g % gx, (g / gx) % gy, g / (gx * gy), lds);
     }
 }
 
@@ -1695,7 +1732,6 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
 }
 
 // tiled forms, every block of the level in one launch each
-extern int g_march_kch;
 int g_visc_sb = 0;
 
 // marching face-flux kernel over the tile table of the level (tuning viscous_tiled >= 2)
@@ -1739,6 +1775,26 @@ void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz
     const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
     hipLaunchKernelGGL((k_grad_sa_march<true, NG_BY>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
                        dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
+}
+
+int g_roe_grad_mix = 1;     // tuning "roe_grad_mix": inviscid Roe march and nodal-gradient march in one interleaved launch
+
+// true when taken: second-order Roe upwind, fw not persistent, viscous part to follow, blocks at rest
+bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    if (!g_roe_grad_mix || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid || kp.dissApprox || kp.fwMode || ntiles <= 0 || nslots <= 0)
+        return false;
+    if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return false;
+    const int nzn = nz + 1, nchn = (nzn + NG_KCH - 1) / NG_KCH;
+    const int gx = (nx + 1 + NG_OUT - 1) / NG_OUT, gy = (ny + 1 + NG_BY - 1) / NG_BY, nG = gx * gy * nchn * nslots;
+    const dim3 blk(64, 4, 1), grd(ntiles + nG);
+    switch (kp.limiter) {
+    case ADFLOW_LIM_NONE: hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_NONE>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn); break;
+    case ADFLOW_LIM_VANALBADA: hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_VANALBADA>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn); break;
+    case ADFLOW_LIM_MINMOD: hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_MINMOD>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn); break;
+    default: return false;
+    }
+    return true;
 }
 
 // the Spalart-Allmaras residual alone, as a k-march (blocks at rest)

@@ -66,6 +66,7 @@ hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t e);
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // one in-order queue on the host
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : 1; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
