@@ -1274,6 +1274,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
                                                               int kch)
 {
     __shared__ double gx[2 * (VM_BY + 1) * VM_G];      // [parity][node row slot 0..4 = rows j0-1 .. j0+3][component][lane]
+    __shared__ double qx[VM_BY * 6 * 64];               // state of the own cell of every row, for the rows above and below
     const int4 t = tiles[blockIdx.x];
     if (t.x < 0) return;
     const BlkView& b = tab[t.x];
@@ -1338,15 +1339,27 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
 #pragma unroll
             for (int q = 0; q < 12; ++q) xb[q * 64 + lane] = ldg(grad, c - sj + q * nb8);
         }
+        // the state of the j neighbours comes from the neighbouring rows through LDS (as plain loads they miss L2: 14 of the
+        // 60 loads per cell went to HBM); only the rows outside the tile are loaded
+        {
+            double* __restrict__ qo = qx + row * (6 * 64) + lane;
+            qo[0] = q0.u; qo[64] = q0.v; qo[128] = q0.w; qo[192] = q0.na; qo[256] = q0.rlv; qo[320] = q0.rev;
+        }
         const VmCell qp1 = vm_ld(m, c + sk, gam, K.eddy);
         const int flag0 = flags[c >> 3];
         double acc[4];
         __syncthreads();
         const int oM = row * VM_G + lane, o0 = (row + 1) * VM_G + lane;       // node rows j-1 and j
+        auto row_state = [&](int r) {
+            const double* __restrict__ qi = qx + r * (6 * 64) + lane;
+            VmCell q;
+            q.u = qi[0]; q.v = qi[64]; q.w = qi[128]; q.na = qi[192]; q.rlv = qi[256]; q.rev = qi[320];
+            return q;
+        };
         // ---- j face (j-1 | j): nodes (i-1..i, j-1, k-1..k)
         {
             double gs[12], nJ[3], dJv[3], f[4];
-            const VmCell qjm = vm_ld(m, c - sj, gam, K.eddy);
+            const VmCell qjm = (row > 0) ? row_state(row - 1) : vm_ld(m, c - sj, gam, K.eddy);
 #pragma unroll
             for (int q = 0; q < 12; ++q) { const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
             vm_ld3(sJ, c - sj, nb8, nJ); vm_ld3(dJ, c - sj, nb8, dJv);
@@ -1370,7 +1383,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
         // ---- j face (j | j+1): nodes (i-1..i, j, k-1..k)
         {
             double gs[12], nJ[3], dJv[3], f[4];
-            const VmCell qjp = vm_ld(m, c + sj, gam, K.eddy);
+            const VmCell qjp = (row < VM_BY - 1) ? row_state(row + 1) : vm_ld(m, c + sj, gam, K.eddy);
 #pragma unroll
             for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
             vm_ld3(sJ, c, nb8, nJ); vm_ld3(dJ, c, nb8, dJv);
