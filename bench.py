@@ -417,7 +417,9 @@ def main():
         dom_traffic = None
         if traffic:
             dom_traffic = traffic.get("kernels", {}).get(dom, {}).get("traffic_bytes_per_launch")
-        achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
+        # the evaluation's kernels overlap on the library's side streams: the roofline figure prices the TIMED evaluation (HIP events
+        # around the K steps on the library's stream, halo copies included), kernels_ms lists them measured one after the other
+        achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
         out = {
             "metric": "Mcells*residual-evals/s", "value": value, "unit": "Mcells*residual-evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec_step * 1e3, "repeats": reps,
@@ -426,17 +428,17 @@ def main():
                                    + wl["desc"] + ", one residual evaluation per step (whalo2 + blocketteRes core, default flags)",
                        "halo_exchange": job.halo, "rank_grid": "x".join(map(str, job.grid)),
                        "cells_per_gpu": job.cells_local, "device": eng.device_name()},
-            # the evaluation is several kernels (SA, inviscid, nodal gradients, viscous): `achieved` prices the WHOLE
-            # evaluation (sum of the kernels' live event durations) against the 255 / 175 B per cell of SURVEY §8(d);
-            # dominant_kernel is the longest of them
+            # the evaluation is several kernels (SA, inviscid, nodal gradients, viscous): `achieved` prices the WHOLE timed
+            # evaluation against the 255 / 175 B per cell of SURVEY §8(d); dominant_kernel is the longest of them
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("traffic_bytes_per_eval"), "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_eval": alg_bytes, "kernels_ms": kern, "eval_kernels_ms": eval_ms,
+                         "algorithmic_bytes_per_eval": alg_bytes, "eval_ms": ev_ms, "kernels_ms": kern, "kernels_ms_sum_serial": eval_ms,
                          "dominant_kernel": dom, "dominant_kernel_ms": kern[dom], "dominant_kernel_traffic": dom_traffic,
                          "dominant_kernel_share": kern[dom] / eval_ms},
-            "whole_eval": {"event_ms_per_step": ev_ms, "halo_and_gaps_ms": ev_ms - eval_ms,
-                           "hbm_frac": alg_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "whole_eval": {"event_ms_per_step": ev_ms, "overlap_gain_ms": eval_ms - ev_ms,
+                           "hbm_frac": alg_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic_over_algorithmic": ((traffic or {}).get("traffic_bytes_per_eval") or 0.0) / alg_bytes or None},
         }
 
     # ---- config 2: Euler JST + 3-level W multigrid cycle (N=1 extras, or the workload itself when asked for)
