@@ -67,6 +67,10 @@ struct Block {
     std::vector<BcFaceDev> bc;      // boundary subfaces (device BCData), first nViscBocos = viscous walls
     std::vector<void*> bc_allocs;   // device copies of the BCData members: replaced at every bc_register
     int nViscBocos = 0;
+    // coloured finite-difference Jacobian (adflow_gpu_fd_jacobian): reference state / residual, stencil blocks
+    double *wref = nullptr, *dwref = nullptr, *jac = nullptr;
+    void* jac_raw = nullptr;
+    int jac_ncomp = 0;
 };
 
 typedef std::tuple<int, int, int> Key;   // (level, sps, nn): iteration order = level, sps, nn
@@ -238,6 +242,8 @@ int copy_box(Block* b, double* dev, const double* host_c, int ncomp, int lo_i, i
     return 0;
 }
 
+int g_lumped = 0;       // inputDiscretization::lumpedDiss while a preconditioner matrix is assembled
+
 KParams make_kparams(int level, double rFil, int fwMode)
 {
     const adflow_opts& o = g_opts;
@@ -251,6 +257,7 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.viscous = (o.equations == ADFLOW_NS || o.equations == ADFLOW_RANS);
     k.eddyModel = (o.equations == ADFLOW_RANS);
     k.dirScaling = o.dirScaling;
+    k.lumpedDiss = g_lumped;
     k.sigma = o.sigma;
     k.useQCR = o.useQCR;
     k.useRotationSA = o.useRotationSA;
@@ -365,6 +372,7 @@ int adflow_gpu_finalize(void)
 {
     for (auto& kv : g_blocks) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
+        if (kv.second->jac_raw) (void)hipFree(kv.second->jac_raw);
         for (void* p : kv.second->bc_allocs) (void)hipFree(p);
         delete kv.second;
     }
@@ -520,6 +528,7 @@ int adflow_gpu_block_release(int nn, int level, int sps)
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     bc_plan_drop(level);
     for (void* p : it->second->allocs) (void)hipFree(p);
+    if (it->second->jac_raw) (void)hipFree(it->second->jac_raw);
     for (void* p : it->second->bc_allocs) (void)hipFree(p);
     delete it->second;
     g_blocks.erase(it);
@@ -533,6 +542,7 @@ int adflow_gpu_release_all(void)
     bc_plan_drop_all();
     for (auto& kv : g_blocks) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
+        if (kv.second->jac_raw) (void)hipFree(kv.second->jac_raw);
         for (void* p : kv.second->bc_allocs) (void)hipFree(p);
         delete kv.second;
     }
@@ -919,6 +929,7 @@ static int block_res_enqueue(int level, unsigned flags)
     kp.onlyRadii = !(flags & ADFLOW_RES_UPDATE_INTERMED);
     kp.coarseInit = 0;
     kp.dissApprox = (flags & ADFLOW_RES_DISS_APPROX) ? 1 : 0;
+    if (kp.dissApprox && (flags & ADFLOW_RES_UPWIND_FIRST_ORDER)) kp.lumpedDiss = 1;   // blockette.F90:643
     const bool viscApprox = (flags & ADFLOW_RES_VISC_APPROX) != 0;
     int rc = 0;
     if (flags & ADFLOW_RES_CLOSURES) {
@@ -1070,6 +1081,186 @@ int adflow_gpu_reference_shock_sensor(int level)
 int adflow_gpu_block_res(int level, unsigned flags)
 {
     int rc = block_res_enqueue(level, flags);
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+// ---- coloured finite-difference Jacobian (adjointUtils::setupStateResidualMatrix, useAD = F; adjointUtils.F90:7-715) ----------
+static JacSpec g_jac;                 // stencil / colouring / state range of the last assembly
+static bool g_jac_valid = false;
+
+static void jac_spec(unsigned flags, bool viscous, bool rans, JacSpec* J)
+{
+    memset(J, 0, sizeof *J);
+    // state range (adjointUtils.F90:85-106)
+    if (flags & ADFLOW_JAC_TURB_ONLY) { J->lStart = 5; J->nState = 1; }
+    else { J->lStart = 0; J->nState = (rans && !(flags & ADFLOW_JAC_FROZEN_TURB)) ? 6 : 5; }
+    int n = 0;
+    auto add = [&](int a, int b, int c) { J->st[n][0] = a; J->st[n][1] = b; J->st[n][2] = c; ++n; };
+    auto star = [&](int r) { add(-r, 0, 0); add(r, 0, 0); add(0, -r, 0); add(0, r, 0); add(0, 0, -r); add(0, 0, r); };
+    if (flags & ADFLOW_JAC_PC) {
+        add(0, 0, 0); star(1);                                          // euler_pc_stencil (stencils.f90:34-40)
+        if (viscous && (flags & ADFLOW_JAC_VISC_PC)) {                  // visc_pc_stencil (:60-85), setup_3x3x3_coloring
+            for (int c = -1; c <= 1; ++c)
+                for (int b = -1; b <= 1; ++b)
+                    for (int a = -1; a <= 1; ++a)
+                        if ((a != 0) + (b != 0) + (c != 0) >= 2) add(a, b, c);
+            J->ca = 1; J->cb = 3; J->cc = 9; J->cn = 27; J->cm = 3;
+        } else {
+            J->ca = 1; J->cb = 5; J->cc = 4; J->cn = 7; J->cm = 7;      // setup_PC_coloring (adjointUtils.F90:1089-1119)
+        }
+    } else if (viscous) {
+        for (int c = -1; c <= 1; ++c)                                   // visc_drdw_stencil (stencils.f90:87-106)
+            for (int b = -1; b <= 1; ++b)
+                for (int a = -1; a <= 1; ++a) add(a, b, c);
+        star(2);
+        J->ca = 1; J->cb = 19; J->cc = 11; J->cn = 35; J->cm = 35;      // setup_dRdw_visc_coloring (:1153-1183)
+    } else {
+        add(0, 0, 0);                                                   // euler_drdw_stencil (stencils.f90:42-55)
+        for (int d = 0; d < 3; ++d)
+            for (int r : {-2, -1, 1, 2}) add(d == 0 ? r : 0, d == 1 ? r : 0, d == 2 ? r : 0);
+        J->ca = 1; J->cb = 3; J->cc = 4; J->cn = 13; J->cm = 13;        // setup_dRdw_euler_coloring (:1121-1151)
+    }
+    J->nStencil = n;
+}
+
+// masterRoutines::block_res_state (masterRoutines.F90:1214-1283) for every block of the level: closures with halos, turbulence
+// and mean-flow boundary conditions, the residual core, actuator sources.  resScale is applied by the extraction kernel.
+static int block_res_state_enqueue(int level, unsigned resFlags, bool turbBC)
+{
+    KParams kp = make_kparams(level, 1.0, 0);
+    int rc = for_level(level, [&](Block* b) {
+        launch_closures_halo(b->v, kp, g_stream);
+        b->ss_valid = false;
+        b->etot_consistent = false;
+        return 0;
+    });
+    if (rc) return rc;
+    if (turbBC && apply_turb_bc_enqueue(level, 1)) return 1;
+    if (apply_bc_enqueue(level, 1)) return 1;
+    if (g_bc_callback) {
+        HIPCHK(hipStreamSynchronize(g_stream));
+        g_bc_callback(level, 1);
+    }
+    return block_res_enqueue(level, resFlags);
+}
+
+int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
+{
+    if (need_ready()) return 1;
+    if (!(delta > 0.0)) return fail("fd_jacobian: delta must be positive");
+    if (flags & ~(ADFLOW_JAC_PC | ADFLOW_JAC_FROZEN_TURB | ADFLOW_JAC_TURB_ONLY | ADFLOW_JAC_VISC_PC)) return fail("fd_jacobian: unknown flags 0x%x", flags);
+    if (level != g_opts.groundLevel) return fail("fd_jacobian: level %d is not the ground level %d (setupStateResidualMatrix sets both)", level, g_opts.groundLevel);
+    const bool rans = g_opts.equations == ADFLOW_RANS;
+    const bool viscous = rans || g_opts.equations == ADFLOW_NS;
+    if ((flags & ADFLOW_JAC_TURB_ONLY) && !rans) return fail("fd_jacobian: ADFLOW_JAC_TURB_ONLY needs the RANS equations");
+    if ((flags & ADFLOW_JAC_TURB_ONLY) && (flags & ADFLOW_JAC_FROZEN_TURB)) return fail("fd_jacobian: TURB_ONLY and FROZEN_TURB exclude each other");
+    JacSpec J;
+    jac_spec(flags, viscous, rans, &J);
+    const int ncomp = J.nStencil * J.nState * J.nState;
+    int rc = for_level(level, [&](Block* b) {
+        if (!b->wref) {
+            if (alloc_arr(b, &b->wref, b->v.nw) || alloc_arr(b, &b->dwref, 6)) return 1;
+        }
+        if (b->jac_ncomp != ncomp) {
+            if (b->jac_raw) HIPCHK(hipFree(b->jac_raw));
+            b->jac_raw = nullptr; b->jac = nullptr; b->jac_ncomp = 0;
+            const size_t bytes = (size_t)b->v.nbox * ncomp * sizeof(double) + 256;
+            HIPCHK(hipMalloc(&b->jac_raw, bytes));
+            b->jac = (double*)b->jac_raw + ADF_PAD0;
+            b->jac_ncomp = ncomp;
+        }
+        HIPCHK(hipMemsetAsync(b->jac_raw, 0, (size_t)b->v.nbox * ncomp * sizeof(double) + 256, g_stream));
+        return 0;
+    });
+    if (rc) return rc;
+    g_jac_valid = false;
+
+    // whalo2(1, 1, nw, T, T, T) (adjointUtils.F90:113)
+    if (g_comm.count(std::make_pair(level, 2)))
+        if (halo_exchange_enqueue(level, 1, rans ? 6 : 5, 1, 1, 2)) return 1;
+
+    // the switches of the preconditioner matrix (adjointUtils.F90:176-191), restored below
+    const adflow_opts saved = g_opts;
+    const int savedLumped = g_lumped;
+    unsigned resFlags = 0;
+    if (!(flags & ADFLOW_JAC_TURB_ONLY)) resFlags |= ADFLOW_RES_FLOW;
+    const bool turbRes = rans && !(flags & ADFLOW_JAC_FROZEN_TURB);
+    if (turbRes) resFlags |= ADFLOW_RES_TURB;
+    if (flags & ADFLOW_JAC_PC) {
+        g_lumped = 1;
+        g_opts.acousticScaleFactor = 1.0;
+        g_opts.orderTurb = 1;                                           // constants::firstOrder
+        resFlags |= ADFLOW_RES_DISS_APPROX | ADFLOW_RES_VISC_APPROX;     // dissApprox = viscApprox = lumpedDiss
+        // referenceShockSensor on the unperturbed state (adjointUtils.F90:258-260): the sensor is not linearised
+        const bool pressure = (g_opts.equations == ADFLOW_EULER) || (g_opts.spaceDiscr == ADFLOW_DISS_MATRIX);
+        rc = for_level(level, [&](Block* b) {
+            if (pressure) HIPCHK(hipMemcpyAsync(b->v.ss, b->v.p, sizeof(double) * (size_t)b->boxsize, hipMemcpyDeviceToDevice, g_stream));
+            else launch_entropy(b->v, g_stream);
+            return 0;
+        });
+    }
+    // frozenTurb: equations = NSEquations (adjointUtils.F90:218-222) -- no turbulence boundary conditions, no SA residual; the eddy
+    // viscosity is still recomputed from nuTilde because eddyModel stays set (turbUtils.F90:604-612)
+    const bool turbBC = rans && !(flags & ADFLOW_JAC_FROZEN_TURB);
+    auto restore = [&]() { g_opts = saved; g_lumped = savedLumped; };
+
+    // setFDReference (adjointUtils.F90:1971-2024): reference residual, then the reference state INCLUDING the halos the boundary
+    // conditions just wrote
+    if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC);
+    if (!rc) rc = for_level(level, [&](Block* b) {
+        launch_fd_copy(b->v, b->wref, b->v.w, b->v.nw, g_stream);
+        launch_fd_extract(b->v, b->dwref, b->jac, -1, 0, J, 0.0, g_opts.turbResScale, g_stream);
+        return 0;
+    });
+    const double deltaInv = 1.0 / delta;
+    for (int col = 0; col < J.cn && !rc; ++col) {
+        for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
+            rc = for_level(level, [&](Block* b) {
+                launch_fd_state(b->v, b->wref, l, col, J, delta, g_stream);
+                return 0;
+            });
+            if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC);
+            if (!rc) rc = for_level(level, [&](Block* b) {
+                launch_fd_extract(b->v, b->dwref, b->jac, l, col, J, deltaInv, g_opts.turbResScale, g_stream);
+                return 0;
+            });
+        }
+    }
+    // resetFDReference (adjointUtils.F90:2026-2058): w back, dw = the (scaled) reference residual
+    if (!rc) rc = for_level(level, [&](Block* b) {
+        launch_fd_state(b->v, b->wref, 0, -1, J, 0.0, g_stream);
+        launch_fd_extract(b->v, b->dwref, b->jac, -2, 0, J, 0.0, g_opts.turbResScale, g_stream);
+        b->ss_valid = false;
+        b->etot_consistent = false;
+        return 0;
+    });
+    restore();
+    if (rc) return rc;
+    g_jac = J;
+    g_jac_valid = true;
+    return sync_and_check();
+}
+
+int adflow_gpu_jacobian_info(int32_t* nState, int32_t* nStencil, int32_t* stencil)
+{
+    if (!g_jac_valid) return fail("jacobian_info: no assembled Jacobian (call adflow_gpu_fd_jacobian first)");
+    if (nState) *nState = g_jac.nState;
+    if (nStencil) *nStencil = g_jac.nStencil;
+    if (stencil)
+        for (int s = 0; s < g_jac.nStencil; ++s)
+            for (int d = 0; d < 3; ++d) stencil[(size_t)d * g_jac.nStencil + s] = g_jac.st[s][d];
+    return 0;
+}
+
+int adflow_gpu_download_jacobian(int nn, int level, int sps, double* blocks)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (!g_jac_valid || !b->jac) return fail("download_jacobian: no assembled Jacobian on block (%d,%d,%d)", nn, level, sps);
+    if (!blocks) return fail("download_jacobian: blocks is NULL");
+    BlkView& v = b->v;
+    int rc = copy_box(b, b->jac, blocks, b->jac_ncomp, 2, v.nx, 2, v.ny, 2, v.nz, false);
     if (rc) return rc;
     return sync_and_check();
 }

@@ -228,6 +228,7 @@ struct KParams {
     int fwMode;            // 0: fw not persistent (rFil==1, sfil==0, no store)  1: persistent fw
     int storeIntermed;     // store dtl / radii
     int dissApprox;        // lumped dissipation with the frozen sensor in b.ss (inviscidDissFlux*Approx)
+    int lumpedDiss;        // inputDiscretization::lumpedDiss (preconditioner assembly): first-order Roe upwind (fluxes.F90:1536)
     double sigma;
     double rFil, sfil;
     double vis2, vis4, vis2Coarse, adis, acousticScaleFactor, kappaCoef;
@@ -239,6 +240,18 @@ struct KParams {
     double cfl, cflLimit, smoop, fcoll, turbResScale;
     double wInf[10];
 };
+
+// coloured finite-difference Jacobian (kernels_jac.hip)
+struct JacSpec {
+    int nStencil, nState, lStart;     // lStart: first state variable (0-based) of the matrix
+    int ca, cb, cc, cn, cm;           // colour(i,j,k) = (ca (i mod cm) + cb (j mod cm) + cc (k mod cm)) mod cn   (0-based)
+    int st[33][3];                    // stencil offsets (row = perturbed cell + offset)
+};
+void launch_fd_state(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, hipStream_t s);
+void launch_fd_copy(const BlkView& b, double* dst, const double* src, int ncomp, hipStream_t s);
+void launch_closures_halo(const BlkView& b, const KParams& kp, hipStream_t s);
+void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int col, const JacSpec& J, double deltaInv, double turbResScale,
+                       hipStream_t s);
 
 // ---- kernel launchers (one translation unit per kernel family) -------------
 void launch_time_step_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);

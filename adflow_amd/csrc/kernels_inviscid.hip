@@ -120,7 +120,7 @@ __global__ __launch_bounds__(IV_BX* IV_BY, (SCHEME == ADFLOW_UPWIND ? 2 : 1)) vo
     const double fis2 = kp.rFil * kp.vis2, fis4 = kp.rFil * kp.vis4;
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
     // limiter actually used: first order off the fine grid (fluxes.F90:1531-1538)
-    const int lim = kp.fineGrid ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;
+    const int lim = (kp.fineGrid && !kp.lumpedDiss) ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;
 
     double dwc[5] = {0, 0, 0, 0, 0}, fwd[5] = {0, 0, 0, 0, 0};
     const double* sF = b.sFace;

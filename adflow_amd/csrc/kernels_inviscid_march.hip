@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
     F.fis4 = kp.rFil * kp.vis4;
     F.plim = SCAL ? 0.001 * kp.pInfCorr / pow(kp.rhoInf, kp.gammaInf) : 0.001 * kp.pInfCorr;   // sslim of the entropy sensor / plim
     F.gam = kp.gammaConstant;
-    F.lim = kp.fineGrid ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;           // fluxes.F90:1531-1538
+    F.lim = (kp.fineGrid && !kp.lumpedDiss) ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;           // fluxes.F90:1531-1538
     F.kappaCoef = kp.kappaCoef; F.rFil = kp.rFil; F.gammaConstant = kp.gammaConstant;
     const bool sens = (SCHEME != ADFLOW_UPWIND) && F.doDiss && !F.coarse;
     auto sensor = [&](const MCell& a, const MCell& q, const MCell& d) {

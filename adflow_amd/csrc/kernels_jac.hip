@@ -1,0 +1,139 @@
+// Coloured finite-difference Jacobian blocks of the residual on the device (second half).
+//
+// Reference semantics:
+//   adjointUtils::setupStateResidualMatrix (useAD = F)   src/adjoint/adjointUtils.F90:7-715
+//     colourings setup_PC_coloring / setup_dRdw_euler_coloring / setup_dRdw_visc_coloring   :1089-1185
+//     stencils                                                                              src/modules/stencils.f90
+//   masterRoutines::block_res_state                       src/adjoint/masterRoutines.F90:1214-1283
+//     computePressureSimple(.True.) 0..ib, computeLamViscosity(.True.) / computeEddyViscosity(.True.) 1..ie
+//     (flowUtils.F90:867-930, 1201-1300, turbUtils.F90:581-655), boundary conditions, residual core, resScale
+//     (adjointExtra.F90:601-636)
+//
+// The sweep: for every colour and every state variable l, w(l) of ALL cells of that colour (halos included: the columns of the
+// neighbouring blocks' cells) is raised by delta, the residual is evaluated, and every owned cell stores, for each stencil
+// offset s whose source cell  row - s  has that colour,  d dw(row, :) / d w(row - s, l) = (dw - dw_ref) / delta.
+// A valid colouring gives every cell of a stencil a different colour, so one residual evaluation fills one column of every block
+// of the sparse matrix.  Layout of the result: component ((s * nState + l) * nState + ll) of a box array, i.e. the host sees
+// (nx, ny, nz, nState, nState, nStencil) column-major = blk(ll, l) of the reference for every (row, s).
+// These kernels are pointwise and run once per colour and variable next to a full residual evaluation: HBM-bound, not tuned.
+#include "internal.h"
+
+#define JC_BX 64
+#define JC_BY 4
+
+__device__ __forceinline__ int jc_colour(const JacSpec& J, int i, int j, int k)
+{
+    return (J.ca * (i % J.cm) + J.cb * (j % J.cm) + J.cc * (k % J.cm)) % J.cn;
+}
+
+
+// w <- wref (+ delta on component l of the cells of colour `col`); col < 0: plain restore
+__global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_state(BlkView b, const double* __restrict__ wref, int l, int col, JacSpec J,
+                                                           double delta)
+{
+    const int i = blockIdx.x * JC_BX + threadIdx.x - 14;     // aligned rows (the box origin is shifted by ADF_PAD0)
+    const int j = blockIdx.y * JC_BY + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i < 0 || i > b.ib || j > b.jb) return;
+    const long c = b.idx(i, j, k);
+    const bool hit = (col >= 0) && (jc_colour(J, i, j, k) == col);
+    for (int m = 0; m < b.nw; ++m) {
+        double v = wref[c + m * b.nbox];
+        if (hit && m == l) v += delta;
+        b.w[c + m * b.nbox] = v;
+    }
+}
+
+__global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_copy(BlkView b, double* __restrict__ dst, const double* __restrict__ src, int ncomp)
+{
+    const int i = blockIdx.x * JC_BX + threadIdx.x - 14;
+    const int j = blockIdx.y * JC_BY + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i < 0 || i > b.ib || j > b.jb) return;
+    const long c = b.idx(i, j, k);
+    for (int m = 0; m < ncomp; ++m) dst[c + m * b.nbox] = src[c + m * b.nbox];
+}
+
+// pressure on 0..ib, laminar / eddy viscosity on 1..ie (the includeHalos = .True. forms used by block_res_state)
+__global__ __launch_bounds__(JC_BX* JC_BY) void k_closures_halo(BlkView b, KParams kp)
+{
+    const int i = blockIdx.x * JC_BX + threadIdx.x - 14;
+    const int j = blockIdx.y * JC_BY + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i < 0 || i > b.ib || j > b.jb) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    const double gm1 = kp.gammaConstant - 1.0;
+    double p = gm1 * (b.w[c + 4 * nb] - 0.5 * rho * (u * u + v * v + w * w));
+    p = fmax(p, 1.e-4 * kp.pInfCorr);
+    b.p[c] = p;
+    if (!kp.viscous || i < 1 || i > b.ie || j < 1 || j > b.je || k < 1 || k > b.ke) return;
+    const double muSuth = kp.muSuthDim / kp.muRef, TSuth = kp.TSuthDim / kp.TRef, SSuth = kp.SSuthDim / kp.TRef;
+    const double T = p / (kp.RGas * rho);
+    const double tt = T / TSuth;
+    const double rlv = muSuth * ((TSuth + SSuth) / (T + SSuth)) * (tt * sqrt(tt));
+    b.rlv[c] = rlv;
+    if (kp.eddyModel) {
+        const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
+        const double rnuSA = b.w[c + 5 * nb] * rho;
+        const double chi = rnuSA / rlv;
+        const double chi3 = chi * chi * chi;
+        b.rev[c] = chi3 / (chi3 + cv13) * rnuSA;
+    }
+}
+
+// owned cells: resScale (dw / volRef, turbulence * turbResScale), then either store the reference (l = -1) or the finite
+// differences of the column l of every stencil block whose source cell has colour `col`
+__global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_extract(BlkView b, double* __restrict__ dwref, double* __restrict__ jac, int l, int col,
+                                                             JacSpec J, double deltaInv, double turbResScale)
+{
+    const int i = blockIdx.x * JC_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * JC_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    const double ovol = 1.0 / b.volRef[c];
+    double val[6];
+    for (int m = 0; m < J.nState; ++m) {
+        const int ll = J.lStart + m;
+        val[m] = b.dw[c + ll * nb] * ovol * (ll >= 5 ? turbResScale : 1.0);
+    }
+    if (l == -1) {
+        for (int m = 0; m < J.nState; ++m) dwref[c + m * nb] = val[m];
+        return;
+    }
+    if (l == -2) {                    // resetFDReference: dw = the scaled reference residual
+        for (int m = 0; m < J.nState; ++m) b.dw[c + (J.lStart + m) * nb] = dwref[c + m * nb];
+        return;
+    }
+    for (int s = 0; s < J.nStencil; ++s) {
+        const int pi = i - J.st[s][0], pj = j - J.st[s][1], pk = k - J.st[s][2];      // the perturbed cell
+        if (pi < 0 || pi > b.ib || pj < 0 || pj > b.jb || pk < 0 || pk > b.kb) continue;
+        if (jc_colour(J, pi, pj, pk) != col) continue;
+        for (int m = 0; m < J.nState; ++m)
+            jac[c + ((long)(s * J.nState + (l - J.lStart)) * J.nState + m) * nb] = (val[m] - dwref[c + m * nb]) * deltaInv;
+    }
+}
+
+static dim3 box_grid(const BlkView& b) { return dim3((b.ib + 15 + JC_BX) / JC_BX, (b.jb + JC_BY) / JC_BY, b.kb + 1); }
+static dim3 own_grid(const BlkView& b) { return dim3((b.nx + JC_BX - 1) / JC_BX, (b.ny + JC_BY - 1) / JC_BY, b.nz); }
+
+void launch_fd_state(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fd_state, box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, wref, l, col, J, delta);
+}
+void launch_fd_copy(const BlkView& b, double* dst, const double* src, int ncomp, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fd_copy, box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, dst, src, ncomp);
+}
+void launch_closures_halo(const BlkView& b, const KParams& kp, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_closures_halo, box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, kp);
+}
+void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int col, const JacSpec& J, double deltaInv, double turbResScale,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fd_extract, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, dwref, jac, l, col, J, deltaInv, turbResScale);
+}

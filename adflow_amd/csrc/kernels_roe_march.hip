@@ -405,7 +405,7 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
 // true when the launch was taken: second-order Roe upwind on the fine level of blocks at rest
 bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
-    if (!g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid || kp.dissApprox) return false;
+    if (!g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid || kp.dissApprox || kp.lumpedDiss) return false;
     if (ntiles <= 0) return true;
     switch (kp.limiter) {
     case ADFLOW_LIM_NONE: launch_rm<ADFLOW_LIM_NONE>(tab, tiles, ntiles, kp, s); return true;

@@ -1795,7 +1795,7 @@ int g_roe_grad_mix = 1;     // tuning "roe_grad_mix": inviscid Roe march and nod
 // true when taken: second-order Roe upwind, fw not persistent, viscous part to follow, blocks at rest
 bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
-    if (!g_roe_grad_mix || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid || kp.dissApprox || kp.fwMode || ntiles <= 0 || nslots <= 0)
+    if (!g_roe_grad_mix || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid || kp.dissApprox || kp.lumpedDiss || kp.fwMode || ntiles <= 0 || nslots <= 0)
         return false;
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return false;
     const int nzn = nz + 1, nchn = (nzn + NG_KCH - 1) / NG_KCH;

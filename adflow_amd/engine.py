@@ -106,9 +106,33 @@ class Engine:
     def referenceShockSensor(self, level=1):
         self._chk(self.lib.adflow_gpu_reference_shock_sensor(level))
 
-    def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True, dissApprox=False, viscApprox=False):
+    def setupStateResidualMatrix(self, level=1, usePC=True, frozenTurb=False, useTurbOnly=False, viscPC=False, delta=1e-9):
+        """adjointUtils::setupStateResidualMatrix(useAD=F) (adjointUtils.F90:7-715) without the PETSc calls: the coloured
+        finite-difference blocks stay on the device; jacobianBlocks() brings one block's over."""
+        flags = (capi.JAC_PC if usePC else 0) | (capi.JAC_FROZEN_TURB if frozenTurb else 0) \
+            | (capi.JAC_TURB_ONLY if useTurbOnly else 0) | (capi.JAC_VISC_PC if viscPC else 0)
+        self._chk(self.lib.adflow_gpu_fd_jacobian(level, flags, float(delta)))
+
+    def jacobianInfo(self):
+        ns, nst = ctypes.c_int32(), ctypes.c_int32()
+        self._chk(self.lib.adflow_gpu_jacobian_info(ctypes.byref(ns), ctypes.byref(nst), None))
+        st = np.zeros((nst.value, 3), dtype=np.int32, order="F")
+        self._chk(self.lib.adflow_gpu_jacobian_info(None, None, st.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        return ns.value, st
+
+    def jacobianBlocks(self, nn=1, level=1, sps=1):
+        """(nx, ny, nz, nState, nState, nStencil): blk(ll, l) of stencil entry s at every owned row cell"""
+        ns, st = self.jacobianInfo()
+        blk = self.blocks[(nn, level, sps)]
+        out = np.zeros((blk.nx, blk.ny, blk.nz, ns, ns, st.shape[0]), order="F")
+        self._chk(self.lib.adflow_gpu_download_jacobian(nn, level, sps, out.ctypes.data))
+        return out
+
+    def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True, dissApprox=False, viscApprox=False,
+                     useBlockettes=False):
         flags = (capi.RES_UPDATE_INTERMED if updateIntermed else 0) | (capi.RES_FLOW if flowRes else 0) \
-            | (capi.RES_TURB if turbRes else 0) | (32 if dissApprox else 0) | (64 if viscApprox else 0)
+            | (capi.RES_TURB if turbRes else 0) | (32 if dissApprox else 0) | (64 if viscApprox else 0) \
+            | (128 if useBlockettes else 0)
         self._chk(self.lib.adflow_gpu_block_res(level, flags))
 
     def bc_register(self, faces, nViscBocos: int = 0, nn: int = 1, level: int = 1, sps: int = 1):

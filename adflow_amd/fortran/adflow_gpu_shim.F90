@@ -229,6 +229,22 @@ module adflowGpuShim
             import :: c_int
             integer(c_int), value :: level
         end function
+        ! adjointUtils::setupStateResidualMatrix (useAD = F): coloured finite-difference blocks on the device
+        integer(c_int) function adflow_gpu_fd_jacobian(level, flags, delta) bind(C, name="adflow_gpu_fd_jacobian")
+            import :: c_int, c_double
+            integer(c_int), value :: level, flags
+            real(c_double), value :: delta
+        end function
+        integer(c_int) function adflow_gpu_jacobian_info(nState, nStencil, stencil) bind(C, name="adflow_gpu_jacobian_info")
+            import :: c_int, c_ptr
+            integer(c_int), intent(out) :: nState, nStencil
+            type(c_ptr), value :: stencil
+        end function
+        integer(c_int) function adflow_gpu_download_jacobian(nn, level, sps, blocks) bind(C, name="adflow_gpu_download_jacobian")
+            import :: c_int, c_ptr
+            integer(c_int), value :: nn, level, sps
+            type(c_ptr), value :: blocks
+        end function
         integer(c_int) function adflow_gpu_reference_shock_sensor(level) bind(C, name="adflow_gpu_reference_shock_sensor")
             import :: c_int
             integer(c_int), value :: level

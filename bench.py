@@ -381,6 +381,20 @@ def main():
             log(f"config 5 proxy: {s5 * 1e3:.3f} ms/matvec")
             del w0, vk, wk, rv
             # restore the state (setW clipped / perturbed it by 1e-7) is not needed: the remaining extras re-time only
+            # ---- the preconditioner matrix of NK / ANK: setupStateResidualMatrix(usePC = T, useAD = F), adjointUtils.F90:7-715 --
+            # 7 colours x 6 states coloured finite differences, every one closures + boundary conditions + approximate residual +
+            # the scatter of one column of all 7 stencil blocks; the blocks (7 x 36 doubles per cell) stay on the device
+            eng.setupStateResidualMatrix(1, usePC=True)            # first call allocates the block storage
+            barrier()
+            t0 = time.perf_counter()
+            eng.setupStateResidualMatrix(1, usePC=True)
+            barrier()
+            spc = time.perf_counter() - t0
+            extra["pc_matrix_assembly"] = {
+                "ms": spc * 1e3, "residual_evaluations": 43, "ms_per_evaluation": spc * 1e3 / 43.0,
+                "what": "adflow_gpu_fd_jacobian(PC): 7 colours x 6 states + the reference evaluation, lumped Roe dissipation, "
+                        "thin-layer viscous flux, first-order SA advection; blocks resident in HBM (2016 B per cell)"}
+            log(f"PC matrix assembly: {spc * 1e3:.1f} ms ({spc * 1e3 / 43.0:.2f} ms per coloured evaluation)")
             # ---- config 3: one solver iteration = D-ADI x3 sub-iterations + SA DDADI x3 (test_functionals.py:136-160)
             eng.set_options(prm.replace(spaceDiscr=1, smoother=DADI, nSubiterations=3, nSubIterTurb=3, cfl=1.5, resAveraging=noResAveraging))
             eng.timeStep(1, False)

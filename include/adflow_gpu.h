@@ -203,7 +203,11 @@ enum {
     /* approximate residual of the preconditioner assembly (blockette.F90:755-852, fluxes.F90:3487-4975): */
     ADFLOW_RES_DISS_APPROX = 32u,      /* useDissApprox: inviscidDissFluxScalarApprox / MatrixApprox (lumped 2nd-difference
                                           dissipation with the FROZEN sensor of adflow_gpu_reference_shock_sensor) */
-    ADFLOW_RES_VISC_APPROX = 64u       /* useViscApprox: viscousFluxApprox (thin-layer normal differences) */
+    ADFLOW_RES_VISC_APPROX = 64u,      /* useViscApprox: viscousFluxApprox (thin-layer normal differences) */
+    /* with DISS_APPROX and the Roe upwind scheme the two residual cores of the reference differ: blocketteResCore (useBlockettes = T,
+     * the default) calls inviscidUpwindFlux(.False.) = first-order reconstruction (blockette.F90:643), blockResCore keeps the
+     * limiter (:827).  The host passes this flag when inputDiscretization::useBlockettes is set. */
+    ADFLOW_RES_UPWIND_FIRST_ORDER = 128u
 };
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -380,6 +384,28 @@ int adflow_gpu_set_async(int on);
 int adflow_gpu_abi_sizes(int* opts_bytes, int* desc_bytes);
 /* the same for adflow_bc_subface and adflow_comm_pattern */
 int adflow_gpu_abi_sizes2(int* bc_subface_bytes, int* comm_pattern_bytes);
+
+/* ---- preconditioner / Jacobian assembly: adjointUtils::setupStateResidualMatrix with useAD = F (src/adjoint/adjointUtils.F90:7-715),
+ * consumers NKSolver::FormJacobianNK (NKSolvers.F90:372-435), FormJacobianANK (:1935-2039), the adjoint's dRdwT.
+ * Coloured finite differences of the level's residual (block_res_state, masterRoutines.F90:1214-1283: closures incl. halos,
+ * boundary conditions, residual core, resScale) on the device: one residual evaluation per colour and state variable fills one
+ * column of every stencil block of the matrix.
+ *   ADFLOW_JAC_PC          usePC: 7-point stencil, lumped dissipation with the frozen sensor, thin-layer viscous flux,
+ *                          first-order turbulence advection, acousticScaleFactor = 1 (7 colours)
+ *   without it             the exact dR/dw: 13-point stencil / 13 colours (Euler), 33-point stencil / 35 colours (viscous)
+ *   ADFLOW_JAC_FROZEN_TURB frozenTurb: nState = nwf, RANS evaluated as laminar NS plus the eddy viscosity, no SA residual
+ *   ADFLOW_JAC_TURB_ONLY   useTurbOnly (the turbulence KSP of ANK, NKSolvers.F90:2340-2370): nState = 1, only the SA residual
+ *   ADFLOW_JAC_VISC_PC     inputAdjoint::viscPC with ADFLOW_JAC_PC: the 27-point stencil and the 3x3x3 colouring
+ * delta: the finite-difference step (the reference uses 1e-9).  The state is restored afterwards, dw holds the scaled reference
+ * residual (resetFDReference).  level must be the ground level. */
+enum { ADFLOW_JAC_PC = 1u, ADFLOW_JAC_FROZEN_TURB = 2u, ADFLOW_JAC_TURB_ONLY = 4u, ADFLOW_JAC_VISC_PC = 8u };
+int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta);
+/* nState, nStencil and the stencil offsets (nStencil,3) column-major as src/modules/stencils.f90 of the last assembly:
+ * block (ll, l) of stencil entry s at row cell (i,j,k) is  d dw(i,j,k,ll) / d w(i-di(s), j-dj(s), k-dk(s), l)  (after resScale) */
+int adflow_gpu_jacobian_info(int32_t* nState, int32_t* nStencil, int32_t* stencil);
+/* blocks of block nn over its OWNED cells: (nx, ny, nz, nState, nState, nStencil) column-major.  The host maps rows / columns to
+ * globalCell and calls MatSetValuesBlocked; entries whose source cell lies outside 0..ib are zero */
+int adflow_gpu_download_jacobian(int nn, int level, int sps, double* blocks);
 
 #ifdef __cplusplus
 }

@@ -239,6 +239,21 @@ def blockette_res_core(update_intermed=False, flow_res=True, turb_res=True, diss
     _big_stack(load().ref_blockette_res_core, int(update_intermed), int(flow_res), int(turb_res), int(diss_approx), int(visc_approx))
 
 
+def fd_jacobian(nx, ny, nz, usePC=True, frozenTurb=False, turbOnly=False, viscPC=False, useBlockettes=False, delta=1e-9):
+    """adjointUtils::setupStateResidualMatrix(useAD=F) (adjointUtils.F90:7-715) on the bound block, PETSc stores replaced by
+    an array: returns blocks (nx, ny, nz, nState, nState, nStencil) [blk(ll, l) per row cell and stencil entry]."""
+    import ctypes
+    buf = np.zeros(nx * ny * nz * 36 * 33)
+    ns, nst = ctypes.c_int(), ctypes.c_int()
+    fn = load().ref_fd_jacobian
+    fn.argtypes = [ctypes.c_int] * 5 + [ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    fn.restype = None
+    _big_stack(fn, int(usePC), int(frozenTurb), int(turbOnly), int(viscPC), int(useBlockettes), float(delta), buf.ctypes.data,
+               ctypes.byref(ns), ctypes.byref(nst))
+    n = nx * ny * nz * ns.value * ns.value * nst.value
+    return buf[:n].reshape((nx, ny, nz, ns.value, ns.value, nst.value), order="F")
+
+
 def time_block_res_core(seconds: float, update_intermed=True, flow_res=True, turb_res=True):
     """Repeat the blockResCore sequence for ~`seconds`; returns (evals, elapsed)."""
     import time

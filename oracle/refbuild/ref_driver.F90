@@ -828,6 +828,212 @@ contains
     end subroutine ref_block_res_core2
 
 
+    ! adjointUtils::setupStateResidualMatrix with useAD = F (adjointUtils.F90:7-715) on the CURRENT block, the PETSc calls replaced
+    ! by stores into jac(nx, ny, nz, nState, nState, nStencil) [blk(ll, l) of stencil entry s at the row cell].  Module adjointUtils
+    ! and masterRoutines cannot be compiled here (PETSc matrices, the AD routines), so the loop nest is restated around the
+    ! reference's own routines: block_res_state (masterRoutines.F90:1214-1283) = closures with halos, turbulence and mean-flow
+    ! boundary conditions, blocketteResCore / the blockResCore sequence, actuator sources, resScale; setFDReference /
+    ! resetFDReference (:1971-2058), referenceShockSensor (:1909-1969), the colourings (:1089-1185), stencils.f90.
+    subroutine ref_fd_jacobian(usePC, frozenTurb, turbOnly, viscPC, useBlockettes, delta, jac, nStateOut, nStencilOut) &
+        bind(C, name="ref_fd_jacobian")
+        use blockPointers
+        use flowVarRefState, only: nw, nwf, nt1, nt2, viscous
+        use inputPhysics, only: equations
+        use inputDiscretization, only: lumpedDiss, acousticScaleFactor, orderTurb, spaceDiscr
+        use iteration, only: rFil, currentLevel, groundLevel, rkStage
+        use stencils
+        use blockette, only: blocketteResCore
+        use flowUtils, only: computePressureSimple, computeLamViscosity
+        use turbUtils, only: computeEddyViscosity
+        use BCRoutines, only: applyAllBC_block
+        use turbBCRoutines, only: bcTurbTreatment, applyAllTurbBCThisBlock
+        use residuals, only: sourceTerms_block
+        use actuatorRegionData, only: nActuatorRegions
+        use adjointExtra, only: resScale
+        integer(c_int), value :: usePC, frozenTurb, turbOnly, viscPC, useBlockettes
+        real(c_double), value :: delta
+        type(c_ptr), value :: jac
+        integer(c_int), intent(out) :: nStateOut, nStencilOut
+        external :: initialize_stencils
+        real(kind=realType), dimension(:, :, :, :, :, :), pointer :: Jm
+        real(kind=realType), dimension(:, :, :, :), allocatable :: wtmp, dwtmp
+        real(kind=realType), dimension(:, :, :, :, :), allocatable :: dw_deriv
+        integer(kind=intType), dimension(:, :, :), allocatable :: color
+        integer(kind=intType), dimension(:, :), pointer :: stencil
+        integer(kind=intType) :: n_stencil, nColor, iColor, lStart, lEnd, nState, l, ll, i, j, k, ii, jj, kk, ist, orderTurbSave
+        real(kind=realType) :: acousticScaleSave, one_over_dx
+        logical :: flowRes, turbRes, resetToRANS
+
+        call initialize_stencils
+        if (turbOnly /= 0) then
+            flowRes = .false.; turbRes = .true.; lStart = nt1; lEnd = nt2
+        else if (frozenTurb /= 0) then
+            flowRes = .true.; turbRes = .false.; lStart = 1; lEnd = nwf
+        else
+            flowRes = .true.; turbRes = .true.; lStart = 1; lEnd = nw
+        end if
+        nState = lEnd - lStart + 1
+        rkStage = 0
+        if (usePC /= 0) then
+            if (viscous .and. viscPC /= 0) then
+                stencil => visc_pc_stencil; n_stencil = N_visc_pc
+            else
+                stencil => euler_pc_stencil; n_stencil = N_euler_pc
+            end if
+            lumpedDiss = .true.
+            acousticScaleSave = acousticScaleFactor
+            acousticScaleFactor = one
+            orderTurbSave = orderTurb
+            orderTurb = firstOrder
+        else
+            if (viscous) then
+                stencil => visc_drdw_stencil; n_stencil = N_visc_drdw
+            else
+                stencil => euler_drdw_stencil; n_stencil = N_euler_drdw
+            end if
+        end if
+        nStateOut = int(nState, c_int)
+        nStencilOut = int(n_stencil, c_int)
+        call c_f_pointer(jac, Jm, [nx, ny, nz, nState, nState, n_stencil])
+        Jm = zero
+        one_over_dx = one / delta
+        resetToRANS = .false.
+        if (frozenTurb /= 0 .and. equations == RANSEquations) then
+            equations = NSEquations
+            resetToRANS = .true.
+        end if
+        allocate (wtmp(0:ib, 0:jb, 0:kb, nw), dwtmp(0:ib, 0:jb, 0:kb, nw), dw_deriv(2:il, 2:jl, 2:kl, nw, nw), color(0:ib, 0:jb, 0:kb))
+
+        if (usePC /= 0) call shock_sensor
+        ! setFDReference
+        call res_state(.true., .true.)
+        wtmp = w(0:ib, 0:jb, 0:kb, 1:nw)
+        dwtmp = dw(0:ib, 0:jb, 0:kb, 1:nw)
+
+        do k = 0, kb
+            do j = 0, jb
+                do i = 0, ib
+                    if (usePC /= 0) then
+                        if (viscous .and. viscPC /= 0) then
+                            color(i, j, k) = mod(i, 3) + 3 * mod(j, 3) + 9 * mod(k, 3) + 1     ! setup_3x3x3_coloring
+                        else
+                            color(i, j, k) = mod(i + 5 * j + 4 * k, 7) + 1                     ! setup_PC_coloring
+                        end if
+                    else if (viscous) then
+                        color(i, j, k) = mod(i + 19 * j + 11 * k, 35) + 1                      ! setup_dRdw_visc_coloring
+                    else
+                        color(i, j, k) = mod(i + 3 * j + 4 * k, 13) + 1                        ! setup_dRdw_euler_coloring
+                    end if
+                end do
+            end do
+        end do
+        nColor = maxval(color)
+        if (usePC /= 0 .and. .not. (viscous .and. viscPC /= 0)) nColor = 7
+        if (usePC /= 0 .and. viscous .and. viscPC /= 0) nColor = 27
+        if (usePC == 0 .and. viscous) nColor = 35
+        if (usePC == 0 .and. .not. viscous) nColor = 13
+
+        do iColor = 1, nColor
+            dw_deriv = zero
+            do l = lStart, lEnd
+                w(0:ib, 0:jb, 0:kb, 1:nw) = wtmp
+                do k = 0, kb
+                    do j = 0, jb
+                        do i = 0, ib
+                            if (color(i, j, k) == iColor) w(i, j, k, l) = w(i, j, k, l) + delta
+                        end do
+                    end do
+                end do
+                call res_state(flowRes, turbRes)
+                do ll = lStart, lEnd
+                    dw_deriv(:, :, :, ll, l) = one_over_dx * (dw(2:il, 2:jl, 2:kl, ll) - dwtmp(2:il, 2:jl, 2:kl, ll))
+                end do
+            end do
+            do k = 0, kb
+                do j = 0, jb
+                    do i = 0, ib
+                        if (color(i, j, k) /= iColor) cycle
+                        do ist = 1, n_stencil
+                            ii = stencil(ist, 1); jj = stencil(ist, 2); kk = stencil(ist, 3)
+                            if (i + ii >= 2 .and. i + ii <= il .and. j + jj >= 2 .and. j + jj <= jl .and. &
+                                k + kk >= 2 .and. k + kk <= kl) then
+                                Jm(i + ii - 1, j + jj - 1, k + kk - 1, :, :, ist) = &
+                                    dw_deriv(i + ii, j + jj, k + kk, lStart:lEnd, lStart:lEnd)
+                            end if
+                        end do
+                    end do
+                end do
+            end do
+        end do
+
+        ! resetFDReference and the switches back
+        w(0:ib, 0:jb, 0:kb, 1:nw) = wtmp
+        dw(0:ib, 0:jb, 0:kb, 1:nw) = dwtmp
+        if (usePC /= 0) then
+            lumpedDiss = .false.
+            acousticScaleFactor = acousticScaleSave
+            orderTurb = orderTurbSave
+        end if
+        if (resetToRANS) equations = RANSEquations
+        deallocate (wtmp, dwtmp, dw_deriv, color)
+    contains
+        subroutine res_state(fRes, tRes)            ! masterRoutines.F90:1258-1280
+            logical, intent(in) :: fRes, tRes
+            integer(kind=intType) :: iRegion
+            integer(c_int) :: da
+            real(kind=realType) :: pLocal
+            call computePressureSimple(.true.)
+            call computeLamViscosity(.true.)
+            call computeEddyViscosity(.true.)
+            if (equations == RANSEquations) then
+                call bcTurbTreatment
+                call applyAllTurbBCThisBlock(.true.)
+            end if
+            call applyAllBC_block(.true.)
+            rFil = one
+            if (useBlockettes /= 0) then
+                call blocketteResCore(lumpedDiss, lumpedDiss, .false., fRes, tRes, .true.)
+            else
+                da = merge(1_c_int, 0_c_int, lumpedDiss)
+                call ref_block_res_core2(0_c_int, merge(1_c_int, 0_c_int, fRes), merge(1_c_int, 0_c_int, tRes), da, da)
+            end if
+            do iRegion = 1, nActuatorRegions
+                call sourceTerms_block(1_intType, .true., iRegion, pLocal)
+            end do
+            call resScale
+        end subroutine res_state
+
+        subroutine shock_sensor                     ! adjointUtils.F90:1925-1966
+            integer(kind=intType) :: i, j, k
+            if (equations == EulerEquations .or. spaceDiscr == dissMatrix) then
+                shockSensor(0:ib, 0:jb, 0:kb) = p(0:ib, 0:jb, 0:kb)
+            else
+                do k = 0, kb
+                    do j = 2, jl
+                        do i = 2, il
+                            shockSensor(i, j, k) = p(i, j, k) / (w(i, j, k, irho)**gamma(i, j, k))
+                        end do
+                    end do
+                end do
+                do k = 2, kl
+                    do j = 2, jl
+                        do i = 0, ib
+                            if (i > 1 .and. i < ie) cycle
+                            shockSensor(i, j, k) = p(i, j, k) / (w(i, j, k, irho)**gamma(i, j, k))
+                        end do
+                    end do
+                    do i = 2, il
+                        do j = 0, jb
+                            if (j > 1 .and. j < je) cycle
+                            shockSensor(i, j, k) = p(i, j, k) / (w(i, j, k, irho)**gamma(i, j, k))
+                        end do
+                    end do
+                end do
+            end if
+        end subroutine shock_sensor
+    end subroutine ref_fd_jacobian
+
+
     ! ===================================================================
     ! multi-block mode: the reference's SHELL routines (smoothers, halo
     ! exchange, multigrid) loop over flowDoms(nn,level,sps) and re-aim
@@ -906,6 +1112,7 @@ contains
             d%ux => ux; d%uy => uy; d%uz => uz; d%vx => vx; d%vy => vy; d%vz => vz
             d%wx => wx; d%wy => wy; d%wz => wz; d%qx => qx; d%qy => qy; d%qz => qz
             d%dw => dw; d%fw => fw; d%scratch => scratch
+            d%shockSensor => shockSensor
             d%p1 => p1; d%w1 => w1; d%wr => wr
             d%wn => wn; d%pn => pn; d%dtl => dtl; d%radI => radI; d%radJ => radJ; d%radK => radK
             d%d2Wall => d2Wall

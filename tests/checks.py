@@ -84,7 +84,7 @@ def check_block_res_vs_blockette(engine, dims, prm, update_intermed=False, seed=
     return blk, r
 
 
-def check_block_res_approx(engine, dims, prm, diss_approx=True, visc_approx=True, seed=91, **mk):
+def check_block_res_approx(engine, dims, prm, diss_approx=True, visc_approx=True, seed=91, blockettes=False, **mk):
     """blockResCore with dissApprox / viscApprox (blockette.F90:755-852): the lumped-dissipation and thin-layer
     residual of the preconditioner assembly, sensor FROZEN at a reference state that differs from the state the
     residual is evaluated at (as in the finite-difference Jacobian, adjointUtils.F90:1909-1969)."""
@@ -112,8 +112,13 @@ def check_block_res_approx(engine, dims, prm, diss_approx=True, visc_approx=True
         a["w"][..., 4] *= fac
         a["p"][...] *= fac
     engine.upload_state(1, lvl)
-    ref.block_res_core(True, True, turb, diss_approx=diss_approx, visc_approx=visc_approx)
-    engine.blocketteRes(level=lvl, updateIntermed=True, flowRes=True, turbRes=turb, dissApprox=diss_approx, viscApprox=visc_approx)
+    # the two cores of the reference differ for the Roe scheme: blocketteResCore (the default) is first order here (blockette.F90:643)
+    if blockettes:
+        ref.blockette_res_core(True, True, turb, diss_approx=diss_approx, visc_approx=visc_approx)
+    else:
+        ref.block_res_core(True, True, turb, diss_approx=diss_approx, visc_approx=visc_approx)
+    engine.blocketteRes(level=lvl, updateIntermed=True, flowRes=True, turbRes=turb, dissApprox=diss_approx, viscApprox=visc_approx,
+                        useBlockettes=blockettes)
     dw = engine.download_residual(1, lvl)
     assert_dw(blk, dw, r["dw"], blk.nw, what=f"approx residual diss={diss_approx} visc={visc_approx}")
     # an exact evaluation afterwards must not be affected by the frozen sensor
@@ -121,6 +126,40 @@ def check_block_res_approx(engine, dims, prm, diss_approx=True, visc_approx=True
     engine.blocketteRes(level=lvl, updateIntermed=True, flowRes=True, turbRes=turb)
     dw = engine.download_residual(1, lvl)
     assert_dw(blk, dw, r["dw"], blk.nw, what="exact residual after an approximate one")
+
+
+def check_fd_jacobian(engine, dims, prm, spec, usePC=True, frozenTurb=False, useTurbOnly=False, viscPC=False, delta=1e-5,
+                      tol=1e-9, seed=101, blockettes=False, **mk):
+    """adflow_gpu_fd_jacobian vs adjointUtils::setupStateResidualMatrix(useAD=F) (adjointUtils.F90:7-715, restated around the
+    reference's own routines in oracle/refbuild/ref_driver.F90:ref_fd_jacobian): every block of the coloured finite-difference
+    matrix of ONE block with six physical boundary faces.  A finite difference amplifies the rounding differences between two
+    correct residuals by 1/delta, so the tolerance is RELATIVE TO THE LARGEST ENTRY and scales like 1e-15/delta: the 1e-10 bar
+    of the residual is met at delta = 1e-5, and the reference's own delta = 1e-9 is checked at the 1e-5 it can resolve."""
+    from oracle import ref
+    blk, r, prm = setup_block_with_bc(engine, dims, prm, spec, seed, **mk)
+    Jr = ref.fd_jacobian(blk.nx, blk.ny, blk.nz, usePC, frozenTurb, useTurbOnly, viscPC, blockettes, delta)
+    engine.setupStateResidualMatrix(1, usePC, frozenTurb, useTurbOnly, viscPC, delta)
+    ns, st = engine.jacobianInfo()
+    Jg = engine.jacobianBlocks(1, 1)
+    assert Jg.shape == Jr.shape, (Jg.shape, Jr.shape)
+    scale = np.abs(Jr).max()
+    assert scale > 0.0
+    err = np.abs(Jg - Jr).max() / scale
+    assert err <= tol, (err, tol, np.unravel_index(np.abs(Jg - Jr).argmax(), Jr.shape))
+    # no stencil entry silently skipped (the corner entries of the 27-point preconditioner stencil are empty in the reference
+    # too: the thin-layer residual does not couple them), the diagonal block of every cell is non-zero
+    for s in range(st.shape[0]):
+        assert (np.abs(Jg[..., s]).max() > 1e-7 * scale) == (np.abs(Jr[..., s]).max() > 1e-7 * scale), ("stencil entry", s, st[s])
+    assert sum(np.abs(Jg[..., s]).max() > 1e-7 * scale for s in range(st.shape[0])) >= 7
+    diag = np.abs(Jg[..., 0 if usePC or prm.equations == EulerEquations else 13]).reshape(blk.nx * blk.ny * blk.nz, -1).max(axis=1)
+    assert diag.min() > 0.0
+    # resetFDReference: w is the reference state (boundary halos as the reference evaluation left them), dw the scaled residual
+    engine.download_state(1, 1)
+    assert rel_err(blk["w"], r["w"]) <= TOL
+    dw = engine.download_residual(1, 1)
+    lo, hi = (5, 6) if useTurbOnly else (0, 5 if frozenTurb else blk.nw)
+    assert rel_err(owned(blk, dw)[..., lo:hi], owned(blk, r["dw"])[..., lo:hi]) <= TOL
+    return Jg, Jr, st
 
 
 def check_rk_residual_sequence(engine, dims, prm, seed=3, **mk):

@@ -1,0 +1,53 @@
+"""GPU parity (real MI355X, through the C-ABI): the coloured finite-difference matrix blocks of
+adjointUtils::setupStateResidualMatrix(useAD = F) (adjointUtils.F90:7-715) -- the preconditioner of NK / ANK and the
+adjoint's dR/dw -- against the loop nest restated around the reference's own Fortran routines (oracle/_ref, ref_fd_jacobian).
+SURVEY.md section 8(f) #4."""
+import pytest
+
+import checks
+from adflow_amd.params import (FlowParams, dissScalar, dissMatrix, upwind, NSEquations, RANSEquations, secondOrder, vanAlbeda, minmod)
+
+pytestmark = pytest.mark.gpu
+
+WALL = {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}
+EULER = {1: -6, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}
+OPEN = {1: -6, 3: -1, 4: -1, 6: -6}          # faces 2 and 5 without subfaces: halos stay as given, like 1-to-1 block interfaces
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_pc_euler(engine, sd):
+    checks.check_fd_jacobian(engine, (12, 9, 7), FlowParams(spaceDiscr=sd, limiter=vanAlbeda), EULER)
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_pc_rans(engine, sd):
+    """the matrix FormJacobianNK / FormJacobianANK assemble on the north-star discretisations"""
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=sd, limiter=vanAlbeda, orderTurb=secondOrder, acousticScaleFactor=0.5,
+                      vis4=0.1 if sd == dissMatrix else 0.0156)
+    checks.check_fd_jacobian(engine, (16, 10, 7), rans, WALL, stretch_k=2.0)
+    checks.check_fd_jacobian(engine, (9, 8, 6), rans, OPEN, stretch_k=2.0)
+
+
+def test_pc_rans_variants(engine):
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=minmod)
+    checks.check_fd_jacobian(engine, (10, 7, 6), rans, WALL, frozenTurb=True, stretch_k=2.0)       # ANK, decoupled
+    checks.check_fd_jacobian(engine, (10, 7, 6), rans, WALL, useTurbOnly=True, stretch_k=2.0)      # the turbulence KSP of ANK
+    checks.check_fd_jacobian(engine, (8, 7, 6), rans.replace(spaceDiscr=dissScalar), WALL, viscPC=True, stretch_k=2.0)
+    checks.check_fd_jacobian(engine, (10, 7, 6), rans, WALL, blockettes=True, stretch_k=2.0)       # blocketteResCore as the evaluator
+
+
+def test_exact_drdw(engine):
+    """usePC = F: 13 colours (Euler) / 35 colours (viscous), 13- and 33-point stencils"""
+    checks.check_fd_jacobian(engine, (9, 8, 7), FlowParams(spaceDiscr=dissScalar), EULER, usePC=False)
+    checks.check_fd_jacobian(engine, (9, 8, 7), FlowParams(spaceDiscr=upwind, limiter=vanAlbeda), OPEN, usePC=False)
+    checks.check_fd_jacobian(engine, (8, 7, 6), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, vis4=0.1), WALL, usePC=False,
+                             stretch_k=2.0)
+    checks.check_fd_jacobian(engine, (8, 7, 6), FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda), WALL,
+                             usePC=False, stretch_k=2.0)
+
+
+def test_reference_step(engine):
+    """delta = 1e-9 as the reference: rounding differences of two correct residuals are amplified by 1e9, so only ~1e-6 of the
+    largest entry is resolvable by ANY implementation (the reference against itself with another compiler flag included)"""
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda)
+    checks.check_fd_jacobian(engine, (12, 8, 6), rans, WALL, delta=1e-9, tol=1e-5, stretch_k=2.0)

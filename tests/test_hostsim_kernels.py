@@ -329,6 +329,16 @@ def test_block_res_approx(hostsim_engine, sd):
                                   stretch_k=2.0)
 
 
+def test_block_res_approx_blockette_core(hostsim_engine):
+    """the default core (blocketteResCore) evaluates the approximate Roe flux first order (blockette.F90:643)"""
+    checks.check_block_res_approx(hostsim_engine, (9, 7, 5), FlowParams(spaceDiscr=upwind, limiter=vanAlbeda), visc_approx=False,
+                                  blockettes=True)
+    checks.check_block_res_approx(hostsim_engine, (8, 6, 5), FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=minmod),
+                                  blockettes=True, stretch_k=2.0)
+    checks.check_block_res_approx(hostsim_engine, (8, 6, 5), FlowParams(equations=RANSEquations, spaceDiscr=dissScalar, sigma=0.3),
+                                  blockettes=True, stretch_k=2.0)
+
+
 def test_block_res_visc_approx_only(hostsim_engine):
     checks.check_block_res_approx(hostsim_engine, (8, 6, 5), FlowParams(equations=NSEquations, sigma=0.3), diss_approx=False,
                                   visc_approx=True, stretch_k=2.0)
@@ -372,3 +382,29 @@ def test_adversarial_states(hostsim_engine):
     T.vacuum_cases(hostsim_engine)
     T.wall_revert_case(hostsim_engine)
     T.sa_cases(hostsim_engine, (16, 6, 12))
+
+
+_JAC_WALL = {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}
+_JAC_EULER = {1: -6, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_fd_jacobian_pc_euler(hostsim_engine, sd):
+    """preconditioner matrix (usePC): 7 colours, lumped dissipation, frozen sensor"""
+    checks.check_fd_jacobian(hostsim_engine, (7, 6, 5), FlowParams(spaceDiscr=sd, limiter=vanAlbeda), _JAC_EULER)
+
+
+def test_fd_jacobian_pc_rans(hostsim_engine):
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda, orderTurb=secondOrder, acousticScaleFactor=0.5)
+    checks.check_fd_jacobian(hostsim_engine, (6, 5, 4), rans, _JAC_WALL, stretch_k=2.0)
+    checks.check_fd_jacobian(hostsim_engine, (6, 5, 4), rans, _JAC_WALL, frozenTurb=True, stretch_k=2.0)
+    checks.check_fd_jacobian(hostsim_engine, (6, 5, 4), rans, _JAC_WALL, useTurbOnly=True, stretch_k=2.0)
+    checks.check_fd_jacobian(hostsim_engine, (5, 4, 4), rans.replace(spaceDiscr=dissScalar), _JAC_WALL, viscPC=True, stretch_k=2.0)
+
+
+def test_fd_jacobian_exact(hostsim_engine):
+    """dR/dw (usePC = F): 13 colours (Euler) and 35 colours (viscous), the reference's own step 1e-9 at the accuracy it resolves"""
+    checks.check_fd_jacobian(hostsim_engine, (6, 6, 5), FlowParams(spaceDiscr=dissScalar), _JAC_EULER, usePC=False)
+    checks.check_fd_jacobian(hostsim_engine, (5, 4, 4), FlowParams(equations=NSEquations, spaceDiscr=upwind, limiter=vanAlbeda), _JAC_WALL,
+                             usePC=False, stretch_k=2.0)
+    checks.check_fd_jacobian(hostsim_engine, (6, 5, 4), FlowParams(spaceDiscr=upwind, limiter=minmod), _JAC_EULER, delta=1e-9, tol=1e-5)
