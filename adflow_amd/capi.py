@@ -130,7 +130,7 @@ BC_CALLBACK = ctypes.CFUNCTYPE(None, c_int, c_int)
 
 # array identifiers (include/adflow_gpu.h)
 (ARR_W, ARR_P, ARR_GAMMA, ARR_RLV, ARR_REV, ARR_DW, ARR_FW, ARR_DTL, ARR_RADI, ARR_RADJ, ARR_RADK, ARR_AA,
- ARR_NODAL_GRADS, ARR_WN, ARR_PN, ARR_W1, ARR_P1, ARR_WR, ARR_VOL, ARR_SI, ARR_SJ, ARR_SK, ARR_X) = range(1, 24)
+ ARR_NODAL_GRADS, ARR_WN, ARR_PN, ARR_W1, ARR_P1, ARR_WR, ARR_VOL, ARR_SI, ARR_SJ, ARR_SK, ARR_X, ARR_D2WALL) = range(1, 25)
 
 JAC_PC, JAC_FROZEN_TURB, JAC_TURB_ONLY, JAC_VISC_PC = 1, 2, 4, 8     # include/adflow_gpu.h
 RES_UPDATE_INTERMED, RES_FLOW, RES_TURB, RES_CLOSURES, RES_HALO = 1, 2, 4, 8, 16
@@ -150,6 +150,7 @@ EXPORTS = [
     "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
     "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2", "adflow_gpu_xhalo", "adflow_gpu_actuator_register", "adflow_gpu_comm_register_periodic", "adflow_gpu_coarse_coordinates", "adflow_gpu_exchange_coor",
     "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
+    "adflow_gpu_wall_distance_register", "adflow_gpu_update_wall_distances",
     "adflow_gpu_fd_jacobian", "adflow_gpu_jacobian_info", "adflow_gpu_download_jacobian",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
@@ -197,6 +198,8 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_coarse_coordinates.argtypes = [c_int]
     lib.adflow_gpu_exchange_coor.argtypes = [c_int]
     lib.adflow_gpu_reference_shock_sensor.argtypes = [c_int]
+    lib.adflow_gpu_wall_distance_register.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.adflow_gpu_update_wall_distances.argtypes = [c_int, c_void_p, ctypes.c_int64]
     lib.adflow_gpu_fd_jacobian.argtypes = [c_int, c_uint, c_double]
     lib.adflow_gpu_jacobian_info.argtypes = [POINTER(ctypes.c_int32), POINTER(ctypes.c_int32), POINTER(ctypes.c_int32)]
     lib.adflow_gpu_download_jacobian.argtypes = [c_int, c_int, c_int, c_void_p]

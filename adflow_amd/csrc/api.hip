@@ -71,6 +71,9 @@ struct Block {
     double *wref = nullptr, *dwref = nullptr, *jac = nullptr;
     void* jac_raw = nullptr;
     int jac_ncomp = 0;
+    // wall association of updateWallDistancesQuickly: surfNodeIndices (4,nx,ny,nz), uv (2,nx,ny,nz)
+    int* wd_ind = nullptr;
+    double* wd_uv = nullptr;
 };
 
 typedef std::tuple<int, int, int> Key;   // (level, sps, nn): iteration order = level, sps, nn
@@ -634,6 +637,55 @@ int adflow_gpu_update_geometry(int level)
     return sync_and_check();
 }
 
+// flowDoms(nn,level,sps)%surfNodeIndices / %uv of determineWallAssociation (wallDistance.F90:1663-2002), kept on the device
+int adflow_gpu_wall_distance_register(int nn, int level, int sps, const int32_t* surfNodeIndices, const double* uv)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (!surfNodeIndices || !uv) return fail("wall_distance_register: surfNodeIndices / uv is NULL");
+    const size_t n = (size_t)b->v.nx * b->v.ny * b->v.nz;
+    if (!b->wd_ind) {
+        void *pi = nullptr, *pu = nullptr;
+        HIPCHK(hipMalloc(&pi, n * 4 * sizeof(int32_t)));
+        b->allocs.push_back(pi);
+        HIPCHK(hipMalloc(&pu, n * 2 * sizeof(double)));
+        b->allocs.push_back(pu);
+        b->wd_ind = (int*)pi;
+        b->wd_uv = (double*)pu;
+    }
+    HIPCHK(hipMemcpyAsync(b->wd_ind, surfNodeIndices, n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(b->wd_uv, uv, n * 2 * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    return sync_and_check();
+}
+
+static double* g_xsurf = nullptr;
+static size_t g_xsurf_n = 0;
+
+// updateWallDistancesQuickly (wallDistance.F90:36-120) for every block of the level with a registered association
+int adflow_gpu_update_wall_distances(int level, const double* xSurf, int64_t n)
+{
+    if (need_ready()) return 1;
+    if (n < 0 || (n > 0 && !xSurf) || n % 3) return fail("update_wall_distances: xSurf with %lld entries", (long long)n);
+    if ((size_t)n > g_xsurf_n) {
+        if (g_xsurf) (void)hipFree(g_xsurf);
+        g_xsurf = nullptr; g_xsurf_n = 0;
+        HIPCHK(hipMalloc((void**)&g_xsurf, sizeof(double) * (size_t)n));
+        g_xsurf_n = (size_t)n;
+    }
+    if (n > 0) HIPCHK(hipMemcpyAsync(g_xsurf, xSurf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, g_stream));
+    bool any = false;
+    int rc = for_level(level, [&](Block* b) {
+        if (!b->wd_ind) return 0;
+        if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
+        any = true;
+        launch_wall_distance(b->v, b->wd_ind, b->wd_uv, g_xsurf, g_stream);
+        return 0;
+    });
+    if (rc) return rc;
+    if (!any) return fail("update_wall_distances: no block of level %d has a registered wall association", level);
+    return sync_and_check();
+}
+
 int adflow_gpu_upload_state(int nn, int level, int sps)
 {
     Block* b = find_block(nn, level, sps);
@@ -713,6 +765,7 @@ static int array_spec(Block* b, int which, double** dev, int* nc, int lo[3], int
     case ADFLOW_ARR_WR: *dev = v.wr; *nc = 5; owned(); break;
     case ADFLOW_ARR_NODAL_GRADS:
         *dev = v.grad; *nc = 12; lo[0] = lo[1] = lo[2] = 1; n[0] = v.il; n[1] = v.jl; n[2] = v.kl; break;
+    case ADFLOW_ARR_D2WALL: *dev = v.d2wall; owned(); break;
     case ADFLOW_ARR_X: *dev = v.x; *nc = 3; lo[0] = lo[1] = lo[2] = 0; n[0] = v.ie + 1; n[1] = v.je + 1; n[2] = v.ke + 1; break;
     case ADFLOW_ARR_SI: *dev = v.sI; *nc = 3; lo[0] = 0; lo[1] = lo[2] = 1; n[0] = v.ie + 1; n[1] = v.je; n[2] = v.ke; break;
     case ADFLOW_ARR_SJ: *dev = v.sJ; *nc = 3; lo[1] = 0; lo[0] = lo[2] = 1; n[0] = v.ie; n[1] = v.je + 1; n[2] = v.ke; break;

@@ -321,3 +321,4 @@ void launch_bc_coarse_corrections(const BlkView* tab, const BcEntry* ent, const 
 void launch_corner_row_halos_level(const BlkView* tab, int nslots, const KParams& kp, hipStream_t s);
 void launch_volume_metric(const BlkView& b, int rightHanded, hipStream_t s);
 void launch_boundary_normals(const BlkView& b, const BcFaceDev* faces, int nBocos, hipStream_t s);
+void launch_wall_distance(const BlkView& b, const int* ind, const double* uv, const double* xSurf, hipStream_t s);

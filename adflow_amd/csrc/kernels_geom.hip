@@ -277,3 +277,43 @@ void launch_boundary_normals(const BlkView& b, const BcFaceDev* faces, int nBoco
                            const_cast<double*>(faces[m].norm));
     }
 }
+
+// ---- wallDistance::updateWallDistancesQuickly (src/wallDistance/wallDistance.F90:36-120) -------------------------------------
+// d2Wall of the owned cells from the wall association found once on the host (determineWallAssociation, :1663-2002): the four
+// surface nodes of the closest wall quad and the (u, v) of the closest point on it.  After a mesh warp only the surface
+// coordinates xSurf (gathered by the host's VecScatter, updateXSurf :2004-2051) and the cell centre move.
+// ind: (4, nx, ny, nz) 1-based node numbers, 0 in the first = no association (d2Wall = large); uv: (2, nx, ny, nz).
+__global__ __launch_bounds__(GM_BX* GM_BY) void k_wall_distance(BlkView b, const int4* __restrict__ ind, const double2* __restrict__ uv,
+                                                                const double* __restrict__ xSurf)
+{
+    const int i = blockIdx.x * GM_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * GM_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long t = ((long)(k - 2) * b.ny + (j - 2)) * b.nx + (i - 2);
+    const int4 n = ind[t];
+    if (n.x == 0) { b.d2wall[c] = 1.e+37; return; }                        // constants::large
+    const double u = uv[t].x, v = uv[t].y;
+    const double w1 = (1.0 - u) * (1.0 - v), w2 = u * (1.0 - v), w3 = u * v, w4 = (1.0 - u) * v;
+    const double* x1 = xSurf + 3l * (n.x - 1);
+    const double* x2 = xSurf + 3l * (n.y - 1);
+    const double* x3 = xSurf + 3l * (n.z - 1);
+    const double* x4 = xSurf + 3l * (n.w - 1);
+    const long si = 1, sj = b.ldi, sk = b.ldk;
+    double d2 = 0.0;
+    for (int q = 0; q < 3; ++q) {
+        const double* xq = b.x + (long)q * b.nbox;
+        const double xp = w1 * x1[q] + w2 * x2[q] + w3 * x3[q] + w4 * x4[q];
+        const double xc = 0.125 * (xq[c - si - sj - sk] + xq[c - sj - sk] + xq[c - si - sk] + xq[c - sk] + xq[c - si - sj] + xq[c - sj] +
+                                   xq[c - si] + xq[c]);
+        d2 += (xc - xp) * (xc - xp);
+    }
+    b.d2wall[c] = sqrt(d2);
+}
+
+void launch_wall_distance(const BlkView& b, const int* ind, const double* uv, const double* xSurf, hipStream_t s)
+{
+    dim3 g((b.nx + GM_BX - 1) / GM_BX, (b.ny + GM_BY - 1) / GM_BY, b.nz);
+    hipLaunchKernelGGL(k_wall_distance, g, dim3(GM_BX, GM_BY, 1), 0, s, b, (const int4*)ind, (const double2*)uv, xSurf);
+}

@@ -106,6 +106,15 @@ class Engine:
     def referenceShockSensor(self, level=1):
         self._chk(self.lib.adflow_gpu_reference_shock_sensor(level))
 
+    def registerWallAssociation(self, surfNodeIndices: np.ndarray, uv: np.ndarray, nn=1, level=1, sps=1):
+        """flowDoms%surfNodeIndices (4,nx,ny,nz) int32 / %uv (2,nx,ny,nz), Fortran order"""
+        assert surfNodeIndices.dtype == np.int32 and surfNodeIndices.flags["F_CONTIGUOUS"] and uv.flags["F_CONTIGUOUS"]
+        self._chk(self.lib.adflow_gpu_wall_distance_register(nn, level, sps, surfNodeIndices.ctypes.data, uv.ctypes.data))
+
+    def updateWallDistancesQuickly(self, xSurf: np.ndarray, level=1):
+        xSurf = np.ascontiguousarray(xSurf, dtype=np.float64)
+        self._chk(self.lib.adflow_gpu_update_wall_distances(level, xSurf.ctypes.data, xSurf.size))
+
     def setupStateResidualMatrix(self, level=1, usePC=True, frozenTurb=False, useTurbOnly=False, viscPC=False, delta=1e-9):
         """adjointUtils::setupStateResidualMatrix(useAD=F) (adjointUtils.F90:7-715) without the PETSc calls: the coloured
         finite-difference blocks stay on the device; jacobianBlocks() brings one block's over."""

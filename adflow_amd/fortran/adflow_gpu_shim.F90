@@ -229,6 +229,18 @@ module adflowGpuShim
             import :: c_int
             integer(c_int), value :: level
         end function
+        integer(c_int) function adflow_gpu_wall_distance_register(nn, level, sps, surfNodeIndices, uv) &
+            bind(C, name="adflow_gpu_wall_distance_register")
+            import :: c_int, c_ptr
+            integer(c_int), value :: nn, level, sps
+            type(c_ptr), value :: surfNodeIndices, uv
+        end function
+        integer(c_int) function adflow_gpu_update_wall_distances(level, xSurf, n) bind(C, name="adflow_gpu_update_wall_distances")
+            import :: c_int, c_ptr, c_int64_t
+            integer(c_int), value :: level
+            type(c_ptr), value :: xSurf
+            integer(c_int64_t), value :: n
+        end function
         ! adjointUtils::setupStateResidualMatrix (useAD = F): coloured finite-difference blocks on the device
         integer(c_int) function adflow_gpu_fd_jacobian(level, flags, delta) bind(C, name="adflow_gpu_fd_jacobian")
             import :: c_int, c_double
@@ -587,5 +599,24 @@ contains
                                                           c_loc(flowDoms(nn, level, sps)%viscSubface(mm)%q)), "gpuDownloadWallStress")
         end do
     end subroutine gpuDownloadWallStress
+
+    ! flowDoms(nn,level,sps)%surfNodeIndices / %uv (determineWallAssociation, wallDistance.F90:1663-2002) -> device; once after
+    ! computeWallDistance.  gpuUpdateWallDistances replaces the updateWallDistancesQuickly calls of a level (wallDistance.F90:36,
+    ! blockette.F90:207-209) after updateXSurf filled wallDistanceData::xSurf.
+    subroutine gpuRegisterWallAssociation(nn, level, sps)
+        use block, only: flowDoms
+        integer(kind=intType), intent(in) :: nn, level, sps
+        if (.not. associated(flowDoms(nn, level, sps)%surfNodeIndices)) return
+        call gpuCheck(adflow_gpu_wall_distance_register(int(nn, c_int), int(level, c_int), int(sps, c_int), &
+                                                        c_loc(flowDoms(nn, level, sps)%surfNodeIndices), &
+                                                        c_loc(flowDoms(nn, level, sps)%uv)), "gpuRegisterWallAssociation")
+    end subroutine gpuRegisterWallAssociation
+
+    subroutine gpuUpdateWallDistances(level)
+        use wallDistanceData, only: xSurf
+        integer(kind=intType), intent(in) :: level
+        call gpuCheck(adflow_gpu_update_wall_distances(int(level, c_int), c_loc(xSurf), int(size(xSurf), c_int64_t)), &
+                      "gpuUpdateWallDistances")
+    end subroutine gpuUpdateWallDistances
 
 end module adflowGpuShim

@@ -188,7 +188,8 @@ enum {
     ADFLOW_ARR_W = 1, ADFLOW_ARR_P, ADFLOW_ARR_GAMMA, ADFLOW_ARR_RLV, ADFLOW_ARR_REV,
     ADFLOW_ARR_DW, ADFLOW_ARR_FW, ADFLOW_ARR_DTL, ADFLOW_ARR_RADI, ADFLOW_ARR_RADJ, ADFLOW_ARR_RADK,
     ADFLOW_ARR_AA, ADFLOW_ARR_NODAL_GRADS, ADFLOW_ARR_WN, ADFLOW_ARR_PN, ADFLOW_ARR_W1, ADFLOW_ARR_P1,
-    ADFLOW_ARR_WR, ADFLOW_ARR_VOL, ADFLOW_ARR_SI, ADFLOW_ARR_SJ, ADFLOW_ARR_SK, ADFLOW_ARR_X
+    ADFLOW_ARR_WR, ADFLOW_ARR_VOL, ADFLOW_ARR_SI, ADFLOW_ARR_SJ, ADFLOW_ARR_SK, ADFLOW_ARR_X,
+    ADFLOW_ARR_D2WALL                  /* d2Wall(2:il,2:jl,2:kl) */
 };
 
 /* flags of adflow_gpu_block_res: the logical arguments of blockette::blocketteRes
@@ -233,6 +234,14 @@ int adflow_gpu_upload_geometry(int nn, int level, int sps);   /* x,sI,sJ,sK,vol,
  * boundaryNormals (src/adjoint/adjointExtra.F90:5-364), the `useSpatial` branch of blocketteRes (blockette.F90:203-211) */
 int adflow_gpu_upload_coordinates(int nn, int level, int sps);
 int adflow_gpu_update_geometry(int level);
+/* wallDistance::updateWallDistancesQuickly (src/wallDistance/wallDistance.F90:36-120), called by the `useSpatial` branch for RANS
+ * with useApproxWallDistance (blockette.F90:207-209): d2Wall of the owned cells = | cell centre - closest wall point |, the wall
+ * point re-formed from the association the host found once (determineWallAssociation, :1663-2002) and the current surface
+ * coordinates.  register: flowDoms(nn,level,sps)%surfNodeIndices(4,2:il,2:jl,2:kl) (1-based numbers into xSurf, first = 0: no wall
+ * within reach, d2Wall = large) and %uv(2,2:il,2:jl,2:kl).  update: xSurf = the scattered surface-node vector of updateXSurf
+ * (:2004-2051), n = 3 x nodes; runs after adflow_gpu_update_geometry's coordinates are in place */
+int adflow_gpu_wall_distance_register(int nn, int level, int sps, const int32_t* surfNodeIndices, const double* uv);
+int adflow_gpu_update_wall_distances(int level, const double* xSurf, int64_t n);
 /* Halo node coordinates after the owned nodes moved, the two steps that precede volume / metric in the `useSpatial`
  * branch of blocketteRes (blockette.F90:181-187):
  *   adflow_gpu_xhalo          adjointExtra::xhalo_block (adjointExtra.F90:365-599) of every block of the level: linear

@@ -239,6 +239,17 @@ def blockette_res_core(update_intermed=False, flow_res=True, turb_res=True, diss
     _big_stack(load().ref_blockette_res_core, int(update_intermed), int(flow_res), int(turb_res), int(diss_approx), int(visc_approx))
 
 
+def update_wall_distances(ind: np.ndarray, uv: np.ndarray, xSurf: np.ndarray) -> None:
+    """wallDistance::updateWallDistancesQuickly (wallDistance.F90:36-120) on the bound block (flowDoms(1,1,1) must exist:
+    alloc_doms first); writes the bound d2Wall."""
+    import ctypes
+    fn = load().ref_update_wall_distances
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    fn.restype = None
+    assert ind.dtype == np.int32 and ind.flags["F_CONTIGUOUS"] and uv.flags["F_CONTIGUOUS"] and xSurf.flags["C_CONTIGUOUS"]
+    fn(ind.ctypes.data, uv.ctypes.data, xSurf.ctypes.data, xSurf.size)
+
+
 def fd_jacobian(nx, ny, nz, usePC=True, frozenTurb=False, turbOnly=False, viscPC=False, useBlockettes=False, delta=1e-9):
     """adjointUtils::setupStateResidualMatrix(useAD=F) (adjointUtils.F90:7-715) on the bound block, PETSc stores replaced by
     an array: returns blocks (nx, ny, nz, nState, nState, nStencil) [blk(ll, l) per row cell and stencil entry]."""

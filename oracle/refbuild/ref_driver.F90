@@ -828,6 +828,25 @@ contains
     end subroutine ref_block_res_core2
 
 
+    ! wallDistance::updateWallDistancesQuickly (wallDistance.F90:36-120) on the current block.  Module wallDistance itself needs the
+    ! ADT / overset search modules; the reference ships the same routine (primal + reverse) regenerated by Tapenade in
+    ! adjoint/outputReverse/wallDistance_b.f90, which compiles on its own: that primal is called, unchanged.
+    subroutine ref_update_wall_distances(ind, uvp, xs, n) bind(C, name="ref_update_wall_distances")
+        use blockPointers
+        use wallDistanceData, only: xSurf
+        use walldistance_b, only: updateWallDistancesQuickly
+        type(c_ptr), value :: ind, uvp, xs
+        integer(c_int), value :: n
+        integer(kind=intType), dimension(:, :, :, :), pointer :: ip
+        real(kind=realType), dimension(:, :, :, :), pointer :: up
+        call c_f_pointer(ind, ip, [4, nx, ny, nz])
+        call c_f_pointer(uvp, up, [2, nx, ny, nz])
+        flowDoms(1, 1, 1)%surfNodeIndices(1:, 2:, 2:, 2:) => ip
+        flowDoms(1, 1, 1)%uv(1:, 2:, 2:, 2:) => up
+        call c_f_pointer(xs, xSurf, [n])
+        call updateWallDistancesQuickly(1_intType, 1_intType, 1_intType)
+    end subroutine ref_update_wall_distances
+
     ! adjointUtils::setupStateResidualMatrix with useAD = F (adjointUtils.F90:7-715) on the CURRENT block, the PETSc calls replaced
     ! by stores into jac(nx, ny, nz, nState, nState, nStencil) [blk(ll, l) of stencil entry s at the row cell].  Module adjointUtils
     ! and masterRoutines cannot be compiled here (PETSc matrices, the AD routines), so the loop nest is restated around the

@@ -520,6 +520,42 @@ def check_update_geometry(engine, dims, prm, spec, seed=81, **mk):
     assert_state(engine, {1: blk}, {1: r}, prm, "BCs with the recomputed boundary normals")
 
 
+def check_wall_distance(engine, dims, prm, seed=83, **mk):
+    """wallDistance::updateWallDistancesQuickly (wallDistance.F90:36-120) after a mesh warp: d2Wall of the owned cells from the
+    wall association (four surface nodes + (u, v) per cell, cells without a wall in reach = large) and the moved surface nodes."""
+    from oracle import ref
+    new_level(engine)
+    prm = prm.replace(currentLevel=1, groundLevel=1)
+    blk = make_block(*dims, prm, seed=seed, **mk)
+    engine.set_options(prm)
+    engine.register(blk, nn=1, level=1)
+    rng = np.random.default_rng(seed)
+    nsurf = 57
+    ind = np.asfortranarray(rng.integers(1, nsurf + 1, size=(4, blk.nx, blk.ny, blk.nz), dtype=np.int32))
+    ind[0][rng.uniform(size=ind.shape[1:]) < 0.1] = 0                       # too far away: no association
+    uv = np.asfortranarray(rng.uniform(0.0, 1.0, size=(2, blk.nx, blk.ny, blk.nz)))
+    uv[:, 0, 0, 0] = (0.0, 1.0)
+    engine.registerWallAssociation(ind, uv)
+    # warp the mesh and the surface, then update
+    h = 1.0 / max(dims)
+    blk["x"] += 0.05 * h * rng.uniform(-1, 1, blk["x"].shape)
+    xSurf = rng.uniform(-0.2, 1.2, size=3 * nsurf)
+    r = blk.copy()
+    ref.alloc_doms(1, 1)
+    ref.bind_block(r, prm)
+    r["d2Wall"][...] = -1.0
+    ref.update_wall_distances(ind, uv, xSurf)
+    engine.upload_coordinates(1, 1)
+    engine.updateWallDistancesQuickly(xSurf, 1)
+    out = np.zeros_like(r["d2Wall"])
+    engine.download_array(capi.ARR_D2WALL, out, 1, 1)
+    assert (r["d2Wall"] >= 1e37).sum() == (ind[0] == 0).sum() > 0
+    assert np.array_equal(out >= 1e37, r["d2Wall"] >= 1e37)
+    far = r["d2Wall"] >= 1e37
+    assert rel_err(np.where(far, 0.0, out), np.where(far, 0.0, r["d2Wall"])) <= TOL
+    assert r["d2Wall"].min() > 0.0
+
+
 def check_smoother_with_bc(engine, dims, prm, spec, seed=61, nsweeps=2, **mk):
     """RungeKuttaSmoother / DADISmoother on ONE block whose six faces are physical boundaries: the device
     applies applyAllBC between update and halo exchange (smoothers.F90:369,680) exactly where the reference does."""

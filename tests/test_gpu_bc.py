@@ -109,6 +109,12 @@ def test_update_geometry_after_mesh_warp(engine, dims):
                                  stretch_k=2.0)
 
 
+@pytest.mark.parametrize("dims", [(70, 9, 11), (16, 8, 1)])
+def test_update_wall_distances_quickly(engine, dims):
+    """the RANS part of the `useSpatial` branch (blockette.F90:207-209): d2Wall from the stored wall association"""
+    checks.check_wall_distance(engine, dims, FlowParams(equations=RANSEquations), stretch_k=2.0)
+
+
 def test_apply_all_bc_split_faces(engine):
     """block faces cut into two subfaces of different kinds (wall + farfield, symmetry + Euler wall)"""
     checks.check_apply_bc(engine, (40, 9, 6), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}, split={3: -6, 6: -5, 1: -6})

@@ -408,3 +408,7 @@ def test_fd_jacobian_exact(hostsim_engine):
     checks.check_fd_jacobian(hostsim_engine, (5, 4, 4), FlowParams(equations=NSEquations, spaceDiscr=upwind, limiter=vanAlbeda), _JAC_WALL,
                              usePC=False, stretch_k=2.0)
     checks.check_fd_jacobian(hostsim_engine, (6, 5, 4), FlowParams(spaceDiscr=upwind, limiter=minmod), _JAC_EULER, delta=1e-9, tol=1e-5)
+
+
+def test_update_wall_distances_quickly(hostsim_engine):
+    checks.check_wall_distance(hostsim_engine, (7, 5, 4), FlowParams(equations=RANSEquations), stretch_k=2.0)
