@@ -886,8 +886,10 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     if (level_tab(level, &t)) return 1;
     // the nodal-gradient march reads only the state and the metrics: forked onto its own queue BEFORE the inviscid kernel is
     // enqueued, joined in front of the face-flux kernel
+    const bool viscWs = g_visc_ws && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2 && g_march_by == 4 &&
+                        !withSA;
     const bool viscMarch = kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2 && g_march_by == 4 &&
-                           !(g_viscous_fused >= 2 || (g_viscous_fused == 1 && !needGrad));
+                           !(g_viscous_fused >= 2 || (g_viscous_fused == 1 && !needGrad)) && !viscWs;
     bool gradForked = false, mixed = false;
     if (viscMarch && !withSA && g_phase_base <= 0 && inviscid_march_enabled() && kp.spaceDiscr == ADFLOW_UPWIND && !anyMoving) {
         // Roe inviscid march and nodal-gradient march as ONE launch of interleaved workgroups
@@ -927,7 +929,12 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         return 0;
     });
     if (rc) return rc;
-    if (batched && viscous_is_tiled() >= 2 && (g_viscous_fused >= 2 || (g_viscous_fused == 1 && !needGrad))) {
+    if (batched && viscWs) {
+        // wave-specialised fused kernel over the level's tile table: gradient waves and face waves in one workgroup
+        phase_mark(5);
+        if (ensure_tiles(level)) return 1;
+        launch_visc_ws(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, needGrad, g_stream);
+    } else if (batched && viscous_is_tiled() >= 2 && (g_viscous_fused >= 2 || (g_viscous_fused == 1 && !needGrad))) {
         // nodal gradients and face fluxes in one kernel: the gradients stay in LDS
         launch_visc_fused_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     } else if (batched && viscous_is_tiled() >= 2 && g_march_by == 4) {
@@ -2606,6 +2613,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_grad_mix")) { g_roe_grad_mix = value; return 0; }
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }
     if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
+    if (!strcmp(key, "visc_ws")) { g_visc_ws = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {
         if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");

@@ -124,6 +124,13 @@ __device__ __forceinline__ double fast_exp_neg(double x)
 }
 #endif
 
+// a value that is the same in every lane of the wavefront, moved to a scalar register so that branches on it are scalar branches
+#ifdef HOSTSIM
+__device__ __forceinline__ int wave_uniform(int v) { return v; }
+#else
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
 // value of the neighbouring lane of the 64-wide wavefront: lane_up1 = lane-1
 // (__shfl_up by 1), lane_dn1 = lane+1.  On gfx950 these are single DPP moves
 // (v_mov_b32_dpp wave_shr:1 / wave_shl:1) per 32-bit half instead of a
@@ -265,6 +272,8 @@ void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny,
 bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void launch_visc_ws(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s);
+extern int g_visc_ws;
 void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void adf_phase_mark(int i);    // api.hip: optional HIP event between the phases of blocketteRes

@@ -249,29 +249,49 @@ struct NgPtrs {
     unsigned sj;        // byte stride of one row
 };
 
-// record of the cell at byte offset c; sKp: sK of the plane below (in), of this plane (out)
-__device__ __forceinline__ void ng_record(const NgPtrs& m, unsigned c, double gam, double sKp[3], NgRec& R)
+// raw values of the cell at byte offset c (the loads of ng_record, issued early by the wave-specialised kernel)
+struct NgRaw { double rho, u, v, w, p, sI[3], sJm[3], sJ[3], sK[3], vol; };
+
+__device__ __forceinline__ void ng_load(const NgPtrs& m, unsigned c, NgRaw& q)
 {
-    const double rho = ldg(m.w0, c);
-    R.phi[0] = ldg(m.w1, c); R.phi[1] = ldg(m.w2, c); R.phi[2] = ldg(m.w3, c);
-    R.phi[3] = -(gam * ldg(m.p, c)) * rcp_nr(rho);              // minus the speed of sound squared (heat flux sign)
+    q.rho = ldg(m.w0, c); q.u = ldg(m.w1, c); q.v = ldg(m.w2, c); q.w = ldg(m.w3, c); q.p = ldg(m.p, c);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        q.sI[d] = ldg(m.sI, c + d * m.nb8);
+        q.sJm[d] = ldg(m.sJ, c - m.sj + d * m.nb8);
+        q.sJ[d] = ldg(m.sJ, c + d * m.nb8);
+        q.sK[d] = ldg(m.sK, c + d * m.nb8);
+    }
+    q.vol = ldg(m.vol, c);
+}
+
+// record from the raw values; sKp: sK of the plane below (in), of this plane (out)
+__device__ __forceinline__ void ng_finish(const NgRaw& q, double gam, double sKp[3], NgRec& R)
+{
+    R.phi[0] = q.u; R.phi[1] = q.v; R.phi[2] = q.w;
+    R.phi[3] = -(gam * q.p) * rcp_nr(q.rho);              // minus the speed of sound squared (heat flux sign)
     double tJ[3], tK[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const double si = ldg(m.sI, c + d * m.nb8);
-        R.tI[d] = lane_up1(si) + si;
-        tJ[d] = ldg(m.sJ, c - m.sj + d * m.nb8) + ldg(m.sJ, c + d * m.nb8);
-        const double sk = ldg(m.sK, c + d * m.nb8);
-        tK[d] = sKp[d] + sk;
-        sKp[d] = sk;
+        R.tI[d] = lane_up1(q.sI[d]) + q.sI[d];
+        tJ[d] = q.sJm[d] + q.sJ[d];
+        tK[d] = sKp[d] + q.sK[d];
+        sKp[d] = q.sK[d];
     }
-    const double vol = ldg(m.vol, c);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         R.sTJ[d] = tJ[d] + lane_dn1(tJ[d]);
         R.sTK[d] = tK[d] + lane_dn1(tK[d]);
     }
-    R.sV = vol + lane_dn1(vol);
+    R.sV = q.vol + lane_dn1(q.vol);
+}
+
+// record of the cell at byte offset c; sKp: sK of the plane below (in), of this plane (out)
+__device__ __forceinline__ void ng_record(const NgPtrs& m, unsigned c, double gam, double sKp[3], NgRec& R)
+{
+    NgRaw q;
+    ng_load(m, c, q);
+    ng_finish(q, gam, sKp, R);
 }
 
 __device__ __forceinline__ void ng_publish(double* __restrict__ x, int lane, const NgRec& R)
@@ -1643,6 +1663,317 @@ __global__ __launch_bounds__(64 * VF_ROWS, 2) void k_visc_fused(const BlkView* _
         }
         q0 = q1;
         c += sk; cx += sk;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// WAVE-SPECIALISED nodal gradients + viscous fluxes (tuning "visc_ws").  k_visc_fused above keeps the carried sums of the gradient
+// phase AND the state of the face phase live in every thread and spills.  Here the two phases run in DIFFERENT waves of one
+// workgroup of 8 waves (64 lanes x 8), each with its own register set:
+//   waves 0..3  "face" waves: the body of k_visc_march for the cell rows j_t .. j_t+3 of a tile of the level's tile table; the
+//               gradients of the face nodes come from a 3-plane LDS ring instead of HBM.
+//   waves 4..7  "gradient" waves: the algebra of k_node_grad_march for the five node rows j_t-1 .. j_t+3, SPLIT BY VARIABLE
+//               (wave 4+v forms d(u, v, w, -a^2)[v]/dx_d of all five rows: five rows do not divide over four waves, four
+//               variables do).  The cell records (ng_record) of the six cell rows j_t-1 .. j_t+4 are made once per plane
+//               (waves 4, 5: two rows each, waves 6, 7: one) and shared through LDS; the geometric sums are re-formed by
+//               every gradient wave (additions only).
+// Step n of the march: [A] the records of cell plane n+1 and the face waves' own states go to LDS | barrier | [B] the gradient
+// waves form node plane n (carried sums of cell plane n + the new records) into ring slot n mod 3 while the face waves
+// evaluate cell plane n-1 from node planes n-2 and n-1 | barrier.  The branch between the two roles is a scalar branch on the
+// wave number with the whole march loop inside each arm, so the register allocation is the maximum of the two bodies, not the
+// sum; both arms execute the same number of barriers.  HBM traffic: state, metrics and dw only -- no gradient round trip
+// (2 x 96 B per node) and the state / normals both phases read are fetched by one workgroup at nearly the same time.
+// LDS: ring 3 x 5 x 12 x 512 B + records (4 + 2 x 2) x 14 x 512 B + states 4 x 6 x 512 B = 161,792 B: one workgroup per CU.
+// STG: the gradients are also stored in the block array (wall stress / updateIntermed callers).
+// ---------------------------------------------------------------------------
+#define WS_NR 5                         // node rows of a tile
+#define WS_RR 6                         // cell rows with a record
+#define WS_PLANE (WS_NR * VM_G)         // doubles of one node plane in the ring
+
+template <bool QCR, bool STG>
+__global__ __launch_bounds__(64 * 8, 1) void k_visc_ws(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp, int kch)
+{
+    __shared__ double gx[3 * WS_PLANE];               // [slot][node row 0..4 = rows j_t-1 .. j_t+3][component][lane]
+    __shared__ double rec[4 * NG_SLOT];               // records of the cell rows j_t-1 .. j_t+2: [row][value][lane], single-buffered
+    __shared__ double recX[2 * 2 * NG_SLOT];          // records of the cell rows j_t+3, j_t+4: [parity of the cell plane][row][value][lane]
+    __shared__ double qx[VM_BY * 6 * 64];             // state of the own cell of every face wave
+    const int4 t = tiles[blockIdx.x];
+    if (t.x < 0) return;
+    const BlkView& b = tab[t.x];
+    const int lane = threadIdx.x;
+    const int wave = wave_uniform((int)threadIdx.y);
+    const int i = t.y * VM_OUT + lane;          // columns i0-2 .. i0+61
+    const int jt = 2 + t.z * VM_BY;
+    const int k0 = 2 + t.w * kch;
+    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
+    const int ic = (i < b.ib) ? i : b.ib;
+    const long nb = b.nbox;
+    const unsigned nb8 = 8u * (unsigned)nb, sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
+    const double gam = kp.gammaConstant;
+    if (wave >= VM_BY) {
+        // ======================================================== gradient waves
+        const int var = wave - VM_BY;                                 // 0..3: u, v, w, -a^2
+        NgPtrs m;
+        m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
+        m.p = (GPTR(const double))b.p;
+        m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
+        m.vol = (GPTR(const double))b.vol;
+        m.nb8 = nb8; m.sj = sj;
+        GPTR(double) grad = (GPTR(double))b.grad;
+        // record rows: every gradient wave makes the record of the cell row j_t-1+var in phase A of a step from loads issued one
+        // phase earlier (rawA); waves 0 and 1 also make the records of the rows j_t+3, j_t+4 for the NEXT step at the end of
+        // phase B -- behind their gradient work, while the face waves are still busy -- into a double-buffered slot
+        const int rA = var;
+        const bool two = (var < 2);
+        const int jA = (jt - 1 + rA < b.jb) ? jt - 1 + rA : b.jb;
+        const int jB = (jt + 3 + var < b.jb) ? jt + 3 + var : b.jb;
+        unsigned cA = 8u * (unsigned)(ic + jA * b.ldi + (k0 - 1) * b.ldk);
+        unsigned cB = 8u * (unsigned)(ic + jB * b.ldi + (k0 - 1) * b.ldk);
+        double sKpA[3], sKpB[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sKpA[d] = ldg(m.sK, cA - sk + d * nb8); sKpB[d] = two ? ldg(m.sK, cB - sk + d * nb8) : 0.0; }
+        if (two) {
+            NgRec R;
+            ng_record(m, cB, gam, sKpB, R);                                   // cell plane k0-1
+            ng_publish(recX + (((k0 - 1) & 1) * 2 + var) * NG_SLOT, lane, R);
+        }
+        // carried sums of the previous cell plane: per node row Pt, RIt, V, Pp, RIp; per cell row Q0t, Q0p
+        double SPt[WS_NR][3], SRIt[WS_NR][3], SV[WS_NR], SPp[WS_NR], SRIp[WS_NR], SQt[WS_RR][3], SQp[WS_RR];
+        // store window of the gradients in the block array: every node once over the tiles of the level
+        const bool stLane = STG && lane >= ((t.y == 0) ? 1 : 2) && lane <= 61 && i <= b.il;
+        NgRaw rawA;                        // the loads of the NEXT step's record, issued one phase early
+        ng_load(m, cA, rawA);
+        for (int n = k0 - 2; n <= k1 + 1; ++n) {
+            // n = k0-2: prologue (records and sums of cell plane k0-1, no node plane)
+            const bool prod = (n <= k1) && kp.storeIntermed != 1;
+            if (prod) {
+                NgRec R;
+                ng_finish(rawA, gam, sKpA, R);
+                ng_publish(rec + rA * NG_SLOT, lane, R);
+            }
+            __syncthreads();
+            if (prod) {
+                if (n < k1) {                // cell plane n+2 for the record of step n+1: in flight during the gradient phase
+                    cA += sk;
+                    ng_load(m, cA, rawA);
+                }
+                double* __restrict__ xo = gx + ((n - (k0 - 2)) % 3) * WS_PLANE;
+                double tIp[3], sTKp[3], sTJp[3], sVp = 0.0, php = 0.0;       // the record of the cell row below
+#pragma unroll
+                for (int cr = 0; cr < WS_RR; ++cr) {
+                    const double* __restrict__ x = ((cr < 4) ? rec + cr * NG_SLOT : recX + (((n + 1) & 1) * 2 + (cr - 4)) * NG_SLOT) + lane;
+                    double tI[3], sTK[3], sTJ[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { tI[d] = x[d * 64]; sTK[d] = x[(7 + d) * 64]; sTJ[d] = x[(11 + d) * 64]; }
+                    const double ph = x[(3 + var) * 64];
+                    const double sV = x[10 * 64];
+                    const double q0p = ph + lane_dn1(ph);
+                    if (cr > 0) {
+                        const int r = cr - 1;                        // node row r: own cell row r (below), cell row r+1 = cr (above)
+                        double NPt[3], NRIt[3];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) { NPt[d] = sTKp[d] + sTK[d]; NRIt[d] = tIp[d] + tI[d]; }
+                        const double q0pm = php + lane_dn1(php);
+                        const double NPp = q0pm + q0p, NRIp = php + ph, NV = sVp + sV;
+                        if (n >= k0 - 1) {
+                            double g[3] = {0.0, 0.0, 0.0};
+                            double a = -0.25 * SPp[r];
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) g[d] += a * SPt[r][d];
+                            a = 0.25 * NPp;
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) g[d] += a * NPt[d];
+                            a = -0.25 * (SQp[r] + q0pm);
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) g[d] += a * (SQt[r][d] + sTJp[d]);
+                            a = 0.25 * (SQp[cr] + q0p);
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) g[d] += a * (SQt[cr][d] + sTJ[d]);
+                            const double phi = SRIp[r] + NRIp;
+                            double ti[3];
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) ti[d] = SRIt[r][d] + NRIt[d];
+                            a = -0.25 * phi;
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) g[d] += a * ti[d];
+                            a = 0.25 * lane_dn1(phi);
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) g[d] += a * lane_dn1(ti[d]);
+                            const double oneOverV = rcp_nr(SV[r] + NV);
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                const double gv = g[d] * oneOverV;
+                                xo[r * VM_G + (3 * var + d) * 64 + lane] = gv;
+                                if (STG) {
+                                    const int jn = jt - 1 + r;
+                                    if (stLane && jn <= b.jl && (r > 0 || t.z == 0) && (n >= k0 || t.w == 0))
+                                        stg(grad + (3 * var + d) * nb, 8u * (unsigned)(ic + jn * b.ldi + n * b.ldk), gv);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) { SPt[r][d] = NPt[d]; SRIt[r][d] = NRIt[d]; }
+                        SV[r] = NV; SPp[r] = NPp; SRIp[r] = NRIp;
+                    }
+                    // the sums of the row below were consumed above: now they can take the new plane
+                    if (cr > 0) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) SQt[cr - 1][d] = sTJp[d];
+                        SQp[cr - 1] = php + lane_dn1(php);
+                    }
+                    if (cr == WS_RR - 1) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) SQt[cr][d] = sTJ[d];
+                        SQp[cr] = q0p;
+                    }
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { tIp[d] = tI[d]; sTKp[d] = sTK[d]; sTJp[d] = sTJ[d]; }
+                    sVp = sV; php = ph;
+                }
+                if (two && n < k1) {
+                    NgRec R;
+                    cB += sk;
+                    ng_record(m, cB, gam, sKpB, R);                           // cell plane n+2
+                    ng_publish(recX + ((n & 1) * 2 + var) * NG_SLOT, lane, R);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ============================================================ face waves
+    const int row = wave;
+    const int j = jt + row;
+    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
+    const int jc = (j < b.je) ? j : b.je;
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
+    VmPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
+    m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.rev = (GPTR(const double))b.rev;
+    GPTR(const double) sI = (GPTR(const double))b.sI; GPTR(const double) sJ = (GPTR(const double))b.sJ;
+    GPTR(const double) sK = (GPTR(const double))b.sK;
+    GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
+    GPTR(const double) dK = (GPTR(const double))b.dK;
+    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
+    GPTR(double) dw = (GPTR(double))b.dw;
+    GPTR(double) fw = (GPTR(double))b.fw;
+    VmK K;
+    K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
+    K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
+    VmCell q0 = vm_ld(m, c, gam, K.eddy);
+    double fk[4] = {0.0, 0.0, 0.0, 0.0};
+    const int oM = row * VM_G + lane, o0 = (row + 1) * VM_G + lane;       // node rows j-1 and j
+    for (int n = k0 - 2; n <= k1 + 1; ++n) {
+        const int k = n - 1;                      // the cell plane evaluated in this step
+        const bool act = (k >= k0) && kp.storeIntermed != 2;
+        VmCell qp1 = q0;
+        if (act) {
+            double* __restrict__ qo = qx + row * (6 * 64) + lane;
+            qo[0] = q0.u; qo[64] = q0.v; qo[128] = q0.w; qo[192] = q0.na; qo[256] = q0.rlv; qo[320] = q0.rev;
+            qp1 = vm_ld(m, c + sk, gam, K.eddy);
+        }
+        __syncthreads();
+        if (act) {
+            const double* __restrict__ xb = gx + ((k - (k0 - 2)) % 3) * WS_PLANE;          // node plane k
+            const double* __restrict__ xp = gx + ((k - 1 - (k0 - 2)) % 3) * WS_PLANE;      // node plane k-1
+            const int flag0 = flags[c >> 3];
+            if (k == k0) {
+                // k face below the first plane of the march: nodes (i-1..i, j-1..j, k0-1)
+                double gs[12], nK[3], dKv[3];
+                const VmCell qm1 = vm_ld(m, c - sk, gam, K.eddy);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xp[oM + q * 64]; gs[q] = s + lane_up1(s); }
+                vm_ld3(sK, c - sk, nb8, nK); vm_ld3(dK, c - sk, nb8, dKv);
+                vm_face<QCR>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), fk);
+            }
+            double acc[4];
+            auto row_state = [&](int r) {
+                const double* __restrict__ qi = qx + r * (6 * 64) + lane;
+                VmCell q;
+                q.u = qi[0]; q.v = qi[64]; q.w = qi[128]; q.na = qi[192]; q.rlv = qi[256]; q.rev = qi[320];
+                return q;
+            };
+            // ---- j face (j-1 | j): nodes (i-1..i, j-1, k-1..k)
+            {
+                double gs[12], nJ[3], dJv[3], f[4];
+                const VmCell qjm = (row > 0) ? row_state(row - 1) : vm_ld(m, c - sj, gam, K.eddy);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
+                vm_ld3(sJ, c - sj, nb8, nJ); vm_ld3(dJ, c - sj, nb8, dJv);
+                vm_face<QCR>(K, gs, qjm, q0, nJ, dJv, flg_porJ(flags[(c - sj) >> 3]), f);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) acc[l] = fk[l] + f[l];
+            }
+            // ---- i face (i | i+1): nodes (i, j-1..j, k-1..k) of the own column; the face (i-1 | i) comes from lane-1
+            {
+                double gs[12], nI[3], dIv[3], f[4];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) gs[q] = (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
+                vm_ld3(sI, c, nb8, nI); vm_ld3(dI, c, nb8, dIv);
+                const VmCell qR = vm_dn1(q0);
+                vm_face<QCR>(K, gs, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
+            }
+            // ---- j face (j | j+1): nodes (i-1..i, j, k-1..k)
+            {
+                double gs[12], nJ[3], dJv[3], f[4];
+                const VmCell qjp = (row < VM_BY - 1) ? row_state(row + 1) : vm_ld(m, c + sj, gam, K.eddy);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
+                vm_ld3(sJ, c, nb8, nJ); vm_ld3(dJ, c, nb8, dJv);
+                vm_face<QCR>(K, gs, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), f);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) acc[l] -= f[l];
+            }
+            // ---- k face above the cell: nodes (i-1..i, j-1..j, k)
+            {
+                double gs[12], nK[3], dKv[3], f[4];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { const double s = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
+                vm_ld3(sK, c, nb8, nK); vm_ld3(dK, c, nb8, dKv);
+                vm_face<QCR>(K, gs, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), f);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) { acc[l] -= f[l]; fk[l] = f[l]; }
+            }
+            if (out) {
+                const double blank = flg_blank((uint8_t)flag0);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    const unsigned o = c + (l + 1) * nb8;
+                    double fwn = acc[l];
+                    if (kp.fwMode) {
+                        fwn += ldg(fw, o);
+                        stg(fw, o, fwn);
+                    }
+                    stg(dw, o, (ldg(dw, o) + fwn) * blank);
+                }
+                if (kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
+            }
+            q0 = qp1;
+            c += sk;
+        }
+        __syncthreads();
+    }
+}
+
+int g_visc_ws = 0;          // tuning "visc_ws": wave-specialised fused gradients + viscous fluxes
+
+void launch_visc_ws(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp0, bool storeGrad, hipStream_t s)
+{
+    if (ntiles <= 0) return;
+    KParams kp = kp0;
+    kp.storeIntermed = (g_visc_ws >= 2) ? g_visc_ws - 1 : 0;      // timing experiments: 2 = gradient waves idle, 3 = face waves idle
+    const dim3 blk(64, 8, 1), grd(ntiles);
+#ifdef HOSTSIM
+    if (getenv("ADF_TRACE_WS")) fprintf(stderr, "launch_visc_ws store=%d ntiles=%d\n", (int)storeGrad, ntiles);
+#endif
+    if (kp.useQCR) {
+        if (storeGrad) hipLaunchKernelGGL((k_visc_ws<true, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+        else hipLaunchKernelGGL((k_visc_ws<true, false>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+    } else {
+        if (storeGrad) hipLaunchKernelGGL((k_visc_ws<false, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+        else hipLaunchKernelGGL((k_visc_ws<false, false>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
     }
 }
 

@@ -106,6 +106,23 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("roe_march", 1)
 
 
+def test_visc_wave_specialised(engine):
+    """tuning visc_ws: nodal gradients (gradient waves) and viscous fluxes (face waves) in one workgroup, the gradients stay in an
+    LDS ring.  Partial tiles in i / j / the k chunk, blanked cells, QCR, laminar NS, the stored-gradient variant (wall stress)."""
+    try:
+        engine.set_tuning("visc_ws", 1)
+        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
+        checks.check_block_res(engine, (63, 6, 35), prm, seed=5, stretch_k=2.0, holes=0.05)
+        checks.check_block_res(engine, (61, 9, 33), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
+        checks.check_block_res(engine, (7, 5, 3), FlowParams(equations=NSEquations), seed=7, stretch_k=2.0)
+        checks.check_block_res(engine, (124, 13, 5), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix), seed=8, stretch_k=2.0)
+        checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations), stretch_k=2.0)
+        checks.check_wall_stress(engine, (9, 8, 7), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -3, 4: -4, 5: -3, 6: -6},
+                                 stretch_k=2.0)
+    finally:
+        engine.set_tuning("visc_ws", 0)
+
+
 def test_block_res_without_intermediates(engine):
     """default flags of blocketteRes (updateIntermed = F): dw only; the spectral radii are not an output"""
     from oracle import ref
