@@ -26,6 +26,8 @@ hipStream_t g_stream = nullptr;
 // FP64 issue while they are bound by HBM): launched on their own queues they share the CUs with it (tuning "overlap")
 hipStream_t g_streamB = nullptr, g_streamC = nullptr;
 hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr;
+hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
+hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
 adflow_opts g_opts;
 bool g_have_opts = false;
@@ -353,6 +355,8 @@ int adflow_gpu_init(int device_ordinal)
         HIPCHK(hipStreamCreateWithFlags(&g_streamB, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&g_streamC, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&g_evFork)); HIPCHK(hipEventCreate(&g_evB)); HIPCHK(hipEventCreate(&g_evC));
+        HIPCHK(hipStreamCreateWithFlags(&g_streamX, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&g_evPack, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&g_evComm, hipEventDisableTiming));
     }
     if (!g_events_ready) {
         for (int i = 0; i < 64; ++i) HIPCHK(hipEventCreate(&g_events[i]));
@@ -818,10 +822,12 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
     KParams kp = make_kparams(level, 1.0, 0);
     int rc = for_level(level, [&](Block* b) {
         if (varStart < 1 || varEnd > b->v.nw) return fail("initres: variable range %d..%d outside 1..%d", varStart, varEnd, b->v.nw);
-        launch_initres(b->v, kp, varStart - 1, varEnd - 1, g_stream);
         return 0;
     });
     if (rc) return rc;
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_initres_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, varStart - 1, varEnd - 1, g_stream);
     return sync_and_check();
 }
 
@@ -872,15 +878,28 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     }
     if (kp.spaceDiscr != ADFLOW_DISS_SCALAR && kp.spaceDiscr != ADFLOW_DISS_MATRIX && kp.spaceDiscr != ADFLOW_UPWIND)
         return fail("spaceDiscr=%d not supported (1 scalar, 2 matrix, 9 upwind)", kp.spaceDiscr);
+    const bool wantSensor = kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && fabs(kp.rFil) >= 1.e-10 && !kp.dissApprox;
+    int nStale = 0, nBlk = 0;
     int rc = for_level(level, [&](Block* b) {
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
-        if (kp.viscous && kp.spaceDiscr == ADFLOW_DISS_SCALAR && !b->ss_valid && fabs(kp.rFil) >= 1.e-10 && !kp.dissApprox) {
-            launch_entropy(b->v, g_stream);
-            b->ss_valid = true;
-        }
+        ++nBlk;
+        if (wantSensor && !b->ss_valid) ++nStale;
         return 0;
     });
     if (rc) return rc;
+    if (nStale > 0) {
+        // entropy sensor of the blocks whose state changed: one launch when that is every block of the level (the usual case)
+        if (nStale == nBlk) {
+            LevelTab ts;
+            if (level_tab(level, &ts)) return 1;
+            launch_entropy_level(ts.tab, ts.n, ts.nx, ts.ny, ts.nz, g_stream);
+        }
+        for_level(level, [&](Block* b) {
+            if (nStale != nBlk && !b->ss_valid) launch_entropy(b->v, g_stream);
+            b->ss_valid = true;
+            return 0;
+        });
+    }
     // inviscid part: one launch for every block of the level (blocks are independent given their halos)
     LevelTab t;
     if (level_tab(level, &t)) return 1;
@@ -994,8 +1013,10 @@ static int block_res_enqueue(int level, unsigned flags)
     int rc = 0;
     if (flags & ADFLOW_RES_CLOSURES) {
         // computePressureSimple / computeLamViscosity / computeEddyViscosity (blockette.F90:199-203)
+        LevelTab tc;
+        if (level_tab(level, &tc)) return 1;
+        launch_closures_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream);
         rc = for_level(level, [&](Block* b) {
-            launch_closures(b->v, kp, g_stream);
             b->ss_valid = false;
             b->etot_consistent = false;
             return 0;
@@ -1344,6 +1365,11 @@ int ensure_table(int level)
     memset(h.data(), 0, sizeof(BlkView) * h.size());
     for (auto& kv : g_blocks)
         if (std::get<0>(kv.first) == level && std::get<1>(kv.first) == 1) h[std::get<2>(kv.first)] = kv.second->v;
+    long off = 0;                     // PETSc vector order: block nn ascending (NKSolvers.F90:1240-1253)
+    for (auto& v : h) {
+        v.vecOff = off;
+        off += (long)v.nx * v.ny * v.nz * v.nw;
+    }
     BlkView* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, sizeof(BlkView) * h.size()));
     HIPCHK(hipMemcpy(d, h.data(), sizeof(BlkView) * h.size(), hipMemcpyHostToDevice));
@@ -2044,11 +2070,22 @@ static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPr
     // whalo2 closes by recomputing the total energy of the owned cells from p when
     // both travelled (haloExchange.F90:178-196)
     const bool bothPAndE = commPressure && varStart <= 5 && varEnd >= 5;
+    int nTodo = 0, nBlk = 0;
+    for_level(level, [&](Block* b) {
+        ++nBlk;
+        if (nLayers == 2 && bothPAndE && !b->etot_consistent) ++nTodo;
+        return 0;
+    });
+    if (nTodo > 0 && nTodo == nBlk) {
+        LevelTab t;
+        if (level_tab(level, &t)) return 1;
+        launch_etot_owned_level(t.tab, t.n, t.nx, t.ny, t.nz, g_opts.gammaConstant, g_stream);
+    }
     for_level(level, [&](Block* b) {
         // the exchange never touches owned cells: when their rhoE was produced by
         // computeEtotBlock already (stage update, or a previous whalo2) the pass is an identity
         if (nLayers == 2 && bothPAndE && !b->etot_consistent) {
-            launch_etot_owned(b->v, g_opts.gammaConstant, g_stream);
+            if (nTodo != nBlk) launch_etot_owned(b->v, g_opts.gammaConstant, g_stream);
             b->etot_consistent = true;
         }
         b->ss_valid = false;
@@ -2057,26 +2094,38 @@ static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPr
     return 0;
 }
 
-// pack -> grouped RCCL send/recv -> same-GPU copies -> unpack of the variables in `mask` over one pattern
+// pack -> grouped RCCL send/recv (own queue) || same-GPU copies -> unpack of the variables in `mask` over one pattern
 static int comm_exchange_enqueue(CommPattern* cp, BlkView* tab, unsigned mask, int nvar)
 {
-    // pack every outgoing message, then one grouped RCCL send/recv over xGMI,
-    // with the same-GPU copies enqueued behind the packs (they only read owned cells)
+    // pack every outgoing message on the compute queue, then ONE grouped RCCL send/recv over xGMI on the communication queue;
+    // the same-GPU copies (they read owned cells and write halos no message touches) run on the compute queue WHILE the
+    // messages are in flight, the unpacks wait for the group (haloExchange.F90:553-719 does the same with isend / irecv /
+    // local copy / waitany)
     for (auto& l : cp->sends) launch_halo_pack(tab, l.blkA, l.offA, l.n, mask, l.buf, g_stream);
-    if (!cp->sends.empty() || !cp->recvs.empty()) {
+    const bool remote = !cp->sends.empty() || !cp->recvs.empty();
+    if (remote) {
 #ifndef ADFLOW_NO_RCCL
         if (!g_nccl) return fail("halo exchange needs other ranks but adflow_gpu_comm_init was not called");
+        hipStream_t sx = g_overlap ? g_streamX : g_stream;
+        if (g_overlap) {
+            HIPCHK(hipEventRecord(g_evPack, g_stream));
+            HIPCHK(hipStreamWaitEvent(g_streamX, g_evPack, 0));
+        }
         NCCLCHK(ncclGroupStart());
         for (auto& l : cp->sends)
-            if (l.n > 0) NCCLCHK(ncclSend(l.buf, (size_t)nvar * l.n, ncclDouble, l.peer, g_nccl, g_stream));
+            if (l.n > 0) NCCLCHK(ncclSend(l.buf, (size_t)nvar * l.n, ncclDouble, l.peer, g_nccl, sx));
         for (auto& l : cp->recvs)
-            if (l.n > 0) NCCLCHK(ncclRecv(l.buf, (size_t)nvar * l.n, ncclDouble, l.peer, g_nccl, g_stream));
+            if (l.n > 0) NCCLCHK(ncclRecv(l.buf, (size_t)nvar * l.n, ncclDouble, l.peer, g_nccl, sx));
         NCCLCHK(ncclGroupEnd());
+        if (g_overlap) HIPCHK(hipEventRecord(g_evComm, g_streamX));
 #else
         return fail("built without RCCL: use adflow_gpu_halo_pack/unpack with an external transport");
 #endif
     }
     launch_halo_copy(tab, cp->local.blkA, cp->local.offA, cp->local.blkB, cp->local.offB, cp->local.n, mask, g_stream);
+#ifndef ADFLOW_NO_RCCL
+    if (remote && g_overlap) HIPCHK(hipStreamWaitEvent(g_stream, g_evComm, 0));
+#endif
     for (auto& l : cp->recvs) launch_halo_unpack(tab, l.blkA, l.offA, l.n, mask, l.buf, g_stream);
     // periodic transformations of the halos that crossed a periodic interface: coordinates for the node pattern,
     // velocities when all three travelled (haloExchange.F90:456-457)
@@ -2425,8 +2474,10 @@ int for_level1_in_order(const std::function<int(Block*, long)>& fn)
 int set_w_dev(const double* d_vec)
 {
     const double turbFloor = 1e-6 * g_opts.wInf[5];
-    return for_level1_in_order([&](Block* b, long off) {
-        launch_set_w(b->v, d_vec + off, turbFloor, g_stream);
+    LevelTab t;
+    if (level_tab(1, &t)) return 1;
+    launch_set_w_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbFloor, g_stream);     // block offsets: BlkView::vecOff
+    return for_level1_in_order([&](Block* b, long) {
         b->ss_valid = false;
         b->etot_consistent = false;
         return 0;
@@ -2435,10 +2486,10 @@ int set_w_dev(const double* d_vec)
 
 int get_r_dev(double* d_vec, double turbScale, double* d_sums)
 {
-    return for_level1_in_order([&](Block* b, long off) {
-        launch_get_r(b->v, d_vec + off, turbScale, d_sums, g_stream);
-        return 0;
-    });
+    LevelTab t;
+    if (level_tab(1, &t)) return 1;
+    launch_get_r_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbScale, d_sums, g_stream);
+    return 0;
 }
 }  // namespace
 

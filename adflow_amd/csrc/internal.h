@@ -184,6 +184,7 @@ struct BlkView {
     int *mgIFine, *mgJFine, *mgKFine;        // coarse block: (1:ie,2) stored [m*2+q], m = 0..ie
     double *mgIWeight, *mgJWeight, *mgKWeight;  // coarse block, indexed by cell index
     int *mgICoarse, *mgJCoarse, *mgKCoarse;  // fine block, indexed [i*2+q]
+    long vecOff;     // first entry of the block in the PETSc-ordered state / residual vector of its level (NKSolvers.F90:1240-1253)
     __host__ __device__ inline long idx(int i, int j, int k) const { return (long)i + (long)j * ldi + (long)k * ldk; }
 };
 
@@ -316,6 +317,13 @@ void launch_prolong_update_level(const BlkView* ftab, const BlkView* ctab, int n
 void launch_set_w(const BlkView& b, const double* vec, double turbFloor, hipStream_t s);
 void launch_get_r(const BlkView& b, double* vec, double turbScale, double* sums, hipStream_t s);
 void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
+// level-batched forms (blockIdx.z = slot * planes + plane): one launch for every block of a level
+void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
+void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s);
+void launch_get_r_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double* vec, double turbScale, double* sums, hipStream_t s);
+void launch_entropy_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s);
+void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double gammaConstant, hipStream_t s);
+void launch_initres_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);
 #include <vector>
 void launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& flow,

@@ -208,6 +208,28 @@ __global__ void k_initres(BlkView b, int l0, int l1, int coarse)
     }
 }
 
+__global__ void k_initres_level(const BlkView* __restrict__ tab, int nzb, int l0, int l1, int coarse)
+{
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    const int i = blockIdx.x * 64 + threadIdx.x + 2;
+    const int j = blockIdx.y * 4 + threadIdx.y + 2;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
+    const long c = b.idx(i, j, k);
+    for (int l = l0; l <= l1; ++l) {
+        double v = 0.0;
+        if (coarse && l < 5) v = b.wr[c + l * b.nbox];
+        b.dw[c + l * b.nbox] = v;
+    }
+}
+
+void launch_initres_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, int l0, int l1, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_initres_level, dim3((maxnx + 63) / 64, (maxny + 3) / 4, maxnz * nslots), dim3(64, 4, 1), 0, s, tab, maxnz, l0, l1,
+                       kp.coarseInit);
+}
+
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s)
 {
     dim3 blk(64, 4, 1);

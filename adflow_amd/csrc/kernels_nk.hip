@@ -13,29 +13,40 @@
 #define NK_BX 64
 #define NK_BY 4
 
-__global__ __launch_bounds__(NK_BX* NK_BY) void k_set_w(BlkView b, const double* __restrict__ vec, double turbFloor)
+__device__ __forceinline__ void set_w_body(const BlkView& b, int kz, const double* __restrict__ vec, double turbFloor)
 {
     const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
     const int j = blockIdx.y * NK_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > b.il || j > b.jl) return;
+    const int k = kz + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
     const long c = b.idx(i, j, k);
     const long m = (((long)(k - 2) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw;
     for (int l = 0; l < 5; ++l) b.w[c + l * b.nbox] = vec[m + l];
     if (b.nw > 5) b.w[c + 5 * b.nbox] = fmax(turbFloor, vec[m + 5]);
 }
 
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_set_w(BlkView b, const double* __restrict__ vec, double turbFloor)
+{
+    set_w_body(b, (int)blockIdx.z, vec, turbFloor);
+}
+
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_set_w_level(const BlkView* __restrict__ tab, int nzb, const double* __restrict__ vec,
+                                                              double turbFloor)
+{
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    set_w_body(b, (int)(blockIdx.z % nzb), vec + b.vecOff, turbFloor);
+}
+
 // scale != 0: turbulence residual multiplied by `turbScale`; sums[0] += flow^2, sums[1] += turb^2
-__global__ __launch_bounds__(NK_BX* NK_BY) void k_get_r(BlkView b, double* __restrict__ vec, double turbScale,
-                                                        double* __restrict__ sums)
+__device__ __forceinline__ void get_r_body(const BlkView& b, int kz, double* __restrict__ vec, double turbScale, double* __restrict__ sums)
 {
     __shared__ double red[2][NK_BX * NK_BY];
     const int tid = threadIdx.x + NK_BX * threadIdx.y;
     const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
     const int j = blockIdx.y * NK_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
+    const int k = kz + 2;
     double sf = 0.0, st = 0.0;
-    if (i <= b.il && j <= b.jl) {
+    if (i <= b.il && j <= b.jl && k <= b.kl) {
         const long c = b.idx(i, j, k);
         const long m = (((long)(k - 2) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw;
         const double ovv = 1.0 / b.volRef[c];
@@ -67,13 +78,25 @@ __global__ __launch_bounds__(NK_BX* NK_BY) void k_get_r(BlkView b, double* __res
     }
 }
 
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_get_r(BlkView b, double* __restrict__ vec, double turbScale, double* __restrict__ sums)
+{
+    get_r_body(b, (int)blockIdx.z, vec, turbScale, sums);
+}
+
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_get_r_level(const BlkView* __restrict__ tab, int nzb, double* __restrict__ vec,
+                                                              double turbScale, double* __restrict__ sums)
+{
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    get_r_body(b, (int)(blockIdx.z % nzb), vec + b.vecOff, turbScale, sums);
+}
+
 // owned cells: p from (rho, v, rhoE) with the 1e-4*pInfCorr floor, Sutherland, SA eddy viscosity
-__global__ __launch_bounds__(NK_BX* NK_BY) void k_closures(BlkView b, KParams kp)
+__device__ __forceinline__ void closures_body(const BlkView& b, int kz, const KParams& kp)
 {
     const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
     const int j = blockIdx.y * NK_BY + threadIdx.y + 2;
-    const int k = blockIdx.z + 2;
-    if (i > b.il || j > b.jl) return;
+    const int k = kz + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
     const long c = b.idx(i, j, k);
     const long nb = b.nbox;
     const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
@@ -98,7 +121,34 @@ __global__ __launch_bounds__(NK_BX* NK_BY) void k_closures(BlkView b, KParams kp
     }
 }
 
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_closures(BlkView b, KParams kp) { closures_body(b, (int)blockIdx.z, kp); }
+
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_level(const BlkView* __restrict__ tab, int nzb, KParams kp)
+{
+    closures_body(tab[blockIdx.z / nzb + 1], (int)(blockIdx.z % nzb), kp);
+}
+
 static dim3 nk_grid(const BlkView& b) { return dim3((b.nx + NK_BX - 1) / NK_BX, (b.ny + NK_BY - 1) / NK_BY, b.nz); }
+static dim3 nk_level_grid(int nslots, int maxnx, int maxny, int maxnz)
+{
+    return dim3((maxnx + NK_BX - 1) / NK_BX, (maxny + NK_BY - 1) / NK_BY, maxnz * nslots);
+}
+
+void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_closures_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp);
+}
+void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_set_w_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, vec, turbFloor);
+}
+void launch_get_r_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double* vec, double turbScale, double* sums, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_get_r_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, vec, turbScale, sums);
+}
 
 void launch_set_w(const BlkView& b, const double* vec, double turbFloor, hipStream_t s)
 {

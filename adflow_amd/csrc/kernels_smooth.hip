@@ -60,6 +60,26 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned(BlkView b, double g
     b.w[c + 4 * nb] = ovgm1 * b.p[c] + 0.5 * b.w[c] * (u * u + v * v + w * w);
 }
 
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned_level(const BlkView* __restrict__ tab, int nzb, double gammaConstant)
+{
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
+    const int k = blockIdx.z % nzb + 2;
+    if (i > b.il || j > b.jl || k > b.kl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    const double ovgm1 = 1.0 / (gammaConstant - 1.0);
+    const double u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    b.w[c + 4 * nb] = ovgm1 * b.p[c] + 0.5 * b.w[c] * (u * u + v * v + w * w);
+}
+
+void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double gammaConstant, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_etot_owned_level, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, gammaConstant);
+}
+
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s)
 {
     dim3 blk(SM_BX, SM_BY, 1);

@@ -133,6 +133,25 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_entropy(BlkView b)
     b.ss[c] = b.p[c] / pow(b.w[c], b.gamma[c]);
 }
 
+__global__ __launch_bounds__(TS_BX* TS_BY) void k_entropy_level(const BlkView* __restrict__ tab, int nzb)
+{
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    const int i = blockIdx.x * TS_BX + threadIdx.x + (2 - 16);
+    const int j = blockIdx.y * TS_BY + threadIdx.y;
+    const int k = blockIdx.z % nzb;
+    if (b.nx == 0 || i < 0 || i > b.ib || j > b.jb || k > b.kb) return;
+    const long c = b.idx(i, j, k);
+    b.ss[c] = b.p[c] / pow(b.w[c], b.gamma[c]);
+}
+
+void launch_entropy_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    const int nzb = maxnz + 4;
+    dim3 grd((maxnx + 4 + 14 + TS_BX - 1) / TS_BX, (maxny + 4 + TS_BY - 1) / TS_BY, nzb * nslots);
+    hipLaunchKernelGGL(k_entropy_level, grd, dim3(TS_BX, TS_BY, 1), 0, s, tab, nzb);
+}
+
 void launch_entropy(const BlkView& b, hipStream_t s)
 {
     dim3 blk(TS_BX, TS_BY, 1);
