@@ -548,10 +548,13 @@ __device__ __forceinline__ void gs_record(const GsCell& q, double gam, const dou
 // ROWS: cell rows (waves) per workgroup; GRAD needs ROWS = NG_BY (the LDS record exchange); the SA-only march may run 8 rows: the
 // j neighbours are plain loads and the rows j0-2 .. j0+ROWS+1 a workgroup touches are re-read by the workgroups above and below
 // (349 B per cell at 4 rows, profiles/r02_k_pmc_traffic.txt, at 6.5 TB/s: the kernel is bound by exactly that traffic)
-template <bool GRAD, int ROWS>
+template <bool GRAD, int ROWS, bool LX = false>
 __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
     __shared__ double xr[GRAD ? 2 * NG_BY * NG_SLOT : 1];
+    // LX (tuning sa_march = 3): the state a cell contributes to its j neighbours (u, v, w, nu, vol, nuTilde) goes through LDS,
+    // double buffered over the planes, instead of plain loads of the rows j +- 1, j +- 2
+    __shared__ double sq[LX ? 2 * ROWS * 6 * 64 : 1];
     const BlkView& b = tab[blockIdx.z / nzb + 1];
     const int lane = threadIdx.x, row = threadIdx.y;
     const int i0 = blockIdx.x * GS_OUT + 1, j0 = blockIdx.y * ROWS + 1;      // first node of the tile
@@ -626,8 +629,31 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
             qkp.u = sp1.u; qkp.v = sp1.v; qkp.w = sp1.w; qkp.nu = sp1.rlv * rcp_nr(sp1.rho); qkp.vol = sp1.vol; qkp.nut = n_p1;
             const GsNbr qim = gs_up1(q0), qip = gs_dn1(q0);
             const double n_im2 = lane_up1(qim.nut), n_ip2 = lane_dn1(qip.nut);
-            const GsNbr qjm = gs_nbr_ld(m, c - ojm1), qjp = gs_nbr_ld(m, c + ojp1);
-            const double n_jm2 = ldg(m.w5, c - ojm2), n_jp2 = ldg(m.w5, c + ojp2);
+            GsNbr qjm, qjp;
+            double n_jm2, n_jp2;
+            if (!LX) {
+                qjm = gs_nbr_ld(m, c - ojm1); qjp = gs_nbr_ld(m, c + ojp1);
+                n_jm2 = ldg(m.w5, c - ojm2); n_jp2 = ldg(m.w5, c + ojp2);
+            } else {
+                double* __restrict__ so = sq + (((mm & 1) * ROWS + row) * 6) * 64 + lane;
+                so[0] = q0.u; so[64] = q0.v; so[128] = q0.w; so[192] = q0.nu; so[256] = q0.vol; so[320] = q0.nut;
+                // the rows outside the tile: plain loads, issued before the barrier
+                if (row == 0) qjm = gs_nbr_ld(m, c - ojm1);
+                if (row == ROWS - 1) qjp = gs_nbr_ld(m, c + ojp1);
+                if (row < 2) n_jm2 = ldg(m.w5, c - ojm2);
+                if (row >= ROWS - 2) n_jp2 = ldg(m.w5, c + ojp2);
+                __syncthreads();
+                auto nbr = [&](int r) {
+                    const double* __restrict__ si = sq + (((mm & 1) * ROWS + r) * 6) * 64 + lane;
+                    GsNbr q;
+                    q.u = si[0]; q.v = si[64]; q.w = si[128]; q.nu = si[192]; q.vol = si[256]; q.nut = si[320];
+                    return q;
+                };
+                if (row > 0) qjm = nbr(row - 1);
+                if (row < ROWS - 1) qjp = nbr(row + 1);
+                if (row >= 2) n_jm2 = sq[(((mm & 1) * ROWS + row - 2) * 6 + 5) * 64 + lane];
+                if (row < ROWS - 2) n_jp2 = sq[(((mm & 1) * ROWS + row + 2) * 6 + 5) * 64 + lane];
+            }
             const double nIm[3] = {lane_up1(nI[0]), lane_up1(nI[1]), lane_up1(nI[2])};
             // velocity gradient * 2 vol from the six neighbours (sa.F90:133-190)
             double gu[3][3];
@@ -2108,7 +2134,7 @@ void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int
     }
 }
 
-int g_sa_march = 1;         // tuning "sa_march": 0 = gather kernel, 1 = k-march with 4 rows per workgroup, 2 = with 8 rows (no faster: 0.57 vs 0.54 ms, profiles/r02_l)
+int g_sa_march = 1;         // tuning "sa_march": 0 = gather kernel, 1 = k-march with 4 rows per workgroup, 2 = with 8 rows (no faster: 0.57 vs 0.54 ms, profiles/r02_l), 3 = 4 rows with the j neighbours through LDS
 int g_grad_sa_fused = 0;    // tuning "grad_sa_fused": SA residual evaluated inside the nodal-gradient march
 
 // nodal gradients + Spalart-Allmaras residual of every block of the level in one launch
@@ -2147,7 +2173,10 @@ void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int n
     if (nslots <= 0) return;
     const int nzn = nz + 1;
     const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
-    if (g_sa_march < 2)
+    if (g_sa_march == 3)       // j neighbours through LDS: 287 instead of 349 B per cell from HBM, one barrier per plane, no faster (profiles/r02_x)
+        hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY, true>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
+    else if (g_sa_march < 2)
         hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
                            dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
     else

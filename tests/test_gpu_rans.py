@@ -101,9 +101,15 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("viscous_tiled", 2)
         engine.set_tuning("roe_march", 0)
         checks.check_block_res(engine, (63, 6, 9), FlowParams(equations=RANSEquations, spaceDiscr=upwind), seed=3, stretch_k=2.0)
+        engine.set_tuning("roe_march", 1)
+        for sm in (3, 2, 0):        # SA march with the j neighbours through LDS, with 8 rows, the gather kernel
+            engine.set_tuning("sa_march", sm)
+            prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
+            checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
     finally:
         engine.set_tuning("viscous_tiled", 2)
         engine.set_tuning("roe_march", 1)
+        engine.set_tuning("sa_march", 1)
 
 
 def test_visc_wave_specialised(engine):
