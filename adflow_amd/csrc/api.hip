@@ -925,7 +925,9 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     const bool scalarVisc = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
     if (mixed) {
         // inviscid part already enqueued
-    } else if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) && !kp.dissApprox && !anyMoving) {
+    } else if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) &&
+               (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving) {
+        // (the approximate residual changes the Roe scheme only through the limiter: inviscidUpwindFlux is called either way)
         // matrix dissipation / Roe upwind: k-marching kernel over the level's tile table (every face once in k and i)
         if (ensure_tiles(level)) return 1;
         // second-order Roe upwind on the fine level: the per-cell reconstruction kernel; everything else (matrix, first order)
@@ -1203,15 +1205,19 @@ static void jac_spec(unsigned flags, bool viscous, bool rans, JacSpec* J)
         J->ca = 1; J->cb = 3; J->cc = 4; J->cn = 13; J->cm = 13;        // setup_dRdw_euler_coloring (:1121-1151)
     }
     J->nStencil = n;
+    for (int q = 0; q < n; ++q) {
+        const int v = (J->ca * J->st[q][0] + J->cb * J->st[q][1] + J->cc * J->st[q][2]) % J->cn;
+        J->sc[q] = (v < 0) ? v + J->cn : v;
+    }
 }
 
 // masterRoutines::block_res_state (masterRoutines.F90:1214-1283) for every block of the level: closures with halos, turbulence
 // and mean-flow boundary conditions, the residual core, actuator sources.  resScale is applied by the extraction kernel.
-static int block_res_state_enqueue(int level, unsigned resFlags, bool turbBC)
+static int block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bool closuresDone = false)
 {
     KParams kp = make_kparams(level, 1.0, 0);
     int rc = for_level(level, [&](Block* b) {
-        launch_closures_halo(b->v, kp, g_stream);
+        if (!closuresDone) launch_closures_halo(b->v, kp, g_stream);
         b->ss_valid = false;
         b->etot_consistent = false;
         return 0;
@@ -1297,11 +1303,12 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
     const double deltaInv = 1.0 / delta;
     for (int col = 0; col < J.cn && !rc; ++col) {
         for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
+            const KParams kpc = make_kparams(level, 1.0, 0);
             rc = for_level(level, [&](Block* b) {
-                launch_fd_state(b->v, b->wref, l, col, J, delta, g_stream);
+                launch_fd_state_closures(b->v, b->wref, l, col, J, delta, kpc, g_stream);
                 return 0;
             });
-            if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC);
+            if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC, true);
             if (!rc) rc = for_level(level, [&](Block* b) {
                 launch_fd_extract(b->v, b->dwref, b->jac, l, col, J, deltaInv, g_opts.turbResScale, g_stream);
                 return 0;

@@ -254,8 +254,11 @@ struct JacSpec {
     int nStencil, nState, lStart;     // lStart: first state variable (0-based) of the matrix
     int ca, cb, cc, cn, cm;           // colour(i,j,k) = (ca (i mod cm) + cb (j mod cm) + cc (k mod cm)) mod cn   (0-based)
     int st[33][3];                    // stencil offsets (row = perturbed cell + offset)
+    int sc[33];                       // (ca di + cb dj + cc dk) mod cn of every entry (linear colourings)
 };
 void launch_fd_state(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, hipStream_t s);
+void launch_fd_state_closures(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, const KParams& kp,
+                              hipStream_t s);
 void launch_fd_copy(const BlkView& b, double* dst, const double* src, int ncomp, hipStream_t s);
 void launch_closures_halo(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int col, const JacSpec& J, double deltaInv, double turbResScale,

@@ -27,9 +27,13 @@ __device__ __forceinline__ int jc_colour(const JacSpec& J, int i, int j, int k)
 }
 
 
-// w <- wref (+ delta on component l of the cells of colour `col`); col < 0: plain restore
+__device__ __forceinline__ void closures_halo_at(const BlkView& b, const KParams& kp, int i, int j, int k, long c, const double wv[6]);
+
+// w <- wref (+ delta on component l of the cells of colour `col`); col < 0: plain restore.  CLOS: also the closures of
+// block_res_state from the new state (pressure on 0..ib, laminar / eddy viscosity on 1..ie) -- one pass instead of two
+template <bool CLOS>
 __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_state(BlkView b, const double* __restrict__ wref, int l, int col, JacSpec J,
-                                                           double delta)
+                                                           double delta, KParams kp)
 {
     const int i = blockIdx.x * JC_BX + threadIdx.x - 14;     // aligned rows (the box origin is shifted by ADF_PAD0)
     const int j = blockIdx.y * JC_BY + threadIdx.y;
@@ -37,11 +41,14 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_state(BlkView b, const doub
     if (i < 0 || i > b.ib || j > b.jb) return;
     const long c = b.idx(i, j, k);
     const bool hit = (col >= 0) && (jc_colour(J, i, j, k) == col);
+    double wv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int m = 0; m < b.nw; ++m) {
         double v = wref[c + m * b.nbox];
         if (hit && m == l) v += delta;
         b.w[c + m * b.nbox] = v;
+        wv[m] = v;
     }
+    if (CLOS) closures_halo_at(b, kp, i, j, k, c, wv);
 }
 
 __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_copy(BlkView b, double* __restrict__ dst, const double* __restrict__ src, int ncomp)
@@ -55,17 +62,11 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_copy(BlkView b, double* __r
 }
 
 // pressure on 0..ib, laminar / eddy viscosity on 1..ie (the includeHalos = .True. forms used by block_res_state)
-__global__ __launch_bounds__(JC_BX* JC_BY) void k_closures_halo(BlkView b, KParams kp)
+__device__ __forceinline__ void closures_halo_at(const BlkView& b, const KParams& kp, int i, int j, int k, long c, const double wv[6])
 {
-    const int i = blockIdx.x * JC_BX + threadIdx.x - 14;
-    const int j = blockIdx.y * JC_BY + threadIdx.y;
-    const int k = blockIdx.z;
-    if (i < 0 || i > b.ib || j > b.jb) return;
-    const long c = b.idx(i, j, k);
-    const long nb = b.nbox;
-    const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    const double rho = wv[0], u = wv[1], v = wv[2], w = wv[3];
     const double gm1 = kp.gammaConstant - 1.0;
-    double p = gm1 * (b.w[c + 4 * nb] - 0.5 * rho * (u * u + v * v + w * w));
+    double p = gm1 * (wv[4] - 0.5 * rho * (u * u + v * v + w * w));
     p = fmax(p, 1.e-4 * kp.pInfCorr);
     b.p[c] = p;
     if (!kp.viscous || i < 1 || i > b.ie || j < 1 || j > b.je || k < 1 || k > b.ke) return;
@@ -76,11 +77,23 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_closures_halo(BlkView b, KPara
     b.rlv[c] = rlv;
     if (kp.eddyModel) {
         const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
-        const double rnuSA = b.w[c + 5 * nb] * rho;
+        const double rnuSA = wv[5] * rho;
         const double chi = rnuSA / rlv;
         const double chi3 = chi * chi * chi;
         b.rev[c] = chi3 / (chi3 + cv13) * rnuSA;
     }
+}
+
+__global__ __launch_bounds__(JC_BX* JC_BY) void k_closures_halo(BlkView b, KParams kp)
+{
+    const int i = blockIdx.x * JC_BX + threadIdx.x - 14;
+    const int j = blockIdx.y * JC_BY + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i < 0 || i > b.ib || j > b.jb) return;
+    const long c = b.idx(i, j, k);
+    double wv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < b.nw; ++m) wv[m] = b.w[c + m * b.nbox];
+    closures_halo_at(b, kp, i, j, k, c, wv);
 }
 
 // owned cells: resScale (dw / volRef, turbulence * turbResScale), then either store the reference (l = -1) or the finite
@@ -108,10 +121,17 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_extract(BlkView b, double* 
         for (int m = 0; m < J.nState; ++m) b.dw[c + (J.lStart + m) * nb] = dwref[c + m * nb];
         return;
     }
+    const bool linear = (J.cm == J.cn);
+    const int c0 = jc_colour(J, i, j, k);
     for (int s = 0; s < J.nStencil; ++s) {
         const int pi = i - J.st[s][0], pj = j - J.st[s][1], pk = k - J.st[s][2];      // the perturbed cell
         if (pi < 0 || pi > b.ib || pj < 0 || pj > b.jb || pk < 0 || pk > b.kb) continue;
-        if (jc_colour(J, pi, pj, pk) != col) continue;
+        if (linear) {
+            // colour(p) = colour(row) - (ca di + cb dj + cc dk)  (mod cn); J.sc[s] holds the second term reduced to 0..cn-1
+            int d = c0 - J.sc[s];
+            if (d < 0) d += J.cn;
+            if (d != col) continue;
+        } else if (jc_colour(J, pi, pj, pk) != col) continue;
         for (int m = 0; m < J.nState; ++m)
             jac[c + ((long)(s * J.nState + (l - J.lStart)) * J.nState + m) * nb] = (val[m] - dwref[c + m * nb]) * deltaInv;
     }
@@ -122,7 +142,14 @@ static dim3 own_grid(const BlkView& b) { return dim3((b.nx + JC_BX - 1) / JC_BX,
 
 void launch_fd_state(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fd_state, box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, wref, l, col, J, delta);
+    KParams kp = KParams();
+    hipLaunchKernelGGL((k_fd_state<false>), box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, wref, l, col, J, delta, kp);
+}
+// state of one coloured evaluation and the closures of block_res_state in one pass
+void launch_fd_state_closures(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, const KParams& kp,
+                              hipStream_t s)
+{
+    hipLaunchKernelGGL((k_fd_state<true>), box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, wref, l, col, J, delta, kp);
 }
 void launch_fd_copy(const BlkView& b, double* dst, const double* src, int ncomp, hipStream_t s)
 {
