@@ -1848,9 +1848,14 @@ static int apply_bc_enqueue(int level, int secondHalo)
     if (bc_plan(level, &pl)) return 1;
     if (pl->nent == 0) return 0;
     KParams kp = make_kparams(level, 1.0, 0);
-    if (pl->anyEulerWall &&
-        (g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_NORMAL_MOMENTUM || g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_QUADRATIC))
-        return fail("eulerWallBCTreatment=%d is not implemented on the device (1 constant, 2 linear)", g_opts.eulerWallBCTreatment);
+    if (pl->anyEulerWall && g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_QUADRATIC)
+        return fail("eulerWallBCTreatment=%d: bcEulerWall has no quadratic extrapolation (1 constant, 2 linear, 4 normal momentum)",
+                    g_opts.eulerWallBCTreatment);
+    if (pl->anyEulerWall && g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_NORMAL_MOMENTUM && kp.fineGrid) {
+        bool moving = false;
+        for_level(level, [&](Block* b) { moving = moving || b->v.sFace || b->v.moving; return 0; });
+        if (moving) return fail("eulerWallBCTreatment = normal momentum on moving blocks needs the cell-centre grid velocity (not mirrored)");
+    }
     LevelTab t;
     if (level_tab(level, &t)) return 1;
     launch_apply_all_bc(t.tab, pl->d_ent, pl->d_order, pl->flow, kp, secondHalo, g_opts.eulerWallBCTreatment,

@@ -289,6 +289,43 @@ __global__ __launch_bounds__(256) void k_bc_eulerwall(BC_ARGS, KParams kp, int s
     const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
     const double rface = f.rface ? f.rface[s.f] : 0.0;
     const double u = b.w[s.c2 + nb], v = b.w[s.c2 + 2 * nb], w = b.w[s.c2 + 3 * nb];
+    if (wallTreatment == ADFLOW_WALLBC_NORMAL_MOMENTUM) {
+        // pressure gradient from the normal momentum equation (BCRoutines.F90:1123-1234): central differences of the unit
+        // normal and of the interior pressure along the two directions of the face, clipped to the subface; ssi = the normal of
+        // the boundary face, ssj / ssk = the face normals of the first interior cell in the generic j / k directions
+        // (setBCPointers, utils.F90:1100-1137).  Blocks at rest only (the grid velocity s of the cell centre is not mirrored).
+        const int isize = f.icEnd - f.icBeg + 1;
+        const int a = f.icBeg + (int)(s.f % isize), q = f.jcBeg + (int)(s.f / isize);
+        long sa, sb;
+        const double *Sn, *Sa, *Sb;
+        switch (f.faceID) {
+        case ADFLOW_IMIN: case ADFLOW_IMAX: sa = b.ldi; sb = b.ldk; Sn = b.sI; Sa = b.sJ; Sb = b.sK; break;
+        case ADFLOW_JMIN: case ADFLOW_JMAX: sa = 1; sb = b.ldk; Sn = b.sJ; Sa = b.sI; Sb = b.sK; break;
+        default: sa = 1; sb = b.ldi; Sn = b.sK; Sa = b.sI; Sb = b.sJ; break;
+        }
+        const long cf = (f.faceID == ADFLOW_IMIN || f.faceID == ADFLOW_JMIN || f.faceID == ADFLOW_KMIN) ? s.c1 : s.c2;   // the boundary face
+        const int am1 = (a - 1 > f.icBeg) ? a - 1 : f.icBeg, ap1 = (a + 1 < f.icEnd) ? a + 1 : f.icEnd;
+        const int qm1 = (q - 1 > f.jcBeg) ? q - 1 : f.jcBeg, qp1 = (q + 1 < f.jcEnd) ? q + 1 : f.jcEnd;
+        const double a1 = 1.0 / (double)((ap1 - am1 > 1) ? ap1 - am1 : 1), b1 = 1.0 / (double)((qp1 - qm1 > 1) ? qp1 - qm1 : 1);
+        const double sixa = 2.0 * Sn[cf], siya = 2.0 * Sn[cf + nb], siza = 2.0 * Sn[cf + 2 * nb];
+        const double sjxa = Sa[s.c2 - sa] + Sa[s.c2], sjya = Sa[s.c2 - sa + nb] + Sa[s.c2 + nb],
+                     sjza = Sa[s.c2 - sa + 2 * nb] + Sa[s.c2 + 2 * nb];
+        const double skxa = Sb[s.c2 - sb] + Sb[s.c2], skya = Sb[s.c2 - sb + nb] + Sb[s.c2 + nb],
+                     skza = Sb[s.c2 - sb + 2 * nb] + Sb[s.c2 + 2 * nb];
+        const long fjp = s.f + (ap1 - a), fjm = s.f + (am1 - a), fkp = s.f + (long)(qp1 - q) * isize, fkm = s.f + (long)(qm1 - q) * isize;
+        const double rxj = a1 * (f.norm[fjp] - f.norm[fjm]), ryj = a1 * (f.norm[fjp + s.fn] - f.norm[fjm + s.fn]),
+                     rzj = a1 * (f.norm[fjp + 2 * s.fn] - f.norm[fjm + 2 * s.fn]);
+        const double dpj = a1 * (b.p[s.c2 + (ap1 - a) * sa] - b.p[s.c2 + (am1 - a) * sa]);
+        const double rxk = b1 * (f.norm[fkp] - f.norm[fkm]), ryk = b1 * (f.norm[fkp + s.fn] - f.norm[fkm + s.fn]),
+                     rzk = b1 * (f.norm[fkp + 2 * s.fn] - f.norm[fkm + 2 * s.fn]);
+        const double dpk = b1 * (b.p[s.c2 + (qp1 - q) * sb] - b.p[s.c2 + (qm1 - q) * sb]);
+        const double ri = nx * sixa + ny * siya + nz * siza;
+        const double rj = nx * sjxa + ny * sjya + nz * sjza;
+        const double rk = nx * skxa + ny * skya + nz * skza;
+        const double qj = u * sjxa + v * sjya + w * sjza;
+        const double qk = u * skxa + v * skya + w * skza;
+        grad = ((qj * (u * rxj + v * ryj + w * rzj) + qk * (u * rxk + v * ryk + w * rzk)) * b.w[s.c2] - rj * dpj - rk * dpk) / ri;
+    }
     b.p[s.c1] = bc_mydim(b.p[s.c2], grad);
     const double vn = 2.0 * (rface - u * nx - v * ny - w * nz);
     b.w[s.c1] = b.w[s.c2];

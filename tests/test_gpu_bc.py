@@ -32,6 +32,16 @@ def test_apply_all_bc_wall_and_outflow_treatments(engine, treat):
     checks.check_apply_bc(engine, (12, 10, 6), prm, VISC_SPECS[0], stretch_k=2.0)
 
 
+def test_euler_wall_normal_momentum(engine):
+    """eulerWallBCTreatment = normalMomentum (BCRoutines.F90:1123-1234): wall pressure gradient from the normal momentum equation,
+    Euler walls on all three face directions, full faces and split subfaces, a single-cell-wide subface (the clipped differences)"""
+    prm = FlowParams(eulerWallBCTreatment=4)
+    checks.check_apply_bc(engine, (12, 10, 6), prm, {1: -5, 2: -6, 3: -5, 4: -15, 5: -5, 6: -9})
+    checks.check_apply_bc(engine, (9, 7, 5), prm, {1: -6, 2: -5, 3: -1, 4: -5, 5: -6, 6: -5}, secondHalo=False)
+    checks.check_apply_bc(engine, (10, 8, 1), prm, {1: -5, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
+    checks.check_apply_bc(engine, (12, 8, 6), prm, {1: -6, 2: -6, 3: -5, 4: -5, 5: -1, 6: -5}, split={3: -6, 6: -5})
+
+
 @pytest.mark.parametrize("spec", VISC_SPECS)
 def test_apply_all_bc_rans(engine, spec):
     checks.check_apply_bc(engine, (20, 7, 6), FlowParams(equations=RANSEquations), spec, stretch_k=2.0)

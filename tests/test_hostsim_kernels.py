@@ -417,3 +417,8 @@ def test_fd_jacobian_exact(hostsim_engine):
 
 def test_update_wall_distances_quickly(hostsim_engine):
     checks.check_wall_distance(hostsim_engine, (7, 5, 4), FlowParams(equations=RANSEquations), stretch_k=2.0)
+
+
+def test_euler_wall_normal_momentum(hostsim_engine):
+    import test_gpu_bc
+    test_gpu_bc.test_euler_wall_normal_momentum(hostsim_engine)
