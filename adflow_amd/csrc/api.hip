@@ -248,6 +248,7 @@ int copy_box(Block* b, double* dev, const double* host_c, int ncomp, int lo_i, i
 }
 
 int g_lumped = 0;       // inputDiscretization::lumpedDiss while a preconditioner matrix is assembled
+int g_metric_from_x = 3;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march re-form the face normals from the node coordinates
 
 KParams make_kparams(int level, double rFil, int fwMode)
 {
@@ -263,6 +264,7 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.eddyModel = (o.equations == ADFLOW_RANS);
     k.dirScaling = o.dirScaling;
     k.lumpedDiss = g_lumped;
+    k.metricFromX = g_metric_from_x;
     k.sigma = o.sigma;
     k.useQCR = o.useQCR;
     k.useRotationSA = o.useRotationSA;
@@ -437,6 +439,7 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     v.ib = v.nx + 3; v.jb = v.ny + 3; v.kb = v.nz + 3;
     v.ldi = ((v.ib + 1 + 15) / 16) * 16;
     v.ldk = v.ldi * (v.jb + 1);
+    v.mfact = d->rightHanded ? 0.5 : -0.5;
     b->boxsize = (long)v.ldk * (v.kb + 1);
     v.nbox = ((b->boxsize + 15) / 16) * 16 + 16;
     int rc = 0;
@@ -2677,6 +2680,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }
     if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
     if (!strcmp(key, "visc_ws")) { g_visc_ws = value; return 0; }
+    if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {
         if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");

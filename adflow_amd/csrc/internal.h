@@ -184,6 +184,7 @@ struct BlkView {
     int *mgIFine, *mgJFine, *mgKFine;        // coarse block: (1:ie,2) stored [m*2+q], m = 0..ie
     double *mgIWeight, *mgJWeight, *mgKWeight;  // coarse block, indexed by cell index
     int *mgICoarse, *mgJCoarse, *mgKCoarse;  // fine block, indexed [i*2+q]
+    double mfact;    // +0.5 (right-handed block) or -0.5: the factor of the face-normal cross products (metric_block, adjointExtra.F90:176-268)
     long vecOff;     // first entry of the block in the PETSc-ordered state / residual vector of its level (NKSolvers.F90:1240-1253)
     __host__ __device__ inline long idx(int i, int j, int k) const { return (long)i + (long)j * ldi + (long)k * ldk; }
 };
@@ -236,6 +237,7 @@ struct KParams {
     int fwMode;            // 0: fw not persistent (rFil==1, sfil==0, no store)  1: persistent fw
     int storeIntermed;     // store dtl / radii
     int dissApprox;        // lumped dissipation with the frozen sensor in b.ss (inviscidDissFlux*Approx)
+    int metricFromX;       // marching kernels re-form the face normals from the node coordinates (as blocketteResCore, blockette.F90:854-960)
     int lumpedDiss;        // inputDiscretization::lumpedDiss (preconditioner assembly): first-order Roe upwind (fluxes.F90:1536)
     double sigma;
     double rFil, sfil;

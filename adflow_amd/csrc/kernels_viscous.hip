@@ -247,10 +247,60 @@ struct NgPtrs {
     GPTR(const double) sI; GPTR(const double) sJ; GPTR(const double) sK; GPTR(const double) vol;
     unsigned nb8;       // byte stride between the components of a vector array
     unsigned sj;        // byte stride of one row
+    GPTR(const double) x; double mfact;     // node coordinates and the cross-product factor (normals re-formed from the nodes)
 };
+
+// ---- face normals of a cell from its eight corner nodes, the formulas (and operand order) of metric_block
+// (adjointExtra.F90:176-268, k_metric in kernels_geom.hip): a marching thread loads the two nodes (i, j, k) and (i, j-1, k) of
+// its column per plane, takes the column i-1 by DPP and keeps the plane below: 6 loads instead of the 12 of sI, sJ(j-1), sJ, sK
+struct NgNodes { double a[3], b[3]; };          // x(i, j, k) and x(i, j-1, k)
+
+__device__ __forceinline__ void ngx_load(const NgPtrs& m, unsigned c, NgNodes& n)
+{
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { n.a[d] = ldg(m.x, c + d * m.nb8); n.b[d] = ldg(m.x, c - m.sj + d * m.nb8); }
+}
+
+__device__ __forceinline__ void ngx_cross(double fact, const double p1[3], const double p2[3], const double q1[3], const double q2[3],
+                                          double s[3])
+{
+    const double v1x = p1[0] - p2[0], v1y = p1[1] - p2[1], v1z = p1[2] - p2[2];
+    const double v2x = q1[0] - q2[0], v2y = q1[1] - q2[1], v2z = q1[2] - q2[2];
+    s[0] = fact * (v1y * v2z - v1z * v2y);
+    s[1] = fact * (v1z * v2x - v1x * v2z);
+    s[2] = fact * (v1x * v2y - v1y * v2x);
+}
+
+// sK of the node plane N alone (the plane below the first cell plane of a march)
+__device__ __forceinline__ void ngx_normal_k(double fact, const NgNodes& N, double nK[3])
+{
+    double Na1[3], Nb1[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { Na1[d] = lane_up1(N.a[d]); Nb1[d] = lane_up1(N.b[d]); }
+    ngx_cross(fact, N.a, Nb1, Na1, N.b, nK);                       // v1 = x(i,j,k) - x(l,m,k) ; v2 = x(l,j,k) - x(i,m,k)
+}
+
+// normals stored at the cell (i, j, k): sI, sJ(j-1), sJ, sK from the node planes k-1 (P) and k (N)
+__device__ __forceinline__ void ngx_normals(double fact, const NgNodes& P, const NgNodes& N, double nI[3], double nJm[3], double nJ[3],
+                                            double nK[3])
+{
+    double Na1[3], Nb1[3], Pa1[3], Pb1[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { Na1[d] = lane_up1(N.a[d]); Nb1[d] = lane_up1(N.b[d]); Pa1[d] = lane_up1(P.a[d]); Pb1[d] = lane_up1(P.b[d]); }
+    ngx_cross(fact, P.a, N.b, N.a, P.b, nI);                       // v1 = x(i,j,n) - x(i,m,k) ; v2 = x(i,j,k) - x(i,m,n)
+    ngx_cross(fact, P.a, Na1, Pa1, N.a, nJ);                       // v1 = x(i,j,n) - x(l,j,k) ; v2 = x(l,j,n) - x(i,j,k)
+    ngx_cross(fact, P.b, Nb1, Pb1, N.b, nJm);                      // the same one row below
+    ngx_cross(fact, N.a, Nb1, Na1, N.b, nK);
+}
 
 // raw values of the cell at byte offset c (the loads of ng_record, issued early by the wave-specialised kernel)
 struct NgRaw { double rho, u, v, w, p, sI[3], sJm[3], sJ[3], sK[3], vol; };
+
+__device__ __forceinline__ void ng_load_state(const NgPtrs& m, unsigned c, NgRaw& q)
+{
+    q.rho = ldg(m.w0, c); q.u = ldg(m.w1, c); q.v = ldg(m.w2, c); q.w = ldg(m.w3, c); q.p = ldg(m.p, c);
+    q.vol = ldg(m.vol, c);
+}
 
 __device__ __forceinline__ void ng_load(const NgPtrs& m, unsigned c, NgRaw& q)
 {
@@ -294,6 +344,18 @@ __device__ __forceinline__ void ng_record(const NgPtrs& m, unsigned c, double ga
     ng_finish(q, gam, sKp, R);
 }
 
+// the same with the face normals re-formed from the nodes; P: nodes of the plane below (in), of this plane (out)
+__device__ __forceinline__ void ng_record_x(const NgPtrs& m, unsigned c, double gam, double sKp[3], NgNodes& P, NgRec& R)
+{
+    NgRaw q;
+    NgNodes N;
+    ng_load_state(m, c, q);
+    ngx_load(m, c, N);
+    ngx_normals(m.mfact, P, N, q.sI, q.sJm, q.sJ, q.sK);
+    P = N;
+    ng_finish(q, gam, sKp, R);
+}
+
 __device__ __forceinline__ void ng_publish(double* __restrict__ x, int lane, const NgRec& R)
 {
 #pragma unroll
@@ -328,9 +390,11 @@ __device__ __forceinline__ void ng_outer(double g[12], double sign, const double
 }
 
 // body of the kernel for the workgroup (bx, by, bz) of its grid; xr: 2 * NG_BY * NG_SLOT doubles of LDS owned by the caller
+template <bool XN>
 __device__ __forceinline__ void node_grad_body(const BlkView* __restrict__ tab, int nzb, double gam, int bx, int by, int bz,
                                                double* __restrict__ xr)
 {
+    constexpr bool xn = XN;          // face normals re-formed from the node coordinates (tuning metric_from_x & 2: not faster here)
     const BlkView& b = tab[bz / nzb + 1];                 // level-batched: bz = slot * nzb + k chunk
     const int lane = threadIdx.x, row = threadIdx.y;
     const int i0 = bx * NG_OUT + 1, j0 = by * NG_BY + 1;      // first node of the tile
@@ -348,22 +412,31 @@ __device__ __forceinline__ void node_grad_body(const BlkView* __restrict__ tab, 
     m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
     m.vol = (GPTR(const double))b.vol;
     m.nb8 = 8u * (unsigned)nb; m.sj = 8u * (unsigned)b.ldi;
+    m.x = (GPTR(const double))b.x; m.mfact = b.mfact;
     GPTR(double) grad = (GPTR(double))b.grad;
     const unsigned sk = 8u * (unsigned)b.ldk;
     unsigned c = 8u * (unsigned)(ic + jc * b.ldi + kn0 * b.ldk);
     unsigned cx = 8u * (unsigned)(ic + jx * b.ldi + kn0 * b.ldk);
     double sKp[3], sKpx[3];
+    NgNodes Pn, Pnx;            // xn: nodes of the plane below, own row and the row above the tile
+    if (xn) {
+        ngx_load(m, c - sk, Pn); ngx_load(m, cx - sk, Pnx);
+        ngx_normal_k(m.mfact, Pn, sKp); ngx_normal_k(m.mfact, Pnx, sKpx);
+    } else {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * m.nb8); sKpx[d] = ldg(m.sK, cx - sk + d * m.nb8); }
+        for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * m.nb8); sKpx[d] = ldg(m.sK, cx - sk + d * m.nb8); }
+    }
     NgPlane S;       // sums of the previous cell plane
     for (int mm = kn0; mm <= kn1 + 1; ++mm) {
         double* __restrict__ xb = xr + ((mm - kn0) & 1) * (NG_BY * NG_SLOT);
         NgRec R;
-        ng_record(m, c, gam, sKp, R);
+        if (xn) ng_record_x(m, c, gam, sKp, Pn, R);
+        else ng_record(m, c, gam, sKp, R);
         if (row > 0) ng_publish(xb + (row - 1) * NG_SLOT, lane, R);
         if (row == 0) {
             NgRec X;
-            ng_record(m, cx, gam, sKpx, X);
+            if (xn) ng_record_x(m, cx, gam, sKpx, Pnx, X);
+            else ng_record(m, cx, gam, sKpx, X);
             ng_publish(xb + (NG_BY - 1) * NG_SLOT, lane, X);
         }
         __syncthreads();
@@ -425,10 +498,11 @@ __device__ __forceinline__ void node_grad_body(const BlkView* __restrict__ tab, 
     }
 }
 
+template <bool XN>
 __global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView* __restrict__ tab, int nzb, double gam)
 {
     __shared__ double xr[2 * NG_BY * NG_SLOT];            // [parity][row slot 0..3 = cell rows j0+1 .. j0+4][value][lane]
-    node_grad_body(tab, nzb, gam, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, xr);
+    node_grad_body<XN>(tab, nzb, gam, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, xr);
 }
 
 // ---------------------------------------------------------------------------
@@ -443,7 +517,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView
 #include "kernels_roe_march.hip"
 #define MIX_LDS ((2 * RM_XJ) > (2 * NG_BY * NG_SLOT) ? (2 * RM_XJ) : (2 * NG_BY * NG_SLOT))
 
-template <int LIM>
+template <int LIM, bool XN>
 __global__ __launch_bounds__(256, 2) void k_roe_grad_mix(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, int nR, KParams kp,
                                                          int kch, int gx, int gy, int nG, int nzb)
 {
@@ -455,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void k_roe_grad_mix(const BlkView* __restri
         roe_march_body<LIM, false, false>(tab, tiles, kp, kch, a0, lds);
     } else {
         const int g = (int)bq - a0;          // gradient tiles before this block
-        node_grad_body(tab, nzb, kp.gammaConstant, g % gx, (g / gx) % gy, g / (gx * gy), lds);
+        node_grad_body<XN>(tab, nzb, kp.gammaConstant, g % gx, (g / gx) % gy, g / (gx * gy), lds);
     }
 }
 
@@ -577,6 +651,8 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
     NgPtrs mx;                                            // record of the cell row above the tile (wave 0): plain loads
     mx.w0 = m.w0; mx.w1 = m.w1; mx.w2 = m.w2; mx.w3 = m.w3; mx.p = m.p; mx.sI = m.sI; mx.sJ = m.sJ; mx.sK = m.sK; mx.vol = m.vol;
     mx.nb8 = m.nb8; mx.sj = m.sj;
+    mx.x = (GPTR(const double))b.x; mx.mfact = b.mfact;
+    const int xn = GRAD ? 0 : (kp.metricFromX & 1);       // SA-only march: face normals re-formed from the node coordinates
     GPTR(double) grad = (GPTR(double))b.grad;
     GPTR(double) dw5 = (GPTR(double))b.dw + 5 * nb;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
@@ -589,8 +665,16 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
     const bool secondOrd = (kp.orderTurb == 2) && kp.groundLevelIsOne;
     const double cb3Inv = 1.0 / kp.sa_cb3;
     double sKp[3], sKpx[3];
+    NgNodes Pn;
+    if (xn) {
+        ngx_load(mx, c - sk, Pn);
+        ngx_normal_k(mx.mfact, Pn, sKp);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * m.nb8); sKpx[d] = GRAD ? ldg(mx.sK, cx - sk + d * m.nb8) : 0.0; }
+        for (int d = 0; d < 3; ++d) sKpx[d] = 0.0;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * m.nb8); sKpx[d] = GRAD ? ldg(mx.sK, cx - sk + d * m.nb8) : 0.0; }
+    }
     // window of the own column: planes kn0-1 (SA neighbour below) and kn0; nuTilde of planes kn0-2 .. kn0+1
     const unsigned ckm2 = (kn0 >= 2) ? 2 * sk : sk;       // plane kn0-2 clamped at 0 (kn0 = 1: not read by a produced cell)
     GsCell s0 = gs_ld(m, c);
@@ -603,7 +687,14 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
         const unsigned ckp1 = (mm + 1 <= b.kb) ? sk : 0u;
         // ---- loads of this plane: the four face-normal triples, the state of the plane above, nuTilde two planes above
         double nI[3], nJm[3], nJ[3], nK[3];
-        vm_ld3(m.sI, c, m.nb8, nI); vm_ld3(m.sJ, c - ojm1, m.nb8, nJm); vm_ld3(m.sJ, c, m.nb8, nJ); vm_ld3(m.sK, c, m.nb8, nK);
+        if (xn) {
+            NgNodes Nn;
+            ngx_load(mx, c, Nn);
+            ngx_normals(mx.mfact, Pn, Nn, nI, nJm, nJ, nK);
+            Pn = Nn;
+        } else {
+            vm_ld3(m.sI, c, m.nb8, nI); vm_ld3(m.sJ, c - ojm1, m.nb8, nJm); vm_ld3(m.sJ, c, m.nb8, nJ); vm_ld3(m.sK, c, m.nb8, nK);
+        }
         const GsCell sp1 = gs_ld(m, c + ckp1);
         const double n_p2 = ldg(m.w5, c + ckp2);
         const double sKm[3] = {sKp[0], sKp[1], sKp[2]};    // sK of the plane below, before gs_record advances it
@@ -2159,9 +2250,18 @@ bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int 
     const int gx = (nx + 1 + NG_OUT - 1) / NG_OUT, gy = (ny + 1 + NG_BY - 1) / NG_BY, nG = gx * gy * nchn * nslots;
     const dim3 blk(64, 4, 1), grd(ntiles + nG);
     switch (kp.limiter) {
-    case ADFLOW_LIM_NONE: hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_NONE>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn); break;
-    case ADFLOW_LIM_VANALBADA: hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_VANALBADA>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn); break;
-    case ADFLOW_LIM_MINMOD: hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_MINMOD>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn); break;
+    case ADFLOW_LIM_NONE:
+        if (kp.metricFromX & 2) hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_NONE, true>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
+        else hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_NONE, false>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
+        break;
+    case ADFLOW_LIM_VANALBADA:
+        if (kp.metricFromX & 2) hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_VANALBADA, true>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
+        else hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_VANALBADA, false>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
+        break;
+    case ADFLOW_LIM_MINMOD:
+        if (kp.metricFromX & 2) hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_MINMOD, true>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
+        else hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_MINMOD, false>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
+        break;
     default: return false;
     }
     return true;
@@ -2189,8 +2289,12 @@ void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny,
     if (nslots <= 0) return;
     const int nzn = nz + 1;
     const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
-    hipLaunchKernelGGL(k_node_grad_march, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                       dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+    if (kp.metricFromX & 2)
+        hipLaunchKernelGGL(k_node_grad_march<true>, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+    else
+        hipLaunchKernelGGL(k_node_grad_march<false>, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
 }
 
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
@@ -2200,8 +2304,12 @@ void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz
     const int nzn = nz + 1;                              // node planes 1..kl
     if (g_viscous_tiled >= 2) {
         const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
-        hipLaunchKernelGGL(k_node_grad_march, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+        if (kp.metricFromX & 2)
+            hipLaunchKernelGGL(k_node_grad_march<true>, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                               dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+        else
+            hipLaunchKernelGGL(k_node_grad_march<false>, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
+                               dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
     } else
         hipLaunchKernelGGL(k_nodal_gradients_t, dim3((nx + 1 + VS_BX - 1) / VS_BX, (ny + 1 + VS_BY - 1) / VS_BY, nzn * nslots), blk, 0, s,
                            tab, nzn);

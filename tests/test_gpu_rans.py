@@ -106,10 +106,20 @@ def test_viscous_kernel_variants(engine):
             engine.set_tuning("sa_march", sm)
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
+        engine.set_tuning("sa_march", 1)
+        for mx in (0, 1):           # face normals from the arrays everywhere / re-formed from the nodes in the SA march only (default: both marches)
+            engine.set_tuning("metric_from_x", mx)
+            prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+            checks.check_block_res(engine, (63, 11, 35), prm, seed=20 + mx, stretch_k=2.0, holes=0.05)
+            engine.set_tuning("roe_grad_mix", 0)
+            checks.check_block_res(engine, (23, 9, 7), prm, seed=30 + mx, stretch_k=2.0)
+            engine.set_tuning("roe_grad_mix", 1)
     finally:
         engine.set_tuning("viscous_tiled", 2)
         engine.set_tuning("roe_march", 1)
         engine.set_tuning("sa_march", 1)
+        engine.set_tuning("metric_from_x", 3)
+        engine.set_tuning("roe_grad_mix", 1)
 
 
 def test_visc_wave_specialised(engine):

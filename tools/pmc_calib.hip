@@ -60,6 +60,31 @@ int main(int argc, char** argv)
         printf("copy8: reads %zu B writes %zu B per launch; copy16: the same; read5w1: reads %zu B writes %zu B\n", n * 8, n * 8,
                5 * (n / 4) * 8, (n / 4) * 8);
     }
+    if (!strcmp(mode, "bw")) {
+        // achievable HBM bandwidth of the three access shapes (hipEvent timing, 10 launches each): what "peak" means in practice
+        const size_t n = (size_t)1 << 27;
+        double *s, *d;
+        CK(hipMalloc(&s, 5 * n * sizeof(double) / 4 + n * sizeof(double)));
+        CK(hipMalloc(&d, n * sizeof(double)));
+        CK(hipMemset(s, 0, 5 * n * sizeof(double) / 4 + n * sizeof(double)));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int which = 0; which < 3; ++which) {
+            for (int it = -2; it < 10; ++it) {
+                if (it == 0) CK(hipEventRecord(e0, 0));
+                if (which == 0) hipLaunchKernelGGL(copy8, dim3(8192), dim3(256), 0, 0, d, s, n);
+                if (which == 1) hipLaunchKernelGGL(copy16, dim3(8192), dim3(256), 0, 0, (double2*)d, (const double2*)s, n / 2);
+                if (which == 2) hipLaunchKernelGGL(read5w1, dim3(8192), dim3(256), 0, 0, d, s, n / 4);
+            }
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double bytes = (which < 2) ? 16.0 * n : 6.0 * (n / 4) * 8.0;
+            printf("%s: %.3f ms per launch, %.0f GB/s (read + write)\n", which == 0 ? "copy8" : which == 1 ? "copy16" : "read5w1", ms / 10.0,
+                   bytes / (ms / 10.0 * 1e-3) / 1e9);
+        }
+    }
     if (!strcmp(mode, "probe") || !strcmp(mode, "all")) {
         const size_t n = 1 << 22;
         std::vector<double> hx(n), hr(n), hs(n);
