@@ -2238,7 +2238,10 @@ void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz
                        dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
 }
 
-int g_roe_grad_mix = 1;     // tuning "roe_grad_mix": inviscid Roe march and nodal-gradient march in one interleaved launch
+int g_roe_grad_mix = 0;     // tuning "roe_grad_mix": inviscid Roe march and nodal-gradient march in one interleaved launch.  Off since the
+                            // gradient march re-forms its normals from the nodes: the interleaved launch moves 591 B per cell against
+                            // 197 + 254 of the two kernels on separate queues (L2 shared by two access streams) and is 0.07 ms slower
+                            // (profiles/r02_af_variants.txt)
 
 // true when taken: second-order Roe upwind, fw not persistent, viscous part to follow, blocks at rest
 bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)

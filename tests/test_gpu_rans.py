@@ -111,15 +111,15 @@ def test_viscous_kernel_variants(engine):
             engine.set_tuning("metric_from_x", mx)
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=20 + mx, stretch_k=2.0, holes=0.05)
-            engine.set_tuning("roe_grad_mix", 0)
+            engine.set_tuning("roe_grad_mix", 1)      # Roe march and gradient march as one interleaved launch
             checks.check_block_res(engine, (23, 9, 7), prm, seed=30 + mx, stretch_k=2.0)
-            engine.set_tuning("roe_grad_mix", 1)
+            engine.set_tuning("roe_grad_mix", 0)
     finally:
         engine.set_tuning("viscous_tiled", 2)
         engine.set_tuning("roe_march", 1)
         engine.set_tuning("sa_march", 1)
         engine.set_tuning("metric_from_x", 3)
-        engine.set_tuning("roe_grad_mix", 1)
+        engine.set_tuning("roe_grad_mix", 0)
 
 
 def test_visc_wave_specialised(engine):

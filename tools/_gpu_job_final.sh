@@ -9,11 +9,13 @@ timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.log; tail 
 B="python bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 2 --min-seconds 0.2"
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o t -- $B > $O/${TAG}_prof.log 2>&1
 python tools/rocpd_summary.py $O/prof/t_results.db $O/${TAG}_kernel_trace.md "($TAG, git ${GIT}: $B)" | head -12
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f -o f -- $B > /dev/null 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o w -- $B > /dev/null 2>&1
+# counters per kernel: the kernels one after the other on one queue (concurrent kernels share the counters)
+BP="$B --tuning overlap=0 --tuning roe_grad_mix=0"
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f -o f -- $BP > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o w -- $BP > /dev/null 2>&1
 python tools/pmc_traffic.py bench $O/pmc_f/f_results.db $O/pmc_w/w_results.db crm_rans_sa_upwind_8x160x128x64 $O/pmc_traffic.json "${GIT:-unknown}" "profiles/${TAG}_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE -- $B)" > $O/${TAG}_pmc_traffic.txt 2>&1
 (python tools/pmc_summary.py $O/pmc_f/f_results.db; python tools/pmc_summary.py $O/pmc_w/w_results.db) | grep -v rocclr >> $O/${TAG}_pmc_traffic.txt
-timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD -d $O/pmc_sq -o s -- $B > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD -d $O/pmc_sq -o s -- $BP > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_sq/s_results.db | grep -v rocclr > $O/${TAG}_pmc_sq.txt
 B2="python bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 2 --min-seconds 0.2 --workload euler_jst_8x128"
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f2 -o f -- $B2 > /dev/null 2>&1
