@@ -377,15 +377,14 @@ int adflow_gpu_device_name(char* buf, int len)
     return 0;
 }
 
+static void free_side_buffers(void);
+
 int adflow_gpu_finalize(void)
 {
-    for (auto& kv : g_blocks) {
-        for (void* p : kv.second->allocs) (void)hipFree(p);
-        if (kv.second->jac_raw) (void)hipFree(kv.second->jac_raw);
-        for (void* p : kv.second->bc_allocs) (void)hipFree(p);
-        delete kv.second;
-    }
-    g_blocks.clear();
+    // device tables, tile tables, communication patterns, boundary plans and every block: the same path as release_all, so
+    // that an init after a finalize starts from an empty registry
+    if (g_device >= 0) (void)adflow_gpu_release_all();
+    free_side_buffers();
     if (g_events_ready) {
         for (int i = 0; i < 64; ++i) (void)hipEventDestroy(g_events[i]);
         g_events_ready = false;
@@ -394,6 +393,12 @@ int adflow_gpu_finalize(void)
         (void)hipHostFree(g_stage);
         g_stage = nullptr;
         g_stage_elems = 0;
+    }
+    if (g_streamB) {
+        (void)hipStreamDestroy(g_streamB); (void)hipStreamDestroy(g_streamC); (void)hipStreamDestroy(g_streamX);
+        (void)hipEventDestroy(g_evFork); (void)hipEventDestroy(g_evB); (void)hipEventDestroy(g_evC);
+        (void)hipEventDestroy(g_evPack); (void)hipEventDestroy(g_evComm);
+        g_streamB = g_streamC = g_streamX = nullptr;
     }
     if (g_stream) {
         (void)hipStreamDestroy(g_stream);
@@ -667,6 +672,13 @@ int adflow_gpu_wall_distance_register(int nn, int level, int sps, const int32_t*
 
 static double* g_xsurf = nullptr;
 static size_t g_xsurf_n = 0;
+
+static void free_xsurf(void)
+{
+    if (g_xsurf) (void)hipFree(g_xsurf);
+    g_xsurf = nullptr;
+    g_xsurf_n = 0;
+}
 
 // updateWallDistancesQuickly (wallDistance.F90:36-120) for every block of the level with a registered association
 int adflow_gpu_update_wall_distances(int level, const double* xSurf, int64_t n)
@@ -2719,3 +2731,20 @@ int adflow_gpu_abi_sizes2(int* bc_subface_bytes, int* comm_pattern_bytes)
 }
 
 }  // extern "C"
+
+// device buffers that outlive the blocks (vector staging, norm sums, surface nodes): released by adflow_gpu_finalize
+static void free_side_buffers(void)
+{
+    free_xsurf();
+    if (g_vec_dev) (void)hipFree(g_vec_dev);
+    g_vec_dev = nullptr;
+    g_vec_elems = 0;
+    if (g_norm_dev) (void)hipFree(g_norm_dev);
+    g_norm_dev = nullptr;
+#ifndef ADFLOW_NO_RCCL
+    if (g_nccl) (void)ncclCommDestroy(g_nccl);
+    g_nccl = nullptr;
+    g_rank = 0;
+    g_nranks = 1;
+#endif
+}

@@ -422,3 +422,19 @@ def test_update_wall_distances_quickly(hostsim_engine):
 def test_euler_wall_normal_momentum(hostsim_engine):
     import test_gpu_bc
     test_gpu_bc.test_euler_wall_normal_momentum(hostsim_engine)
+
+
+def test_finalize_then_init_starts_clean(hostsim_engine):
+    """adflow_gpu_finalize releases blocks, device tables, tile tables, communication patterns and side buffers: a second
+    adflow_gpu_init in the same process must not see anything of the first life"""
+    from adflow_amd.engine import Engine
+    from hostsim.build import build
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    checks.check_block_res(hostsim_engine, (9, 6, 5), prm, seed=41, stretch_k=2.0)
+    checks.check_nk_residual(hostsim_engine, BrickTopology(1, 1, 1, 6, 5, 4), prm, stretch_k=2.0)
+    e1 = Engine(0, _lib_path=build())          # same library instance as the fixture
+    e1.close()                                 # adflow_gpu_finalize
+    e2 = Engine(0, _lib_path=build())          # adflow_gpu_init again (left open: the fixture keeps using the library)
+    checks.check_block_res(e2, (7, 8, 6), prm, seed=42, stretch_k=2.0)
+    checks.check_nk_residual(e2, BrickTopology(1, 1, 1, 5, 6, 4), prm, stretch_k=2.0)
+    hostsim_engine.blocks.clear()
