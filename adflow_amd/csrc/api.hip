@@ -2498,12 +2498,17 @@ int for_level1_in_order(const std::function<int(Block*, long)>& fn)
     return 0;
 }
 
-int set_w_dev(const double* d_vec)
+int set_w_dev(const double* d_vec, bool withClosures = false)
 {
     const double turbFloor = 1e-6 * g_opts.wInf[5];
     LevelTab t;
     if (level_tab(1, &t)) return 1;
-    launch_set_w_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbFloor, g_stream);     // block offsets: BlkView::vecOff
+    // block offsets: BlkView::vecOff; withClosures: the closures blocketteRes would start with, in the same pass
+    if (withClosures) {
+        KParams kp = make_kparams(1, 1.0, 0);
+        launch_set_w_closures_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbFloor, kp, g_stream);
+    } else
+        launch_set_w_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbFloor, g_stream);
     return for_level1_in_order([&](Block* b, long) {
         b->ss_valid = false;
         b->etot_consistent = false;
@@ -2548,11 +2553,11 @@ static int get_vec_common(double* out, long n, double turbScale, double* sumsq2)
 int adflow_gpu_get_r_vec(double* rVec, long n, double* sumsq2) { return get_vec_common(rVec, n, g_opts.turbResScale, sumsq2); }
 int adflow_gpu_get_res(double* res, long n) { return get_vec_common(res, n, 1.0, nullptr); }
 
-static int nk_core_enqueue(void)
+static int nk_core_enqueue(bool closuresDone = false)
 {
     // blocketteRes with its default arguments (blockette.F90:130-160): exact residual,
     // flow + turbulence, no intermediate update
-    unsigned flags = ADFLOW_RES_CLOSURES | ADFLOW_RES_HALO | ADFLOW_RES_FLOW;
+    unsigned flags = (closuresDone ? 0u : ADFLOW_RES_CLOSURES) | ADFLOW_RES_HALO | ADFLOW_RES_FLOW;
     if (g_opts.equations == ADFLOW_RANS) flags |= ADFLOW_RES_TURB;
     return block_res_enqueue(1, flags);
 }
@@ -2561,8 +2566,8 @@ int adflow_gpu_nk_residual_dev(const double* d_wVec, double* d_rVec, long n)
 {
     if (need_ready()) return 1;
     if (!d_wVec || !d_rVec || n != level1_dof()) return fail("nk_residual: n=%ld but the level-1 blocks hold %ld DOF", n, level1_dof());
-    if (set_w_dev(d_wVec)) return 1;
-    if (nk_core_enqueue()) return 1;
+    if (set_w_dev(d_wVec, true)) return 1;
+    if (nk_core_enqueue(true)) return 1;
     if (get_r_dev(d_rVec, g_opts.turbResScale, nullptr)) return 1;
     return sync_and_check();
 }
@@ -2573,8 +2578,8 @@ int adflow_gpu_nk_residual(const double* wVec, double* rVec, long n)
     if (!wVec || !rVec || n != level1_dof()) return fail("nk_residual: n=%ld but the level-1 blocks hold %ld DOF", n, level1_dof());
     if (vec_reserve((size_t)n)) return 1;
     HIPCHK(hipMemcpyAsync(g_vec_dev, wVec, sizeof(double) * n, hipMemcpyHostToDevice, g_stream));
-    if (set_w_dev(g_vec_dev)) return 1;
-    if (nk_core_enqueue()) return 1;
+    if (set_w_dev(g_vec_dev, true)) return 1;
+    if (nk_core_enqueue(true)) return 1;
     if (get_r_dev(g_vec_dev, g_opts.turbResScale, nullptr)) return 1;
     HIPCHK(hipMemcpyAsync(rVec, g_vec_dev, sizeof(double) * n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));

@@ -324,6 +324,8 @@ void launch_get_r(const BlkView& b, double* vec, double turbScale, double* sums,
 void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 // level-batched forms (blockIdx.z = slot * planes + plane): one launch for every block of a level
 void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
+void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
+                                 const KParams& kp, hipStream_t s);
 void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s);
 void launch_get_r_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double* vec, double turbScale, double* sums, hipStream_t s);
 void launch_entropy_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s);

@@ -123,6 +123,16 @@ __device__ __forceinline__ void closures_body(const BlkView& b, int kz, const KP
 
 __global__ __launch_bounds__(NK_BX* NK_BY) void k_closures(BlkView b, KParams kp) { closures_body(b, (int)blockIdx.z, kp); }
 
+// setW followed by the closures of blocketteRes in one pass (FormFunction_mf: NKSolvers.F90:437-461 -> blockette.F90:199-203):
+// each thread reads back only what it wrote itself
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_set_w_closures_level(const BlkView* __restrict__ tab, int nzb, const double* __restrict__ vec,
+                                                                       double turbFloor, KParams kp)
+{
+    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    set_w_body(b, (int)(blockIdx.z % nzb), vec + b.vecOff, turbFloor);
+    closures_body(b, (int)(blockIdx.z % nzb), kp);
+}
+
 __global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_level(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
     closures_body(tab[blockIdx.z / nzb + 1], (int)(blockIdx.z % nzb), kp);
@@ -138,6 +148,13 @@ void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny,
 {
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_closures_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp);
+}
+void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
+                                 const KParams& kp, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_set_w_closures_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, vec, turbFloor,
+                       kp);
 }
 void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s)
 {
