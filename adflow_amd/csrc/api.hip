@@ -70,9 +70,9 @@ struct Block {
     std::vector<void*> bc_allocs;   // device copies of the BCData members: replaced at every bc_register
     int nViscBocos = 0;
     // coloured finite-difference Jacobian (adflow_gpu_fd_jacobian): reference state / residual, stencil blocks
-    double *wref = nullptr, *dwref = nullptr, *jac = nullptr;
-    void* jac_raw = nullptr;
-    int jac_ncomp = 0;
+    double *wref = nullptr, *dwref = nullptr, *jac = nullptr, *snap = nullptr;
+    void *jac_raw = nullptr, *snap_raw = nullptr;
+    int jac_ncomp = 0, snap_ncomp = 0;
     // wall association of updateWallDistancesQuickly: surfNodeIndices (4,nx,ny,nz), uv (2,nx,ny,nz)
     int* wd_ind = nullptr;
     double* wd_uv = nullptr;
@@ -248,6 +248,7 @@ int copy_box(Block* b, double* dev, const double* host_c, int ncomp, int lo_i, i
 }
 
 int g_lumped = 0;       // inputDiscretization::lumpedDiss while a preconditioner matrix is assembled
+int g_visc_approx_march = 1;   // tuning "visc_approx_march": 0 = the gather kernel k_viscous_approx per block
 int g_metric_from_x = 3;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march re-form the face normals from the node coordinates
 
 KParams make_kparams(int level, double rFil, int fwMode)
@@ -544,6 +545,7 @@ int adflow_gpu_block_release(int nn, int level, int sps)
     bc_plan_drop(level);
     for (void* p : it->second->allocs) (void)hipFree(p);
     if (it->second->jac_raw) (void)hipFree(it->second->jac_raw);
+    if (it->second->snap_raw) (void)hipFree(it->second->snap_raw);
     for (void* p : it->second->bc_allocs) (void)hipFree(p);
     delete it->second;
     g_blocks.erase(it);
@@ -558,6 +560,7 @@ int adflow_gpu_release_all(void)
     for (auto& kv : g_blocks) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
         if (kv.second->jac_raw) (void)hipFree(kv.second->jac_raw);
+        if (kv.second->snap_raw) (void)hipFree(kv.second->snap_raw);
         for (void* p : kv.second->bc_allocs) (void)hipFree(p);
         delete kv.second;
     }
@@ -955,16 +958,22 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     phase_mark(4);
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
     const bool batched = !viscApprox && viscous_is_tiled();
+    // thin-layer viscous flux of the preconditioner assembly: marching form over the tile table (blocks at rest, 4-row tiles)
+    const bool approxMarch = viscApprox && g_visc_approx_march && viscous_is_tiled() >= 2 && g_march_by == 4 && !anyMoving;
     rc = for_level(level, [&](Block* b) {
         if (!b->face_vectors_valid) {
             launch_face_vectors(b->v, g_stream);
             b->face_vectors_valid = true;
         }
-        if (viscApprox) launch_viscous_approx(b->v, kp, g_stream);   // viscousFluxApprox instead of gradients + viscousFlux
-        else if (!batched) launch_viscous(b->v, kp, g_stream);
+        if (viscApprox && !approxMarch) launch_viscous_approx(b->v, kp, g_stream);   // viscousFluxApprox instead of gradients + viscousFlux
+        else if (!viscApprox && !batched) launch_viscous(b->v, kp, g_stream);
         return 0;
     });
     if (rc) return rc;
+    if (approxMarch) {
+        if (ensure_tiles(level)) return 1;
+        launch_visc_march_approx(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
+    }
     if (batched && viscWs) {
         // wave-specialised fused kernel over the level's tile table: gradient waves and face waves in one workgroup
         phase_mark(5);
@@ -1273,6 +1282,15 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
             b->jac_ncomp = ncomp;
         }
         HIPCHK(hipMemsetAsync(b->jac_raw, 0, (size_t)b->v.nbox * ncomp * sizeof(double) + 256, g_stream));
+        // the finite differences of the nColour evaluations of one state variable, scattered into the blocks once per variable
+        const int nsnap = J.cn * J.nState;
+        if (b->snap_ncomp != nsnap) {
+            if (b->snap_raw) HIPCHK(hipFree(b->snap_raw));
+            b->snap_raw = nullptr; b->snap = nullptr; b->snap_ncomp = 0;
+            HIPCHK(hipMalloc(&b->snap_raw, (size_t)b->v.nbox * nsnap * sizeof(double) + 256));
+            b->snap = (double*)b->snap_raw + ADF_PAD0;
+            b->snap_ncomp = nsnap;
+        }
         return 0;
     });
     if (rc) return rc;
@@ -1316,19 +1334,25 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
         return 0;
     });
     const double deltaInv = 1.0 / delta;
-    for (int col = 0; col < J.cn && !rc; ++col) {
-        for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
-            const KParams kpc = make_kparams(level, 1.0, 0);
+    // the reference loops colours outside and state variables inside; every (colour, variable) evaluation is independent, so the
+    // loops are exchanged here: the nColour evaluations of one variable are kept (dense) and scattered into the blocks together
+    const KParams kpc = make_kparams(level, 1.0, 0);
+    for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
+        for (int col = 0; col < J.cn && !rc; ++col) {
             rc = for_level(level, [&](Block* b) {
                 launch_fd_state_closures(b->v, b->wref, l, col, J, delta, kpc, g_stream);
                 return 0;
             });
             if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC, true);
             if (!rc) rc = for_level(level, [&](Block* b) {
-                launch_fd_extract(b->v, b->dwref, b->jac, l, col, J, deltaInv, g_opts.turbResScale, g_stream);
+                launch_fd_snap(b->v, b->dwref, b->snap + (size_t)col * J.nState * b->v.nbox, J, deltaInv, g_opts.turbResScale, g_stream);
                 return 0;
             });
         }
+        if (!rc) rc = for_level(level, [&](Block* b) {
+            launch_fd_scatter(b->v, b->snap, b->jac, l, J, g_stream);
+            return 0;
+        });
     }
     // resetFDReference (adjointUtils.F90:2026-2058): w back, dw = the (scaled) reference residual
     if (!rc) rc = for_level(level, [&](Block* b) {
@@ -2697,6 +2721,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }
     if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
     if (!strcmp(key, "visc_ws")) { g_visc_ws = value; return 0; }
+    if (!strcmp(key, "visc_approx_march")) { g_visc_approx_march = value; return 0; }
     if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {

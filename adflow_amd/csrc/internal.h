@@ -261,6 +261,8 @@ struct JacSpec {
 void launch_fd_state(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, hipStream_t s);
 void launch_fd_state_closures(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, const KParams& kp,
                               hipStream_t s);
+void launch_fd_snap(const BlkView& b, const double* dwref, double* snap, const JacSpec& J, double deltaInv, double turbResScale, hipStream_t s);
+void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, hipStream_t s);
 void launch_fd_copy(const BlkView& b, double* dst, const double* src, int ncomp, hipStream_t s);
 void launch_closures_halo(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int col, const JacSpec& J, double deltaInv, double turbResScale,
@@ -278,6 +280,7 @@ void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny,
 bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void launch_visc_ws(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s);
 extern int g_visc_ws;
 void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

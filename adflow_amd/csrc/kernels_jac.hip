@@ -96,8 +96,8 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_closures_halo(BlkView b, KPara
     closures_halo_at(b, kp, i, j, k, c, wv);
 }
 
-// owned cells: resScale (dw / volRef, turbulence * turbResScale), then either store the reference (l = -1) or the finite
-// differences of the column l of every stencil block whose source cell has colour `col`
+// owned cells: resScale (dw / volRef, turbulence * turbResScale) and store the reference residual (l = -1), or put it back into dw
+// (l = -2, resetFDReference)
 __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_extract(BlkView b, double* __restrict__ dwref, double* __restrict__ jac, int l, int col,
                                                              JacSpec J, double deltaInv, double turbResScale)
 {
@@ -121,19 +121,53 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_extract(BlkView b, double* 
         for (int m = 0; m < J.nState; ++m) b.dw[c + (J.lStart + m) * nb] = dwref[c + m * nb];
         return;
     }
+}
+
+// finite differences of ONE coloured evaluation, stored densely: snap[m] = (resScale(dw)[m] - dwref[m]) / delta on the owned cells.
+// The scatter into the stencil blocks happens once per state variable (k_fd_scatter): written per evaluation, every cell has ONE
+// matching stencil entry and consecutive lanes hit different entries -- 1/nColour-dense 8-byte stores into nStencil separate
+// streams ran at 0.3 TB/s (200 us per 1.3 M-cell block and evaluation, profiles/r02_ah)
+__global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_snap(BlkView b, const double* __restrict__ dwref, double* __restrict__ snap, JacSpec J,
+                                                          double deltaInv, double turbResScale)
+{
+    const int i = blockIdx.x * JC_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * JC_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
+    const double ovol = 1.0 / b.volRef[c];
+    for (int m = 0; m < J.nState; ++m) {
+        const int ll = J.lStart + m;
+        const double val = b.dw[c + ll * nb] * ovol * (ll >= 5 ? turbResScale : 1.0);
+        snap[c + m * nb] = (val - dwref[c + m * nb]) * deltaInv;
+    }
+}
+
+// column l of every stencil block of the owned cells from the nColour snapshots of that state variable: entry s of the row cell
+// takes the snapshot of the colour of its source cell row - offset(s)
+__global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_scatter(BlkView b, const double* __restrict__ snap, double* __restrict__ jac, int l,
+                                                             JacSpec J)
+{
+    const int i = blockIdx.x * JC_BX + threadIdx.x + 2;
+    const int j = blockIdx.y * JC_BY + threadIdx.y + 2;
+    const int k = blockIdx.z + 2;
+    if (i > b.il || j > b.jl) return;
+    const long c = b.idx(i, j, k);
+    const long nb = b.nbox;
     const bool linear = (J.cm == J.cn);
     const int c0 = jc_colour(J, i, j, k);
     for (int s = 0; s < J.nStencil; ++s) {
         const int pi = i - J.st[s][0], pj = j - J.st[s][1], pk = k - J.st[s][2];      // the perturbed cell
         if (pi < 0 || pi > b.ib || pj < 0 || pj > b.jb || pk < 0 || pk > b.kb) continue;
+        int d;
         if (linear) {
-            // colour(p) = colour(row) - (ca di + cb dj + cc dk)  (mod cn); J.sc[s] holds the second term reduced to 0..cn-1
-            int d = c0 - J.sc[s];
+            d = c0 - J.sc[s];
             if (d < 0) d += J.cn;
-            if (d != col) continue;
-        } else if (jc_colour(J, pi, pj, pk) != col) continue;
-        for (int m = 0; m < J.nState; ++m)
-            jac[c + ((long)(s * J.nState + (l - J.lStart)) * J.nState + m) * nb] = (val[m] - dwref[c + m * nb]) * deltaInv;
+        } else
+            d = jc_colour(J, pi, pj, pk);
+        const double* __restrict__ src = snap + (long)d * J.nState * nb + c;
+        for (int m = 0; m < J.nState; ++m) jac[c + ((long)(s * J.nState + (l - J.lStart)) * J.nState + m) * nb] = src[m * nb];
     }
 }
 
@@ -163,4 +197,13 @@ void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int 
                        hipStream_t s)
 {
     hipLaunchKernelGGL(k_fd_extract, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, dwref, jac, l, col, J, deltaInv, turbResScale);
+}
+
+void launch_fd_snap(const BlkView& b, const double* dwref, double* snap, const JacSpec& J, double deltaInv, double turbResScale, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fd_snap, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, dwref, snap, J, deltaInv, turbResScale);
+}
+void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fd_scatter, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, snap, jac, l, J);
 }

@@ -68,6 +68,10 @@ struct RmK {              // uniform scalars of a launch
 template <int LIM>
 __device__ __forceinline__ void rm_recon1(const RmK& K, double qm, double q0, double qp, double& plus, double& minus)
 {
+    if (LIM == ADFLOW_LIM_FIRST_ORDER) {          // the cell value on both faces (lumped dissipation of the preconditioner, fluxes.F90:1536)
+        plus = q0; minus = q0;
+        return;
+    }
     const double dm = q0 - qm, dp = qp - q0;
     double A, B;
     if (LIM == ADFLOW_LIM_NONE) {
@@ -405,13 +409,15 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
 // true when the launch was taken: second-order Roe upwind on the fine level of blocks at rest
 bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
-    if (!g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid || kp.dissApprox || kp.lumpedDiss) return false;
+    // (the approximate residual changes the Roe scheme only through the limiter: lumpedDiss = first order)
+    if (!g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid) return false;
     if (ntiles <= 0) return true;
-    switch (kp.limiter) {
+    switch (kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter) {
+    case ADFLOW_LIM_FIRST_ORDER: launch_rm<ADFLOW_LIM_FIRST_ORDER>(tab, tiles, ntiles, kp, s); return true;
     case ADFLOW_LIM_NONE: launch_rm<ADFLOW_LIM_NONE>(tab, tiles, ntiles, kp, s); return true;
     case ADFLOW_LIM_VANALBADA: launch_rm<ADFLOW_LIM_VANALBADA>(tab, tiles, ntiles, kp, s); return true;
     case ADFLOW_LIM_MINMOD: launch_rm<ADFLOW_LIM_MINMOD>(tab, tiles, ntiles, kp, s); return true;
-    default: return false;      // first order: k_inviscid_march
+    default: return false;
     }
 }
 #endif   // ADF_ROE_BODY_ONLY

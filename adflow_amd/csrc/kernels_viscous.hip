@@ -1406,11 +1406,14 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gs[12], const
 
 // SB: scheduling fences between the face blocks (limits how far the compiler hoists the loads of later faces: fewer live
 // registers, less latency overlap) -- tuning "visc_sb"
-template <bool QCR, int SB>
+// APPROX: viscousFluxApprox (fluxes.F90:3487-3859), the thin-layer form of the preconditioner assembly: the face gradient is the
+// difference of the two cell values along the centre-to-centre vector, i.e. the formulas below with the nodal gradients set to
+// zero -- no gradient loads, no LDS ring
+template <bool QCR, int SB, bool APPROX = false>
 __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                               int kch)
 {
-    __shared__ double gx[2 * (VM_BY + 1) * VM_G];      // [parity][node row slot 0..4 = rows j0-1 .. j0+3][component][lane]
+    __shared__ double gx[APPROX ? 1 : 2 * (VM_BY + 1) * VM_G];      // [parity][node row slot 0..4 = rows j0-1 .. j0+3][component][lane]
     __shared__ double qx[VM_BY * 6 * 64];               // state of the own cell of every row, for the rows above and below
     const int4 t = tiles[blockIdx.x];
     if (t.x < 0) return;
@@ -1442,7 +1445,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
     const double gam = kp.gammaConstant;
 
     // node plane k0-1 -> LDS buffer 1 (the march starts with buffer 0); cell planes k0-1 and k0 of the own column
-    {
+    if (!APPROX) {
         double* __restrict__ xp = gx + (VM_BY + 1) * VM_G;
 #pragma unroll
         for (int q = 0; q < 12; ++q) xp[(row + 1) * VM_G + q * 64 + lane] = ldg(grad, c - sk + q * nb8);
@@ -1460,21 +1463,27 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
         const double* __restrict__ xp = gx + (VM_BY + 1) * VM_G;
         double gs[12], nK[3], dKv[3];
 #pragma unroll
-        for (int q = 0; q < 12; ++q) { const double s = xp[(row + 1) * VM_G + q * 64 + lane] + xp[row * VM_G + q * 64 + lane]; gs[q] = s + lane_up1(s); }
+        for (int q = 0; q < 12; ++q) {
+            if (APPROX) { gs[q] = 0.0; continue; }
+            const double s = xp[(row + 1) * VM_G + q * 64 + lane] + xp[row * VM_G + q * 64 + lane];
+            gs[q] = s + lane_up1(s);
+        }
         vm_ld3(sK, c - sk, nb8, nK); vm_ld3(dK, c - sk, nb8, dKv);
         vm_face<QCR>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), fk);
     }
     for (int k = k0; k <= k1; ++k) {
-        double* __restrict__ xb = gx + ((k - k0) & 1) * ((VM_BY + 1) * VM_G);               // node plane k
-        const double* __restrict__ xp = gx + ((k - k0 + 1) & 1) * ((VM_BY + 1) * VM_G);     // node plane k-1
+        double* __restrict__ xb = gx + (APPROX ? 0 : ((k - k0) & 1) * ((VM_BY + 1) * VM_G));               // node plane k
+        const double* __restrict__ xp = gx + (APPROX ? 0 : ((k - k0 + 1) & 1) * ((VM_BY + 1) * VM_G));     // node plane k-1
         // ---- own node of plane k -> LDS; row 0 also fetches the node row below the tile.  Both node planes stay in LDS and
         //      every face reads its four nodes from there (carried in registers they push the kernel over the 256 VGPRs of
         //      two waves per SIMD and the spills serialise the loads)
+        if (!APPROX) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) xb[(row + 1) * VM_G + q * 64 + lane] = ldg(grad, c + q * nb8);
-        if (row == 0) {
+            for (int q = 0; q < 12; ++q) xb[(row + 1) * VM_G + q * 64 + lane] = ldg(grad, c + q * nb8);
+            if (row == 0) {
 #pragma unroll
-            for (int q = 0; q < 12; ++q) xb[q * 64 + lane] = ldg(grad, c - sj + q * nb8);
+                for (int q = 0; q < 12; ++q) xb[q * 64 + lane] = ldg(grad, c - sj + q * nb8);
+            }
         }
         // the state of the j neighbours comes from the neighbouring rows through LDS (as plain loads they miss L2: 14 of the
         // 60 loads per cell went to HBM); only the rows outside the tile are loaded
@@ -1498,7 +1507,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
             double gs[12], nJ[3], dJv[3], f[4];
             const VmCell qjm = (row > 0) ? row_state(row - 1) : vm_ld(m, c - sj, gam, K.eddy);
 #pragma unroll
-            for (int q = 0; q < 12; ++q) { const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
+            for (int q = 0; q < 12; ++q) { if (APPROX) { gs[q] = 0.0; continue; } const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
             vm_ld3(sJ, c - sj, nb8, nJ); vm_ld3(dJ, c - sj, nb8, dJv);
             vm_face<QCR>(K, gs, qjm, q0, nJ, dJv, flg_porJ(flags[(c - sj) >> 3]), f);
 #pragma unroll
@@ -1509,7 +1518,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
         {
             double gs[12], nI[3], dIv[3], f[4];
 #pragma unroll
-            for (int q = 0; q < 12; ++q) gs[q] = (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
+            for (int q = 0; q < 12; ++q) gs[q] = APPROX ? 0.0 : (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
             vm_ld3(sI, c, nb8, nI); vm_ld3(dI, c, nb8, dIv);
             const VmCell qR = vm_dn1(q0);
             vm_face<QCR>(K, gs, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
@@ -1522,7 +1531,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
             double gs[12], nJ[3], dJv[3], f[4];
             const VmCell qjp = (row < VM_BY - 1) ? row_state(row + 1) : vm_ld(m, c + sj, gam, K.eddy);
 #pragma unroll
-            for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
+            for (int q = 0; q < 12; ++q) { if (APPROX) { gs[q] = 0.0; continue; } const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
             vm_ld3(sJ, c, nb8, nJ); vm_ld3(dJ, c, nb8, dJv);
             vm_face<QCR>(K, gs, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), f);
 #pragma unroll
@@ -1533,7 +1542,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
         {
             double gs[12], nK[3], dKv[3], f[4];
 #pragma unroll
-            for (int q = 0; q < 12; ++q) { const double s = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
+            for (int q = 0; q < 12; ++q) { if (APPROX) { gs[q] = 0.0; continue; } const double s = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
             vm_ld3(sK, c, nb8, nK); vm_ld3(dK, c, nb8, dKv);
             vm_face<QCR>(K, gs, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), f);
 #pragma unroll
@@ -2196,6 +2205,13 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
 int g_visc_sb = 0;
 
 // marching face-flux kernel over the tile table of the level (tuning viscous_tiled >= 2)
+// viscousFluxApprox of every block of the level (thin-layer form, no nodal gradients)
+void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL((k_visc_march<false, 0, true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
+}
+
 void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;

@@ -22,7 +22,7 @@ def test_euler_matrix_block_res(engine, dims):
     checks.check_block_res(engine, dims, FlowParams(spaceDiscr=dissMatrix, vis4=0.1), seed=sum(dims))
 
 
-@pytest.mark.parametrize("lim", [vanAlbeda, minmod, noLimiter])
+@pytest.mark.parametrize("lim", [vanAlbeda, minmod, noLimiter, 1])     # 1 = firstOrder limiter on the fine grid
 def test_euler_upwind_block_res(engine, lim):
     checks.check_block_res(engine, (24, 20, 10), FlowParams(spaceDiscr=upwind, limiter=lim), seed=lim)
 

@@ -32,6 +32,14 @@ def test_rans_sa_options(engine):
     checks.check_block_res(engine, (17, 9, 5), prm, seed=8, stretch_k=2.0)
 
 
+def test_north_star_block_vs_reference_default_path(engine):
+    """ONE block of BASELINE configs[3] at full size (160 x 128 x 64, RANS-SA, Roe upwind, van Albada) with the flags the bench
+    times (updateIntermed = F) against the reference's default residual path blocketteResCore (blockette.F90:299-753)"""
+    from adflow_amd.params import vanAlbeda
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda)
+    checks.check_block_res_vs_blockette(engine, (160, 128, 64), prm, False, seed=44, stretch_k=3.0)
+
+
 def test_ns_rk_stage_residuals(engine):
     checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations), stretch_k=2.0)
 

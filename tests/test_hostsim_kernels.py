@@ -21,7 +21,7 @@ def test_euler_matrix(hostsim_engine):
     checks.check_block_res(hostsim_engine, (12, 10, 6), FlowParams(spaceDiscr=dissMatrix, vis4=0.1), seed=2)
 
 
-@pytest.mark.parametrize("lim", [vanAlbeda, minmod, noLimiter])
+@pytest.mark.parametrize("lim", [vanAlbeda, minmod, noLimiter, 1])     # 1 = firstOrder limiter on the fine grid
 def test_euler_upwind(hostsim_engine, lim):
     checks.check_block_res(hostsim_engine, (12, 10, 6), FlowParams(spaceDiscr=upwind, limiter=lim), seed=lim)
 
