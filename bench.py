@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+HBM_STREAM_GBS = 4900.0  # what plain streaming copies reach on the boxes of this pool (tools/pmc_calib.bin bw, profiles/r02_bw_calib.txt)
 
 WORKLOADS = {
     # BASELINE.json configs[3] (the configuration the metric is quoted on), SURVEY §8(d) rows 4a / 4b
@@ -449,7 +450,11 @@ def main():
                          "traffic": (traffic or {}).get("traffic_bytes_per_eval"), "traffic_source": traffic_src,
                          "algorithmic_bytes_per_eval": alg_bytes, "eval_ms": ev_ms, "kernels_ms": kern, "kernels_ms_sum_serial": eval_ms,
                          "dominant_kernel": dom, "dominant_kernel_ms": kern[dom], "dominant_kernel_traffic": dom_traffic,
-                         "dominant_kernel_share": kern[dom] / eval_ms},
+                         "dominant_kernel_share": kern[dom] / eval_ms,
+                         # context, not the priced peak: the streaming-copy ceiling measured on this pool and the fraction of it the
+                         # evaluation reaches for the bytes the counters say it actually moves
+                         "streaming_copy_gbs": HBM_STREAM_GBS,
+                         "traffic_gbs": ((traffic or {}).get("traffic_bytes_per_eval") or 0.0) / (ev_ms * 1e-3) / 1e9 or None},
             "whole_eval": {"event_ms_per_step": ev_ms, "overlap_gain_ms": eval_ms - ev_ms,
                            "hbm_frac": alg_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "traffic_over_algorithmic": ((traffic or {}).get("traffic_bytes_per_eval") or 0.0) / alg_bytes or None},
