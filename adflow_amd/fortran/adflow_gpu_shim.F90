@@ -241,6 +241,34 @@ module adflowGpuShim
             type(c_ptr), value :: xSurf
             integer(c_int64_t), value :: n
         end function
+        ! RCCL bootstrap (gpuCommInit below), host hooks, device-resident NK vectors, tuning
+        integer(c_int) function adflow_gpu_comm_unique_id(id128) bind(C, name="adflow_gpu_comm_unique_id")
+            import :: c_int, c_char
+            character(kind=c_char), intent(out) :: id128(128)
+        end function
+        integer(c_int) function adflow_gpu_comm_init(rank, nranks, id128) bind(C, name="adflow_gpu_comm_init")
+            import :: c_int, c_char
+            integer(c_int), value :: rank, nranks
+            character(kind=c_char), intent(in) :: id128(128)
+        end function
+        integer(c_int) function adflow_gpu_set_bc_callback(fn) bind(C, name="adflow_gpu_set_bc_callback")
+            import :: c_int, c_funptr
+            type(c_funptr), value :: fn        ! subroutine fn(level, secondHalo) bind(C), integer(c_int), value arguments
+        end function
+        integer(c_int) function adflow_gpu_set_turb_bc_callback(fn) bind(C, name="adflow_gpu_set_turb_bc_callback")
+            import :: c_int, c_funptr
+            type(c_funptr), value :: fn
+        end function
+        integer(c_int) function adflow_gpu_nk_residual_dev(wVec, rVec, n) bind(C, name="adflow_gpu_nk_residual_dev")
+            import :: c_int, c_ptr, c_long
+            type(c_ptr), value :: wVec, rVec   ! DEVICE pointers (VecHIPGetArray of PETSc vectors living on the GPU)
+            integer(c_long), value :: n
+        end function
+        integer(c_int) function adflow_gpu_set_tuning(key, value) bind(C, name="adflow_gpu_set_tuning")
+            import :: c_int, c_char
+            character(kind=c_char), intent(in) :: key(*)
+            integer(c_int), value :: value
+        end function
         ! adjointUtils::setupStateResidualMatrix (useAD = F): coloured finite-difference blocks on the device
         integer(c_int) function adflow_gpu_fd_jacobian(level, flags, delta) bind(C, name="adflow_gpu_fd_jacobian")
             import :: c_int, c_double
@@ -599,6 +627,19 @@ contains
                                                           c_loc(flowDoms(nn, level, sps)%viscSubface(mm)%q)), "gpuDownloadWallStress")
         end do
     end subroutine gpuDownloadWallStress
+
+    ! RCCL bootstrap over the reference's own MPI communicator: rank 0 draws the unique id, it travels with the existing
+    ! mpi_bcast, every rank joins.  Once, after adflow_gpu_init and before the first gpuRegisterComm with remote neighbours.
+    subroutine gpuCommInit()
+        use communication, only: adflow_comm_world, myID, nProc
+        character(kind=c_char) :: id(128)
+        integer :: ierr
+        if (nProc == 1) return
+        id = c_null_char
+        if (myID == 0) call gpuCheck(adflow_gpu_comm_unique_id(id), "gpuCommInit")
+        call mpi_bcast(id, 128, mpi_character, 0, adflow_comm_world, ierr)
+        call gpuCheck(adflow_gpu_comm_init(int(myID, c_int), int(nProc, c_int), id), "gpuCommInit")
+    end subroutine gpuCommInit
 
     ! flowDoms(nn,level,sps)%surfNodeIndices / %uv (determineWallAssociation, wallDistance.F90:1663-2002) -> device; once after
     ! computeWallDistance.  gpuUpdateWallDistances replaces the updateWallDistancesQuickly calls of a level (wallDistance.F90:36,
