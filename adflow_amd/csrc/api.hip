@@ -249,7 +249,7 @@ int copy_box(Block* b, double* dev, const double* host_c, int ncomp, int lo_i, i
 
 int g_lumped = 0;       // inputDiscretization::lumpedDiss while a preconditioner matrix is assembled
 int g_visc_approx_march = 1;   // tuning "visc_approx_march": 0 = the gather kernel k_viscous_approx per block
-int g_metric_from_x = 3;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march re-form the face normals from the node coordinates
+int g_metric_from_x = 7;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march, bit 2 the time-step kernel re-form the face normals from the node coordinates
 
 KParams make_kparams(int level, double rFil, int fwMode)
 {
@@ -1068,7 +1068,15 @@ static int block_res_enqueue(int level, unsigned flags)
     // without updateIntermed the reference's default path (blocketteResCore, blockette.F90:299-753) keeps them in the
     // blockette's private arrays: they are not an output of the evaluation.  Only scalar JST needs them (and the entropy
     // sensor the same kernel leaves in ss).
-    if (!(g_skip_unused_radii && kp.onlyRadii && kp.spaceDiscr != ADFLOW_DISS_SCALAR)) {
+    // Euler + scalar JST: the marching kernel forms the radii itself when nothing else needs them (no updateIntermed: neither the
+    // radii nor dtl are outputs, blockette.F90:660-750)
+    bool anyMovingR = false;
+    for_level(level, [&](Block* b) { anyMovingR = anyMovingR || b->v.sFace || b->v.moving; return 0; });
+    const bool radiiInMarch = g_skip_unused_radii && kp.onlyRadii && (flags & ADFLOW_RES_FLOW) && g_use_march && !kp.viscous &&
+                              kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.fineGrid && !kp.dissApprox && !anyMovingR && fabs(kp.rFil) >= 1.e-10 &&
+                              euler_march_radii_capable(kp);
+    kp.radiiInMarch = radiiInMarch ? 1 : 0;
+    if (!radiiInMarch && !(g_skip_unused_radii && kp.onlyRadii && kp.spaceDiscr != ADFLOW_DISS_SCALAR)) {
         rc = time_step_level(level, kp);
         if (rc) return rc;
     }
@@ -2721,6 +2729,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }
     if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
     if (!strcmp(key, "visc_ws")) { g_visc_ws = value; return 0; }
+    if (!strcmp(key, "euler_radii")) { g_euler_radii = value; return 0; }
     if (!strcmp(key, "visc_approx_march")) { g_visc_approx_march = value; return 0; }
     if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }

@@ -83,6 +83,7 @@ __device__ __forceinline__ double fastdiv(double a, double b) { return a * rcp_n
 __device__ __forceinline__ double fastsqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double fast_root6(double x) { return pow(x, 1.0 / 6.0); }
 __device__ __forceinline__ double fast_exp_neg(double x) { return exp(x); }
+__device__ __forceinline__ double fast_powa(double x, double a) { return pow(x, a); }
 #else
 __device__ __forceinline__ double fastsqrt(double x) { return x * rsq_nr(fmax(x, 1.e-300)); }
 // x^(1/6) for x in the normal positive range: single-precision seed of z = x^(-1/6) (v_log_f32 / v_exp_f32), two Newton steps
@@ -97,6 +98,47 @@ __device__ __forceinline__ double fast_root6(double x)
     }
     const double z2 = z * z;
     return x * (z2 * z2 * z);
+}
+// x^a for x in the normal positive range and moderate a (the directional scaling of the spectral radii, adis = 0.67 by default):
+// x = m 2^e with m in [0.707, 1.414); ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172, odd series to s^19 (truncation
+// 1e-16); 2^(a log2 x) = 2^k exp(f ln 2) with the degree-13 Taylor polynomial on |f ln 2| <= 0.347 (4e-18).  ~50 issue slots
+// instead of the ~200 of log() + exp().
+__device__ __forceinline__ double fast_powa(double x, double a)
+{
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+    if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
+    const double s = (m - 1.0) * rcp_nr(m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 19.0;
+    p = __builtin_fma(p, s2, 1.0 / 17.0);
+    p = __builtin_fma(p, s2, 1.0 / 15.0);
+    p = __builtin_fma(p, s2, 1.0 / 13.0);
+    p = __builtin_fma(p, s2, 1.0 / 11.0);
+    p = __builtin_fma(p, s2, 1.0 / 9.0);
+    p = __builtin_fma(p, s2, 1.0 / 7.0);
+    p = __builtin_fma(p, s2, 1.0 / 5.0);
+    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    p = __builtin_fma(p, s2, 1.0);
+    const double log2x = __builtin_fma(2.0 * s * p, 1.4426950408889634, (double)e);
+    const double t = a * log2x;
+    const double k = __builtin_rint(t);
+    const double r = (t - k) * 6.93147180559945309417e-01;
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, r, 1.0 / 479001600.0);
+    q = __builtin_fma(q, r, 1.0 / 39916800.0);
+    q = __builtin_fma(q, r, 1.0 / 3628800.0);
+    q = __builtin_fma(q, r, 1.0 / 362880.0);
+    q = __builtin_fma(q, r, 1.0 / 40320.0);
+    q = __builtin_fma(q, r, 1.0 / 5040.0);
+    q = __builtin_fma(q, r, 1.0 / 720.0);
+    q = __builtin_fma(q, r, 1.0 / 120.0);
+    q = __builtin_fma(q, r, 1.0 / 24.0);
+    q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.0);
+    q = __builtin_fma(q, r, 1.0);
+    return __builtin_ldexp(q, (int)k);
 }
 // exp(x) for x <= 0 (the ft2 term of Spalart-Allmaras): 0 below -700, else 2^k * P(r) with k = round(x log2 e), r = x - k ln 2
 // in two pieces, Taylor polynomial of degree 13 on |r| <= ln2 / 2 (truncation 1e-17), ldexp.  ~25 slots instead of ~60.
@@ -237,6 +279,7 @@ struct KParams {
     int fwMode;            // 0: fw not persistent (rFil==1, sfil==0, no store)  1: persistent fw
     int storeIntermed;     // store dtl / radii
     int dissApprox;        // lumped dissipation with the frozen sensor in b.ss (inviscidDissFlux*Approx)
+    int radiiInMarch;      // the Euler march forms the spectral radii itself (no k_time_step pass in front)
     int metricFromX;       // marching kernels re-form the face normals from the node coordinates (as blocketteResCore, blockette.F90:854-960)
     int lumpedDiss;        // inputDiscretization::lumpedDiss (preconditioner assembly): first-order Roe upwind (fluxes.F90:1536)
     double sigma;
@@ -281,6 +324,8 @@ bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int 
 void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+bool euler_march_radii_capable(const KParams& kp);
+extern int g_euler_radii;
 void launch_visc_ws(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s);
 extern int g_visc_ws;
 void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

@@ -283,6 +283,36 @@ __global__ __launch_bounds__(64 * EM_BY, MINW) void k_euler_march(const BlkView*
 // immediately.  The register allocator gets the full 256-VGPR budget (2 waves
 // per SIMD); latency hiding comes from the pipeline, not from occupancy.
 // ---------------------------------------------------------------------------
+// spectral radii of one cell from its state and the SUMS of its two face normals per direction: the arithmetic of k_time_step
+// (solverUtils.F90:131-199, blocks at rest), evaluated inside the march by the RADII form of the kernel below
+struct Rad3 { double rI, rJ, rK; };
+
+__device__ __forceinline__ Rad3 em_radii(const KParams& kp, const Cell& q, const double sIs[3], const double sJs[3], const double sKs[3])
+{
+    const double clim2 = 0.000001 * kp.gammaInf * kp.pInfCorr / kp.rhoInf;
+    const double cc2 = fmax(kp.gammaConstant * q.p * rcp_nr(q.rho), clim2);
+    const double si2 = sIs[0] * sIs[0] + sIs[1] * sIs[1] + sIs[2] * sIs[2];
+    const double sj2 = sJs[0] * sJs[0] + sJs[1] * sJs[1] + sJs[2] * sJs[2];
+    const double sk2 = sKs[0] * sKs[0] + sKs[1] * sKs[1] + sKs[2] * sKs[2];
+    double ri = 0.5 * (fabs(q.u * sIs[0] + q.v * sIs[1] + q.w * sIs[2]) + kp.acousticScaleFactor * fastsqrt(cc2 * si2));
+    double rj = 0.5 * (fabs(q.u * sJs[0] + q.v * sJs[1] + q.w * sJs[2]) + kp.acousticScaleFactor * fastsqrt(cc2 * sj2));
+    double rk = 0.5 * (fabs(q.u * sKs[0] + q.v * sKs[1] + q.w * sKs[2]) + kp.acousticScaleFactor * fastsqrt(cc2 * sk2));
+    Rad3 r;
+    if (kp.doScaling) {
+        // radI = ri (1 + (rj/ri)^adis + (rk/ri)^adis) etc. (solverUtils.F90:187-199): three powers of the radii themselves
+        // (fast_powa, internal.h) and three reciprocals instead of the three log + three exp of k_time_step
+        const double epsr = 1.e-25;
+        ri = fmax(ri, epsr); rj = fmax(rj, epsr); rk = fmax(rk, epsr);
+        const double x = fast_powa(ri, kp.adis), y = fast_powa(rj, kp.adis), z = fast_powa(rk, kp.adis);
+        r.rI = ri * (1.0 + (y + z) * rcp_nr(x));
+        r.rJ = rj * (1.0 + (z + x) * rcp_nr(y));
+        r.rK = rk * (1.0 + (x + y) * rcp_nr(z));
+    } else {
+        r.rI = ri; r.rJ = rj; r.rK = rk;
+    }
+    return r;
+}
+
 struct InA {      // loads of phase A of plane k (the state of cell k+1 goes straight into the window)
     double radK0;             // radK(k)
     double sKx, sKy, sKz;     // normal of the face k-1|k (stored at k-1)
@@ -310,19 +340,28 @@ __device__ __forceinline__ d2_t ldg2(GPTR(const double) base, unsigned byteoff)
     return *(GPTR(const d2_t))((GPTR(const char))base + byteoff);
 }
 
-template <bool FW, bool LDSJ, int BY>
+// RADII (with LDSJ): the spectral radii are formed inside the march instead of being read from radI/J/K (tuning "euler_radii"):
+// the radii of cell plane k+1 are computed at the end of step k -- own cell from the normals in flight plus nine loads the next
+// steps repeat anyway (L1 / L2 hits), the two waves at the tile edges also the cell of the row outside the tile -- and radJ goes
+// to the neighbouring rows through a double-buffered LDS slot behind the barrier the state ring has anyway.  Removes the
+// k_time_step pass in front of an evaluation that does not need dtl (blocketteRes without updateIntermed).
+template <bool FW, bool LDSJ, int BY, bool RADII = false>
 __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
                                                                  KParams kp, int kch)
 {
     // BY rows of cells per workgroup (4: two workgroups per CU; 8: one, with 12 instead of 2 x 8 staged rows per 8 produced)
     constexpr int EL_ROWS = BY + 4, EL_PANEL = EL_ROWS * 64, EL_SLOT = 6 * EL_PANEL;
     __shared__ __attribute__((aligned(16))) double lds[LDSJ ? 3 * EL_SLOT : 2];
+    __shared__ double rjx[RADII ? 2 * (BY + 2) * 64 : 1];       // radJ of the rows j0-1 .. j0+BY: [plane parity][row][lane]
     const int4 t = tiles[blockIdx.x];
     if (t.x < 0) return;
     const BlkView& b = tab[t.x];
     const int lane = threadIdx.x;
     const int i = t.y * EM_OUT + lane;
-    const int j = 2 + t.z * BY + (int)threadIdx.y;
+    // RADII: the waves 0 and BY-1 of a tile also form the radii of the rows outside it; every second workgroup shifts its
+    // wave -> row assignment by BY / 2 so that those waves of two co-resident workgroups sit on different SIMDs
+    const int ty = RADII ? wave_uniform((int)((threadIdx.y + (BY / 2) * (blockIdx.x & 1u)) % BY)) : (int)threadIdx.y;
+    const int j = 2 + t.z * BY + ty;
     const int k0 = 2 + t.w * kch;
     const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
     const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
@@ -349,15 +388,17 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
     const double fis2 = kp.rFil * kp.vis2, fis4 = kp.rFil * kp.vis4;
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
 
+    struct RawN { double sI[3], sJm[3], sJ[3], sKm[3], sK[3]; };     // RADII: normals requested for the radii of the next plane
+    RawN rawOwn, rawEdge;
     InA a;
     // phase-A loads of the plane at byte offset cc; the state of the cell above it lands in `up`
     auto loadA = [&](unsigned cc, Cell& up) {
         if (!LDSJ) up = ld_cell(m, cc + sk);
         a.flag0 = flags[cc >> 3];
-        a.radK0 = ldg(radK, cc);
+        if (!RADII) a.radK0 = ldg(radK, cc);
         a.sKx = ldg(sKx, cc - sk); a.sKy = ldg(sKy, cc - sk); a.sKz = ldg(sKz, cc - sk);
         a.sIx = ldg(sIx, cc - 8u); a.sIy = ldg(sIy, cc - 8u); a.sIz = ldg(sIz, cc - 8u);
-        a.radI0 = ldg(radI, cc);
+        if (!RADII) a.radI0 = ldg(radI, cc);
         if (FW) {
 #pragma unroll
             for (int l = 0; l < 5; ++l) a.fwOld[l] = ldg(fw + l * nb, cc - sk);
@@ -371,13 +412,12 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
         q.flagJm = flags[(cc - sj) >> 3];
         q.sMx = ldg(sJx, cc - sj); q.sMy = ldg(sJy, cc - sj); q.sMz = ldg(sJz, cc - sj);
         q.sPx = ldg(sJx, cc); q.sPy = ldg(sJy, cc); q.sPz = ldg(sJz, cc);
-        q.rJm = ldg(radJ, cc - sj); q.rJ0 = ldg(radJ, cc); q.rJp = ldg(radJ, cc + sj);
+        if (!RADII) { q.rJm = ldg(radJ, cc - sj); q.rJ0 = ldg(radJ, cc); q.rJp = ldg(radJ, cc + sj); }
     };
 
     // ---- LDS ring (LDSJ): slot of plane k0+n is n % 3.  This wave stages rows 2*ty and
     //      2*ty+1 of the 8-row panel: lanes 0-31 the first, lanes 32-63 the second row,
     //      two adjacent cells per lane.
-    const int ty = threadIdx.y;
     const int hrow = 2 * ty + (lane >> 5), xp = 2 * (lane & 31);
     unsigned cs = 0;            // byte offset of this lane's pair in the plane being staged
     int splane = k0;            // plane index of the next staging load
@@ -415,14 +455,68 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
 
     // prologue: window k-2 .. k of the own column, phase-A loads of the first plane
     Cell S0 = ld_cell(m, c - 2 * sk), S1 = ld_cell(m, c - sk), S2 = ld_cell(m, c), S3;
-    double radKm = ldg(radK, c - sk);
+    // RADII: the face normals of a cell (sI of the face i-1|i -- the face i|i+1 comes from lane+1 --, both sJ, both sK) are requested
+    // one phase before the radii are formed from them, so that their latency hides behind the barrier and the next phase
+    auto raw_issue = [&](unsigned cc, RawN& n) {
+        n.sI[0] = ldg(sIx, cc - 8u); n.sI[1] = ldg(sIy, cc - 8u); n.sI[2] = ldg(sIz, cc - 8u);
+        n.sJm[0] = ldg(sJx, cc - sj); n.sJm[1] = ldg(sJy, cc - sj); n.sJm[2] = ldg(sJz, cc - sj);
+        n.sJ[0] = ldg(sJx, cc); n.sJ[1] = ldg(sJy, cc); n.sJ[2] = ldg(sJz, cc);
+        n.sKm[0] = ldg(sKx, cc - sk); n.sKm[1] = ldg(sKy, cc - sk); n.sKm[2] = ldg(sKz, cc - sk);
+        n.sK[0] = ldg(sKx, cc); n.sK[1] = ldg(sKy, cc); n.sK[2] = ldg(sKz, cc);
+    };
+    auto raw_radii = [&](const RawN& n, const Cell& q) {
+        double sIs[3], sJs[3], sKs[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sIs[d] = n.sI[d] + lane_dn1(n.sI[d]); sJs[d] = n.sJm[d] + n.sJ[d]; sKs[d] = n.sKm[d] + n.sK[d]; }
+        return em_radii(kp, q, sIs, sJs, sKs);
+    };
+    // offsets of the cells of the rows outside the tile (clamped like the staged rows), same column and plane as c
+    const int jlo = 1 + t.z * BY, jhi_ = 2 + t.z * BY + BY;                    // j0 - 1, j0 + BY
+    const unsigned cLo = 8u * (unsigned)(ic + ((jlo < b.jb) ? jlo : b.jb) * b.ldi + k0 * b.ldk);
+    const unsigned cHi = 8u * (unsigned)(ic + ((jhi_ < b.jb) ? jhi_ : b.jb) * b.ldi + k0 * b.ldk);
+    // the own cell at its TRUE row (clamped at the end of the box only: a row beyond jl still publishes the radJ of the real cell
+    // je, which the row below needs for its upper face), state from the ring
+    const unsigned cOwn = 8u * (unsigned)(ic + ((j < b.jb) ? j : b.jb) * b.ldi + k0 * b.ldk);
+    const unsigned cEdge = (ty == 0) ? cLo : cHi;          // the row outside the tile this wave looks after (waves 0 and BY-1)
+    const bool edgeWave = (ty == 0 || ty == BY - 1);
+    const int edgeRowSlot = (ty == 0) ? 1 : BY + 2, edgeOut = (ty == 0) ? 0 : BY + 1;
+    int pl = 0;                      // current plane relative to k0
+    auto radii_issue = [&](int q) {
+        const unsigned koff = (unsigned)q * sk;
+        raw_issue(cOwn + koff, rawOwn);
+        if (edgeWave) raw_issue(cEdge + koff, rawEdge);
+    };
+    // radii of plane k0 + q from the requested normals and the state ring slot of that plane: own row -> `own` and rjx slot ty + 1;
+    // waves 0 / BY-1 also the row outside the tile.  (BY = 1 is not instantiated: one wave would own both outside rows.)
+    auto radii_finish = [&](int q, int slotPlane, Rad3& own) {
+        const int par = q & 1;
+        own = raw_radii(rawOwn, lds_cell(slotPlane, ty + 2));
+        rjx[(par * (BY + 2) + ty + 1) * 64 + lane] = own.rJ;
+        if (edgeWave) rjx[(par * (BY + 2) + edgeOut) * 64 + lane] = raw_radii(rawEdge, lds_cell(slotPlane, edgeRowSlot)).rJ;
+    };
+    Rad3 Rcur;                       // RADII: radii of the own cell at the current plane
+    Rcur.rI = Rcur.rJ = Rcur.rK = 0.0;
+    double radKm = 0.0;
+    if (RADII) {
+        RawN n;
+        raw_issue(c - sk, n);
+        radKm = raw_radii(n, S1).rK;
+    } else
+        radKm = ldg(radK, c - sk);
     int flagm = flags[(c - sk) >> 3];
     if (LDSJ) {
         stage_load(); stage_store(0);
         stage_load(); stage_store(1);
         stage_load();                 // plane k0+2: stays in flight until the first step stores it
     }
+    if (RADII) radii_issue(0);
     loadA(c, S3);
+    Rad3 Rnext = Rcur;
+    if (RADII) {
+        __syncthreads();              // plane k0 of the state ring is complete
+        radii_finish(0, 0, Rcur);
+        radii_issue(1);               // plane k0+1: formed during the first step
+    }
     if (LDSJ) {
         __syncthreads();
         S3 = lds_cell(1, ty + 2);
@@ -438,7 +532,7 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
         const int por = flg_porK((uint8_t)flagm);
         em_central(qm1, q0, a.sKx, a.sKy, a.sKz, por, fc);
         if (doDiss) {
-            const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * (radKm + a.radK0);
+            const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * (radKm + (RADII ? Rcur.rK : a.radK0));
             em_jst(cons_of(qm2), cons_of(qm1), cons_of(q0), cons_of(qp1), rrad, dssKm, dssK0, fis2, fis4, fd);
         }
         if (store && out) {
@@ -470,12 +564,15 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
             stage_load();             // plane k+3
         }
         loadB(c, q);
+        // RADII: radii of plane k+1 from the normals requested at the end of the previous step (state: ring slot of plane k+1);
+        // radJ goes to the other parity of rjx, read by the next step behind the barrier that closes this one
+        if (RADII) radii_finish(pl + 1, sl1, Rnext);
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= phase A(k) =================
         kface(!first, qm2, qm1, q0, qp1);
         const int flag0 = a.flag0;
-        const double radK0 = a.radK0;
+        const double radK0 = RADII ? Rcur.rK : a.radK0;
         {
             const Cell qL = shfl_cell_up(q0, 1);
             const Cons W0 = cons_of(q0);
@@ -490,7 +587,7 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
                 const double pR = lane_dn1(q0.p);
                 const double d0 = em_sensor(qL.p, q0.p, pR, sslim);
                 const double dL = lane_up1(d0);
-                const double rad0 = a.radI0;
+                const double rad0 = RADII ? Rcur.rI : a.radI0;
                 const double radL = lane_up1(rad0);
                 const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * (radL + rad0);
                 em_jst(WLL, WL, W0, WR, rrad, dL, d0, fis2, fis4, gd);
@@ -530,6 +627,12 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
             if (doDiss) {
                 const double dm = em_sensor(q.qa.p, q.qb.p, q0.p, sslim), d0 = em_sensor(q.qb.p, q0.p, q.qc.p, sslim),
                              dp = em_sensor(q0.p, q.qc.p, q.qd.p, sslim);
+                if (RADII) {
+                    const int par = pl & 1;
+                    q.rJm = rjx[(par * (BY + 2) + ty) * 64 + lane];
+                    q.rJ0 = Rcur.rJ;
+                    q.rJp = rjx[(par * (BY + 2) + ty + 2) * 64 + lane];
+                }
                 const double rrM = (porM == ADF_POR_NORMAL ? 0.5 : 0.0) * (q.rJm + q.rJ0);
                 const double rrP = (porP == ADF_POR_NORMAL ? 0.5 : 0.0) * (q.rJ0 + q.rJp);
                 const Cons Wa = cons_of(q.qa), Wb = cons_of(q.qb), W0 = cons_of(q0), Wc = cons_of(q.qc), Wd = cons_of(q.qd);
@@ -545,6 +648,11 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
         dssKm = dssK0;
         flagm = flag0;
         c += sk;
+        if (RADII) {
+            ++pl;
+            Rcur = Rnext;
+            radii_issue(pl + 1);      // normals of plane k+2: in flight across the barrier
+        }
         if (LDSJ) {
             // plane k+2 is complete in LDS, plane k is no longer read: its slot takes plane k+3
             __syncthreads();
@@ -562,6 +670,7 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
     kface(true, S0, S1, S2, S3);
 }
 
+int g_euler_radii = 1;          // tuning "euler_radii": the Euler march forms the spectral radii itself where nothing else needs them
 int g_march_minw = 2;
 int g_march_kch = EM_KCH;      // k-chunk length of a tile (tuning "march_kch")
 int g_march_pipe = 2;          // tuning "march_pipe": 0 plain, 1 software-pipelined, 2 pipelined + state rows shared through LDS
@@ -582,7 +691,12 @@ void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const
         } else if (g_march_pipe >= 2) {
             if (kp.fwMode)
                 hipLaunchKernelGGL((k_euler_march_p<true, true, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-            else
+            else if (kp.radiiInMarch) {
+#ifdef HOSTSIM
+                if (getenv("ADF_TRACE_WS")) fprintf(stderr, "launch_euler_march: radii inside the march, ntiles=%d\n", ntiles);
+#endif
+                hipLaunchKernelGGL((k_euler_march_p<false, true, EM_BY, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+            } else
                 hipLaunchKernelGGL((k_euler_march_p<false, true, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
         } else if (kp.fwMode)
             hipLaunchKernelGGL((k_euler_march_p<true, false, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
@@ -595,6 +709,13 @@ void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const
     } else {
         hipLaunchKernelGGL((k_euler_march<2, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
     }
+}
+
+// true when launch_euler_march would run the form of the kernel that can compute the radii itself
+bool euler_march_radii_capable(const KParams& kp)
+{
+    // fast_powa is built for moderate exponents (2^(adis log2 r) must stay far from the ends of the exponent range)
+    return g_euler_radii && g_march_pipe >= 2 && march_rows() == EM_BY && !kp.fwMode && (!kp.doScaling || (kp.adis > 0.0 && kp.adis <= 2.0));
 }
 
 // tile decomposition of one block for the table built by the host

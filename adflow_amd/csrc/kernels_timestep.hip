@@ -40,10 +40,51 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(const BlkView* __res
     double cc2 = gam * pp / rho;
     cc2 = fmax(cc2, clim2);
 
+    // sums of the two face normals of the cell in every direction: from the stored normals, or (tuning metric_from_x & 4) re-formed
+    // from the eight corner nodes with the formulas of metric_block (adjointExtra.F90:176-268) -- 24 B of coordinates per cell from
+    // HBM instead of 72 B of normals, the corner nodes are shared by eight cells
+    double sIs[3], sJs[3], sKs[3];
+    if (kp.metricFromX & 4) {
+        const long sj = b.ldi, sk = b.ldk;
+        double n[2][2][2][3];                       // [di][dj][dk]: x(i-1+di, j-1+dj, k-1+dk)
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+                for (int dk = 0; dk < 2; ++dk) {
+                    const long q = c - (1 - di) - (1 - dj) * sj - (1 - dk) * sk;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) n[di][dj][dk][d] = b.x[q + d * nb];
+                }
+        auto cross_add = [&](const double* p1, const double* p2, const double* q1, const double* q2, double* sN) {
+            const double v1x = p1[0] - p2[0], v1y = p1[1] - p2[1], v1z = p1[2] - p2[2];
+            const double v2x = q1[0] - q2[0], v2y = q1[1] - q2[1], v2z = q1[2] - q2[2];
+            sN[0] += b.mfact * (v1y * v2z - v1z * v2y);
+            sN[1] += b.mfact * (v1z * v2x - v1x * v2z);
+            sN[2] += b.mfact * (v1x * v2y - v1y * v2x);
+        };
+#pragma unroll
+        for (int d = 0; d < 3; ++d) sIs[d] = sJs[d] = sKs[d] = 0.0;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            // sI at node plane i-1+f: v1 = x(i,j,n) - x(i,m,k) ; v2 = x(i,j,k) - x(i,m,n)
+            cross_add(n[f][1][0], n[f][0][1], n[f][1][1], n[f][0][0], sIs);
+            // sJ at node row j-1+f: v1 = x(i,j,n) - x(l,j,k) ; v2 = x(l,j,n) - x(i,j,k)
+            cross_add(n[1][f][0], n[0][f][1], n[0][f][0], n[1][f][1], sJs);
+            // sK at node plane k-1+f: v1 = x(i,j,k) - x(l,m,k) ; v2 = x(l,j,k) - x(i,m,k)
+            cross_add(n[1][1][f], n[0][0][f], n[0][1][f], n[1][0][f], sKs);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            sIs[d] = b.sI[c - 1 + d * nb] + b.sI[c + d * nb];
+            sJs[d] = b.sJ[c - b.ldi + d * nb] + b.sJ[c + d * nb];
+            sKs[d] = b.sK[c - b.ldk + d * nb] + b.sK[c + d * nb];
+        }
+    }
     // i-direction: faces i-1 and i
-    double sx = b.sI[c - 1] + b.sI[c];
-    double sy = b.sI[c - 1 + nb] + b.sI[c + nb];
-    double sz = b.sI[c - 1 + 2 * nb] + b.sI[c + 2 * nb];
+    double sx = sIs[0], sy = sIs[1], sz = sIs[2];
     const double si2 = sx * sx + sy * sy + sz * sz;
     // grid velocity of a moving block: sum over the two faces (solverUtils.F90:147-181)
     double sFace = 0.0, sFaceJ = 0.0, sFaceK = 0.0;
@@ -55,16 +96,12 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(const BlkView* __res
     }
     double ri = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * si2));
 
-    sx = b.sJ[c - b.ldi] + b.sJ[c];
-    sy = b.sJ[c - b.ldi + nb] + b.sJ[c + nb];
-    sz = b.sJ[c - b.ldi + 2 * nb] + b.sJ[c + 2 * nb];
+    sx = sJs[0]; sy = sJs[1]; sz = sJs[2];
     const double sj2 = sx * sx + sy * sy + sz * sz;
     sFace = sFaceJ;
     double rj = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * sj2));
 
-    sx = b.sK[c - b.ldk] + b.sK[c];
-    sy = b.sK[c - b.ldk + nb] + b.sK[c + nb];
-    sz = b.sK[c - b.ldk + 2 * nb] + b.sK[c + 2 * nb];
+    sx = sKs[0]; sy = sKs[1]; sz = sKs[2];
     const double sk2 = sx * sx + sy * sy + sz * sz;
     sFace = sFaceK;
     double rk = 0.5 * (fabs(uux * sx + uuy * sy + uuz * sz - sFace) + kp.acousticScaleFactor * sqrt(cc2 * sk2));

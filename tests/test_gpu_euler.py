@@ -90,3 +90,32 @@ def test_actuator_regions(engine):
     checks.check_actuator_regions(engine, (70, 9, 8), FlowParams())
     checks.check_actuator_regions(engine, (24, 10, 8), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
     checks.check_actuator_regions(engine, (20, 10, 8), FlowParams(), holes=0.1)
+
+
+def test_euler_radii_inside_the_march(engine):
+    """blocketteRes with its default flags on Euler + scalar JST: the marching kernel forms the spectral radii itself (no k_time_step
+    pass).  Against the reference's default path blocketteResCore; partial tiles in i / j, two k chunks, a one-cell-thick block,
+    no directional scaling, and the separate-kernel path (tuning euler_radii = 0) on the same inputs."""
+    from adflow_amd.params import dissScalar
+    for dims in ((63, 9, 35), (124, 6, 5), (16, 8, 1)):
+        checks.check_block_res_vs_blockette(engine, dims, FlowParams(spaceDiscr=dissScalar), False, seed=sum(dims),
+                                            holes=0.05 if dims[2] > 1 else 0.0)
+    # dirScaling = F: blocketteResCore scales unconditionally (blockette.F90:2021-2039), blockResCore honours the switch
+    from oracle import ref
+    from util import owned, rel_err, TOL
+    from adflow_amd.synth import make_block
+    prm = FlowParams(spaceDiscr=dissScalar, dirScaling=False)
+    engine.release_all()
+    blk = make_block(20, 13, 40, prm, seed=73, holes=0.05)
+    r = checks.ref_bind(blk, prm)
+    ref.block_res_core(False, True, False)
+    engine.set_options(prm)
+    engine.register(blk)
+    engine.blocketteRes(1, False, True, False)
+    dw = engine.download_residual()
+    assert rel_err(owned(blk, dw), owned(blk, r["dw"])) <= TOL
+    try:
+        engine.set_tuning("euler_radii", 0)
+        checks.check_block_res_vs_blockette(engine, (63, 9, 35), FlowParams(spaceDiscr=dissScalar), False, seed=3)
+    finally:
+        engine.set_tuning("euler_radii", 1)

@@ -126,7 +126,7 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("viscous_tiled", 2)
         engine.set_tuning("roe_march", 1)
         engine.set_tuning("sa_march", 1)
-        engine.set_tuning("metric_from_x", 3)
+        engine.set_tuning("metric_from_x", 7)
         engine.set_tuning("roe_grad_mix", 0)
 
 

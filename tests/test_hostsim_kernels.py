@@ -438,3 +438,8 @@ def test_finalize_then_init_starts_clean(hostsim_engine):
     checks.check_block_res(e2, (7, 8, 6), prm, seed=42, stretch_k=2.0)
     checks.check_nk_residual(e2, BrickTopology(1, 1, 1, 5, 6, 4), prm, stretch_k=2.0)
     hostsim_engine.blocks.clear()
+
+
+def test_euler_radii_inside_the_march(hostsim_engine):
+    import test_gpu_euler
+    test_gpu_euler.test_euler_radii_inside_the_march(hostsim_engine)

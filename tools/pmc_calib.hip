@@ -27,6 +27,13 @@ __global__ void read5w1(double* __restrict__ d, const double* __restrict__ s, si
         d[i] = s[i] + s[i + n] + s[i + 2 * n] + s[i + 3 * n] + s[i + 4 * n];
 }
 
+#include "../adflow_amd/csrc/internal.h"
+__global__ void probe_pow(const double* __restrict__ x, double* __restrict__ y, double a, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fast_powa(x[i], a);
+}
+
 template <int NR>
 __global__ void probe(const double* __restrict__ x, double* __restrict__ rc, double* __restrict__ rs, size_t n)
 {
@@ -59,6 +66,23 @@ int main(int argc, char** argv)
         CK(hipDeviceSynchronize());
         printf("copy8: reads %zu B writes %zu B per launch; copy16: the same; read5w1: reads %zu B writes %zu B\n", n * 8, n * 8,
                5 * (n / 4) * 8, (n / 4) * 8);
+    }
+    if (!strcmp(mode, "pow")) {
+        // accuracy of fast_powa (internal.h) against the host's pow over the range the spectral radii live in
+        const size_t n = 1 << 22;
+        std::vector<double> hx(n), hy(n);
+        srand(11);
+        for (size_t i = 0; i < n; ++i) hx[i] = exp(((double)rand() / RAND_MAX) * 80.0 - 58.0);   // 1e-25 .. 3e9
+        double *x, *y;
+        CK(hipMalloc(&x, n * 8)); CK(hipMalloc(&y, n * 8));
+        CK(hipMemcpy(x, hx.data(), n * 8, hipMemcpyHostToDevice));
+        for (double a : {0.67, 2.0 / 3.0, 0.5, 1.0, 0.25}) {
+            hipLaunchKernelGGL(probe_pow, dim3((n + 255) / 256), dim3(256), 0, 0, x, y, a, n);
+            CK(hipMemcpy(hy.data(), y, n * 8, hipMemcpyDeviceToHost));
+            double er = 0;
+            for (size_t i = 0; i < n; ++i) er = fmax(er, fabs(hy[i] / pow(hx[i], a) - 1.0));
+            printf("fast_powa(x, %.4f): max rel err %.3e over x in 1e-25 .. 3e9\n", a, er);
+        }
     }
     if (!strcmp(mode, "bw")) {
         // achievable HBM bandwidth of the three access shapes (hipEvent timing, 10 launches each): what "peak" means in practice
