@@ -216,7 +216,7 @@ class Job:
         self.eng.blocketteRes(1, False, True, self.wl["equations"] == 3)
 
 
-def timed(eng, fn, steps, barrier, min_seconds=1.0, max_reps=2000):
+def timed(eng, fn, steps, barrier, min_seconds=1.0, max_reps=2000, agree=None):
     """Time `steps` calls of fn, repeated until the region lasts >= min_seconds (the driver's busy sampler needs that);
     returns (seconds per step, repeats, event ms per step)."""
     barrier()
@@ -225,6 +225,8 @@ def timed(eng, fn, steps, barrier, min_seconds=1.0, max_reps=2000):
         fn()
     barrier()
     probe = time.perf_counter() - t0
+    if agree is not None:
+        probe = agree(probe)      # every rank must repeat the same number of times: each step holds a halo exchange
     reps = int(min(max_reps, max(1, -(-min_seconds // max(probe, 1e-6)))))
     barrier()
     t0 = time.perf_counter()
@@ -317,13 +319,21 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
+    def agree(x):
+        # the same number on every rank (maximum over ranks)
+        if world == 1:
+            return x
+        t_ = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
+
     extras_on = (world == 1 and not a.no_extras and a.workload == DEFAULT_WORKLOAD and not a.tuning)
     job = Job(a, a.workload, eng, rank, world, keep_w=extras_on)
     wl, prm = job.wl, job.prm
     eng.set_async(True)
     for _ in range(a.warmup):
         job.step()
-    sec_step, reps, ev_ms = timed(eng, job.step, a.steps, barrier, a.min_seconds)
+    sec_step, reps, ev_ms = timed(eng, job.step, a.steps, barrier, a.min_seconds, agree=agree)
     log(f"timed loop done: {sec_step * 1e3:.3f} ms/step ({reps} x {a.steps} steps)")
     if world > 1:
         t = torch.tensor([sec_step], dtype=torch.float64, device="cuda")
