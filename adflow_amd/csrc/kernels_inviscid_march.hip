@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
     }
 }
 
-int g_inviscid_march = 1;      // tuning "inviscid_march": 0 = cell-gather kernel for matrix / upwind too, 2 = marching form for NS / RANS scalar JST as well
+int g_inviscid_march = 2;      // tuning "inviscid_march": 0 = cell-gather kernel for matrix / upwind too, 1 = gather kernel for NS / RANS scalar JST only, 2 = marching form there as well (3.07 vs 3.33 ms per scalar-JST RANS evaluation, profiles/r02_as_ab_config3.txt)
 
 template <int SCHEME>
 static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)

@@ -73,18 +73,21 @@ def test_wall_stress_storage(engine):
 
 
 def test_inviscid_march_variants(engine):
-    """tuning inviscid_march: 0 = cell-gather kernel for matrix / upwind, 2 = marching form for NS / RANS scalar JST too"""
+    """tuning inviscid_march: 0 = cell-gather kernel for matrix / upwind, 1 = gather kernel for NS / RANS scalar JST (2, the default: marching form there too)"""
     from adflow_amd.params import NSEquations
     try:
         engine.set_tuning("inviscid_march", 0)
         for sd in (dissMatrix, upwind):
             checks.check_block_res(engine, (70, 9, 8), FlowParams(equations=RANSEquations, spaceDiscr=sd), seed=sd, stretch_k=2.0)
-        engine.set_tuning("inviscid_march", 2)
+        engine.set_tuning("inviscid_march", 1)
         engine.set_tuning("march_kch", 5)
         checks.check_block_res(engine, (70, 9, 12), FlowParams(equations=RANSEquations), seed=6, stretch_k=2.0)
         checks.check_rk_residual_sequence(engine, (24, 10, 8), FlowParams(equations=NSEquations), stretch_k=2.0)
+        engine.set_tuning("inviscid_march", 2)          # the default form again, with partial k chunks
+        checks.check_block_res(engine, (70, 9, 12), FlowParams(equations=RANSEquations), seed=7, stretch_k=2.0)
+        checks.check_rk_residual_sequence(engine, (24, 10, 8), FlowParams(equations=NSEquations), stretch_k=2.0)
     finally:
-        engine.set_tuning("inviscid_march", 1)
+        engine.set_tuning("inviscid_march", 2)
         engine.set_tuning("march_kch", 32)
 
 

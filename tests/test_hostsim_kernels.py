@@ -294,17 +294,20 @@ def test_actuator_regions(hostsim_engine):
 
 
 def test_inviscid_march_variants(hostsim_engine):
-    """tuning inviscid_march: 0 = cell-gather kernel for matrix / upwind, 2 = marching form for NS / RANS scalar JST too"""
+    """tuning inviscid_march: 0 = cell-gather kernel for matrix / upwind, 1 = gather kernel for NS / RANS scalar JST (2, the default: marching form there too)"""
     try:
         hostsim_engine.set_tuning("inviscid_march", 0)
         for sd in (dissMatrix, upwind):
             checks.check_block_res(hostsim_engine, (9, 6, 5), FlowParams(equations=RANSEquations, spaceDiscr=sd), seed=sd, stretch_k=2.0)
-        hostsim_engine.set_tuning("inviscid_march", 2)
+        hostsim_engine.set_tuning("inviscid_march", 1)
         hostsim_engine.set_tuning("march_kch", 4)
         checks.check_block_res(hostsim_engine, (13, 6, 7), FlowParams(equations=RANSEquations), seed=6, stretch_k=2.0)
         checks.check_rk_residual_sequence(hostsim_engine, (9, 5, 7), FlowParams(equations=NSEquations), stretch_k=2.0)
+        hostsim_engine.set_tuning("inviscid_march", 2)          # the default form again, with partial k chunks
+        checks.check_block_res(hostsim_engine, (13, 6, 7), FlowParams(equations=RANSEquations), seed=7, stretch_k=2.0)
+        checks.check_rk_residual_sequence(hostsim_engine, (9, 5, 7), FlowParams(equations=NSEquations), stretch_k=2.0)
     finally:
-        hostsim_engine.set_tuning("inviscid_march", 1)
+        hostsim_engine.set_tuning("inviscid_march", 2)
         hostsim_engine.set_tuning("march_kch", 32)
 
 
