@@ -1441,11 +1441,6 @@ int level_tab(int level, LevelTab* t)
     if (ensure_table(level)) return 1;
     const LevelDims& ld = g_tab_dims[level];
     t->tab = g_tab[level]; t->n = g_tab_size[level]; t->nx = ld.nx; t->ny = ld.ny; t->nz = ld.nz;
-    // the level-batched launches fold (block slot, k plane) into gridDim.z, which HIP limits to 65535
-    if ((long)(ld.nz + 4) * t->n > 65535)
-        return fail("level %d: %d block slots x %d k planes exceed the 65535 limit of gridDim.z of the level-batched launches "
-                    "(about %d blocks of this depth per rank): distribute the blocks over more ranks", level, t->n, ld.nz + 4,
-                    65535 / (ld.nz + 4));
     return 0;
 }
 
@@ -2729,6 +2724,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }
     if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
     if (!strcmp(key, "visc_ws")) { g_visc_ws = value; return 0; }
+    if (!strcmp(key, "max_grid_z")) { g_max_grid_z = (value > 0) ? value : 65535; return 0; }
     if (!strcmp(key, "euler_radii")) { g_euler_radii = value; return 0; }
     if (!strcmp(key, "visc_approx_march")) { g_visc_approx_march = value; return 0; }
     if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }

@@ -311,6 +311,26 @@ void launch_closures_halo(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int col, const JacSpec& J, double deltaInv, double turbResScale,
                        hipStream_t s);
 
+// The level-batched launches fold (block slot, plane) into gridDim.z, which HIP limits to 65535: a launcher whose level has more
+// slots than fit calls itself on consecutive slot ranges (the kernels index the table relative to the pointer they get).
+extern int g_max_grid_z;          // 65535; tuning "max_grid_z" lowers it for the tests
+inline int level_slots_per_launch(int planes)
+{
+    const int per = g_max_grid_z / (planes > 0 ? planes : 1);
+    return per > 0 ? per : 1;
+}
+#define LEVEL_SPLIT(nslots, planes, CALL)                                                         \
+    {                                                                                             \
+        const int per_ = level_slots_per_launch(planes);                                          \
+        if ((nslots) > per_) {                                                                    \
+            for (int s0_ = 0; s0_ < (nslots); s0_ += per_) {                                      \
+                const int n_ = ((nslots) - s0_ < per_) ? (nslots) - s0_ : per_;                   \
+                CALL;                                                                             \
+            }                                                                                     \
+            return;                                                                               \
+        }                                                                                         \
+    }
+
 // ---- kernel launchers (one translation unit per kernel family) -------------
 void launch_time_step_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_entropy(const BlkView& b, hipStream_t s);

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void k_xhalo(const BlkView* __restrict__ tab)
 
 void launch_xhalo_level(const BlkView* tab, int nslots, int nx, int ny, int nz, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_xhalo_level(tab + s0_, n_, nx, ny, nz, s));
     if (nslots <= 0) return;
     const int ie = nx + 2, je = ny + 2, jl = ny + 1, kl = nz + 1;
     dim3 blk(64, 4, 1);
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(256) void k_coarse_coordinates(const BlkView* __res
 
 void launch_coarse_coordinates_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_coarse_coordinates_level(ctab + s0_, ftab + s0_, n_, nx, ny, nz, s));
     if (nslots <= 0) return;
     const int il = nx + 1, jl = ny + 1, kl = nz + 1;
     hipLaunchKernelGGL(k_coarse_coordinates, dim3((il + 63) / 64, (jl * kl + 3) / 4, nslots), dim3(64, 4, 1), 0, s, ctab, ftab);

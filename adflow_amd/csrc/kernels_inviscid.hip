@@ -182,6 +182,7 @@ static void launch_scheme(const BlkView* b, int nzb, const KParams& kp, dim3 grd
 
 void launch_inviscid_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_inviscid_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s));
     if (nslots <= 0) return;
     dim3 blk(IV_BX, IV_BY, 1);
     dim3 grd((maxnx + IV_BX - 1) / IV_BX, (maxny + IV_BY - 1) / IV_BY, maxnz * nslots);
@@ -225,6 +226,7 @@ __global__ void k_initres_level(const BlkView* __restrict__ tab, int nzb, int l0
 
 void launch_initres_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, int l0, int l1, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_initres_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, l0, l1, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_initres_level, dim3((maxnx + 63) / 64, (maxny + 3) / 4, maxnz * nslots), dim3(64, 4, 1), 0, s, tab, maxnz, l0, l1,
                        kp.coarseInit);

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(MG_BX* MG_BY) void k_prolong_update(const BlkView* 
 // nx, ny, nz = the largest extents of the blocks the grid runs over (coarse blocks unless stated otherwise).
 void launch_restrict_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_restrict_level(ctab + s0_, ftab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_restrict, dim3((nx + MG_BX - 1) / MG_BX, (ny + MG_BY - 1) / MG_BY, nz * nslots), dim3(MG_BX, MG_BY, 1), 0, s,
                        ctab, ftab, nz, kp);
@@ -181,6 +182,7 @@ void launch_restrict_level(const BlkView* ctab, const BlkView* ftab, int nslots,
 
 void launch_store_entry_state_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_store_entry_state_level(ctab + s0_, n_, nx, ny, nz, s));
     if (nslots <= 0) return;
     const int nzb = nz + 2;
     hipLaunchKernelGGL(k_store_entry_state, dim3((nx + 2 + 15 + MG_BX - 1) / MG_BX, (ny + 2 + MG_BY - 1) / MG_BY, nzb * nslots),
@@ -189,6 +191,7 @@ void launch_store_entry_state_level(const BlkView* ctab, int nslots, int nx, int
 
 void launch_forcing_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, double fcoll, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_forcing_level(ctab + s0_, n_, nx, ny, nz, fcoll, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_forcing, dim3((nx + MG_BX - 1) / MG_BX, (ny + MG_BY - 1) / MG_BY, nz * nslots), dim3(MG_BX, MG_BY, 1), 0, s,
                        ctab, nz, fcoll);
@@ -196,6 +199,7 @@ void launch_forcing_level(const BlkView* ctab, int nslots, int nx, int ny, int n
 
 void launch_corrections_level(const BlkView* ctab, int nslots, int nx, int ny, int nz, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_corrections_level(ctab + s0_, n_, nx, ny, nz, s));
     if (nslots <= 0) return;
     const int nzb = nz + 2;
     hipLaunchKernelGGL(k_corrections, dim3((nx + 2 + 15 + MG_BX - 1) / MG_BX, (ny + 2 + MG_BY - 1) / MG_BY, nzb * nslots),
@@ -206,6 +210,7 @@ void launch_corrections_level(const BlkView* ctab, int nslots, int nx, int ny, i
 void launch_prolong_update_level(const BlkView* ftab, const BlkView* ctab, int nslots, int nx, int ny, int nz, const KParams& kp,
                                  hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_prolong_update_level(ftab + s0_, ctab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_prolong_update, dim3((nx + MG_BX - 1) / MG_BX, (ny + MG_BY - 1) / MG_BY, nz * nslots), dim3(MG_BX, MG_BY, 1), 0,
                        s, ftab, ctab, nz, kp);

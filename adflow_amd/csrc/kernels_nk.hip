@@ -146,23 +146,27 @@ static dim3 nk_level_grid(int nslots, int maxnx, int maxny, int maxnz)
 
 void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_closures_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_closures_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp);
 }
 void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
                                  const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_set_w_closures_level(tab + s0_, n_, maxnx, maxny, maxnz, vec, turbFloor, kp, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_set_w_closures_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, vec, turbFloor,
                        kp);
 }
 void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_set_w_level(tab + s0_, n_, maxnx, maxny, maxnz, vec, turbFloor, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_set_w_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, vec, turbFloor);
 }
 void launch_get_r_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double* vec, double turbScale, double* sums, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_get_r_level(tab + s0_, n_, maxnx, maxny, maxnz, vec, turbScale, sums, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_get_r_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, vec, turbScale, sums);
 }

@@ -378,6 +378,7 @@ extern int g_lines_i_tiled;
 
 void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_sa_solve_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     dim3 blk(SA_BX, SA_BY, 1);
     dim3 grd((nx + SA_BX - 1) / SA_BX, (ny + SA_BY - 1) / SA_BY, nz * nslots);
@@ -397,6 +398,7 @@ void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int n
 
 void launch_sa_residual_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_sa_residual_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     dim3 blk(SA_BX, SA_BY, 1);
     dim3 grd((nx + SA_BX - 1) / SA_BX, (ny + SA_BY - 1) / SA_BY, nz * nslots);

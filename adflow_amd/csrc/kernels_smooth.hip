@@ -33,6 +33,8 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_rk_save(const BlkView* __restr
     b.pn[c] = b.p[c];
 }
 
+int g_max_grid_z = 65535;   // tuning "max_grid_z" (tests): the launchers split a level into slot ranges that fit gridDim.z
+
 static dim3 level_grid(int nslots, int maxnx, int maxny, int maxnz)
 {
     return dim3((maxnx + SM_BX - 1) / SM_BX, (maxny + SM_BY - 1) / SM_BY, maxnz * nslots);
@@ -41,6 +43,7 @@ static dim3 level_grid(int nslots, int maxnx, int maxny, int maxnz)
 // the pointwise smoother kernels cover every block of a level in one launch (blockIdx.z = slot * maxnz + plane)
 void launch_rk_save_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_rk_save_level(tab + s0_, n_, maxnx, maxny, maxnz, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_rk_save, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz);
 }
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned_level(const BlkView
 
 void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double gammaConstant, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_etot_owned_level(tab + s0_, n_, maxnx, maxny, maxnz, gammaConstant, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_etot_owned_level, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, gammaConstant);
 }
@@ -104,6 +108,7 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_scale_dw(const BlkView* __rest
 
 void launch_scale_dw_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double factor, int timesVol, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_scale_dw_level(tab + s0_, n_, maxnx, maxny, maxnz, factor, timesVol, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_scale_dw, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, factor, timesVol);
 }
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_low_speed_precond(const BlkVie
 
 void launch_low_speed_precond_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_low_speed_precond_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s));
     if (nslots <= 0) return;
     const double uInf2 = kp.wInf[1] * kp.wInf[1] + kp.wInf[2] * kp.wInf[2] + kp.wInf[3] * kp.wInf[3];
     hipLaunchKernelGGL(k_low_speed_precond, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, uInf2);
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_stage_update(const BlkView* __
 void launch_stage_update_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, double scale,
                                int fromWn, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_stage_update_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, scale, fromWn, s));
     if (nslots <= 0) return;
     const dim3 grd = level_grid(nslots, maxnx, maxny, maxnz), blk(SM_BX, SM_BY, 1);
     if (fromWn)
@@ -495,6 +502,7 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
 
 void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_res_averaging_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_ra_rfl, dim3((maxnx + SM_BX - 1) / SM_BX, (maxny + SM_BY - 1) / SM_BY, maxnz * nslots),
                        dim3(SM_BX, SM_BY, 1), 0, s, tab, kp, maxnz);
@@ -962,6 +970,7 @@ int g_lines_i_tiled = 1;      // tuning "lines_i_tiled": 0 = one-line-per-lane i
 // computedwDADI incl. the -cfl*dtl*vol scaling of executeDADIStep
 void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_dadi_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     dim3 blk(64, 1, 1);
     hipLaunchKernelGGL((k_dadi_sweep<1>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);

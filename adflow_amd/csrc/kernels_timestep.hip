@@ -183,6 +183,7 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_entropy_level(const BlkView* _
 
 void launch_entropy_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_entropy_level(tab + s0_, n_, maxnx, maxny, maxnz, s));
     if (nslots <= 0) return;
     const int nzb = maxnz + 4;
     dim3 grd((maxnx + 4 + 14 + TS_BX - 1) / TS_BX, (maxny + 4 + TS_BY - 1) / TS_BY, nzb * nslots);
@@ -198,6 +199,7 @@ void launch_entropy(const BlkView& b, hipStream_t s)
 
 void launch_time_step_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_time_step_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s));
     if (nslots <= 0) return;
     dim3 blk(TS_BX, TS_BY, 1);
     const int nzb = maxnz + 4;

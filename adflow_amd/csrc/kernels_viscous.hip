@@ -2228,6 +2228,7 @@ int g_viscous_fused = 0;    // tuning "viscous_fused": 0 = off, 1 = where the gr
 // fused nodal gradients + viscous fluxes (one launch for every block of the level)
 void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_visc_fused_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     const int nch = (nz + VF_KCH - 1) / VF_KCH;
     const int rows = (g_viscous_fused_rows == 4) ? 4 : 8;
@@ -2247,6 +2248,7 @@ int g_grad_sa_fused = 0;    // tuning "grad_sa_fused": SA residual evaluated ins
 // nodal gradients + Spalart-Allmaras residual of every block of the level in one launch
 void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_grad_sa_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     const int nzn = nz + 1;
     const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
@@ -2289,6 +2291,7 @@ bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int 
 // the Spalart-Allmaras residual alone, as a k-march (blocks at rest)
 void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_sa_march_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     const int nzn = nz + 1;
     const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
@@ -2305,6 +2308,7 @@ void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int n
 
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_node_gradients_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     const int nzn = nz + 1;
     const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
@@ -2318,6 +2322,7 @@ void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny,
 
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
+    LEVEL_SPLIT(nslots, nz + 4, launch_viscous_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     dim3 blk(VS_BX, VS_BY, 1);
     const int nzn = nz + 1;                              // node planes 1..kl

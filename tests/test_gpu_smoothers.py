@@ -94,3 +94,8 @@ def test_periodic_halos(engine):
     """a18: periodic transformations of the halo exchange (velocities) and of exchangeCoor (coordinates)"""
     checks.check_periodic_halos(engine, BrickTopology(2, 1, 1, 20, 9, 8), FlowParams())
     checks.check_periodic_halos(engine, BrickTopology(1, 2, 1, 70, 6, 4), FlowParams(equations=RANSEquations), stretch_k=2.0)
+
+
+def test_level_launches_split_over_slot_ranges(engine):
+    import test_hostsim_kernels
+    test_hostsim_kernels.test_level_launches_split_over_slot_ranges(engine)

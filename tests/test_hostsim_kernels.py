@@ -446,3 +446,22 @@ def test_finalize_then_init_starts_clean(hostsim_engine):
 def test_euler_radii_inside_the_march(hostsim_engine):
     import test_gpu_euler
     test_gpu_euler.test_euler_radii_inside_the_march(hostsim_engine)
+
+
+def test_level_launches_split_over_slot_ranges(hostsim_engine):
+    """gridDim.z holds (block slot, plane): with more slots than fit (lowered here by tuning max_grid_z; 65535 in production, i.e.
+    ~1800 blocks of 32 planes per GPU) every level launcher calls itself on consecutive slot ranges"""
+    e = hostsim_engine
+    topo = BrickTopology(2, 2, 2, 5, 4, 3)
+    try:
+        e.set_tuning("max_grid_z", 15)            # 15 / (3 + 4) = 2 of the 8 slots per launch
+        rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, nSubIterTurb=2)
+        checks.check_nk_residual(e, topo, rans, stretch_k=2.0)
+        checks.check_sa_solve(e, topo, rans, stretch_k=2.0)
+        checks.check_rk_smoother(e, topo, FlowParams(resAveraging=alternateResAveraging))
+        checks.check_dadi_smoother(e, topo, FlowParams(equations=RANSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2),
+                                   stretch_k=2.0)
+        checks.check_mg_cycle(e, BrickTopology(2, 2, 1, 8, 4, 4), FlowParams(), [0, 1, 0, -1], ncycles=1)
+        checks.check_halo_exchange(e, topo, FlowParams(equations=RANSEquations), 2)
+    finally:
+        e.set_tuning("max_grid_z", 0)
