@@ -580,6 +580,10 @@ int adflow_gpu_upload_geometry(int nn, int level, int sps)
     if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
     const adflow_block_desc& d = b->d;
     BlkView& v = b->v;
+    // the marching kernels re-form face normals from the node coordinates and the viscous kernel derives its face vectors from
+    // them: x is as much part of the geometry as the normals and the volumes
+    if (!d.x || !d.sI || !d.sJ || !d.sK || !d.vol)
+        return fail("block (%d,%d,%d): x, sI, sJ, sK and vol host arrays are required", nn, level, sps);
     int rc = 0;
     rc |= copy_box(b, v.x, d.x, 3, 0, v.ie + 1, 0, v.je + 1, 0, v.ke + 1, true);
     rc |= copy_box(b, v.sI, d.sI, 3, 0, v.ie + 1, 1, v.je, 1, v.ke, true);
