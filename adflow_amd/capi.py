@@ -266,7 +266,7 @@ def _ptr(a: Optional[np.ndarray]):
 
 def desc_from_block(blk) -> AdflowBlockDesc:
     d = AdflowBlockDesc()
-    d.nx, d.ny, d.nz, d.nw, d.rightHanded = blk.nx, blk.ny, blk.nz, blk.nw, 1
+    d.nx, d.ny, d.nz, d.nw, d.rightHanded = blk.nx, blk.ny, blk.nz, blk.nw, int(getattr(blk, "rightHanded", True))
     for name in ("w", "p", "gamma", "rlv", "rev", "x", "sI", "sJ", "sK", "vol", "volRef", "d2Wall",
                  "porI", "porJ", "porK", "iblank", "dw", "fw", "dtl", "radI", "radJ", "radK", "w1", "p1", "wr",
                  "mgIFine", "mgJFine", "mgKFine", "mgIWeight", "mgJWeight", "mgKWeight", "mgICoarse", "mgJCoarse",

@@ -33,6 +33,7 @@ class Block:
     nw: int
     a: Dict[str, np.ndarray] = field(default_factory=dict)
     rotRate: Optional[tuple] = None      # cgnsDoms%rotRate of a moving block (blockIsMoving), None at rest
+    rightHanded: bool = True             # blockType%rightHanded: (i, j, k) right-handed; False: metric_block uses fact = -half
 
     # index helpers (reference naming)
     @property
@@ -67,7 +68,7 @@ class Block:
         return self.a[name][2:self.il + 1, 2:self.jl + 1, 2:self.kl + 1]
 
     def copy(self) -> "Block":
-        return Block(self.nx, self.ny, self.nz, self.nw, {k: v.copy(order="F") for k, v in self.a.items()}, self.rotRate)
+        return Block(self.nx, self.ny, self.nz, self.nw, {k: v.copy(order="F") for k, v in self.a.items()}, self.rotRate, self.rightHanded)
 
 
 def add_grid_velocities(blk: "Block", prm, rotRate=(0.05, -0.03, 0.12), rotCenter=(0.3, -0.2, 0.1)):
@@ -198,7 +199,7 @@ def sa_eddy_viscosity(prm: FlowParams, rho, nut, rlv):
 
 def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.0), amp=0.02,
                stretch_k=1.0, wall_kmin=None, noise=0.02, wave=0.05, origin=(0.0, 0.0, 0.0), holes=0.0,
-               noflux_jmax=False, moving=False) -> Block:
+               noflux_jmax=False, moving=False, left_handed=False) -> Block:
     """Analytic curvilinear block + perturbed free-stream state.
     moving: a block of a steadily rotating frame (add_grid_velocities)."""
     rng = np.random.default_rng(seed)
@@ -207,6 +208,13 @@ def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.
     ib, jb, kb = b.ib, b.jb, b.kb
     x = make_nodes(nx, ny, nz, lengths, amp, stretch_k, origin)
     sI, sJ, sK = face_metrics(x)
+    if left_handed:
+        # mirror image of the block: the index system becomes left-handed and the reference's metric_block takes fact = -half so
+        # that the normals keep pointing towards increasing indices (adjointExtra.F90:205-211)
+        x[..., 0] = -x[..., 0]
+        sI, sJ, sK = face_metrics(x)
+        sI, sJ, sK = np.asfortranarray(-sI), np.asfortranarray(-sJ), np.asfortranarray(-sK)
+        b.rightHanded = False
     vol = cell_volumes(x)
     b["x"], b["sI"], b["sJ"], b["sK"], b["vol"] = x, sI, sJ, sK, vol
     b["volRef"] = vol.copy(order="F")

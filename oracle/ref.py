@@ -108,6 +108,7 @@ def bind_block(blk, prm) -> None:
     lib = load()
     set_params(prm)
     lib.ref_set_dims(blk.nx, blk.ny, blk.nz, blk.nw, 5)
+    lib.ref_set_int(b"rightHanded", int(getattr(blk, "rightHanded", True)))      # after ref_set_dims (it resets the flag)
     ib, jb, kb = blk.ib, blk.jb, blk.kb
     ie, je, ke = blk.ie, blk.je, blk.ke
     a = blk.a

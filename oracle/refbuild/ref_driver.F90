@@ -269,12 +269,14 @@ contains
         use flowVarRefState, only: viscous, eddyModel, kPresent
         use inputTimeSpectral, only: nTimeIntervalsSpectral
         use inputUnsteady, only: timeIntegrationScheme
+        use blockPointers, only: rightHanded
         character(kind=c_char), dimension(*), intent(in) :: name
         integer(c_int), value :: v
         character(len=64) :: n
         n = cstr(name)
         select case (trim(n))
         case ('equations'); equations = v
+        case ('rightHanded'); rightHanded = (v /= 0)
         case ('equationMode'); equationMode = v
         case ('spaceDiscr'); spaceDiscr = v
         case ('spaceDiscrCoarse'); spaceDiscrCoarse = v

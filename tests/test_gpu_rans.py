@@ -40,6 +40,17 @@ def test_north_star_block_vs_reference_default_path(engine):
     checks.check_block_res_vs_blockette(engine, (160, 128, 64), prm, False, seed=44, stretch_k=3.0)
 
 
+def test_left_handed_block(engine):
+    """a block whose (i, j, k) system is left-handed (mirror image): metric_block takes fact = -half.  The marching kernels that
+    re-form the face normals from the nodes (SA, nodal gradients, time step) must do the same; update_geometry too."""
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    checks.check_block_res(engine, (23, 9, 7), prm, seed=52, stretch_k=2.0, left_handed=True)
+    checks.check_block_res(engine, (12, 6, 5), FlowParams(equations=RANSEquations), seed=53, stretch_k=2.0, left_handed=True)
+    checks.check_block_res_vs_blockette(engine, (20, 9, 8), FlowParams(), False, seed=54, left_handed=True)
+    checks.check_update_geometry(engine, (9, 8, 6), FlowParams(equations=NSEquations), {1: -6, 2: -6, 3: -3, 4: -6, 5: -1, 6: -1},
+                                 stretch_k=2.0, left_handed=True)
+
+
 def test_ns_rk_stage_residuals(engine):
     checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations), stretch_k=2.0)
 

@@ -465,3 +465,8 @@ def test_level_launches_split_over_slot_ranges(hostsim_engine):
         checks.check_halo_exchange(e, topo, FlowParams(equations=RANSEquations), 2)
     finally:
         e.set_tuning("max_grid_z", 0)
+
+
+def test_left_handed_block(hostsim_engine):
+    import test_gpu_rans
+    test_gpu_rans.test_left_handed_block(hostsim_engine)
