@@ -28,6 +28,30 @@ def test_mach3_shock_dissipation_clips_entropy_fix_limiter_extremes(engine):
     shock_cases(engine, (70, 9, 6))
 
 
+def shock_default_flags_case(engine, dims):
+    """the same Mach-3 shock through blocketteRes with its DEFAULT flags: for Euler + scalar JST the march forms the spectral radii
+    itself (fast_powa, rcp / rsq forms) on states whose radii span orders of magnitude; RANS takes the marching kernels"""
+    from oracle import ref
+    from util import owned, rel_err, TOL
+    for eq, sd in ((1, dissScalar), (3, upwind), (3, dissScalar)):
+        prm = FlowParams(equations=eq, spaceDiscr=sd)
+        blk = adversarial.shock_block(dims, prm, seed=90 + sd, stretch_k=2.0 if eq != 1 else 1.0)
+        assert min(adversarial.count_shock_branches(blk, prm).values()) > 0
+        engine.release_all()
+        r = checks.ref_bind(blk, prm)
+        ref.block_res_core(False, True, eq == 3)
+        engine.set_options(prm)
+        engine.register(blk)
+        engine.blocketteRes(1, False, True, eq == 3)
+        dw = engine.download_residual()
+        e = rel_err(owned(blk, dw), owned(blk, r["dw"]))
+        assert e <= TOL, (eq, sd, e)
+
+
+def test_mach3_shock_default_flags(engine):
+    shock_default_flags_case(engine, (70, 9, 6))
+
+
 def vacuum_cases(engine):
     n = checks.check_vacuum_smoother(engine, BrickTopology(1, 1, 1, 12, 8, 6), FlowParams(resAveraging=noResAveraging))
     assert n > 0, "the reference clipped no cell: the state is not adversarial enough"

@@ -470,3 +470,8 @@ def test_level_launches_split_over_slot_ranges(hostsim_engine):
 def test_left_handed_block(hostsim_engine):
     import test_gpu_rans
     test_gpu_rans.test_left_handed_block(hostsim_engine)
+
+
+def test_mach3_shock_default_flags(hostsim_engine):
+    import test_gpu_adversarial
+    test_gpu_adversarial.shock_default_flags_case(hostsim_engine, (22, 7, 6))
