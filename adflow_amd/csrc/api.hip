@@ -63,6 +63,7 @@ struct Block {
     long boxsize = 0;         // ldi*(jb+1)*(kb+1)
     std::vector<void*> allocs;
     bool geom_uploaded = false;
+    bool normals_from_x_ok = true;     // the uploaded sI / sJ / sK equal metric_block(x): the kernels may re-form them from the nodes
     bool face_vectors_valid = false;   // dI/dJ/dK derived from x
     bool ss_valid = false;    // entropy sensor variable matches the current state
     bool etot_consistent = false;   // owned-cell rhoE already equals computeEtotBlock(p, rho, v)
@@ -266,6 +267,9 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.dirScaling = o.dirScaling;
     k.lumpedDiss = g_lumped;
     k.metricFromX = g_metric_from_x;
+    if (k.metricFromX)
+        for (auto& kv : g_blocks)
+            if (std::get<0>(kv.first) == level && !kv.second->normals_from_x_ok) { k.metricFromX = 0; break; }
     k.sigma = o.sigma;
     k.useQCR = o.useQCR;
     k.useRotationSA = o.useRotationSA;
@@ -574,6 +578,56 @@ int adflow_gpu_release_all(void)
     return 0;
 }
 
+// The marching kernels may re-form face normals from the node coordinates (tuning metric_from_x).  That is only the same
+// computation if the host's sI / sJ / sK ARE metric_block(x) (adjointExtra.F90:176-268), which holds for every mesh the reference
+// builds; a sample of faces of each array is checked against the cross products at upload, and a block that fails keeps the
+// level on the stored normals instead of silently evaluating a different geometry.
+static bool normals_match_nodes(const Block* b)
+{
+    const adflow_block_desc& d = b->d;
+    const BlkView& v = b->v;
+    const double fact = d.rightHanded ? 0.5 : -0.5;
+    const size_t nxn = (size_t)v.ie + 1, nyn = (size_t)v.je + 1, nzn = (size_t)v.ke + 1;        // x(0:ie, 0:je, 0:ke, 3)
+    auto X = [&](int i, int j, int k, int q) { return d.x[(size_t)i + nxn * ((size_t)j + nyn * ((size_t)k + nzn * q))]; };
+    auto cross = [&](const double p1[3], const double p2[3], const double q1[3], const double q2[3], double s[3]) {
+        const double a[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, c[3] = {q1[0] - q2[0], q1[1] - q2[1], q1[2] - q2[2]};
+        s[0] = fact * (a[1] * c[2] - a[2] * c[1]); s[1] = fact * (a[2] * c[0] - a[0] * c[2]); s[2] = fact * (a[0] * c[1] - a[1] * c[0]);
+    };
+    auto node = [&](int i, int j, int k, double p[3]) { for (int q = 0; q < 3; ++q) p[q] = X(i, j, k, q); };
+    double worst = 0.0, scale = 0.0;
+    const int ns = 5;
+    for (int a = 0; a < ns; ++a)
+        for (int c = 0; c < ns; ++c)
+            for (int e = 0; e < ns; ++e) {
+                // sample points spread over the index ranges incl. the first and last faces
+                const int i = 1 + (int)((long)(v.ie - 1) * a / (ns - 1)), j = 1 + (int)((long)(v.je - 1) * c / (ns - 1)),
+                          k = 1 + (int)((long)(v.ke - 1) * e / (ns - 1));
+                double n11[3], n10[3], n01[3], n00[3], s[3];
+                // sI(i, j, k), i = 0..ie, j = 1..je, k = 1..ke: nodes (i, j-1..j, k-1..k)
+                node(i, j, k - 1, n11); node(i, j - 1, k, n10); node(i, j, k, n01); node(i, j - 1, k - 1, n00);
+                cross(n11, n10, n01, n00, s);
+                for (int q = 0; q < 3; ++q) {
+                    const double h = d.sI[(size_t)i + nxn * ((size_t)(j - 1) + (size_t)v.je * ((size_t)(k - 1) + (size_t)v.ke * q))];
+                    worst = std::max(worst, fabs(h - s[q])); scale = std::max(scale, fabs(h));
+                }
+                // sJ(i, j, k), i = 1..ie, j = 0..je, k = 1..ke: v1 = x(i,j,n) - x(l,j,k) ; v2 = x(l,j,n) - x(i,j,k)
+                node(i, j, k - 1, n11); node(i - 1, j, k, n10); node(i - 1, j, k - 1, n01); node(i, j, k, n00);
+                cross(n11, n10, n01, n00, s);
+                for (int q = 0; q < 3; ++q) {
+                    const double h = d.sJ[(size_t)(i - 1) + (size_t)v.ie * ((size_t)j + nyn * ((size_t)(k - 1) + (size_t)v.ke * q))];
+                    worst = std::max(worst, fabs(h - s[q])); scale = std::max(scale, fabs(h));
+                }
+                // sK(i, j, k), i = 1..ie, j = 1..je, k = 0..ke: v1 = x(i,j,k) - x(l,m,k) ; v2 = x(l,j,k) - x(i,m,k)
+                node(i, j, k, n11); node(i - 1, j - 1, k, n10); node(i - 1, j, k, n01); node(i, j - 1, k, n00);
+                cross(n11, n10, n01, n00, s);
+                for (int q = 0; q < 3; ++q) {
+                    const double h = d.sK[(size_t)(i - 1) + (size_t)v.ie * ((size_t)(j - 1) + (size_t)v.je * ((size_t)k + nzn * q))];
+                    worst = std::max(worst, fabs(h - s[q])); scale = std::max(scale, fabs(h));
+                }
+            }
+    return worst <= 1.e-11 * std::max(scale, 1.e-300);
+}
+
 int adflow_gpu_upload_geometry(int nn, int level, int sps)
 {
     Block* b = find_block(nn, level, sps);
@@ -626,6 +680,7 @@ int adflow_gpu_upload_geometry(int nn, int level, int sps)
     HIPCHK(hipStreamSynchronize(g_stream));
     b->geom_uploaded = true;
     b->face_vectors_valid = false;
+    b->normals_from_x_ok = normals_match_nodes(b);
     return 0;
 }
 
@@ -650,6 +705,7 @@ int adflow_gpu_update_geometry(int level)
         launch_volume_metric(b->v, b->d.rightHanded, g_stream);
         if (!b->bc.empty()) launch_boundary_normals(b->v, b->bc.data(), (int)b->bc.size(), g_stream);
         b->face_vectors_valid = false;
+        b->normals_from_x_ok = true;        // the normals on the device now ARE metric_block(x)
         return 0;
     });
     if (rc) return rc;

@@ -51,6 +51,20 @@ def test_left_handed_block(engine):
                                  stretch_k=2.0, left_handed=True)
 
 
+def test_normals_not_derived_from_the_nodes_keep_the_stored_normals(engine):
+    """the kernels re-form face normals from x only if the uploaded sI / sJ / sK ARE metric_block(x); a block whose normals were
+    altered independently of its coordinates must be evaluated with the normals it was given, like the reference does"""
+    from adflow_amd.synth import make_block
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    blk = make_block(23, 9, 7, prm, seed=61, stretch_k=2.0)
+    blk["sI"] *= 1.001
+    blk["sK"] *= 0.9995
+    checks.check_block_res(engine, (23, 9, 7), prm, blk=blk)
+    blk = make_block(12, 6, 5, FlowParams(), seed=62)
+    blk["sJ"] *= 1.002
+    checks.check_block_res(engine, (12, 6, 5), FlowParams(), blk=blk)
+
+
 def test_ns_rk_stage_residuals(engine):
     checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations), stretch_k=2.0)
 

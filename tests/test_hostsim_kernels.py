@@ -475,3 +475,8 @@ def test_left_handed_block(hostsim_engine):
 def test_mach3_shock_default_flags(hostsim_engine):
     import test_gpu_adversarial
     test_gpu_adversarial.shock_default_flags_case(hostsim_engine, (22, 7, 6))
+
+
+def test_normals_not_derived_from_the_nodes_keep_the_stored_normals(hostsim_engine):
+    import test_gpu_rans
+    test_gpu_rans.test_normals_not_derived_from_the_nodes_keep_the_stored_normals(hostsim_engine)
