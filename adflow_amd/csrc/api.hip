@@ -1395,12 +1395,14 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
 
     // setFDReference (adjointUtils.F90:1971-2024): reference residual, then the reference state INCLUDING the halos the boundary
     // conditions just wrote
+    bool haveRef = false;           // wref holds the reference state: an error further down still puts the state back
     if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC);
     if (!rc) rc = for_level(level, [&](Block* b) {
         launch_fd_copy(b->v, b->wref, b->v.w, b->v.nw, g_stream);
         launch_fd_extract(b->v, b->dwref, b->jac, -1, 0, J, 0.0, g_opts.turbResScale, g_stream);
         return 0;
     });
+    if (!rc) haveRef = true;
     const double deltaInv = 1.0 / delta;
     // the reference loops colours outside and state variables inside; every (colour, variable) evaluation is independent, so the
     // loops are exchanged here: the nColour evaluations of one variable are kept (dense) and scattered into the blocks together
@@ -1430,6 +1432,16 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
         b->etot_consistent = false;
         return 0;
     });
+    if (rc && haveRef) {
+        // the sweep stopped half way: the level must not keep a perturbed state (the error text of the failed call is kept)
+        for_level(level, [&](Block* b) {
+            launch_fd_state(b->v, b->wref, 0, -1, J, 0.0, g_stream);
+            b->ss_valid = false;
+            b->etot_consistent = false;
+            return 0;
+        });
+        (void)hipStreamSynchronize(g_stream);
+    }
     restore();
     if (rc) return rc;
     g_jac = J;
