@@ -250,7 +250,8 @@ int copy_box(Block* b, double* dev, const double* host_c, int ncomp, int lo_i, i
 
 int g_lumped = 0;       // inputDiscretization::lumpedDiss while a preconditioner matrix is assembled
 int g_visc_approx_march = 1;   // tuning "visc_approx_march": 0 = the gather kernel k_viscous_approx per block
-int g_metric_from_x = 7;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march, bit 2 the time-step kernel re-form the face normals from the node coordinates
+int g_metric_from_x = 7;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march, bit 2 the time-step kernel re-form the face normals from the node coordinates;
+                           // bit 3 the Roe march too (off: that kernel is bound by FP64 issue, the cross products cost more than the 6 loads saved - profiles/r02_ba_variants.txt)
 
 KParams make_kparams(int level, double rFil, int fwMode)
 {

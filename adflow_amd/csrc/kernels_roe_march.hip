@@ -193,7 +193,7 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
 // written here, otherwise the sum dw + fw is left in dw for the viscous kernel to complete (residuals.F90:334-344)
 // body of the kernel for workgroup `bid` of the tile table; xj: 2 * RM_XJ doubles of LDS (the caller owns the allocation so that
 // the mixed kernel of kernels_viscous.hip can give the same bytes to either of its two bodies)
-template <int LIM, bool FW, bool FINAL>
+template <int LIM, bool FW, bool FINAL, bool XN = false>
 __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, const KParams& kp, int kch,
                                                int bid, double* __restrict__ xj)
 {
@@ -245,6 +245,11 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     }
     int flagm = flags[(c - sk) >> 3];
     double acc[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};   // accD: dissipation part, kept apart only when FW
+    // XN: the face normals re-formed from the node coordinates (internal.h ngx_*): the node plane below the cell is kept
+    GPTR(const double) xnod = (GPTR(const double))b.x;
+    const unsigned nb8 = 8u * (unsigned)nb;
+    NgNodes Pn;
+    if (XN) ngx_load_x(xnod, c - sk, nb8, sj, Pn);
 
     for (int k = k0; k <= k1 + 1; ++k) {
         const RCell qp1 = rm_ld(m, c + sk);
@@ -286,7 +291,22 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         double ULk0[5], URk0[5];
         rm_recon<LIM>(K, qm1, q0, qp1, ULk0, URk0);
         double fc[5], fd[5];
-        rm_face(K, qm1, q0, ULk, URk0, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), fc, fd);
+        double nI[3], nJm[3], nJ[3];
+        if (XN) {
+            double nKb[3];
+            ngx_normal_k(b.mfact, Pn, nKb);
+            rm_face(K, qm1, q0, ULk, URk0, nKb[0], nKb[1], nKb[2], flg_porK((uint8_t)flagm), fc, fd);
+            if (body) {
+                NgNodes Nn;
+                ngx_load_x(xnod, c, nb8, sj, Nn);
+                double nKu[3];
+                ngx_normals(b.mfact, Pn, Nn, nI, nJm, nJ, nKu);
+                Pn = Nn;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) nI[d] = lane_up1(nI[d]);      // this lane's i-face is (i-1 | i): sI of the cell i-1
+            }
+        } else
+            rm_face(K, qm1, q0, ULk, URk0, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), fc, fd);
         // ---- finish cell k-1 and write it
         if (k > k0 && out) {
             const unsigned cw = c - sk;
@@ -324,7 +344,8 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
             for (int l = 0; l < 5; ++l) ULm[l] = lane_up1(ULi[l]);
             const int por = flg_porI((uint8_t)lane_up1(flag0));
             double gc[5], gd[5];
-            rm_face(K, qL, q0, ULm, URi, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, gc, gd);
+            if (XN) rm_face(K, qL, q0, ULm, URi, nI[0], nI[1], nI[2], por, gc, gd);
+            else rm_face(K, qL, q0, ULm, URi, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, gc, gd);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 if (FW) {
@@ -347,13 +368,15 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
             }
             const int porM = flg_porJ(flags[(c - sj) >> 3]), porP = flg_porJ((uint8_t)flag0);
             double hc[5], hd[5];
-            rm_face(K, qjm, q0, Lm, URj, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, hc, hd);
+            if (XN) rm_face(K, qjm, q0, Lm, URj, nJm[0], nJm[1], nJm[2], porM, hc, hd);
+            else rm_face(K, qjm, q0, Lm, URj, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, hc, hd);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 if (FW) { acc[l] -= hc[l]; accD[l] -= hd[l]; }
                 else acc[l] -= hc[l] + hd[l];
             }
-            rm_face(K, q0, qjp, ULj, Rp, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, hc, hd);
+            if (XN) rm_face(K, q0, qjp, ULj, Rp, nJ[0], nJ[1], nJ[2], porP, hc, hd);
+            else rm_face(K, q0, qjp, ULj, Rp, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, hc, hd);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 if (FW) { acc[l] += hc[l]; accD[l] += hd[l]; }
@@ -367,12 +390,12 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     }
 }
 
-template <int LIM, bool FW, bool FINAL>
+template <int LIM, bool FW, bool FINAL, bool XN = false>
 __global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                              int kch)
 {
     __shared__ double xj[2 * RM_XJ];
-    roe_march_body<LIM, FW, FINAL>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
+    roe_march_body<LIM, FW, FINAL, XN>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
 }
 
 #ifndef ADF_ROE_BODY_ONLY
@@ -401,7 +424,10 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
         if (final_) hipLaunchKernelGGL((k_roe_march<LIM, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
-        if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, pad, s, tab, tiles, kp, kch);
+        if ((kp.metricFromX & 8) && !pad) {      // tuning metric_from_x bit 3: normals from the nodes
+            if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+            else hipLaunchKernelGGL((k_roe_march<LIM, false, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        } else if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, pad, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, pad, s, tab, tiles, kp, kch);
     }
 }

@@ -250,48 +250,7 @@ struct NgPtrs {
     GPTR(const double) x; double mfact;     // node coordinates and the cross-product factor (normals re-formed from the nodes)
 };
 
-// ---- face normals of a cell from its eight corner nodes, the formulas (and operand order) of metric_block
-// (adjointExtra.F90:176-268, k_metric in kernels_geom.hip): a marching thread loads the two nodes (i, j, k) and (i, j-1, k) of
-// its column per plane, takes the column i-1 by DPP and keeps the plane below: 6 loads instead of the 12 of sI, sJ(j-1), sJ, sK
-struct NgNodes { double a[3], b[3]; };          // x(i, j, k) and x(i, j-1, k)
-
-__device__ __forceinline__ void ngx_load(const NgPtrs& m, unsigned c, NgNodes& n)
-{
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { n.a[d] = ldg(m.x, c + d * m.nb8); n.b[d] = ldg(m.x, c - m.sj + d * m.nb8); }
-}
-
-__device__ __forceinline__ void ngx_cross(double fact, const double p1[3], const double p2[3], const double q1[3], const double q2[3],
-                                          double s[3])
-{
-    const double v1x = p1[0] - p2[0], v1y = p1[1] - p2[1], v1z = p1[2] - p2[2];
-    const double v2x = q1[0] - q2[0], v2y = q1[1] - q2[1], v2z = q1[2] - q2[2];
-    s[0] = fact * (v1y * v2z - v1z * v2y);
-    s[1] = fact * (v1z * v2x - v1x * v2z);
-    s[2] = fact * (v1x * v2y - v1y * v2x);
-}
-
-// sK of the node plane N alone (the plane below the first cell plane of a march)
-__device__ __forceinline__ void ngx_normal_k(double fact, const NgNodes& N, double nK[3])
-{
-    double Na1[3], Nb1[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { Na1[d] = lane_up1(N.a[d]); Nb1[d] = lane_up1(N.b[d]); }
-    ngx_cross(fact, N.a, Nb1, Na1, N.b, nK);                       // v1 = x(i,j,k) - x(l,m,k) ; v2 = x(l,j,k) - x(i,m,k)
-}
-
-// normals stored at the cell (i, j, k): sI, sJ(j-1), sJ, sK from the node planes k-1 (P) and k (N)
-__device__ __forceinline__ void ngx_normals(double fact, const NgNodes& P, const NgNodes& N, double nI[3], double nJm[3], double nJ[3],
-                                            double nK[3])
-{
-    double Na1[3], Nb1[3], Pa1[3], Pb1[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { Na1[d] = lane_up1(N.a[d]); Nb1[d] = lane_up1(N.b[d]); Pa1[d] = lane_up1(P.a[d]); Pb1[d] = lane_up1(P.b[d]); }
-    ngx_cross(fact, P.a, N.b, N.a, P.b, nI);                       // v1 = x(i,j,n) - x(i,m,k) ; v2 = x(i,j,k) - x(i,m,n)
-    ngx_cross(fact, P.a, Na1, Pa1, N.a, nJ);                       // v1 = x(i,j,n) - x(l,j,k) ; v2 = x(l,j,n) - x(i,j,k)
-    ngx_cross(fact, P.b, Nb1, Pb1, N.b, nJm);                      // the same one row below
-    ngx_cross(fact, N.a, Nb1, Na1, N.b, nK);
-}
+__device__ __forceinline__ void ngx_load(const NgPtrs& m, unsigned c, NgNodes& n) { ngx_load_x(m.x, c, m.nb8, m.sj, n); }
 
 // raw values of the cell at byte offset c (the loads of ng_record, issued early by the wave-specialised kernel)
 struct NgRaw { double rho, u, v, w, p, sI[3], sJm[3], sJ[3], sK[3], vol; };

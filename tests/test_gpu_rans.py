@@ -4,8 +4,8 @@ reference's own Fortran (oracle/_ref).  BASELINE configs 3-4 parity sizes."""
 import pytest
 
 import checks
-from adflow_amd.params import (FlowParams, dissScalar, dissMatrix, upwind, NSEquations, RANSEquations, secondOrder,
-                               vorticity)
+from adflow_amd.params import (FlowParams, dissScalar, dissMatrix, upwind, EulerEquations, NSEquations, RANSEquations, secondOrder,
+                               vorticity, noLimiter, vanAlbeda, minmod)
 
 pytestmark = pytest.mark.gpu
 
@@ -143,10 +143,14 @@ def test_viscous_kernel_variants(engine):
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
         engine.set_tuning("sa_march", 1)
-        for mx in (0, 1):           # face normals from the arrays everywhere / re-formed from the nodes in the SA march only (default: both marches)
+        for mx in (0, 1, 15):       # face normals from the arrays everywhere / re-formed from the nodes in the SA march only / in
+                                    # every march incl. the Roe one (bit 3); the default 7 = SA + gradient marches + time step
             engine.set_tuning("metric_from_x", mx)
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=20 + mx, stretch_k=2.0, holes=0.05)
+            if mx == 15:
+                for lim in (noLimiter, vanAlbeda, minmod):
+                    checks.check_block_res(engine, (61, 6, 5), FlowParams(equations=EulerEquations, spaceDiscr=upwind, limiter=lim), seed=40 + lim)
             engine.set_tuning("roe_grad_mix", 1)      # Roe march and gradient march as one interleaved launch
             checks.check_block_res(engine, (23, 9, 7), prm, seed=30 + mx, stretch_k=2.0)
             engine.set_tuning("roe_grad_mix", 0)
