@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows, g_grad_sa_fused, g_sa_march, g_roe_lds_pad, g_roe_grad_mix;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows, g_grad_sa_fused, g_sa_march, g_roe_lds_pad, g_roe_grad_mix, g_xcd_tiles, g_grad_kch;
 
 namespace {
 
@@ -29,6 +29,7 @@ hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr;
 hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
+int g_overlap_grad = 1, g_overlap_sa = 1;     // tuning "overlap_grad" / "overlap_sa": the gradient march / the SA residual on their own queues
 adflow_opts g_opts;
 bool g_have_opts = false;
 hipEvent_t g_events[64];
@@ -994,7 +995,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         if (ensure_tiles(level)) return 1;
         mixed = launch_roe_grad_mix(g_tab[level], g_tiles[level].first, g_tiles[level].second, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
-    if (viscMarch && !mixed && g_overlap && g_phase_base <= 0) {
+    if (viscMarch && !mixed && g_overlap && g_overlap_grad && g_phase_base <= 0) {
         HIPCHK(hipEventRecord(g_evFork, g_stream));
         HIPCHK(hipStreamWaitEvent(g_streamC, g_evFork, 0));
         gradForked = true;
@@ -1161,7 +1162,7 @@ static int block_res_enqueue(int level, unsigned flags)
             LevelTab t;
             if (level_tab(level, &t)) return 1;
             hipStream_t ss = g_stream;
-            if (g_overlap && g_phase_base <= 0 && (flags & ADFLOW_RES_FLOW)) {
+            if (g_overlap && g_overlap_sa && g_phase_base <= 0 && (flags & ADFLOW_RES_FLOW)) {
                 // fork: the SA residual (writes dw(:,:,:,itu1) only) runs beside the mean-flow kernels; joined below
                 HIPCHK(hipEventRecord(g_evFork, g_stream));
                 HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
@@ -2793,6 +2794,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "grad_sa_fused")) { g_grad_sa_fused = value; return 0; }
     if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
     if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
+    if (!strcmp(key, "overlap_grad")) { g_overlap_grad = value; return 0; }
+    if (!strcmp(key, "overlap_sa")) { g_overlap_sa = value; return 0; }
     if (!strcmp(key, "roe_grad_mix")) { g_roe_grad_mix = value; return 0; }
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }
     if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
@@ -2801,6 +2804,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "euler_radii")) { g_euler_radii = value; return 0; }
     if (!strcmp(key, "visc_approx_march")) { g_visc_approx_march = value; return 0; }
     if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }
+    if (!strcmp(key, "xcd_tiles")) { g_xcd_tiles = value; return 0; }
+    if (!strcmp(key, "grad_kch")) { g_grad_kch = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {
         if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");

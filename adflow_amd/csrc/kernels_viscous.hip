@@ -351,15 +351,15 @@ __device__ __forceinline__ void ng_outer(double g[12], double sign, const double
 // body of the kernel for the workgroup (bx, by, bz) of its grid; xr: 2 * NG_BY * NG_SLOT doubles of LDS owned by the caller
 template <bool XN>
 __device__ __forceinline__ void node_grad_body(const BlkView* __restrict__ tab, int nzb, double gam, int bx, int by, int bz,
-                                               double* __restrict__ xr)
+                                               double* __restrict__ xr, int kch = NG_KCH)
 {
     constexpr bool xn = XN;          // face normals re-formed from the node coordinates (tuning metric_from_x & 2: not faster here)
     const BlkView& b = tab[bz / nzb + 1];                 // level-batched: bz = slot * nzb + k chunk
     const int lane = threadIdx.x, row = threadIdx.y;
     const int i0 = bx * NG_OUT + 1, j0 = by * NG_BY + 1;      // first node of the tile
-    const int kn0 = (bz % nzb) * NG_KCH + 1;
+    const int kn0 = (bz % nzb) * kch + 1;
     if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
-    const int kn1 = (kn0 + NG_KCH - 1 < b.kl) ? kn0 + NG_KCH - 1 : b.kl;
+    const int kn1 = (kn0 + kch - 1 < b.kl) ? kn0 + kch - 1 : b.kl;
     const int i = i0 - 1 + lane, j = j0 + row;
     const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
     const int jx = (j0 + NG_BY < b.jb) ? j0 + NG_BY : b.jb;                    // cell row above the tile (record made by wave 0)
@@ -457,11 +457,51 @@ __device__ __forceinline__ void node_grad_body(const BlkView* __restrict__ tab, 
     }
 }
 
+// 1-D launches of the gradient / SA marches: the dispatcher places workgroup p on XCD p % 8, so with `per` = workgroups per XCD
+// the tile index is (p % 8) per + p / 8: every XCD owns a contiguous run of the (i, j, k chunk, block) tile order and the rows
+// shared by j-neighbouring tiles meet in one L2 instead of being fetched from HBM by two XCDs.  per = 0: tile index = p.
+struct TileGrid { int gx, gy, total, per, kch; };     // kch: node planes per march
+
+__device__ __forceinline__ bool tile_of_workgroup(const TileGrid& g, int& bx, int& by, int& bz)
+{
+    const int p = (int)blockIdx.x;
+    const int t = g.per ? (p & 7) * g.per + (p >> 3) : p;
+    if (t >= g.total) return false;
+    bx = t % g.gx;
+    const int r = t / g.gx;
+    by = r % g.gy; bz = r / g.gy;
+    return true;
+}
+
+int g_xcd_tiles = 1;        // tuning "xcd_tiles": 0 = gradient / SA march tiles in launch order
+
+int g_grad_kch = NG_KCH;    // tuning "grad_kch": longest k chunk of the gradient / SA marches; the node planes are spread evenly over the chunks
+
+// chunks of nzn node planes: count and (balanced) length
+static void node_chunks(int nzn, int* nchn, int* kch)
+{
+    const int L = g_grad_kch > 0 ? g_grad_kch : NG_KCH;
+    *nchn = (nzn + L - 1) / L;
+    *kch = (nzn + *nchn - 1) / *nchn;
+}
+
+static TileGrid tile_grid(int gx, int gy, int nchn, int nslots, int kch)
+{
+    TileGrid g;
+    g.gx = gx; g.gy = gy; g.total = gx * gy * nchn * nslots;
+    g.per = g_xcd_tiles ? (g.total + 7) / 8 : 0;
+    g.kch = kch;
+    return g;
+}
+static int tile_grid_size(const TileGrid& g) { return g.per ? 8 * g.per : g.total; }
+
 template <bool XN>
-__global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView* __restrict__ tab, int nzb, double gam)
+__global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView* __restrict__ tab, int nzb, double gam, TileGrid tg)
 {
     __shared__ double xr[2 * NG_BY * NG_SLOT];            // [parity][row slot 0..3 = cell rows j0+1 .. j0+4][value][lane]
-    node_grad_body<XN>(tab, nzb, gam, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, xr);
+    int bx, by, bz;
+    if (!tile_of_workgroup(tg, bx, by, bz)) return;
+    node_grad_body<XN>(tab, nzb, gam, bx, by, bz, xr, tg.kch);
 }
 
 // ---------------------------------------------------------------------------
@@ -582,18 +622,20 @@ __device__ __forceinline__ void gs_record(const GsCell& q, double gam, const dou
 // j neighbours are plain loads and the rows j0-2 .. j0+ROWS+1 a workgroup touches are re-read by the workgroups above and below
 // (349 B per cell at 4 rows, profiles/r02_k_pmc_traffic.txt, at 6.5 TB/s: the kernel is bound by exactly that traffic)
 template <bool GRAD, int ROWS, bool LX = false>
-__global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp)
+__global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
 {
     __shared__ double xr[GRAD ? 2 * NG_BY * NG_SLOT : 1];
     // LX (tuning sa_march = 3): the state a cell contributes to its j neighbours (u, v, w, nu, vol, nuTilde) goes through LDS,
     // double buffered over the planes, instead of plain loads of the rows j +- 1, j +- 2
     __shared__ double sq[LX ? 2 * ROWS * 6 * 64 : 1];
-    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    int bx, by, bz;
+    if (!tile_of_workgroup(tg, bx, by, bz)) return;
+    const BlkView& b = tab[bz / nzb + 1];
     const int lane = threadIdx.x, row = threadIdx.y;
-    const int i0 = blockIdx.x * GS_OUT + 1, j0 = blockIdx.y * ROWS + 1;      // first node of the tile
-    const int kn0 = (blockIdx.z % nzb) * NG_KCH + 1;
+    const int i0 = bx * GS_OUT + 1, j0 = by * ROWS + 1;      // first node of the tile
+    const int kn0 = (bz % nzb) * tg.kch + 1;
     if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
-    const int kn1 = (kn0 + NG_KCH - 1 < b.kl) ? kn0 + NG_KCH - 1 : b.kl;
+    const int kn1 = (kn0 + tg.kch - 1 < b.kl) ? kn0 + tg.kch - 1 : b.kl;
     const int i = i0 - 1 + lane, j = j0 + row;
     const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
     const int jx = (j0 + ROWS < b.jb) ? j0 + ROWS : b.jb;
@@ -2210,9 +2252,10 @@ void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz
     LEVEL_SPLIT(nslots, nz + 4, launch_grad_sa_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     const int nzn = nz + 1;
-    const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
-    hipLaunchKernelGGL((k_grad_sa_march<true, NG_BY>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                       dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
+    int nchn, kch;
+    node_chunks(nzn, &nchn, &kch);
+    const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
+    hipLaunchKernelGGL((k_grad_sa_march<true, NG_BY>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
 }
 
 int g_roe_grad_mix = 0;     // tuning "roe_grad_mix": inviscid Roe march and nodal-gradient march in one interleaved launch.  Off since the
@@ -2253,16 +2296,19 @@ void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int n
     LEVEL_SPLIT(nslots, nz + 4, launch_sa_march_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     const int nzn = nz + 1;
-    const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
-    if (g_sa_march == 3)       // j neighbours through LDS: 287 instead of 349 B per cell from HBM, one barrier per plane, no faster (profiles/r02_x)
-        hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY, true>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
-    else if (g_sa_march < 2)
-        hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp);
-    else
-        hipLaunchKernelGGL((k_grad_sa_march<false, 8>), dim3((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + 7) / 8, nchn * nslots), dim3(64, 8, 1), 0, s,
-                           tab, nchn, kp);
+    int nchn, kch;
+    node_chunks(nzn, &nchn, &kch);
+    const int gx = (nx + 1 + GS_OUT - 1) / GS_OUT;
+    if (g_sa_march == 3) {     // j neighbours through LDS: 287 instead of 349 B per cell from HBM, one barrier per plane, no faster (profiles/r02_x)
+        const TileGrid tg = tile_grid(gx, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
+        hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY, true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
+    } else if (g_sa_march < 2) {
+        const TileGrid tg = tile_grid(gx, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
+        hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
+    } else {
+        const TileGrid tg = tile_grid(gx, (ny + 1 + 7) / 8, nchn, nslots, kch);
+        hipLaunchKernelGGL((k_grad_sa_march<false, 8>), dim3(tile_grid_size(tg)), dim3(64, 8, 1), 0, s, tab, nchn, kp, tg);
+    }
 }
 
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
@@ -2270,13 +2316,13 @@ void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny,
     LEVEL_SPLIT(nslots, nz + 4, launch_node_gradients_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
     const int nzn = nz + 1;
-    const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
+    int nchn, kch;
+    node_chunks(nzn, &nchn, &kch);
+    const TileGrid tgn = tile_grid((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
     if (kp.metricFromX & 2)
-        hipLaunchKernelGGL(k_node_grad_march<true>, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+        hipLaunchKernelGGL(k_node_grad_march<true>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
     else
-        hipLaunchKernelGGL(k_node_grad_march<false>, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                           dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+        hipLaunchKernelGGL(k_node_grad_march<false>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
 }
 
 void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
@@ -2286,13 +2332,13 @@ void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz
     dim3 blk(VS_BX, VS_BY, 1);
     const int nzn = nz + 1;                              // node planes 1..kl
     if (g_viscous_tiled >= 2) {
-        const int nchn = (nzn + NG_KCH - 1) / NG_KCH;
+        int nchn, kch;
+        node_chunks(nzn, &nchn, &kch);
+        const TileGrid tgn = tile_grid((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
         if (kp.metricFromX & 2)
-            hipLaunchKernelGGL(k_node_grad_march<true>, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                               dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+            hipLaunchKernelGGL(k_node_grad_march<true>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
         else
-            hipLaunchKernelGGL(k_node_grad_march<false>, dim3((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn * nslots),
-                               dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant);
+            hipLaunchKernelGGL(k_node_grad_march<false>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
     } else
         hipLaunchKernelGGL(k_nodal_gradients_t, dim3((nx + 1 + VS_BX - 1) / VS_BX, (ny + 1 + VS_BY - 1) / VS_BY, nzn * nslots), blk, 0, s,
                            tab, nzn);

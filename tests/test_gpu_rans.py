@@ -143,6 +143,13 @@ def test_viscous_kernel_variants(engine):
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
         engine.set_tuning("sa_march", 1)
+        for xt, gk in ((0, 32), (1, 5), (1, 64)):     # gradient / SA march tiles in launch order; k chunks of <= 5 planes; one chunk
+            engine.set_tuning("xcd_tiles", xt)
+            engine.set_tuning("grad_kch", gk)
+            prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
+            checks.check_block_res(engine, (63, 11, 35), prm, seed=50 + gk, stretch_k=2.0, holes=0.05)
+        engine.set_tuning("xcd_tiles", 1)
+        engine.set_tuning("grad_kch", 32)
         for mx in (0, 1, 15):       # face normals from the arrays everywhere / re-formed from the nodes in the SA march only / in
                                     # every march incl. the Roe one (bit 3); the default 7 = SA + gradient marches + time step
             engine.set_tuning("metric_from_x", mx)
@@ -160,6 +167,8 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("sa_march", 1)
         engine.set_tuning("metric_from_x", 7)
         engine.set_tuning("roe_grad_mix", 0)
+        engine.set_tuning("xcd_tiles", 1)
+        engine.set_tuning("grad_kch", 32)
 
 
 def test_visc_wave_specialised(engine):
