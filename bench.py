@@ -269,6 +269,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported under 'extra' (N=1)")
+    ap.add_argument("--force-extras", action="store_true", help="run the extras although --tuning is given (A/B runs of a tuning key)")
     ap.add_argument("--no-mg", action="store_true", help="skip the config-2 multigrid cycle measurement")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K steps until the region lasts this long")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
@@ -327,7 +328,7 @@ def main():
         dist.all_reduce(t_, op=dist.ReduceOp.MAX)
         return float(t_.item())
 
-    extras_on = (world == 1 and not a.no_extras and a.workload == DEFAULT_WORKLOAD and not a.tuning)
+    extras_on = (world == 1 and not a.no_extras and a.workload == DEFAULT_WORKLOAD and (not a.tuning or a.force_extras))
     job = Job(a, a.workload, eng, rank, world, keep_w=extras_on)
     wl, prm = job.wl, job.prm
     eng.set_async(True)
