@@ -19,7 +19,14 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 import checks  # noqa: E402
 from adflow_amd.params import (FlowParams, EulerEquations, NSEquations, RANSEquations, dissScalar, dissMatrix, upwind,  # noqa: E402
-                               noLimiter, vanAlbeda, minmod, firstOrder, secondOrder)
+                               noLimiter, vanAlbeda, minmod, firstOrder, secondOrder, DADI, RungeKutta, noResAveraging,
+                               alternateResAveraging)
+from adflow_amd.topology import BrickTopology  # noqa: E402
+
+# BCType: -1 symm, -3 adiabatic wall, -4 isothermal wall, -5 Euler wall, -6 farfield, -7 supersonic inflow, -9 supersonic outflow,
+# -15 extrap
+EULER_BC = [-1, -5, -6, -7, -9, -15]
+VISC_BC = [-1, -3, -4, -6, -7, -9, -15]
 
 EDGE_NX = [1, 2, 3, 5, 58, 59, 60, 61, 62, 63, 64, 65, 119, 120, 121, 124, 125]
 EDGE_NY = [1, 2, 3, 4, 5, 7, 8, 9, 12, 13]
@@ -56,7 +63,22 @@ def draw_case(rng):
         mk["holes"] = 0.05
     if rng.random() < 0.15:
         mk["left_handed"] = True
-    entry = str(rng.choice(["block_res", "blockette", "blockette_intermed"], p=[0.6, 0.25, 0.15]))
+    entry = str(rng.choice(["block_res", "blockette", "blockette_intermed", "approx", "bc", "rk", "dadi", "sa_solve", "nk"],
+                           p=[0.3, 0.1, 0.1, 0.1, 0.15, 0.07, 0.06, 0.06, 0.06]))
+    if entry == "bc":
+        kinds = EULER_BC if eq == EulerEquations else VISC_BC
+        mk["spec"] = {f: int(rng.choice(kinds)) for f in range(1, 7)}
+        mk["secondHalo"] = bool(rng.random() < 0.6)
+        mk.pop("left_handed", None)
+    if entry in ("rk", "dadi", "sa_solve", "nk"):
+        # periodic bricks of 1 - 2 blocks; even cell counts are not needed on a single grid
+        mk = dict(seed=mk["seed"], topo=(int(rng.integers(1, 3)), int(rng.integers(1, 3)), 1,
+                                       int(rng.integers(3, 20)), int(rng.integers(3, 10)), int(rng.integers(3, 9))))
+        if entry == "sa_solve":
+            kw["equations"] = RANSEquations
+            kw["nSubIterTurb"] = int(rng.integers(1, 3))
+        if entry in ("rk", "dadi"):
+            kw["resAveraging"] = int(rng.choice([noResAveraging, alternateResAveraging]))
     return (nx, ny, nz), kw, mk, entry
 
 
@@ -64,11 +86,43 @@ def run_case(engine, dims, kw, mk, entry):
     prm = FlowParams(**kw)
     mk = dict(mk)
     seed = mk.pop("seed")
-    if entry == "block_res" or not kw.get("dirScaling", True):
+    if entry == "approx":
+        mk.pop("left_handed", None)
+        checks.check_block_res_approx(engine, dims, prm, seed=seed, **mk)
+    elif entry == "bc":
+        spec, second = mk.pop("spec"), mk.pop("secondHalo")
+        checks.check_apply_bc(engine, (max(dims[0], 2), max(dims[1], 2), max(dims[2], 1)), prm, spec, secondHalo=second, seed=seed, **mk)
+    elif entry in ("rk", "dadi", "sa_solve", "nk"):
+        topo = BrickTopology(*mk.pop("topo"))
+        if entry == "rk":
+            checks.check_rk_smoother(engine, topo, prm.replace(smoother=RungeKutta), seed=seed)
+        elif entry == "dadi":
+            checks.check_dadi_smoother(engine, topo, prm.replace(smoother=DADI, cfl=1.5), seed=seed)
+        elif entry == "sa_solve":
+            checks.check_sa_solve(engine, topo, prm, seed=seed)
+        else:
+            checks.check_nk_residual(engine, topo, prm, seed=seed)
+    elif entry == "block_res" or not kw.get("dirScaling", True):
         # (blocketteResCore scales the dissipation unconditionally: the dirScaling = F case has blockResCore as its reference)
         checks.check_block_res(engine, dims, prm, seed=seed, **mk)
     else:
         checks.check_block_res_vs_blockette(engine, dims, prm, update_intermed=(entry == "blockette_intermed"), seed=seed, **mk)
+
+
+def sweep(engine, cases, seed, only=-1, quiet=False):
+    """Run `cases` random cases; returns (number run, description of the first failure or None)."""
+    rng = np.random.default_rng(seed)
+    for n in range(cases):
+        dims, kw, mk, entry = draw_case(rng)
+        if only >= 0 and n != only:
+            continue
+        try:
+            run_case(engine, dims, kw, mk, entry)
+            if not quiet:
+                print(f"[{n:4d}] ok   {dims} {entry} {kw} {mk}", flush=True)
+        except AssertionError as ex:
+            return n + 1, f"case {n} (seed {seed}): {dims} {entry} {kw} {mk}: {ex}"
+    return cases, None
 
 
 def main():
@@ -84,22 +138,13 @@ def main():
     else:
         from hostsim.build import build
         eng = Engine(0, _lib_path=build())
-    rng = np.random.default_rng(a.seed)
     t0 = time.time()
-    nfail = 0
-    for n in range(a.cases):
-        dims, kw, mk, entry = draw_case(rng)
-        if a.only >= 0 and n != a.only:
-            continue
-        try:
-            run_case(eng, dims, kw, mk, entry)
-            print(f"[{n:4d}] ok   {dims} {entry} {kw} {mk}", flush=True)
-        except AssertionError as ex:
-            nfail += 1
-            print(f"[{n:4d}] FAIL {dims} {entry} {kw} {mk}: {ex}", flush=True)
-            print(f"reproduce: python tests/fuzz_parity.py --seed {a.seed} --cases {a.cases} --only {n}" + (" --gpu" if a.gpu else ""))
-            break
-    print(f"{a.cases if not nfail else n + 1} cases, {nfail} failures, {time.time() - t0:.0f} s")
+    n, failure = sweep(eng, a.cases, a.seed, a.only)
+    if failure:
+        print("FAIL", failure)
+        print(f"reproduce: python tests/fuzz_parity.py --seed {a.seed} --cases {a.cases} --only {n - 1}" + (" --gpu" if a.gpu else ""))
+    print(f"{n} cases, {1 if failure else 0} failures, {time.time() - t0:.0f} s")
+    nfail = 1 if failure else 0
     eng.close()
     return 1 if nfail else 0
 

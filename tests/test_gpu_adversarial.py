@@ -95,3 +95,10 @@ def sa_cases(engine, dims):
 
 def test_spalart_allmaras_limiters(engine):
     sa_cases(engine, (24, 8, 16))
+
+
+def test_random_parity_sweep(engine):
+    """tests/fuzz_parity.py on the GPU: 300 random cases (sizes around the tile edges, options, entry points) against the reference"""
+    import fuzz_parity
+    n, failure = fuzz_parity.sweep(engine, 300, seed=20260926, quiet=True)
+    assert failure is None, failure

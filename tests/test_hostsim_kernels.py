@@ -480,3 +480,11 @@ def test_mach3_shock_default_flags(hostsim_engine):
 def test_normals_not_derived_from_the_nodes_keep_the_stored_normals(hostsim_engine):
     import test_gpu_rans
     test_gpu_rans.test_normals_not_derived_from_the_nodes_keep_the_stored_normals(hostsim_engine)
+
+
+def test_random_parity_sweep(hostsim_engine):
+    """a sample of tests/fuzz_parity.py: random sizes around the tile edges, random options, entry points (block_res, the blockette
+    twin, approximate residual, boundary conditions, RK / D-ADI smoothers, SA solve, NK residual), all against the reference"""
+    import fuzz_parity
+    n, failure = fuzz_parity.sweep(hostsim_engine, 40, seed=20260926, quiet=True)
+    assert failure is None, failure
