@@ -29,6 +29,7 @@ hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr;
 hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
+int g_visc_first = 1;      // tuning "visc_first"
 int g_overlap_grad = 1, g_overlap_sa = 1;     // tuning "overlap_grad" / "overlap_sa": the gradient march / the SA residual on their own queues
 adflow_opts g_opts;
 bool g_have_opts = false;
@@ -324,7 +325,8 @@ int for_level(int level, Fn fn)
 
 }  // namespace
 // instrumentation of blocketteRes (tuning "phase_events" = first event slot): marks 0 entry, 1 closures / BCs / halos done,
-// 2 time step, 3 SA residual, 4 inviscid fluxes, 5 nodal gradients, 6 viscous fluxes + sources (end)
+// 2 time step, 3 SA residual, 4 inviscid fluxes, 5 nodal gradients, 6 viscous fluxes + sources (end); with the viscous march in
+// front of the Roe march (tuning visc_first): 4 nodal gradients, 5 viscous fluxes, 6 inviscid fluxes + sources
 void adf_phase_mark(int i)
 {
     static unsigned hit = 0;
@@ -995,7 +997,11 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         if (ensure_tiles(level)) return 1;
         mixed = launch_roe_grad_mix(g_tab[level], g_tiles[level].first, g_tiles[level].second, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
-    if (viscMarch && !mixed && g_overlap && g_overlap_grad && g_phase_base <= 0) {
+    // viscous march first, Roe march last (tuning "visc_first"): the Roe kernel, bound by FP64 issue, adds the viscous sums it finds
+    // in dw(2:5) instead of the viscous kernel, bound by HBM, reading dw back
+    const bool viscFirst = g_visc_first && viscMarch && !mixed && !withSA && !kp.fwMode && !anyMoving && inviscid_march_enabled() &&
+                           !kp.dissApprox && !kp.lumpedDiss && roe_march_takes(kp);
+    if (viscMarch && !mixed && !viscFirst && g_overlap && g_overlap_grad && g_phase_base <= 0) {
         HIPCHK(hipEventRecord(g_evFork, g_stream));
         HIPCHK(hipStreamWaitEvent(g_streamC, g_evFork, 0));
         gradForked = true;
@@ -1005,6 +1011,8 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     const bool scalarVisc = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
     if (mixed) {
         // inviscid part already enqueued
+    } else if (viscFirst) {
+        // enqueued behind the viscous march below
     } else if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) &&
                (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving) {
         // (the approximate residual changes the Roe scheme only through the limiter: inviscidUpwindFlux is called either way)
@@ -1017,7 +1025,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     } else {
         launch_inviscid_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
-    phase_mark(4);
+    if (!viscFirst) phase_mark(4);
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
     const bool batched = !viscApprox && viscous_is_tiled();
     // thin-layer viscous flux of the preconditioner assembly: marching form over the tile table (blocks at rest, 4-row tiles)
@@ -1047,6 +1055,18 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     } else if (batched && viscous_is_tiled() >= 2 && g_march_by == 4) {
         // k-marching nodal gradients (with the SA residual when the caller left it to this kernel), then the k-marching face
         // kernel over the level's tile table
+        if (viscFirst) {
+            KParams kv = kp;
+            kv.viscFirst = 1;
+            if (ensure_tiles(level)) return 1;
+            // (phase marks in this order: 4 = nodal gradients, 5 = viscous fluxes, 6 = inviscid fluxes; bench.py labels them so)
+            launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kv, g_stream);
+            phase_mark(4);
+            launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+            phase_mark(5);
+            launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+            return 0;
+        }
         hipStream_t sg = gradForked ? g_streamC : g_stream;
         if (mixed) { /* gradients came with the inviscid launch */ }
         else if (withSA) launch_grad_sa_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, sg);
@@ -2795,6 +2815,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
     if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
     if (!strcmp(key, "overlap_grad")) { g_overlap_grad = value; return 0; }
+    if (!strcmp(key, "visc_first")) { g_visc_first = value; return 0; }
     if (!strcmp(key, "overlap_sa")) { g_overlap_sa = value; return 0; }
     if (!strcmp(key, "roe_grad_mix")) { g_roe_grad_mix = value; return 0; }
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }

@@ -279,6 +279,7 @@ struct KParams {
     int fwMode;            // 0: fw not persistent (rFil==1, sfil==0, no store)  1: persistent fw
     int storeIntermed;     // store dtl / radii
     int dissApprox;        // lumped dissipation with the frozen sensor in b.ss (inviscidDissFlux*Approx)
+    int viscFirst;         // the viscous march runs BEFORE the Roe march: it writes its flux sums into dw(2:5), the Roe march adds them and completes dw
     int radiiInMarch;      // the Euler march forms the spectral radii itself (no k_time_step pass in front)
     int metricFromX;       // marching kernels re-form the face normals from the node coordinates (as blocketteResCore, blockette.F90:854-960)
     int lumpedDiss;        // inputDiscretization::lumpedDiss (preconditioner assembly): first-order Roe upwind (fluxes.F90:1536)
@@ -423,6 +424,7 @@ void launch_halo_unpack(const BlkView* tab, const int* blk, const long* off, int
 void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 int inviscid_march_enabled();
 bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+bool roe_march_takes(const KParams& kp);
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
 void launch_restrict_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

@@ -193,7 +193,8 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
 // written here, otherwise the sum dw + fw is left in dw for the viscous kernel to complete (residuals.F90:334-344)
 // body of the kernel for workgroup `bid` of the tile table; xj: 2 * RM_XJ doubles of LDS (the caller owns the allocation so that
 // the mixed kernel of kernels_viscous.hip can give the same bytes to either of its two bodies)
-template <int LIM, bool FW, bool FINAL, bool XN = false>
+// ADDV (with FINAL, without FW): dw(2:5) holds the viscous flux sums of k_visc_march<.., FIRST> on entry; they are added before iblank
+template <int LIM, bool FW, bool FINAL, bool XN = false, bool ADDV = false>
 __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, const KParams& kp, int kch,
                                                int bid, double* __restrict__ xj)
 {
@@ -254,6 +255,11 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     for (int k = k0; k <= k1 + 1; ++k) {
         const RCell qp1 = rm_ld(m, c + sk);
         const int flag0 = flags[c >> 3];
+        double vsum[4] = {0, 0, 0, 0};       // ADDV: viscous flux sums of the cell finished in this step, requested a step's work ahead
+        if (ADDV && k > k0 && out) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) vsum[l] = ldg((GPTR(const double))dw + (l + 1) * nb, c - sk);
+        }
         double* __restrict__ xb = xj + ((k - k0) & 1) * RM_XJ;
         const bool body = (k <= k1);
         RCell qjm, qjp;
@@ -323,6 +329,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
                     stg(dw + l * nb, cw, FINAL ? (d + fwn) * blank : d);
                 } else {
                     d += fd[l];
+                    if (ADDV && l > 0) d += vsum[l - 1];
                     stg(dw + l * nb, cw, d * blank);      // not FINAL: the viscous kernel adds its part to dw(2:5) and re-applies iblank
                 }
             }
@@ -390,12 +397,12 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     }
 }
 
-template <int LIM, bool FW, bool FINAL, bool XN = false>
+template <int LIM, bool FW, bool FINAL, bool XN = false, bool ADDV = false>
 __global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                              int kch)
 {
     __shared__ double xj[2 * RM_XJ];
-    roe_march_body<LIM, FW, FINAL, XN>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
+    roe_march_body<LIM, FW, FINAL, XN, ADDV>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
 }
 
 #ifndef ADF_ROE_BODY_ONLY
@@ -423,6 +430,8 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
     if (kp.fwMode) {
         if (final_) hipLaunchKernelGGL((k_roe_march<LIM, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
+    } else if (kp.viscFirst) {
+        hipLaunchKernelGGL((k_roe_march<LIM, false, true, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
         if ((kp.metricFromX & 8) && !pad) {      // tuning metric_from_x bit 3: normals from the nodes
             if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
@@ -430,6 +439,13 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
         } else if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, pad, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, pad, s, tab, tiles, kp, kch);
     }
+}
+
+bool roe_march_takes(const KParams& kp)
+{
+    if (!g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid) return false;
+    const int lim = kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter;
+    return lim == ADFLOW_LIM_FIRST_ORDER || lim == ADFLOW_LIM_NONE || lim == ADFLOW_LIM_VANALBADA || lim == ADFLOW_LIM_MINMOD;
 }
 
 // true when the launch was taken: second-order Roe upwind on the fine level of blocks at rest

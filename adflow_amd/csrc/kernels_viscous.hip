@@ -1410,7 +1410,9 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gs[12], const
 // APPROX: viscousFluxApprox (fluxes.F90:3487-3859), the thin-layer form of the preconditioner assembly: the face gradient is the
 // difference of the two cell values along the centre-to-centre vector, i.e. the formulas below with the nodal gradients set to
 // zero -- no gradient loads, no LDS ring
-template <bool QCR, int SB, bool APPROX = false>
+// FIRST: the kernel runs before the inviscid march: its flux sums are stored to dw(2:5) as they are, k_roe_march<.., ADDV> adds
+// them to its own sums and applies iblank (saves this kernel the read of dw: the Roe kernel is bound by FP64 issue, not by HBM)
+template <bool QCR, int SB, bool APPROX = false, bool FIRST = false>
 __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                               int kch)
 {
@@ -1555,13 +1557,14 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
             for (int l = 0; l < 4; ++l) {
                 const unsigned o = c + (l + 1) * nb8;
                 double fwn = acc[l];
+                if (FIRST) { stg(dw, o, fwn); continue; }
                 if (kp.fwMode) {
                     fwn += ldg(fw, o);
                     stg(fw, o, fwn);
                 }
                 stg(dw, o, (ldg(dw, o) + fwn) * blank);
             }
-            if (kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
+            if (!FIRST && kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
         }
         q0 = qp1;
         c += sk;
@@ -2217,7 +2220,10 @@ void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const 
 {
     if (ntiles <= 0) return;
     const dim3 blk(64, VM_BY, 1), grd(ntiles);
-    if (kp.useQCR) hipLaunchKernelGGL((k_visc_march<true, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+    if (kp.viscFirst) {
+        if (kp.useQCR) hipLaunchKernelGGL((k_visc_march<true, 1, false, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+        else hipLaunchKernelGGL((k_visc_march<false, 0, false, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+    } else if (kp.useQCR) hipLaunchKernelGGL((k_visc_march<true, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
     else if (g_visc_sb == 0) hipLaunchKernelGGL((k_visc_march<false, 0>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
     else if (g_visc_sb == 1) hipLaunchKernelGGL((k_visc_march<false, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
     else hipLaunchKernelGGL((k_visc_march<false, 2>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);

@@ -56,6 +56,8 @@ WORKLOADS = {
 }
 DEFAULT_WORKLOAD = "crm_rans_sa_upwind_8x160x128x64"
 PHASES = ["closures+bc", "time step", "SA residual", "inviscid", "nodal gradients", "viscous"]   # between marks 0..6 of api.hip
+# Roe upwind + viscous fluxes (tuning visc_first, default on): the viscous march runs in front of the Roe march, marks 4..6 in that order
+PHASES_VISC_FIRST = ["closures+bc", "time step", "SA residual", "nodal gradients", "viscous", "inviscid"]
 
 
 CPU_WORKER = r"""
@@ -240,7 +242,7 @@ def timed(eng, fn, steps, barrier, min_seconds=1.0, max_reps=2000, agree=None):
     return dt / (reps * steps), reps, eng.event_elapsed_ms(0, 1) / (reps * steps)
 
 
-def phase_times(eng, fn, n=10):
+def phase_times(eng, fn, n=10, names=PHASES):
     """live HIP-event durations (ms) between the phase marks of blocketteRes, averaged over n evaluations"""
     base = 40
     eng.set_tuning("phase_events", base)
@@ -258,7 +260,7 @@ def phase_times(eng, fn, n=10):
             except Exception:
                 pass        # mark not recorded by this configuration (e.g. no viscous part)
     eng.set_tuning("phase_events", 0)
-    return {PHASES[m]: acc[m] / ok[m] for m in range(6) if ok[m]}
+    return {names[m]: acc[m] / ok[m] for m in range(6) if ok[m]}
 
 
 def main():
@@ -345,7 +347,8 @@ def main():
 
     # ---- per-kernel durations of one evaluation, live HIP events on the library's stream
     eng.set_async(False)
-    ph = phase_times(eng, job.step)
+    visc_first = int(tuning.get("visc_first", 1)) != 0 and "upwind" in a.workload
+    ph = phase_times(eng, job.step, names=PHASES_VISC_FIRST if visc_first else PHASES)
     log("phases (ms): " + ", ".join(f"{k} {v:.3f}" for k, v in ph.items()))
     kern = {k: v for k, v in ph.items() if k != "closures+bc"}
     dom = max(kern, key=kern.get)
