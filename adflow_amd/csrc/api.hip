@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows, g_grad_sa_fused, g_sa_march, g_roe_lds_pad, g_roe_grad_mix, g_xcd_tiles, g_grad_kch;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows, g_grad_sa_fused, g_sa_march, g_roe_lds_pad, g_roe_grad_mix, g_xcd_tiles, g_grad_kch, g_dadi_post_i_fused;
 
 namespace {
 
@@ -2827,6 +2827,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }
     if (!strcmp(key, "xcd_tiles")) { g_xcd_tiles = value; return 0; }
     if (!strcmp(key, "grad_kch")) { g_grad_kch = value; return 0; }
+    if (!strcmp(key, "dadi_post_i_fused")) { g_dadi_post_i_fused = value; return 0; }
     if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {
         if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");

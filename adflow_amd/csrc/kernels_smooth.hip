@@ -700,7 +700,9 @@ __device__ __forceinline__ void dadi_post_k(const BlkView& b, long c, double d[5
 //  DIR 2 (k): solve along k, post T_zeta * (-1/vol)
 // scale: factor applied to the incoming dw on load (DIR 1 only: -cfl*dtl*vol of
 // executeDADIStep, smoothers.F90:514-532)
-template <int DIR>
+// POSTI (DIR 2, tiled i sweep in front): the transform T_zeta^-1 T_xi that follows the i-solve is applied to the update as it is
+// loaded here instead of in a pointwise pass of its own (one read and one write of dw less)
+template <int DIR, bool POSTI = false>
 __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ tab, KParams kp, int slot0)
 {
     const BlkView& b = tab[slot0 + blockIdx.z + 1];     // level-batched: one z-slice of the grid per block
@@ -733,6 +735,7 @@ __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ t
             for (int l = 0; l < 5; ++l) d[l] *= sc0;
             dadi_pre_j(b, c, d);
         }
+        if (DIR == 2 && POSTI) dadi_post_i(b, c, d);
         if (solve) {
             if (m < n - 1) dadi_cell<DIR>(b, kp, c + s, s, sN, nxt);
             double ddn[3];
@@ -965,6 +968,7 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_dadi_post_i(const BlkView* __r
     for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
 }
 
+int g_dadi_post_i_fused = 1;  // tuning "dadi_post_i_fused": the transform after the i-solve inside the k sweep
 int g_lines_i_tiled = 1;      // tuning "lines_i_tiled": 0 = one-line-per-lane i sweeps (D-ADI and SA), block after block
 
 // computedwDADI incl. the -cfl*dtl*vol scaling of executeDADIStep
@@ -980,11 +984,12 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
             hipLaunchKernelGGL(k_dadi_rows_i, pg, pb, 0, s, tab, nz, kp);
             hipLaunchKernelGGL(k_dadi_solve_i, dim3(5 * ((ny + 63) / 64), nz, nslots), blk, 0, s, tab, kp);
         }
-        hipLaunchKernelGGL(k_dadi_post_i, pg, pb, 0, s, tab, nz);
+        if (!g_dadi_post_i_fused) hipLaunchKernelGGL(k_dadi_post_i, pg, pb, 0, s, tab, nz);
     } else {
         // lines along i put the lanes on j (stride ldi): with every block in flight at once these uncoalesced
         // sweeps thrash the L2 (measured 10.0 ms batched vs 8 x 0.86 ms one block at a time): block after block
         for (int m = 0; m < nslots; ++m) hipLaunchKernelGGL((k_dadi_sweep<0>), dim3((ny + 63) / 64, nz, 1), blk, 0, s, tab, kp, m);
     }
-    hipLaunchKernelGGL((k_dadi_sweep<2>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+    if (g_lines_i_tiled && g_dadi_post_i_fused) hipLaunchKernelGGL((k_dadi_sweep<2, true>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+    else hipLaunchKernelGGL((k_dadi_sweep<2>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
 }
