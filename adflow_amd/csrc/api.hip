@@ -1001,6 +1001,9 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     // in dw(2:5) instead of the viscous kernel, bound by HBM, reading dw back
     const bool viscFirst = g_visc_first && viscMarch && !mixed && !withSA && !kp.fwMode && !anyMoving && inviscid_march_enabled() &&
                            !kp.dissApprox && !kp.lumpedDiss && roe_march_takes(kp);
+    // the same order for the thin-layer viscous march of the preconditioner assembly (no gradient march in front of it)
+    const bool approxFirst = g_visc_first && viscApprox && g_visc_approx_march && viscous_is_tiled() >= 2 && g_march_by == 4 && kp.viscous &&
+                             fabs(kp.rFil) >= 1.e-10 && !kp.fwMode && !anyMoving && inviscid_march_enabled() && roe_march_takes(kp);
     if (viscMarch && !mixed && !viscFirst && g_overlap && g_overlap_grad && g_phase_base <= 0) {
         HIPCHK(hipEventRecord(g_evFork, g_stream));
         HIPCHK(hipStreamWaitEvent(g_streamC, g_evFork, 0));
@@ -1011,7 +1014,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     const bool scalarVisc = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
     if (mixed) {
         // inviscid part already enqueued
-    } else if (viscFirst) {
+    } else if (viscFirst || approxFirst) {
         // enqueued behind the viscous march below
     } else if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) &&
                (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving) {
@@ -1025,7 +1028,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     } else {
         launch_inviscid_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
-    if (!viscFirst) phase_mark(4);
+    if (!viscFirst && !approxFirst) phase_mark(4);
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
     const bool batched = !viscApprox && viscous_is_tiled();
     // thin-layer viscous flux of the preconditioner assembly: marching form over the tile table (blocks at rest, 4-row tiles)
@@ -1042,7 +1045,15 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     if (rc) return rc;
     if (approxMarch) {
         if (ensure_tiles(level)) return 1;
-        launch_visc_march_approx(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
+        if (approxFirst) {
+            KParams kv = kp;
+            kv.viscFirst = 1;
+            phase_mark(4);
+            launch_visc_march_approx(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+            phase_mark(5);
+            launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+        } else
+            launch_visc_march_approx(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
     }
     if (batched && viscWs) {
         // wave-specialised fused kernel over the level's tile table: gradient waves and face waves in one workgroup

@@ -145,10 +145,17 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_snap(BlkView b, const doubl
 }
 
 // column l of every stencil block of the owned cells from the nColour snapshots of that state variable: entry s of the row cell
-// takes the snapshot of the colour of its source cell row - offset(s)
+// takes the snapshot of the colour of its source cell row - offset(s).  Over its stencil a cell reads every snapshot once, but
+// WHICH snapshot belongs to entry s differs from lane to lane (the colour of the source cell): read directly, one load touches
+// nColour arrays with 1/nColour of the lanes each (0.50 ms per 1.3 M-cell block and variable, 8-byte gathers bound by the
+// texture path).  So the snapshots of a cell pass through a lane-private LDS column: nColour coalesced loads, then nStencil
+// coalesced stores that pick their value from the column.
+// NC: capacity of the column (7 colours: 14 KB of LDS per workgroup; 35: 70 KB)
+template <int NC>
 __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_scatter(BlkView b, const double* __restrict__ snap, double* __restrict__ jac, int l,
                                                              JacSpec J)
 {
+    __shared__ double col[JC_BY][NC][JC_BX];
     const int i = blockIdx.x * JC_BX + threadIdx.x + 2;
     const int j = blockIdx.y * JC_BY + threadIdx.y + 2;
     const int k = blockIdx.z + 2;
@@ -157,17 +164,21 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_scatter(BlkView b, const do
     const long nb = b.nbox;
     const bool linear = (J.cm == J.cn);
     const int c0 = jc_colour(J, i, j, k);
-    for (int s = 0; s < J.nStencil; ++s) {
-        const int pi = i - J.st[s][0], pj = j - J.st[s][1], pk = k - J.st[s][2];      // the perturbed cell
-        if (pi < 0 || pi > b.ib || pj < 0 || pj > b.jb || pk < 0 || pk > b.kb) continue;
-        int d;
-        if (linear) {
-            d = c0 - J.sc[s];
-            if (d < 0) d += J.cn;
-        } else
-            d = jc_colour(J, pi, pj, pk);
-        const double* __restrict__ src = snap + (long)d * J.nState * nb + c;
-        for (int m = 0; m < J.nState; ++m) jac[c + ((long)(s * J.nState + (l - J.lStart)) * J.nState + m) * nb] = src[m * nb];
+    double (*mine)[JC_BX] = col[threadIdx.y];
+    const int lane = threadIdx.x;
+    for (int m = 0; m < J.nState; ++m) {
+        for (int d = 0; d < J.cn; ++d) mine[d][lane] = snap[((long)d * J.nState + m) * nb + c];
+        for (int s = 0; s < J.nStencil; ++s) {
+            const int pi = i - J.st[s][0], pj = j - J.st[s][1], pk = k - J.st[s][2];      // the perturbed cell
+            if (pi < 0 || pi > b.ib || pj < 0 || pj > b.jb || pk < 0 || pk > b.kb) continue;
+            int d;
+            if (linear) {
+                d = c0 - J.sc[s];
+                if (d < 0) d += J.cn;
+            } else
+                d = jc_colour(J, pi, pj, pk);
+            jac[c + ((long)(s * J.nState + (l - J.lStart)) * J.nState + m) * nb] = mine[d][lane];
+        }
     }
 }
 
@@ -205,5 +216,9 @@ void launch_fd_snap(const BlkView& b, const double* dwref, double* snap, const J
 }
 void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fd_scatter, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, snap, jac, l, J);
+    const dim3 g = own_grid(b), t(JC_BX, JC_BY, 1);
+    if (J.cn <= 7) hipLaunchKernelGGL(k_fd_scatter<7>, g, t, 0, s, b, snap, jac, l, J);
+    else if (J.cn <= 13) hipLaunchKernelGGL(k_fd_scatter<13>, g, t, 0, s, b, snap, jac, l, J);
+    else if (J.cn <= 27) hipLaunchKernelGGL(k_fd_scatter<27>, g, t, 0, s, b, snap, jac, l, J);
+    else hipLaunchKernelGGL(k_fd_scatter<35>, g, t, 0, s, b, snap, jac, l, J);
 }

@@ -2213,7 +2213,8 @@ int g_visc_sb = 0;
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL((k_visc_march<false, 0, true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
+    if (kp.viscFirst) hipLaunchKernelGGL((k_visc_march<false, 0, true, true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
+    else hipLaunchKernelGGL((k_visc_march<false, 0, true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
 }
 
 void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
