@@ -29,6 +29,7 @@ hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr;
 hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
+int g_ra_fold_scale = 1;   // tuning "ra_fold_scale": the stage scaling of dw inside the first residual-averaging sweep
 int g_visc_first = 1;      // tuning "visc_first"
 int g_overlap_grad = 1, g_overlap_sa = 1;     // tuning "overlap_grad" / "overlap_sa": the gradient march / the SA residual on their own queues
 adflow_opts g_opts;
@@ -171,7 +172,7 @@ void invalidate_comm_level(int level)
 
 
 int ensure_table(int level);
-int res_averaging_level(int level, const KParams& kp);
+int res_averaging_level(int level, const KParams& kp, double scaleDtl = 0.0);
 int time_step_level(int level, const KParams& kp);
 struct LevelTab { const BlkView* tab; int n, nx, ny, nz; };
 int level_tab(int level, LevelTab* t);
@@ -1562,11 +1563,16 @@ int time_step_level(int level, const KParams& kp)
 }
 
 // implicit residual averaging of every block of the level (one launch per direction)
-int res_averaging_level(int level, const KParams& kp)
+// scaleDtl != 0: dw enters as scaleDtl dtl dw (the stage scaling of the Runge-Kutta smoother): folded into the first sweep when every
+// block of the level has an i sweep, a pointwise pass in front otherwise
+int res_averaging_level(int level, const KParams& kp, double scaleDtl)
 {
     if (ensure_table(level)) return 1;
     const LevelDims& ld = g_tab_dims[level];
-    launch_res_averaging_level(g_tab[level], g_tab_size[level], ld.nx, ld.ny, ld.nz, kp, g_stream);
+    bool fold = (scaleDtl != 0.0) && g_ra_fold_scale;
+    for_level(level, [&](Block* b) { fold = fold && b->v.nx > 1; return 0; });
+    if (scaleDtl != 0.0 && !fold) launch_scale_dw_level(g_tab[level], g_tab_size[level], ld.nx, ld.ny, ld.nz, scaleDtl, 0, g_stream);
+    launch_res_averaging_level(g_tab[level], g_tab_size[level], ld.nx, ld.ny, ld.nz, kp, g_stream, fold ? scaleDtl : 0.0);
     return 0;
 }
 
@@ -2374,8 +2380,7 @@ int adflow_gpu_rk_smooth(int level)
         const double scale = (g_opts.lowSpeedPreconditioner ? 0.8 : 1.0) * kp.cfl * g_opts.etaRK[stage - 1];   // smoothers.F90:202
         if (level_tab(level, &t)) return 1;      // a BC callback of the previous stage may have rebuilt the device table
         if (smooth_residual(stage)) {
-            launch_scale_dw_level(t.tab, t.n, t.nx, t.ny, t.nz, scale, 0, g_stream);
-            if (res_averaging_level(level, kp)) return 1;
+            if (res_averaging_level(level, kp, scale)) return 1;
             if (finish_stage(level, kp, 0.0, 1)) return 1;
         } else {
             if (finish_stage(level, kp, scale, 1)) return 1;
@@ -2827,6 +2832,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
     if (!strcmp(key, "overlap_grad")) { g_overlap_grad = value; return 0; }
     if (!strcmp(key, "visc_first")) { g_visc_first = value; return 0; }
+    if (!strcmp(key, "ra_fold_scale")) { g_ra_fold_scale = value; return 0; }
     if (!strcmp(key, "overlap_sa")) { g_overlap_sa = value; return 0; }
     if (!strcmp(key, "roe_grad_mix")) { g_roe_grad_mix = value; return 0; }
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }

@@ -412,7 +412,8 @@ void launch_source_terms(const BlkView* tab, const int* blk, const long* off, in
 void launch_low_speed_precond_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_stage_update_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, double scale,
                                int fromWn, hipStream_t s);
-void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
+void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s,
+                                double scaleDtl = 0.0);
 void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_halo_copy(const BlkView* tab, const int* donorBlk, const long* donorOff, const int* haloBlk, const long* haloOff,
                       int n, unsigned mask, hipStream_t s);

@@ -381,8 +381,10 @@ __global__ __launch_bounds__(64 * 5) void k_res_averaging(const BlkView* __restr
 // (three tiles = 18.5 KB held it at 8 waves per CU; the kernel is bound by load latency).
 // PASS 0: forward elimination (the eliminated diagonal d is the same for the five equations: only the equation-0 workgroups
 // store it, scratch 1); PASS 1: back substitution in a second launch, whose boundary orders it after every d store.
+// scaleDtl != 0 (PASS 0): the update enters the first solve as scaleDtl dtl dw, the scaling of the Runge-Kutta stage
+// (smoothers.F90:202-230) that would otherwise be a pointwise pass over dw of its own
 template <int PASS>
-__global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restrict__ tab, KParams kp)
+__global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restrict__ tab, KParams kp, double scaleDtl)
 {
     __shared__ double tile[64 * RA_LD];
     const BlkView& b = tab[blockIdx.z + 1];
@@ -434,6 +436,7 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
             if (j0 + r <= b.jl && i <= b.il) {
                 const long c = b.idx(i, j0 + r, k);
                 rv[q] = dw[c]; rr[q] = R[c + 1]; rf[q] = flg_blank(b.flags[c]);
+                if (scaleDtl != 0.0) rv[q] *= scaleDtl * b.dtl[c];
             }
         }
         double tv[RA_CH], tr[RA_CH], tb[RA_CH];
@@ -500,16 +503,18 @@ __global__ __launch_bounds__(64) void k_res_averaging_i(const BlkView* __restric
     }
 }
 
-void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
+// scaleDtl != 0: only for levels whose blocks all have more than one cell in i (the scaling rides on the i sweep)
+void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s,
+                                double scaleDtl)
 {
-    LEVEL_SPLIT(nslots, maxnz + 4, launch_res_averaging_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s));
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_res_averaging_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s, scaleDtl));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_ra_rfl, dim3((maxnx + SM_BX - 1) / SM_BX, (maxny + SM_BY - 1) / SM_BY, maxnz * nslots),
                        dim3(SM_BX, SM_BY, 1), 0, s, tab, kp, maxnz);
     const dim3 blk(64, 1, 1);
     if (maxnx > 1) {
-        hipLaunchKernelGGL((k_res_averaging_i<0>), dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
-        hipLaunchKernelGGL((k_res_averaging_i<1>), dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp);
+        hipLaunchKernelGGL((k_res_averaging_i<0>), dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp, scaleDtl);
+        hipLaunchKernelGGL((k_res_averaging_i<1>), dim3(5 * ((maxny + 63) / 64), maxnz, nslots), blk, 0, s, tab, kp, 0.0);
     }
     const dim3 blk5(64, 5, 1);        // 64 lines x 5 equations
     if (maxny > 1) hipLaunchKernelGGL((k_res_averaging<1>), dim3((maxnx + 63) / 64, maxnz, nslots), blk5, 0, s, tab, kp);
