@@ -30,7 +30,7 @@ hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group o
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
 int g_ra_fold_scale = 1;   // tuning "ra_fold_scale": the stage scaling of dw inside the first residual-averaging sweep
-int g_visc_first = 1;      // tuning "visc_first"
+int g_visc_first = 7;      // tuning "visc_first": bit 0 Roe upwind, bit 1 matrix dissipation, bit 2 scalar JST (NS / RANS)
 int g_overlap_grad = 1, g_overlap_sa = 1;     // tuning "overlap_grad" / "overlap_sa": the gradient march / the SA residual on their own queues
 adflow_opts g_opts;
 bool g_have_opts = false;
@@ -1000,11 +1000,16 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     }
     // viscous march first, Roe march last (tuning "visc_first"): the Roe kernel, bound by FP64 issue, adds the viscous sums it finds
     // in dw(2:5) instead of the viscous kernel, bound by HBM, reading dw back
-    const bool viscFirst = g_visc_first && viscMarch && !mixed && !withSA && !kp.fwMode && !anyMoving && inviscid_march_enabled() &&
-                           !kp.dissApprox && !kp.lumpedDiss && roe_march_takes(kp);
+    // (any inviscid kernel over the tile table can take that role: Roe, matrix dissipation, scalar JST of NS / RANS)
+    const bool scalarViscM = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
+    const bool tileInviscid = inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarViscM) &&
+                              (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving;
+    const int vfMask = (kp.spaceDiscr == ADFLOW_UPWIND) ? 1 : (kp.spaceDiscr == ADFLOW_DISS_MATRIX ? 2 : 4);
+    const bool viscFirst = (g_visc_first & vfMask) && viscMarch && !mixed && !withSA && !kp.fwMode && tileInviscid &&
+                           !kp.dissApprox && !kp.lumpedDiss;
     // the same order for the thin-layer viscous march of the preconditioner assembly (no gradient march in front of it)
-    const bool approxFirst = g_visc_first && viscApprox && g_visc_approx_march && viscous_is_tiled() >= 2 && g_march_by == 4 && kp.viscous &&
-                             fabs(kp.rFil) >= 1.e-10 && !kp.fwMode && !anyMoving && inviscid_march_enabled() && roe_march_takes(kp);
+    const bool approxFirst = (g_visc_first & vfMask) && viscApprox && g_visc_approx_march && viscous_is_tiled() >= 2 && g_march_by == 4 &&
+                             kp.viscous && fabs(kp.rFil) >= 1.e-10 && !kp.fwMode && tileInviscid;
     if (viscMarch && !mixed && !viscFirst && g_overlap && g_overlap_grad && g_phase_base <= 0) {
         HIPCHK(hipEventRecord(g_evFork, g_stream));
         HIPCHK(hipStreamWaitEvent(g_streamC, g_evFork, 0));
@@ -1052,7 +1057,8 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
             phase_mark(4);
             launch_visc_march_approx(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
             phase_mark(5);
-            launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+            if (!launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream))
+                launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
         } else
             launch_visc_march_approx(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
     }
@@ -1076,7 +1082,8 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
             phase_mark(4);
             launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
             phase_mark(5);
-            launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+            if (!launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream))
+                launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
             return 0;
         }
         hipStream_t sg = gradForked ? g_streamC : g_stream;

@@ -104,7 +104,8 @@ __device__ __forceinline__ void im_face(const ImFace& F, const MCell& a, const M
 
 // FW: persistent dissipation residual of the Runge-Kutta scheme; FINAL: dw = (dw + fw) iblank written here, otherwise dw and
 // fw are left for the viscous kernel to complete (residual_block, residuals.F90:334-344)
-template <int SCHEME, bool FW, bool FINAL>
+// ADDV (without FW and FINAL): the viscous march ran first and left its flux sums in dw(2:5); they are added here, before iblank
+template <int SCHEME, bool FW, bool FINAL, bool ADDV = false>
 __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
                                                                   KParams kp, int kch)
 {
@@ -164,6 +165,11 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
         const int flag0 = flags[c >> 3];
         const double dssK0 = sens ? sensor(qm1, q0, qp1) : 0.0;
         const double radK0 = SCAL ? ldg(radK, c) : 0.0;
+        double vsum[4] = {0, 0, 0, 0};       // ADDV: requested ahead of the face evaluation that precedes their use
+        if (ADDV && k > k0 && out) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) vsum[l] = ldg((GPTR(const double))dw + (l + 1) * nb, c - sk);
+        }
         // ---- k-face between cells k-1 and k (normal and porosity stored at cell k-1)
         double fc[5], fd[5];
         im_face<SCHEME>(F, qm2, qm1, q0, qp1, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), dssKm,
@@ -187,6 +193,8 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
                 } else if (FW) {
                     stg(fw + l * nb, cw, fwn);
                     stg(dw + l * nb, cw, d);
+                } else if (ADDV) {
+                    stg(dw + l * nb, cw, ((d + fwn) + (l > 0 ? vsum[l - 1] : 0.0)) * blank);
                 } else {
                     stg(dw + l * nb, cw, (d + fwn) * blank);      // fw not persistent: the viscous kernel adds its part to dw(2:5) and re-applies iblank
                 }
@@ -264,6 +272,8 @@ static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const K
     if (kp.fwMode) {
         if (final_) hipLaunchKernelGGL((k_inviscid_march<SCHEME, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_inviscid_march<SCHEME, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
+    } else if (kp.viscFirst) {
+        hipLaunchKernelGGL((k_inviscid_march<SCHEME, false, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
         if (final_) hipLaunchKernelGGL((k_inviscid_march<SCHEME, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_inviscid_march<SCHEME, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);

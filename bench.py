@@ -347,7 +347,8 @@ def main():
 
     # ---- per-kernel durations of one evaluation, live HIP events on the library's stream
     eng.set_async(False)
-    visc_first = int(tuning.get("visc_first", 1)) != 0 and "upwind" in a.workload
+    vf_bits = int(tuning.get("visc_first", 7))         # bit 0 Roe upwind, bit 1 matrix dissipation, bit 2 scalar JST of NS / RANS
+    visc_first = (vf_bits & 1) != 0 and "upwind" in a.workload
     ph = phase_times(eng, job.step, names=PHASES_VISC_FIRST if visc_first else PHASES)
     log("phases (ms): " + ", ".join(f"{k} {v:.3f}" for k, v in ph.items()))
     kern = {k: v for k, v in ph.items() if k != "closures+bc"}
@@ -364,7 +365,7 @@ def main():
                 job.step()
             s4b, r4b, e4b = timed(eng, job.step, a.steps, barrier, a.min_seconds)
             eng.set_async(False)
-            ph4b = phase_times(eng, job.step)
+            ph4b = phase_times(eng, job.step, names=PHASES_VISC_FIRST if (vf_bits & 2) else PHASES)
             extra["crm_rans_sa_matrix_8x160x128x64"] = {
                 "value": job.cells_local / s4b / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_step": s4b * 1e3,
                 "whole_eval_hbm_frac": 255.0 * job.cells_local / s4b / 1e9 / HBM_PEAK_GBS, "phase_ms": ph4b}

@@ -143,12 +143,14 @@ def test_viscous_kernel_variants(engine):
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
         engine.set_tuning("sa_march", 1)
-        for vf in (0, 1):            # Roe march, then viscous march completing dw / viscous march first, the Roe march adds its sums (default)
+        for vf in (0, 7):            # inviscid march, then viscous march completing dw / viscous march first, the inviscid march adds its sums (default)
             engine.set_tuning("visc_first", vf)
             for prm in (FlowParams(equations=RANSEquations, spaceDiscr=upwind, useQCR=True, muSuthDim=1.0),
-                        FlowParams(equations=NSEquations, spaceDiscr=upwind, limiter=minmod, muSuthDim=1.0)):
+                        FlowParams(equations=NSEquations, spaceDiscr=upwind, limiter=minmod, muSuthDim=1.0),
+                        FlowParams(equations=RANSEquations, spaceDiscr=dissMatrix, vis4=0.1, muSuthDim=1.0),
+                        FlowParams(equations=NSEquations, spaceDiscr=dissScalar, muSuthDim=1.0)):
                 checks.check_block_res(engine, (63, 6, 35), prm, seed=60 + vf, stretch_k=2.0, holes=0.05)
-        engine.set_tuning("visc_first", 1)
+        engine.set_tuning("visc_first", 7)
         for xt, gk in ((0, 32), (1, 5), (1, 64)):     # gradient / SA march tiles in launch order; k chunks of <= 5 planes; one chunk
             engine.set_tuning("xcd_tiles", xt)
             engine.set_tuning("grad_kch", gk)
@@ -175,7 +177,7 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("roe_grad_mix", 0)
         engine.set_tuning("xcd_tiles", 1)
         engine.set_tuning("grad_kch", 32)
-        engine.set_tuning("visc_first", 1)
+        engine.set_tuning("visc_first", 7)
 
 
 def test_visc_wave_specialised(engine):
