@@ -29,6 +29,7 @@ hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr;
 hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
+int g_sa_solve_march = 1;  // tuning "sa_solve_march": the residual / jacobian pass of saSolve as the k-marching kernel
 int g_ra_fold_scale = 1;   // tuning "ra_fold_scale": the stage scaling of dw inside the first residual-averaging sweep
 int g_visc_first = 7;      // tuning "visc_first": bit 0 Roe upwind, bit 1 matrix dissipation, bit 2 scalar JST (NS / RANS)
 int g_overlap_grad = 1, g_overlap_sa = 1;     // tuning "overlap_grad" / "overlap_sa": the gradient march / the SA residual on their own queues
@@ -2748,7 +2749,9 @@ int adflow_gpu_sa_solve(int level)
         if (turb_bc_treatment_enqueue(level, kp)) return 1;
         LevelTab t;
         if (level_tab(level, &t)) return 1;
-        launch_sa_solve_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        bool movingS = false;
+        for_level(level, [&](Block* b) { movingS = movingS || b->v.sFace || b->v.moving; return 0; });
+        launch_sa_solve_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream, g_sa_march == 1 && g_sa_solve_march && !movingS);
         if (turb_bc_apply_enqueue(level, kp, 1)) return 1;
         if (g_turb_bc_callback) {
             HIPCHK(hipStreamSynchronize(g_stream));
@@ -2840,6 +2843,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "overlap_grad")) { g_overlap_grad = value; return 0; }
     if (!strcmp(key, "visc_first")) { g_visc_first = value; return 0; }
     if (!strcmp(key, "ra_fold_scale")) { g_ra_fold_scale = value; return 0; }
+    if (!strcmp(key, "sa_solve_march")) { g_sa_solve_march = value; return 0; }
     if (!strcmp(key, "overlap_sa")) { g_overlap_sa = value; return 0; }
     if (!strcmp(key, "roe_grad_mix")) { g_roe_grad_mix = value; return 0; }
     if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }

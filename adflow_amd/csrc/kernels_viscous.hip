@@ -621,7 +621,9 @@ __device__ __forceinline__ void gs_record(const GsCell& q, double gam, const dou
 // ROWS: cell rows (waves) per workgroup; GRAD needs ROWS = NG_BY (the LDS record exchange); the SA-only march may run 8 rows: the
 // j neighbours are plain loads and the rows j0-2 .. j0+ROWS+1 a workgroup touches are re-read by the workgroups above and below
 // (349 B per cell at 4 rows, profiles/r02_k_pmc_traffic.txt, at 6.5 TB/s: the kernel is bound by exactly that traffic)
-template <bool GRAD, int ROWS, bool LX = false>
+// SOLVE (saSolve): also stores the right-hand side (scratch 0) and the central jacobian qq (scratch 1) of the DDADI line solves,
+// as k_sa_residual<true> (kernels_sa.hip)
+template <bool GRAD, int ROWS, bool LX = false, bool SOLVE = false>
 __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
 {
     __shared__ double xr[GRAD ? 2 * NG_BY * NG_SLOT : 1];
@@ -756,7 +758,8 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
                     gu[v][d] = qq[v][0] * nI[d] - qq[v][1] * nIm[d] + qq[v][2] * nJ[d] - qq[v][3] * nJm[d] + qq[v][4] * nK[d] - qq[v][5] * sKm[d];
-            double dvt = sa_source(kp, gu, s0.vol, q0.nu, n_0, ldg(m.d2wall, c));
+            double qjac = 0.0;
+            double dvt = sa_source(kp, gu, s0.vol, q0.nu, n_0, ldg(m.d2wall, c), SOLVE ? &qjac : nullptr);
             SaDir dk, dj, di;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -768,12 +771,38 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
             dj.nt[0] = n_jm2; dj.nt[1] = qjm.nut; dj.nt[2] = n_0; dj.nt[3] = qjp.nut; dj.nt[4] = n_jp2;
             di.volm = qim.vol; di.volp = qip.vol; di.num = qim.nu; di.nup = qip.nu; di.qsf = 0.0;
             di.nt[0] = n_im2; di.nt[1] = qim.nut; di.nt[2] = n_0; di.nt[3] = qip.nut; di.nt[4] = n_ip2;
-            dvt += sa_advect(dk, s0.vol, s0.u, s0.v, s0.w, secondOrd);
-            dvt += sa_advect(dj, s0.vol, s0.u, s0.v, s0.w, secondOrd);
-            dvt += sa_advect(di, s0.vol, s0.u, s0.v, s0.w, secondOrd);
-            dvt += sa_diffuse(dk, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
-            dvt += sa_diffuse(dj, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
-            dvt += sa_diffuse(di, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
+            if (SOLVE) {
+                // central jacobian of advection and diffusion with the implicit boundary part (turbUtils.F90:972-1004,1060-1092,
+                // sa.F90:452-468): max(bmt, 0) of the face behind a boundary cell
+                double bmK1 = 0.0, bmK2 = 0.0, bmJ1 = 0.0, bmJ2 = 0.0, bmI1 = 0.0, bmI2 = 0.0;
+                if (b.bmt[0] && outC) {
+                    if (i == 2) bmI1 = fmax(b.bmt[0][(j - 1) + (long)b.je * (mm - 1)], 0.0);
+                    if (i == b.il) bmI2 = fmax(b.bmt[1][(j - 1) + (long)b.je * (mm - 1)], 0.0);
+                    if (j == 2) bmJ1 = fmax(b.bmt[2][(i - 1) + (long)b.ie * (mm - 1)], 0.0);
+                    if (j == b.jl) bmJ2 = fmax(b.bmt[3][(i - 1) + (long)b.ie * (mm - 1)], 0.0);
+                    if (mm == 2) bmK1 = fmax(b.bmt[4][(i - 1) + (long)b.ie * (j - 1)], 0.0);
+                    if (mm == b.kl) bmK2 = fmax(b.bmt[5][(i - 1) + (long)b.ie * (j - 1)], 0.0);
+                }
+                double uu, c1m, c1p;
+                dvt += sa_advect(dk, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uu); qjac += fabs(uu) + ((uu > 0.0) ? uu * bmK1 : -uu * bmK2);
+                dvt += sa_advect(dj, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uu); qjac += fabs(uu) + ((uu > 0.0) ? uu * bmJ1 : -uu * bmJ2);
+                dvt += sa_advect(di, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uu); qjac += fabs(uu) + ((uu > 0.0) ? uu * bmI1 : -uu * bmI2);
+                dvt += sa_diffuse(dk, s0.vol, q0.nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qjac += c1m + c1p + ((mm == 2) ? c1m * bmK1 : c1p * bmK2);
+                dvt += sa_diffuse(dj, s0.vol, q0.nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qjac += c1m + c1p + ((j == 2) ? c1m * bmJ1 : c1p * bmJ2);
+                dvt += sa_diffuse(di, s0.vol, q0.nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qjac += c1m + c1p + ((i == 2) ? c1m * bmI1 : c1p * bmI2);
+                if (outC) {
+                    GPTR(double) scr = (GPTR(double))b.scratch;
+                    stg(scr, c, dvt);
+                    stg(scr + nb, c, kp.sa_qqFactor * qjac);      // implicit relaxation factor of saSolve (sa.F90:830-836)
+                }
+            } else {
+                dvt += sa_advect(dk, s0.vol, s0.u, s0.v, s0.w, secondOrd);
+                dvt += sa_advect(dj, s0.vol, s0.u, s0.v, s0.w, secondOrd);
+                dvt += sa_advect(di, s0.vol, s0.u, s0.v, s0.w, secondOrd);
+                dvt += sa_diffuse(dk, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
+                dvt += sa_diffuse(dj, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
+                dvt += sa_diffuse(di, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
+            }
             if (outC) stg(dw5, c, -ldg(m.volRef, c) * dvt * flg_blank(flags[c >> 3]));
         }
         if (GRAD) {
@@ -2316,6 +2345,17 @@ void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int n
         const TileGrid tg = tile_grid(gx, (ny + 1 + 7) / 8, nchn, nslots, kch);
         hipLaunchKernelGGL((k_grad_sa_march<false, 8>), dim3(tile_grid_size(tg)), dim3(64, 8, 1), 0, s, tab, nchn, kp, tg);
     }
+}
+
+// the SA residual with the right-hand side and the central jacobian of saSolve (blocks at rest)
+void launch_sa_march_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    LEVEL_SPLIT(nslots, nz + 4, launch_sa_march_solve_level(tab + s0_, n_, nx, ny, nz, kp, s));
+    if (nslots <= 0) return;
+    int nchn, kch;
+    node_chunks(nz + 1, &nchn, &kch);
+    const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
+    hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY, false, true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
 }
 
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)

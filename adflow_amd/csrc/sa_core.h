@@ -96,7 +96,9 @@ __device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double
 // source term of the SA equation for one cell (sa.F90:133-300), WITHOUT the jacobian part of saSolve: gu[m][d] = twice the
 // volume times the gradient of velocity component m (the Green-Gauss sum over the six faces), returns dvt (before advection /
 // diffusion)
-__device__ __forceinline__ double sa_source(const KParams& kp, const double gu[3][3], double vol0, double nu, double nut, double d2)
+// qqOut (saSolve): -d(source)/d(nuTilde) clipped at zero, sa.F90:306-332
+__device__ __forceinline__ double sa_source(const KParams& kp, const double gu[3][3], double vol0, double nu, double nut, double d2,
+                                            double* qqOut = nullptr)
 {
     const double fact = 0.25 * rcp_nr(vol0);
     double ss, strainMag2 = 0.0;
@@ -136,6 +138,19 @@ __device__ __forceinline__ double sa_source(const KParams& kp, const double gu[3
     const double fwSa = gg * termFw;
     const double term1 = kp.sa_cb1 * (1.0 - ft2) * ss;
     const double term2 = dist2Inv * (kar2Inv * kp.sa_cb1 * ((1.0 - ft2) * fv2 + ft2) - kp.sa_cw1 * fwSa);
+    if (qqOut) {
+        const double t1 = chi3 + cv13;
+        const double dfv1 = 3.0 * chi2 * cv13 * rcp_nr(t1 * t1);
+        const double t2 = 1.0 + chi * fv1;
+        const double nuInv = rcp_nr(nu);
+        const double dfv2 = (chi2 * dfv1 - 1.0) * nuInv * rcp_nr(t2 * t2);
+        const double dft2 = -2.0 * kp.sa_ct4 * chi * ft2 * nuInv;
+        const double drr = (1.0 - rr * (fv2 + nut * dfv2)) * kar2Inv * dist2Inv * rcp_nr(sst);
+        const double dgg = (1.0 - kp.sa_cw2 + 6.0 * kp.sa_cw2 * (rr2 * rr2 * rr)) * drr;
+        const double dfw = (cw36 * rcp_nr(gg6 + cw36)) * termFw * dgg;
+        const double qq = -2.0 * term2 * nut - dist2Inv * nut * nut * (kp.sa_cb1 * kar2Inv * (dfv2 - ft2 * dfv2 - fv2 * dft2 + dft2) - kp.sa_cw1 * dfw);
+        *qqOut = fmax(qq, 0.0);
+    }
     return (term1 + term2 * nut) * nut;
 }
 
