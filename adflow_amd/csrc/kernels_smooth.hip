@@ -214,8 +214,7 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_stage_update(const BlkView* __
 #pragma unroll
         for (int l = 0; l < 5; ++l) d[l] *= dt;
     }
-    const double gam = b.gamma[c];
-    const double gm1 = gam - 1.0;
+    const double gm1 = kp.gammaConstant - 1.0;      // cpConstant, the only cp model of the path: gamma(i,j,k) = gammaConstant
     const double rho0 = b.w[c], u0 = b.w[c + nb], v0 = b.w[c + 2 * nb], w0 = b.w[c + 3 * nb], e0 = b.w[c + 4 * nb];
     const double p0 = b.p[c];
     double ovr = 1.0 / rho0;
