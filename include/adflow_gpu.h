@@ -383,7 +383,7 @@ int adflow_gpu_event_record(int slot);                   /* slot in [0,64) */
 int adflow_gpu_event_elapsed_ms(int slot_start, int slot_stop, double* ms);
 int adflow_gpu_sync(void);
 /* performance knobs for A/B measurements; results never depend on them.
- * "euler_march" (default 1): k-marching fused kernel for Euler + scalar JST */
+ * "euler_march" (default 1): k-marching fused kernel for Euler + scalar JST; the full list with defaults: DESIGN.md section 8b */
 int adflow_gpu_set_tuning(const char* key, int value);
 /* on != 0: hot-path entry points only ENQUEUE on the library stream (no host
  * sync at return); the caller orders with adflow_gpu_sync().  Default off. */
