@@ -1514,6 +1514,33 @@ int adflow_gpu_download_jacobian(int nn, int level, int sps, double* blocks)
     return sync_and_check();
 }
 
+int adflow_gpu_download_jacobian_rows(int nn, int level, int sps, double* rows)
+{
+    Block* b = find_block(nn, level, sps);
+    if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
+    if (!g_jac_valid || !b->jac) return fail("download_jacobian_rows: no assembled Jacobian on block (%d,%d,%d)", nn, level, sps);
+    if (!rows) return fail("download_jacobian_rows: rows is NULL");
+    const BlkView& v = b->v;
+    const int nS = g_jac.nState, nSt = g_jac.nStencil;
+    if (nS * nS >= 37) return fail("download_jacobian_rows: nState = %d exceeds the tile of the transposition kernel", nS);
+    const size_t perPlane = (size_t)v.nx * v.ny * nSt * nS * nS;          // doubles of one k plane of rows
+    int nk = (int)std::max<size_t>(1, ((size_t)128 << 20) / (perPlane * 8));   // slabs of <= 128 MB on the device
+    if (nk > v.nz) nk = v.nz;
+    double* d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_out, perPlane * nk * 8));
+    for (int k0 = 0; k0 < v.nz; k0 += nk) {
+        const int n = std::min(nk, v.nz - k0);
+        launch_jac_rows(v, b->jac, d_out, nS, nSt, k0 + 2, n, g_stream);
+        if (hipMemcpyAsync(rows + perPlane * k0, d_out, perPlane * n * 8, hipMemcpyDeviceToHost, g_stream) != hipSuccess ||
+            hipStreamSynchronize(g_stream) != hipSuccess) {
+            (void)hipFree(d_out);
+            return fail("download_jacobian_rows: copy of the planes %d.. failed", k0 + 2);
+        }
+    }
+    HIPCHK(hipFree(d_out));
+    return sync_and_check();
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------ halo exchange

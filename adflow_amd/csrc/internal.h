@@ -351,6 +351,7 @@ void launch_fd_state_closures(const BlkView& b, const double* wref, int l, int c
                               hipStream_t s);
 void launch_fd_snap(const BlkView& b, const double* dwref, double* snap, const JacSpec& J, double deltaInv, double turbResScale, hipStream_t s);
 void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, hipStream_t s);
+void launch_jac_rows(const BlkView& b, const double* jac, double* out, int nState, int nStencil, int k0, int nk, hipStream_t s);
 void launch_fd_copy(const BlkView& b, double* dst, const double* src, int ncomp, hipStream_t s);
 void launch_closures_halo(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int col, const JacSpec& J, double deltaInv, double turbResScale,

@@ -182,6 +182,40 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_scatter(BlkView b, const do
     }
 }
 
+// blocks of the owned cells of the planes k0 .. k0+nk-1 in the order of one MatSetValuesBlocked call per row cell:
+// out(ll, l, s, i, j, k-k0), ll fastest.  A workgroup moves the nState x nState block of ONE stencil entry for 64 cells of a
+// row: coalesced reads along i from the entry-major device storage, an LDS tile, runs of nState^2 doubles out.
+#define JR_LD 37
+__global__ __launch_bounds__(64) void k_jac_rows(BlkView b, const double* __restrict__ jac, double* __restrict__ out, int nState, int nStencil,
+                                                 int k0)
+{
+    __shared__ double tile[64 * JR_LD];
+    const int lane = threadIdx.x;
+    const int i0 = blockIdx.x * 64 + 2;
+    const int j = blockIdx.y + 2;
+    const int s = blockIdx.z % nStencil, kk = blockIdx.z / nStencil;
+    const int k = k0 + kk;
+    const int nS2 = nState * nState;
+    const long nb = b.nbox;
+    const int i = i0 + lane;
+    if (i <= b.il) {
+        const long c = b.idx(i, j, k);
+        for (int e = 0; e < nS2; ++e) tile[lane * JR_LD + e] = jac[c + ((long)s * nS2 + e) * nb];
+    }
+    __syncthreads();
+    const int ncell = (b.il - i0 + 1 < 64) ? b.il - i0 + 1 : 64;
+    const long row0 = (long)(i0 - 2) + (long)b.nx * ((j - 2) + (long)b.ny * kk);     // first cell of the tile in the slab's row order
+    for (int t = lane; t < ncell * nS2; t += 64) {
+        const int cell = t / nS2, e = t - cell * nS2;
+        out[((row0 + cell) * nStencil + s) * nS2 + e] = tile[cell * JR_LD + e];
+    }
+}
+
+void launch_jac_rows(const BlkView& b, const double* jac, double* out, int nState, int nStencil, int k0, int nk, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_jac_rows, dim3((b.nx + 63) / 64, b.ny, nk * nStencil), dim3(64, 1, 1), 0, s, b, jac, out, nState, nStencil, k0);
+}
+
 static dim3 box_grid(const BlkView& b) { return dim3((b.ib + 15 + JC_BX) / JC_BX, (b.jb + JC_BY) / JC_BY, b.kb + 1); }
 static dim3 own_grid(const BlkView& b) { return dim3((b.nx + JC_BX - 1) / JC_BX, (b.ny + JC_BY - 1) / JC_BY, b.nz); }
 

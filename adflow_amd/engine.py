@@ -137,6 +137,15 @@ class Engine:
         self._chk(self.lib.adflow_gpu_download_jacobian(nn, level, sps, out.ctypes.data))
         return out
 
+    def jacobianRows(self, nn=1, level=1, sps=1):
+        """(nState, nState, nStencil, nx, ny, nz): the same blocks, contiguous per row cell (one MatSetValuesBlocked per cell and
+        stencil entry reads nState^2 consecutive doubles)"""
+        ns, st = self.jacobianInfo()
+        blk = self.blocks[(nn, level, sps)]
+        out = np.zeros((ns, ns, st.shape[0], blk.nx, blk.ny, blk.nz), order="F")
+        self._chk(self.lib.adflow_gpu_download_jacobian_rows(nn, level, sps, out.ctypes.data))
+        return out
+
     def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True, dissApprox=False, viscApprox=False,
                      useBlockettes=False):
         flags = (capi.RES_UPDATE_INTERMED if updateIntermed else 0) | (capi.RES_FLOW if flowRes else 0) \

@@ -285,6 +285,11 @@ module adflowGpuShim
             integer(c_int), value :: nn, level, sps
             type(c_ptr), value :: blocks
         end function
+        integer(c_int) function adflow_gpu_download_jacobian_rows(nn, level, sps, rows) bind(C, name="adflow_gpu_download_jacobian_rows")
+            import :: c_int, c_ptr
+            integer(c_int), value :: nn, level, sps
+            type(c_ptr), value :: rows
+        end function
         integer(c_int) function adflow_gpu_reference_shock_sensor(level) bind(C, name="adflow_gpu_reference_shock_sensor")
             import :: c_int
             integer(c_int), value :: level

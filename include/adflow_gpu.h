@@ -415,6 +415,11 @@ int adflow_gpu_jacobian_info(int32_t* nState, int32_t* nStencil, int32_t* stenci
 /* blocks of block nn over its OWNED cells: (nx, ny, nz, nState, nState, nStencil) column-major.  The host maps rows / columns to
  * globalCell and calls MatSetValuesBlocked; entries whose source cell lies outside 0..ib are zero */
 int adflow_gpu_download_jacobian(int nn, int level, int sps, double* blocks);
+/* the same blocks in the order of the reference's insertion loop (adjointUtils.F90:560-700, one MatSetValuesBlocked per row cell
+ * and stencil entry with MAT_ROW_ORIENTED off): rows(nState, nState, nStencil, nx, ny, nz) column-major, i.e. the nStencil
+ * blocks blk(ll, l) of a row cell are contiguous and the cells follow in the order of the PETSc rows of the block (i fastest).
+ * Transposed on the device, copied in slabs of k planes */
+int adflow_gpu_download_jacobian_rows(int nn, int level, int sps, double* rows);
 
 #ifdef __cplusplus
 }

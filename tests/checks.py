@@ -146,6 +146,10 @@ def check_fd_jacobian(engine, dims, prm, spec, usePC=True, frozenTurb=False, use
     assert scale > 0.0
     err = np.abs(Jg - Jr).max() / scale
     assert err <= tol, (err, tol, np.unravel_index(np.abs(Jg - Jr).argmax(), Jr.shape))
+    # the row-ordered download (one contiguous run of blocks per row cell) is the same numbers, permuted
+    Jrows = engine.jacobianRows(1, 1)
+    assert Jrows.shape == (ns, ns, st.shape[0], blk.nx, blk.ny, blk.nz)
+    assert np.array_equal(Jrows, np.transpose(Jg, (3, 4, 5, 0, 1, 2)))
     # no stencil entry silently skipped (the corner entries of the 27-point preconditioner stencil are empty in the reference
     # too: the thin-layer residual does not couple them), the diagonal block of every cell is non-zero
     for s in range(st.shape[0]):
