@@ -59,6 +59,15 @@ def test_dadi_smoother_rans_tutorial_wing_config(engine):
     checks.check_dadi_smoother(engine, BrickTopology(2, 2, 1, 12, 10, 8), prm, stretch_k=2.5)
 
 
+def test_dadi_and_sa_solve_north_star_size_block(engine):
+    """the line-solve kernels at the block size of the north-star mesh (160 x 128 x 64: 160 is no multiple of the 64-line
+    workgroups nor of the 8-cell chunks of the tiled i sweeps), D-ADI with two sub-iterations and the SA DDADI solve, against
+    the reference's DADISmoother / sa_block"""
+    prm = FlowParams(equations=RANSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=1)
+    checks.check_dadi_smoother(engine, BrickTopology(1, 1, 1, 160, 128, 64), prm, stretch_k=3.0)
+    checks.check_sa_solve(engine, BrickTopology(1, 1, 1, 160, 128, 64), prm, stretch_k=3.0)
+
+
 def test_dadi_degenerate_lines(engine):
     prm = FlowParams(equations=NSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2)
     checks.check_dadi_smoother(engine, BrickTopology(1, 1, 2, 5, 1, 4), prm, stretch_k=2.0)
