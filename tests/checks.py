@@ -146,6 +146,11 @@ def check_fd_jacobian(engine, dims, prm, spec, usePC=True, frozenTurb=False, use
     assert scale > 0.0
     err = np.abs(Jg - Jr).max() / scale
     assert err <= tol, (err, tol, np.unravel_index(np.abs(Jg - Jr).argmax(), Jr.shape))
+    if ns == 6:
+        # RANS: next to a wall the SA diagonal dwarfs everything else; the mean-flow blocks against their own scale
+        scf = np.abs(Jr[..., :5, :5, :]).max()
+        errf = np.abs(Jg[..., :5, :5, :] - Jr[..., :5, :5, :]).max() / scf
+        assert errf <= tol, ("mean-flow blocks", errf, tol)
     # the row-ordered download (one contiguous run of blocks per row cell) is the same numbers, permuted
     Jrows = engine.jacobianRows(1, 1)
     assert Jrows.shape == (ns, ns, st.shape[0], blk.nx, blk.ny, blk.nz)
@@ -154,7 +159,10 @@ def check_fd_jacobian(engine, dims, prm, spec, usePC=True, frozenTurb=False, use
     # too: the thin-layer residual does not couple them), the diagonal block of every cell is non-zero
     for s in range(st.shape[0]):
         assert (np.abs(Jg[..., s]).max() > 1e-7 * scale) == (np.abs(Jr[..., s]).max() > 1e-7 * scale), ("stencil entry", s, st[s])
-    assert sum(np.abs(Jg[..., s]).max() > 1e-7 * scale for s in range(st.shape[0])) >= 7
+    # (how many entries clear the threshold depends on the dynamic range: next to a wall the SA diagonal is ~1e12 and the
+    # off-diagonal blocks fall below 1e-7 of it -- the count has to equal the reference's, not a fixed number)
+    n_ref = sum(np.abs(Jr[..., s]).max() > 1e-7 * scale for s in range(st.shape[0]))
+    assert sum(np.abs(Jg[..., s]).max() > 1e-7 * scale for s in range(st.shape[0])) == n_ref >= 1
     diag = np.abs(Jg[..., 0 if usePC or prm.equations == EulerEquations else 13]).reshape(blk.nx * blk.ny * blk.nz, -1).max(axis=1)
     assert diag.min() > 0.0
     # resetFDReference: w is the reference state (boundary halos as the reference evaluation left them), dw the scaled residual

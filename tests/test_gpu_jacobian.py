@@ -51,3 +51,10 @@ def test_reference_step(engine):
     largest entry is resolvable by ANY implementation (the reference against itself with another compiler flag included)"""
     rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda)
     checks.check_fd_jacobian(engine, (12, 8, 6), rans, WALL, delta=1e-9, tol=1e-5, stretch_k=2.0)
+
+
+def test_pc_rans_larger_block(engine):
+    """the preconditioner matrix on a 70 x 24 x 40 block: two i tiles, six j tiles and two k chunks of the marching kernels of the
+    approximate residual, the scatter through the LDS column with partial rows"""
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda)
+    checks.check_fd_jacobian(engine, (70, 24, 40), rans, WALL, stretch_k=2.0)

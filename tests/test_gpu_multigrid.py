@@ -59,3 +59,10 @@ def test_mg_cycle_three_levels_w(engine):
     """3-level W cycle: the coarsest level is visited twice"""
     checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 16, 8, 8), FlowParams(),
                           [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0], nlevels=3)
+
+
+def test_mg_3w_cycle_larger_blocks(engine):
+    """3-level W cycle on two 64 x 48 x 32 blocks: several tiles and k chunks on the fine level, 16 x 12 x 8 blocks on the coarsest"""
+    from adflow_amd.topology import BrickTopology
+    checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 64, 48, 32), FlowParams(), [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1],
+                          ncycles=1, nlevels=3)

@@ -68,6 +68,12 @@ def test_dadi_and_sa_solve_north_star_size_block(engine):
     checks.check_sa_solve(engine, BrickTopology(1, 1, 1, 160, 128, 64), prm, stretch_k=3.0)
 
 
+def test_rk_smoother_with_residual_averaging_config_1_size_block(engine):
+    """RK5 + alternate residual averaging on a 128^3 Euler block (the block size of BASELINE config 1 in bench.py): four k chunks
+    and three i tiles of the march, 128-cell lines of the averaging sweeps"""
+    checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 128, 128, 128), FlowParams(resAveraging=alternateResAveraging))
+
+
 def test_dadi_degenerate_lines(engine):
     prm = FlowParams(equations=NSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2)
     checks.check_dadi_smoother(engine, BrickTopology(1, 1, 2, 5, 1, 4), prm, stretch_k=2.0)
