@@ -33,7 +33,7 @@ EDGE_NY = [1, 2, 3, 4, 5, 7, 8, 9, 12, 13]
 EDGE_NZ = [1, 2, 3, 5, 20, 21, 22, 23, 31, 32, 33, 34, 43, 44, 45]
 
 
-def draw_case(rng):
+def draw_case(rng, huge=False):
     eq = int(rng.choice([EulerEquations, NSEquations, RANSEquations], p=[0.25, 0.25, 0.5]))
     sd = int(rng.choice([dissScalar, dissMatrix, upwind], p=[0.3, 0.2, 0.5]))
     big = rng.random() < 0.35
@@ -56,6 +56,8 @@ def draw_case(rng):
         kw["useft2SA"] = bool(rng.random() < 0.7)
     if eq != EulerEquations and rng.random() < 0.4:
         kw["muSuthDim"] = 1.0          # viscous-dominated
+    if huge:     # GPU runs: several i tiles, many j tiles, three or more k chunks
+        nx, ny, nz = int(rng.integers(100, 201)), int(rng.integers(5, 41)), int(rng.integers(40, 101))
     mk = dict(seed=int(rng.integers(1, 10 ** 6)))
     if rng.random() < 0.5:
         mk["stretch_k"] = float(rng.choice([1.5, 2.0, 3.0]))
@@ -65,6 +67,8 @@ def draw_case(rng):
         mk["left_handed"] = True
     entry = str(rng.choice(["block_res", "blockette", "blockette_intermed", "approx", "bc", "rk", "dadi", "sa_solve", "nk"],
                            p=[0.3, 0.1, 0.1, 0.1, 0.15, 0.07, 0.06, 0.06, 0.06]))
+    if huge:
+        entry = str(rng.choice(["block_res", "blockette", "blockette_intermed"]))
     if entry == "bc":
         kinds = EULER_BC if eq == EulerEquations else VISC_BC
         mk["spec"] = {f: int(rng.choice(kinds)) for f in range(1, 7)}
@@ -109,11 +113,11 @@ def run_case(engine, dims, kw, mk, entry):
         checks.check_block_res_vs_blockette(engine, dims, prm, update_intermed=(entry == "blockette_intermed"), seed=seed, **mk)
 
 
-def sweep(engine, cases, seed, only=-1, quiet=False):
+def sweep(engine, cases, seed, only=-1, quiet=False, big=False):
     """Run `cases` random cases; returns (number run, description of the first failure or None)."""
     rng = np.random.default_rng(seed)
     for n in range(cases):
-        dims, kw, mk, entry = draw_case(rng)
+        dims, kw, mk, entry = draw_case(rng, big)
         if only >= 0 and n != only:
             continue
         try:
@@ -131,6 +135,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--gpu", action="store_true", help="the HIP library on cuda:0 instead of the emulator")
     ap.add_argument("--only", type=int, default=-1, help="run this case index only")
+    ap.add_argument("--big", action="store_true", help="blocks of 100-200 x 5-40 x 40-100 cells (residual entry points only; for --gpu)")
     a = ap.parse_args()
     from adflow_amd.engine import Engine
     if a.gpu:
@@ -139,10 +144,11 @@ def main():
         from hostsim.build import build
         eng = Engine(0, _lib_path=build())
     t0 = time.time()
-    n, failure = sweep(eng, a.cases, a.seed, a.only)
+    n, failure = sweep(eng, a.cases, a.seed, a.only, big=a.big)
     if failure:
         print("FAIL", failure)
-        print(f"reproduce: python tests/fuzz_parity.py --seed {a.seed} --cases {a.cases} --only {n - 1}" + (" --gpu" if a.gpu else ""))
+        print(f"reproduce: python tests/fuzz_parity.py --seed {a.seed} --cases {a.cases} --only {n - 1}" + (" --gpu" if a.gpu else "")
+              + (" --big" if a.big else ""))
     print(f"{n} cases, {1 if failure else 0} failures, {time.time() - t0:.0f} s")
     nfail = 1 if failure else 0
     eng.close()
