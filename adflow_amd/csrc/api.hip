@@ -69,6 +69,7 @@ struct Block {
     bool geom_uploaded = false;
     bool normals_from_x_ok = true;     // the uploaded sI / sJ / sK equal metric_block(x): the kernels may re-form them from the nodes
     bool face_vectors_valid = false;   // dI/dJ/dK derived from x
+    bool node_sums_valid = false;      // nsum (LDS-tiled gradient kernel only) derived from the normals and volumes
     bool ss_valid = false;    // entropy sensor variable matches the current state
     bool etot_consistent = false;   // owned-cell rhoE already equals computeEtotBlock(p, rho, v)
     std::vector<BcFaceDev> bc;      // boundary subfaces (device BCData), first nViscBocos = viscous walls
@@ -1044,6 +1045,11 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         if (!b->face_vectors_valid) {
             launch_face_vectors(b->v, g_stream);
             b->face_vectors_valid = true;
+            b->node_sums_valid = false;       // every invalidation of the face vectors is a change of the geometry
+        }
+        if (batched && viscous_is_tiled() == 1 && !b->node_sums_valid) {
+            launch_node_sums(b->v, g_stream);
+            b->node_sums_valid = true;
         }
         if (viscApprox && !approxMarch) launch_viscous_approx(b->v, kp, g_stream);   // viscousFluxApprox instead of gradients + viscousFlux
         else if (!viscApprox && !batched) launch_viscous(b->v, kp, g_stream);

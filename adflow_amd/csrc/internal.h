@@ -403,6 +403,7 @@ void launch_xhalo_symm(const BlkView* tab, const BcEntry* ent, const int* order,
 void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, const KParams& kp, hipStream_t s);
 void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_face_vectors(const BlkView& b, hipStream_t s);
+void launch_node_sums(const BlkView& b, hipStream_t s);
 void launch_sa_residual_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, bool marchRes = false);
 void launch_sa_march_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

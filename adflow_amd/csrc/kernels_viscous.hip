@@ -1082,12 +1082,19 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_face_vectors(BlkView b)
     }
 }
 
-// derived static geometry of the viscous path: face vectors + the normal sums / inverse volume sums of the nodes
+// derived static geometry of the viscous path: the face vectors dI / dJ / dK
 void launch_face_vectors(const BlkView& b, hipStream_t s)
 {
     dim3 blk(VS_BX, VS_BY, 1);
     dim3 g((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
     hipLaunchKernelGGL(k_face_vectors, g, blk, 0, s, b);
+}
+// ... and the normal sums / inverse volume sums of the nodes, read by the LDS-tiled gradient kernel only (viscous_tiled = 1):
+// formed when that kernel is about to run, not with every geometry update (1.2 ms for the 8 north-star blocks)
+void launch_node_sums(const BlkView& b, hipStream_t s)
+{
+    dim3 blk(VS_BX, VS_BY, 1);
+    dim3 g((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
     hipLaunchKernelGGL(k_node_sums, g, blk, 0, s, b);
 }
 
