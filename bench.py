@@ -53,6 +53,9 @@ WORKLOADS = {
     # same cell count as the Euler workload, cut into 512 blocks of 32^3 (a production multiblock mesh per GPU)
     "euler_jst_512x32": dict(equations=1, spaceDiscr=1, nblocks=512, dims=(32, 32, 32), bytes_per_cell=175.0,
                              desc="Euler, central + scalar JST, 32^3 blocks"),
+    # about the cell count of the north-star workload (11.2 M) in 343 blocks of 32^3
+    "rans_sa_upwind_343x32": dict(equations=3, spaceDiscr=9, nblocks=343, dims=(32, 32, 32), bytes_per_cell=255.0,
+                                  desc="RANS-SA, Roe upwind (van Albada), 32^3 blocks"),
 }
 DEFAULT_WORKLOAD = "crm_rans_sa_upwind_8x160x128x64"
 PHASES = ["closures+bc", "time step", "SA residual", "inviscid", "nodal gradients", "viscous"]   # between marks 0..6 of api.hip
