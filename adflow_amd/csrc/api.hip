@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_visc_sb, g_viscous_fused, g_viscous_fused_rows, g_grad_sa_fused, g_sa_march, g_roe_lds_pad, g_roe_grad_mix, g_xcd_tiles, g_grad_kch, g_dadi_post_i_fused;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_visc_gf, g_xcd_tiles, g_grad_kch, g_dadi_post_i_fused;
 
 namespace {
 
@@ -69,7 +69,6 @@ struct Block {
     bool geom_uploaded = false;
     bool normals_from_x_ok = true;     // the uploaded sI / sJ / sK equal metric_block(x): the kernels may re-form them from the nodes
     bool face_vectors_valid = false;   // dI/dJ/dK derived from x
-    bool node_sums_valid = false;      // nsum (LDS-tiled gradient kernel only) derived from the normals and volumes
     bool ss_valid = false;    // entropy sensor variable matches the current state
     bool etot_consistent = false;   // owned-cell rhoE already equals computeEtotBlock(p, rho, v)
     std::vector<BcFaceDev> bc;      // boundary subfaces (device BCData), first nViscBocos = viscous walls
@@ -481,7 +480,6 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     rc |= alloc_arr(b, &v.dI, 3);
     rc |= alloc_arr(b, &v.dJ, 3);
     rc |= alloc_arr(b, &v.dK, 3);
-    rc |= alloc_arr(b, &v.nsum, 19);
     rc |= alloc_arr(b, &v.dw, v.nw);
     rc |= alloc_arr(b, &v.fw, 5);
     rc |= alloc_arr(b, &v.dtl, 1);
@@ -916,7 +914,7 @@ int adflow_gpu_initres(int level, int varStart, int varEnd)
     return sync_and_check();
 }
 
-static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad, bool withSA = false);
+static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad);
 static int source_terms_enqueue(int withBlank);
 
 // residual (residuals.F90:1028) = residual_block of every block; blockResCore (blockette.F90:755) is the same sum of
@@ -929,11 +927,11 @@ static bool has_wall_subfaces(int level);
 
 // needGradHbm: the caller wants the nodal gradients in the block arrays (updateIntermed copy-out, blockette.F90:706-750)
 static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false, bool lowSpeed = true, bool stage0 = true,
-                                 bool needGradHbm = false, bool withSA = false)
+                                 bool needGradHbm = false)
 {
     const bool wallStress = stage0 && !viscApprox && kp.viscous && level == g_opts.groundLevel && fabs(kp.rFil) >= 1.e-10 &&
                             has_wall_subfaces(level);
-    if (enqueue_flow_fluxes(level, kp, viscApprox, needGradHbm || wallStress, withSA)) return 1;
+    if (enqueue_flow_fluxes(level, kp, viscApprox, needGradHbm || wallStress)) return 1;
     if (wallStress)
         if (wall_stress_enqueue(level, kp)) return 1;
     // sourceTerms() of the call sites of `residual` (smoothers.F90:74,409, multiGrid.F90:52,887,949): fine level only
@@ -946,7 +944,7 @@ static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox =
     return 0;
 }
 
-static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad, bool withSA)
+static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bool needGrad)
 {
     bool anyMoving = false;     // grid velocities / rotational source: the generic kernels carry them
     for_level(level, [&](Block* b) { anyMoving = anyMoving || b->v.sFace || b->v.moving; return 0; });
@@ -990,16 +988,8 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     if (level_tab(level, &t)) return 1;
     // the nodal-gradient march reads only the state and the metrics: forked onto its own queue BEFORE the inviscid kernel is
     // enqueued, joined in front of the face-flux kernel
-    const bool viscWs = g_visc_ws && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2 && g_march_by == 4 &&
-                        !withSA;
-    const bool viscMarch = kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2 && g_march_by == 4 &&
-                           !(g_viscous_fused >= 2 || (g_viscous_fused == 1 && !needGrad)) && !viscWs;
-    bool gradForked = false, mixed = false;
-    if (viscMarch && !withSA && g_phase_base <= 0 && inviscid_march_enabled() && kp.spaceDiscr == ADFLOW_UPWIND && !anyMoving) {
-        // Roe inviscid march and nodal-gradient march as ONE launch of interleaved workgroups
-        if (ensure_tiles(level)) return 1;
-        mixed = launch_roe_grad_mix(g_tab[level], g_tiles[level].first, g_tiles[level].second, t.n, t.nx, t.ny, t.nz, kp, g_stream);
-    }
+    const bool viscMarch = kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2 && g_march_by == 4;
+    bool gradForked = false;
     // viscous march first, Roe march last (tuning "visc_first"): the Roe kernel, bound by FP64 issue, adds the viscous sums it finds
     // in dw(2:5) instead of the viscous kernel, bound by HBM, reading dw back
     // (any inviscid kernel over the tile table can take that role: Roe, matrix dissipation, scalar JST of NS / RANS)
@@ -1007,12 +997,12 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     const bool tileInviscid = inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarViscM) &&
                               (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving;
     const int vfMask = (kp.spaceDiscr == ADFLOW_UPWIND) ? 1 : (kp.spaceDiscr == ADFLOW_DISS_MATRIX ? 2 : 4);
-    const bool viscFirst = (g_visc_first & vfMask) && viscMarch && !mixed && !withSA && !kp.fwMode && tileInviscid &&
+    const bool viscFirst = (g_visc_first & vfMask) && viscMarch && !kp.fwMode && tileInviscid &&
                            !kp.dissApprox && !kp.lumpedDiss;
     // the same order for the thin-layer viscous march of the preconditioner assembly (no gradient march in front of it)
     const bool approxFirst = (g_visc_first & vfMask) && viscApprox && g_visc_approx_march && viscous_is_tiled() >= 2 && g_march_by == 4 &&
                              kp.viscous && fabs(kp.rFil) >= 1.e-10 && !kp.fwMode && tileInviscid;
-    if (viscMarch && !mixed && !viscFirst && g_overlap && g_overlap_grad && g_phase_base <= 0) {
+    if (viscMarch && !viscFirst && !g_visc_gf && g_overlap && g_overlap_grad && g_phase_base <= 0) {
         HIPCHK(hipEventRecord(g_evFork, g_stream));
         HIPCHK(hipStreamWaitEvent(g_streamC, g_evFork, 0));
         gradForked = true;
@@ -1020,9 +1010,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     // scalar JST with the entropy sensor (NS / RANS, fine level) also has a marching form, but it is bound by memory like
     // the gather form (1.06 vs 1.10 ms on 8 x 128x128x96): only with tuning inviscid_march = 2
     const bool scalarVisc = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
-    if (mixed) {
-        // inviscid part already enqueued
-    } else if (viscFirst || approxFirst) {
+    if (viscFirst || approxFirst) {
         // enqueued behind the viscous march below
     } else if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) &&
                (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving) {
@@ -1038,18 +1026,13 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     }
     if (!viscFirst && !approxFirst) phase_mark(4);
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
-    const bool batched = !viscApprox && viscous_is_tiled();
+    const bool batched = !viscApprox && viscMarch;
     // thin-layer viscous flux of the preconditioner assembly: marching form over the tile table (blocks at rest, 4-row tiles)
     const bool approxMarch = viscApprox && g_visc_approx_march && viscous_is_tiled() >= 2 && g_march_by == 4 && !anyMoving;
     rc = for_level(level, [&](Block* b) {
         if (!b->face_vectors_valid) {
             launch_face_vectors(b->v, g_stream);
             b->face_vectors_valid = true;
-            b->node_sums_valid = false;       // every invalidation of the face vectors is a change of the geometry
-        }
-        if (batched && viscous_is_tiled() == 1 && !b->node_sums_valid) {
-            launch_node_sums(b->v, g_stream);
-            b->node_sums_valid = true;
         }
         if (viscApprox && !approxMarch) launch_viscous_approx(b->v, kp, g_stream);   // viscousFluxApprox instead of gradients + viscousFlux
         else if (!viscApprox && !batched) launch_viscous(b->v, kp, g_stream);
@@ -1069,15 +1052,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         } else
             launch_visc_march_approx(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
     }
-    if (batched && viscWs) {
-        // wave-specialised fused kernel over the level's tile table: gradient waves and face waves in one workgroup
-        phase_mark(5);
-        if (ensure_tiles(level)) return 1;
-        launch_visc_ws(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, needGrad, g_stream);
-    } else if (batched && viscous_is_tiled() >= 2 && (g_viscous_fused >= 2 || (g_viscous_fused == 1 && !needGrad))) {
-        // nodal gradients and face fluxes in one kernel: the gradients stay in LDS
-        launch_visc_fused_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
-    } else if (batched && viscous_is_tiled() >= 2 && g_march_by == 4) {
+    if (batched) {
         // k-marching nodal gradients (with the SA residual when the caller left it to this kernel), then the k-marching face
         // kernel over the level's tile table
         if (viscFirst) {
@@ -1085,18 +1060,27 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
             kv.viscFirst = 1;
             if (ensure_tiles(level)) return 1;
             // (phase marks in this order: 4 = nodal gradients, 5 = viscous fluxes, 6 = inviscid fluxes; bench.py labels them so)
-            launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kv, g_stream);
-            phase_mark(4);
-            launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+            if (g_visc_gf) {
+                // gradients and face fluxes in one kernel: the gradients stay in LDS (and go to HBM only when a caller reads them)
+                phase_mark(4);
+                launch_visc_gf_level(t.tab, t.n, t.nx, t.ny, t.nz, kv, needGrad, g_stream);
+            } else {
+                launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kv, g_stream);
+                phase_mark(4);
+                launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+            }
             phase_mark(5);
             if (!launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream))
                 launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
             return 0;
         }
+        if (g_visc_gf) {
+            phase_mark(5);
+            launch_visc_gf_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, needGrad, g_stream);
+            return 0;
+        }
         hipStream_t sg = gradForked ? g_streamC : g_stream;
-        if (mixed) { /* gradients came with the inviscid launch */ }
-        else if (withSA) launch_grad_sa_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, sg);
-        else launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, sg);
+        launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, sg);
         if (gradForked) {
             HIPCHK(hipEventRecord(g_evC, g_streamC));
             HIPCHK(hipStreamWaitEvent(g_stream, g_evC, 0));     // join: the face kernel needs the gradients and dw of the inviscid kernel
@@ -1104,8 +1088,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         phase_mark(5);
         if (ensure_tiles(level)) return 1;
         launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
-    } else if (batched)
-        launch_viscous_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    }
     return 0;
 }
 
@@ -1190,9 +1173,7 @@ static int block_res_enqueue(int level, unsigned flags)
     }
     phase_mark(2);
     // blockResCore order: SA residual first, then the mean-flow fluxes (blockette.F90:806-851)
-    // the SA residual rides on the nodal-gradient march when that kernel runs in this evaluation (exact viscous fluxes,
-    // marching kernels, blocks at rest); otherwise its own gather kernel
-    bool saFused = false, saForked = false;
+    bool saForked = false;
     if ((flags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
         bool moving = false;
         rc = for_level(level, [&](Block* b) {
@@ -1201,10 +1182,7 @@ static int block_res_enqueue(int level, unsigned flags)
             return 0;
         });
         if (rc) return rc;
-        saFused = g_grad_sa_fused && (flags & ADFLOW_RES_FLOW) && !viscApprox && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !moving &&
-                  viscous_is_tiled() >= 2 && g_march_by == 4 && g_viscous_fused < 2 &&
-                  !(g_viscous_fused == 1 && !(flags & ADFLOW_RES_UPDATE_INTERMED));
-        if (!saFused) {
+        {
             LevelTab t;
             if (level_tab(level, &t)) return 1;
             hipStream_t ss = g_stream;
@@ -1222,7 +1200,7 @@ static int block_res_enqueue(int level, unsigned flags)
     }
     phase_mark(3);
     if (flags & ADFLOW_RES_FLOW) {
-        rc = enqueue_flow_residual(level, kp, viscApprox, false, true, (flags & ADFLOW_RES_UPDATE_INTERMED) != 0, saFused);
+        rc = enqueue_flow_residual(level, kp, viscApprox, false, true, (flags & ADFLOW_RES_UPDATE_INTERMED) != 0);
         if (rc) return rc;
     }
     if (saForked) HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0));      // join
@@ -2868,20 +2846,14 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "viscous_tiled")) { g_viscous_tiled = value; return 0; }
     if (!strcmp(key, "inviscid_march")) { g_inviscid_march = value; return 0; }
     if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
-    if (!strcmp(key, "visc_sb")) { g_visc_sb = value; return 0; }
-    if (!strcmp(key, "viscous_fused")) { g_viscous_fused = value; return 0; }
-    if (!strcmp(key, "grad_sa_fused")) { g_grad_sa_fused = value; return 0; }
     if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
+    if (!strcmp(key, "visc_gf")) { g_visc_gf = value; return 0; }
     if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
     if (!strcmp(key, "overlap_grad")) { g_overlap_grad = value; return 0; }
     if (!strcmp(key, "visc_first")) { g_visc_first = value; return 0; }
     if (!strcmp(key, "ra_fold_scale")) { g_ra_fold_scale = value; return 0; }
     if (!strcmp(key, "sa_solve_march")) { g_sa_solve_march = value; return 0; }
     if (!strcmp(key, "overlap_sa")) { g_overlap_sa = value; return 0; }
-    if (!strcmp(key, "roe_grad_mix")) { g_roe_grad_mix = value; return 0; }
-    if (!strcmp(key, "roe_lds_pad")) { g_roe_lds_pad = value; return 0; }
-    if (!strcmp(key, "viscous_fused_rows")) { g_viscous_fused_rows = value; return 0; }
-    if (!strcmp(key, "visc_ws")) { g_visc_ws = value; return 0; }
     if (!strcmp(key, "max_grid_z")) { g_max_grid_z = (value > 0) ? value : 65535; return 0; }
     if (!strcmp(key, "euler_radii")) { g_euler_radii = value; return 0; }
     if (!strcmp(key, "visc_approx_march")) { g_visc_approx_march = value; return 0; }

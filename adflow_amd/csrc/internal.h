@@ -208,7 +208,6 @@ struct BlkView {
     int moving;             // blockIsMoving: rotational source with rot = cgnsDoms%rotRate (fluxes.F90:372-397)
     double rot[3];
     double *dI, *dJ, *dK;   // derived geometry: vector between the two cell centres of a face (viscous normal correction)
-    double *nsum;           // derived geometry: 18 summed normals of a node's dual cell + 1/sum(vol) (nodal gradients)
     // implicit turbulence boundary treatment of Spalart-Allmaras (turbBCRoutines.F90:662-798): halo = bvt - bmt * interior.
     // Index 0..5 = iMin,iMax,jMin,jMax,kMin,kMax; entry (a,b) at (a-1) + A*(b-1), A = je (i faces) or ie (j,k faces).
     // NULL until a block registers boundary subfaces (= all zero, the periodic / internal case).
@@ -383,19 +382,14 @@ void launch_entropy(const BlkView& b, hipStream_t s);
 void launch_inviscid_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
-void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 int viscous_is_tiled();
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
-bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
-void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 bool euler_march_radii_capable(const KParams& kp);
 extern int g_euler_radii;
-void launch_visc_ws(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s);
-extern int g_visc_ws;
-void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+void launch_visc_gf_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, bool storeGrad, hipStream_t s);
 void adf_phase_mark(int i);    // api.hip: optional HIP event between the phases of blocketteRes
 void launch_coarse_coordinates_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, hipStream_t s);
 void launch_xhalo_level(const BlkView* tab, int nslots, int nx, int ny, int nz, hipStream_t s);
@@ -403,7 +397,6 @@ void launch_xhalo_symm(const BlkView* tab, const BcEntry* ent, const int* order,
 void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, const KParams& kp, hipStream_t s);
 void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_face_vectors(const BlkView& b, hipStream_t s);
-void launch_node_sums(const BlkView& b, hipStream_t s);
 void launch_sa_residual_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, bool marchRes = false);
 void launch_sa_march_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);

@@ -405,25 +405,14 @@ __global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __re
     roe_march_body<LIM, FW, FINAL, XN, ADDV>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
 }
 
-#ifndef ADF_ROE_BODY_ONLY
 int g_roe_march = 1;       // tuning "roe_march": 0 = k_inviscid_march<upwind> (reconstruction per face) on the fine level too
 
 extern int g_march_kch;
-
-int g_roe_lds_pad = 0;     // tuning "roe_lds_pad": extra (unused) dynamic LDS bytes per workgroup: > 41 KB leaves one workgroup per CU,
-                           // i.e. half of the wave slots to the bandwidth-bound kernels running beside it on the side streams
 
 template <int LIM>
 static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     const dim3 blk(64, RM_BY, 1), grd(ntiles);
-    const size_t pad = (size_t)g_roe_lds_pad;
-#ifndef HOSTSIM
-    if (pad) {
-        (void)hipFuncSetAttribute((const void*)k_roe_march<LIM, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-        (void)hipFuncSetAttribute((const void*)k_roe_march<LIM, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-    }
-#endif
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
     const bool final_ = !(kp.viscous && doDiss);
     const int kch = g_march_kch;
@@ -433,11 +422,8 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
     } else if (kp.viscFirst) {
         hipLaunchKernelGGL((k_roe_march<LIM, false, true, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
-        if ((kp.metricFromX & 8) && !pad) {      // tuning metric_from_x bit 3: normals from the nodes
-            if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
-            else hipLaunchKernelGGL((k_roe_march<LIM, false, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
-        } else if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, pad, s, tab, tiles, kp, kch);
-        else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, pad, s, tab, tiles, kp, kch);
+        if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
     }
 }
 
@@ -462,4 +448,3 @@ bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const K
     default: return false;
     }
 }
-#endif   // ADF_ROE_BODY_ONLY

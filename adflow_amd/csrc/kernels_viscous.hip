@@ -108,120 +108,6 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
 }
 
 // ---------------------------------------------------------------------------
-// Tiled form of the nodal-gradient kernel.  k_nodal_gradients issues ~164 loads per node (8 cells x 6
-// values + 108 face-normal components + 8 volumes) and is bound by the texture-address unit.  Here
-//   * the six summed normal vectors of a node's dual cell and 1/sum(vol) are static geometry: formed once
-//     per mesh by k_node_sums with exactly the summation order of grad_dir (19 values per node);
-//   * u, v, w, a^2 of the 65 x 5 x 2 cells a workgroup's 64 x 4 nodes touch are staged once through LDS
-//     (a^2 = gamma p / rho evaluated once per cell instead of three times per node and cell).
-// 19 + ~18 global loads per node remain.  Arithmetic and its order are unchanged.
-// ---------------------------------------------------------------------------
-#define NS_NCOMP 19
-__global__ __launch_bounds__(VS_BX* VS_BY) void k_node_sums(BlkView b)
-{
-    const int i = blockIdx.x * VS_BX + threadIdx.x + 1;
-    const int j = blockIdx.y * VS_BY + threadIdx.y + 1;
-    const int k = blockIdx.z + 1;
-    if (i > b.il || j > b.jl) return;
-    const long c = b.idx(i, j, k), nb = b.nbox;
-    const long si = 1, sj = b.ldi, sk = b.ldk;
-    const long sd3[3] = {sk, sj, si};
-    const long s13[3] = {si, si, sj};
-    const long s23[3] = {sj, sk, sk};
-    const double* sN3[3] = {b.sK, b.sJ, b.sI};
-#pragma unroll
-    for (int dir = 0; dir < 3; ++dir) {
-        const long sd = sd3[dir], s1 = s13[dir], s2 = s23[dir];
-        const double* __restrict__ sN = sN3[dir];
-        const long cc[4] = {c, c + s1, c + s2, c + s1 + s2};
-        double mid[4][3], hi[4][3];
-        double sm[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                sm[d] += sN[cc[q] - sd + d * nb];
-                mid[q][d] = sN[cc[q] + d * nb];
-                hi[q][d] = sN[cc[q] + sd + d * nb];
-            }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { sm[d] += mid[q][d]; sp[d] += mid[q][d]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) sp[d] += hi[q][d];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            b.nsum[c + (6 * dir + d) * nb] = sm[d];
-            b.nsum[c + (6 * dir + 3 + d) * nb] = sp[d];
-        }
-    }
-    b.nsum[c + 18 * nb] = 1.0 / (b.vol[c] + b.vol[c + sk] + b.vol[c + si] + b.vol[c + si + sk] + b.vol[c + sj] +
-                                 b.vol[c + sj + sk] + b.vol[c + si + sj] + b.vol[c + si + sj + sk]);
-}
-
-#define NT_LDX 66
-#define NT_ROWS (VS_BY + 1)
-#define NT_PLANE (NT_ROWS * NT_LDX)
-
-__device__ __forceinline__ void grad_acc(const double* __restrict__ ns, long c, long nb, int off, double sign, double ubar, double vbar,
-                                         double wbar, double a2, double g[12])
-{
-    const double sx = ns[c + off * nb], sy = ns[c + (off + 1) * nb], sz = ns[c + (off + 2) * nb];
-    g[0] += sign * ubar * sx; g[1] += sign * ubar * sy; g[2] += sign * ubar * sz;
-    g[3] += sign * vbar * sx; g[4] += sign * vbar * sy; g[5] += sign * vbar * sz;
-    g[6] += sign * wbar * sx; g[7] += sign * wbar * sy; g[8] += sign * wbar * sz;
-    g[9] -= sign * a2 * sx; g[10] -= sign * a2 * sy; g[11] -= sign * a2 * sz;
-}
-
-__global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients_t(const BlkView* __restrict__ tab, int nzb)
-{
-    __shared__ double cu[2 * NT_PLANE], cv[2 * NT_PLANE], cw[2 * NT_PLANE], ca[2 * NT_PLANE];
-    const BlkView& b = tab[blockIdx.z / nzb + 1];      // level-batched: blockIdx.z = slot * nzb + node plane
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int i0 = blockIdx.x * VS_BX + 1, j0 = blockIdx.y * VS_BY + 1;
-    const int i = i0 + tx, j = j0 + ty, k = blockIdx.z % nzb + 1;
-    if (b.nx == 0 || k > b.kl || i0 > b.il || j0 > b.jl) return;      // uniform per workgroup
-    const long nb = b.nbox;
-    // ---- stage u, v, w, a^2 of cells (i0..i0+64, j0..j0+4, k..k+1)
-    for (int e = ty * VS_BX + tx; e < 2 * NT_ROWS * 65; e += VS_BX * VS_BY) {
-        const int row = e / 65, x = e % 65;
-        const int pl = row / NT_ROWS, r = row % NT_ROWS;
-        int ic = i0 + x, jc = j0 + r;
-        if (ic > b.ib) ic = b.ib;
-        if (jc > b.jb) jc = b.jb;
-        const long q = b.idx(ic, jc, k + pl);
-        const int o = pl * NT_PLANE + r * NT_LDX + x;
-        cu[o] = b.w[q + nb]; cv[o] = b.w[q + 2 * nb]; cw[o] = b.w[q + 3 * nb];
-        ca[o] = aa_at(b, q);
-    }
-    __syncthreads();
-    if (i > b.il || j > b.jl) return;
-    const long c = b.idx(i, j, k);
-    // LDS offsets of the eight cells, index di + 2 dj + 4 dk
-    int o[8];
-#pragma unroll
-    for (int n = 0; n < 8; ++n) o[n] = (n >> 2) * NT_PLANE + (ty + ((n >> 1) & 1)) * NT_LDX + tx + (n & 1);
-    double g[12];
-#pragma unroll
-    for (int m = 0; m < 12; ++m) g[m] = 0.0;
-#define NT_BAR(arr, a, bq, cq, d) (0.25 * (arr[o[a]] + arr[o[bq]] + arr[o[cq]] + arr[o[d]]))
-    // k-direction: patches (di, dj) at dk = 0 / 1 ; j-direction: (di, dk) at dj = 0 / 1 ; i-direction: (dj, dk) at di = 0 / 1
-    grad_acc(b.nsum, c, nb, 0, -1.0, NT_BAR(cu, 0, 1, 2, 3), NT_BAR(cv, 0, 1, 2, 3), NT_BAR(cw, 0, 1, 2, 3), NT_BAR(ca, 0, 1, 2, 3), g);
-    grad_acc(b.nsum, c, nb, 3, +1.0, NT_BAR(cu, 4, 5, 6, 7), NT_BAR(cv, 4, 5, 6, 7), NT_BAR(cw, 4, 5, 6, 7), NT_BAR(ca, 4, 5, 6, 7), g);
-    grad_acc(b.nsum, c, nb, 6, -1.0, NT_BAR(cu, 0, 1, 4, 5), NT_BAR(cv, 0, 1, 4, 5), NT_BAR(cw, 0, 1, 4, 5), NT_BAR(ca, 0, 1, 4, 5), g);
-    grad_acc(b.nsum, c, nb, 9, +1.0, NT_BAR(cu, 2, 3, 6, 7), NT_BAR(cv, 2, 3, 6, 7), NT_BAR(cw, 2, 3, 6, 7), NT_BAR(ca, 2, 3, 6, 7), g);
-    grad_acc(b.nsum, c, nb, 12, -1.0, NT_BAR(cu, 0, 2, 4, 6), NT_BAR(cv, 0, 2, 4, 6), NT_BAR(cw, 0, 2, 4, 6), NT_BAR(ca, 0, 2, 4, 6), g);
-    grad_acc(b.nsum, c, nb, 15, +1.0, NT_BAR(cu, 1, 3, 5, 7), NT_BAR(cv, 1, 3, 5, 7), NT_BAR(cw, 1, 3, 5, 7), NT_BAR(ca, 1, 3, 5, 7), g);
-#undef NT_BAR
-    const double oneOverV = b.nsum[c + 18 * nb];
-#pragma unroll
-    for (int m = 0; m < 12; ++m) b.grad[c + m * nb] = g[m] * oneOverV;
-}
-
-// ---------------------------------------------------------------------------
 // k-marching form of the nodal-gradient kernel (tuning "viscous_tiled" >= 2).  k_nodal_gradients_t reads 19 static
 // sums per node (152 B) next to ~6 state values and is bound by that traffic.  The dual-cell surface integral factorises:
 // with the per-CELL vectors  tI = sI(i-1) + sI(i),  tJ = sJ(j-1) + sJ(j),  tK = sK(k-1) + sK(k)  the normal of the
@@ -505,41 +391,11 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView
 }
 
 // ---------------------------------------------------------------------------
-// HORIZONTAL fusion of the Roe-upwind inviscid march (bound by FP64 issue: 76 % VALU busy, 2.4 TB/s) and the nodal-gradient
-// march (bound by HBM: 5.3 TB/s, 12 % VALU busy): one launch whose workgroups are roe tiles and gradient tiles interleaved in
-// proportion to their counts, so that every CU holds both kinds at any time and the gradient kernel's memory time hides under
-// the inviscid kernel's arithmetic.  The two bodies are the kernels above, unchanged; they share one LDS allocation
-// (max of the two) and the register allocation of the larger one.  Separate queues do not give this mixing: either kernel
-// alone fills every wave slot of the chip (profiles/r02_m: 2.94 vs 3.13 ms).
-// ---------------------------------------------------------------------------
-#define ADF_ROE_BODY_ONLY
-#include "kernels_roe_march.hip"
-#define MIX_LDS ((2 * RM_XJ) > (2 * NG_BY * NG_SLOT) ? (2 * RM_XJ) : (2 * NG_BY * NG_SLOT))
-
-template <int LIM, bool XN>
-__global__ __launch_bounds__(256, 2) void k_roe_grad_mix(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, int nR, KParams kp,
-                                                         int kch, int gx, int gy, int nG, int nzb)
-{
-    __shared__ double lds[MIX_LDS];
-    // block b of nR + nG: the a-th roe tile with a = floor(b nR / (nR + nG)) if that quotient steps at b, else a gradient tile
-    const long tot = (long)nR + nG, bq = blockIdx.x;
-    const int a0 = (int)((bq * nR) / tot), a1 = (int)(((bq + 1) * nR) / tot);
-    if (a1 > a0) {
-        roe_march_body<LIM, false, false>(tab, tiles, kp, kch, a0, lds);
-    } else {
-        const int g = (int)bq - a0;          // gradient tiles before this block
-        node_grad_body<XN>(tab, nzb, kp.gammaConstant, g % gx, (g / gx) % gy, g / (gx * gy), lds);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Nodal gradients AND the Spalart-Allmaras residual in one march (tuning "grad_sa_fused").  k_sa_residual gathers 73 values per
-// cell (237 B per cell from HBM, 3.5 TB/s: bound by load latency) and 14 of its 19 distinct arrays -- rho, u, v, w, the nine face
-// normals, vol -- are exactly what the cell record of k_node_grad_march reads.  Here the gradient march also keeps a three-plane
-// window of its own column (u, v, w, nu = rlv / rho, vol; five planes of nuTilde), takes the i neighbours by DPP lane shifts
-// and loads only the j neighbours, d2Wall, volRef and the lower-j normal in addition: the SA residual of cell plane m is
-// evaluated right after the record of plane m (the plane above is the one loaded for the next record).
-// Tiles advance by 60: nodes of lanes 1..60 and cells of lanes 2..61 (second-order advection reaches i +- 2).
+// The Spalart-Allmaras residual as a k-march.  k_sa_residual gathers 73 values per cell (237 B per cell from HBM, bound by load
+// latency).  Here a thread keeps a three-plane window of its own column (u, v, w, nu = rlv / rho, vol; five planes of nuTilde),
+// takes the i neighbours by DPP lane shifts and loads only the j neighbours, d2Wall and volRef; the face normals are re-formed
+// from the node coordinates (tuning metric_from_x bit 0) or loaded.  No LDS, no barrier.
+// Tiles advance by 60: cells of lanes 2..61 (second-order advection reaches i +- 2).
 // Arithmetic of the SA terms: sa_core.h (shared with k_sa_residual), same order of the sweeps (k, j, i).
 // ---------------------------------------------------------------------------
 #define GS_OUT 60
@@ -592,71 +448,32 @@ __device__ __forceinline__ GsNbr gs_dn1(const GsNbr& q)
     return r;
 }
 
-// record of a cell from its preloaded state and the face normals of its plane; nI / nJm / nJ / nK: sI(c), sJ(c - sj), sJ(c),
-// sK(c) (kept by the caller for the SA terms); sKp: sK of the plane below (in), of this plane (out)
-__device__ __forceinline__ void gs_record(const GsCell& q, double gam, const double nI[3], const double nJm[3], const double nJ[3],
-                                          const double nK[3], double sKp[3], NgRec& R)
-{
-    R.phi[0] = q.u; R.phi[1] = q.v; R.phi[2] = q.w;
-    R.phi[3] = -(gam * q.p) * rcp_nr(q.rho);
-    double tJ[3], tK[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        R.tI[d] = lane_up1(nI[d]) + nI[d];
-        tJ[d] = nJm[d] + nJ[d];
-        tK[d] = sKp[d] + nK[d];
-        sKp[d] = nK[d];
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        R.sTJ[d] = tJ[d] + lane_dn1(tJ[d]);
-        R.sTK[d] = tK[d] + lane_dn1(tK[d]);
-    }
-    R.sV = q.vol + lane_dn1(q.vol);
-}
-
-// GRAD = false: the Spalart-Allmaras residual alone as a k-march (no records, no LDS, no barrier), the default.
-// GRAD = true needs ~310 registers: at two waves per SIMD it spills 300 B per thread (2.6 ms on config 4a), at one wave per SIMD it
-// runs 1.67 ms against 0.55 + 0.68 ms of the two separate kernels (profiles/r02_g, r02_j): kept as a tuning option only.
-// ROWS: cell rows (waves) per workgroup; GRAD needs ROWS = NG_BY (the LDS record exchange); the SA-only march may run 8 rows: the
-// j neighbours are plain loads and the rows j0-2 .. j0+ROWS+1 a workgroup touches are re-read by the workgroups above and below
-// (349 B per cell at 4 rows, profiles/r02_k_pmc_traffic.txt, at 6.5 TB/s: the kernel is bound by exactly that traffic)
 // SOLVE (saSolve): also stores the right-hand side (scratch 0) and the central jacobian qq (scratch 1) of the DDADI line solves,
 // as k_sa_residual<true> (kernels_sa.hip)
-template <bool GRAD, int ROWS, bool LX = false, bool SOLVE = false>
-__global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
+template <bool SOLVE>
+__global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
 {
-    __shared__ double xr[GRAD ? 2 * NG_BY * NG_SLOT : 1];
-    // LX (tuning sa_march = 3): the state a cell contributes to its j neighbours (u, v, w, nu, vol, nuTilde) goes through LDS,
-    // double buffered over the planes, instead of plain loads of the rows j +- 1, j +- 2
-    __shared__ double sq[LX ? 2 * ROWS * 6 * 64 : 1];
     int bx, by, bz;
     if (!tile_of_workgroup(tg, bx, by, bz)) return;
     const BlkView& b = tab[bz / nzb + 1];
     const int lane = threadIdx.x, row = threadIdx.y;
-    const int i0 = bx * GS_OUT + 1, j0 = by * ROWS + 1;      // first node of the tile
+    const int i0 = bx * GS_OUT + 1, j0 = by * NG_BY + 1;      // first node of the tile
     const int kn0 = (bz % nzb) * tg.kch + 1;
     if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
     const int kn1 = (kn0 + tg.kch - 1 < b.kl) ? kn0 + tg.kch - 1 : b.kl;
     const int i = i0 - 1 + lane, j = j0 + row;
     const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
-    const int jx = (j0 + ROWS < b.jb) ? j0 + ROWS : b.jb;
-    const bool outN = (lane >= 1 && lane <= GS_OUT && i <= b.il && j <= b.jl);            // node produced
     const bool outC = (lane >= 2 && lane <= GS_OUT + 1 && i <= b.il && j >= 2 && j <= b.jl);   // SA cell produced
     const long nb = b.nbox;
-    const double gam = kp.gammaConstant;
     GsPtrs m;
     m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w5 = m.w3 + 2 * nb;
     m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.vol = (GPTR(const double))b.vol;
     m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
     m.d2wall = (GPTR(const double))b.d2wall; m.volRef = (GPTR(const double))b.volRef;
     m.nb8 = 8u * (unsigned)nb; m.sj = 8u * (unsigned)b.ldi;
-    NgPtrs mx;                                            // record of the cell row above the tile (wave 0): plain loads
-    mx.w0 = m.w0; mx.w1 = m.w1; mx.w2 = m.w2; mx.w3 = m.w3; mx.p = m.p; mx.sI = m.sI; mx.sJ = m.sJ; mx.sK = m.sK; mx.vol = m.vol;
-    mx.nb8 = m.nb8; mx.sj = m.sj;
-    mx.x = (GPTR(const double))b.x; mx.mfact = b.mfact;
-    const int xn = GRAD ? 0 : (kp.metricFromX & 1);       // SA-only march: face normals re-formed from the node coordinates
-    GPTR(double) grad = (GPTR(double))b.grad;
+    GPTR(const double) xnod = (GPTR(const double))b.x;
+    const double mfact = b.mfact;
+    const int xn = (kp.metricFromX & 1);                  // face normals re-formed from the node coordinates
     GPTR(double) dw5 = (GPTR(double))b.dw + 5 * nb;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     const unsigned sk = 8u * (unsigned)b.ldk, sj = m.sj;
@@ -664,56 +481,40 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
     const unsigned ojm2 = (jc >= 2) ? 2 * sj : (unsigned)jc * sj, ojp2 = (jc + 2 <= b.jb) ? 2 * sj : (unsigned)(b.jb - jc) * sj;
     const unsigned ojm1 = (jc >= 1) ? sj : 0u, ojp1 = (jc + 1 <= b.jb) ? sj : 0u;
     unsigned c = 8u * (unsigned)(ic + jc * b.ldi + kn0 * b.ldk);
-    unsigned cx = 8u * (unsigned)(ic + jx * b.ldi + kn0 * b.ldk);
     const bool secondOrd = (kp.orderTurb == 2) && kp.groundLevelIsOne;
     const double cb3Inv = 1.0 / kp.sa_cb3;
-    double sKp[3], sKpx[3];
+    double sKp[3];
     NgNodes Pn;
     if (xn) {
-        ngx_load(mx, c - sk, Pn);
-        ngx_normal_k(mx.mfact, Pn, sKp);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) sKpx[d] = 0.0;
+        ngx_load_x(xnod, c - sk, m.nb8, m.sj, Pn);
+        ngx_normal_k(mfact, Pn, sKp);
     } else {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * m.nb8); sKpx[d] = GRAD ? ldg(mx.sK, cx - sk + d * m.nb8) : 0.0; }
+        for (int d = 0; d < 3; ++d) sKp[d] = ldg(m.sK, c - sk + d * m.nb8);
     }
     // window of the own column: planes kn0-1 (SA neighbour below) and kn0; nuTilde of planes kn0-2 .. kn0+1
     const unsigned ckm2 = (kn0 >= 2) ? 2 * sk : sk;       // plane kn0-2 clamped at 0 (kn0 = 1: not read by a produced cell)
     GsCell s0 = gs_ld(m, c);
     GsNbr sm1 = gs_nbr_ld(m, c - sk);
     double n_m2 = ldg(m.w5, c - ckm2), n_0 = ldg(m.w5, c), n_p1 = ldg(m.w5, c + sk);
-    NgPlane S;
     for (int mm = kn0; mm <= kn1 + 1; ++mm) {
-        double* __restrict__ xb = xr + ((mm - kn0) & 1) * (NG_BY * NG_SLOT);
         const unsigned ckp2 = (mm + 2 <= b.kb) ? 2 * sk : ((mm + 1 <= b.kb) ? sk : 0u);
         const unsigned ckp1 = (mm + 1 <= b.kb) ? sk : 0u;
         // ---- loads of this plane: the four face-normal triples, the state of the plane above, nuTilde two planes above
         double nI[3], nJm[3], nJ[3], nK[3];
         if (xn) {
             NgNodes Nn;
-            ngx_load(mx, c, Nn);
-            ngx_normals(mx.mfact, Pn, Nn, nI, nJm, nJ, nK);
+            ngx_load_x(xnod, c, m.nb8, m.sj, Nn);
+            ngx_normals(mfact, Pn, Nn, nI, nJm, nJ, nK);
             Pn = Nn;
         } else {
             vm_ld3(m.sI, c, m.nb8, nI); vm_ld3(m.sJ, c - ojm1, m.nb8, nJm); vm_ld3(m.sJ, c, m.nb8, nJ); vm_ld3(m.sK, c, m.nb8, nK);
         }
         const GsCell sp1 = gs_ld(m, c + ckp1);
         const double n_p2 = ldg(m.w5, c + ckp2);
-        const double sKm[3] = {sKp[0], sKp[1], sKp[2]};    // sK of the plane below, before gs_record advances it
-        NgRec R;
-        if (GRAD) {
-            gs_record(s0, gam, nI, nJm, nJ, nK, sKp, R);
-            if (row > 0) ng_publish(xb + (row - 1) * NG_SLOT, lane, R);
-            if (row == 0) {
-                NgRec X;
-                ng_record(mx, cx, gam, sKpx, X);
-                ng_publish(xb + (NG_BY - 1) * NG_SLOT, lane, X);
-            }
-        } else {
+        const double sKm[3] = {sKp[0], sKp[1], sKp[2]};    // sK of the plane below
 #pragma unroll
-            for (int d = 0; d < 3; ++d) sKp[d] = nK[d];
-        }
+        for (int d = 0; d < 3; ++d) sKp[d] = nK[d];
         // ---- Spalart-Allmaras residual of cell (i, j, mm): sweeps k, j, i as the reference (sa.F90, turbUtils.F90)
         const bool saPlane = (mm >= 2 && mm <= kn1);
         if (saPlane) {
@@ -723,31 +524,8 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
             qkp.u = sp1.u; qkp.v = sp1.v; qkp.w = sp1.w; qkp.nu = sp1.rlv * rcp_nr(sp1.rho); qkp.vol = sp1.vol; qkp.nut = n_p1;
             const GsNbr qim = gs_up1(q0), qip = gs_dn1(q0);
             const double n_im2 = lane_up1(qim.nut), n_ip2 = lane_dn1(qip.nut);
-            GsNbr qjm, qjp;
-            double n_jm2, n_jp2;
-            if (!LX) {
-                qjm = gs_nbr_ld(m, c - ojm1); qjp = gs_nbr_ld(m, c + ojp1);
-                n_jm2 = ldg(m.w5, c - ojm2); n_jp2 = ldg(m.w5, c + ojp2);
-            } else {
-                double* __restrict__ so = sq + (((mm & 1) * ROWS + row) * 6) * 64 + lane;
-                so[0] = q0.u; so[64] = q0.v; so[128] = q0.w; so[192] = q0.nu; so[256] = q0.vol; so[320] = q0.nut;
-                // the rows outside the tile: plain loads, issued before the barrier
-                if (row == 0) qjm = gs_nbr_ld(m, c - ojm1);
-                if (row == ROWS - 1) qjp = gs_nbr_ld(m, c + ojp1);
-                if (row < 2) n_jm2 = ldg(m.w5, c - ojm2);
-                if (row >= ROWS - 2) n_jp2 = ldg(m.w5, c + ojp2);
-                __syncthreads();
-                auto nbr = [&](int r) {
-                    const double* __restrict__ si = sq + (((mm & 1) * ROWS + r) * 6) * 64 + lane;
-                    GsNbr q;
-                    q.u = si[0]; q.v = si[64]; q.w = si[128]; q.nu = si[192]; q.vol = si[256]; q.nut = si[320];
-                    return q;
-                };
-                if (row > 0) qjm = nbr(row - 1);
-                if (row < ROWS - 1) qjp = nbr(row + 1);
-                if (row >= 2) n_jm2 = sq[(((mm & 1) * ROWS + row - 2) * 6 + 5) * 64 + lane];
-                if (row < ROWS - 2) n_jp2 = sq[(((mm & 1) * ROWS + row + 2) * 6 + 5) * 64 + lane];
-            }
+            const GsNbr qjm = gs_nbr_ld(m, c - ojm1), qjp = gs_nbr_ld(m, c + ojp1);
+            const double n_jm2 = ldg(m.w5, c - ojm2), n_jp2 = ldg(m.w5, c + ojp2);
             const double nIm[3] = {lane_up1(nI[0]), lane_up1(nI[1]), lane_up1(nI[2])};
             // velocity gradient * 2 vol from the six neighbours (sa.F90:133-190)
             double gu[3][3];
@@ -805,68 +583,12 @@ __global__ __launch_bounds__(64 * ROWS, GRAD ? 1 : 2) void k_grad_sa_march(const
             }
             if (outC) stg(dw5, c, -ldg(m.volRef, c) * dvt * flg_blank(flags[c >> 3]));
         }
-        if (GRAD) {
-        __syncthreads();
-        NgRec U;
-        ng_fetch(xb + row * NG_SLOT, lane, U);
-        NgPlane N;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            N.Pt[d] = R.sTK[d] + U.sTK[d];
-            N.Q0t[d] = R.sTJ[d]; N.Q1t[d] = U.sTJ[d];
-            N.RIt[d] = R.tI[d] + U.tI[d];
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            N.Q0p[v] = R.phi[v] + lane_dn1(R.phi[v]);
-            N.Q1p[v] = U.phi[v] + lane_dn1(U.phi[v]);
-            N.Pp[v] = N.Q0p[v] + N.Q1p[v];
-            N.RIp[v] = R.phi[v] + U.phi[v];
-        }
-        N.V = R.sV + U.sV;
-        if (mm > kn0) {
-            double g[12];
-#pragma unroll
-            for (int q = 0; q < 12; ++q) g[q] = 0.0;
-            ng_outer(g, -1.0, S.Pp, S.Pt);
-            ng_outer(g, +1.0, N.Pp, N.Pt);
-            double t[3], ph[4];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t[d] = S.Q0t[d] + N.Q0t[d];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ph[v] = S.Q0p[v] + N.Q0p[v];
-            ng_outer(g, -1.0, ph, t);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t[d] = S.Q1t[d] + N.Q1t[d];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ph[v] = S.Q1p[v] + N.Q1p[v];
-            ng_outer(g, +1.0, ph, t);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t[d] = S.RIt[d] + N.RIt[d];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ph[v] = S.RIp[v] + N.RIp[v];
-            ng_outer(g, -1.0, ph, t);
-            double t1[3], ph1[4];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t[d]);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
-            ng_outer(g, +1.0, ph1, t1);
-            const double oneOverV = rcp_nr(S.V + N.V);
-            if (outN) {
-                const unsigned cn = c - sk;
-#pragma unroll
-                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cn, g[q] * oneOverV);
-            }
-        }
-        S = N;
-        }
         // ---- advance the window
         n_m2 = sm1.nut;
         sm1.u = s0.u; sm1.v = s0.v; sm1.w = s0.w; sm1.nu = s0.rlv * rcp_nr(s0.rho); sm1.vol = s0.vol; sm1.nut = n_0;
         s0 = sp1;
         n_0 = n_p1; n_p1 = n_p2;
-        c += ckp1; cx += sk;
+        c += ckp1;
     }
 }
 
@@ -1089,20 +811,6 @@ void launch_face_vectors(const BlkView& b, hipStream_t s)
     dim3 g((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
     hipLaunchKernelGGL(k_face_vectors, g, blk, 0, s, b);
 }
-// ... and the normal sums / inverse volume sums of the nodes, read by the LDS-tiled gradient kernel only (viscous_tiled = 1):
-// formed when that kernel is about to run, not with every geometry update (1.2 ms for the 8 north-star blocks)
-void launch_node_sums(const BlkView& b, hipStream_t s)
-{
-    dim3 blk(VS_BX, VS_BY, 1);
-    dim3 g((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
-    hipLaunchKernelGGL(k_node_sums, g, blk, 0, s, b);
-}
-
-#define VT_LDX 66                       // 65 nodes per row (+1 pad)
-#define VT_ROWS (VS_BY + 1)             // node rows j0-1 .. j0+VS_BY-1
-#define VT_COMP (VT_ROWS * VT_LDX)      // doubles of one gradient component in one node plane
-#define VT_PLANE (12 * VT_COMP)
-
 struct VCell { double u, v, w, aa, rlv, rev, gam; };
 
 __device__ __forceinline__ VCell vcell_at(const BlkView& b, const KParams& kp, long q)
@@ -1116,230 +824,6 @@ __device__ __forceinline__ VCell vcell_at(const BlkView& b, const KParams& kp, l
     c.rev = kp.eddyModel ? b.rev[q] : 0.0;
     return c;
 }
-
-// face between L and R; o0..o3: LDS offsets (component 0) of the face nodes in the reference order
-// (-s1-s2), (-s2), (-s1), (0); fN/dN: normal and centre-to-centre vector of the face
-__device__ __forceinline__ void visc_face_t(const KParams& kp, const double* __restrict__ gl, int o0, int o1, int o2, int o3,
-                                            const VCell& L, const VCell& R, const double fN[3], const double dN[3], int por_code,
-                                            double f[4])
-{
-    double por = 0.5 * kp.rFil;
-    if (por_code == ADF_POR_NOFLUX) por = 0.0;
-    const double mul = por * (L.rlv + R.rlv);
-    double mue = 0.0;
-    if (kp.eddyModel) mue = por * (L.rev + R.rev);
-    const double mut = mul + mue;
-    const double gm1 = 0.5 * (L.gam + R.gam) - 1.0;
-    const double heatCoef = mul * (1.0 / (kp.prandtl * gm1)) + mue * (1.0 / (kp.prandtlTurb * gm1));
-    double gr[12];
-#pragma unroll
-    for (int m = 0; m < 12; ++m) {
-        const double* g = gl + m * VT_COMP;
-        gr[m] = 0.25 * (g[o0] + g[o1] + g[o2] + g[o3]);
-    }
-    const double ss = 1.0 / sqrt(dN[0] * dN[0] + dN[1] * dN[1] + dN[2] * dN[2]);
-    const double ssx = ss * dN[0], ssy = ss * dN[1], ssz = ss * dN[2];
-    double corr;
-    corr = gr[0] * ssx + gr[1] * ssy + gr[2] * ssz - (R.u - L.u) * ss;
-    double u_x = gr[0] - corr * ssx, u_y = gr[1] - corr * ssy, u_z = gr[2] - corr * ssz;
-    corr = gr[3] * ssx + gr[4] * ssy + gr[5] * ssz - (R.v - L.v) * ss;
-    double v_x = gr[3] - corr * ssx, v_y = gr[4] - corr * ssy, v_z = gr[5] - corr * ssz;
-    corr = gr[6] * ssx + gr[7] * ssy + gr[8] * ssz - (R.w - L.w) * ss;
-    double w_x = gr[6] - corr * ssx, w_y = gr[7] - corr * ssy, w_z = gr[8] - corr * ssz;
-    corr = gr[9] * ssx + gr[10] * ssy + gr[11] * ssz + (R.aa - L.aa) * ss;
-    double q_x = gr[9] - corr * ssx, q_y = gr[10] - corr * ssy, q_z = gr[11] - corr * ssz;
-
-    const double fracDiv = (2.0 * (1.0 / 3.0)) * (u_x + v_y + w_z);
-    const double tauxxS = 2.0 * u_x - fracDiv, tauyyS = 2.0 * v_y - fracDiv, tauzzS = 2.0 * w_z - fracDiv;
-    const double tauxyS = u_y + v_x, tauxzS = u_z + w_x, tauyzS = v_z + w_y;
-    q_x *= heatCoef; q_y *= heatCoef; q_z *= heatCoef;
-    double tauxx, tauyy, tauzz, tauxy, tauxz, tauyz;
-    if (kp.useQCR) {
-        double den = sqrt(u_x * u_x + u_y * u_y + u_z * u_z + v_x * v_x + v_y * v_y + v_z * v_z + w_x * w_x + w_y * w_y +
-                          w_z * w_z);
-        den = fmax(den, 1.e-14);
-        const double fact = mue * 0.3 / den;
-        const double Wxy = u_y - v_x, Wxz = u_z - w_x, Wyz = v_z - w_y;
-        const double Wyx = -Wxy, Wzx = -Wxz, Wzy = -Wyz;
-        const double exx = fact * (Wxy * tauxyS + Wxz * tauxzS) * 2.0;
-        const double eyy = fact * (Wyx * tauxyS + Wyz * tauyzS) * 2.0;
-        const double ezz = fact * (Wzx * tauxzS + Wzy * tauyzS) * 2.0;
-        const double exy = fact * (Wxy * tauyyS + Wxz * tauyzS + Wyx * tauxxS + Wyz * tauxzS);
-        const double exz = fact * (Wxy * tauyzS + Wxz * tauzzS + Wzx * tauxxS + Wzy * tauxyS);
-        const double eyz = fact * (Wyx * tauxzS + Wyz * tauzzS + Wzx * tauxyS + Wzy * tauyyS);
-        tauxx = mut * tauxxS - exx; tauyy = mut * tauyyS - eyy; tauzz = mut * tauzzS - ezz;
-        tauxy = mut * tauxyS - exy; tauxz = mut * tauxzS - exz; tauyz = mut * tauyzS - eyz;
-    } else {
-        tauxx = mut * tauxxS; tauyy = mut * tauyyS; tauzz = mut * tauzzS;
-        tauxy = mut * tauxyS; tauxz = mut * tauxzS; tauyz = mut * tauyzS;
-    }
-    const double ubar = 0.5 * (L.u + R.u), vbar = 0.5 * (L.v + R.v), wbar = 0.5 * (L.w + R.w);
-    const double nx = fN[0], ny = fN[1], nz = fN[2];
-    const double fmx = tauxx * nx + tauxy * ny + tauxz * nz;
-    const double fmy = tauxy * nx + tauyy * ny + tauyz * nz;
-    const double fmz = tauxz * nx + tauyz * ny + tauzz * nz;
-    double frhoE = (ubar * tauxx + vbar * tauxy + wbar * tauxz) * nx;
-    frhoE = frhoE + (ubar * tauxy + vbar * tauyy + wbar * tauyz) * ny;
-    frhoE = frhoE + (ubar * tauxz + vbar * tauyz + wbar * tauzz) * nz;
-    frhoE = frhoE - q_x * nx - q_y * ny - q_z * nz;
-    f[0] = fmx; f[1] = fmy; f[2] = fmz; f[3] = frhoE;
-}
-
-#define VT_KCH 8      // planes marched by one workgroup: each new plane stages ONE node plane (the other is reused)
-
-__device__ __forceinline__ void vt_stage_plane(const BlkView& b, double* __restrict__ gl, int slot, int i0, int j0, int kn, int tx,
-                                               int ty)
-{
-    const long nb = b.nbox;
-    int in = i0 - 1 + tx;
-    if (in > b.ib) in = b.ib;
-    // rows = (component, node row) of node plane kn; nodes i0-1 .. i0+63
-    for (int it = 0; it < (12 * VT_ROWS) / VS_BY; ++it) {
-        const int row = ty * ((12 * VT_ROWS) / VS_BY) + it;
-        const int m = row / VT_ROWS, r = row % VT_ROWS;
-        int jn = j0 - 1 + r;
-        if (jn > b.jb) jn = b.jb;
-        gl[slot * VT_PLANE + row * VT_LDX + tx] = b.grad[m * nb + b.idx(in, jn, kn)];
-    }
-    const int t = ty * VS_BX + tx;      // the 65th node of every row
-    if (t < 12 * VT_ROWS) {
-        const int m = t / VT_ROWS, r = t % VT_ROWS;
-        int jn = j0 - 1 + r;
-        if (jn > b.jb) jn = b.jb;
-        int in2 = i0 + VS_BX - 1;
-        if (in2 > b.ib) in2 = b.ib;
-        gl[slot * VT_PLANE + t * VT_LDX + VS_BX] = b.grad[m * nb + b.idx(in2, jn, kn)];
-    }
-}
-
-// The same node plane in two steps: global loads into registers (issued before the faces of the current plane are
-// evaluated, so their latency hides under that arithmetic), LDS stores after the barrier that frees the slot.
-#define VT_NPRE ((12 * VT_ROWS) / VS_BY + 1)
-__device__ __forceinline__ void vt_prefetch_plane(const BlkView& b, double pre[VT_NPRE], int i0, int j0, int kn, int tx, int ty)
-{
-    const long nb = b.nbox;
-    int in = i0 - 1 + tx;
-    if (in > b.ib) in = b.ib;
-#pragma unroll
-    for (int it = 0; it < (12 * VT_ROWS) / VS_BY; ++it) {
-        const int row = ty * ((12 * VT_ROWS) / VS_BY) + it;
-        const int m = row / VT_ROWS, r = row % VT_ROWS;
-        int jn = j0 - 1 + r;
-        if (jn > b.jb) jn = b.jb;
-        pre[it] = b.grad[m * nb + b.idx(in, jn, kn)];
-    }
-    const int t = ty * VS_BX + tx;
-    pre[VT_NPRE - 1] = 0.0;
-    if (t < 12 * VT_ROWS) {
-        const int m = t / VT_ROWS, r = t % VT_ROWS;
-        int jn = j0 - 1 + r;
-        if (jn > b.jb) jn = b.jb;
-        int in2 = i0 + VS_BX - 1;
-        if (in2 > b.ib) in2 = b.ib;
-        pre[VT_NPRE - 1] = b.grad[m * nb + b.idx(in2, jn, kn)];
-    }
-}
-
-__device__ __forceinline__ void vt_store_plane(double* __restrict__ gl, int slot, const double pre[VT_NPRE], int tx, int ty)
-{
-#pragma unroll
-    for (int it = 0; it < (12 * VT_ROWS) / VS_BY; ++it) {
-        const int row = ty * ((12 * VT_ROWS) / VS_BY) + it;
-        gl[slot * VT_PLANE + row * VT_LDX + tx] = pre[it];
-    }
-    const int t = ty * VS_BX + tx;
-    if (t < 12 * VT_ROWS) gl[slot * VT_PLANE + t * VT_LDX + VS_BX] = pre[VT_NPRE - 1];
-}
-
-__global__ __launch_bounds__(VS_BX* VS_BY, 2) void k_viscous_t(const BlkView* __restrict__ tab, int nzb, KParams kp)
-{
-    __shared__ double gl[2 * VT_PLANE];     // two node planes (ring), 12 components, VT_ROWS x 65 nodes
-    const BlkView& b = tab[blockIdx.z / nzb + 1];      // level-batched: blockIdx.z = slot * nzb + k chunk
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int i0 = blockIdx.x * VS_BX + 2, j0 = blockIdx.y * VS_BY + 2;
-    const int i = i0 + tx, j = j0 + ty;
-    const int k0 = (blockIdx.z % nzb) * VT_KCH + 2;
-    if (b.nx == 0 || k0 > b.kl || i0 > b.il || j0 > b.jl) return;     // uniform per workgroup
-    const int k1 = (k0 + VT_KCH - 1 < b.kl) ? k0 + VT_KCH - 1 : b.kl;
-    const long nb = b.nbox;
-    const long si = 1, sj = b.ldi, sk = b.ldk;
-    const bool valid = (i <= b.il && j <= b.jl);
-    // reference sweep order k, j, i (fluxes.F90:2610, 2903, 3197); rolled: six inlined faces would not fit 256 VGPRs
-    const long sd3[3] = {sk, sj, si};
-    const int D13[3] = {1, 1, VT_LDX};            // s1 = si, si, sj
-    const double* sN3[3] = {b.sK, b.sJ, b.sI};
-    const double* dN3[3] = {b.dK, b.dJ, b.dI};
-    const int shift3[3] = {4, 2, 0};              // porosity bits of the direction inside the flag byte
-    int pLo = 0;                                   // slot of node plane k-1
-    vt_stage_plane(b, gl, pLo, i0, j0, k0 - 1, tx, ty);
-    vt_stage_plane(b, gl, 1 - pLo, i0, j0, k0, tx, ty);
-    __syncthreads();
-    double fk[4] = {0, 0, 0, 0};                   // flux through the k face below the cell: the upper face of the previous plane
-    for (int k = k0; k <= k1; ++k) {
-        const int pHi = 1 - pLo;
-        double pre[VT_NPRE];
-        if (k < k1) vt_prefetch_plane(b, pre, i0, j0, k + 1, tx, ty);     // node plane of the NEXT step: in flight under the faces
-        if (valid) {
-            const long c = b.idx(i, j, k);
-            const uint8_t f0 = b.flags[c];
-            double acc[5] = {0, 0, 0, 0, 0};
-            const VCell C = vcell_at(b, kp, c);
-            // LDS offset (component 0) of this cell's corner node (i-1, j-1, k-1); +1 / +VT_LDX step to i, j; the k step
-            // goes to the other slot.  Face nodes in the reference order (-s1-s2), (-s2), (-s1), (0).
-            const int o000 = pLo * VT_PLANE + ty * VT_LDX + tx;
-            const int Dk = (pHi - pLo) * VT_PLANE;
-            const int Dd3[3] = {Dk, VT_LDX, 1};
-            const int D23[3] = {VT_LDX, Dk, Dk};  // s2 = sj, sk, sk
-#pragma unroll 1
-            for (int d = 0; d < 3; ++d) {
-                const long sd = sd3[d], cm = c - sd;
-                const double* __restrict__ sN = sN3[d];
-                const double* __restrict__ dN = dN3[d];
-                const int D1 = D13[d], D2 = D23[d], oP = o000 + Dd3[d];
-                double fM[4], fP[4];
-                if (d == 0 && k > k0) {
-                    // the face below was the upper k face of the previous plane: same inputs, same flux
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) fM[m] = fk[m];
-                } else {
-                    const VCell M = vcell_at(b, kp, cm);
-                    const double nM[3] = {sN[cm], sN[cm + nb], sN[cm + 2 * nb]};
-                    const double dM[3] = {dN[cm], dN[cm + nb], dN[cm + 2 * nb]};
-                    const int porM = (b.flags[cm] >> shift3[d]) & 3;
-                    visc_face_t(kp, gl, o000, o000 + D1, o000 + D2, o000 + D1 + D2, M, C, nM, dM, porM, fM);
-                }
-                const VCell P = vcell_at(b, kp, c + sd);
-                const double nP[3] = {sN[c], sN[c + nb], sN[c + 2 * nb]};
-                const double dP[3] = {dN[c], dN[c + nb], dN[c + 2 * nb]};
-                const int porP = (f0 >> shift3[d]) & 3;
-                visc_face_t(kp, gl, oP, oP + D1, oP + D2, oP + D1 + D2, C, P, nP, dP, porP, fP);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    acc[m + 1] += fM[m];
-                    acc[m + 1] -= fP[m];
-                }
-                if (d == 0) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) fk[m] = fP[m];
-                }
-            }
-            const double blank = flg_blank(f0);
-#pragma unroll
-            for (int l = 0; l < 5; ++l) {
-                const double fwn = (kp.fwMode ? b.fw[c + l * nb] : 0.0) + acc[l];   // without fwMode dw already holds dw + fw
-                if (kp.fwMode) b.fw[c + l * nb] = fwn;
-                b.dw[c + l * nb] = (b.dw[c + l * nb] + fwn) * blank;
-            }
-        }
-        __syncthreads();        // every wave is done with plane k-1 before its slot takes plane k+1
-        if (k < k1) {
-            vt_store_plane(gl, pLo, pre, tx, ty);
-            __syncthreads();
-        }
-        pLo = pHi;
-    }
-}
-
 
 // ---------------------------------------------------------------------------
 // k-marching form of the face-flux kernel (tuning "viscous_tiled" >= 2) over the level's XCD-ordered tile table (the table of
@@ -1609,537 +1093,262 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
 }
 
 // ---------------------------------------------------------------------------
-// FUSED nodal gradients + viscous fluxes (tuning "viscous_fused").  The two marching kernels above exchange the 12 nodal
-// gradients through HBM: 106 B per cell written, ~140 B read back, and the gradient kernel re-reads the state and the face
-// normals the flux kernel reads as well (344 + 487 B per cell measured, profiles/r02_c_pmc_traffic.txt; both kernels run at
-// ~5 TB/s, i.e. they are bound by that traffic).  Here one workgroup of 8 waves (64 lanes x 8 cell rows) marches in k and
-//   phase A  makes the cell record of plane m (ng_record: state, tI / tJ / tK, i-pair sums) and publishes it in LDS,
-//   phase B  forms the gradients of node plane m-1 from the records of planes m-1 (carried sums) and m (ng_* algebra of
-//            k_node_grad_march) and stores them in a two-plane LDS ring,
-//   phase C  evaluates the faces of cell plane m-1 from node planes m-2 and m-1 in that ring (vm_face of k_visc_march),
-// with two barriers per plane.  The gradients never leave the CU.  Rows: wave r owns cell row / node row j0-1+r; cell rows
-// 1..7 are produced (the j faces of a cell need node rows j-1 and j), wave 0 also makes the record of the cell row above
-// the tile.  LDS: records 8 x 14 x 512 B + gradient ring 2 x 8 x 12 x 512 B = 153 KB: one workgroup per CU.
-// k_wall_stress and the updateIntermed copy-out read the gradients from HBM: those callers run k_node_grad_march as well.
+// FUSED nodal gradients + viscous fluxes, two workgroups per CU (tuning "visc_gf", default on).  k_node_grad_march and k_visc_march
+// exchange the 12 nodal gradients through HBM (103 B per cell written, 125 B read back) and both read the state and the face
+// normals: 194 + 427 B per cell by the counters, 0.45 + 0.84 ms.  Here ONE workgroup of four waves marches in k and keeps the
+// gradients in LDS:
+//   * wave r owns node row jn = j0-1+r of the tile: per plane it loads the raw values of the cell rows jn and jn+1 (no record
+//     exchange between waves), forms the gradient of its node (i, jn, m-1) from the cell planes m-1 (carried) and m with the
+//     factorised surface integral of k_node_grad_march, and writes it to a THREE-slot LDS ring (72 KB): one barrier per plane,
+//     no second one, because the slot written in step m+1 was last read in step m-1;
+//   * waves 1..3 then evaluate the four faces of cell (i, jn, m-1) (k face carried, i face once with DPP hand-over, both j
+//     faces) from node planes m-2 and m-1 in the ring with vm_face, the arithmetic of k_visc_march; the cell states of the two
+//     planes and of the row above are the values the gradient part holds anyway, the row below is a plain load;
+//   * 3 of 4 rows and 60 of 64 columns produce output; LDS 73.7 KB and <= 256 VGPRs leave two workgroups per CU, which run out
+//     of phase and hide each other's load latency (the single-workgroup fusions of round 2 ran eight waves in barrier lockstep).
+// Reference: flowUtils.F90:1676-2026 (allNodalGradients), fluxes.F90:2534-3485 (viscousFlux), residuals.F90:334-344.
+// STG: the gradients are also stored to b.grad (updateIntermed copy-out).  FIRST: as k_visc_march.
 // ---------------------------------------------------------------------------
-#define VF_OUT 60
-#define VF_KCH 32
+#define GF_OUT 60
+#define GF_ROWS 3
+#define GF_G (12 * 64)
 
-// VF_ROWS: waves per workgroup (VF_ROWS - 1 cell rows produced): 8 -> one workgroup per CU, 4 -> two
-template <bool QCR, int VF_ROWS>
-__global__ __launch_bounds__(64 * VF_ROWS, 2) void k_visc_fused(const BlkView* __restrict__ tab, int nzb, KParams kp)
+struct GfPtrs {
+    GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) p;
+    GPTR(const double) rlv; GPTR(const double) rev; GPTR(const double) vol;
+    GPTR(const double) sI; GPTR(const double) sJ; GPTR(const double) sK;
+    unsigned nb8;
+};
+
+// state + volume of one cell
+struct GfRaw { VmCell q; double vol; };
+
+__device__ __forceinline__ GfRaw gf_ld(const GfPtrs& m, unsigned o, double gam, bool eddy)
 {
-    constexpr int VF_REC = VF_ROWS * NG_SLOT;      // doubles of the record exchange
-    constexpr int VF_GPL = VF_ROWS * VM_G;         // doubles of one node plane in the ring
-    __shared__ double vf_lds[VF_REC + 2 * VF_GPL];     // 8 rows: 155,648 B of the 160 KiB per CU; 4 rows: 77,824 B
-    double* __restrict__ xr = vf_lds;                     // records: slot s = cell row j0+s (s = 0..7), row 0 publishes slot 7
-    double* __restrict__ gx = vf_lds + VF_REC;            // gradient ring [parity][node row][component][lane]
-    const BlkView& b = tab[blockIdx.z / nzb + 1];         // level-batched: blockIdx.z = slot * nzb + k chunk
-    const int lane = threadIdx.x, row = threadIdx.y;
-    const int i0 = blockIdx.x * VF_OUT + 2, j0 = blockIdx.y * (VF_ROWS - 1) + 2;      // first produced cell
-    const int k0 = (blockIdx.z % nzb) * VF_KCH + 2;
-    if (b.nx == 0 || k0 > b.kl || i0 > b.il || j0 > b.jl) return;                      // uniform per workgroup
-    const int k1 = (k0 + VF_KCH - 1 < b.kl) ? k0 + VF_KCH - 1 : b.kl;
-    const int i = i0 - 2 + lane, j = j0 - 1 + row;
-    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.je) ? j : b.je;
-    const int jx = (j0 + VF_ROWS - 1 < b.jb) ? j0 + VF_ROWS - 1 : b.jb;               // cell row above the tile
-    const bool out = (row >= 1 && lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
-    const long nb = b.nbox;
-    const unsigned nb8 = 8u * (unsigned)nb, sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
-    NgPtrs m;
-    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
-    m.p = (GPTR(const double))b.p;
-    m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
-    m.vol = (GPTR(const double))b.vol;
-    m.nb8 = nb8; m.sj = sj;
-    VmPtrs vp;
-    vp.w0 = m.w0; vp.w1 = m.w1; vp.w2 = m.w2; vp.w3 = m.w3; vp.p = m.p;
-    vp.rlv = (GPTR(const double))b.rlv; vp.rev = (GPTR(const double))b.rev;
-    GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
-    GPTR(const double) dK = (GPTR(const double))b.dK;
-    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
-    GPTR(double) dw = (GPTR(double))b.dw;
-    GPTR(double) fw = (GPTR(double))b.fw;
-    VmK K;
-    K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
-    K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
-    const double gam = kp.gammaConstant;
-
-    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + (k0 - 1) * b.ldk);      // cell plane of the record made in this iteration
-    unsigned cx = 8u * (unsigned)(ic + jx * b.ldi + (k0 - 1) * b.ldk);
-    double sKp[3], sKpx[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * nb8); sKpx[d] = ldg(m.sK, cx - sk + d * nb8); }
-    NgPlane S;                 // sums of the previous cell plane
-    VmCell q0;                 // state of the own cell in the previous plane (the plane whose faces are evaluated)
-    double fk[4] = {0, 0, 0, 0};
-    const int oM = (row - 1) * VM_G + lane, o0 = row * VM_G + lane;        // node rows j-1 and j of a ring plane
-    for (int mm = k0 - 1; mm <= k1 + 1; ++mm) {
-        // ---------------- phase A: record of cell plane mm
-        NgRec R;
-        ng_record(m, c, gam, sKp, R);
-        VmCell q1;             // the own cell in plane mm
-        q1.u = R.phi[0]; q1.v = R.phi[1]; q1.w = R.phi[2]; q1.na = R.phi[3];
-        q1.rlv = ldg(vp.rlv, c);
-        q1.rev = K.eddy ? ldg(vp.rev, c) : 0.0;
-        if (row > 0) ng_publish(xr + (row - 1) * NG_SLOT, lane, R);
-        if (row == 0) {
-            NgRec X;
-            ng_record(m, cx, gam, sKpx, X);
-            ng_publish(xr + (VF_ROWS - 1) * NG_SLOT, lane, X);
-        }
-        __syncthreads();
-        // ---------------- phase B: sums of plane mm; gradients of node plane mm-1 -> ring slot (mm-1) & 1
-        {
-            NgRec U;
-            ng_fetch(xr + row * NG_SLOT, lane, U);
-            NgPlane N;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                N.Pt[d] = R.sTK[d] + U.sTK[d];
-                N.Q0t[d] = R.sTJ[d]; N.Q1t[d] = U.sTJ[d];
-                N.RIt[d] = R.tI[d] + U.tI[d];
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                N.Q0p[v] = R.phi[v] + lane_dn1(R.phi[v]);
-                N.Q1p[v] = U.phi[v] + lane_dn1(U.phi[v]);
-                N.Pp[v] = N.Q0p[v] + N.Q1p[v];
-                N.RIp[v] = R.phi[v] + U.phi[v];
-            }
-            N.V = R.sV + U.sV;
-            if (mm >= k0) {
-                double g[12];
-#pragma unroll
-                for (int q = 0; q < 12; ++q) g[q] = 0.0;
-                ng_outer(g, -1.0, S.Pp, S.Pt);
-                ng_outer(g, +1.0, N.Pp, N.Pt);
-                double t[3], ph[4];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) t[d] = S.Q0t[d] + N.Q0t[d];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) ph[v] = S.Q0p[v] + N.Q0p[v];
-                ng_outer(g, -1.0, ph, t);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) t[d] = S.Q1t[d] + N.Q1t[d];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) ph[v] = S.Q1p[v] + N.Q1p[v];
-                ng_outer(g, +1.0, ph, t);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) t[d] = S.RIt[d] + N.RIt[d];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) ph[v] = S.RIp[v] + N.RIp[v];
-                ng_outer(g, -1.0, ph, t);
-                double t1[3], ph1[4];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t[d]);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
-                ng_outer(g, +1.0, ph1, t1);
-                const double oneOverV = rcp_nr(S.V + N.V);
-                double* __restrict__ gb = gx + ((mm - 1) & 1) * VF_GPL;
-#pragma unroll
-                for (int q = 0; q < 12; ++q) gb[row * VM_G + q * 64 + lane] = g[q] * oneOverV;
-            }
-            S = N;
-        }
-        __syncthreads();
-        // ---------------- phase C: faces of cell plane mm-1 (node planes mm-2 and mm-1)
-        if (mm >= k0 + 1 && row >= 1) {
-            const unsigned cf = c - sk;                                        // the cell whose faces are evaluated
-            const double* __restrict__ xb = gx + ((mm - 1) & 1) * VF_GPL;      // node plane mm-1
-            const double* __restrict__ xp = gx + (mm & 1) * VF_GPL;            // node plane mm-2
-            const int flag0 = flags[cf >> 3];
-            double acc[4];
-            if (mm == k0 + 1) {
-                // k face below the first plane of the march: nodes (i-1..i, j-1..j, k0-1)
-                double gs[12], nK[3], dKv[3];
-                const VmCell qm1 = vm_ld(vp, cf - sk, gam, K.eddy);
-#pragma unroll
-                for (int q = 0; q < 12; ++q) { const double a = xp[oM + q * 64] + xp[o0 + q * 64]; gs[q] = a + lane_up1(a); }
-                vm_ld3(m.sK, cf - sk, nb8, nK); vm_ld3(dK, cf - sk, nb8, dKv);
-                vm_face<QCR>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(cf - sk) >> 3]), fk);
-            }
-            // ---- the four faces the cell evaluates, as a ROLLED loop (one inlined face evaluation: the sums of the gradient
-            //      phase stay in registers next to it; unrolled, the four evaluations spill 350 B per thread):
-            //        0: (j-1 | j)  nodes (i-1..i, j-1, k-1..k)     1: (i | i+1)  nodes (i, j-1..j, k-1..k), (i-1 | i) from lane-1
-            //        2: (j | j+1)  nodes (i-1..i, j,   k-1..k)     3: (k | k+1)  nodes (i-1..i, j-1..j, k)
-#pragma unroll
-            for (int l = 0; l < 4; ++l) acc[l] = fk[l];
-#pragma unroll 1
-            for (int fc = 0; fc < 4; ++fc) {
-                double gs[12], fN[3], dN[3], f[4];
-                VmCell L, Rr;
-                int por;
-                if (fc == 0) {
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) { const double a = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = a + lane_up1(a); }
-                    L = vm_ld(vp, cf - sj, gam, K.eddy); Rr = q0;
-                    vm_ld3(m.sJ, cf - sj, nb8, fN); vm_ld3(dJ, cf - sj, nb8, dN);
-                    por = flg_porJ(flags[(cf - sj) >> 3]);
-                } else if (fc == 1) {
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) gs[q] = (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
-                    L = q0; Rr = vm_dn1(q0);
-                    vm_ld3(m.sI, cf, nb8, fN); vm_ld3(dI, cf, nb8, dN);
-                    por = flg_porI((uint8_t)flag0);
-                } else if (fc == 2) {
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) { const double a = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = a + lane_up1(a); }
-                    L = q0; Rr = vm_ld(vp, cf + sj, gam, K.eddy);
-                    vm_ld3(m.sJ, cf, nb8, fN); vm_ld3(dJ, cf, nb8, dN);
-                    por = flg_porJ((uint8_t)flag0);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) { const double a = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = a + lane_up1(a); }
-                    L = q0; Rr = q1;
-                    vm_ld3(m.sK, cf, nb8, fN); vm_ld3(dK, cf, nb8, dN);
-                    por = flg_porK((uint8_t)flag0);
-                }
-                vm_face<QCR>(K, gs, L, Rr, fN, dN, por, f);
-                if (fc == 0) {
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) acc[l] += f[l];
-                } else if (fc == 1) {
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
-                } else {
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) acc[l] -= f[l];
-                    if (fc == 3) {
-#pragma unroll
-                        for (int l = 0; l < 4; ++l) fk[l] = f[l];
-                    }
-                }
-            }
-            if (out) {
-                const double blank = flg_blank((uint8_t)flag0);
-#pragma unroll
-                for (int l = 0; l < 4; ++l) {
-                    const unsigned o = cf + (l + 1) * nb8;
-                    double fwn = acc[l];
-                    if (kp.fwMode) {
-                        fwn += ldg(fw, o);
-                        stg(fw, o, fwn);
-                    }
-                    stg(dw, o, (ldg(dw, o) + fwn) * blank);
-                }
-                if (kp.fwMode) stg(dw, cf, (ldg(dw, cf) + ldg(fw, cf)) * blank);
-            }
-        }
-        q0 = q1;
-        c += sk; cx += sk;
-    }
+    GfRaw r;
+    r.q.u = ldg(m.w1, o); r.q.v = ldg(m.w2, o); r.q.w = ldg(m.w3, o);
+    r.q.na = -(gam * ldg(m.p, o)) * rcp_nr(ldg(m.w0, o));
+    r.q.rlv = ldg(m.rlv, o);
+    r.q.rev = eddy ? ldg(m.rev, o) : 0.0;
+    r.vol = ldg(m.vol, o);
+    return r;
 }
 
-// ---------------------------------------------------------------------------
-// WAVE-SPECIALISED nodal gradients + viscous fluxes (tuning "visc_ws").  k_visc_fused above keeps the carried sums of the gradient
-// phase AND the state of the face phase live in every thread and spills.  Here the two phases run in DIFFERENT waves of one
-// workgroup of 8 waves (64 lanes x 8), each with its own register set:
-//   waves 0..3  "face" waves: the body of k_visc_march for the cell rows j_t .. j_t+3 of a tile of the level's tile table; the
-//               gradients of the face nodes come from a 3-plane LDS ring instead of HBM.
-//   waves 4..7  "gradient" waves: the algebra of k_node_grad_march for the five node rows j_t-1 .. j_t+3, SPLIT BY VARIABLE
-//               (wave 4+v forms d(u, v, w, -a^2)[v]/dx_d of all five rows: five rows do not divide over four waves, four
-//               variables do).  The cell records (ng_record) of the six cell rows j_t-1 .. j_t+4 are made once per plane
-//               (waves 4, 5: two rows each, waves 6, 7: one) and shared through LDS; the geometric sums are re-formed by
-//               every gradient wave (additions only).
-// Step n of the march: [A] the records of cell plane n+1 and the face waves' own states go to LDS | barrier | [B] the gradient
-// waves form node plane n (carried sums of cell plane n + the new records) into ring slot n mod 3 while the face waves
-// evaluate cell plane n-1 from node planes n-2 and n-1 | barrier.  The branch between the two roles is a scalar branch on the
-// wave number with the whole march loop inside each arm, so the register allocation is the maximum of the two bodies, not the
-// sum; both arms execute the same number of barriers.  HBM traffic: state, metrics and dw only -- no gradient round trip
-// (2 x 96 B per node) and the state / normals both phases read are fetched by one workgroup at nearly the same time.
-// LDS: ring 3 x 5 x 12 x 512 B + records (4 + 2 x 2) x 14 x 512 B + states 4 x 6 x 512 B = 161,792 B: one workgroup per CU.
-// STG: the gradients are also stored in the block array (wall stress / updateIntermed callers).
-// ---------------------------------------------------------------------------
-#define WS_NR 5                         // node rows of a tile
-#define WS_RR 6                         // cell rows with a record
-#define WS_PLANE (WS_NR * VM_G)         // doubles of one node plane in the ring
+// metric sums of one cell plane around the node column of the thread (the t-part of NgPlane)
+struct GfMet { double Pt[3], Q0t[3], Q1t[3], RIt[3], V; };
 
-template <bool QCR, bool STG>
-__global__ __launch_bounds__(64 * 8, 1) void k_visc_ws(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp, int kch)
+template <bool QCR, bool FIRST, bool STG>
+__global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
 {
-    __shared__ double gx[3 * WS_PLANE];               // [slot][node row 0..4 = rows j_t-1 .. j_t+3][component][lane]
-    __shared__ double rec[4 * NG_SLOT];               // records of the cell rows j_t-1 .. j_t+2: [row][value][lane], single-buffered
-    __shared__ double recX[2 * 2 * NG_SLOT];          // records of the cell rows j_t+3, j_t+4: [parity of the cell plane][row][value][lane]
-    __shared__ double qx[VM_BY * 6 * 64];             // state of the own cell of every face wave
-    const int4 t = tiles[blockIdx.x];
-    if (t.x < 0) return;
-    const BlkView& b = tab[t.x];
-    const int lane = threadIdx.x;
-    const int wave = wave_uniform((int)threadIdx.y);
-    const int i = t.y * VM_OUT + lane;          // columns i0-2 .. i0+61
-    const int jt = 2 + t.z * VM_BY;
-    const int k0 = 2 + t.w * kch;
-    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
+    __shared__ double ring[3 * 4 * GF_G];         // [slot][node row 0..3 = rows j0-1 .. j0+2][component][lane]
+    int bx, by, bz;
+    if (!tile_of_workgroup(tg, bx, by, bz)) return;
+    const BlkView& b = tab[bz / nzb + 1];
+    const int lane = threadIdx.x, r = threadIdx.y;
+    const int i = bx * GF_OUT + lane;             // cells i0-2 .. i0+61, i0 = 2 + 60 bx
+    const int j0 = 2 + by * GF_ROWS;              // first produced cell row
+    const int k0 = 2 + (bz % nzb) * tg.kch;
+    if (b.nx == 0 || k0 > b.kl || bx * GF_OUT + 2 > b.il || j0 > b.jl) return;          // uniform per workgroup
+    const int k1 = (k0 + tg.kch - 1 < b.kl) ? k0 + tg.kch - 1 : b.kl;
+    const int jn = j0 - 1 + r;                    // node row of the wave; waves 1..3: also its cell row
     const int ic = (i < b.ib) ? i : b.ib;
+    const int jA = (jn < b.jb) ? jn : b.jb, jB = (jn + 1 < b.jb) ? jn + 1 : b.jb;
+    const bool outC = (r >= 1 && lane >= 2 && lane <= 61 && i <= b.il && jn <= b.jl);
+    const bool outN = (lane >= 1 && lane <= 61 && i <= b.il && jn <= b.jl);
     const long nb = b.nbox;
     const unsigned nb8 = 8u * (unsigned)nb, sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
-    const double gam = kp.gammaConstant;
-    if (wave >= VM_BY) {
-        // ======================================================== gradient waves
-        const int var = wave - VM_BY;                                 // 0..3: u, v, w, -a^2
-        NgPtrs m;
-        m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
-        m.p = (GPTR(const double))b.p;
-        m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
-        m.vol = (GPTR(const double))b.vol;
-        m.nb8 = nb8; m.sj = sj;
-        GPTR(double) grad = (GPTR(double))b.grad;
-        // record rows: every gradient wave makes the record of the cell row j_t-1+var in phase A of a step from loads issued one
-        // phase earlier (rawA); waves 0 and 1 also make the records of the rows j_t+3, j_t+4 for the NEXT step at the end of
-        // phase B -- behind their gradient work, while the face waves are still busy -- into a double-buffered slot
-        const int rA = var;
-        const bool two = (var < 2);
-        const int jA = (jt - 1 + rA < b.jb) ? jt - 1 + rA : b.jb;
-        const int jB = (jt + 3 + var < b.jb) ? jt + 3 + var : b.jb;
-        unsigned cA = 8u * (unsigned)(ic + jA * b.ldi + (k0 - 1) * b.ldk);
-        unsigned cB = 8u * (unsigned)(ic + jB * b.ldi + (k0 - 1) * b.ldk);
-        double sKpA[3], sKpB[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { sKpA[d] = ldg(m.sK, cA - sk + d * nb8); sKpB[d] = two ? ldg(m.sK, cB - sk + d * nb8) : 0.0; }
-        if (two) {
-            NgRec R;
-            ng_record(m, cB, gam, sKpB, R);                                   // cell plane k0-1
-            ng_publish(recX + (((k0 - 1) & 1) * 2 + var) * NG_SLOT, lane, R);
-        }
-        // carried sums of the previous cell plane: per node row Pt, RIt, V, Pp, RIp; per cell row Q0t, Q0p
-        double SPt[WS_NR][3], SRIt[WS_NR][3], SV[WS_NR], SPp[WS_NR], SRIp[WS_NR], SQt[WS_RR][3], SQp[WS_RR];
-        // store window of the gradients in the block array: every node once over the tiles of the level
-        const bool stLane = STG && lane >= ((t.y == 0) ? 1 : 2) && lane <= 61 && i <= b.il;
-        NgRaw rawA;                        // the loads of the NEXT step's record, issued one phase early
-        ng_load(m, cA, rawA);
-        for (int n = k0 - 2; n <= k1 + 1; ++n) {
-            // n = k0-2: prologue (records and sums of cell plane k0-1, no node plane)
-            const bool prod = (n <= k1) && kp.storeIntermed != 1;
-            if (prod) {
-                NgRec R;
-                ng_finish(rawA, gam, sKpA, R);
-                ng_publish(rec + rA * NG_SLOT, lane, R);
-            }
-            __syncthreads();
-            if (prod) {
-                if (n < k1) {                // cell plane n+2 for the record of step n+1: in flight during the gradient phase
-                    cA += sk;
-                    ng_load(m, cA, rawA);
-                }
-                double* __restrict__ xo = gx + ((n - (k0 - 2)) % 3) * WS_PLANE;
-                double tIp[3], sTKp[3], sTJp[3], sVp = 0.0, php = 0.0;       // the record of the cell row below
-#pragma unroll
-                for (int cr = 0; cr < WS_RR; ++cr) {
-                    const double* __restrict__ x = ((cr < 4) ? rec + cr * NG_SLOT : recX + (((n + 1) & 1) * 2 + (cr - 4)) * NG_SLOT) + lane;
-                    double tI[3], sTK[3], sTJ[3];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) { tI[d] = x[d * 64]; sTK[d] = x[(7 + d) * 64]; sTJ[d] = x[(11 + d) * 64]; }
-                    const double ph = x[(3 + var) * 64];
-                    const double sV = x[10 * 64];
-                    const double q0p = ph + lane_dn1(ph);
-                    if (cr > 0) {
-                        const int r = cr - 1;                        // node row r: own cell row r (below), cell row r+1 = cr (above)
-                        double NPt[3], NRIt[3];
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) { NPt[d] = sTKp[d] + sTK[d]; NRIt[d] = tIp[d] + tI[d]; }
-                        const double q0pm = php + lane_dn1(php);
-                        const double NPp = q0pm + q0p, NRIp = php + ph, NV = sVp + sV;
-                        if (n >= k0 - 1) {
-                            double g[3] = {0.0, 0.0, 0.0};
-                            double a = -0.25 * SPp[r];
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) g[d] += a * SPt[r][d];
-                            a = 0.25 * NPp;
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) g[d] += a * NPt[d];
-                            a = -0.25 * (SQp[r] + q0pm);
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) g[d] += a * (SQt[r][d] + sTJp[d]);
-                            a = 0.25 * (SQp[cr] + q0p);
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) g[d] += a * (SQt[cr][d] + sTJ[d]);
-                            const double phi = SRIp[r] + NRIp;
-                            double ti[3];
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) ti[d] = SRIt[r][d] + NRIt[d];
-                            a = -0.25 * phi;
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) g[d] += a * ti[d];
-                            a = 0.25 * lane_dn1(phi);
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) g[d] += a * lane_dn1(ti[d]);
-                            const double oneOverV = rcp_nr(SV[r] + NV);
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) {
-                                const double gv = g[d] * oneOverV;
-                                xo[r * VM_G + (3 * var + d) * 64 + lane] = gv;
-                                if (STG) {
-                                    const int jn = jt - 1 + r;
-                                    if (stLane && jn <= b.jl && (r > 0 || t.z == 0) && (n >= k0 || t.w == 0))
-                                        stg(grad + (3 * var + d) * nb, 8u * (unsigned)(ic + jn * b.ldi + n * b.ldk), gv);
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) { SPt[r][d] = NPt[d]; SRIt[r][d] = NRIt[d]; }
-                        SV[r] = NV; SPp[r] = NPp; SRIp[r] = NRIp;
-                    }
-                    // the sums of the row below were consumed above: now they can take the new plane
-                    if (cr > 0) {
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) SQt[cr - 1][d] = sTJp[d];
-                        SQp[cr - 1] = php + lane_dn1(php);
-                    }
-                    if (cr == WS_RR - 1) {
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) SQt[cr][d] = sTJ[d];
-                        SQp[cr] = q0p;
-                    }
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) { tIp[d] = tI[d]; sTKp[d] = sTK[d]; sTJp[d] = sTJ[d]; }
-                    sVp = sV; php = ph;
-                }
-                if (two && n < k1) {
-                    NgRec R;
-                    cB += sk;
-                    ng_record(m, cB, gam, sKpB, R);                           // cell plane n+2
-                    ng_publish(recX + ((n & 1) * 2 + var) * NG_SLOT, lane, R);
-                }
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    // ============================================================ face waves
-    const int row = wave;
-    const int j = jt + row;
-    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
-    const int jc = (j < b.je) ? j : b.je;
-    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
-    VmPtrs m;
+    GfPtrs m;
     m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
     m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.rev = (GPTR(const double))b.rev;
-    GPTR(const double) sI = (GPTR(const double))b.sI; GPTR(const double) sJ = (GPTR(const double))b.sJ;
-    GPTR(const double) sK = (GPTR(const double))b.sK;
+    m.vol = (GPTR(const double))b.vol;
+    m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
+    m.nb8 = nb8;
     GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
     GPTR(const double) dK = (GPTR(const double))b.dK;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     GPTR(double) dw = (GPTR(double))b.dw;
     GPTR(double) fw = (GPTR(double))b.fw;
+    GPTR(double) grad = (GPTR(double))b.grad;
     VmK K;
     K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
     K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
-    VmCell q0 = vm_ld(m, c, gam, K.eddy);
-    double fk[4] = {0.0, 0.0, 0.0, 0.0};
-    const int oM = row * VM_G + lane, o0 = (row + 1) * VM_G + lane;       // node rows j-1 and j
-    for (int n = k0 - 2; n <= k1 + 1; ++n) {
-        const int k = n - 1;                      // the cell plane evaluated in this step
-        const bool act = (k >= k0) && kp.storeIntermed != 2;
-        VmCell qp1 = q0;
-        if (act) {
-            double* __restrict__ qo = qx + row * (6 * 64) + lane;
-            qo[0] = q0.u; qo[64] = q0.v; qo[128] = q0.w; qo[192] = q0.na; qo[256] = q0.rlv; qo[320] = q0.rev;
-            qp1 = vm_ld(m, c + sk, gam, K.eddy);
+    const double gam = kp.gammaConstant;
+    // byte offsets of the cells (ic, jA, m) and (ic, jB, m); the row below the own one (jn >= 1)
+    unsigned cA = 8u * (unsigned)(ic + jA * b.ldi + (k0 - 1) * b.ldk);
+    const unsigned dB = 8u * (unsigned)((jB - jA) * b.ldi);          // row jn+1 relative to row jn (0 at the upper end of the box)
+    const unsigned dM = (jA >= 1) ? sj : 0u;                          // row jn-1
+    // carried: state of the rows jn, jn+1 at the previous plane, metric sums of that plane, sK of that plane, the k-face flux
+    VmCell qA, qB;
+    GfMet S;
+    double sKA[3], sKB[3], fk[4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sKA[d] = ldg(m.sK, cA - sk + d * nb8); sKB[d] = ldg(m.sK, cA + dB - sk + d * nb8); }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) fk[l] = 0.0;
+    qA.u = qA.v = qA.w = qA.na = qA.rlv = qA.rev = 0.0;
+    qB = qA;
+    for (int mm = k0 - 1; mm <= k1 + 1; ++mm) {
+        // ---- cell plane mm of the rows jn and jn+1: state, normals, volume
+        const GfRaw a = gf_ld(m, cA, gam, K.eddy), bq = gf_ld(m, cA + dB, gam, K.eddy);
+        double aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3];
+        vm_ld3(m.sI, cA, nb8, aI); vm_ld3(m.sJ, cA - dM, nb8, aJm); vm_ld3(m.sJ, cA, nb8, aJ); vm_ld3(m.sK, cA, nb8, aK);
+        vm_ld3(m.sI, cA + dB, nb8, bI); vm_ld3(m.sJ, cA + dB, nb8, bJ); vm_ld3(m.sK, cA + dB, nb8, bK);
+        // ---- metric sums of this plane (ng_finish for both rows; the row above takes sJ(j-1) from the own row)
+        GfMet N;
+        {
+            double tJa[3], tKa[3], tJb[3], tKb[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double tIa = lane_up1(aI[d]) + aI[d], tIb = lane_up1(bI[d]) + bI[d];
+                N.RIt[d] = tIa + tIb;
+                tJa[d] = aJm[d] + aJ[d]; tJb[d] = aJ[d] + bJ[d];
+                tKa[d] = sKA[d] + aK[d]; tKb[d] = sKB[d] + bK[d];
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                N.Q0t[d] = tJa[d] + lane_dn1(tJa[d]);
+                N.Q1t[d] = tJb[d] + lane_dn1(tJb[d]);
+                N.Pt[d] = (tKa[d] + lane_dn1(tKa[d])) + (tKb[d] + lane_dn1(tKb[d]));
+            }
+            N.V = (a.vol + lane_dn1(a.vol)) + (bq.vol + lane_dn1(bq.vol));
+        }
+        // ---- gradient of node (i, jn, mm-1) from the cell planes mm-1 (qA, qB, S) and mm -> ring
+        if (mm >= k0) {
+            const double sA[4] = {qA.u, qA.v, qA.w, qA.na}, sB[4] = {qB.u, qB.v, qB.w, qB.na};
+            const double nA[4] = {a.q.u, a.q.v, a.q.w, a.q.na}, nB[4] = {bq.q.u, bq.q.v, bq.q.w, bq.q.na};
+            double g[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) g[q] = 0.0;
+            double SQ0[4], SQ1[4], NQ0[4], NQ1[4], ph[4], t3[3];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                SQ0[v] = sA[v] + lane_dn1(sA[v]); SQ1[v] = sB[v] + lane_dn1(sB[v]);
+                NQ0[v] = nA[v] + lane_dn1(nA[v]); NQ1[v] = nB[v] + lane_dn1(nB[v]);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = SQ0[v] + SQ1[v];
+            ng_outer(g, -1.0, ph, S.Pt);                          // k direction: below the node -, above +
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = NQ0[v] + NQ1[v];
+            ng_outer(g, +1.0, ph, N.Pt);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t3[d] = S.Q0t[d] + N.Q0t[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = SQ0[v] + NQ0[v];
+            ng_outer(g, -1.0, ph, t3);                            // j direction: own row -, row above +
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t3[d] = S.Q1t[d] + N.Q1t[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = SQ1[v] + NQ1[v];
+            ng_outer(g, +1.0, ph, t3);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t3[d] = S.RIt[d] + N.RIt[d];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph[v] = (sA[v] + sB[v]) + (nA[v] + nB[v]);
+            ng_outer(g, -1.0, ph, t3);                            // i direction: own column -, column i+1 +
+            double t1[3], ph1[4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t3[d]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
+            ng_outer(g, +1.0, ph1, t1);
+            const double oneOverV = rcp_nr(S.V + N.V);
+            double* __restrict__ xo = ring + (((mm - k0) % 3) * 4 + r) * GF_G + lane;        // node plane mm-1 -> slot (mm-k0) % 3
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                g[q] *= oneOverV;
+                xo[q * 64] = g[q];
+            }
+            if (STG && outN) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cA - sk, g[q]);
+            }
+        }
+        // ---- loads of the face part (cell plane mm-1), requested above the barrier
+        const unsigned cF = cA - sk;
+        const bool facePlane = (r >= 1 && mm >= k0);           // uniform per wave
+        const bool full = (mm > k0);                           // all faces (first step of the march: the k face below plane k0 only)
+        VmCell qjm;
+        double nI[3], dIv[3], nJ[3], dJv[3], nJm[3], dJm[3], dKv[3];
+        int flag0 = 0, flagM = 0;
+        if (facePlane) {
+            vm_ld3(dK, cF, nb8, dKv);
+            flag0 = flags[cF >> 3];
+            if (full) {
+                qjm = gf_ld(m, cF - dM, gam, K.eddy).q;
+                vm_ld3(m.sI, cF, nb8, nI); vm_ld3(dI, cF, nb8, dIv);
+                vm_ld3(m.sJ, cF, nb8, nJ); vm_ld3(dJ, cF, nb8, dJv);
+                vm_ld3(m.sJ, cF - dM, nb8, nJm); vm_ld3(dJ, cF - dM, nb8, dJm);
+                flagM = flags[(cF - dM) >> 3];
+            }
         }
         __syncthreads();
-        if (act) {
-            const double* __restrict__ xb = gx + ((k - (k0 - 2)) % 3) * WS_PLANE;          // node plane k
-            const double* __restrict__ xp = gx + ((k - 1 - (k0 - 2)) % 3) * WS_PLANE;      // node plane k-1
-            const int flag0 = flags[c >> 3];
-            if (k == k0) {
-                // k face below the first plane of the march: nodes (i-1..i, j-1..j, k0-1)
-                double gs[12], nK[3], dKv[3];
-                const VmCell qm1 = vm_ld(m, c - sk, gam, K.eddy);
-#pragma unroll
-                for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xp[oM + q * 64]; gs[q] = s + lane_up1(s); }
-                vm_ld3(sK, c - sk, nb8, nK); vm_ld3(dK, c - sk, nb8, dKv);
-                vm_face<QCR>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), fk);
-            }
+        if (facePlane) {
+            const double* __restrict__ xb = ring + (((mm - k0) % 3) * 4) * GF_G;            // node plane mm-1
+            const double* __restrict__ xp = ring + (((mm - k0 + 2) % 3) * 4) * GF_G;        // node plane mm-2
+            const int oM = (r - 1) * GF_G + lane, o0 = r * GF_G + lane;                     // node rows jn-1 and jn
             double acc[4];
-            auto row_state = [&](int r) {
-                const double* __restrict__ qi = qx + r * (6 * 64) + lane;
-                VmCell q;
-                q.u = qi[0]; q.v = qi[64]; q.w = qi[128]; q.na = qi[192]; q.rlv = qi[256]; q.rev = qi[320];
-                return q;
-            };
-            // ---- j face (j-1 | j): nodes (i-1..i, j-1, k-1..k)
-            {
-                double gs[12], nJ[3], dJv[3], f[4];
-                const VmCell qjm = (row > 0) ? row_state(row - 1) : vm_ld(m, c - sj, gam, K.eddy);
+            if (full) {
+                // ---- j face (jn-1 | jn): nodes (i-1..i, jn-1, mm-2..mm-1)
+                {
+                    double gs[12], f[4];
 #pragma unroll
-                for (int q = 0; q < 12; ++q) { const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
-                vm_ld3(sJ, c - sj, nb8, nJ); vm_ld3(dJ, c - sj, nb8, dJv);
-                vm_face<QCR>(K, gs, qjm, q0, nJ, dJv, flg_porJ(flags[(c - sj) >> 3]), f);
+                    for (int q = 0; q < 12; ++q) { const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
+                    vm_face<QCR>(K, gs, qjm, qA, nJm, dJm, flg_porJ((uint8_t)flagM), f);
 #pragma unroll
-                for (int l = 0; l < 4; ++l) acc[l] = fk[l] + f[l];
+                    for (int l = 0; l < 4; ++l) acc[l] = fk[l] + f[l];
+                }
+                // ---- i face (i | i+1): nodes (i, jn-1..jn, mm-2..mm-1); the face (i-1 | i) comes from lane-1
+                {
+                    double gs[12], f[4];
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) gs[q] = (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
+                    const VmCell qR = vm_dn1(qA);
+                    vm_face<QCR>(K, gs, qA, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
+                }
+                // ---- j face (jn | jn+1): nodes (i-1..i, jn, mm-2..mm-1)
+                {
+                    double gs[12], f[4];
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
+                    vm_face<QCR>(K, gs, qA, qB, nJ, dJv, flg_porJ((uint8_t)flag0), f);
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) acc[l] -= f[l];
+                }
             }
-            // ---- i face (i | i+1): nodes (i, j-1..j, k-1..k) of the own column; the face (i-1 | i) comes from lane-1
+            // ---- k face above cell plane mm-1: nodes (i-1..i, jn-1..jn, mm-1); sKA still holds sK of plane mm-1
             {
-                double gs[12], nI[3], dIv[3], f[4];
-#pragma unroll
-                for (int q = 0; q < 12; ++q) gs[q] = (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
-                vm_ld3(sI, c, nb8, nI); vm_ld3(dI, c, nb8, dIv);
-                const VmCell qR = vm_dn1(q0);
-                vm_face<QCR>(K, gs, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
-#pragma unroll
-                for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
-            }
-            // ---- j face (j | j+1): nodes (i-1..i, j, k-1..k)
-            {
-                double gs[12], nJ[3], dJv[3], f[4];
-                const VmCell qjp = (row < VM_BY - 1) ? row_state(row + 1) : vm_ld(m, c + sj, gam, K.eddy);
-#pragma unroll
-                for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
-                vm_ld3(sJ, c, nb8, nJ); vm_ld3(dJ, c, nb8, dJv);
-                vm_face<QCR>(K, gs, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), f);
-#pragma unroll
-                for (int l = 0; l < 4; ++l) acc[l] -= f[l];
-            }
-            // ---- k face above the cell: nodes (i-1..i, j-1..j, k)
-            {
-                double gs[12], nK[3], dKv[3], f[4];
+                double gs[12], f[4];
 #pragma unroll
                 for (int q = 0; q < 12; ++q) { const double s = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
-                vm_ld3(sK, c, nb8, nK); vm_ld3(dK, c, nb8, dKv);
-                vm_face<QCR>(K, gs, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), f);
+                vm_face<QCR>(K, gs, qA, a.q, sKA, dKv, flg_porK((uint8_t)flag0), f);
 #pragma unroll
-                for (int l = 0; l < 4; ++l) { acc[l] -= f[l]; fk[l] = f[l]; }
+                for (int l = 0; l < 4; ++l) { if (full) acc[l] -= f[l]; fk[l] = f[l]; }
             }
-            if (out) {
+            if (full && outC) {
                 const double blank = flg_blank((uint8_t)flag0);
 #pragma unroll
                 for (int l = 0; l < 4; ++l) {
-                    const unsigned o = c + (l + 1) * nb8;
+                    const unsigned o = cF + (l + 1) * nb8;
                     double fwn = acc[l];
+                    if (FIRST) { stg(dw, o, fwn); continue; }
                     if (kp.fwMode) {
                         fwn += ldg(fw, o);
                         stg(fw, o, fwn);
                     }
                     stg(dw, o, (ldg(dw, o) + fwn) * blank);
                 }
-                if (kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
+                if (!FIRST && kp.fwMode) stg(dw, cF, (ldg(dw, cF) + ldg(fw, cF)) * blank);    // the density residual has no viscous part
             }
-            q0 = qp1;
-            c += sk;
         }
-        __syncthreads();
-    }
-}
-
-int g_visc_ws = 0;          // tuning "visc_ws": wave-specialised fused gradients + viscous fluxes
-
-void launch_visc_ws(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp0, bool storeGrad, hipStream_t s)
-{
-    if (ntiles <= 0) return;
-    KParams kp = kp0;
-    kp.storeIntermed = (g_visc_ws >= 2) ? g_visc_ws - 1 : 0;      // timing experiments: 2 = gradient waves idle, 3 = face waves idle
-    const dim3 blk(64, 8, 1), grd(ntiles);
-#ifdef HOSTSIM
-    if (getenv("ADF_TRACE_WS")) fprintf(stderr, "launch_visc_ws store=%d ntiles=%d\n", (int)storeGrad, ntiles);
-#endif
-    if (kp.useQCR) {
-        if (storeGrad) hipLaunchKernelGGL((k_visc_ws<true, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-        else hipLaunchKernelGGL((k_visc_ws<true, false>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-    } else {
-        if (storeGrad) hipLaunchKernelGGL((k_visc_ws<false, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-        else hipLaunchKernelGGL((k_visc_ws<false, false>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+        // ---- advance
+        qA = a.q; qB = bq.q;
+        S = N;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sKA[d] = aK[d]; sKB[d] = bK[d]; }
+        cA += sk;
     }
 }
 
@@ -2241,9 +1450,6 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
     hipLaunchKernelGGL(k_viscous, gc, blk, 0, s, b, kp);
 }
 
-// tiled forms, every block of the level in one launch each
-int g_visc_sb = 0;
-
 // marching face-flux kernel over the tile table of the level (tuning viscous_tiled >= 2)
 // viscousFluxApprox of every block of the level (thin-layer form, no nodal gradients)
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
@@ -2261,97 +1467,42 @@ void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const 
         if (kp.useQCR) hipLaunchKernelGGL((k_visc_march<true, 1, false, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
         else hipLaunchKernelGGL((k_visc_march<false, 0, false, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
     } else if (kp.useQCR) hipLaunchKernelGGL((k_visc_march<true, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-    else if (g_visc_sb == 0) hipLaunchKernelGGL((k_visc_march<false, 0>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-    else if (g_visc_sb == 1) hipLaunchKernelGGL((k_visc_march<false, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-    else hipLaunchKernelGGL((k_visc_march<false, 2>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
+    else hipLaunchKernelGGL((k_visc_march<false, 0>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
 }
 
-int g_viscous_fused_rows = 8;   // tuning "viscous_fused_rows": 8 or 4 waves per workgroup
-int g_viscous_fused = 0;    // tuning "viscous_fused": 0 = off, 1 = where the gradients need not reach HBM, 2 = always
+int g_visc_gf = 1;          // tuning "visc_gf": nodal gradients + viscous fluxes as ONE kernel (k_visc_gf), 0 = k_node_grad_march + k_visc_march
 
-// fused nodal gradients + viscous fluxes (one launch for every block of the level)
-void launch_visc_fused_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+// fused nodal gradients + viscous fluxes of every block of the level in one launch
+void launch_visc_gf_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, bool storeGrad, hipStream_t s)
 {
-    LEVEL_SPLIT(nslots, nz + 4, launch_visc_fused_level(tab + s0_, n_, nx, ny, nz, kp, s));
+    LEVEL_SPLIT(nslots, nz + 4, launch_visc_gf_level(tab + s0_, n_, nx, ny, nz, kp, storeGrad, s));
     if (nslots <= 0) return;
-    const int nch = (nz + VF_KCH - 1) / VF_KCH;
-    const int rows = (g_viscous_fused_rows == 4) ? 4 : 8;
-    const dim3 blk(64, rows, 1), grd((nx + VF_OUT - 1) / VF_OUT, (ny + rows - 2) / (rows - 1), nch * nslots);
-    if (rows == 8) {
-        if (kp.useQCR) hipLaunchKernelGGL((k_visc_fused<true, 8>), grd, blk, 0, s, tab, nch, kp);
-        else hipLaunchKernelGGL((k_visc_fused<false, 8>), grd, blk, 0, s, tab, nch, kp);
+    const int L = g_march_kch > 0 ? g_march_kch : 32;
+    const int nch = (nz + L - 1) / L, kch = (nz + nch - 1) / nch;
+    const TileGrid tg = tile_grid((nx + GF_OUT - 1) / GF_OUT, (ny + GF_ROWS - 1) / GF_ROWS, nch, nslots, kch);
+    const dim3 grd(tile_grid_size(tg)), blk(64, 4, 1);
+#define GF_LAUNCH(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, nch, kp, tg)
+    if (kp.useQCR) {
+        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, true, false); }
+        else { if (storeGrad) GF_LAUNCH(true, false, true); else GF_LAUNCH(true, false, false); }
     } else {
-        if (kp.useQCR) hipLaunchKernelGGL((k_visc_fused<true, 4>), grd, blk, 0, s, tab, nch, kp);
-        else hipLaunchKernelGGL((k_visc_fused<false, 4>), grd, blk, 0, s, tab, nch, kp);
+        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(false, true, true); else GF_LAUNCH(false, true, false); }
+        else { if (storeGrad) GF_LAUNCH(false, false, true); else GF_LAUNCH(false, false, false); }
     }
+#undef GF_LAUNCH
 }
 
-int g_sa_march = 1;         // tuning "sa_march": 0 = gather kernel, 1 = k-march with 4 rows per workgroup, 2 = with 8 rows (no faster: 0.57 vs 0.54 ms, profiles/r02_l), 3 = 4 rows with the j neighbours through LDS
-int g_grad_sa_fused = 0;    // tuning "grad_sa_fused": SA residual evaluated inside the nodal-gradient march
-
-// nodal gradients + Spalart-Allmaras residual of every block of the level in one launch
-void launch_grad_sa_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
-{
-    LEVEL_SPLIT(nslots, nz + 4, launch_grad_sa_level(tab + s0_, n_, nx, ny, nz, kp, s));
-    if (nslots <= 0) return;
-    const int nzn = nz + 1;
-    int nchn, kch;
-    node_chunks(nzn, &nchn, &kch);
-    const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-    hipLaunchKernelGGL((k_grad_sa_march<true, NG_BY>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
-}
-
-int g_roe_grad_mix = 0;     // tuning "roe_grad_mix": inviscid Roe march and nodal-gradient march in one interleaved launch.  Off since the
-                            // gradient march re-forms its normals from the nodes: the interleaved launch moves 591 B per cell against
-                            // 197 + 254 of the two kernels on separate queues (L2 shared by two access streams) and is 0.07 ms slower
-                            // (profiles/r02_af_variants.txt)
-
-// true when taken: second-order Roe upwind, fw not persistent, viscous part to follow, blocks at rest
-bool launch_roe_grad_mix(const BlkView* tab, const int4* tiles, int ntiles, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
-{
-    if (!g_roe_grad_mix || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid || kp.dissApprox || kp.lumpedDiss || kp.fwMode || ntiles <= 0 || nslots <= 0)
-        return false;
-    if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return false;
-    const int nzn = nz + 1, nchn = (nzn + NG_KCH - 1) / NG_KCH;
-    const int gx = (nx + 1 + NG_OUT - 1) / NG_OUT, gy = (ny + 1 + NG_BY - 1) / NG_BY, nG = gx * gy * nchn * nslots;
-    const dim3 blk(64, 4, 1), grd(ntiles + nG);
-    switch (kp.limiter) {
-    case ADFLOW_LIM_NONE:
-        if (kp.metricFromX & 2) hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_NONE, true>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
-        else hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_NONE, false>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
-        break;
-    case ADFLOW_LIM_VANALBADA:
-        if (kp.metricFromX & 2) hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_VANALBADA, true>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
-        else hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_VANALBADA, false>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
-        break;
-    case ADFLOW_LIM_MINMOD:
-        if (kp.metricFromX & 2) hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_MINMOD, true>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
-        else hipLaunchKernelGGL((k_roe_grad_mix<ADFLOW_LIM_MINMOD, false>), grd, blk, 0, s, tab, tiles, ntiles, kp, g_march_kch, gx, gy, nG, nchn);
-        break;
-    default: return false;
-    }
-    return true;
-}
+int g_sa_march = 1;         // tuning "sa_march": 0 = gather kernel (k_sa_residual), 1 = k-march
 
 // the Spalart-Allmaras residual alone, as a k-march (blocks at rest)
 void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
     LEVEL_SPLIT(nslots, nz + 4, launch_sa_march_level(tab + s0_, n_, nx, ny, nz, kp, s));
     if (nslots <= 0) return;
-    const int nzn = nz + 1;
     int nchn, kch;
-    node_chunks(nzn, &nchn, &kch);
-    const int gx = (nx + 1 + GS_OUT - 1) / GS_OUT;
-    if (g_sa_march == 3) {     // j neighbours through LDS: 287 instead of 349 B per cell from HBM, one barrier per plane, no faster (profiles/r02_x)
-        const TileGrid tg = tile_grid(gx, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-        hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY, true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
-    } else if (g_sa_march < 2) {
-        const TileGrid tg = tile_grid(gx, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-        hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
-    } else {
-        const TileGrid tg = tile_grid(gx, (ny + 1 + 7) / 8, nchn, nslots, kch);
-        hipLaunchKernelGGL((k_grad_sa_march<false, 8>), dim3(tile_grid_size(tg)), dim3(64, 8, 1), 0, s, tab, nchn, kp, tg);
-    }
+    node_chunks(nz + 1, &nchn, &kch);
+    const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
+    hipLaunchKernelGGL((k_sa_march<false>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
 }
 
 // the SA residual with the right-hand side and the central jacobian of saSolve (blocks at rest)
@@ -2362,7 +1513,7 @@ void launch_sa_march_solve_level(const BlkView* tab, int nslots, int nx, int ny,
     int nchn, kch;
     node_chunks(nz + 1, &nchn, &kch);
     const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-    hipLaunchKernelGGL((k_grad_sa_march<false, NG_BY, false, true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
+    hipLaunchKernelGGL((k_sa_march<true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
 }
 
 void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
@@ -2377,28 +1528,6 @@ void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny,
         hipLaunchKernelGGL(k_node_grad_march<true>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
     else
         hipLaunchKernelGGL(k_node_grad_march<false>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
-}
-
-void launch_viscous_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
-{
-    LEVEL_SPLIT(nslots, nz + 4, launch_viscous_level(tab + s0_, n_, nx, ny, nz, kp, s));
-    if (nslots <= 0) return;
-    dim3 blk(VS_BX, VS_BY, 1);
-    const int nzn = nz + 1;                              // node planes 1..kl
-    if (g_viscous_tiled >= 2) {
-        int nchn, kch;
-        node_chunks(nzn, &nchn, &kch);
-        const TileGrid tgn = tile_grid((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-        if (kp.metricFromX & 2)
-            hipLaunchKernelGGL(k_node_grad_march<true>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
-        else
-            hipLaunchKernelGGL(k_node_grad_march<false>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
-    } else
-        hipLaunchKernelGGL(k_nodal_gradients_t, dim3((nx + 1 + VS_BX - 1) / VS_BX, (ny + 1 + VS_BY - 1) / VS_BY, nzn * nslots), blk, 0, s,
-                           tab, nzn);
-    adf_phase_mark(5);
-    const int nch = (nz + VT_KCH - 1) / VT_KCH;
-    hipLaunchKernelGGL(k_viscous_t, dim3((nx + VS_BX - 1) / VS_BX, (ny + VS_BY - 1) / VS_BY, nch * nslots), blk, 0, s, tab, nch, kp);
 }
 
 int viscous_is_tiled() { return g_viscous_tiled; }

@@ -127,10 +127,10 @@ def test_viscous_dominated(engine, eq, qcr):
 
 
 def test_viscous_kernel_variants(engine):
-    """tuning viscous_tiled: 2 = k-marching gradient + face kernels (default), 1 = LDS-tiled pair, 0 = gather pair;
+    """tuning viscous_tiled: 2 = k-marching gradient + face kernels (default), 0 = gather pair;
     roe_march: 0 = per-face reconstruction kernel; partial tiles in i, j and the k chunk; blanked cells"""
     try:
-        for vt in (2, 1, 0):
+        for vt in (2, 0):
             engine.set_tuning("viscous_tiled", vt)
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
             checks.check_block_res(engine, (63, 6, 35), prm, seed=vt, stretch_k=2.0, holes=0.05)
@@ -138,7 +138,7 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("roe_march", 0)
         checks.check_block_res(engine, (63, 6, 9), FlowParams(equations=RANSEquations, spaceDiscr=upwind), seed=3, stretch_k=2.0)
         engine.set_tuning("roe_march", 1)
-        for sm in (3, 2, 0):        # SA march with the j neighbours through LDS, with 8 rows, the gather kernel
+        for sm in (0,):             # the gather kernel instead of the SA march
             engine.set_tuning("sa_march", sm)
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
@@ -158,43 +158,50 @@ def test_viscous_kernel_variants(engine):
             checks.check_block_res(engine, (63, 11, 35), prm, seed=50 + gk, stretch_k=2.0, holes=0.05)
         engine.set_tuning("xcd_tiles", 1)
         engine.set_tuning("grad_kch", 32)
-        for mx in (0, 1, 15):       # face normals from the arrays everywhere / re-formed from the nodes in the SA march only / in
-                                    # every march incl. the Roe one (bit 3); the default 7 = SA + gradient marches + time step
+        for mx in (0, 1):           # face normals from the arrays everywhere / re-formed from the nodes in the SA march only;
+                                    # the default 7 = SA + gradient marches + time step
             engine.set_tuning("metric_from_x", mx)
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=20 + mx, stretch_k=2.0, holes=0.05)
-            if mx == 15:
-                for lim in (noLimiter, vanAlbeda, minmod):
-                    checks.check_block_res(engine, (61, 6, 5), FlowParams(equations=EulerEquations, spaceDiscr=upwind, limiter=lim), seed=40 + lim)
-            engine.set_tuning("roe_grad_mix", 1)      # Roe march and gradient march as one interleaved launch
-            checks.check_block_res(engine, (23, 9, 7), prm, seed=30 + mx, stretch_k=2.0)
-            engine.set_tuning("roe_grad_mix", 0)
     finally:
         engine.set_tuning("viscous_tiled", 2)
         engine.set_tuning("roe_march", 1)
         engine.set_tuning("sa_march", 1)
         engine.set_tuning("metric_from_x", 7)
-        engine.set_tuning("roe_grad_mix", 0)
         engine.set_tuning("xcd_tiles", 1)
         engine.set_tuning("grad_kch", 32)
         engine.set_tuning("visc_first", 7)
 
 
-def test_visc_wave_specialised(engine):
-    """tuning visc_ws: nodal gradients (gradient waves) and viscous fluxes (face waves) in one workgroup, the gradients stay in an
-    LDS ring.  Partial tiles in i / j / the k chunk, blanked cells, QCR, laminar NS, the stored-gradient variant (wall stress)."""
+def test_visc_gradient_fused(engine):
+    """k_visc_gf (tuning visc_gf, default 1): nodal gradients and viscous fluxes in one kernel, the gradients stay in an LDS ring.
+    Partial tiles in i (60 columns) / j (3 rows) / the k chunk, blanked cells, QCR, laminar NS, matrix / scalar dissipation (the
+    kernel completing dw instead of handing its sums to the inviscid march), persistent fw of the RK stages, the stored-gradient
+    variant (wall stress, updateIntermed); visc_gf = 0: the separate gradient + face marches."""
     try:
-        engine.set_tuning("visc_ws", 1)
-        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
-        checks.check_block_res(engine, (63, 6, 35), prm, seed=5, stretch_k=2.0, holes=0.05)
-        checks.check_block_res(engine, (61, 9, 33), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
-        checks.check_block_res(engine, (7, 5, 3), FlowParams(equations=NSEquations), seed=7, stretch_k=2.0)
-        checks.check_block_res(engine, (124, 13, 5), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix), seed=8, stretch_k=2.0)
-        checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations), stretch_k=2.0)
-        checks.check_wall_stress(engine, (9, 8, 7), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -3, 4: -4, 5: -3, 6: -6},
-                                 stretch_k=2.0)
+        for gf in (1, 0):
+            engine.set_tuning("visc_gf", gf)
+            prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
+            checks.check_block_res(engine, (63, 7, 35), prm, seed=5, stretch_k=2.0, holes=0.05)
+            checks.check_block_res(engine, (61, 9, 33), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
+            checks.check_block_res(engine, (7, 5, 3), FlowParams(equations=NSEquations), seed=7, stretch_k=2.0)
+            checks.check_block_res(engine, (124, 13, 5), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, muSuthDim=1.0), seed=8, stretch_k=2.0)
+            checks.check_block_res(engine, (1, 1, 1), FlowParams(equations=NSEquations, muSuthDim=1.0), seed=9)
+            checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations, muSuthDim=1.0), stretch_k=2.0)
+            checks.check_wall_stress(engine, (9, 8, 7), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -3, 4: -4, 5: -3, 6: -6},
+                                     stretch_k=2.0)
+            for vf in (0, 7):
+                engine.set_tuning("visc_first", vf)
+                checks.check_block_res(engine, (24, 10, 8), FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0), seed=vf,
+                                       stretch_k=2.0)
+            engine.set_tuning("visc_first", 7)
+            engine.set_tuning("march_kch", 5)
+            checks.check_block_res(engine, (20, 4, 13), prm, seed=11, stretch_k=2.0)
+            engine.set_tuning("march_kch", 32)
     finally:
-        engine.set_tuning("visc_ws", 0)
+        engine.set_tuning("visc_gf", 1)
+        engine.set_tuning("visc_first", 7)
+        engine.set_tuning("march_kch", 32)
 
 
 def test_block_res_without_intermediates(engine):

@@ -361,9 +361,9 @@ def test_viscous_kernel_variants(hostsim_engine):
         else test_gpu_rans.test_viscous_kernel_variants(hostsim_engine)
 
 
-def test_visc_wave_specialised(hostsim_engine):
+def test_visc_gradient_fused(hostsim_engine):
     import test_gpu_rans
-    test_gpu_rans.test_visc_wave_specialised(hostsim_engine)
+    test_gpu_rans.test_visc_gradient_fused(hostsim_engine)
 
 
 def test_block_res_without_intermediates(hostsim_engine):

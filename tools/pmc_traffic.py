@@ -16,7 +16,7 @@ import sqlite3
 import sys
 
 PHASE_OF = [("k_roe_march", "inviscid"), ("k_inviscid_march", "inviscid"), ("k_inviscid<", "inviscid"), ("k_euler_march", "inviscid"),
-            ("k_sa_residual", "SA residual"), ("k_grad_sa_march<false", "SA residual"), ("k_grad_sa_march<true", "nodal gradients"), ("k_roe_grad_mix", "inviscid + nodal gradients (one launch)"), ("k_nodal_gradients", "nodal gradients"), ("k_node_grad", "nodal gradients"),
+            ("k_sa_residual", "SA residual"), ("k_sa_march", "SA residual"), ("k_visc_gf", "nodal gradients + viscous (fused)"), ("k_nodal_gradients", "nodal gradients"), ("k_node_grad", "nodal gradients"),
             ("k_viscous", "viscous"), ("k_visc_march", "viscous"), ("k_time_step", "time step"), ("k_halo_copy", "halo copies"), ("k_entropy", "entropy sensor")]
 
 
