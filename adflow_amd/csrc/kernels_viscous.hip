@@ -1093,25 +1093,31 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
 }
 
 // ---------------------------------------------------------------------------
-// FUSED nodal gradients + viscous fluxes, two workgroups per CU (tuning "visc_gf", default on).  k_node_grad_march and k_visc_march
+// FUSED nodal gradients + viscous fluxes, two workgroups per CU (tuning "visc_gf").  k_node_grad_march and k_visc_march
 // exchange the 12 nodal gradients through HBM (103 B per cell written, 125 B read back) and both read the state and the face
 // normals: 194 + 427 B per cell by the counters, 0.45 + 0.84 ms.  Here ONE workgroup of four waves marches in k and keeps the
 // gradients in LDS:
 //   * wave r owns node row jn = j0-1+r of the tile: per plane it loads the raw values of the cell rows jn and jn+1 (no record
 //     exchange between waves), forms the gradient of its node (i, jn, m-1) from the cell planes m-1 (carried) and m with the
-//     factorised surface integral of k_node_grad_march, and writes it to a THREE-slot LDS ring (72 KB): one barrier per plane,
-//     no second one, because the slot written in step m+1 was last read in step m-1;
-//   * waves 1..3 then evaluate the four faces of cell (i, jn, m-1) (k face carried, i face once with DPP hand-over, both j
-//     faces) from node planes m-2 and m-1 in the ring with vm_face, the arithmetic of k_visc_march; the cell states of the two
-//     planes and of the row above are the values the gradient part holds anyway, the row below is a plain load;
-//   * 3 of 4 rows and 60 of 64 columns produce output; LDS 73.7 KB and <= 256 VGPRs leave two workgroups per CU, which run out
-//     of phase and hide each other's load latency (the single-workgroup fusions of round 2 ran eight waves in barrier lockstep).
+//     factorised surface integral of k_node_grad_march, and writes it to a THREE-slot LDS ring: one barrier per plane, no
+//     second one, because the slot written in step m+1 was last read in step m-1;
+//   * with exactly the two cell rows it holds a wave can evaluate the i face and the k face of cell (i, jn, m-1) and the j face
+//     ABOVE it, (jn | jn+1): three face evaluations per cell (3.25 with the tile-edge row of wave 0, which evaluates its upper
+//     j face only), no state of a third row.  The flux through the j face BELOW the cell comes from wave r-1 through a
+//     double-buffered LDS slot one step later (the barrier of the next plane orders it): a cell's sum is completed and stored
+//     one plane behind its own faces;
+//   * ring entries are [slot][node row][lane 1..61][12 components] (16-byte LDS accesses); ring 70 272 B + hand-over 11 520 B =
+//     81 792 B: two workgroups per CU, which run out of phase and hide each other's load latency (the single-workgroup
+//     fusions of round 2 ran eight waves in barrier lockstep).  3 of 4 rows and 60 of 64 columns produce output.
 // Reference: flowUtils.F90:1676-2026 (allNodalGradients), fluxes.F90:2534-3485 (viscousFlux), residuals.F90:334-344.
-// STG: the gradients are also stored to b.grad (updateIntermed copy-out).  FIRST: as k_visc_march.
+// STG: the gradients are also stored to b.grad (updateIntermed copy-out, wall stress).  FIRST: as k_visc_march.
 // ---------------------------------------------------------------------------
 #define GF_OUT 60
 #define GF_ROWS 3
-#define GF_G (12 * 64)
+#define GF_NL 61                  // node columns kept per row: lanes 1..61
+#define GF_G (12 * GF_NL)         // doubles of one node row of one plane
+#define GF_RING (3 * 4 * GF_G)
+#define GF_FJ (3 * GF_OUT * 4)    // doubles of one parity of the j-flux hand-over: rows 0..2, lanes 2..61, 4 components
 
 struct GfPtrs {
     GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) p;
@@ -1137,10 +1143,15 @@ __device__ __forceinline__ GfRaw gf_ld(const GfPtrs& m, unsigned o, double gam, 
 // metric sums of one cell plane around the node column of the thread (the t-part of NgPlane)
 struct GfMet { double Pt[3], Q0t[3], Q1t[3], RIt[3], V; };
 
+// two doubles moved as one 16-byte LDS access
+struct __attribute__((aligned(16))) Dbl2 { double x, y; };
+__device__ __forceinline__ Dbl2 mk2(double x, double y) { Dbl2 v; v.x = x; v.y = y; return v; }
+
 template <bool QCR, bool FIRST, bool STG>
 __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
 {
-    __shared__ double ring[3 * 4 * GF_G];         // [slot][node row 0..3 = rows j0-1 .. j0+2][component][lane]
+    __shared__ __attribute__((aligned(16))) double ring[GF_RING];   // [slot][node row 0..3 = rows j0-1 .. j0+2][lane-1][component]
+    __shared__ __attribute__((aligned(16))) double fjx[2 * GF_FJ];  // [parity][row][lane-2][component]
     int bx, by, bz;
     if (!tile_of_workgroup(tg, bx, by, bz)) return;
     const BlkView& b = tab[bz / nzb + 1];
@@ -1155,6 +1166,9 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
     const int jA = (jn < b.jb) ? jn : b.jb, jB = (jn + 1 < b.jb) ? jn + 1 : b.jb;
     const bool outC = (r >= 1 && lane >= 2 && lane <= 61 && i <= b.il && jn <= b.jl);
     const bool outN = (lane >= 1 && lane <= 61 && i <= b.il && jn <= b.jl);
+    const bool ringLane = (lane >= 1 && lane <= GF_NL);
+    const int nl = ringLane ? lane - 1 : 0;       // ring column of the thread (clamped: the lanes outside read entry 0 and drop it)
+    const int fl = (lane >= 2 && lane <= 61) ? lane - 2 : 0;
     const long nb = b.nbox;
     const unsigned nb8 = 8u * (unsigned)nb, sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
     GfPtrs m;
@@ -1177,22 +1191,51 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
     unsigned cA = 8u * (unsigned)(ic + jA * b.ldi + (k0 - 1) * b.ldk);
     const unsigned dB = 8u * (unsigned)((jB - jA) * b.ldi);          // row jn+1 relative to row jn (0 at the upper end of the box)
     const unsigned dM = (jA >= 1) ? sj : 0u;                          // row jn-1
-    // carried: state of the rows jn, jn+1 at the previous plane, metric sums of that plane, sK of that plane, the k-face flux
+    // carried: state of the rows jn, jn+1 at the previous plane, metric sums and normals of that plane, the k-face flux, the own
+    // part of the flux sum of the plane before
     VmCell qA, qB;
     GfMet S;
-    double sKA[3], sKB[3], fk[4];
+    double sKA[3], sKB[3], fk[4], pend[4];
+    int flagP = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { sKA[d] = ldg(m.sK, cA - sk + d * nb8); sKB[d] = ldg(m.sK, cA + dB - sk + d * nb8); }
 #pragma unroll
-    for (int l = 0; l < 4; ++l) fk[l] = 0.0;
+    for (int l = 0; l < 4; ++l) { fk[l] = 0.0; pend[l] = 0.0; }
     qA.u = qA.v = qA.w = qA.na = qA.rlv = qA.rev = 0.0;
     qB = qA;
+    S.V = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) S.Pt[d] = S.Q0t[d] = S.Q1t[d] = S.RIt[d] = 0.0;
+    // completes the flux sum of cell plane kc (byte offset c) with the j flux handed over by the wave below and stores it
+    auto finish = [&](unsigned c, const double* __restrict__ fjr, int flg) {
+        const Dbl2 f01 = *reinterpret_cast<const Dbl2*>(fjr), f23 = *reinterpret_cast<const Dbl2*>(fjr + 2);
+        const double fl4[4] = {f01.x, f01.y, f23.x, f23.y};
+        if (!outC) return;
+        const double blank = flg_blank((uint8_t)flg);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const unsigned o = c + (l + 1) * nb8;
+            double fwn = pend[l] + fl4[l];
+            if (FIRST) { stg(dw, o, fwn); continue; }
+            if (kp.fwMode) {
+                fwn += ldg(fw, o);
+                stg(fw, o, fwn);
+            }
+            stg(dw, o, (ldg(dw, o) + fwn) * blank);
+        }
+        if (!FIRST && kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
+    };
     for (int mm = k0 - 1; mm <= k1 + 1; ++mm) {
-        // ---- cell plane mm of the rows jn and jn+1: state, normals, volume
+        // ---- cell plane mm of the rows jn and jn+1: state, normals, volume; centre-to-centre vectors and flags of plane mm-1
         const GfRaw a = gf_ld(m, cA, gam, K.eddy), bq = gf_ld(m, cA + dB, gam, K.eddy);
         double aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3];
         vm_ld3(m.sI, cA, nb8, aI); vm_ld3(m.sJ, cA - dM, nb8, aJm); vm_ld3(m.sJ, cA, nb8, aJ); vm_ld3(m.sK, cA, nb8, aK);
         vm_ld3(m.sI, cA + dB, nb8, bI); vm_ld3(m.sJ, cA + dB, nb8, bJ); vm_ld3(m.sK, cA + dB, nb8, bK);
+        const unsigned cF = cA - sk;
+        const bool facePlane = (mm >= k0);
+        const bool full = (mm > k0);                           // all faces (first step of the march: the k face below plane k0 only)
+        double dIv[3], dJv[3], dKv[3], sIA[3], sJA[3];
+        int flag0 = 0;
         // ---- metric sums of this plane (ng_finish for both rows; the row above takes sJ(j-1) from the own row)
         GfMet N;
         {
@@ -1253,103 +1296,100 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
             for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
             ng_outer(g, +1.0, ph1, t1);
             const double oneOverV = rcp_nr(S.V + N.V);
-            double* __restrict__ xo = ring + (((mm - k0) % 3) * 4 + r) * GF_G + lane;        // node plane mm-1 -> slot (mm-k0) % 3
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                g[q] *= oneOverV;
-                xo[q * 64] = g[q];
+            for (int q = 0; q < 12; ++q) g[q] *= oneOverV;
+            if (ringLane) {
+                double* __restrict__ xo = ring + (((mm - k0) % 3) * 4 + r) * GF_G + nl * 12;     // node plane mm-1 -> slot (mm-k0) % 3
+#pragma unroll
+                for (int q = 0; q < 12; q += 2) *reinterpret_cast<Dbl2*>(xo + q) = mk2(g[q], g[q + 1]);
             }
             if (STG && outN) {
 #pragma unroll
-                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cA - sk, g[q]);
+                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cF, g[q]);
             }
         }
-        // ---- loads of the face part (cell plane mm-1), requested above the barrier
-        const unsigned cF = cA - sk;
-        const bool facePlane = (r >= 1 && mm >= k0);           // uniform per wave
-        const bool full = (mm > k0);                           // all faces (first step of the march: the k face below plane k0 only)
-        VmCell qjm;
-        double nI[3], dIv[3], nJ[3], dJv[3], nJm[3], dJm[3], dKv[3];
-        int flag0 = 0, flagM = 0;
+        // ---- loads of the face part (cell plane mm-1), requested above the barrier; sI / sJ of that plane again (carried they spill)
         if (facePlane) {
-            vm_ld3(dK, cF, nb8, dKv);
+            if (r >= 1) vm_ld3(dK, cF, nb8, dKv);
             flag0 = flags[cF >> 3];
             if (full) {
-                qjm = gf_ld(m, cF - dM, gam, K.eddy).q;
-                vm_ld3(m.sI, cF, nb8, nI); vm_ld3(dI, cF, nb8, dIv);
-                vm_ld3(m.sJ, cF, nb8, nJ); vm_ld3(dJ, cF, nb8, dJv);
-                vm_ld3(m.sJ, cF - dM, nb8, nJm); vm_ld3(dJ, cF - dM, nb8, dJm);
-                flagM = flags[(cF - dM) >> 3];
+                if (r >= 1) vm_ld3(dI, cF, nb8, dIv);
+                vm_ld3(dJ, cF, nb8, dJv);
+                if (r >= 1) vm_ld3(m.sI, cF, nb8, sIA);
+                vm_ld3(m.sJ, cF, nb8, sJA);
             }
         }
         __syncthreads();
         if (facePlane) {
-            const double* __restrict__ xb = ring + (((mm - k0) % 3) * 4) * GF_G;            // node plane mm-1
-            const double* __restrict__ xp = ring + (((mm - k0 + 2) % 3) * 4) * GF_G;        // node plane mm-2
-            const int oM = (r - 1) * GF_G + lane, o0 = r * GF_G + lane;                     // node rows jn-1 and jn
-            double acc[4];
+            const double* __restrict__ xb = ring + (((mm - k0) % 3) * 4) * GF_G + nl * 12;            // node plane mm-1
+            const double* __restrict__ xp = ring + (((mm - k0 + 2) % 3) * 4) * GF_G + nl * 12;        // node plane mm-2
+            const int oM = (r >= 1 ? r - 1 : 0) * GF_G, o0 = r * GF_G;                                // node rows jn-1 and jn
+            if (full && r >= 1 && mm - 2 >= k0) {
+                // cell plane mm-2: the j flux from the wave below has arrived (written in step mm-1)
+                finish(cF - sk, fjx + ((mm - 1) & 1) * GF_FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
+            }
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
             if (full) {
-                // ---- j face (jn-1 | jn): nodes (i-1..i, jn-1, mm-2..mm-1)
-                {
-                    double gs[12], f[4];
+                // ---- j face (jn | jn+1): nodes (i-1..i, jn, mm-2..mm-1); handed to the wave above
+                double gs[12], f[4];
 #pragma unroll
-                    for (int q = 0; q < 12; ++q) { const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
-                    vm_face<QCR>(K, gs, qjm, qA, nJm, dJm, flg_porJ((uint8_t)flagM), f);
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) acc[l] = fk[l] + f[l];
+                for (int q = 0; q < 12; q += 2) {
+                    const Dbl2 u = *reinterpret_cast<const Dbl2*>(xp + o0 + q), v = *reinterpret_cast<const Dbl2*>(xb + o0 + q);
+                    const double s0 = u.x + v.x, s1 = u.y + v.y;
+                    gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                 }
-                // ---- i face (i | i+1): nodes (i, jn-1..jn, mm-2..mm-1); the face (i-1 | i) comes from lane-1
-                {
+                vm_face<QCR>(K, gs, qA, qB, sJA, dJv, flg_porJ((uint8_t)flag0), f);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) acc[l] = -f[l];
+                if (r < 3 && lane >= 2 && lane <= 61) {
+                    double* __restrict__ fo = fjx + (mm & 1) * GF_FJ + (r * GF_OUT + fl) * 4;
+                    *reinterpret_cast<Dbl2*>(fo) = mk2(f[0], f[1]);
+                    *reinterpret_cast<Dbl2*>(fo + 2) = mk2(f[2], f[3]);
+                }
+            }
+            if (r >= 1) {
+                if (full) {
+                    // ---- i face (i | i+1): nodes (i, jn-1..jn, mm-2..mm-1); the face (i-1 | i) comes from lane-1
                     double gs[12], f[4];
 #pragma unroll
-                    for (int q = 0; q < 12; ++q) gs[q] = (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
+                    for (int q = 0; q < 12; q += 2) {
+                        const Dbl2 u = *reinterpret_cast<const Dbl2*>(xp + oM + q), v = *reinterpret_cast<const Dbl2*>(xp + o0 + q);
+                        const Dbl2 w = *reinterpret_cast<const Dbl2*>(xb + oM + q), z = *reinterpret_cast<const Dbl2*>(xb + o0 + q);
+                        gs[q] = (u.x + v.x) + (w.x + z.x); gs[q + 1] = (u.y + v.y) + (w.y + z.y);
+                    }
                     const VmCell qR = vm_dn1(qA);
-                    vm_face<QCR>(K, gs, qA, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
+                    vm_face<QCR>(K, gs, qA, qR, sIA, dIv, flg_porI((uint8_t)flag0), f);
 #pragma unroll
                     for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
                 }
-                // ---- j face (jn | jn+1): nodes (i-1..i, jn, mm-2..mm-1)
+                // ---- k face above cell plane mm-1: nodes (i-1..i, jn-1..jn, mm-1); sKA still holds sK of plane mm-1
                 {
                     double gs[12], f[4];
 #pragma unroll
-                    for (int q = 0; q < 12; ++q) { const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
-                    vm_face<QCR>(K, gs, qA, qB, nJ, dJv, flg_porJ((uint8_t)flag0), f);
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) acc[l] -= f[l];
-                }
-            }
-            // ---- k face above cell plane mm-1: nodes (i-1..i, jn-1..jn, mm-1); sKA still holds sK of plane mm-1
-            {
-                double gs[12], f[4];
-#pragma unroll
-                for (int q = 0; q < 12; ++q) { const double s = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
-                vm_face<QCR>(K, gs, qA, a.q, sKA, dKv, flg_porK((uint8_t)flag0), f);
-#pragma unroll
-                for (int l = 0; l < 4; ++l) { if (full) acc[l] -= f[l]; fk[l] = f[l]; }
-            }
-            if (full && outC) {
-                const double blank = flg_blank((uint8_t)flag0);
-#pragma unroll
-                for (int l = 0; l < 4; ++l) {
-                    const unsigned o = cF + (l + 1) * nb8;
-                    double fwn = acc[l];
-                    if (FIRST) { stg(dw, o, fwn); continue; }
-                    if (kp.fwMode) {
-                        fwn += ldg(fw, o);
-                        stg(fw, o, fwn);
+                    for (int q = 0; q < 12; q += 2) {
+                        const Dbl2 w = *reinterpret_cast<const Dbl2*>(xb + oM + q), z = *reinterpret_cast<const Dbl2*>(xb + o0 + q);
+                        const double s0 = w.x + z.x, s1 = w.y + z.y;
+                        gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                     }
-                    stg(dw, o, (ldg(dw, o) + fwn) * blank);
+                    vm_face<QCR>(K, gs, qA, a.q, sKA, dKv, flg_porK((uint8_t)flag0), f);
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) { pend[l] = (acc[l] + fk[l]) - f[l]; fk[l] = f[l]; }
                 }
-                if (!FIRST && kp.fwMode) stg(dw, cF, (ldg(dw, cF) + ldg(fw, cF)) * blank);    // the density residual has no viscous part
+                flagP = flag0;
             }
         }
         // ---- advance
         qA = a.q; qB = bq.q;
         S = N;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { sKA[d] = aK[d]; sKB[d] = bK[d]; }
+        for (int d = 0; d < 3; ++d) {
+            sKA[d] = aK[d]; sKB[d] = bK[d];
+        }
         cA += sk;
     }
+    // ---- the last plane of the chunk: its j flux was handed over in the last step
+    __syncthreads();
+    if (r >= 1 && k1 >= k0) finish(cA - 2 * sk, fjx + ((k1 + 1) & 1) * GF_FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
 }
 
 // ---------------------------------------------------------------------------
