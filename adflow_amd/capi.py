@@ -36,6 +36,7 @@ class AdflowOpts(ctypes.Structure):
         ("viscWallBCTreatment", c_int32),
         ("outflowTreatment", c_int32),
         ("hScalingInlet", c_int32), ("unsupported", c_int32), ("lowSpeedPreconditioner", c_int32),
+        ("exchangePressureEarly", c_int32), ("reserved_i", c_int32),
         ("gammaConstant", c_double), ("prandtl", c_double), ("prandtlTurb", c_double),
         ("SSuthDim", c_double), ("muSuthDim", c_double), ("TSuthDim", c_double),
         ("SAKappa", c_double), ("SAcb1", c_double), ("SAcb2", c_double), ("SAsigma", c_double), ("SAcv1", c_double),

@@ -124,6 +124,9 @@ std::map<std::pair<int, int>, CommPattern> g_comm;   // (level, nLayers)
 std::map<int, BlkView*> g_tab;                        // level -> device table indexed by nn
 std::map<int, int> g_tab_size;
 std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
+std::map<int, std::pair<int4*, int>> g_gf_tiles;       // level -> round-fitted chunk table of k_visc_gf
+int g_gf_fit = 1;           // tuning "gf_fit": k chunks of k_visc_gf fitted to whole rounds of resident workgroups (0: chunks of march_kch planes)
+int g_num_cus = 0;
 int g_skip_unused_radii = 1;                             // tuning "skip_unused_radii"
 int g_phase_base = 0;                                    // tuning "phase_events": first of 8 event slots, 0 = off
 bool g_use_march = true;                               // tuning: adflow_gpu_set_tuning("euler_march", 0|1)
@@ -169,6 +172,11 @@ void invalidate_comm_level(int level)
         (void)hipFree(jt->second.first);
         g_tiles.erase(jt);
     }
+    jt = g_gf_tiles.find(level);
+    if (jt != g_gf_tiles.end()) {
+        (void)hipFree(jt->second.first);
+        g_gf_tiles.erase(jt);
+    }
 }
 
 
@@ -178,6 +186,7 @@ int time_step_level(int level, const KParams& kp);
 struct LevelTab { const BlkView* tab; int n, nx, ny, nz; };
 int level_tab(int level, LevelTab* t);
 int ensure_tiles(int level);
+int ensure_gf_tiles(int level);
 int make_list(int level, const int32_t* blk, const int32_t* idx, int ld, int first, int n, int** d_blk, long** d_off);
 
 Block* find_block(int nn, int level, int sps)
@@ -1063,7 +1072,8 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
             if (g_visc_gf) {
                 // gradients and face fluxes in one kernel: the gradients stay in LDS (and go to HBM only when a caller reads them)
                 phase_mark(4);
-                launch_visc_gf_level(t.tab, t.n, t.nx, t.ny, t.nz, kv, needGrad, g_stream);
+                if (ensure_gf_tiles(level)) return 1;
+                launch_visc_gf(g_tab[level], g_gf_tiles[level].first, g_gf_tiles[level].second, kv, needGrad, g_stream);
             } else {
                 launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kv, g_stream);
                 phase_mark(4);
@@ -1076,7 +1086,8 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         }
         if (g_visc_gf) {
             phase_mark(5);
-            launch_visc_gf_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, needGrad, g_stream);
+            if (ensure_gf_tiles(level)) return 1;
+            launch_visc_gf(g_tab[level], g_gf_tiles[level].first, g_gf_tiles[level].second, kp, needGrad, g_stream);
             return 0;
         }
         hipStream_t sg = gradForked ? g_streamC : g_stream;
@@ -1116,6 +1127,7 @@ static int turb_bc_apply_enqueue(int level, const KParams& kp, int secondHalo);
 static int bc_coarse_corrections_enqueue(int coarseLevel, double fact);
 static void bc_plan_drop(int level);
 static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers);
+static int early_pressure_exchange_enqueue(int level);
 
 static int block_res_enqueue(int level, unsigned flags)
 {
@@ -1629,6 +1641,128 @@ int ensure_tiles(int level)
     HIPCHK(hipMalloc((void**)&d, sizeof(int4) * phys.size()));
     HIPCHK(hipMemcpy(d, phys.data(), sizeof(int4) * phys.size(), hipMemcpyHostToDevice));
     g_tiles[level] = std::make_pair(d, (int)phys.size());
+    return 0;
+}
+
+// Chunk table of the fused gradient + viscous march (k_visc_gf).  A column = (block, 60-column tile, 3-row tile); every column is cut
+// into chunks of k planes, one workgroup per chunk, and a workgroup costs (planes + ~1.5 warm-up planes).  The device keeps
+// W = 2 x CUs workgroups of this kernel resident and dispatches them in launch order, so the launch runs in "rounds" of W workgroups
+// of about equal duration: with N columns x c chunks just above a multiple of W the last round is almost empty (north-star mesh:
+// 1032 columns x 2 chunks = 4.03 rounds = the time of 5).  Here the NUMBER of chunks is chosen as a whole number of rounds, columns
+// get c or c+1 chunks, the chunks are launched longest first (every round holds chunks of one length), and within a round
+// workgroup p = 8 s + x takes the x-th contiguous eighth of the round's chunks, so that XCD x (which receives the workgroups
+// p % 8 == x) works on neighbouring tiles.  Entry: x = block slot (-1: empty), y = bx | by << 16, z = first plane, w = last plane.
+int ensure_gf_tiles(int level)
+{
+    if (g_gf_tiles.count(level)) return 0;
+    if (ensure_table(level)) return 1;
+    struct Col { int slot, bx, by, nz; };
+    std::vector<Col> cols;
+    long planes = 0;
+    for (auto& kv : g_blocks) {
+        if (std::get<0>(kv.first) != level || std::get<1>(kv.first) != 1) continue;
+        const BlkView& v = kv.second->v;
+        const int gx = (v.nx + 59) / 60, gy = (v.ny + 2) / 3;
+        for (int by = 0; by < gy; ++by)
+            for (int bx = 0; bx < gx; ++bx) { cols.push_back(Col{std::get<2>(kv.first), bx, by, v.nz}); planes += v.nz; }
+    }
+    const int N = (int)cols.size();
+    if (N == 0) { g_gf_tiles[level] = std::make_pair((int4*)nullptr, 0); return 0; }
+    if (g_num_cus <= 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, g_device) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    const int W = 2 * g_num_cus;
+    const double warm = 1.5;
+    const int kmin = 8;
+    // chunks of a column for a total of T chunks: proportional to its planes (largest remainder), at least 1, at most nz / kmin
+    auto split = [&](long T, std::vector<int>& c) {
+        c.assign(N, 1);
+        long used = 0;
+        std::vector<std::pair<double, int>> rem(N);
+        for (int q = 0; q < N; ++q) {
+            const double want = (double)T * cols[q].nz / (double)planes;
+            const int cmax = std::max(1, cols[q].nz / kmin);
+            c[q] = std::min(cmax, std::max(1, (int)want));
+            rem[q] = std::make_pair(want - c[q], q);
+            used += c[q];
+        }
+        std::sort(rem.begin(), rem.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+        for (int q = 0; q < N && used < T; ++q) {
+            const int id = rem[q].second;
+            if (c[id] < std::max(1, cols[id].nz / kmin)) { ++c[id]; ++used; }
+        }
+    };
+    auto makespan = [&](const std::vector<int>& c) {
+        std::vector<int> len;
+        for (int q = 0; q < N; ++q)
+            for (int e = 0; e < c[q]; ++e) len.push_back((cols[q].nz + c[q] - 1 - e) / c[q]);
+        std::sort(len.begin(), len.end(), [](int a, int b) { return a > b; });
+        double t = 0.0;
+        for (size_t q = 0; q < len.size(); q += W) t += len[q] + warm;
+        return t;
+    };
+    std::vector<int> best;
+    if (g_gf_fit) {
+        double tbest = 1.e300;
+        const long Tmax = std::max<long>(N, planes / kmin);
+        for (long m = 1; m * W <= Tmax + W; ++m) {
+            std::vector<int> c;
+            split(m * W, c);
+            const double t = makespan(c);
+            if (t < tbest - 1.e-9) { tbest = t; best = c; }
+            if (m > 64) break;
+        }
+        // a level much smaller than the device: one chunk per column unless splitting fills more of it
+        std::vector<int> one(N, 1);
+        if (makespan(one) < tbest) best = one;
+    } else {
+        best.resize(N);
+        const int L = g_march_kch > 0 ? g_march_kch : 32;
+        for (int q = 0; q < N; ++q) best[q] = (cols[q].nz + L - 1) / L;
+    }
+    struct Chunk { int col, k0, k1; };
+    std::vector<Chunk> ch;
+    for (int q = 0; q < N; ++q) {
+        int k = 2;
+        for (int e = 0; e < best[q]; ++e) {
+            const int len = (cols[q].nz + best[q] - 1 - e) / best[q];
+            if (len <= 0) continue;
+            ch.push_back(Chunk{q, k, k + len - 1});
+            k += len;
+        }
+    }
+    // longest first; chunks of one length in (block, k, row tile, column tile) order
+    std::stable_sort(ch.begin(), ch.end(), [&](const Chunk& a, const Chunk& b) {
+        const int la = a.k1 - a.k0, lb = b.k1 - b.k0;
+        if (la != lb) return la > lb;
+        if (cols[a.col].slot != cols[b.col].slot) return cols[a.col].slot < cols[b.col].slot;
+        if (a.k0 != b.k0) return a.k0 < b.k0;
+        return a.col < b.col;
+    });
+    const int T = (int)ch.size();
+    const int rounds = (T + W - 1) / W;
+    std::vector<int4> phys((size_t)rounds * W);
+    for (int p = 0; p < rounds * W; ++p) {
+        const int q = p / W, s = (p % W) / 8, x = (p % W) % 8;      // (W is a multiple of 8 on the device: x = the XCD of workgroup p)
+        const int nIn = std::min(W, T - q * W);             // chunks of this round
+        const int per = (nIn + 7) / 8;
+        const int e = (s < per && x * per + s < nIn) ? q * W + x * per + s : -1;
+        int4 t;
+        if (e >= 0) {
+            const Col& c = cols[ch[e].col];
+            t.x = c.slot; t.y = c.bx | (c.by << 16); t.z = ch[e].k0; t.w = ch[e].k1;
+        } else { t.x = -1; t.y = t.z = t.w = 0; }
+        phys[p] = t;
+    }
+    // trailing empty entries are not launched
+    int n = (int)phys.size();
+    while (n > 0 && phys[n - 1].x < 0) --n;
+    int4* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(int4) * std::max(n, 1)));
+    HIPCHK(hipMemcpy(d, phys.data(), sizeof(int4) * n, hipMemcpyHostToDevice));
+    g_gf_tiles[level] = std::make_pair(d, n);
     return 0;
 }
 
@@ -2243,6 +2377,18 @@ int adflow_gpu_halo_unpack(int level, int nLayers, int islot, int varStart, int 
 
 static int comm_exchange_enqueue(CommPattern* cp, BlkView* tab, unsigned mask, int nvar);
 
+// exchangePressureEarly (smoothers.F90:363-365, 674-676, multiGrid.F90:602-604): with the normal-momentum treatment of inviscid
+// walls bcEulerWall reads the pressure of the first halo layer of the neighbouring blocks, so the reference exchanges the pressure
+// alone -- whalo1(currentLevel, 1, 0, .true., .false., .false.) -- BEFORE applyAllBC, on the fine grid only
+static int early_pressure_exchange_enqueue(int level)
+{
+    if (!g_opts.exchangePressureEarly || level > g_opts.groundLevel) return 0;
+    if (!g_comm.count(std::make_pair(level, 1)))
+        return fail("exchangePressureEarly: the 1-layer cell pattern of level %d (commPatternCell_1st / internalCell_1st) is not registered",
+                    level);
+    return halo_exchange_enqueue(level, 1, 0, 1, 0, 1);
+}
+
 static int halo_exchange_enqueue(int level, int varStart, int varEnd, int commPressure, int commVisc, int nLayers)
 {
     CommPattern* cp;
@@ -2368,6 +2514,7 @@ static int finish_stage(int level, const KParams& kp, double scale, int fromWn)
     });
     if (rc) return rc;
     const int secondHalo = (level <= g_opts.groundLevel);
+    if (early_pressure_exchange_enqueue(level)) return 1;
     if (apply_bc_enqueue(level, secondHalo)) return 1;
     if (g_bc_callback) {
         HIPCHK(hipStreamSynchronize(g_stream));
@@ -2522,6 +2669,7 @@ static int transfer_to_fine_enqueue(int level)
     if (bc_coarse_corrections_enqueue(level + 1, 0.0)) return 1;
     launch_prolong_update_level(tf.tab, tc.tab, tc.n, tf.nx, tf.ny, tf.nz, kf, g_stream);
     const int secondHalo = (level <= g_opts.groundLevel);
+    if (early_pressure_exchange_enqueue(level)) return 1;          // multiGrid.F90:602-604
     if (apply_bc_enqueue(level, secondHalo)) return 1;
     if (g_bc_callback) {
         HIPCHK(hipStreamSynchronize(g_stream));
@@ -2873,6 +3021,16 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_march_kch = value;
         for (auto& kv : g_tiles) (void)hipFree(kv.second.first);   // tile tables depend on the chunk length
         g_tiles.clear();
+        for (auto& kv : g_gf_tiles) (void)hipFree(kv.second.first);
+        g_gf_tiles.clear();
+        return 0;
+    }
+    if (!strcmp(key, "gf_fit") || !strcmp(key, "gf_cus")) {
+        if (!strcmp(key, "gf_fit")) g_gf_fit = value;
+        else g_num_cus = value;                                      // tests: the round size on a device with `value` CUs
+        if (g_stream) (void)hipStreamSynchronize(g_stream);
+        for (auto& kv : g_gf_tiles) (void)hipFree(kv.second.first);
+        g_gf_tiles.clear();
         return 0;
     }
     return fail("unknown tuning key '%s'", key);

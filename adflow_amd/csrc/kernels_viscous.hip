@@ -1148,19 +1148,18 @@ struct __attribute__((aligned(16))) Dbl2 { double x, y; };
 __device__ __forceinline__ Dbl2 mk2(double x, double y) { Dbl2 v; v.x = x; v.y = y; return v; }
 
 template <bool QCR, bool FIRST, bool STG>
-__global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
+__global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
     __shared__ __attribute__((aligned(16))) double ring[GF_RING];   // [slot][node row 0..3 = rows j0-1 .. j0+2][lane-1][component]
     __shared__ __attribute__((aligned(16))) double fjx[2 * GF_FJ];  // [parity][row][lane-2][component]
-    int bx, by, bz;
-    if (!tile_of_workgroup(tg, bx, by, bz)) return;
-    const BlkView& b = tab[bz / nzb + 1];
+    const int4 tl = tiles[blockIdx.x];
+    if (tl.x < 0) return;
+    const BlkView& b = tab[tl.x];
     const int lane = threadIdx.x, r = threadIdx.y;
+    const int bx = tl.y & 0xffff, by = tl.y >> 16;
     const int i = bx * GF_OUT + lane;             // cells i0-2 .. i0+61, i0 = 2 + 60 bx
     const int j0 = 2 + by * GF_ROWS;              // first produced cell row
-    const int k0 = 2 + (bz % nzb) * tg.kch;
-    if (b.nx == 0 || k0 > b.kl || bx * GF_OUT + 2 > b.il || j0 > b.jl) return;          // uniform per workgroup
-    const int k1 = (k0 + tg.kch - 1 < b.kl) ? k0 + tg.kch - 1 : b.kl;
+    const int k0 = tl.z, k1 = tl.w;               // planes of the chunk
     const int jn = j0 - 1 + r;                    // node row of the wave; waves 1..3: also its cell row
     const int ic = (i < b.ib) ? i : b.ib;
     const int jA = (jn < b.jb) ? jn : b.jb, jB = (jn + 1 < b.jb) ? jn + 1 : b.jb;
@@ -1512,16 +1511,12 @@ void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const 
 
 int g_visc_gf = 1;          // tuning "visc_gf": nodal gradients + viscous fluxes as ONE kernel (k_visc_gf), 0 = k_node_grad_march + k_visc_march
 
-// fused nodal gradients + viscous fluxes of every block of the level in one launch
-void launch_visc_gf_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, bool storeGrad, hipStream_t s)
+// fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
+void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)
 {
-    LEVEL_SPLIT(nslots, nz + 4, launch_visc_gf_level(tab + s0_, n_, nx, ny, nz, kp, storeGrad, s));
-    if (nslots <= 0) return;
-    const int L = g_march_kch > 0 ? g_march_kch : 32;
-    const int nch = (nz + L - 1) / L, kch = (nz + nch - 1) / nch;
-    const TileGrid tg = tile_grid((nx + GF_OUT - 1) / GF_OUT, (ny + GF_ROWS - 1) / GF_ROWS, nch, nslots, kch);
-    const dim3 grd(tile_grid_size(tg)), blk(64, 4, 1);
-#define GF_LAUNCH(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, nch, kp, tg)
+    if (ntiles <= 0) return;
+    const dim3 grd(ntiles), blk(64, 4, 1);
+#define GF_LAUNCH(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, tiles, kp)
     if (kp.useQCR) {
         if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, true, false); }
         else { if (storeGrad) GF_LAUNCH(true, false, true); else GF_LAUNCH(true, false, false); }

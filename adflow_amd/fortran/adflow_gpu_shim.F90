@@ -23,6 +23,7 @@ module adflowGpuShim
         integer(c_int32_t) :: eulerWallBCTreatment, viscWallBCTreatment, outflowTreatment
         integer(c_int32_t) :: hScalingInlet, unsupported
         integer(c_int32_t) :: lowSpeedPreconditioner
+        integer(c_int32_t) :: exchangePressureEarly, reserved_i
         real(c_double) :: gammaConstant, prandtl, prandtlTurb
         real(c_double) :: SSuthDim, muSuthDim, TSuthDim
         real(c_double) :: SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot
@@ -358,7 +359,7 @@ contains
         use inputPhysics
         use inputDiscretization
         use inputIteration
-        use iteration, only: groundLevel, ordersConverged
+        use iteration, only: groundLevel, ordersConverged, exchangePressureEarly
         use flowVarRefState
         use paramTurb, only: rsaCw1
         use oversetData, only: oversetPresent
@@ -382,6 +383,8 @@ contains
         if (wallFunctions) o%unsupported = ior(o%unsupported, 4)
         if (oversetPresent) o%unsupported = ior(o%unsupported, 8)
         o%lowSpeedPreconditioner = merge(1, 0, lowSpeedPreconditioner)
+        o%exchangePressureEarly = merge(1, 0, exchangePressureEarly)
+        o%reserved_i = 0
         o%gammaConstant = gammaConstant; o%prandtl = prandtl; o%prandtlTurb = prandtlTurb
         o%SSuthDim = SSuthDim; o%muSuthDim = muSuthDim; o%TSuthDim = TSuthDim
         o%SAKappa = SAKappa; o%SAcb1 = SAcb1; o%SAcb2 = SAcb2; o%SAsigma = SAsigma; o%SAcv1 = SAcv1

@@ -88,6 +88,7 @@ class FlowParams:
     outflowTreatment: int = 1
     lowSpeedPreconditioner: bool = False
     hScalingInlet: bool = False
+    exchangePressureEarly: bool = False   # iteration.f90:44: normal-momentum Euler walls present on any process
     LRef: float = 1.0
     ordersConverged: float = 16.0
     alfaTurb: float = 0.8

@@ -40,8 +40,10 @@ class CommPattern:
 
 @dataclass
 class BrickTopology:
-    """Bi x Bj x Bk equal blocks of nx x ny x nz cells, periodic in all three
-    index directions; block g (0-based, i fastest) lives on rank owner(g)."""
+    """Bi x Bj x Bk equal blocks of nx x ny x nz cells, periodic in the index
+    directions flagged in `periodic` (default: all three; the halos beyond a
+    non-periodic end of the brick belong to boundary subfaces and appear in no
+    pattern); block g (0-based, i fastest) lives on rank owner(g)."""
     Bi: int
     Bj: int
     Bk: int
@@ -49,6 +51,7 @@ class BrickTopology:
     ny: int
     nz: int
     owner: Callable[[int], int] = lambda g: 0
+    periodic: Tuple[bool, bool, bool] = (True, True, True)
 
     @property
     def nblocks(self):
@@ -121,13 +124,24 @@ class BrickTopology:
                 gk = (bk * nz + hk - 2) % (self.Bk * nz)
                 dg = (gi // nx) + self.Bi * ((gj // ny) + self.Bj * (gk // nz))
                 di, dj, dk = gi % nx + 2, gj % ny + 2, gk % nz + 2
+            # halos beyond a non-periodic end of the brick have no donor
+            if nodes:
+                gwj, gwk = bj * ny + hj - 1, bk * nz + hk - 1
+                inside = [(gw >= 0) & (gw <= self.Bi * nx), (gwj >= 0) & (gwj <= self.Bj * ny), (gwk >= 0) & (gwk <= self.Bk * nz)]
+            else:
+                gwj, gwk = bj * ny + hj - 2, bk * nz + hk - 2
+                inside = [(gw >= 0) & (gw < self.Bi * nx), (gwj >= 0) & (gwj < self.Bj * ny), (gwk >= 0) & (gwk < self.Bk * nz)]
+            keepm = np.ones(hi.shape, bool)
+            for d in range(3):
+                if not self.periodic[d]:
+                    keepm &= inside[d]
             rh = self.owner(g)
-            udg = np.unique(dg)
+            udg = np.unique(dg[keepm])
             downers = np.array([self.owner(int(x)) for x in udg])
             for dgu, rd in zip(udg, downers):
                 if only_rank is not None and rh != only_rank and rd != only_rank:
                     continue
-                m = dg == dgu
+                m = (dg == dgu) & keepm
                 didx = np.stack([di[m], dj[m], dk[m]], axis=1)
                 hidx = np.stack([hi[m], hj[m], hk[m]], axis=1)
                 n = int(m.sum())

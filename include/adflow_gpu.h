@@ -108,6 +108,11 @@ typedef struct adflow_opts {
      * adflow_gpu_set_options refuses a non-zero mask instead of silently returning steady, constant-gamma, 1-to-1 results. */
     int32_t unsupported;
     int32_t lowSpeedPreconditioner;   /* inputDiscretization: residual_block's 5x5 low-Mach transform (residuals.F90:172-331) + the 0.8 RK step factor (smoothers.F90:202) */
+    /* iteration::exchangePressureEarly (iteration.f90:44-53; set by solvers.F90:35-39,140-144 = eulerWallBcTreatment == normalMomentum
+     * .and. EulerWallsPresent(), a reduction over ALL processes): pressure-only whalo1 before applyAllBC in every smoother stage
+     * and in transferToFineGrid (smoothers.F90:363,674, multiGrid.F90:602) */
+    int32_t exchangePressureEarly;
+    int32_t reserved_i;
     double gammaConstant, prandtl, prandtlTurb;
     double SSuthDim, muSuthDim, TSuthDim;
     double SAKappa, SAcb1, SAcb2, SAsigma, SAcv1, SAcw1, SAcw2, SAcw3, SAct1, SAct2, SAct3, SAct4, SAcrot;

@@ -55,7 +55,7 @@ def load(fast: bool = False) -> ctypes.CDLL:
 _INT_PARAMS = ["equations", "spaceDiscr", "spaceDiscrCoarse", "limiter", "orderTurb", "turbModel", "turbProd",
                "smoother", "nRKStages", "rkStage", "currentLevel", "groundLevel", "resAveraging", "nSubIterTurb", "nSubiterations", "turbRelax",
                "eulerWallBCTreatment", "viscWallBCTreatment", "outflowTreatment"]
-_BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA", "lowSpeedPreconditioner", "hScalingInlet"]
+_BOOL_PARAMS = ["viscous", "eddyModel", "dirScaling", "useQCR", "useRotationSA", "useft2SA", "lowSpeedPreconditioner", "hScalingInlet", "exchangePressureEarly"]
 _REAL_PARAMS = ["vis2", "vis4", "vis2Coarse", "adis", "acousticScaleFactor", "kappaCoef", "sigma", "cfl",
                 "cflCoarse", "cflLimit", "fcoll", "smoop", "alfaTurb", "betaTurb", "rFil", "gammaConstant",
                 "gammaInf", "pInf", "pInfCorr", "rhoInf", "uInf", "RGas", "muInf", "muRef", "TRef", "timeRef",

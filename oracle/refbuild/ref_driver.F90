@@ -297,6 +297,7 @@ contains
         case ('turbTreatment'); turbTreatment = v
         case ('turbRelax'); turbRelax = v
         case ('eulerWallBCTreatment'); eulerWallBCTreatment = v
+        case ('exchangePressureEarly'); exchangePressureEarly = (v /= 0)
         case ('viscWallBCTreatment'); viscWallBCTreatment = v
         case ('outflowTreatment'); outflowTreatment = v
         case ('nSubIterTurb'); nSubIterTurb = v

@@ -1020,6 +1020,64 @@ def setup_blocks_with_bc(engine, prm, blocks_spec, seed=91, **mk):
     return blocks, rblocks, prm
 
 
+def check_pressure_early_exchange(engine, dims, prm, wall_face=5, seed=131, sweeps=1, **mk):
+    """exchangePressureEarly (iteration.f90:44-53, smoothers.F90:363-365 / 674-676): two blocks joined in i, an inviscid wall with
+    the normal-momentum pressure extrapolation spanning the interface.  bcEulerWall differentiates the pressure ALONG the wall,
+    i.e. reads the first halo layer of the neighbouring block, and the reference refreshes exactly that layer (pressure only,
+    whalo1) before applyAllBC in every stage.  The test first shows that the step depends on it (the reference WITHOUT the early
+    exchange gives a different state), then compares the device against the reference's own smoother."""
+    from oracle import ref
+    from adflow_amd.synth import make_bocos
+    from adflow_amd.topology import BrickTopology, apply_local_copies_fast
+    engine.release_all()
+    prm = prm.replace(currentLevel=1, groundLevel=1, eulerWallBCTreatment=4, exchangePressureEarly=True)
+    topo = BrickTopology(2, 1, 1, *dims, periodic=(False, False, False))
+    others = {3: -6, 4: -6, 5: -6, 6: -6}
+    others[wall_face] = -5
+    specs = {1: {**others, 1: -6}, 2: {**others, 2: -6}}         # the i faces between the blocks stay 1-to-1
+    name = "RungeKuttaSmoother" if prm.smoother == RungeKutta else "DADISmoother"
+
+    def reference_run(early):
+        blocks = make_brick(topo, prm, seed, **mk)
+        pats = {L: topo.patterns(L)[0] for L in (1, 2)}
+        apply_local_copies_fast(blocks, pats[2])
+        bocos = {nn: make_bocos(blocks[nn], prm, specs[nn], seed=seed + nn) for nn in blocks}
+        rblocks = {nn: b.copy() for nn, b in blocks.items()}
+        ref.alloc_doms(2, 1)
+        ref.bind_blocks(rblocks, prm.replace(exchangePressureEarly=early), level=1, nlevels=1, alloc=False, bocos=bocos)
+        for L in (1, 2):
+            ref.set_internal_comm(1, L, pats[L])
+        for nn in sorted(rblocks):
+            ref.call_level("setPointers", 1, nn)
+            ref.call("applyAllBC_block", 1)
+        for s in range(sweeps):
+            ref.load().ref_set_int(b"rkStage", 0)
+            ref.call_level("timeStep", 1, 0)
+            ref.call_level("initres", 1, 1, 5)
+            ref.call_level("residual", 1)
+            ref.call_level(name, 1)
+        return blocks, rblocks, bocos, pats
+
+    _, r_off, _, _ = reference_run(False)
+    off = {nn: b["p"].copy() for nn, b in r_off.items()}
+    blocks, rblocks, bocos, pats = reference_run(True)
+    moved = max(rel_err(off[nn], rblocks[nn]["p"]) for nn in rblocks)
+    assert moved > 1e-8, ("the early pressure exchange does not change this step", moved)
+    engine.set_options(prm)
+    for nn, b in blocks.items():
+        engine.register(b, nn=nn, level=1)
+        engine.bc_register(*bocos[nn], nn=nn, level=1)
+    for L in (1, 2):
+        engine.comm_register(1, L, pats[L])
+    engine.applyAllBC(1, True)
+    for s in range(sweeps):
+        engine.timeStep(1, False)
+        engine.residual(1, 0)
+        getattr(engine, name)(1)
+    assert_state(engine, blocks, rblocks, prm, f"{name} with exchangePressureEarly")
+    return moved
+
+
 def check_multiblock_bc(engine, prm, blocks_spec, seed=91, **mk):
     """applyAllBC over a level of several blocks with different subface lists, then (RANS) the SA solve and one
     smoother sweep on them: the device groups the subfaces of all blocks by kind / position in the block's list,

@@ -42,6 +42,13 @@ def test_euler_wall_normal_momentum(engine):
     checks.check_apply_bc(engine, (12, 8, 6), prm, {1: -6, 2: -6, 3: -5, 4: -5, 5: -1, 6: -5}, split={3: -6, 6: -5})
 
 
+def test_exchange_pressure_early(engine):
+    """normal-momentum Euler wall across a block interface: the pressure-only whalo1 in front of applyAllBC in every RK stage /
+    D-ADI step (smoothers.F90:363, :674) -- the reference without it gives a different state"""
+    checks.check_pressure_early_exchange(engine, (8, 6, 5), FlowParams(), wall_face=5)
+    checks.check_pressure_early_exchange(engine, (6, 7, 5), FlowParams(smoother=DADI, resAveraging=noResAveraging), wall_face=3, sweeps=2)
+
+
 @pytest.mark.parametrize("spec", VISC_SPECS)
 def test_apply_all_bc_rans(engine, spec):
     checks.check_apply_bc(engine, (20, 7, 6), FlowParams(equations=RANSEquations), spec, stretch_k=2.0)

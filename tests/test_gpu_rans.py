@@ -195,13 +195,21 @@ def test_visc_gradient_fused(engine):
                 checks.check_block_res(engine, (24, 10, 8), FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0), seed=vf,
                                        stretch_k=2.0)
             engine.set_tuning("visc_first", 7)
+            engine.set_tuning("gf_fit", 0)            # k chunks of march_kch planes
             engine.set_tuning("march_kch", 5)
             checks.check_block_res(engine, (20, 4, 13), prm, seed=11, stretch_k=2.0)
             engine.set_tuning("march_kch", 32)
+            engine.set_tuning("gf_fit", 1)            # chunks fitted to rounds of 2 x CUs workgroups: as on a device with 1 / 3 CUs
+            for cus in (1, 3):
+                engine.set_tuning("gf_cus", cus)
+                checks.check_block_res(engine, (70, 7, 21), prm, seed=12 + cus, stretch_k=2.0, holes=0.05)
+            engine.set_tuning("gf_cus", 0)
     finally:
         engine.set_tuning("visc_gf", 1)
         engine.set_tuning("visc_first", 7)
         engine.set_tuning("march_kch", 32)
+        engine.set_tuning("gf_fit", 1)
+        engine.set_tuning("gf_cus", 0)
 
 
 def test_block_res_without_intermediates(engine):

@@ -366,6 +366,11 @@ def test_visc_gradient_fused(hostsim_engine):
     test_gpu_rans.test_visc_gradient_fused(hostsim_engine)
 
 
+def test_exchange_pressure_early(hostsim_engine):
+    import test_gpu_bc
+    test_gpu_bc.test_exchange_pressure_early(hostsim_engine)
+
+
 def test_block_res_without_intermediates(hostsim_engine):
     import test_gpu_rans
     test_gpu_rans.test_block_res_without_intermediates(hostsim_engine)
