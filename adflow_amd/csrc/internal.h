@@ -390,6 +390,7 @@ bool euler_march_radii_capable(const KParams& kp);
 extern int g_euler_radii;
 void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s);
+int adf_round_size();          // api.hip: workgroups of a marching kernel resident at a time (2 x CUs)
 void adf_phase_mark(int i);    // api.hip: optional HIP event between the phases of blocketteRes
 void launch_coarse_coordinates_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, hipStream_t s);
 void launch_xhalo_level(const BlkView* tab, int nslots, int nx, int ny, int nz, hipStream_t s);

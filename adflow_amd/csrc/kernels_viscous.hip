@@ -346,12 +346,22 @@ __device__ __forceinline__ void node_grad_body(const BlkView* __restrict__ tab, 
 // 1-D launches of the gradient / SA marches: the dispatcher places workgroup p on XCD p % 8, so with `per` = workgroups per XCD
 // the tile index is (p % 8) per + p / 8: every XCD owns a contiguous run of the (i, j, k chunk, block) tile order and the rows
 // shared by j-neighbouring tiles meet in one L2 instead of being fetched from HBM by two XCDs.  per = 0: tile index = p.
-struct TileGrid { int gx, gy, total, per, kch; };     // kch: node planes per march
+// W > 0 (xcd_tiles = 2, default): the same within every ROUND of W resident workgroups, so that the eight XCDs work on neighbouring
+// tiles at any time (api.hip ensure_tiles).
+struct TileGrid { int gx, gy, total, per, kch, W; };     // kch: node planes per march
 
 __device__ __forceinline__ bool tile_of_workgroup(const TileGrid& g, int& bx, int& by, int& bz)
 {
     const int p = (int)blockIdx.x;
-    const int t = g.per ? (p & 7) * g.per + (p >> 3) : p;
+    int t;
+    if (g.W > 0) {
+        const int q = p / g.W, pr = p - q * g.W;
+        const int left = g.total - q * g.W, nIn = left < g.W ? left : g.W, per = (nIn + 7) >> 3;
+        const int x = pr & 7, s = pr >> 3;
+        if (s >= per || x * per + s >= nIn) return false;
+        t = q * g.W + x * per + s;
+    } else
+        t = g.per ? (p & 7) * g.per + (p >> 3) : p;
     if (t >= g.total) return false;
     bx = t % g.gx;
     const int r = t / g.gx;
@@ -359,7 +369,7 @@ __device__ __forceinline__ bool tile_of_workgroup(const TileGrid& g, int& bx, in
     return true;
 }
 
-int g_xcd_tiles = 1;        // tuning "xcd_tiles": 0 = gradient / SA march tiles in launch order
+int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
 
 int g_grad_kch = NG_KCH;    // tuning "grad_kch": longest k chunk of the gradient / SA marches; the node planes are spread evenly over the chunks
 
@@ -377,9 +387,14 @@ static TileGrid tile_grid(int gx, int gy, int nchn, int nslots, int kch)
     g.gx = gx; g.gy = gy; g.total = gx * gy * nchn * nslots;
     g.per = g_xcd_tiles ? (g.total + 7) / 8 : 0;
     g.kch = kch;
+    g.W = (g_xcd_tiles >= 2) ? adf_round_size() : 0;
     return g;
 }
-static int tile_grid_size(const TileGrid& g) { return g.per ? 8 * g.per : g.total; }
+static int tile_grid_size(const TileGrid& g)
+{
+    if (g.W > 0) return ((g.total + g.W - 1) / g.W) * g.W;
+    return g.per ? 8 * g.per : g.total;
+}
 
 template <bool XN>
 __global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView* __restrict__ tab, int nzb, double gam, TileGrid tg)
