@@ -154,7 +154,7 @@ EXPORTS = [
     "adflow_gpu_wall_distance_register", "adflow_gpu_update_wall_distances",
     "adflow_gpu_fd_jacobian", "adflow_gpu_jacobian_info", "adflow_gpu_download_jacobian", "adflow_gpu_download_jacobian_rows",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
-    "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning",
+    "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning", "adflow_gpu_march_stats",
 ]
 
 _libs = {}
@@ -231,6 +231,7 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_comm_init.argtypes = [c_int, c_int, c_void_p]
     lib.adflow_gpu_event_record.argtypes = [c_int]
     lib.adflow_gpu_event_elapsed_ms.argtypes = [c_int, c_int, POINTER(c_double)]
+    lib.adflow_gpu_march_stats.argtypes = [c_int, POINTER(c_double), c_int]
     so, sd = c_int(), c_int()
     lib.adflow_gpu_abi_sizes(ctypes.byref(so), ctypes.byref(sd))
     if so.value != ctypes.sizeof(AdflowOpts) or sd.value != ctypes.sizeof(AdflowBlockDesc):

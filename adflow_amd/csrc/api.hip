@@ -121,6 +121,8 @@ struct ActRegion {       // one actuator region (actuatorRegionData.F90); the ce
 std::vector<ActRegion> g_act;
 
 std::map<std::pair<int, int>, CommPattern> g_comm;   // (level, nLayers)
+int g_comm_self = 0;        // tuning "comm_self": same-process interfaces through pack / RCCL send+recv to self / unpack
+int g_self_rank = 0;        // rank of this process in the RCCL communicator
 std::map<int, BlkView*> g_tab;                        // level -> device table indexed by nn
 std::map<int, int> g_tab_size;
 std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
@@ -1848,22 +1850,39 @@ int build_comm(int level, int nLayers, CommPattern** out)
         std::vector<int> db2(nc), hb2(nc);
         std::vector<long> dof2(nc), hof2(nc);
         for (int t = 0; t < nc; ++t) { db2[t] = db[perm[t]]; dof2[t] = dof[perm[t]]; hb2[t] = hb[perm[t]]; hof2[t] = hof[perm[t]]; }
-        if (upload_list(db2, dof2, &cp.local.blkA, &cp.local.offA)) return 1;
-        if (upload_list(hb2, hof2, &cp.local.blkB, &cp.local.offB)) return 1;
+        if (g_comm_self && nc > 0) {
+            // tuning "comm_self": the same-process interfaces take the inter-GPU path -- k_halo_pack, ncclSend / ncclRecv to the own
+            // rank inside the group, k_halo_unpack -- so that the RCCL leg of whalo1 / whalo2 executes on a single GPU
+            // (the t-th packed donor is the t-th unpacked halo)
+            cp.local.n = 0;
+            CommList s, r;
+            s.n = r.n = nc;
+            s.peer = r.peer = g_self_rank;
+            if (upload_list(db2, dof2, &s.blkA, &s.offA)) return 1;
+            if (upload_list(hb2, hof2, &r.blkA, &r.offA)) return 1;
+            HIPCHK(hipMalloc((void**)&s.buf, sizeof(double) * 11 * (size_t)nc));
+            HIPCHK(hipMalloc((void**)&r.buf, sizeof(double) * 11 * (size_t)nc));
+            cp.sends.push_back(s);
+            cp.recvs.push_back(r);
+        } else {
+            if (upload_list(db2, dof2, &cp.local.blkA, &cp.local.offA)) return 1;
+            if (upload_list(hb2, hof2, &cp.local.blkB, &cp.local.offB)) return 1;
+        }
     }
     const int ns = (int)cp.h_sendProc.size(), nr = (int)cp.h_recvProc.size();
     const int nst = ns ? cp.h_nsendCum[ns] : 0, nrt = nr ? cp.h_nrecvCum[nr] : 0;
-    cp.sends.resize(ns);
-    cp.recvs.resize(nr);
+    const int s0 = (int)cp.sends.size(), r0 = (int)cp.recvs.size();       // the self message, when there is one
+    cp.sends.resize(s0 + ns);
+    cp.recvs.resize(r0 + nr);
     for (int i = 0; i < ns; ++i) {
-        CommList& l = cp.sends[i];
+        CommList& l = cp.sends[s0 + i];
         l.peer = cp.h_sendProc[i];
         l.n = cp.h_nsendCum[i + 1] - cp.h_nsendCum[i];
         if (make_list(level, cp.h_sendBlock.data(), cp.h_sendIdx.data(), nst, cp.h_nsendCum[i], l.n, &l.blkA, &l.offA)) return 1;
         HIPCHK(hipMalloc((void**)&l.buf, sizeof(double) * 11 * (size_t)std::max(l.n, 1)));
     }
     for (int i = 0; i < nr; ++i) {
-        CommList& l = cp.recvs[i];
+        CommList& l = cp.recvs[r0 + i];
         l.peer = cp.h_recvProc[i];
         l.n = cp.h_nrecvCum[i + 1] - cp.h_nrecvCum[i];
         if (make_list(level, cp.h_recvBlock.data(), cp.h_recvIdx.data(), nrt, cp.h_nrecvCum[i], l.n, &l.blkA, &l.offA)) return 1;
@@ -2269,6 +2288,7 @@ int adflow_gpu_comm_init(int rank, int nranks, const void* id128)
     NCCLCHK(ncclCommInitRank(&g_nccl, nranks, id, rank));
     g_rank = rank;
     g_nranks = nranks;
+    g_self_rank = rank;
     return 0;
 #else
     (void)rank; (void)nranks; (void)id128;
@@ -2986,6 +3006,35 @@ int adflow_gpu_event_elapsed_ms(int a, int b, double* ms)
     return 0;
 }
 
+int adflow_gpu_march_stats(int level, double* out, int n)
+{
+    if (need_ready()) return 1;
+    if (!out || n < 4) return fail("march_stats: n = %d (>= 4)", n);
+    for (int q = 0; q < n; ++q) out[q] = 0.0;
+    if (ensure_gf_tiles(level) || ensure_tiles(level)) return 1;
+    // fused gradient + viscous march: every chunk marches its planes + 2 (k_visc_gf: mm = k0-1 .. k1+1), four wavefronts
+    {
+        const auto& tt = g_gf_tiles[level];
+        std::vector<int4> h((size_t)tt.second);
+        if (tt.second > 0) HIPCHK(hipMemcpy(h.data(), tt.first, sizeof(int4) * h.size(), hipMemcpyDeviceToHost));
+        for (const int4& t : h)
+            if (t.x >= 0) out[1] += 4.0 * (t.w - t.z + 3);
+    }
+    for (auto& kv : g_blocks) {
+        if (std::get<0>(kv.first) != level || std::get<1>(kv.first) != 1) continue;
+        const BlkView& v = kv.second->v;
+        // tile table (k_roe_march, k_visc_march, ...): 60 columns x march_by rows x march_kch planes, kch + 1 trips per chunk
+        int ntx, nty, ntz;
+        euler_march_tiles(v, &ntx, &nty, &ntz);
+        out[2] += (double)g_march_by * ntx * nty * (v.nz + ntz);
+        // SA / nodal-gradient marches: nz + 1 node planes in balanced chunks of <= grad_kch, kch + 1 trips per chunk, 4 rows
+        const int nzn = v.nz + 1, L = g_grad_kch > 0 ? g_grad_kch : 32, nch = (nzn + L - 1) / L, kch = (nzn + nch - 1) / nch;
+        out[0] += 4.0 * ((v.nx + 1 + 59) / 60) * ((v.ny + 1 + 3) / 4) * nch * (kch + 1);
+        out[3] += 4.0 * ((v.nx + 1 + 61) / 62) * ((v.ny + 1 + 3) / 4) * nch * (kch + 1);
+    }
+    return 0;
+}
+
 int adflow_gpu_sync(void)
 {
     if (g_device < 0) return fail("adflow_gpu_init has not been called");
@@ -3048,6 +3097,12 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_tiles.clear();
         for (auto& kv : g_gf_tiles) (void)hipFree(kv.second.first);
         g_gf_tiles.clear();
+        return 0;
+    }
+    if (!strcmp(key, "comm_self")) {
+        if (g_stream) (void)hipStreamSynchronize(g_stream);
+        g_comm_self = value;
+        for (auto& kv : g_comm) drop_comm_lists(kv.second);        // rebuilt at the next exchange
         return 0;
     }
     if (!strcmp(key, "gf_fit") || !strcmp(key, "gf_cus")) {

@@ -290,6 +290,16 @@ class Engine:
         c = capi.comm_pattern_struct(cp)
         self._chk(self.lib.adflow_gpu_comm_register(level, nLayers, ctypes.byref(c)))
 
+    def comm_init_single(self):
+        """RCCL communicator of ONE rank (adflow_gpu_comm_unique_id + adflow_gpu_comm_init(0, 1, id)): what a multi-rank host does
+        with the id broadcast over MPI / torch.distributed; enough for messages to the own rank (tuning comm_self)."""
+        if getattr(self, "_comm_ready", False):
+            return
+        raw = (ctypes.c_char * 128)()
+        self._chk(self.lib.adflow_gpu_comm_unique_id(raw))
+        self._chk(self.lib.adflow_gpu_comm_init(0, 1, raw))
+        self._comm_ready = True
+
     def whalo1(self, level, start, end, commPressure=True, commGamma=True, commViscous=True):
         self._chk(self.lib.adflow_gpu_halo_exchange(level, start, end, int(commPressure), int(commViscous), 1))
 
@@ -309,6 +319,11 @@ class Engine:
         ms = ctypes.c_double()
         self._chk(self.lib.adflow_gpu_event_elapsed_ms(a, b, ctypes.byref(ms)))
         return ms.value
+
+    def march_stats(self, level: int = 1):
+        out = (ctypes.c_double * 4)()
+        self._chk(self.lib.adflow_gpu_march_stats(level, out, 4))
+        return {"sa_march": out[0], "visc_gf": out[1], "tile_march": out[2], "node_grad_march": out[3]}
 
     def sync(self):
         self._chk(self.lib.adflow_gpu_sync())

@@ -32,7 +32,56 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-HBM_STREAM_GBS = 4900.0  # what plain streaming copies reach on the boxes of this pool (tools/pmc_calib.bin bw, profiles/r02_bw_calib.txt)
+# context figures (never the priced peak): the streaming ceiling and the sustained FP64 issue clock, measured on a box of the pool by
+# `tools/pmc_calib.bin bw2` (16 B per lane, 8 loads in flight per thread, exact grid; v_fma_f64 chains) -> profiles/calibration.json;
+# without that file the guide's figures: 6.29 TB/s (float4 copy), 2.4 GHz
+HBM_STREAM_GBS = 6290.0
+ISSUE_CLOCK_GHZ = 2.4
+N_SIMD_PER_CU = 4
+
+
+def load_calibration():
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "calibration.json")))
+        return c
+    except (OSError, ValueError):
+        return {}
+
+
+def fp64_issue_roofline(eng, eval_ms, kernels_ms, qcr=False, gf=True, spaceDiscr=9):
+    """FP64 VALU issue bound of the evaluation: wavefront-steps of every marching kernel (adflow_gpu_march_stats) x the issue cycles of
+    its main loop (profiles/isa_counts.json: 4 cycles per VALU instruction of a 64-wide wavefront, 16 per f64 transcendental seed) over
+    all SIMDs at the sustained issue clock.  The kernels share the SIMDs, so the floor of the evaluation is the SUM."""
+    try:
+        isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
+        steps = eng.march_stats(1)
+        name = eng.device_name()
+        cus = int(name.split(",")[-1].split("CUs")[0]) if "CUs" in name else 256
+    except Exception as ex:   # no counts committed: no issue roofline
+        return {"error": str(ex)}
+    cal = load_calibration()
+    clock = float(cal.get("issue_clock_ghz_at_4_cycles", ISSUE_CLOCK_GHZ))
+    simds = cus * N_SIMD_PER_CU
+    inv = {9: "roe_march", 2: "matrix_march", 1: "euler_march"}[spaceDiscr]
+    plan = [("SA residual", "sa_march", "sa_march"), ("inviscid", inv, "tile_march")]
+    if gf:
+        plan.append(("nodal gradients + viscous (fused)", "visc_gf_qcr" if qcr else "visc_gf", "visc_gf"))
+    else:
+        plan += [("nodal gradients", "node_grad_march", "node_grad_march"), ("viscous", "visc_march", "tile_march")]
+    kern, total = {}, 0.0
+    for label, ik, sk in plan:
+        k = isa["kernels"].get(ik)
+        if not k:
+            continue
+        ms = steps[sk] * k["issue_cycles"] / (simds * clock * 1e9) * 1e3
+        kern[label] = {"kernel": k["what"], "wave_steps": steps[sk], "valu_per_step": k["valu"], "f64_per_step": k["f64"],
+                       "issue_cycles_per_step": k["issue_cycles"], "issue_floor_ms": ms,
+                       "measured_ms": kernels_ms.get(label), "frac_of_issue": (ms / kernels_ms[label]) if kernels_ms.get(label) else None}
+        total += ms
+    return {"bound": "fp64 valu issue", "floor_ms": total, "frac": total / eval_ms if eval_ms else None, "issue_clock_ghz": clock,
+            "issue_clock_source": "profiles/calibration.json (tools/pmc_calib.bin bw2)" if "issue_clock_ghz_at_4_cycles" in cal
+            else "MI355X_MICROARCH.md peak engine clock", "simds": simds, "isa_counts_git": isa.get("git"), "kernels": kern,
+            "note": "floor = sum over the kernels (they share the SIMDs); frac = floor / measured evaluation"}
 
 WORKLOADS = {
     # BASELINE.json configs[3] (the configuration the metric is quoted on), SURVEY §8(d) rows 4a / 4b
@@ -61,6 +110,9 @@ DEFAULT_WORKLOAD = "crm_rans_sa_upwind_8x160x128x64"
 PHASES = ["closures+bc", "time step", "SA residual", "inviscid", "nodal gradients", "viscous"]   # between marks 0..6 of api.hip
 # Roe upwind + viscous fluxes (tuning visc_first, default on): the viscous march runs in front of the Roe march, marks 4..6 in that order
 PHASES_VISC_FIRST = ["closures+bc", "time step", "SA residual", "nodal gradients", "viscous", "inviscid"]
+# k_visc_gf (tuning visc_gf, default on): gradients and viscous fluxes are one kernel between marks 4 and 5
+PHASES_GF_FIRST = ["closures+bc", "time step", "SA residual", "(mark)", "nodal gradients + viscous (fused)", "inviscid"]
+PHASES_GF = ["closures+bc", "time step", "SA residual", "inviscid", "(mark)", "nodal gradients + viscous (fused)"]
 
 
 CPU_WORKER = r"""
@@ -71,26 +123,23 @@ from adflow_amd.synth import make_block
 from oracle import ref
 n1, n2, n3, equations, spaceDiscr, seconds, seed = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]),
                                                     int(sys.argv[6]), float(sys.argv[7]), int(sys.argv[8]))
+path, fast = sys.argv[9], int(sys.argv[10])
+ref.load(fast=bool(fast))
 prm = FlowParams(equations=equations, spaceDiscr=spaceDiscr, vis4=0.1 if spaceDiscr == 2 else 0.0156)
 blk = make_block(n1, n2, n3, prm, seed=seed, stretch_k=3.0 if equations == 3 else 1.0)
 ref.bind_block(blk, prm)
-n, dt = ref.time_block_res_core(seconds, False, True, equations == 3)
+n, dt = ref.time_block_res_core(seconds, False, True, equations == 3, blockette=(path == "blockette"))
 print(json.dumps({"rate": blk.ncells * n / dt}))
 """
 
 
-def cpu_baseline(equations, spaceDiscr, seconds=12.0, max_cores=32, dims=(64, 64, 64)):
-    """The reference's own Fortran (oracle/_ref) on this box's host cores: one
-    pinned process per core, each repeating blockResCore on its own block."""
-    from oracle import ref
-    if not ref.available():
-        return None
+def _cpu_run(equations, spaceDiscr, seconds, cores, dims, path, fast):
+    """`cores` pinned processes, each repeating the reference's residual core on its own block; returns the list of rates"""
     avail = sorted(os.sched_getaffinity(0))
-    cores = max(1, min(len(avail), max_cores))
     procs = []
     for i in range(cores):
         cmd = ["taskset", "-c", str(avail[i]), sys.executable, "-c", CPU_WORKER, ROOT,
-               str(dims[0]), str(dims[1]), str(dims[2]), str(equations), str(spaceDiscr), str(seconds), str(100 + i)]
+               str(dims[0]), str(dims[1]), str(dims[2]), str(equations), str(spaceDiscr), str(seconds), str(100 + i), path, str(int(fast))]
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
     rates = []
     deadline = time.time() + seconds + 120.0
@@ -100,14 +149,38 @@ def cpu_baseline(equations, spaceDiscr, seconds=12.0, max_cores=32, dims=(64, 64
             rates.append(json.loads(out.strip().splitlines()[-1])["rate"])
         except Exception:
             pr.kill()
-    if not rates:
+    return rates
+
+
+def cpu_baseline(equations, spaceDiscr, seconds=8.0, max_cores=32, dims=(64, 64, 64)):
+    """The reference's own Fortran (oracle/_ref) on this box's host cores, as BASELINE.md section 2 asks: the DEFAULT residual path
+    of pyADflow, blocketteResCore (blockette.F90:299-753), one pinned process per core; beside it the same with the reference's
+    production flags (-ffast-math, config.LINUX_GFORTRAN.mk:34-36), a solo run on ONE core (no memory-bandwidth contention), and the
+    unblocked twin blockResCore that round 1 / 2 timed."""
+    from oracle import ref
+    if not ref.available():
         return None
+    cores = max(1, min(len(os.sched_getaffinity(0)), max_cores))
     what = {1: "Euler", 2: "laminar NS", 3: "RANS-SA"}[equations] + {1: " scalar JST", 2: " matrix dissipation", 9: " Roe upwind"}[spaceDiscr]
-    return {"value": sum(rates) / 1e6, "unit": "Mcells*residual-evals/s", "cores": len(rates), "kind": "reference",
-            "sample": f"{len(rates)} pinned processes x one {dims[0]}x{dims[1]}x{dims[2]} block each ({what}), ~{seconds:.0f} s of "
-                      "blockResCore evaluations (blockette.F90:755-852, updateIntermed=F) of the reference Fortran "
-                      "(amdflang -O3 -fdefault-real-8); no MPI halo exchange",
-            "per_core": sum(rates) / len(rates) / 1e6}
+    main = _cpu_run(equations, spaceDiscr, seconds, cores, dims, "blockette", False)
+    if not main:
+        return None
+    out = {"value": sum(main) / 1e6, "unit": "Mcells*residual-evals/s", "cores": len(main), "kind": "reference",
+           "sample": f"{len(main)} pinned processes x one {dims[0]}x{dims[1]}x{dims[2]} block each ({what}), ~{seconds:.0f} s of "
+                     "blocketteResCore evaluations (blockette.F90:299-753, the default residual path; updateIntermed=F) of the reference "
+                     "Fortran (amdflang -O3 -fdefault-real-8); no MPI halo exchange",
+           "per_core": sum(main) / len(main) / 1e6}
+    solo = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), 1, dims, "blockette", False)
+    if solo:
+        out["solo_one_core"] = solo[0] / 1e6
+    if ref.available(fast=True):
+        fast = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), cores, dims, "blockette", True)
+        if fast:
+            out["fast_math"] = {"value": sum(fast) / 1e6, "cores": len(fast), "flags": "-O3 -ffast-math (oracle/refbuild/Makefile FAST=1)"}
+    plain = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), cores, dims, "block", False)
+    if plain:
+        out["blockResCore_twin"] = {"value": sum(plain) / 1e6, "cores": len(plain), "what": "blockette.F90:755-852 (the figure of rounds 1-2)"}
+    return out
 
 
 T_START = time.perf_counter()
@@ -352,9 +425,15 @@ def main():
     eng.set_async(False)
     vf_bits = int(tuning.get("visc_first", 7))         # bit 0 Roe upwind, bit 1 matrix dissipation, bit 2 scalar JST of NS / RANS
     visc_first = (vf_bits & 1) != 0 and "upwind" in a.workload
-    ph = phase_times(eng, job.step, names=PHASES_VISC_FIRST if visc_first else PHASES)
+    gf_on = int(tuning.get("visc_gf", 1)) != 0 and wl["equations"] >= 2
+
+    def phase_names(first):
+        if gf_on:
+            return PHASES_GF_FIRST if first else PHASES_GF
+        return PHASES_VISC_FIRST if first else PHASES
+    ph = phase_times(eng, job.step, names=phase_names(visc_first))
     log("phases (ms): " + ", ".join(f"{k} {v:.3f}" for k, v in ph.items()))
-    kern = {k: v for k, v in ph.items() if k != "closures+bc"}
+    kern = {k: v for k, v in ph.items() if k not in ("closures+bc", "(mark)")}
     dom = max(kern, key=kern.get)
 
     extra = {}
@@ -368,7 +447,8 @@ def main():
                 job.step()
             s4b, r4b, e4b = timed(eng, job.step, a.steps, barrier, a.min_seconds)
             eng.set_async(False)
-            ph4b = phase_times(eng, job.step, names=PHASES_VISC_FIRST if (vf_bits & 2) else PHASES)
+            ph4b = phase_times(eng, job.step, names=phase_names((vf_bits & 2) != 0))
+            ph4b.pop("(mark)", None)
             extra["crm_rans_sa_matrix_8x160x128x64"] = {
                 "value": job.cells_local / s4b / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_step": s4b * 1e3,
                 "whole_eval_hbm_frac": 255.0 * job.cells_local / s4b / 1e9 / HBM_PEAK_GBS, "phase_ms": ph4b}
@@ -453,6 +533,8 @@ def main():
         # the evaluation's kernels overlap on the library's side streams: the roofline figure prices the TIMED evaluation (HIP events
         # around the K steps on the library's stream, halo copies included), kernels_ms lists them measured one after the other
         achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
+        cal = load_calibration()
+        stream_gbs = float(cal.get("copy16u8_1gib_gbs", HBM_STREAM_GBS))
         out = {
             "metric": "Mcells*residual-evals/s", "value": value, "unit": "Mcells*residual-evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec_step * 1e3, "repeats": reps,
@@ -471,7 +553,12 @@ def main():
                          "dominant_kernel_share": kern[dom] / eval_ms,
                          # context, not the priced peak: the streaming-copy ceiling measured on this pool and the fraction of it the
                          # evaluation reaches for the bytes the counters say it actually moves
-                         "streaming_copy_gbs": HBM_STREAM_GBS,
+                         "streaming_copy_gbs": stream_gbs,
+                         "streaming_copy_source": "profiles/calibration.json (tools/pmc_calib.bin bw2: 16 B per lane, 8 loads in flight per "
+                                                  "thread, 1 GiB arrays)" if "copy16u8_1gib_gbs" in cal else "MI355X_MICROARCH.md (float4 copy)",
+                         "infinity_cache_copy_gbs": cal.get("copy16u8_32mib_gbs"),
+                         # the second bound: FP64 VALU issue (SURVEY section 8(d) asks for it beside GB/s)
+                         "fp64_issue": fp64_issue_roofline(eng, ev_ms, kern, gf=gf_on, spaceDiscr=wl["spaceDiscr"]) if wl["equations"] == 3 else None,
                          "traffic_gbs": ((traffic or {}).get("traffic_bytes_per_eval") or 0.0) / (ev_ms * 1e-3) / 1e9 or None},
             "whole_eval": {"event_ms_per_step": ev_ms, "overlap_gain_ms": eval_ms - ev_ms,
                            "hbm_frac": alg_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

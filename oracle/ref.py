@@ -266,11 +266,16 @@ def fd_jacobian(nx, ny, nz, usePC=True, frozenTurb=False, turbOnly=False, viscPC
     return buf[:n].reshape((nx, ny, nz, ns.value, ns.value, nst.value), order="F")
 
 
-def time_block_res_core(seconds: float, update_intermed=True, flow_res=True, turb_res=True):
-    """Repeat the blockResCore sequence for ~`seconds`; returns (evals, elapsed)."""
+def time_block_res_core(seconds: float, update_intermed=True, flow_res=True, turb_res=True, blockette=False):
+    """Repeat the blockResCore sequence (blockette = True: the default path blocketteResCore) for ~`seconds`;
+    returns (evals, elapsed)."""
     import time
-    fn = load().ref_block_res_core
-    a = (int(update_intermed), int(flow_res), int(turb_res))
+    if blockette:
+        fn = load().ref_blockette_res_core
+        a = (int(update_intermed), int(flow_res), int(turb_res), 0, 0)
+    else:
+        fn = load().ref_block_res_core
+        a = (int(update_intermed), int(flow_res), int(turb_res))
 
     def loop():
         fn(*a)   # warm-up

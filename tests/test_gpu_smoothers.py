@@ -24,6 +24,23 @@ def test_halo_pack_unpack_loopback(engine, nLayers, nranks):
     checks.check_halo_loopback(engine, BrickTopology(2, 2, 2, 8, 6, 5), nranks, FlowParams(equations=RANSEquations), nLayers)
 
 
+@pytest.mark.parametrize("nLayers", [2, 1])
+def test_halo_exchange_rccl_self_loopback(engine, nLayers):
+    """the RCCL leg of whalo1 / whalo2 (api.hip comm_exchange_enqueue: k_halo_pack -> ncclGroupStart .. ncclSend / ncclRecv ..
+    ncclGroupEnd on the communication queue -> k_halo_unpack; replaces mpi_isend / mpi_irecv / waitany of
+    haloExchange.F90:553-719) EXECUTED on one GPU: tuning comm_self routes every same-process interface through a message to
+    the own rank.  Compared with the reference's whalo1 / whalo2, then one RK sweep with the exchange between the stages."""
+    engine.comm_init_single()
+    try:
+        engine.set_tuning("comm_self", 1)
+        checks.check_halo_exchange(engine, BrickTopology(2, 2, 2, 8, 6, 5), FlowParams(equations=RANSEquations), nLayers)
+        checks.check_halo_exchange(engine, BrickTopology(1, 1, 1, 7, 5, 3), FlowParams(), nLayers)
+        if nLayers == 2:
+            checks.check_rk_smoother(engine, BrickTopology(2, 1, 2, 12, 8, 6), FlowParams())
+    finally:
+        engine.set_tuning("comm_self", 0)
+
+
 def test_halo_exchange_self_periodic_single_block(engine):
     checks.check_halo_exchange(engine, BrickTopology(1, 1, 1, 7, 5, 3), FlowParams(), 2)
 

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Main-loop instruction counts of the marching kernels of one RANS-SA evaluation -> profiles/isa_counts.json.
+
+Runs on the build machine (hipcc cross-compiles gfx950 without a GPU): compiles the kernel sources to assembly, finds the
+march loop of every kernel (tools/isa_count.py) and records VALU / FP64 / transcendental / memory instruction counts per
+wavefront and plane, with the git hash of the sources.  bench.py multiplies them with the wavefront-steps of the workload
+(adflow_gpu_march_stats) to price the evaluation against the FP64 VALU issue rate (`roofline.fp64_issue`).
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from isa_count import main_loop  # noqa: E402
+
+KERNELS = {
+    # key of adflow_gpu_march_stats : (source, regex of the mangled name, what)
+    "sa_march": ("kernels_viscous.hip", r"k_sa_marchILb0E", "k_sa_march<false>: Spalart-Allmaras residual"),
+    "visc_gf": ("kernels_viscous.hip", r"k_visc_gfILb0ELb1ELb0E", "k_visc_gf<false,true,false>: nodal gradients + viscous fluxes"),
+    "visc_gf_qcr": ("kernels_viscous.hip", r"k_visc_gfILb1ELb1ELb0E", "k_visc_gf<true,true,false>: the same with QCR"),
+    "node_grad_march": ("kernels_viscous.hip", r"k_node_grad_marchILb1E", "k_node_grad_march<true> (visc_gf = 0)"),
+    "visc_march": ("kernels_viscous.hip", r"k_visc_marchILb0ELi0ELb0ELb1E", "k_visc_march<false,0,false,true> (visc_gf = 0)"),
+    "roe_march": ("kernels_roe_march.hip", r"k_roe_marchILi3ELb0ELb1ELb0ELb1E", "k_roe_march<vanAlbada,.,FINAL,.,ADDV>: central + Roe upwind"),
+    "matrix_march": ("kernels_inviscid_march.hip", r"k_inviscid_marchILi2E", "k_inviscid_march<matrix,...> (first instantiation found)"),
+    "euler_march": ("kernels_euler_march.hip", r"k_euler_march_p", "k_euler_march_p (first instantiation found)"),
+}
+
+
+def main():
+    out = {"git": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
+           "note": "per wavefront and march step (one k plane); issue_cycles = 4 x VALU + 12 more per f64 transcendental seed "
+                   "(quarter rate); a CDNA SIMD issues one VALU instruction of a 64-wide wavefront every 4 cycles",
+           "kernels": {}}
+    srcs = sorted({v[0] for v in KERNELS.values()})
+    with tempfile.TemporaryDirectory() as td:
+        asm = {}
+        for s in srcs:
+            o = os.path.join(td, s + ".s")
+            r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                                os.path.join(ROOT, "adflow_amd", "csrc", s), "-o", o], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise SystemExit(r.stderr[-2000:])
+            asm[s] = o
+        for key, (src, pat, what) in KERNELS.items():
+            r = main_loop(asm[src], pat)
+            if r is None:
+                continue
+            r["what"] = what
+            r["kernel"] = r["kernel"].split(":")[0]
+            out["kernels"][key] = r
+    p = os.path.join(ROOT, "profiles", "isa_counts.json")
+    json.dump(out, open(p, "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print(f"{k:16s} valu {v['valu']:5d} f64 {v['f64']:5d} trans {v['trans64']:3d} loads {v['gload']:3d} lds {v['ds']:3d} scratch {v['scratch']:3d} "
+              f"issue cycles {v['issue_cycles']:6d} vgpr {v.get('NumVgprs')} scratch B {v.get('ScratchSize')}")
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,39 @@ __global__ void read5w1(double* __restrict__ d, const double* __restrict__ s, si
         d[i] = s[i] + s[i + n] + s[i + 2 * n] + s[i + 3 * n] + s[i + 4 * n];
 }
 
+// streaming copy as the guide measures it (MI355X_MICROARCH.md: 6.29 TB/s with a float4 copy): 16 bytes per lane, U independent
+// loads in flight per thread (256 threads x U x 16 B = 32 KiB per workgroup at U = 8), exact grid, no grid-stride tail
+template <int U>
+__global__ __launch_bounds__(256) void copy16u(double2* __restrict__ d, const double2* __restrict__ s)
+{
+    const size_t base = ((size_t)blockIdx.x * U) * 256 + threadIdx.x;
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = s[base + (size_t)u * 256];
+#pragma unroll
+    for (int u = 0; u < U; ++u) d[base + (size_t)u * 256] = v[u];
+}
+// read-only stream (sum into one value per thread, stored only if nonzero-impossible): the read side alone
+template <int U>
+__global__ __launch_bounds__(256) void read16u(const double2* __restrict__ s, double* __restrict__ out)
+{
+    const size_t base = ((size_t)blockIdx.x * U) * 256 + threadIdx.x;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const double2 v = s[base + (size_t)u * 256]; acc += v.x + v.y; }
+    if (acc == 123.456) out[threadIdx.x] = acc;
+}
+// FP64 issue rate: 8 independent FMA chains per lane, N trips: 8 N v_fma_f64 per wave, nothing else in the loop but the counter
+__global__ __launch_bounds__(256) void valu_fma(double* __restrict__ out, int n, double a, double b)
+{
+    double x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < n; ++i) {
+        x0 = __builtin_fma(x0, a, b); x1 = __builtin_fma(x1, a, b); x2 = __builtin_fma(x2, a, b); x3 = __builtin_fma(x3, a, b);
+        x4 = __builtin_fma(x4, a, b); x5 = __builtin_fma(x5, a, b); x6 = __builtin_fma(x6, a, b); x7 = __builtin_fma(x7, a, b);
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+}
+
 #include "../adflow_amd/csrc/internal.h"
 __global__ void probe_pow(const double* __restrict__ x, double* __restrict__ y, double a, size_t n)
 {
@@ -107,6 +140,53 @@ int main(int argc, char** argv)
             const double bytes = (which < 2) ? 16.0 * n : 6.0 * (n / 4) * 8.0;
             printf("%s: %.3f ms per launch, %.0f GB/s (read + write)\n", which == 0 ? "copy8" : which == 1 ? "copy16" : "read5w1", ms / 10.0,
                    bytes / (ms / 10.0 * 1e-3) / 1e9);
+        }
+    }
+    if (!strcmp(mode, "bw2")) {
+        // (a) the guide's streaming ceiling with our own kernel: 16 B per lane, 8 loads in flight per thread, exact grid, > 256 MiB
+        //     working set (HBM) and a 64 MiB one (Infinity Cache: FETCH_SIZE counts these requests too, they are not HBM traffic);
+        // (b) the sustained FP64 issue rate: v_fma_f64 per second per SIMD -> the clock the issue roofline of bench.py is priced at
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, 0));
+        printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
+        for (int ws = 0; ws < 2; ++ws) {
+            const size_t n2 = ws == 0 ? ((size_t)1 << 26) : ((size_t)1 << 21);   // double2 elements: 1 GiB / 32 MiB per array
+            double2 *s, *d; double* o;
+            CK(hipMalloc(&s, n2 * 16)); CK(hipMalloc(&d, n2 * 16)); CK(hipMalloc(&o, 4096));
+            CK(hipMemset(s, 0, n2 * 16));
+            const int reps = ws == 0 ? 10 : 200;
+            for (int which = 0; which < 2; ++which) {
+                for (int it = -2; it < reps; ++it) {
+                    if (it == 0) CK(hipEventRecord(e0, 0));
+                    if (which == 0) hipLaunchKernelGGL(copy16u<8>, dim3((unsigned)(n2 / (8 * 256))), dim3(256), 0, 0, d, s);
+                    else hipLaunchKernelGGL(read16u<8>, dim3((unsigned)(n2 / (8 * 256))), dim3(256), 0, 0, s, o);
+                }
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const double bytes = (which == 0 ? 32.0 : 16.0) * n2;
+                printf(", \"%s_%s_gbs\": %.0f", which == 0 ? "copy16u8" : "read16u8", ws == 0 ? "1gib" : "32mib", bytes / (ms / reps * 1e-3) / 1e9);
+            }
+            CK(hipFree(s)); CK(hipFree(d)); CK(hipFree(o));
+        }
+        {
+            double* o;
+            const int wgs = prop.multiProcessorCount * 8, trips = 1 << 16;      // 8 workgroups x 4 waves per CU = 8 waves per SIMD
+            CK(hipMalloc(&o, (size_t)wgs * 256 * 8));
+            for (int it = -1; it < 3; ++it) {
+                if (it == 0) CK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(valu_fma, dim3(wgs), dim3(256), 0, 0, o, trips, 1.0000001, 1.e-9);
+            }
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double wave_insts = (double)wgs * 4.0 * 8.0 * trips;          // v_fma_f64 issued by all waves of one launch
+            const double per_simd = wave_insts / (ms / 3.0 * 1e-3) / (prop.multiProcessorCount * 4.0);
+            printf(", \"fma64_wave_insts_per_s_per_simd\": %.4e, \"issue_clock_ghz_at_4_cycles\": %.3f}\n", per_simd, per_simd * 4.0 / 1e9);
         }
     }
     if (!strcmp(mode, "probe") || !strcmp(mode, "all")) {
