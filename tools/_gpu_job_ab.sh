@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
 TAG=${TAG:-r03_x}
-if [ -n "$TESTS" ]; then timeout 1200 python -m pytest $TESTS -m gpu -x -q 2>&1 | tail -6 | tee $O/${TAG}_pytest.txt; fi
+if [ -n "$TESTS" ]; then timeout 1200 python -m pytest $TESTS -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -8 | tee $O/${TAG}_pytest.txt; fi
 B="python bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 2 --min-seconds 0.5 ${BENCH_EXTRA}"
 IFS='|' read -ra SETS <<< "$AB"
 for rep in $(seq 1 ${REPS:-2}); do

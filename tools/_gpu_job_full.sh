@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
 TAG=${TAG:-r03_full}
-if [ -z "$NOTESTS" ]; then timeout 1500 python -m pytest ${TESTS:-tests} -m gpu -x -q 2>&1 | tail -5 | tee $O/${TAG}_pytest.txt; fi
+if [ -z "$NOTESTS" ]; then timeout 1500 python -m pytest ${TESTS:-tests} -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -8 | tee $O/${TAG}_pytest.txt; fi
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 tools/pmc_calib.bin bw2 | tee $O/${TAG}_calibration.json
 cp $O/${TAG}_calibration.json profiles/calibration.json
