@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_visc_gf, g_xcd_tiles, g_grad_kch, g_dadi_post_i_fused;
+extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_visc_gf, g_gf_pf, g_xcd_tiles, g_grad_kch, g_dadi_post_i_fused;
 
 namespace {
 
@@ -81,6 +81,7 @@ struct Block {
     // wall association of updateWallDistancesQuickly: surfNodeIndices (4,nx,ny,nz), uv (2,nx,ny,nz)
     int* wd_ind = nullptr;
     double* wd_uv = nullptr;
+    int wd_max_node = 0;               // largest 1-based surface node the association refers to
 };
 
 typedef std::tuple<int, int, int> Key;   // (level, sps, nn): iteration order = level, sps, nn
@@ -708,6 +709,9 @@ int adflow_gpu_upload_coordinates(int nn, int level, int sps)
     if (!b->d.x) return fail("block (%d,%d,%d): no coordinate array", nn, level, sps);
     if (copy_box(b, b->v.x, b->d.x, 3, 0, b->v.ie + 1, 0, b->v.je + 1, 0, b->v.ke + 1, true)) return 1;
     b->face_vectors_valid = false;
+    // the stored sI / sJ / sK are now those of the OLD nodes: until update_geometry (or an upload of the new normals) re-forms
+    // them no kernel may take its normals from x while another reads the arrays (two geometries in one residual)
+    b->normals_from_x_ok = false;
     return sync_and_check();
 }
 
@@ -735,6 +739,13 @@ int adflow_gpu_wall_distance_register(int nn, int level, int sps, const int32_t*
     if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
     if (!surfNodeIndices || !uv) return fail("wall_distance_register: surfNodeIndices / uv is NULL");
     const size_t n = (size_t)b->v.nx * b->v.ny * b->v.nz;
+    // largest surface node any cell refers to: update_wall_distances checks it against the xSurf it is handed
+    int32_t mx = 0;
+    for (size_t q = 0; q < 4 * n; ++q) {
+        if (surfNodeIndices[q] < 0) return fail("wall_distance_register: negative surface node index");
+        mx = std::max(mx, surfNodeIndices[q]);
+    }
+    b->wd_max_node = mx;
     if (!b->wd_ind) {
         void *pi = nullptr, *pu = nullptr;
         HIPCHK(hipMalloc(&pi, n * 4 * sizeof(int32_t)));
@@ -775,12 +786,15 @@ int adflow_gpu_update_wall_distances(int level, const double* xSurf, int64_t n)
     int rc = for_level(level, [&](Block* b) {
         if (!b->wd_ind) return 0;
         if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
+        if ((int64_t)3 * b->wd_max_node > n)
+            return fail("update_wall_distances: the association of a level-%d block refers to surface node %d but xSurf holds %lld nodes",
+                        level, b->wd_max_node, (long long)(n / 3));
         any = true;
         launch_wall_distance(b->v, b->wd_ind, b->wd_uv, g_xsurf, g_stream);
         return 0;
     });
     if (rc) return rc;
-    if (!any) return fail("update_wall_distances: no block of level %d has a registered wall association", level);
+    (void)any;          // no association on this level (a level without walls): nothing to update, as updateWallDistancesQuickly
     return sync_and_check();
 }
 
@@ -895,6 +909,13 @@ int adflow_gpu_upload_array(int nn, int level, int sps, int which, const double*
     if (which == ADFLOW_ARR_W || which == ADFLOW_ARR_P || which == ADFLOW_ARR_GAMMA) {
         b->ss_valid = false;
         b->etot_consistent = false;
+    }
+    if (which == ADFLOW_ARR_X || which == ADFLOW_ARR_SI || which == ADFLOW_ARR_SJ || which == ADFLOW_ARR_SK) {
+        // nodes or normals replaced one array at a time: the derived face vectors are stale, and the normals count as
+        // metric_block(x) again only when the device data says so
+        if (sync_and_check()) return 1;
+        b->face_vectors_valid = false;
+        b->normals_from_x_ok = normals_match_nodes(b);
     }
     return sync_and_check();
 }
@@ -1215,7 +1236,10 @@ static int block_res_enqueue(int level, unsigned flags)
     phase_mark(3);
     if (flags & ADFLOW_RES_FLOW) {
         rc = enqueue_flow_residual(level, kp, viscApprox, false, true, (flags & ADFLOW_RES_UPDATE_INTERMED) != 0);
-        if (rc) return rc;
+        if (rc) {
+            if (saForked) (void)hipStreamWaitEvent(g_stream, g_evB, 0);      // never leave the side queue unjoined
+            return rc;
+        }
     }
     if (saForked) HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0));      // join
     phase_mark(6);
@@ -3064,6 +3088,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
     if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
     if (!strcmp(key, "visc_gf")) { g_visc_gf = value; return 0; }
+    if (!strcmp(key, "gf_pf")) { g_gf_pf = value; return 0; }
     if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
     if (!strcmp(key, "overlap_grad")) { g_overlap_grad = value; return 0; }
     if (!strcmp(key, "visc_first")) { g_visc_first = value; return 0; }

@@ -88,8 +88,11 @@ __device__ __forceinline__ double fast_powa(double x, double a) { return pow(x, 
 __device__ __forceinline__ double fastsqrt(double x) { return x * rsq_nr(fmax(x, 1.e-300)); }
 // x^(1/6) for x in the normal positive range: single-precision seed of z = x^(-1/6) (v_log_f32 / v_exp_f32), two Newton steps
 // z <- z (7 - x z^6) / 6 in FP64 (quadratic: 1e-7 -> 4e-14 -> 1e-26), result x z^5.  ~25 issue slots instead of ~150 of pow().
+// Outside 1e-30 .. 1e30 the single-precision seed under- / overflows (x -> 0 when the SA variable is negative and rr is far below
+// zero: the reference bounds rr only from above, sa.F90): the library pow there, a branch no realistic state takes.
 __device__ __forceinline__ double fast_root6(double x)
 {
+    if (!(x > 1.e-30 && x < 1.e30)) return pow(x, 1.0 / 6.0);
     double z = (double)__builtin_amdgcn_exp2f(-(1.0f / 6.0f) * __builtin_amdgcn_logf((float)x));
 #pragma unroll
     for (int it = 0; it < 2; ++it) {

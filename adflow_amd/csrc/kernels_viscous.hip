@@ -1162,7 +1162,8 @@ struct GfMet { double Pt[3], Q0t[3], Q1t[3], RIt[3], V; };
 struct __attribute__((aligned(16))) Dbl2 { double x, y; };
 __device__ __forceinline__ Dbl2 mk2(double x, double y) { Dbl2 v; v.x = x; v.y = y; return v; }
 
-template <bool QCR, bool FIRST, bool STG>
+// PF = 1 (tuning "gf_pf"): the loads of the face part are requested at the top of the step, in one batch with those of the gradient part
+template <bool QCR, bool FIRST, bool STG, int PF = 0>
 __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
     __shared__ __attribute__((aligned(16))) double ring[GF_RING];   // [slot][node row 0..3 = rows j0-1 .. j0+2][lane-1][component]
@@ -1250,6 +1251,18 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
         const bool full = (mm > k0);                           // all faces (first step of the march: the k face below plane k0 only)
         double dIv[3], dJv[3], dKv[3], sIA[3], sJA[3];
         int flag0 = 0;
+        auto face_loads = [&]() {
+            if (!facePlane) return;
+            if (r >= 1) vm_ld3(dK, cF, nb8, dKv);
+            flag0 = flags[cF >> 3];
+            if (full) {
+                if (r >= 1) vm_ld3(dI, cF, nb8, dIv);
+                vm_ld3(dJ, cF, nb8, dJv);
+                if (r >= 1) vm_ld3(m.sI, cF, nb8, sIA);
+                vm_ld3(m.sJ, cF, nb8, sJA);
+            }
+        };
+        if (PF == 1) face_loads();
         // ---- metric sums of this plane (ng_finish for both rows; the row above takes sJ(j-1) from the own row)
         GfMet N;
         {
@@ -1323,16 +1336,7 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
             }
         }
         // ---- loads of the face part (cell plane mm-1), requested above the barrier; sI / sJ of that plane again (carried they spill)
-        if (facePlane) {
-            if (r >= 1) vm_ld3(dK, cF, nb8, dKv);
-            flag0 = flags[cF >> 3];
-            if (full) {
-                if (r >= 1) vm_ld3(dI, cF, nb8, dIv);
-                vm_ld3(dJ, cF, nb8, dJv);
-                if (r >= 1) vm_ld3(m.sI, cF, nb8, sIA);
-                vm_ld3(m.sJ, cF, nb8, sJA);
-            }
-        }
+        if (PF == 0) face_loads();
         __syncthreads();
         if (facePlane) {
             const double* __restrict__ xb = ring + (((mm - k0) % 3) * 4) * GF_G + nl * 12;            // node plane mm-1
@@ -1524,6 +1528,7 @@ void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const 
     else hipLaunchKernelGGL((k_visc_march<false, 0>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
 }
 
+int g_gf_pf = 0;            // tuning "gf_pf": 1 = face-part loads of k_visc_gf requested at the top of the step
 int g_visc_gf = 1;          // tuning "visc_gf": nodal gradients + viscous fluxes as ONE kernel (k_visc_gf), 0 = k_node_grad_march + k_visc_march
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
@@ -1531,7 +1536,11 @@ void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KPa
 {
     if (ntiles <= 0) return;
     const dim3 grd(ntiles), blk(64, 4, 1);
-#define GF_LAUNCH(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, tiles, kp)
+#define GF_LAUNCH(Q, F, G)                                                                            \
+    do {                                                                                              \
+        if (g_gf_pf == 1) hipLaunchKernelGGL((k_visc_gf<Q, F, G, 1>), grd, blk, 0, s, tab, tiles, kp); \
+        else hipLaunchKernelGGL((k_visc_gf<Q, F, G, 0>), grd, blk, 0, s, tab, tiles, kp);             \
+    } while (0)
     if (kp.useQCR) {
         if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, true, false); }
         else { if (storeGrad) GF_LAUNCH(true, false, true); else GF_LAUNCH(true, false, false); }

@@ -239,17 +239,30 @@ class Job:
         self.prm = FlowParams(equations=wl["equations"], spaceDiscr=wl["spaceDiscr"], vis4=0.1 if wl["spaceDiscr"] == 2 else 0.0156)
         eng.set_options(self.prm)
         nb, dims = wl["nblocks"], wl["dims"]
-        e = round(nb ** (1.0 / 3.0))                 # per-GPU brick of e x e x e blocks
+        e = round(nb ** (1.0 / 3.0))                 # brick of e x e x e blocks
         assert e ** 3 == nb
-        # weak scaling: every GPU owns an e^3 brick of blocks; the ranks form an rx x ry x rz grid of such bricks, periodic
-        # in all three directions, so every evaluation is preceded by the 2-layer exchange of blocketteRes (whalo2,
-        # blockette.F90:246): same-GPU copies + RCCL send/recv with up to 7 distinct peers at 8 ranks
-        rx, ry, rz = rank_grid(world)
-        self.grid = (rx, ry, rz)
+        self.scaling = getattr(a, "scaling", "weak")
+        if self.scaling == "strong":
+            # BASELINE.json north_star / configs[3]: the SAME mesh (one e^3 brick, periodic) farmed over the GPUs, whole blocks to
+            # ranks by a greedy bin-pack on the cell count (the criterion of loadBalance.F90:409; equal blocks here, so every rank
+            # gets nb / N of them, neighbours in k first): total work fixed, the exchange grows with N
+            rx = ry = rz = 1
+            self.grid = (1, 1, 1)
+            # (greedy on equal blocks = nb / N each; taken in index order, k slowest, so that a rank's blocks are neighbours)
+            own = {g: (g * world) // nb for g in range(nb)}
 
-        def owner(g, Bi=e * rx, Bj=e * ry):
-            bi, bj, bk = g % Bi, (g // Bi) % Bj, g // (Bi * Bj)
-            return (bi // e) + rx * ((bj // e) + ry * (bk // e))
+            def owner(g):
+                return own[g]
+        else:
+            # weak scaling: every GPU owns an e^3 brick of blocks; the ranks form an rx x ry x rz grid of such bricks, periodic
+            # in all three directions, so every evaluation is preceded by the 2-layer exchange of blocketteRes (whalo2,
+            # blockette.F90:246): same-GPU copies + RCCL send/recv with up to 7 distinct peers at 8 ranks
+            rx, ry, rz = rank_grid(world)
+            self.grid = (rx, ry, rz)
+
+            def owner(g, Bi=e * rx, Bj=e * ry):
+                bi, bj, bk = g % Bi, (g // Bi) % Bj, g // (Bi * Bj)
+                return (bi // e) + rx * ((bj // e) + ry * (bk // e))
         self.topo = [BrickTopology(e * rx, e * ry, e * rz, dims[0] >> l, dims[1] >> l, dims[2] >> l, owner=owner) for l in range(levels)]
         lid = self.topo[0].local_ids()
         self.cells_local = 0
@@ -351,6 +364,9 @@ def main():
     ap.add_argument("--no-mg", action="store_true", help="skip the config-2 multigrid cycle measurement")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K steps until the region lasts this long")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): every GPU owns its own brick of the workload's blocks; strong: the SAME "
+                         "mesh (BASELINE north_star: the 8-block CRM mesh) split over the GPUs, 8 / N blocks each")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -418,7 +434,12 @@ def main():
         t = torch.tensor([sec_step], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sec_step = float(t.item())
-    cells_total = job.cells_local * world
+    if world > 1:
+        tc = torch.tensor([float(job.cells_local)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        cells_total = int(tc.item())
+    else:
+        cells_total = job.cells_local
     value = cells_total / sec_step / 1e6
 
     # ---- per-kernel durations of one evaluation, live HIP events on the library's stream
@@ -538,10 +559,12 @@ def main():
         out = {
             "metric": "Mcells*residual-evals/s", "value": value, "unit": "Mcells*residual-evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec_step * 1e3, "repeats": reps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {wl['nblocks']} blocks x {wl['dims'][0]}x{wl['dims'][1]}x{wl['dims'][2]} cells per GPU, "
                                    + wl["desc"] + ", one residual evaluation per step (whalo2 + blocketteRes core, default flags)",
                        "halo_exchange": job.halo, "rank_grid": "x".join(map(str, job.grid)),
+                       "partition": ("strong: one periodic brick of %d blocks, %d per rank (contiguous in k)" % (wl["nblocks"], wl["nblocks"] // world))
+                       if a.scaling == "strong" else "weak: one brick of the workload's blocks per rank",
                        "cells_per_gpu": job.cells_local, "device": eng.device_name()},
             # the evaluation is several kernels (SA, inviscid, nodal gradients, viscous): `achieved` prices the WHOLE timed
             # evaluation against the 255 / 175 B per cell of SURVEY §8(d); dominant_kernel is the longest of them

@@ -200,7 +200,11 @@ enum {
 /* flags of adflow_gpu_block_res: the logical arguments of blockette::blocketteRes
  * (src/NKSolver/blockette.F90:70-120) */
 enum {
-    ADFLOW_RES_UPDATE_INTERMED = 1u,   /* also store dtl, radI/J/K */
+    ADFLOW_RES_UPDATE_INTERMED = 1u,   /* also store dtl, radI/J/K.  WITHOUT it the spectral radii and dtl are not outputs of the call
+                                          (as in blocketteResCore, which keeps them in tile-private arrays): for matrix dissipation
+                                          and Roe upwind they are not formed at all, and ADFLOW_ARR_RADI/J/K, ADFLOW_ARR_DTL on the
+                                          device are UNDEFINED afterwards (adflow_gpu_time_step or a call with this flag refreshes
+                                          them; the smoothers call the time step themselves) */
     ADFLOW_RES_FLOW = 2u,              /* useFlowRes  */
     ADFLOW_RES_TURB = 4u,              /* useTurbRes  */
     /* the part of blocketteRes in front of the core (blockette.F90:195-246): */

@@ -51,3 +51,12 @@ def hostsim_engine():
     eng = Engine(0, _lib_path=build())
     yield eng
     eng.close()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """the largest LOCAL error |a-b| / (|b| + 1e-6 max|b|) any residual comparison of the session saw (tests/util.py)"""
+    try:
+        from util import worst_local_error, LOCAL_TOL
+        terminalreporter.write_line(f"worst local residual error of the session: {worst_local_error():.3e} (bound {LOCAL_TOL:.0e})")
+    except Exception:
+        pass

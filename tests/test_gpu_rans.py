@@ -40,6 +40,22 @@ def test_north_star_block_vs_reference_default_path(engine):
     checks.check_block_res_vs_blockette(engine, (160, 128, 64), prm, False, seed=44, stretch_k=3.0)
 
 
+def test_north_star_block_matrix_dissipation(engine):
+    """config 4b at full size: one 160 x 128 x 64 block, RANS-SA with matrix dissipation (vis4 = 0.1), default flags, against
+    blocketteResCore -- the size the bench quotes its 4b figure on"""
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=dissMatrix, vis4=0.1)
+    checks.check_block_res_vs_blockette(engine, (160, 128, 64), prm, False, seed=45, stretch_k=3.0)
+
+
+def test_multiblock_brick_at_bench_block_size(engine):
+    """2 x 2 x 2 blocks of 64 x 48 x 32 cells (several tiles, k chunks and rounds per block; every block with face, edge and
+    corner neighbours): stale halos -> whalo2 -> blocketteRes with the default flags, block by block against the reference"""
+    from adflow_amd.topology import BrickTopology
+    for sd in (upwind, dissMatrix):
+        prm = FlowParams(equations=RANSEquations, spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156)
+        checks.check_brick_block_res(engine, BrickTopology(2, 2, 2, 64, 48, 32), prm, seed=sd, stretch_k=2.0)
+
+
 def test_left_handed_block(engine):
     """a block whose (i, j, k) system is left-handed (mirror image): metric_block takes fact = -half.  The marching kernels that
     re-form the face normals from the nodes (SA, nodal gradients, time step) must do the same; update_geometry too."""

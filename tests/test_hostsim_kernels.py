@@ -366,6 +366,12 @@ def test_visc_gradient_fused(hostsim_engine):
     test_gpu_rans.test_visc_gradient_fused(hostsim_engine)
 
 
+def test_multiblock_brick_block_res(hostsim_engine):
+    from adflow_amd.topology import BrickTopology
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    checks.check_brick_block_res(hostsim_engine, BrickTopology(2, 1, 2, 10, 7, 6), prm, seed=3, stretch_k=2.0)
+
+
 def test_exchange_pressure_early(hostsim_engine):
     import test_gpu_bc
     test_gpu_bc.test_exchange_pressure_early(hostsim_engine)

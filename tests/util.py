@@ -16,6 +16,26 @@ def rel_err(a, b):
     return np.abs(a - b).max() / den
 
 
+LOCAL_TOL = 1e-6   # second, LOCAL measure (round-2 verdict): see rel_err_local
+_worst_local = [0.0]
+
+
+def rel_err_local(a, b, floor=1e-6):
+    """max over the cells of |a-b| / (|b| + floor max|b|): pins cells whose value is far below the field maximum (the SA residual
+    away from the wall, the energy residual in the free stream), which the global measure leaves loose.  With errors of
+    1e-16 .. 1e-13 of the field maximum this stays below 1e-7; the bound LOCAL_TOL is deliberately looser than TOL."""
+    den = np.abs(b) + floor * np.abs(b).max()
+    if not np.all(den > 0.0):
+        return float(np.abs(a - b).max())
+    e = float((np.abs(a - b) / den).max())
+    _worst_local[0] = max(_worst_local[0], e)
+    return e
+
+
+def worst_local_error():
+    return _worst_local[0]
+
+
 def owned(blk, arr):
     return arr[2:blk.il + 1, 2:blk.jl + 1, 2:blk.kl + 1]
 
