@@ -186,15 +186,23 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
     fd[4] = -porFlux * (lam3 * drE + hAvg * abv6 + unAvg * abv7);
 }
 
-// LDS exchange of the j-direction states: UL of rows -1..2 (slots 0..3) and UR of rows 1..4 (slots 4..7) of the tile
-#define RM_XJ (8 * 5 * 64)
+// LDS exchange of the j direction, per parity of the plane: the right states UR of the rows 0..4 of the tile (row 4 = the row
+// above it, reconstructed by wave 3) and the fluxes handed to the rows 0..3 through their LOWER j face
+#define RM_UR (5 * 5 * 64)
+#define RM_FJ(FW) (4 * ((FW) ? 10 : 5) * 64)
+#define RM_XJ(FW) (RM_UR + RM_FJ(FW))
 
 // FW: persistent dissipation residual of the Runge-Kutta scheme (fw kept between the stages); FINAL: dw = (dw + fw) iblank
 // written here, otherwise the sum dw + fw is left in dw for the viscous kernel to complete (residuals.F90:334-344)
-// body of the kernel for workgroup `bid` of the tile table; xj: 2 * RM_XJ doubles of LDS (the caller owns the allocation so that
-// the mixed kernel of kernels_viscous.hip can give the same bytes to either of its two bodies)
-// ADDV (with FINAL, without FW): dw(2:5) holds the viscous flux sums of k_visc_march<.., FIRST> on entry; they are added before iblank
-template <int LIM, bool FW, bool FINAL, bool XN = false, bool ADDV = false>
+// ADDV (with FINAL, without FW): dw(2:5) holds the viscous flux sums of the viscous march on entry; they are added before iblank
+//
+// Faces per cell (round 3): a wave evaluates the k face below its cell (carried), the i face (i-1 | i) (the other one by DPP) and
+// the j face ABOVE its cell; the flux through the j face BELOW comes from the wave of the row below through LDS, one plane later
+// (the barrier of the next plane orders it, double-buffered by parity): the sum of cell k-1 is completed behind the barrier of
+// step k.  The face below row 0 of the tile has no wave: it is the "fifth j face" and wave (k mod 4) takes it in plane k -- it
+// loads the three rows j0-2 .. j0 of that plane, reconstructs cell j0-1 and hands the flux to wave 0 -- so that over four planes
+// every SIMD carries the same load: 3.25 face evaluations and 3.5 reconstructions per cell (4 and 3.5 before).
+template <int LIM, bool FW, bool FINAL, bool ADDV = false>
 __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, const KParams& kp, int kch,
                                                int bid, double* __restrict__ xj)
 {
@@ -203,7 +211,8 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     const BlkView& b = tab[t.x];
     const int lane = threadIdx.x, row = threadIdx.y;
     const int i = t.y * RM_OUT + lane;          // columns i0-2 .. i0+61
-    const int j = 2 + t.z * RM_BY + row;
+    const int j0 = 2 + t.z * RM_BY;
+    const int j = j0 + row;
     const int k0 = 2 + t.w * kch;
     const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
     const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
@@ -214,6 +223,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     const long nb = b.nbox;
     const unsigned sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
     unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
+    unsigned cE = 8u * (unsigned)(ic + j0 * b.ldi + k0 * b.ldk);      // row j0 of the tile (the fifth j face lies below it)
     const unsigned oj2 = 8u * (unsigned)((jp2 - jc) * b.ldi);   // offset to row j+2 (clamped)
 
     RmPtrs m;
@@ -233,6 +243,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     K.factMinmod = (3.0 - kp.kappaCoef) / fmax(1.e-10, 1.0 - kp.kappaCoef);
     K.gam = kp.gammaConstant; K.gm1 = kp.gammaConstant - 1.0; K.ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
     K.porDiss = 0.5 * kp.rFil;
+    constexpr int NF = FW ? 10 : 5;             // values of one handed flux: central + dissipation apart only when fw persists
 
     // window k-1 .. k+1 of the own column; left state of the face above cell k-1
     RCell qm1, q0;
@@ -246,11 +257,6 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     }
     int flagm = flags[(c - sk) >> 3];
     double acc[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};   // accD: dissipation part, kept apart only when FW
-    // XN: the face normals re-formed from the node coordinates (internal.h ngx_*): the node plane below the cell is kept
-    GPTR(const double) xnod = (GPTR(const double))b.x;
-    const unsigned nb8 = 8u * (unsigned)nb;
-    NgNodes Pn;
-    if (XN) ngx_load_x(xnod, c - sk, nb8, sj, Pn);
 
     for (int k = k0; k <= k1 + 1; ++k) {
         const RCell qp1 = rm_ld(m, c + sk);
@@ -260,77 +266,65 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
 #pragma unroll
             for (int l = 0; l < 4; ++l) vsum[l] = ldg((GPTR(const double))dw + (l + 1) * nb, c - sk);
         }
-        double* __restrict__ xb = xj + ((k - k0) & 1) * RM_XJ;
+        double* __restrict__ xb = xj + (k & 1) * RM_XJ(FW);                 // UR of this plane | fluxes handed over in this plane
+        const double* __restrict__ xf = xj + ((k - 1) & 1) * RM_XJ(FW) + RM_UR;   // fluxes handed over in the plane before
         const bool body = (k <= k1);
-        RCell qjm, qjp;
-        double ULj[5], URj[5];
+        const bool fifth = body && (wave_uniform(row) == (k & 3));         // this wave evaluates the face below row 0 in this plane
+        RCell qjp, qEm, qE0;
+        double ULj[5], ULe[5];
         if (body) {
-            // ---- j-direction, first half: reconstruct the own cell (+ the cell outside the tile for the edge rows) and
-            //      publish the states the neighbouring rows need
-            qjm = rm_ld(m, c - sj);
+            // ---- j direction, first half: reconstruct the own cell (wave 3: also the cell above the tile) and publish the right
+            //      states the row below needs
+            const RCell qjm = rm_ld(m, c - sj);
             qjp = rm_ld(m, c + sj);
+            double URj[5];
             rm_recon<LIM>(K, qjm, q0, qjp, ULj, URj);
-            if (row < RM_BY - 1) {
 #pragma unroll
-                for (int l = 0; l < 5; ++l) xb[((row + 1) * 5 + l) * 64 + lane] = ULj[l];
-            }
-            if (row > 0) {
-#pragma unroll
-                for (int l = 0; l < 5; ++l) xb[((4 + row - 1) * 5 + l) * 64 + lane] = URj[l];
-            }
-            if (row == 0) {
-                const RCell qjm2 = rm_ld(m, c - 2 * sj);
-                double pl[5], mi[5];
-                rm_recon<LIM>(K, qjm2, qjm, q0, pl, mi);
-#pragma unroll
-                for (int l = 0; l < 5; ++l) xb[(0 * 5 + l) * 64 + lane] = pl[l];
-            }
+            for (int l = 0; l < 5; ++l) xb[(row * 5 + l) * 64 + lane] = URj[l];
             if (row == RM_BY - 1) {
                 const RCell qjp2 = rm_ld(m, c + oj2);
                 double pl[5], mi[5];
                 rm_recon<LIM>(K, q0, qjp, qjp2, pl, mi);
 #pragma unroll
-                for (int l = 0; l < 5; ++l) xb[(7 * 5 + l) * 64 + lane] = mi[l];
+                for (int l = 0; l < 5; ++l) xb[(4 * 5 + l) * 64 + lane] = mi[l];
+            }
+            if (fifth) {
+                const RCell qEmm = rm_ld(m, cE - 2 * sj);
+                qEm = rm_ld(m, cE - sj);
+                qE0 = rm_ld(m, cE);
+                double mi[5];
+                rm_recon<LIM>(K, qEmm, qEm, qE0, ULe, mi);                  // left state of the face (j0-1 | j0)
             }
         }
         // ---- k-face between cells k-1 and k (normal and porosity stored at cell k-1)
         double ULk0[5], URk0[5];
         rm_recon<LIM>(K, qm1, q0, qp1, ULk0, URk0);
         double fc[5], fd[5];
-        double nI[3], nJm[3], nJ[3];
-        if (XN) {
-            double nKb[3];
-            ngx_normal_k(b.mfact, Pn, nKb);
-            rm_face(K, qm1, q0, ULk, URk0, nKb[0], nKb[1], nKb[2], flg_porK((uint8_t)flagm), fc, fd);
-            if (body) {
-                NgNodes Nn;
-                ngx_load_x(xnod, c, nb8, sj, Nn);
-                double nKu[3];
-                ngx_normals(b.mfact, Pn, Nn, nI, nJm, nJ, nKu);
-                Pn = Nn;
+        rm_face(K, qm1, q0, ULk, URk0, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), fc, fd);
+        __syncthreads();
+        // ---- finish cell k-1 with the flux through its lower j face (handed over in the plane before) and write it
+        if (k > k0) {
+            double fl[NF];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) nI[d] = lane_up1(nI[d]);      // this lane's i-face is (i-1 | i): sI of the cell i-1
-            }
-        } else
-            rm_face(K, qm1, q0, ULk, URk0, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), fc, fd);
-        // ---- finish cell k-1 and write it
-        if (k > k0 && out) {
-            const unsigned cw = c - sk;
-            const double blank = flg_blank((uint8_t)flagm);
+            for (int l = 0; l < NF; ++l) fl[l] = xf[(row * NF + l) * 64 + lane];
+            if (out) {
+                const unsigned cw = c - sk;
+                const double blank = flg_blank((uint8_t)flagm);
 #pragma unroll
-            for (int l = 0; l < 5; ++l) {
-                double d = acc[l] + fc[l];
-                if (kp.coarseInit) d += ldg(wr + l * nb, cw);
-                if (FW) {
-                    double fwn = accD[l] + fd[l];
-                    const double old = ldg(fw + l * nb, cw);
-                    fwn = K.doDiss ? (kp.sfil * old + fwn) : old;
-                    if (K.doDiss || !FINAL) stg(fw + l * nb, cw, fwn);
-                    stg(dw + l * nb, cw, FINAL ? (d + fwn) * blank : d);
-                } else {
-                    d += fd[l];
-                    if (ADDV && l > 0) d += vsum[l - 1];
-                    stg(dw + l * nb, cw, d * blank);      // not FINAL: the viscous kernel adds its part to dw(2:5) and re-applies iblank
+                for (int l = 0; l < 5; ++l) {
+                    double d = (acc[l] - fl[l]) + fc[l];
+                    if (kp.coarseInit) d += ldg(wr + l * nb, cw);
+                    if (FW) {
+                        double fwn = (accD[l] - fl[5 + l < NF ? 5 + l : l]) + fd[l];
+                        const double old = ldg(fw + l * nb, cw);
+                        fwn = K.doDiss ? (kp.sfil * old + fwn) : old;
+                        if (K.doDiss || !FINAL) stg(fw + l * nb, cw, fwn);
+                        stg(dw + l * nb, cw, FINAL ? (d + fwn) * blank : d);
+                    } else {
+                        d += fd[l];
+                        if (ADDV && l > 0) d += vsum[l - 1];
+                        stg(dw + l * nb, cw, d * blank);      // not FINAL: the viscous kernel adds its part to dw(2:5) and re-applies iblank
+                    }
                 }
             }
         }
@@ -351,8 +345,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
             for (int l = 0; l < 5; ++l) ULm[l] = lane_up1(ULi[l]);
             const int por = flg_porI((uint8_t)lane_up1(flag0));
             double gc[5], gd[5];
-            if (XN) rm_face(K, qL, q0, ULm, URi, nI[0], nI[1], nI[2], por, gc, gd);
-            else rm_face(K, qL, q0, ULm, URi, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, gc, gd);
+            rm_face(K, qL, q0, ULm, URi, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, gc, gd);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 if (FW) {
@@ -364,45 +357,55 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
                 }
             }
         }
-        // ---- j-direction, second half: both faces of the cell with the neighbours' states
-        __syncthreads();
+        // ---- j face above the cell with the right state of the row above; its flux is handed to that row
         {
-            double Lm[5], Rp[5];
+            double Rp[5];
 #pragma unroll
-            for (int l = 0; l < 5; ++l) {
-                Lm[l] = xb[(row * 5 + l) * 64 + lane];            // left state of face (j-1 | j): UL of row-1
-                Rp[l] = xb[((4 + row) * 5 + l) * 64 + lane];      // right state of face (j | j+1): UR of row+1
-            }
-            const int porM = flg_porJ(flags[(c - sj) >> 3]), porP = flg_porJ((uint8_t)flag0);
+            for (int l = 0; l < 5; ++l) Rp[l] = xb[((row + 1) * 5 + l) * 64 + lane];
             double hc[5], hd[5];
-            if (XN) rm_face(K, qjm, q0, Lm, URj, nJm[0], nJm[1], nJm[2], porM, hc, hd);
-            else rm_face(K, qjm, q0, Lm, URj, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, hc, hd);
-#pragma unroll
-            for (int l = 0; l < 5; ++l) {
-                if (FW) { acc[l] -= hc[l]; accD[l] -= hd[l]; }
-                else acc[l] -= hc[l] + hd[l];
-            }
-            if (XN) rm_face(K, q0, qjp, ULj, Rp, nJ[0], nJ[1], nJ[2], porP, hc, hd);
-            else rm_face(K, q0, qjp, ULj, Rp, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, hc, hd);
+            rm_face(K, q0, qjp, ULj, Rp, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), flg_porJ((uint8_t)flag0), hc, hd);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 if (FW) { acc[l] += hc[l]; accD[l] += hd[l]; }
                 else acc[l] += hc[l] + hd[l];
             }
+            if (row < RM_BY - 1) {
+                double* __restrict__ fo = xb + RM_UR + ((row + 1) * NF) * 64 + lane;
+#pragma unroll
+                for (int l = 0; l < 5; ++l) {
+                    if (FW) { fo[l * 64] = hc[l]; fo[(5 + l) * 64] = hd[l]; }
+                    else fo[l * 64] = hc[l] + hd[l];
+                }
+            }
+        }
+        // ---- the fifth j face (j0-1 | j0): right state = UR of row 0
+        if (fifth) {
+            double Rm[5];
+#pragma unroll
+            for (int l = 0; l < 5; ++l) Rm[l] = xb[l * 64 + lane];
+            double hc[5], hd[5];
+            const unsigned cm = cE - sj;
+            rm_face(K, qEm, qE0, ULe, Rm, ldg(sJx, cm), ldg(sJy, cm), ldg(sJz, cm), flg_porJ(flags[cm >> 3]), hc, hd);
+            double* __restrict__ fo = xb + RM_UR + lane;
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                if (FW) { fo[l * 64] = hc[l]; fo[(5 + l) * 64] = hd[l]; }
+                else fo[l * 64] = hc[l] + hd[l];
+            }
         }
         // ---- advance the window
         qm1 = q0; q0 = qp1;
         flagm = flag0;
-        c += sk;
+        c += sk; cE += sk;
     }
 }
 
-template <int LIM, bool FW, bool FINAL, bool XN = false, bool ADDV = false>
+template <int LIM, bool FW, bool FINAL, bool ADDV = false>
 __global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                              int kch)
 {
-    __shared__ double xj[2 * RM_XJ];
-    roe_march_body<LIM, FW, FINAL, XN, ADDV>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
+    __shared__ double xj[2 * RM_XJ(FW)];
+    roe_march_body<LIM, FW, FINAL, ADDV>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
 }
 
 int g_roe_march = 1;       // tuning "roe_march": 0 = k_inviscid_march<upwind> (reconstruction per face) on the fine level too
@@ -420,7 +423,7 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
         if (final_) hipLaunchKernelGGL((k_roe_march<LIM, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else if (kp.viscFirst) {
-        hipLaunchKernelGGL((k_roe_march<LIM, false, true, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        hipLaunchKernelGGL((k_roe_march<LIM, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
         if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
