@@ -122,6 +122,11 @@ struct ActRegion {       // one actuator region (actuatorRegionData.F90); the ce
 std::vector<ActRegion> g_act;
 
 std::map<std::pair<int, int>, CommPattern> g_comm;   // (level, nLayers)
+double* g_rvec_target = nullptr;     // residual vector the kernels of the evaluation in flight write (nk_residual_dev)
+int g_rvec_done = 0;                  // bit 0: flow entries written, bit 1: turbulence entry written
+long g_state_gen = 0;        // bumped by every call that changes what a multigrid cycle enqueues (options, tuning, blocks, patterns, subfaces)
+int g_mg_graph = 1;         // tuning "mg_graph": a repeated adflow_gpu_mg_cycle is captured once into a hipGraph and replayed
+int g_nk_fuse = 1;          // tuning "nk_fuse": setRVec inside the kernels that complete dw (adflow_gpu_nk_residual_dev)
 int g_comm_self = 0;        // tuning "comm_self": same-process interfaces through pack / RCCL send+recv to self / unpack
 int g_self_rank = 0;        // rank of this process in the RCCL communicator
 std::map<int, BlkView*> g_tab;                        // level -> device table indexed by nn
@@ -161,6 +166,7 @@ void drop_comm_lists(CommPattern& cp)
 
 void invalidate_comm_level(int level)
 {
+    ++g_state_gen;
     if (level == 1)
         for (auto& r : g_act) r.built = false;      // cell offsets depend on the registered blocks
     for (auto& kv : g_comm)
@@ -443,6 +449,7 @@ int adflow_gpu_set_options(const adflow_opts* o)
                     (o->unsupported & 4) ? " wall functions;" : "", (o->unsupported & 8) ? " overset blocks;" : "");
     if (o->equations == ADFLOW_RANS && o->turbModel != 2)   // spalartAllmaras (constants.F90)
         return fail("turbModel=%d not supported (Spalart-Allmaras only)", o->turbModel);
+    if (memcmp(&g_opts, o, sizeof g_opts) != 0) ++g_state_gen;
     g_opts = *o;
     g_have_opts = true;
     return 0;
@@ -1159,6 +1166,7 @@ static int block_res_enqueue(int level, unsigned flags)
     KParams kp = make_kparams(level, 1.0, 0);
     kp.onlyRadii = !(flags & ADFLOW_RES_UPDATE_INTERMED);
     kp.coarseInit = 0;
+    if (level == 1 && g_rvec_target) { kp.rvec = g_rvec_target; kp.rvecTurbScale = g_opts.turbResScale; }
     kp.dissApprox = (flags & ADFLOW_RES_DISS_APPROX) ? 1 : 0;
     if (kp.dissApprox && (flags & ADFLOW_RES_UPWIND_FIRST_ORDER)) kp.lumpedDiss = 1;   // blockette.F90:643
     const bool viscApprox = (flags & ADFLOW_RES_VISC_APPROX) != 0;
@@ -1251,6 +1259,7 @@ static int block_res_enqueue(int level, unsigned flags)
 // ---- actuator regions (actuatorRegionData.F90) -----------------------------------------------------------------------
 int adflow_gpu_actuator_register(int nRegions, const adflow_actuator_region* regions)
 {
+    ++g_state_gen;
     if (g_device < 0) return fail("adflow_gpu_init has not been called");
     if (nRegions < 0 || (nRegions > 0 && !regions)) return fail("actuator_register: nRegions=%d", nRegions);
     if (g_stream) (void)hipStreamSynchronize(g_stream);
@@ -1641,6 +1650,8 @@ int res_averaging_level(int level, const KParams& kp, double scaleDtl)
 }  // namespace
 
 // workgroups of a marching kernel resident at a time: two per CU (256 VGPRs, <= 80 KB of LDS each)
+void adf_note_rvec(int bits) { g_rvec_done |= bits; }
+
 int adf_round_size()
 {
     if (g_num_cus <= 0) {
@@ -1957,12 +1968,14 @@ extern "C" {
 
 int adflow_gpu_set_bc_callback(adflow_bc_callback fn)
 {
+    ++g_state_gen;
     g_bc_callback = fn;
     return 0;
 }
 
 int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBocos, const adflow_bc_subface* faces)
 {
+    ++g_state_gen;
     Block* b = find_block(nn, level, sps);
     if (!b) return fail("block (%d,%d,%d) not registered", nn, level, sps);
     if (nBocos < 0 || nViscBocos < 0 || nViscBocos > nBocos) return fail("bc_register: nBocos=%d nViscBocos=%d", nBocos, nViscBocos);
@@ -2322,6 +2335,7 @@ int adflow_gpu_comm_init(int rank, int nranks, const void* id128)
 
 int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* p)
 {
+    ++g_state_gen;
     if (g_device < 0) return fail("adflow_gpu_init has not been called");
     if (!p) return fail("null comm pattern");
     if (nLayers < 0 || nLayers > 2) return fail("nLayers must be 1 or 2 (cell halos) or 0 (the node pattern of exchangeCoor)");
@@ -2359,6 +2373,7 @@ int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* 
 
 int adflow_gpu_comm_register_periodic(int level, int nLayers, int nPeriodic, const adflow_periodic_data* pd)
 {
+    ++g_state_gen;
     auto it = g_comm.find(std::make_pair(level, nLayers));
     if (it == g_comm.end()) return fail("comm_register_periodic: no pattern registered for level %d, nLayers %d", level, nLayers);
     if (nPeriodic < 0 || (nPeriodic > 0 && !pd)) return fail("comm_register_periodic: nPeriodic=%d", nPeriodic);
@@ -2773,12 +2788,130 @@ int adflow_gpu_coarse_coordinates(int coarseLevel)
     return sync_and_check();
 }
 
+// executeMGCycle as ONE hipGraph.  A cycle enqueues ~10^3 kernels and most of them (the coarse levels) run 10 - 40 us: the launch
+// gaps, not the kernels, bound them (profiles/r02_br_mg_trace.md).  Everything a cycle enqueues is fixed by the options, the tuning,
+// the registered blocks / patterns / subfaces and the cycling strategy, so the third identical call in a row (the first warms the
+// caches, no allocation may happen under capture; the second is captured) replays the graph.  Not captured: host callbacks
+// (boundary-condition hooks), phase events, actuator regions (their relaxation factor changes from cycle to cycle), RCCL messages.
+namespace {
+struct MgGraph {
+    std::vector<int32_t> cyc;
+    long gen = -1;
+    int seen = 0;                   // identical calls in a row that ran directly
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    bool failed = false;            // capture or instantiation failed once: direct enqueue from then on
+    // what is enqueued also depends on the blocks' host-side flags (a stale sensor adds a k_entropy pass, ...): the graph is valid
+    // for the flags it was captured from (pre) and leaves the flags of the end of the captured cycle (post)
+    std::vector<unsigned char> pre, post;
+};
+MgGraph g_mgg;
+
+void mg_graph_drop()
+{
+    if (g_mgg.exec) (void)hipGraphExecDestroy(g_mgg.exec);
+    if (g_mgg.graph) (void)hipGraphDestroy(g_mgg.graph);
+    g_mgg.exec = nullptr; g_mgg.graph = nullptr; g_mgg.seen = 0; g_mgg.gen = -1; g_mgg.cyc.clear();
+}
+
+std::vector<unsigned char> block_flags()
+{
+    std::vector<unsigned char> f;
+    for (auto& kv : g_blocks) {
+        const Block* b = kv.second;
+        f.push_back((unsigned char)(b->geom_uploaded | (b->normals_from_x_ok << 1) | (b->face_vectors_valid << 2) | (b->ss_valid << 3) |
+                                    (b->etot_consistent << 4)));
+    }
+    return f;
+}
+
+void set_block_flags(const std::vector<unsigned char>& f)
+{
+    size_t q = 0;
+    for (auto& kv : g_blocks) {
+        if (q >= f.size()) break;
+        Block* b = kv.second;
+        const unsigned char v = f[q++];
+        b->geom_uploaded = v & 1; b->normals_from_x_ok = (v >> 1) & 1; b->face_vectors_valid = (v >> 2) & 1; b->ss_valid = (v >> 3) & 1;
+        b->etot_consistent = (v >> 4) & 1;
+    }
+}
+
+bool mg_graph_eligible()
+{
+#ifdef HOSTSIM
+    return false;
+#else
+    if (!g_mg_graph || g_mgg.failed || g_bc_callback || g_turb_bc_callback || g_phase_base > 0 || !g_act.empty()) return false;
+    for (auto& kv : g_comm)
+        if (!kv.second.h_sendProc.empty() || !kv.second.h_recvProc.empty() || g_comm_self) return false;
+    return true;
+#endif
+}
+}  // namespace
+
+static int mg_cycle_enqueue(const int32_t* cycling, int nSteps);
+
 int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
 {
     if (need_ready()) return 1;
     if (!cycling || nSteps < 1) return fail("mg_cycle: empty cycling strategy");
+#ifndef HOSTSIM
+    if (mg_graph_eligible()) {
+        const bool same = (g_mgg.gen == g_state_gen && (int)g_mgg.cyc.size() == nSteps && !memcmp(g_mgg.cyc.data(), cycling, sizeof(int32_t) * nSteps));
+        if (!same) {
+            mg_graph_drop();
+            g_mgg.cyc.assign(cycling, cycling + nSteps);
+            g_mgg.gen = g_state_gen;
+        }
+        if (g_mgg.exec && block_flags() == g_mgg.pre) {
+            HIPCHK(hipGraphLaunch(g_mgg.exec, g_stream));
+            set_block_flags(g_mgg.post);
+            return sync_and_check();
+        }
+        if (g_mgg.exec) {           // other flags than the captured cycle started from: this call runs directly
+            g_mgg.seen = 0;
+        } else if (g_mgg.seen >= 1) {
+            // the previous identical call ran directly (every cache is warm): capture this one
+            HIPCHK(hipStreamSynchronize(g_stream));
+            g_mgg.pre = block_flags();
+            if (hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const bool was = g_async;
+                g_async = true;
+                const int rc = mg_cycle_enqueue(cycling, nSteps);
+                g_async = was;
+                hipGraph_t gr = nullptr;
+                const hipError_t e1 = hipStreamEndCapture(g_stream, &gr);
+                if (rc == 0 && e1 == hipSuccess && gr && hipGraphInstantiate(&g_mgg.exec, gr, nullptr, nullptr, 0) == hipSuccess) {
+                    g_mgg.graph = gr;
+                    g_mgg.post = block_flags();
+                    HIPCHK(hipGraphLaunch(g_mgg.exec, g_stream));
+                    return sync_and_check();
+                }
+                // capture failed: nothing was executed; fall back to the direct path for good
+                if (gr) (void)hipGraphDestroy(gr);
+                (void)hipGetLastError();
+                g_mgg.exec = nullptr;
+                g_mgg.failed = true;
+                if (rc) return rc;
+            } else {
+                (void)hipGetLastError();
+                g_mgg.failed = true;
+            }
+        }
+        ++g_mgg.seen;
+    }
+#endif
     const bool was_async = g_async;
     g_async = true;                 // the whole cycle is enqueued, one sync at the end
+    const int rc = mg_cycle_enqueue(cycling, nSteps);
+    g_async = was_async;
+    if (rc) return rc;
+    return sync_and_check();
+}
+
+static int mg_cycle_enqueue(const int32_t* cycling, int nSteps)
+{
     int level = g_opts.groundLevel;
     int rc = 0;
     for (int n = 0; n < nSteps && !rc; ++n) {
@@ -2820,9 +2953,7 @@ int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
         rc = time_step_level(level, kp);
         if (!rc) rc = enqueue_flow_residual(level, kp);
     }
-    g_async = was_async;
-    if (rc) return rc;
-    return sync_and_check();
+    return rc;
 }
 
 // --------------------------------------------------------- Newton-Krylov glue
@@ -2929,13 +3060,28 @@ static int nk_core_enqueue(bool closuresDone = false)
     return block_res_enqueue(1, flags);
 }
 
+// FormFunction_mf on device vectors (d_rVec may be d_wVec: every entry of w is consumed by setW before the first residual kernel starts)
+static int nk_residual_enqueue(const double* d_wVec, double* d_rVec)
+{
+    if (set_w_dev(d_wVec, true)) return 1;
+    // setRVec rides on the kernels that complete dw (Roe march, SA march) where those run; otherwise its own pass.  Actuator
+    // sources are added to dw behind the core: then the vector is taken from dw afterwards.
+    g_rvec_done = 0;
+    g_rvec_target = (g_nk_fuse && g_act.empty()) ? d_rVec : nullptr;
+    const int rc = nk_core_enqueue(true);
+    g_rvec_target = nullptr;
+    if (rc) return rc;
+    const int need = (g_opts.equations == ADFLOW_RANS) ? 3 : 1;
+    if ((g_rvec_done & need) != need)
+        if (get_r_dev(d_rVec, g_opts.turbResScale, nullptr)) return 1;
+    return 0;
+}
+
 int adflow_gpu_nk_residual_dev(const double* d_wVec, double* d_rVec, long n)
 {
     if (need_ready()) return 1;
     if (!d_wVec || !d_rVec || n != level1_dof()) return fail("nk_residual: n=%ld but the level-1 blocks hold %ld DOF", n, level1_dof());
-    if (set_w_dev(d_wVec, true)) return 1;
-    if (nk_core_enqueue(true)) return 1;
-    if (get_r_dev(d_rVec, g_opts.turbResScale, nullptr)) return 1;
+    if (nk_residual_enqueue(d_wVec, d_rVec)) return 1;
     return sync_and_check();
 }
 
@@ -2945,9 +3091,7 @@ int adflow_gpu_nk_residual(const double* wVec, double* rVec, long n)
     if (!wVec || !rVec || n != level1_dof()) return fail("nk_residual: n=%ld but the level-1 blocks hold %ld DOF", n, level1_dof());
     if (vec_reserve((size_t)n)) return 1;
     HIPCHK(hipMemcpyAsync(g_vec_dev, wVec, sizeof(double) * n, hipMemcpyHostToDevice, g_stream));
-    if (set_w_dev(g_vec_dev, true)) return 1;
-    if (nk_core_enqueue(true)) return 1;
-    if (get_r_dev(g_vec_dev, g_opts.turbResScale, nullptr)) return 1;
+    if (nk_residual_enqueue(g_vec_dev, g_vec_dev)) return 1;
     HIPCHK(hipMemcpyAsync(rVec, g_vec_dev, sizeof(double) * n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     return 0;
@@ -2987,6 +3131,7 @@ int adflow_gpu_sa_solve(int level)
 
 int adflow_gpu_set_turb_bc_callback(adflow_bc_callback fn)
 {
+    ++g_state_gen;
     g_turb_bc_callback = fn;
     return 0;
 }
@@ -3069,6 +3214,7 @@ int adflow_gpu_sync(void)
 
 int adflow_gpu_set_tuning(const char* key, int value)
 {
+    ++g_state_gen;
     if (!key) return fail("null tuning key");
     if (!strcmp(key, "euler_march")) { g_use_march = (value != 0); return 0; }
     if (!strcmp(key, "march_minw")) { g_march_minw = value; return 0; }
@@ -3124,6 +3270,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_gf_tiles.clear();
         return 0;
     }
+    if (!strcmp(key, "nk_fuse")) { g_nk_fuse = value; return 0; }
+    if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);
         g_comm_self = value;

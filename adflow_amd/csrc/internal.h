@@ -295,6 +295,10 @@ struct KParams {
     double sa_updFactor;   // alfaTurb for explicit relaxation, else 1
     double cfl, cflLimit, smoop, fcoll, turbResScale;
     double wInf[10];
+    // matrix-free matvec (adflow_gpu_nk_residual_dev): the kernels that complete dw also write setRVec's entries dw / volRef
+    // (NKSolvers.F90:1262-1376) of the PETSc-ordered residual vector (block offset BlkView::vecOff); NULL otherwise
+    double* rvec;
+    double rvecTurbScale;
 };
 
 // ---- face normals of a cell from its eight corner nodes, the formulas (and operand order) of metric_block
@@ -393,6 +397,7 @@ bool euler_march_radii_capable(const KParams& kp);
 extern int g_euler_radii;
 void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s);
+void adf_note_rvec(int bits);   // api.hip: a launcher reports that its kernel wrote the flow (1) / turbulence (2) part of kp.rvec
 int adf_round_size();          // api.hip: workgroups of a marching kernel resident at a time (2 x CUs)
 void adf_phase_mark(int i);    // api.hip: optional HIP event between the phases of blocketteRes
 void launch_coarse_coordinates_level(const BlkView* ctab, const BlkView* ftab, int nslots, int nx, int ny, int nz, hipStream_t s);

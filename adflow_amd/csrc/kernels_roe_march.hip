@@ -202,7 +202,8 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
 // step k.  The face below row 0 of the tile has no wave: it is the "fifth j face" and wave (k mod 4) takes it in plane k -- it
 // loads the three rows j0-2 .. j0 of that plane, reconstructs cell j0-1 and hands the flux to wave 0 -- so that over four planes
 // every SIMD carries the same load: 3.25 face evaluations and 3.5 reconstructions per cell (4 and 3.5 before).
-template <int LIM, bool FW, bool FINAL, bool ADDV = false>
+// RV (with FINAL, without FW): the completed residual also goes to the matrix-free residual vector kp.rvec as dw / volRef (setRVec)
+template <int LIM, bool FW, bool FINAL, bool ADDV = false, bool RV = false>
 __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, const KParams& kp, int kch,
                                                int bid, double* __restrict__ xj)
 {
@@ -310,6 +311,12 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
             if (out) {
                 const unsigned cw = c - sk;
                 const double blank = flg_blank((uint8_t)flagm);
+                double ovv = 0.0;
+                double* __restrict__ rv = nullptr;
+                if (RV) {
+                    ovv = 1.0 / ldg((GPTR(const double))b.volRef, cw);
+                    rv = kp.rvec + b.vecOff + ((((long)(k - 3) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw);
+                }
 #pragma unroll
                 for (int l = 0; l < 5; ++l) {
                     double d = (acc[l] - fl[l]) + fc[l];
@@ -324,6 +331,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
                         d += fd[l];
                         if (ADDV && l > 0) d += vsum[l - 1];
                         stg(dw + l * nb, cw, d * blank);      // not FINAL: the viscous kernel adds its part to dw(2:5) and re-applies iblank
+                        if (RV) rv[l] = (d * blank) * ovv;
                     }
                 }
             }
@@ -400,12 +408,12 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     }
 }
 
-template <int LIM, bool FW, bool FINAL, bool ADDV = false>
+template <int LIM, bool FW, bool FINAL, bool ADDV = false, bool RV = false>
 __global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                              int kch)
 {
     __shared__ double xj[2 * RM_XJ(FW)];
-    roe_march_body<LIM, FW, FINAL, ADDV>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
+    roe_march_body<LIM, FW, FINAL, ADDV, RV>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
 }
 
 int g_roe_march = 1;       // tuning "roe_march": 0 = k_inviscid_march<upwind> (reconstruction per face) on the fine level too
@@ -423,9 +431,16 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
         if (final_) hipLaunchKernelGGL((k_roe_march<LIM, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else if (kp.viscFirst) {
-        hipLaunchKernelGGL((k_roe_march<LIM, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        if (kp.rvec) {
+            hipLaunchKernelGGL((k_roe_march<LIM, false, true, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+            adf_note_rvec(1);
+        } else
+            hipLaunchKernelGGL((k_roe_march<LIM, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
-        if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        if (final_ && kp.rvec) {
+            hipLaunchKernelGGL((k_roe_march<LIM, false, true, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+            adf_note_rvec(1);
+        } else if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
     }
 }

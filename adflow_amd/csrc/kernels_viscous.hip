@@ -596,7 +596,13 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
                 dvt += sa_diffuse(dj, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
                 dvt += sa_diffuse(di, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
             }
-            if (outC) stg(dw5, c, -ldg(m.volRef, c) * dvt * flg_blank(flags[c >> 3]));
+            if (outC) {
+                const double blank = flg_blank(flags[c >> 3]);
+                stg(dw5, c, -ldg(m.volRef, c) * dvt * blank);
+                // setRVec of the matrix-free matvec: dw / volRef * turbResScale
+                if (!SOLVE && kp.rvec)
+                    kp.rvec[b.vecOff + ((((long)(mm - 2) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw) + 5] = -dvt * blank * kp.rvecTurbScale;
+            }
         }
         // ---- advance the window
         n_m2 = sm1.nut;
@@ -1562,6 +1568,7 @@ void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int n
     node_chunks(nz + 1, &nchn, &kch);
     const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
     hipLaunchKernelGGL((k_sa_march<false>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
+    if (kp.rvec) adf_note_rvec(2);
 }
 
 // the SA residual with the right-hand side and the central jacobian of saSolve (blocks at rest)

@@ -984,7 +984,7 @@ def check_nk_residual(engine, topo, prm, seed=21, bc_spec=None, **mk):
         assert e <= TOL, ("rVec", l, e)
     # getRes (no turbResScale) and setRVec norms
     r2, sf, st = engine.setRVec(wVec.size)
-    assert rel_err(r2, rGpu) == 0.0
+    assert rel_err(r2, rGpu) <= 1e-14       # setRVec as its own pass vs inside the kernels that complete dw: rounding of 1 / volRef
     assert abs(sf - (rf[:, :5] ** 2).sum()) <= 1e-9 * sf
     if nw > 5:
         assert abs(st - (rf[:, 5] ** 2).sum()) <= 1e-9 * max(st, 1e-300)

@@ -66,3 +66,19 @@ def test_mg_3w_cycle_larger_blocks(engine):
     from adflow_amd.topology import BrickTopology
     checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 64, 48, 32), FlowParams(), [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1],
                           ncycles=1, nlevels=3)
+
+
+def test_mg_cycle_graph_replay(engine):
+    """adflow_gpu_mg_cycle captures the second identical cycle into a hipGraph and replays it from the third on (tuning mg_graph):
+    four cycles in a row against the reference, RK W cycle with residual averaging and RANS D-ADI + SA solve; then the same without
+    the graph, and a state upload between the cycles (other block flags than the captured ones: that call runs directly)"""
+    from adflow_amd.params import RANSEquations
+    rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=2)
+    try:
+        for g in (1, 0):
+            engine.set_tuning("mg_graph", g)
+            checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 16, 8, 8), FlowParams(), [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1], ncycles=4,
+                                  nlevels=3)
+            checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 12, 8, 8), rans, [0, 1, 0, -1], ncycles=4, stretch_k=2.5)
+    finally:
+        engine.set_tuning("mg_graph", 1)
