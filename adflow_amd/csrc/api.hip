@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_minw, g_march_kch, g_march_pipe, g_march_by, g_viscous_tiled, g_lines_i_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_visc_gf, g_gf_pf, g_xcd_tiles, g_grad_kch, g_dadi_post_i_fused;
+extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_xcd_tiles, g_grad_kch;
 
 namespace {
 
@@ -29,10 +29,6 @@ hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr;
 hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
-int g_sa_solve_march = 1;  // tuning "sa_solve_march": the residual / jacobian pass of saSolve as the k-marching kernel
-int g_ra_fold_scale = 1;   // tuning "ra_fold_scale": the stage scaling of dw inside the first residual-averaging sweep
-int g_visc_first = 7;      // tuning "visc_first": bit 0 Roe upwind, bit 1 matrix dissipation, bit 2 scalar JST (NS / RANS)
-int g_overlap_grad = 1, g_overlap_sa = 1;     // tuning "overlap_grad" / "overlap_sa": the gradient march / the SA residual on their own queues
 adflow_opts g_opts;
 bool g_have_opts = false;
 hipEvent_t g_events[64];
@@ -126,16 +122,14 @@ double* g_rvec_target = nullptr;     // residual vector the kernels of the evalu
 int g_rvec_done = 0;                  // bit 0: flow entries written, bit 1: turbulence entry written
 long g_state_gen = 0;        // bumped by every call that changes what a multigrid cycle enqueues (options, tuning, blocks, patterns, subfaces)
 int g_mg_graph = 1;         // tuning "mg_graph": a repeated adflow_gpu_mg_cycle is captured once into a hipGraph and replayed
-int g_nk_fuse = 1;          // tuning "nk_fuse": setRVec inside the kernels that complete dw (adflow_gpu_nk_residual_dev)
 int g_comm_self = 0;        // tuning "comm_self": same-process interfaces through pack / RCCL send+recv to self / unpack
 int g_self_rank = 0;        // rank of this process in the RCCL communicator
 std::map<int, BlkView*> g_tab;                        // level -> device table indexed by nn
 std::map<int, int> g_tab_size;
 std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
 std::map<int, std::pair<int4*, int>> g_gf_tiles;       // level -> round-fitted chunk table of k_visc_gf
-int g_gf_fit = 1;           // tuning "gf_fit": k chunks of k_visc_gf fitted to whole rounds of resident workgroups (0: chunks of march_kch planes)
 int g_num_cus = 0;
-int g_skip_unused_radii = 1;                             // tuning "skip_unused_radii"
+int g_gf_nofit = 0;         // tuning gf_cus = -1 (tests): chunks of march_kch planes instead of the round fit
 int g_phase_base = 0;                                    // tuning "phase_events": first of 8 event slots, 0 = off
 bool g_use_march = true;                               // tuning: adflow_gpu_set_tuning("euler_march", 0|1)
 adflow_bc_callback g_bc_callback = nullptr;
@@ -271,7 +265,6 @@ int copy_box(Block* b, double* dev, const double* host_c, int ncomp, int lo_i, i
 }
 
 int g_lumped = 0;       // inputDiscretization::lumpedDiss while a preconditioner matrix is assembled
-int g_visc_approx_march = 1;   // tuning "visc_approx_march": 0 = the gather kernel k_viscous_approx per block
 int g_metric_from_x = 7;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march, bit 2 the time-step kernel re-form the face normals from the node coordinates;
                            // bit 3 the Roe march too (off: that kernel is bound by FP64 issue, the cross products cost more than the 6 loads saved - profiles/r02_ba_variants.txt)
 
@@ -1025,27 +1018,18 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     // inviscid part: one launch for every block of the level (blocks are independent given their halos)
     LevelTab t;
     if (level_tab(level, &t)) return 1;
-    // the nodal-gradient march reads only the state and the metrics: forked onto its own queue BEFORE the inviscid kernel is
-    // enqueued, joined in front of the face-flux kernel
-    const bool viscMarch = kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2 && g_march_by == 4;
-    bool gradForked = false;
-    // viscous march first, Roe march last (tuning "visc_first"): the Roe kernel, bound by FP64 issue, adds the viscous sums it finds
-    // in dw(2:5) instead of the viscous kernel, bound by HBM, reading dw back
-    // (any inviscid kernel over the tile table can take that role: Roe, matrix dissipation, scalar JST of NS / RANS)
+    // exact viscous fluxes of blocks at rest: nodal gradients + face fluxes as ONE marching kernel (k_visc_gf)
+    const bool viscMarch = kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2;
+    // viscous march first, inviscid march last: the inviscid kernel (Roe: bound by FP64 issue) adds the viscous sums it finds in
+    // dw(2:5) instead of the viscous kernel reading dw back.  Any inviscid kernel over the tile table can take that role (Roe,
+    // matrix dissipation, scalar JST of NS / RANS); not with the persistent fw of the Runge-Kutta stages.
     const bool scalarViscM = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
     const bool tileInviscid = inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarViscM) &&
                               (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving;
-    const int vfMask = (kp.spaceDiscr == ADFLOW_UPWIND) ? 1 : (kp.spaceDiscr == ADFLOW_DISS_MATRIX ? 2 : 4);
-    const bool viscFirst = (g_visc_first & vfMask) && viscMarch && !kp.fwMode && tileInviscid &&
-                           !kp.dissApprox && !kp.lumpedDiss;
-    // the same order for the thin-layer viscous march of the preconditioner assembly (no gradient march in front of it)
-    const bool approxFirst = (g_visc_first & vfMask) && viscApprox && g_visc_approx_march && viscous_is_tiled() >= 2 && g_march_by == 4 &&
-                             kp.viscous && fabs(kp.rFil) >= 1.e-10 && !kp.fwMode && tileInviscid;
-    if (viscMarch && !viscFirst && !g_visc_gf && g_overlap && g_overlap_grad && g_phase_base <= 0) {
-        HIPCHK(hipEventRecord(g_evFork, g_stream));
-        HIPCHK(hipStreamWaitEvent(g_streamC, g_evFork, 0));
-        gradForked = true;
-    }
+    const bool viscFirst = viscMarch && !kp.fwMode && tileInviscid && !kp.dissApprox && !kp.lumpedDiss;
+    // the same order for the thin-layer viscous march of the preconditioner assembly (no gradients)
+    const bool approxFirst = viscApprox && viscous_is_tiled() >= 2 && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !kp.fwMode &&
+                             tileInviscid;
     // scalar JST with the entropy sensor (NS / RANS, fine level) also has a marching form, but it is bound by memory like
     // the gather form (1.06 vs 1.10 ms on 8 x 128x128x96): only with tuning inviscid_march = 2
     const bool scalarVisc = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
@@ -1067,7 +1051,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     if (!(kp.viscous && fabs(kp.rFil) >= 1.e-10)) return 0;
     const bool batched = !viscApprox && viscMarch;
     // thin-layer viscous flux of the preconditioner assembly: marching form over the tile table (blocks at rest, 4-row tiles)
-    const bool approxMarch = viscApprox && g_visc_approx_march && viscous_is_tiled() >= 2 && g_march_by == 4 && !anyMoving;
+    const bool approxMarch = viscApprox && viscous_is_tiled() >= 2 && !anyMoving;
     rc = for_level(level, [&](Block* b) {
         if (!b->face_vectors_valid) {
             launch_face_vectors(b->v, g_stream);
@@ -1092,43 +1076,22 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
             launch_visc_march_approx(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
     }
     if (batched) {
-        // k-marching nodal gradients (with the SA residual when the caller left it to this kernel), then the k-marching face
-        // kernel over the level's tile table
+        // gradients and face fluxes in one kernel: the gradients stay in LDS (and go to HBM only when a caller reads them)
+        // (phase marks: 4 .. 5 = nodal gradients + viscous fluxes, 5 .. 6 = inviscid fluxes when they follow; bench.py labels them so)
+        if (ensure_gf_tiles(level)) return 1;
         if (viscFirst) {
             KParams kv = kp;
             kv.viscFirst = 1;
             if (ensure_tiles(level)) return 1;
-            // (phase marks in this order: 4 = nodal gradients, 5 = viscous fluxes, 6 = inviscid fluxes; bench.py labels them so)
-            if (g_visc_gf) {
-                // gradients and face fluxes in one kernel: the gradients stay in LDS (and go to HBM only when a caller reads them)
-                phase_mark(4);
-                if (ensure_gf_tiles(level)) return 1;
-                launch_visc_gf(g_tab[level], g_gf_tiles[level].first, g_gf_tiles[level].second, kv, needGrad, g_stream);
-            } else {
-                launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kv, g_stream);
-                phase_mark(4);
-                launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
-            }
+            phase_mark(4);
+            launch_visc_gf(g_tab[level], g_gf_tiles[level].first, g_gf_tiles[level].second, kv, needGrad, g_stream);
             phase_mark(5);
             if (!launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream))
                 launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
             return 0;
         }
-        if (g_visc_gf) {
-            phase_mark(5);
-            if (ensure_gf_tiles(level)) return 1;
-            launch_visc_gf(g_tab[level], g_gf_tiles[level].first, g_gf_tiles[level].second, kp, needGrad, g_stream);
-            return 0;
-        }
-        hipStream_t sg = gradForked ? g_streamC : g_stream;
-        launch_node_gradients_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, sg);
-        if (gradForked) {
-            HIPCHK(hipEventRecord(g_evC, g_streamC));
-            HIPCHK(hipStreamWaitEvent(g_stream, g_evC, 0));     // join: the face kernel needs the gradients and dw of the inviscid kernel
-        }
         phase_mark(5);
-        if (ensure_tiles(level)) return 1;
-        launch_visc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_stream);
+        launch_visc_gf(g_tab[level], g_gf_tiles[level].first, g_gf_tiles[level].second, kp, needGrad, g_stream);
     }
     return 0;
 }
@@ -1206,11 +1169,11 @@ static int block_res_enqueue(int level, unsigned flags)
     // radii nor dtl are outputs, blockette.F90:660-750)
     bool anyMovingR = false;
     for_level(level, [&](Block* b) { anyMovingR = anyMovingR || b->v.sFace || b->v.moving; return 0; });
-    const bool radiiInMarch = g_skip_unused_radii && kp.onlyRadii && (flags & ADFLOW_RES_FLOW) && g_use_march && !kp.viscous &&
+    const bool radiiInMarch = kp.onlyRadii && (flags & ADFLOW_RES_FLOW) && g_use_march && !kp.viscous &&
                               kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.fineGrid && !kp.dissApprox && !anyMovingR && fabs(kp.rFil) >= 1.e-10 &&
                               euler_march_radii_capable(kp);
     kp.radiiInMarch = radiiInMarch ? 1 : 0;
-    if (!radiiInMarch && !(g_skip_unused_radii && kp.onlyRadii && kp.spaceDiscr != ADFLOW_DISS_SCALAR)) {
+    if (!radiiInMarch && !(kp.onlyRadii && kp.spaceDiscr != ADFLOW_DISS_SCALAR)) {
         rc = time_step_level(level, kp);
         if (rc) return rc;
     }
@@ -1229,7 +1192,7 @@ static int block_res_enqueue(int level, unsigned flags)
             LevelTab t;
             if (level_tab(level, &t)) return 1;
             hipStream_t ss = g_stream;
-            if (g_overlap && g_overlap_sa && g_phase_base <= 0 && (flags & ADFLOW_RES_FLOW)) {
+            if (g_overlap && g_phase_base <= 0 && (flags & ADFLOW_RES_FLOW)) {
                 // fork: the SA residual (writes dw(:,:,:,itu1) only) runs beside the mean-flow kernels; joined below
                 HIPCHK(hipEventRecord(g_evFork, g_stream));
                 HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
@@ -1635,7 +1598,7 @@ int res_averaging_level(int level, const KParams& kp, double scaleDtl)
 {
     if (ensure_table(level)) return 1;
     const LevelDims& ld = g_tab_dims[level];
-    bool fold = (scaleDtl != 0.0) && g_ra_fold_scale;
+    bool fold = (scaleDtl != 0.0);
     for_level(level, [&](Block* b) { fold = fold && b->v.nx > 1; return 0; });
     if (scaleDtl != 0.0 && !fold) launch_scale_dw_level(g_tab[level], g_tab_size[level], ld.nx, ld.ny, ld.nz, scaleDtl, 0, g_stream);
     launch_res_averaging_level(g_tab[level], g_tab_size[level], ld.nx, ld.ny, ld.nz, kp, g_stream, fold ? scaleDtl : 0.0);
@@ -1760,7 +1723,7 @@ int ensure_gf_tiles(int level)
         return t;
     };
     std::vector<int> best;
-    if (g_gf_fit) {
+    if (!g_gf_nofit) {
         double tbest = 1.e300;
         const long Tmax = std::max<long>(N, planes / kmin);
         for (long m = 1; m * W <= Tmax + W; ++m) {
@@ -3067,7 +3030,7 @@ static int nk_residual_enqueue(const double* d_wVec, double* d_rVec)
     // setRVec rides on the kernels that complete dw (Roe march, SA march) where those run; otherwise its own pass.  Actuator
     // sources are added to dw behind the core: then the vector is taken from dw afterwards.
     g_rvec_done = 0;
-    g_rvec_target = (g_nk_fuse && g_act.empty()) ? d_rVec : nullptr;
+    g_rvec_target = g_act.empty() ? d_rVec : nullptr;
     const int rc = nk_core_enqueue(true);
     g_rvec_target = nullptr;
     if (rc) return rc;
@@ -3117,7 +3080,7 @@ int adflow_gpu_sa_solve(int level)
         if (level_tab(level, &t)) return 1;
         bool movingS = false;
         for_level(level, [&](Block* b) { movingS = movingS || b->v.sFace || b->v.moving; return 0; });
-        launch_sa_solve_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream, g_sa_march == 1 && g_sa_solve_march && !movingS);
+        launch_sa_solve_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream, g_sa_march == 1 && !movingS);
         if (turb_bc_apply_enqueue(level, kp, 1)) return 1;
         if (g_turb_bc_callback) {
             HIPCHK(hipStreamSynchronize(g_stream));
@@ -3195,7 +3158,7 @@ int adflow_gpu_march_stats(int level, double* out, int n)
         // tile table (k_roe_march, k_visc_march, ...): 60 columns x march_by rows x march_kch planes, kch + 1 trips per chunk
         int ntx, nty, ntz;
         euler_march_tiles(v, &ntx, &nty, &ntz);
-        out[2] += (double)g_march_by * ntx * nty * (v.nz + ntz);
+        out[2] += 4.0 * ntx * nty * (v.nz + ntz);
         // SA / nodal-gradient marches: nz + 1 node planes in balanced chunks of <= grad_kch, kch + 1 trips per chunk, 4 rows
         const int nzn = v.nz + 1, L = g_grad_kch > 0 ? g_grad_kch : 32, nch = (nzn + L - 1) / L, kch = (nzn + nch - 1) / nch;
         out[0] += 4.0 * ((v.nx + 1 + 59) / 60) * ((v.ny + 1 + 3) / 4) * nch * (kch + 1);
@@ -3217,33 +3180,12 @@ int adflow_gpu_set_tuning(const char* key, int value)
     ++g_state_gen;
     if (!key) return fail("null tuning key");
     if (!strcmp(key, "euler_march")) { g_use_march = (value != 0); return 0; }
-    if (!strcmp(key, "march_minw")) { g_march_minw = value; return 0; }
-    if (!strcmp(key, "march_pipe") || !strcmp(key, "march_by")) {
-        if (!strcmp(key, "march_by")) {
-            if (value != 4 && value != 8) return fail("march_by must be 4 or 8");
-            g_march_by = value;
-        } else
-            g_march_pipe = value;
-        if (g_stream) (void)hipStreamSynchronize(g_stream);
-        for (auto& kv : g_tiles) (void)hipFree(kv.second.first);   // tile tables depend on the rows per workgroup
-        g_tiles.clear();
-        return 0;
-    }
     if (!strcmp(key, "viscous_tiled")) { g_viscous_tiled = value; return 0; }
     if (!strcmp(key, "inviscid_march")) { g_inviscid_march = value; return 0; }
     if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
     if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
-    if (!strcmp(key, "visc_gf")) { g_visc_gf = value; return 0; }
-    if (!strcmp(key, "gf_pf")) { g_gf_pf = value; return 0; }
     if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
-    if (!strcmp(key, "overlap_grad")) { g_overlap_grad = value; return 0; }
-    if (!strcmp(key, "visc_first")) { g_visc_first = value; return 0; }
-    if (!strcmp(key, "ra_fold_scale")) { g_ra_fold_scale = value; return 0; }
-    if (!strcmp(key, "sa_solve_march")) { g_sa_solve_march = value; return 0; }
-    if (!strcmp(key, "overlap_sa")) { g_overlap_sa = value; return 0; }
     if (!strcmp(key, "max_grid_z")) { g_max_grid_z = (value > 0) ? value : 65535; return 0; }
-    if (!strcmp(key, "euler_radii")) { g_euler_radii = value; return 0; }
-    if (!strcmp(key, "visc_approx_march")) { g_visc_approx_march = value; return 0; }
     if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }
     if (!strcmp(key, "xcd_tiles")) {
         g_xcd_tiles = value;
@@ -3253,14 +3195,11 @@ int adflow_gpu_set_tuning(const char* key, int value)
         return 0;
     }
     if (!strcmp(key, "grad_kch")) { g_grad_kch = value; return 0; }
-    if (!strcmp(key, "dadi_post_i_fused")) { g_dadi_post_i_fused = value; return 0; }
-    if (!strcmp(key, "skip_unused_radii")) { g_skip_unused_radii = value; return 0; }
     if (!strcmp(key, "phase_events")) {
         if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");
         g_phase_base = value;
         return 0;
     }
-    if (!strcmp(key, "lines_i_tiled")) { g_lines_i_tiled = value; return 0; }
     if (!strcmp(key, "march_kch")) {
         if (value < 4) return fail("march_kch must be >= 4");
         g_march_kch = value;
@@ -3270,7 +3209,6 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_gf_tiles.clear();
         return 0;
     }
-    if (!strcmp(key, "nk_fuse")) { g_nk_fuse = value; return 0; }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);
@@ -3278,9 +3216,10 @@ int adflow_gpu_set_tuning(const char* key, int value)
         for (auto& kv : g_comm) drop_comm_lists(kv.second);        // rebuilt at the next exchange
         return 0;
     }
-    if (!strcmp(key, "gf_fit") || !strcmp(key, "gf_cus")) {
-        if (!strcmp(key, "gf_fit")) g_gf_fit = value;
-        else g_num_cus = value;                                      // tests: the round size on a device with `value` CUs
+    if (!strcmp(key, "gf_cus")) {
+        // tests: the round size on a device with `value` CUs (0 = ask the device; -1 = chunks of march_kch planes, no fitting)
+        g_gf_nofit = (value < 0);
+        g_num_cus = value > 0 ? value : 0;
         if (g_stream) (void)hipStreamSynchronize(g_stream);
         for (auto& kv : g_gf_tiles) (void)hipFree(kv.second.first);
         g_gf_tiles.clear();

@@ -114,164 +114,6 @@ __device__ __forceinline__ double em_sensor(double sm, double s0, double sp, dou
     return fabs((sp - 2.0 * s0 + sm) / (sp + 2.0 * s0 + sm + sslim));
 }
 
-// MINW: minimum waves per SIMD requested from the register allocator (2: 256
-// VGPRs, no spills; 3: 168 VGPRs; 4: 128 VGPRs) — selectable for A/B runs
-// FW: persistent dissipation residual fw of the Runge-Kutta scheme is read/written
-template <int MINW, bool FW>
-__global__ __launch_bounds__(64 * EM_BY, MINW) void k_euler_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
-                                                           KParams kp, int kch)
-{
-    const int4 t = tiles[blockIdx.x];           // x: block slot, y/z/w: tile coordinates
-    if (t.x < 0) return;                        // padding entry of the XCD-ordered table
-    const BlkView& b = tab[t.x];
-    const int lane = threadIdx.x;
-    const int i = t.y * EM_OUT + lane;          // columns i0-2 .. i0+61, i0 = 2 + 60*tx
-    const int j = 2 + t.z * EM_BY + (int)threadIdx.y;
-    const int k0 = 2 + t.w * kch;
-    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
-    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
-    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jl) ? j : b.jl;   // clamped: every lane takes part in the shuffles
-    const long nb = b.nbox;
-    const unsigned sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;   // strides in bytes
-    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);           // byte offset of the column at plane k
-
-    EmPtrs m;
-    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w4 = m.w3 + nb;
-    m.p = (GPTR(const double))b.p;
-    GPTR(const double) radI = (GPTR(const double))b.radI;
-    GPTR(const double) radJ = (GPTR(const double))b.radJ;
-    GPTR(const double) radK = (GPTR(const double))b.radK;
-    GPTR(const double) sIx = (GPTR(const double))b.sI; GPTR(const double) sIy = sIx + nb; GPTR(const double) sIz = sIy + nb;
-    GPTR(const double) sJx = (GPTR(const double))b.sJ; GPTR(const double) sJy = sJx + nb; GPTR(const double) sJz = sJy + nb;
-    GPTR(const double) sKx = (GPTR(const double))b.sK; GPTR(const double) sKy = sKx + nb; GPTR(const double) sKz = sKy + nb;
-    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
-    GPTR(double) dw = (GPTR(double))b.dw;
-    GPTR(double) fw = (GPTR(double))b.fw;
-    GPTR(const double) wr = (GPTR(const double))b.wr;
-    const unsigned fl_shift = 3;   // flags are bytes: element index = byte offset >> 3
-
-    const double sslim = 0.001 * kp.pInfCorr;
-    const double fis2 = kp.rFil * kp.vis2, fis4 = kp.rFil * kp.vis4;
-    const bool doDiss = fabs(kp.rFil) >= 1.e-10;
-
-    // 4-plane window k-2 .. k+1 of the own column
-    Cell qm2 = ld_cell(m, c - 2 * sk), qm1 = ld_cell(m, c - sk), q0 = ld_cell(m, c);
-    double radKm = ldg(radK, c - sk);
-    int flagm = flags[(c - sk) >> fl_shift];                   // flags of cell k-1 (porK of the face below cell k)
-    double dssKm = em_sensor(qm2.p, qm1.p, q0.p, sslim);   // k-sensor of cell k-1, carried along the march
-    double accC[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};   // cell k-1: central / dissipative partial sums
-
-    for (int k = k0; k <= k1 + 1; ++k) {
-        const Cell qp1 = ld_cell(m, c + sk);
-        const int flag0 = flags[c >> fl_shift];
-        const double radK0 = ldg(radK, c);
-        const double dssK0 = em_sensor(qm1.p, q0.p, qp1.p, sslim);
-        // ---- k-face between cells k-1 and k: normal and porosity stored at cell k-1
-        double fc[5], fd[5] = {0, 0, 0, 0, 0};
-        {
-            const double sx = ldg(sKx, c - sk), sy = ldg(sKy, c - sk), sz = ldg(sKz, c - sk);
-            const int por = flg_porK((uint8_t)flagm);
-            em_central(qm1, q0, sx, sy, sz, por, fc);
-            if (doDiss) {
-                const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * (radKm + radK0);
-                em_jst(cons_of(qm2), cons_of(qm1), cons_of(q0), cons_of(qp1), rrad, dssKm, dssK0, fis2, fis4, fd);
-            }
-        }
-        // ---- finish cell k-1 (left of the face) and write it
-        if (k > k0 && out) {
-            const unsigned cw = c - sk;
-            const double blank = flg_blank((uint8_t)flagm);
-#pragma unroll
-            for (int l = 0; l < 5; ++l) {
-                double fwn = accD[l] - fd[l];
-                if (FW) {
-                    const double old = ldg(fw + l * nb, cw);
-                    fwn = doDiss ? (kp.sfil * old + fwn) : old;
-                    if (doDiss) stg(fw + l * nb, cw, fwn);
-                }
-                double d = accC[l] + fc[l];
-                if (kp.coarseInit) d += ldg(wr + l * nb, cw);
-                stg(dw + l * nb, cw, (d + fwn) * blank);
-            }
-        }
-        if (k > k1) break;
-        // ---- start cell k (right of the k-face)
-#pragma unroll
-        for (int l = 0; l < 5; ++l) { accC[l] = -fc[l]; accD[l] = fd[l]; }
-
-        // ---- i-direction: this lane evaluates the face between i-1 and i, the face
-        //      between i and i+1 comes from lane+1
-        {
-            const Cell qL = shfl_cell_up(q0, 1);
-            const Cons W0 = cons_of(q0);
-            const Cons WL = cons_of(qL);
-            const Cons WLL = shfl_cons(W0, 2, true);
-            const Cons WR = shfl_cons(W0, 1, false);
-            const double sx = ldg(sIx, c - 8u), sy = ldg(sIy, c - 8u), sz = ldg(sIz, c - 8u);
-            const int flagL = lane_up1(flag0);
-            const int por = flg_porI((uint8_t)flagL);
-            double gc[5], gd[5] = {0, 0, 0, 0, 0};
-            em_central(qL, q0, sx, sy, sz, por, gc);
-            if (doDiss) {
-                const double pR = lane_dn1(q0.p);
-                const double d0 = em_sensor(qL.p, q0.p, pR, sslim);
-                const double dL = lane_up1(d0);
-                const double rad0 = ldg(radI, c);
-                const double radL = lane_up1(rad0);
-                const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * (radL + rad0);
-                em_jst(WLL, WL, W0, WR, rrad, dL, d0, fis2, fis4, gd);
-            }
-#pragma unroll
-            for (int l = 0; l < 5; ++l) {
-                if (FW) {
-                    const double gcP = lane_dn1(gc[l]);
-                    const double gdP = lane_dn1(gd[l]);
-                    accC[l] += gcP - gc[l];      // + plus face, - minus face
-                    accD[l] += gd[l] - gdP;      // fw(R) += f : minus face adds, plus face subtracts
-                } else {
-                    // no persistent fw: only the net contribution N = D - F matters
-                    // (right cell += N, left cell -= N): one hand-over per component
-                    const double n = gd[l] - gc[l];
-                    accD[l] += n - lane_dn1(n);
-                }
-            }
-        }
-        // ---- j-direction: both faces of the cell, neighbours through L1/L2
-        {
-            const Cell qa = ld_cell(m, c - 2 * sj), qb = ld_cell(m, c - sj), qc = ld_cell(m, c + sj), qd = ld_cell(m, c + 2 * sj);
-            const int porM = flg_porJ(flags[(c - sj) >> fl_shift]), porP = flg_porJ((uint8_t)flag0);
-            double hc[5], hd[5];
-            // minus face (j-1 | j): normal at cell j-1
-            em_central(qb, q0, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, hc);
-#pragma unroll
-            for (int l = 0; l < 5; ++l) accC[l] -= hc[l];
-            em_central(q0, qc, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, hc);
-#pragma unroll
-            for (int l = 0; l < 5; ++l) accC[l] += hc[l];
-            if (doDiss) {
-                const double dm = em_sensor(qa.p, qb.p, q0.p, sslim), d0 = em_sensor(qb.p, q0.p, qc.p, sslim),
-                             dp = em_sensor(q0.p, qc.p, qd.p, sslim);
-                const double r0 = ldg(radJ, c);
-                const double rrM = (porM == ADF_POR_NORMAL ? 0.5 : 0.0) * (ldg(radJ, c - sj) + r0);
-                const double rrP = (porP == ADF_POR_NORMAL ? 0.5 : 0.0) * (r0 + ldg(radJ, c + sj));
-                const Cons Wa = cons_of(qa), Wb = cons_of(qb), W0 = cons_of(q0), Wc = cons_of(qc), Wd = cons_of(qd);
-                em_jst(Wa, Wb, W0, Wc, rrM, dm, d0, fis2, fis4, hd);
-#pragma unroll
-                for (int l = 0; l < 5; ++l) accD[l] += hd[l];
-                em_jst(Wb, W0, Wc, Wd, rrP, d0, dp, fis2, fis4, hd);
-#pragma unroll
-                for (int l = 0; l < 5; ++l) accD[l] -= hd[l];
-            }
-        }
-        // ---- advance the window
-        qm2 = qm1; qm1 = q0; q0 = qp1;
-        radKm = radK0;
-        dssKm = dssK0;
-        flagm = flag0;
-        c += sk;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Software-pipelined form of the same march.  One plane of the march is split
 // in two phases, each with its own set of global loads:
@@ -670,52 +512,26 @@ __global__ __launch_bounds__(64 * BY, 2) void k_euler_march_p(const BlkView* __r
     kface(true, S0, S1, S2, S3);
 }
 
-int g_euler_radii = 1;          // tuning "euler_radii": the Euler march forms the spectral radii itself where nothing else needs them
-int g_march_minw = 2;
 int g_march_kch = EM_KCH;      // k-chunk length of a tile (tuning "march_kch")
-int g_march_pipe = 2;          // tuning "march_pipe": 0 plain, 1 software-pipelined, 2 pipelined + state rows shared through LDS
-int g_march_by = EM_BY;        // tuning "march_by": 4 or 8 rows of cells per workgroup (8 only with march_pipe = 2)
-static int march_rows() { return (g_march_pipe >= 2 && g_march_by == 8) ? 8 : EM_BY; }
+static int march_rows() { return EM_BY; }
 
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;
     const dim3 blk(64, EM_BY, 1);
-    if (g_march_pipe) {
-        if (g_march_pipe >= 2 && march_rows() == 8) {
-            const dim3 blk8(64, 8, 1);
-            if (kp.fwMode)
-                hipLaunchKernelGGL((k_euler_march_p<true, true, 8>), dim3(ntiles), blk8, 0, s, tab, tiles, kp, g_march_kch);
-            else
-                hipLaunchKernelGGL((k_euler_march_p<false, true, 8>), dim3(ntiles), blk8, 0, s, tab, tiles, kp, g_march_kch);
-        } else if (g_march_pipe >= 2) {
-            if (kp.fwMode)
-                hipLaunchKernelGGL((k_euler_march_p<true, true, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-            else if (kp.radiiInMarch) {
-#ifdef HOSTSIM
-                if (getenv("ADF_TRACE_WS")) fprintf(stderr, "launch_euler_march: radii inside the march, ntiles=%d\n", ntiles);
-#endif
-                hipLaunchKernelGGL((k_euler_march_p<false, true, EM_BY, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-            } else
-                hipLaunchKernelGGL((k_euler_march_p<false, true, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-        } else if (kp.fwMode)
-            hipLaunchKernelGGL((k_euler_march_p<true, false, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-        else
-            hipLaunchKernelGGL((k_euler_march_p<false, false, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-    } else if (kp.fwMode) {
-        hipLaunchKernelGGL((k_euler_march<2, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-    } else if (g_march_minw >= 3) {
-        hipLaunchKernelGGL((k_euler_march<3, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-    } else {
-        hipLaunchKernelGGL((k_euler_march<2, false>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
-    }
+    if (kp.fwMode)
+        hipLaunchKernelGGL((k_euler_march_p<true, true, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+    else if (kp.radiiInMarch)
+        hipLaunchKernelGGL((k_euler_march_p<false, true, EM_BY, true>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
+    else
+        hipLaunchKernelGGL((k_euler_march_p<false, true, EM_BY>), dim3(ntiles), blk, 0, s, tab, tiles, kp, g_march_kch);
 }
 
 // true when launch_euler_march would run the form of the kernel that can compute the radii itself
 bool euler_march_radii_capable(const KParams& kp)
 {
     // fast_powa is built for moderate exponents (2^(adis log2 r) must stay far from the ends of the exponent range)
-    return g_euler_radii && g_march_pipe >= 2 && march_rows() == EM_BY && !kp.fwMode && (!kp.doScaling || (kp.adis > 0.0 && kp.adis <= 2.0));
+    return !kp.fwMode && (!kp.doScaling || (kp.adis > 0.0 && kp.adis <= 2.0));
 }
 
 // tile decomposition of one block for the table built by the host

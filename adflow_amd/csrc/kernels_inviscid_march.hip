@@ -291,6 +291,5 @@ void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, co
     else launch_im<ADFLOW_DISS_SCALAR>(tab, tiles, ntiles, kp, g_march_kch, s);     // NS / RANS on the fine level only (caller)
 }
 
-extern int g_march_by, g_march_pipe;
 // the shared tile table has IM_BY rows per tile unless the Euler kernel was switched to 8 rows (tuning march_by)
-int inviscid_march_enabled() { return (g_march_pipe >= 2 && g_march_by == 8) ? 0 : g_inviscid_march; }
+int inviscid_march_enabled() { return g_inviscid_march; }

@@ -374,7 +374,6 @@ __global__ __launch_bounds__(64) void k_sa_solve_i(const BlkView* __restrict__ t
     }
 }
 
-extern int g_lines_i_tiled;
 
 // marchRes: residual, right-hand side and central jacobian from the k-marching kernel (blocks at rest) instead of the gather kernel
 void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, bool marchRes)
@@ -388,13 +387,8 @@ void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int n
     dim3 l64(64, 1, 1);
     // sweep order of the reference: j, i, k
     hipLaunchKernelGGL((k_sa_sweep<1>), dim3((nx + 63) / 64, nz, nslots), l64, 0, s, tab, kp, 0);
-    if (g_lines_i_tiled) {
-        hipLaunchKernelGGL(k_sa_rows_i, grd, blk, 0, s, tab, nz, kp);
-        hipLaunchKernelGGL(k_sa_solve_i, dim3((ny + 63) / 64, nz, nslots), l64, 0, s, tab);
-    } else {
-        // i lines one block at a time (uncoalesced, see launch_dadi_level)
-        for (int m = 0; m < nslots; ++m) hipLaunchKernelGGL((k_sa_sweep<0>), dim3((ny + 63) / 64, nz, 1), l64, 0, s, tab, kp, m);
-    }
+    hipLaunchKernelGGL(k_sa_rows_i, grd, blk, 0, s, tab, nz, kp);
+    hipLaunchKernelGGL(k_sa_solve_i, dim3((ny + 63) / 64, nz, nslots), l64, 0, s, tab);
     hipLaunchKernelGGL((k_sa_sweep<2>), dim3((nx + 63) / 64, ny, nslots), l64, 0, s, tab, kp, 0);
 }
 

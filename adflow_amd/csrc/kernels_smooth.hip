@@ -972,8 +972,6 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_dadi_post_i(const BlkView* __r
     for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
 }
 
-int g_dadi_post_i_fused = 1;  // tuning "dadi_post_i_fused": the transform after the i-solve inside the k sweep
-int g_lines_i_tiled = 1;      // tuning "lines_i_tiled": 0 = one-line-per-lane i sweeps (D-ADI and SA), block after block
 
 // computedwDADI incl. the -cfl*dtl*vol scaling of executeDADIStep
 void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
@@ -982,18 +980,12 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
     if (nslots <= 0) return;
     dim3 blk(64, 1, 1);
     hipLaunchKernelGGL((k_dadi_sweep<1>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
-    if (g_lines_i_tiled) {
+    // i direction: rows pointwise, Thomas per (line, equation) through LDS tiles; the transform behind the i-solve is applied
+    // by the k sweep as it loads the update
+    if (nx > 1) {
         const dim3 pg((nx + SM_BX - 1) / SM_BX, (ny + SM_BY - 1) / SM_BY, nz * nslots), pb(SM_BX, SM_BY, 1);
-        if (nx > 1) {
-            hipLaunchKernelGGL(k_dadi_rows_i, pg, pb, 0, s, tab, nz, kp);
-            hipLaunchKernelGGL(k_dadi_solve_i, dim3(5 * ((ny + 63) / 64), nz, nslots), blk, 0, s, tab, kp);
-        }
-        if (!g_dadi_post_i_fused) hipLaunchKernelGGL(k_dadi_post_i, pg, pb, 0, s, tab, nz);
-    } else {
-        // lines along i put the lanes on j (stride ldi): with every block in flight at once these uncoalesced
-        // sweeps thrash the L2 (measured 10.0 ms batched vs 8 x 0.86 ms one block at a time): block after block
-        for (int m = 0; m < nslots; ++m) hipLaunchKernelGGL((k_dadi_sweep<0>), dim3((ny + 63) / 64, nz, 1), blk, 0, s, tab, kp, m);
+        hipLaunchKernelGGL(k_dadi_rows_i, pg, pb, 0, s, tab, nz, kp);
+        hipLaunchKernelGGL(k_dadi_solve_i, dim3(5 * ((ny + 63) / 64), nz, nslots), blk, 0, s, tab, kp);
     }
-    if (g_lines_i_tiled && g_dadi_post_i_fused) hipLaunchKernelGGL((k_dadi_sweep<2, true>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
-    else hipLaunchKernelGGL((k_dadi_sweep<2>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+    hipLaunchKernelGGL((k_dadi_sweep<2, true>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
 }

@@ -108,120 +108,15 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
 }
 
 // ---------------------------------------------------------------------------
-// k-marching form of the nodal-gradient kernel (tuning "viscous_tiled" >= 2).  k_nodal_gradients_t reads 19 static
-// sums per node (152 B) next to ~6 state values and is bound by that traffic.  The dual-cell surface integral factorises:
-// with the per-CELL vectors  tI = sI(i-1) + sI(i),  tJ = sJ(j-1) + sJ(j),  tK = sK(k-1) + sK(k)  the normal of the
-// integration point of direction k at cell plane m is the sum of tK over the 2 x 2 cells around the node column, the one of
-// direction j at cell row m the sum of tJ over (i..i+1) x (k..k+1), and likewise for i; the averaged state is the sum of
-// (u, v, w, -a^2) over the same four cells.  So a thread marching in k needs, per plane, ONE cell record (5 state values,
-// the 9 face normals stored at the cell, sJ(j-1), vol; sI(i-1) by a DPP lane shift, sK(k-1) carried) and the record of the
-// cell above it in j, which the neighbouring wave publishes through LDS; the i-neighbour comes by DPP, the k-neighbour is
-// the next plane.  ~19 loads and 12 stores per node instead of ~45 loads, no static nsum array (-152 B per node).
-// The sums are formed in a different order than the reference's (flowUtils.F90:1712-1979): results agree to rounding.
-// Mapping: workgroup = 64 lanes (cells i0-1 .. i0+62, producing nodes i0 .. i0+61) x 4 rows, NG_KCH node planes per march.
+// The dual-cell surface integral of allNodalGradients (flowUtils.F90:1712-1979) factorises: with the per-CELL vectors
+// tI = sI(i-1) + sI(i), tJ = sJ(j-1) + sJ(j), tK = sK(k-1) + sK(k) the normal of the integration point of direction k at cell plane m is
+// the sum of tK over the 2 x 2 cells around the node column, the one of direction j at cell row m the sum of tJ over
+// (i..i+1) x (k..k+1), and likewise for i; the averaged state is the sum of (u, v, w, -a^2) over the same four cells.  A thread
+// marching in k needs one cell record per plane and row (k_visc_gf below); the sums are formed in another order than the
+// reference's: results agree to rounding.
 // ---------------------------------------------------------------------------
-#define NG_OUT 62
 #define NG_BY 4
 #define NG_KCH 32
-#define NG_NV 14                        // published values per cell and plane
-#define NG_SLOT (NG_NV * 64)
-
-struct NgRec { double tI[3], phi[4], sTK[3], sV, sTJ[3]; };
-
-struct NgPtrs {
-    GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) p;
-    GPTR(const double) sI; GPTR(const double) sJ; GPTR(const double) sK; GPTR(const double) vol;
-    unsigned nb8;       // byte stride between the components of a vector array
-    unsigned sj;        // byte stride of one row
-    GPTR(const double) x; double mfact;     // node coordinates and the cross-product factor (normals re-formed from the nodes)
-};
-
-__device__ __forceinline__ void ngx_load(const NgPtrs& m, unsigned c, NgNodes& n) { ngx_load_x(m.x, c, m.nb8, m.sj, n); }
-
-// raw values of the cell at byte offset c (the loads of ng_record, issued early by the wave-specialised kernel)
-struct NgRaw { double rho, u, v, w, p, sI[3], sJm[3], sJ[3], sK[3], vol; };
-
-__device__ __forceinline__ void ng_load_state(const NgPtrs& m, unsigned c, NgRaw& q)
-{
-    q.rho = ldg(m.w0, c); q.u = ldg(m.w1, c); q.v = ldg(m.w2, c); q.w = ldg(m.w3, c); q.p = ldg(m.p, c);
-    q.vol = ldg(m.vol, c);
-}
-
-__device__ __forceinline__ void ng_load(const NgPtrs& m, unsigned c, NgRaw& q)
-{
-    q.rho = ldg(m.w0, c); q.u = ldg(m.w1, c); q.v = ldg(m.w2, c); q.w = ldg(m.w3, c); q.p = ldg(m.p, c);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        q.sI[d] = ldg(m.sI, c + d * m.nb8);
-        q.sJm[d] = ldg(m.sJ, c - m.sj + d * m.nb8);
-        q.sJ[d] = ldg(m.sJ, c + d * m.nb8);
-        q.sK[d] = ldg(m.sK, c + d * m.nb8);
-    }
-    q.vol = ldg(m.vol, c);
-}
-
-// record from the raw values; sKp: sK of the plane below (in), of this plane (out)
-__device__ __forceinline__ void ng_finish(const NgRaw& q, double gam, double sKp[3], NgRec& R)
-{
-    R.phi[0] = q.u; R.phi[1] = q.v; R.phi[2] = q.w;
-    R.phi[3] = -(gam * q.p) * rcp_nr(q.rho);              // minus the speed of sound squared (heat flux sign)
-    double tJ[3], tK[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        R.tI[d] = lane_up1(q.sI[d]) + q.sI[d];
-        tJ[d] = q.sJm[d] + q.sJ[d];
-        tK[d] = sKp[d] + q.sK[d];
-        sKp[d] = q.sK[d];
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        R.sTJ[d] = tJ[d] + lane_dn1(tJ[d]);
-        R.sTK[d] = tK[d] + lane_dn1(tK[d]);
-    }
-    R.sV = q.vol + lane_dn1(q.vol);
-}
-
-// record of the cell at byte offset c; sKp: sK of the plane below (in), of this plane (out)
-__device__ __forceinline__ void ng_record(const NgPtrs& m, unsigned c, double gam, double sKp[3], NgRec& R)
-{
-    NgRaw q;
-    ng_load(m, c, q);
-    ng_finish(q, gam, sKp, R);
-}
-
-// the same with the face normals re-formed from the nodes; P: nodes of the plane below (in), of this plane (out)
-__device__ __forceinline__ void ng_record_x(const NgPtrs& m, unsigned c, double gam, double sKp[3], NgNodes& P, NgRec& R)
-{
-    NgRaw q;
-    NgNodes N;
-    ng_load_state(m, c, q);
-    ngx_load(m, c, N);
-    ngx_normals(m.mfact, P, N, q.sI, q.sJm, q.sJ, q.sK);
-    P = N;
-    ng_finish(q, gam, sKp, R);
-}
-
-__device__ __forceinline__ void ng_publish(double* __restrict__ x, int lane, const NgRec& R)
-{
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { x[d * 64 + lane] = R.tI[d]; x[(7 + d) * 64 + lane] = R.sTK[d]; x[(11 + d) * 64 + lane] = R.sTJ[d]; }
-#pragma unroll
-    for (int d = 0; d < 4; ++d) x[(3 + d) * 64 + lane] = R.phi[d];
-    x[10 * 64 + lane] = R.sV;
-}
-
-__device__ __forceinline__ void ng_fetch(const double* __restrict__ x, int lane, NgRec& R)
-{
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { R.tI[d] = x[d * 64 + lane]; R.sTK[d] = x[(7 + d) * 64 + lane]; R.sTJ[d] = x[(11 + d) * 64 + lane]; }
-#pragma unroll
-    for (int d = 0; d < 4; ++d) R.phi[d] = x[(3 + d) * 64 + lane];
-    R.sV = x[10 * 64 + lane];
-}
-
-// sums of one cell plane around the node column of the thread: P (direction k), Q0 / Q1 (direction j at the own row / the row
-// above), RI (direction i at the own column; the column i+1 comes by DPP when used), V (volumes)
-struct NgPlane { double Pt[3], Pp[4], Q0t[3], Q0p[4], Q1t[3], Q1p[4], RIt[3], RIp[4], V; };
 
 // g += sign * 0.25 * phi (x) t
 __device__ __forceinline__ void ng_outer(double g[12], double sign, const double ph[4], const double t[3])
@@ -231,115 +126,6 @@ __device__ __forceinline__ void ng_outer(double g[12], double sign, const double
         const double a = sign * 0.25 * ph[v];
 #pragma unroll
         for (int d = 0; d < 3; ++d) g[3 * v + d] += a * t[d];
-    }
-}
-
-// body of the kernel for the workgroup (bx, by, bz) of its grid; xr: 2 * NG_BY * NG_SLOT doubles of LDS owned by the caller
-template <bool XN>
-__device__ __forceinline__ void node_grad_body(const BlkView* __restrict__ tab, int nzb, double gam, int bx, int by, int bz,
-                                               double* __restrict__ xr, int kch = NG_KCH)
-{
-    constexpr bool xn = XN;          // face normals re-formed from the node coordinates (tuning metric_from_x & 2: not faster here)
-    const BlkView& b = tab[bz / nzb + 1];                 // level-batched: bz = slot * nzb + k chunk
-    const int lane = threadIdx.x, row = threadIdx.y;
-    const int i0 = bx * NG_OUT + 1, j0 = by * NG_BY + 1;      // first node of the tile
-    const int kn0 = (bz % nzb) * kch + 1;
-    if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
-    const int kn1 = (kn0 + kch - 1 < b.kl) ? kn0 + kch - 1 : b.kl;
-    const int i = i0 - 1 + lane, j = j0 + row;
-    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
-    const int jx = (j0 + NG_BY < b.jb) ? j0 + NG_BY : b.jb;                    // cell row above the tile (record made by wave 0)
-    const bool out = (lane >= 1 && lane <= NG_OUT && i <= b.il && j <= b.jl);
-    const long nb = b.nbox;
-    NgPtrs m;
-    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
-    m.p = (GPTR(const double))b.p;
-    m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
-    m.vol = (GPTR(const double))b.vol;
-    m.nb8 = 8u * (unsigned)nb; m.sj = 8u * (unsigned)b.ldi;
-    m.x = (GPTR(const double))b.x; m.mfact = b.mfact;
-    GPTR(double) grad = (GPTR(double))b.grad;
-    const unsigned sk = 8u * (unsigned)b.ldk;
-    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + kn0 * b.ldk);
-    unsigned cx = 8u * (unsigned)(ic + jx * b.ldi + kn0 * b.ldk);
-    double sKp[3], sKpx[3];
-    NgNodes Pn, Pnx;            // xn: nodes of the plane below, own row and the row above the tile
-    if (xn) {
-        ngx_load(m, c - sk, Pn); ngx_load(m, cx - sk, Pnx);
-        ngx_normal_k(m.mfact, Pn, sKp); ngx_normal_k(m.mfact, Pnx, sKpx);
-    } else {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { sKp[d] = ldg(m.sK, c - sk + d * m.nb8); sKpx[d] = ldg(m.sK, cx - sk + d * m.nb8); }
-    }
-    NgPlane S;       // sums of the previous cell plane
-    for (int mm = kn0; mm <= kn1 + 1; ++mm) {
-        double* __restrict__ xb = xr + ((mm - kn0) & 1) * (NG_BY * NG_SLOT);
-        NgRec R;
-        if (xn) ng_record_x(m, c, gam, sKp, Pn, R);
-        else ng_record(m, c, gam, sKp, R);
-        if (row > 0) ng_publish(xb + (row - 1) * NG_SLOT, lane, R);
-        if (row == 0) {
-            NgRec X;
-            if (xn) ng_record_x(m, cx, gam, sKpx, Pnx, X);
-            else ng_record(m, cx, gam, sKpx, X);
-            ng_publish(xb + (NG_BY - 1) * NG_SLOT, lane, X);
-        }
-        __syncthreads();
-        NgRec U;                       // the cell above in j
-        ng_fetch(xb + row * NG_SLOT, lane, U);
-        NgPlane N;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            N.Pt[d] = R.sTK[d] + U.sTK[d];
-            N.Q0t[d] = R.sTJ[d]; N.Q1t[d] = U.sTJ[d];
-            N.RIt[d] = R.tI[d] + U.tI[d];
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            N.Q0p[v] = R.phi[v] + lane_dn1(R.phi[v]);
-            N.Q1p[v] = U.phi[v] + lane_dn1(U.phi[v]);
-            N.Pp[v] = N.Q0p[v] + N.Q1p[v];
-            N.RIp[v] = R.phi[v] + U.phi[v];
-        }
-        N.V = R.sV + U.sV;
-        if (mm > kn0) {
-            // node plane mm-1 from the cell planes mm-1 (S) and mm (N)
-            double g[12];
-#pragma unroll
-            for (int q = 0; q < 12; ++q) g[q] = 0.0;
-            ng_outer(g, -1.0, S.Pp, S.Pt);                    // k direction: below the node -, above +
-            ng_outer(g, +1.0, N.Pp, N.Pt);
-            double t[3], ph[4];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t[d] = S.Q0t[d] + N.Q0t[d];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ph[v] = S.Q0p[v] + N.Q0p[v];
-            ng_outer(g, -1.0, ph, t);                         // j direction: own row -, row above +
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t[d] = S.Q1t[d] + N.Q1t[d];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ph[v] = S.Q1p[v] + N.Q1p[v];
-            ng_outer(g, +1.0, ph, t);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t[d] = S.RIt[d] + N.RIt[d];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ph[v] = S.RIp[v] + N.RIp[v];
-            ng_outer(g, -1.0, ph, t);                         // i direction: own column -, column i+1 +
-            double t1[3], ph1[4];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t[d]);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
-            ng_outer(g, +1.0, ph1, t1);
-            const double oneOverV = rcp_nr(S.V + N.V);
-            if (out) {
-                const unsigned cn = c - sk;
-#pragma unroll
-                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cn, g[q] * oneOverV);
-            }
-        }
-        S = N;
-        c += sk; cx += sk;
     }
 }
 
@@ -394,15 +180,6 @@ static int tile_grid_size(const TileGrid& g)
 {
     if (g.W > 0) return ((g.total + g.W - 1) / g.W) * g.W;
     return g.per ? 8 * g.per : g.total;
-}
-
-template <bool XN>
-__global__ __launch_bounds__(64 * NG_BY, 2) void k_node_grad_march(const BlkView* __restrict__ tab, int nzb, double gam, TileGrid tg)
-{
-    __shared__ double xr[2 * NG_BY * NG_SLOT];            // [parity][row slot 0..3 = cell rows j0+1 .. j0+4][value][lane]
-    int bx, by, bz;
-    if (!tile_of_workgroup(tg, bx, by, bz)) return;
-    node_grad_body<XN>(tab, nzb, gam, bx, by, bz, xr, tg.kch);
 }
 
 // ---------------------------------------------------------------------------
@@ -847,22 +624,12 @@ __device__ __forceinline__ VCell vcell_at(const BlkView& b, const KParams& kp, l
 }
 
 // ---------------------------------------------------------------------------
-// k-marching form of the face-flux kernel (tuning "viscous_tiled" >= 2) over the level's XCD-ordered tile table (the table of
-// the inviscid marching kernels: 60 produced columns per 64-lane wavefront, 4 rows, march_kch planes).  k_viscous_t stages
-// the gradient planes in a separate phase between two barriers per plane, evaluates five faces per cell and loads the state
-// of every neighbour per face: it waits 70 % of its wave cycles (profiles/r02_a_pmc_sq.txt) and moves 660 B per cell.  Here
-//   * a thread loads the 12 gradients of ITS node (i, j, k) with plain coalesced loads and publishes them in LDS for the
-//     row above (one barrier per plane, double-buffered); the node plane below is carried in registers, the nodes at
-//     i-1 come by DPP lane shifts: no staging phase, no 65th column;
-//   * k faces are carried (once per face), i faces are evaluated by the left cell and handed to lane+1 by DPP (once per
-//     face), both j faces are evaluated by the cell (rows are different waves): 4 face evaluations per cell;
-//   * the own column's state is a two-plane window; the heat-conduction factors use the constant gamma of the path;
-//     1/|d| comes from v_rsq_f64; without the persistent fw of the RK scheme only dw is read and written.
-// Face arithmetic as visc_face_t (fluxes.F90:2610-2860); the 4-node average is formed from pair sums (rounding only).
+// Face arithmetic of the marching viscous kernels (k_visc_gf, k_visc_approx_march): vm_face = fluxes.F90:2610-2860 with the SUM of
+// the gradients of the four face nodes handed in (the 4-node average is formed from pair sums: rounding only), the constant gamma
+// of the path in the heat-conduction factors and 1/|d| from v_rsq_f64.
 // ---------------------------------------------------------------------------
 #define VM_OUT 60          // tile table shared with the inviscid marching kernels
 #define VM_BY 4
-#define VM_G (12 * 64)     // one node row of one plane in LDS
 
 struct VmCell { double u, v, w, na, rlv, rev; };      // na = - gamma p / rho (minus the speed of sound squared)
 
@@ -946,18 +713,16 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gs[12], const
     f[3] = frhoE - q_x * nx - q_y * ny - q_z * nz;
 }
 
-// SB: scheduling fences between the face blocks (limits how far the compiler hoists the loads of later faces: fewer live
-// registers, less latency overlap) -- tuning "visc_sb"
-// APPROX: viscousFluxApprox (fluxes.F90:3487-3859), the thin-layer form of the preconditioner assembly: the face gradient is the
-// difference of the two cell values along the centre-to-centre vector, i.e. the formulas below with the nodal gradients set to
-// zero -- no gradient loads, no LDS ring
-// FIRST: the kernel runs before the inviscid march: its flux sums are stored to dw(2:5) as they are, k_roe_march<.., ADDV> adds
-// them to its own sums and applies iblank (saves this kernel the read of dw: the Roe kernel is bound by FP64 issue, not by HBM)
-template <bool QCR, int SB, bool APPROX = false, bool FIRST = false>
-__global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
-                                                              int kch)
+// viscousFluxApprox (fluxes.F90:3487-3859), the thin-layer form of the preconditioner assembly, as a k-march over the level's tile
+// table: the face gradient is the difference of the two cell values along the centre-to-centre vector, i.e. vm_face with the nodal
+// gradients set to zero -- no gradients, no LDS ring.  k faces carried, i faces once (DPP hand-over of the flux), both j faces per
+// cell; the state of the j neighbours through LDS.
+// FIRST: the kernel runs before the inviscid march: its flux sums are stored to dw(2:5) as they are, the inviscid march (ADDV) adds
+// them to its own sums and applies iblank
+template <bool FIRST>
+__global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
+                                                                     KParams kp, int kch)
 {
-    __shared__ double gx[APPROX ? 1 : 2 * (VM_BY + 1) * VM_G];      // [parity][node row slot 0..4 = rows j0-1 .. j0+3][component][lane]
     __shared__ double qx[VM_BY * 6 * 64];               // state of the own cell of every row, for the rows above and below
     const int4 t = tiles[blockIdx.x];
     if (t.x < 0) return;
@@ -979,7 +744,6 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
     GPTR(const double) sK = (GPTR(const double))b.sK;
     GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
     GPTR(const double) dK = (GPTR(const double))b.dK;
-    GPTR(const double) grad = (GPTR(const double))b.grad;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     GPTR(double) dw = (GPTR(double))b.dw;
     GPTR(double) fw = (GPTR(double))b.fw;
@@ -987,50 +751,20 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
     K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
     K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
     const double gam = kp.gammaConstant;
+    double gs[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) gs[q] = 0.0;
 
-    // node plane k0-1 -> LDS buffer 1 (the march starts with buffer 0); cell planes k0-1 and k0 of the own column
-    if (!APPROX) {
-        double* __restrict__ xp = gx + (VM_BY + 1) * VM_G;
-#pragma unroll
-        for (int q = 0; q < 12; ++q) xp[(row + 1) * VM_G + q * 64 + lane] = ldg(grad, c - sk + q * nb8);
-        if (row == 0) {
-#pragma unroll
-            for (int q = 0; q < 12; ++q) xp[q * 64 + lane] = ldg(grad, c - sk - sj + q * nb8);
-        }
-    }
     const VmCell qm1 = vm_ld(m, c - sk, gam, K.eddy);
     VmCell q0 = vm_ld(m, c, gam, K.eddy);
     double fk[4];
-    __syncthreads();
     {
-        // k face below the first plane of the march: nodes (i-1..i, j-1..j, k0-1)
-        const double* __restrict__ xp = gx + (VM_BY + 1) * VM_G;
-        double gs[12], nK[3], dKv[3];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            if (APPROX) { gs[q] = 0.0; continue; }
-            const double s = xp[(row + 1) * VM_G + q * 64 + lane] + xp[row * VM_G + q * 64 + lane];
-            gs[q] = s + lane_up1(s);
-        }
+        // k face below the first plane of the march
+        double nK[3], dKv[3];
         vm_ld3(sK, c - sk, nb8, nK); vm_ld3(dK, c - sk, nb8, dKv);
-        vm_face<QCR>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), fk);
+        vm_face<false>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), fk);
     }
     for (int k = k0; k <= k1; ++k) {
-        double* __restrict__ xb = gx + (APPROX ? 0 : ((k - k0) & 1) * ((VM_BY + 1) * VM_G));               // node plane k
-        const double* __restrict__ xp = gx + (APPROX ? 0 : ((k - k0 + 1) & 1) * ((VM_BY + 1) * VM_G));     // node plane k-1
-        // ---- own node of plane k -> LDS; row 0 also fetches the node row below the tile.  Both node planes stay in LDS and
-        //      every face reads its four nodes from there (carried in registers they push the kernel over the 256 VGPRs of
-        //      two waves per SIMD and the spills serialise the loads)
-        if (!APPROX) {
-#pragma unroll
-            for (int q = 0; q < 12; ++q) xb[(row + 1) * VM_G + q * 64 + lane] = ldg(grad, c + q * nb8);
-            if (row == 0) {
-#pragma unroll
-                for (int q = 0; q < 12; ++q) xb[q * 64 + lane] = ldg(grad, c - sj + q * nb8);
-            }
-        }
-        // the state of the j neighbours comes from the neighbouring rows through LDS (as plain loads they miss L2: 14 of the
-        // 60 loads per cell went to HBM); only the rows outside the tile are loaded
         {
             double* __restrict__ qo = qx + row * (6 * 64) + lane;
             qo[0] = q0.u; qo[64] = q0.v; qo[128] = q0.w; qo[192] = q0.na; qo[256] = q0.rlv; qo[320] = q0.rev;
@@ -1039,56 +773,44 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
         const int flag0 = flags[c >> 3];
         double acc[4];
         __syncthreads();
-        const int oM = row * VM_G + lane, o0 = (row + 1) * VM_G + lane;       // node rows j-1 and j
         auto row_state = [&](int r) {
             const double* __restrict__ qi = qx + r * (6 * 64) + lane;
             VmCell q;
             q.u = qi[0]; q.v = qi[64]; q.w = qi[128]; q.na = qi[192]; q.rlv = qi[256]; q.rev = qi[320];
             return q;
         };
-        // ---- j face (j-1 | j): nodes (i-1..i, j-1, k-1..k)
+        // ---- j face (j-1 | j)
         {
-            double gs[12], nJ[3], dJv[3], f[4];
+            double nJ[3], dJv[3], f[4];
             const VmCell qjm = (row > 0) ? row_state(row - 1) : vm_ld(m, c - sj, gam, K.eddy);
-#pragma unroll
-            for (int q = 0; q < 12; ++q) { if (APPROX) { gs[q] = 0.0; continue; } const double s = xp[oM + q * 64] + xb[oM + q * 64]; gs[q] = s + lane_up1(s); }
             vm_ld3(sJ, c - sj, nb8, nJ); vm_ld3(dJ, c - sj, nb8, dJv);
-            vm_face<QCR>(K, gs, qjm, q0, nJ, dJv, flg_porJ(flags[(c - sj) >> 3]), f);
+            vm_face<false>(K, gs, qjm, q0, nJ, dJv, flg_porJ(flags[(c - sj) >> 3]), f);
 #pragma unroll
             for (int l = 0; l < 4; ++l) acc[l] = fk[l] + f[l];
         }
-        if (SB >= 1) __builtin_amdgcn_sched_barrier(0);
-        // ---- i face (i | i+1): nodes (i, j-1..j, k-1..k) of the own column; the face (i-1 | i) comes from lane-1
+        // ---- i face (i | i+1); the face (i-1 | i) comes from lane-1
         {
-            double gs[12], nI[3], dIv[3], f[4];
-#pragma unroll
-            for (int q = 0; q < 12; ++q) gs[q] = APPROX ? 0.0 : (xp[oM + q * 64] + xp[o0 + q * 64]) + (xb[oM + q * 64] + xb[o0 + q * 64]);
+            double nI[3], dIv[3], f[4];
             vm_ld3(sI, c, nb8, nI); vm_ld3(dI, c, nb8, dIv);
             const VmCell qR = vm_dn1(q0);
-            vm_face<QCR>(K, gs, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
+            vm_face<false>(K, gs, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
 #pragma unroll
             for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
         }
-        if (SB >= 1) __builtin_amdgcn_sched_barrier(0);
-        // ---- j face (j | j+1): nodes (i-1..i, j, k-1..k)
+        // ---- j face (j | j+1)
         {
-            double gs[12], nJ[3], dJv[3], f[4];
+            double nJ[3], dJv[3], f[4];
             const VmCell qjp = (row < VM_BY - 1) ? row_state(row + 1) : vm_ld(m, c + sj, gam, K.eddy);
-#pragma unroll
-            for (int q = 0; q < 12; ++q) { if (APPROX) { gs[q] = 0.0; continue; } const double s = xp[o0 + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
             vm_ld3(sJ, c, nb8, nJ); vm_ld3(dJ, c, nb8, dJv);
-            vm_face<QCR>(K, gs, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), f);
+            vm_face<false>(K, gs, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), f);
 #pragma unroll
             for (int l = 0; l < 4; ++l) acc[l] -= f[l];
         }
-        if (SB >= 1) __builtin_amdgcn_sched_barrier(0);
-        // ---- k face above the cell: nodes (i-1..i, j-1..j, k)
+        // ---- k face above the cell
         {
-            double gs[12], nK[3], dKv[3], f[4];
-#pragma unroll
-            for (int q = 0; q < 12; ++q) { if (APPROX) { gs[q] = 0.0; continue; } const double s = xb[oM + q * 64] + xb[o0 + q * 64]; gs[q] = s + lane_up1(s); }
+            double nK[3], dKv[3], f[4];
             vm_ld3(sK, c, nb8, nK); vm_ld3(dK, c, nb8, dKv);
-            vm_face<QCR>(K, gs, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), f);
+            vm_face<false>(K, gs, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), f);
 #pragma unroll
             for (int l = 0; l < 4; ++l) { acc[l] -= f[l]; fk[l] = f[l]; }
         }
@@ -1109,7 +831,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_march(const BlkView* __r
         }
         q0 = qp1;
         c += sk;
-        __syncthreads();        // every wave is done with plane k-1 before its buffer takes plane k+1
+        __syncthreads();        // every wave has read the row states of this plane before they are replaced
     }
 }
 
@@ -1168,8 +890,7 @@ struct GfMet { double Pt[3], Q0t[3], Q1t[3], RIt[3], V; };
 struct __attribute__((aligned(16))) Dbl2 { double x, y; };
 __device__ __forceinline__ Dbl2 mk2(double x, double y) { Dbl2 v; v.x = x; v.y = y; return v; }
 
-// PF = 1 (tuning "gf_pf"): the loads of the face part are requested at the top of the step, in one batch with those of the gradient part
-template <bool QCR, bool FIRST, bool STG, int PF = 0>
+template <bool QCR, bool FIRST, bool STG>
 __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
     __shared__ __attribute__((aligned(16))) double ring[GF_RING];   // [slot][node row 0..3 = rows j0-1 .. j0+2][lane-1][component]
@@ -1268,7 +989,6 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
                 vm_ld3(m.sJ, cF, nb8, sJA);
             }
         };
-        if (PF == 1) face_loads();
         // ---- metric sums of this plane (ng_finish for both rows; the row above takes sJ(j-1) from the own row)
         GfMet N;
         {
@@ -1342,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
             }
         }
         // ---- loads of the face part (cell plane mm-1), requested above the barrier; sI / sJ of that plane again (carried they spill)
-        if (PF == 0) face_loads();
+        face_loads();          // requested above the barrier (at the top of the step: no faster, profiles/r03_f)
         __syncthreads();
         if (facePlane) {
             const double* __restrict__ xb = ring + (((mm - k0) % 3) * 4) * GF_G + nl * 12;            // node plane mm-1
@@ -1519,34 +1239,16 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;
-    if (kp.viscFirst) hipLaunchKernelGGL((k_visc_march<false, 0, true, true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
-    else hipLaunchKernelGGL((k_visc_march<false, 0, true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
+    if (kp.viscFirst) hipLaunchKernelGGL((k_visc_approx_march<true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
+    else hipLaunchKernelGGL((k_visc_approx_march<false>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
 }
-
-void launch_visc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
-{
-    if (ntiles <= 0) return;
-    const dim3 blk(64, VM_BY, 1), grd(ntiles);
-    if (kp.viscFirst) {
-        if (kp.useQCR) hipLaunchKernelGGL((k_visc_march<true, 1, false, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-        else hipLaunchKernelGGL((k_visc_march<false, 0, false, true>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-    } else if (kp.useQCR) hipLaunchKernelGGL((k_visc_march<true, 1>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-    else hipLaunchKernelGGL((k_visc_march<false, 0>), grd, blk, 0, s, tab, tiles, kp, g_march_kch);
-}
-
-int g_gf_pf = 0;            // tuning "gf_pf": 1 = face-part loads of k_visc_gf requested at the top of the step
-int g_visc_gf = 1;          // tuning "visc_gf": nodal gradients + viscous fluxes as ONE kernel (k_visc_gf), 0 = k_node_grad_march + k_visc_march
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)
 {
     if (ntiles <= 0) return;
     const dim3 grd(ntiles), blk(64, 4, 1);
-#define GF_LAUNCH(Q, F, G)                                                                            \
-    do {                                                                                              \
-        if (g_gf_pf == 1) hipLaunchKernelGGL((k_visc_gf<Q, F, G, 1>), grd, blk, 0, s, tab, tiles, kp); \
-        else hipLaunchKernelGGL((k_visc_gf<Q, F, G, 0>), grd, blk, 0, s, tab, tiles, kp);             \
-    } while (0)
+#define GF_LAUNCH(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, tiles, kp)
     if (kp.useQCR) {
         if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, true, false); }
         else { if (storeGrad) GF_LAUNCH(true, false, true); else GF_LAUNCH(true, false, false); }
@@ -1580,20 +1282,6 @@ void launch_sa_march_solve_level(const BlkView* tab, int nslots, int nx, int ny,
     node_chunks(nz + 1, &nchn, &kch);
     const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
     hipLaunchKernelGGL((k_sa_march<true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
-}
-
-void launch_node_gradients_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
-{
-    LEVEL_SPLIT(nslots, nz + 4, launch_node_gradients_level(tab + s0_, n_, nx, ny, nz, kp, s));
-    if (nslots <= 0) return;
-    const int nzn = nz + 1;
-    int nchn, kch;
-    node_chunks(nzn, &nchn, &kch);
-    const TileGrid tgn = tile_grid((nx + 1 + NG_OUT - 1) / NG_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-    if (kp.metricFromX & 2)
-        hipLaunchKernelGGL(k_node_grad_march<true>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
-    else
-        hipLaunchKernelGGL(k_node_grad_march<false>, dim3(tile_grid_size(tgn)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp.gammaConstant, tgn);
 }
 
 int viscous_is_tiled() { return g_viscous_tiled; }

@@ -64,10 +64,7 @@ def fp64_issue_roofline(eng, eval_ms, kernels_ms, qcr=False, gf=True, spaceDiscr
     simds = cus * N_SIMD_PER_CU
     inv = {9: "roe_march", 2: "matrix_march", 1: "euler_march"}[spaceDiscr]
     plan = [("SA residual", "sa_march", "sa_march"), ("inviscid", inv, "tile_march")]
-    if gf:
-        plan.append(("nodal gradients + viscous (fused)", "visc_gf_qcr" if qcr else "visc_gf", "visc_gf"))
-    else:
-        plan += [("nodal gradients", "node_grad_march", "node_grad_march"), ("viscous", "visc_march", "tile_march")]
+    plan.append(("nodal gradients + viscous (fused)", "visc_gf_qcr" if qcr else "visc_gf", "visc_gf"))
     kern, total = {}, 0.0
     for label, ik, sk in plan:
         k = isa["kernels"].get(ik)
@@ -109,7 +106,6 @@ WORKLOADS = {
 DEFAULT_WORKLOAD = "crm_rans_sa_upwind_8x160x128x64"
 PHASES = ["closures+bc", "time step", "SA residual", "inviscid", "nodal gradients", "viscous"]   # between marks 0..6 of api.hip
 # Roe upwind + viscous fluxes (tuning visc_first, default on): the viscous march runs in front of the Roe march, marks 4..6 in that order
-PHASES_VISC_FIRST = ["closures+bc", "time step", "SA residual", "nodal gradients", "viscous", "inviscid"]
 # k_visc_gf (tuning visc_gf, default on): gradients and viscous fluxes are one kernel between marks 4 and 5
 PHASES_GF_FIRST = ["closures+bc", "time step", "SA residual", "(mark)", "nodal gradients + viscous (fused)", "inviscid"]
 PHASES_GF = ["closures+bc", "time step", "SA residual", "inviscid", "(mark)", "nodal gradients + viscous (fused)"]
@@ -444,15 +440,14 @@ def main():
 
     # ---- per-kernel durations of one evaluation, live HIP events on the library's stream
     eng.set_async(False)
-    vf_bits = int(tuning.get("visc_first", 7))         # bit 0 Roe upwind, bit 1 matrix dissipation, bit 2 scalar JST of NS / RANS
-    visc_first = (vf_bits & 1) != 0 and "upwind" in a.workload
-    gf_on = int(tuning.get("visc_gf", 1)) != 0 and wl["equations"] >= 2
+    # NS / RANS over the tile table: the fused gradient + viscous march runs in front of the inviscid march (api.hip enqueue_flow_fluxes)
+    gf_on = wl["equations"] >= 2
 
     def phase_names(first):
         if gf_on:
             return PHASES_GF_FIRST if first else PHASES_GF
-        return PHASES_VISC_FIRST if first else PHASES
-    ph = phase_times(eng, job.step, names=phase_names(visc_first))
+        return PHASES
+    ph = phase_times(eng, job.step, names=phase_names(True))
     log("phases (ms): " + ", ".join(f"{k} {v:.3f}" for k, v in ph.items()))
     kern = {k: v for k, v in ph.items() if k not in ("closures+bc", "(mark)")}
     dom = max(kern, key=kern.get)
@@ -468,7 +463,7 @@ def main():
                 job.step()
             s4b, r4b, e4b = timed(eng, job.step, a.steps, barrier, a.min_seconds)
             eng.set_async(False)
-            ph4b = phase_times(eng, job.step, names=phase_names((vf_bits & 2) != 0))
+            ph4b = phase_times(eng, job.step, names=phase_names(True))
             ph4b.pop("(mark)", None)
             extra["crm_rans_sa_matrix_8x160x128x64"] = {
                 "value": job.cells_local / s4b / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_step": s4b * 1e3,

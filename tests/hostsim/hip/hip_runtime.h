@@ -71,6 +71,13 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t e);
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // one in-order queue on the host
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+// graph capture does not exist on the emulator: the library never asks for it under HOSTSIM (mg_graph_eligible), the types only have
+// to compile
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum { hipStreamCaptureModeThreadLocal = 1 };
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : 1; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n); return *p ? hipSuccess : 1; }

@@ -51,16 +51,14 @@ def test_blanked_cells_and_noflux_faces(engine, sd):
                            wall_kmin=True)
 
 
-@pytest.mark.parametrize("pipe,kch", [(2, 4), (2, 5), (2, 64), (1, 4), (0, 4), (1, 64), (0, 32)])
-def test_euler_march_variants(engine, pipe, kch):
-    """marching kernel: k-chunk boundaries, software-pipelined and plain form"""
-    engine.set_tuning("march_pipe", pipe)
+@pytest.mark.parametrize("kch", [4, 5, 64])
+def test_euler_march_variants(engine, kch):
+    """marching kernel: k-chunk boundaries"""
     engine.set_tuning("march_kch", kch)
     try:
         checks.check_block_res(engine, (70, 9, 11), FlowParams(spaceDiscr=dissScalar), seed=77, wall_kmin=True)
         checks.check_rk_residual_sequence(engine, (20, 6, 7), FlowParams(spaceDiscr=dissScalar), seed=78)
     finally:
-        engine.set_tuning("march_pipe", 2)
         engine.set_tuning("march_kch", 32)
 
 
@@ -95,7 +93,7 @@ def test_actuator_regions(engine):
 def test_euler_radii_inside_the_march(engine):
     """blocketteRes with its default flags on Euler + scalar JST: the marching kernel forms the spectral radii itself (no k_time_step
     pass).  Against the reference's default path blocketteResCore; partial tiles in i / j, two k chunks, a one-cell-thick block,
-    no directional scaling, and the separate-kernel path (tuning euler_radii = 0) on the same inputs."""
+    no directional scaling, and the separate-kernel path (updateIntermed = T) on the same inputs."""
     from adflow_amd.params import dissScalar
     for dims in ((63, 9, 35), (124, 6, 5), (16, 8, 1)):
         checks.check_block_res_vs_blockette(engine, dims, FlowParams(spaceDiscr=dissScalar), False, seed=sum(dims),
@@ -114,8 +112,5 @@ def test_euler_radii_inside_the_march(engine):
     engine.blocketteRes(1, False, True, False)
     dw = engine.download_residual()
     assert rel_err(owned(blk, dw), owned(blk, r["dw"])) <= TOL
-    try:
-        engine.set_tuning("euler_radii", 0)
-        checks.check_block_res_vs_blockette(engine, (63, 9, 35), FlowParams(spaceDiscr=dissScalar), False, seed=3)
-    finally:
-        engine.set_tuning("euler_radii", 1)
+    # with updateIntermed the radii are an output: the separate k_time_step pass in front of the march
+    checks.check_block_res_vs_blockette(engine, (63, 9, 35), FlowParams(spaceDiscr=dissScalar), True, seed=3)

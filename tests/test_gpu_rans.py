@@ -159,14 +159,16 @@ def test_viscous_kernel_variants(engine):
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
         engine.set_tuning("sa_march", 1)
-        for vf in (0, 7):            # inviscid march, then viscous march completing dw / viscous march first, the inviscid march adds its sums (default)
-            engine.set_tuning("visc_first", vf)
-            for prm in (FlowParams(equations=RANSEquations, spaceDiscr=upwind, useQCR=True, muSuthDim=1.0),
-                        FlowParams(equations=NSEquations, spaceDiscr=upwind, limiter=minmod, muSuthDim=1.0),
-                        FlowParams(equations=RANSEquations, spaceDiscr=dissMatrix, vis4=0.1, muSuthDim=1.0),
-                        FlowParams(equations=NSEquations, spaceDiscr=dissScalar, muSuthDim=1.0)):
-                checks.check_block_res(engine, (63, 6, 35), prm, seed=60 + vf, stretch_k=2.0, holes=0.05)
-        engine.set_tuning("visc_first", 7)
+        # the viscous march in front of each inviscid march over the tile table (Roe, matrix dissipation, scalar JST), QCR, minmod
+        for prm in (FlowParams(equations=RANSEquations, spaceDiscr=upwind, useQCR=True, muSuthDim=1.0),
+                    FlowParams(equations=NSEquations, spaceDiscr=upwind, limiter=minmod, muSuthDim=1.0),
+                    FlowParams(equations=RANSEquations, spaceDiscr=dissMatrix, vis4=0.1, muSuthDim=1.0),
+                    FlowParams(equations=NSEquations, spaceDiscr=dissScalar, muSuthDim=1.0)):
+            checks.check_block_res(engine, (63, 6, 35), prm, seed=67, stretch_k=2.0, holes=0.05)
+        for im in (0, 2):            # the gather inviscid kernel: the viscous march then completes dw itself
+            engine.set_tuning("inviscid_march", im)
+            checks.check_block_res(engine, (63, 6, 35), FlowParams(equations=RANSEquations, spaceDiscr=dissMatrix, vis4=0.1, muSuthDim=1.0),
+                                   seed=68, stretch_k=2.0, holes=0.05)
         for xt, gk in ((0, 32), (1, 5), (1, 64)):     # gradient / SA march tiles in launch order; k chunks of <= 5 planes; one chunk
             engine.set_tuning("xcd_tiles", xt)
             engine.set_tuning("grad_kch", gk)
@@ -186,45 +188,33 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("metric_from_x", 7)
         engine.set_tuning("xcd_tiles", 1)
         engine.set_tuning("grad_kch", 32)
-        engine.set_tuning("visc_first", 7)
+        engine.set_tuning("inviscid_march", 2)
 
 
 def test_visc_gradient_fused(engine):
-    """k_visc_gf (tuning visc_gf, default 1): nodal gradients and viscous fluxes in one kernel, the gradients stay in an LDS ring.
-    Partial tiles in i (60 columns) / j (3 rows) / the k chunk, blanked cells, QCR, laminar NS, matrix / scalar dissipation (the
-    kernel completing dw instead of handing its sums to the inviscid march), persistent fw of the RK stages, the stored-gradient
-    variant (wall stress, updateIntermed); visc_gf = 0: the separate gradient + face marches."""
+    """k_visc_gf: nodal gradients and viscous fluxes in one kernel, the gradients stay in an LDS ring.
+    Partial tiles in i (60 columns) / j (3 rows) / the k chunk, blanked cells, QCR, laminar NS, matrix / scalar dissipation, the
+    kernel completing dw itself (persistent fw of the RK stages), the stored-gradient variant (wall stress, updateIntermed), k chunks
+    of march_kch planes (gf_cus = -1) and chunks fitted to rounds of 2 x CUs workgroups as on a device with 1 / 3 CUs."""
     try:
-        for gf in (1, 0):
-            engine.set_tuning("visc_gf", gf)
-            prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
-            checks.check_block_res(engine, (63, 7, 35), prm, seed=5, stretch_k=2.0, holes=0.05)
-            checks.check_block_res(engine, (61, 9, 33), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
-            checks.check_block_res(engine, (7, 5, 3), FlowParams(equations=NSEquations), seed=7, stretch_k=2.0)
-            checks.check_block_res(engine, (124, 13, 5), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, muSuthDim=1.0), seed=8, stretch_k=2.0)
-            checks.check_block_res(engine, (1, 1, 1), FlowParams(equations=NSEquations, muSuthDim=1.0), seed=9)
-            checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations, muSuthDim=1.0), stretch_k=2.0)
-            checks.check_wall_stress(engine, (9, 8, 7), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -3, 4: -4, 5: -3, 6: -6},
-                                     stretch_k=2.0)
-            for vf in (0, 7):
-                engine.set_tuning("visc_first", vf)
-                checks.check_block_res(engine, (24, 10, 8), FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0), seed=vf,
-                                       stretch_k=2.0)
-            engine.set_tuning("visc_first", 7)
-            engine.set_tuning("gf_fit", 0)            # k chunks of march_kch planes
-            engine.set_tuning("march_kch", 5)
-            checks.check_block_res(engine, (20, 4, 13), prm, seed=11, stretch_k=2.0)
-            engine.set_tuning("march_kch", 32)
-            engine.set_tuning("gf_fit", 1)            # chunks fitted to rounds of 2 x CUs workgroups: as on a device with 1 / 3 CUs
-            for cus in (1, 3):
-                engine.set_tuning("gf_cus", cus)
-                checks.check_block_res(engine, (70, 7, 21), prm, seed=12 + cus, stretch_k=2.0, holes=0.05)
-            engine.set_tuning("gf_cus", 0)
-    finally:
-        engine.set_tuning("visc_gf", 1)
-        engine.set_tuning("visc_first", 7)
+        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
+        checks.check_block_res(engine, (63, 7, 35), prm, seed=5, stretch_k=2.0, holes=0.05)
+        checks.check_block_res(engine, (61, 9, 33), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
+        checks.check_block_res(engine, (7, 5, 3), FlowParams(equations=NSEquations), seed=7, stretch_k=2.0)
+        checks.check_block_res(engine, (124, 13, 5), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, muSuthDim=1.0), seed=8, stretch_k=2.0)
+        checks.check_block_res(engine, (1, 1, 1), FlowParams(equations=NSEquations, muSuthDim=1.0), seed=9)
+        checks.check_rk_residual_sequence(engine, (12, 10, 6), FlowParams(equations=NSEquations, muSuthDim=1.0), stretch_k=2.0)
+        checks.check_wall_stress(engine, (9, 8, 7), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -3, 4: -4, 5: -3, 6: -6},
+                                 stretch_k=2.0)
+        engine.set_tuning("gf_cus", -1)           # k chunks of march_kch planes
+        engine.set_tuning("march_kch", 5)
+        checks.check_block_res(engine, (20, 4, 13), prm, seed=11, stretch_k=2.0)
         engine.set_tuning("march_kch", 32)
-        engine.set_tuning("gf_fit", 1)
+        for cus in (1, 3):
+            engine.set_tuning("gf_cus", cus)
+            checks.check_block_res(engine, (70, 7, 21), prm, seed=12 + cus, stretch_k=2.0, holes=0.05)
+    finally:
+        engine.set_tuning("march_kch", 32)
         engine.set_tuning("gf_cus", 0)
 
 

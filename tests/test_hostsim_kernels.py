@@ -146,30 +146,14 @@ def test_mg_cycle_three_levels(hostsim_engine):
                           [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0], ncycles=1, nlevels=3)
 
 
-@pytest.mark.parametrize("pipe,kch", [(2, 4), (2, 5), (2, 32), (1, 4), (0, 4), (1, 5)])
-def test_euler_march_variants(hostsim_engine, pipe, kch):
-    """marching kernel: chunk boundaries (k-chunks of 4/5 planes on an 11-plane block) for the
-    software-pipelined and the plain form"""
-    hostsim_engine.set_tuning("march_pipe", pipe)
+@pytest.mark.parametrize("kch", [4, 5, 32])
+def test_euler_march_variants(hostsim_engine, kch):
+    """marching kernel: chunk boundaries (k-chunks of 4/5 planes on an 11-plane block)"""
     hostsim_engine.set_tuning("march_kch", kch)
     try:
         checks.check_block_res(hostsim_engine, (13, 6, 11), FlowParams(spaceDiscr=dissScalar), seed=77, wall_kmin=True)
         checks.check_rk_residual_sequence(hostsim_engine, (9, 5, 7), FlowParams(spaceDiscr=dissScalar), seed=78)
     finally:
-        hostsim_engine.set_tuning("march_pipe", 2)
-        hostsim_engine.set_tuning("march_kch", 32)
-
-
-def test_euler_march_eight_rows(hostsim_engine):
-    """marching kernel with 8 rows of cells per workgroup (tuning march_by = 8): ragged j extents, chunk boundaries"""
-    hostsim_engine.set_tuning("march_by", 8)
-    hostsim_engine.set_tuning("march_kch", 5)
-    try:
-        checks.check_block_res(hostsim_engine, (13, 11, 9), FlowParams(spaceDiscr=dissScalar), seed=79, wall_kmin=True)
-        checks.check_block_res(hostsim_engine, (7, 3, 4), FlowParams(spaceDiscr=dissScalar), seed=80)
-        checks.check_rk_residual_sequence(hostsim_engine, (9, 17, 7), FlowParams(spaceDiscr=dissScalar), seed=81)
-    finally:
-        hostsim_engine.set_tuning("march_by", 4)
         hostsim_engine.set_tuning("march_kch", 32)
 
 

@@ -21,9 +21,7 @@ KERNELS = {
     "sa_march": ("kernels_viscous.hip", r"k_sa_marchILb0E", "k_sa_march<false>: Spalart-Allmaras residual"),
     "visc_gf": ("kernels_viscous.hip", r"k_visc_gfILb0ELb1ELb0E", "k_visc_gf<false,true,false>: nodal gradients + viscous fluxes"),
     "visc_gf_qcr": ("kernels_viscous.hip", r"k_visc_gfILb1ELb1ELb0E", "k_visc_gf<true,true,false>: the same with QCR"),
-    "node_grad_march": ("kernels_viscous.hip", r"k_node_grad_marchILb1E", "k_node_grad_march<true> (visc_gf = 0)"),
-    "visc_march": ("kernels_viscous.hip", r"k_visc_marchILb0ELi0ELb0ELb1E", "k_visc_march<false,0,false,true> (visc_gf = 0)"),
-    "roe_march": ("kernels_roe_march.hip", r"k_roe_marchILi3ELb0ELb1ELb0ELb1E", "k_roe_march<vanAlbada,.,FINAL,.,ADDV>: central + Roe upwind"),
+    "roe_march": ("kernels_roe_march.hip", r"k_roe_marchILi3ELb0ELb1ELb1ELb0E", "k_roe_march<vanAlbada,.,FINAL,ADDV>: central + Roe upwind"),
     "matrix_march": ("kernels_inviscid_march.hip", r"k_inviscid_marchILi2E", "k_inviscid_march<matrix,...> (first instantiation found)"),
     "euler_march": ("kernels_euler_march.hip", r"k_euler_march_p", "k_euler_march_p (first instantiation found)"),
 }
