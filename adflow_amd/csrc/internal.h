@@ -88,19 +88,23 @@ __device__ __forceinline__ double fast_powa(double x, double a) { return pow(x, 
 __device__ __forceinline__ double fastsqrt(double x) { return x * rsq_nr(fmax(x, 1.e-300)); }
 // x^(1/6) for x in the normal positive range: single-precision seed of z = x^(-1/6) (v_log_f32 / v_exp_f32), two Newton steps
 // z <- z (7 - x z^6) / 6 in FP64 (quadratic: 1e-7 -> 4e-14 -> 1e-26), result x z^5.  ~25 issue slots instead of ~150 of pow().
-// Outside 1e-30 .. 1e30 the single-precision seed under- / overflows (x -> 0 when the SA variable is negative and rr is far below
-// zero: the reference bounds rr only from above, sa.F90): the library pow there, a branch no realistic state takes.
+// The argument is first scaled into [2^-6, 2^6) by a power of 2^6 taken from its exponent (x = x' 2^(6k), x^(1/6) = x'^(1/6) 2^k), so that
+// the single-precision seed never under- / overflows: x reaches 1e-100 when the SA variable is negative and rr is far below zero (the
+// reference bounds rr only from above, sa.F90).  x = 0 (gg^6 overflowed) gives 0 as the reference's power does.
 __device__ __forceinline__ double fast_root6(double x)
 {
-    if (!(x > 1.e-30 && x < 1.e30)) return pow(x, 1.0 / 6.0);
-    double z = (double)__builtin_amdgcn_exp2f(-(1.0f / 6.0f) * __builtin_amdgcn_logf((float)x));
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const int k = (e >= 0 ? e : e - 5) / 6;                 // floor(e / 6)
+    const double xs = __builtin_ldexp(x, -6 * k);
+    double z = (double)__builtin_amdgcn_exp2f(-(1.0f / 6.0f) * __builtin_amdgcn_logf((float)xs));
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const double z2 = z * z, z6 = z2 * z2 * z2;
-        z = z * __builtin_fma(-x, z6, 7.0) * (1.0 / 6.0);
+        z = z * __builtin_fma(-xs, z6, 7.0) * (1.0 / 6.0);
     }
     const double z2 = z * z;
-    return x * (z2 * z2 * z);
+    const double r = __builtin_ldexp(xs * (z2 * z2 * z), k);
+    return (x == 0.0) ? 0.0 : r;
 }
 // x^a for x in the normal positive range and moderate a (the directional scaling of the spectral radii, adis = 0.67 by default):
 // x = m 2^e with m in [0.707, 1.414); ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172, odd series to s^19 (truncation

@@ -242,7 +242,8 @@ __device__ __forceinline__ GsNbr gs_dn1(const GsNbr& q)
 
 // SOLVE (saSolve): also stores the right-hand side (scratch 0) and the central jacobian qq (scratch 1) of the DDADI line solves,
 // as k_sa_residual<true> (kernels_sa.hip)
-template <bool SOLVE>
+// RV: the residual also goes to the matrix-free residual vector kp.rvec (setRVec: dw / volRef * turbResScale)
+template <bool SOLVE, bool RV = false>
 __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
 {
     int bx, by, bz;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
                 const double blank = flg_blank(flags[c >> 3]);
                 stg(dw5, c, -ldg(m.volRef, c) * dvt * blank);
                 // setRVec of the matrix-free matvec: dw / volRef * turbResScale
-                if (!SOLVE && kp.rvec)
+                if (RV)
                     kp.rvec[b.vecOff + ((((long)(mm - 2) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw) + 5] = -dvt * blank * kp.rvecTurbScale;
             }
         }
@@ -1269,8 +1270,11 @@ void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int n
     int nchn, kch;
     node_chunks(nz + 1, &nchn, &kch);
     const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-    hipLaunchKernelGGL((k_sa_march<false>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
-    if (kp.rvec) adf_note_rvec(2);
+    if (kp.rvec) {
+        hipLaunchKernelGGL((k_sa_march<false, true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
+        adf_note_rvec(2);
+    } else
+        hipLaunchKernelGGL((k_sa_march<false>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
 }
 
 // the SA residual with the right-hand side and the central jacobian of saSolve (blocks at rest)

@@ -97,6 +97,23 @@ def test_spalart_allmaras_limiters(engine):
     sa_cases(engine, (24, 8, 16))
 
 
+def test_spalart_allmaras_negative_working_variable(engine):
+    """nuTilde < 0 in a pocket close to the wall (a transient of a diverging outer iteration): sst is floored at 1e-10, rr is only
+    bounded from above (sa.F90), so rr ~ -1e9 and the argument of the sixth root in fw drops to ~1e-60 and below -- outside the
+    range of a single-precision seed (round-2 advisor finding).  The residual must stay finite and equal to the reference's."""
+    import numpy as np
+    from adflow_amd.synth import make_block
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    dims = (24, 8, 16)
+    blk = make_block(*dims, prm, seed=19, stretch_k=2.0)
+    w = blk["w"]
+    nu = blk["rlv"] / w[..., 0]
+    w[6:14, :, 3:7, 5] = -50.0 * nu[6:14, :, 3:7]
+    w[15:18, :, 3:6, 5] = -1e6 * nu[15:18, :, 3:6]
+    blk["d2Wall"][:, :, :6] = 1e-6
+    r = checks.check_block_res(engine, dims, prm, blk=blk)
+
+
 def test_random_parity_sweep(engine):
     """tests/fuzz_parity.py on the GPU: 300 random cases (sizes around the tile edges, options, entry points) against the reference"""
     import fuzz_parity
