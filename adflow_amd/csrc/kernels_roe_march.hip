@@ -270,7 +270,11 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         double* __restrict__ xb = xj + (k & 1) * RM_XJ(FW);                 // UR of this plane | fluxes handed over in this plane
         const double* __restrict__ xf = xj + ((k - 1) & 1) * RM_XJ(FW) + RM_UR;   // fluxes handed over in the plane before
         const bool body = (k <= k1);
+#ifdef RM_COUNT_NO_FIFTH          // tools/isa_report.py: the loop without the block a wave executes in one plane of four
+        const bool fifth = false;
+#else
         const bool fifth = body && (wave_uniform(row) == (k & 3));         // this wave evaluates the face below row 0 in this plane
+#endif
         RCell qjp, qEm, qE0;
         double ULj[5], ULe[5];
         if (body) {

@@ -49,6 +49,21 @@ def main():
             r["what"] = what
             r["kernel"] = r["kernel"].split(":")[0]
             out["kernels"][key] = r
+        # k_roe_march: the block of the fifth j face is executed by a wave in ONE plane of four (the role rotates over the four waves):
+        # the loop is compiled again without it and the average step priced as  without + (with - without) / 4
+        o = os.path.join(td, "roe_nofifth.s")
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                            "-DRM_COUNT_NO_FIFTH", os.path.join(ROOT, "adflow_amd", "csrc", "kernels_roe_march.hip"), "-o", o],
+                           capture_output=True, text=True)
+        if r.returncode == 0 and "roe_march" in out["kernels"]:
+            base = main_loop(o, KERNELS["roe_march"][1])
+            full = out["kernels"]["roe_march"]
+            if base:
+                full["static_issue_cycles"] = full["issue_cycles"]
+                full["static_valu"] = full["valu"]
+                full["issue_cycles"] = base["issue_cycles"] + (full["issue_cycles"] - base["issue_cycles"]) // 4
+                full["valu"] = base["valu"] + (full["valu"] - base["valu"]) // 4
+                full["what"] += " (average step: the fifth-j-face block counted once in four planes)"
     p = os.path.join(ROOT, "profiles", "isa_counts.json")
     json.dump(out, open(p, "w"), indent=1)
     for k, v in out["kernels"].items():
