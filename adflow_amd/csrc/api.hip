@@ -1645,8 +1645,9 @@ int ensure_tiles(int level)
                 }
     }
     // workgroup p runs on XCD p % 8.  xcd_tiles = 1: XCD x takes the x-th contiguous eighth of the whole table; 2 (default): of every
-    // ROUND of resident workgroups (adf_round_size), so that at any time the eight XCDs work on neighbouring tiles of one block: the
-    // rows two XCDs share then meet in the memory-side cache and the DRAM pages stay open (measured on k_visc_gf: 1.31 -> 0.89 ms)
+    // ROUND of resident workgroups (adf_round_size), so that at any time the eight XCDs work on neighbouring tiles of one block
+    // (no measurable difference to 1 on the north-star mesh, profiles/r03_d_xcd_round_ab.txt; it keeps the working set of a round
+    // compact when a level holds many blocks)
     const int n = (int)nat.size();
     const int W = (g_xcd_tiles >= 2) ? adf_round_size() : ((n + 7) / 8) * 8;
     const int rounds = (n + W - 1) / W;

@@ -29,7 +29,7 @@ EULER_BC = [-1, -5, -6, -7, -9, -15]
 VISC_BC = [-1, -3, -4, -6, -7, -9, -15]
 
 EDGE_NX = [1, 2, 3, 5, 58, 59, 60, 61, 62, 63, 64, 65, 119, 120, 121, 124, 125]
-EDGE_NY = [1, 2, 3, 4, 5, 7, 8, 9, 12, 13]
+EDGE_NY = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14]
 EDGE_NZ = [1, 2, 3, 5, 20, 21, 22, 23, 31, 32, 33, 34, 43, 44, 45]
 
 
