@@ -24,15 +24,21 @@ import ctypes  # noqa: E402
 
 def main():
     rank, world, port, nLayers = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    mode = sys.argv[5] if len(sys.argv) > 5 else "mod"
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     prm = FlowParams(equations=RANSEquations)
     dims = (6, 5, 4)
-    topo = BrickTopology(2, 2, 1, *dims, owner=lambda g: g % world)
+    if mode == "strong":      # bench.py --scaling strong: ONE 2x2x2 brick, nb / N blocks per rank, contiguous in k
+        shape = (2, 2, 2)
+        topo = BrickTopology(*shape, *dims, owner=lambda g: (g * world) // 8)
+    else:
+        shape = (2, 2, 1)
+        topo = BrickTopology(*shape, *dims, owner=lambda g: g % world)
     lid = topo.local_ids()
     # every rank can rebuild every block (seeded): expected halos come from the
     # single-rank version of the same topology
     allb = {g: make_block(*dims, prm, seed=50 + g, stretch_k=2.0) for g in range(topo.nblocks)}
-    single = BrickTopology(2, 2, 1, *dims)
+    single = BrickTopology(*shape, *dims)
     exp = {single.local_ids()[g]: allb[g].copy() for g in range(topo.nblocks)}
     apply_local_copies_fast(exp, single.patterns(nLayers)[0])
     mine = {lid[g]: allb[g] for g in topo.blocks_of(rank)}
