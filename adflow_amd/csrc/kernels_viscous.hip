@@ -134,7 +134,9 @@ __device__ __forceinline__ void ng_outer(double g[12], double sign, const double
 // shared by j-neighbouring tiles meet in one L2 instead of being fetched from HBM by two XCDs.  per = 0: tile index = p.
 // W > 0 (xcd_tiles = 2, default): the same within every ROUND of W resident workgroups, so that the eight XCDs work on neighbouring
 // tiles at any time (api.hip ensure_tiles).
-struct TileGrid { int gx, gy, total, per, kch, W; };     // kch: node planes per march
+// part: 0 = every tile, 1 = only the tiles whose produced cells read no halo cell (2 layers), 2 = only the others (the evaluation split
+// around the halo exchange, api.hip block_res_split_enqueue)
+struct TileGrid { int gx, gy, total, per, kch, W, part; };     // kch: node planes per march
 
 __device__ __forceinline__ bool tile_of_workgroup(const TileGrid& g, int& bx, int& by, int& bz)
 {
@@ -174,6 +176,7 @@ static TileGrid tile_grid(int gx, int gy, int nchn, int nslots, int kch)
     g.per = g_xcd_tiles ? (g.total + 7) / 8 : 0;
     g.kch = kch;
     g.W = (g_xcd_tiles >= 2) ? adf_round_size() : 0;
+    g.part = 0;
     return g;
 }
 static int tile_grid_size(const TileGrid& g)
@@ -254,6 +257,14 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
     const int kn0 = (bz % nzb) * tg.kch + 1;
     if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
     const int kn1 = (kn0 + tg.kch - 1 < b.kl) ? kn0 + tg.kch - 1 : b.kl;
+    if (tg.part) {
+        // cells this tile produces: i0+1 .. i0+60, j0 .. j0+3 (from 2), planes max(kn0, 2) .. kn1; the SA stencil reaches +-2
+        const int ia = i0 + 1, ib_ = (i0 + GS_OUT < b.il) ? i0 + GS_OUT : b.il;
+        const int ja = (j0 > 2) ? j0 : 2, jb_ = (j0 + NG_BY - 1 < b.jl) ? j0 + NG_BY - 1 : b.jl;
+        const int ka = (kn0 > 2) ? kn0 : 2;
+        const bool interior = (ia - 2 >= 2 && ib_ + 2 <= b.il && ja - 2 >= 2 && jb_ + 2 <= b.jl && ka - 2 >= 2 && kn1 + 2 <= b.kl);
+        if (interior != (tg.part == 1)) return;               // uniform per workgroup
+    }
     const int i = i0 - 1 + lane, j = j0 + row;
     const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
     const bool outC = (lane >= 2 && lane <= GS_OUT + 1 && i <= b.il && j >= 2 && j <= b.jl);   // SA cell produced
@@ -1263,13 +1274,14 @@ void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KPa
 int g_sa_march = 1;         // tuning "sa_march": 0 = gather kernel (k_sa_residual), 1 = k-march
 
 // the Spalart-Allmaras residual alone, as a k-march (blocks at rest)
-void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, int part)
 {
-    LEVEL_SPLIT(nslots, nz + 4, launch_sa_march_level(tab + s0_, n_, nx, ny, nz, kp, s));
+    LEVEL_SPLIT(nslots, nz + 4, launch_sa_march_level(tab + s0_, n_, nx, ny, nz, kp, s, part));
     if (nslots <= 0) return;
     int nchn, kch;
     node_chunks(nz + 1, &nchn, &kch);
-    const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
+    TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
+    tg.part = part;
     if (kp.rvec) {
         hipLaunchKernelGGL((k_sa_march<false, true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
         adf_note_rvec(2);

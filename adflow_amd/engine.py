@@ -147,10 +147,11 @@ class Engine:
         return out
 
     def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True, dissApprox=False, viscApprox=False,
-                     useBlockettes=False):
+                     useBlockettes=False, halo=False):
+        """halo: also the part of blocketteRes in front of the core -- boundary conditions and whalo2 (ADFLOW_RES_HALO)"""
         flags = (capi.RES_UPDATE_INTERMED if updateIntermed else 0) | (capi.RES_FLOW if flowRes else 0) \
             | (capi.RES_TURB if turbRes else 0) | (32 if dissApprox else 0) | (64 if viscApprox else 0) \
-            | (128 if useBlockettes else 0)
+            | (128 if useBlockettes else 0) | (16 if halo else 0)
         self._chk(self.lib.adflow_gpu_block_res(level, flags))
 
     def bc_register(self, faces, nViscBocos: int = 0, nn: int = 1, level: int = 1, sps: int = 1):

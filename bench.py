@@ -230,7 +230,7 @@ class Job:
         from adflow_amd.synth import make_block, make_coarse_block
         from adflow_amd.topology import BrickTopology
         import numpy as np
-        self.name, self.eng, self.rank, self.world = name, eng, rank, world
+        self.name, self.eng, self.rank, self.world, self.a = name, eng, rank, world, a
         wl = self.wl = WORKLOADS[name]
         self.prm = FlowParams(equations=wl["equations"], spaceDiscr=wl["spaceDiscr"], vis4=0.1 if wl["spaceDiscr"] == 2 else 0.0156)
         eng.set_options(self.prm)
@@ -297,9 +297,14 @@ class Job:
         self.do_halo = not self.halo.startswith("FAILED")
 
     def step(self):
+        # blocketteRes with the reference's default flags: updateIntermed = F, flowRes = T, turbRes = T.  The exchange in front of
+        # the core is whalo2 either way; inside ONE call (default) the library may run the tiles that read no halo cell while the
+        # messages are in flight (api.hip block_res_split_enqueue; only when the pattern has messages, i.e. N > 1 or comm_self)
+        if self.do_halo and not getattr(self.a, "separate_halo", False):
+            self.eng.blocketteRes(1, False, True, self.wl["equations"] == 3, halo=True)
+            return
         if self.do_halo:
             self.eng.whalo2(1, 1, self.prm.nw)
-        # blocketteRes core with the reference's default flags: updateIntermed = F, flowRes = T, turbRes = T
         self.eng.blocketteRes(1, False, True, self.wl["equations"] == 3)
 
 
@@ -360,6 +365,8 @@ def main():
     ap.add_argument("--no-mg", action="store_true", help="skip the config-2 multigrid cycle measurement")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K steps until the region lasts this long")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
+    ap.add_argument("--separate-halo", action="store_true",
+                    help="whalo2 and the blocketteRes core as two calls (rounds 1-2) instead of one call with the exchange inside")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, the driver's contract): every GPU owns its own brick of the workload's blocks; strong: the SAME "
                          "mesh (BASELINE north_star: the 8-block CRM mesh) split over the GPUs, 8 / N blocks each")

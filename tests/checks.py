@@ -86,10 +86,11 @@ def check_block_res_vs_blockette(engine, dims, prm, update_intermed=False, seed=
     return blk, r
 
 
-def check_brick_block_res(engine, topo, prm, seed=17, **mk):
+def check_brick_block_res(engine, topo, prm, seed=17, fused_halo=False, **mk):
     """The bench's step on a multi-block brick: whalo2 (2-layer exchange, state scrambled before it so that the halos are stale)
     followed by the blocketteRes core with the default flags on EVERY block, against the reference's own whalo2 +
-    blocketteResCore per block (blockette.F90:246, 299-753)."""
+    blocketteResCore per block (blockette.F90:246, 299-753).  fused_halo: ONE call with ADFLOW_RES_HALO (the exchange inside
+    blocketteRes, where the library may put the halo-free tiles between the messages' departure and arrival)."""
     from oracle import ref
     blocks, rblocks = setup_brick(engine, topo, prm, seed, **mk)
     rng = np.random.default_rng(seed)
@@ -104,8 +105,11 @@ def check_brick_block_res(engine, topo, prm, seed=17, **mk):
                 r[n][...] = b[n]
         engine.upload_state(nn, 1)
     ref.call_level("whalo2", 1, 1, prm.nw)
-    engine.whalo2(1, 1, prm.nw)
-    engine.blocketteRes(level=1, updateIntermed=False, flowRes=True, turbRes=turb)
+    if fused_halo:
+        engine.blocketteRes(level=1, updateIntermed=False, flowRes=True, turbRes=turb, halo=True)
+    else:
+        engine.whalo2(1, 1, prm.nw)
+        engine.blocketteRes(level=1, updateIntermed=False, flowRes=True, turbRes=turb)
     for nn in sorted(rblocks):
         ref.call_level("setPointers", 1, nn)
         ref.blockette_res_core(False, True, turb)

@@ -56,6 +56,28 @@ def test_multiblock_brick_at_bench_block_size(engine):
         checks.check_brick_block_res(engine, BrickTopology(2, 2, 2, 64, 48, 32), prm, seed=sd, stretch_k=2.0)
 
 
+def test_evaluation_split_around_the_exchange(engine):
+    """tuning split_eval = 2: whalo2 + blocketteRes in one call with the tiles that read no halo cell between the start and the end
+    of the exchange, the others behind it: blocks with several interior tiles in every direction (interior / boundary partition of
+    the SA march and of the chunk table of k_visc_gf), RANS and laminar, Roe and matrix dissipation; stale halos before the call"""
+    from adflow_amd.topology import BrickTopology
+    try:
+        engine.set_tuning("split_eval", 2)
+        engine.set_tuning("gf_cus", 2)            # small rounds: several k chunks per column, interior ones among them
+        engine.set_tuning("grad_kch", 8)          # the same for the SA march
+        for prm in (FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0),
+                    FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, vis4=0.1, muSuthDim=1.0)):
+            checks.check_brick_block_res(engine, BrickTopology(2, 1, 1, 130, 14, 40), prm, seed=23, fused_halo=True, stretch_k=2.0)
+        engine.set_tuning("gf_cus", 0)
+        engine.set_tuning("grad_kch", 32)
+        checks.check_brick_block_res(engine, BrickTopology(2, 2, 1, 9, 7, 5), FlowParams(equations=RANSEquations, spaceDiscr=upwind), seed=24,
+                                     fused_halo=True, stretch_k=2.0)
+    finally:
+        engine.set_tuning("split_eval", 1)
+        engine.set_tuning("gf_cus", 0)
+        engine.set_tuning("grad_kch", 32)
+
+
 def test_left_handed_block(engine):
     """a block whose (i, j, k) system is left-handed (mirror image): metric_block takes fact = -half.  The marching kernels that
     re-form the face normals from the nodes (SA, nodal gradients, time step) must do the same; update_geometry too."""
