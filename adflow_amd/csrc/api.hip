@@ -15,7 +15,8 @@
 
 #include "internal.h"
 
-extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_xcd_tiles, g_grad_kch;
+extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march;
+int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
 
 namespace {
 
@@ -130,6 +131,7 @@ std::map<int, int> g_tab_size;
 std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
 std::map<int, std::pair<int4*, int>> g_gf_tiles;       // level -> round-fitted chunk table of k_visc_gf
 std::map<int, std::pair<int4*, int>> g_gf_tiles_int, g_gf_tiles_bnd;   // the same chunks: those that read no halo cell / the others
+std::map<int, std::pair<int4*, int>> g_sa_tiles, g_sa_tiles_int, g_sa_tiles_bnd;   // the same three for k_sa_march
 int g_num_cus = 0;
 int g_gf_nofit = 0;         // tuning gf_cus = -1 (tests): chunks of march_kch planes instead of the round fit
 int g_phase_base = 0;                                    // tuning "phase_events": first of 8 event slots, 0 = off
@@ -177,7 +179,7 @@ void invalidate_comm_level(int level)
         (void)hipFree(jt->second.first);
         g_tiles.erase(jt);
     }
-    for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd}) {
+    for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
         jt = mp->find(level);
         if (jt != mp->end()) {
             (void)hipFree(jt->second.first);
@@ -194,6 +196,7 @@ struct LevelTab { const BlkView* tab; int n, nx, ny, nz; };
 int level_tab(int level, LevelTab* t);
 int ensure_tiles(int level);
 int ensure_gf_tiles(int level);
+int ensure_sa_tiles(int level);
 int build_comm(int level, int nLayers, CommPattern** out);
 int halo_mask(int varStart, int varEnd, int commPressure, int commVisc, unsigned* mask, int* nvar);
 int make_list(int level, const int32_t* blk, const int32_t* idx, int ld, int first, int n, int** d_blk, long** d_off);
@@ -1172,7 +1175,7 @@ static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0
         return 0;
     });
     if (rc) return rc;
-    if (ensure_tiles(level) || ensure_gf_tiles(level)) return 1;
+    if (ensure_tiles(level) || ensure_gf_tiles(level) || (rans && ensure_sa_tiles(level))) return 1;
     *taken = 1;
     KParams kv = kp;
     kv.viscFirst = 1;
@@ -1183,7 +1186,7 @@ static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0
     // ---- halo-free tiles
     if (rans) {
         HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
-        launch_sa_march_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_streamB, 1);
+        launch_sa_march(t.tab, g_sa_tiles_int[level].first, g_sa_tiles_int[level].second, kp, g_streamB, false);
     }
     launch_visc_gf(g_tab[level], g_gf_tiles_int[level].first, g_gf_tiles_int[level].second, kv, false, g_stream);
     // ---- messages in
@@ -1193,7 +1196,7 @@ static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0
     if (rans) {
         HIPCHK(hipEventRecord(g_evC, g_stream));
         HIPCHK(hipStreamWaitEvent(g_streamB, g_evC, 0));
-        launch_sa_march_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_streamB, 2);
+        launch_sa_march(t.tab, g_sa_tiles_bnd[level].first, g_sa_tiles_bnd[level].second, kp, g_streamB, false);
         HIPCHK(hipEventRecord(g_evB, g_streamB));
     }
     launch_visc_gf(g_tab[level], g_gf_tiles_bnd[level].first, g_gf_tiles_bnd[level].second, kv, false, g_stream);
@@ -1285,8 +1288,10 @@ static int block_res_enqueue(int level, unsigned flags)
                 ss = g_streamB;
                 saForked = true;
             }
-            if (g_sa_march && !moving) launch_sa_march_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, ss);
-            else launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, ss);
+            if (g_sa_march && !moving) {
+                if (ensure_sa_tiles(level)) return 1;
+                launch_sa_march(t.tab, g_sa_tiles[level].first, g_sa_tiles[level].second, kp, ss, false);
+            } else launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, ss);
             if (saForked) HIPCHK(hipEventRecord(g_evB, g_streamB));
         }
     }
@@ -1763,9 +1768,11 @@ int ensure_tiles(int level)
 // get c or c+1 chunks, the chunks are launched longest first (every round holds chunks of one length), and within a round
 // workgroup p = 8 s + x takes the x-th contiguous eighth of the round's chunks, so that XCD x (which receives the workgroups
 // p % 8 == x) works on neighbouring tiles.  Entry: x = block slot (-1: empty), y = bx | by << 16, z = first plane, w = last plane.
-int ensure_gf_tiles(int level)
+// R = produced cell rows per workgroup (3: k_visc_gf, 4: k_sa_march), warm = planes a chunk costs beyond its own, reach = cells the
+// stencil of a produced cell reaches (the interior / boundary partition); all / in / bd: the three tables
+static int build_chunk_tables(int level, int R, double warm, int reach, std::pair<int4*, int>* all, std::pair<int4*, int>* in_,
+                              std::pair<int4*, int>* bd_)
 {
-    if (g_gf_tiles.count(level)) return 0;
     if (ensure_table(level)) return 1;
     struct Col { int slot, bx, by, nz, nx, ny; };
     std::vector<Col> cols;
@@ -1773,14 +1780,14 @@ int ensure_gf_tiles(int level)
     for (auto& kv : g_blocks) {
         if (std::get<0>(kv.first) != level || std::get<1>(kv.first) != 1) continue;
         const BlkView& v = kv.second->v;
-        const int gx = (v.nx + 59) / 60, gy = (v.ny + 2) / 3;
+        const int gx = (v.nx + 59) / 60, gy = (v.ny + R - 1) / R;
         for (int by = 0; by < gy; ++by)
             for (int bx = 0; bx < gx; ++bx) { cols.push_back(Col{std::get<2>(kv.first), bx, by, v.nz, v.nx, v.ny}); planes += v.nz; }
     }
     const int N = (int)cols.size();
-    if (N == 0) { g_gf_tiles[level] = std::make_pair((int4*)nullptr, 0); return 0; }
+    *all = *in_ = *bd_ = std::make_pair((int4*)nullptr, 0);
+    if (N == 0) return 0;
     const int W = adf_round_size();
-    const double warm = 1.5;
     const int kmin = 8;
     // chunks of a column for a total of T chunks: proportional to its planes (largest remainder), at least 1, at most nz / kmin
     auto split = [&](long T, std::vector<int>& c) {
@@ -1872,23 +1879,38 @@ int ensure_gf_tiles(int level)
         *out = std::make_pair(d, n);
         return 0;
     };
-    std::pair<int4*, int> all;
-    if (make_table(ch, &all)) return 1;
-    g_gf_tiles[level] = all;
+    if (make_table(ch, all)) return 1;
     // the same chunks in two tables for the evaluation split around the halo exchange: "interior" = the produced cells (columns
-    // 2+60 bx .., rows 2+3 by .., planes k0 .. k1) and their +-1 stencil lie inside the owned range
+    // 2+60 bx .., rows 2+R by .., planes k0 .. k1) and their stencil (+-reach) lie inside the owned range
     std::vector<Chunk> in, bd;
     for (const Chunk& c : ch) {
         const Col& q = cols[c.col];
         const int il = q.nx + 1, jl = q.ny + 1, kl = q.nz + 1;
-        const int ia = 2 + 60 * q.bx, ib_ = std::min(ia + 59, il), ja = 2 + 3 * q.by, jb_ = std::min(ja + 2, jl);
-        const bool interior = (ia - 1 >= 2 && ib_ + 1 <= il && ja - 1 >= 2 && jb_ + 1 <= jl && c.k0 - 1 >= 2 && c.k1 + 1 <= kl);
+        const int ia = 2 + 60 * q.bx, ib_ = std::min(ia + 59, il), ja = 2 + R * q.by, jb_ = std::min(ja + R - 1, jl);
+        const bool interior = (ia - reach >= 2 && ib_ + reach <= il && ja - reach >= 2 && jb_ + reach <= jl && c.k0 - reach >= 2 &&
+                               c.k1 + reach <= kl);
         (interior ? in : bd).push_back(c);
     }
-    std::pair<int4*, int> pi, pb;
-    if (make_table(in, &pi) || make_table(bd, &pb)) return 1;
-    g_gf_tiles_int[level] = pi;
-    g_gf_tiles_bnd[level] = pb;
+    if (make_table(in, in_) || make_table(bd, bd_)) return 1;
+    return 0;
+}
+
+int ensure_gf_tiles(int level)
+{
+    if (g_gf_tiles.count(level)) return 0;
+    std::pair<int4*, int> a, i, b;
+    if (build_chunk_tables(level, 3, 1.5, 1, &a, &i, &b)) return 1;
+    g_gf_tiles[level] = a; g_gf_tiles_int[level] = i; g_gf_tiles_bnd[level] = b;
+    return 0;
+}
+
+// chunk tables of the Spalart-Allmaras march: 60 columns x 4 rows, no warm-up plane beyond the window fill, stencil +-2
+int ensure_sa_tiles(int level)
+{
+    if (g_sa_tiles.count(level)) return 0;
+    std::pair<int4*, int> a, i, b;
+    if (build_chunk_tables(level, 4, 0.5, 2, &a, &i, &b)) return 1;
+    g_sa_tiles[level] = a; g_sa_tiles_int[level] = i; g_sa_tiles_bnd[level] = b;
     return 0;
 }
 
@@ -3207,7 +3229,12 @@ int adflow_gpu_sa_solve(int level)
         if (level_tab(level, &t)) return 1;
         bool movingS = false;
         for_level(level, [&](Block* b) { movingS = movingS || b->v.sFace || b->v.moving; return 0; });
-        launch_sa_solve_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream, g_sa_march == 1 && !movingS);
+        const bool marchRes = (g_sa_march == 1 && !movingS);
+        if (marchRes) {
+            if (ensure_sa_tiles(level)) return 1;
+            launch_sa_march(t.tab, g_sa_tiles[level].first, g_sa_tiles[level].second, kp, g_stream, true);
+        }
+        launch_sa_solve_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream, marchRes);
         if (turb_bc_apply_enqueue(level, kp, 1)) return 1;
         if (g_turb_bc_callback) {
             HIPCHK(hipStreamSynchronize(g_stream));
@@ -3270,7 +3297,15 @@ int adflow_gpu_march_stats(int level, double* out, int n)
     if (need_ready()) return 1;
     if (!out || n < 4) return fail("march_stats: n = %d (>= 4)", n);
     for (int q = 0; q < n; ++q) out[q] = 0.0;
-    if (ensure_gf_tiles(level) || ensure_tiles(level)) return 1;
+    if (ensure_gf_tiles(level) || ensure_sa_tiles(level) || ensure_tiles(level)) return 1;
+    // Spalart-Allmaras march: one trip per produced plane, four wavefronts
+    {
+        const auto& tt = g_sa_tiles[level];
+        std::vector<int4> h((size_t)tt.second);
+        if (tt.second > 0) HIPCHK(hipMemcpy(h.data(), tt.first, sizeof(int4) * h.size(), hipMemcpyDeviceToHost));
+        for (const int4& t : h)
+            if (t.x >= 0) out[0] += 4.0 * (t.w - t.z + 1);
+    }
     // fused gradient + viscous march: every chunk marches its planes + 2 (k_visc_gf: mm = k0-1 .. k1+1), four wavefronts
     {
         const auto& tt = g_gf_tiles[level];
@@ -3286,10 +3321,6 @@ int adflow_gpu_march_stats(int level, double* out, int n)
         int ntx, nty, ntz;
         euler_march_tiles(v, &ntx, &nty, &ntz);
         out[2] += 4.0 * ntx * nty * (v.nz + ntz);
-        // SA / nodal-gradient marches: nz + 1 node planes in balanced chunks of <= grad_kch, kch + 1 trips per chunk, 4 rows
-        const int nzn = v.nz + 1, L = g_grad_kch > 0 ? g_grad_kch : 32, nch = (nzn + L - 1) / L, kch = (nzn + nch - 1) / nch;
-        out[0] += 4.0 * ((v.nx + 1 + 59) / 60) * ((v.ny + 1 + 3) / 4) * nch * (kch + 1);
-        out[3] += 4.0 * ((v.nx + 1 + 61) / 62) * ((v.ny + 1 + 3) / 4) * nch * (kch + 1);
     }
     return 0;
 }
@@ -3321,7 +3352,6 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_tiles.clear();
         return 0;
     }
-    if (!strcmp(key, "grad_kch")) { g_grad_kch = value; return 0; }
     if (!strcmp(key, "phase_events")) {
         if (value != 0 && (value < 8 || value > 56)) return fail("phase_events: first slot must be 8..56 (or 0 = off)");
         g_phase_base = value;
@@ -3332,7 +3362,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_march_kch = value;
         for (auto& kv : g_tiles) (void)hipFree(kv.second.first);   // tile tables depend on the chunk length
         g_tiles.clear();
-        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd}) {
+        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
             for (auto& kv : *mp) (void)hipFree(kv.second.first);
             mp->clear();
         }
@@ -3351,7 +3381,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_gf_nofit = (value < 0);
         g_num_cus = value > 0 ? value : 0;
         if (g_stream) (void)hipStreamSynchronize(g_stream);
-        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd}) {
+        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
             for (auto& kv : *mp) (void)hipFree(kv.second.first);
             mp->clear();
         }

@@ -394,7 +394,7 @@ void launch_inviscid_level(const BlkView* tab, int nslots, int maxnx, int maxny,
 void launch_initres(const BlkView& b, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s);
 int viscous_is_tiled();
-void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, int part = 0);
+void launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s, bool solve);
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 bool euler_march_radii_capable(const KParams& kp);
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s);
@@ -409,7 +409,6 @@ void launch_viscous_approx(const BlkView& b, const KParams& kp, hipStream_t s);
 void launch_face_vectors(const BlkView& b, hipStream_t s);
 void launch_sa_residual_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, bool marchRes = false);
-void launch_sa_march_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void launch_rk_save_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s);
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s);
 void launch_scale_dw_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double factor, int timesVol, hipStream_t s);

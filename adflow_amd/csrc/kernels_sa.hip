@@ -375,15 +375,15 @@ __global__ __launch_bounds__(64) void k_sa_solve_i(const BlkView* __restrict__ t
 }
 
 
-// marchRes: residual, right-hand side and central jacobian from the k-marching kernel (blocks at rest) instead of the gather kernel
+// marchRes: residual, right-hand side and central jacobian were left by the k-marching kernel (launch_sa_march, blocks at rest);
+// otherwise the gather kernel forms them here
 void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, bool marchRes)
 {
     LEVEL_SPLIT(nslots, nz + 4, launch_sa_solve_level(tab + s0_, n_, nx, ny, nz, kp, s, marchRes));
     if (nslots <= 0) return;
     dim3 blk(SA_BX, SA_BY, 1);
     dim3 grd((nx + SA_BX - 1) / SA_BX, (ny + SA_BY - 1) / SA_BY, nz * nslots);
-    if (marchRes) launch_sa_march_solve_level(tab, nslots, nx, ny, nz, kp, s);
-    else hipLaunchKernelGGL((k_sa_residual<true>), grd, blk, 0, s, tab, nz, kp);
+    if (!marchRes) hipLaunchKernelGGL((k_sa_residual<true>), grd, blk, 0, s, tab, nz, kp);
     dim3 l64(64, 1, 1);
     // sweep order of the reference: j, i, k
     hipLaunchKernelGGL((k_sa_sweep<1>), dim3((nx + 63) / 64, nz, nslots), l64, 0, s, tab, kp, 0);

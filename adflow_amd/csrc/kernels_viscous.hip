@@ -129,68 +129,14 @@ __device__ __forceinline__ void ng_outer(double g[12], double sign, const double
     }
 }
 
-// 1-D launches of the gradient / SA marches: the dispatcher places workgroup p on XCD p % 8, so with `per` = workgroups per XCD
-// the tile index is (p % 8) per + p / 8: every XCD owns a contiguous run of the (i, j, k chunk, block) tile order and the rows
-// shared by j-neighbouring tiles meet in one L2 instead of being fetched from HBM by two XCDs.  per = 0: tile index = p.
-// W > 0 (xcd_tiles = 2, default): the same within every ROUND of W resident workgroups, so that the eight XCDs work on neighbouring
-// tiles at any time (api.hip ensure_tiles).
-// part: 0 = every tile, 1 = only the tiles whose produced cells read no halo cell (2 layers), 2 = only the others (the evaluation split
-// around the halo exchange, api.hip block_res_split_enqueue)
-struct TileGrid { int gx, gy, total, per, kch, W, part; };     // kch: node planes per march
-
-__device__ __forceinline__ bool tile_of_workgroup(const TileGrid& g, int& bx, int& by, int& bz)
-{
-    const int p = (int)blockIdx.x;
-    int t;
-    if (g.W > 0) {
-        const int q = p / g.W, pr = p - q * g.W;
-        const int left = g.total - q * g.W, nIn = left < g.W ? left : g.W, per = (nIn + 7) >> 3;
-        const int x = pr & 7, s = pr >> 3;
-        if (s >= per || x * per + s >= nIn) return false;
-        t = q * g.W + x * per + s;
-    } else
-        t = g.per ? (p & 7) * g.per + (p >> 3) : p;
-    if (t >= g.total) return false;
-    bx = t % g.gx;
-    const int r = t / g.gx;
-    by = r % g.gy; bz = r / g.gy;
-    return true;
-}
-
-int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
-
-int g_grad_kch = NG_KCH;    // tuning "grad_kch": longest k chunk of the gradient / SA marches; the node planes are spread evenly over the chunks
-
-// chunks of nzn node planes: count and (balanced) length
-static void node_chunks(int nzn, int* nchn, int* kch)
-{
-    const int L = g_grad_kch > 0 ? g_grad_kch : NG_KCH;
-    *nchn = (nzn + L - 1) / L;
-    *kch = (nzn + *nchn - 1) / *nchn;
-}
-
-static TileGrid tile_grid(int gx, int gy, int nchn, int nslots, int kch)
-{
-    TileGrid g;
-    g.gx = gx; g.gy = gy; g.total = gx * gy * nchn * nslots;
-    g.per = g_xcd_tiles ? (g.total + 7) / 8 : 0;
-    g.kch = kch;
-    g.W = (g_xcd_tiles >= 2) ? adf_round_size() : 0;
-    g.part = 0;
-    return g;
-}
-static int tile_grid_size(const TileGrid& g)
-{
-    if (g.W > 0) return ((g.total + g.W - 1) / g.W) * g.W;
-    return g.per ? 8 * g.per : g.total;
-}
-
 // ---------------------------------------------------------------------------
 // The Spalart-Allmaras residual as a k-march.  k_sa_residual gathers 73 values per cell (237 B per cell from HBM, bound by load
 // latency).  Here a thread keeps a three-plane window of its own column (u, v, w, nu = rlv / rho, vol; five planes of nuTilde),
 // takes the i neighbours by DPP lane shifts and loads only the j neighbours, d2Wall and volRef; the face normals are re-formed
 // from the node coordinates (tuning metric_from_x bit 0) or loaded.  No LDS, no barrier.
 // Tiles advance by 60: cells of lanes 2..61 (second-order advection reaches i +- 2).
+// Work list: the level's round-fitted chunk table (api.hip ensure_sa_tiles; x = slot or -1, y = bx | by << 16, z / w = first / last cell
+// plane): 60 columns x 4 rows x (k0 .. k1), one loop trip per produced plane.
 // Arithmetic of the SA terms: sa_core.h (shared with k_sa_residual), same order of the sweeps (k, j, i).
 // ---------------------------------------------------------------------------
 #define GS_OUT 60
@@ -247,27 +193,16 @@ __device__ __forceinline__ GsNbr gs_dn1(const GsNbr& q)
 // as k_sa_residual<true> (kernels_sa.hip)
 // RV: the residual also goes to the matrix-free residual vector kp.rvec (setRVec: dw / volRef * turbResScale)
 template <bool SOLVE, bool RV = false>
-__global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __restrict__ tab, int nzb, KParams kp, TileGrid tg)
+__global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
-    int bx, by, bz;
-    if (!tile_of_workgroup(tg, bx, by, bz)) return;
-    const BlkView& b = tab[bz / nzb + 1];
+    const int4 tl = tiles[blockIdx.x];
+    if (tl.x < 0) return;
+    const BlkView& b = tab[tl.x];
     const int lane = threadIdx.x, row = threadIdx.y;
-    const int i0 = bx * GS_OUT + 1, j0 = by * NG_BY + 1;      // first node of the tile
-    const int kn0 = (bz % nzb) * tg.kch + 1;
-    if (b.nx == 0 || kn0 > b.kl || i0 > b.il || j0 > b.jl) return;            // uniform per workgroup
-    const int kn1 = (kn0 + tg.kch - 1 < b.kl) ? kn0 + tg.kch - 1 : b.kl;
-    if (tg.part) {
-        // cells this tile produces: i0+1 .. i0+60, j0 .. j0+3 (from 2), planes max(kn0, 2) .. kn1; the SA stencil reaches +-2
-        const int ia = i0 + 1, ib_ = (i0 + GS_OUT < b.il) ? i0 + GS_OUT : b.il;
-        const int ja = (j0 > 2) ? j0 : 2, jb_ = (j0 + NG_BY - 1 < b.jl) ? j0 + NG_BY - 1 : b.jl;
-        const int ka = (kn0 > 2) ? kn0 : 2;
-        const bool interior = (ia - 2 >= 2 && ib_ + 2 <= b.il && ja - 2 >= 2 && jb_ + 2 <= b.jl && ka - 2 >= 2 && kn1 + 2 <= b.kl);
-        if (interior != (tg.part == 1)) return;               // uniform per workgroup
-    }
-    const int i = i0 - 1 + lane, j = j0 + row;
+    const int kn0 = tl.z, kn1 = tl.w;                          // cell planes of the chunk (2 .. kl)
+    const int i = (tl.y & 0xffff) * GS_OUT + lane, j = 2 + (tl.y >> 16) * NG_BY + row;      // cells of lanes 2 .. 61
     const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.jb) ? j : b.jb;
-    const bool outC = (lane >= 2 && lane <= GS_OUT + 1 && i <= b.il && j >= 2 && j <= b.jl);   // SA cell produced
+    const bool outC = (lane >= 2 && lane <= GS_OUT + 1 && i <= b.il && j <= b.jl);   // SA cell produced
     const long nb = b.nbox;
     GsPtrs m;
     m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w5 = m.w3 + 2 * nb;
@@ -297,11 +232,10 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
         for (int d = 0; d < 3; ++d) sKp[d] = ldg(m.sK, c - sk + d * m.nb8);
     }
     // window of the own column: planes kn0-1 (SA neighbour below) and kn0; nuTilde of planes kn0-2 .. kn0+1
-    const unsigned ckm2 = (kn0 >= 2) ? 2 * sk : sk;       // plane kn0-2 clamped at 0 (kn0 = 1: not read by a produced cell)
     GsCell s0 = gs_ld(m, c);
     GsNbr sm1 = gs_nbr_ld(m, c - sk);
-    double n_m2 = ldg(m.w5, c - ckm2), n_0 = ldg(m.w5, c), n_p1 = ldg(m.w5, c + sk);
-    for (int mm = kn0; mm <= kn1 + 1; ++mm) {
+    double n_m2 = ldg(m.w5, c - 2 * sk), n_0 = ldg(m.w5, c), n_p1 = ldg(m.w5, c + sk);
+    for (int mm = kn0; mm <= kn1; ++mm) {
         const unsigned ckp2 = (mm + 2 <= b.kb) ? 2 * sk : ((mm + 1 <= b.kb) ? sk : 0u);
         const unsigned ckp1 = (mm + 1 <= b.kb) ? sk : 0u;
         // ---- loads of this plane: the four face-normal triples, the state of the plane above, nuTilde two planes above
@@ -320,8 +254,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
 #pragma unroll
         for (int d = 0; d < 3; ++d) sKp[d] = nK[d];
         // ---- Spalart-Allmaras residual of cell (i, j, mm): sweeps k, j, i as the reference (sa.F90, turbUtils.F90)
-        const bool saPlane = (mm >= 2 && mm <= kn1);
-        if (saPlane) {
+        {
             GsNbr q0;
             q0.u = s0.u; q0.v = s0.v; q0.w = s0.w; q0.nu = s0.rlv * rcp_nr(s0.rho); q0.vol = s0.vol; q0.nut = n_0;
             GsNbr qkp;
@@ -1273,31 +1206,18 @@ void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KPa
 
 int g_sa_march = 1;         // tuning "sa_march": 0 = gather kernel (k_sa_residual), 1 = k-march
 
-// the Spalart-Allmaras residual alone, as a k-march (blocks at rest)
-void launch_sa_march_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, int part)
+// the Spalart-Allmaras residual as a k-march over a chunk table of the level (blocks at rest); solve: also the right-hand side and the
+// central jacobian of saSolve
+void launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s, bool solve)
 {
-    LEVEL_SPLIT(nslots, nz + 4, launch_sa_march_level(tab + s0_, n_, nx, ny, nz, kp, s, part));
-    if (nslots <= 0) return;
-    int nchn, kch;
-    node_chunks(nz + 1, &nchn, &kch);
-    TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-    tg.part = part;
-    if (kp.rvec) {
-        hipLaunchKernelGGL((k_sa_march<false, true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
+    if (ntiles <= 0) return;
+    const dim3 grd(ntiles), blk(64, NG_BY, 1);
+    if (solve) hipLaunchKernelGGL((k_sa_march<true>), grd, blk, 0, s, tab, tiles, kp);
+    else if (kp.rvec) {
+        hipLaunchKernelGGL((k_sa_march<false, true>), grd, blk, 0, s, tab, tiles, kp);
         adf_note_rvec(2);
     } else
-        hipLaunchKernelGGL((k_sa_march<false>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
-}
-
-// the SA residual with the right-hand side and the central jacobian of saSolve (blocks at rest)
-void launch_sa_march_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
-{
-    LEVEL_SPLIT(nslots, nz + 4, launch_sa_march_solve_level(tab + s0_, n_, nx, ny, nz, kp, s));
-    if (nslots <= 0) return;
-    int nchn, kch;
-    node_chunks(nz + 1, &nchn, &kch);
-    const TileGrid tg = tile_grid((nx + 1 + GS_OUT - 1) / GS_OUT, (ny + 1 + NG_BY - 1) / NG_BY, nchn, nslots, kch);
-    hipLaunchKernelGGL((k_sa_march<true>), dim3(tile_grid_size(tg)), dim3(64, NG_BY, 1), 0, s, tab, nchn, kp, tg);
+        hipLaunchKernelGGL((k_sa_march<false>), grd, blk, 0, s, tab, tiles, kp);
 }
 
 int viscous_is_tiled() { return g_viscous_tiled; }

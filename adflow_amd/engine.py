@@ -324,7 +324,7 @@ class Engine:
     def march_stats(self, level: int = 1):
         out = (ctypes.c_double * 4)()
         self._chk(self.lib.adflow_gpu_march_stats(level, out, 4))
-        return {"sa_march": out[0], "visc_gf": out[1], "tile_march": out[2], "node_grad_march": out[3]}
+        return {"sa_march": out[0], "visc_gf": out[1], "tile_march": out[2]}
 
     def sync(self):
         self._chk(self.lib.adflow_gpu_sync())

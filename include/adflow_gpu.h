@@ -393,7 +393,7 @@ int adflow_gpu_event_elapsed_ms(int slot_start, int slot_stop, double* ms);
 int adflow_gpu_sync(void);
 /* wavefront-steps (wavefronts x k-planes marched) one evaluation of `level` costs each marching kernel, for the FP64-issue roofline of
  * bench.py (steps x the instruction count of the kernel's main loop, profiles/isa_counts.json): out[0] Spalart-Allmaras march,
- * [1] fused nodal gradients + viscous fluxes, [2] inviscid / viscous marches over the tile table, [3] nodal-gradient march;
+ * [1] fused nodal gradients + viscous fluxes, [2] inviscid / viscous marches over the tile table, [3] reserved (0);
  * n >= 4.  Geometry only, no device work. */
 int adflow_gpu_march_stats(int level, double* out, int n);
 /* performance knobs for A/B measurements; results never depend on them.

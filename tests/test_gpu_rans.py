@@ -64,18 +64,15 @@ def test_evaluation_split_around_the_exchange(engine):
     try:
         engine.set_tuning("split_eval", 2)
         engine.set_tuning("gf_cus", 2)            # small rounds: several k chunks per column, interior ones among them
-        engine.set_tuning("grad_kch", 8)          # the same for the SA march
         for prm in (FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0),
                     FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, vis4=0.1, muSuthDim=1.0)):
             checks.check_brick_block_res(engine, BrickTopology(2, 1, 1, 130, 14, 40), prm, seed=23, fused_halo=True, stretch_k=2.0)
         engine.set_tuning("gf_cus", 0)
-        engine.set_tuning("grad_kch", 32)
         checks.check_brick_block_res(engine, BrickTopology(2, 2, 1, 9, 7, 5), FlowParams(equations=RANSEquations, spaceDiscr=upwind), seed=24,
                                      fused_halo=True, stretch_k=2.0)
     finally:
         engine.set_tuning("split_eval", 1)
         engine.set_tuning("gf_cus", 0)
-        engine.set_tuning("grad_kch", 32)
 
 
 def test_left_handed_block(engine):
@@ -191,13 +188,14 @@ def test_viscous_kernel_variants(engine):
             engine.set_tuning("inviscid_march", im)
             checks.check_block_res(engine, (63, 6, 35), FlowParams(equations=RANSEquations, spaceDiscr=dissMatrix, vis4=0.1, muSuthDim=1.0),
                                    seed=68, stretch_k=2.0, holes=0.05)
-        for xt, gk in ((0, 32), (1, 5), (1, 64)):     # gradient / SA march tiles in launch order; k chunks of <= 5 planes; one chunk
+        for xt, cus in ((0, 0), (1, -1), (2, 3)):     # chunk tables of the SA / fused viscous marches: tiles in launch order; chunks of
+                                                      # march_kch planes without the round fit; rounds of six workgroups
             engine.set_tuning("xcd_tiles", xt)
-            engine.set_tuning("grad_kch", gk)
+            engine.set_tuning("gf_cus", cus)
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
-            checks.check_block_res(engine, (63, 11, 35), prm, seed=50 + gk, stretch_k=2.0, holes=0.05)
-        engine.set_tuning("xcd_tiles", 1)
-        engine.set_tuning("grad_kch", 32)
+            checks.check_block_res(engine, (63, 11, 35), prm, seed=50 + cus, stretch_k=2.0, holes=0.05)
+        engine.set_tuning("xcd_tiles", 2)
+        engine.set_tuning("gf_cus", 0)
         for mx in (0, 1):           # face normals from the arrays everywhere / re-formed from the nodes in the SA march only;
                                     # the default 7 = SA + gradient marches + time step
             engine.set_tuning("metric_from_x", mx)
@@ -208,8 +206,8 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("roe_march", 1)
         engine.set_tuning("sa_march", 1)
         engine.set_tuning("metric_from_x", 7)
-        engine.set_tuning("xcd_tiles", 1)
-        engine.set_tuning("grad_kch", 32)
+        engine.set_tuning("xcd_tiles", 2)
+        engine.set_tuning("gf_cus", 0)
         engine.set_tuning("inviscid_march", 2)
 
 

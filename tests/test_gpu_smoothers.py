@@ -38,10 +38,10 @@ def test_halo_exchange_rccl_self_loopback(engine, nLayers):
         if nLayers == 2:
             checks.check_rk_smoother(engine, BrickTopology(2, 1, 2, 12, 8, 6), FlowParams())
             # whalo2 inside blocketteRes: the halo-free tiles run while the messages to the own rank are in flight (split_eval = 1)
-            engine.set_tuning("grad_kch", 8)
+            engine.set_tuning("gf_cus", 2)          # small rounds: several k chunks per column, interior ones among them
             checks.check_brick_block_res(engine, BrickTopology(2, 1, 1, 130, 14, 40), FlowParams(equations=RANSEquations, spaceDiscr=upwind),
                                          seed=29, fused_halo=True, stretch_k=2.0)
-            engine.set_tuning("grad_kch", 32)
+            engine.set_tuning("gf_cus", 0)
     finally:
         engine.set_tuning("comm_self", 0)
 

@@ -361,13 +361,11 @@ def test_evaluation_split_around_the_exchange(hostsim_engine):
     try:
         hostsim_engine.set_tuning("split_eval", 2)
         hostsim_engine.set_tuning("gf_cus", 1)
-        hostsim_engine.set_tuning("grad_kch", 8)
         prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
         checks.check_brick_block_res(hostsim_engine, BrickTopology(2, 1, 1, 130, 11, 24), prm, seed=23, fused_halo=True, stretch_k=2.0)
     finally:
         hostsim_engine.set_tuning("split_eval", 1)
         hostsim_engine.set_tuning("gf_cus", 0)
-        hostsim_engine.set_tuning("grad_kch", 32)
 
 
 def test_exchange_pressure_early(hostsim_engine):
