@@ -3121,7 +3121,7 @@ int set_w_dev(const double* d_vec, bool withClosures = false)
         launch_set_w_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbFloor, g_stream);
     return for_level1_in_order([&](Block* b, long) {
         b->ss_valid = false;
-        b->etot_consistent = false;
+        b->etot_consistent = withClosures;        // k_set_w_closures_level leaves rhoE as computeEtot(p) already
         return 0;
     });
 }

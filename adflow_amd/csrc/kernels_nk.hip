@@ -91,6 +91,9 @@ __global__ __launch_bounds__(NK_BX* NK_BY) void k_get_r_level(const BlkView* __r
 }
 
 // owned cells: p from (rho, v, rhoE) with the 1e-4*pInfCorr floor, Sutherland, SA eddy viscosity
+// ETOT: also rhoE back from the (floored) p, the pass whalo2 closes with (haloExchange.F90:178-196, k_etot_owned_level): the exchange that
+// follows in FormFunction_mf touches no owned cell, so the result is the same and the pass over w, p is saved
+template <bool ETOT = false>
 __device__ __forceinline__ void closures_body(const BlkView& b, int kz, const KParams& kp)
 {
     const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
@@ -105,6 +108,10 @@ __device__ __forceinline__ void closures_body(const BlkView& b, int kz, const KP
     double p = gm1 * (b.w[c + 4 * nb] - 0.5 * rho * v2);
     p = fmax(p, 1.e-4 * kp.pInfCorr);
     b.p[c] = p;
+    if (ETOT) {
+        const double ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
+        b.w[c + 4 * nb] = ovgm1 * p + 0.5 * rho * v2;
+    }
     if (kp.viscous) {
         const double muSuth = kp.muSuthDim / kp.muRef, TSuth = kp.TSuthDim / kp.TRef, SSuth = kp.SSuthDim / kp.TRef;
         const double T = p / (kp.RGas * rho);
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(NK_BX* NK_BY) void k_set_w_closures_level(const Blk
 {
     const BlkView& b = tab[blockIdx.z / nzb + 1];
     set_w_body(b, (int)(blockIdx.z % nzb), vec + b.vecOff, turbFloor);
-    closures_body(b, (int)(blockIdx.z % nzb), kp);
+    closures_body<true>(b, (int)(blockIdx.z % nzb), kp);
 }
 
 __global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_level(const BlkView* __restrict__ tab, int nzb, KParams kp)

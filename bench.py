@@ -363,6 +363,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported under 'extra' (N=1)")
     ap.add_argument("--force-extras", action="store_true", help="run the extras although --tuning is given (A/B runs of a tuning key)")
     ap.add_argument("--no-mg", action="store_true", help="skip the config-2 multigrid cycle measurement")
+    ap.add_argument("--only-extras", default="", help="comma list out of 4b,matvec,pc,config3,config2: time only these extras (kernel traces)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K steps until the region lasts this long")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
     ap.add_argument("--separate-halo", action="store_true",
@@ -460,78 +461,86 @@ def main():
     dom = max(kern, key=kern.get)
 
     extra = {}
+    only = set(x for x in a.only_extras.split(",") if x)
+
+    def want(name):
+        return not only or name in only
     if extras_on:
         try:
-            # ---- config 4b: matrix dissipation on the same blocks
-            p4b = prm.replace(spaceDiscr=2, vis4=0.1)
-            eng.set_options(p4b)
-            eng.set_async(True)
-            for _ in range(3):
-                job.step()
-            s4b, r4b, e4b = timed(eng, job.step, a.steps, barrier, a.min_seconds)
-            eng.set_async(False)
-            ph4b = phase_times(eng, job.step, names=phase_names(True))
-            ph4b.pop("(mark)", None)
-            extra["crm_rans_sa_matrix_8x160x128x64"] = {
-                "value": job.cells_local / s4b / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_step": s4b * 1e3,
-                "whole_eval_hbm_frac": 255.0 * job.cells_local / s4b / 1e9 / HBM_PEAK_GBS, "phase_ms": ph4b}
-            log(f"4b matrix: {s4b * 1e3:.3f} ms/step")
-            eng.set_options(prm)
-            # ---- config 5: GMRES proxy, 30 matrix-free matvecs FormFunction_mf(w + h v_k) (NKSolvers.F90:437-461), vectors on the device
-            n = sum(v.size for v in job.wvec)
-            w0 = torch.from_numpy(np.concatenate(job.wvec)).cuda()
-            job.wvec = []
-            gen = torch.Generator(device="cuda").manual_seed(5)
-            vk = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 0.5
-            vk /= vk.norm()
-            wk = w0 + 1e-7 * vk
-            rv = torch.empty_like(w0)
-            torch.cuda.synchronize()
+            if want("4b"):
+                # ---- config 4b: matrix dissipation on the same blocks
+                p4b = prm.replace(spaceDiscr=2, vis4=0.1)
+                eng.set_options(p4b)
+                eng.set_async(True)
+                for _ in range(3):
+                    job.step()
+                s4b, r4b, e4b = timed(eng, job.step, a.steps, barrier, a.min_seconds)
+                eng.set_async(False)
+                ph4b = phase_times(eng, job.step, names=phase_names(True))
+                ph4b.pop("(mark)", None)
+                extra["crm_rans_sa_matrix_8x160x128x64"] = {
+                    "value": job.cells_local / s4b / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_step": s4b * 1e3,
+                    "whole_eval_hbm_frac": 255.0 * job.cells_local / s4b / 1e9 / HBM_PEAK_GBS, "phase_ms": ph4b}
+                log(f"4b matrix: {s4b * 1e3:.3f} ms/step")
+                eng.set_options(prm)
+            if want("matvec"):
+                # ---- config 5: GMRES proxy, 30 matrix-free matvecs FormFunction_mf(w + h v_k) (NKSolvers.F90:437-461), vectors on the device
+                n = sum(v.size for v in job.wvec)
+                w0 = torch.from_numpy(np.concatenate(job.wvec)).cuda()
+                job.wvec = []
+                gen = torch.Generator(device="cuda").manual_seed(5)
+                vk = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) - 0.5
+                vk /= vk.norm()
+                wk = w0 + 1e-7 * vk
+                rv = torch.empty_like(w0)
+                torch.cuda.synchronize()
 
-            def matvec():
-                capi.check(eng.lib.adflow_gpu_nk_residual_dev(wk.data_ptr(), rv.data_ptr(), n), eng.lib)
-            eng.set_async(True)
-            for _ in range(3):
-                matvec()
-            s5, r5, e5 = timed(eng, matvec, 30, barrier, a.min_seconds)
-            eng.set_async(False)
-            extra["config5_gmres_proxy"] = {
-                "value": job.cells_local / s5 / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_matvec": s5 * 1e3,
-                "ms_per_30_matvecs": 30 * s5 * 1e3, "bytes_per_cell": 255.0 + 96.0,
-                "whole_eval_hbm_frac": (255.0 + 96.0) * job.cells_local / s5 / 1e9 / HBM_PEAK_GBS,
-                "what": "setW + blocketteRes(default flags: closures, BCs, whalo2, core) + setRVec at w + 1e-7 v, device vectors"}
-            log(f"config 5 proxy: {s5 * 1e3:.3f} ms/matvec")
-            del w0, vk, wk, rv
-            # restore the state (setW clipped / perturbed it by 1e-7) is not needed: the remaining extras re-time only
-            # ---- the preconditioner matrix of NK / ANK: setupStateResidualMatrix(usePC = T, useAD = F), adjointUtils.F90:7-715 --
-            # 7 colours x 6 states coloured finite differences, every one closures + boundary conditions + approximate residual +
-            # the scatter of one column of all 7 stencil blocks; the blocks (7 x 36 doubles per cell) stay on the device
-            eng.setupStateResidualMatrix(1, usePC=True)            # first call allocates the block storage
-            barrier()
-            t0 = time.perf_counter()
-            eng.setupStateResidualMatrix(1, usePC=True)
-            barrier()
-            spc = time.perf_counter() - t0
-            extra["pc_matrix_assembly"] = {
-                "ms": spc * 1e3, "residual_evaluations": 43, "ms_per_evaluation": spc * 1e3 / 43.0,
-                "what": "adflow_gpu_fd_jacobian(PC): 7 colours x 6 states + the reference evaluation, lumped Roe dissipation, "
-                        "thin-layer viscous flux, first-order SA advection; blocks resident in HBM (2016 B per cell)"}
-            log(f"PC matrix assembly: {spc * 1e3:.1f} ms ({spc * 1e3 / 43.0:.2f} ms per coloured evaluation)")
-            # ---- config 3: one solver iteration = D-ADI x3 sub-iterations + SA DDADI x3 (test_functionals.py:136-160)
-            eng.set_options(prm.replace(spaceDiscr=1, smoother=DADI, nSubiterations=3, nSubIterTurb=3, cfl=1.5, resAveraging=noResAveraging))
-            eng.timeStep(1, False)
-            eng.residual(1, 0)
-            for _ in range(2):
-                eng.executeMGCycle([0])
-            s3, r3, e3 = timed(eng, lambda: eng.executeMGCycle([0]), 5, barrier, a.min_seconds)
-            b_res, b_dadi, b_upd = 255.0 + 32.0, 244.0, 224.0
-            extra["config3_dadi_iteration"] = {
-                "iterations_per_s": 1.0 / s3, "ms_per_iteration": s3 * 1e3,
-                "what": "single grid on the same blocks with scalar JST: D-ADI x3 sub-iterations + SA DDADI x3",
-                "hbm_frac": 3 * (b_res + b_dadi + b_upd) * job.cells_local / s3 / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_formula": "3 x (B_res 287 + B_dadi 244 + B_upd 224) B per cell, SA solve not counted"}
-            log(f"config 3 iteration: {s3 * 1e3:.3f} ms")
-            eng.set_options(prm)
+                def matvec():
+                    capi.check(eng.lib.adflow_gpu_nk_residual_dev(wk.data_ptr(), rv.data_ptr(), n), eng.lib)
+                eng.set_async(True)
+                for _ in range(3):
+                    matvec()
+                s5, r5, e5 = timed(eng, matvec, 30, barrier, a.min_seconds)
+                eng.set_async(False)
+                extra["config5_gmres_proxy"] = {
+                    "value": job.cells_local / s5 / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_matvec": s5 * 1e3,
+                    "ms_per_30_matvecs": 30 * s5 * 1e3, "bytes_per_cell": 255.0 + 96.0,
+                    "whole_eval_hbm_frac": (255.0 + 96.0) * job.cells_local / s5 / 1e9 / HBM_PEAK_GBS,
+                    "what": "setW + blocketteRes(default flags: closures, BCs, whalo2, core) + setRVec at w + 1e-7 v, device vectors"}
+                log(f"config 5 proxy: {s5 * 1e3:.3f} ms/matvec")
+                del w0, vk, wk, rv
+            if want("pc"):
+                # restore the state (setW clipped / perturbed it by 1e-7) is not needed: the remaining extras re-time only
+                # ---- the preconditioner matrix of NK / ANK: setupStateResidualMatrix(usePC = T, useAD = F), adjointUtils.F90:7-715 --
+                # 7 colours x 6 states coloured finite differences, every one closures + boundary conditions + approximate residual +
+                # the scatter of one column of all 7 stencil blocks; the blocks (7 x 36 doubles per cell) stay on the device
+                eng.setupStateResidualMatrix(1, usePC=True)            # first call allocates the block storage
+                barrier()
+                t0 = time.perf_counter()
+                eng.setupStateResidualMatrix(1, usePC=True)
+                barrier()
+                spc = time.perf_counter() - t0
+                extra["pc_matrix_assembly"] = {
+                    "ms": spc * 1e3, "residual_evaluations": 43, "ms_per_evaluation": spc * 1e3 / 43.0,
+                    "what": "adflow_gpu_fd_jacobian(PC): 7 colours x 6 states + the reference evaluation, lumped Roe dissipation, "
+                            "thin-layer viscous flux, first-order SA advection; blocks resident in HBM (2016 B per cell)"}
+                log(f"PC matrix assembly: {spc * 1e3:.1f} ms ({spc * 1e3 / 43.0:.2f} ms per coloured evaluation)")
+            if want("config3"):
+                # ---- config 3: one solver iteration = D-ADI x3 sub-iterations + SA DDADI x3 (test_functionals.py:136-160)
+                eng.set_options(prm.replace(spaceDiscr=1, smoother=DADI, nSubiterations=3, nSubIterTurb=3, cfl=1.5, resAveraging=noResAveraging))
+                eng.timeStep(1, False)
+                eng.residual(1, 0)
+                for _ in range(2):
+                    eng.executeMGCycle([0])
+                s3, r3, e3 = timed(eng, lambda: eng.executeMGCycle([0]), 5, barrier, a.min_seconds)
+                b_res, b_dadi, b_upd = 255.0 + 32.0, 244.0, 224.0
+                extra["config3_dadi_iteration"] = {
+                    "iterations_per_s": 1.0 / s3, "ms_per_iteration": s3 * 1e3,
+                    "what": "single grid on the same blocks with scalar JST: D-ADI x3 sub-iterations + SA DDADI x3",
+                    "hbm_frac": 3 * (b_res + b_dadi + b_upd) * job.cells_local / s3 / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_formula": "3 x (B_res 287 + B_dadi 244 + B_upd 224) B per cell, SA solve not counted"}
+                log(f"config 3 iteration: {s3 * 1e3:.3f} ms")
+                eng.set_options(prm)
         except Exception as ex:
             extra["error_rans_extras"] = str(ex)
             log("RANS extras failed: " + str(ex))
@@ -591,7 +600,7 @@ def main():
         }
 
     # ---- config 2: Euler JST + 3-level W multigrid cycle (N=1 extras, or the workload itself when asked for)
-    if extras_on and not a.no_mg:
+    if extras_on and not a.no_mg and want("config2"):
         try:
             eng.release_all()
             del job

@@ -23,6 +23,15 @@ def test_nk_residual_crm_rans_parity_size(engine, sd):
     checks.check_nk_residual(engine, BrickTopology(2, 2, 2, 24, 20, 10), prm, stretch_k=3.0)
 
 
+def test_nk_residual_vector_stores_of_the_marches(engine):
+    """setRVec inside the marching kernels: blocks wider than one 60-column tile with a partial last tile, several k chunks,
+    RANS (nw = 6: word 5 of a cell comes from the SA march), laminar and Euler Roe (nw = 5)"""
+    from adflow_amd.params import NSEquations
+    checks.check_nk_residual(engine, BrickTopology(2, 1, 1, 70, 9, 37), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+    checks.check_nk_residual(engine, BrickTopology(1, 1, 2, 121, 6, 5), FlowParams(equations=NSEquations, spaceDiscr=upwind), stretch_k=2.0)
+    checks.check_nk_residual(engine, BrickTopology(1, 2, 1, 63, 5, 4), FlowParams(spaceDiscr=upwind))
+
+
 def test_matrix_free_matvec_is_linear(engine):
     """(R(w + h v) - R(w)) / h is linear in v to O(h): the property PETSc's MFFD relies on."""
     prm = FlowParams()

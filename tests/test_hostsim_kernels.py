@@ -111,6 +111,10 @@ def test_nk_residual(hostsim_engine):
     checks.check_nk_residual(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams())
     checks.check_nk_residual(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
                              FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+    # two column tiles, the second partial: the word-ordered setRVec stores of the Roe march (nw = 6 and nw = 5)
+    checks.check_nk_residual(hostsim_engine, BrickTopology(1, 1, 1, 63, 5, 4),
+                             FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+    checks.check_nk_residual(hostsim_engine, BrickTopology(1, 1, 1, 61, 3, 3), FlowParams(spaceDiscr=upwind))
 
 
 def test_sa_ddadi_solve(hostsim_engine):
