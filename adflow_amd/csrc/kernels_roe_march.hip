@@ -80,11 +80,14 @@ __device__ __forceinline__ void rm_recon1(const RmK& K, double qm, double q0, do
         const double epsLim = 1.e-10;
         const double cm = copysign(fmax(fabs(dm), epsLim), dm), cp = copysign(fmax(fabs(dp), epsLim), dp);
         if (LIM == ADFLOW_LIM_VANALBADA) {
-            // f(r) = r (r + 1) / (r^2 + 1) with r = max(0, a / b)  ==  a (a + b) / (a^2 + b^2) for a b > 0, else 0
+            // f(r) = r (r + 1) / (r^2 + 1) with r = max(0, a / b)  ==  a (a + b) / (a^2 + b^2) for a b > 0, else 0:
+            // A = f(d+ / d-) d- = d+ d- (d+ + c-) / (d+^2 + c-^2), B likewise; both vanish unless d+ d- > 0 (one of them zero: the
+            // product is the zero factor), so max(d+ d-, 0) replaces the two selects
             const double dA = dp * dp + cm * cm, dB = dm * dm + cp * cp;
             const double r = rcp_nr(dA * dB);
-            A = (dp * cm > 0.0) ? (dp * (dp + cm)) * (r * dB) * dm : 0.0;
-            B = (dm * cp > 0.0) ? (dm * (dm + cp)) * (r * dA) * dp : 0.0;
+            const double tp = fmax(dp * dm, 0.0);
+            A = (tp * (dp + cm)) * (r * dB);
+            B = (tp * (dm + cp)) * (r * dA);
         } else {   // minmod: f(r) = min(1, factMinmod max(0, r))
             const double r = rcp_nr(cm * cp);
             A = fmin(1.0, K.factMinmod * fmax(0.0, dp * (r * cp))) * dm;

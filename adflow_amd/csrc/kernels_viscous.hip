@@ -118,14 +118,17 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
 #define NG_BY 4
 #define NG_KCH 32
 
-// g += sign * 0.25 * phi (x) t
-__device__ __forceinline__ void ng_outer(double g[12], double sign, const double ph[4], const double t[3])
+// g += (NEG ? -1 : +1) phi (x) t   (the factor 0.25 of the surface integral rides on 1 / volume in the caller)
+template <bool NEG>
+__device__ __forceinline__ void ng_outer(double g[12], const double ph[4], const double t[3])
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const double a = sign * 0.25 * ph[v];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) g[3 * v + d] += a * t[d];
+        for (int d = 0; d < 3; ++d) {
+            if (NEG) g[3 * v + d] -= ph[v] * t[d];
+            else g[3 * v + d] += ph[v] * t[d];
+        }
     }
 }
 
@@ -602,10 +605,11 @@ __device__ __forceinline__ VmCell vm_dn1(const VmCell& q)
 
 struct VmK { double porV, hl, ht; bool eddy; };       // 0.5 rFil; 1 / (prandtl (gamma-1)); 1 / (prandtlTurb (gamma-1))
 
-// viscous flux through the face between L and R (normal fN pointing from L to R, centre-to-centre vector dN); gs: SUM of the
-// gradients of the four face nodes (the average is gs / 4)
+// viscous flux through the face between L and R (normal fN pointing from L to R, centre-to-centre vector dN); gr: AVERAGE of the
+// gradients of the four face nodes (k_visc_gf keeps a QUARTER of every nodal gradient in its ring -- the factor rides on 1 / volume --
+// so the average is the plain sum of four ring entries: exact, powers of two)
 template <bool QCR>
-__device__ __forceinline__ void vm_face(const VmK& K, const double gs[12], const VmCell& L, const VmCell& R, const double fN[3],
+__device__ __forceinline__ void vm_face(const VmK& K, const double gr[12], const VmCell& L, const VmCell& R, const double fN[3],
                                         const double dN[3], int por_code, double f[4])
 {
     double por = K.porV;
@@ -616,9 +620,6 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gs[12], const
     const double heatCoef = mul * K.hl + mue * K.ht;
     const double ss = rsq_nr(dN[0] * dN[0] + dN[1] * dN[1] + dN[2] * dN[2]);
     const double ssx = ss * dN[0], ssy = ss * dN[1], ssz = ss * dN[2];
-    double gr[12];
-#pragma unroll
-    for (int q = 0; q < 12; ++q) gr[q] = 0.25 * gs[q];
     double corr;
     corr = gr[0] * ssx + gr[1] * ssy + gr[2] * ssz - (R.u - L.u) * ss;
     const double u_x = gr[0] - corr * ssx, u_y = gr[1] - corr * ssy, u_z = gr[2] - corr * ssz;
@@ -968,32 +969,34 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = SQ0[v] + SQ1[v];
-            ng_outer(g, -1.0, ph, S.Pt);                          // k direction: below the node -, above +
+            ng_outer<true>(g, ph, S.Pt);                          // k direction: below the node -, above +
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = NQ0[v] + NQ1[v];
-            ng_outer(g, +1.0, ph, N.Pt);
+            ng_outer<false>(g, ph, N.Pt);
 #pragma unroll
             for (int d = 0; d < 3; ++d) t3[d] = S.Q0t[d] + N.Q0t[d];
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = SQ0[v] + NQ0[v];
-            ng_outer(g, -1.0, ph, t3);                            // j direction: own row -, row above +
+            ng_outer<true>(g, ph, t3);                            // j direction: own row -, row above +
 #pragma unroll
             for (int d = 0; d < 3; ++d) t3[d] = S.Q1t[d] + N.Q1t[d];
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = SQ1[v] + NQ1[v];
-            ng_outer(g, +1.0, ph, t3);
+            ng_outer<false>(g, ph, t3);
 #pragma unroll
             for (int d = 0; d < 3; ++d) t3[d] = S.RIt[d] + N.RIt[d];
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = (sA[v] + sB[v]) + (nA[v] + nB[v]);
-            ng_outer(g, -1.0, ph, t3);                            // i direction: own column -, column i+1 +
+            ng_outer<true>(g, ph, t3);                            // i direction: own column -, column i+1 +
             double t1[3], ph1[4];
 #pragma unroll
             for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t3[d]);
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
-            ng_outer(g, +1.0, ph1, t1);
-            const double oneOverV = rcp_nr(S.V + N.V);
+            ng_outer<false>(g, ph1, t1);
+            // a QUARTER of the gradient goes to the ring (the faces then average four nodes by adding); with the 0.25 of the surface
+            // integral: 1 / (16 V).  Powers of two: the face gradients are bitwise what 0.25 (g0 + g1 + g2 + g3) gives
+            const double oneOverV = 0.0625 * rcp_nr(S.V + N.V);
 #pragma unroll
             for (int q = 0; q < 12; ++q) g[q] *= oneOverV;
             if (ringLane) {
@@ -1003,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
             }
             if (STG && outN) {
 #pragma unroll
-                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cF, g[q]);
+                for (int q = 0; q < 12; ++q) stg(grad + q * nb, cF, 4.0 * g[q]);
             }
         }
         // ---- loads of the face part (cell plane mm-1), requested above the barrier; sI / sJ of that plane again (carried they spill)
