@@ -82,12 +82,14 @@ __device__ __forceinline__ void rm_recon1(const RmK& K, double qm, double q0, do
         if (LIM == ADFLOW_LIM_VANALBADA) {
             // f(r) = r (r + 1) / (r^2 + 1) with r = max(0, a / b)  ==  a (a + b) / (a^2 + b^2) for a b > 0, else 0:
             // A = f(d+ / d-) d- = d+ d- (d+ + c-) / (d+^2 + c-^2), B likewise; both vanish unless d+ d- > 0 (one of them zero: the
-            // product is the zero factor), so max(d+ d-, 0) replaces the two selects
+            // product is the zero factor), so max(d+ d-, 0) replaces the two selects, and with the common reciprocal
+            // A = s (d+ + c-) dB, B = s (d- + c+) dA, s = max(d+ d-, 0) / (dA dB): the states are q0 +- s (...)
             const double dA = dp * dp + cm * cm, dB = dm * dm + cp * cp;
-            const double r = rcp_nr(dA * dB);
-            const double tp = fmax(dp * dm, 0.0);
-            A = (tp * (dp + cm)) * (r * dB);
-            B = (tp * (dm + cp)) * (r * dA);
+            const double s = fmax(dp * dm, 0.0) * rcp_nr(dA * dB);
+            const double A1 = (dp + cm) * dB, B1 = (dm + cp) * dA;
+            plus = q0 + s * (K.omk * A1 + K.opk * B1);
+            minus = q0 - s * (K.opk * A1 + K.omk * B1);
+            return;
         } else {   // minmod: f(r) = min(1, factMinmod max(0, r))
             const double r = rcp_nr(cm * cp);
             A = fmin(1.0, K.factMinmod * fmax(0.0, dp * (r * cp))) * dm;
@@ -142,7 +144,7 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
     if (por == ADF_POR_NOFLUX || por == ADF_POR_BOUND) porFlux = 0.0;
     const double rsl = rsq_nr(L[0]), rsr = rsq_nr(R[0]);       // 1 / z1l, 1 / z1r
     const double z1l = L[0] * rsl, z1r = R[0] * rsr;
-    const double tmp = rcp_nr(z1l + z1r);
+    const double zs = z1l + z1r;
     const double kl = 0.5 * (L[1] * L[1] + L[2] * L[2] + L[3] * L[3]), kr = 0.5 * (R[1] * R[1] + R[2] * R[2] + R[3] * R[3]);
     const double Etl = K.ovgm1 * L[4] + L[0] * kl, Etr = K.ovgm1 * R[4] + R[0] * kr;   // etot, cpConstant (flowUtils.F90:551-640)
     const double dr = R[0] - L[0];
@@ -150,30 +152,39 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
     const double drv = R[0] * R[2] - L[0] * L[2];
     const double drw = R[0] * R[3] - L[0] * L[3];
     const double drE = Etr - Etl;
+    const double a2n = nx * nx + ny * ny + nz * nz;
+    const double ra = rsq_nr(fmax(a2n, 1.e-50));               // 1 / max(1e-25, area)
+    const double area = a2n * ra;
+    const double sx = nx * ra, sy = ny * ra, sz = nz * ra;
+    // the sound speeds of the two states for the entropy fix: sqrt(gamma p / rho) = sqrt(gamma p) / sqrt(rho); its eta shares one
+    // reciprocal with the Roe weights (1 / x = y / (x y))
+    const double gpl = K.gam * L[4], gpr = K.gam * R[4];
+    const double cl = gpl * rsq_nr(gpl) * rsl, cr = gpr * rsq_nr(gpr) * rsr;
+    const double eta = 0.5 * (fabs((L[1] - R[1]) * sx + (L[2] - R[2]) * sy + (L[3] - R[3]) * sz) + fabs(cl - cr));
+    const double etaC = fmax(eta, 1.e-290);                    // q4eta is only used where lam < 2 eta, i.e. eta > 0
+    const double rze = rcp_nr(zs * etaC);
+    const double tmp = rze * etaC;                             // 1 / (z1l + z1r)
+    const double q4eta = 0.25 * (rze * zs);                    // 1 / (4 eta)
     const double wl = z1l * tmp, wr = z1r * tmp;
     const double uAvg = wl * L[1] + wr * R[1];
     const double vAvg = wl * L[2] + wr * R[2];
     const double wAvg = wl * L[3] + wr * R[3];
     const double hAvg = tmp * ((Etl + L[4]) * rsl + (Etr + R[4]) * rsr);
-    const double a2n = nx * nx + ny * ny + nz * nz;
-    const double ra = rsq_nr(fmax(a2n, 1.e-50));               // 1 / max(1e-25, area)
-    const double area = a2n * ra;
-    const double sx = nx * ra, sy = ny * ra, sz = nz * ra;
     const double alphaAvg = 0.5 * (uAvg * uAvg + vAvg * vAvg + wAvg * wAvg);
     const double a2Avg = fabs(K.gm1 * (hAvg - alphaAvg));
     const double ovaAvg = rsq_nr(a2Avg), ova2Avg = ovaAvg * ovaAvg, aAvg = a2Avg * ovaAvg;
     double unAvg = uAvg * sx + vAvg * sy + wAvg * sz;
     if (por == ADF_POR_BOUND) unAvg = 0.0;                     // rFace = 0: blocks at rest (moving blocks use the gather kernel)
-    // sound speeds of the two states for the entropy fix: sqrt(gamma p / rho) = sqrt(gamma p) / sqrt(rho)
-    const double gpl = K.gam * L[4], gpr = K.gam * R[4];
-    const double cl = gpl * rsq_nr(gpl) * rsl, cr = gpr * rsq_nr(gpr) * rsr;
-    const double eta = 0.5 * (fabs((L[1] - R[1]) * sx + (L[2] - R[2]) * sy + (L[3] - R[3]) * sz) + fabs(cl - cr));
     double lam1 = fabs(unAvg + aAvg), lam2 = fabs(unAvg - aAvg), lam3 = fabs(unAvg);
     const double two_eta = 2.0 * eta;
-    const double q4eta = 0.25 * rcp_nr(fmax(eta, 1.e-300));    // only used where lam < 2 eta, i.e. eta > 0
-    if (lam1 < two_eta) lam1 = eta + lam1 * lam1 * q4eta;
-    if (lam2 < two_eta) lam2 = eta + lam2 * lam2 * q4eta;
-    if (lam3 < two_eta) lam3 = eta + lam3 * lam3 * q4eta;
+    // lam < 2 eta: lam <- eta + lam^2 / (4 eta).  Without selects: with lc = min(lam, 2 eta) the parabola is >= lam below 2 eta and
+    // equals 2 eta <= lam from there on
+    {
+        const double l1 = fmin(lam1, two_eta), l2 = fmin(lam2, two_eta), l3 = fmin(lam3, two_eta);
+        lam1 = fmax(lam1, eta + (l1 * l1) * q4eta);
+        lam2 = fmax(lam2, eta + (l2 * l2) * q4eta);
+        lam3 = fmax(lam3, eta + (l3 * l3) * q4eta);
+    }
     lam1 *= area; lam2 *= area; lam3 *= area;
     const double abv1 = 0.5 * (lam1 + lam2);
     const double abv2 = 0.5 * (lam1 - lam2);
