@@ -173,6 +173,13 @@ __device__ __forceinline__ double fast_exp_neg(double x)
 }
 #endif
 
+// binary exponent of a finite x > 0 (frexp: x = f 2^e, 0.5 <= f < 1)
+#ifdef HOSTSIM
+__device__ __forceinline__ int exponent_of(double x) { int e; (void)frexp(x, &e); return e; }
+#else
+__device__ __forceinline__ int exponent_of(double x) { return __builtin_amdgcn_frexp_exp(x); }
+#endif
+
 // a value that is the same in every lane of the wavefront, moved to a scalar register so that branches on it are scalar branches
 #ifdef HOSTSIM
 __device__ __forceinline__ int wave_uniform(int v) { return v; }

@@ -55,6 +55,18 @@ def test_rk_smoother_euler(engine, resavg):
     checks.check_rk_smoother(engine, BrickTopology(2, 1, 1, 16, 12, 8), FlowParams(resAveraging=resavg), nsweeps=2)
 
 
+def test_res_averaging_line_bundles(engine):
+    """k_ra_line (lines resident in LDS): several bundles per direction with a ragged last one, blanked cells, a 2 x 2 x 2 brick at a
+    third of the bench size, lines too long for the LDS buffer (two-pass kernels), one-cell directions"""
+    prm = FlowParams(resAveraging=alwaysResAveraging)
+    checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 70, 37, 19), prm, holes=0.05)
+    checks.check_rk_smoother(engine, BrickTopology(2, 2, 2, 48, 40, 36), FlowParams(resAveraging=alternateResAveraging))
+    checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 3, 2, 19), prm)
+    checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 1340, 2, 1), prm)
+    checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 2, 1040, 3), prm)
+    checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 3, 2, 1040), prm)
+
+
 def test_rk_smoother_multiblock_tutorial_wing_size(engine):
     # BASELINE config 2 parity size: 6 blocks, ~12 096 cells
     checks.check_rk_smoother(engine, BrickTopology(3, 2, 1, 16, 14, 9), FlowParams(), nsweeps=2)

@@ -70,6 +70,17 @@ def test_rk_smoother(hostsim_engine, resavg):
     checks.check_rk_smoother(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams(resAveraging=resavg))
 
 
+def test_res_averaging_line_bundles(hostsim_engine):
+    """k_ra_line: more lines than one bundle in every direction (ragged last bundle), blocks of different sizes on one level, a line too
+    long for the LDS buffer (two-pass kernels), one-cell directions"""
+    from adflow_amd.params import alwaysResAveraging
+    prm = FlowParams(resAveraging=alwaysResAveraging)
+    checks.check_rk_smoother(hostsim_engine, BrickTopology(1, 1, 1, 19, 18, 3), prm, holes=0.05)
+    checks.check_rk_smoother(hostsim_engine, BrickTopology(1, 1, 1, 3, 2, 19), prm)
+    checks.check_rk_smoother(hostsim_engine, BrickTopology(1, 1, 1, 1340, 2, 1), prm)
+    checks.check_rk_smoother(hostsim_engine, BrickTopology(1, 1, 1, 2, 1040, 1), prm)
+
+
 def test_rk_smoother_rans(hostsim_engine):
     checks.check_rk_smoother(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
                              FlowParams(equations=RANSEquations, resAveraging=noResAveraging), stretch_k=2.0)
