@@ -139,6 +139,8 @@ bool g_use_march = true;                               // tuning: adflow_gpu_set
 adflow_bc_callback g_bc_callback = nullptr;
 adflow_bc_callback g_turb_bc_callback = nullptr;
 double* g_norm_dev = nullptr;
+int* g_floor_flag_dev = nullptr;      // raised by k_set_w_closures_level when a pressure hit its floor (FormFunction_mf)
+bool g_etot_on_flag = false;          // the next whalo2 close recomputes the owned energy only if that flag is up
 
 void free_list(CommList& l)
 {
@@ -2583,7 +2585,8 @@ static int halo_exchange_close(int level, int varStart, int varEnd, int commPres
     if (nTodo > 0 && nTodo == nBlk) {
         LevelTab t;
         if (level_tab(level, &t)) return 1;
-        launch_etot_owned_level(t.tab, t.n, t.nx, t.ny, t.nz, g_opts.gammaConstant, g_stream);
+        launch_etot_owned_level(t.tab, t.n, t.nx, t.ny, t.nz, g_opts.gammaConstant, g_stream,
+                                (g_etot_on_flag && level == 1) ? g_floor_flag_dev : nullptr);
     }
     for_level(level, [&](Block* b) {
         // the exchange never touches owned cells: when their rhoE was produced by
@@ -3116,12 +3119,14 @@ int set_w_dev(const double* d_vec, bool withClosures = false)
     // block offsets: BlkView::vecOff; withClosures: the closures blocketteRes would start with, in the same pass
     if (withClosures) {
         KParams kp = make_kparams(1, 1.0, 0);
-        launch_set_w_closures_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbFloor, kp, g_stream);
+        if (!g_floor_flag_dev) HIPCHK(hipMalloc((void**)&g_floor_flag_dev, sizeof(int)));
+        HIPCHK(hipMemsetAsync(g_floor_flag_dev, 0, sizeof(int), g_stream));
+        launch_set_w_closures_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbFloor, kp, g_floor_flag_dev, g_stream);
     } else
         launch_set_w_level(t.tab, t.n, t.nx, t.ny, t.nz, d_vec, turbFloor, g_stream);
     return for_level1_in_order([&](Block* b, long) {
         b->ss_valid = false;
-        b->etot_consistent = withClosures;        // k_set_w_closures_level leaves rhoE as computeEtot(p) already
+        b->etot_consistent = false;
         return 0;
     });
 }
@@ -3176,12 +3181,14 @@ static int nk_core_enqueue(bool closuresDone = false)
 static int nk_residual_enqueue(const double* d_wVec, double* d_rVec)
 {
     if (set_w_dev(d_wVec, true)) return 1;
+    g_etot_on_flag = true;      // the owned energy is computeEtot(p) already wherever p kept its value (k_set_w_closures_level)
     // setRVec rides on the kernels that complete dw (Roe march, SA march) where those run; otherwise its own pass.  Actuator
     // sources are added to dw behind the core: then the vector is taken from dw afterwards.
     g_rvec_done = 0;
     g_rvec_target = g_act.empty() ? d_rVec : nullptr;
     const int rc = nk_core_enqueue(true);
     g_rvec_target = nullptr;
+    g_etot_on_flag = false;
     if (rc) return rc;
     const int need = (g_opts.equations == ADFLOW_RANS) ? 3 : 1;
     if ((g_rvec_done & need) != need)
@@ -3421,6 +3428,8 @@ static void free_side_buffers(void)
     g_vec_elems = 0;
     if (g_norm_dev) (void)hipFree(g_norm_dev);
     g_norm_dev = nullptr;
+    if (g_floor_flag_dev) (void)hipFree(g_floor_flag_dev);
+    g_floor_flag_dev = nullptr;
 #ifndef ADFLOW_NO_RCCL
     if (g_nccl) (void)ncclCommDestroy(g_nccl);
     g_nccl = nullptr;

@@ -452,11 +452,12 @@ void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 // level-batched forms (blockIdx.z = slot * planes + plane): one launch for every block of a level
 void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
 void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
-                                 const KParams& kp, hipStream_t s);
+                                 const KParams& kp, int* floored, hipStream_t s);
 void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s);
 void launch_get_r_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double* vec, double turbScale, double* sums, hipStream_t s);
 void launch_entropy_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, hipStream_t s);
-void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double gammaConstant, hipStream_t s);
+void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double gammaConstant, hipStream_t s,
+                             const int* onlyIf = nullptr);
 void launch_initres_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, int l0, int l1, hipStream_t s);
 void launch_res_norms(const BlkView& b, int nvar, double* out, hipStream_t s);
 #include <vector>

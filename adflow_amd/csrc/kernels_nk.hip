@@ -91,10 +91,13 @@ __global__ __launch_bounds__(NK_BX* NK_BY) void k_get_r_level(const BlkView* __r
 }
 
 // owned cells: p from (rho, v, rhoE) with the 1e-4*pInfCorr floor, Sutherland, SA eddy viscosity
-// ETOT: also rhoE back from the (floored) p, the pass whalo2 closes with (haloExchange.F90:178-196, k_etot_owned_level): the exchange that
-// follows in FormFunction_mf touches no owned cell, so the result is the same and the pass over w, p is saved
+// ETOT: also rhoE back from p, the pass whalo2 closes with on the owned cells (haloExchange.F90:178-196, k_etot_owned_level).  The
+// exchange that follows in FormFunction_mf carries the energy of the VECTOR into the neighbours' halos and only then recomputes the
+// owned one: where p was not floored the two agree (the same expression of the same values), so the energy is rewritten here and the
+// pass over w, p is saved; a cell whose pressure hit the floor keeps the vector's energy for the exchange and raises *floored, on
+// which the pass behind the exchange then runs as before
 template <bool ETOT = false>
-__device__ __forceinline__ void closures_body(const BlkView& b, int kz, const KParams& kp)
+__device__ __forceinline__ void closures_body(const BlkView& b, int kz, const KParams& kp, int* __restrict__ floored = nullptr)
 {
     const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
     const int j = blockIdx.y * NK_BY + threadIdx.y + 2;
@@ -106,11 +109,16 @@ __device__ __forceinline__ void closures_body(const BlkView& b, int kz, const KP
     const double gm1 = kp.gammaConstant - 1.0;
     const double v2 = u * u + v * v + w * w;
     double p = gm1 * (b.w[c + 4 * nb] - 0.5 * rho * v2);
-    p = fmax(p, 1.e-4 * kp.pInfCorr);
+    const double pFloor = 1.e-4 * kp.pInfCorr;
+    const bool hitFloor = !(p >= pFloor);
+    p = fmax(p, pFloor);
     b.p[c] = p;
     if (ETOT) {
-        const double ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
-        b.w[c + 4 * nb] = ovgm1 * p + 0.5 * rho * v2;
+        if (hitFloor) *floored = 1;
+        else {
+            const double ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
+            b.w[c + 4 * nb] = ovgm1 * p + 0.5 * rho * v2;
+        }
     }
     if (kp.viscous) {
         const double muSuth = kp.muSuthDim / kp.muRef, TSuth = kp.TSuthDim / kp.TRef, SSuth = kp.SSuthDim / kp.TRef;
@@ -133,11 +141,11 @@ __global__ __launch_bounds__(NK_BX* NK_BY) void k_closures(BlkView b, KParams kp
 // setW followed by the closures of blocketteRes in one pass (FormFunction_mf: NKSolvers.F90:437-461 -> blockette.F90:199-203):
 // each thread reads back only what it wrote itself
 __global__ __launch_bounds__(NK_BX* NK_BY) void k_set_w_closures_level(const BlkView* __restrict__ tab, int nzb, const double* __restrict__ vec,
-                                                                       double turbFloor, KParams kp)
+                                                                       double turbFloor, KParams kp, int* __restrict__ floored)
 {
     const BlkView& b = tab[blockIdx.z / nzb + 1];
     set_w_body(b, (int)(blockIdx.z % nzb), vec + b.vecOff, turbFloor);
-    closures_body<true>(b, (int)(blockIdx.z % nzb), kp);
+    closures_body<true>(b, (int)(blockIdx.z % nzb), kp, floored);
 }
 
 __global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_level(const BlkView* __restrict__ tab, int nzb, KParams kp)
@@ -158,12 +166,12 @@ void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny,
     hipLaunchKernelGGL(k_closures_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp);
 }
 void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
-                                 const KParams& kp, hipStream_t s)
+                                 const KParams& kp, int* floored, hipStream_t s)
 {
-    LEVEL_SPLIT(nslots, maxnz + 4, launch_set_w_closures_level(tab + s0_, n_, maxnx, maxny, maxnz, vec, turbFloor, kp, s));
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_set_w_closures_level(tab + s0_, n_, maxnx, maxny, maxnz, vec, turbFloor, kp, floored, s));
     if (nslots <= 0) return;
     hipLaunchKernelGGL(k_set_w_closures_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, vec, turbFloor,
-                       kp);
+                       kp, floored);
 }
 void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s)
 {

@@ -63,8 +63,12 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned(BlkView b, double g
     b.w[c + 4 * nb] = ovgm1 * b.p[c] + 0.5 * b.w[c] * (u * u + v * v + w * w);
 }
 
-__global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned_level(const BlkView* __restrict__ tab, int nzb, double gammaConstant)
+// onlyIf: the pass runs only when *onlyIf != 0 (the matrix-free residual: k_set_w_closures_level has rewritten the energy already unless a
+// pressure hit its floor)
+__global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned_level(const BlkView* __restrict__ tab, int nzb, double gammaConstant,
+                                                                   const int* __restrict__ onlyIf)
 {
+    if (onlyIf && *onlyIf == 0) return;
     const BlkView& b = tab[blockIdx.z / nzb + 1];
     const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
     const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
@@ -77,11 +81,13 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned_level(const BlkView
     b.w[c + 4 * nb] = ovgm1 * b.p[c] + 0.5 * b.w[c] * (u * u + v * v + w * w);
 }
 
-void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double gammaConstant, hipStream_t s)
+void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double gammaConstant, hipStream_t s,
+                             const int* onlyIf)
 {
-    LEVEL_SPLIT(nslots, maxnz + 4, launch_etot_owned_level(tab + s0_, n_, maxnx, maxny, maxnz, gammaConstant, s));
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_etot_owned_level(tab + s0_, n_, maxnx, maxny, maxnz, gammaConstant, s, onlyIf));
     if (nslots <= 0) return;
-    hipLaunchKernelGGL(k_etot_owned_level, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, gammaConstant);
+    hipLaunchKernelGGL(k_etot_owned_level, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, gammaConstant,
+                       onlyIf);
 }
 
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s)

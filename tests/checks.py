@@ -926,10 +926,12 @@ def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, nlevels=2, bc
             assert_dw(b, dw, rfine[nn]["dw"], 5, what=f"residual after cycle {n}")
 
 
-def check_nk_residual(engine, topo, prm, seed=21, bc_spec=None, **mk):
+def check_nk_residual(engine, topo, prm, seed=21, bc_spec=None, floor_p=False, **mk):
     """FormFunction_mf = setW + blocketteRes + setRVec (NKSolvers.F90:437-461,1262-1376):
     the vector glue is restated in numpy (NKSolvers.F90 needs PETSc), every
-    arithmetic step in between is the reference's own routine."""
+    arithmetic step in between is the reference's own routine.
+    floor_p: some cells of the vector carry so little energy that computePressureSimple floors their pressure: whalo2 then hands the
+    VECTOR's energy to the neighbours' halos and recomputes the owned one from the floored pressure (haloExchange.F90:178-196)"""
     from oracle import ref
     if bc_spec:      # one block, physical boundaries applied on the device inside blocketteRes
         blk, r, prm = setup_block_with_bc(engine, (topo.nx, topo.ny, topo.nz), prm, bc_spec, seed, **mk)
@@ -946,6 +948,9 @@ def check_nk_residual(engine, topo, prm, seed=21, bc_spec=None, **mk):
         wv *= 1.0 + 1e-3 * rng.uniform(-1, 1, wv.shape)
         if nw > 5:
             wv[::7, 5] = 0.0       # exercises the 1e-6*wInf clipping of setW
+        if floor_p:
+            sel = slice(3, None, 5)
+            wv[sel, 4] = 0.4 * wv[sel, 0] * (wv[sel, 1] ** 2 + wv[sel, 2] ** 2 + wv[sel, 3] ** 2)     # below the kinetic energy: p < 0
         parts.append(wv.reshape(-1))
     wVec = np.concatenate(parts)
     # --- reference side

@@ -32,6 +32,14 @@ def test_nk_residual_vector_stores_of_the_marches(engine):
     checks.check_nk_residual(engine, BrickTopology(1, 2, 1, 63, 5, 4), FlowParams(spaceDiscr=upwind))
 
 
+def test_nk_residual_with_floored_pressures(engine):
+    """every fifth cell of the vector has less total than kinetic energy: computePressureSimple floors p, whalo2 exchanges the vector's
+    energy and recomputes the owned one afterwards (the device pass that does it runs only in this case)"""
+    checks.check_nk_residual(engine, BrickTopology(2, 2, 1, 12, 10, 8), FlowParams(), floor_p=True)
+    checks.check_nk_residual(engine, BrickTopology(2, 1, 2, 24, 9, 10), FlowParams(equations=RANSEquations, spaceDiscr=dissMatrix, vis4=0.1),
+                             floor_p=True, stretch_k=3.0)
+
+
 def test_matrix_free_matvec_is_linear(engine):
     """(R(w + h v) - R(w)) / h is linear in v to O(h): the property PETSc's MFFD relies on."""
     prm = FlowParams()
