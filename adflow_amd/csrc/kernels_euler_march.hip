@@ -182,7 +182,7 @@ __device__ __forceinline__ d2_t ldg2(GPTR(const double) base, unsigned byteoff)
     return *(GPTR(const d2_t))((GPTR(const char))base + byteoff);
 }
 
-// RADII (with LDSJ): the spectral radii are formed inside the march instead of being read from radI/J/K (tuning "euler_radii"):
+// RADII (with LDSJ): the spectral radii are formed inside the march instead of being read from radI/J/K:
 // the radii of cell plane k+1 are computed at the end of step k -- own cell from the normals in flight plus nine loads the next
 // steps repeat anyway (L1 / L2 hits), the two waves at the tile edges also the cell of the row outside the tile -- and radJ goes
 // to the neighbouring rows through a double-buffered LDS slot behind the barrier the state ring has anyway.  Removes the

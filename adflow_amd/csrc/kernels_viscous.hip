@@ -782,9 +782,9 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
 }
 
 // ---------------------------------------------------------------------------
-// FUSED nodal gradients + viscous fluxes, two workgroups per CU (tuning "visc_gf").  k_node_grad_march and k_visc_march
-// exchange the 12 nodal gradients through HBM (103 B per cell written, 125 B read back) and both read the state and the face
-// normals: 194 + 427 B per cell by the counters, 0.45 + 0.84 ms.  Here ONE workgroup of four waves marches in k and keeps the
+// FUSED nodal gradients + viscous fluxes, two workgroups per CU (tuning "viscous_tiled" = 2, the default).  The pair of round 2,
+// k_node_grad_march and k_visc_march, exchanged the 12 nodal gradients through HBM (103 B per cell written, 125 B read back) and
+// both read the state and the face normals: 194 + 427 B per cell by the counters, 0.45 + 0.84 ms.  Here ONE workgroup of four waves marches in k and keeps the
 // gradients in LDS:
 //   * wave r owns node row jn = j0-1+r of the tile: per plane it loads the raw values of the cell rows jn and jn+1 (no record
 //     exchange between waves), forms the gradient of its node (i, jn, m-1) from the cell planes m-1 (carried) and m with the
