@@ -105,8 +105,8 @@ WORKLOADS = {
 }
 DEFAULT_WORKLOAD = "crm_rans_sa_upwind_8x160x128x64"
 PHASES = ["closures+bc", "time step", "SA residual", "inviscid", "nodal gradients", "viscous"]   # between marks 0..6 of api.hip
-# Roe upwind + viscous fluxes (tuning visc_first, default on): the viscous march runs in front of the Roe march, marks 4..6 in that order
-# k_visc_gf (tuning visc_gf, default on): gradients and viscous fluxes are one kernel between marks 4 and 5
+# NS / RANS over the tile table: k_visc_gf (gradients + viscous fluxes, one kernel between marks 4 and 5) runs in front of the Roe /
+# matrix march, which adds its sums and completes dw
 PHASES_GF_FIRST = ["closures+bc", "time step", "SA residual", "(mark)", "nodal gradients + viscous (fused)", "inviscid"]
 PHASES_GF = ["closures+bc", "time step", "SA residual", "inviscid", "(mark)", "nodal gradients + viscous (fused)"]
 
@@ -363,7 +363,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported under 'extra' (N=1)")
     ap.add_argument("--force-extras", action="store_true", help="run the extras although --tuning is given (A/B runs of a tuning key)")
     ap.add_argument("--no-mg", action="store_true", help="skip the config-2 multigrid cycle measurement")
-    ap.add_argument("--only-extras", default="", help="comma list out of 4b,matvec,pc,config3,config2: time only these extras (kernel traces)")
+    ap.add_argument("--only-extras", default="", help="comma list out of 4b,matvec,pc,config3,config2,small: time only these extras (kernel traces)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K steps until the region lasts this long")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
     ap.add_argument("--separate-halo", action="store_true",
@@ -643,6 +643,25 @@ def main():
         except Exception as ex:
             extra["error_config2"] = str(ex)
             log("config 2 extras failed: " + str(ex))
+    # ---- small blocks: about the cell count of the headline in 343 blocks of 32^3 (a production multiblock mesh per GPU)
+    if extras_on and want("small"):
+        try:
+            eng.release_all()
+            j3 = Job(a, "rans_sa_upwind_343x32", eng, rank, world)
+            eng.set_async(True)
+            for _ in range(3):
+                j3.step()
+            s3b, r3b, e3b = timed(eng, j3.step, a.steps, barrier, a.min_seconds)
+            eng.set_async(False)
+            extra["rans_sa_upwind_343x32"] = {"value": j3.cells_local / s3b / 1e6, "unit": "Mcells*residual-evals/s", "ms_per_step": s3b * 1e3,
+                                              "cells_per_gpu": j3.cells_local,
+                                              "whole_eval_hbm_frac": 255.0 * j3.cells_local / s3b / 1e9 / HBM_PEAK_GBS,
+                                              "what": "the headline evaluation on 343 blocks of 32^3 cells (7 x 7 x 7 periodic brick)"}
+            log(f"343 x 32^3 blocks: {s3b * 1e3:.3f} ms/step")
+            del j3
+        except Exception as ex:
+            extra["error_small_blocks"] = str(ex)
+            log("small-block extra failed: " + str(ex))
     eng.close()
     if world > 1:
         dist.destroy_process_group()
