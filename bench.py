@@ -278,7 +278,8 @@ class Job:
                 for k in list(b_.a.keys()):
                     if k not in ("dw",):
                         del b_.a[k]
-            log(f"{name}: block {lid[g]}/{nb} generated and uploaded")
+            if nb <= 16 or lid[g] % 49 == 0 or lid[g] == nb:
+                log(f"{name}: block {lid[g]}/{nb} generated and uploaded")
         self.halo = "off"
         self.cp = []
         try:
