@@ -31,8 +31,15 @@ __global__ void k_halo_copy(const BlkView* __restrict__ tab, const int* __restri
     const BlkView& db = tab[donorBlk[t]];
     const BlkView& hb = tab[haloBlk[t]];
     const long dof = donorOff[t], hof = haloOff[t];
+    // every value is requested before the first is stored: a store in between would order the loads behind it (the compiler cannot
+    // know that halos and donors never overlap) and leave ONE 8-byte load in flight per lane -- 2.3 TB/s of payload on the 8-block mesh
+    double val[HALO_NVAR];
+#pragma unroll
     for (int v = 0; v < HALO_NVAR; ++v)
-        if (mask & (1u << v)) halo_var(hb, v)[hof] = halo_var(db, v)[dof];
+        if (mask & (1u << v)) val[v] = halo_var(db, v)[dof];
+#pragma unroll
+    for (int v = 0; v < HALO_NVAR; ++v)
+        if (mask & (1u << v)) halo_var(hb, v)[hof] = val[v];
 }
 
 __global__ void k_halo_pack(const BlkView* __restrict__ tab, const int* __restrict__ blk, const long* __restrict__ off,
@@ -42,10 +49,15 @@ __global__ void k_halo_pack(const BlkView* __restrict__ tab, const int* __restri
     if (t >= n) return;
     const BlkView& b = tab[blk[t]];
     const long o = off[t];
+    double val[HALO_NVAR];
+#pragma unroll
+    for (int v = 0; v < HALO_NVAR; ++v)
+        if (mask & (1u << v)) val[v] = halo_var(b, v)[o];
     int q = 0;
+#pragma unroll
     for (int v = 0; v < HALO_NVAR; ++v)
         if (mask & (1u << v)) {
-            buf[(long)q * n + t] = halo_var(b, v)[o];
+            buf[(long)q * n + t] = val[v];
             ++q;
         }
 }
@@ -57,12 +69,17 @@ __global__ void k_halo_unpack(const BlkView* __restrict__ tab, const int* __rest
     if (t >= n) return;
     const BlkView& b = tab[blk[t]];
     const long o = off[t];
+    double val[HALO_NVAR];
     int q = 0;
+#pragma unroll
     for (int v = 0; v < HALO_NVAR; ++v)
         if (mask & (1u << v)) {
-            halo_var(b, v)[o] = buf[(long)q * n + t];
+            val[v] = buf[(long)q * n + t];
             ++q;
         }
+#pragma unroll
+    for (int v = 0; v < HALO_NVAR; ++v)
+        if (mask & (1u << v)) halo_var(b, v)[o] = val[v];
 }
 
 // periodic transformations on the receiving side (haloExchange.F90:487-551 velocities, :2644-2712 coordinates)
