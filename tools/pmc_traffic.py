@@ -76,7 +76,8 @@ def main():
     ent = {"git": git, "source": src, "kernels": kernels,
            "traffic_bytes_per_eval": sum(kernels[p]["traffic_bytes_per_launch"] for p in core),
            "correction": f"FETCH_SIZE x{ff:.3f}, WRITE_SIZE x{wf:.3f} ("
-                         + ("calibrated with tools/pmc_calib.bin read5w1 on the same box" if cal else "gfx950 note of MI355X_MICROARCH.md, uncalibrated") + ")"}
+                         + ("calibrated with tools/pmc_calib.bin read5w1 on the same box" if cal else "gfx950 note of MI355X_MICROARCH.md; tools/pmc_mall.py measures 0.5000 raw counter bytes per byte read with 16-byte "
+                            "streams, on 1 GiB and on Infinity-Cache-resident 32 MiB arrays alike: profiles/r03_mall_fetch.json") + ")"}
     tab[workload] = ent
     json.dump(tab, open(out, "w"), indent=1)
     print(json.dumps(ent, indent=1))
