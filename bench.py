@@ -65,7 +65,14 @@ def fp64_issue_roofline(eng, eval_ms, kernels_ms, qcr=False, gf=True, spaceDiscr
     inv = {9: "roe_march", 2: "matrix_march", 1: "euler_march"}[spaceDiscr]
     plan = [("SA residual", "sa_march", "sa_march"), ("inviscid", inv, "tile_march")]
     plan.append(("nodal gradients + viscous (fused)", "visc_gf_qcr" if qcr else "visc_gf", "visc_gf"))
-    kern, total = {}, 0.0
+    # dynamic instruction counts (SQ_INSTS_VALU per launch, tools/_gpu_job_sq.sh -> profiles/pmc_sq.json) where they were collected:
+    # the assembly holds both sides of every uniform branch (normals from the nodes or from the arrays, first / second order, the face
+    # part wave 0 of k_visc_gf skips), the counter only what was issued
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json"))).get(DEFAULT_WORKLOAD, {})
+    except (OSError, ValueError):
+        sq = {}
+    kern, total, total_dyn, have_dyn = {}, 0.0, 0.0, bool(sq.get("kernels")) and spaceDiscr == 9 and not qcr
     for label, ik, sk in plan:
         k = isa["kernels"].get(ik)
         if not k:
@@ -75,10 +82,23 @@ def fp64_issue_roofline(eng, eval_ms, kernels_ms, qcr=False, gf=True, spaceDiscr
                        "issue_cycles_per_step": k["issue_cycles"], "issue_floor_ms": ms,
                        "measured_ms": kernels_ms.get(label), "frac_of_issue": (ms / kernels_ms[label]) if kernels_ms.get(label) else None}
         total += ms
-    return {"bound": "fp64 valu issue", "floor_ms": total, "frac": total / eval_ms if eval_ms else None, "issue_clock_ghz": clock,
+        dyn = (sq.get("kernels", {}).get(label) or {}).get("SQ_INSTS_VALU") if have_dyn else None
+        if dyn:
+            msd = dyn * (k["issue_cycles"] / k["valu"]) / (simds * clock * 1e9) * 1e3
+            kern[label].update({"insts_valu_counted": dyn, "issue_floor_ms_counted": msd,
+                                "frac_of_issue_counted": (msd / kernels_ms[label]) if kernels_ms.get(label) else None,
+                                "valu_active_per_wave_cycle": sq["kernels"][label].get("valu_active_per_wave_cycle"),
+                                "wait_any_per_wave_cycle": sq["kernels"][label].get("wait_any_per_wave_cycle")})
+            total_dyn += msd
+        else:
+            have_dyn = False
+    return {"bound": "fp64 valu issue", "floor_ms": total, "frac": total / eval_ms if eval_ms else None,
+            "floor_ms_counted": total_dyn if have_dyn else None, "frac_counted": (total_dyn / eval_ms) if have_dyn and eval_ms else None,
+            "counted_source": sq.get("source") if have_dyn else None, "issue_clock_ghz": clock,
             "issue_clock_source": "profiles/calibration.json (tools/pmc_calib.bin bw2)" if "issue_clock_ghz_at_4_cycles" in cal
             else "MI355X_MICROARCH.md peak engine clock", "simds": simds, "isa_counts_git": isa.get("git"), "kernels": kern,
-            "note": "floor = sum over the kernels (they share the SIMDs); frac = floor / measured evaluation"}
+            "note": "floor = sum over the kernels (they share the SIMDs); frac = floor / measured evaluation; *_counted: the same from "
+                    "SQ_INSTS_VALU per launch instead of the static count of the march loop (uniform branches not taken are not issued)"}
 
 WORKLOADS = {
     # BASELINE.json configs[3] (the configuration the metric is quoted on), SURVEY §8(d) rows 4a / 4b
