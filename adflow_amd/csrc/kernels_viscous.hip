@@ -795,7 +795,9 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
 //     j face only), no state of a third row.  The flux through the j face BELOW the cell comes from wave r-1 through a
 //     double-buffered LDS slot one step later (the barrier of the next plane orders it): a cell's sum is completed and stored
 //     one plane behind its own faces;
-//   * ring entries are [slot][node row][lane 1..61][12 components] (16-byte LDS accesses); ring 70 272 B + hand-over 11 520 B =
+//   * ring entries are [slot][node row][component pair][lane 1..61][2] (16-byte LDS accesses, consecutive lanes 16 bytes apart: no bank
+//     conflict; with the twelve components of a lane side by side -- 96 bytes from lane to lane -- lanes n and n + 8 met in the same
+//     banks); ring 70 272 B + hand-over 11 520 B =
 //     81 792 B: two workgroups per CU, which run out of phase and hide each other's load latency (the single-workgroup
 //     fusions of round 2 ran eight waves in barrier lockstep).  3 of 4 rows and 60 of 64 columns produce output.
 // Reference: flowUtils.F90:1676-2026 (allNodalGradients), fluxes.F90:2534-3485 (viscousFlux), residuals.F90:334-344.
@@ -839,7 +841,7 @@ __device__ __forceinline__ Dbl2 mk2(double x, double y) { Dbl2 v; v.x = x; v.y =
 template <bool QCR, bool FIRST, bool STG>
 __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
-    __shared__ __attribute__((aligned(16))) double ring[GF_RING];   // [slot][node row 0..3 = rows j0-1 .. j0+2][lane-1][component]
+    __shared__ __attribute__((aligned(16))) double ring[GF_RING];   // [slot][node row 0..3 = rows j0-1 .. j0+2][component pair][lane-1][2]
     __shared__ __attribute__((aligned(16))) double fjx[2 * GF_FJ];  // [parity][row][lane-2][component]
     const int4 tl = tiles[blockIdx.x];
     if (tl.x < 0) return;
@@ -1000,9 +1002,9 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
 #pragma unroll
             for (int q = 0; q < 12; ++q) g[q] *= oneOverV;
             if (ringLane) {
-                double* __restrict__ xo = ring + (((mm - k0) % 3) * 4 + r) * GF_G + nl * 12;     // node plane mm-1 -> slot (mm-k0) % 3
+                double* __restrict__ xo = ring + (((mm - k0) % 3) * 4 + r) * GF_G + nl * 2;     // node plane mm-1 -> slot (mm-k0) % 3
 #pragma unroll
-                for (int q = 0; q < 12; q += 2) *reinterpret_cast<Dbl2*>(xo + q) = mk2(g[q], g[q + 1]);
+                for (int q = 0; q < 12; q += 2) *reinterpret_cast<Dbl2*>(xo + q * GF_NL) = mk2(g[q], g[q + 1]);
             }
             if (STG && outN) {
 #pragma unroll
@@ -1013,8 +1015,8 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
         face_loads();          // requested above the barrier (at the top of the step: no faster, profiles/r03_f)
         __syncthreads();
         if (facePlane) {
-            const double* __restrict__ xb = ring + (((mm - k0) % 3) * 4) * GF_G + nl * 12;            // node plane mm-1
-            const double* __restrict__ xp = ring + (((mm - k0 + 2) % 3) * 4) * GF_G + nl * 12;        // node plane mm-2
+            const double* __restrict__ xb = ring + (((mm - k0) % 3) * 4) * GF_G + nl * 2;            // node plane mm-1
+            const double* __restrict__ xp = ring + (((mm - k0 + 2) % 3) * 4) * GF_G + nl * 2;        // node plane mm-2
             const int oM = (r >= 1 ? r - 1 : 0) * GF_G, o0 = r * GF_G;                                // node rows jn-1 and jn
             if (full && r >= 1 && mm - 2 >= k0) {
                 // cell plane mm-2: the j flux from the wave below has arrived (written in step mm-1)
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
                 double gs[12], f[4];
 #pragma unroll
                 for (int q = 0; q < 12; q += 2) {
-                    const Dbl2 u = *reinterpret_cast<const Dbl2*>(xp + o0 + q), v = *reinterpret_cast<const Dbl2*>(xb + o0 + q);
+                    const Dbl2 u = *reinterpret_cast<const Dbl2*>(xp + o0 + q * GF_NL), v = *reinterpret_cast<const Dbl2*>(xb + o0 + q * GF_NL);
                     const double s0 = u.x + v.x, s1 = u.y + v.y;
                     gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                 }
@@ -1045,8 +1047,8 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
                     double gs[12], f[4];
 #pragma unroll
                     for (int q = 0; q < 12; q += 2) {
-                        const Dbl2 u = *reinterpret_cast<const Dbl2*>(xp + oM + q), v = *reinterpret_cast<const Dbl2*>(xp + o0 + q);
-                        const Dbl2 w = *reinterpret_cast<const Dbl2*>(xb + oM + q), z = *reinterpret_cast<const Dbl2*>(xb + o0 + q);
+                        const Dbl2 u = *reinterpret_cast<const Dbl2*>(xp + oM + q * GF_NL), v = *reinterpret_cast<const Dbl2*>(xp + o0 + q * GF_NL);
+                        const Dbl2 w = *reinterpret_cast<const Dbl2*>(xb + oM + q * GF_NL), z = *reinterpret_cast<const Dbl2*>(xb + o0 + q * GF_NL);
                         gs[q] = (u.x + v.x) + (w.x + z.x); gs[q + 1] = (u.y + v.y) + (w.y + z.y);
                     }
                     const VmCell qR = vm_dn1(qA);
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
                     double gs[12], f[4];
 #pragma unroll
                     for (int q = 0; q < 12; q += 2) {
-                        const Dbl2 w = *reinterpret_cast<const Dbl2*>(xb + oM + q), z = *reinterpret_cast<const Dbl2*>(xb + o0 + q);
+                        const Dbl2 w = *reinterpret_cast<const Dbl2*>(xb + oM + q * GF_NL), z = *reinterpret_cast<const Dbl2*>(xb + o0 + q * GF_NL);
                         const double s0 = w.x + z.x, s1 = w.y + z.y;
                         gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                     }
