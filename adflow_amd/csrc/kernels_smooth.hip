@@ -975,23 +975,33 @@ __device__ __forceinline__ void tile_store(const BlkView& b, double* __restrict_
     }
 }
 
+// A wavefront covers 64 consecutive cells of an i line of which the inner 62 produce rows: the coefficients of a cell (five square
+// roots and eight divisions) are formed ONCE and reach the neighbouring rows by lane shifts (three evaluations per cell before: the
+// kernel was bound by FP64 issue, 0.55 ms on 8 x 128x128x96)
+#define DR_OUT 62
 __global__ __launch_bounds__(SM_BX* SM_BY) void k_dadi_rows_i(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
     const BlkView& b = tab[blockIdx.z / nzb + 1];
-    const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * DR_OUT + lane + 1;              // lanes 1 .. 62 produce the cells 2 + 62 bx .. 63 + 62 bx
     const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
     const int k = blockIdx.z % nzb + 2;
-    if (i > b.il || j > b.jl || k > b.kl) return;
-    const long c = b.idx(i, j, k), nb = b.nbox;
+    if (b.nx == 0 || k > b.kl || (int)(blockIdx.x * DR_OUT) + 2 > b.il || (int)(blockIdx.y * SM_BY) + 2 > b.jl) return;   // uniform per workgroup
+    const int ic = (i < b.ie) ? i : b.ie;                      // (cells 1 and ie: the neighbours of the first / last row, never used)
+    const int jc = (j < b.jl) ? j : b.jl;                      // rows beyond the block repeat the last one and store nothing
+    const long c = b.idx(ic, jc, k), nb = b.nbox;
     const int m = i - 2, n = b.nx;
-    DadiCell cur, nxt, prv;
+    DadiCell cur;
     dadi_cell<0>(b, kp, c, 1, b.sI, cur);
-    if (m > 0) dadi_cell<0>(b, kp, c - 1, 1, b.sI, prv);
-    if (m < n - 1) dadi_cell<0>(b, kp, c + 1, 1, b.sI, nxt);
+    const double pvt1 = lane_up1(cur.vt1), nvt3 = lane_dn1(cur.vt3);
+    double pdP[3], ndM[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { pdP[g] = lane_up1(cur.dP[g]); ndM[g] = lane_dn1(cur.dM[g]); }
+    if (lane < 1 || lane > DR_OUT || i > b.il || j > b.jl) return;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        const double bbv = (m > 0) ? (-prv.vt1 - prv.dP[g]) * cur.ddt : 0.0;
-        const double ddv = (m < n - 1) ? (-nxt.vt3 + nxt.dM[g]) * cur.ddt : 0.0;
+        const double bbv = (m > 0) ? (-pvt1 - pdP[g]) * cur.ddt : 0.0;
+        const double ddv = (m < n - 1) ? (-nvt3 + ndM[g]) * cur.ddt : 0.0;
         const double ccv = 1.0 + (cur.vt1 + cur.vt3 + cur.dP[g] - cur.dM[g]) * cur.ddt;
         b.grad[c + (3 * g) * nb] = bbv;
         b.grad[c + (3 * g + 1) * nb] = ccv;
@@ -1126,7 +1136,7 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
     // i direction: rows pointwise, Thomas per (line, equation) through LDS tiles; the transform behind the i-solve is applied
     // by the k sweep as it loads the update
     if (nx > 1) {
-        const dim3 pg((nx + SM_BX - 1) / SM_BX, (ny + SM_BY - 1) / SM_BY, nz * nslots), pb(SM_BX, SM_BY, 1);
+        const dim3 pg((nx + DR_OUT - 1) / DR_OUT, (ny + SM_BY - 1) / SM_BY, nz * nslots), pb(SM_BX, SM_BY, 1);
         hipLaunchKernelGGL(k_dadi_rows_i, pg, pb, 0, s, tab, nz, kp);
         hipLaunchKernelGGL(k_dadi_solve_i, dim3(5 * ((ny + 63) / 64), nz, nslots), blk, 0, s, tab, kp);
     }

@@ -90,6 +90,9 @@ def test_dadi_smoother(hostsim_engine):
     checks.check_dadi_smoother(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams(resAveraging=noResAveraging, cfl=1.5))
     prm = FlowParams(equations=RANSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=3)
     checks.check_dadi_smoother(hostsim_engine, BrickTopology(1, 1, 2, 5, 1, 4), prm, stretch_k=2.0)
+    # i lines longer than one 62-cell tile of k_dadi_rows_i (the neighbours' coefficients by lane shifts), a partial row group
+    checks.check_dadi_smoother(hostsim_engine, BrickTopology(1, 1, 1, 65, 5, 3), FlowParams(resAveraging=noResAveraging, cfl=1.5), holes=0.05)
+    checks.check_dadi_smoother(hostsim_engine, BrickTopology(1, 1, 1, 63, 2, 2), prm, stretch_k=2.0)
 
 
 from golden_cases import CASES as _GOLD, load_case as _load_case  # noqa: E402
