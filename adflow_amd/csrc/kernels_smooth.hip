@@ -689,7 +689,7 @@ __device__ __forceinline__ void dadi_cell(const BlkView& b, const KParams& kp, l
     double qs = 0.0;
     if (b.sFace) qs = (b.sFace[c - s + DIR * nb] + b.sFace[c + DIR * nb]) * volhalf;     // uniform branch
     const double qq = r1 * u + r2 * v + r3 * w - qs;
-    const double cijk = sqrt(b.gamma[c] * b.p[c] / rho);
+    const double cijk = sqrt(kp.gammaConstant * b.p[c] / rho);      // (calorically perfect gas: gamma(i,j,k) = gammaConstant, as the marching kernels)
     const double cc = cijk * sqrt(r1 * r1 + r2 * r2 + r3 * r3);
     // metric used in eps2: the k-direction mixes sK(k) with sJ(k-1) in the
     // reference (residuals.F90:1625-1627) and that is reproduced here
@@ -727,12 +727,12 @@ __device__ __forceinline__ void dadi_cell(const BlkView& b, const KParams& kp, l
 }
 
 // T_eta^-1 applied to the physical update (residuals.F90:1276-1331)
-__device__ __forceinline__ void dadi_pre_j(const BlkView& b, long c, double d[5])
+__device__ __forceinline__ void dadi_pre_j(const BlkView& b, long c, double d[5], double gam)
 {
     const long nb = b.nbox;
     const double rho = b.w[c], uvel = b.w[c + nb], vvel = b.w[c + 2 * nb], wvel = b.w[c + 3 * nb];
-    const double gm1 = b.gamma[c] - 1.0;
-    const double cijk = sqrt(b.gamma[c] * b.p[c] / rho);
+    const double gm1 = gam - 1.0;
+    const double cijk = sqrt(gam * b.p[c] / rho);
     const double c2inv = 1.0 / (cijk * cijk);
     const double xfact = 2.0 * cijk;
     const double alphinv = sqrt(2.0) * cijk / rho;
@@ -811,11 +811,10 @@ __device__ __forceinline__ void dadi_post_i(const BlkView& b, long c, double d[5
 }
 
 // after the k-solve: T_zeta and the -1/vol scaling (residuals.F90:1676-1745)
-__device__ __forceinline__ void dadi_post_k(const BlkView& b, long c, double d[5])
+__device__ __forceinline__ void dadi_post_k(const BlkView& b, long c, double d[5], double gam)
 {
     const long nb = b.nbox;
     const double rho = b.w[c], uvel = b.w[c + nb], vvel = b.w[c + 2 * nb], wvel = b.w[c + 3 * nb];
-    const double gam = b.gamma[c];
     const long s = b.ldk;
     double rk1 = 0.5 * (b.sK[c] + b.sK[c - s]), rk2 = 0.5 * (b.sK[c + nb] + b.sK[c - s + nb]),
            rk3 = 0.5 * (b.sK[c + 2 * nb] + b.sK[c - s + 2 * nb]);
@@ -880,7 +879,7 @@ __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ t
             const double sc0 = -kp.cfl * b.dtl[c] * b.vol[c];   // executeDADIStep scaling
 #pragma unroll
             for (int l = 0; l < 5; ++l) d[l] *= sc0;
-            dadi_pre_j(b, c, d);
+            dadi_pre_j(b, c, d, kp.gammaConstant);
         }
         if (DIR == 2 && POSTI) dadi_post_i(b, c, d);
         if (solve) {
@@ -910,7 +909,7 @@ __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ t
         } else {
             if (DIR == 0) dadi_post_i(b, c, d);
             else if (DIR == 1) dadi_post_j(b, c, d);
-            else dadi_post_k(b, c, d);
+            else dadi_post_k(b, c, d, kp.gammaConstant);
 #pragma unroll
             for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
         }
@@ -930,7 +929,7 @@ __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ t
         for (int l = 0; l < 5; ++l) fprev[l] = d[l];
         if (DIR == 0) dadi_post_i(b, c, d);
         else if (DIR == 1) dadi_post_j(b, c, d);
-        else dadi_post_k(b, c, d);
+        else dadi_post_k(b, c, d, kp.gammaConstant);
 #pragma unroll
         for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
     }
