@@ -144,7 +144,8 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(const BlkView* __r
 // dd = (-c1p + min(uu,0)) rblank, cc = qq, ff = rhs rblank; elimination from the END of
 // the line towards index 2, then forward substitution.  scratch: 0 rhs/solution, 1 qq,
 // 2 modified cc, 3 bb.  LAST: the k sweep, followed by the update of nuTilde and rev.
-template <int DIR>
+// PRE: bb and dd of the direction were left in scratch (3, 4) j / (5, 6) i / (7, 8) k by k_sa_march<true>; otherwise they are formed here
+template <int DIR, bool PRE = false>
 __global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab, KParams kp, int slot0)
 {
     const BlkView& b = tab[slot0 + blockIdx.z + 1];
@@ -162,22 +163,27 @@ __global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab
     double* rhs = b.scratch;
     double* qqA = b.scratch + nb;
     double* ccA = b.scratch + 2 * nb;
-    double* bbA = b.scratch + 3 * nb;
+    double* bbA = b.scratch + (PRE ? (DIR == 1 ? 3 : (DIR == 0 ? 5 : 7)) : 3) * nb;
+    const double* ddA = b.scratch + (DIR == 1 ? 4 : (DIR == 0 ? 6 : 8)) * nb;
     // backward elimination: m = n-1 (index jl) down to 0 (index 2)
     double ccN = 1.0, bbN = 0.0, ffN = 0.0;   // values of row m+1
     for (int m = n - 1; m >= 0; --m) {
         const long c = c0 + m * s;
-        SaDir d;
-        load_dir(b, c, s, sN, d, DIR);
-        const double vol0 = b.vol[c];
-        const double nu = b.rlv[c] / b.w[c];
-        double c1m, c1p, uu;
-        (void)sa_diffuse(d, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p);
-        (void)sa_advect(d, vol0, b.w[c + nb], b.w[c + 2 * nb], b.w[c + 3 * nb], false, &uu);
         const double rblank = flg_blank(b.flags[c]);
-        const double um = (uu < 0.0) ? uu : 0.0, up = (uu > 0.0) ? uu : 0.0;
-        const double bb = (-c1m - up) * rblank;
-        const double dd = (-c1p + um) * rblank;
+        double bb, dd;
+        if (PRE) { bb = bbA[c]; dd = ddA[c]; }
+        else {
+            SaDir d;
+            load_dir(b, c, s, sN, d, DIR);
+            const double vol0 = b.vol[c];
+            const double nu = b.rlv[c] / b.w[c];
+            double c1m, c1p, uu;
+            (void)sa_diffuse(d, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p);
+            (void)sa_advect(d, vol0, b.w[c + nb], b.w[c + 2 * nb], b.w[c + 3 * nb], false, &uu);
+            const double um = (uu < 0.0) ? uu : 0.0, up = (uu > 0.0) ? uu : 0.0;
+            bb = (-c1m - up) * rblank;
+            dd = (-c1p + um) * rblank;
+        }
         double cc = qqA[c];
         double ff = rhs[c] * rblank;
         if (m < n - 1) {
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab
             ff = ff - f * ffN;
         }
         ccA[c] = cc;
-        bbA[c] = bb;
+        if (!PRE) bbA[c] = bb;
         rhs[c] = ff;
         ccN = cc; bbN = bb; ffN = ff;
     }
@@ -307,6 +313,9 @@ __device__ __forceinline__ void sa_line_to_global(const BlkView& b, double* __re
     __syncthreads();
 }
 
+// PRE: bb, dd of the i direction in scratch 5, 6 (k_sa_march<true>) and the right-hand side not yet blanked; otherwise in 3, 4 with the
+// blanked right-hand side (k_sa_rows_i)
+template <bool PRE>
 __global__ __launch_bounds__(64) void k_sa_solve_i(const BlkView* __restrict__ tab)
 {
     __shared__ double tile[64 * SI_LD];
@@ -319,8 +328,8 @@ __global__ __launch_bounds__(64) void k_sa_solve_i(const BlkView* __restrict__ t
     double* __restrict__ rhs = b.scratch;
     const double* __restrict__ qqA = b.scratch + nb;
     double* __restrict__ ccA = b.scratch + 2 * nb;
-    const double* __restrict__ bbA = b.scratch + 3 * nb;
-    const double* __restrict__ ddA = b.scratch + 4 * nb;
+    const double* __restrict__ bbA = b.scratch + (PRE ? 5 : 3) * nb;
+    const double* __restrict__ ddA = b.scratch + (PRE ? 6 : 4) * nb;
     const int nch = (n + SI_CH - 1) / SI_CH;
     // elimination from the end of the line: chunks right to left
     double ccN = 1.0, bbN = 0.0, ffN = 0.0;
@@ -383,12 +392,19 @@ void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int n
     if (nslots <= 0) return;
     dim3 blk(SA_BX, SA_BY, 1);
     dim3 grd((nx + SA_BX - 1) / SA_BX, (ny + SA_BY - 1) / SA_BY, nz * nslots);
-    if (!marchRes) hipLaunchKernelGGL((k_sa_residual<true>), grd, blk, 0, s, tab, nz, kp);
     dim3 l64(64, 1, 1);
     // sweep order of the reference: j, i, k
+    if (marchRes) {
+        // the marching kernel left the off-diagonals of all three directions beside the right-hand side and the central jacobian
+        hipLaunchKernelGGL((k_sa_sweep<1, true>), dim3((nx + 63) / 64, nz, nslots), l64, 0, s, tab, kp, 0);
+        hipLaunchKernelGGL((k_sa_solve_i<true>), dim3((ny + 63) / 64, nz, nslots), l64, 0, s, tab);
+        hipLaunchKernelGGL((k_sa_sweep<2, true>), dim3((nx + 63) / 64, ny, nslots), l64, 0, s, tab, kp, 0);
+        return;
+    }
+    hipLaunchKernelGGL((k_sa_residual<true>), grd, blk, 0, s, tab, nz, kp);
     hipLaunchKernelGGL((k_sa_sweep<1>), dim3((nx + 63) / 64, nz, nslots), l64, 0, s, tab, kp, 0);
     hipLaunchKernelGGL(k_sa_rows_i, grd, blk, 0, s, tab, nz, kp);
-    hipLaunchKernelGGL(k_sa_solve_i, dim3((ny + 63) / 64, nz, nslots), l64, 0, s, tab);
+    hipLaunchKernelGGL((k_sa_solve_i<false>), dim3((ny + 63) / 64, nz, nslots), l64, 0, s, tab);
     hipLaunchKernelGGL((k_sa_sweep<2>), dim3((nx + 63) / 64, ny, nslots), l64, 0, s, tab, kp, 0);
 }
 

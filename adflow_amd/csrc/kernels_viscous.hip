@@ -301,15 +301,23 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
                     if (mm == 2) bmK1 = fmax(b.bmt[4][(i - 1) + (long)b.ie * (j - 1)], 0.0);
                     if (mm == b.kl) bmK2 = fmax(b.bmt[5][(i - 1) + (long)b.ie * (j - 1)], 0.0);
                 }
-                double uu, c1m, c1p;
-                dvt += sa_advect(dk, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uu); qjac += fabs(uu) + ((uu > 0.0) ? uu * bmK1 : -uu * bmK2);
-                dvt += sa_advect(dj, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uu); qjac += fabs(uu) + ((uu > 0.0) ? uu * bmJ1 : -uu * bmJ2);
-                dvt += sa_advect(di, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uu); qjac += fabs(uu) + ((uu > 0.0) ? uu * bmI1 : -uu * bmI2);
+                // the off-diagonals of the three line solves of saSolve (sa.F90:858-1240: bb = (-c1m - max(uu, 0)) rblank, dd = (-c1p +
+                // min(uu, 0)) rblank) depend on the frozen state only and everything they are made of is at hand here: written once
+                // (scratch 3 .. 8: bb, dd of j, i, k), the sweeps then read two values per cell and direction instead of forming them
+                // from ~20
+                double uuK, uuJ, uuI, c1m, c1p;
+                const double rbl = flg_blank(flags[c >> 3]);
+                GPTR(double) scr = (GPTR(double))b.scratch;
+                dvt += sa_advect(dk, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uuK); qjac += fabs(uuK) + ((uuK > 0.0) ? uuK * bmK1 : -uuK * bmK2);
+                dvt += sa_advect(dj, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uuJ); qjac += fabs(uuJ) + ((uuJ > 0.0) ? uuJ * bmJ1 : -uuJ * bmJ2);
+                dvt += sa_advect(di, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uuI); qjac += fabs(uuI) + ((uuI > 0.0) ? uuI * bmI1 : -uuI * bmI2);
                 dvt += sa_diffuse(dk, s0.vol, q0.nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qjac += c1m + c1p + ((mm == 2) ? c1m * bmK1 : c1p * bmK2);
+                if (outC) { stg(scr + 7 * nb, c, (-c1m - fmax(uuK, 0.0)) * rbl); stg(scr + 8 * nb, c, (-c1p + fmin(uuK, 0.0)) * rbl); }
                 dvt += sa_diffuse(dj, s0.vol, q0.nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qjac += c1m + c1p + ((j == 2) ? c1m * bmJ1 : c1p * bmJ2);
+                if (outC) { stg(scr + 3 * nb, c, (-c1m - fmax(uuJ, 0.0)) * rbl); stg(scr + 4 * nb, c, (-c1p + fmin(uuJ, 0.0)) * rbl); }
                 dvt += sa_diffuse(di, s0.vol, q0.nu, kp.sa_cb2, cb3Inv, &c1m, &c1p); qjac += c1m + c1p + ((i == 2) ? c1m * bmI1 : c1p * bmI2);
+                if (outC) { stg(scr + 5 * nb, c, (-c1m - fmax(uuI, 0.0)) * rbl); stg(scr + 6 * nb, c, (-c1p + fmin(uuI, 0.0)) * rbl); }
                 if (outC) {
-                    GPTR(double) scr = (GPTR(double))b.scratch;
                     stg(scr, c, dvt);
                     stg(scr + nb, c, kp.sa_qqFactor * qjac);      // implicit relaxation factor of saSolve (sa.F90:830-836)
                 }
