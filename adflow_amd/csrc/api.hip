@@ -614,6 +614,7 @@ static bool normals_match_nodes(const Block* b)
 {
     const adflow_block_desc& d = b->d;
     const BlkView& v = b->v;
+    if (!d.x || !d.sI || !d.sJ || !d.sK) return false;
     const double fact = d.rightHanded ? 0.5 : -0.5;
     const size_t nxn = (size_t)v.ie + 1, nyn = (size_t)v.je + 1, nzn = (size_t)v.ke + 1;        // x(0:ie, 0:je, 0:ke, 3)
     auto X = [&](int i, int j, int k, int q) { return d.x[(size_t)i + nxn * ((size_t)j + nyn * ((size_t)k + nzn * q))]; };
@@ -922,11 +923,14 @@ int adflow_gpu_upload_array(int nn, int level, int sps, int which, const double*
         b->etot_consistent = false;
     }
     if (which == ADFLOW_ARR_X || which == ADFLOW_ARR_SI || which == ADFLOW_ARR_SJ || which == ADFLOW_ARR_SK) {
-        // nodes or normals replaced one array at a time: the derived face vectors are stale, and the normals count as
-        // metric_block(x) again only when the device data says so
+        // nodes or normals replaced one array at a time: the derived face vectors are stale.  The normals count as metric_block(x)
+        // again only when the array came from the registered descriptor pointer (then the host arrays the check reads ARE what the
+        // device holds); after an upload from any other buffer the stored normals are used until update_geometry / upload_geometry
+        // (round-3 advisor finding)
         if (sync_and_check()) return 1;
         b->face_vectors_valid = false;
-        b->normals_from_x_ok = normals_match_nodes(b);
+        const double* own = which == ADFLOW_ARR_X ? b->d.x : which == ADFLOW_ARR_SI ? b->d.sI : which == ADFLOW_ARR_SJ ? b->d.sJ : b->d.sK;
+        b->normals_from_x_ok = (host == own) && normals_match_nodes(b);
     }
     return sync_and_check();
 }
@@ -962,7 +966,7 @@ static int source_terms_enqueue(int withBlank);
 
 // residual (residuals.F90:1028) = residual_block of every block; blockResCore (blockette.F90:755) is the same sum of
 // fluxes WITHOUT the low-speed preconditioner of residual_block (residuals.F90:172-331) -> lowSpeed = false there.
-static int wall_stress_enqueue(int level, const KParams& kp);
+static int wall_stress_enqueue(int level, const KParams& kp, bool formGrad);
 
 // stage0: the reference's rkStage is 0 at this call -> on the ground level viscousFlux also stores the wall stress tensor
 // and heat flux of the viscous subfaces (storeWallTensor, fluxes.F90:2586-2592)
@@ -974,9 +978,12 @@ static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox =
 {
     const bool wallStress = stage0 && !viscApprox && kp.viscous && level == g_opts.groundLevel && fabs(kp.rFil) >= 1.e-10 &&
                             has_wall_subfaces(level);
-    if (enqueue_flow_fluxes(level, kp, viscApprox, needGradHbm || wallStress)) return 1;
+    // the wall stress reads the gradients of the node planes ON the wall faces only: when the flux kernel keeps its gradients in
+    // LDS (k_visc_gf) those few nodes are formed again by the wall-stress launch instead of every node of the level being stored
+    const bool gradOnChip = viscous_is_tiled() >= 2 && !needGradHbm;
+    if (enqueue_flow_fluxes(level, kp, viscApprox, needGradHbm)) return 1;
     if (wallStress)
-        if (wall_stress_enqueue(level, kp)) return 1;
+        if (wall_stress_enqueue(level, kp, gradOnChip)) return 1;
     // sourceTerms() of the call sites of `residual` (smoothers.F90:74,409, multiGrid.F90:52,887,949): fine level only
     if (lowSpeed && level == 1 && source_terms_enqueue(1)) return 1;
     if (lowSpeed && g_opts.lowSpeedPreconditioner) {
@@ -1157,7 +1164,7 @@ static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0
     if (rans && !g_sa_march) return 0;
     bool moving = false, wall = has_wall_subfaces(level) && level == g_opts.groundLevel;
     for_level(level, [&](Block* b) { moving = moving || b->v.sFace || b->v.moving; return 0; });
-    if (moving || wall || !g_act.empty()) return 0;
+    if (moving || !g_act.empty()) return 0;
     CommPattern* cp;
     if (build_comm(level, 2, &cp)) return 1;
     const bool messages = !cp->sends.empty() || !cp->recvs.empty();
@@ -1181,30 +1188,43 @@ static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0
     *taken = 1;
     KParams kv = kp;
     kv.viscFirst = 1;
-    // ---- messages out, same-GPU copies
-    HIPCHK(hipEventRecord(g_evFork, g_stream));
-    bool remote = false;
-    if (comm_exchange_begin(cp, g_tab[level], mask, nvar, &remote)) return 1;
-    // ---- halo-free tiles
-    if (rans) {
-        HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
-        launch_sa_march(t.tab, g_sa_tiles_int[level].first, g_sa_tiles_int[level].second, kp, g_streamB, false);
+    // (everything behind the fork runs inside `run`: an error exit must not leave the side queue unjoined -- round-3 advisor finding)
+    bool forked = false;
+    auto run = [&]() -> int {
+        // ---- messages out, same-GPU copies
+        HIPCHK(hipEventRecord(g_evFork, g_stream));
+        bool remote = false;
+        if (comm_exchange_begin(cp, g_tab[level], mask, nvar, &remote)) return 1;
+        // ---- halo-free tiles
+        if (rans) {
+            HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
+            forked = true;
+            launch_sa_march(t.tab, g_sa_tiles_int[level].first, g_sa_tiles_int[level].second, kp, g_streamB, false);
+        }
+        launch_visc_gf(g_tab[level], g_gf_tiles_int[level].first, g_gf_tiles_int[level].second, kv, false, g_stream);
+        // ---- messages in
+        if (comm_exchange_end(cp, g_tab[level], mask, remote)) return 1;
+        if (halo_exchange_close(level, lStart, lEnd, 1, 2)) return 1;
+        // ---- the tiles next to the block faces, then the inviscid march over all of them
+        if (rans) {
+            HIPCHK(hipEventRecord(g_evC, g_stream));
+            HIPCHK(hipStreamWaitEvent(g_streamB, g_evC, 0));
+            launch_sa_march(t.tab, g_sa_tiles_bnd[level].first, g_sa_tiles_bnd[level].second, kp, g_streamB, false);
+            HIPCHK(hipEventRecord(g_evB, g_streamB));
+        }
+        launch_visc_gf(g_tab[level], g_gf_tiles_bnd[level].first, g_gf_tiles_bnd[level].second, kv, false, g_stream);
+        if (!launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream))
+            launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
+        if (rans) HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0));      // join
+        forked = false;
+        return 0;
+    };
+    if (run()) {
+        if (forked && hipEventRecord(g_evB, g_streamB) == hipSuccess) (void)hipStreamWaitEvent(g_stream, g_evB, 0);
+        return 1;
     }
-    launch_visc_gf(g_tab[level], g_gf_tiles_int[level].first, g_gf_tiles_int[level].second, kv, false, g_stream);
-    // ---- messages in
-    if (comm_exchange_end(cp, g_tab[level], mask, remote)) return 1;
-    if (halo_exchange_close(level, lStart, lEnd, 1, 2)) return 1;
-    // ---- the tiles next to the block faces, then the inviscid march over all of them
-    if (rans) {
-        HIPCHK(hipEventRecord(g_evC, g_stream));
-        HIPCHK(hipStreamWaitEvent(g_streamB, g_evC, 0));
-        launch_sa_march(t.tab, g_sa_tiles_bnd[level].first, g_sa_tiles_bnd[level].second, kp, g_streamB, false);
-        HIPCHK(hipEventRecord(g_evB, g_streamB));
-    }
-    launch_visc_gf(g_tab[level], g_gf_tiles_bnd[level].first, g_gf_tiles_bnd[level].second, kv, false, g_stream);
-    if (!launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream))
-        launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
-    if (rans) HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0));      // join
+    // viscSubface%tau / %q (storeWall, blockette.F90:135): from the node planes on the wall faces, formed behind the exchange
+    if (wall && wall_stress_enqueue(level, kp, true)) return 1;
     return 0;
 }
 
@@ -1720,6 +1740,30 @@ int adf_round_size()
 
 namespace {
 
+// Launch order of T work items that run in rounds of W resident workgroups: slot p of the table -> item (or -1 = empty slot).  Every
+// round occupies Wp = W rounded up to a multiple of 8 slots, so that slot p is dispatched to XCD p % 8 in every round whatever the CU
+// count (round-3 advisor finding: with W % 8 != 0 the plain (p % W) / 8, (p % W) % 8 decode dropped items); inside a round XCD x takes
+// the x-th contiguous eighth of the round's items.  Checked: every item exactly once.
+int round_order(int T, int W, std::vector<int>* out)
+{
+    if (W < 1) W = 1;
+    const int Wp = (W + 7) / 8 * 8, rounds = (T + W - 1) / W;
+    out->assign((size_t)rounds * Wp, -1);
+    long seen = 0;
+    for (int q = 0; q < rounds; ++q) {
+        const int nIn = std::min(W, T - q * W), per = (nIn + 7) / 8;
+        for (int pr = 0; pr < Wp; ++pr) {
+            const int s = pr / 8, x = pr % 8;
+            if (s < per && x * per + s < nIn) { (*out)[(size_t)q * Wp + pr] = q * W + x * per + s; ++seen; }
+        }
+    }
+    if (seen != T) return fail("round_order: %ld of %d work items placed (W = %d)", seen, T, W);
+    std::vector<char> hit((size_t)T, 0);
+    for (int e : *out)
+        if (e >= 0) { if (hit[e]) return fail("round_order: item %d placed twice", e); hit[e] = 1; }
+    return 0;
+}
+
 int ensure_tiles(int level)
 {
     if (g_tiles.count(level)) return 0;
@@ -1743,15 +1787,16 @@ int ensure_tiles(int level)
     // compact when a level holds many blocks)
     const int n = (int)nat.size();
     const int W = (g_xcd_tiles >= 2) ? adf_round_size() : ((n + 7) / 8) * 8;
-    const int rounds = (n + W - 1) / W;
-    std::vector<int4> phys((size_t)rounds * W);
-    for (int p = 0; p < rounds * W; ++p) {
-        const int q = p / W, pr = p % W;
-        const int nIn = std::min(W, n - q * W), per = (nIn + 7) / 8;
-        const int x = pr % 8, s = pr / 8;
-        int L = (s < per && x * per + s < nIn) ? q * W + x * per + s : -1;
-        if (!g_xcd_tiles) L = (p < n) ? p : -1;
-        if (L >= 0) phys[p] = nat[L];
+    std::vector<int> ord;
+    if (g_xcd_tiles) {
+        if (round_order(n, W, &ord)) return 1;
+    } else {
+        ord.resize(n);
+        for (int p = 0; p < n; ++p) ord[p] = p;
+    }
+    std::vector<int4> phys(ord.size());
+    for (size_t p = 0; p < ord.size(); ++p) {
+        if (ord[p] >= 0) phys[p] = nat[ord[p]];
         else { phys[p].x = -1; phys[p].y = phys[p].z = phys[p].w = 0; }
     }
     while (!phys.empty() && phys.back().x < 0) phys.pop_back();
@@ -1859,13 +1904,11 @@ static int build_chunk_tables(int level, int R, double warm, int reach, std::pai
     // round-ordered device table of a chunk list
     auto make_table = [&](const std::vector<Chunk>& list, std::pair<int4*, int>* out) -> int {
         const int T = (int)list.size();
-        const int rounds = (T + W - 1) / W;
-        std::vector<int4> phys((size_t)rounds * W);
-        for (int p = 0; p < rounds * W; ++p) {
-            const int q = p / W, s = (p % W) / 8, x = (p % W) % 8;      // (W is a multiple of 8 on the device: x = the XCD of workgroup p)
-            const int nIn = std::min(W, T - q * W);             // chunks of this round
-            const int per = (nIn + 7) / 8;
-            const int e = (s < per && x * per + s < nIn) ? q * W + x * per + s : -1;
+        std::vector<int> ord;
+        if (round_order(T, W, &ord)) return 1;
+        std::vector<int4> phys(ord.size());
+        for (size_t p = 0; p < ord.size(); ++p) {
+            const int e = ord[p];
             int4 tt;
             if (e >= 0) {
                 const Col& c = cols[list[e].col];
@@ -2270,7 +2313,9 @@ static int bc_plan(int level, BcPlan** out)
         if (ent[e].f.tauq) {
             order.push_back(e);
             pl.wall.count++;
-            pl.wall.maxCells = std::max(pl.wall.maxCells, cells(e));
+            // (the launch over the wall faces also covers the (n1 + 1) (n2 + 1) nodes of their plane: k_wall_node_grad)
+            const BcFaceDev& f = ent[e].f;
+            pl.wall.maxCells = std::max(pl.wall.maxCells, (long)(f.icEnd - f.icBeg + 2) * (f.jcEnd - f.jcBeg + 2));
         }
     if (pl.nent > 0) {
         HIPCHK(hipMalloc((void**)&pl.d_ent, sizeof(BcEntry) * ent.size()));
@@ -2349,14 +2394,14 @@ static bool has_wall_subfaces(int level)
 }
 
 // viscSubface(:)%tau / %q of every viscous subface of the level, from the nodal gradients the viscous kernels just used
-static int wall_stress_enqueue(int level, const KParams& kp)
+static int wall_stress_enqueue(int level, const KParams& kp, bool formGrad)
 {
     BcPlan* pl;
     if (bc_plan(level, &pl)) return 1;
     if (pl->wall.count == 0) return 0;
     LevelTab t;
     if (level_tab(level, &t)) return 1;
-    launch_wall_stress(t.tab, pl->d_ent, pl->d_order, pl->wall, kp, g_stream);
+    launch_wall_stress(t.tab, pl->d_ent, pl->d_order, pl->wall, kp, formGrad, g_stream);
     return 0;
 }
 
@@ -3003,12 +3048,14 @@ int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
                     HIPCHK(hipGraphLaunch(g_mgg.exec, g_stream));
                     return sync_and_check();
                 }
-                // capture failed: nothing was executed; fall back to the direct path for good
+                // capture failed: nothing was executed, but the enqueue walked the host-side block flags (ss_valid, etot_consistent,
+                // face_vectors_valid) to their post-cycle values: put them back, then run the cycle directly -- for good, and also
+                // when the enqueue itself reported an error under capture (the direct path reports it again if it is a real one)
                 if (gr) (void)hipGraphDestroy(gr);
                 (void)hipGetLastError();
                 g_mgg.exec = nullptr;
                 g_mgg.failed = true;
-                if (rc) return rc;
+                set_block_flags(g_mgg.pre);
             } else {
                 (void)hipGetLastError();
                 g_mgg.failed = true;
@@ -3369,7 +3416,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_march_kch = value;
         for (auto& kv : g_tiles) (void)hipFree(kv.second.first);   // tile tables depend on the chunk length
         g_tiles.clear();
-        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
+        for (auto* mp : {&g_tiles, &g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
             for (auto& kv : *mp) (void)hipFree(kv.second.first);
             mp->clear();
         }
@@ -3388,7 +3435,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_gf_nofit = (value < 0);
         g_num_cus = value > 0 ? value : 0;
         if (g_stream) (void)hipStreamSynchronize(g_stream);
-        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
+        for (auto* mp : {&g_tiles, &g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
             for (auto& kv : *mp) (void)hipFree(kv.second.first);
             mp->clear();
         }

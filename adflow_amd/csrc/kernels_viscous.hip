@@ -74,14 +74,9 @@ __device__ __forceinline__ void grad_dir(const BlkView& b, long c, long sd, long
     }
 }
 
-// nodes 1..il x 1..jl x 1..kl ; node (i,j,k) is stored at cell index (i,j,k)
-__global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
+// gradient of the node stored at cell index c (nodes 1..il x 1..jl x 1..kl; node (i,j,k) is stored at cell index (i,j,k))
+__device__ __forceinline__ void node_gradient(const BlkView& b, long c)
 {
-    const int i = blockIdx.x * VS_BX + threadIdx.x + (2 - 16);   // aligned rows, see internal.h
-    const int j = blockIdx.y * VS_BY + threadIdx.y + 1;
-    const int k = blockIdx.z + 1;
-    if (i < 1 || i > b.il || j > b.jl) return;
-    const long c = b.idx(i, j, k);
     const long nb = b.nbox;
     const long si = 1, sj = b.ldi, sk = b.ldk;
     // the eight cells around the node, index di + 2 dj + 4 dk
@@ -105,6 +100,15 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
                                    b.vol[c + sj + sk] + b.vol[c + si + sj] + b.vol[c + si + sj + sk]);
 #pragma unroll
     for (int m = 0; m < 12; ++m) b.grad[c + m * nb] = g[m] * oneOverV;
+}
+
+__global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
+{
+    const int i = blockIdx.x * VS_BX + threadIdx.x + (2 - 16);   // aligned rows, see internal.h
+    const int j = blockIdx.y * VS_BY + threadIdx.y + 1;
+    const int k = blockIdx.z + 1;
+    if (i < 1 || i > b.il || j > b.jl) return;
+    node_gradient(b, b.idx(i, j, k));
 }
 
 // ---------------------------------------------------------------------------
@@ -474,6 +478,33 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous(BlkView b, KParams kp)
     }
 }
 
+// Nodal gradients of the node plane ON a viscous-wall subface: the only gradients the stored wall stress reads (the four nodes of a
+// wall face, fluxes.F90:2849-2879).  k_visc_gf keeps its gradients in LDS; instead of writing all twelve of every node of the block
+// for the sake of the wall faces (96 B per cell), the few nodes of the wall planes are formed again here, in the reference's own
+// summation order (k_nodal_gradients).  blockIdx.y = subface entry of the level's boundary plan.
+__global__ __launch_bounds__(256) void k_wall_node_grad(const BlkView* __restrict__ tab, const BcEntry* __restrict__ ent,
+                                                        const int* __restrict__ order)
+{
+    const BcEntry& e = ent[order[blockIdx.y]];
+    const BcFaceDev& f = e.f;
+    if (!f.tauq) return;
+    const BlkView& b = tab[e.slot];
+    int r[4];
+    bc_owned_range(f.faceID, f.icBeg, f.icEnd, f.jcBeg, f.jcEnd, b.il, b.jl, b.kl, r);
+    const int na = r[1] - r[0] + 2, nbb = r[3] - r[2] + 2;         // nodes r[0]-1 .. r[1]
+    if (na <= 1 || nbb <= 1) return;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)na * nbb) return;
+    const int a = r[0] - 1 + (int)(t % na), bb = r[2] - 1 + (int)(t / na);
+    long c;
+    switch (f.faceID) {
+    case ADFLOW_IMIN: case ADFLOW_IMAX: c = b.idx(f.faceID == ADFLOW_IMIN ? 1 : b.il, a, bb); break;
+    case ADFLOW_JMIN: case ADFLOW_JMAX: c = b.idx(a, f.faceID == ADFLOW_JMIN ? 1 : b.jl, bb); break;
+    default: c = b.idx(a, bb, f.faceID == ADFLOW_KMIN ? 1 : b.kl);
+    }
+    node_gradient(b, c);
+}
+
 // Stress tensor and heat flux vector on the faces of the viscous-wall subfaces: what viscousFlux stores in
 // viscSubface(:)%tau / %q when storeWallTensor is set (rkStage == 0 on the ground level, fluxes.F90:2586-2592,
 // 2861-2892, 3155-3185, 3450-3480).  Same face evaluation as the flux kernels, from the nodal gradients they left in
@@ -512,9 +543,15 @@ __global__ __launch_bounds__(256) void k_wall_stress(const BlkView* __restrict__
     for (int m = 0; m < 9; ++m) f.tauq[m * n + t] = tq[m];
 }
 
-void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, const KParams& kp, hipStream_t s)
+void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order, const BcPhase& ph, const KParams& kp, bool formGrad,
+                        hipStream_t s)
 {
     if (ph.count <= 0 || ph.maxCells <= 0) return;
+    // formGrad: the flux kernel kept its gradients on chip -> the node planes of the wall faces are formed here.  maxCells counts the
+    // cells of a subface incl. its halo ring (>= the (n1 + 1) (n2 + 1) nodes of its owned faces)
+    if (formGrad)
+        hipLaunchKernelGGL(k_wall_node_grad, dim3((unsigned)((ph.maxCells + 255) / 256), ph.count, 1), dim3(256, 1, 1), 0, s, tab, ent,
+                           order + ph.first);
     hipLaunchKernelGGL(k_wall_stress, dim3((unsigned)((ph.maxCells + 255) / 256), ph.count, 1), dim3(256, 1, 1), 0, s, tab, ent,
                        order + ph.first, kp);
 }

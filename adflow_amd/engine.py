@@ -147,11 +147,13 @@ class Engine:
         return out
 
     def blocketteRes(self, level=1, updateIntermed=True, flowRes=True, turbRes=True, dissApprox=False, viscApprox=False,
-                     useBlockettes=False, halo=False):
-        """halo: also the part of blocketteRes in front of the core -- boundary conditions and whalo2 (ADFLOW_RES_HALO)"""
+                     useBlockettes=False, halo=False, closures=False):
+        """halo: also the part of blocketteRes in front of the core -- boundary conditions and whalo2 (ADFLOW_RES_HALO);
+        closures: and the derived values in front of those -- computePressureSimple, computeLamViscosity, computeEddyViscosity
+        (ADFLOW_RES_CLOSURES, blockette.F90:199-203).  Both = the reference's whole blocketteRes."""
         flags = (capi.RES_UPDATE_INTERMED if updateIntermed else 0) | (capi.RES_FLOW if flowRes else 0) \
             | (capi.RES_TURB if turbRes else 0) | (32 if dissApprox else 0) | (64 if viscApprox else 0) \
-            | (128 if useBlockettes else 0) | (16 if halo else 0)
+            | (128 if useBlockettes else 0) | (capi.RES_HALO if halo else 0) | (capi.RES_CLOSURES if closures else 0)
         self._chk(self.lib.adflow_gpu_block_res(level, flags))
 
     def bc_register(self, faces, nViscBocos: int = 0, nn: int = 1, level: int = 1, sps: int = 1):

@@ -378,6 +378,30 @@ def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7, split=()):
     return faces, nvisc
 
 
+def set_porosities(blk: Block, faces) -> None:
+    """porI / porJ / porK of a block from its boundary subfaces, as setPorosities does (preprocessingAPI.F90:524-678): normalFlux
+    everywhere, boundFlux on the faces of viscous / inviscid walls and extrapolation boundaries; every other boundary kind (farfield,
+    symmetry, in- / outflow) and every 1-to-1 interface keeps normalFlux."""
+    porI, porJ, porK = blk["porI"], blk["porJ"], blk["porK"]       # (1:il,2:jl,2:kl), (2:il,1:jl,2:kl), (2:il,2:jl,1:kl)
+    porI[...] = normalFlux
+    porJ[...] = normalFlux
+    porK[...] = normalFlux
+    for f in faces:
+        if f["bcType"] not in (-3, -4, -5, -15):
+            continue
+        fid = f["faceID"]
+        amax = blk.jl if fid <= 2 else blk.il
+        bmax = blk.kl if fid <= 4 else blk.jl
+        a0, a1 = max(f["icBeg"], 2) - 2, min(f["icEnd"], amax) - 2          # owned face cells, 0-based
+        b0, b1 = max(f["jcBeg"], 2) - 2, min(f["jcEnd"], bmax) - 2
+        if fid <= 2:
+            porI[0 if fid == 1 else blk.nx, a0:a1 + 1, b0:b1 + 1] = boundFlux
+        elif fid <= 4:
+            porJ[a0:a1 + 1, 0 if fid == 3 else blk.ny, b0:b1 + 1] = boundFlux
+        else:
+            porK[a0:a1 + 1, b0:b1 + 1, 0 if fid == 5 else blk.nz] = boundFlux
+
+
 # ----------------------------------------------------------------------------
 # multigrid: regular 2:1 coarsening maps (src/preprocessing/coarseUtils.F90:254-420)
 # ----------------------------------------------------------------------------

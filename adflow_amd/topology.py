@@ -76,6 +76,21 @@ class BrickTopology:
     def blocks_of(self, rank) -> List[int]:
         return [g for g in range(self.nblocks) if self.owner(g) == rank]
 
+    def boundary_spec(self, g, brick_spec: Dict[int, int]) -> Dict[int, int]:
+        """{faceID: BCType} of block g: the faces of the block that lie on a NON-periodic end of the brick take the kind
+        `brick_spec` gives for that end of the brick (faceID 1..6 = iMin, iMax, jMin, jMax, kMin, kMax); every other face of
+        the block is a 1-to-1 interface."""
+        c, B = self.coords(g), (self.Bi, self.Bj, self.Bk)
+        out = {}
+        for d in range(3):
+            if self.periodic[d]:
+                continue
+            if c[d] == 0 and (2 * d + 1) in brick_spec:
+                out[2 * d + 1] = brick_spec[2 * d + 1]
+            if c[d] == B[d] - 1 and (2 * d + 2) in brick_spec:
+                out[2 * d + 2] = brick_spec[2 * d + 2]
+        return out
+
     def patterns(self, nLayers: int, only_rank=None) -> Dict[int, CommPattern]:
         """CommPattern per rank for halo depth nLayers (1: cells 1..ie, 2: 0..ib),
         faces, edges and corners included.  only_rank: build just that rank's

@@ -117,6 +117,89 @@ def check_brick_block_res(engine, topo, prm, seed=17, fused_halo=False, **mk):
         assert_dw(blocks[nn], dw, rblocks[nn]["dw"], blocks[nn].nw, what=f"block {nn}: whalo2 + blocketteResCore")
 
 
+def setup_brick_with_bc(engine, topo, prm, brick_spec, seed=19, **mk):
+    """A brick of blocks whose NON-periodic ends are physical boundaries (brick_spec: {faceID of the brick: BCType}) and whose inner
+    faces are 1-to-1 interfaces: boundary subfaces, porosities (setPorosities) and both communication patterns on the engine and in
+    the reference's flowDoms.  Returns (blocks, rblocks, bocos)."""
+    from oracle import ref
+    from adflow_amd.synth import make_bocos, set_porosities
+    from adflow_amd.topology import apply_local_copies_fast
+    new_level(engine)
+    prm = prm.replace(currentLevel=1, groundLevel=1)
+    blocks = make_brick(topo, prm, seed, wall_kmin=False, **mk)
+    lid = topo.local_ids()
+    bocos = {}
+    for g in range(topo.nblocks):
+        spec = topo.boundary_spec(g, brick_spec)
+        nn = lid[g]
+        if spec:
+            bocos[nn] = make_bocos(blocks[nn], prm, spec, seed=seed + 31 * g + 1)
+        set_porosities(blocks[nn], bocos[nn][0] if nn in bocos else [])
+    pats = {L: topo.patterns(L)[0] for L in (1, 2)}
+    apply_local_copies_fast(blocks, pats[2])
+    rblocks = {nn: b.copy() for nn, b in blocks.items()}
+    ref.alloc_doms(max(blocks), 1)
+    ref.bind_blocks(rblocks, prm, level=1, nlevels=1, alloc=False, bocos=bocos)
+    engine.set_options(prm)
+    for nn, b in blocks.items():
+        engine.register(b, nn=nn, level=1)
+        if nn in bocos:
+            engine.bc_register(*bocos[nn], nn=nn, level=1)
+    for L in (1, 2):
+        ref.set_internal_comm(1, L, pats[L])
+        engine.comm_register(1, L, pats[L])
+    return blocks, rblocks, bocos, prm
+
+
+def check_blockette_res_with_bc(engine, topo, prm, brick_spec, seed=19, split_eval=None, **mk):
+    """The reference's WHOLE blocketteRes (blockette.F90:199-283, default flags, storeWall = T) on a wall-bounded mesh, as ONE
+    library call (ADFLOW_RES_CLOSURES | HALO | FLOW | TURB): derived values of the owned cells, turbulence + mean-flow boundary
+    conditions of every subface, whalo2 over the 1-to-1 interfaces, blocketteResCore; compared: dw of every block and
+    viscSubface%tau / %q of every viscous subface.  The state is scrambled first so that p / rlv / rev and every halo are stale."""
+    from oracle import ref
+    blocks, rblocks, bocos, prm = setup_brick_with_bc(engine, topo, prm, brick_spec, seed, **mk)
+    rng = np.random.default_rng(seed)
+    turb = prm.equations == RANSEquations
+    for nn in sorted(blocks):
+        b, r = blocks[nn], rblocks[nn]
+        sl = (slice(2, b.il + 1), slice(2, b.jl + 1), slice(2, b.kl + 1))
+        b["w"][sl] *= rng.uniform(0.97, 1.03, b["w"][sl].shape)       # owned cells only: closures and halos are now stale
+        r["w"][...] = b["w"]
+        engine.upload_state(nn, 1)
+    for nn in sorted(rblocks):
+        ref.call_level("setPointers", 1, nn)
+        ref.call("computePressureSimple", 0)
+        ref.call("computeLamViscosity", 0)
+        ref.call("computeEddyViscosity", 0)
+        if turb:
+            ref.call("bcTurbTreatment")
+            ref.call("applyAllTurbBCThisBlock", 1)
+        ref.call("applyAllBC_block", 1)
+    ref.call_level("whalo2", 1, 1, prm.nw)
+    if split_eval is not None:
+        engine.set_tuning("split_eval", split_eval)
+    try:
+        engine.blocketteRes(level=1, updateIntermed=False, flowRes=True, turbRes=turb, halo=True, closures=True)
+    finally:
+        if split_eval is not None:
+            engine.set_tuning("split_eval", 1)
+    nwall = 0
+    for nn in sorted(rblocks):
+        ref.call_level("setPointers", 1, nn)
+        ref.blockette_res_core(False, True, turb)
+        dw = engine.download_residual(nn, 1)
+        assert_dw(blocks[nn], dw, rblocks[nn]["dw"], blocks[nn].nw, what=f"block {nn}: blocketteRes with boundary conditions")
+        faces, nvisc = bocos.get(nn, ([], 0))
+        for mm in range(1, nvisc + 1):
+            tau_r, q_r = ref.wall_stress(mm)
+            tau, q = engine.wall_stress(tau_r.shape[:2], mm, nn=nn)
+            assert np.abs(tau_r).max() > 0
+            e = max(rel_err(tau, tau_r), rel_err(q, q_r))
+            assert e <= TOL, ("wall stress", nn, mm, faces[mm - 1]["faceID"], e)
+            nwall += 1
+    return nwall
+
+
 def check_block_res_approx(engine, dims, prm, diss_approx=True, visc_approx=True, seed=91, blockettes=False, **mk):
     """blockResCore with dissApprox / viscApprox (blockette.F90:755-852): the lumped-dissipation and thin-layer
     residual of the preconditioner assembly, sensor FROZEN at a reference state that differs from the state the

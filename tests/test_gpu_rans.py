@@ -56,6 +56,50 @@ def test_multiblock_brick_at_bench_block_size(engine):
         checks.check_brick_block_res(engine, BrickTopology(2, 2, 2, 64, 48, 32), prm, seed=sd, stretch_k=2.0)
 
 
+# the brick ends of the wall-bounded bench workload: viscous wall below (kMin), a symmetry plane (jMin), farfield elsewhere
+WALL_BRICK = {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}
+
+
+def test_blockette_res_wall_bounded_brick(engine):
+    """the reference's WHOLE blocketteRes (closures, turbulence + mean-flow boundary conditions, whalo2, core with storeWall) on
+    wall-bounded bricks: dw of every block and viscSubface%tau / %q of every viscous subface; with and without the evaluation split
+    around the exchange (which now also runs on meshes with walls)"""
+    from adflow_amd.topology import BrickTopology
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    open3 = (False, False, False)
+    n = checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 2, 10, 7, 6, periodic=open3), prm, WALL_BRICK, seed=3, stretch_k=2.0)
+    assert n == 2
+    # isothermal + adiabatic walls on several faces, matrix dissipation, QCR
+    spec = {1: -4, 2: -6, 3: -3, 4: -15, 5: -3, 6: -9}
+    prm2 = FlowParams(equations=RANSEquations, spaceDiscr=dissMatrix, vis4=0.1, useQCR=True)
+    assert checks.check_blockette_res_with_bc(engine, BrickTopology(2, 2, 1, 9, 6, 5, periodic=open3), prm2, spec, seed=5, stretch_k=2.0) == 8
+    # the split evaluation (tiles that read no halo cell first) on a mesh with walls
+    checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 1, 130, 11, 24, periodic=open3), prm.replace(muSuthDim=1.0), WALL_BRICK,
+                                       seed=7, split_eval=2, stretch_k=2.0)
+    # laminar NS, one block with six physical faces
+    checks.check_blockette_res_with_bc(engine, BrickTopology(1, 1, 1, 12, 8, 6, periodic=open3), FlowParams(equations=NSEquations), spec, seed=9,
+                                       stretch_k=2.0)
+
+
+def test_north_star_block_with_six_physical_faces(engine):
+    """ONE 160 x 128 x 64 block of BASELINE configs[3] whose six faces are physical boundaries (viscous wall, symmetry, farfield):
+    the whole blocketteRes incl. viscSubface%tau / %q at full size -- what a near-body block of a CRM mesh executes"""
+    from adflow_amd.topology import BrickTopology
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    checks.check_blockette_res_with_bc(engine, BrickTopology(1, 1, 1, 160, 128, 64, periodic=(False, False, False)), prm, WALL_BRICK,
+                                       seed=46, stretch_k=3.0)
+
+
+def test_wall_bounded_brick_at_bench_block_size(engine):
+    """2 x 2 x 2 blocks of 64 x 48 x 32 cells, the brick's ends physical boundaries (the layout of the bench's default workload):
+    whole blocketteRes in one call, block by block against the reference, wall stress of the four lower blocks"""
+    from adflow_amd.topology import BrickTopology
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    n = checks.check_blockette_res_with_bc(engine, BrickTopology(2, 2, 2, 64, 48, 32, periodic=(False, False, False)), prm, WALL_BRICK,
+                                           seed=47, stretch_k=2.0)
+    assert n == 4
+
+
 def test_evaluation_split_around_the_exchange(engine):
     """tuning split_eval = 2: whalo2 + blocketteRes in one call with the tiles that read no halo cell between the start and the end
     of the exchange, the others behind it: blocks with several interior tiles in every direction (interior / boundary partition of
@@ -230,7 +274,7 @@ def test_visc_gradient_fused(engine):
         engine.set_tuning("march_kch", 5)
         checks.check_block_res(engine, (20, 4, 13), prm, seed=11, stretch_k=2.0)
         engine.set_tuning("march_kch", 32)
-        for cus in (1, 3):
+        for cus in (1, 3, 5, 27):      # rounds of 2, 6, 10, 54 workgroups: 10 and 54 are not multiples of 8 (round-3 advisor finding)
             engine.set_tuning("gf_cus", cus)
             checks.check_block_res(engine, (70, 7, 21), prm, seed=12 + cus, stretch_k=2.0, holes=0.05)
     finally:

@@ -29,6 +29,15 @@ def per_kernel(db, counter):
     return out
 
 
+def evaluations(tab):
+    """number of residual evaluations in the profiled run = launches of the kernel that completes dw (one per evaluation)"""
+    for key in ("k_roe_march", "k_inviscid_march", "k_euler_march", "k_inviscid<"):
+        n = [cnt for name, (v, cnt) in tab.items() if key in name]
+        if n:
+            return max(n)
+    return 0
+
+
 def load(out):
     return json.load(open(out)) if os.path.exists(out) else {}
 
@@ -72,9 +81,24 @@ def main():
         e["fetch_bytes"] = ff * e["fetch_kib_raw"] * 1024.0
         e["write_bytes"] = wf * e["write_kib_raw"] * 1024.0
         e["traffic_bytes_per_launch"] = e["fetch_bytes"] + e["write_bytes"]
-    core = [p for p in kernels if p not in ("halo copies",)]
-    ent = {"git": git, "source": src, "kernels": kernels,
-           "traffic_bytes_per_eval": sum(kernels[p]["traffic_bytes_per_launch"] for p in core),
+    # EVERY kernel of the step (round-3 verdict, weak 2): all kernels that run at least once per evaluation -- halo copies, boundary
+    # conditions, derived values, wall stress included -- summed over the run and divided by the number of evaluations; kernels of the
+    # set-up (face vectors, uploads: fewer launches than evaluations) are left out
+    nev = min(evaluations(f) or 1, evaluations(w) or 1)
+    step_total, others = 0.0, {}
+    for name in sorted(set(f) | set(w)):
+        fv, fn = f.get(name, (0.0, 0))
+        wv, wn = w.get(name, (0.0, 0))
+        if max(fn, wn) < nev or "at::native" in name:
+            continue
+        b = (ff * fv * fn / max(evaluations(f), 1) + wf * wv * wn / max(evaluations(w), 1)) * 1024.0
+        step_total += b
+        if not any(key in name for key, _ in PHASE_OF):
+            others[name[:60]] = b
+    ent = {"git": git, "source": src, "kernels": kernels, "evaluations_profiled": nev,
+           "other_kernels_bytes_per_eval": others,
+           "traffic_bytes_per_eval": step_total,
+           "traffic_bytes_per_eval_marches_only": sum(kernels[p]["traffic_bytes_per_launch"] for p in kernels if p != "halo copies"),
            "correction": f"FETCH_SIZE x{ff:.3f}, WRITE_SIZE x{wf:.3f} ("
                          + ("calibrated with tools/pmc_calib.bin read5w1 on the same box" if cal else "gfx950 note of MI355X_MICROARCH.md; tools/pmc_mall.py measures 0.5000 raw counter bytes per byte read with 16-byte "
                             "streams, on 1 GiB and on Infinity-Cache-resident 32 MiB arrays alike: profiles/r03_mall_fetch.json") + ")"}
