@@ -140,7 +140,7 @@ adflow_bc_callback g_bc_callback = nullptr;
 adflow_bc_callback g_turb_bc_callback = nullptr;
 double* g_norm_dev = nullptr;
 int* g_floor_flag_dev = nullptr;      // raised by k_set_w_closures_level when a pressure hit its floor (FormFunction_mf)
-bool g_etot_on_flag = false;          // the next whalo2 close recomputes the owned energy only if that flag is up
+int g_etot_flag_level = 0;            // > 0: the next whalo2 close on that level recomputes the owned energy only if the floor flag is up
 
 void free_list(CommList& l)
 {
@@ -1240,11 +1240,20 @@ static int block_res_enqueue(int level, unsigned flags)
     if (kp.dissApprox && (flags & ADFLOW_RES_UPWIND_FIRST_ORDER)) kp.lumpedDiss = 1;   // blockette.F90:643
     const bool viscApprox = (flags & ADFLOW_RES_VISC_APPROX) != 0;
     int rc = 0;
+    bool etotInClosures = false;
     if (flags & ADFLOW_RES_CLOSURES) {
         // computePressureSimple / computeLamViscosity / computeEddyViscosity (blockette.F90:199-203)
         LevelTab tc;
         if (level_tab(level, &tc)) return 1;
-        launch_closures_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream);
+        // when the whalo2 of this call follows (mean-flow variables incl. the energy), the energy it would recompute on the owned
+        // cells is written by the same pass wherever the pressure kept its value (as FormFunction_mf does, kernels_nk.hip
+        // closures_body): a floored cell raises the device flag and whalo2's closing pass runs only then
+        etotInClosures = (flags & ADFLOW_RES_HALO) && (flags & ADFLOW_RES_FLOW) && g_comm.count(std::make_pair(level, 2)) > 0;
+        if (etotInClosures) {
+            if (!g_floor_flag_dev) HIPCHK(hipMalloc((void**)&g_floor_flag_dev, sizeof(int)));
+            HIPCHK(hipMemsetAsync(g_floor_flag_dev, 0, sizeof(int), g_stream));
+        }
+        launch_closures_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream, etotInClosures ? g_floor_flag_dev : nullptr);
         rc = for_level(level, [&](Block* b) {
             b->ss_valid = false;
             b->etot_consistent = false;
@@ -1266,9 +1275,13 @@ static int block_res_enqueue(int level, unsigned flags)
         if (g_comm.count(std::make_pair(level, 2))) {
             // the exchange with the halo-free tiles of the evaluation inside it, where the evaluation is the marching RANS / NS one
             int taken = 0;
-            if (block_res_split_enqueue(level, flags, kp, lStart, lEnd, &taken)) return 1;
+            const int flagLevelWas = g_etot_flag_level;
+            if (etotInClosures) g_etot_flag_level = level;
+            rc = block_res_split_enqueue(level, flags, kp, lStart, lEnd, &taken);
+            if (!rc && !taken) rc = halo_exchange_enqueue(level, lStart, lEnd, 1, 1, 2);
+            g_etot_flag_level = flagLevelWas;
+            if (rc) return 1;
             if (taken) return 0;
-            if (halo_exchange_enqueue(level, lStart, lEnd, 1, 1, 2)) return 1;
         }
     }
     phase_mark(1);
@@ -2631,7 +2644,7 @@ static int halo_exchange_close(int level, int varStart, int varEnd, int commPres
         LevelTab t;
         if (level_tab(level, &t)) return 1;
         launch_etot_owned_level(t.tab, t.n, t.nx, t.ny, t.nz, g_opts.gammaConstant, g_stream,
-                                (g_etot_on_flag && level == 1) ? g_floor_flag_dev : nullptr);
+                                (g_etot_flag_level == level) ? g_floor_flag_dev : nullptr);
     }
     for_level(level, [&](Block* b) {
         // the exchange never touches owned cells: when their rhoE was produced by
@@ -3228,14 +3241,14 @@ static int nk_core_enqueue(bool closuresDone = false)
 static int nk_residual_enqueue(const double* d_wVec, double* d_rVec)
 {
     if (set_w_dev(d_wVec, true)) return 1;
-    g_etot_on_flag = true;      // the owned energy is computeEtot(p) already wherever p kept its value (k_set_w_closures_level)
+    g_etot_flag_level = 1;      // the owned energy is computeEtot(p) already wherever p kept its value (k_set_w_closures_level)
     // setRVec rides on the kernels that complete dw (Roe march, SA march) where those run; otherwise its own pass.  Actuator
     // sources are added to dw behind the core: then the vector is taken from dw afterwards.
     g_rvec_done = 0;
     g_rvec_target = g_act.empty() ? d_rVec : nullptr;
     const int rc = nk_core_enqueue(true);
     g_rvec_target = nullptr;
-    g_etot_on_flag = false;
+    g_etot_flag_level = 0;
     if (rc) return rc;
     const int need = (g_opts.equations == ADFLOW_RANS) ? 3 : 1;
     if ((g_rvec_done & need) != need)

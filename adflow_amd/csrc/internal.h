@@ -451,7 +451,8 @@ void launch_set_w(const BlkView& b, const double* vec, double turbFloor, hipStre
 void launch_get_r(const BlkView& b, double* vec, double turbScale, double* sums, hipStream_t s);
 void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 // level-batched forms (blockIdx.z = slot * planes + plane): one launch for every block of a level
-void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s);
+void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s,
+                           int* floored = nullptr);
 void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
                                  const KParams& kp, int* floored, hipStream_t s);
 void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s);

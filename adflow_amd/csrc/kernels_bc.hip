@@ -86,6 +86,33 @@ __device__ __forceinline__ void bc_second_halo(const BlkView& b, const KParams& 
     bc_etot(b, kp, s.c0);
 }
 
+// First halo h (with its energy, computeEtot) and -- second -- the extrapolated second halo (extrapolate2ndHalo) written from
+// REGISTERS: i2 = (rho, u, v, w, p) of the first interior slab.  The kernels above this line write the first halo and read it back for
+// the energy and for the second halo (three dependent trips to memory per thread of a launch that fills an eighth of the chip); the
+// common boundary kinds of a RANS mesh (farfield, walls, extrapolation) go through here.  Same expressions, same values.
+struct BcState { double rho, u, v, w, p, rlv, rev; };
+__device__ __forceinline__ void bc_store_halos(const BlkView& b, const KParams& kp, const BcSlab& s, const BcState& h, const BcState& i2,
+                                               bool second)
+{
+    const long nb = b.nbox;
+    const double ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
+    b.w[s.c1] = h.rho; b.w[s.c1 + nb] = h.u; b.w[s.c1 + 2 * nb] = h.v; b.w[s.c1 + 3 * nb] = h.w;
+    b.p[s.c1] = h.p;
+    if (kp.viscous) b.rlv[s.c1] = h.rlv;
+    if (kp.eddyModel) b.rev[s.c1] = h.rev;
+    b.w[s.c1 + 4 * nb] = ovgm1 * h.p + 0.5 * h.rho * (h.u * h.u + h.v * h.v + h.w * h.w);
+    if (!second) return;
+    const double factor = 0.5;
+    const double r0 = fmax(factor * h.rho, 2.0 * h.rho - i2.rho);
+    const double u0 = 2.0 * h.u - i2.u, v0 = 2.0 * h.v - i2.v, w0 = 2.0 * h.w - i2.w;
+    const double p0 = fmax(factor * h.p, 2.0 * h.p - i2.p);
+    b.w[s.c0] = r0; b.w[s.c0 + nb] = u0; b.w[s.c0 + 2 * nb] = v0; b.w[s.c0 + 3 * nb] = w0;
+    b.p[s.c0] = p0;
+    if (kp.viscous) b.rlv[s.c0] = h.rlv;
+    if (kp.eddyModel) b.rev[s.c0] = h.rev;
+    b.w[s.c0 + 4 * nb] = ovgm1 * p0 + 0.5 * r0 * (u0 * u0 + v0 * v0 + w0 * w0);
+}
+
 // symmetry: layer 1 mirrors slab 2, layer 0 mirrors slab 3 (two separate passes in the reference)
 __global__ __launch_bounds__(256) void k_bc_symm(BC_ARGS, KParams kp, int second)
 {
@@ -246,33 +273,30 @@ __global__ __launch_bounds__(256) void k_bc_nswall(BC_ARGS, KParams kp, int seco
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
     const double rhok = 0.0;     // correctForK = .false. (no k equation)
-    double p1;
+    BcState i2, h;
+    i2.rho = b.w[s.c2]; i2.u = b.w[s.c2 + nb]; i2.v = b.w[s.c2 + 2 * nb]; i2.w = b.w[s.c2 + 3 * nb]; i2.p = b.p[s.c2];
     if (wallTreatment == ADFLOW_WALLBC_CONSTANT) {
-        p1 = b.p[s.c2] - 4.0 * (1.0 / 3.0) * rhok;
+        h.p = i2.p - 4.0 * (1.0 / 3.0) * rhok;
     } else {
-        p1 = 2 * b.p[s.c2] - b.p[s.c3];
-        if (p1 <= 0.0) p1 = b.p[s.c2];
+        h.p = 2 * i2.p - b.p[s.c3];
+        if (h.p <= 0.0) h.p = i2.p;
     }
-    b.p[s.c1] = p1;
     if (ISO) {
         const double tw = f.tns[s.f];
-        const double t2 = b.p[s.c2] / (kp.RGas * b.w[s.c2]);
+        const double t2 = i2.p / (kp.RGas * i2.rho);
         double t1 = 2.0 * tw - t2;
         t1 = fmax(0.5 * tw, t1);
         t1 = fmin(2.0 * tw, t1);
-        b.w[s.c1] = p1 / (kp.RGas * t1);
+        h.rho = h.p / (kp.RGas * t1);
     } else {
-        b.w[s.c1] = b.w[s.c2];
+        h.rho = i2.rho;
     }
-#pragma unroll
-    for (int l = 1; l <= 3; ++l) {
-        const double us = f.uslip ? f.uslip[s.f + (l - 1) * s.fn] : 0.0;
-        b.w[s.c1 + l * nb] = -b.w[s.c2 + l * nb] + 2.0 * us;
-    }
-    b.rlv[s.c1] = b.rlv[s.c2];
-    if (kp.eddyModel) b.rev[s.c1] = -b.rev[s.c2];
-    bc_etot(b, kp, s.c1);
-    if (second) bc_second_halo(b, kp, s);
+    const double us0 = f.uslip ? f.uslip[s.f] : 0.0, us1 = f.uslip ? f.uslip[s.f + s.fn] : 0.0, us2 = f.uslip ? f.uslip[s.f + 2 * s.fn] : 0.0;
+    h.u = -i2.u + 2.0 * us0; h.v = -i2.v + 2.0 * us1; h.w = -i2.w + 2.0 * us2;
+    h.rlv = b.rlv[s.c2];
+    h.rev = kp.eddyModel ? -b.rev[s.c2] : 0.0;
+    // (the laminar viscosity of a viscous wall's halo is stored whatever kp.viscous says: the kind exists on viscous meshes only)
+    bc_store_halos(b, kp, s, h, i2, second != 0);
 }
 
 // myDim (utils): max(x - y, 0)
@@ -379,16 +403,14 @@ __global__ __launch_bounds__(256) void k_bc_farfield(BC_ARGS, KParams kp, int se
         sf = s0;
     }
     const double cc = cf * cf / gam2;
-    const double rho1 = pow(sf * cc, ovgm1);
-    b.w[s.c1] = rho1;
-    b.w[s.c1 + nb] = uf;
-    b.w[s.c1 + 2 * nb] = vf;
-    b.w[s.c1 + 3 * nb] = wf;
-    b.p[s.c1] = rho1 * cc;
-    if (kp.viscous) b.rlv[s.c1] = b.rlv[s.c2];
-    if (kp.eddyModel) b.rev[s.c1] = b.rev[s.c2];
-    bc_etot(b, kp, s.c1);
-    if (second) bc_second_halo(b, kp, s);
+    BcState h, i2;
+    h.rho = pow(sf * cc, ovgm1);
+    h.u = uf; h.v = vf; h.w = wf;
+    h.p = h.rho * cc;
+    h.rlv = kp.viscous ? b.rlv[s.c2] : 0.0;
+    h.rev = kp.eddyModel ? b.rev[s.c2] : 0.0;
+    i2.rho = rho2; i2.u = ue; i2.v = ve; i2.w = we; i2.p = p2;
+    bc_store_halos(b, kp, s, h, i2, second != 0);
 }
 
 // extrap / supersonic outflow: fw2, fw3 = weights of slab 2 and 3
@@ -402,18 +424,16 @@ __global__ __launch_bounds__(256) void k_bc_extrap(BC_ARGS, KParams kp, int seco
     if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
     const double factor = 0.5;
-    double r = fw2 * b.w[s.c2] + fw3 * b.w[s.c3];
-    r = fmax(factor * b.w[s.c2], r);
-    b.w[s.c1] = r;
-#pragma unroll
-    for (int l = 1; l <= 3; ++l) b.w[s.c1 + l * nb] = fw2 * b.w[s.c2 + l * nb] + fw3 * b.w[s.c3 + l * nb];
-    double p1 = fw2 * b.p[s.c2] + fw3 * b.p[s.c3];
-    p1 = fmax(factor * b.p[s.c2], p1);
-    b.p[s.c1] = p1;
-    if (kp.viscous) b.rlv[s.c1] = b.rlv[s.c2];
-    if (kp.eddyModel) b.rev[s.c1] = b.rev[s.c2];
-    bc_etot(b, kp, s.c1);
-    if (second) bc_second_halo(b, kp, s);
+    BcState h, i2;
+    i2.rho = b.w[s.c2]; i2.u = b.w[s.c2 + nb]; i2.v = b.w[s.c2 + 2 * nb]; i2.w = b.w[s.c2 + 3 * nb]; i2.p = b.p[s.c2];
+    h.rho = fmax(factor * i2.rho, fw2 * i2.rho + fw3 * b.w[s.c3]);
+    h.u = fw2 * i2.u + fw3 * b.w[s.c3 + nb];
+    h.v = fw2 * i2.v + fw3 * b.w[s.c3 + 2 * nb];
+    h.w = fw2 * i2.w + fw3 * b.w[s.c3 + 3 * nb];
+    h.p = fmax(factor * i2.p, fw2 * i2.p + fw3 * b.p[s.c3]);
+    h.rlv = kp.viscous ? b.rlv[s.c2] : 0.0;
+    h.rev = kp.eddyModel ? b.rev[s.c2] : 0.0;
+    bc_store_halos(b, kp, s, h, i2, second != 0);
 }
 
 // supersonic inflow (BCRoutines.F90:1411-1477): both halo layers take the prescribed state

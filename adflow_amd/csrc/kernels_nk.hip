@@ -148,9 +148,12 @@ __global__ __launch_bounds__(NK_BX* NK_BY) void k_set_w_closures_level(const Blk
     closures_body<true>(b, (int)(blockIdx.z % nzb), kp, floored);
 }
 
-__global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_level(const BlkView* __restrict__ tab, int nzb, KParams kp)
+// ETOT: the closures of blocketteRes when its whalo2 follows (blockette.F90:199-246): the energy whalo2 would recompute on the owned
+// cells is written here, as in k_set_w_closures_level
+template <bool ETOT>
+__global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_level(const BlkView* __restrict__ tab, int nzb, KParams kp, int* __restrict__ floored)
 {
-    closures_body(tab[blockIdx.z / nzb + 1], (int)(blockIdx.z % nzb), kp);
+    closures_body<ETOT>(tab[blockIdx.z / nzb + 1], (int)(blockIdx.z % nzb), kp, floored);
 }
 
 static dim3 nk_grid(const BlkView& b) { return dim3((b.nx + NK_BX - 1) / NK_BX, (b.ny + NK_BY - 1) / NK_BY, b.nz); }
@@ -159,11 +162,15 @@ static dim3 nk_level_grid(int nslots, int maxnx, int maxny, int maxnz)
     return dim3((maxnx + NK_BX - 1) / NK_BX, (maxny + NK_BY - 1) / NK_BY, maxnz * nslots);
 }
 
-void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s)
+void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s, int* floored)
 {
-    LEVEL_SPLIT(nslots, maxnz + 4, launch_closures_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s));
+    LEVEL_SPLIT(nslots, maxnz + 4, launch_closures_level(tab + s0_, n_, maxnx, maxny, maxnz, kp, s, floored));
     if (nslots <= 0) return;
-    hipLaunchKernelGGL(k_closures_level, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp);
+    if (floored)
+        hipLaunchKernelGGL(k_closures_level<true>, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp, floored);
+    else
+        hipLaunchKernelGGL(k_closures_level<false>, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp,
+                           (int*)nullptr);
 }
 void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
                                  const KParams& kp, int* floored, hipStream_t s)

@@ -151,7 +151,7 @@ def setup_brick_with_bc(engine, topo, prm, brick_spec, seed=19, **mk):
     return blocks, rblocks, bocos, prm
 
 
-def check_blockette_res_with_bc(engine, topo, prm, brick_spec, seed=19, split_eval=None, **mk):
+def check_blockette_res_with_bc(engine, topo, prm, brick_spec, seed=19, split_eval=None, floor_p=False, **mk):
     """The reference's WHOLE blocketteRes (blockette.F90:199-283, default flags, storeWall = T) on a wall-bounded mesh, as ONE
     library call (ADFLOW_RES_CLOSURES | HALO | FLOW | TURB): derived values of the owned cells, turbulence + mean-flow boundary
     conditions of every subface, whalo2 over the 1-to-1 interfaces, blocketteResCore; compared: dw of every block and
@@ -164,6 +164,13 @@ def check_blockette_res_with_bc(engine, topo, prm, brick_spec, seed=19, split_ev
         b, r = blocks[nn], rblocks[nn]
         sl = (slice(2, b.il + 1), slice(2, b.jl + 1), slice(2, b.kl + 1))
         b["w"][sl] *= rng.uniform(0.97, 1.03, b["w"][sl].shape)       # owned cells only: closures and halos are now stale
+        if floor_p:
+            # some owned cells carry less energy than their kinetic energy: computePressureSimple floors their pressure, whalo2 hands
+            # the OLD energy to the neighbours' halos and recomputes the owned one from the floored pressure (haloExchange.F90:178-196)
+            wo = b["w"][sl]
+            sel = rng.uniform(0, 1, wo.shape[:3]) < 0.02
+            wo[sel, 4] = 0.4 * wo[sel, 0] * (wo[sel, 1] ** 2 + wo[sel, 2] ** 2 + wo[sel, 3] ** 2)
+            b["w"][sl] = wo
         r["w"][...] = b["w"]
         engine.upload_state(nn, 1)
     for nn in sorted(rblocks):

@@ -79,6 +79,9 @@ def test_blockette_res_wall_bounded_brick(engine):
     # laminar NS, one block with six physical faces
     checks.check_blockette_res_with_bc(engine, BrickTopology(1, 1, 1, 12, 8, 6, periodic=open3), FlowParams(equations=NSEquations), spec, seed=9,
                                        stretch_k=2.0)
+    # pressures at their floor: the energy whalo2 recomputes is written by the closures pass except in those cells
+    checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 2, 10, 7, 6, periodic=open3), FlowParams(equations=NSEquations), WALL_BRICK,
+                                       seed=11, floor_p=True, stretch_k=2.0)
 
 
 def test_north_star_block_with_six_physical_faces(engine):
