@@ -65,20 +65,25 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned(BlkView b, double g
 
 // onlyIf: the pass runs only when *onlyIf != 0 (the matrix-free residual: k_set_w_closures_level has rewritten the energy already unless a
 // pressure hit its floor)
+// KCOL: a workgroup walks the planes of its 64 x 4 column (1 / nz of the workgroups: the launch that only finds the flag down costs
+// the dispatch of a few hundred workgroups instead of tens of thousands)
+template <bool KCOL>
 __global__ __launch_bounds__(SM_BX* SM_BY) void k_etot_owned_level(const BlkView* __restrict__ tab, int nzb, double gammaConstant,
                                                                    const int* __restrict__ onlyIf)
 {
     if (onlyIf && *onlyIf == 0) return;
-    const BlkView& b = tab[blockIdx.z / nzb + 1];
+    const BlkView& b = tab[(KCOL ? blockIdx.z : blockIdx.z / nzb) + 1];
     const int i = blockIdx.x * SM_BX + threadIdx.x + 2;
     const int j = blockIdx.y * SM_BY + threadIdx.y + 2;
-    const int k = blockIdx.z % nzb + 2;
-    if (i > b.il || j > b.jl || k > b.kl) return;
-    const long c = b.idx(i, j, k);
+    if (i > b.il || j > b.jl) return;
+    const int k0 = KCOL ? 2 : (int)(blockIdx.z % nzb) + 2, k1 = KCOL ? b.kl : k0;
     const long nb = b.nbox;
     const double ovgm1 = 1.0 / (gammaConstant - 1.0);
-    const double u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
-    b.w[c + 4 * nb] = ovgm1 * b.p[c] + 0.5 * b.w[c] * (u * u + v * v + w * w);
+    for (int k = k0; k <= k1 && k <= b.kl; ++k) {
+        const long c = b.idx(i, j, k);
+        const double u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+        b.w[c + 4 * nb] = ovgm1 * b.p[c] + 0.5 * b.w[c] * (u * u + v * v + w * w);
+    }
 }
 
 void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, double gammaConstant, hipStream_t s,
@@ -86,8 +91,14 @@ void launch_etot_owned_level(const BlkView* tab, int nslots, int maxnx, int maxn
 {
     LEVEL_SPLIT(nslots, maxnz + 4, launch_etot_owned_level(tab + s0_, n_, maxnx, maxny, maxnz, gammaConstant, s, onlyIf));
     if (nslots <= 0) return;
-    hipLaunchKernelGGL(k_etot_owned_level, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, gammaConstant,
-                       onlyIf);
+    if (onlyIf) {
+        // (the rare case: it runs only when a pressure hit its floor)
+        const dim3 g((maxnx + SM_BX - 1) / SM_BX, (maxny + SM_BY - 1) / SM_BY, nslots);
+        hipLaunchKernelGGL(k_etot_owned_level<true>, g, dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, gammaConstant, onlyIf);
+        return;
+    }
+    hipLaunchKernelGGL(k_etot_owned_level<false>, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz,
+                       gammaConstant, onlyIf);
 }
 
 void launch_etot_owned(const BlkView& b, double gammaConstant, hipStream_t s)
