@@ -213,9 +213,17 @@ def cpu_baseline(equations, spaceDiscr, seconds=8.0, max_cores=None, dims=(64, 6
         fast = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), cores, dims, "blockette", True)
         if fast:
             out["fast_math"] = {"value": sum(fast) / 1e6, "cores": len(fast), "flags": "-O3 -ffast-math (oracle/refbuild/Makefile FAST=1)"}
-    plain = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), cores, dims, "block", False)
-    if plain:
-        out["blockResCore_twin"] = {"value": sum(plain) / 1e6, "cores": len(plain), "what": "blockette.F90:755-852 (the figure of rounds 1-2)"}
+    if cores > 32:
+        # the evaluation is bound by the host's memory bandwidth: fewer processes can deliver more.  The 32-process figure of round 3
+        # beside the all-core one; `value` stays the all-core run the task asks for, `best` names the larger of the two
+        sub = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), 32, dims, "blockette", False)
+        if sub:
+            out["cores_32"] = {"value": sum(sub) / 1e6, "cores": len(sub)}
+            out["best"] = max(out["value"], out["cores_32"]["value"])
+    else:
+        plain = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), cores, dims, "block", False)
+        if plain:
+            out["blockResCore_twin"] = {"value": sum(plain) / 1e6, "cores": len(plain), "what": "blockette.F90:755-852 (the figure of rounds 1-2)"}
     return out
 
 
