@@ -3443,6 +3443,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         for (auto& kv : g_comm) drop_comm_lists(kv.second);        // rebuilt at the next exchange
         return 0;
     }
+    if (!strcmp(key, "dadi_pcr")) { g_dadi_pcr = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_cus")) {
         // tests: the round size on a device with `value` CUs (0 = ask the device; -1 = chunks of march_kch planes, no fitting)
         g_gf_nofit = (value < 0);

@@ -1136,6 +1136,111 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_dadi_post_i(const BlkView* __r
 }
 
 
+// ---------------------------------------------------------------------------
+// Round 4: the i direction of D-ADI as PARALLEL CYCLIC REDUCTION along the lanes.  The three pieces above move every value four
+// times through transposing tiles (counted: rows 221 + solve 557 B per cell and sub-iteration, profiles/r04_e_config3_pmc_bytes.md).
+// An i line lies along the lanes: a workgroup of NW wavefronts holds one whole line (nx <= 64 NW cells), every thread forms the
+// tridiagonal rows of ITS cell from coalesced loads (dadi_cell<0>; the neighbours' terms through LDS), and the three coefficient sets
+// with their five right-hand sides are reduced in ceil(log2 nx) steps, all lanes busy: step s eliminates the unknowns at distance s,
+//   alpha = -a_i, gamma = -c_i (rows kept normalised: b = 1),  b' = 1 + alpha c_(i-s) + gamma a_(i+s),
+//   a' = alpha a_(i-s) / b',  c' = gamma c_(i+s) / b',  d' = (d + alpha d_(i-s) + gamma d_(i+s)) / b'
+// until every row stands alone (x = d).  The rows are diagonally dominant (cc = 1 + positive terms), so the reduction is as stable as
+// the Thomas recurrence of the reference (residuals.F90:1750-1783); results agree to rounding.  The transform that follows the
+// i-solve (T_zeta^-1 T_xi, residuals.F90:1540-1583) is applied before the store: the k sweep loads a finished update.
+// One read of dw + the cell data, one write of dw; no scratch arrays.  A workgroup walks PI_JL consecutive j lines of one k plane.
+// ---------------------------------------------------------------------------
+#define PI_JL 8
+#define PI_NC 11          // components in LDS per cell and buffer: a(3), c(3), d(5)
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_dadi_i_pcr(const BlkView* __restrict__ tab, KParams kp)
+{
+    constexpr int T = 64 * NW;
+    __shared__ double P[2 * PI_NC * T];
+    const BlkView& b = tab[blockIdx.z + 1];
+    const int t = threadIdx.x, n = b.nx;
+    const int k = blockIdx.y + 2;
+    const int j0 = blockIdx.x * PI_JL + 2;
+    if (b.nx == 0 || k > b.kl || j0 > b.jl || n > T) return;        // uniform per workgroup
+    const bool act = t < n;
+    const int tc = act ? t : n - 1;                                  // inactive threads repeat the last cell (loads stay inside the box)
+    const long nb = b.nbox;
+    static const int grp[5] = {0, 0, 0, 1, 2};
+    double* __restrict__ X = P + PI_NC * T;                          // the neighbour exchange lives in buffer 1 (free until step 2)
+    for (int jl_ = 0; jl_ < PI_JL; ++jl_) {
+        const int j = j0 + jl_;
+        if (j > b.jl) break;                                         // uniform
+        const long c = b.idx(2 + tc, j, k);
+        double d[5];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) d[l] = b.dw[c + l * nb];
+        double a[3], cc[3];
+        if (n > 1) {
+            DadiCell cur;
+            dadi_cell<0>(b, kp, c, 1, b.sI, cur);
+            // (vt1, dP) go to the row above (cell i+1 reads its lower neighbour), (vt3, dM) to the row below
+            X[0 * T + t] = cur.vt1; X[1 * T + t] = cur.dP[0]; X[2 * T + t] = cur.dP[1]; X[3 * T + t] = cur.dP[2];
+            X[4 * T + t] = cur.vt3; X[5 * T + t] = cur.dM[0]; X[6 * T + t] = cur.dM[1]; X[7 * T + t] = cur.dM[2];
+            __syncthreads();
+            const int tm = (t > 0) ? t - 1 : 0, tp = (t < T - 1) ? t + 1 : T - 1;
+            const double pvt1 = X[0 * T + tm], nvt3 = X[4 * T + tp];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const double bbv = (t > 0) ? (-pvt1 - X[(1 + g) * T + tm]) * cur.ddt : 0.0;
+                const double ddv = (t < n - 1) ? (-nvt3 + X[(5 + g) * T + tp]) * cur.ddt : 0.0;
+                const double ccv = 1.0 + (cur.vt1 + cur.vt3 + cur.dP[g] - cur.dM[g]) * cur.ddt;
+                const double inv = act ? rcp_nr(ccv) : 0.0;
+                a[g] = bbv * inv; cc[g] = ddv * inv;                 // inactive threads: the identity row (a = c = 0, d = 0)
+#pragma unroll
+                for (int l = 0; l < 5; ++l)
+                    if (grp[l] == g) d[l] = act ? d[l] * inv : 0.0;
+            }
+            int cur_ = 0;
+            for (int st = 1; st < n; st <<= 1) {
+                double* __restrict__ Q = P + cur_ * PI_NC * T;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) { Q[g * T + t] = a[g]; Q[(3 + g) * T + t] = cc[g]; }
+#pragma unroll
+                for (int l = 0; l < 5; ++l) Q[(6 + l) * T + t] = d[l];
+                __syncthreads();
+                const bool lo = t >= st, hi = t + st < n;
+                const int im = lo ? t - st : t, ip = hi ? t + st : t;
+                double al[3], ga[3], inv[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const double am = lo ? Q[g * T + im] : 0.0, cm = lo ? Q[(3 + g) * T + im] : 0.0;
+                    const double ap = hi ? Q[g * T + ip] : 0.0, cp = hi ? Q[(3 + g) * T + ip] : 0.0;
+                    al[g] = -a[g]; ga[g] = -cc[g];
+                    inv[g] = rcp_nr(1.0 + al[g] * cm + ga[g] * ap);
+                    a[g] = al[g] * am * inv[g];
+                    cc[g] = ga[g] * cp * inv[g];
+                }
+#pragma unroll
+                for (int l = 0; l < 5; ++l) {
+                    const int g = grp[l];
+                    const double dm = lo ? Q[(6 + l) * T + im] : 0.0, dp = hi ? Q[(6 + l) * T + ip] : 0.0;
+                    d[l] = (d[l] + al[g] * dm + ga[g] * dp) * inv[g];
+                }
+                cur_ ^= 1;
+            }
+        }
+        if (act) {
+            dadi_post_i(b, c, d);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
+        }
+        __syncthreads();                                             // the next line's exchange reuses buffer 1
+    }
+}
+
+template <int NW>
+static void launch_dadi_i_pcr(const BlkView* tab, int nslots, int ny, int nz, const KParams& kp, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_dadi_i_pcr<NW>), dim3((ny + PI_JL - 1) / PI_JL, nz, nslots), dim3(64 * NW, 1, 1), 0, s, tab, kp);
+}
+
+int g_dadi_pcr = 1;      // tuning "dadi_pcr": the i direction of D-ADI by cyclic reduction along the lanes (0: rows + tiled Thomas)
+
 // computedwDADI incl. the -cfl*dtl*vol scaling of executeDADIStep
 void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
 {
@@ -1143,6 +1248,15 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
     if (nslots <= 0) return;
     dim3 blk(64, 1, 1);
     hipLaunchKernelGGL((k_dadi_sweep<1>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
+    if (g_dadi_pcr && nx <= 256) {
+        // i direction: cyclic reduction along the lanes with its transform applied (k_dadi_i_pcr); nx = the widest block of the level
+        if (nx <= 64) launch_dadi_i_pcr<1>(tab, nslots, ny, nz, kp, s);
+        else if (nx <= 128) launch_dadi_i_pcr<2>(tab, nslots, ny, nz, kp, s);
+        else if (nx <= 192) launch_dadi_i_pcr<3>(tab, nslots, ny, nz, kp, s);
+        else launch_dadi_i_pcr<4>(tab, nslots, ny, nz, kp, s);
+        hipLaunchKernelGGL((k_dadi_sweep<2, false>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+        return;
+    }
     // i direction: rows pointwise, Thomas per (line, equation) through LDS tiles; the transform behind the i-solve is applied
     // by the k sweep as it loads the update
     if (nx > 1) {

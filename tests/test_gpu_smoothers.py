@@ -108,6 +108,20 @@ def test_rk_smoother_with_residual_averaging_config_1_size_block(engine):
     checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 128, 128, 128), FlowParams(resAveraging=alternateResAveraging))
 
 
+def test_dadi_i_direction_by_cyclic_reduction(engine):
+    """k_dadi_i_pcr: i lines of 70 / 130 / 200 cells (workgroups of 2 / 3 / 4 wavefronts, reduction steps across the wavefronts), a
+    9-cell line, one-cell lines; tuning dadi_pcr = 0 (rows + tiled Thomas: the form for lines beyond 256 cells) on the same case"""
+    prm = FlowParams(equations=RANSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2)
+    for nx, ny, nz in ((70, 5, 4), (130, 9, 3), (200, 3, 5), (9, 8, 7)):
+        checks.check_dadi_smoother(engine, BrickTopology(1, 1, 1, nx, ny, nz), prm, stretch_k=2.0)
+    checks.check_dadi_smoother(engine, BrickTopology(1, 2, 1, 1, 6, 5), FlowParams(resAveraging=noResAveraging, cfl=1.5, nSubiterations=2))
+    try:
+        engine.set_tuning("dadi_pcr", 0)
+        checks.check_dadi_smoother(engine, BrickTopology(1, 1, 1, 130, 9, 3), prm, stretch_k=2.0)
+    finally:
+        engine.set_tuning("dadi_pcr", 1)
+
+
 def test_dadi_degenerate_lines(engine):
     prm = FlowParams(equations=NSEquations, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2)
     checks.check_dadi_smoother(engine, BrickTopology(1, 1, 2, 5, 1, 4), prm, stretch_k=2.0)

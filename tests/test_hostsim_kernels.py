@@ -376,6 +376,11 @@ def test_multiblock_brick_block_res(hostsim_engine):
     checks.check_brick_block_res(hostsim_engine, BrickTopology(2, 1, 2, 10, 7, 6), prm, seed=3, stretch_k=2.0)
 
 
+def test_dadi_i_direction_by_cyclic_reduction(hostsim_engine):
+    import test_gpu_smoothers
+    test_gpu_smoothers.test_dadi_i_direction_by_cyclic_reduction(hostsim_engine)
+
+
 def test_blockette_res_wall_bounded_brick(hostsim_engine):
     import test_gpu_rans
     test_gpu_rans.test_blockette_res_wall_bounded_brick(hostsim_engine)

@@ -1,3 +1,2 @@
-export GIT=9d6a08e TAG=r04_d
-bash tools/_gpu_job_full.sh
-bash tools/_gpu_job_sq.sh
+export GIT=5983536 TAG=r04_e EXTRAS="config3 config2 matvec small"
+bash tools/_gpu_job_pmc_extras.sh
