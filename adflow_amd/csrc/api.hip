@@ -140,6 +140,7 @@ adflow_bc_callback g_bc_callback = nullptr;
 adflow_bc_callback g_turb_bc_callback = nullptr;
 double* g_norm_dev = nullptr;
 int* g_floor_flag_dev = nullptr;      // raised by k_set_w_closures_level when a pressure hit its floor (FormFunction_mf)
+int g_dadi_upd = 1;                  // tuning "dadi_upd": the D-ADI state update inside the k sweep's back substitution
 int g_etot_flag_level = 0;            // > 0: the next whalo2 close on that level recomputes the owned energy only if the floor flag is up
 
 void free_list(CommList& l)
@@ -2753,11 +2754,12 @@ int adflow_gpu_halo_exchange(int level, int varStart, int varEnd, int commPressu
 // ----------------------------------------------------------------- smoothers
 // one stage of either smoother after dw holds the scaled update: state update,
 // boundary-condition hook, halo exchange (smoothers.F90:292-380, 600-691)
-static int finish_stage(int level, const KParams& kp, double scale, int fromWn)
+// updated: the state update ran inside the kernel that completed the increment (D-ADI k sweep)
+static int finish_stage(int level, const KParams& kp, double scale, int fromWn, bool updated = false)
 {
     LevelTab t;
     if (level_tab(level, &t)) return 1;
-    launch_stage_update_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, scale, fromWn, g_stream);
+    if (!updated) launch_stage_update_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, scale, fromWn, g_stream);
     int rc = for_level(level, [&](Block* b) {
         b->ss_valid = false;
         b->etot_consistent = true;
@@ -2820,9 +2822,10 @@ int adflow_gpu_dadi_smooth(int level)
         KParams kp = make_kparams(level, 1.0, 0);
         LevelTab t;
         if (level_tab(level, &t)) return 1;
-        launch_dadi_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        const bool fuseUpd = !smooth_residual(0) && g_dadi_upd;               // (tuning "dadi_upd")
+        launch_dadi_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, g_stream, fuseUpd);
         if (smooth_residual(0) && res_averaging_level(level, kp)) return 1;   // rkStage stays 0 under DADI
-        if (finish_stage(level, kp, 0.0, 0)) return 1;
+        if (finish_stage(level, kp, 0.0, 0, fuseUpd)) return 1;
         if (it < nsub) {
             if (enqueue_flow_residual(level, kp)) return 1;
         }
@@ -3444,6 +3447,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         return 0;
     }
     if (!strcmp(key, "dadi_pcr")) { g_dadi_pcr = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "dadi_upd")) { g_dadi_upd = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_cus")) {
         // tests: the round size on a device with `value` CUs (0 = ask the device; -1 = chunks of march_kch planes, no fitting)
         g_gf_nofit = (value < 0);

@@ -428,7 +428,7 @@ void launch_stage_update_level(const BlkView* tab, int nslots, int maxnx, int ma
                                int fromWn, hipStream_t s);
 void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s,
                                 double scaleDtl = 0.0);
-void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, bool withUpdate = false);
 void launch_halo_copy(const BlkView* tab, const int* donorBlk, const long* donorOff, const int* haloBlk, const long* haloOff,
                       int n, unsigned mask, hipStream_t s);
 void launch_periodic(const BlkView* tab, const int* blk, const long* off, int n, const double rotMatrix[9], const double rotCenter[3],

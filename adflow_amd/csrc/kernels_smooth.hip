@@ -210,6 +210,50 @@ void launch_low_speed_precond_level(const BlkView* tab, int nslots, int maxnx, i
     hipLaunchKernelGGL(k_low_speed_precond, level_grid(nslots, maxnx, maxny, maxnz), dim3(SM_BX, SM_BY, 1), 0, s, tab, maxnz, uInf2);
 }
 
+// The update of one cell from its increment d (executeRkStage / executeDADIStep, smoothers.F90:292-380, 600-691): the pressure
+// increment from the conservative ones, density and pressure floors, computeEtotBlock, Sutherland, SA eddy viscosity.
+// (rho0 .. p0): the state the increment was linearised at; (rhoB .. pB): the state it is subtracted from.
+__device__ __forceinline__ void stage_update_cell(const BlkView& b, const KParams& kp, long c, const double d[5], double rho0, double u0,
+                                                  double v0, double w0, double e0, double p0, double rhoB, double uB, double vB, double wB,
+                                                  double pB)
+{
+    const long nb = b.nbox;
+    const double gm1 = kp.gammaConstant - 1.0;      // cpConstant, the only cp model of the path: gamma(i,j,k) = gammaConstant
+    double ovr = rcp_nr(rho0);      // (reciprocals and the square root as v_rcp / v_rsq + one Newton step, internal.h)
+    const double v2 = u0 * u0 + v0 * v0 + w0 * w0;
+    const double dp = (ovr * p0 - gm1 * (ovr * e0 - v2)) * d[0] + gm1 * (d[4] - u0 * d[1] - v0 * d[2] - w0 * d[3]);
+    const double ru = rhoB * uB - d[1], rv = rhoB * vB - d[2], rw = rhoB * wB - d[3];
+    double rho = rhoB - d[0];
+    rho = fmax(rho, 1.e-4 * kp.rhoInf);
+    ovr = rcp_nr(rho);
+    const double u = ovr * ru, v = ovr * rv, w = ovr * rw;
+    double p = pB - dp;
+    p = fmax(p, 1.e-4 * kp.pInfCorr);
+    b.w[c] = rho;
+    b.w[c + nb] = u;
+    b.w[c + 2 * nb] = v;
+    b.w[c + 3 * nb] = w;
+    b.p[c] = p;
+    // computeEtotBlock, cpConstant
+    const double ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
+    b.w[c + 4 * nb] = ovgm1 * p + 0.5 * rho * (u * u + v * v + w * w);
+    if (kp.viscous) {
+        // computeLamViscosity (Sutherland)
+        const double muSuth = kp.muSuthDim / kp.muRef, TSuth = kp.TSuthDim / kp.TRef, SSuth = kp.SSuthDim / kp.TRef;
+        const double T = p * ovr * (1.0 / kp.RGas);
+        const double tt = T * (1.0 / TSuth);
+        const double rlv = muSuth * ((TSuth + SSuth) * rcp_nr(T + SSuth)) * (tt * fastsqrt(tt));
+        b.rlv[c] = rlv;
+        if (kp.eddyModel && kp.updateEddy) {
+            const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
+            const double rnuSA = b.w[c + 5 * nb] * rho;
+            const double chi = rnuSA * rcp_nr(rlv);
+            const double chi3 = chi * chi * chi;
+            b.rev[c] = chi3 * rcp_nr(chi3 + cv13) * rnuSA;
+        }
+    }
+}
+
 // State update of one stage.  FROM_WN: Runge-Kutta (new = stage-0 state - dw),
 // otherwise D-ADI (new = current - dw).  scale != 0: dw is first multiplied by
 // scale*dtl (fused k_scale_dw when no residual averaging sits in between).
@@ -231,48 +275,15 @@ __global__ __launch_bounds__(SM_BX* SM_BY) void k_stage_update(const BlkView* __
 #pragma unroll
         for (int l = 0; l < 5; ++l) d[l] *= dt;
     }
-    const double gm1 = kp.gammaConstant - 1.0;      // cpConstant, the only cp model of the path: gamma(i,j,k) = gammaConstant
     const double rho0 = b.w[c], u0 = b.w[c + nb], v0 = b.w[c + 2 * nb], w0 = b.w[c + 3 * nb], e0 = b.w[c + 4 * nb];
     const double p0 = b.p[c];
-    double ovr = 1.0 / rho0;
-    const double v2 = u0 * u0 + v0 * v0 + w0 * w0;
-    const double dp = (ovr * p0 - gm1 * (ovr * e0 - v2)) * d[0] + gm1 * (d[4] - u0 * d[1] - v0 * d[2] - w0 * d[3]);
     double rhoB, uB, vB, wB, pB;
     if (FROM_WN) {
         rhoB = b.wn[c]; uB = b.wn[c + nb]; vB = b.wn[c + 2 * nb]; wB = b.wn[c + 3 * nb]; pB = b.pn[c];
     } else {
         rhoB = rho0; uB = u0; vB = v0; wB = w0; pB = p0;
     }
-    const double ru = rhoB * uB - d[1], rv = rhoB * vB - d[2], rw = rhoB * wB - d[3];
-    double rho = rhoB - d[0];
-    rho = fmax(rho, 1.e-4 * kp.rhoInf);
-    ovr = 1.0 / rho;
-    const double u = ovr * ru, v = ovr * rv, w = ovr * rw;
-    double p = pB - dp;
-    p = fmax(p, 1.e-4 * kp.pInfCorr);
-    b.w[c] = rho;
-    b.w[c + nb] = u;
-    b.w[c + 2 * nb] = v;
-    b.w[c + 3 * nb] = w;
-    b.p[c] = p;
-    // computeEtotBlock, cpConstant
-    const double ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
-    b.w[c + 4 * nb] = ovgm1 * p + 0.5 * rho * (u * u + v * v + w * w);
-    if (kp.viscous) {
-        // computeLamViscosity (Sutherland)
-        const double muSuth = kp.muSuthDim / kp.muRef, TSuth = kp.TSuthDim / kp.TRef, SSuth = kp.SSuthDim / kp.TRef;
-        const double T = p / (kp.RGas * rho);
-        const double tt = T / TSuth;
-        const double rlv = muSuth * ((TSuth + SSuth) / (T + SSuth)) * (tt * sqrt(tt));
-        b.rlv[c] = rlv;
-        if (kp.eddyModel && kp.updateEddy) {
-            const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
-            const double rnuSA = b.w[c + 5 * nb] * rho;
-            const double chi = rnuSA / rlv;
-            const double chi3 = chi * chi * chi;
-            b.rev[c] = chi3 / (chi3 + cv13) * rnuSA;
-        }
-    }
+    stage_update_cell(b, kp, c, d, rho0, u0, v0, w0, e0, p0, rhoB, uB, vB, wB, pB);
 }
 
 void launch_stage_update_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, double scale,
@@ -683,58 +694,98 @@ struct DadiCell {          // per-cell coefficients of one direction
     double ddt;            // dual_dt * max(iblank,0)
 };
 
-// DIR: 0 = i, 1 = j, 2 = k.  Coefficients of cell c (residuals.F90:1349-1376 for j)
+// DIR: 0 = i, 1 = j, 2 = k.  Coefficients of cell c (residuals.F90:1349-1376 for j), in two halves so that a marching thread can
+// REQUEST the values of a cell one step before it forms the coefficients (round 4: the sweeps waited for these loads in every step)
+struct DadiRaw {
+    double vol, volP, volM, rho, u, v, w, p, n0[3], nm[3], mk[3], rlv[3], rev[3], dtl, qs;
+    int flag;
+};
+
 template <int DIR>
-__device__ __forceinline__ void dadi_cell(const BlkView& b, const KParams& kp, long c, long s, const double* __restrict__ sN,
-                                          DadiCell& o)
+__device__ __forceinline__ void dadi_load(const BlkView& b, const KParams& kp, long c, long s, const double* __restrict__ sN, DadiRaw& r)
 {
     const long nb = b.nbox;
-    const double vol = b.vol[c], rho = b.w[c];
-    const double u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
-    const double volhalf = 0.5 / vol;
-    // mean normal of the two faces (velocity part)
-    const double r1 = volhalf * (sN[c] + sN[c - s]);
-    const double r2 = volhalf * (sN[c + nb] + sN[c - s + nb]);
-    const double r3 = volhalf * (sN[c + 2 * nb] + sN[c - s + 2 * nb]);
+    r.vol = b.vol[c]; r.rho = b.w[c];
+    r.u = b.w[c + nb]; r.v = b.w[c + 2 * nb]; r.w = b.w[c + 3 * nb];
+    r.p = b.p[c];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { r.n0[q] = sN[c + q * nb]; r.nm[q] = sN[c - s + q * nb]; }
     // grid velocity of a moving block (residuals.F90:1192-1196)
-    double qs = 0.0;
-    if (b.sFace) qs = (b.sFace[c - s + DIR * nb] + b.sFace[c + DIR * nb]) * volhalf;     // uniform branch
+    r.qs = 0.0;
+    if (b.sFace) r.qs = b.sFace[c - s + DIR * nb] + b.sFace[c + DIR * nb];     // uniform branch
+    if (DIR == 2) {
+        // metric used in eps2: the k-direction mixes sK(k) with sJ(k-1) in the reference (residuals.F90:1625-1627): reproduced
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r.mk[q] = b.sJ[c - s + q * nb];
+    }
+    if (kp.viscous) {
+        r.rlv[0] = b.rlv[c - s]; r.rlv[1] = b.rlv[c]; r.rlv[2] = b.rlv[c + s];
+        if (kp.eddyModel) { r.rev[0] = b.rev[c - s]; r.rev[1] = b.rev[c]; r.rev[2] = b.rev[c + s]; }
+        r.volP = b.vol[c + s]; r.volM = b.vol[c - s];
+    }
+    r.dtl = b.dtl[c];
+    r.flag = b.flags[c];
+}
+
+template <int DIR>
+__device__ __forceinline__ void dadi_coef(const KParams& kp, const DadiRaw& r, DadiCell& o)
+{
+    // divisions and square roots as v_rcp / v_rsq + one Newton step (internal.h: 2e-15 relative): with one wavefront per SIMD the
+    // sweeps are bound by the ~1200 instructions of a step, two thirds of them the compiler's IEEE division / sqrt sequences
+    const double vol = r.vol, rho = r.rho, u = r.u, v = r.v, w = r.w;
+    const double ovol = rcp_nr(vol), orho = rcp_nr(rho);
+    const double volhalf = 0.5 * ovol;
+    // mean normal of the two faces (velocity part)
+    const double r1 = volhalf * (r.n0[0] + r.nm[0]);
+    const double r2 = volhalf * (r.n0[1] + r.nm[1]);
+    const double r3 = volhalf * (r.n0[2] + r.nm[2]);
+    const double qs = r.qs * volhalf;
     const double qq = r1 * u + r2 * v + r3 * w - qs;
-    const double cijk = sqrt(kp.gammaConstant * b.p[c] / rho);      // (calorically perfect gas: gamma(i,j,k) = gammaConstant, as the marching kernels)
-    const double cc = cijk * sqrt(r1 * r1 + r2 * r2 + r3 * r3);
-    // metric used in eps2: the k-direction mixes sK(k) with sJ(k-1) in the
-    // reference (residuals.F90:1625-1627) and that is reproduced here
+    const double cijk = fastsqrt(kp.gammaConstant * r.p * orho);      // (calorically perfect gas: gamma(i,j,k) = gammaConstant, as the marching kernels)
+    const double cc = cijk * fastsqrt(r1 * r1 + r2 * r2 + r3 * r3);
     double m1 = r1, m2 = r2, m3 = r3;
     if (DIR == 2) {
-        m1 = volhalf * (b.sK[c] + b.sJ[c - s]);
-        m2 = volhalf * (b.sK[c + nb] + b.sJ[c - s + nb]);
-        m3 = volhalf * (b.sK[c + 2 * nb] + b.sJ[c - s + 2 * nb]);
+        m1 = volhalf * (r.n0[0] + r.mk[0]);
+        m2 = volhalf * (r.n0[1] + r.mk[1]);
+        m3 = volhalf * (r.n0[2] + r.mk[2]);
     }
     const double epsval = 0.08, fac = 1.05;
     const double cInf2 = kp.gammaInf * kp.pInf / kp.rhoInf;
     const double eps2 = epsval * epsval * cInf2 * (m1 * m1 + m2 * m2 + m3 * m3);
-    o.dP[0] = 0.5 * (qq + fac * sqrt(qq * qq + eps2));
-    o.dP[1] = 0.5 * (qq + cc + fac * sqrt((qq + cc) * (qq + cc) + eps2));
-    o.dP[2] = 0.5 * (qq - cc + fac * sqrt((qq - cc) * (qq - cc) + eps2));
-    o.dM[0] = 0.5 * (qq - fac * sqrt(qq * qq + eps2));
-    o.dM[1] = 0.5 * (qq + cc - fac * sqrt((qq + cc) * (qq + cc) + eps2));
-    o.dM[2] = 0.5 * (qq - cc - fac * sqrt((qq - cc) * (qq - cc) + eps2));
+    const double s0 = fac * fastsqrt(qq * qq + eps2), s1 = fac * fastsqrt((qq + cc) * (qq + cc) + eps2),
+                 s2 = fac * fastsqrt((qq - cc) * (qq - cc) + eps2);
+    o.dP[0] = 0.5 * (qq + s0);
+    o.dP[1] = 0.5 * (qq + cc + s1);
+    o.dP[2] = 0.5 * (qq - cc + s2);
+    o.dM[0] = 0.5 * (qq - s0);
+    o.dM[1] = 0.5 * (qq + cc - s1);
+    o.dM[2] = 0.5 * (qq - cc - s2);
     // viscous terms: metterm(face) = |S|^2 * mut / (vol_m + vol_m+1)
     double mtP = 0.0, mtM = 0.0;
     if (kp.viscous) {
-        double mutP = b.rlv[c] + b.rlv[c + s], mutM = b.rlv[c - s] + b.rlv[c];
+        double mutP = r.rlv[1] + r.rlv[2], mutM = r.rlv[0] + r.rlv[1];
         if (kp.eddyModel) {
-            mutP += b.rev[c] + b.rev[c + s];
-            mutM += b.rev[c - s] + b.rev[c];
+            mutP += r.rev[1] + r.rev[2];
+            mutM += r.rev[0] + r.rev[1];
         }
-        const double sp = sN[c] * sN[c] + sN[c + nb] * sN[c + nb] + sN[c + 2 * nb] * sN[c + 2 * nb];
-        const double sm = sN[c - s] * sN[c - s] + sN[c - s + nb] * sN[c - s + nb] + sN[c - s + 2 * nb] * sN[c - s + 2 * nb];
-        mtP = sp * mutP * (1.0 / (vol + b.vol[c + s]));
-        mtM = sm * mutM * (1.0 / (b.vol[c - s] + vol));
+        const double sp = r.n0[0] * r.n0[0] + r.n0[1] * r.n0[1] + r.n0[2] * r.n0[2];
+        const double sm = r.nm[0] * r.nm[0] + r.nm[1] * r.nm[1] + r.nm[2] * r.nm[2];
+        mtP = sp * mutP * rcp_nr(vol + r.volP);
+        mtM = sm * mutM * rcp_nr(r.volM + vol);
     }
-    o.vt1 = mtP / vol / rho;
-    o.vt3 = mtM / vol / rho;
-    o.ddt = kp.cfl * b.dtl[c] * vol * flg_blank(b.flags[c]);
+    const double ovr = ovol * orho;
+    o.vt1 = mtP * ovr;
+    o.vt3 = mtM * ovr;
+    o.ddt = kp.cfl * r.dtl * vol * flg_blank((uint8_t)r.flag);
+}
+
+template <int DIR>
+__device__ __forceinline__ void dadi_cell(const BlkView& b, const KParams& kp, long c, long s, const double* __restrict__ sN,
+                                          DadiCell& o)
+{
+    DadiRaw r;
+    dadi_load<DIR>(b, kp, c, s, sN, r);
+    dadi_coef<DIR>(kp, r, o);
 }
 
 // T_eta^-1 applied to the physical update (residuals.F90:1276-1331)
@@ -791,8 +842,8 @@ __device__ __forceinline__ void unit_mean_normal(const double* __restrict__ sN, 
     r[0] = 0.5 * (sN[c] + sN[c - s]);
     r[1] = 0.5 * (sN[c + nb] + sN[c - s + nb]);
     r[2] = 0.5 * (sN[c + 2 * nb] + sN[c - s + 2 * nb]);
-    const double rr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    r[0] /= rr; r[1] /= rr; r[2] /= rr;
+    const double orr = rsq_nr(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    r[0] *= orr; r[1] *= orr; r[2] *= orr;
 }
 
 // after the j-solve: T_xi^-1 T_eta (residuals.F90:1404-1446)
@@ -853,96 +904,261 @@ __device__ __forceinline__ void dadi_post_k(const BlkView& b, long c, double d[5
 
 // One direction of the D-ADI sweep, one line per lane.
 //  DIR 1 (j): pre-transform T_eta^-1, solve along j, post-transform T_xi^-1 T_eta
-//  DIR 0 (i): solve along i, post T_zeta^-1 T_xi
 //  DIR 2 (k): solve along k, post T_zeta * (-1/vol)
 // scale: factor applied to the incoming dw on load (DIR 1 only: -cfl*dtl*vol of
 // executeDADIStep, smoothers.F90:514-532)
 // POSTI (DIR 2, tiled i sweep in front): the transform T_zeta^-1 T_xi that follows the i-solve is applied to the update as it is
 // loaded here instead of in a pointwise pass of its own (one read and one write of dw less)
-template <int DIR, bool POSTI = false>
+// Round 4: both marches are software pipelines.  A lane walks its line alone (82 k lines per level: 1.5 wavefronts per SIMD), so
+// nothing hides a load but the thread itself: the values of cell m+2 and the update of cell m+1 are REQUESTED in step m (two value
+// sets alternate, the loop runs two steps per trip so that no register copy waits for a load), the coefficients of cell m+1 are formed
+// from the set requested one step earlier, and the pre-transform of the j sweep reuses the values the coefficients were formed
+// from; the back substitution requests row m-1 (update, eliminated super-diagonals, the metrics of its transform) in step m.
+struct DadiPre { double rho, u, v, w, p, n0[3], nm[3], sc0; };      // what T_eta^-1 and the scaling of cell m need (from DadiRaw)
+struct DadiBack { double d[5], sc[3], g[13]; };                      // row of the back substitution + the metrics of its transform
+
+__device__ __forceinline__ void dadi_pre_of(const KParams& kp, const DadiRaw& r, DadiPre& o)
+{
+    o.rho = r.rho; o.u = r.u; o.v = r.v; o.w = r.w; o.p = r.p;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { o.n0[q] = r.n0[q]; o.nm[q] = r.nm[q]; }
+    o.sc0 = -kp.cfl * r.dtl * r.vol;      // executeDADIStep scaling
+}
+
+// T_eta^-1 (dadi_pre_j) from values
+__device__ __forceinline__ void dadi_pre_j_v(const DadiPre& q, double d[5], double gam)
+{
+    const double rho = q.rho, uvel = q.u, vvel = q.v, wvel = q.w;
+    const double gm1 = gam - 1.0;
+    const double orho = rcp_nr(rho);
+    const double c2 = gam * q.p * orho;
+    const double ocijk = rsq_nr(c2), cijk = c2 * ocijk;
+    const double c2inv = ocijk * ocijk;
+    const double oxfact = 0.5 * ocijk;                    // 1 / (2 c)
+    const double alphinv = sqrt(2.0) * cijk * orho;
+    const double uvw = 0.5 * (uvel * uvel + vvel * vvel + wvel * wvel);
+    double rj1 = 0.5 * (q.n0[0] + q.nm[0]), rj2 = 0.5 * (q.n0[1] + q.nm[1]), rj3 = 0.5 * (q.n0[2] + q.nm[2]);
+    const double orj = rsq_nr(rj1 * rj1 + rj2 * rj2 + rj3 * rj3);
+    const double uu = uvel * rj1 + vvel * rj2 + wvel * rj3;
+    rj1 *= orj; rj2 *= orj; rj3 *= orj;
+    const double dw1 = d[0], dw2 = d[1], dw3 = d[2], dw4 = d[3], dw5 = d[4];
+    double a1 = dw2 * uvel + dw3 * vvel + dw4 * wvel - dw5;
+    a1 = a1 * gm1 * c2inv + dw1 * (1.0 - uvw * gm1 * c2inv);
+    const double a2 = (rj2 * wvel - rj3 * vvel) * dw1 + rj3 * dw3 - rj2 * dw4;
+    const double a3 = (rj3 * uvel - rj1 * wvel) * dw1 + rj1 * dw4 - rj3 * dw2;
+    const double a4 = (rj1 * vvel - rj2 * uvel) * dw1 + rj2 * dw2 - rj1 * dw3;
+    double a5 = uvw * dw1 - uvel * dw2 - vvel * dw3 - wvel * dw4 + dw5;
+    a5 = a5 * gm1 * c2inv;
+    const double a6 = uu * dw1 * orj - rj1 * dw2 - rj2 * dw3 - rj3 * dw4;
+    d[0] = a1 * rj1 + a2 * orho;
+    d[1] = a1 * rj2 + a3 * orho;
+    d[2] = a1 * rj3 + a4 * orho;
+    d[3] = (0.5 * a5 - a6 * oxfact) * alphinv;
+    d[4] = (0.5 * a5 + a6 * oxfact) * alphinv;
+}
+
+// row m of the back substitution and what its transform reads: DIR 1: sI(c), sI(c-1), sJ(c), sJ(c-ldi); DIR 2: rho, u, v, w, p,
+// rhoE, vol, sK(c), sK(c-ldk)
+template <int DIR>
+__device__ __forceinline__ void dadi_back_load(const BlkView& b, long c, bool withSc, const double* __restrict__ sc, DadiBack& o)
+{
+    static const int grp[5] = {0, 0, 0, 1, 2};
+    (void)grp;
+    const long nb = b.nbox;
+#pragma unroll
+    for (int l = 0; l < 5; ++l) o.d[l] = b.dw[c + l * nb];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) o.sc[g] = withSc ? sc[c + g * nb] : 0.0;
+    if (DIR == 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            o.g[q] = b.sI[c + q * nb]; o.g[3 + q] = b.sI[c - 1 + q * nb];
+            o.g[6 + q] = b.sJ[c + q * nb]; o.g[9 + q] = b.sJ[c - b.ldi + q * nb];
+        }
+        o.g[12] = 0.0;
+    } else {
+        o.g[0] = b.w[c]; o.g[1] = b.w[c + nb]; o.g[2] = b.w[c + 2 * nb]; o.g[3] = b.w[c + 3 * nb];
+        o.g[4] = b.p[c]; o.g[5] = b.w[c + 4 * nb]; o.g[6] = b.vol[c];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { o.g[7 + q] = b.sK[c + q * nb]; o.g[10 + q] = b.sK[c - b.ldk + q * nb]; }
+    }
+}
+
+__device__ __forceinline__ void unit_mean_normal_v(const double* n0, const double* nm, double r[3])
+{
+    r[0] = 0.5 * (n0[0] + nm[0]);
+    r[1] = 0.5 * (n0[1] + nm[1]);
+    r[2] = 0.5 * (n0[2] + nm[2]);
+    const double orr = rsq_nr(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    r[0] *= orr; r[1] *= orr; r[2] *= orr;
+}
+
+// the post-transforms of dadi_post_j / dadi_post_k from the values of dadi_back_load
+template <int DIR>
+__device__ __forceinline__ void dadi_back_post(const DadiBack& q, double d[5], double gam)
+{
+    if (DIR == 1) {
+        double ri[3], rj[3];
+        unit_mean_normal_v(q.g, q.g + 3, ri);
+        unit_mean_normal_v(q.g + 6, q.g + 9, rj);
+        const double a1 = ri[0] * rj[0] + ri[1] * rj[1] + ri[2] * rj[2];
+        const double a2 = ri[0] * rj[1] - rj[0] * ri[1];
+        const double a3 = ri[2] * rj[1] - rj[2] * ri[1];
+        const double a4 = ri[0] * rj[2] - rj[0] * ri[2];
+        dadi_rotate(a1, a2, a3, a4, d);
+        return;
+    }
+    const double rho = q.g[0], uvel = q.g[1], vvel = q.g[2], wvel = q.g[3];
+    double rk1 = 0.5 * (q.g[7] + q.g[10]), rk2 = 0.5 * (q.g[8] + q.g[11]), rk3 = 0.5 * (q.g[9] + q.g[12]);
+    const double ork = rsq_nr(rk1 * rk1 + rk2 * rk2 + rk3 * rk3);
+    const double uu = uvel * rk1 + vvel * rk2 + wvel * rk3;
+    rk1 *= ork; rk2 *= ork; rk3 *= ork;
+    const double uvw = 0.5 * (uvel * uvel + vvel * vvel + wvel * wvel);
+    const double orho = rcp_nr(rho);
+    const double c2 = gam * q.g[4] * orho;                 // c^2
+    const double cijkinv = rsq_nr(c2);
+    const double alph = rho * cijkinv * (1.0 / sqrt(2.0));
+    const double xfact = 2.0 * c2 * cijkinv;               // 2 c
+    const double ge = gam * q.g[5] * orho - (gam - 1.0) * uvw;
+    const double dw1 = d[0], dw2 = d[1], dw3 = d[2];
+    const double dw4 = d[3] * alph, dw5 = d[4] * alph;
+    const double a1 = dw1 * rk1 + dw2 * rk2 + dw3 * rk3 + dw4 + dw5;
+    const double a2 = 0.5 * xfact * (dw4 - dw5);
+    const double a3 = uvw * (rk1 * dw1 + rk2 * dw2 + rk3 * dw3);
+    const double volfact = -rcp_nr(q.g[6]);
+    const double hx = 0.5 * xfact * uu * ork;
+    d[0] = a1 * volfact;
+    d[1] = (a1 * uvel - rho * (rk3 * dw2 - rk2 * dw3) + a2 * rk1) * volfact;
+    d[2] = (a1 * vvel - rho * (rk1 * dw3 - rk3 * dw1) + a2 * rk2) * volfact;
+    d[3] = (a1 * wvel - rho * (rk2 * dw1 - rk1 * dw2) + a2 * rk3) * volfact;
+    d[4] = (a3 + rho * ((vvel * rk3 - wvel * rk2) * dw1 + (wvel * rk1 - uvel * rk3) * dw2 + (uvel * rk2 - vvel * rk1) * dw3) +
+            (ge + hx) * dw4 + (ge - hx) * dw5) * volfact;
+}
+
+// UPD (DIR 2): the state update of executeDADIStep follows the last transform in the same step (no residual averaging in between):
+// the back substitution holds the state of the cell already (it feeds T_zeta), so k_stage_update's read of dw, w, p is saved
+template <int DIR, bool POSTI = false, bool UPD = false>
 __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ tab, KParams kp, int slot0)
 {
+    static_assert(DIR == 1 || DIR == 2, "the i direction has its own kernels");
+    static_assert(!UPD || DIR == 2, "the update follows the k sweep");
     const BlkView& b = tab[slot0 + blockIdx.z + 1];     // level-batched: one z-slice of the grid per block
     const int a = blockIdx.x * 64 + threadIdx.x + 2;
     const int bb = blockIdx.y + 2;
     int n, amax, bmax;
     long c0, s;
     const double* sN;
-    if (DIR == 0) { amax = b.jl; bmax = b.kl; n = b.nx; c0 = b.idx(2, a, bb); s = 1; sN = b.sI; }
-    else if (DIR == 1) { amax = b.il; bmax = b.kl; n = b.ny; c0 = b.idx(a, 2, bb); s = b.ldi; sN = b.sJ; }
+    if (DIR == 1) { amax = b.il; bmax = b.kl; n = b.ny; c0 = b.idx(a, 2, bb); s = b.ldi; sN = b.sJ; }
     else { amax = b.il; bmax = b.jl; n = b.nz; c0 = b.idx(a, bb, 2); s = b.ldk; sN = b.sK; }
     if (b.nx == 0 || a > amax || bb > bmax) return;
     const long nb = b.nbox;
     double* sc = b.scratch;   // components 0..2: modified super-diagonals of the three eigenvalue groups
-    const bool solve = (n > 1);   // "if (jl > 2)" etc.: skip the inversion for one-cell lines
     static const int grp[5] = {0, 0, 0, 1, 2};
-
-    DadiCell cur, nxt, prv;
-    if (solve) dadi_cell<DIR>(b, kp, c0, s, sN, cur);
-    double ddp[3] = {0, 0, 0};          // dd'(m-1)
-    double fprev[5] = {0, 0, 0, 0, 0};  // ff'(m-1)
-    for (int m = 0; m < n; ++m) {
-        const long c = c0 + m * s;
+    const double gam = kp.gammaConstant;
+    if (n <= 1) {
+        // "if (jl > 2)" etc.: no inversion for one-cell lines, the transforms only
         double d[5];
 #pragma unroll
-        for (int l = 0; l < 5; ++l) d[l] = b.dw[c + l * nb];
+        for (int l = 0; l < 5; ++l) d[l] = b.dw[c0 + l * nb];
         if (DIR == 1) {
-            const double sc0 = -kp.cfl * b.dtl[c] * b.vol[c];   // executeDADIStep scaling
+            const double sc0 = -kp.cfl * b.dtl[c0] * b.vol[c0];
 #pragma unroll
             for (int l = 0; l < 5; ++l) d[l] *= sc0;
-            dadi_pre_j(b, c, d, kp.gammaConstant);
-        }
-        if (DIR == 2 && POSTI) dadi_post_i(b, c, d);
-        if (solve) {
-            if (m < n - 1) dadi_cell<DIR>(b, kp, c + s, s, sN, nxt);
-            double ddn[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                // row m: sub-diagonal from cell m-1, super-diagonal from cell m+1, both scaled with ddt(m)
-                const double bbv = (m > 0) ? (-prv.vt1 - prv.dP[g]) * cur.ddt : 0.0;
-                const double ddv = (m < n - 1) ? (-nxt.vt3 + nxt.dM[g]) * cur.ddt : 0.0;
-                const double ccv = 1.0 + (cur.vt1 + cur.vt3 + cur.dP[g] - cur.dM[g]) * cur.ddt;
-                const double d0 = 1.0 / (ccv - bbv * ddp[g]);
-                ddn[g] = ddv * d0;
-                sc[c + g * nb] = ddn[g];
-#pragma unroll
-                for (int l = 0; l < 5; ++l)
-                    if (grp[l] == g) d[l] = (d[l] - bbv * fprev[l]) * d0;
-            }
-#pragma unroll
-            for (int g = 0; g < 3; ++g) ddp[g] = ddn[g];
-#pragma unroll
-            for (int l = 0; l < 5; ++l) fprev[l] = d[l];
-            prv = cur;
-            cur = nxt;
-#pragma unroll
-            for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
+            dadi_pre_j(b, c0, d, gam);
+            dadi_post_j(b, c0, d);
         } else {
-            if (DIR == 0) dadi_post_i(b, c, d);
-            else if (DIR == 1) dadi_post_j(b, c, d);
-            else dadi_post_k(b, c, d, kp.gammaConstant);
-#pragma unroll
-            for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
+            if (POSTI) dadi_post_i(b, c0, d);
+            const double rho0 = b.w[c0], u0 = b.w[c0 + nb], v0 = b.w[c0 + 2 * nb], w0 = b.w[c0 + 3 * nb], e0 = b.w[c0 + 4 * nb], p0 = b.p[c0];
+            dadi_post_k(b, c0, d, gam);
+            if (UPD) stage_update_cell(b, kp, c0, d, rho0, u0, v0, w0, e0, p0, rho0, u0, v0, w0, p0);
         }
+#pragma unroll
+        for (int l = 0; l < 5; ++l) b.dw[c0 + l * nb] = d[l];
+        return;
     }
-    if (!solve) return;
-    // back substitution + post-transform
-    for (int m = n - 1; m >= 0; --m) {
+    // ---- forward elimination.  State entering step m: cur = coefficients of cell m, prv of m-1, pre = transform values of cell m,
+    // dX = update of cell m, rX = raw values of cell m+1 (requested a step ago); the step requests cell m+2 into (rY, dY)
+    DadiCell cur, nxt, prv;
+    DadiPre pre;
+    DadiRaw rA, rB;
+    double dA[5], dB[5];
+    double ddp[3] = {0, 0, 0};          // dd'(m-1)
+    double fprev[5] = {0, 0, 0, 0, 0};  // ff'(m-1)
+    dadi_load<DIR>(b, kp, c0, s, sN, rA);
+    dadi_coef<DIR>(kp, rA, cur);
+    dadi_pre_of(kp, rA, pre);
+    prv = cur;
+#pragma unroll
+    for (int l = 0; l < 5; ++l) dA[l] = b.dw[c0 + l * nb];
+    dadi_load<DIR>(b, kp, c0 + s, s, sN, rA);          // cell 1 (n >= 2)
+    auto fwd = [&](int m, double* __restrict__ dX, DadiRaw& rX, double* __restrict__ dY, DadiRaw& rY) {
         const long c = c0 + m * s;
+        if (m + 2 < n) dadi_load<DIR>(b, kp, c + 2 * s, s, sN, rY);
+        if (m + 1 < n) {
+#pragma unroll
+            for (int l = 0; l < 5; ++l) dY[l] = b.dw[c + s + l * nb];
+        }
         double d[5];
 #pragma unroll
-        for (int l = 0; l < 5; ++l) d[l] = b.dw[c + l * nb];
+        for (int l = 0; l < 5; ++l) d[l] = dX[l];
+        if (DIR == 1) {
+#pragma unroll
+            for (int l = 0; l < 5; ++l) d[l] *= pre.sc0;
+            dadi_pre_j_v(pre, d, gam);
+        }
+        if (DIR == 2 && POSTI) dadi_post_i(b, c, d);
+        if (m < n - 1) { dadi_coef<DIR>(kp, rX, nxt); dadi_pre_of(kp, rX, pre); }
+        double ddn[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            // row m: sub-diagonal from cell m-1, super-diagonal from cell m+1, both scaled with ddt(m)
+            const double bbv = (m > 0) ? (-prv.vt1 - prv.dP[g]) * cur.ddt : 0.0;
+            const double ddv = (m < n - 1) ? (-nxt.vt3 + nxt.dM[g]) * cur.ddt : 0.0;
+            const double ccv = 1.0 + (cur.vt1 + cur.vt3 + cur.dP[g] - cur.dM[g]) * cur.ddt;
+            const double d0 = rcp_nr(ccv - bbv * ddp[g]);
+            ddn[g] = ddv * d0;
+            sc[c + g * nb] = ddn[g];
+#pragma unroll
+            for (int l = 0; l < 5; ++l)
+                if (grp[l] == g) d[l] = (d[l] - bbv * fprev[l]) * d0;
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) ddp[g] = ddn[g];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) fprev[l] = d[l];
+        prv = cur;
+        cur = nxt;
+#pragma unroll
+        for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
+    };
+    for (int m = 0; m < n; m += 2) {
+        fwd(m, dA, rA, dB, rB);
+        if (m + 1 < n) fwd(m + 1, dB, rB, dA, rA);
+    }
+    // ---- back substitution + post-transform; row n-1 keeps its value (fprev), its transform is applied like the others
+    DadiBack qA, qB;
+    dadi_back_load<DIR>(b, c0 + (long)(n - 1) * s, false, sc, qA);
+    auto bwd = [&](int m, DadiBack& qX, DadiBack& qY) {
+        const long c = c0 + m * s;
+        if (m > 0) dadi_back_load<DIR>(b, c - s, true, sc, qY);
+        double d[5];
         if (m < n - 1) {
 #pragma unroll
-            for (int l = 0; l < 5; ++l) d[l] -= sc[c + grp[l] * nb] * fprev[l];
+            for (int l = 0; l < 5; ++l) d[l] = qX.d[l] - qX.sc[grp[l]] * fprev[l];
+        } else {
+#pragma unroll
+            for (int l = 0; l < 5; ++l) d[l] = fprev[l];
         }
 #pragma unroll
         for (int l = 0; l < 5; ++l) fprev[l] = d[l];
-        if (DIR == 0) dadi_post_i(b, c, d);
-        else if (DIR == 1) dadi_post_j(b, c, d);
-        else dadi_post_k(b, c, d, kp.gammaConstant);
+        dadi_back_post<DIR>(qX, d, gam);
 #pragma unroll
         for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
+        if (UPD) stage_update_cell(b, kp, c, d, qX.g[0], qX.g[1], qX.g[2], qX.g[3], qX.g[5], qX.g[4], qX.g[0], qX.g[1], qX.g[2], qX.g[3], qX.g[4]);
+    };
+    for (int m = n - 1; m >= 0; m -= 2) {
+        bwd(m, qA, qB);
+        if (m - 1 >= 0) bwd(m - 1, qB, qA);
     }
 }
 
@@ -1242,9 +1458,10 @@ static void launch_dadi_i_pcr(const BlkView* tab, int nslots, int ny, int nz, co
 int g_dadi_pcr = 1;      // tuning "dadi_pcr": the i direction of D-ADI by cyclic reduction along the lanes (0: rows + tiled Thomas)
 
 // computedwDADI incl. the -cfl*dtl*vol scaling of executeDADIStep
-void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s)
+// withUpdate: the k sweep also updates the state (no residual averaging follows): finish_stage then skips k_stage_update
+void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, bool withUpdate)
 {
-    LEVEL_SPLIT(nslots, nz + 4, launch_dadi_level(tab + s0_, n_, nx, ny, nz, kp, s));
+    LEVEL_SPLIT(nslots, nz + 4, launch_dadi_level(tab + s0_, n_, nx, ny, nz, kp, s, withUpdate));
     if (nslots <= 0) return;
     dim3 blk(64, 1, 1);
     hipLaunchKernelGGL((k_dadi_sweep<1>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
@@ -1254,7 +1471,8 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
         else if (nx <= 128) launch_dadi_i_pcr<2>(tab, nslots, ny, nz, kp, s);
         else if (nx <= 192) launch_dadi_i_pcr<3>(tab, nslots, ny, nz, kp, s);
         else launch_dadi_i_pcr<4>(tab, nslots, ny, nz, kp, s);
-        hipLaunchKernelGGL((k_dadi_sweep<2, false>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+        if (withUpdate) hipLaunchKernelGGL((k_dadi_sweep<2, false, true>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+        else hipLaunchKernelGGL((k_dadi_sweep<2, false>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
         return;
     }
     // i direction: rows pointwise, Thomas per (line, equation) through LDS tiles; the transform behind the i-solve is applied
@@ -1264,5 +1482,6 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
         hipLaunchKernelGGL(k_dadi_rows_i, pg, pb, 0, s, tab, nz, kp);
         hipLaunchKernelGGL(k_dadi_solve_i, dim3(5 * ((ny + 63) / 64), nz, nslots), blk, 0, s, tab, kp);
     }
-    hipLaunchKernelGGL((k_dadi_sweep<2, true>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+    if (withUpdate) hipLaunchKernelGGL((k_dadi_sweep<2, true, true>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+    else hipLaunchKernelGGL((k_dadi_sweep<2, true>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
 }

@@ -1,2 +1,5 @@
-export GIT=5983536 TAG=r04_e EXTRAS="config3 config2 matvec small"
-bash tools/_gpu_job_pmc_extras.sh
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out; mkdir -p $O; TAG=r04_g
+timeout 900 python -m pytest tests/test_gpu_smoothers.py tests/test_gpu_multigrid.py -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -4 | tee $O/${TAG}_pytest.txt
+export EXTRAS=config3 TAG=r04_g ROWS=18
+bash tools/_gpu_job_extras.sh
