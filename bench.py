@@ -135,6 +135,11 @@ WORKLOADS = {
     # same cell count as the Euler workload, cut into 512 blocks of 32^3 (a production multiblock mesh per GPU)
     "euler_jst_512x32": dict(equations=1, spaceDiscr=1, nblocks=512, dims=(32, 32, 32), bytes_per_cell=175.0,
                              desc="Euler, central + scalar JST, 32^3 blocks"),
+    # the shard ONE GPU holds when the 8-block mesh is split over 8 GPUs (BASELINE north_star, --scaling strong at N = 8): one periodic
+    # block whose six interfaces all lead to other ranks.  At N = 1 its neighbours are itself; with tuning comm_self every interface
+    # takes the inter-GPU path (pack, ncclSend / ncclRecv to the own rank, unpack): extra "strong_shard_one_block"
+    "crm_strong_shard_1x160x128x64": dict(equations=3, spaceDiscr=9, nblocks=1, dims=(160, 128, 64), bytes_per_cell=255.0,
+                                          desc="RANS-SA, Roe upwind: one block = the N = 8 shard of the north-star mesh"),
     # about the cell count of the north-star workload (11.2 M) in 343 blocks of 32^3
     "rans_sa_upwind_343x32": dict(equations=3, spaceDiscr=9, nblocks=343, dims=(32, 32, 32), bytes_per_cell=255.0,
                                   desc="RANS-SA, Roe upwind (van Albada), 32^3 blocks"),
@@ -441,7 +446,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported under 'extra' (N=1)")
     ap.add_argument("--force-extras", action="store_true", help="run the extras although --tuning is given (A/B runs of a tuning key)")
     ap.add_argument("--no-mg", action="store_true", help="skip the config-2 multigrid cycle measurement")
-    ap.add_argument("--only-extras", default="", help="comma list out of 4b,matvec,pc,config3,periodic,config2,small: time only these extras (kernel traces)")
+    ap.add_argument("--only-extras", default="", help="comma list out of 4b,matvec,pc,config3,periodic,config2,shard,small: time only these extras (kernel traces)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K steps until the region lasts this long")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
     ap.add_argument("--separate-halo", action="store_true",
@@ -751,6 +756,37 @@ def main():
         except Exception as ex:
             extra["error_config2"] = str(ex)
             log("config 2 extras failed: " + str(ex))
+    # ---- de-risking N > 1 at N = 1 (round-3 verdict, next 5 i): the N = 8 strong-scaling shard, its exchange through RCCL to the own rank
+    if extras_on and want("shard"):
+        try:
+            eng.release_all()
+            eng.set_options(prm)
+            js = Job(a, "crm_strong_shard_1x160x128x64", eng, rank, world)
+            res = {}
+            for label, cs, sp in (("same_gpu_copies", 0, 1), ("rccl_self_no_split", 1, 0), ("rccl_self_split", 1, 1)):
+                eng.set_tuning("comm_self", cs)
+                eng.set_tuning("split_eval", sp)
+                eng.set_async(True)
+                for _ in range(3):
+                    js.step()
+                ss_, _, es_ = timed(eng, js.step, a.steps, barrier, min(a.min_seconds, 0.5))
+                eng.set_async(False)
+                res[label] = {"ms_per_step": ss_ * 1e3}
+            eng.set_tuning("comm_self", 0)
+            eng.set_tuning("split_eval", 1)
+            halo_cells = int(js.cp[0].ncopy)
+            extra["strong_shard_one_block"] = {
+                "cells": js.cells_local, "halo_cells_exchanged": halo_cells, "bytes_received_per_eval": halo_cells * 9 * 8, **res,
+                "exchange_through_rccl_ms": res["rccl_self_no_split"]["ms_per_step"] - res["same_gpu_copies"]["ms_per_step"],
+                "split_gain_ms": res["rccl_self_no_split"]["ms_per_step"] - res["rccl_self_split"]["ms_per_step"],
+                "what": "one 160x128x64 periodic block = what each GPU holds at N = 8 of --scaling strong; rccl_self: every interface "
+                        "through k_halo_pack -> ncclSend / ncclRecv to the own rank -> k_halo_unpack (the code path of N > 1, executed on "
+                        "one GPU: the transfer is a device copy, not xGMI); split: interior tiles between departure and arrival"}
+            log("N = 8 shard (one block): " + ", ".join(f"{k} {v['ms_per_step']:.3f} ms" for k, v in res.items()))
+            del js
+        except Exception as ex:
+            extra["error_strong_shard"] = str(ex)
+            log("strong-shard extra failed: " + str(ex))
     # ---- small blocks: about the cell count of the headline in 343 blocks of 32^3 (a production multiblock mesh per GPU)
     if extras_on and want("small"):
         try:
