@@ -133,7 +133,7 @@ BC_CALLBACK = ctypes.CFUNCTYPE(None, c_int, c_int)
 (ARR_W, ARR_P, ARR_GAMMA, ARR_RLV, ARR_REV, ARR_DW, ARR_FW, ARR_DTL, ARR_RADI, ARR_RADJ, ARR_RADK, ARR_AA,
  ARR_NODAL_GRADS, ARR_WN, ARR_PN, ARR_W1, ARR_P1, ARR_WR, ARR_VOL, ARR_SI, ARR_SJ, ARR_SK, ARR_X, ARR_D2WALL) = range(1, 25)
 
-JAC_PC, JAC_FROZEN_TURB, JAC_TURB_ONLY, JAC_VISC_PC = 1, 2, 4, 8     # include/adflow_gpu.h
+JAC_PC, JAC_FROZEN_TURB, JAC_TURB_ONLY, JAC_VISC_PC, JAC_USE_AD = 1, 2, 4, 8, 16     # include/adflow_gpu.h
 RES_UPDATE_INTERMED, RES_FLOW, RES_TURB, RES_CLOSURES, RES_HALO = 1, 2, 4, 8, 16
 
 EXPORTS = [

@@ -1487,18 +1487,152 @@ static int block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bo
     return block_res_enqueue(level, resFlags);
 }
 
+// ---- forward-mode linearisation (kernels_ad.hip): dual copies of the arrays the gather kernels touch ----------------------------
+struct AdBlock { BlkView v; std::vector<void*> allocs; };
+static std::map<Block*, AdBlock> g_ad;
+static BlkView* g_ad_tab = nullptr;        // device table of the level being linearised, slot layout of g_tab[level]
+
+static void ad_drop()
+{
+    for (auto& kv : g_ad)
+        for (void* q : kv.second.allocs) (void)hipFree(q);
+    g_ad.clear();
+    if (g_ad_tab) (void)hipFree(g_ad_tab);
+    g_ad_tab = nullptr;
+}
+
+// dual array of ncomp components over the box of b (16 bytes per entry, the same padding as the library's arrays), filled with
+// (src, 0) when src is given; the returned pointer is typed double* because BlkView is (the kernels see it as Dual*)
+static int ad_array(Block* b, AdBlock& a, double** field, const double* src, int ncomp)
+{
+    const size_t n = (size_t)b->v.nbox * ncomp;
+    void* raw = nullptr;
+    HIPCHK(hipMalloc(&raw, (n + 32) * 16));
+    a.allocs.push_back(raw);
+    if (src) ad_launch_from_real(src - ADF_PAD0, raw, (long)n, g_stream);
+    else HIPCHK(hipMemsetAsync(raw, 0, (n + 32) * 16, g_stream));
+    *field = (double*)((char*)raw + (size_t)ADF_PAD0 * 16);
+    return 0;
+}
+
+static int ad_prepare(int level)
+{
+    ad_drop();
+    if (ensure_table(level)) return 1;
+    const int maxnn = g_tab_size[level];
+    std::vector<BlkView> h(maxnn + 1);
+    memset(h.data(), 0, sizeof(BlkView) * h.size());
+    const bool viscous = g_opts.equations != ADFLOW_EULER;
+    int rc = for_level(level, [&](Block* b) {
+        if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
+        if (viscous && !b->face_vectors_valid) {
+            launch_face_vectors(b->v, g_stream);
+            b->face_vectors_valid = true;
+        }
+        AdBlock& a = g_ad[b];
+        a.v = b->v;
+        BlkView& v = a.v;
+        const BlkView& p = b->v;
+        // active arrays (the seed kernel fills w; the evaluation writes the rest)
+        if (ad_array(b, a, &v.w, nullptr, p.nw) || ad_array(b, a, &v.p, nullptr, 1) || ad_array(b, a, &v.rlv, p.rlv, 1) ||
+            ad_array(b, a, &v.rev, p.rev, 1) || ad_array(b, a, &v.dw, nullptr, p.nw) || ad_array(b, a, &v.fw, nullptr, 5) ||
+            ad_array(b, a, &v.dtl, nullptr, 1) || ad_array(b, a, &v.radI, nullptr, 1) || ad_array(b, a, &v.radJ, nullptr, 1) ||
+            ad_array(b, a, &v.radK, nullptr, 1) || ad_array(b, a, &v.ss, p.ss, 1) || ad_array(b, a, &v.scratch, nullptr, 2))
+            return 1;
+        if (viscous && ad_array(b, a, &v.grad, nullptr, 12)) return 1;
+        // passive arrays: value = the library's, derivative 0
+        if (ad_array(b, a, &v.gamma, p.gamma, 1) || ad_array(b, a, &v.x, p.x, 3) || ad_array(b, a, &v.sI, p.sI, 3) ||
+            ad_array(b, a, &v.sJ, p.sJ, 3) || ad_array(b, a, &v.sK, p.sK, 3) || ad_array(b, a, &v.vol, p.vol, 1) ||
+            ad_array(b, a, &v.volRef, p.volRef, 1))
+            return 1;
+        if (p.d2wall && ad_array(b, a, &v.d2wall, p.d2wall, 1)) return 1;
+        if (viscous && p.dI && (ad_array(b, a, &v.dI, p.dI, 3) || ad_array(b, a, &v.dJ, p.dJ, 3) || ad_array(b, a, &v.dK, p.dK, 3))) return 1;
+        v.aa = nullptr; v.wn = v.pn = v.w1 = v.p1 = v.wr = nullptr; v.sFace = nullptr;
+        // face arrays of the turbulence boundary treatment
+        const size_t nf[3] = {(size_t)p.je * p.ke, (size_t)p.ie * p.ke, (size_t)p.ie * p.je};
+        for (int f6 = 0; f6 < 6; ++f6)
+            for (int which = 0; which < 2; ++which) {
+                double** dst = &(which ? v.bvt : v.bmt)[f6];
+                if (!(which ? p.bvt : p.bmt)[f6]) { *dst = nullptr; continue; }
+                void* raw = nullptr;
+                HIPCHK(hipMalloc(&raw, nf[f6 / 2] * 16));
+                HIPCHK(hipMemsetAsync(raw, 0, nf[f6 / 2] * 16, g_stream));
+                a.allocs.push_back(raw);
+                *dst = (double*)raw;
+            }
+        return 0;
+    });
+    if (rc) return rc;
+    for (auto& kv : g_blocks)
+        if (std::get<0>(kv.first) == level && std::get<1>(kv.first) == 1) h[std::get<2>(kv.first)] = g_ad[kv.second].v;
+    HIPCHK(hipMalloc((void**)&g_ad_tab, sizeof(BlkView) * h.size()));
+    HIPCHK(hipMemcpyAsync(g_ad_tab, h.data(), sizeof(BlkView) * h.size(), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+// masterRoutines::block_res_state_d (masterRoutines.F90:1285-1393) on the dual arrays of the level: closures with halos,
+// turbulence + mean-flow boundary conditions, time step (the spectral radii of the scalar dissipation), SA, fluxes.
+// viscPC: block_res_state_d keeps the FULL viscous flux in the preconditioner matrix then (masterRoutines.F90:1380: `.not. lumpedDiss
+// .or. viscPC`) -- unlike the finite-difference path block_res_state, whose viscApprox = lumpedDiss whatever viscPC says (:1269-1270)
+static int ad_apply_bc_enqueue(int level, const KParams& kp, bool turbBC);
+static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bool viscPC)
+{
+    KParams kp = make_kparams(level, 1.0, 0);
+    kp.onlyRadii = 1;
+    kp.coarseInit = 0;
+    kp.dissApprox = (resFlags & ADFLOW_RES_DISS_APPROX) ? 1 : 0;
+    const bool viscApprox = (resFlags & ADFLOW_RES_VISC_APPROX) != 0 && !viscPC;
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    int rc = for_level(level, [&](Block* b) {
+        ad_launch_closures_halo(g_ad[b].v, kp, g_stream);
+        return 0;
+    });
+    if (rc) return rc;
+    if (ad_apply_bc_enqueue(level, kp, turbBC)) return 1;
+    // timeStep_block_d: only the scalar dissipation reads the spectral radii; the NS / RANS kernel also leaves the entropy sensor
+    // in ss -- not under dissApprox, where ss keeps the frozen sensor of referenceShockSensor (value part, derivative 0)
+    if ((resFlags & ADFLOW_RES_FLOW) && kp.spaceDiscr == ADFLOW_DISS_SCALAR)
+        ad_launch_time_step_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    if ((resFlags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS)
+        ad_launch_sa_residual_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    if (resFlags & ADFLOW_RES_FLOW) {
+        ad_launch_inviscid_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        if (kp.viscous && fabs(kp.rFil) >= 1.e-10) {
+            rc = for_level(level, [&](Block* b) {
+                if (viscApprox) ad_launch_viscous_approx(g_ad[b].v, kp, g_stream);
+                else ad_launch_viscous(g_ad[b].v, kp, g_stream);
+                return 0;
+            });
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
 int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
 {
     if (need_ready()) return 1;
     if (!(delta > 0.0)) return fail("fd_jacobian: delta must be positive");
-    if (flags & ~(ADFLOW_JAC_PC | ADFLOW_JAC_FROZEN_TURB | ADFLOW_JAC_TURB_ONLY | ADFLOW_JAC_VISC_PC)) return fail("fd_jacobian: unknown flags 0x%x", flags);
+    if (flags & ~(ADFLOW_JAC_PC | ADFLOW_JAC_FROZEN_TURB | ADFLOW_JAC_TURB_ONLY | ADFLOW_JAC_VISC_PC | ADFLOW_JAC_USE_AD))
+        return fail("fd_jacobian: unknown flags 0x%x", flags);
+    const bool useAD = (flags & ADFLOW_JAC_USE_AD) != 0;
+    if (useAD) {
+        // forward-mode seeds instead of perturbations (adjointUtils.F90:227-409): gather kernels on dual numbers, blocks at rest
+        bool moving = false;
+        for_level(level, [&](Block* b) { moving = moving || b->v.sFace || b->v.moving; return 0; });
+        if (moving) return fail("fd_jacobian(useAD): moving blocks are not linearised (grid velocities)");
+        if (!g_act.empty()) return fail("fd_jacobian(useAD): actuator regions are not linearised");
+        if (g_bc_callback) return fail("fd_jacobian(useAD): a host boundary-condition hook cannot be linearised");
+    }
     if (level != g_opts.groundLevel) return fail("fd_jacobian: level %d is not the ground level %d (setupStateResidualMatrix sets both)", level, g_opts.groundLevel);
     const bool rans = g_opts.equations == ADFLOW_RANS;
     const bool viscous = rans || g_opts.equations == ADFLOW_NS;
     if ((flags & ADFLOW_JAC_TURB_ONLY) && !rans) return fail("fd_jacobian: ADFLOW_JAC_TURB_ONLY needs the RANS equations");
     if ((flags & ADFLOW_JAC_TURB_ONLY) && (flags & ADFLOW_JAC_FROZEN_TURB)) return fail("fd_jacobian: TURB_ONLY and FROZEN_TURB exclude each other");
     JacSpec J;
-    jac_spec(flags, viscous, rans, &J);
+    jac_spec(flags & ~ADFLOW_JAC_USE_AD, viscous, rans, &J);
     const int ncomp = J.nStencil * J.nState * J.nState;
     int rc = for_level(level, [&](Block* b) {
         if (!b->wref) {
@@ -1555,6 +1689,38 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
     // viscosity is still recomputed from nuTilde because eddyModel stays set (turbUtils.F90:604-612)
     const bool turbBC = rans && !(flags & ADFLOW_JAC_FROZEN_TURB);
     auto restore = [&]() { g_opts = saved; g_lumped = savedLumped; };
+
+    if (useAD) {
+        // one forward-mode evaluation per (colour, state variable): seed = 1 on component l of the cells of the colour (halos
+        // included), block_res_state_d, the derivative of the scaled residual is the column of every stencil block
+        if (!rc) rc = ad_prepare(level);
+        for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
+            for (int col = 0; col < J.cn && !rc; ++col) {
+                rc = for_level(level, [&](Block* b) {
+                    AdBlock& a = g_ad[b];
+                    ad_launch_seed(b->v, a.v.w, l, col, J, g_stream);
+                    return 0;
+                });
+                if (!rc) rc = ad_block_res_state_enqueue(level, resFlags, turbBC, (flags & ADFLOW_JAC_VISC_PC) != 0);
+                if (!rc) rc = for_level(level, [&](Block* b) {
+                    ad_launch_snap(b->v, g_ad[b].v.dw, b->snap + (size_t)col * J.nState * b->v.nbox, J, g_opts.turbResScale, g_stream);
+                    return 0;
+                });
+            }
+            if (!rc) rc = for_level(level, [&](Block* b) {
+                launch_fd_scatter(b->v, b->snap, b->jac, l, J, g_stream);
+                return 0;
+            });
+        }
+        if (!rc) rc = sync_and_check();
+        else (void)hipStreamSynchronize(g_stream);
+        ad_drop();
+        restore();
+        if (rc) return rc;
+        g_jac = J;
+        g_jac_valid = true;
+        return 0;
+    }
 
     // setFDReference (adjointUtils.F90:1971-2024): reference residual, then the reference state INCLUDING the halos the boundary
     // conditions just wrote
@@ -2398,6 +2564,28 @@ static int apply_bc_enqueue(int level, int secondHalo)
         if (!b->bc.empty()) b->ss_valid = false;
         return 0;
     });
+}
+
+// bcTurbTreatment_d + applyAllTurbBCThisBlock_d + applyAllBC_block_d on the dual arrays of the level (kernels_ad.hip)
+static int ad_apply_bc_enqueue(int level, const KParams& kp, bool turbBC)
+{
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return 1;
+    if (pl->nent == 0) return 0;
+    if (pl->anyEulerWall && g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_QUADRATIC)
+        return fail("eulerWallBCTreatment=%d: bcEulerWall has no quadratic extrapolation", g_opts.eulerWallBCTreatment);
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    if (turbBC) ad_launch_turb_bc(g_ad_tab, t.n, pl->maxFace, pl->d_ent, pl->d_order, pl->ordinal, kp, 1, g_stream);
+    // applyAllBC_block_d (src/adjoint/outputForward/BCExtra_d.F90:10-139) applies the kinds that were differentiated: symmetry,
+    // polar symmetry, viscous walls, farfield, subsonic out- / inflow, Euler wall.  Extrapolation and the supersonic kinds are NOT
+    // in it: their halos keep the values of the last primal boundary-condition pass with a zero derivative.  Reproduced.
+    std::vector<BcPhase> flow;
+    for (const BcPhase& ph : pl->flow)
+        if (ph.kind != BCP_EXTRAP && ph.kind != BCP_SUPERSONIC_INFLOW) flow.push_back(ph);
+    ad_launch_apply_all_bc(g_ad_tab, pl->d_ent, pl->d_order, flow, kp, 1, g_opts.eulerWallBCTreatment, g_opts.viscWallBCTreatment,
+                           g_opts.outflowTreatment, g_opts.hScalingInlet, g_stream);
+    return 0;
 }
 
 static bool has_wall_subfaces(int level)

@@ -206,43 +206,16 @@ __device__ __forceinline__ double lane_dn1(double v)
 {
     return __hiloint2double(lane_dn1(__double2hiint(v)), lane_dn1(__double2loint(v)));
 }
+
+
+
+
 #endif
 
-struct BlkView {
-    int nx, ny, nz, nw;
-    int il, jl, kl, ie, je, ke, ib, jb, kb;
-    int ldi;        // j-stride (doubles)
-    int ldk;        // k-stride
-    long nbox;      // stride between variables of a multi-component array
-    // state
-    double *w, *p, *gamma, *rlv, *rev;
-    // geometry
-    double *x, *sI, *sJ, *sK, *vol, *volRef, *d2wall;
-    double* sFace;          // moving blocks: sFaceI/J/K as components 0..2 (entry at the left cell of the face); NULL at rest
-    int moving;             // blockIsMoving: rotational source with rot = cgnsDoms%rotRate (fluxes.F90:372-397)
-    double rot[3];
-    double *dI, *dJ, *dK;   // derived geometry: vector between the two cell centres of a face (viscous normal correction)
-    // implicit turbulence boundary treatment of Spalart-Allmaras (turbBCRoutines.F90:662-798): halo = bvt - bmt * interior.
-    // Index 0..5 = iMin,iMax,jMin,jMax,kMin,kMax; entry (a,b) at (a-1) + A*(b-1), A = je (i faces) or ie (j,k faces).
-    // NULL until a block registers boundary subfaces (= all zero, the periodic / internal case).
-    double *bmt[6], *bvt[6];
-    uint8_t* flags;  // bits 0-1 porI+1, 2-3 porJ+1, 4-5 porK+1, bit 6 iblank>0
-    // residual + work
-    double *dw, *fw, *dtl, *radI, *radJ, *radK;
-    double *ss;      // JST sensor variable (entropy p/rho^gamma) for NS/RANS
-    double *aa;      // speed of sound squared
-    double *grad;    // 12 nodal gradients ux,uy,uz,vx,...,qz
-    double *scratch; // nscratch work arrays
-    double *wn, *pn; // RK stage-0 state
-    double *w1, *p1, *wr; // multigrid
-    // multigrid maps (device copies of coarseUtils.F90:254-262): index 2*m+{0,1} for coarse/fine cell m
-    int *mgIFine, *mgJFine, *mgKFine;        // coarse block: (1:ie,2) stored [m*2+q], m = 0..ie
-    double *mgIWeight, *mgJWeight, *mgKWeight;  // coarse block, indexed by cell index
-    int *mgICoarse, *mgJCoarse, *mgKCoarse;  // fine block, indexed [i*2+q]
-    double mfact;    // +0.5 (right-handed block) or -0.5: the factor of the face-normal cross products (metric_block, adjointExtra.F90:176-268)
-    long vecOff;     // first entry of the block in the PETSc-ordered state / residual vector of its level (NKSolvers.F90:1240-1253)
-    __host__ __device__ inline long idx(int i, int j, int k) const { return (long)i + (long)j * ldi + (long)k * ldk; }
-};
+typedef double adf_real8;      // a double that stays one where `double` is re-defined (kernels_ad.hip)
+#define ADF_BLKVIEW BlkView
+#include "blkview_def.h"
+#undef ADF_BLKVIEW
 
 // one boundary subface on the device (adflow_bc_subface with device copies of the BCData members)
 struct BcFaceDev {
@@ -477,3 +450,21 @@ void launch_corner_row_halos_level(const BlkView* tab, int nslots, const KParams
 void launch_volume_metric(const BlkView& b, int rightHanded, hipStream_t s);
 void launch_boundary_normals(const BlkView& b, const BcFaceDev* faces, int nBocos, hipStream_t s);
 void launch_wall_distance(const BlkView& b, const int* ind, const double* uv, const double* xSurf, hipStream_t s);
+
+// ---- forward-mode twins of the gather kernels (kernels_ad.hip)
+// entry points of kernels_ad.hip (BlkView-layout views whose array pointers lead to dual numbers, blkview_def.h)
+void ad_launch_from_real(const double* src, void* dst, long n, hipStream_t s);
+void ad_launch_value(const void* src, double* dst, long n, int deriv, hipStream_t s);
+void ad_launch_seed(const BlkView& b, void* wd, int l, int col, const JacSpec& J, hipStream_t s);
+void ad_launch_snap(const BlkView& b, const void* dwd, double* snap, const JacSpec& J, double turbResScale, hipStream_t s);
+void ad_launch_closures_halo(const BlkView& adv, const KParams& kp, hipStream_t s);
+void ad_launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& flow, const KParams& kp,
+                            int second, int eulerWallTreatment, int viscWallTreatment, int outflowTreatment, int hScalingInlet, hipStream_t s);
+void ad_launch_turb_bc(const BlkView* tab, int nslots, long maxFace, const BcEntry* ent, const int* order, const std::vector<BcPhase>& ordinal,
+                       const KParams& kp, int second, hipStream_t s);
+void ad_launch_time_step_level(const BlkView* tab, int n, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void ad_launch_entropy_level(const BlkView* tab, int n, int nx, int ny, int nz, hipStream_t s);
+void ad_launch_sa_residual_level(const BlkView* tab, int n, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void ad_launch_inviscid_level(const BlkView* tab, int n, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
+void ad_launch_viscous(const BlkView& adv, const KParams& kp, hipStream_t s);
+void ad_launch_viscous_approx(const BlkView& adv, const KParams& kp, hipStream_t s);

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
     node_gradient(b, b.idx(i, j, k));
 }
 
+#ifndef ADF_AD_BUILD      // (kernels_ad.hip compiles the gather kernels only: no lane exchange, no LDS)
 // ---------------------------------------------------------------------------
 // The dual-cell surface integral of allNodalGradients (flowUtils.F90:1712-1979) factorises: with the per-CELL vectors
 // tI = sI(i-1) + sI(i), tJ = sJ(j-1) + sJ(j), tK = sK(k-1) + sK(k) the normal of the integration point of direction k at cell plane m is
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
     }
 }
 
+#endif
 // viscous flux through the face between cells cL and cL+sd (fluxes.F90:2610-2860);
 // the four face nodes are cL, cL-s1, cL-s2, cL-s1-s2.
 __device__ __forceinline__ void visc_face(const BlkView& b, const KParams& kp, long cL, long sd, long s1, long s2,
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous(BlkView b, KParams kp)
     }
 }
 
+#ifndef ADF_AD_BUILD
 // Nodal gradients of the node plane ON a viscous-wall subface: the only gradients the stored wall stress reads (the four nodes of a
 // wall face, fluxes.F90:2849-2879).  k_visc_gf keeps its gradients in LDS; instead of writing all twelve of every node of the block
 // for the sake of the wall faces (96 B per cell), the few nodes of the wall planes are formed again here, in the reference's own
@@ -555,6 +558,7 @@ void launch_wall_stress(const BlkView* tab, const BcEntry* ent, const int* order
     hipLaunchKernelGGL(k_wall_stress, dim3((unsigned)((ph.maxCells + 255) / 256), ph.count, 1), dim3(256, 1, 1), 0, s, tab, ent,
                        order + ph.first, kp);
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // Tiled form of the face-flux kernel.  The gather form above issues ~560 loads
@@ -616,6 +620,7 @@ __device__ __forceinline__ VCell vcell_at(const BlkView& b, const KParams& kp, l
     return c;
 }
 
+#ifndef ADF_AD_BUILD
 // ---------------------------------------------------------------------------
 // Face arithmetic of the marching viscous kernels (k_visc_gf, k_visc_approx_march): vm_face = fluxes.F90:2610-2860 with the SUM of
 // the gradients of the four face nodes handed in (the 4-node average is formed from pair sums: rounding only), the constant gamma
@@ -1131,6 +1136,7 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
     if (r >= 1 && k1 >= k0) finish(cA - 2 * sk, fjx + ((k1 + 1) & 1) * GF_FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
 }
 
+#endif
 // ---------------------------------------------------------------------------
 // viscousFluxApprox (fluxes.F90:3487-3859): thin-layer form for the preconditioner assembly.  The gradient on a
 // face is the difference of the two cell values along the centre-to-centre vector d (no nodal gradients):
@@ -1229,6 +1235,7 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
     hipLaunchKernelGGL(k_viscous, gc, blk, 0, s, b, kp);
 }
 
+#ifndef ADF_AD_BUILD      // (kernels_ad.hip compiles the gather kernels only)
 // marching face-flux kernel over the tile table of the level (tuning viscous_tiled >= 2)
 // viscousFluxApprox of every block of the level (thin-layer form, no nodal gradients)
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
@@ -1271,3 +1278,4 @@ void launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KP
 }
 
 int viscous_is_tiled() { return g_viscous_tiled; }
+#endif

@@ -115,11 +115,12 @@ class Engine:
         xSurf = np.ascontiguousarray(xSurf, dtype=np.float64)
         self._chk(self.lib.adflow_gpu_update_wall_distances(level, xSurf.ctypes.data, xSurf.size))
 
-    def setupStateResidualMatrix(self, level=1, usePC=True, frozenTurb=False, useTurbOnly=False, viscPC=False, delta=1e-9):
-        """adjointUtils::setupStateResidualMatrix(useAD=F) (adjointUtils.F90:7-715) without the PETSc calls: the coloured
-        finite-difference blocks stay on the device; jacobianBlocks() brings one block's over."""
+    def setupStateResidualMatrix(self, level=1, usePC=True, frozenTurb=False, useTurbOnly=False, viscPC=False, delta=1e-9, useAD=False):
+        """adjointUtils::setupStateResidualMatrix (adjointUtils.F90:7-715) without the PETSc calls: the stencil blocks stay on the
+        device; jacobianBlocks() brings one block's over.  useAD = False: coloured finite differences with step delta; True: one
+        forward-mode (dual-number) evaluation per colour and state variable, the exact derivative (adjointUtils.F90:227-409)."""
         flags = (capi.JAC_PC if usePC else 0) | (capi.JAC_FROZEN_TURB if frozenTurb else 0) \
-            | (capi.JAC_TURB_ONLY if useTurbOnly else 0) | (capi.JAC_VISC_PC if viscPC else 0)
+            | (capi.JAC_TURB_ONLY if useTurbOnly else 0) | (capi.JAC_VISC_PC if viscPC else 0) | (capi.JAC_USE_AD if useAD else 0)
         self._chk(self.lib.adflow_gpu_fd_jacobian(level, flags, float(delta)))
 
     def jacobianInfo(self):

@@ -420,8 +420,12 @@ int adflow_gpu_abi_sizes2(int* bc_subface_bytes, int* comm_pattern_bytes);
  *   ADFLOW_JAC_TURB_ONLY   useTurbOnly (the turbulence KSP of ANK, NKSolvers.F90:2340-2370): nState = 1, only the SA residual
  *   ADFLOW_JAC_VISC_PC     inputAdjoint::viscPC with ADFLOW_JAC_PC: the 27-point stencil and the 3x3x3 colouring
  * delta: the finite-difference step (the reference uses 1e-9).  The state is restored afterwards, dw holds the scaled reference
- * residual (resetFDReference).  level must be the ground level. */
-enum { ADFLOW_JAC_PC = 1u, ADFLOW_JAC_FROZEN_TURB = 2u, ADFLOW_JAC_TURB_ONLY = 4u, ADFLOW_JAC_VISC_PC = 8u };
+ * residual (resetFDReference).  level must be the ground level.
+ *   ADFLOW_JAC_USE_AD      useAD = T (adjointUtils.F90:227-409): every column from ONE forward-mode evaluation (seed 1 on the state
+ *                          variable of the colour's cells, masterRoutines::block_res_state_d) instead of a finite difference: the
+ *                          exact derivative, `delta` is not used.  Dual-number twins of the gather kernels (csrc/kernels_ad.hip)
+ */
+enum { ADFLOW_JAC_PC = 1u, ADFLOW_JAC_FROZEN_TURB = 2u, ADFLOW_JAC_TURB_ONLY = 4u, ADFLOW_JAC_VISC_PC = 8u, ADFLOW_JAC_USE_AD = 16u };
 int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta);
 /* nState, nStencil and the stencil offsets (nStencil,3) column-major as src/modules/stencils.f90 of the last assembly:
  * block (ll, l) of stencil entry s at row cell (i,j,k) is  d dw(i,j,k,ll) / d w(i-di(s), j-dj(s), k-dk(s), l)  (after resScale) */

@@ -266,6 +266,20 @@ def fd_jacobian(nx, ny, nz, usePC=True, frozenTurb=False, turbOnly=False, viscPC
     return buf[:n].reshape((nx, ny, nz, ns.value, ns.value, nst.value), order="F")
 
 
+def ad_jacobian(nx, ny, nz, usePC=True, frozenTurb=False, turbOnly=False, viscPC=False):
+    """adjointUtils::setupStateResidualMatrix(useAD=T) (adjointUtils.F90:227-409) on flowDoms(1,1,1): the reference's own Tapenade
+    forward routines in the call sequence of block_res_state_d.  Returns blocks (nx, ny, nz, nState, nState, nStencil)."""
+    import ctypes
+    buf = np.zeros(nx * ny * nz * 36 * 33)
+    ns, nst = ctypes.c_int(), ctypes.c_int()
+    fn = load().ref_ad_jacobian
+    fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    fn.restype = None
+    _big_stack(fn, int(usePC), int(frozenTurb), int(turbOnly), int(viscPC), buf.ctypes.data, ctypes.byref(ns), ctypes.byref(nst))
+    n = nx * ny * nz * ns.value * ns.value * nst.value
+    return buf[:n].reshape((nx, ny, nz, ns.value, ns.value, nst.value), order="F")
+
+
 def time_block_res_core(seconds: float, update_intermed=True, flow_res=True, turb_res=True, blockette=False):
     """Repeat the blockResCore sequence (blockette = True: the default path blocketteResCore) for ~`seconds`;
     returns (evals, elapsed)."""

@@ -1056,6 +1056,284 @@ contains
     end subroutine ref_fd_jacobian
 
 
+    ! adjointUtils::setupStateResidualMatrix with useAD = T (adjointUtils.F90:227-409) on flowDoms(1, 1, 1): the loop nest of the
+    ! colours / state variables restated as in ref_fd_jacobian (the original stores through PETSc), the derivative storage of
+    ! allocDerivativeValues / zeroADSeeds (adjointUtils.F90:717-1083) restated for one block; every arithmetic routine is the
+    ! reference's OWN Tapenade output (src/adjoint/outputForward/*.f90) in the call sequence of masterRoutines::block_res_state_d
+    ! (masterRoutines.F90:1285-1393).  Needs the block committed to flowDoms (ref_alloc_doms / ref_commit_block).
+    subroutine ref_ad_jacobian(usePC, frozenTurb, turbOnly, viscPC, jac, nStateOut, nStencilOut) bind(C, name="ref_ad_jacobian")
+        use block, only: flowDoms, flowDomsd
+        use blockPointers
+        use flowVarRefState
+        use inputPhysics, only: equations, turbModel
+        use inputDiscretization, only: lumpedDiss, acousticScaleFactor, orderTurb, spaceDiscr
+        use inputAdjoint, only: viscPCopt => viscPC
+        use iteration, only: rFil, currentLevel, groundLevel, rkStage
+        use stencils
+        use utils, only: setPointers_d, setPointers
+        use flowutils_d, only: computePressureSimple_d, computeLamViscosity_d, computeSpeedOfSoundSquared_d, allNodalGradients_d
+        use turbutils_d, only: computeEddyViscosity_d, turbAdvection_d
+        use turbbcroutines_d, only: bcTurbTreatment_d, applyAllTurbBCThisBlock_d
+        use BCExtra_d, only: applyAllBC_block_d
+        use solverutils_d, only: timeStep_block_d
+        use sa_d, only: saSource_d, saViscous_d, saResScale_d, qq
+        use fluxes_d, only: inviscidCentralFlux_d, inviscidDissFluxScalar_d, inviscidDissFluxMatrix_d, inviscidUpwindFlux_d, &
+                            inviscidDissFluxScalarApprox_d, inviscidDissFluxMatrixApprox_d, viscousFlux_d, viscousFluxApprox_d
+        use adjointextra_d, only: sumDwAndFw_d, resScale_d
+        integer(c_int), value :: usePC, frozenTurb, turbOnly, viscPC
+        type(c_ptr), value :: jac
+        integer(c_int), intent(out) :: nStateOut, nStencilOut
+        external :: initialize_stencils
+        real(kind=realType), dimension(:, :, :, :, :, :), pointer :: Jm
+        real(kind=realType), dimension(:, :, :, :, :), allocatable :: dw_deriv
+        integer(kind=intType), dimension(:, :, :), allocatable :: color
+        integer(kind=intType), dimension(:, :), pointer :: stencil
+        integer(kind=intType) :: n_stencil, nColor, iColor, lStart, lEnd, nState, l, ll, i, j, k, ii, jj, kk, ist, orderTurbSave, mm
+        integer(kind=intType) :: iBeg, iStop, jBeg, jStop, qnBeg, qnStop, rnBeg, rnStop
+        real(kind=realType) :: acousticScaleSave
+        logical :: resetToRANS, viscPCSave
+
+        call initialize_stencils
+        if (turbOnly /= 0) then
+            lStart = nt1; lEnd = nt2
+        else if (frozenTurb /= 0) then
+            lStart = 1; lEnd = nwf
+        else
+            lStart = 1; lEnd = nw
+        end if
+        nState = lEnd - lStart + 1
+        rkStage = 0
+        viscPCSave = viscPCopt
+        viscPCopt = (viscPC /= 0)
+        if (usePC /= 0) then
+            if (viscous .and. viscPC /= 0) then
+                stencil => visc_pc_stencil; n_stencil = N_visc_pc
+            else
+                stencil => euler_pc_stencil; n_stencil = N_euler_pc
+            end if
+            lumpedDiss = .true.
+            acousticScaleSave = acousticScaleFactor
+            acousticScaleFactor = one
+            orderTurbSave = orderTurb
+            orderTurb = firstOrder
+        else
+            if (viscous) then
+                stencil => visc_drdw_stencil; n_stencil = N_visc_drdw
+            else
+                stencil => euler_drdw_stencil; n_stencil = N_euler_drdw
+            end if
+        end if
+        nStateOut = int(nState, c_int)
+        nStencilOut = int(n_stencil, c_int)
+        call setPointers(1_intType, 1_intType, 1_intType)
+        call c_f_pointer(jac, Jm, [nx, ny, nz, nState, nState, n_stencil])
+        Jm = zero
+        resetToRANS = .false.
+        if (frozenTurb /= 0 .and. equations == RANSEquations) then
+            equations = NSEquations
+            resetToRANS = .true.
+        end if
+
+        ! ---- allocDerivativeValues + zeroADSeeds for the one block
+        if (allocated(flowDomsd)) deallocate (flowDomsd)
+        allocate (flowDomsd(1, 1, 1))
+        if (allocated(winfd)) deallocate (winfd)
+        allocate (winfd(size(winf)))
+        winfd = zero
+        rhoinfd = zero; uinfd = zero; pinfd = zero; pinfcorrd = zero; rgasd = zero; muinfd = zero; gammainfd = zero
+        if (.not. associated(flowDoms(1, 1, 1)%d2wall)) allocate (flowDoms(1, 1, 1)%d2wall(2:il, 2:jl, 2:kl))
+        associate (D => flowDomsd(1, 1, 1))
+            allocate (D%x(0:ie, 0:je, 0:ke, 3), D%vol(0:ib, 0:jb, 0:kb), D%si(0:ie, 1:je, 1:ke, 3), D%sj(1:ie, 0:je, 1:ke, 3), &
+                      D%sk(1:ie, 1:je, 0:ke, 3), D%rotMatrixI(il, 2:jl, 2:kl, 3, 3), D%rotMatrixJ(2:il, jl, 2:kl, 3, 3), &
+                      D%rotMatrixK(2:il, 2:jl, kl, 3, 3), D%s(ie, je, ke, 3), D%sFaceI(0:ie, je, ke), D%sFaceJ(ie, 0:je, ke), &
+                      D%sFaceK(ie, je, 0:ke), D%w(0:ib, 0:jb, 0:kb, 1:nw), D%dw(0:ib, 0:jb, 0:kb, 1:nw), D%fw(0:ib, 0:jb, 0:kb, 1:nw), &
+                      D%scratch(0:ib, 0:jb, 0:kb, 5), D%p(0:ib, 0:jb, 0:kb), D%gamma(0:ib, 0:jb, 0:kb), D%aa(0:ib, 0:jb, 0:kb), &
+                      D%ux(il, jl, kl), D%uy(il, jl, kl), D%uz(il, jl, kl), D%vx(il, jl, kl), D%vy(il, jl, kl), D%vz(il, jl, kl), &
+                      D%wx(il, jl, kl), D%wy(il, jl, kl), D%wz(il, jl, kl), D%qx(il, jl, kl), D%qy(il, jl, kl), D%qz(il, jl, kl), &
+                      D%rlv(0:ib, 0:jb, 0:kb), D%rev(0:ib, 0:jb, 0:kb), D%dtl(1:ie, 1:je, 1:ke), D%radI(1:ie, 1:je, 1:ke), &
+                      D%radJ(1:ie, 1:je, 1:ke), D%radK(1:ie, 1:je, 1:ke), D%BCData(nBocos), &
+                      D%bmti1(je, ke, nt1:nt2, nt1:nt2), D%bmti2(je, ke, nt1:nt2, nt1:nt2), D%bmtj1(ie, ke, nt1:nt2, nt1:nt2), &
+                      D%bmtj2(ie, ke, nt1:nt2, nt1:nt2), D%bmtk1(ie, je, nt1:nt2, nt1:nt2), D%bmtk2(ie, je, nt1:nt2, nt1:nt2), &
+                      D%bvti1(je, ke, nt1:nt2), D%bvti2(je, ke, nt1:nt2), D%bvtj1(ie, ke, nt1:nt2), D%bvtj2(ie, ke, nt1:nt2), &
+                      D%bvtk1(ie, je, nt1:nt2), D%bvtk2(ie, je, nt1:nt2), D%d2Wall(2:il, 2:jl, 2:kl), D%viscSubface(nViscBocos))
+            D%nBocos = nBocos; D%nViscBocos = nViscBocos
+            D%x = zero; D%vol = zero; D%si = zero; D%sj = zero; D%sk = zero; D%rotMatrixI = zero; D%rotMatrixJ = zero
+            D%rotMatrixK = zero; D%s = zero; D%sFaceI = zero; D%sFaceJ = zero; D%sFaceK = zero; D%w = zero; D%dw = zero; D%fw = zero
+            D%scratch = zero; D%p = zero; D%gamma = zero; D%aa = zero; D%ux = zero; D%uy = zero; D%uz = zero; D%vx = zero; D%vy = zero
+            D%vz = zero; D%wx = zero; D%wy = zero; D%wz = zero; D%qx = zero; D%qy = zero; D%qz = zero; D%rlv = zero; D%rev = zero
+            D%dtl = zero; D%radI = zero; D%radJ = zero; D%radK = zero; D%bmti1 = zero; D%bmti2 = zero; D%bmtj1 = zero; D%bmtj2 = zero
+            D%bmtk1 = zero; D%bmtk2 = zero; D%bvti1 = zero; D%bvti2 = zero; D%bvtj1 = zero; D%bvtj2 = zero; D%bvtk1 = zero
+            D%bvtk2 = zero; D%d2Wall = zero
+            do mm = 1, nBocos
+                iBeg = BCData(mm)%icBeg; iStop = BCData(mm)%icEnd; jBeg = BCData(mm)%jcBeg; jStop = BCData(mm)%jcEnd
+                qnBeg = BCData(mm)%inBeg; qnStop = BCData(mm)%inEnd; rnBeg = BCData(mm)%jnBeg; rnStop = BCData(mm)%jnEnd
+                allocate (D%BCData(mm)%norm(iBeg:iStop, jBeg:jStop, 3), D%BCData(mm)%rface(iBeg:iStop, jBeg:jStop), &
+                          D%BCData(mm)%Fp(qnBeg + 1:qnStop, rnBeg + 1:rnStop, 3), D%BCData(mm)%Fv(qnBeg + 1:qnStop, rnBeg + 1:rnStop, 3), &
+                          D%BCData(mm)%Tp(qnBeg:qnStop, rnBeg:rnStop, 3), D%BCData(mm)%Tv(qnBeg:qnStop, rnBeg:rnStop, 3), &
+                          D%BCData(mm)%F(qnBeg:qnStop, rnBeg:rnStop, 3), D%BCData(mm)%T(qnBeg:qnStop, rnBeg:rnStop, 3), &
+                          D%BCData(mm)%area(qnBeg + 1:qnStop, rnBeg + 1:rnStop), D%BCData(mm)%uSlip(iBeg:iStop, jBeg:jStop, 3), &
+                          D%BCData(mm)%TNS_Wall(iBeg:iStop, jBeg:jStop), D%BCData(mm)%ptInlet(iBeg:iStop, jBeg:jStop), &
+                          D%BCData(mm)%htInlet(iBeg:iStop, jBeg:jStop), D%BCData(mm)%ttInlet(iBeg:iStop, jBeg:jStop), &
+                          D%BCData(mm)%turbInlet(iBeg:iStop, jBeg:jStop, nt1:nt2), D%BCData(mm)%ps(iBeg:iStop, jBeg:jStop))
+                D%BCData(mm)%norm = zero; D%BCData(mm)%rface = zero; D%BCData(mm)%Fp = zero; D%BCData(mm)%Fv = zero
+                D%BCData(mm)%Tp = zero; D%BCData(mm)%Tv = zero; D%BCData(mm)%F = zero; D%BCData(mm)%T = zero; D%BCData(mm)%area = zero
+                D%BCData(mm)%uSlip = zero; D%BCData(mm)%TNS_Wall = zero; D%BCData(mm)%ptInlet = zero; D%BCData(mm)%htInlet = zero
+                D%BCData(mm)%ttInlet = zero; D%BCData(mm)%turbInlet = zero; D%BCData(mm)%ps = zero
+            end do
+            do mm = 1, nViscBocos
+                iBeg = BCData(mm)%inBeg + 1; iStop = BCData(mm)%inEnd; jBeg = BCData(mm)%jnBeg + 1; jStop = BCData(mm)%jnEnd
+                allocate (D%viscSubface(mm)%tau(iBeg:iStop, jBeg:jStop, 6), D%viscSubface(mm)%q(iBeg:iStop, jBeg:jStop, 6))
+                D%viscSubface(mm)%tau = zero; D%viscSubface(mm)%q = zero
+            end do
+        end associate
+        call setPointers_d(1_intType, 1_intType, 1_intType)
+
+        allocate (dw_deriv(2:il, 2:jl, 2:kl, nw, nw), color(0:ib, 0:jb, 0:kb))
+        if (usePC /= 0) call shock_sensor_ad
+        do k = 0, kb
+            do j = 0, jb
+                do i = 0, ib
+                    if (usePC /= 0) then
+                        if (viscous .and. viscPC /= 0) then
+                            color(i, j, k) = mod(i, 3) + 3 * mod(j, 3) + 9 * mod(k, 3) + 1
+                        else
+                            color(i, j, k) = mod(i + 5 * j + 4 * k, 7) + 1
+                        end if
+                    else if (viscous) then
+                        color(i, j, k) = mod(i + 19 * j + 11 * k, 35) + 1
+                    else
+                        color(i, j, k) = mod(i + 3 * j + 4 * k, 13) + 1
+                    end if
+                end do
+            end do
+        end do
+        if (usePC /= 0 .and. .not. (viscous .and. viscPC /= 0)) nColor = 7
+        if (usePC /= 0 .and. viscous .and. viscPC /= 0) nColor = 27
+        if (usePC == 0 .and. viscous) nColor = 35
+        if (usePC == 0 .and. .not. viscous) nColor = 13
+
+        if (equations == RANSEquations .and. .not. allocated(qq)) allocate (qq(2:il, 2:jl, 2:kl))
+        do iColor = 1, nColor
+            dw_deriv = zero
+            do l = lStart, lEnd
+                wd = zero
+                do k = 0, kb
+                    do j = 0, jb
+                        do i = 0, ib
+                            if (color(i, j, k) == iColor) wd(i, j, k, l) = one
+                        end do
+                    end do
+                end do
+                call res_state_d
+                do ll = lStart, lEnd
+                    dw_deriv(:, :, :, ll, l) = dwd(2:il, 2:jl, 2:kl, ll)
+                end do
+            end do
+            do k = 0, kb
+                do j = 0, jb
+                    do i = 0, ib
+                        if (color(i, j, k) /= iColor) cycle
+                        do ist = 1, n_stencil
+                            ii = stencil(ist, 1); jj = stencil(ist, 2); kk = stencil(ist, 3)
+                            if (i + ii >= 2 .and. i + ii <= il .and. j + jj >= 2 .and. j + jj <= jl .and. &
+                                k + kk >= 2 .and. k + kk <= kl) then
+                                Jm(i + ii - 1, j + jj - 1, k + kk - 1, :, :, ist) = &
+                                    dw_deriv(i + ii, j + jj, k + kk, lStart:lEnd, lStart:lEnd)
+                            end if
+                        end do
+                    end do
+                end do
+            end do
+        end do
+        if (allocated(qq)) deallocate (qq)
+        if (usePC /= 0) then
+            lumpedDiss = .false.
+            acousticScaleFactor = acousticScaleSave
+            orderTurb = orderTurbSave
+        end if
+        viscPCopt = viscPCSave
+        if (resetToRANS) equations = RANSEquations
+        deallocate (dw_deriv, color)
+    contains
+        subroutine res_state_d                      ! masterRoutines.F90:1319-1392
+            call computePressureSimple_d(.true.)
+            call computeLamViscosity_d(.true.)
+            call computeEddyViscosity_d(.true.)
+            if (equations == RANSEquations) then
+                call bcTurbTreatment_d
+                call applyAllTurbBCThisBlock_d(.true.)
+            end if
+            call applyAllBC_block_d(.true.)
+            rFil = one
+            call timeStep_block_d(.false.)
+            dw = zero
+            dwd = zero
+            if (equations == RANSEquations) then
+                if (turbModel == spalartAllmaras) then
+                    call saSource_d
+                    call turbAdvection_d(1_intType, 1_intType, itu1 - 1, qq)
+                    call saViscous_d
+                    call saResScale_d
+                end if
+            end if
+            call inviscidCentralFlux_d
+            if (lumpedDiss) then
+                select case (spaceDiscr)
+                case (dissScalar); call inviscidDissFluxScalarApprox_d
+                case (dissMatrix); call inviscidDissFluxMatrixApprox_d
+                case (upwind); call inviscidUpwindFlux_d(.true.)
+                end select
+            else
+                select case (spaceDiscr)
+                case (dissScalar); call inviscidDissFluxScalar_d
+                case (dissMatrix); call inviscidDissFluxMatrix_d
+                case (upwind); call inviscidUpwindFlux_d(.true.)
+                end select
+            end if
+            if (viscous) then
+                call computeSpeedOfSoundSquared_d
+                if (.not. lumpedDiss .or. viscPCopt) then
+                    call allNodalGradients_d
+                    call viscousFlux_d
+                else
+                    call viscousFluxApprox_d
+                end if
+            end if
+            call sumDwAndFw_d
+            call resScale_d
+        end subroutine res_state_d
+
+        subroutine shock_sensor_ad                  ! referenceShockSensor, adjointUtils.F90:1925-1966
+            integer(kind=intType) :: i, j, k
+            if (equations == EulerEquations .or. spaceDiscr == dissMatrix) then
+                shockSensor(0:ib, 0:jb, 0:kb) = p(0:ib, 0:jb, 0:kb)
+            else
+                do k = 0, kb
+                    do j = 2, jl
+                        do i = 2, il
+                            shockSensor(i, j, k) = p(i, j, k) / (w(i, j, k, irho)**gamma(i, j, k))
+                        end do
+                    end do
+                end do
+                do k = 2, kl
+                    do j = 2, jl
+                        do i = 0, ib
+                            if (i > 1 .and. i < ie) cycle
+                            shockSensor(i, j, k) = p(i, j, k) / (w(i, j, k, irho)**gamma(i, j, k))
+                        end do
+                    end do
+                    do i = 2, il
+                        do j = 0, jb
+                            if (j > 1 .and. j < je) cycle
+                            shockSensor(i, j, k) = p(i, j, k) / (w(i, j, k, irho)**gamma(i, j, k))
+                        end do
+                    end do
+                end do
+            end if
+        end subroutine shock_sensor_ad
+    end subroutine ref_ad_jacobian
+
+
     ! ===================================================================
     ! multi-block mode: the reference's SHELL routines (smoothers, halo
     ! exchange, multigrid) loop over flowDoms(nn,level,sps) and re-aim

@@ -297,6 +297,38 @@ def check_fd_jacobian(engine, dims, prm, spec, usePC=True, frozenTurb=False, use
     return Jg, Jr, st
 
 
+def check_ad_jacobian(engine, dims, prm, spec, usePC=True, frozenTurb=False, useTurbOnly=False, viscPC=False, tol=1e-10, seed=103, **mk):
+    """adflow_gpu_fd_jacobian(ADFLOW_JAC_USE_AD) vs adjointUtils::setupStateResidualMatrix(useAD = T) (adjointUtils.F90:227-409):
+    every stencil block of ONE block with six physical boundary faces, the reference side being its own Tapenade forward routines
+    (src/adjoint/outputForward) in the call sequence of block_res_state_d (oracle/refbuild/ref_driver.F90:ref_ad_jacobian).  Both
+    sides are exact derivatives: the tolerance is the residual's 1e-10, relative to the largest entry -- and, for RANS, of the
+    mean-flow blocks against their own scale.  Also: the assembly leaves state and residual of the level untouched."""
+    from oracle import ref
+    blk, r, prm = setup_block_with_bc(engine, dims, prm, spec, seed, **mk)
+    Jr = ref.ad_jacobian(blk.nx, blk.ny, blk.nz, usePC, frozenTurb, useTurbOnly, viscPC)
+    w0 = blk["w"].copy(order="F")
+    engine.download_state(1, 1)
+    w_before = blk["w"].copy(order="F")
+    engine.setupStateResidualMatrix(1, usePC, frozenTurb, useTurbOnly, viscPC, useAD=True)
+    ns, st = engine.jacobianInfo()
+    Jg = engine.jacobianBlocks(1, 1)
+    assert Jg.shape == Jr.shape, (Jg.shape, Jr.shape)
+    scale = np.abs(Jr).max()
+    assert scale > 0.0
+    err = np.abs(Jg - Jr).max() / scale
+    assert err <= tol, (err, tol, np.unravel_index(np.abs(Jg - Jr).argmax(), Jr.shape))
+    if ns == 6:
+        scf = np.abs(Jr[..., :5, :5, :]).max()
+        errf = np.abs(Jg[..., :5, :5, :] - Jr[..., :5, :5, :]).max() / scf
+        assert errf <= tol, ("mean-flow blocks", errf, tol)
+    n_ref = sum(np.abs(Jr[..., s]).max() > 1e-7 * scale for s in range(st.shape[0]))
+    assert sum(np.abs(Jg[..., s]).max() > 1e-7 * scale for s in range(st.shape[0])) == n_ref >= 1
+    engine.download_state(1, 1)
+    assert rel_err(blk["w"], w_before) <= 1e-14        # forward mode perturbs nothing (whalo2 in front re-forms the owned energy)
+    blk["w"][...] = w0
+    return Jg, Jr, st
+
+
 def check_rk_residual_sequence(engine, dims, prm, seed=3, **mk):
     """residual() inside the RK smoother: rFil = cdisRK(stage+1) with the
     dissipation residual fw PERSISTENT between stages (residuals.F90:61-65,

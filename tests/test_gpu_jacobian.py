@@ -46,6 +46,54 @@ def test_exact_drdw(engine):
                              usePC=False, stretch_k=2.0)
 
 
+# ---- forward-mode assembly (useAD = T, adjointUtils.F90:227-409) against the reference's own Tapenade routines ---------------------
+FAR = {1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -6}      # Euler: farfield, an inviscid wall, a symmetry plane
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_ad_pc(engine, sd):
+    """the preconditioner matrix by forward mode (ADPC): Euler and RANS-SA, every discretisation.  The Euler case keeps the
+    extrapolation / supersonic-outflow faces: applyAllBC_block_d does not linearise them (BCExtra_d.F90) and neither does the
+    library (their halos keep value and seed)"""
+    checks.check_ad_jacobian(engine, (12, 9, 7), FlowParams(spaceDiscr=sd, limiter=vanAlbeda), EULER)
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=sd, limiter=vanAlbeda, orderTurb=secondOrder, acousticScaleFactor=0.5,
+                      vis4=0.1 if sd == dissMatrix else 0.0156)
+    checks.check_ad_jacobian(engine, (12, 8, 6), rans, WALL, stretch_k=2.0)
+
+
+@pytest.mark.parametrize("sd", [dissScalar, dissMatrix, upwind])
+def test_ad_exact_drdw(engine, sd):
+    """the exact dR/dw by forward mode (the adjoint's matrix): 13 / 35 colours, spectral radii, pressure / entropy sensors, limiters,
+    nodal gradients and the full viscous flux linearised.  (No extrapolation faces here: a linear extrapolation puts the pressure
+    sensor of the boundary cells exactly on the kink of abs(), where the sign of the derivative is the sign of a rounding error)"""
+    checks.check_ad_jacobian(engine, (9, 8, 7), FlowParams(spaceDiscr=sd, limiter=vanAlbeda), FAR, usePC=False)
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=sd, limiter=vanAlbeda, vis4=0.1 if sd == dissMatrix else 0.0156)
+    checks.check_ad_jacobian(engine, (8, 7, 6), rans, WALL, usePC=False, stretch_k=2.0)
+
+
+def test_ad_variants(engine):
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=minmod)
+    checks.check_ad_jacobian(engine, (10, 7, 6), rans, WALL, frozenTurb=True, stretch_k=2.0)
+    checks.check_ad_jacobian(engine, (10, 7, 6), rans, WALL, useTurbOnly=True, stretch_k=2.0)
+    checks.check_ad_jacobian(engine, (8, 7, 6), rans.replace(spaceDiscr=dissScalar), WALL, viscPC=True, stretch_k=2.0)
+    checks.check_ad_jacobian(engine, (8, 7, 6), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, vis4=0.1), WALL, usePC=False,
+                             stretch_k=2.0)
+    checks.check_ad_jacobian(engine, (9, 8, 6), rans.replace(limiter=vanAlbeda, useQCR=True), OPEN, usePC=False, stretch_k=2.0)
+
+
+def test_ad_agrees_with_finite_differences(engine):
+    """the two assemblies of the library against each other on a 24 x 16 x 12 RANS block (several workgroups per direction): the
+    forward-mode blocks equal the finite-difference ones to the truncation error of the difference"""
+    import numpy as np
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda)
+    checks.setup_block_with_bc(engine, (24, 16, 12), rans, WALL, 105, stretch_k=2.0)
+    engine.setupStateResidualMatrix(1, True, useAD=True)
+    Ja = engine.jacobianBlocks(1, 1).copy()
+    engine.setupStateResidualMatrix(1, True, delta=1e-6)
+    Jf = engine.jacobianBlocks(1, 1)
+    assert np.abs(Ja[..., :5, :5, :] - Jf[..., :5, :5, :]).max() <= 1e-5 * np.abs(Ja[..., :5, :5, :]).max()
+
+
 def test_reference_step(engine):
     """delta = 1e-9 as the reference: rounding differences of two correct residuals are amplified by 1e9, so only ~1e-6 of the
     largest entry is resolvable by ANY implementation (the reference against itself with another compiler flag included)"""

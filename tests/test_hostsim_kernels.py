@@ -455,6 +455,14 @@ def test_fd_jacobian_exact(hostsim_engine):
     checks.check_fd_jacobian(hostsim_engine, (6, 5, 4), FlowParams(spaceDiscr=upwind, limiter=minmod), _JAC_EULER, delta=1e-9, tol=1e-5)
 
 
+def test_ad_jacobian(hostsim_engine):
+    """forward-mode assembly: the dual-number twins of the gather kernels (kernels_ad.hip) against the reference's Tapenade routines"""
+    import test_gpu_jacobian as tj
+    tj.test_ad_pc(hostsim_engine, upwind)
+    tj.test_ad_exact_drdw(hostsim_engine, dissScalar)
+    tj.test_ad_variants(hostsim_engine)
+
+
 def test_update_wall_distances_quickly(hostsim_engine):
     checks.check_wall_distance(hostsim_engine, (7, 5, 4), FlowParams(equations=RANSEquations), stretch_k=2.0)
 
