@@ -384,6 +384,66 @@ __global__ __launch_bounds__(64) void k_sa_solve_i(const BlkView* __restrict__ t
 }
 
 
+#ifndef ADF_AD_BUILD
+// Round 4: the i direction of the DDADI solve as parallel cyclic reduction along the lanes (the scheme of k_dadi_i_pcr,
+// kernels_smooth.hip): a workgroup of NW wavefronts holds one i line, every lane one row  bb x(i-1) + qq x(i) + dd x(i+1) = rhs,
+// normalised by its diagonal; ceil(log2 nx) reduction steps through LDS, then the right-hand side of the k sweep rhs = x qq.
+// One coalesced read of (bb, qq, dd, rhs) and one write of rhs per cell instead of the transposing tiles (counted 133 B per cell).
+#define SP_JL 8
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_sa_i_pcr(const BlkView* __restrict__ tab)
+{
+    constexpr int T = 64 * NW;
+    __shared__ double P[2 * 3 * T];
+    const BlkView& b = tab[blockIdx.z + 1];
+    const int t = threadIdx.x, n = b.nx;
+    const int k = blockIdx.y + 2;
+    const int j0 = blockIdx.x * SP_JL + 2;
+    if (b.nx == 0 || k > b.kl || j0 > b.jl || n > T) return;        // uniform per workgroup
+    const bool act = t < n;
+    const int tc = act ? t : n - 1;
+    const long nb = b.nbox;
+    double* __restrict__ rhs = b.scratch;
+    const double* __restrict__ qqA = b.scratch + nb;
+    const double* __restrict__ bbA = b.scratch + 5 * nb;
+    const double* __restrict__ ddA = b.scratch + 6 * nb;
+    for (int jl_ = 0; jl_ < SP_JL; ++jl_) {
+        const int j = j0 + jl_;
+        if (j > b.jl) break;                                         // uniform
+        const long c = b.idx(2 + tc, j, k);
+        const double qq = qqA[c];
+        const double inv = rcp_nr(qq);
+        double a = (act && t > 0) ? bbA[c] * inv : 0.0;
+        double cc = (act && t < n - 1) ? ddA[c] * inv : 0.0;
+        double d = act ? rhs[c] * inv : 0.0;
+        int cur_ = 0;
+        for (int st = 1; st < n; st <<= 1) {
+            double* __restrict__ Q = P + cur_ * 3 * T;
+            Q[t] = a; Q[T + t] = cc; Q[2 * T + t] = d;
+            __syncthreads();
+            const bool lo = t >= st, hi = t + st < n;
+            const int im = lo ? t - st : t, ip = hi ? t + st : t;
+            const double am = lo ? Q[im] : 0.0, cm = lo ? Q[T + im] : 0.0, dm = lo ? Q[2 * T + im] : 0.0;
+            const double ap = hi ? Q[ip] : 0.0, cp = hi ? Q[T + ip] : 0.0, dp = hi ? Q[2 * T + ip] : 0.0;
+            const double al = -a, ga = -cc;
+            const double iv = rcp_nr(1.0 + al * cm + ga * ap);
+            d = (d + al * dm + ga * dp) * iv;
+            a = al * am * iv;
+            cc = ga * cp * iv;
+            cur_ ^= 1;
+        }
+        if (act) rhs[c] = d * qq;
+        __syncthreads();
+    }
+}
+
+template <int NW>
+static void launch_sa_i_pcr(const BlkView* tab, int nslots, int ny, int nz, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_sa_i_pcr<NW>), dim3((ny + SP_JL - 1) / SP_JL, nz, nslots), dim3(64 * NW, 1, 1), 0, s, tab);
+}
+#endif
+
 // marchRes: residual, right-hand side and central jacobian were left by the k-marching kernel (launch_sa_march, blocks at rest);
 // otherwise the gather kernel forms them here
 void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int nz, const KParams& kp, hipStream_t s, bool marchRes)
@@ -397,7 +457,15 @@ void launch_sa_solve_level(const BlkView* tab, int nslots, int nx, int ny, int n
     if (marchRes) {
         // the marching kernel left the off-diagonals of all three directions beside the right-hand side and the central jacobian
         hipLaunchKernelGGL((k_sa_sweep<1, true>), dim3((nx + 63) / 64, nz, nslots), l64, 0, s, tab, kp, 0);
-        hipLaunchKernelGGL((k_sa_solve_i<true>), dim3((ny + 63) / 64, nz, nslots), l64, 0, s, tab);
+#ifndef ADF_AD_BUILD
+        if (g_dadi_pcr && nx <= 256) {
+            if (nx <= 64) launch_sa_i_pcr<1>(tab, nslots, ny, nz, s);
+            else if (nx <= 128) launch_sa_i_pcr<2>(tab, nslots, ny, nz, s);
+            else if (nx <= 192) launch_sa_i_pcr<3>(tab, nslots, ny, nz, s);
+            else launch_sa_i_pcr<4>(tab, nslots, ny, nz, s);
+        } else
+#endif
+            hipLaunchKernelGGL((k_sa_solve_i<true>), dim3((ny + 63) / 64, nz, nslots), l64, 0, s, tab);
         hipLaunchKernelGGL((k_sa_sweep<2, true>), dim3((nx + 63) / 64, ny, nslots), l64, 0, s, tab, kp, 0);
         return;
     }

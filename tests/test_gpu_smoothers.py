@@ -115,6 +115,9 @@ def test_dadi_i_direction_by_cyclic_reduction(engine):
     for nx, ny, nz in ((70, 5, 4), (130, 9, 3), (200, 3, 5), (9, 8, 7)):
         checks.check_dadi_smoother(engine, BrickTopology(1, 1, 1, nx, ny, nz), prm, stretch_k=2.0)
     checks.check_dadi_smoother(engine, BrickTopology(1, 2, 1, 1, 6, 5), FlowParams(resAveraging=noResAveraging, cfl=1.5, nSubiterations=2))
+    # the same scheme in the i direction of the SA DDADI solve (k_sa_i_pcr)
+    for nx, ny, nz in ((70, 5, 4), (130, 9, 3), (200, 3, 5), (9, 8, 7)):
+        checks.check_sa_solve(engine, BrickTopology(1, 1, 1, nx, ny, nz), prm.replace(nSubIterTurb=2), stretch_k=2.0)
     try:
         engine.set_tuning("dadi_pcr", 0)
         checks.check_dadi_smoother(engine, BrickTopology(1, 1, 1, 130, 9, 3), prm, stretch_k=2.0)
