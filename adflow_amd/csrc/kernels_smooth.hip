@@ -660,6 +660,81 @@ __global__ __launch_bounds__(256) void k_ra_line_i(const BlkView* __restrict__ t
         }
 }
 
+// Round 4: residual averaging along i by parallel cyclic reduction along the lanes (the scheme of k_dadi_i_pcr below): a workgroup of
+// NW wavefronts holds one i line, lane m the row  -epz(m-1) x(m-1) + (1 + epz(m) + epz(m-1)) x(m) - epz(m) x(m+1) = dw(m)  of the five
+// equations (one coefficient set), normalised by its diagonal; ceil(log2 nx) steps through LDS, all lanes busy, coalesced row
+// accesses and no transposition: one read and one write of dw.  k_ra_line_i keeps the lines of more than 256 cells.
+#define RP_JL 8
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_ra_i_pcr(const BlkView* __restrict__ tab, KParams kp, double scaleDtl)
+{
+    constexpr int T = 64 * NW;
+    __shared__ double P[2 * 7 * T];
+    const BlkView& b = tab[blockIdx.z + 1];
+    const int t = threadIdx.x, n = b.nx;
+    const int k = blockIdx.y + 2;
+    const int j0 = blockIdx.x * RP_JL + 2;
+    if (b.nx == 0 || k > b.kl || j0 > b.jl || n <= 1 || n > T) return;        // uniform per workgroup
+    const bool act = t < n;
+    const int tc = act ? t : n - 1;
+    const long nb = b.nbox;
+    const double rfl0 = 0.5 * kp.cfl / kp.cflLimit;
+    const double* __restrict__ R = b.scratch;
+    for (int jl_ = 0; jl_ < RP_JL; ++jl_) {
+        const int j = j0 + jl_;
+        if (j > b.jl) break;                                         // uniform
+        const long c = b.idx(2 + tc, j, k);
+        const double sc = (scaleDtl != 0.0) ? scaleDtl * b.dtl[c] : 1.0;
+        double d[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) d[q] = act ? b.dw[c + q * nb] * sc : 0.0;
+        // epz(m) lives between the cells m and m+1 (0 beyond the line ends)
+        const double r0 = R[c], rp = R[c + 1], rm = R[c - 1];
+        double epz = 0.0, epzm = 0.0;
+        if (act && t < n - 1) { const double r = rfl0 * (r0 + rp); epz = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * flg_blank(b.flags[c]); }
+        if (act && t > 0) { const double r = rfl0 * (rm + r0); epzm = 0.25 * kp.smoop * fmax(r * r - 1.0, 0.0) * flg_blank(b.flags[c - 1]); }
+        const double inv = rcp_nr(1.0 + epz + epzm);
+        double a = -epzm * inv, cc = -epz * inv;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) d[q] *= inv;
+        int cur_ = 0;
+        for (int st = 1; st < n; st <<= 1) {
+            double* __restrict__ Q = P + cur_ * 7 * T;
+            Q[t] = a; Q[T + t] = cc;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Q[(2 + q) * T + t] = d[q];
+            __syncthreads();
+            const bool lo = t >= st, hi = t + st < n;
+            const int im = lo ? t - st : t, ip = hi ? t + st : t;
+            const double am = lo ? Q[im] : 0.0, cm = lo ? Q[T + im] : 0.0;
+            const double ap = hi ? Q[ip] : 0.0, cp = hi ? Q[T + ip] : 0.0;
+            const double al = -a, ga = -cc;
+            const double iv = rcp_nr(1.0 + al * cm + ga * ap);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const double dm = lo ? Q[(2 + q) * T + im] : 0.0, dp = hi ? Q[(2 + q) * T + ip] : 0.0;
+                d[q] = (d[q] + al * dm + ga * dp) * iv;
+            }
+            a = al * am * iv;
+            cc = ga * cp * iv;
+            cur_ ^= 1;
+        }
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) b.dw[c + q * nb] = d[q];
+        }
+        __syncthreads();
+    }
+}
+
+template <int NW>
+static void launch_ra_i_pcr(const BlkView* tab, int nslots, int ny, int nz, const KParams& kp, double scaleDtl, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_ra_i_pcr<NW>), dim3((ny + RP_JL - 1) / RP_JL, nz, nslots), dim3(64 * NW, 1, 1), 0, s, tab, kp, scaleDtl);
+}
+
+int g_ra_pcr = 1;        // tuning "ra_pcr": residual averaging along i by cyclic reduction (0: LDS-resident lines / two-pass kernels)
+
 // scaleDtl != 0: only for levels whose blocks all have more than one cell in i (the scaling rides on the i sweep)
 void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s,
                                 double scaleDtl)
@@ -670,7 +745,12 @@ void launch_res_averaging_level(const BlkView* tab, int nslots, int maxnx, int m
                        dim3(SM_BX, SM_BY, 1), 0, s, tab, kp, maxnz);
     const dim3 blk(64, 1, 1);
     const dim3 blk5(64, 5, 1);        // 64 lines x 5 equations
-    if (maxnx > 1) {
+    if (maxnx > 1 && maxnx <= 256 && g_ra_pcr) {
+        if (maxnx <= 64) launch_ra_i_pcr<1>(tab, nslots, maxny, maxnz, kp, scaleDtl, s);
+        else if (maxnx <= 128) launch_ra_i_pcr<2>(tab, nslots, maxny, maxnz, kp, scaleDtl, s);
+        else if (maxnx <= 192) launch_ra_i_pcr<3>(tab, nslots, maxny, maxnz, kp, scaleDtl, s);
+        else launch_ra_i_pcr<4>(tab, nslots, maxny, maxnz, kp, scaleDtl, s);
+    } else if (maxnx > 1) {
         // i lines resident in LDS while at least two of them fit the buffer; longer lines: the two-pass kernels
         const int P = ((maxnx + RL_C - 1) & ~(RL_C - 1)) + 1;          // whole chunks, odd (LDS banks)
         const int fit = RL_BUF / (7 * P), NL = fit < 16 ? fit : 16;

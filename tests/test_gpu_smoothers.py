@@ -65,6 +65,16 @@ def test_res_averaging_line_bundles(engine):
     checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 1340, 2, 1), prm)
     checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 2, 1040, 3), prm)
     checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 3, 2, 1040), prm)
+    # the i direction by cyclic reduction (k_ra_i_pcr, lines up to 256 cells: 1 .. 4 wavefronts per line); ra_pcr = 0: the
+    # LDS-resident lines on the same cases
+    for nx in (130, 200, 250):
+        checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, nx, 5, 4), prm, holes=0.05)
+    try:
+        engine.set_tuning("ra_pcr", 0)
+        checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 70, 37, 19), prm, holes=0.05)
+        checks.check_rk_smoother(engine, BrickTopology(1, 1, 1, 130, 5, 4), prm, holes=0.05)
+    finally:
+        engine.set_tuning("ra_pcr", 1)
 
 
 def test_rk_smoother_multiblock_tutorial_wing_size(engine):
