@@ -11,6 +11,13 @@ module adflowGpuShim
     use constants
     implicit none
 
+    ! ---- flag bits of adflow_gpu_block_res / adflow_gpu_fd_jacobian (include/adflow_gpu.h) ----
+    integer(c_int), parameter :: ADFLOW_RES_UPDATE_INTERMED = 1, ADFLOW_RES_FLOW = 2, ADFLOW_RES_TURB = 4, ADFLOW_RES_CLOSURES = 8, &
+                                 ADFLOW_RES_HALO = 16, ADFLOW_RES_DISS_APPROX = 32, ADFLOW_RES_VISC_APPROX = 64, &
+                                 ADFLOW_RES_UPWIND_FIRST_ORDER = 128
+    integer(c_int), parameter :: ADFLOW_JAC_PC = 1, ADFLOW_JAC_FROZEN_TURB = 2, ADFLOW_JAC_TURB_ONLY = 4, ADFLOW_JAC_VISC_PC = 8, &
+                                 ADFLOW_JAC_USE_AD = 16
+
     ! ---- mirror of adflow_opts (include/adflow_gpu.h) -----------------------
     type, bind(C) :: adflow_opts
         integer(c_int32_t) :: equations, turbModel, turbProd
@@ -270,7 +277,8 @@ module adflowGpuShim
             character(kind=c_char), intent(in) :: key(*)
             integer(c_int), value :: value
         end function
-        ! adjointUtils::setupStateResidualMatrix (useAD = F): coloured finite-difference blocks on the device
+        ! adjointUtils::setupStateResidualMatrix: coloured finite-difference blocks (useAD = F) or, with ADFLOW_JAC_USE_AD, the
+        ! forward-mode blocks of useAD = T (adjointUtils.F90:227-409), on the device
         integer(c_int) function adflow_gpu_fd_jacobian(level, flags, delta) bind(C, name="adflow_gpu_fd_jacobian")
             import :: c_int, c_double
             integer(c_int), value :: level, flags
