@@ -28,9 +28,14 @@ def main():
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     prm = FlowParams(equations=RANSEquations)
     dims = (6, 5, 4)
+    periodic = (True, True, True)
     if mode == "strong":      # bench.py --scaling strong: ONE 2x2x2 brick, nb / N blocks per rank, contiguous in k
         shape = (2, 2, 2)
         topo = BrickTopology(*shape, *dims, owner=lambda g: (g * world) // 8)
+    elif mode == "wall":      # bench.py's default workload at N = 2 (weak): 2 x 1 x 1 ranks, each a 2x2x2 brick, the ends of the whole
+        shape = (4, 2, 2)     # 4x2x2 brick physical boundaries (no pattern entry beyond them), 1-to-1 interfaces inside
+        periodic = (False, False, False)
+        topo = BrickTopology(*shape, *dims, owner=lambda g: (g % 4) // 2, periodic=periodic)
     else:
         shape = (2, 2, 1)
         topo = BrickTopology(*shape, *dims, owner=lambda g: g % world)
@@ -38,7 +43,7 @@ def main():
     # every rank can rebuild every block (seeded): expected halos come from the
     # single-rank version of the same topology
     allb = {g: make_block(*dims, prm, seed=50 + g, stretch_k=2.0) for g in range(topo.nblocks)}
-    single = BrickTopology(*shape, *dims)
+    single = BrickTopology(*shape, *dims, periodic=periodic)
     exp = {single.local_ids()[g]: allb[g].copy() for g in range(topo.nblocks)}
     apply_local_copies_fast(exp, single.patterns(nLayers)[0])
     mine = {lid[g]: allb[g] for g in topo.blocks_of(rank)}

@@ -1,3 +1,2 @@
-export GIT=68d5ecc TAG=r04_m
-bash tools/_gpu_job_full.sh
-bash tools/_gpu_job_sq.sh
+export GIT=2fe1163 TAG=r04_n EXTRAS="config3" ROWS=14
+bash tools/_gpu_job_pmc_extras.sh
