@@ -546,8 +546,14 @@ __global__ __launch_bounds__(256) void k_turb_bc_treatment(BC_ARGS, KParams kp)
     case ADFLOW_BC_NSWALL_ADIABATIC: case ADFLOW_BC_NSWALL_ISOTHERMAL:
         b.bmt[fi][e] = 1.0;
         break;
-    case ADFLOW_BC_SYMM: case ADFLOW_BC_SYMM_POLAR: case ADFLOW_BC_EULERWALL: case ADFLOW_BC_SUPERSONIC_OUTFLOW: case ADFLOW_BC_EXTRAP:
-    case ADFLOW_BC_SUBSONIC_OUTFLOW: case ADFLOW_BC_MASSBLEED_OUTFLOW:
+    case ADFLOW_BC_SYMM: case ADFLOW_BC_SYMM_POLAR: case ADFLOW_BC_EULERWALL:
+        b.bmt[fi][e] = -1.0;
+        break;
+#ifndef ADF_AD_BUILD
+    // The in- and outflow kinds (bcTurbInflow / bcTurbOutflow) stand inside `#ifndef USE_TAPENADE` in the reference
+    // (turbBCRoutines.F90:743-763): its forward-mode code leaves bmt = bvt = 0 on those subfaces -- the halo takes nuTilde = 0 with
+    // a zero derivative.  The dual build (kernels_ad.hip) reproduces that.
+    case ADFLOW_BC_SUPERSONIC_OUTFLOW: case ADFLOW_BC_EXTRAP: case ADFLOW_BC_SUBSONIC_OUTFLOW: case ADFLOW_BC_MASSBLEED_OUTFLOW:
         b.bmt[fi][e] = -1.0;
         break;
     case ADFLOW_BC_SUPERSONIC_INFLOW: case ADFLOW_BC_SUBSONIC_INFLOW:     // bcTurbInflow (turbBCRoutines.F90:460-515)
@@ -556,6 +562,7 @@ __global__ __launch_bounds__(256) void k_turb_bc_treatment(BC_ARGS, KParams kp)
             b.bmt[fi][e] = 1.0;
         }
         break;
+#endif
     case ADFLOW_BC_FARFIELD: {
         const double dot = f.norm[t] * kp.wInf[1] + f.norm[t + n] * kp.wInf[2] + f.norm[t + 2 * n] * kp.wInf[3] -
                            (f.rface ? f.rface[t] : 0.0);

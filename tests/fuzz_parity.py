@@ -65,8 +65,8 @@ def draw_case(rng, huge=False):
         mk["holes"] = 0.05
     if rng.random() < 0.15:
         mk["left_handed"] = True
-    entry = str(rng.choice(["block_res", "blockette", "blockette_intermed", "approx", "bc", "rk", "dadi", "sa_solve", "nk"],
-                           p=[0.3, 0.1, 0.1, 0.1, 0.15, 0.07, 0.06, 0.06, 0.06]))
+    entry = str(rng.choice(["block_res", "blockette", "blockette_intermed", "approx", "bc", "rk", "dadi", "sa_solve", "nk", "full_bc", "ad"],
+                           p=[0.22, 0.08, 0.08, 0.08, 0.12, 0.08, 0.08, 0.06, 0.06, 0.09, 0.05]))
     if huge:
         entry = str(rng.choice(["block_res", "blockette", "blockette_intermed"]))
     if entry == "bc":
@@ -74,10 +74,36 @@ def draw_case(rng, huge=False):
         mk["spec"] = {f: int(rng.choice(kinds)) for f in range(1, 7)}
         mk["secondHalo"] = bool(rng.random() < 0.6)
         mk.pop("left_handed", None)
+    if entry == "full_bc":
+        # round 4: the whole blocketteRes on a brick whose ends are physical boundaries (closures, BCs, whalo2, core, wall stress)
+        kinds = [-1, -5, -6, -15] if eq == EulerEquations else [-1, -3, -4, -6, -15]
+        wide = rng.random() < 0.25
+        mk = dict(seed=mk["seed"], topo=(int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 3)),
+                                       int(rng.choice([61, 70, 125])) if wide else int(rng.integers(3, 14)), int(rng.integers(3, 9)),
+                                       int(rng.integers(3, 8))),
+                  spec={f: int(rng.choice(kinds)) for f in range(1, 7)}, floor_p=bool(eq != RANSEquations and rng.random() < 0.2),     # (RANS with floored pressures: the reference itself yields NaN)
+                  split_eval=(2 if rng.random() < 0.3 else None))
+        if rng.random() < 0.5:
+            mk["stretch_k"] = 2.0
+        if "dirScaling" in kw:
+            kw["dirScaling"] = True     # (blocketteResCore, the reference of this entry, scales the dissipation unconditionally)
+    if entry == "ad":
+        # round 4: forward-mode assembly against the reference's Tapenade routines (no extrapolation faces under the exact
+        # linearisation: DESIGN 5)
+        usePC = bool(rng.random() < 0.6)
+        kinds = ([-1, -5, -6] if eq == EulerEquations else [-1, -3, -4, -6]) + ([-15, -9] if usePC else [])
+        mk = dict(seed=mk["seed"], spec={f: int(rng.choice(kinds)) for f in range(1, 7)}, usePC=usePC,
+                  frozenTurb=bool(eq == RANSEquations and rng.random() < 0.2))
+        nx, ny, nz = int(rng.integers(3, 9)), int(rng.integers(3, 7)), int(rng.integers(3, 6))
+        if eq != EulerEquations:
+            mk["stretch_k"] = 2.0
     if entry in ("rk", "dadi", "sa_solve", "nk"):
-        # periodic bricks of 1 - 2 blocks; even cell counts are not needed on a single grid
+        # periodic bricks of 1 - 2 blocks; even cell counts are not needed on a single grid.  One case in four with i lines of more
+        # than one wavefront (the cyclic-reduction kernels of round 4)
+        wide = rng.random() < 0.25 and entry != "nk"
         mk = dict(seed=mk["seed"], topo=(int(rng.integers(1, 3)), int(rng.integers(1, 3)), 1,
-                                       int(rng.integers(3, 20)), int(rng.integers(3, 10)), int(rng.integers(3, 9))))
+                                       int(rng.choice([65, 70, 129, 190, 250])) if wide else int(rng.integers(3, 20)),
+                                       int(rng.integers(3, 10)), int(rng.integers(3, 9))))
         if entry == "sa_solve":
             kw["equations"] = RANSEquations
             kw["nSubIterTurb"] = int(rng.integers(1, 3))
@@ -96,6 +122,13 @@ def run_case(engine, dims, kw, mk, entry):
     elif entry == "bc":
         spec, second = mk.pop("spec"), mk.pop("secondHalo")
         checks.check_apply_bc(engine, (max(dims[0], 2), max(dims[1], 2), max(dims[2], 1)), prm, spec, secondHalo=second, seed=seed, **mk)
+    elif entry == "full_bc":
+        t = mk.pop("topo")
+        if prm.equations == RANSEquations and not any(v in (-3, -4) for v in mk["spec"].values()):
+            mk["spec"][5] = -3          # SA wants a wall distance that means something
+        checks.check_blockette_res_with_bc(engine, BrickTopology(*t, periodic=(False, False, False)), prm, mk.pop("spec"), seed=seed, **mk)
+    elif entry == "ad":
+        checks.check_ad_jacobian(engine, dims, prm, mk.pop("spec"), usePC=mk.pop("usePC"), frozenTurb=mk.pop("frozenTurb"), seed=seed, **mk)
     elif entry in ("rk", "dadi", "sa_solve", "nk"):
         topo = BrickTopology(*mk.pop("topo"))
         if entry == "rk":
