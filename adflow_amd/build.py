@@ -37,7 +37,9 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
-        if force or _stale(o, [s] + hdrs):
+        # kernels_ad.hip #includes the gather-kernel SOURCES a second time (dual numbers): it is stale when any of them is
+        deps = [s] + hdrs + (srcs if os.path.basename(s) == "kernels_ad.hip" else [])
+        if force or _stale(o, deps):
             jobs.append((s, o))
 
     def cc(job):

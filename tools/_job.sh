@@ -1,2 +1,2 @@
-export GIT=2fe1163 TAG=r04_n EXTRAS="config3" ROWS=14
-bash tools/_gpu_job_pmc_extras.sh
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+python tools/dbg/ad_gpu_case.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" | tail -6
