@@ -151,7 +151,7 @@ def setup_brick_with_bc(engine, topo, prm, brick_spec, seed=19, **mk):
     return blocks, rblocks, bocos, prm
 
 
-def check_blockette_res_with_bc(engine, topo, prm, brick_spec, seed=19, split_eval=None, floor_p=False, **mk):
+def check_blockette_res_with_bc(engine, topo, prm, brick_spec, seed=19, split_eval=None, floor_p=False, allow_degenerate=False, **mk):
     """The reference's WHOLE blocketteRes (blockette.F90:199-283, default flags, storeWall = T) on a wall-bounded mesh, as ONE
     library call (ADFLOW_RES_CLOSURES | HALO | FLOW | TURB): derived values of the owned cells, turbulence + mean-flow boundary
     conditions of every subface, whalo2 over the 1-to-1 interfaces, blocketteResCore; compared: dw of every block and
@@ -195,6 +195,11 @@ def check_blockette_res_with_bc(engine, topo, prm, brick_spec, seed=19, split_ev
         ref.call_level("setPointers", 1, nn)
         ref.blockette_res_core(False, True, turb)
         dw = engine.download_residual(nn, 1)
+        if allow_degenerate and not np.isfinite(owned(blocks[nn], rblocks[nn]["dw"])).all():
+            # (random sweeps: a floored pressure next to an extrapolation boundary can make the REFERENCE produce NaN; then only the
+            # pattern is compared)
+            assert np.array_equal(np.isfinite(owned(blocks[nn], dw)), np.isfinite(owned(blocks[nn], rblocks[nn]["dw"])))
+            continue
         assert_dw(blocks[nn], dw, rblocks[nn]["dw"], blocks[nn].nw, what=f"block {nn}: blocketteRes with boundary conditions")
         faces, nvisc = bocos.get(nn, ([], 0))
         for mm in range(1, nvisc + 1):

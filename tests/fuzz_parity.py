@@ -126,7 +126,8 @@ def run_case(engine, dims, kw, mk, entry):
         t = mk.pop("topo")
         if prm.equations == RANSEquations and not any(v in (-3, -4) for v in mk["spec"].values()):
             mk["spec"][5] = -3          # SA wants a wall distance that means something
-        checks.check_blockette_res_with_bc(engine, BrickTopology(*t, periodic=(False, False, False)), prm, mk.pop("spec"), seed=seed, **mk)
+        checks.check_blockette_res_with_bc(engine, BrickTopology(*t, periodic=(False, False, False)), prm, mk.pop("spec"), seed=seed,
+                                           allow_degenerate=mk.get("floor_p", False), **mk)
     elif entry == "ad":
         checks.check_ad_jacobian(engine, dims, prm, mk.pop("spec"), usePC=mk.pop("usePC"), frozenTurb=mk.pop("frozenTurb"), seed=seed, **mk)
     elif entry in ("rk", "dadi", "sa_solve", "nk"):
