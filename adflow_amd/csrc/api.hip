@@ -3635,6 +3635,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
         return 0;
     }
     if (!strcmp(key, "dadi_pcr")) { g_dadi_pcr = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "dadi_kpipe")) { g_dadi_kpipe = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "dadi_jpipe")) { g_dadi_jpipe = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ra_pcr")) { g_ra_pcr = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "dadi_upd")) { g_dadi_upd = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_cus")) {

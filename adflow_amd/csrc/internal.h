@@ -351,6 +351,7 @@ void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int 
 // slots than fit calls itself on consecutive slot ranges (the kernels index the table relative to the pointer they get).
 extern int g_max_grid_z;          // 65535; tuning "max_grid_z" lowers it for the tests
 extern int g_ra_pcr;              // kernels_smooth.hip, tuning "ra_pcr"
+extern int g_dadi_jpipe, g_dadi_kpipe;
 extern int g_dadi_pcr;            // kernels_smooth.hip, tuning "dadi_pcr"
 inline int level_slots_per_launch(int planes)
 {

@@ -1117,7 +1117,9 @@ __device__ __forceinline__ void dadi_back_post(const DadiBack& q, double d[5], d
 
 // UPD (DIR 2): the state update of executeDADIStep follows the last transform in the same step (no residual averaging in between):
 // the back substitution holds the state of the cell already (it feeds T_zeta), so k_stage_update's read of dw, w, p is saved
-template <int DIR, bool POSTI = false, bool UPD = false>
+// PIPE = false: the values of cell m+1 and the update of cell m are requested in step m itself (fewer registers: the wavefronts of a
+// level then all fit the chip at once) -- measured against the pipeline per direction, see launch_dadi_level
+template <int DIR, bool POSTI = false, bool UPD = false, bool PIPE = true>
 __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ tab, KParams kp, int slot0)
 {
     static_assert(DIR == 1 || DIR == 2, "the i direction has its own kernels");
@@ -1173,14 +1175,18 @@ __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ t
     dadi_load<DIR>(b, kp, c0 + s, s, sN, rA);          // cell 1 (n >= 2)
     auto fwd = [&](int m, double* __restrict__ dX, DadiRaw& rX, double* __restrict__ dY, DadiRaw& rY) {
         const long c = c0 + m * s;
-        if (m + 2 < n) dadi_load<DIR>(b, kp, c + 2 * s, s, sN, rY);
-        if (m + 1 < n) {
+        if (PIPE) {
+            if (m + 2 < n) dadi_load<DIR>(b, kp, c + 2 * s, s, sN, rY);
+            if (m + 1 < n) {
 #pragma unroll
-            for (int l = 0; l < 5; ++l) dY[l] = b.dw[c + s + l * nb];
+                for (int l = 0; l < 5; ++l) dY[l] = b.dw[c + s + l * nb];
+            }
+        } else if (m > 0 && m + 1 < n) {
+            dadi_load<DIR>(b, kp, c + s, s, sN, rX);          // (cell 1 was requested in front of the loop)
         }
         double d[5];
 #pragma unroll
-        for (int l = 0; l < 5; ++l) d[l] = dX[l];
+        for (int l = 0; l < 5; ++l) d[l] = (PIPE || m == 0) ? dX[l] : b.dw[c + l * nb];
         if (DIR == 1) {
 #pragma unroll
             for (int l = 0; l < 5; ++l) d[l] *= pre.sc0;
@@ -1211,9 +1217,13 @@ __global__ __launch_bounds__(64) void k_dadi_sweep(const BlkView* __restrict__ t
 #pragma unroll
         for (int l = 0; l < 5; ++l) b.dw[c + l * nb] = d[l];
     };
-    for (int m = 0; m < n; m += 2) {
-        fwd(m, dA, rA, dB, rB);
-        if (m + 1 < n) fwd(m + 1, dB, rB, dA, rA);
+    if (PIPE) {
+        for (int m = 0; m < n; m += 2) {
+            fwd(m, dA, rA, dB, rB);
+            if (m + 1 < n) fwd(m + 1, dB, rB, dA, rA);
+        }
+    } else {
+        for (int m = 0; m < n; ++m) fwd(m, dA, rA, dA, rA);
     }
     // ---- back substitution + post-transform; row n-1 keeps its value (fprev), its transform is applied like the others
     DadiBack qA, qB;
@@ -1535,6 +1545,8 @@ static void launch_dadi_i_pcr(const BlkView* tab, int nslots, int ny, int nz, co
     hipLaunchKernelGGL((k_dadi_i_pcr<NW>), dim3((ny + PI_JL - 1) / PI_JL, nz, nslots), dim3(64 * NW, 1, 1), 0, s, tab, kp);
 }
 
+int g_dadi_kpipe = 1;    // tuning "dadi_kpipe": the same for the k sweep
+int g_dadi_jpipe = 0;    // tuning "dadi_jpipe": 1 = the j sweep as a software pipeline too (322 registers: one wavefront per SIMD, its 1536 wavefronts run as two rounds: 0.90 ms); 0 = plain with the reciprocal forms (208 registers, every wavefront resident: 0.73 ms)
 int g_dadi_pcr = 1;      // tuning "dadi_pcr": the i direction of D-ADI by cyclic reduction along the lanes (0: rows + tiled Thomas)
 
 // computedwDADI incl. the -cfl*dtl*vol scaling of executeDADIStep
@@ -1544,15 +1556,22 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
     LEVEL_SPLIT(nslots, nz + 4, launch_dadi_level(tab + s0_, n_, nx, ny, nz, kp, s, withUpdate));
     if (nslots <= 0) return;
     dim3 blk(64, 1, 1);
-    hipLaunchKernelGGL((k_dadi_sweep<1>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
+    if (g_dadi_jpipe) hipLaunchKernelGGL((k_dadi_sweep<1>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
+    else hipLaunchKernelGGL((k_dadi_sweep<1, false, false, false>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
     if (g_dadi_pcr && nx <= 256) {
         // i direction: cyclic reduction along the lanes with its transform applied (k_dadi_i_pcr); nx = the widest block of the level
         if (nx <= 64) launch_dadi_i_pcr<1>(tab, nslots, ny, nz, kp, s);
         else if (nx <= 128) launch_dadi_i_pcr<2>(tab, nslots, ny, nz, kp, s);
         else if (nx <= 192) launch_dadi_i_pcr<3>(tab, nslots, ny, nz, kp, s);
         else launch_dadi_i_pcr<4>(tab, nslots, ny, nz, kp, s);
-        if (withUpdate) hipLaunchKernelGGL((k_dadi_sweep<2, false, true>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
-        else hipLaunchKernelGGL((k_dadi_sweep<2, false>), dim3((nx + 63) / 64, ny, nslots), blk, 0, s, tab, kp, 0);
+        const dim3 gk((nx + 63) / 64, ny, nslots);
+        if (g_dadi_kpipe) {
+            if (withUpdate) hipLaunchKernelGGL((k_dadi_sweep<2, false, true>), gk, blk, 0, s, tab, kp, 0);
+            else hipLaunchKernelGGL((k_dadi_sweep<2, false>), gk, blk, 0, s, tab, kp, 0);
+        } else {
+            if (withUpdate) hipLaunchKernelGGL((k_dadi_sweep<2, false, true, false>), gk, blk, 0, s, tab, kp, 0);
+            else hipLaunchKernelGGL((k_dadi_sweep<2, false, false, false>), gk, blk, 0, s, tab, kp, 0);
+        }
         return;
     }
     // i direction: rows pointwise, Thomas per (line, equation) through LDS tiles; the transform behind the i-solve is applied

@@ -1,5 +1,4 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_smoothers.py -m gpu -x -q -k "dadi" 2>&1 | tail -2
-export EXTRAS=config3 TAG=r04_q ROWS=12
-bash tools/_gpu_job_extras.sh
+for T in "0 0" "0 1" "1 0" "1 1" "0 0" "0 1"; do set -- $T
+echo "jpipe=$1 kpipe=$2: $(timeout 600 python bench.py --no-cpu-baseline --only-extras config3 --force-extras --tuning dadi_jpipe=$1 --tuning dadi_kpipe=$2 2>&1 >/dev/null | grep -a 'config 3' | tail -1)"
+done
