@@ -26,7 +26,7 @@ hipStream_t g_stream = nullptr;
 // side streams of blocketteRes: the SA residual and the nodal gradients are independent of the inviscid kernel (which is bound by
 // FP64 issue while they are bound by HBM): launched on their own queues they share the CUs with it (tuning "overlap")
 hipStream_t g_streamB = nullptr, g_streamC = nullptr;
-hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr;
+hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr, g_evB1 = nullptr;
 hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
@@ -390,7 +390,7 @@ int adflow_gpu_init(int device_ordinal)
     if (!g_streamB) {
         HIPCHK(hipStreamCreateWithFlags(&g_streamB, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&g_streamC, hipStreamNonBlocking));
-        HIPCHK(hipEventCreate(&g_evFork)); HIPCHK(hipEventCreate(&g_evB)); HIPCHK(hipEventCreate(&g_evC));
+        HIPCHK(hipEventCreate(&g_evFork)); HIPCHK(hipEventCreate(&g_evB)); HIPCHK(hipEventCreate(&g_evC)); HIPCHK(hipEventCreate(&g_evB1));
         HIPCHK(hipStreamCreateWithFlags(&g_streamX, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&g_evPack, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&g_evComm, hipEventDisableTiming));
     }
@@ -430,7 +430,7 @@ int adflow_gpu_finalize(void)
     }
     if (g_streamB) {
         (void)hipStreamDestroy(g_streamB); (void)hipStreamDestroy(g_streamC); (void)hipStreamDestroy(g_streamX);
-        (void)hipEventDestroy(g_evFork); (void)hipEventDestroy(g_evB); (void)hipEventDestroy(g_evC);
+        (void)hipEventDestroy(g_evFork); (void)hipEventDestroy(g_evB); (void)hipEventDestroy(g_evC); (void)hipEventDestroy(g_evB1);
         (void)hipEventDestroy(g_evPack); (void)hipEventDestroy(g_evComm);
         g_streamB = g_streamC = g_streamX = nullptr;
     }
@@ -972,6 +972,7 @@ static int wall_stress_enqueue(int level, const KParams& kp, bool formGrad);
 // stage0: the reference's rkStage is 0 at this call -> on the ground level viscousFlux also stores the wall stress tensor
 // and heat flux of the viscous subfaces (storeWallTensor, fluxes.F90:2586-2592)
 static bool has_wall_subfaces(int level);
+static bool level_has_subfaces(int level);
 
 // needGradHbm: the caller wants the nodal gradients in the block arrays (updateIntermed copy-out, blockette.F90:706-750)
 static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false, bool lowSpeed = true, bool stage0 = true,
@@ -1143,16 +1144,22 @@ static int early_pressure_exchange_enqueue(int level);
 static int halo_exchange_close(int level, int varStart, int varEnd, int commPressure, int nLayers);
 static int comm_exchange_begin(CommPattern* cp, BlkView* tab, unsigned mask, int nvar, bool* remoteOut);
 static int comm_exchange_end(CommPattern* cp, BlkView* tab, unsigned mask, bool remote);
-static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0, int lStart, int lEnd, int* taken);
+static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0, int lStart, int lEnd, int* taken,
+                                   const std::function<int()>& frontBCs);
 
-// whalo2 + blocketteRes core with the exchange HIDDEN behind the tiles that read no halo cell (round-2 verdict, next 3 iii).  Order:
-//   packs, RCCL group on the communication queue, same-GPU copies           (comm_exchange_begin)
-//   SA march (side queue) and fused viscous march over their INTERIOR tiles  -- run while the messages are in flight
-//   wait for the group, unpacks, periodic transforms, whalo2's closing energy (comm_exchange_end, halo_exchange_close)
-//   SA march and viscous march over the BOUNDARY tiles, inviscid march over every tile (it adds the viscous sums), join.
+// whalo2 + blocketteRes core with the exchange -- and, round 4, the boundary conditions in front of it -- HIDDEN behind the tiles that
+// read no halo cell (round-2 verdict, next 3 iii).  Two queues from the fork behind the derived values:
+//   main queue:  boundary conditions (frontBCs), packs, RCCL group on the communication queue, same-GPU copies, wait for the group,
+//                unpacks, periodic transforms, whalo2's closing energy; then the fused viscous march over the BOUNDARY tiles, the
+//                inviscid march over every tile (it adds the viscous sums), the wall stress
+//   side queue:  SA march and fused viscous march over their INTERIOR tiles (they read owned cells only: neither a boundary halo
+//                nor an exchanged one) -- while the boundary kernels (a few hundred workgroups each) and the copies leave the chip
+//                idle; then, behind the exchange, the SA march over the boundary tiles
 // Taken for the default flags of blocketteRes on NS / RANS with the marching kernels, blocks at rest, when the pattern has messages
-// (tuning "split_eval" = 1, the default) or always (2: tests).  On the north-star mesh 16 % of the tiles are interior.
-static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0, int lStart, int lEnd, int* taken)
+// (tuning "split_eval" = 1, the default), always (2: tests), never (0).  On the north-star mesh
+// 16 % of the tiles are interior.
+static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0, int lStart, int lEnd, int* taken,
+                                   const std::function<int()>& frontBCs)
 {
     *taken = 0;
     if (!g_split_eval || !g_overlap || g_phase_base > 0 || kp0.rvec) return 0;
@@ -1169,7 +1176,10 @@ static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0
     CommPattern* cp;
     if (build_comm(level, 2, &cp)) return 1;
     const bool messages = !cp->sends.empty() || !cp->recvs.empty();
+    // (boundary subfaces alone do not make it pay: measured on the wall-bounded bench mesh at N = 1 the split costs 0.03 ms --
+    //  2.45 against 2.42 ms -- the two extra launches per kernel outweigh what the interior tiles hide of the boundary kernels)
     if (g_split_eval < 2 && !messages) return 0;
+    if (g_bc_callback) return 0;               // (a host hook between the device passes synchronises the queue)
     unsigned mask; int nvar;
     if (halo_mask(lStart, lEnd, 1, 1, &mask, &nvar)) return 1;
     if (nvar == 0) return 0;
@@ -1192,31 +1202,29 @@ static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0
     // (everything behind the fork runs inside `run`: an error exit must not leave the side queue unjoined -- round-3 advisor finding)
     bool forked = false;
     auto run = [&]() -> int {
-        // ---- messages out, same-GPU copies
+        // ---- fork behind the derived values: the halo-free tiles on the side queue
         HIPCHK(hipEventRecord(g_evFork, g_stream));
+        HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
+        forked = true;
+        if (rans) launch_sa_march(t.tab, g_sa_tiles_int[level].first, g_sa_tiles_int[level].second, kp, g_streamB, false);
+        launch_visc_gf(g_tab[level], g_gf_tiles_int[level].first, g_gf_tiles_int[level].second, kv, false, g_streamB);
+        HIPCHK(hipEventRecord(g_evB1, g_streamB));
+        // ---- main queue: boundary conditions, messages out, same-GPU copies, messages in
+        if (frontBCs()) return 1;
         bool remote = false;
         if (comm_exchange_begin(cp, g_tab[level], mask, nvar, &remote)) return 1;
-        // ---- halo-free tiles
-        if (rans) {
-            HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
-            forked = true;
-            launch_sa_march(t.tab, g_sa_tiles_int[level].first, g_sa_tiles_int[level].second, kp, g_streamB, false);
-        }
-        launch_visc_gf(g_tab[level], g_gf_tiles_int[level].first, g_gf_tiles_int[level].second, kv, false, g_stream);
-        // ---- messages in
         if (comm_exchange_end(cp, g_tab[level], mask, remote)) return 1;
         if (halo_exchange_close(level, lStart, lEnd, 1, 2)) return 1;
         // ---- the tiles next to the block faces, then the inviscid march over all of them
-        if (rans) {
-            HIPCHK(hipEventRecord(g_evC, g_stream));
-            HIPCHK(hipStreamWaitEvent(g_streamB, g_evC, 0));
-            launch_sa_march(t.tab, g_sa_tiles_bnd[level].first, g_sa_tiles_bnd[level].second, kp, g_streamB, false);
-            HIPCHK(hipEventRecord(g_evB, g_streamB));
-        }
+        HIPCHK(hipEventRecord(g_evC, g_stream));
+        HIPCHK(hipStreamWaitEvent(g_streamB, g_evC, 0));
+        if (rans) launch_sa_march(t.tab, g_sa_tiles_bnd[level].first, g_sa_tiles_bnd[level].second, kp, g_streamB, false);
+        HIPCHK(hipEventRecord(g_evB, g_streamB));
         launch_visc_gf(g_tab[level], g_gf_tiles_bnd[level].first, g_gf_tiles_bnd[level].second, kv, false, g_stream);
+        HIPCHK(hipStreamWaitEvent(g_stream, g_evB1, 0));               // the interior viscous sums are in dw(2:5)
         if (!launch_roe_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream))
             launch_inviscid_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kv, g_stream);
-        if (rans) HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0));      // join
+        HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0));                // join
         forked = false;
         return 0;
     };
@@ -1264,26 +1272,33 @@ static int block_res_enqueue(int level, unsigned flags)
     }
     if (flags & ADFLOW_RES_HALO) {
         // BCTurbTreatment + applyAllTurbBCThisBlock(.true.) before applyAllBC_block(.true.) (blockette.F90:220-226)
-        if ((flags & ADFLOW_RES_TURB) && apply_turb_bc_enqueue(level, 1)) return 1;
-        if (apply_bc_enqueue(level, 1)) return 1;
-        if (g_bc_callback) {
-            HIPCHK(hipStreamSynchronize(g_stream));
-            g_bc_callback(level, 1);
-        }
+        auto frontBCs = [&]() -> int {
+            if ((flags & ADFLOW_RES_TURB) && apply_turb_bc_enqueue(level, 1)) return 1;
+            if (apply_bc_enqueue(level, 1)) return 1;
+            if (g_bc_callback) {
+                HIPCHK(hipStreamSynchronize(g_stream));
+                g_bc_callback(level, 1);
+            }
+            return 0;
+        };
         int lStart = 1, lEnd = (g_opts.equations == ADFLOW_RANS) ? 6 : 5;
         if ((flags & ADFLOW_RES_FLOW) && !(flags & ADFLOW_RES_TURB)) lEnd = 5;
         if (!(flags & ADFLOW_RES_FLOW) && (flags & ADFLOW_RES_TURB)) lStart = 6;
         if (g_comm.count(std::make_pair(level, 2))) {
-            // the exchange with the halo-free tiles of the evaluation inside it, where the evaluation is the marching RANS / NS one
+            // the boundary conditions and the exchange with the halo-free tiles of the evaluation beside them, where the evaluation
+            // is the marching RANS / NS one
             int taken = 0;
             const int flagLevelWas = g_etot_flag_level;
             if (etotInClosures) g_etot_flag_level = level;
-            rc = block_res_split_enqueue(level, flags, kp, lStart, lEnd, &taken);
-            if (!rc && !taken) rc = halo_exchange_enqueue(level, lStart, lEnd, 1, 1, 2);
+            rc = block_res_split_enqueue(level, flags, kp, lStart, lEnd, &taken, frontBCs);
+            if (!rc && !taken) {
+                rc = frontBCs();
+                if (!rc) rc = halo_exchange_enqueue(level, lStart, lEnd, 1, 1, 2);
+            }
             g_etot_flag_level = flagLevelWas;
             if (rc) return 1;
             if (taken) return 0;
-        }
+        } else if (frontBCs()) return 1;
     }
     phase_mark(1);
     // timeStep_block(onlyRadii): with matrix dissipation / Roe upwind nothing in the residual reads the spectral radii, and
@@ -2586,6 +2601,13 @@ static int ad_apply_bc_enqueue(int level, const KParams& kp, bool turbBC)
     ad_launch_apply_all_bc(g_ad_tab, pl->d_ent, pl->d_order, flow, kp, 1, g_opts.eulerWallBCTreatment, g_opts.viscWallBCTreatment,
                            g_opts.outflowTreatment, g_opts.hScalingInlet, g_stream);
     return 0;
+}
+
+static bool level_has_subfaces(int level)
+{
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return false;
+    return pl->nent > 0;
 }
 
 static bool has_wall_subfaces(int level)
