@@ -120,6 +120,7 @@ inline double __shfl_down(double v, unsigned delta, int width = 64) {
     const int src = (l + (int)delta < width) ? me + (int)delta : me;
     return hostsim::shfl_exchange(v, src);
 }
+inline int __double2hiint(double v) { long long b; std::memcpy(&b, &v, 8); return (int)(b >> 32); }
 inline int __shfl_up(int v, unsigned delta, int width = 64) { return (int)__shfl_up((double)v, delta, width); }
 inline int __shfl_down(int v, unsigned delta, int width = 64) { return (int)__shfl_down((double)v, delta, width); }
 inline double __shfl_xor(double v, int mask, int width = 64) {

@@ -1,3 +1,2 @@
-export GIT=c3d745e TAG=r04_s
-bash tools/_gpu_job_full.sh
-bash tools/_gpu_job_sq.sh
+export TAG=r04_v AB="overlap=1" REPS=2 TESTS="tests/test_gpu_rans.py tests/test_gpu_adversarial.py tests/test_gpu_euler.py tests/test_gpu_nk.py"
+bash tools/_gpu_job_ab.sh

@@ -37,8 +37,10 @@ def main():
         asm = {}
         for s in srcs:
             o = os.path.join(td, s + ".s")
+            # RM_COUNT_NO_CLAMP: the Roe march without the block a lane enters only where a difference lies inside the limiter's
+            # epsLim clamp (uniform flow); register / scratch figures of the shipped kernel are taken from the library's own build
             r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
-                                os.path.join(ROOT, "adflow_amd", "csrc", s), "-o", o], capture_output=True, text=True)
+                                "-DRM_COUNT_NO_CLAMP", os.path.join(ROOT, "adflow_amd", "csrc", s), "-o", o], capture_output=True, text=True)
             if r.returncode != 0:
                 raise SystemExit(r.stderr[-2000:])
             asm[s] = o
@@ -53,7 +55,7 @@ def main():
         # the loop is compiled again without it and the average step priced as  without + (with - without) / 4
         o = os.path.join(td, "roe_nofifth.s")
         r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
-                            "-DRM_COUNT_NO_FIFTH", os.path.join(ROOT, "adflow_amd", "csrc", "kernels_roe_march.hip"), "-o", o],
+                            "-DRM_COUNT_NO_FIFTH", "-DRM_COUNT_NO_CLAMP", os.path.join(ROOT, "adflow_amd", "csrc", "kernels_roe_march.hip"), "-o", o],
                            capture_output=True, text=True)
         if r.returncode == 0 and "roe_march" in out["kernels"]:
             base = main_loop(o, KERNELS["roe_march"][1])
