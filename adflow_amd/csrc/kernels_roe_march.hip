@@ -305,32 +305,72 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     double acc[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};   // accD: dissipation part, kept apart only when FW
 
     // A wave is resident with ONE other per SIMD: what a step loads has to be in flight while it computes.  The step is laid out as
-    //   request: plane k+1 of the own column, rows j-1 / j+1 (j+2) of plane k, the k normal, the viscous sums of cell k-1
+    //   request: plane k+1 of the own column, rows j-1 / j+1 of plane k, the k normal
     //   A: the i face of cell k -- state, normal and porosity are in registers since the step before
-    //   B: j reconstruction + publication, k reconstruction + k face; request: j normal, i normal and flags of plane k+1
+    //   B: j reconstruction + publication; request of the rows only some waves need; k reconstruction + k face; their
+    //      reconstructions; request: j normal, viscous sums of cell k-1, i normal and flags of plane k+1
     //   barrier; finish cell k-1; j face (+ the fifth one)
     // with scheduling barriers between the parts (the compiler otherwise sinks every load to its first use: nine drained batches).
-    for (int k = k0; k <= k1 + 1; ++k) {
-        double* __restrict__ xb = xj + (k & 1) * RM_XJ(FW);                 // UR of this plane | fluxes handed over in this plane
+    // The step that only finishes the last cell stands behind the loop: inside it, its path around the j reconstruction would make
+    // every wait behind that point count as if the loads of the top were still pending.
+    double fc[5], fd[5];
+    auto kface = [&](const RCell& qp1, double nKx, double nKy, double nKz, double ULk0[5], auto&& between) {
+        double URk0[5];
+        rm_recon<LIM>(K, qm1, q0, qp1, ULk0, URk0);
+        between();
+        rm_face(K, qm1, q0, ULk, URk0, nKx, nKy, nKz, flg_porK((uint8_t)flagm), fc, fd);    // normal and porosity stored at cell k-1
+    };
+    // finish cell k-1 with the flux through its lower j face (handed over in the plane before) and write it
+    auto finish = [&](int k, const double vsum[4]) {
         const double* __restrict__ xf = xj + ((k - 1) & 1) * RM_XJ(FW) + RM_UR;   // fluxes handed over in the plane before
-        const bool body = (k <= k1);
+        double fl[NF];
+#pragma unroll
+        for (int l = 0; l < NF; ++l) fl[l] = xf[(row * NF + l) * 64 + lane];
+        if (out) {
+            const unsigned cw = c - sk;
+            const double blank = flg_blank((uint8_t)flagm);
+            double ovv = 0.0;
+            double* __restrict__ rv = nullptr;
+            if (RV) {
+                ovv = 1.0 / ldg((GPTR(const double))b.volRef, cw);
+                rv = kp.rvec + b.vecOff + ((((long)(k - 3) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw);
+            }
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                double d = (acc[l] - fl[l]) + fc[l];
+                if (kp.coarseInit) d += ldg(wr + l * nb, cw);
+                if (FW) {
+                    double fwn = (accD[l] - fl[5 + l < NF ? 5 + l : l]) + fd[l];
+                    const double old = ldg(fw + l * nb, cw);
+                    fwn = K.doDiss ? (kp.sfil * old + fwn) : old;
+                    if (K.doDiss || !FINAL) stg(fw + l * nb, cw, fwn);
+                    stg(dw + l * nb, cw, FINAL ? (d + fwn) * blank : d);
+                } else {
+                    d += fd[l];
+                    if (ADDV && l > 0) d += vsum[l - 1];
+                    stg(dw + l * nb, cw, d * blank);      // not FINAL: the viscous kernel adds its part to dw(2:5) and re-applies iblank
+                    if (RV) rv[l] = (d * blank) * ovv;
+                }
+            }
+        }
+    };
+
+    for (int k = k0; k <= k1; ++k) {
+        double* __restrict__ xb = xj + (k & 1) * RM_XJ(FW);                 // UR of this plane | fluxes handed over in this plane
 #ifdef RM_COUNT_NO_FIFTH          // tools/isa_report.py: the loop without the block a wave executes in one plane of four
         const bool fifth = false;
 #else
-        const bool fifth = body && (wave_uniform(row) == (k & 3));         // this wave evaluates the face below row 0 in this plane
+        const bool fifth = (wave_uniform(row) == (k & 3));                  // this wave evaluates the face below row 0 in this plane
 #endif
         // ---- request
         const RCell qp1 = rm_ld(m, c + sk);
         const double nKx = ldg(sKx, c - sk), nKy = ldg(sKy, c - sk), nKz = ldg(sKz, c - sk);
-        RCell qjm, qjp, qjp2;
-        if (body) {
-            qjm = rm_ld(m, c - sj);
-            qjp = rm_ld(m, c + sj);
-        }
+        const RCell qjm = rm_ld(m, c - sj);
+        const RCell qjp = rm_ld(m, c + sj);
         __builtin_amdgcn_sched_barrier(0);
         // ---- A: this lane evaluates the i face (i-1 | i) of cell k; the face (i | i+1) comes from lane+1
-        double gI[5] = {0, 0, 0, 0, 0}, gID[5] = {0, 0, 0, 0, 0};
-        if (body) {
+        double gI[5], gID[5] = {0, 0, 0, 0, 0};
+        {
             const RCell qL = rm_up1(q0), qR = rm_dn1(q0);
             double ULi[5], URi[5], ULm[5];
             rm_recon<LIM>(K, qL, q0, qR, ULi, URi);
@@ -351,92 +391,57 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- B
-        RCell qEm, qE0;
+        // ---- B: j direction, first half: reconstruct the own cell and publish the right state the row below needs.  The rows only
+        //      some waves need (wave 3: the row above the tile; the wave of the fifth face: three rows below it) are requested BEHIND
+        //      the wait of this reconstruction and consumed behind the k face: a conditional request in front of a wait makes the
+        //      wave that issued it wait for it there
+        RCell qEmm, qEm, qE0;
         double ULj[5], ULe[5];
-        if (body) {
-            RCell qEmm;
-            if (row == RM_BY - 1) qjp2 = rm_ld(m, c + oj2);
-            if (fifth) {
-                qEmm = rm_ld(m, cE - 2 * sj);
-                qEm = rm_ld(m, cE - sj);
-                qE0 = rm_ld(m, cE);
-            }
-            // j direction, first half: reconstruct the own cell (wave 3: also the cell above the tile) and publish the right states
-            // the row below needs
+        {
             double URj[5];
             rm_recon<LIM>(K, qjm, q0, qjp, ULj, URj);
 #pragma unroll
             for (int l = 0; l < 5; ++l) xb[(row * 5 + l) * 64 + lane] = URj[l];
-            if (row == RM_BY - 1) {
-                double pl[5], mi[5];
-                rm_recon<LIM>(K, q0, qjp, qjp2, pl, mi);
-#pragma unroll
-                for (int l = 0; l < 5; ++l) xb[(4 * 5 + l) * 64 + lane] = mi[l];
-            }
-            if (fifth) {
-                double mi[5];
-                rm_recon<LIM>(K, qEmm, qEm, qE0, ULe, mi);                  // left state of the face (j0-1 | j0)
-            }
         }
-        // k-face between cells k-1 and k (normal and porosity stored at cell k-1)
-        double ULk0[5], URk0[5];
-        rm_recon<LIM>(K, qm1, q0, qp1, ULk0, URk0);
-        double fc[5], fd[5];
-        rm_face(K, qm1, q0, ULk, URk0, nKx, nKy, nKz, flg_porK((uint8_t)flagm), fc, fd);
+        double ULk0[5];
+        kface(qp1, nKx, nKy, nKz, ULk0, []() {});
+        __builtin_amdgcn_sched_barrier(0);
+        int flagE = 0;
+        if (fifth) {
+            flagE = flags[(cE - sj) >> 3];
+            qEmm = rm_ld(m, cE - 2 * sj);
+            qEm = rm_ld(m, cE - sj);
+            qE0 = rm_ld(m, cE);
+        }
+        if (row == RM_BY - 1) {                                          // wave 3: also the cell above the tile
+            const RCell qjp2 = rm_ld(m, c + oj2);
+            double pl[5], mi[5];
+            rm_recon<LIM>(K, q0, qjp, qjp2, pl, mi);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) xb[(4 * 5 + l) * 64 + lane] = mi[l];
+        }
+        if (fifth) {
+            double mi[5];
+            rm_recon<LIM>(K, qEmm, qEm, qE0, ULe, mi);                  // left state of the face (j0-1 | j0)
+        }
         // request what the part behind the barrier and phase A of the next step consume
-        double nJ[3] = {0, 0, 0}, nIn[3] = {0, 0, 0}, nE[3] = {0, 0, 0};
-        int flagp = 0, flagE = 0;
+        double nJ[3], nIn[3], nE[3] = {0, 0, 0};
         double vsum[4] = {0, 0, 0, 0};       // ADDV: viscous flux sums of the cell finished in this step
         if (ADDV && k > k0 && out) {
 #pragma unroll
             for (int l = 0; l < 4; ++l) vsum[l] = ldg((GPTR(const double))dw + (l + 1) * nb, c - sk);
         }
-        if (body) {
-            nJ[0] = ldg(sJx, c); nJ[1] = ldg(sJy, c); nJ[2] = ldg(sJz, c);
-            nIn[0] = ldg(sIx, c + sk - 8u); nIn[1] = ldg(sIy, c + sk - 8u); nIn[2] = ldg(sIz, c + sk - 8u);
-            flagp = flags[(c + sk) >> 3];
-            if (fifth) {
-                const unsigned cm = cE - sj;
-                nE[0] = ldg(sJx, cm); nE[1] = ldg(sJy, cm); nE[2] = ldg(sJz, cm);
-                flagE = flags[cm >> 3];
-            }
+        nJ[0] = ldg(sJx, c); nJ[1] = ldg(sJy, c); nJ[2] = ldg(sJz, c);
+        nIn[0] = ldg(sIx, c + sk - 8u); nIn[1] = ldg(sIy, c + sk - 8u); nIn[2] = ldg(sIz, c + sk - 8u);
+        const int flagp = flags[(c + sk) >> 3];
+        if (fifth) {
+            const unsigned cm = cE - sj;
+            nE[0] = ldg(sJx, cm); nE[1] = ldg(sJy, cm); nE[2] = ldg(sJz, cm);
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        // ---- finish cell k-1 with the flux through its lower j face (handed over in the plane before) and write it
-        if (k > k0) {
-            double fl[NF];
-#pragma unroll
-            for (int l = 0; l < NF; ++l) fl[l] = xf[(row * NF + l) * 64 + lane];
-            if (out) {
-                const unsigned cw = c - sk;
-                const double blank = flg_blank((uint8_t)flagm);
-                double ovv = 0.0;
-                double* __restrict__ rv = nullptr;
-                if (RV) {
-                    ovv = 1.0 / ldg((GPTR(const double))b.volRef, cw);
-                    rv = kp.rvec + b.vecOff + ((((long)(k - 3) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw);
-                }
-#pragma unroll
-                for (int l = 0; l < 5; ++l) {
-                    double d = (acc[l] - fl[l]) + fc[l];
-                    if (kp.coarseInit) d += ldg(wr + l * nb, cw);
-                    if (FW) {
-                        double fwn = (accD[l] - fl[5 + l < NF ? 5 + l : l]) + fd[l];
-                        const double old = ldg(fw + l * nb, cw);
-                        fwn = K.doDiss ? (kp.sfil * old + fwn) : old;
-                        if (K.doDiss || !FINAL) stg(fw + l * nb, cw, fwn);
-                        stg(dw + l * nb, cw, FINAL ? (d + fwn) * blank : d);
-                    } else {
-                        d += fd[l];
-                        if (ADDV && l > 0) d += vsum[l - 1];
-                        stg(dw + l * nb, cw, d * blank);      // not FINAL: the viscous kernel adds its part to dw(2:5) and re-applies iblank
-                        if (RV) rv[l] = (d * blank) * ovv;
-                    }
-                }
-            }
-        }
-        if (!body) break;
+        __builtin_amdgcn_sched_barrier(0);
+        if (k > k0) finish(k, vsum);
         // ---- start cell k: the k face below it and its two i faces
 #pragma unroll
         for (int l = 0; l < 5; ++l) {
@@ -485,6 +490,20 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
 #pragma unroll
         for (int d = 0; d < 3; ++d) nI[d] = nIn[d];
         c += sk; cE += sk;
+    }
+    // ---- the k face above the last cell of the chunk, and that cell
+    {
+        const RCell qp1 = rm_ld(m, c + sk);
+        const double nKx = ldg(sKx, c - sk), nKy = ldg(sKy, c - sk), nKz = ldg(sKz, c - sk);
+        double vsum[4] = {0, 0, 0, 0};
+        if (ADDV && out) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) vsum[l] = ldg((GPTR(const double))dw + (l + 1) * nb, c - sk);
+        }
+        double ULk0[5];
+        kface(qp1, nKx, nKy, nKz, ULk0, []() {});
+        __syncthreads();
+        finish(k1 + 1, vsum);
     }
 }
 
