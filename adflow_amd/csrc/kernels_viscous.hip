@@ -184,6 +184,24 @@ __device__ __forceinline__ GsNbr gs_nbr_ld(const GsPtrs& m, unsigned c)
     return q;
 }
 
+// the same in two halves: request (seven values in flight), then the kinematic viscosity
+struct GsNbrRaw { double u, v, w, rlv, rho, vol, nut; };
+__device__ __forceinline__ GsNbrRaw gs_nbr_req(const GsPtrs& m, unsigned c)
+{
+    GsNbrRaw q;
+    q.u = ldg(m.w1, c); q.v = ldg(m.w2, c); q.w = ldg(m.w3, c);
+    q.rlv = ldg(m.rlv, c); q.rho = ldg(m.w0, c);
+    q.vol = ldg(m.vol, c);
+    q.nut = ldg(m.w5, c);
+    return q;
+}
+__device__ __forceinline__ GsNbr gs_nbr_of(const GsNbrRaw& r)
+{
+    GsNbr q;
+    q.u = r.u; q.v = r.v; q.w = r.w; q.nu = r.rlv * rcp_nr(r.rho); q.vol = r.vol; q.nut = r.nut;
+    return q;
+}
+
 __device__ __forceinline__ GsNbr gs_up1(const GsNbr& q)
 {
     GsNbr r;
@@ -246,7 +264,15 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
     for (int mm = kn0; mm <= kn1; ++mm) {
         const unsigned ckp2 = (mm + 2 <= b.kb) ? 2 * sk : ((mm + 1 <= b.kb) ? sk : 0u);
         const unsigned ckp1 = (mm + 1 <= b.kb) ? sk : 0u;
-        // ---- loads of this plane: the four face-normal triples, the state of the plane above, nuTilde two planes above
+        // ---- loads of this plane, ONE batch in front of the arithmetic (the wave shares its SIMD with one other: every further
+        //      batch is a further exposed latency): the state of the plane above, nuTilde two planes above, the j neighbours, wall
+        //      distance, reference volume, flags; then the four face-normal triples (or the node rows they are formed from)
+        const GsCell sp1 = gs_ld(m, c + ckp1);
+        const double n_p2 = ldg(m.w5, c + ckp2);
+        const GsNbrRaw rjm = gs_nbr_req(m, c - ojm1), rjp = gs_nbr_req(m, c + ojp1);
+        const double n_jm2 = ldg(m.w5, c - ojm2), n_jp2 = ldg(m.w5, c + ojp2);
+        const double d2w = ldg(m.d2wall, c), volRef0 = ldg(m.volRef, c);
+        const int flag0 = flags[c >> 3];
         double nI[3], nJm[3], nJ[3], nK[3];
         if (xn) {
             NgNodes Nn;
@@ -256,8 +282,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
         } else {
             vm_ld3(m.sI, c, m.nb8, nI); vm_ld3(m.sJ, c - ojm1, m.nb8, nJm); vm_ld3(m.sJ, c, m.nb8, nJ); vm_ld3(m.sK, c, m.nb8, nK);
         }
-        const GsCell sp1 = gs_ld(m, c + ckp1);
-        const double n_p2 = ldg(m.w5, c + ckp2);
+        __builtin_amdgcn_sched_barrier(0);
         const double sKm[3] = {sKp[0], sKp[1], sKp[2]};    // sK of the plane below
 #pragma unroll
         for (int d = 0; d < 3; ++d) sKp[d] = nK[d];
@@ -269,8 +294,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
             qkp.u = sp1.u; qkp.v = sp1.v; qkp.w = sp1.w; qkp.nu = sp1.rlv * rcp_nr(sp1.rho); qkp.vol = sp1.vol; qkp.nut = n_p1;
             const GsNbr qim = gs_up1(q0), qip = gs_dn1(q0);
             const double n_im2 = lane_up1(qim.nut), n_ip2 = lane_dn1(qip.nut);
-            const GsNbr qjm = gs_nbr_ld(m, c - ojm1), qjp = gs_nbr_ld(m, c + ojp1);
-            const double n_jm2 = ldg(m.w5, c - ojm2), n_jp2 = ldg(m.w5, c + ojp2);
+            const GsNbr qjm = gs_nbr_of(rjm), qjp = gs_nbr_of(rjp);
             const double nIm[3] = {lane_up1(nI[0]), lane_up1(nI[1]), lane_up1(nI[2])};
             // velocity gradient * 2 vol from the six neighbours (sa.F90:133-190)
             double gu[3][3];
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
                 for (int d = 0; d < 3; ++d)
                     gu[v][d] = qq[v][0] * nI[d] - qq[v][1] * nIm[d] + qq[v][2] * nJ[d] - qq[v][3] * nJm[d] + qq[v][4] * nK[d] - qq[v][5] * sKm[d];
             double qjac = 0.0;
-            double dvt = sa_source(kp, gu, s0.vol, q0.nu, n_0, ldg(m.d2wall, c), SOLVE ? &qjac : nullptr);
+            double dvt = sa_source(kp, gu, s0.vol, q0.nu, n_0, d2w, SOLVE ? &qjac : nullptr);
             SaDir dk, dj, di;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -311,7 +335,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
                 // (scratch 3 .. 8: bb, dd of j, i, k), the sweeps then read two values per cell and direction instead of forming them
                 // from ~20
                 double uuK, uuJ, uuI, c1m, c1p;
-                const double rbl = flg_blank(flags[c >> 3]);
+                const double rbl = flg_blank((uint8_t)flag0);
                 GPTR(double) scr = (GPTR(double))b.scratch;
                 dvt += sa_advect(dk, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uuK); qjac += fabs(uuK) + ((uuK > 0.0) ? uuK * bmK1 : -uuK * bmK2);
                 dvt += sa_advect(dj, s0.vol, s0.u, s0.v, s0.w, secondOrd, &uuJ); qjac += fabs(uuJ) + ((uuJ > 0.0) ? uuJ * bmJ1 : -uuJ * bmJ2);
@@ -335,8 +359,8 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
                 dvt += sa_diffuse(di, s0.vol, q0.nu, kp.sa_cb2, cb3Inv);
             }
             if (outC) {
-                const double blank = flg_blank(flags[c >> 3]);
-                stg(dw5, c, -ldg(m.volRef, c) * dvt * blank);
+                const double blank = flg_blank((uint8_t)flag0);
+                stg(dw5, c, -volRef0 * dvt * blank);
                 // setRVec of the matrix-free matvec: dw / volRef * turbResScale
                 if (RV)
                     kp.rvec[b.vecOff + ((((long)(mm - 2) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw) + 5] = -dvt * blank * kp.rvecTurbScale;
