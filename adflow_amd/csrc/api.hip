@@ -30,6 +30,8 @@ hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr, g_evB1 = nullpt
 hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
+int g_sa_side = 0;         // tuning "sa_side": SA residual on a side queue beside the mean-flow kernels.  Round 4: with every march laid out
+                           // for two resident waves per SIMD the kernels no longer fill each other's gaps (2.26 beside, 2.21 ms in a row)
 adflow_opts g_opts;
 bool g_have_opts = false;
 hipEvent_t g_events[64];
@@ -1332,7 +1334,7 @@ static int block_res_enqueue(int level, unsigned flags)
             LevelTab t;
             if (level_tab(level, &t)) return 1;
             hipStream_t ss = g_stream;
-            if (g_overlap && g_phase_base <= 0 && (flags & ADFLOW_RES_FLOW)) {
+            if (g_overlap && g_sa_side && g_phase_base <= 0 && (flags & ADFLOW_RES_FLOW)) {
                 // fork: the SA residual (writes dw(:,:,:,itu1) only) runs beside the mean-flow kernels; joined below
                 HIPCHK(hipEventRecord(g_evFork, g_stream));
                 HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
@@ -3623,6 +3625,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
     if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
     if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
+    if (!strcmp(key, "sa_side")) { g_sa_side = value; return 0; }
     if (!strcmp(key, "max_grid_z")) { g_max_grid_z = (value > 0) ? value : 65535; return 0; }
     if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }
     if (!strcmp(key, "xcd_tiles")) {

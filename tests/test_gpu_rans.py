@@ -225,6 +225,9 @@ def test_viscous_kernel_variants(engine):
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
         engine.set_tuning("sa_march", 1)
+        engine.set_tuning("sa_side", 1)     # the SA march on its side queue beside the mean-flow kernels (the default of rounds 2-3)
+        checks.check_block_res(engine, (63, 11, 35), FlowParams(equations=RANSEquations, spaceDiscr=upwind), seed=12, stretch_k=2.0)
+        engine.set_tuning("sa_side", 0)
         # the viscous march in front of each inviscid march over the tile table (Roe, matrix dissipation, scalar JST), QCR, minmod
         for prm in (FlowParams(equations=RANSEquations, spaceDiscr=upwind, useQCR=True, muSuthDim=1.0),
                     FlowParams(equations=NSEquations, spaceDiscr=upwind, limiter=minmod, muSuthDim=1.0),
@@ -252,6 +255,7 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("viscous_tiled", 2)
         engine.set_tuning("roe_march", 1)
         engine.set_tuning("sa_march", 1)
+        engine.set_tuning("sa_side", 0)
         engine.set_tuning("metric_from_x", 7)
         engine.set_tuning("xcd_tiles", 2)
         engine.set_tuning("gf_cus", 0)
