@@ -234,6 +234,7 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
 #define RM_UR (5 * 5 * 64)
 #define RM_FJ(FW) (4 * ((FW) ? 10 : 5) * 64)
 #define RM_XJ(FW) (RM_UR + RM_FJ(FW))
+#define RM_XQ (12 * 64)        // rows j0-1 and j0 of the plane as wave 0 holds them (six values each), for the wave of the fifth face
 
 // FW: persistent dissipation residual of the Runge-Kutta scheme (fw kept between the stages); FINAL: dw = (dw + fw) iblank
 // written here, otherwise the sum dw + fw is left in dw for the viscous kernel to complete (residuals.F90:334-344)
@@ -242,9 +243,11 @@ __device__ __forceinline__ void rm_face(const RmK& K, const RCell& b, const RCel
 // Faces per cell (round 3): a wave evaluates the k face below its cell (carried), the i face (i-1 | i) (the other one by DPP) and
 // the j face ABOVE its cell; the flux through the j face BELOW comes from the wave of the row below through LDS, one plane later
 // (the barrier of the next plane orders it, double-buffered by parity): the sum of cell k-1 is completed behind the barrier of
-// step k.  The face below row 0 of the tile has no wave: it is the "fifth j face" and wave (k mod 4) takes it in plane k -- it
-// loads the three rows j0-2 .. j0 of that plane, reconstructs cell j0-1 and hands the flux to wave 0 -- so that over four planes
-// every SIMD carries the same load: 3.25 face evaluations and 3.5 reconstructions per cell (4 and 3.5 before).
+// step k.  The face below row 0 of the tile has no wave: it is the "fifth j face" and wave (k mod 4) takes it in plane k -- behind
+// the barrier it takes the rows j0-1 and j0 of that plane from LDS, where wave 0 has put its own row and the row below it
+// (round 4; it loaded them itself before: 17 values requested and awaited while three waves stood at the barrier), loads row
+// j0-2, reconstructs cell j0-1 and hands the flux to wave 0 -- so that over four planes every SIMD carries the same load: 3.25
+// face evaluations and 3.5 reconstructions per cell (4 and 3.5 before).
 // RV (with FINAL, without FW): the completed residual also goes to the matrix-free residual vector kp.rvec as dw / volRef (setRVec)
 template <int LIM, bool FW, bool FINAL, bool ADDV = false, bool RV = false>
 __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, const KParams& kp, int kch,
@@ -395,34 +398,29 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         //      some waves need (wave 3: the row above the tile; the wave of the fifth face: three rows below it) are requested BEHIND
         //      the wait of this reconstruction and consumed behind the k face: a conditional request in front of a wait makes the
         //      wave that issued it wait for it there
-        RCell qEmm, qEm, qE0;
-        double ULj[5], ULe[5];
+        double* __restrict__ xq = xj + 2 * RM_XJ(FW) + (k & 1) * RM_XQ;
+        double ULj[5];
         {
             double URj[5];
             rm_recon<LIM>(K, qjm, q0, qjp, ULj, URj);
 #pragma unroll
             for (int l = 0; l < 5; ++l) xb[(row * 5 + l) * 64 + lane] = URj[l];
+            if (row == 0) {               // rows j0-1 and j0 of this plane for the wave of the fifth face
+                xq[0 * 64 + lane] = qjm.rho; xq[1 * 64 + lane] = qjm.u; xq[2 * 64 + lane] = qjm.v; xq[3 * 64 + lane] = qjm.w;
+                xq[4 * 64 + lane] = qjm.p; xq[5 * 64 + lane] = qjm.e;
+                xq[6 * 64 + lane] = q0.rho; xq[7 * 64 + lane] = q0.u; xq[8 * 64 + lane] = q0.v; xq[9 * 64 + lane] = q0.w;
+                xq[10 * 64 + lane] = q0.p; xq[11 * 64 + lane] = q0.e;
+            }
         }
         double ULk0[5];
         kface(qp1, nKx, nKy, nKz, ULk0, []() {});
         __builtin_amdgcn_sched_barrier(0);
-        int flagE = 0;
-        if (fifth) {
-            flagE = flags[(cE - sj) >> 3];
-            qEmm = rm_ld(m, cE - 2 * sj);
-            qEm = rm_ld(m, cE - sj);
-            qE0 = rm_ld(m, cE);
-        }
         if (row == RM_BY - 1) {                                          // wave 3: also the cell above the tile
             const RCell qjp2 = rm_ld(m, c + oj2);
             double pl[5], mi[5];
             rm_recon<LIM>(K, q0, qjp, qjp2, pl, mi);
 #pragma unroll
             for (int l = 0; l < 5; ++l) xb[(4 * 5 + l) * 64 + lane] = mi[l];
-        }
-        if (fifth) {
-            double mi[5];
-            rm_recon<LIM>(K, qEmm, qEm, qE0, ULe, mi);                  // left state of the face (j0-1 | j0)
         }
         // request what the part behind the barrier and phase A of the next step consume
         double nJ[3], nIn[3], nE[3] = {0, 0, 0};
@@ -434,9 +432,13 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         nJ[0] = ldg(sJx, c); nJ[1] = ldg(sJy, c); nJ[2] = ldg(sJz, c);
         nIn[0] = ldg(sIx, c + sk - 8u); nIn[1] = ldg(sIy, c + sk - 8u); nIn[2] = ldg(sIz, c + sk - 8u);
         const int flagp = flags[(c + sk) >> 3];
+        RCell qEmm;
+        int flagE = 0;
         if (fifth) {
             const unsigned cm = cE - sj;
+            qEmm = rm_ld(m, cE - 2 * sj);
             nE[0] = ldg(sJx, cm); nE[1] = ldg(sJy, cm); nE[2] = ldg(sJz, cm);
+            flagE = flags[cm >> 3];
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -472,6 +474,13 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         }
         // ---- the fifth j face (j0-1 | j0): right state = UR of row 0
         if (fifth) {
+            RCell qEm, qE0;
+            qEm.rho = xq[0 * 64 + lane]; qEm.u = xq[1 * 64 + lane]; qEm.v = xq[2 * 64 + lane]; qEm.w = xq[3 * 64 + lane];
+            qEm.p = xq[4 * 64 + lane]; qEm.e = xq[5 * 64 + lane];
+            qE0.rho = xq[6 * 64 + lane]; qE0.u = xq[7 * 64 + lane]; qE0.v = xq[8 * 64 + lane]; qE0.w = xq[9 * 64 + lane];
+            qE0.p = xq[10 * 64 + lane]; qE0.e = xq[11 * 64 + lane];
+            double ULe[5], mi[5];
+            rm_recon<LIM>(K, qEmm, qEm, qE0, ULe, mi);                  // left state of the face (j0-1 | j0)
             double Rm[5];
 #pragma unroll
             for (int l = 0; l < 5; ++l) Rm[l] = xb[l * 64 + lane];
@@ -511,7 +520,7 @@ template <int LIM, bool FW, bool FINAL, bool ADDV = false, bool RV = false>
 __global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                              int kch)
 {
-    __shared__ double xj[2 * RM_XJ(FW)];
+    __shared__ double xj[2 * RM_XJ(FW) + 2 * RM_XQ];
     roe_march_body<LIM, FW, FINAL, ADDV, RV>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
 }
 
