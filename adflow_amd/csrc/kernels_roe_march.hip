@@ -370,6 +370,8 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         const double nKx = ldg(sKx, c - sk), nKy = ldg(sKy, c - sk), nKz = ldg(sKz, c - sk);
         const RCell qjm = rm_ld(m, c - sj);
         const RCell qjp = rm_ld(m, c + sj);
+        RCell qjp2;
+        if (row == RM_BY - 1) qjp2 = rm_ld(m, c + oj2);                     // wave 3: also reconstructs the cell above the tile
         __builtin_amdgcn_sched_barrier(0);
         // ---- A: this lane evaluates the i face (i-1 | i) of cell k; the face (i | i+1) comes from lane+1
         double gI[5], gID[5] = {0, 0, 0, 0, 0};
@@ -416,14 +418,13 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         kface(qp1, nKx, nKy, nKz, ULk0, []() {});
         __builtin_amdgcn_sched_barrier(0);
         if (row == RM_BY - 1) {                                          // wave 3: also the cell above the tile
-            const RCell qjp2 = rm_ld(m, c + oj2);
             double pl[5], mi[5];
             rm_recon<LIM>(K, q0, qjp, qjp2, pl, mi);
 #pragma unroll
             for (int l = 0; l < 5; ++l) xb[(4 * 5 + l) * 64 + lane] = mi[l];
         }
         // request what the part behind the barrier and phase A of the next step consume
-        double nJ[3], nIn[3], nE[3] = {0, 0, 0};
+        double nJ[3], nIn[3], nE[3];
         double vsum[4] = {0, 0, 0, 0};       // ADDV: viscous flux sums of the cell finished in this step
         if (ADDV && k > k0 && out) {
 #pragma unroll
@@ -432,14 +433,13 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         nJ[0] = ldg(sJx, c); nJ[1] = ldg(sJy, c); nJ[2] = ldg(sJz, c);
         nIn[0] = ldg(sIx, c + sk - 8u); nIn[1] = ldg(sIy, c + sk - 8u); nIn[2] = ldg(sIz, c + sk - 8u);
         const int flagp = flags[(c + sk) >> 3];
+        // (normal and flags of the fifth face by every wave: inside the condition the compiler decodes the flags there and then, i.e.
+        // makes that wave wait for this whole request in front of the barrier)
         RCell qEmm;
-        int flagE = 0;
-        if (fifth) {
-            const unsigned cm = cE - sj;
-            qEmm = rm_ld(m, cE - 2 * sj);
-            nE[0] = ldg(sJx, cm); nE[1] = ldg(sJy, cm); nE[2] = ldg(sJz, cm);
-            flagE = flags[cm >> 3];
-        }
+        const unsigned cm = cE - sj;
+        nE[0] = ldg(sJx, cm); nE[1] = ldg(sJy, cm); nE[2] = ldg(sJz, cm);
+        const int flagE = flags[cm >> 3];
+        if (fifth) qEmm = rm_ld(m, cE - 2 * sj);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
