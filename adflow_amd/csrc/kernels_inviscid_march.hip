@@ -170,10 +170,20 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
 #pragma unroll
             for (int l = 0; l < 4; ++l) vsum[l] = ldg((GPTR(const double))dw + (l + 1) * nb, c - sk);
         }
+        // ---- everything else the step reads, requested HERE: the wave shares its SIMD with one other, and every request that stands
+        //      in front of its own use is a latency nobody covers (round 4; the k and the i face below run on what has arrived)
+        const double nK[3] = {ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk)};
+        const double nI[3] = {ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u)};
+        const double radI0 = SCAL ? ldg(radI, c) : 0.0;
+        const MCell qa = im_ld<SCAL>(m, c - 2 * sj), qb = im_ld<SCAL>(m, c - sj), qc = im_ld<SCAL>(m, c + sj), qd = im_ld<SCAL>(m, c + 2 * sj);
+        const int flagJm = flags[(c - sj) >> 3];
+        const double radJ0 = SCAL ? ldg(radJ, c) : 0.0, radJm = SCAL ? ldg(radJ, c - sj) : 0.0, radJp = SCAL ? ldg(radJ, c + sj) : 0.0;
+        const double nJm[3] = {ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj)};
+        const double nJ[3] = {ldg(sJx, c), ldg(sJy, c), ldg(sJz, c)};
+        __builtin_amdgcn_sched_barrier(0);
         // ---- k-face between cells k-1 and k (normal and porosity stored at cell k-1)
         double fc[5], fd[5];
-        im_face<SCHEME>(F, qm2, qm1, q0, qp1, ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk), flg_porK((uint8_t)flagm), dssKm,
-                        dssK0, fc, fd, radKm + radK0);
+        im_face<SCHEME>(F, qm2, qm1, q0, qp1, nK[0], nK[1], nK[2], flg_porK((uint8_t)flagm), dssKm, dssK0, fc, fd, radKm + radK0);
         // ---- finish cell k-1 and write it
         if (k > k0 && out) {
             const unsigned cw = c - sk;
@@ -215,12 +225,9 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
                 dL = lane_up1(d0);
             }
             double radSum = 0.0;
-            if (SCAL) {
-                const double rad0 = ldg(radI, c);
-                radSum = lane_up1(rad0) + rad0;
-            }
+            if (SCAL) radSum = lane_up1(radI0) + radI0;
             double gc[5], gd[5];
-            im_face<SCHEME>(F, qLL, qL, q0, qR, ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u), por, dL, d0, gc, gd, radSum);
+            im_face<SCHEME>(F, qLL, qL, q0, qR, nI[0], nI[1], nI[2], por, dL, d0, gc, gd, radSum);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 accC[l] += lane_dn1(gc[l]) - gc[l];     // + plus face, - minus face
@@ -229,9 +236,7 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
         }
         // ---- j-direction: both faces of the cell
         {
-            const MCell qa = im_ld<SCAL>(m, c - 2 * sj), qb = im_ld<SCAL>(m, c - sj), qc = im_ld<SCAL>(m, c + sj),
-                        qd = im_ld<SCAL>(m, c + 2 * sj);
-            const int porM = flg_porJ(flags[(c - sj) >> 3]), porP = flg_porJ((uint8_t)flag0);
+            const int porM = flg_porJ((uint8_t)flagJm), porP = flg_porJ((uint8_t)flag0);
             double dm = 0.0, d0 = 0.0, dp = 0.0;
             if (sens) {
                 dm = sensor(qa, qb, q0);
@@ -240,15 +245,14 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
             }
             double rM = 0.0, rP = 0.0;
             if (SCAL) {
-                const double r0 = ldg(radJ, c);
-                rM = ldg(radJ, c - sj) + r0;
-                rP = r0 + ldg(radJ, c + sj);
+                rM = radJm + radJ0;
+                rP = radJ0 + radJp;
             }
             double hc[5], hd[5];
-            im_face<SCHEME>(F, qa, qb, q0, qc, ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj), porM, dm, d0, hc, hd, rM);
+            im_face<SCHEME>(F, qa, qb, q0, qc, nJm[0], nJm[1], nJm[2], porM, dm, d0, hc, hd, rM);
 #pragma unroll
             for (int l = 0; l < 5; ++l) { accC[l] -= hc[l]; accD[l] += hd[l]; }
-            im_face<SCHEME>(F, qb, q0, qc, qd, ldg(sJx, c), ldg(sJy, c), ldg(sJz, c), porP, d0, dp, hc, hd, rP);
+            im_face<SCHEME>(F, qb, q0, qc, qd, nJ[0], nJ[1], nJ[2], porP, d0, dp, hc, hd, rP);
 #pragma unroll
             for (int l = 0; l < 5; ++l) { accC[l] += hc[l]; accD[l] -= hd[l]; }
         }
