@@ -127,7 +127,7 @@ __device__ __forceinline__ void rm_recon(const RmK& K, const RCell& a, const RCe
         rm_va_sym(a.w, b.w, c.w, plus[3], minus[3], range);
         rm_va_sym(a.p, b.p, c.p, plus[4], minus[4], range);
 #ifdef RM_COUNT_NO_CLAMP           // tools/isa_report.py: the loop as a wave executes it where no difference lies inside the clamp
-        if (range < 0x3ddb7cdfu) __builtin_trap();
+        if (range < 0x3ddb7cdfu) plus[0] = 0.0;        // (keeps the range arithmetic alive: a compare + select where the kernel branches)
         return;
 #endif
         if (range >= 0x3ddb7cdfu) return;      // 0x3ddb7cdf: high word of epsLim = 1e-10; an equal high word takes the clamped form too

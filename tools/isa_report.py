@@ -66,6 +66,17 @@ def main():
                 full["issue_cycles"] = base["issue_cycles"] + (full["issue_cycles"] - base["issue_cycles"]) // 4
                 full["valu"] = base["valu"] + (full["valu"] - base["valu"]) // 4
                 full["what"] += " (average step: the fifth-j-face block counted once in four planes)"
+        # registers / scratch / LDS of the Roe march as the library ships it (with the clamp block)
+        o = os.path.join(td, "roe_shipped.s")
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                            os.path.join(ROOT, "adflow_amd", "csrc", "kernels_roe_march.hip"), "-o", o], capture_output=True, text=True)
+        if r.returncode == 0 and "roe_march" in out["kernels"]:
+            shipped = main_loop(o, KERNELS["roe_march"][1])
+            if shipped:
+                for key in ("NumVgprs", "ScratchSize", "LDSByteSize", "Occupancy", "NumSgprs"):
+                    if key in shipped:
+                        out["kernels"]["roe_march"][key] = shipped[key]
+                out["kernels"]["roe_march"]["what"] += "; counted without the block a lane enters where a difference lies inside the limiter's clamp"
     p = os.path.join(ROOT, "profiles", "isa_counts.json")
     json.dump(out, open(p, "w"), indent=1)
     for k, v in out["kernels"].items():
