@@ -48,6 +48,44 @@ def shock_block(dims, prm: FlowParams, seed=1, mach=3.0, **mk):
     return blk
 
 
+def clamp_block(dims, prm: FlowParams, seed=1, **mk):
+    """State for the epsLim clamp of the MUSCL limiters (fluxes.F90:2103-2294): the lower half in i is a uniform flow with
+    perturbations of 2e-11 .. 2e-10 relative (differences of either sign, on both sides of epsLim = 1e-10, some exactly zero), the
+    upper half carries 1 % noise, so that the residual the comparison is scaled by is of order one."""
+    blk = make_block(*dims, prm, seed=seed, **mk)
+    w, p = blk["w"], blk["p"]
+    ni = w.shape[0]
+    rng = np.random.default_rng(seed)
+    i = np.arange(ni)[:, None, None]
+    low = i < ni // 2
+    tiny = rng.choice([0.0, 2.e-11, 5.e-11, 1.e-10, 2.e-10], size=p.shape) * rng.uniform(-1, 1, p.shape)
+    base = [1.0, 0.8, 0.05, -0.03]
+    for l in range(4):
+        noisy = base[l] * (1.0 + 0.01 * rng.uniform(-1, 1, p.shape))
+        tl = rng.choice([0.0, 2.e-11, 5.e-11, 1.e-10, 2.e-10], size=p.shape) * rng.uniform(-1, 1, p.shape)
+        w[..., l] = np.where(low, base[l] + tl, noisy)
+    p0 = 1.0 / prm.gammaConstant
+    p[...] = np.where(low, p0 + tiny, p0 * (1.0 + 0.01 * rng.uniform(-1, 1, p.shape)))
+    _energy(blk, prm)
+    return blk
+
+
+def count_clamped_differences(blk):
+    """cells whose smaller one-sided difference (any of rho, u, v, w, p; any direction) lies strictly between 0 and epsLim"""
+    q = [blk["w"][..., l] for l in range(4)] + [blk["p"]]
+    n = 0
+    for a in q:
+        for ax in range(3):
+            d = np.abs(np.diff(a, axis=ax))
+            lo = [slice(None)] * 3
+            hi = [slice(None)] * 3
+            lo[ax] = slice(0, -1)
+            hi[ax] = slice(1, None)
+            m = np.minimum(d[tuple(lo)], d[tuple(hi)])
+            n += int(((m > 0.0) & (m < 1.e-10)).sum())
+    return n
+
+
 def count_shock_branches(blk, prm: FlowParams):
     """recount of the branches on the i faces (cells 1..ie, faces i = 1..il) from the block's arrays"""
     g = prm.gammaConstant

@@ -28,6 +28,21 @@ def test_mach3_shock_dissipation_clips_entropy_fix_limiter_extremes(engine):
     shock_cases(engine, (70, 9, 6))
 
 
+def clamp_cases(engine, dims):
+    """differences inside the epsLim clamp of the limiters: k_roe_march takes its symmetric van Albada form only where no difference
+    of a reconstruction lies in (0, epsLim) and the clamped form of the reference elsewhere"""
+    for eq in (1, RANSEquations):
+        for lim in (vanAlbeda, minmod):
+            prm = FlowParams(equations=eq, spaceDiscr=upwind, limiter=lim)
+            blk = adversarial.clamp_block(dims, prm, seed=40 + lim, stretch_k=2.0 if eq != 1 else 1.0)
+            assert adversarial.count_clamped_differences(blk) > 1000
+            checks.check_block_res(engine, dims, prm, blk=blk)
+
+
+def test_limiter_clamp_tiny_differences(engine):
+    clamp_cases(engine, (70, 9, 6))
+
+
 def shock_default_flags_case(engine, dims):
     """the same Mach-3 shock through blocketteRes with its DEFAULT flags: for Euler + scalar JST the march forms the spectral radii
     itself (fast_powa, rcp / rsq forms) on states whose radii span orders of magnitude; RANS takes the marching kernels"""

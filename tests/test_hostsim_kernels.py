@@ -429,6 +429,11 @@ def test_adversarial_states(hostsim_engine):
     T.sa_cases(hostsim_engine, (16, 6, 12))
 
 
+def test_limiter_clamp_tiny_differences(hostsim_engine):
+    import test_gpu_adversarial as T
+    T.clamp_cases(hostsim_engine, (30, 7, 6))
+
+
 _JAC_WALL = {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}
 _JAC_EULER = {1: -6, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9}
 

@@ -1,2 +1,2 @@
-export GIT=63117be TAG=r04_fin EXTRAS="config3 matvec 4b" ROWS=24
-bash tools/_gpu_job_extras.sh
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_gpu_adversarial.py -m gpu -x -q 2>&1 | tail -4
