@@ -1,2 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_adversarial.py -m gpu -x -q 2>&1 | tail -4
+O=gpurun_out; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -5 | tee $O/r04_fin2_pytest.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 600 python bench.py --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_fin2_bench_noextras.json
