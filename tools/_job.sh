@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -5 | tee $O/r04_fin2_pytest.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 600 python bench.py --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_fin2_bench_noextras.json
+timeout 400 rocprofv3 --kernel-trace -d $O/prof -o t -- python bench.py --no-extras --no-cpu-baseline --steps 6 --warmup 2 --min-seconds 0.1 > /dev/null 2>&1
+python tools/_q.py $O/prof/t_results.db | tee $O/r04_bc_dispatches.txt
+rm -rf $O/prof
