@@ -538,3 +538,27 @@ def test_random_parity_sweep(hostsim_engine):
     import fuzz_parity
     n, failure = fuzz_parity.sweep(hostsim_engine, 40, seed=20260926, quiet=True)
     assert failure is None, failure
+
+
+def test_documented_tuning_keys_are_the_library_s(hostsim_engine):
+    """DESIGN.md 8b lists the tuning keys with their defaults: every one of them is accepted (set to its default), an unknown key is
+    refused -- the table and adflow_gpu_set_tuning stay in step"""
+    import os
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "DESIGN.md")).read()
+    i = txt.index("## 8b. Tuning keys")
+    j = txt.index("## 8a.", i)
+    keys = []
+    for line in txt[i:j].split("\n"):
+        if not line.startswith("| `"):
+            continue
+        cells = [c.strip() for c in line.strip("|").split("|")]
+        ks = re.findall(r"`([a-z_0-9]+)`", cells[0])
+        ds = [d.strip() for d in cells[1].split(",")]
+        assert len(ds) == len(ks), line
+        keys += list(zip(ks, ds))
+    assert len(keys) >= 20, keys
+    for k, d in keys:
+        hostsim_engine.set_tuning(k, int(d))
+    with pytest.raises(Exception):
+        hostsim_engine.set_tuning("no_such_key", 1)
