@@ -34,6 +34,9 @@ class Block:
     a: Dict[str, np.ndarray] = field(default_factory=dict)
     rotRate: Optional[tuple] = None      # cgnsDoms%rotRate of a moving block (blockIsMoving), None at rest
     rightHanded: bool = True             # blockType%rightHanded: (i, j, k) right-handed; False: metric_block uses fact = -half
+    nodeParams: Optional[tuple] = None   # (xi, eta, zeta) of the nodes 0..ie / je / ke in the analytic map (make_nodes)
+    coarsened: tuple = ("regular", "regular", "regular")   # blockType%iCoarsened / jCoarsened / kCoarsened (block.F90:230-233)
+    nodeMap: Optional[tuple] = None      # coarse block: per direction the FINE node of every coarse node 1..il (imap of createCoarseBlocks)
 
     # index helpers (reference naming)
     @property
@@ -68,7 +71,8 @@ class Block:
         return self.a[name][2:self.il + 1, 2:self.jl + 1, 2:self.kl + 1]
 
     def copy(self) -> "Block":
-        return Block(self.nx, self.ny, self.nz, self.nw, {k: v.copy(order="F") for k, v in self.a.items()}, self.rotRate, self.rightHanded)
+        return Block(self.nx, self.ny, self.nz, self.nw, {k: v.copy(order="F") for k, v in self.a.items()}, self.rotRate, self.rightHanded,
+                     self.nodeParams, self.coarsened, self.nodeMap)
 
 
 def add_grid_velocities(blk: "Block", prm, rotRate=(0.05, -0.03, 0.12), rotCenter=(0.3, -0.2, 0.1)):
@@ -100,17 +104,25 @@ def F(shape, dtype=np.float64):
 # ----------------------------------------------------------------------------
 # geometry
 # ----------------------------------------------------------------------------
-def make_nodes(nx, ny, nz, lengths=(1.0, 1.0, 1.0), amp=0.02, stretch_k=1.0, origin=(0.0, 0.0, 0.0)):
-    """Nodes x(0:ie,0:je,0:ke,3): smooth non-orthogonal right-handed map of the
-    unit cube (node 1 -> 0, node il -> 1; halo nodes 0 and ie continue the map)."""
-    ie, je, ke = nx + 2, ny + 2, nz + 2
-    xi = (np.arange(ie + 1) - 1.0) / nx
-    et = (np.arange(je + 1) - 1.0) / ny
-    ze = (np.arange(ke + 1) - 1.0) / nz
+def node_params(nx, ny, nz, stretch_k=1.0):
+    """Parameters (xi, eta, zeta) of the nodes 0..ie / je / ke of a uniformly divided block (node 1 -> 0, node il -> 1)."""
+    xi = (np.arange(nx + 3) - 1.0) / nx
+    et = (np.arange(ny + 3) - 1.0) / ny
+    ze = (np.arange(nz + 3) - 1.0) / nz
     if stretch_k != 1.0:
         # geometric-like clustering towards the k=kmin plane (wall)
         s = stretch_k
         ze = np.sign(ze) * (np.expm1(s * np.abs(ze)) / math.expm1(s))
+    return xi, et, ze
+
+
+def make_nodes(nx, ny, nz, lengths=(1.0, 1.0, 1.0), amp=0.02, stretch_k=1.0, origin=(0.0, 0.0, 0.0), params=None):
+    """Nodes x(0:ie,0:je,0:ke,3): smooth non-orthogonal right-handed map of the
+    unit cube (node 1 -> 0, node il -> 1; halo nodes 0 and ie continue the map).
+    params: the nodes' (xi, eta, zeta) instead of the uniform division (irregularly coarsened multigrid levels)."""
+    ie, je, ke = nx + 2, ny + 2, nz + 2
+    xi, et, ze = params if params is not None else node_params(nx, ny, nz, stretch_k)
+    assert len(xi) == ie + 1 and len(et) == je + 1 and len(ze) == ke + 1
     X, E, Z = np.meshgrid(xi, et, ze, indexing="ij")
     tp = 2.0 * math.pi
     x = F((ie + 1, je + 1, ke + 1, 3))
@@ -199,14 +211,16 @@ def sa_eddy_viscosity(prm: FlowParams, rho, nut, rlv):
 
 def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.0), amp=0.02,
                stretch_k=1.0, wall_kmin=None, noise=0.02, wave=0.05, origin=(0.0, 0.0, 0.0), holes=0.0,
-               noflux_jmax=False, moving=False, left_handed=False) -> Block:
+               noflux_jmax=False, moving=False, left_handed=False, params=None) -> Block:
     """Analytic curvilinear block + perturbed free-stream state.
-    moving: a block of a steadily rotating frame (add_grid_velocities)."""
+    moving: a block of a steadily rotating frame (add_grid_velocities).
+    params: (xi, eta, zeta) of the nodes (make_nodes) instead of the uniform division."""
     rng = np.random.default_rng(seed)
     nw = prm.nw
     b = Block(nx, ny, nz, nw)
     ib, jb, kb = b.ib, b.jb, b.kb
-    x = make_nodes(nx, ny, nz, lengths, amp, stretch_k, origin)
+    b.nodeParams = params if params is not None else node_params(nx, ny, nz, stretch_k)
+    x = make_nodes(nx, ny, nz, lengths, amp, stretch_k, origin, b.nodeParams)
     sI, sJ, sK = face_metrics(x)
     if left_handed:
         # mirror image of the block: the index system becomes left-handed and the reference's metric_block takes fact = -half so
@@ -284,10 +298,12 @@ def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.
 # boundaries (one subface per face, cell range including the first halo ring as the
 # reference's preprocessing builds it).  Viscous walls come first (nViscBocos).
 # ----------------------------------------------------------------------------
-def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7, split=()):
+def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7, split=(), split_at=None):
     """spec: {faceID (1..6 = iMin,iMax,jMin,jMax,kMin,kMax): BCType}.  Returns (faces, nViscBocos).
     split: {faceID: BCType of the second half}: the face is cut in two subfaces along its first index (the lower
-    half keeps spec's kind), as block faces that are only partly a wall / partly farfield are in real meshes."""
+    half keeps spec's kind), as block faces that are only partly a wall / partly farfield are in real meshes.
+    split_at: {faceID: last cell of the lower subface} instead of the middle of the face (coarse multigrid levels: the cut
+    follows the fine level's)."""
     rng = np.random.default_rng(seed)
     ie, je, ke = blk.ie, blk.je, blk.ke
     sI, sJ, sK = blk["sI"], blk["sJ"], blk["sK"]
@@ -354,7 +370,7 @@ def make_bocos(blk: Block, prm: FlowParams, spec: dict, seed=7, split=()):
     for fid, typ2 in dict(split).items():
         m = next(ix for ix, f in enumerate(faces) if f["faceID"] == fid)
         f = faces[m]
-        h = (f["icBeg"] + f["icEnd"]) // 2
+        h = (f["icBeg"] + f["icEnd"]) // 2 if not split_at or fid not in split_at else int(split_at[fid])
         lo, hi = dict(f), dict(f)
         lo["icEnd"], hi["icBeg"], hi["bcType"] = h, h + 1, int(typ2)
         n0 = h - f["icBeg"] + 1
@@ -403,36 +419,92 @@ def set_porosities(blk: Block, faces) -> None:
 
 
 # ----------------------------------------------------------------------------
-# multigrid: regular 2:1 coarsening maps (src/preprocessing/coarseUtils.F90:254-420)
+# multigrid: coarsening maps of createCoarseBlocks (src/preprocessing/coarseUtils.F90:73-420)
 # ----------------------------------------------------------------------------
-def mg_maps_1d(nf: int):
-    """Maps of one direction for nf fine cells (nf even) -> nc = nf/2 coarse cells.
-    Returns (mgFine (1:ie_c,2), mgWeight (2:il_c), mgCoarse (2:il_f,2))."""
-    assert nf % 2 == 0 and nf >= 2
-    nc = nf // 2
+def coarsen_1d(nf: int, state: str = "regular", keep=()):
+    """One index direction of createCoarseBlocks for nf fine cells (nodes 1..nf+1).
+    state: the fine level's iCoarsened ("regular" / "leftStarted" / "rightStarted"): a level that was itself coarsened
+    irregularly from the left is swept from the right and vice versa (coarseUtils.F90:134-153).
+    keep: fine NODES that must survive besides the block ends (the boundaries of the subfaces, :117-127).
+    Every second node is dropped; where two kept nodes end up adjacent the coarse cell between them consists of ONE fine
+    cell: its fine index is stored twice and its restriction weight is 1/2 (:281-295), and the fine cell interpolates from
+    that coarse cell alone (:331-343).
+    Returns (mgFine (1:ie_c,2), mgWeight (2:il_c), mgCoarse (2:il_f,2), nodeMap (coarse node 1..il_c -> fine node), state_c)."""
+    assert nf >= 1
+    iil = nf + 1
+    co = np.zeros(iil + 2, bool)                # 1-based; co[0] and co[iil+1] unused
+    co[1] = co[iil] = True
+    for n in keep:
+        co[int(n)] = True
+    if state == "leftStarted":
+        new = "rightStarted"
+        for i in range(iil - 1, 1, -1):
+            if not co[i + 1]:
+                co[i] = True
+    else:
+        new = "leftStarted"
+        for i in range(2, iil):
+            if not co[i - 1]:
+                co[i] = True
+    il = int(co[1:iil + 1].sum())
+    nc = il - 1
+    if nf == 2 * nc:
+        new = "regular"
     ie_c = nc + 2
-    ie_f, ib_f = nf + 2, nf + 3
-    fine = np.zeros((ie_c, 2), np.int32, order="F")
+    fine = np.zeros((ie_c, 2), np.int32, order="F")           # row m-1 = coarse cell m
     fine[0] = (0, 1)
-    fine[ie_c - 1] = (ie_f, ib_f)
-    for ii in range(2, nc + 2):                 # coarse cell ii covers fine cells 2ii-2, 2ii-1
-        fine[ii - 1] = (2 * ii - 2, 2 * ii - 1)
+    fine[ie_c - 1] = (nf + 2, nf + 3)
     weight = np.ones(nc, np.float64)
-    coarse = np.zeros((nf, 2), np.int32, order="F")
-    for i in range(2, nf + 2):                  # fine cell i: nearest / next-nearest coarse cell
-        ii = i // 2 + 1
-        coarse[i - 2] = (ii, ii - 1) if i % 2 == 0 else (ii, ii + 1)
-    return fine, weight, coarse
+    coarse = np.zeros((nf, 2), np.int32, order="F")           # row i-2 = fine cell i
+    ii = 2
+    for i in range(2, iil + 1):
+        if co[i]:
+            if co[i - 1]:
+                fine[ii - 1] = (i, i)
+                weight[ii - 2] = 0.5
+                coarse[i - 2] = (ii, ii)
+            else:
+                fine[ii - 1] = (i - 1, i)
+                coarse[i - 2] = (ii, ii + 1)
+            ii += 1
+        else:
+            coarse[i - 2] = (ii, ii - 1)
+    node_map = np.array([i for i in range(1, iil + 1) if co[i]], np.int32)
+    assert ii == il + 1 and node_map.size == il
+    return fine, weight, coarse, node_map, new
 
 
-def make_coarse_block(fine: Block, prm: FlowParams, **mk) -> Block:
-    """Level+1 block of `fine` (same analytic map at half resolution) with the
-    transfer maps attached to both blocks."""
-    c = make_block(fine.nx // 2, fine.ny // 2, fine.nz // 2, prm, **mk)
-    for d, nf in (("I", fine.nx), ("J", fine.ny), ("K", fine.nz)):
-        f, wgt, co = mg_maps_1d(nf)
-        c["mg%sFine" % d], c["mg%sWeight" % d] = f, wgt
-        fine["mg%sCoarse" % d] = co
+def mg_maps_1d(nf: int):
+    """Maps of one direction for nf fine cells coarsened from a regular level (even nf: 2:1, nc = nf/2).
+    Returns (mgFine (1:ie_c,2), mgWeight (2:il_c), mgCoarse (2:il_f,2))."""
+    return coarsen_1d(nf)[:3]
+
+
+def make_coarse_block(fine: Block, prm: FlowParams, keep=((), (), ()), **mk) -> Block:
+    """Level+1 block of `fine` with the transfer maps attached to both blocks.  Even cell counts: the same analytic map
+    at half resolution; otherwise the coarse nodes ARE the surviving fine nodes (their parameters in the analytic map), halo
+    nodes by extrapolation -- what the reference's coarse levels hold (coarseOwnedCoordinates, preprocessingAPI.F90:3945).
+    keep: per direction the fine nodes where subfaces begin / end (they survive every coarsening, coarseUtils.F90:117-127).
+    The coarse block records nodeMap = per direction the fine node of every coarse node 1..il."""
+    maps = [coarsen_1d(nf, st, kp) for nf, st, kp in zip((fine.nx, fine.ny, fine.nz), fine.coarsened, keep)]
+    ncs = [m[1].size for m in maps]
+    regular = all((m[1] == 1.0).all() for m in maps)
+    if regular and (2 * ncs[0], 2 * ncs[1], 2 * ncs[2]) == (fine.nx, fine.ny, fine.nz):
+        mk.pop("params", None)
+        c = make_block(ncs[0], ncs[1], ncs[2], prm, **mk)
+    else:
+        fp = fine.nodeParams if fine.nodeParams is not None else node_params(fine.nx, fine.ny, fine.nz, mk.get("stretch_k", 1.0))
+        par = []
+        for t, m in zip(fp, maps):
+            own = np.asarray(t)[m[3]]                       # parameters of the surviving nodes 1..il_c
+            par.append(np.concatenate([[2.0 * own[0] - own[1]], own, [2.0 * own[-1] - own[-2]]]))
+        mk["params"] = tuple(par)
+        c = make_block(ncs[0], ncs[1], ncs[2], prm, **mk)
+    c.coarsened = tuple(m[4] for m in maps)
+    c.nodeMap = tuple(m[3] for m in maps)
+    for d, m in zip("IJK", maps):
+        c["mg%sFine" % d], c["mg%sWeight" % d] = m[0], m[1]
+        fine["mg%sCoarse" % d] = m[2]
     ie, je, ke = c.ie, c.je, c.ke
     c["w1"] = F((ie, je, ke, 5))
     c["p1"] = F((ie, je, ke))

@@ -507,7 +507,8 @@ def check_coarse_level_geometry(engine, topo, prm, seed=87, **mk):
     second node), then xhalo + exchangeCoor + volume / metric of the coarse level against the reference's routines."""
     from oracle import ref
     levels, rlevels = setup_multilevel_brick(engine, topo, prm, nlevels=2, seed=seed, **mk)
-    t2 = type(topo)(topo.Bi, topo.Bj, topo.Bk, topo.nx // 2, topo.ny // 2, topo.nz // 2)
+    c1 = next(iter(levels[1].values()))
+    t2 = type(topo)(topo.Bi, topo.Bj, topo.Bk, c1.nx, c1.ny, c1.nz)
     for lv, t in ((1, topo), (2, t2)):
         npat = t.patterns(0)[0]
         ref.set_internal_comm(lv, 0, npat)
@@ -515,10 +516,12 @@ def check_coarse_level_geometry(engine, topo, prm, seed=87, **mk):
     _warp_owned_nodes(levels[0], seed)
     for nn, b in levels[0].items():
         engine.upload_coordinates(nn, 1)
-        # numpy statement of coarseOwnedCoordinates: coarse node ii = fine node 2 ii - 1
+        # numpy statement of coarseOwnedCoordinates: coarse node ii = the fine node that survived the coarsening
+        # (2 ii - 1 for an even cell count; the upper fine cell of the coarse cell otherwise, node 1 stays node 1)
         rc = rlevels[1][nn]
         rc["x"][...] = 7.0
-        rc["x"][1:-1, 1:-1, 1:-1] = b["x"][1:-1:2, 1:-1:2, 1:-1:2]
+        nm = [np.concatenate([[1], rc["mg%sFine" % d][1:-1, 1]]) for d in "IJK"]
+        rc["x"][1:-1, 1:-1, 1:-1] = b["x"][np.ix_(nm[0], nm[1], nm[2])]
     p2 = prm.replace(currentLevel=2, groundLevel=1)
     for nn in sorted(rlevels[1]):
         ref.call_level("setPointers", 2, nn)
@@ -956,10 +959,14 @@ def check_dadi_smoother(engine, topo, prm, seed=9, nsweeps=1, **mk):
         assert_state(engine, blocks, rblocks, prm, f"DADI sweep {sweep}")
 
 
-def setup_multilevel_brick(engine, topo, prm, nlevels=2, seed=1, bc_spec=None, **mk):
+def setup_multilevel_brick(engine, topo, prm, nlevels=2, seed=1, bc_spec=None, bc_split=None, **mk):
     """Periodic bricks on levels 1..nlevels (2:1 coarsening) on the engine and in the
     reference's flowDoms, with 1-to-1 patterns on every level.
     bc_spec (single block only): the six faces are physical boundaries on every level instead.
+    bc_split ({faceID: BCType of the upper half}): those faces carry TWO subfaces; the node where they meet survives every
+    coarsening (createCoarseBlocks keeps subface boundaries, coarseUtils.F90:117-127), which makes coarse cells of ONE fine
+    cell with restriction weight 1/2 in the interior of the block.
+    Blocks with odd cell counts coarsen irregularly (coarseUtils.F90:134-153, 281-295).
     Returns (levels, rlevels): lists of {nn: Block}, index 0 = level 1."""
     from oracle import ref
     from adflow_amd.synth import make_coarse_block, make_bocos
@@ -967,15 +974,27 @@ def setup_multilevel_brick(engine, topo, prm, nlevels=2, seed=1, bc_spec=None, *
     engine.release_all()
     levels = [make_brick(topo, prm, seed, **mk)]
     topos = [topo]
+    # cut of a split face: last cell of the lower subface along the face's first index = the NODE that must survive
+    cuts = [{}]                                             # per level {faceID: h}
+    for fid in dict(bc_split or {}):
+        n1 = topo.ny if fid <= 2 else topo.nx               # first index of the face: j on i faces, i on j and k faces
+        cuts[0][fid] = (1 + n1 + 2) // 2
     for lv in range(2, nlevels + 1):
         t = topos[-1]
-        topos.append(BrickTopology(t.Bi, t.Bj, t.Bk, t.nx // 2, t.ny // 2, t.nz // 2))
-        levels.append({nn: make_coarse_block(b, prm, seed=seed + 1000 * lv + nn, **mk) for nn, b in levels[-1].items()})
+        keep = [[], [], []]
+        for fid, h in cuts[-1].items():
+            keep[1 if fid <= 2 else 0].append(h)
+        levels.append({nn: make_coarse_block(b, prm, keep=keep, seed=seed + 1000 * lv + nn, **mk) for nn, b in levels[-1].items()})
+        nm = next(iter(levels[-1].values())).nodeMap
+        cuts.append({fid: int(np.where(nm[1 if fid <= 2 else 0] == h)[0][0]) + 1 for fid, h in cuts[-1].items()})
+        c1 = next(iter(levels[-1].values()))       # equal blocks coarsen alike (odd counts: createCoarseBlocks' irregular coarsening)
+        topos.append(BrickTopology(t.Bi, t.Bj, t.Bk, c1.nx, c1.ny, c1.nz))
     bocos = [None] * nlevels
     if bc_spec:
         assert topo.nblocks == 1
         pats = [{L: CommPattern() for L in (1, 2)} for t in topos]
-        bocos = [{1: make_bocos(lev[1], prm, bc_spec, seed=seed + 7 * lv)} for lv, lev in enumerate(levels)]
+        bocos = [{1: make_bocos(lev[1], prm, bc_spec, seed=seed + 7 * lv, split=bc_split or (), split_at=cuts[lv])}
+                 for lv, lev in enumerate(levels)]
     else:
         pats = [{L: t.patterns(L)[0] for L in (1, 2)} for t in topos]
         apply_local_copies_fast(levels[0], pats[0][2])
@@ -999,15 +1018,32 @@ def setup_multilevel_brick(engine, topo, prm, nlevels=2, seed=1, bc_spec=None, *
     return levels, rlevels
 
 
+def count_half_weight_cells(levels):
+    """(coarse cells with restriction weight 1/2 at a block end, in the interior of a direction) summed over the coarse levels:
+    lets a test assert that it really runs createCoarseBlocks' irregular coarsening"""
+    ends = inner = 0
+    for lev in levels[1:]:
+        b = next(iter(lev.values()))
+        for d in "IJK":
+            w = b["mg%sWeight" % d]
+            half = np.where(w == 0.5)[0]
+            ends += int(((half == 0) | (half == w.size - 1)).sum())
+            inner += int(((half > 0) & (half < w.size - 1)).sum())
+    return ends, inner
+
+
 def setup_two_level_brick(engine, topo, prm, seed=1, **mk):
     levels, rlevels = setup_multilevel_brick(engine, topo, prm, 2, seed, **mk)
     return levels[0], levels[1], rlevels[0], rlevels[1]
 
 
-def check_mg_transfer(engine, topo, prm, seed=11, **mk):
-    """transferToCoarseGrid then transferToFineGrid (multiGrid.F90:5-652)."""
+def check_mg_transfer(engine, topo, prm, seed=11, irregular=None, **mk):
+    """transferToCoarseGrid then transferToFineGrid (multiGrid.F90:5-652).
+    irregular: (half-weight cells at block ends, in the interior) the coarsening must produce (count_half_weight_cells)."""
     from oracle import ref
     fine, coarse, rfine, rcoarse = setup_two_level_brick(engine, topo, prm, seed, **mk)
+    if irregular is not None:
+        assert count_half_weight_cells([fine, coarse]) == tuple(irregular)
     ref.load().ref_set_int(b"rkStage", 0)
     ref.call_level("transferToCoarseGrid", 1)
     engine.transferToCoarseGrid(1)
@@ -1027,10 +1063,13 @@ def check_mg_transfer(engine, topo, prm, seed=11, **mk):
     assert_state(engine, fine, rfine, prm, "prolongated state", level=1)
 
 
-def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, nlevels=2, bc_spec=None, **mk):
-    """executeMGCycle (multiGrid.F90:825-955) for a given cycling strategy."""
+def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, nlevels=2, bc_spec=None, bc_split=None, irregular=None, **mk):
+    """executeMGCycle (multiGrid.F90:825-955) for a given cycling strategy.
+    irregular: (half-weight cells at block ends, in the interior) the coarsening must produce (count_half_weight_cells)."""
     from oracle import ref
-    levels, rlevels = setup_multilevel_brick(engine, topo, prm, nlevels, seed, bc_spec=bc_spec, **mk)
+    levels, rlevels = setup_multilevel_brick(engine, topo, prm, nlevels, seed, bc_spec=bc_spec, bc_split=bc_split, **mk)
+    if irregular is not None:
+        assert count_half_weight_cells(levels) == tuple(irregular), count_half_weight_cells(levels)
     fine, rfine = levels[0], rlevels[0]
     ref.set_cycling(cycling)
     # entry condition of the cycle: time step and residual of the ground level are known

@@ -173,3 +173,5 @@ def test_coordinate_halos(engine):
     checks.check_xhalo_symmetry(engine, (70, 9, 8), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -1, 5: -1, 6: -6})
     checks.check_xhalo_symmetry(engine, (24, 10, 8), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5})
     checks.check_coarse_level_geometry(engine, BrickTopology(2, 1, 1, 24, 12, 8), FlowParams())
+    # odd cell counts: the coarse nodes are the nodes createCoarseBlocks kept (1, 3, .., il - 1, il), not every second one
+    checks.check_coarse_level_geometry(engine, BrickTopology(2, 1, 1, 17, 13, 9), FlowParams())

@@ -121,6 +121,22 @@ def test_mg_cycle(hostsim_engine, cycling):
     checks.check_mg_cycle(hostsim_engine, BrickTopology(2, 1, 1, 8, 6, 4), FlowParams(), cycling)
 
 
+def test_mg_irregular_coarsening(hostsim_engine):
+    """odd cell counts and subface boundaries on even nodes: coarse cells of ONE fine cell with restriction weight 1/2
+    (createCoarseBlocks, coarseUtils.F90:117-153, 281-343); twins of tests/test_gpu_multigrid.py::test_mg_*_irregular*"""
+    e = hostsim_engine
+    checks.check_mg_transfer(e, BrickTopology(2, 1, 1, 9, 7, 5), FlowParams(resAveraging=noResAveraging), irregular=(3, 0))
+    checks.check_mg_cycle(e, BrickTopology(1, 1, 1, 11, 9, 7), FlowParams(), [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0], ncycles=1,
+                          nlevels=3, irregular=(4, 0))
+    spec = {1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1}
+    checks.check_mg_cycle(e, BrickTopology(1, 1, 1, 10, 8, 4), FlowParams(), [0, 1, 0, -1], ncycles=1, bc_spec=spec,
+                          bc_split={3: -6, 5: -5}, irregular=(1, 1))
+    rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=2)
+    checks.check_mg_cycle(e, BrickTopology(1, 1, 1, 9, 5, 7), rans, [0, 1, 0, 1, 0, -1, 0, -1], ncycles=1, nlevels=3,
+                          bc_spec={1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}, bc_split={5: -6}, irregular=(4, 1), stretch_k=2.0)
+    checks.check_coarse_level_geometry(e, BrickTopology(2, 1, 1, 9, 7, 5), FlowParams())
+
+
 def test_nk_residual(hostsim_engine):
     checks.check_nk_residual(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams())
     checks.check_nk_residual(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
