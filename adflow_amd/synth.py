@@ -36,6 +36,7 @@ class Block:
     rightHanded: bool = True             # blockType%rightHanded: (i, j, k) right-handed; False: metric_block uses fact = -half
     nodeParams: Optional[tuple] = None   # (xi, eta, zeta) of the nodes 0..ie / je / ke in the analytic map (make_nodes)
     coarsened: tuple = ("regular", "regular", "regular")   # blockType%iCoarsened / jCoarsened / kCoarsened (block.F90:230-233)
+    frame: Optional[dict] = None         # LatticeTopology.frame: the block's place in the one analytic map of a multi-block mesh
     nodeMap: Optional[tuple] = None      # coarse block: per direction the FINE node of every coarse node 1..il (imap of createCoarseBlocks)
 
     # index helpers (reference naming)
@@ -72,7 +73,7 @@ class Block:
 
     def copy(self) -> "Block":
         return Block(self.nx, self.ny, self.nz, self.nw, {k: v.copy(order="F") for k, v in self.a.items()}, self.rotRate, self.rightHanded,
-                     self.nodeParams, self.coarsened, self.nodeMap)
+                     self.nodeParams, self.coarsened, self.frame, self.nodeMap)
 
 
 def add_grid_velocities(blk: "Block", prm, rotRate=(0.05, -0.03, 0.12), rotCenter=(0.3, -0.2, 0.1)):
@@ -116,14 +117,25 @@ def node_params(nx, ny, nz, stretch_k=1.0):
     return xi, et, ze
 
 
-def make_nodes(nx, ny, nz, lengths=(1.0, 1.0, 1.0), amp=0.02, stretch_k=1.0, origin=(0.0, 0.0, 0.0), params=None):
+def make_nodes(nx, ny, nz, lengths=(1.0, 1.0, 1.0), amp=0.02, stretch_k=1.0, origin=(0.0, 0.0, 0.0), params=None, frame=None):
     """Nodes x(0:ie,0:je,0:ke,3): smooth non-orthogonal right-handed map of the
     unit cube (node 1 -> 0, node il -> 1; halo nodes 0 and ie continue the map).
-    params: the nodes' (xi, eta, zeta) instead of the uniform division (irregularly coarsened multigrid levels)."""
+    params: the nodes' (xi, eta, zeta) instead of the uniform division (irregularly coarsened multigrid levels).
+    frame (LatticeTopology.frame): the block is one of several that share ONE map; `params` are then the nodes' offsets from
+    node 1 along the block's own index directions in lattice units, the lattice position of a node is o + T offsets and its
+    (xi, eta, zeta) that position times `scale` -- blocks of any orientation and size get identical coordinates on shared nodes."""
     ie, je, ke = nx + 2, ny + 2, nz + 2
     xi, et, ze = params if params is not None else node_params(nx, ny, nz, stretch_k)
     assert len(xi) == ie + 1 and len(et) == je + 1 and len(ze) == ke + 1
     X, E, Z = np.meshgrid(xi, et, ze, indexing="ij")
+    if frame is not None:
+        T, o, sc = frame["T"], frame["o"], frame["scale"]
+        P = [(o[a] + T[a, 0] * X + T[a, 1] * E + T[a, 2] * Z) * sc[a] for a in range(3)]
+        X, E, Z = P
+        amp = frame.get("amp", amp)
+        sz = frame.get("stretch_z", 1.0)
+        if sz != 1.0:
+            Z = np.sign(Z) * (np.expm1(sz * np.abs(Z)) / math.expm1(sz))
     tp = 2.0 * math.pi
     x = F((ie + 1, je + 1, ke + 1, 3))
     x[..., 0] = origin[0] + lengths[0] * (X + amp * np.sin(tp * E) * np.sin(tp * Z))
@@ -211,17 +223,22 @@ def sa_eddy_viscosity(prm: FlowParams, rho, nut, rlv):
 
 def make_block(nx, ny, nz, prm: FlowParams, seed=20260925, lengths=(1.0, 1.0, 1.0), amp=0.02,
                stretch_k=1.0, wall_kmin=None, noise=0.02, wave=0.05, origin=(0.0, 0.0, 0.0), holes=0.0,
-               noflux_jmax=False, moving=False, left_handed=False, params=None) -> Block:
+               noflux_jmax=False, moving=False, left_handed=False, params=None, frame=None) -> Block:
     """Analytic curvilinear block + perturbed free-stream state.
     moving: a block of a steadily rotating frame (add_grid_velocities).
-    params: (xi, eta, zeta) of the nodes (make_nodes) instead of the uniform division."""
+    params: (xi, eta, zeta) of the nodes (make_nodes) instead of the uniform division; frame: see make_nodes."""
     rng = np.random.default_rng(seed)
     nw = prm.nw
     b = Block(nx, ny, nz, nw)
     ib, jb, kb = b.ib, b.jb, b.kb
     b.nodeParams = params if params is not None else node_params(nx, ny, nz, stretch_k)
-    x = make_nodes(nx, ny, nz, lengths, amp, stretch_k, origin, b.nodeParams)
+    b.frame = frame
+    x = make_nodes(nx, ny, nz, lengths, amp, stretch_k, origin, b.nodeParams, frame)
     sI, sJ, sK = face_metrics(x)
+    if frame is not None and np.linalg.det(frame["T"]) < 0:
+        assert not left_handed
+        sI, sJ, sK = np.asfortranarray(-sI), np.asfortranarray(-sJ), np.asfortranarray(-sK)
+        b.rightHanded = False
     if left_handed:
         # mirror image of the block: the index system becomes left-handed and the reference's metric_block takes fact = -half so
         # that the normals keep pointing towards increasing indices (adjointExtra.F90:205-211)
@@ -489,7 +506,9 @@ def make_coarse_block(fine: Block, prm: FlowParams, keep=((), (), ()), **mk) -> 
     maps = [coarsen_1d(nf, st, kp) for nf, st, kp in zip((fine.nx, fine.ny, fine.nz), fine.coarsened, keep)]
     ncs = [m[1].size for m in maps]
     regular = all((m[1] == 1.0).all() for m in maps)
-    if regular and (2 * ncs[0], 2 * ncs[1], 2 * ncs[2]) == (fine.nx, fine.ny, fine.nz):
+    if fine.frame is not None:
+        mk["frame"] = fine.frame
+    if fine.frame is None and regular and (2 * ncs[0], 2 * ncs[1], 2 * ncs[2]) == (fine.nx, fine.ny, fine.nz):
         mk.pop("params", None)
         c = make_block(ncs[0], ncs[1], ncs[2], prm, **mk)
     else:

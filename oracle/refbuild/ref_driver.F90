@@ -1389,7 +1389,7 @@ contains
             d%ie = ie; d%je = je; d%ke = ke
             d%ib = ib; d%jb = jb; d%kb = kb
             d%cgnsBlockID = 1
-            d%rightHanded = .true.
+            d%rightHanded = rightHanded
             d%iBegor = 1; d%iEndor = il; d%jBegor = 1; d%jEndor = jl; d%kBegor = 1; d%kEndor = kl
             d%nSubface = nBocos; d%n1to1 = 0; d%nBocos = nBocos; d%nViscBocos = nViscBocos
             d%BCType => BCType; d%BCFaceID => BCFaceID; d%BCData => BCData

@@ -17,7 +17,7 @@ sys.path.insert(0, HERE)
 from adflow_amd.engine import Engine  # noqa: E402
 from adflow_amd.params import FlowParams, RANSEquations  # noqa: E402
 from adflow_amd.synth import make_block  # noqa: E402
-from adflow_amd.topology import BrickTopology, apply_local_copies_fast  # noqa: E402
+from adflow_amd.topology import BrickTopology, apply_local_copies_fast, ell_topology  # noqa: E402
 from hostsim.build import build  # noqa: E402
 import ctypes  # noqa: E402
 
@@ -39,11 +39,18 @@ def main():
     else:
         shape = (2, 2, 1)
         topo = BrickTopology(*shape, *dims, owner=lambda g: g % world)
+    if mode == "ell":         # three blocks of different sizes joined with rotated index systems (tests/test_gpu_topology.py): blocks A and
+        topo = ell_topology(owner=lambda g: 0 if g != 1 else 1)       # C on rank 0, B on rank 1; B's edge halos come from C
+        single = ell_topology()
+        allb = {g: single.make_block(g, prm, seed=50 + g) for g in range(topo.nblocks)}
+        bdims = {g: topo.dims(g) for g in range(topo.nblocks)}
+    else:
+        allb = {g: make_block(*dims, prm, seed=50 + g, stretch_k=2.0) for g in range(topo.nblocks)}
+        single = BrickTopology(*shape, *dims, periodic=periodic)
+        bdims = {g: dims for g in range(topo.nblocks)}
     lid = topo.local_ids()
     # every rank can rebuild every block (seeded): expected halos come from the
     # single-rank version of the same topology
-    allb = {g: make_block(*dims, prm, seed=50 + g, stretch_k=2.0) for g in range(topo.nblocks)}
-    single = BrickTopology(*shape, *dims, periodic=periodic)
     exp = {single.local_ids()[g]: allb[g].copy() for g in range(topo.nblocks)}
     apply_local_copies_fast(exp, single.patterns(nLayers)[0])
     mine = {lid[g]: allb[g] for g in topo.blocks_of(rank)}
@@ -84,7 +91,7 @@ def main():
         nn = lid[g]
         eng.download_state(nn, 1)
         e = exp[single.local_ids()[g]]
-        sl = tuple(slice(lo, n + 2 + nLayers) for n in dims)
+        sl = tuple(slice(lo, n + 2 + nLayers) for n in bdims[g])
         for name in ("w", "p", "rlv", "rev"):
             a, b = mine[nn][name][sl], e[name][sl]
             if not np.array_equal(a, b):

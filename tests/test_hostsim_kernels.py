@@ -137,6 +137,26 @@ def test_mg_irregular_coarsening(hostsim_engine):
     checks.check_coarse_level_geometry(e, BrickTopology(2, 1, 1, 9, 7, 5), FlowParams())
 
 
+def test_rotated_interfaces(hostsim_engine):
+    """1-to-1 interfaces with a transformation between blocks of different sizes (modules/block.F90:271-309): the emulator twin
+    of tests/test_gpu_topology.py"""
+    from adflow_amd.topology import ell_topology
+    e = hostsim_engine
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    for nLayers in (1, 2):
+        checks.check_halo_exchange(e, ell_topology(), rans, nLayers)
+        checks.check_halo_loopback(e, ell_topology(), 3, rans, nLayers)
+    checks.check_coordinate_halos_brick(e, ell_topology(), FlowParams())
+    walls = {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}
+    for se in (None, 2):
+        assert checks.check_blockette_res_with_bc(e, ell_topology(stretch_z=2.0), rans, walls, split_eval=se) == 2
+    spec = {1: -6, 2: -6, 3: -6, 4: -6, 5: -5, 6: -6}
+    assert checks.check_pressure_early_exchange(e, None, FlowParams(), topo=ell_topology(), lattice_spec=spec) > 1e-6
+    checks.check_dadi_smoother(e, ell_topology(), FlowParams(resAveraging=noResAveraging, cfl=1.5))
+    checks.check_mg_cycle(e, ell_topology(), FlowParams(), [0, 1, 0, -1], ncycles=1, brick_spec={1: -6, 2: -6, 3: -1, 4: -6, 5: -5, 6: -6})
+    checks.check_nk_residual(e, ell_topology(), rans)
+
+
 def test_nk_residual(hostsim_engine):
     checks.check_nk_residual(hostsim_engine, BrickTopology(2, 1, 1, 6, 5, 4), FlowParams())
     checks.check_nk_residual(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),

@@ -19,10 +19,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("nLayers,mode", [(1, "mod"), (2, "mod"), (2, "strong"), (2, "wall")])
+@pytest.mark.parametrize("nLayers,mode", [(1, "mod"), (2, "mod"), (2, "strong"), (2, "wall"), (1, "ell"), (2, "ell")])
 def test_two_rank_halo_exchange_gloo(nLayers, mode):
     """mode "strong": the partition of bench.py --scaling strong (one 2x2x2 brick, 8 / N blocks per rank); "wall": the weak-scaling
-    layout of the default (wall-bounded) workload at two ranks: a non-periodic 4x2x2 brick, one 2x2x2 half per rank"""
+    layout of the default (wall-bounded) workload at two ranks: a non-periodic 4x2x2 brick, one 2x2x2 half per rank; "ell": three
+    blocks of different sizes whose interfaces carry a transformation (one of them, with an index running against its neighbour's,
+    on the other rank)"""
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_halo_worker.py"), str(r), "2", str(port), str(nLayers), mode],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
