@@ -67,6 +67,9 @@ struct Block {
     std::vector<void*> allocs;
     bool geom_uploaded = false;
     bool normals_from_x_ok = true;     // the uploaded sI / sJ / sK equal metric_block(x): the kernels may re-form them from the nodes
+    unsigned geom_is_host = 0;         // bit 0..3: the device copy of x / sI / sJ / sK IS the descriptor's host array (set by an upload from
+                                       // the registered pointer, cleared by an upload from any other buffer): normals_match_nodes reads the
+                                       // HOST arrays, so it speaks for the device only when all four bits are set (round-4 advisor finding)
     bool face_vectors_valid = false;   // dI/dJ/dK derived from x
     bool ss_valid = false;    // entropy sensor variable matches the current state
     bool etot_consistent = false;   // owned-cell rhoE already equals computeEtotBlock(p, rho, v)
@@ -712,6 +715,7 @@ int adflow_gpu_upload_geometry(int nn, int level, int sps)
     HIPCHK(hipStreamSynchronize(g_stream));
     b->geom_uploaded = true;
     b->face_vectors_valid = false;
+    b->geom_is_host = 15;
     b->normals_from_x_ok = normals_match_nodes(b);
     return 0;
 }
@@ -724,6 +728,7 @@ int adflow_gpu_upload_coordinates(int nn, int level, int sps)
     if (!b->d.x) return fail("block (%d,%d,%d): no coordinate array", nn, level, sps);
     if (copy_box(b, b->v.x, b->d.x, 3, 0, b->v.ie + 1, 0, b->v.je + 1, 0, b->v.ke + 1, true)) return 1;
     b->face_vectors_valid = false;
+    b->geom_is_host |= 1;
     // the stored sI / sJ / sK are now those of the OLD nodes: until update_geometry (or an upload of the new normals) re-forms
     // them no kernel may take its normals from x while another reads the arrays (two geometries in one residual)
     b->normals_from_x_ok = false;
@@ -740,7 +745,8 @@ int adflow_gpu_update_geometry(int level)
         launch_volume_metric(b->v, b->d.rightHanded, g_stream);
         if (!b->bc.empty()) launch_boundary_normals(b->v, b->bc.data(), (int)b->bc.size(), g_stream);
         b->face_vectors_valid = false;
-        b->normals_from_x_ok = true;        // the normals on the device now ARE metric_block(x)
+        b->geom_is_host &= 1;               // sI / sJ / sK were re-formed on the device: they are no longer the host arrays ...
+        b->normals_from_x_ok = true;        // ... but they ARE metric_block(x) of the device's nodes
         return 0;
     });
     if (rc) return rc;
@@ -933,7 +939,11 @@ int adflow_gpu_upload_array(int nn, int level, int sps, int which, const double*
         if (sync_and_check()) return 1;
         b->face_vectors_valid = false;
         const double* own = which == ADFLOW_ARR_X ? b->d.x : which == ADFLOW_ARR_SI ? b->d.sI : which == ADFLOW_ARR_SJ ? b->d.sJ : b->d.sK;
-        b->normals_from_x_ok = (host == own) && normals_match_nodes(b);
+        const unsigned bit = which == ADFLOW_ARR_X ? 1u : which == ADFLOW_ARR_SI ? 2u : which == ADFLOW_ARR_SJ ? 4u : 8u;
+        if (host == own) b->geom_is_host |= bit; else b->geom_is_host &= ~bit;
+        // the host-side comparison speaks for the device only when ALL FOUR device arrays are the descriptor's: a foreign sI followed by
+        // an upload of x from the registered pointer must not switch the re-formed normals back on
+        b->normals_from_x_ok = b->geom_is_host == 15 && normals_match_nodes(b);
     }
     return sync_and_check();
 }
@@ -1631,10 +1641,10 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
 int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
 {
     if (need_ready()) return 1;
-    if (!(delta > 0.0)) return fail("fd_jacobian: delta must be positive");
     if (flags & ~(ADFLOW_JAC_PC | ADFLOW_JAC_FROZEN_TURB | ADFLOW_JAC_TURB_ONLY | ADFLOW_JAC_VISC_PC | ADFLOW_JAC_USE_AD))
         return fail("fd_jacobian: unknown flags 0x%x", flags);
     const bool useAD = (flags & ADFLOW_JAC_USE_AD) != 0;
+    if (!useAD && !(delta > 0.0)) return fail("fd_jacobian: delta must be positive");     // forward mode has no step size
     if (useAD) {
         // forward-mode seeds instead of perturbations (adjointUtils.F90:227-409): gather kernels on dual numbers, blocks at rest
         bool moving = false;
@@ -1642,6 +1652,8 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
         if (moving) return fail("fd_jacobian(useAD): moving blocks are not linearised (grid velocities)");
         if (!g_act.empty()) return fail("fd_jacobian(useAD): actuator regions are not linearised");
         if (g_bc_callback) return fail("fd_jacobian(useAD): a host boundary-condition hook cannot be linearised");
+        if (g_turb_bc_callback && g_opts.equations == ADFLOW_RANS && !(flags & ADFLOW_JAC_FROZEN_TURB))
+            return fail("fd_jacobian(useAD): a host turbulence boundary-condition hook cannot be linearised");
     }
     if (level != g_opts.groundLevel) return fail("fd_jacobian: level %d is not the ground level %d (setupStateResidualMatrix sets both)", level, g_opts.groundLevel);
     const bool rans = g_opts.equations == ADFLOW_RANS;
@@ -3631,6 +3643,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "xcd_tiles")) {
         g_xcd_tiles = value;
         if (g_stream) (void)hipStreamSynchronize(g_stream);
+        mg_graph_drop();       // a captured cycle holds the device pointer of the tile table (g_state_gen above retires it as well)
         for (auto& kv : g_tiles) (void)hipFree(kv.second.first);
         g_tiles.clear();
         return 0;
@@ -3643,8 +3656,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "march_kch")) {
         if (value < 4) return fail("march_kch must be >= 4");
         g_march_kch = value;
-        for (auto& kv : g_tiles) (void)hipFree(kv.second.first);   // tile tables depend on the chunk length
-        g_tiles.clear();
+        if (g_stream) (void)hipStreamSynchronize(g_stream);
+        mg_graph_drop();
         for (auto* mp : {&g_tiles, &g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
             for (auto& kv : *mp) (void)hipFree(kv.second.first);
             mp->clear();
@@ -3669,6 +3682,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         g_gf_nofit = (value < 0);
         g_num_cus = value > 0 ? value : 0;
         if (g_stream) (void)hipStreamSynchronize(g_stream);
+        mg_graph_drop();
         for (auto* mp : {&g_tiles, &g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd, &g_sa_tiles, &g_sa_tiles_int, &g_sa_tiles_bnd}) {
             for (auto& kv : *mp) (void)hipFree(kv.second.first);
             mp->clear();

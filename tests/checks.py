@@ -61,6 +61,35 @@ def check_block_res(engine, dims, prm, seed=1, blk=None, **mk):
     return blk, r
 
 
+def check_foreign_normals_then_own_nodes(engine, dims, prm, seed=5, **mk):
+    """Round-4 advisor finding: the face normals replaced from a FOREIGN buffer (sI scaled: no longer metric_block(x)), then the
+    nodes uploaded again from the registered array.  The host-side check 'normals equal metric_block(x)' reads the descriptor's
+    arrays, which still agree with each other -- but the device holds the foreign sI: kernels that re-form their normals from the
+    nodes (SA march, time step) must stay switched off, and the residual must be the reference's with the SCALED sI."""
+    from oracle import ref
+    lvl = new_level(engine)
+    prm = prm.replace(currentLevel=lvl, groundLevel=lvl)
+    blk = make_block(*dims, prm, seed=seed, **mk)
+    r = ref_bind(blk, prm)
+    r["sI"][...] *= 1.03
+    turb = prm.equations == RANSEquations
+    ref.block_res_core(True, True, turb)
+    engine.set_options(prm)
+    engine.register(blk, nn=1, level=lvl)
+    foreign = np.asfortranarray(blk["sI"] * 1.03)
+    engine.upload_array(capi.ARR_SI, foreign, 1, lvl)
+    engine.upload_array(capi.ARR_X, blk["x"], 1, lvl)            # the registered pointer: must not re-enable the normals from x
+    engine.blocketteRes(level=lvl, updateIntermed=True, flowRes=True, turbRes=turb)
+    dw = engine.download_residual(1, lvl)
+    assert_dw(blk, dw, r["dw"], blk.nw, what="dw with foreign sI")
+    # and back: the own sI uploaded again -> all four device arrays are the descriptor's, the re-formed normals are allowed again
+    engine.upload_array(capi.ARR_SI, blk["sI"], 1, lvl)
+    r["sI"][...] = blk["sI"]
+    ref.block_res_core(True, True, turb)
+    engine.blocketteRes(level=lvl, updateIntermed=True, flowRes=True, turbRes=turb)
+    assert_dw(blk, engine.download_residual(1, lvl), r["dw"], blk.nw, what="dw with the own sI again")
+
+
 def check_block_res_vs_blockette(engine, dims, prm, update_intermed=False, seed=1, **mk):
     """adflow_gpu_block_res vs blockette::blocketteResCore (blockette.F90:299-753), the reference's DEFAULT residual path
     (useBlockettes = True, pyADflow.py:5734): metrics recomputed from x per 8^3 tile, fused SA routines, its own timeStep.

@@ -315,3 +315,9 @@ def test_block_res_vs_blockette_core(engine, sd, update):
     prm = FlowParams(equations=RANSEquations, spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156)
     checks.check_block_res_vs_blockette(engine, (24, 20, 10), prm, update, seed=sd, stretch_k=3.0)
     checks.check_block_res_vs_blockette(engine, (17, 9, 11), FlowParams(spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156), update, seed=sd)
+
+
+def test_foreign_normals_then_own_nodes(engine):
+    """round-4 advisor: an upload of sI from a foreign buffer followed by x from the registered pointer must leave the kernels on the
+    stored normals"""
+    checks.check_foreign_normals_then_own_nodes(engine, (63, 11, 35), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)

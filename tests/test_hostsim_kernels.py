@@ -137,6 +137,10 @@ def test_mg_irregular_coarsening(hostsim_engine):
     checks.check_coarse_level_geometry(e, BrickTopology(2, 1, 1, 9, 7, 5), FlowParams())
 
 
+def test_foreign_normals_then_own_nodes(hostsim_engine):
+    checks.check_foreign_normals_then_own_nodes(hostsim_engine, (9, 7, 6), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+
+
 def test_rotated_interfaces(hostsim_engine):
     """1-to-1 interfaces with a transformation between blocks of different sizes (modules/block.F90:271-309): the emulator twin
     of tests/test_gpu_topology.py"""
