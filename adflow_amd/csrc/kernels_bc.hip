@@ -40,10 +40,9 @@ struct BcSlab {            // cell offsets of the four slabs and the BCData inde
     long fn;               // stride between components of norm / uSlip
 };
 
-__device__ __forceinline__ bool bc_slab(const BlkView& b, const BcFaceDev& f, BcSlab& s)
+__device__ __forceinline__ bool bc_slab_t(const BlkView& b, const BcFaceDev& f, long t, BcSlab& s)
 {
     const int isize = f.icEnd - f.icBeg + 1, jsize = f.jcEnd - f.jcBeg + 1;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)isize * jsize) return false;
     const int i = f.icBeg + (int)(t % isize), j = f.jcBeg + (int)(t / isize);
     long base, step;
@@ -59,6 +58,10 @@ __device__ __forceinline__ bool bc_slab(const BlkView& b, const BcFaceDev& f, Bc
     s.f = t;
     s.fn = (long)isize * jsize;
     return true;
+}
+__device__ __forceinline__ bool bc_slab(const BlkView& b, const BcFaceDev& f, BcSlab& s)
+{
+    return bc_slab_t(b, f, (long)blockIdx.x * blockDim.x + threadIdx.x, s);
 }
 
 // computeEtot (BCRoutines.F90:1816-1868)
@@ -114,11 +117,8 @@ __device__ __forceinline__ void bc_store_halos(const BlkView& b, const KParams& 
 }
 
 // symmetry: layer 1 mirrors slab 2, layer 0 mirrors slab 3 (two separate passes in the reference)
-__global__ __launch_bounds__(256) void k_bc_symm(BC_ARGS, KParams kp, int second)
+__device__ __forceinline__ void bcc_symm(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second)
 {
-    BC_PROLOGUE
-    BcSlab s;
-    if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
     const long ch = second ? s.c0 : s.c1, cd = second ? s.c3 : s.c2;
     const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
@@ -134,14 +134,18 @@ __global__ __launch_bounds__(256) void k_bc_symm(BC_ARGS, KParams kp, int second
     if (kp.viscous) b.rlv[ch] = b.rlv[cd];
     if (kp.eddyModel) b.rev[ch] = b.rev[cd];
 }
-
-// polar symmetry: the mirror direction is the diagonal of the face cell (degenerate "axis" faces), xx(i+1,j+1) - xx(i,j)
-// of the face's node plane (BCRoutines.F90:370-379, setBCPointers utils.F90:1103-1133)
-__global__ __launch_bounds__(256) void k_bc_symm_polar(BC_ARGS, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_bc_symm(BC_ARGS, KParams kp, int second)
 {
     BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
+    bcc_symm(b, f, s, kp, second);
+}
+
+// polar symmetry: the mirror direction is the diagonal of the face cell (degenerate "axis" faces), xx(i+1,j+1) - xx(i,j)
+// of the face's node plane (BCRoutines.F90:370-379, setBCPointers utils.F90:1103-1133)
+__device__ __forceinline__ void bcc_symm_polar(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second)
+{
     const long nb = b.nbox;
     const int isize = f.icEnd - f.icBeg + 1;
     const int i = f.icBeg + (int)(s.f % isize), j = f.jcBeg + (int)(s.f / isize);
@@ -166,14 +170,18 @@ __global__ __launch_bounds__(256) void k_bc_symm_polar(BC_ARGS, KParams kp, int 
     if (kp.viscous) b.rlv[ch] = b.rlv[cd];
     if (kp.eddyModel) b.rev[ch] = b.rev[cd];
 }
-
-// subsonic outflow / outflow mass bleed: static pressure prescribed, entropy, tangential velocity and the outgoing
-// acoustic Riemann variable extrapolated
-__global__ __launch_bounds__(256) void k_bc_subsonic_outflow(BC_ARGS, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_bc_symm_polar(BC_ARGS, KParams kp, int second)
 {
     BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
+    bcc_symm_polar(b, f, s, kp, second);
+}
+
+// subsonic outflow / outflow mass bleed: static pressure prescribed, entropy, tangential velocity and the outgoing
+// acoustic Riemann variable extrapolated
+__device__ __forceinline__ void bcc_subsonic_outflow(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second)
+{
     const long nb = b.nbox;
     const double pExit = f.ps[s.f];
     const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
@@ -199,14 +207,18 @@ __global__ __launch_bounds__(256) void k_bc_subsonic_outflow(BC_ARGS, KParams kp
     bc_etot(b, kp, s.c1);
     if (second) bc_second_halo(b, kp, s);
 }
-
-// subsonic inflow: total conditions + flow direction, or density + velocity prescribed; the outgoing acoustic
-// Riemann variable comes from the interior
-__global__ __launch_bounds__(256) void k_bc_subsonic_inflow(BC_ARGS, KParams kp, int second, int hScalingInlet)
+__global__ __launch_bounds__(256) void k_bc_subsonic_outflow(BC_ARGS, KParams kp, int second)
 {
     BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
+    bcc_subsonic_outflow(b, f, s, kp, second);
+}
+
+// subsonic inflow: total conditions + flow direction, or density + velocity prescribed; the outgoing acoustic
+// Riemann variable comes from the interior
+__device__ __forceinline__ void bcc_subsonic_inflow(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second, int hScalingInlet)
+{
     const long nb = b.nbox;
     const double nx = f.norm[s.f], ny = f.norm[s.f + s.fn], nz = f.norm[s.f + 2 * s.fn];
     const double gam2 = b.gamma[s.c2];
@@ -263,14 +275,18 @@ __global__ __launch_bounds__(256) void k_bc_subsonic_inflow(BC_ARGS, KParams kp,
     bc_etot(b, kp, s.c1);
     if (second) bc_second_halo(b, kp, s);
 }
-
-// viscous walls; ISO: isothermal (wall temperature TNS_Wall)
-template <bool ISO>
-__global__ __launch_bounds__(256) void k_bc_nswall(BC_ARGS, KParams kp, int second, int wallTreatment)
+__global__ __launch_bounds__(256) void k_bc_subsonic_inflow(BC_ARGS, KParams kp, int second, int hScalingInlet)
 {
     BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
+    bcc_subsonic_inflow(b, f, s, kp, second, hScalingInlet);
+}
+
+// viscous walls; ISO: isothermal (wall temperature TNS_Wall)
+template <bool ISO>
+__device__ __forceinline__ void bcc_nswall(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second, int wallTreatment)
+{
     const long nb = b.nbox;
     const double rhok = 0.0;     // correctForK = .false. (no k equation)
     BcState i2, h;
@@ -298,15 +314,20 @@ __global__ __launch_bounds__(256) void k_bc_nswall(BC_ARGS, KParams kp, int seco
     // (the laminar viscosity of a viscous wall's halo is stored whatever kp.viscous says: the kind exists on viscous meshes only)
     bc_store_halos(b, kp, s, h, i2, second != 0);
 }
-
-// myDim (utils): max(x - y, 0)
-__device__ __forceinline__ double bc_mydim(double x, double y) { return fmax(x - y, 0.0); }
-
-__global__ __launch_bounds__(256) void k_bc_eulerwall(BC_ARGS, KParams kp, int second, int wallTreatment)
+template <bool ISO>
+__global__ __launch_bounds__(256) void k_bc_nswall(BC_ARGS, KParams kp, int second, int wallTreatment)
 {
     BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
+    bcc_nswall<ISO>(b, f, s, kp, second, wallTreatment);
+}
+
+// myDim (utils): max(x - y, 0)
+__device__ __forceinline__ double bc_mydim(double x, double y) { return fmax(x - y, 0.0); }
+
+__device__ __forceinline__ void bcc_eulerwall(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second, int wallTreatment)
+{
     const long nb = b.nbox;
     double grad = 0.0;
     if (wallTreatment == ADFLOW_WALLBC_LINEAR) grad = b.p[s.c3] - b.p[s.c2];
@@ -361,12 +382,16 @@ __global__ __launch_bounds__(256) void k_bc_eulerwall(BC_ARGS, KParams kp, int s
     bc_etot(b, kp, s.c1);
     if (second) bc_second_halo(b, kp, s);
 }
-
-__global__ __launch_bounds__(256) void k_bc_farfield(BC_ARGS, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_bc_eulerwall(BC_ARGS, KParams kp, int second, int wallTreatment)
 {
     BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
+    bcc_eulerwall(b, f, s, kp, second, wallTreatment);
+}
+
+__device__ __forceinline__ void bcc_farfield(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second)
+{
     const long nb = b.nbox;
     const double gm1 = kp.gammaInf - 1.0;
     const double ovgm1 = 1.0 / gm1;
@@ -412,16 +437,20 @@ __global__ __launch_bounds__(256) void k_bc_farfield(BC_ARGS, KParams kp, int se
     i2.rho = rho2; i2.u = ue; i2.v = ve; i2.w = we; i2.p = p2;
     bc_store_halos(b, kp, s, h, i2, second != 0);
 }
-
-// extrap / supersonic outflow: fw2, fw3 = weights of slab 2 and 3
-__global__ __launch_bounds__(256) void k_bc_extrap(BC_ARGS, KParams kp, int second, int outflowTreatment)
+__global__ __launch_bounds__(256) void k_bc_farfield(BC_ARGS, KParams kp, int second)
 {
     BC_PROLOGUE
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    bcc_farfield(b, f, s, kp, second);
+}
+
+// extrap / supersonic outflow: fw2, fw3 = weights of slab 2 and 3
+__device__ __forceinline__ void bcc_extrap(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second, int outflowTreatment)
+{
     // extrap: linear; supersonic outflow: constant or linear (BCRoutines.F90:1512-1531)
     double fw2 = 2.0, fw3 = -1.0;
     if (f.type == ADFLOW_BC_SUPERSONIC_OUTFLOW && outflowTreatment == 1) { fw2 = 1.0; fw3 = 0.0; }
-    BcSlab s;
-    if (!bc_slab(b, f, s)) return;
     const long nb = b.nbox;
     const double factor = 0.5;
     BcState h, i2;
@@ -435,13 +464,17 @@ __global__ __launch_bounds__(256) void k_bc_extrap(BC_ARGS, KParams kp, int seco
     h.rev = kp.eddyModel ? b.rev[s.c2] : 0.0;
     bc_store_halos(b, kp, s, h, i2, second != 0);
 }
-
-// supersonic inflow (BCRoutines.F90:1411-1477): both halo layers take the prescribed state
-__global__ __launch_bounds__(256) void k_bc_supersonic_inflow(BC_ARGS, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_bc_extrap(BC_ARGS, KParams kp, int second, int outflowTreatment)
 {
     BC_PROLOGUE
     BcSlab s;
     if (!bc_slab(b, f, s)) return;
+    bcc_extrap(b, f, s, kp, second, outflowTreatment);
+}
+
+// supersonic inflow (BCRoutines.F90:1411-1477): both halo layers take the prescribed state
+__device__ __forceinline__ void bcc_supersonic_inflow(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second)
+{
     const long nb = b.nbox;
     b.w[s.c1] = f.rho[s.f];
     b.w[s.c1 + nb] = f.vx[s.f];
@@ -461,6 +494,13 @@ __global__ __launch_bounds__(256) void k_bc_supersonic_inflow(BC_ARGS, KParams k
         if (kp.eddyModel) b.rev[s.c0] = b.rev[s.c1];
         bc_etot(b, kp, s.c0);
     }
+}
+__global__ __launch_bounds__(256) void k_bc_supersonic_inflow(BC_ARGS, KParams kp, int second)
+{
+    BC_PROLOGUE
+    BcSlab s;
+    if (!bc_slab(b, f, s)) return;
+    bcc_supersonic_inflow(b, f, s, kp, second);
 }
 
 static dim3 bc_grid(const BcPhase& ph) { return dim3((unsigned)((ph.maxCells + 255) / 256), (unsigned)ph.count, 1); }
@@ -528,12 +568,10 @@ __global__ __launch_bounds__(256) void k_turb_bc_zero(const BlkView* __restrict_
         }
 }
 
-__global__ __launch_bounds__(256) void k_turb_bc_treatment(BC_ARGS, KParams kp)
+// bmt / bvt of cell t of a subface (bcTurbTreatment)
+__device__ __forceinline__ void bcc_turb_treatment(const BlkView& b, const BcFaceDev& f, long t, const KParams& kp)
 {
-    BC_PROLOGUE
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n = (long)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
-    if (t >= n || !b.bmt[0]) return;
     // the face arrays only cover 1..ie x 1..je (turbBCRoutines.F90:684-735): skip range cells outside
     const int isize = f.icEnd - f.icBeg + 1;
     const int i = f.icBeg + (int)(t % isize), j = f.jcBeg + (int)(t / isize);
@@ -573,12 +611,17 @@ __global__ __launch_bounds__(256) void k_turb_bc_treatment(BC_ARGS, KParams kp)
     default: break;
     }
 }
-
-__global__ __launch_bounds__(256) void k_apply_turb_bc(BC_ARGS, KParams kp, int second)
+__global__ __launch_bounds__(256) void k_turb_bc_treatment(BC_ARGS, KParams kp)
 {
     BC_PROLOGUE
-    BcSlab s;
-    if (!bc_slab(b, f, s) || !b.bmt[0]) return;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
+    if (t >= n || !b.bmt[0]) return;
+    bcc_turb_treatment(b, f, t, kp);
+}
+
+__device__ __forceinline__ void bcc_turb_apply(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, int second)
+{
     int fi;
     const long e = bc_face_entry(b, f, s.f, &fi);
     const long nt = 5 * b.nbox;
@@ -591,6 +634,13 @@ __global__ __launch_bounds__(256) void k_apply_turb_bc(BC_ARGS, KParams kp, int 
         b.w[s.c0 + nt] = b.w[s.c1 + nt];
         if (kp.eddyModel) b.rev[s.c0] = b.rev[s.c1];
     }
+}
+__global__ __launch_bounds__(256) void k_apply_turb_bc(BC_ARGS, KParams kp, int second)
+{
+    BC_PROLOGUE
+    BcSlab s;
+    if (!bc_slab(b, f, s) || !b.bmt[0]) return;
+    bcc_turb_apply(b, f, s, kp, second);
 }
 
 // `ordinal`: one launch per ordinal of a subface within its block (the r-th subfaces of all blocks together)
