@@ -1147,6 +1147,7 @@ int adflow_gpu_residual(int level, int rkStage)
 static int block_res_enqueue(int level, unsigned flags);
 static int apply_bc_enqueue(int level, int secondHalo);
 static int apply_turb_bc_enqueue(int level, int secondHalo);
+static int apply_turb_and_flow_bc_enqueue(int level, int secondHalo, bool turbBC);
 static int turb_bc_treatment_enqueue(int level, const KParams& kp);
 static int turb_bc_apply_enqueue(int level, const KParams& kp, int secondHalo);
 static int bc_coarse_corrections_enqueue(int coarseLevel, double fact);
@@ -1285,8 +1286,7 @@ static int block_res_enqueue(int level, unsigned flags)
     if (flags & ADFLOW_RES_HALO) {
         // BCTurbTreatment + applyAllTurbBCThisBlock(.true.) before applyAllBC_block(.true.) (blockette.F90:220-226)
         auto frontBCs = [&]() -> int {
-            if ((flags & ADFLOW_RES_TURB) && apply_turb_bc_enqueue(level, 1)) return 1;
-            if (apply_bc_enqueue(level, 1)) return 1;
+            if (apply_turb_and_flow_bc_enqueue(level, 1, (flags & ADFLOW_RES_TURB) != 0)) return 1;
             if (g_bc_callback) {
                 HIPCHK(hipStreamSynchronize(g_stream));
                 g_bc_callback(level, 1);
@@ -1505,8 +1505,7 @@ static int block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bo
         return 0;
     });
     if (rc) return rc;
-    if (turbBC && apply_turb_bc_enqueue(level, 1)) return 1;
-    if (apply_bc_enqueue(level, 1)) return 1;
+    if (apply_turb_and_flow_bc_enqueue(level, 1, turbBC)) return 1;
     if (g_bc_callback) {
         HIPCHK(hipStreamSynchronize(g_stream));
         g_bc_callback(level, 1);
@@ -2423,6 +2422,14 @@ int adflow_gpu_bc_register(int nn, int level, int sps, int nBocos, int nViscBoco
                 (which ? b->v.bvt : b->v.bmt)[f6] = (double*)raw;
             }
         invalidate_comm_level(level);   // the device block table holds copies of BlkView
+    } else if (v.nw > 5) {
+        // a new registration: the faces that carry no subface any more must read bmt = bvt = 0 (the merged turbulence treatment
+        // writes the cells of the subfaces only)
+        const size_t nf[3] = {(size_t)v.je * v.ke, (size_t)v.ie * v.ke, (size_t)v.ie * v.je};
+        for (int f6 = 0; f6 < 6; ++f6) {
+            HIPCHK(hipMemsetAsync(b->v.bmt[f6], 0, sizeof(double) * nf[f6 / 2], g_stream));
+            HIPCHK(hipMemsetAsync(b->v.bvt[f6], 0, sizeof(double) * nf[f6 / 2], g_stream));
+        }
     }
     return 0;
 }
@@ -2437,8 +2444,16 @@ struct BcPlan {
     long maxFace = 0;
     bool anyEulerWall = false;
     int nent = 0;
+    // merged application (kernels_bc.hip: k_bc_faces + k_bc_edges): mean-flow kind per entry, per block the (entry, action) steps in
+    // the reference's order, the largest subface
+    int* d_kinds = nullptr;
+    int2* d_steps = nullptr;
+    int* d_stepOff = nullptr;
+    int nblk = 0;
+    long maxCells = 0;
 };
 static std::map<int, BcPlan> g_bcplan;
+int g_bc_merge = 1;          // tuning "bc_merge": 2 launches per application instead of one per kind and ordinal
 
 static void bc_plan_drop(int level)
 {
@@ -2446,6 +2461,9 @@ static void bc_plan_drop(int level)
     if (it == g_bcplan.end()) return;
     if (it->second.d_ent) (void)hipFree(it->second.d_ent);
     if (it->second.d_order) (void)hipFree(it->second.d_order);
+    if (it->second.d_kinds) (void)hipFree(it->second.d_kinds);
+    if (it->second.d_steps) (void)hipFree(it->second.d_steps);
+    if (it->second.d_stepOff) (void)hipFree(it->second.d_stepOff);
     g_bcplan.erase(it);
 }
 
@@ -2526,7 +2544,35 @@ static int bc_plan(int level, BcPlan** out)
             const BcFaceDev& f = ent[e].f;
             pl.wall.maxCells = std::max(pl.wall.maxCells, (long)(f.icEnd - f.icBeg + 2) * (f.jcEnd - f.jcBeg + 2));
         }
+    // merged application: kind of every entry; per block its steps -- the turbulence boundary condition of every subface in index
+    // order (applyAllTurbBCThisBlock), then the mean-flow kinds in the order of `flow` (one entry per block and phase)
+    std::vector<int> kinds(ent.size(), -1), blkOf(ent.size(), -1);
+    std::vector<std::vector<int2>> steps(blocks.size());
+    for (size_t q = 0; q < blocks.size(); ++q)
+        for (int m = 0; m < blocks[q].n; ++m) {
+            blkOf[blocks[q].first + m] = (int)q;
+            int2 st; st.x = blocks[q].first + m; st.y = 100;      // BCP_TURB (kernels_bc.hip)
+            steps[q].push_back(st);
+            pl.maxCells = std::max(pl.maxCells, cells(blocks[q].first + m));
+        }
+    for (const BcPhase& ph : pl.flow)
+        for (int t = 0; t < ph.count; ++t) {
+            const int e = order[ph.first + t];
+            int2 st; st.x = e; st.y = ph.kind;
+            steps[blkOf[e]].push_back(st);
+            if (ph.kind != BCP_SYMM2 && ph.kind != BCP_SYMMPOLAR2) kinds[e] = ph.kind;
+        }
+    pl.nblk = (int)blocks.size();
     if (pl.nent > 0) {
+        std::vector<int2> flat;
+        std::vector<int> off(1, 0);
+        for (auto& v : steps) { flat.insert(flat.end(), v.begin(), v.end()); off.push_back((int)flat.size()); }
+        HIPCHK(hipMalloc((void**)&pl.d_kinds, sizeof(int) * kinds.size()));
+        HIPCHK(hipMemcpy(pl.d_kinds, kinds.data(), sizeof(int) * kinds.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&pl.d_steps, sizeof(int2) * flat.size()));
+        HIPCHK(hipMemcpy(pl.d_steps, flat.data(), sizeof(int2) * flat.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&pl.d_stepOff, sizeof(int) * off.size()));
+        HIPCHK(hipMemcpy(pl.d_stepOff, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMalloc((void**)&pl.d_ent, sizeof(BcEntry) * ent.size()));
         HIPCHK(hipMemcpy(pl.d_ent, ent.data(), sizeof(BcEntry) * ent.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMalloc((void**)&pl.d_order, sizeof(int) * order.size()));
@@ -2545,7 +2591,8 @@ static int turb_bc_treatment_enqueue(int level, const KParams& kp)
     if (pl->nent == 0) return 0;
     LevelTab t;
     if (level_tab(level, &t)) return 1;
-    launch_turb_bc_treatment(t.tab, t.n, pl->maxFace, pl->d_ent, pl->d_order, pl->ordinal, kp, g_stream);
+    if (g_bc_merge) launch_turb_bc_treatment_all(t.tab, pl->d_ent, pl->nent, pl->maxCells, kp, g_stream);   // (face arrays zeroed at registration)
+    else launch_turb_bc_treatment(t.tab, t.n, pl->maxFace, pl->d_ent, pl->d_order, pl->ordinal, kp, g_stream);
     return 0;
 }
 
@@ -2561,18 +2608,67 @@ static int turb_bc_apply_enqueue(int level, const KParams& kp, int secondHalo)
     return 0;
 }
 
+// Merged application (kernels_bc.hip): [bcTurbTreatment + applyAllTurbBCThisBlock] and / or applyAllBC of every block of the level
+// in two launches.  *taken = false: not applicable here (tuning off; Euler walls with the normal-momentum pressure gradient, which
+// differentiate along the wall and therefore read beyond the edge cells) -- the caller takes the launches per kind and ordinal.
+static int bc_merged_enqueue(int level, int secondHalo, bool turb, bool flow, bool* taken)
+{
+    *taken = false;
+    if (!g_bc_merge) return 0;
+    BcPlan* pl;
+    if (bc_plan(level, &pl)) return 1;
+    *taken = true;
+    if (pl->nent == 0) return 0;
+    turb = turb && g_opts.equations == ADFLOW_RANS;
+    if (!turb && !flow) return 0;
+    KParams kp = make_kparams(level, 1.0, 0);
+    if (flow && pl->anyEulerWall) {
+        if (g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_QUADRATIC || (g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_NORMAL_MOMENTUM && kp.fineGrid)) {
+            *taken = false;
+            return 0;
+        }
+    }
+    LevelTab t;
+    if (level_tab(level, &t)) return 1;
+    launch_bc_merged(t.tab, pl->d_ent, pl->nent, pl->d_kinds, pl->maxCells, pl->d_steps, pl->d_stepOff, pl->nblk, kp, secondHalo,
+                     g_opts.eulerWallBCTreatment, g_opts.viscWallBCTreatment, g_opts.outflowTreatment, g_opts.hScalingInlet, turb ? 1 : 0,
+                     flow ? 1 : 0, g_stream);
+    if (flow)
+        return for_level(level, [&](Block* b) {
+            if (!b->bc.empty()) b->ss_valid = false;
+            return 0;
+        });
+    return 0;
+}
+
 // bcTurbTreatment + applyAllTurbBCThisBlock(secondHalo) for the blocks of `level` with registered subfaces
 static int apply_turb_bc_enqueue(int level, int secondHalo)
 {
     if (g_opts.equations != ADFLOW_RANS) return 0;
+    bool taken;
+    if (bc_merged_enqueue(level, secondHalo, true, false, &taken)) return 1;
+    if (taken) return 0;
     KParams kp = make_kparams(level, 1.0, 0);
     if (turb_bc_treatment_enqueue(level, kp)) return 1;
     return turb_bc_apply_enqueue(level, kp, secondHalo);
 }
 
+// both, in the order of blocketteRes (blockette.F90:228-244): turbulence first
+static int apply_turb_and_flow_bc_enqueue(int level, int secondHalo, bool turbBC)
+{
+    bool taken;
+    if (bc_merged_enqueue(level, secondHalo, turbBC, true, &taken)) return 1;
+    if (taken) return 0;
+    if (turbBC && apply_turb_bc_enqueue(level, secondHalo)) return 1;
+    return apply_bc_enqueue(level, secondHalo);
+}
+
 // applyAllBC (BCRoutines.F90:15-54) for the blocks of `level` that registered subfaces
 static int apply_bc_enqueue(int level, int secondHalo)
 {
+    bool taken;
+    if (bc_merged_enqueue(level, secondHalo, false, true, &taken)) return 1;
+    if (taken) return 0;
     BcPlan* pl;
     if (bc_plan(level, &pl)) return 1;
     if (pl->nent == 0) return 0;
@@ -3665,6 +3761,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
         return 0;
     }
     if (!strcmp(key, "split_eval")) { g_split_eval = value; return 0; }
+    if (!strcmp(key, "bc_merge")) { g_bc_merge = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);

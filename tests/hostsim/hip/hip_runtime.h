@@ -37,6 +37,7 @@ struct dim3 {
 };
 struct uint3_ { unsigned x, y, z; };
 struct int4 { int x, y, z, w; };
+struct int2 { int x, y; };
 struct double2 { double x, y; };
 extern thread_local uint3_ threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
