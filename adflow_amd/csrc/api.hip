@@ -2453,7 +2453,12 @@ struct BcPlan {
     long maxCells = 0;
 };
 static std::map<int, BcPlan> g_bcplan;
-int g_bc_merge = 1;          // tuning "bc_merge": 2 launches per application instead of one per kind and ordinal
+// tuning "bc_merge": 2 launches per application instead of one per kind and ordinal.  1 (default): on levels whose largest subface
+// has at most g_bc_merge_cells cells -- the coarse multigrid levels and meshes of small blocks, where an application is a chain of
+// 5 us launches; on fat blocks the ordered edge pass (ONE workgroup per block walking ~13 steps) costs more than the launches it
+// replaces: measured on 8 x 160x128x64, k_bc_faces 94 + k_bc_edges 155 us against 132 us (profiles/r05_b_*).  2: always, 0: never
+int g_bc_merge = 1;
+long g_bc_merge_cells = 6000;
 
 static void bc_plan_drop(int level)
 {
@@ -2591,7 +2596,8 @@ static int turb_bc_treatment_enqueue(int level, const KParams& kp)
     if (pl->nent == 0) return 0;
     LevelTab t;
     if (level_tab(level, &t)) return 1;
-    if (g_bc_merge) launch_turb_bc_treatment_all(t.tab, pl->d_ent, pl->nent, pl->maxCells, kp, g_stream);   // (face arrays zeroed at registration)
+    if (g_bc_merge == 2 || (g_bc_merge == 1 && pl->maxCells <= g_bc_merge_cells))
+        launch_turb_bc_treatment_all(t.tab, pl->d_ent, pl->nent, pl->maxCells, kp, g_stream);   // (face arrays zeroed at registration)
     else launch_turb_bc_treatment(t.tab, t.n, pl->maxFace, pl->d_ent, pl->d_order, pl->ordinal, kp, g_stream);
     return 0;
 }
@@ -2617,6 +2623,7 @@ static int bc_merged_enqueue(int level, int secondHalo, bool turb, bool flow, bo
     if (!g_bc_merge) return 0;
     BcPlan* pl;
     if (bc_plan(level, &pl)) return 1;
+    if (g_bc_merge == 1 && pl->maxCells > g_bc_merge_cells) return 0;
     *taken = true;
     if (pl->nent == 0) return 0;
     turb = turb && g_opts.equations == ADFLOW_RANS;

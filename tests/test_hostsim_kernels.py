@@ -141,6 +141,24 @@ def test_foreign_normals_then_own_nodes(hostsim_engine):
     checks.check_foreign_normals_then_own_nodes(hostsim_engine, (9, 7, 6), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
 
 
+@pytest.mark.parametrize("merge", [0, 2])
+def test_bc_merged_application(hostsim_engine, merge):
+    """tuning bc_merge: one launch over the cells off the block edges + one ordered pass over the edge rings (2), one launch per kind
+    and ordinal (0); faces with cells off the edges (more than 6 cells wide)"""
+    e = hostsim_engine
+    try:
+        e.set_tuning("bc_merge", merge)
+        checks.check_apply_bc(e, (12, 10, 9), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9})
+        checks.check_apply_bc(e, (12, 10, 9), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, stretch_k=2.0)
+        checks.check_apply_bc(e, (14, 10, 9), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5}, secondHalo=False)
+        rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=2)
+        checks.check_smoother_with_bc(e, (10, 9, 8), rans, {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}, stretch_k=2.0)
+        checks.check_blockette_res_with_bc(e, BrickTopology(2, 1, 1, 10, 9, 8, periodic=(False, False, False)),
+                                           FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}, stretch_k=2.0)
+    finally:
+        e.set_tuning("bc_merge", 1)
+
+
 def test_rotated_interfaces(hostsim_engine):
     """1-to-1 interfaces with a transformation between blocks of different sizes (modules/block.F90:271-309): the emulator twin
     of tests/test_gpu_topology.py"""
