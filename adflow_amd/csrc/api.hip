@@ -15,7 +15,8 @@
 
 #include "internal.h"
 
-extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march;
+extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_gf_prefetch;
+int g_front_overlap = 1;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions
 int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
 
 namespace {
@@ -1262,7 +1263,12 @@ static int block_res_enqueue(int level, unsigned flags)
     if (kp.dissApprox && (flags & ADFLOW_RES_UPWIND_FIRST_ORDER)) kp.lumpedDiss = 1;   // blockette.F90:643
     const bool viscApprox = (flags & ADFLOW_RES_VISC_APPROX) != 0;
     int rc = 0;
-    bool etotInClosures = false;
+    bool etotInClosures = false, closForked = false;
+    // (every exit below the fork joins the side queue first)
+    struct Joiner {
+        bool* f;
+        ~Joiner() { if (*f) { (void)hipStreamWaitEvent(g_stream, g_evB, 0); *f = false; } }
+    } joiner{&closForked};
     if (flags & ADFLOW_RES_CLOSURES) {
         // computePressureSimple / computeLamViscosity / computeEddyViscosity (blockette.F90:199-203)
         LevelTab tc;
@@ -1275,7 +1281,19 @@ static int block_res_enqueue(int level, unsigned flags)
             if (!g_floor_flag_dev) HIPCHK(hipMalloc((void**)&g_floor_flag_dev, sizeof(int)));
             HIPCHK(hipMemsetAsync(g_floor_flag_dev, 0, sizeof(int), g_stream));
         }
-        launch_closures_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream, etotInClosures ? g_floor_flag_dev : nullptr);
+        // tuning front_overlap: with boundary subfaces on the level the derived values of the SHELL (the two cell layers behind every
+        // block face: all the boundary conditions and the exchange read) come first, the core follows on the side queue beside the
+        // boundary-condition launches and is joined behind them (kernels_nk.hip k_closures_shell / k_closures_core)
+        closForked = g_front_overlap && g_overlap && (flags & ADFLOW_RES_HALO) && !g_bc_callback && !g_turb_bc_callback && g_phase_base <= 0 &&
+                     level_has_subfaces(level);
+        if (closForked) {
+            launch_closures_part(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream, etotInClosures ? g_floor_flag_dev : nullptr, 0);
+            HIPCHK(hipEventRecord(g_evFork, g_stream));
+            HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
+            launch_closures_part(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_streamB, etotInClosures ? g_floor_flag_dev : nullptr, 1);
+            HIPCHK(hipEventRecord(g_evB, g_streamB));
+        } else
+            launch_closures_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream, etotInClosures ? g_floor_flag_dev : nullptr);
         rc = for_level(level, [&](Block* b) {
             b->ss_valid = false;
             b->etot_consistent = false;
@@ -1287,6 +1305,7 @@ static int block_res_enqueue(int level, unsigned flags)
         // BCTurbTreatment + applyAllTurbBCThisBlock(.true.) before applyAllBC_block(.true.) (blockette.F90:220-226)
         auto frontBCs = [&]() -> int {
             if (apply_turb_and_flow_bc_enqueue(level, 1, (flags & ADFLOW_RES_TURB) != 0)) return 1;
+            if (closForked) { HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0)); closForked = false; }      // join: the core's derived values
             if (g_bc_callback) {
                 HIPCHK(hipStreamSynchronize(g_stream));
                 g_bc_callback(level, 1);
@@ -3769,6 +3788,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
     }
     if (!strcmp(key, "split_eval")) { g_split_eval = value; return 0; }
     if (!strcmp(key, "bc_merge")) { g_bc_merge = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "front_overlap")) { g_front_overlap = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "gf_prefetch")) { g_gf_prefetch = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);

@@ -429,6 +429,7 @@ void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 // level-batched forms (blockIdx.z = slot * planes + plane): one launch for every block of a level
 void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s,
                            int* floored = nullptr);
+void launch_closures_part(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s, int* floored, int part);
 void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
                                  const KParams& kp, int* floored, hipStream_t s);
 void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s);

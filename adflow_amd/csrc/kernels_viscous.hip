@@ -912,8 +912,14 @@ struct GfMet { double Pt[3], Q0t[3], Q1t[3], RIt[3], V; };
 struct __attribute__((aligned(16))) Dbl2 { double x, y; };
 __device__ __forceinline__ Dbl2 mk2(double x, double y) { Dbl2 v; v.x = x; v.y = y; return v; }
 
-template <bool QCR, bool FIRST, bool STG>
-__global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
+// one cell plane of the rows jn, jn+1 as loaded (the prefetching form keeps it a whole step before it is used)
+struct GfReq { double au, av, aw, ap, ar, alv, aev, avol, bu, bv, bw, bp, br, blv, bev, bvol, aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3]; };
+
+// PF (tuning "gf_prefetch"): ONE workgroup per CU -- one wavefront per SIMD with the whole 512-entry register file -- and the 37 values
+// of cell plane mm+1 requested at the top of step mm: the request that stood fully exposed in front of the gradient part (a third of
+// the wave cycles waiting, profiles/r04_fin_pmc_sq.txt) has a whole step to land.
+template <bool QCR, bool FIRST, bool STG, bool PF = false>
+__global__ __launch_bounds__(256, PF ? 1 : 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
     __shared__ __attribute__((aligned(16))) double ring[GF_RING];   // [slot][node row 0..3 = rows j0-1 .. j0+2][component pair][lane-1][2]
     __shared__ __attribute__((aligned(16))) double fjx[2 * GF_FJ];  // [parity][row][lane-2][component]
@@ -989,12 +995,20 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
         }
         if (!FIRST && kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
     };
+    auto request = [&](unsigned c) {
+        GfReq q;
+        q.au = ldg(m.w1, c); q.av = ldg(m.w2, c); q.aw = ldg(m.w3, c); q.ap = ldg(m.p, c); q.ar = ldg(m.w0, c);
+        q.alv = ldg(m.rlv, c); q.aev = K.eddy ? ldg(m.rev, c) : 0.0; q.avol = ldg(m.vol, c);
+        const unsigned cb = c + dB;
+        q.bu = ldg(m.w1, cb); q.bv = ldg(m.w2, cb); q.bw = ldg(m.w3, cb); q.bp = ldg(m.p, cb); q.br = ldg(m.w0, cb);
+        q.blv = ldg(m.rlv, cb); q.bev = K.eddy ? ldg(m.rev, cb) : 0.0; q.bvol = ldg(m.vol, cb);
+        vm_ld3(m.sI, c, nb8, q.aI); vm_ld3(m.sJ, c - dM, nb8, q.aJm); vm_ld3(m.sJ, c, nb8, q.aJ); vm_ld3(m.sK, c, nb8, q.aK);
+        vm_ld3(m.sI, cb, nb8, q.bI); vm_ld3(m.sJ, cb, nb8, q.bJ); vm_ld3(m.sK, cb, nb8, q.bK);
+        return q;
+    };
+    GfReq cur;
+    if (PF) cur = request(cA);
     for (int mm = k0 - 1; mm <= k1 + 1; ++mm) {
-        // ---- cell plane mm of the rows jn and jn+1: state, normals, volume; centre-to-centre vectors and flags of plane mm-1
-        const GfRaw a = gf_ld(m, cA, gam, K.eddy), bq = gf_ld(m, cA + dB, gam, K.eddy);
-        double aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3];
-        vm_ld3(m.sI, cA, nb8, aI); vm_ld3(m.sJ, cA - dM, nb8, aJm); vm_ld3(m.sJ, cA, nb8, aJ); vm_ld3(m.sK, cA, nb8, aK);
-        vm_ld3(m.sI, cA + dB, nb8, bI); vm_ld3(m.sJ, cA + dB, nb8, bJ); vm_ld3(m.sK, cA + dB, nb8, bK);
         const unsigned cF = cA - sk;
         const bool facePlane = (mm >= k0);
         const bool full = (mm > k0);                           // all faces (first step of the march: the k face below plane k0 only)
@@ -1011,6 +1025,24 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
                 vm_ld3(m.sJ, cF, nb8, sJA);
             }
         };
+        // ---- cell plane mm of the rows jn and jn+1: state, normals, volume; centre-to-centre vectors and flags of plane mm-1
+        GfReq nxt;
+        if (PF) {
+            // plane mm+1 (the face part's loads follow behind the gradient part as in the plain form: requested up here the compiler
+            // parks them in AGPRs at once, i.e. waits for them in front of the gradient part)
+            nxt = request(cA + (mm <= k1 ? sk : 0u));
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            cur = request(cA);
+        }
+        GfRaw a, bq;
+        a.q.u = cur.au; a.q.v = cur.av; a.q.w = cur.aw; a.q.na = -(gam * cur.ap) * rcp_nr(cur.ar); a.q.rlv = cur.alv; a.q.rev = cur.aev; a.vol = cur.avol;
+        bq.q.u = cur.bu; bq.q.v = cur.bv; bq.q.w = cur.bw; bq.q.na = -(gam * cur.bp) * rcp_nr(cur.br); bq.q.rlv = cur.blv; bq.q.rev = cur.bev; bq.vol = cur.bvol;
+        double aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            aI[d] = cur.aI[d]; aJm[d] = cur.aJm[d]; aJ[d] = cur.aJ[d]; aK[d] = cur.aK[d]; bI[d] = cur.bI[d]; bJ[d] = cur.bJ[d]; bK[d] = cur.bK[d];
+        }
         // ---- metric sums of this plane (ng_finish for both rows; the row above takes sJ(j-1) from the own row)
         GfMet N;
         {
@@ -1154,6 +1186,7 @@ __global__ __launch_bounds__(256, 2) void k_visc_gf(const BlkView* __restrict__ 
             sKA[d] = aK[d]; sKB[d] = bK[d];
         }
         cA += sk;
+        if (PF) cur = nxt;
     }
     // ---- the last plane of the chunk: its j flux was handed over in the last step
     __syncthreads();
@@ -1270,10 +1303,16 @@ void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles,
 }
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
+int g_gf_prefetch = 0;      // tuning "gf_prefetch": k_visc_gf<.., PF>: one workgroup per CU, cell plane mm+1 requested a step ahead
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)
 {
     if (ntiles <= 0) return;
     const dim3 grd(ntiles), blk(64, 4, 1);
+    if (g_gf_prefetch && !storeGrad && kp.viscFirst) {
+        if (kp.useQCR) hipLaunchKernelGGL((k_visc_gf<true, true, false, true>), grd, blk, 0, s, tab, tiles, kp);
+        else hipLaunchKernelGGL((k_visc_gf<false, true, false, true>), grd, blk, 0, s, tab, tiles, kp);
+        return;
+    }
 #define GF_LAUNCH(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, tiles, kp)
     if (kp.useQCR) {
         if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, true, false); }

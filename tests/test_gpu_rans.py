@@ -321,3 +321,33 @@ def test_foreign_normals_then_own_nodes(engine):
     """round-4 advisor: an upload of sI from a foreign buffer followed by x from the registered pointer must leave the kernels on the
     stored normals"""
     checks.check_foreign_normals_then_own_nodes(engine, (63, 11, 35), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+
+
+def test_visc_gf_prefetch_variant(engine):
+    """tuning gf_prefetch: k_visc_gf<.., PF> (one workgroup per CU, the cell plane mm+1 requested a step ahead): partial tiles, QCR, RK
+    stages with persistent fw, walls"""
+    try:
+        engine.set_tuning("gf_prefetch", 1)
+        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
+        checks.check_block_res(engine, (63, 11, 35), prm, seed=71, stretch_k=2.0, holes=0.05)
+        checks.check_block_res(engine, (130, 7, 9), prm.replace(useQCR=True), seed=72, stretch_k=2.0)
+        checks.check_block_res_vs_blockette(engine, (24, 16, 8), prm, seed=73, stretch_k=2.0)
+        checks.check_rk_residual_sequence(engine, (20, 9, 12), FlowParams(equations=NSEquations), stretch_k=2.0)
+    finally:
+        engine.set_tuning("gf_prefetch", 0)
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_front_overlap_shell_and_core(engine, overlap):
+    """tuning front_overlap: derived values as shell + core (the core on the side queue beside the boundary-condition launches)"""
+    from adflow_amd.topology import BrickTopology
+    spec = {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    try:
+        engine.set_tuning("front_overlap", overlap)
+        for dims in ((70, 9, 11), (130, 5, 3), (3, 2, 1), (24, 16, 2)):
+            checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 1, *dims, periodic=(False, False, False)), rans, spec, stretch_k=2.0)
+        checks.check_blockette_res_with_bc(engine, BrickTopology(2, 2, 2, 64, 48, 32, periodic=(False, False, False)), rans, spec, floor_p=True,
+                                           stretch_k=2.0)
+    finally:
+        engine.set_tuning("front_overlap", 1)

@@ -159,6 +159,33 @@ def test_bc_merged_application(hostsim_engine, merge):
         e.set_tuning("bc_merge", 1)
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_front_overlap_shell_and_core(hostsim_engine, overlap):
+    """tuning front_overlap: the derived values of blocketteRes as shell (two layers behind the block faces) + core on a side queue
+    beside the boundary conditions; blocks thinner than the shell in one or several directions"""
+    e = hostsim_engine
+    spec = {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    try:
+        e.set_tuning("front_overlap", overlap)
+        for dims in ((9, 7, 6), (5, 4, 3), (3, 2, 1), (70, 5, 2), (4, 9, 8)):
+            checks.check_blockette_res_with_bc(e, BrickTopology(2, 1, 1, *dims, periodic=(False, False, False)), rans, spec, stretch_k=2.0)
+        checks.check_blockette_res_with_bc(e, BrickTopology(1, 2, 1, 8, 6, 5, periodic=(False, False, False)), rans, spec, floor_p=True, stretch_k=2.0)
+    finally:
+        e.set_tuning("front_overlap", 1)
+
+
+def test_visc_gf_prefetch_variant(hostsim_engine):
+    e = hostsim_engine
+    try:
+        e.set_tuning("gf_prefetch", 1)
+        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
+        checks.check_block_res(e, (63, 5, 9), prm, seed=71, stretch_k=2.0, holes=0.05)
+        checks.check_block_res(e, (10, 7, 6), prm.replace(useQCR=True), seed=72, stretch_k=2.0)
+    finally:
+        e.set_tuning("gf_prefetch", 0)
+
+
 def test_rotated_interfaces(hostsim_engine):
     """1-to-1 interfaces with a transformation between blocks of different sizes (modules/block.F90:271-309): the emulator twin
     of tests/test_gpu_topology.py"""
