@@ -148,7 +148,7 @@ EXPORTS = [
     "adflow_gpu_set_w_vec", "adflow_gpu_get_r_vec", "adflow_gpu_get_res", "adflow_gpu_nk_residual",
     "adflow_gpu_nk_residual_dev",
     "adflow_gpu_transfer_to_coarse", "adflow_gpu_transfer_to_fine", "adflow_gpu_mg_cycle",
-    "adflow_gpu_comm_register", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
+    "adflow_gpu_comm_register", "adflow_gpu_comm_info", "adflow_gpu_halo_slot_info", "adflow_gpu_halo_pack", "adflow_gpu_halo_unpack",
     "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2", "adflow_gpu_xhalo", "adflow_gpu_actuator_register", "adflow_gpu_comm_register_periodic", "adflow_gpu_coarse_coordinates", "adflow_gpu_exchange_coor",
     "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
     "adflow_gpu_wall_distance_register", "adflow_gpu_update_wall_distances",
@@ -223,6 +223,7 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_mg_cycle.argtypes = [c_void_p, c_int]
     lib.adflow_gpu_comm_register.argtypes = [c_int, c_int, POINTER(AdflowCommPattern)]
     lib.adflow_gpu_halo_slot_info.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]
+    lib.adflow_gpu_comm_info.argtypes = [POINTER(c_int)] * 4
     lib.adflow_gpu_halo_pack.argtypes = [c_int] * 7 + [c_void_p]
     lib.adflow_gpu_halo_unpack.argtypes = [c_int] * 7 + [c_void_p]
     lib.adflow_gpu_halo_local_copy.argtypes = [c_int] * 6

@@ -16,7 +16,7 @@
 #include "internal.h"
 
 extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_gf_prefetch;
-int g_front_overlap = 1;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions
+int g_front_overlap = 0;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions (off: measured no gain at N = 1, profiles/r05_e_ab.txt)
 int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
 
 namespace {
@@ -2830,6 +2830,25 @@ int adflow_gpu_comm_init(int rank, int nranks, const void* id128)
     (void)rank; (void)nranks; (void)id128;
     return fail("built without RCCL");
 #endif
+}
+
+int adflow_gpu_comm_info(int* rank, int* nranks, int* commCount, int* commUserRank)
+{
+    int cnt = -1, ur = -1;
+#ifndef ADFLOW_NO_RCCL
+    if (rank) *rank = g_rank;
+    if (nranks) *nranks = g_nranks;
+    if (g_nccl) {
+        NCCLCHK(ncclCommCount(g_nccl, &cnt));
+        NCCLCHK(ncclCommUserRank(g_nccl, &ur));
+    }
+#else
+    if (rank) *rank = 0;
+    if (nranks) *nranks = 1;
+#endif
+    if (commCount) *commCount = cnt;
+    if (commUserRank) *commUserRank = ur;
+    return 0;
 }
 
 int adflow_gpu_comm_register(int level, int nLayers, const adflow_comm_pattern* p)

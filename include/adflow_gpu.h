@@ -230,6 +230,10 @@ int adflow_gpu_device_name(char* buf, int len);
  *      src/utils/haloExchange.F90:553-719 ------------------------------------ */
 int adflow_gpu_comm_unique_id(void* id128);                       /* rank 0: create id (128 bytes) */
 int adflow_gpu_comm_init(int rank, int nranks, const void* id128); /* all ranks */
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank; -1 / -1 before adflow_gpu_comm_init) beside the rank and
+ * size the library was given: lets a launcher check that every rank joined ONE communicator of the expected size before the first
+ * exchange (the reference's myID / nProc of communication.F90 come from MPI_Comm_rank / _size the same way). */
+int adflow_gpu_comm_info(int* rank, int* nranks, int* commCount, int* commUserRank);
 
 /* ---- data model -------------------------------------------------------- */
 int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_desc* d);

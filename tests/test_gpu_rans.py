@@ -350,4 +350,4 @@ def test_front_overlap_shell_and_core(engine, overlap):
         checks.check_blockette_res_with_bc(engine, BrickTopology(2, 2, 2, 64, 48, 32, periodic=(False, False, False)), rans, spec, floor_p=True,
                                            stretch_k=2.0)
     finally:
-        engine.set_tuning("front_overlap", 1)
+        engine.set_tuning("front_overlap", 0)

@@ -172,7 +172,7 @@ def test_front_overlap_shell_and_core(hostsim_engine, overlap):
             checks.check_blockette_res_with_bc(e, BrickTopology(2, 1, 1, *dims, periodic=(False, False, False)), rans, spec, stretch_k=2.0)
         checks.check_blockette_res_with_bc(e, BrickTopology(1, 2, 1, 8, 6, 5, periodic=(False, False, False)), rans, spec, floor_p=True, stretch_k=2.0)
     finally:
-        e.set_tuning("front_overlap", 1)
+        e.set_tuning("front_overlap", 0)
 
 
 def test_visc_gf_prefetch_variant(hostsim_engine):
