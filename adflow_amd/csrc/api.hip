@@ -575,6 +575,7 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
 
 static void bc_plan_drop(int level);
 static void bc_plan_drop_all();
+static void ad_cache_drop();      // the cached dual arrays of the forward-mode assembly refer to the blocks
 
 int adflow_gpu_block_release(int nn, int level, int sps)
 {
@@ -582,6 +583,7 @@ int adflow_gpu_block_release(int nn, int level, int sps)
     if (it == g_blocks.end()) return fail("block (%d,%d,%d) not registered", nn, level, sps);
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     bc_plan_drop(level);
+    ad_cache_drop();
     for (void* p : it->second->allocs) (void)hipFree(p);
     if (it->second->jac_raw) (void)hipFree(it->second->jac_raw);
     if (it->second->snap_raw) (void)hipFree(it->second->snap_raw);
@@ -596,6 +598,7 @@ int adflow_gpu_release_all(void)
 {
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     bc_plan_drop_all();
+    ad_cache_drop();
     for (auto& kv : g_blocks) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
         if (kv.second->jac_raw) (void)hipFree(kv.second->jac_raw);
@@ -1533,49 +1536,54 @@ static int block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bo
 }
 
 // ---- forward-mode linearisation (kernels_ad.hip): dual copies of the arrays the gather kernels touch ----------------------------
-struct AdBlock { BlkView v; std::vector<void*> allocs; };
+// Round 5 (round-4 advisor): ONE slab per level instead of ~57 hipMalloc / hipFree per block and call, kept between calls (tuning
+// "ad_cache", default 1; dropped when a block is released or the level's layout changes) -- on the north-star mesh the 13.5 GB of
+// dual arrays cost 0-400 ms per assembly to map, depending on the box (profiles/r05_f_bench.json against r05_d) -- and the free
+// memory is checked before the slab is requested.
+struct AdInit { char* dst; const double* src; size_t n, zeroBytes; };   // dual array at dst: (src, 0) for n entries, or zeroBytes of zero
+struct AdBlock { BlkView v; std::vector<AdInit> init; };
 static std::map<Block*, AdBlock> g_ad;
 static BlkView* g_ad_tab = nullptr;        // device table of the level being linearised, slot layout of g_tab[level]
+static char* g_ad_slab = nullptr;
+static size_t g_ad_slab_bytes = 0, g_ad_bump = 0;
+static bool g_ad_measure = false;
+static std::vector<long> g_ad_sig;         // what the cached slab was laid out for
+int g_ad_cache = 1;
 
+static void ad_drop();
+static void ad_cache_drop() { ad_drop(); }
 static void ad_drop()
 {
-    for (auto& kv : g_ad)
-        for (void* q : kv.second.allocs) (void)hipFree(q);
     g_ad.clear();
+    if (g_ad_slab) (void)hipFree(g_ad_slab);
+    g_ad_slab = nullptr; g_ad_slab_bytes = 0; g_ad_sig.clear();
     if (g_ad_tab) (void)hipFree(g_ad_tab);
     g_ad_tab = nullptr;
 }
 
-// dual array of ncomp components over the box of b (16 bytes per entry, the same padding as the library's arrays), filled with
-// (src, 0) when src is given; the returned pointer is typed double* because BlkView is (the kernels see it as Dual*)
+// dual array of ncomp components over the box of b (16 bytes per entry, the same padding as the library's arrays) out of the
+// level's slab, filled with (src, 0) when src is given; the returned pointer is typed double* because BlkView is (the kernels see
+// it as Dual*).  Measuring pass: only the size is added up.
 static int ad_array(Block* b, AdBlock& a, double** field, const double* src, int ncomp)
 {
     const size_t n = (size_t)b->v.nbox * ncomp;
-    void* raw = nullptr;
-    HIPCHK(hipMalloc(&raw, (n + 32) * 16));
-    a.allocs.push_back(raw);
-    if (src) ad_launch_from_real(src - ADF_PAD0, raw, (long)n, g_stream);
-    else HIPCHK(hipMemsetAsync(raw, 0, (n + 32) * 16, g_stream));
-    *field = (double*)((char*)raw + (size_t)ADF_PAD0 * 16);
+    const size_t bytes = ((n + 32) * 16 + 255) & ~(size_t)255;
+    if (g_ad_measure) { g_ad_bump += bytes; *field = nullptr; return 0; }
+    if (g_ad_bump + bytes > g_ad_slab_bytes) return fail("forward mode: the slab of dual arrays is too small (internal error)");
+    char* raw = g_ad_slab + g_ad_bump;
+    g_ad_bump += bytes;
+    a.init.push_back(AdInit{raw, src ? src - ADF_PAD0 : nullptr, n, (n + 32) * 16});
+    *field = (double*)(raw + (size_t)ADF_PAD0 * 16);
     return 0;
 }
 
-static int ad_prepare(int level)
+// lays the dual arrays of every block of the level out (measuring pass or in the slab)
+static int ad_layout(int level, bool viscous)
 {
-    ad_drop();
-    if (ensure_table(level)) return 1;
-    const int maxnn = g_tab_size[level];
-    std::vector<BlkView> h(maxnn + 1);
-    memset(h.data(), 0, sizeof(BlkView) * h.size());
-    const bool viscous = g_opts.equations != ADFLOW_EULER;
-    int rc = for_level(level, [&](Block* b) {
-        if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
-        if (viscous && !b->face_vectors_valid) {
-            launch_face_vectors(b->v, g_stream);
-            b->face_vectors_valid = true;
-        }
+    return for_level(level, [&](Block* b) {
         AdBlock& a = g_ad[b];
         a.v = b->v;
+        a.init.clear();
         BlkView& v = a.v;
         const BlkView& p = b->v;
         // active arrays (the seed kernel fills w; the evaluation writes the rest)
@@ -1599,19 +1607,67 @@ static int ad_prepare(int level)
             for (int which = 0; which < 2; ++which) {
                 double** dst = &(which ? v.bvt : v.bmt)[f6];
                 if (!(which ? p.bvt : p.bmt)[f6]) { *dst = nullptr; continue; }
-                void* raw = nullptr;
-                HIPCHK(hipMalloc(&raw, nf[f6 / 2] * 16));
-                HIPCHK(hipMemsetAsync(raw, 0, nf[f6 / 2] * 16, g_stream));
-                a.allocs.push_back(raw);
+                const size_t bytes = (nf[f6 / 2] * 16 + 255) & ~(size_t)255;
+                if (g_ad_measure) { g_ad_bump += bytes; continue; }
+                if (g_ad_bump + bytes > g_ad_slab_bytes) return fail("forward mode: the slab of dual arrays is too small (internal error)");
+                char* raw = g_ad_slab + g_ad_bump;
+                g_ad_bump += bytes;
+                a.init.push_back(AdInit{raw, nullptr, nf[f6 / 2], nf[f6 / 2] * 16});
                 *dst = (double*)raw;
             }
         return 0;
     });
+}
+
+static int ad_prepare(int level)
+{
+    if (ensure_table(level)) return 1;
+    const int maxnn = g_tab_size[level];
+    const bool viscous = g_opts.equations != ADFLOW_EULER;
+    // the layout the slab must have: level, model, and per block its identity, box, variables and optional arrays
+    std::vector<long> sig = {level, viscous ? 1 : 0, maxnn};
+    int rc = for_level(level, [&](Block* b) {
+        if (!b->geom_uploaded) return fail("geometry of a level-%d block has not been uploaded", level);
+        if (viscous && !b->face_vectors_valid) {
+            launch_face_vectors(b->v, g_stream);
+            b->face_vectors_valid = true;
+        }
+        const BlkView& p = b->v;
+        sig.push_back((long)(uintptr_t)b); sig.push_back(p.nbox); sig.push_back(p.nw);
+        sig.push_back((p.d2wall ? 1 : 0) | (p.dI ? 2 : 0) | (p.bmt[0] ? 4 : 0));
+        sig.push_back((long)(uintptr_t)p.w); sig.push_back((long)(uintptr_t)p.x);
+        return 0;
+    });
     if (rc) return rc;
-    for (auto& kv : g_blocks)
-        if (std::get<0>(kv.first) == level && std::get<1>(kv.first) == 1) h[std::get<2>(kv.first)] = g_ad[kv.second].v;
-    HIPCHK(hipMalloc((void**)&g_ad_tab, sizeof(BlkView) * h.size()));
-    HIPCHK(hipMemcpyAsync(g_ad_tab, h.data(), sizeof(BlkView) * h.size(), hipMemcpyHostToDevice, g_stream));
+    if (!g_ad_slab || sig != g_ad_sig) {
+        ad_drop();
+        g_ad_measure = true; g_ad_bump = 0;
+        rc = ad_layout(level, viscous);
+        g_ad_measure = false;
+        if (rc) return rc;
+        const size_t need = g_ad_bump + 4096;
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB < need + ((size_t)64 << 20))
+            return fail("forward mode needs %.2f GB for the dual copies of the level's arrays, %.2f GB are free on the device", need / 1.e9, freeB / 1.e9);
+        HIPCHK(hipMalloc((void**)&g_ad_slab, need));
+        g_ad_slab_bytes = need;
+        g_ad_bump = 0;
+        g_ad.clear();
+        if (ad_layout(level, viscous)) { ad_drop(); return 1; }
+        std::vector<BlkView> h(maxnn + 1);
+        memset(h.data(), 0, sizeof(BlkView) * h.size());
+        for (auto& kv : g_blocks)
+            if (std::get<0>(kv.first) == level && std::get<1>(kv.first) == 1) h[std::get<2>(kv.first)] = g_ad[kv.second].v;
+        HIPCHK(hipMalloc((void**)&g_ad_tab, sizeof(BlkView) * h.size()));
+        HIPCHK(hipMemcpyAsync(g_ad_tab, h.data(), sizeof(BlkView) * h.size(), hipMemcpyHostToDevice, g_stream));
+        g_ad_sig = sig;
+    }
+    // values of this call: the passive arrays and the frozen closures from the library's arrays, zero elsewhere
+    for (auto& kv : g_ad)
+        for (const AdInit& q : kv.second.init) {
+            if (q.src) ad_launch_from_real(q.src, q.dst, (long)q.n, g_stream);
+            else HIPCHK(hipMemsetAsync(q.dst, 0, q.zeroBytes, g_stream));
+        }
     HIPCHK(hipStreamSynchronize(g_stream));
     return 0;
 }
@@ -1761,7 +1817,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
         }
         if (!rc) rc = sync_and_check();
         else (void)hipStreamSynchronize(g_stream);
-        ad_drop();
+        if (!g_ad_cache || rc) ad_drop();
         restore();
         if (rc) return rc;
         g_jac = J;
@@ -3808,6 +3864,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "split_eval")) { g_split_eval = value; return 0; }
     if (!strcmp(key, "bc_merge")) { g_bc_merge = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "front_overlap")) { g_front_overlap = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
     if (!strcmp(key, "gf_prefetch")) { g_gf_prefetch = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {

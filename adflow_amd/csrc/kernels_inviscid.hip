@@ -97,8 +97,15 @@ __device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, lo
 
 // FINAL: dw = (init + central + fw) * iblank written; otherwise the viscous kernel completes the sum: with the persistent
 // fw of the Runge-Kutta scheme (fwMode) dw = init + central and fw are stored, else only dw = init + central + fw.
-template <int SCHEME, bool VISC, bool FINAL>
-__global__ __launch_bounds__(IV_BX* IV_BY, (SCHEME == ADFLOW_UPWIND ? 2 : 1)) void k_inviscid(const BlkView* __restrict__ tab, int nzb, KParams kp)
+#ifdef ADF_AD_BUILD
+#define IV_MINWG(S) 1       // dual numbers: the whole register file (256 registers + 1.4 KB of scratch per lane with two workgroups per CU)
+#else
+#define IV_MINWG(S) ((S) == ADFLOW_UPWIND ? 2 : 1)
+#endif
+// LIMT >= 0: the limiter at compile time (the first-order Roe flux of the coarse levels and of the preconditioner matrix: no
+// reconstruction code in the kernel -- in the dual-number build that is the difference between 460 B of scratch per lane and none)
+template <int SCHEME, bool VISC, bool FINAL, int LIMT = -1>
+__global__ __launch_bounds__(IV_BX* IV_BY, IV_MINWG(SCHEME)) void k_inviscid(const BlkView* __restrict__ tab, int nzb, KParams kp)
 {
     // level-batched: blockIdx.z = block slot * nzb + plane
     const BlkView& b = tab[blockIdx.z / nzb + 1];
@@ -120,15 +127,30 @@ __global__ __launch_bounds__(IV_BX* IV_BY, (SCHEME == ADFLOW_UPWIND ? 2 : 1)) vo
     const double fis2 = kp.rFil * kp.vis2, fis4 = kp.rFil * kp.vis4;
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
     // limiter actually used: first order off the fine grid (fluxes.F90:1531-1538)
-    const int lim = (kp.fineGrid && !kp.lumpedDiss) ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;
+    const int lim = (LIMT >= 0) ? LIMT : ((kp.fineGrid && !kp.lumpedDiss) ? kp.limiter : ADFLOW_LIM_FIRST_ORDER);
 
     double dwc[5] = {0, 0, 0, 0, 0}, fwd[5] = {0, 0, 0, 0, 0};
     const double* sF = b.sFace;
+#ifdef ADF_AD_BUILD
+    // dual numbers: the three directions one after the other in ONE copy of the code (a loop the compiler must not unroll), so that
+    // only one direction's line of states is live at a time
+    {
+        const long strd[3] = {1, b.ldi, b.ldk};
+        const double* sNd[3] = {b.sI, b.sJ, b.sK};
+        const double* radd[3] = {b.radI, b.radJ, b.radK};
+        const int pM[3] = {flg_porI(fi), flg_porJ(fj), flg_porK(fk)}, pP[3] = {flg_porI(f0), flg_porJ(f0), flg_porK(f0)};
+#pragma nounroll
+        for (int d = 0; d < 3; ++d)
+            dir_flux<SCHEME, VISC>(b, kp, c, strd[d], sNd[d], radd[d], pM[d], pP[d], sslim, fis2, fis4, doDiss, lim, dwc, fwd,
+                                   sF ? sF + d * nb : nullptr);
+    }
+#else
     dir_flux<SCHEME, VISC>(b, kp, c, 1, b.sI, b.radI, flg_porI(fi), flg_porI(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd, sF);
     dir_flux<SCHEME, VISC>(b, kp, c, b.ldi, b.sJ, b.radJ, flg_porJ(fj), flg_porJ(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd,
                            sF ? sF + nb : nullptr);
     dir_flux<SCHEME, VISC>(b, kp, c, b.ldk, b.sK, b.radK, flg_porK(fk), flg_porK(f0), sslim, fis2, fis4, doDiss, lim, dwc, fwd,
                            sF ? sF + 2 * nb : nullptr);
+#endif
     if (b.moving) {
         // rotational source of the momentum equations, steady mode: the equations are solved in the inertial frame
         // (inviscidCentralFlux, fluxes.F90:372-397)
@@ -170,6 +192,16 @@ static void launch_scheme(const BlkView* b, int nzb, const KParams& kp, dim3 grd
     // the viscous kernel completes the sum unless rFil == 0 (viscousFlux returns
     // early, fluxes.F90:2585: the stored fw already holds the viscous part)
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
+    if (SCHEME == ADFLOW_UPWIND && ((kp.fineGrid && !kp.lumpedDiss) ? kp.limiter : ADFLOW_LIM_FIRST_ORDER) == ADFLOW_LIM_FIRST_ORDER) {
+        constexpr int FO = ADFLOW_LIM_FIRST_ORDER;
+        if (kp.viscous) {
+            if (doDiss) hipLaunchKernelGGL((k_inviscid<SCHEME, true, false, FO>), grd, blk, 0, s, b, nzb, kp);
+            else hipLaunchKernelGGL((k_inviscid<SCHEME, true, true, FO>), grd, blk, 0, s, b, nzb, kp);
+        } else {
+            hipLaunchKernelGGL((k_inviscid<SCHEME, false, true, FO>), grd, blk, 0, s, b, nzb, kp);
+        }
+        return;
+    }
     if (kp.viscous) {
         if (doDiss)
             hipLaunchKernelGGL((k_inviscid<SCHEME, true, false>), grd, blk, 0, s, b, nzb, kp);

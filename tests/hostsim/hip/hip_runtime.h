@@ -81,6 +81,7 @@ inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : 1; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)1 << 40; *t = (size_t)1 << 40; return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n); return *p ? hipSuccess : 1; }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
