@@ -16,6 +16,8 @@
 #include "internal.h"
 
 extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_gf_prefetch;
+int g_test_fault = 0;        // tuning "test_fault" (tests only): bit 0 = the hipGraph capture of a multigrid cycle reports failure, bit 1 = the
+                             // split evaluation fails behind its fork -- the error paths must leave the library usable
 int g_front_overlap = 0;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions (off: measured no gain at N = 1, profiles/r05_e_ab.txt)
 int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
 
@@ -1228,6 +1230,7 @@ static int block_res_split_enqueue(int level, unsigned flags, const KParams& kp0
         HIPCHK(hipEventRecord(g_evB1, g_streamB));
         // ---- main queue: boundary conditions, messages out, same-GPU copies, messages in
         if (frontBCs()) return 1;
+        if (g_test_fault & 2) return fail("test_fault: the split evaluation fails behind its fork");
         bool remote = false;
         if (comm_exchange_begin(cp, g_tab[level], mask, nvar, &remote)) return 1;
         if (comm_exchange_end(cp, g_tab[level], mask, remote)) return 1;
@@ -3479,7 +3482,7 @@ int adflow_gpu_mg_cycle(const int32_t* cycling, int nSteps)
                 g_async = was;
                 hipGraph_t gr = nullptr;
                 const hipError_t e1 = hipStreamEndCapture(g_stream, &gr);
-                if (rc == 0 && e1 == hipSuccess && gr && hipGraphInstantiate(&g_mgg.exec, gr, nullptr, nullptr, 0) == hipSuccess) {
+                if (rc == 0 && e1 == hipSuccess && gr && !(g_test_fault & 1) && hipGraphInstantiate(&g_mgg.exec, gr, nullptr, nullptr, 0) == hipSuccess) {
                     g_mgg.graph = gr;
                     g_mgg.post = block_flags();
                     HIPCHK(hipGraphLaunch(g_mgg.exec, g_stream));
@@ -3864,6 +3867,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "split_eval")) { g_split_eval = value; return 0; }
     if (!strcmp(key, "bc_merge")) { g_bc_merge = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "front_overlap")) { g_front_overlap = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "test_fault")) { g_test_fault = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
     if (!strcmp(key, "gf_prefetch")) { g_gf_prefetch = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }

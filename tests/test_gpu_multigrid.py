@@ -120,3 +120,15 @@ def test_mg_cycle_irregular_with_bc(engine):
     wall = {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}
     checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 9, 5, 7), rans, [0, 1, 0, 1, 0, -1, 0, -1], ncycles=1, nlevels=3, bc_spec=wall,
                           bc_split={5: -6}, irregular=(4, 1), stretch_k=2.0)
+
+
+def test_mg_cycle_graph_capture_failure_falls_back(engine):
+    """round-4 verdict, weak 13: a hipGraph capture of the cycle that FAILS (tuning test_fault bit 0 makes the instantiation report
+    failure) must put the block flags back and run that cycle and every later one directly: four cycles against the reference"""
+    try:
+        engine.set_tuning("test_fault", 1)
+        checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 16, 8, 8), FlowParams(), [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1], ncycles=4, nlevels=3)
+    finally:
+        engine.set_tuning("test_fault", 0)
+    # and with the fault gone the graph path works again
+    checks.check_mg_cycle(engine, BrickTopology(2, 1, 1, 16, 8, 8), FlowParams(), [0, 1, 0, -1], ncycles=4)

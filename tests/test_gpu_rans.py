@@ -351,3 +351,38 @@ def test_front_overlap_shell_and_core(engine, overlap):
                                            stretch_k=2.0)
     finally:
         engine.set_tuning("front_overlap", 0)
+
+
+def test_split_evaluation_error_exit_joins_the_side_queue(engine):
+    """round-4 verdict, weak 13: an error behind the fork of the split evaluation (tuning test_fault bit 1) is reported and the side
+    queue joined: the very next evaluation -- split again -- is correct"""
+    from adflow_amd.topology import BrickTopology
+    spec = {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    topo = BrickTopology(2, 1, 1, 70, 9, 11, periodic=(False, False, False))
+    try:
+        engine.set_tuning("test_fault", 2)
+        with pytest.raises(Exception, match="test_fault"):
+            checks.check_blockette_res_with_bc(engine, topo, rans, spec, split_eval=2, stretch_k=2.0)
+    finally:
+        engine.set_tuning("test_fault", 0)
+        engine.set_tuning("split_eval", 1)
+    checks.check_blockette_res_with_bc(engine, topo, rans, spec, split_eval=2, stretch_k=2.0)
+
+
+def test_wall_bounded_brick_through_rccl_self_and_split(engine):
+    """round-4 verdict, next 8 (i): the product's own exchange on the wall-bounded 2 x 2 x 2 brick with every interface as an RCCL
+    message to the own rank (comm_self) and the evaluation split around it (the default when the pattern has messages): derived values,
+    boundary conditions on the main queue while the interior tiles of the SA and viscous marches run on the side queue, pack ->
+    ncclSend / ncclRecv -> unpack, the boundary tiles, the inviscid march; 64 x 48 x 32 and 128 x 64 x 32 blocks"""
+    from adflow_amd.topology import BrickTopology
+    prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    engine.comm_init_single()
+    try:
+        engine.set_tuning("comm_self", 1)
+        for dims, seed in (((64, 48, 32), 47), ((128, 64, 32), 53)):
+            n = checks.check_blockette_res_with_bc(engine, BrickTopology(2, 2, 2, *dims, periodic=(False, False, False)), prm, WALL_BRICK,
+                                                   seed=seed, stretch_k=2.0)
+            assert n == 4
+    finally:
+        engine.set_tuning("comm_self", 0)
