@@ -15,7 +15,8 @@
 
 #include "internal.h"
 
-extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_gf_prefetch;
+extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_gf_prefetch, g_gf_waves;
+int visc_gf_rows();
 int g_test_fault = 0;        // tuning "test_fault" (tests only): bit 0 = the hipGraph capture of a multigrid cycle reports failure, bit 1 = the
                              // split evaluation fails behind its fork -- the error paths must leave the library usable
 int g_front_overlap = 0;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions (off: measured no gain at N = 1, profiles/r05_e_ab.txt)
@@ -2104,7 +2105,7 @@ int ensure_tiles(int level)
 // R = produced cell rows per workgroup (3: k_visc_gf, 4: k_sa_march), warm = planes a chunk costs beyond its own, reach = cells the
 // stencil of a produced cell reaches (the interior / boundary partition); all / in / bd: the three tables
 static int build_chunk_tables(int level, int R, double warm, int reach, std::pair<int4*, int>* all, std::pair<int4*, int>* in_,
-                              std::pair<int4*, int>* bd_)
+                              std::pair<int4*, int>* bd_, int wgPerCU = 2)
 {
     if (ensure_table(level)) return 1;
     struct Col { int slot, bx, by, nz, nx, ny; };
@@ -2120,7 +2121,7 @@ static int build_chunk_tables(int level, int R, double warm, int reach, std::pai
     const int N = (int)cols.size();
     *all = *in_ = *bd_ = std::make_pair((int4*)nullptr, 0);
     if (N == 0) return 0;
-    const int W = adf_round_size();
+    const int W = adf_round_size() * wgPerCU / 2;       // resident workgroups of the kernel: wgPerCU per CU
     const int kmin = 8;
     // chunks of a column for a total of T chunks: proportional to its planes (largest remainder), at least 1, at most nz / kmin
     auto split = [&](long T, std::vector<int>& c) {
@@ -2230,7 +2231,7 @@ int ensure_gf_tiles(int level)
 {
     if (g_gf_tiles.count(level)) return 0;
     std::pair<int4*, int> a, i, b;
-    if (build_chunk_tables(level, 3, 1.5, 1, &a, &i, &b)) return 1;
+    if (build_chunk_tables(level, visc_gf_rows(), 1.5, 1, &a, &i, &b, visc_gf_rows() == 7 ? 1 : 2)) return 1;
     g_gf_tiles[level] = a; g_gf_tiles_int[level] = i; g_gf_tiles_bnd[level] = b;
     return 0;
 }
@@ -3870,6 +3871,17 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "test_fault")) { g_test_fault = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
     if (!strcmp(key, "gf_prefetch")) { g_gf_prefetch = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "gf_waves")) {
+        if (value != 4 && value != 8) return fail("gf_waves must be 4 or 8");
+        g_gf_waves = value;
+        if (g_stream) (void)hipStreamSynchronize(g_stream);
+        mg_graph_drop();
+        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd}) {
+            for (auto& kv : *mp) (void)hipFree(kv.second.first);
+            mp->clear();
+        }
+        return 0;
+    }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);

@@ -883,6 +883,11 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
 #define GF_G (12 * GF_NL)         // doubles of one node row of one plane
 #define GF_RING (3 * 4 * GF_G)
 #define GF_FJ (3 * GF_OUT * 4)    // doubles of one parity of the j-flux hand-over: rows 0..2, lanes 2..61, 4 components
+// NW waves per workgroup (template parameter; tuning "gf_waves"): 4 = the form above; 8 = ONE workgroup of eight waves per CU -- eight
+// node rows, SEVEN produced cell rows for nine loaded (1.29 instead of 1.67 rows of the gradient part's 17 arrays per produced row,
+// one idle face part in eight waves instead of one in four), the ring at two slots (93.7 KB + 26.9 KB of hand-over) and a second
+// barrier at the end of the step in exchange (the slot written in step m+1 was read in step m)
+#define GF_NSLOT(NW) ((NW) == 4 ? 3 : 2)
 
 struct GfPtrs {
     GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) p;
@@ -918,18 +923,20 @@ struct GfReq { double au, av, aw, ap, ar, alv, aev, avol, bu, bv, bw, bp, br, bl
 // PF (tuning "gf_prefetch"): ONE workgroup per CU -- one wavefront per SIMD with the whole 512-entry register file -- and the 37 values
 // of cell plane mm+1 requested at the top of step mm: the request that stood fully exposed in front of the gradient part (a third of
 // the wave cycles waiting, profiles/r04_fin_pmc_sq.txt) has a whole step to land.
-template <bool QCR, bool FIRST, bool STG, bool PF = false>
-__global__ __launch_bounds__(256, PF ? 1 : 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
+template <bool QCR, bool FIRST, bool STG, bool PF = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
-    __shared__ __attribute__((aligned(16))) double ring[GF_RING];   // [slot][node row 0..3 = rows j0-1 .. j0+2][component pair][lane-1][2]
-    __shared__ __attribute__((aligned(16))) double fjx[2 * GF_FJ];  // [parity][row][lane-2][component]
+    constexpr int NSLOT = GF_NSLOT(NW);
+    __shared__ __attribute__((aligned(16))) double ring[NSLOT * NW * GF_G];   // [slot][node row 0..NW-1 = rows j0-1 .. j0+NW-2][component pair][lane-1][2]
+    __shared__ __attribute__((aligned(16))) double fjx[2 * (NW - 1) * GF_OUT * 4];  // [parity][row][lane-2][component]
+    constexpr int FJ = (NW - 1) * GF_OUT * 4;
     const int4 tl = tiles[blockIdx.x];
     if (tl.x < 0) return;
     const BlkView& b = tab[tl.x];
     const int lane = threadIdx.x, r = threadIdx.y;
     const int bx = tl.y & 0xffff, by = tl.y >> 16;
     const int i = bx * GF_OUT + lane;             // cells i0-2 .. i0+61, i0 = 2 + 60 bx
-    const int j0 = 2 + by * GF_ROWS;              // first produced cell row
+    const int j0 = 2 + by * (NW - 1);             // first produced cell row
     const int k0 = tl.z, k1 = tl.w;               // planes of the chunk
     const int jn = j0 - 1 + r;                    // node row of the wave; waves 1..3: also its cell row
     const int ic = (i < b.ib) ? i : b.ib;
@@ -1108,7 +1115,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void k_visc_gf(const BlkView* __re
 #pragma unroll
             for (int q = 0; q < 12; ++q) g[q] *= oneOverV;
             if (ringLane) {
-                double* __restrict__ xo = ring + (((mm - k0) % 3) * 4 + r) * GF_G + nl * 2;     // node plane mm-1 -> slot (mm-k0) % 3
+                double* __restrict__ xo = ring + (((mm - k0) % NSLOT) * NW + r) * GF_G + nl * 2;     // node plane mm-1 -> slot (mm-k0) % NSLOT
 #pragma unroll
                 for (int q = 0; q < 12; q += 2) *reinterpret_cast<Dbl2*>(xo + q * GF_NL) = mk2(g[q], g[q + 1]);
             }
@@ -1121,12 +1128,12 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void k_visc_gf(const BlkView* __re
         face_loads();          // requested above the barrier (at the top of the step: no faster, profiles/r03_f)
         __syncthreads();
         if (facePlane) {
-            const double* __restrict__ xb = ring + (((mm - k0) % 3) * 4) * GF_G + nl * 2;            // node plane mm-1
-            const double* __restrict__ xp = ring + (((mm - k0 + 2) % 3) * 4) * GF_G + nl * 2;        // node plane mm-2
+            const double* __restrict__ xb = ring + (((mm - k0) % NSLOT) * NW) * GF_G + nl * 2;                    // node plane mm-1
+            const double* __restrict__ xp = ring + (((mm - k0 + NSLOT - 1) % NSLOT) * NW) * GF_G + nl * 2;        // node plane mm-2
             const int oM = (r >= 1 ? r - 1 : 0) * GF_G, o0 = r * GF_G;                                // node rows jn-1 and jn
             if (full && r >= 1 && mm - 2 >= k0) {
                 // cell plane mm-2: the j flux from the wave below has arrived (written in step mm-1)
-                finish(cF - sk, fjx + ((mm - 1) & 1) * GF_FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
+                finish(cF - sk, fjx + ((mm - 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
             }
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             if (full) {
@@ -1141,8 +1148,8 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void k_visc_gf(const BlkView* __re
                 vm_face<QCR>(K, gs, qA, qB, sJA, dJv, flg_porJ((uint8_t)flag0), f);
 #pragma unroll
                 for (int l = 0; l < 4; ++l) acc[l] = -f[l];
-                if (r < 3 && lane >= 2 && lane <= 61) {
-                    double* __restrict__ fo = fjx + (mm & 1) * GF_FJ + (r * GF_OUT + fl) * 4;
+                if (r < NW - 1 && lane >= 2 && lane <= 61) {
+                    double* __restrict__ fo = fjx + (mm & 1) * FJ + (r * GF_OUT + fl) * 4;
                     *reinterpret_cast<Dbl2*>(fo) = mk2(f[0], f[1]);
                     *reinterpret_cast<Dbl2*>(fo + 2) = mk2(f[2], f[3]);
                 }
@@ -1187,10 +1194,11 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void k_visc_gf(const BlkView* __re
         }
         cA += sk;
         if (PF) cur = nxt;
+        if (NSLOT == 2) __syncthreads();       // the slot the next step writes was read in this one
     }
     // ---- the last plane of the chunk: its j flux was handed over in the last step
     __syncthreads();
-    if (r >= 1 && k1 >= k0) finish(cA - 2 * sk, fjx + ((k1 + 1) & 1) * GF_FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
+    if (r >= 1 && k1 >= k0) finish(cA - 2 * sk, fjx + ((k1 + 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
 }
 
 #endif
@@ -1304,10 +1312,25 @@ void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles,
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
 int g_gf_prefetch = 0;      // tuning "gf_prefetch": k_visc_gf<.., PF>: one workgroup per CU, cell plane mm+1 requested a step ahead
+int g_gf_waves = 4;         // tuning "gf_waves": 8 = eight waves per workgroup, seven produced rows (the chunk tables follow: api.hip)
+int visc_gf_rows() { return g_gf_waves == 8 ? 7 : 3; }
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)
 {
     if (ntiles <= 0) return;
     const dim3 grd(ntiles), blk(64, 4, 1);
+    if (g_gf_waves == 8) {
+        const dim3 blk8(64, 8, 1);
+#define GF_LAUNCH8(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G, false, 8>), grd, blk8, 0, s, tab, tiles, kp)
+        if (kp.useQCR) {
+            if (kp.viscFirst) { if (storeGrad) GF_LAUNCH8(true, true, true); else GF_LAUNCH8(true, true, false); }
+            else { if (storeGrad) GF_LAUNCH8(true, false, true); else GF_LAUNCH8(true, false, false); }
+        } else {
+            if (kp.viscFirst) { if (storeGrad) GF_LAUNCH8(false, true, true); else GF_LAUNCH8(false, true, false); }
+            else { if (storeGrad) GF_LAUNCH8(false, false, true); else GF_LAUNCH8(false, false, false); }
+        }
+#undef GF_LAUNCH8
+        return;
+    }
     if (g_gf_prefetch && !storeGrad && kp.viscFirst) {
         if (kp.useQCR) hipLaunchKernelGGL((k_visc_gf<true, true, false, true>), grd, blk, 0, s, tab, tiles, kp);
         else hipLaunchKernelGGL((k_visc_gf<false, true, false, true>), grd, blk, 0, s, tab, tiles, kp);

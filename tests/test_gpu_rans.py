@@ -386,3 +386,19 @@ def test_wall_bounded_brick_through_rccl_self_and_split(engine):
             assert n == 4
     finally:
         engine.set_tuning("comm_self", 0)
+
+
+def test_visc_gf_eight_waves(engine):
+    """tuning gf_waves = 8: k_visc_gf<.., NW = 8>, one workgroup of eight waves per CU, seven produced rows per nine loaded, two ring slots
+    and two barriers per plane: the cases of test_visc_gradient_fused (partial tiles in i / j / k, QCR, persistent fw, stored
+    gradients, chunk tables of small devices), the split evaluation and a wall-bounded brick"""
+    from adflow_amd.topology import BrickTopology
+    try:
+        engine.set_tuning("gf_waves", 8)
+        test_visc_gradient_fused(engine)
+        engine.set_tuning("gf_waves", 8)
+        rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+        checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 2, 70, 19, 11, periodic=(False, False, False)), rans,
+                                           {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}, split_eval=2, stretch_k=2.0)
+    finally:
+        engine.set_tuning("gf_waves", 4)

@@ -455,6 +455,19 @@ def test_visc_gradient_fused(hostsim_engine):
     test_gpu_rans.test_visc_gradient_fused(hostsim_engine)
 
 
+def test_visc_gf_eight_waves(hostsim_engine):
+    e = hostsim_engine
+    try:
+        e.set_tuning("gf_waves", 8)
+        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
+        checks.check_block_res(e, (63, 9, 7), prm, seed=5, stretch_k=2.0, holes=0.05)
+        checks.check_block_res(e, (9, 16, 5), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
+        checks.check_rk_residual_sequence(e, (6, 8, 5), FlowParams(equations=NSEquations, muSuthDim=1.0), stretch_k=2.0)
+        checks.check_wall_stress(e, (9, 8, 7), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -3, 4: -4, 5: -3, 6: -6}, stretch_k=2.0)
+    finally:
+        e.set_tuning("gf_waves", 4)
+
+
 def test_multiblock_brick_block_res(hostsim_engine):
     from adflow_amd.topology import BrickTopology
     prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
