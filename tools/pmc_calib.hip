@@ -82,6 +82,103 @@ __global__ void probe(const double* __restrict__ x, double* __restrict__ rc, dou
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+
+// "streams": the access shape of the fused viscous march without its arithmetic -- workgroups of four waves, 80 KB of LDS each (two per
+// CU), wave r reads the rows j0-1+r and j0+r of NA arrays per plane (8 bytes per lane, 64 lanes = one 512-byte piece per array and
+// row), one wait per plane, 18 planes per chunk -- over two layouts of the SAME bytes:
+//   layout 0: structure of arrays, component stride = the whole box (what the library holds: 12.6 MB between the pieces of a row)
+//   layout 1: row-blocked, component stride = one row (the NA pieces of a row are contiguous: NA x 1408 bytes)
+// Says whether the 4.1 TB/s the marches draw is the memory system's answer to forty scattered 512-byte streams per tile.
+template <int NA, int NF, int NS>
+__global__ __launch_bounds__(256, 2) void streams(const double* __restrict__ base, double* __restrict__ out, int layout, long nbox, int ldi, long ldk,
+                                                  int ntx, int nty, int nch, int planes, double* __restrict__ wr)
+{
+    __shared__ double pad[10000];                       // 80 KB: two workgroups per CU, as k_visc_gf
+    const int lane = threadIdx.x, r = threadIdx.y;
+    int t = blockIdx.x;
+    const int bx = t % ntx; t /= ntx;
+    const int by = t % nty; t /= nty;
+    const int ch = t % nch; const int blk = t / nch;
+    const int i = bx * 60 + lane, j = by * 3 + r + 1, k0 = ch * planes + 1;
+    const long cstride = layout == 0 ? nbox : (long)ldi;                 // doubles between components
+    const long rowA = layout == 0 ? (long)j * ldi : (long)j * ldi * (NA + NF);
+    const long rowB = layout == 0 ? (long)(j + 1) * ldi : (long)(j + 1) * ldi * (NA + NF);
+    const long kst = layout == 0 ? ldk : ldk * (NA + NF);
+    const double* b = base + (long)blk * nbox * (NA + NF);
+    double acc = 0.0;
+    for (int k = k0; k < k0 + planes + 2; ++k) {
+        double v[2 * NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            v[2 * a] = b[(long)k * kst + rowA + a * cstride + i];
+            v[2 * a + 1] = b[(long)k * kst + rowB + a * cstride + i];
+        }
+#pragma unroll
+        for (int a = 0; a < 2 * NA; ++a) acc += v[a];
+        // the face part: NF more arrays of the own row at plane k-1 (behind the gradient arrays in the buffer), six re-reads of gradient
+        // arrays of that plane (L2), NS stores
+        double f[NF + 6];
+#pragma unroll
+        for (int a = 0; a < NF; ++a) f[a] = b[(long)(k - 1) * kst + rowA + (NA + a) * cstride + i];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) f[NF + a] = b[(long)(k - 1) * kst + rowA + a * cstride + i];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < NF + 6; ++a) acc += f[a];
+        if (NS > 0 && r >= 1 && lane >= 2 && lane < 62) {
+#pragma unroll
+            for (int a = 0; a < NS; ++a) wr[(long)blk * nbox * NS + (long)k * ldk + (long)j * ldi + a * nbox + i] = acc;
+        }
+    }
+    if (acc == 123.456) { pad[lane] = acc; out[lane] = pad[lane ^ 1]; }
+}
+
+// the same with the gradient part's loads requested ONE PLANE AHEAD (registers are free here): what a prefetching form of the march
+// could reach at the same occupancy
+template <int NA, int NF, int NS>
+__global__ __launch_bounds__(256, 2) void streams_pf(const double* __restrict__ base, double* __restrict__ out, int layout, long nbox, int ldi, long ldk,
+                                                     int ntx, int nty, int nch, int planes, double* __restrict__ wr)
+{
+    __shared__ double pad[10000];
+    const int lane = threadIdx.x, r = threadIdx.y;
+    int t = blockIdx.x;
+    const int bx = t % ntx; t /= ntx;
+    const int by = t % nty; t /= nty;
+    const int ch = t % nch; const int blk = t / nch;
+    const int i = bx * 60 + lane, j = by * 3 + r + 1, k0 = ch * planes + 1;
+    const long cstride = layout == 0 ? nbox : (long)ldi;
+    const long rowA = layout == 0 ? (long)j * ldi : (long)j * ldi * (NA + NF);
+    const long rowB = layout == 0 ? (long)(j + 1) * ldi : (long)(j + 1) * ldi * (NA + NF);
+    const long kst = layout == 0 ? ldk : ldk * (NA + NF);
+    const double* b = base + (long)blk * nbox * (NA + NF);
+    double acc = 0.0;
+    double v[2 * NA], w[2 * NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { v[2 * a] = b[(long)k0 * kst + rowA + a * cstride + i]; v[2 * a + 1] = b[(long)k0 * kst + rowB + a * cstride + i]; }
+    for (int k = k0; k < k0 + planes + 2; ++k) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { w[2 * a] = b[(long)(k + 1) * kst + rowA + a * cstride + i]; w[2 * a + 1] = b[(long)(k + 1) * kst + rowB + a * cstride + i]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 2 * NA; ++a) acc += v[a];
+        double f[NF + 6];
+#pragma unroll
+        for (int a = 0; a < NF; ++a) f[a] = b[(long)(k - 1) * kst + rowA + (NA + a) * cstride + i];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) f[NF + a] = b[(long)(k - 1) * kst + rowA + a * cstride + i];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < NF + 6; ++a) acc += f[a];
+        if (NS > 0 && r >= 1 && lane >= 2 && lane < 62) {
+#pragma unroll
+            for (int a = 0; a < NS; ++a) wr[(long)blk * nbox * NS + (long)k * ldk + (long)j * ldi + a * nbox + i] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < 2 * NA; ++a) v[a] = w[a];
+    }
+    if (acc == 123.456) { pad[lane] = acc; out[lane] = pad[lane ^ 1]; }
+}
+
 int main(int argc, char** argv)
 {
     const char* mode = argc > 1 ? argv[1] : "all";
@@ -188,6 +285,41 @@ int main(int argc, char** argv)
             const double per_simd = wave_insts / (ms / 3.0 * 1e-3) / (prop.multiProcessorCount * 4.0);
             printf(", \"fma64_wave_insts_per_s_per_simd\": %.4e, \"issue_clock_ghz_at_4_cycles\": %.3f}\n", per_simd, per_simd * 4.0 / 1e9);
         }
+    }
+    if (!strcmp(mode, "streams")) {
+        // 8 blocks of 160x128x64 cells (box 176 x 132 x 68), tiles of 60 columns x 3 rows, chunks of 16 planes
+        const int ldi = 176, nj = 132, nk = 68, nblk = 8, ntx = 3, nty = 43, planes = 16, nch = 4;
+        const long ldk = (long)ldi * nj, nbox = ldk * nk;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        double *buf, *o;
+        const int NAmax = 27;
+        double* wr;
+        CK(hipMalloc(&buf, (size_t)nbox * NAmax * nblk * 8 + (1 << 20))); CK(hipMalloc(&o, 4096));
+        CK(hipMalloc(&wr, (size_t)nbox * 4 * nblk * 8 + (1 << 20)));
+        CK(hipMemset(buf, 0, (size_t)nbox * NAmax * nblk * 8));
+        printf("{\"what\": \"4-wave workgroups, 2 per CU, two rows x NA arrays x 512 B per wave and plane, no arithmetic\"");
+        for (int layout = 0; layout < 2; ++layout) {
+            const int reps = 20;
+            for (int it = -2; it < reps; ++it) {
+                if (it == 0) CK(hipEventRecord(e0, 0));
+                if (argc > 2 && !strcmp(argv[2], "grad"))
+                    hipLaunchKernelGGL((streams<17, 0, 0>), dim3(ntx * nty * nch * nblk), dim3(64, 4), 0, 0, buf, o, layout, nbox * 27 / 17 * 0 + nbox, ldi, ldk, ntx, nty, nch, planes, wr);
+                else if (argc > 2 && !strcmp(argv[2], "pf"))
+                    hipLaunchKernelGGL((streams_pf<17, 10, 4>), dim3(ntx * nty * nch * nblk), dim3(64, 4), 0, 0, buf, o, layout, nbox, ldi, ldk, ntx, nty, nch, planes, wr);
+                else
+                    hipLaunchKernelGGL((streams<17, 10, 4>), dim3(ntx * nty * nch * nblk), dim3(64, 4), 0, 0, buf, o, layout, nbox, ldi, ldk, ntx, nty, nch, planes, wr);
+            }
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            // bytes requested by the waves (rows shared by the waves of a workgroup counted once: 5 rows per tile and plane)
+            const double req = (double)ntx * nty * nch * nblk * (planes + 2) * 5.0 * 17 * 512.0;
+            printf(", \"layout%d_ms\": %.4f, \"layout%d_distinct_gbs\": %.0f", layout, ms / reps, layout, req / (ms / reps * 1e-3) / 1e9);
+        }
+        printf("}\n");
+        CK(hipFree(buf)); CK(hipFree(o));
     }
     if (!strcmp(mode, "probe") || !strcmp(mode, "all")) {
         const size_t n = 1 << 22;
