@@ -560,10 +560,20 @@ def test_fd_jacobian_exact(hostsim_engine):
 
 def test_ad_jacobian(hostsim_engine):
     """forward-mode assembly: the dual-number twins of the gather kernels (kernels_ad.hip) against the reference's Tapenade routines"""
+    # (the cases of tests/test_gpu_jacobian.py::test_ad_* on smaller blocks: most of the time here is the reference's own forward mode)
     import test_gpu_jacobian as tj
-    tj.test_ad_pc(hostsim_engine, upwind)
-    tj.test_ad_exact_drdw(hostsim_engine, dissScalar)
-    tj.test_ad_variants(hostsim_engine)
+    from adflow_amd.params import vanAlbeda, minmod, secondOrder
+    e = hostsim_engine
+    checks.check_ad_jacobian(e, (8, 6, 5), FlowParams(spaceDiscr=upwind, limiter=vanAlbeda), tj.EULER)
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda, orderTurb=secondOrder, acousticScaleFactor=0.5)
+    checks.check_ad_jacobian(e, (8, 6, 5), rans, tj.WALL, stretch_k=2.0)
+    checks.check_ad_jacobian(e, (6, 5, 4), FlowParams(spaceDiscr=dissScalar, limiter=vanAlbeda), tj.FAR, usePC=False)
+    checks.check_ad_jacobian(e, (6, 5, 4), rans.replace(spaceDiscr=dissScalar), tj.WALL, usePC=False, stretch_k=2.0)
+    rm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=minmod)
+    checks.check_ad_jacobian(e, (7, 5, 4), rm, tj.WALL, frozenTurb=True, stretch_k=2.0)
+    checks.check_ad_jacobian(e, (7, 5, 4), rm, tj.WALL, useTurbOnly=True, stretch_k=2.0)
+    checks.check_ad_jacobian(e, (6, 5, 4), rm.replace(spaceDiscr=dissScalar), tj.WALL, viscPC=True, stretch_k=2.0)
+    checks.check_ad_jacobian(e, (7, 6, 5), rm.replace(limiter=vanAlbeda, useQCR=True), tj.OPEN, usePC=False, stretch_k=2.0)
 
 
 def test_update_wall_distances_quickly(hostsim_engine):
