@@ -304,6 +304,12 @@ class Engine:
         self._chk(self.lib.adflow_gpu_comm_init(0, 1, raw))
         self._comm_ready = True
 
+    def comm_info(self):
+        """(rank, nranks as given to adflow_gpu_comm_init; ncclCommCount, ncclCommUserRank as the communicator reports them, -1 before)"""
+        v = [ctypes.c_int() for _ in range(4)]
+        self._chk(self.lib.adflow_gpu_comm_info(*[ctypes.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
+
     def whalo1(self, level, start, end, commPressure=True, commGamma=True, commViscous=True):
         self._chk(self.lib.adflow_gpu_halo_exchange(level, start, end, int(commPressure), int(commViscous), 1))
 

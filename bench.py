@@ -272,6 +272,8 @@ def cpu_baseline(equations, spaceDiscr, seconds=8.0, max_cores=None, dims=(64, 6
     out = {"value": sum(main) / 1e6, "unit": "Mcells*residual-evals/s", "cores": len(main), "kind": "reference",
            "host_logical_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": avail, "host": topo,
            "placement": "one pinned process per physical core, cores taken round-robin over the NUMA nodes, SMT siblings last",
+           # `cores` = pinned processes; under a cgroup quota they share that many CPUs' worth of time
+           "effective_cpus": min(len(main), topo["cgroup_quota_cpus"]) if topo.get("cgroup_quota_cpus") else len(main),
            "sample": f"{len(main)} pinned processes x one {dims[0]}x{dims[1]}x{dims[2]} block each ({what}), ~{seconds:.0f} s of "
                      "blocketteResCore evaluations (blockette.F90:299-753, the default residual path; updateIntermed=F) of the reference "
                      "Fortran (amdflang -O3 -fdefault-real-8); no MPI halo exchange",

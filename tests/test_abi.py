@@ -93,3 +93,11 @@ def test_shim_hands_no_aliased_arrays_to_coarse_levels():
         m = re.search(r"if \(level == 1\) then(.*?)end if", blk, flags=re.S)
         assert m
     assert "sps = 1" in open(os.path.join(ROOT, "adflow_amd", "csrc", "api.hip")).read()
+
+
+def test_comm_info_without_a_communicator():
+    """adflow_gpu_comm_info before adflow_gpu_comm_init: rank 0 of 1, no communicator (-1, -1); needs no GPU"""
+    lib = capi.load()
+    v = [ctypes.c_int(7) for _ in range(4)]
+    assert lib.adflow_gpu_comm_info(*[ctypes.byref(x) for x in v]) == 0
+    assert [x.value for x in v] == [0, 1, -1, -1]

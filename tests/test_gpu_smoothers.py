@@ -31,6 +31,7 @@ def test_halo_exchange_rccl_self_loopback(engine, nLayers):
     haloExchange.F90:553-719) EXECUTED on one GPU: tuning comm_self routes every same-process interface through a message to
     the own rank.  Compared with the reference's whalo1 / whalo2, then one RK sweep with the exchange between the stages."""
     engine.comm_init_single()
+    assert engine.comm_info() == (0, 1, 1, 0)      # what the RCCL communicator itself reports: one rank, this one
     try:
         engine.set_tuning("comm_self", 1)
         checks.check_halo_exchange(engine, BrickTopology(2, 2, 2, 8, 6, 5), FlowParams(equations=RANSEquations), nLayers)
