@@ -89,21 +89,26 @@ __global__ void probe(const double* __restrict__ x, double* __restrict__ rc, dou
 //   layout 0: structure of arrays, component stride = the whole box (what the library holds: 12.6 MB between the pieces of a row)
 //   layout 1: row-blocked, component stride = one row (the NA pieces of a row are contiguous: NA x 1408 bytes)
 // Says whether the 4.1 TB/s the marches draw is the memory system's answer to forty scattered 512-byte streams per tile.
-template <int NA, int NF, int NS>
+template <int NA, int NF, int NS, bool OWN = false>
 __global__ __launch_bounds__(256, 2) void streams(const double* __restrict__ base, double* __restrict__ out, int layout, long nbox, int ldi, long ldk,
                                                   int ntx, int nty, int nch, int planes, double* __restrict__ wr)
 {
     __shared__ double pad[10000];                       // 80 KB: two workgroups per CU, as k_visc_gf
     const int lane = threadIdx.x, r = threadIdx.y;
     int t = blockIdx.x;
+    if (layout >= 2) {      // the library's launch order: within every round of 512 resident workgroups XCD x (= blockIdx % 8) takes the
+        const int q = t / 512, pr = t % 512;      // x-th contiguous 64 of the round's tiles (j-neighbours, which share rows, on one L2)
+        t = q * 512 + (pr % 8) * 64 + pr / 8;
+        if (t >= (int)gridDim.x) return;
+    }
     const int bx = t % ntx; t /= ntx;
     const int by = t % nty; t /= nty;
     const int ch = t % nch; const int blk = t / nch;
     const int i = bx * 60 + lane, j = by * 3 + r + 1, k0 = ch * planes + 1;
-    const long cstride = layout == 0 ? nbox : (long)ldi;                 // doubles between components
-    const long rowA = layout == 0 ? (long)j * ldi : (long)j * ldi * (NA + NF);
-    const long rowB = layout == 0 ? (long)(j + 1) * ldi : (long)(j + 1) * ldi * (NA + NF);
-    const long kst = layout == 0 ? ldk : ldk * (NA + NF);
+    const long cstride = (layout & 1) == 0 ? nbox : (long)ldi;                 // doubles between components
+    const long rowA = (layout & 1) == 0 ? (long)j * ldi : (long)j * ldi * (NA + NF);
+    const long rowB = (layout & 1) == 0 ? (long)(j + 1) * ldi : (long)(j + 1) * ldi * (NA + NF);
+    const long kst = (layout & 1) == 0 ? ldk : ldk * (NA + NF);
     const double* b = base + (long)blk * nbox * (NA + NF);
     double acc = 0.0;
     for (int k = k0; k < k0 + planes + 2; ++k) {
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void streams(const double* __restrict__ bas
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             v[2 * a] = b[(long)k * kst + rowA + a * cstride + i];
-            v[2 * a + 1] = b[(long)k * kst + rowB + a * cstride + i];
+            v[2 * a + 1] = (!OWN || r == 3) ? b[(long)k * kst + rowB + a * cstride + i] : 0.0;   // OWN: the row above through LDS (not modelled)
         }
 #pragma unroll
         for (int a = 0; a < 2 * NA; ++a) acc += v[a];
@@ -142,14 +147,19 @@ __global__ __launch_bounds__(256, 2) void streams_pf(const double* __restrict__ 
     __shared__ double pad[10000];
     const int lane = threadIdx.x, r = threadIdx.y;
     int t = blockIdx.x;
+    if (layout >= 2) {      // the library's launch order: within every round of 512 resident workgroups XCD x (= blockIdx % 8) takes the
+        const int q = t / 512, pr = t % 512;      // x-th contiguous 64 of the round's tiles (j-neighbours, which share rows, on one L2)
+        t = q * 512 + (pr % 8) * 64 + pr / 8;
+        if (t >= (int)gridDim.x) return;
+    }
     const int bx = t % ntx; t /= ntx;
     const int by = t % nty; t /= nty;
     const int ch = t % nch; const int blk = t / nch;
     const int i = bx * 60 + lane, j = by * 3 + r + 1, k0 = ch * planes + 1;
-    const long cstride = layout == 0 ? nbox : (long)ldi;
-    const long rowA = layout == 0 ? (long)j * ldi : (long)j * ldi * (NA + NF);
-    const long rowB = layout == 0 ? (long)(j + 1) * ldi : (long)(j + 1) * ldi * (NA + NF);
-    const long kst = layout == 0 ? ldk : ldk * (NA + NF);
+    const long cstride = (layout & 1) == 0 ? nbox : (long)ldi;
+    const long rowA = (layout & 1) == 0 ? (long)j * ldi : (long)j * ldi * (NA + NF);
+    const long rowB = (layout & 1) == 0 ? (long)(j + 1) * ldi : (long)(j + 1) * ldi * (NA + NF);
+    const long kst = (layout & 1) == 0 ? ldk : ldk * (NA + NF);
     const double* b = base + (long)blk * nbox * (NA + NF);
     double acc = 0.0;
     double v[2 * NA], w[2 * NA];
@@ -299,12 +309,14 @@ int main(int argc, char** argv)
         CK(hipMalloc(&wr, (size_t)nbox * 4 * nblk * 8 + (1 << 20)));
         CK(hipMemset(buf, 0, (size_t)nbox * NAmax * nblk * 8));
         printf("{\"what\": \"4-wave workgroups, 2 per CU, two rows x NA arrays x 512 B per wave and plane, no arithmetic\"");
-        for (int layout = 0; layout < 2; ++layout) {
+        for (int layout = 0; layout < 4; ++layout) {      // 0 / 1: SoA / row-blocked in launch order; 2 / 3: the same in the XCD-aware order
             const int reps = 20;
             for (int it = -2; it < reps; ++it) {
                 if (it == 0) CK(hipEventRecord(e0, 0));
                 if (argc > 2 && !strcmp(argv[2], "grad"))
                     hipLaunchKernelGGL((streams<17, 0, 0>), dim3(ntx * nty * nch * nblk), dim3(64, 4), 0, 0, buf, o, layout, nbox * 27 / 17 * 0 + nbox, ldi, ldk, ntx, nty, nch, planes, wr);
+                else if (argc > 2 && !strcmp(argv[2], "own"))
+                    hipLaunchKernelGGL((streams<17, 10, 4, true>), dim3(ntx * nty * nch * nblk), dim3(64, 4), 0, 0, buf, o, layout, nbox, ldi, ldk, ntx, nty, nch, planes, wr);
                 else if (argc > 2 && !strcmp(argv[2], "pf"))
                     hipLaunchKernelGGL((streams_pf<17, 10, 4>), dim3(ntx * nty * nch * nblk), dim3(64, 4), 0, 0, buf, o, layout, nbox, ldi, ldk, ntx, nty, nch, planes, wr);
                 else
