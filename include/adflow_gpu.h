@@ -427,7 +427,10 @@ int adflow_gpu_abi_sizes2(int* bc_subface_bytes, int* comm_pattern_bytes);
  * residual (resetFDReference).  level must be the ground level.
  *   ADFLOW_JAC_USE_AD      useAD = T (adjointUtils.F90:227-409): every column from ONE forward-mode evaluation (seed 1 on the state
  *                          variable of the colour's cells, masterRoutines::block_res_state_d) instead of a finite difference: the
- *                          exact derivative, `delta` is not used.  Dual-number twins of the gather kernels (csrc/kernels_ad.hip)
+ *                          exact derivative, `delta` is not used.  Dual-number twins of the gather kernels (csrc/kernels_ad.hip).
+ *                          The dual copies of the level's arrays (about 1 KB per box cell) are one slab that is KEPT between calls
+ *                          and freed with the blocks (adflow_gpu_block_release / _release_all) or by tuning "ad_cache" = 0; the call
+ *                          fails with a message when the device has not that much memory free.
  */
 enum { ADFLOW_JAC_PC = 1u, ADFLOW_JAC_FROZEN_TURB = 2u, ADFLOW_JAC_TURB_ONLY = 4u, ADFLOW_JAC_VISC_PC = 8u, ADFLOW_JAC_USE_AD = 16u };
 int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta);
