@@ -813,7 +813,7 @@ def setup_brick(engine, topo, prm, seed=1, **mk):
     return blocks, rblocks
 
 
-def assert_state(engine, blocks, rblocks, prm, what, tol=TOL, level=1, rlv_first_halo_only=False, rlv_no_edges=False):
+def assert_state(engine, blocks, rblocks, prm, what, tol=TOL, level=1, rlv_first_halo_only=False, rlv_no_edges=False, nonfinite_ok=False):
     """rlv_no_edges: leave the halo EDGES and corners of rlv out (cells outside the owned range in two or more directions): with
     several blocks AND boundary subfaces the reference's coarse levels -- whose rlv pointer aliases the FINE array (utils.F90:3420) --
     exchange / extrapolate into such cells of the fine array; no stencil of an owned cell reads rlv there (the viscous flux averages
@@ -829,6 +829,12 @@ def assert_state(engine, blocks, rblocks, prm, what, tol=TOL, level=1, rlv_first
                 a, r = np.where(edge, 0.0, a), np.where(edge, 0.0, r)
             if n == "rlv" and rlv_first_halo_only:
                 a, r = a[1:-1, 1:-1, 1:-1], r[1:-1, 1:-1, 1:-1]
+            if nonfinite_ok and not (np.isfinite(a).all() and np.isfinite(r).all()):
+                # (random sweeps: inf / NaN that the REFERENCE produces too, e.g. in halo corners of degenerate boundary sets: the same
+                # cells must be non-finite on both sides, the others are compared)
+                assert np.array_equal(np.isfinite(a), np.isfinite(r)), (what, nn, n, "non-finite pattern")
+                fin = np.isfinite(r)
+                a, r = np.where(fin, a, 0.0), np.where(fin, r, 0.0)
             if n == "w":
                 for l in range(b.nw):
                     e = rel_err(a[..., l], r[..., l])
@@ -1119,7 +1125,7 @@ def check_mg_transfer(engine, topo, prm, seed=11, irregular=None, **mk):
 
 
 def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, nlevels=2, bc_spec=None, bc_split=None, irregular=None,
-                   brick_spec=None, **mk):
+                   brick_spec=None, allow_degenerate=False, **mk):
     """executeMGCycle (multiGrid.F90:825-955) for a given cycling strategy.
     irregular: (half-weight cells at block ends, in the interior) the coarsening must produce (count_half_weight_cells)."""
     from oracle import ref
@@ -1144,9 +1150,13 @@ def check_mg_cycle(engine, topo, prm, cycling, ncycles=2, seed=13, nlevels=2, bc
         # value into 2nd-halo EDGE cells before the wall/farfield pass repairs its source.  No stencil of an owned
         # cell reads those cells; every level owns its rlv here, so they are left out of the comparison.
         assert_state(engine, fine, rfine, prm, f"MG cycle {n}", level=1, rlv_first_halo_only=bool(bc_spec or brick_spec),
-                     rlv_no_edges=bool(brick_spec))
+                     rlv_no_edges=bool(brick_spec), nonfinite_ok=allow_degenerate)
         for nn, b in fine.items():
             dw = engine.download_residual(nn, 1)
+            if allow_degenerate and not np.isfinite(owned(b, rfine[nn]["dw"])).all():
+                # (random sweeps: a cycle on a tiny coarse level can make the REFERENCE produce NaN; then only the pattern is compared)
+                assert np.array_equal(np.isfinite(owned(b, dw)), np.isfinite(owned(b, rfine[nn]["dw"])))
+                return
             assert_dw(b, dw, rfine[nn]["dw"], 5, what=f"residual after cycle {n}")
 
 

@@ -65,8 +65,9 @@ def draw_case(rng, huge=False):
         mk["holes"] = 0.05
     if rng.random() < 0.15:
         mk["left_handed"] = True
-    entry = str(rng.choice(["block_res", "blockette", "blockette_intermed", "approx", "bc", "rk", "dadi", "sa_solve", "nk", "full_bc", "ad"],
-                           p=[0.22, 0.08, 0.08, 0.08, 0.12, 0.08, 0.08, 0.06, 0.06, 0.09, 0.05]))
+    entry = str(rng.choice(["block_res", "blockette", "blockette_intermed", "approx", "bc", "rk", "dadi", "sa_solve", "nk", "full_bc", "ad",
+                            "mg", "lattice"],
+                           p=[0.18, 0.07, 0.07, 0.07, 0.11, 0.07, 0.07, 0.05, 0.05, 0.09, 0.05, 0.07, 0.05]))
     if huge:
         entry = str(rng.choice(["block_res", "blockette", "blockette_intermed"]))
     if entry == "bc":
@@ -97,6 +98,27 @@ def draw_case(rng, huge=False):
         nx, ny, nz = int(rng.integers(3, 9)), int(rng.integers(3, 7)), int(rng.integers(3, 6))
         if eq != EulerEquations:
             mk["stretch_k"] = 2.0
+    if entry == "mg":
+        # round 5: multigrid cycles on blocks of ANY cell count (odd counts coarsen irregularly: half-weight cells), 2 or 3 levels,
+        # periodic bricks or one block with six boundary subfaces of which some are cut in two (the cut survives the coarsening)
+        nlev = int(rng.integers(2, 4))
+        lo = 4 if nlev == 2 else 8
+        dims3 = (int(rng.integers(lo, 22)), int(rng.integers(lo, 16)), int(rng.integers(lo, 12)))
+        withbc = bool(rng.random() < 0.5)
+        kinds = [-1, -5, -6] if eq == EulerEquations else [-1, -6]      # (viscous: the wall is put on kMin below, where d2Wall points)
+        mk = dict(seed=mk["seed"], nlev=nlev, dims3=dims3, nb=(1 if withbc else int(rng.integers(1, 3))),
+                  spec=({f: int(rng.choice(kinds)) for f in range(1, 7)} if withbc else None),
+                  split=({int(rng.choice([3, 5])): int(rng.choice(kinds))} if withbc and rng.random() < 0.5 else None),
+                  dadi=bool(rng.random() < 0.4))
+        kw["resAveraging"] = int(rng.choice([noResAveraging, alternateResAveraging]))
+        if eq != EulerEquations:
+            mk["stretch_k"] = 2.0
+    if entry == "lattice":
+        # round 5: the four-block mesh with rotated / reversed / left-handed index systems, one consumer of the lists at random
+        mk = dict(seed=mk["seed"], what=str(rng.choice(["whalo", "loopback", "coor", "res_bc", "rk", "dadi", "mg_bc", "nk"])),
+                  scale=1, layers=int(rng.integers(1, 3)), split_eval=(2 if rng.random() < 0.5 else None))
+        if eq != EulerEquations:
+            mk["stretch_z"] = 2.0
     if entry in ("rk", "dadi", "sa_solve", "nk"):
         # periodic bricks of 1 - 2 blocks; even cell counts are not needed on a single grid.  One case in four with i lines of more
         # than one wavefront (the cyclic-reduction kernels of round 4)
@@ -130,6 +152,43 @@ def run_case(engine, dims, kw, mk, entry):
                                            allow_degenerate=mk.get("floor_p", False), **mk)
     elif entry == "ad":
         checks.check_ad_jacobian(engine, dims, prm, mk.pop("spec"), usePC=mk.pop("usePC"), frozenTurb=mk.pop("frozenTurb"), seed=seed, **mk)
+    elif entry == "mg":
+        nlev, d3 = mk.pop("nlev"), mk.pop("dims3")
+        cyc = [0, 1, 0, -1] if nlev == 2 else [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1]
+        p2 = prm.replace(smoother=DADI, cfl=1.5, resAveraging=noResAveraging) if mk.pop("dadi") else prm.replace(smoother=RungeKutta)
+        if p2.equations == RANSEquations:
+            p2 = p2.replace(smoother=DADI, cfl=1.5, resAveraging=noResAveraging, nSubiterations=2, nSubIterTurb=2)
+        spec, split, nb = mk.pop("spec"), mk.pop("split"), mk.pop("nb")
+        if spec and p2.equations != EulerEquations:
+            spec[5] = -3
+            if split and 5 in split:
+                split = {3: split[5]}
+        checks.check_mg_cycle(engine, BrickTopology(nb, 1, 1, *d3), p2, cyc, ncycles=1, nlevels=nlev, bc_spec=spec, bc_split=split, seed=seed,
+                              allow_degenerate=True, **mk)
+    elif entry == "lattice":
+        from adflow_amd.topology import ell_topology
+        what, layers, se = mk.pop("what"), mk.pop("layers"), mk.pop("split_eval")
+        topo = ell_topology(mk.pop("scale"), stretch_z=mk.pop("stretch_z", 1.0))
+        walls = {1: -6, 2: -6, 3: -1, 4: -6, 5: (-3 if prm.equations != EulerEquations else -5), 6: -6}
+        if what == "whalo":
+            checks.check_halo_exchange(engine, topo, prm, layers, seed=seed)
+        elif what == "loopback":
+            checks.check_halo_loopback(engine, topo, int(2 + seed % 3), prm, layers, seed=seed)
+        elif what == "coor":
+            checks.check_coordinate_halos_brick(engine, topo, prm, seed=seed)
+        elif what == "res_bc":
+            checks.check_blockette_res_with_bc(engine, topo, prm.replace(dirScaling=True), walls, seed=seed, split_eval=se)
+        elif what == "rk":
+            checks.check_rk_smoother(engine, topo, prm.replace(smoother=RungeKutta), seed=seed)
+        elif what == "dadi":
+            checks.check_dadi_smoother(engine, topo, prm.replace(smoother=DADI, cfl=1.5, resAveraging=noResAveraging), seed=seed)
+        elif what == "mg_bc":
+            p2 = prm.replace(smoother=RungeKutta)
+            if p2.equations == RANSEquations:
+                p2 = p2.replace(smoother=DADI, cfl=1.5, resAveraging=noResAveraging, nSubiterations=2, nSubIterTurb=2)
+            checks.check_mg_cycle(engine, topo, p2, [0, 1, 0, -1], ncycles=1, brick_spec=walls, seed=seed)
+        else:
+            checks.check_nk_residual(engine, topo, prm, seed=seed)
     elif entry in ("rk", "dadi", "sa_solve", "nk"):
         topo = BrickTopology(*mk.pop("topo"))
         if entry == "rk":
@@ -152,14 +211,22 @@ def sweep(engine, cases, seed, only=-1, quiet=False, big=False):
     rng = np.random.default_rng(seed)
     for n in range(cases):
         dims, kw, mk, entry = draw_case(rng, big)
+        # round 5: the tuning keys of the new code paths at random (results never depend on them)
+        tune = {"bc_merge": int(rng.choice([0, 1, 2])), "front_overlap": int(rng.integers(0, 2)), "gf_waves": int(rng.choice([4, 8])),
+                "gf_prefetch": int(rng.integers(0, 2))}
         if only >= 0 and n != only:
             continue
         try:
+            for k_, v_ in tune.items():
+                engine.set_tuning(k_, v_)
             run_case(engine, dims, kw, mk, entry)
             if not quiet:
-                print(f"[{n:4d}] ok   {dims} {entry} {kw} {mk}", flush=True)
+                print(f"[{n:4d}] ok   {dims} {entry} {kw} {mk} {tune}", flush=True)
         except AssertionError as ex:
-            return n + 1, f"case {n} (seed {seed}): {dims} {entry} {kw} {mk}: {ex}"
+            return n + 1, f"case {n} (seed {seed}): {dims} {entry} {kw} {mk} {tune}: {ex}"
+        finally:
+            for k_, v_ in {"bc_merge": 1, "front_overlap": 0, "gf_waves": 4, "gf_prefetch": 0, "split_eval": 1}.items():
+                engine.set_tuning(k_, v_)
     return cases, None
 
 
