@@ -111,6 +111,17 @@ def draw_case(rng, huge=False):
                   split=({int(rng.choice([3, 5])): int(rng.choice(kinds))} if withbc and rng.random() < 0.5 else None),
                   dadi=bool(rng.random() < 0.4))
         kw["resAveraging"] = int(rng.choice([noResAveraging, alternateResAveraging]))
+        # (what this entry must NOT draw: cycles that blow up in the reference itself and then amplify rounding -- measured: the
+        # unlimited fully-upwind scheme between four inviscid walls drives wall pressures to the floor of bcEulerWall within one sweep;
+        # RANS + SA cycles on 20-cell blocks reach NaN in the second cycle)
+        if kw.get("limiter") == noLimiter:
+            kw["limiter"] = vanAlbeda
+        if eq == RANSEquations:
+            kw["equations"] = NSEquations
+            for k_ in ("useQCR", "orderTurb", "useRotationSA", "useft2SA"):
+                kw.pop(k_, None)
+        if "vis2" in kw:
+            kw["vis2"] = max(kw["vis2"], 0.25)
         if eq != EulerEquations:
             mk["stretch_k"] = 2.0
     if entry == "lattice":
