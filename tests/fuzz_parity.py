@@ -116,6 +116,10 @@ def draw_case(rng, huge=False):
         # RANS + SA cycles on 20-cell blocks reach NaN in the second cycle)
         if kw.get("limiter") == noLimiter:
             kw["limiter"] = vanAlbeda
+        # (and: a smoother sweep on the noisy synthetic state can leave p3 >= 2 p2 at an inviscid wall; the linear extrapolation of
+        # bcEulerWall then floors the halo pressure at exactly 0, the Roe average between that halo and its cell has a^2 ~ 1e-17 and
+        # 1 / a turns rounding into O(1) -- in the reference as much as here.  Constant extrapolation keeps the walls in the draw)
+        kw["eulerWallBCTreatment"] = 1
         if eq == RANSEquations:
             kw["equations"] = NSEquations
             for k_ in ("useQCR", "orderTurb", "useRotationSA", "useft2SA"):
