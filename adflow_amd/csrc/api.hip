@@ -1541,7 +1541,7 @@ static int block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bo
 
 // ---- forward-mode linearisation (kernels_ad.hip): dual copies of the arrays the gather kernels touch ----------------------------
 // Round 5 (round-4 advisor): ONE slab per level instead of ~57 hipMalloc / hipFree per block and call, kept between calls (tuning
-// "ad_cache", default 1; dropped when a block is released or the level's layout changes) -- on the north-star mesh the 13.5 GB of
+// "ad_cache", default 1; dropped when a block is released or the level's layout changes) -- on the north-star mesh the 13.5 GB (8.4 GB since the geometry is no longer copied) of
 // dual arrays cost 0-400 ms per assembly to map, depending on the box (profiles/r05_f_bench.json against r05_d) -- and the free
 // memory is checked before the slab is requested.
 struct AdInit { char* dst; const double* src; size_t n, zeroBytes; };   // dual array at dst: (src, 0) for n entries, or zeroBytes of zero
@@ -1597,13 +1597,9 @@ static int ad_layout(int level, bool viscous)
             ad_array(b, a, &v.radK, nullptr, 1) || ad_array(b, a, &v.ss, p.ss, 1) || ad_array(b, a, &v.scratch, nullptr, 2))
             return 1;
         if (viscous && ad_array(b, a, &v.grad, nullptr, 12)) return 1;
-        // passive arrays: value = the library's, derivative 0
-        if (ad_array(b, a, &v.gamma, p.gamma, 1) || ad_array(b, a, &v.x, p.x, 3) || ad_array(b, a, &v.sI, p.sI, 3) ||
-            ad_array(b, a, &v.sJ, p.sJ, 3) || ad_array(b, a, &v.sK, p.sK, 3) || ad_array(b, a, &v.vol, p.vol, 1) ||
-            ad_array(b, a, &v.volRef, p.volRef, 1))
-            return 1;
-        if (p.d2wall && ad_array(b, a, &v.d2wall, p.d2wall, 1)) return 1;
-        if (viscous && p.dI && (ad_array(b, a, &v.dI, p.dI, 3) || ad_array(b, a, &v.dJ, p.dJ, 3) || ad_array(b, a, &v.dK, p.dK, 3))) return 1;
+        // passive arrays: value = the library's, derivative 0.  The geometry (x, sI/sJ/sK, vol, volRef, d2wall, dI/dJ/dK) is read by the
+        // dual kernels as plain doubles out of the library's own arrays (blkview_def.h: ADF_GEOM), so it has no dual copy
+        if (ad_array(b, a, &v.gamma, p.gamma, 1)) return 1;
         v.aa = nullptr; v.wn = v.pn = v.w1 = v.p1 = v.wr = nullptr; v.sFace = nullptr;
         // face arrays of the turbulence boundary treatment
         const size_t nf[3] = {(size_t)p.je * p.ke, (size_t)p.ie * p.ke, (size_t)p.ie * p.je};

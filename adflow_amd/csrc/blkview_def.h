@@ -11,11 +11,13 @@ struct ADF_BLKVIEW {
     // state
     double *w, *p, *gamma, *rlv, *rev;
     // geometry
-    double *x, *sI, *sJ, *sK, *vol, *volRef, *d2wall;
-    double* sFace;          // moving blocks: sFaceI/J/K as components 0..2 (entry at the left cell of the face); NULL at rest
+    // (ADF_GEOM = double; in the forward-mode build the geometry stays PLAIN -- adf_real8 -- and points at the library's own arrays: it
+    //  carries no derivative, and a dual copy of it would double its bytes)
+    ADF_GEOM *x, *sI, *sJ, *sK, *vol, *volRef, *d2wall;
+    ADF_GEOM* sFace;        // moving blocks: sFaceI/J/K as components 0..2 (entry at the left cell of the face); NULL at rest
     int moving;             // blockIsMoving: rotational source with rot = cgnsDoms%rotRate (fluxes.F90:372-397)
     adf_real8 rot[3];
-    double *dI, *dJ, *dK;   // derived geometry: vector between the two cell centres of a face (viscous normal correction)
+    ADF_GEOM *dI, *dJ, *dK; // derived geometry: vector between the two cell centres of a face (viscous normal correction)
     // implicit turbulence boundary treatment of Spalart-Allmaras (turbBCRoutines.F90:662-798): halo = bvt - bmt * interior.
     // Index 0..5 = iMin,iMax,jMin,jMax,kMin,kMax; entry (a,b) at (a-1) + A*(b-1), A = je (i faces) or ie (j,k faces).
     // NULL until a block registers boundary subfaces (= all zero, the periodic / internal case).

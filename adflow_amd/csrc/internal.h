@@ -214,7 +214,9 @@ __device__ __forceinline__ double lane_dn1(double v)
 
 typedef double adf_real8;      // a double that stays one where `double` is re-defined (kernels_ad.hip)
 #define ADF_BLKVIEW BlkView
+#define ADF_GEOM double
 #include "blkview_def.h"
+#undef ADF_GEOM
 #undef ADF_BLKVIEW
 
 // one boundary subface on the device (adflow_bc_subface with device copies of the BCData members)

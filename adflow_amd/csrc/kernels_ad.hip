@@ -71,7 +71,9 @@ namespace adj {
 #define ADF_AD_BUILD 1
 #define double Dual
 #define ADF_BLKVIEW BlkViewAD
+#define ADF_GEOM adf_real8
 #include "blkview_def.h"
+#undef ADF_GEOM
 #undef ADF_BLKVIEW
 #define BlkView BlkViewAD
 

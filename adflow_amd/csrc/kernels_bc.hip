@@ -342,7 +342,7 @@ __device__ __forceinline__ void bcc_eulerwall(const BlkView& b, const BcFaceDev&
         const int isize = f.icEnd - f.icBeg + 1;
         const int a = f.icBeg + (int)(s.f % isize), q = f.jcBeg + (int)(s.f / isize);
         long sa, sb;
-        const double *Sn, *Sa, *Sb;
+        const adf_real8 *Sn, *Sa, *Sb;
         switch (f.faceID) {
         case ADFLOW_IMIN: case ADFLOW_IMAX: sa = b.ldi; sb = b.ldk; Sn = b.sI; Sa = b.sJ; Sb = b.sK; break;
         case ADFLOW_JMIN: case ADFLOW_JMAX: sa = 1; sb = b.ldk; Sn = b.sJ; Sa = b.sI; Sb = b.sK; break;

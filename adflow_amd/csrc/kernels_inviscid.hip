@@ -21,10 +21,10 @@
 // one index direction for the cell at line position 2: central flux through
 // both faces + the selected dissipation
 template <int SCHEME, bool VISC>
-__device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, long c, long s, const double* __restrict__ sN,
+__device__ __forceinline__ void dir_flux(const BlkView& b, const KParams& kp, long c, long s, const adf_real8* __restrict__ sN,
                                          const double* __restrict__ rad, int porM, int porP, double sslim,
                                          double fis2, double fis4, bool doDiss, int lim, double dwc[5], double fwd[5],
-                                         const double* __restrict__ sF)
+                                         const adf_real8* __restrict__ sF)
 {
     Line L;
     load_line(b, c, s, L);
@@ -130,13 +130,13 @@ __global__ __launch_bounds__(IV_BX* IV_BY, IV_MINWG(SCHEME)) void k_inviscid(con
     const int lim = (LIMT >= 0) ? LIMT : ((kp.fineGrid && !kp.lumpedDiss) ? kp.limiter : ADFLOW_LIM_FIRST_ORDER);
 
     double dwc[5] = {0, 0, 0, 0, 0}, fwd[5] = {0, 0, 0, 0, 0};
-    const double* sF = b.sFace;
+    const adf_real8* sF = b.sFace;
 #ifdef ADF_AD_BUILD
     // dual numbers: the three directions one after the other in ONE copy of the code (a loop the compiler must not unroll), so that
     // only one direction's line of states is live at a time
     {
         const long strd[3] = {1, b.ldi, b.ldk};
-        const double* sNd[3] = {b.sI, b.sJ, b.sK};
+        const adf_real8* sNd[3] = {b.sI, b.sJ, b.sK};
         const double* radd[3] = {b.radI, b.radJ, b.radK};
         const int pM[3] = {flg_porI(fi), flg_porJ(fj), flg_porK(fk)}, pP[3] = {flg_porI(f0), flg_porJ(f0), flg_porK(f0)};
 #pragma nounroll

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab
     const int bbi = blockIdx.y + 2;
     int n, amax, bmax;
     long c0, s;
-    const double* sN;
+    const adf_real8* sN;
     if (DIR == 0) { amax = b.jl; bmax = b.kl; n = b.nx; c0 = b.idx(2, a, bbi); s = 1; sN = b.sI; }
     else if (DIR == 1) { amax = b.il; bmax = b.kl; n = b.ny; c0 = b.idx(a, 2, bbi); s = b.ldi; sN = b.sJ; }
     else { amax = b.il; bmax = b.jl; n = b.nz; c0 = b.idx(a, bbi, 2); s = b.ldk; sN = b.sK; }

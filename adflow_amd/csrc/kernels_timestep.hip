@@ -89,7 +89,7 @@ __global__ __launch_bounds__(TS_BX* TS_BY) void k_time_step(const BlkView* __res
     // grid velocity of a moving block: sum over the two faces (solverUtils.F90:147-181)
     double sFace = 0.0, sFaceJ = 0.0, sFaceK = 0.0;
     if (b.sFace) {      // uniform branch: no loads at all for blocks at rest
-        const double* sF = b.sFace;
+        const adf_real8* sF = b.sFace;
         sFace = sF[c - 1] + sF[c];
         sFaceJ = sF[c - b.ldi + nb] + sF[c + nb];
         sFaceK = sF[c - b.ldk + 2 * nb] + sF[c + 2 * nb];

@@ -31,7 +31,7 @@ struct NCell { double u, v, w, aa; };
 // index+1: the normals at `index` are shared, every cell value is loaded once by
 // the caller.  Summation order as in the reference: the four faces at the lower
 // index first, then the four at the upper one.
-__device__ __forceinline__ void grad_dir(const BlkView& b, long c, long sd, long s1, long s2, const double* __restrict__ sN,
+__device__ __forceinline__ void grad_dir(const BlkView& b, long c, long sd, long s1, long s2, const adf_real8* __restrict__ sN,
                                          const NCell& m0, const NCell& m1, const NCell& m2, const NCell& m3, const NCell& p0,
                                          const NCell& p1, const NCell& p2, const NCell& p3, double g[12])
 {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * NG_BY, 2) void k_sa_march(const BlkView* __res
 // viscous flux through the face between cells cL and cL+sd (fluxes.F90:2610-2860);
 // the four face nodes are cL, cL-s1, cL-s2, cL-s1-s2.
 __device__ __forceinline__ void visc_face(const BlkView& b, const KParams& kp, long cL, long sd, long s1, long s2,
-                                          const double* __restrict__ sN, int por_code, double sign, double acc[5],
+                                          const adf_real8* __restrict__ sN, int por_code, double sign, double acc[5],
                                           double* tq = nullptr)
 {
     const long nb = b.nbox;
@@ -405,7 +405,7 @@ __device__ __forceinline__ void visc_face(const BlkView& b, const KParams& kp, l
     double ssv[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const double* xx = b.x + d * nb;
+        const adf_real8* xx = b.x + d * nb;
         ssv[d] = 0.125 * (xx[n0 + sd] - xx[n0 - sd] + xx[n2 + sd] - xx[n2 - sd] + xx[n1 + sd] - xx[n1 - sd] + xx[n3 + sd] -
                           xx[n3 - sd]);
     }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous(BlkView b, KParams kp)
     const long sd3[3] = {sk, sj, si};
     const long s13[3] = {si, si, sj};
     const long s23[3] = {sj, sk, sk};
-    const double* sN3[3] = {b.sK, b.sJ, b.sI};
+    const adf_real8* sN3[3] = {b.sK, b.sJ, b.sI};
     const int porM3[3] = {flg_porK(fk), flg_porJ(fj), flg_porI(fi)};
     const int porP3[3] = {flg_porK(f0), flg_porJ(f0), flg_porI(f0)};
 #pragma unroll 1
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_wall_stress(const BlkView* __restrict__
     const int a = r[0] + (int)(t % na), bb = r[2] + (int)(t / na);
     const long si = 1, sj = b.ldi, sk = b.ldk;
     long cL, sd, s1, s2;
-    const double* sN;
+    const adf_real8* sN;
     int por;
     switch (f.faceID) {
     case ADFLOW_IMIN: case ADFLOW_IMAX:
@@ -609,14 +609,14 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_face_vectors(BlkView b)
     const long sd3[3] = {si, sj, sk};
     const long s13[3] = {sj, si, si};
     const long s23[3] = {sk, sk, sj};
-    double* out3[3] = {b.dI, b.dJ, b.dK};
+    adf_real8* out3[3] = {b.dI, b.dJ, b.dK};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const long sd = sd3[d], s1 = s13[d], s2 = s23[d];
         const long n0 = c - s1 - s2, n1 = c - s2, n2 = c - s1, n3 = c;
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-            const double* xx = b.x + m * nb;
+            const adf_real8* xx = b.x + m * nb;
             out3[d][c + m * nb] = 0.125 * (xx[n0 + sd] - xx[n0 - sd] + xx[n2 + sd] - xx[n2 - sd] + xx[n1 + sd] - xx[n1 - sd] +
                                            xx[n3 + sd] - xx[n3 - sd]);
         }
@@ -1260,14 +1260,14 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_viscous_approx(BlkView b, KPar
     const VCell C = vcell_at(b, kp, c);
     // reference sweep order i, j, k (fluxes.F90:3520, 3666, 3762)
     const long sd3[3] = {si, sj, sk};
-    const double* sN3[3] = {b.sI, b.sJ, b.sK};
-    const double* dN3[3] = {b.dI, b.dJ, b.dK};
+    const adf_real8* sN3[3] = {b.sI, b.sJ, b.sK};
+    const adf_real8* dN3[3] = {b.dI, b.dJ, b.dK};
     const int shift3[3] = {0, 2, 4};
 #pragma unroll 1
     for (int d = 0; d < 3; ++d) {
         const long sd = sd3[d], cm = c - sd;
-        const double* __restrict__ sN = sN3[d];
-        const double* __restrict__ dN = dN3[d];
+        const adf_real8* __restrict__ sN = sN3[d];
+        const adf_real8* __restrict__ dN = dN3[d];
         const VCell M = vcell_at(b, kp, cm), P = vcell_at(b, kp, c + sd);
         const double nM[3] = {sN[cm], sN[cm + nb], sN[cm + 2 * nb]}, nP[3] = {sN[c], sN[c + nb], sN[c + 2 * nb]};
         const double dM[3] = {dN[cm], dN[cm + nb], dN[cm + 2 * nb]}, dP[3] = {dN[c], dN[c + nb], dN[c + 2 * nb]};

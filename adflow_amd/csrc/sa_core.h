@@ -38,7 +38,7 @@ struct SaDir {   // per-direction data of one cell
 };
 
 // dirc: 0, 1, 2 = i, j, k (component of b.sFace)
-__device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const double* __restrict__ sN, SaDir& d, int dirc)
+__device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const adf_real8* __restrict__ sN, SaDir& d, int dirc)
 {
     const long nb = b.nbox;
     d.qsf = 0.0;

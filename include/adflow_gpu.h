@@ -428,7 +428,7 @@ int adflow_gpu_abi_sizes2(int* bc_subface_bytes, int* comm_pattern_bytes);
  *   ADFLOW_JAC_USE_AD      useAD = T (adjointUtils.F90:227-409): every column from ONE forward-mode evaluation (seed 1 on the state
  *                          variable of the colour's cells, masterRoutines::block_res_state_d) instead of a finite difference: the
  *                          exact derivative, `delta` is not used.  Dual-number twins of the gather kernels (csrc/kernels_ad.hip).
- *                          The dual copies of the level's arrays (about 1 KB per box cell) are one slab that is KEPT between calls
+ *                          The dual copies of the level's arrays (about 640 B per box cell) are one slab that is KEPT between calls
  *                          and freed with the blocks (adflow_gpu_block_release / _release_all) or by tuning "ad_cache" = 0; the call
  *                          fails with a message when the device has not that much memory free.
  */

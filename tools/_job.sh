@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
-timeout 400 rocprofv3 --kernel-trace -d $O/prof -o t -- python bench.py --no-extras --no-cpu-baseline --steps 6 --warmup 2 --min-seconds 0.1 > /dev/null 2>&1
-python tools/_q.py $O/prof/t_results.db | tee $O/r04_bc_dispatches.txt
-rm -rf $O/prof
+timeout 900 python -m pytest tests -m gpu -x -q -k "jacobian or forward or _ad or useAD or matvec or pc_" 2>&1 | tail -5
+TAG=r05_r EXTRAS=pc ROWS=25 bash tools/_gpu_job_extras.sh
+cat $O/r05_r_pc.json | tail -1 | cut -c1-1500
