@@ -20,6 +20,7 @@ int visc_gf_rows();
 int g_test_fault = 0;        // tuning "test_fault" (tests only): bit 0 = the hipGraph capture of a multigrid cycle reports failure, bit 1 = the
                              // split evaluation fails behind its fork -- the error paths must leave the library usable
 int g_front_overlap = 0;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions (off: measured no gain at N = 1, profiles/r05_e_ab.txt)
+int g_pc_fused = 1;          // tuning "pc_fused": first-order Roe + thin-layer viscous flux of the preconditioner matrix as ONE march (kernels_pc_march.hip), plain and dual
 int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
 
 namespace {
@@ -1103,7 +1104,14 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     if (rc) return rc;
     if (approxMarch) {
         if (ensure_tiles(level)) return 1;
-        if (approxFirst) {
+        const int limPC = kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter;
+        if (approxFirst && g_pc_fused && kp.spaceDiscr == ADFLOW_UPWIND && kp.fineGrid && limPC == ADFLOW_LIM_FIRST_ORDER && !kp.rvec &&
+            !kp.coarseInit && roe_march_takes(kp)) {
+            // first-order upwind + thin-layer viscous flux: both are functions of the two cells of a face -- one march, dw written once
+            phase_mark(4);
+            launch_pc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream);
+            phase_mark(5);
+        } else if (approxFirst) {
             KParams kv = kp;
             kv.viscFirst = 1;
             phase_mark(4);
@@ -1677,16 +1685,23 @@ static int ad_prepare(int level)
 // viscPC: block_res_state_d keeps the FULL viscous flux in the preconditioner matrix then (masterRoutines.F90:1380: `.not. lumpedDiss
 // .or. viscPC`) -- unlike the finite-difference path block_res_state, whose viscApprox = lumpedDiss whatever viscPC says (:1269-1270)
 static int ad_apply_bc_enqueue(int level, const KParams& kp, bool turbBC);
-static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bool viscPC)
+static KParams ad_kparams(int level, unsigned resFlags)
 {
     KParams kp = make_kparams(level, 1.0, 0);
     kp.onlyRadii = 1;
     kp.coarseInit = 0;
     kp.dissApprox = (resFlags & ADFLOW_RES_DISS_APPROX) ? 1 : 0;
+    return kp;
+}
+// closuresDone: the seed launch of the caller formed pressure and viscosities already (k_seed_closures)
+static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bool viscPC, bool closuresDone = false)
+{
+    KParams kp = ad_kparams(level, resFlags);
     const bool viscApprox = (resFlags & ADFLOW_RES_VISC_APPROX) != 0 && !viscPC;
     LevelTab t;
     if (level_tab(level, &t)) return 1;
-    int rc = for_level(level, [&](Block* b) {
+    int rc = 0;
+    if (!closuresDone) rc = for_level(level, [&](Block* b) {
         ad_launch_closures_halo(g_ad[b].v, kp, g_stream);
         return 0;
     });
@@ -1696,9 +1711,29 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
     // in ss -- not under dissApprox, where ss keeps the frozen sensor of referenceShockSensor (value part, derivative 0)
     if ((resFlags & ADFLOW_RES_FLOW) && kp.spaceDiscr == ADFLOW_DISS_SCALAR)
         ad_launch_time_step_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
-    if ((resFlags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS)
-        ad_launch_sa_residual_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
-    if (resFlags & ADFLOW_RES_FLOW) {
+    if ((resFlags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
+        // the marching form on dual numbers (kernels_sa_march.hip; blocks at rest: moving blocks were refused by the caller)
+        if (g_sa_march && g_pc_fused) {
+            if (ensure_sa_tiles(level)) return 1;
+            ad_launch_sa_march(g_ad_tab, g_sa_tiles[level].first, g_sa_tiles[level].second, kp, g_stream);
+        } else
+            ad_launch_sa_residual_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+    }
+    const int limPC = kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter;
+    if ((resFlags & ADFLOW_RES_FLOW) && g_pc_fused && viscApprox && kp.viscous && fabs(kp.rFil) >= 1.e-10 && kp.spaceDiscr == ADFLOW_UPWIND &&
+        kp.fineGrid && limPC == ADFLOW_LIM_FIRST_ORDER && roe_march_takes(kp) && viscous_is_tiled() >= 2) {
+        // the preconditioner matrix on the upwind scheme: the dual form of the one-march residual (kernels_pc_march.hip) instead of the
+        // gather kernels (blocks at rest: moving blocks were refused by the caller)
+        rc = for_level(level, [&](Block* b) {
+            if (!b->face_vectors_valid) {
+                launch_face_vectors(b->v, g_stream);
+                b->face_vectors_valid = true;
+            }
+            return 0;
+        });
+        if (rc || ensure_tiles(level)) return 1;
+        ad_launch_pc_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream);
+    } else if (resFlags & ADFLOW_RES_FLOW) {
         ad_launch_inviscid_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
         if (kp.viscous && fabs(kp.rFil) >= 1.e-10) {
             rc = for_level(level, [&](Block* b) {
@@ -1799,12 +1834,12 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
         if (!rc) rc = ad_prepare(level);
         for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
             for (int col = 0; col < J.cn && !rc; ++col) {
+                const KParams kps = ad_kparams(level, resFlags);
                 rc = for_level(level, [&](Block* b) {
-                    AdBlock& a = g_ad[b];
-                    ad_launch_seed(b->v, a.v.w, l, col, J, g_stream);
+                    ad_launch_seed_closures(b->v, g_ad[b].v, l, col, J, kps, g_stream);
                     return 0;
                 });
-                if (!rc) rc = ad_block_res_state_enqueue(level, resFlags, turbBC, (flags & ADFLOW_JAC_VISC_PC) != 0);
+                if (!rc) rc = ad_block_res_state_enqueue(level, resFlags, turbBC, (flags & ADFLOW_JAC_VISC_PC) != 0, true);
                 if (!rc) rc = for_level(level, [&](Block* b) {
                     ad_launch_snap(b->v, g_ad[b].v.dw, b->snap + (size_t)col * J.nState * b->v.nbox, J, g_opts.turbResScale, g_stream);
                     return 0;
@@ -3866,6 +3901,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "front_overlap")) { g_front_overlap = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "test_fault")) { g_test_fault = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
+    if (!strcmp(key, "pc_fused")) { g_pc_fused = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_prefetch")) { g_gf_prefetch = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_waves")) {
         if (value != 4 && value != 8) return fail("gf_waves must be 4 or 8");

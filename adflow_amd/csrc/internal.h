@@ -416,6 +416,8 @@ void launch_halo_unpack(const BlkView* tab, const int* blk, const long* off, int
 void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 int inviscid_march_enabled();
 bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+// kernels_pc_march.hip: first-order Roe + thin-layer viscous flux in one march (the mean-flow residual of the preconditioner matrix)
+void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s);
 bool roe_march_takes(const KParams& kp);
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
@@ -465,7 +467,6 @@ void launch_wall_distance(const BlkView& b, const int* ind, const double* uv, co
 // entry points of kernels_ad.hip (BlkView-layout views whose array pointers lead to dual numbers, blkview_def.h)
 void ad_launch_from_real(const double* src, void* dst, long n, hipStream_t s);
 void ad_launch_value(const void* src, double* dst, long n, int deriv, hipStream_t s);
-void ad_launch_seed(const BlkView& b, void* wd, int l, int col, const JacSpec& J, hipStream_t s);
 void ad_launch_snap(const BlkView& b, const void* dwd, double* snap, const JacSpec& J, double turbResScale, hipStream_t s);
 void ad_launch_closures_halo(const BlkView& adv, const KParams& kp, hipStream_t s);
 void ad_launch_apply_all_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& flow, const KParams& kp,
@@ -478,3 +479,6 @@ void ad_launch_sa_residual_level(const BlkView* tab, int n, int nx, int ny, int 
 void ad_launch_inviscid_level(const BlkView* tab, int n, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void ad_launch_viscous(const BlkView& adv, const KParams& kp, hipStream_t s);
 void ad_launch_viscous_approx(const BlkView& adv, const KParams& kp, hipStream_t s);
+void ad_launch_seed_closures(const BlkView& real, const BlkView& adv, int l, int col, const JacSpec& J, const KParams& kp, hipStream_t s);
+void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s);
+void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);

@@ -19,32 +19,64 @@
 #include "dual.h"
 
 // ---- the helpers of internal.h for dual arguments (the fast reciprocal / root forms are plain operations here)
-__device__ __forceinline__ Dual rcp_nr(const Dual& b) { return 1.0 / b; }
-__device__ __forceinline__ Dual rsq_nr(const Dual& x) { return 1.0 / sqrt(x); }
-__device__ __forceinline__ Dual fastdiv(const Dual& a, const Dual& b) { return a / b; }
-__device__ __forceinline__ Dual fastdiv(double a, const Dual& b) { return a / b; }
-__device__ __forceinline__ Dual fastdiv(const Dual& a, double b) { return a / b; }
-__device__ __forceinline__ Dual fastsqrt(const Dual& x) { return sqrt(x); }
+// (round 5: value by the same fast form as the plain build, derivative from it -- the IEEE divisions and roots of `1.0 / b` cost the
+//  dual kernels 3.5 x the transcendental seeds of the plain ones)
+__device__ __forceinline__ Dual rcp_nr(const Dual& b)
+{
+    const double r = rcp_nr(b.v);
+    return Dual(r, -(r * r) * b.d);
+}
+__device__ __forceinline__ Dual rsq_nr(const Dual& x)
+{
+    const double r = rsq_nr(x.v);
+    return Dual(r, (-0.5 * r) * (r * r) * x.d);
+}
+__device__ __forceinline__ Dual fastdiv(const Dual& a, const Dual& b)
+{
+    const double r = rcp_nr(b.v), q = a.v * r;
+    return Dual(q, (a.d - q * b.d) * r);
+}
+__device__ __forceinline__ Dual fastdiv(double a, const Dual& b)
+{
+    const double r = rcp_nr(b.v), q = a * r;
+    return Dual(q, -(q * r) * b.d);
+}
+__device__ __forceinline__ Dual fastdiv(const Dual& a, double b)
+{
+    const double r = rcp_nr(b);
+    return Dual(a.v * r, a.d * r);
+}
+__device__ __forceinline__ Dual fastsqrt(const Dual& x)        // sqrt(0): derivative 0 (dual.h)
+{
+    const double r = rsq_nr(fmax(x.v, 1.e-300));
+    return Dual(x.v * r, x.v == 0.0 ? 0.0 : (0.5 * r) * x.d);
+}
 __device__ __forceinline__ Dual fast_root6(const Dual& x) { return pow(x, 1.0 / 6.0); }
 __device__ __forceinline__ Dual fast_exp_neg(const Dual& x) { return exp(x); }
 __device__ __forceinline__ Dual fast_powa(const Dual& x, double a) { return pow(x, a); }
+// memory and lane moves of the marching form (kernels_pc_march.hip)
+// The marching kernels address every array of a block with ONE byte offset of 8-byte elements (internal.h: ldg / stg); an array of
+// dual numbers has 16-byte elements at the same indices, so its forms of ldg / stg DOUBLE the offset (valid while a component of a
+// block stays below 2 GiB of doubles) -- the same kernel source then addresses plain geometry and dual state side by side.
+typedef double adf_v2 __attribute__((vector_size(16)));     // (value, derivative) as ONE 16-byte access
+__device__ __forceinline__ Dual ldg(GPTR(const Dual) base, unsigned byteoff8)
+{
+    const adf_v2 t = *(GPTR(const adf_v2))((GPTR(const char))base + 2u * byteoff8);
+    return Dual(t[0], t[1]);
+}
+__device__ __forceinline__ void stg(GPTR(Dual) base, unsigned byteoff8, const Dual& v)
+{
+    const adf_v2 t = {v.v, v.d};
+    *(GPTR(adf_v2))((GPTR(char))base + 2u * byteoff8) = t;
+}
+__device__ __forceinline__ Dual lane_up1(const Dual& a) { return Dual(lane_up1(a.v), lane_up1(a.d)); }
+__device__ __forceinline__ Dual lane_dn1(const Dual& a) { return Dual(lane_dn1(a.v), lane_dn1(a.d)); }
 
 // ---- conversions between the library's arrays and the dual arrays (written before `double` changes its meaning)
 __global__ void k_ad_from_real(const double* __restrict__ src, Dual* __restrict__ dst, long n)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) dst[t] = Dual(src[t], 0.0);
-}
-// w <- (w, 1 where the cell has colour `col` and the component is l, else 0): the seed of one pass (adjointUtils.F90:330-347)
-__global__ void k_ad_seed(BlkView b, Dual* __restrict__ wd, int l, int col, JacSpec J)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x - 14;
-    const int j = blockIdx.y * 4 + threadIdx.y;
-    const int k = blockIdx.z;
-    if (i < 0 || i > b.ib || j > b.jb) return;
-    const long c = b.idx(i, j, k);
-    const bool hit = ((J.ca * (i % J.cm) + J.cb * (j % J.cm) + J.cc * (k % J.cm)) % J.cn) == col;
-    for (int m = 0; m < b.nw; ++m) wd[c + m * b.nbox] = Dual(b.w[c + m * b.nbox], (hit && m == l) ? 1.0 : 0.0);
 }
 // derivative part of the scaled residual -> the dense snapshot of the pass (resScale_d + the copy into dw_deriv, adjointUtils.F90:384-388)
 __global__ void k_ad_snap(BlkView b, const Dual* __restrict__ dwd, double* __restrict__ snap, JacSpec J, double turbResScale)
@@ -78,16 +110,11 @@ namespace adj {
 #define BlkView BlkViewAD
 
 // closures of block_res_state_d: pressure on 0..ib, laminar / eddy viscosity on 1..ie (includeHalos = .True.)
-__global__ __launch_bounds__(256) void k_closures_halo(BlkView b, KParams kp)
+__device__ __forceinline__ void closures_halo_cell(const BlkView& b, const KParams& kp, int i, int j, int k, long c, const double wv[6])
 {
-    const int i = blockIdx.x * 64 + threadIdx.x - 14;
-    const int j = blockIdx.y * 4 + threadIdx.y;
-    const int k = blockIdx.z;
-    if (i < 0 || i > b.ib || j > b.jb) return;
-    const long c = b.idx(i, j, k), nb = b.nbox;
-    const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
+    const double rho = wv[0], u = wv[1], v = wv[2], w = wv[3];
     const adf_real8 gm1 = kp.gammaConstant - 1.0;
-    double p = gm1 * (b.w[c + 4 * nb] - 0.5 * rho * (u * u + v * v + w * w));
+    double p = gm1 * (wv[4] - 0.5 * rho * (u * u + v * v + w * w));
     p = fmax(p, 1.e-4 * kp.pInfCorr);
     b.p[c] = p;
     if (!kp.viscous || i < 1 || i > b.ie || j < 1 || j > b.je || k < 1 || k > b.ke) return;
@@ -98,11 +125,43 @@ __global__ __launch_bounds__(256) void k_closures_halo(BlkView b, KParams kp)
     b.rlv[c] = rlv;
     if (kp.eddyModel) {
         const adf_real8 cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
-        const double rnuSA = b.w[c + 5 * nb] * rho;
+        const double rnuSA = wv[5] * rho;
         const double chi = rnuSA / rlv;
         const double chi3 = chi * chi * chi;
         b.rev[c] = chi3 / (chi3 + cv13) * rnuSA;
     }
+}
+__global__ __launch_bounds__(256) void k_closures_halo(BlkView b, KParams kp)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x - 14;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i < 0 || i > b.ib || j > b.jb) return;
+    const long c = b.idx(i, j, k), nb = b.nbox;
+    double wv[6];
+    for (int m = 0; m < 6; ++m) wv[m] = (m < b.nw) ? b.w[c + m * nb] : 0.0;
+    closures_halo_cell(b, kp, i, j, k, c, wv);
+}
+// the seed of one pass (adjointUtils.F90:330-347) and the closures from it in ONE pass over the state: w <- (w of the library, 1 where
+// the cell has colour `col` and the component is l), then pressure and viscosities from the values in registers (round 5: two launches read
+// the 96 B per cell of the dual state back that the first had just written)
+__global__ __launch_bounds__(256) void k_seed_closures(BlkView b, const adf_real8* __restrict__ wsrc, int l, int col, JacSpec J, KParams kp)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x - 14;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i < 0 || i > b.ib || j > b.jb) return;
+    const long c = b.idx(i, j, k), nb = b.nbox;
+    const bool hit = ((J.ca * (i % J.cm) + J.cb * (j % J.cm) + J.cc * (k % J.cm)) % J.cn) == col;
+    double wv[6];
+    for (int m = 0; m < 6; ++m) {
+        if (m < b.nw) {
+            wv[m] = Dual(wsrc[c + m * nb], (hit && m == l) ? 1.0 : 0.0);
+            b.w[c + m * nb] = wv[m];
+        } else
+            wv[m] = 0.0;
+    }
+    closures_halo_cell(b, kp, i, j, k, c, wv);
 }
 
 #include "kernels_inviscid.hip"
@@ -110,6 +169,8 @@ __global__ __launch_bounds__(256) void k_closures_halo(BlkView b, KParams kp)
 #include "kernels_bc.hip"
 #include "kernels_sa.hip"
 #include "kernels_viscous.hip"
+#include "kernels_pc_march.hip"
+#include "kernels_sa_march.hip"
 
 #undef BlkView
 #undef double
@@ -126,13 +187,14 @@ void ad_launch_value(const void* src, double* dst, long n, int deriv, hipStream_
 {
     if (n > 0) hipLaunchKernelGGL(k_ad_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Dual*)src, dst, n, deriv);
 }
-void ad_launch_seed(const BlkView& b, void* wd, int l, int col, const JacSpec& J, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_ad_seed, dim3((b.ib + 15 + 63) / 64, (b.jb + 4) / 4, b.kb + 1), dim3(64, 4, 1), 0, s, b, (Dual*)wd, l, col, J);
-}
 void ad_launch_snap(const BlkView& b, const void* dwd, double* snap, const JacSpec& J, double turbResScale, hipStream_t s)
 {
     hipLaunchKernelGGL(k_ad_snap, dim3((b.nx + 63) / 64, (b.ny + 3) / 4, b.nz), dim3(64, 4, 1), 0, s, b, (const Dual*)dwd, snap, J, turbResScale);
+}
+void ad_launch_seed_closures(const BlkView& real, const BlkView& adv, int l, int col, const JacSpec& J, const KParams& kp, hipStream_t s)
+{
+    hipLaunchKernelGGL(adj::k_seed_closures, dim3((adv.ib + 15 + 63) / 64, (adv.jb + 4) / 4, adv.kb + 1), dim3(64, 4, 1), 0, s, *ADV(&adv),
+                       real.w, l, col, J, kp);
 }
 void ad_launch_closures_halo(const BlkView& adv, const KParams& kp, hipStream_t s)
 {
@@ -164,4 +226,12 @@ void ad_launch_inviscid_level(const BlkView* tab, int n, int nx, int ny, int nz,
 }
 void ad_launch_viscous(const BlkView& adv, const KParams& kp, hipStream_t s) { adj::launch_viscous(*ADV(&adv), kp, s); }
 void ad_launch_viscous_approx(const BlkView& adv, const KParams& kp, hipStream_t s) { adj::launch_viscous_approx(*ADV(&adv), kp, s); }
+void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)
+{
+    adj::launch_pc_march(ADV(tab), tiles, ntiles, kp, kch, s);
+}
+void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    adj::launch_sa_march(ADV(tab), tiles, ntiles, kp, s, false);
+}
 #undef ADV

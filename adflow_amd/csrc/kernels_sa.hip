@@ -35,7 +35,7 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(const BlkView* __r
 
     const double rho = b.w[c], u = b.w[c + nb], v = b.w[c + 2 * nb], w = b.w[c + 3 * nb];
     const double nut = dk.nt[2];
-    const double vol0 = b.vol[c];
+    const adf_real8 vol0 = b.vol[c];
 
     // ---- source (sa.F90:133-300): velocity gradient * 2 vol from the six neighbours
     double gu[3][3];   // gu[comp][xyz]
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(const BlkView* __r
         for (int d = 0; d < 3; ++d)
             gu[m][d] = qip * di.sp[d] - qim * di.sm[d] + qjp * dj.sp[d] - qjm * dj.sm[d] + qkp * dk.sp[d] - qkm * dk.sm[d];
     }
-    const double fact = 0.25 / vol0;
+    const adf_real8 fact = 0.25 / vol0;
     double ss, strainMag2 = 0.0;
     if (kp.turbProd == ADFLOW_TURBPROD_STRAIN) {
         const double sxx = 2.0 * fact * gu[0][0], syy = 2.0 * fact * gu[1][1], szz = 2.0 * fact * gu[2][2];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_residual(const BlkView* __r
     const double kar2Inv = 1.0 / (kp.sa_k * kp.sa_k);
     const double cw3_2 = kp.sa_cw3 * kp.sa_cw3;
     const double cw36 = cw3_2 * cw3_2 * cw3_2;
-    const double cb3Inv = 1.0 / kp.sa_cb3;
+    const adf_real8 cb3Inv = 1.0 / kp.sa_cb3;
     const double nu = b.rlv[c] / rho;
     const double d2 = b.d2wall[c];
     const double dist2Inv = 1.0 / (d2 * d2);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab
     else { amax = b.il; bmax = b.jl; n = b.nz; c0 = b.idx(a, bbi, 2); s = b.ldk; sN = b.sK; }
     if (b.nx == 0 || a > amax || bbi > bmax) return;
     const long nb = b.nbox;
-    const double cb3Inv = 1.0 / kp.sa_cb3;
+    const adf_real8 cb3Inv = 1.0 / kp.sa_cb3;
     double* rhs = b.scratch;
     double* qqA = b.scratch + nb;
     double* ccA = b.scratch + 2 * nb;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void k_sa_sweep(const BlkView* __restrict__ tab
         else {
             SaDir d;
             load_dir(b, c, s, sN, d, DIR);
-            const double vol0 = b.vol[c];
+            const adf_real8 vol0 = b.vol[c];
             const double nu = b.rlv[c] / b.w[c];
             double c1m, c1p, uu;
             (void)sa_diffuse(d, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p);
@@ -264,10 +264,10 @@ __global__ __launch_bounds__(SA_BX* SA_BY) void k_sa_rows_i(const BlkView* __res
     const int k = blockIdx.z % nzb + 2;
     if (i > b.il || j > b.jl || k > b.kl) return;
     const long c = b.idx(i, j, k), nb = b.nbox;
-    const double cb3Inv = 1.0 / kp.sa_cb3;
+    const adf_real8 cb3Inv = 1.0 / kp.sa_cb3;
     SaDir d;
     load_dir(b, c, 1, b.sI, d, 0);
-    const double vol0 = b.vol[c];
+    const adf_real8 vol0 = b.vol[c];
     const double nu = b.rlv[c] / b.w[c];
     double c1m, c1p, uu;
     (void)sa_diffuse(d, vol0, nu, kp.sa_cb2, cb3Inv, &c1m, &c1p);

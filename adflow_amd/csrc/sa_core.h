@@ -30,11 +30,11 @@ __device__ __forceinline__ double upwind_diff(bool secondOrd, bool positive, dou
 }
 
 struct SaDir {   // per-direction data of one cell
-    double sm[3], sp[3];      // normals of the minus / plus face
-    double volm, volp;        // volumes of the minus / plus neighbour
+    adf_real8 sm[3], sp[3];   // normals of the minus / plus face
+    adf_real8 volm, volp;     // volumes of the minus / plus neighbour
     double nt[5];             // nuTilde at -2..+2
     double num, nup;          // laminar kinematic viscosity of the minus / plus neighbour
-    double qsf;               // grid velocity of a moving block: sFace(minus face) + sFace(plus face), else 0
+    adf_real8 qsf;            // grid velocity of a moving block: sFace(minus face) + sFace(plus face), else 0
 };
 
 // dirc: 0, 1, 2 = i, j, k (component of b.sFace)
@@ -57,11 +57,11 @@ __device__ __forceinline__ void load_dir(const BlkView& b, long c, long s, const
 }
 
 // advection in one direction (turbUtils.F90:886-1070)
-__device__ __forceinline__ double sa_advect(const SaDir& d, double vol0, double u, double v, double w, bool secondOrd,
+__device__ __forceinline__ double sa_advect(const SaDir& d, adf_real8 vol0, double u, double v, double w, bool secondOrd,
                                             double* uuOut = nullptr)
 {
-    const double voli = 0.5 * rcp_nr(vol0);
-    const double xa = (d.sp[0] + d.sm[0]) * voli, ya = (d.sp[1] + d.sm[1]) * voli, za = (d.sp[2] + d.sm[2]) * voli;
+    const adf_real8 voli = 0.5 * rcp_nr(vol0);
+    const adf_real8 xa = (d.sp[0] + d.sm[0]) * voli, ya = (d.sp[1] + d.sm[1]) * voli, za = (d.sp[2] + d.sm[2]) * voli;
     const double uu = xa * u + ya * v + za * w - d.qsf * voli;       // qs = (sFace(m) + sFace(m-1)) voli, turbUtils.F90:906
     const double dwt = upwind_diff(secondOrd, uu > 0.0, d.nt[0], d.nt[1], d.nt[2], d.nt[3], d.nt[4]);
     if (uuOut) *uuOut = uu;
@@ -69,17 +69,17 @@ __device__ __forceinline__ double sa_advect(const SaDir& d, double vol0, double 
 }
 
 // diffusion in one direction (sa.F90:385-450)
-__device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double nu, double cb2, double cb3Inv,
+__device__ __forceinline__ double sa_diffuse(const SaDir& d, adf_real8 vol0, double nu, adf_real8 cb2, adf_real8 cb3Inv,
                                              double* c1mOut = nullptr, double* c1pOut = nullptr)
 {
-    const double voli = rcp_nr(vol0);
-    const double volmi = 2.0 * rcp_nr(vol0 + d.volm), volpi = 2.0 * rcp_nr(vol0 + d.volp);
-    const double xm = d.sm[0] * volmi, ym = d.sm[1] * volmi, zm = d.sm[2] * volmi;
-    const double xp = d.sp[0] * volpi, yp = d.sp[1] * volpi, zp = d.sp[2] * volpi;
-    const double xa = 0.5 * (d.sp[0] + d.sm[0]) * voli, ya = 0.5 * (d.sp[1] + d.sm[1]) * voli,
-                 za = 0.5 * (d.sp[2] + d.sm[2]) * voli;
-    const double ttm = xm * xa + ym * ya + zm * za;
-    const double ttp = xp * xa + yp * ya + zp * za;
+    const adf_real8 voli = rcp_nr(vol0);
+    const adf_real8 volmi = 2.0 * rcp_nr(vol0 + d.volm), volpi = 2.0 * rcp_nr(vol0 + d.volp);
+    const adf_real8 xm = d.sm[0] * volmi, ym = d.sm[1] * volmi, zm = d.sm[2] * volmi;
+    const adf_real8 xp = d.sp[0] * volpi, yp = d.sp[1] * volpi, zp = d.sp[2] * volpi;
+    const adf_real8 xa = 0.5 * (d.sp[0] + d.sm[0]) * voli, ya = 0.5 * (d.sp[1] + d.sm[1]) * voli,
+                    za = 0.5 * (d.sp[2] + d.sm[2]) * voli;
+    const adf_real8 ttm = xm * xa + ym * ya + zm * za;
+    const adf_real8 ttp = xp * xa + yp * ya + zp * za;
     const double cnud = -cb2 * d.nt[2] * cb3Inv;
     const double cam = ttm * cnud, cap = ttp * cnud;
     const double nutm = 0.5 * (d.nt[1] + d.nt[2]), nutp = 0.5 * (d.nt[3] + d.nt[2]);
@@ -97,10 +97,10 @@ __device__ __forceinline__ double sa_diffuse(const SaDir& d, double vol0, double
 // volume times the gradient of velocity component m (the Green-Gauss sum over the six faces), returns dvt (before advection /
 // diffusion)
 // qqOut (saSolve): -d(source)/d(nuTilde) clipped at zero, sa.F90:306-332
-__device__ __forceinline__ double sa_source(const KParams& kp, const double gu[3][3], double vol0, double nu, double nut, double d2,
+__device__ __forceinline__ double sa_source(const KParams& kp, const double gu[3][3], adf_real8 vol0, double nu, double nut, adf_real8 d2,
                                             double* qqOut = nullptr)
 {
-    const double fact = 0.25 * rcp_nr(vol0);
+    const adf_real8 fact = 0.25 * rcp_nr(vol0);
     double ss, strainMag2 = 0.0;
     if (kp.turbProd == ADFLOW_TURBPROD_STRAIN) {
         const double sxx = 2.0 * fact * gu[0][0], syy = 2.0 * fact * gu[1][1], szz = 2.0 * fact * gu[2][2];
@@ -115,11 +115,11 @@ __device__ __forceinline__ double sa_source(const KParams& kp, const double gu[3
         const double vortz = 2.0 * fact * (gu[1][0] - gu[0][1]);
         ss = fastsqrt(vortx * vortx + vorty * vorty + vortz * vortz);
     }
-    const double cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
-    const double kar2Inv = 1.0 / (kp.sa_k * kp.sa_k);
-    const double cw3_2 = kp.sa_cw3 * kp.sa_cw3;
-    const double cw36 = cw3_2 * cw3_2 * cw3_2;
-    const double dist2Inv = rcp_nr(d2 * d2);
+    const adf_real8 cv13 = kp.sa_cv1 * kp.sa_cv1 * kp.sa_cv1;
+    const adf_real8 kar2Inv = 1.0 / (kp.sa_k * kp.sa_k);
+    const adf_real8 cw3_2 = kp.sa_cw3 * kp.sa_cw3;
+    const adf_real8 cw36 = cw3_2 * cw3_2 * cw3_2;
+    const adf_real8 dist2Inv = rcp_nr(d2 * d2);
     const double chi = nut * rcp_nr(nu);
     const double chi2 = chi * chi, chi3 = chi * chi2;
     const double fv1 = chi3 * rcp_nr(chi3 + cv13);
