@@ -290,6 +290,11 @@ int g_lumped = 0;       // inputDiscretization::lumpedDiss while a preconditione
 int g_metric_from_x = 7;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march, bit 2 the time-step kernel re-form the face normals from the node coordinates;
                            // bit 3 the Roe march too (off: that kernel is bound by FP64 issue, the cross products cost more than the 6 loads saved - profiles/r02_ba_variants.txt)
 
+// the snapshot request of a Jacobian assembly (KParams::snapTab): set around the coloured evaluations of adflow_gpu_fd_jacobian
+struct SnapReq { bool on = false; SnapSlot* dev = nullptr; int devSlots = 0; int level = 0, col = 0, l0 = 0, n = 0; double deltaInv = 0.0, turbScale = 1.0; };
+static SnapReq g_snapreq;
+int g_jac_snap = 1;         // tuning "jac_snap": the marching kernels of the preconditioner matrix write the snapshots themselves (0: k_fd_snap / k_ad_snap)
+
 KParams make_kparams(int level, double rFil, int fwMode)
 {
     const adflow_opts& o = g_opts;
@@ -334,6 +339,10 @@ KParams make_kparams(int level, double rFil, int fwMode)
     k.cfl = (level == 1) ? o.cfl : o.cflCoarse;
     k.cflLimit = o.cflLimit; k.smoop = o.smoop; k.fcoll = o.fcoll; k.turbResScale = o.turbResScale;
     for (int i = 0; i < 10; ++i) k.wInf[i] = o.wInf[i];
+    if (g_snapreq.on && level == g_snapreq.level) {
+        k.snapTab = g_snapreq.dev; k.snapCol = g_snapreq.col; k.snapL0 = g_snapreq.l0; k.snapN = g_snapreq.n;
+        k.snapDeltaInv = g_snapreq.deltaInv; k.snapTurbScale = g_snapreq.turbScale;
+    }
     return k;
 }
 
@@ -995,6 +1004,27 @@ static bool has_wall_subfaces(int level);
 static bool level_has_subfaces(int level);
 
 // needGradHbm: the caller wants the nodal gradients in the block arrays (updateIntermed copy-out, blockette.F90:706-750)
+// the scheme of the preconditioner matrix that k_pc_march serves: first-order upwind (lumpedDiss, or the user's first-order limiter) on
+// the fine level, no matrix-free vector, no multigrid forcing
+static bool pc_march_scheme(const KParams& kp)
+{
+    const int lim = kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter;
+    return g_pc_fused && kp.spaceDiscr == ADFLOW_UPWIND && kp.fineGrid && lim == ADFLOW_LIM_FIRST_ORDER && !kp.rvec && !kp.coarseInit &&
+           roe_march_takes(kp);
+}
+// ... and the conditions under which enqueue_flow_residual reaches it (thin-layer viscous flux, blocks at rest, the marching kernels on)
+static bool pc_march_applies(int level, const KParams& kp, bool viscApprox)
+{
+    bool anyMoving = false;
+    for_level(level, [&](Block* b) { anyMoving = anyMoving || b->v.sFace || b->v.moving; return 0; });
+    return viscApprox && viscous_is_tiled() >= 2 && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !kp.fwMode && inviscid_march_enabled() &&
+           !anyMoving && pc_march_scheme(kp);
+}
+static bool ad_pc_march_applies(const KParams& kp, bool viscApprox)
+{
+    return viscApprox && viscous_is_tiled() >= 2 && kp.viscous && fabs(kp.rFil) >= 1.e-10 && pc_march_scheme(kp);
+}
+
 static int enqueue_flow_residual(int level, const KParams& kp, bool viscApprox = false, bool lowSpeed = true, bool stage0 = true,
                                  bool needGradHbm = false)
 {
@@ -1104,9 +1134,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     if (rc) return rc;
     if (approxMarch) {
         if (ensure_tiles(level)) return 1;
-        const int limPC = kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter;
-        if (approxFirst && g_pc_fused && kp.spaceDiscr == ADFLOW_UPWIND && kp.fineGrid && limPC == ADFLOW_LIM_FIRST_ORDER && !kp.rvec &&
-            !kp.coarseInit && roe_march_takes(kp)) {
+        if (approxFirst && pc_march_scheme(kp)) {
             // first-order upwind + thin-layer viscous flux: both are functions of the two cells of a face -- one march, dw written once
             phase_mark(4);
             launch_pc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream);
@@ -1719,9 +1747,7 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
         } else
             ad_launch_sa_residual_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
     }
-    const int limPC = kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter;
-    if ((resFlags & ADFLOW_RES_FLOW) && g_pc_fused && viscApprox && kp.viscous && fabs(kp.rFil) >= 1.e-10 && kp.spaceDiscr == ADFLOW_UPWIND &&
-        kp.fineGrid && limPC == ADFLOW_LIM_FIRST_ORDER && roe_march_takes(kp) && viscous_is_tiled() >= 2) {
+    if ((resFlags & ADFLOW_RES_FLOW) && ad_pc_march_applies(kp, viscApprox)) {
         // the preconditioner matrix on the upwind scheme: the dual form of the one-march residual (kernels_pc_march.hip) instead of the
         // gather kernels (blocks at rest: moving blocks were refused by the caller)
         rc = for_level(level, [&](Block* b) {
@@ -1747,9 +1773,33 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
     return 0;
 }
 
+// the device table of the snapshot request: per block slot of the level its snapshot array and its scaled reference residual
+static int snap_request_begin(int level, const JacSpec& J, double deltaInv)
+{
+    if (ensure_table(level)) return 1;
+    const int n = g_tab_size[level] + 1;
+    std::vector<SnapSlot> h((size_t)n, SnapSlot{nullptr, nullptr});
+    for (auto& kv : g_blocks)
+        if (std::get<0>(kv.first) == level && std::get<1>(kv.first) == 1) h[std::get<2>(kv.first)] = SnapSlot{kv.second->snap, kv.second->dwref};
+    if (g_snapreq.devSlots < n) {
+        if (g_snapreq.dev) (void)hipFree(g_snapreq.dev);
+        g_snapreq.dev = nullptr; g_snapreq.devSlots = 0;
+        HIPCHK(hipMalloc((void**)&g_snapreq.dev, sizeof(SnapSlot) * (size_t)n));
+        g_snapreq.devSlots = n;
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));
+    HIPCHK(hipMemcpy(g_snapreq.dev, h.data(), sizeof(SnapSlot) * (size_t)n, hipMemcpyHostToDevice));
+    g_snapreq.level = level; g_snapreq.col = 0; g_snapreq.l0 = J.lStart; g_snapreq.n = J.nState;
+    g_snapreq.deltaInv = deltaInv; g_snapreq.turbScale = g_opts.turbResScale;
+    g_snapreq.on = true;
+    return 0;
+}
+struct SnapRequestGuard { ~SnapRequestGuard() { g_snapreq.on = false; } };
+
 int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
 {
     if (need_ready()) return 1;
+    SnapRequestGuard snapGuard;        // no exit leaves the request standing
     if (flags & ~(ADFLOW_JAC_PC | ADFLOW_JAC_FROZEN_TURB | ADFLOW_JAC_TURB_ONLY | ADFLOW_JAC_VISC_PC | ADFLOW_JAC_USE_AD))
         return fail("fd_jacobian: unknown flags 0x%x", flags);
     const bool useAD = (flags & ADFLOW_JAC_USE_AD) != 0;
@@ -1832,15 +1882,25 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
         // one forward-mode evaluation per (colour, state variable): seed = 1 on component l of the cells of the colour (halos
         // included), block_res_state_d, the derivative of the scaled residual is the column of every stencil block
         if (!rc) rc = ad_prepare(level);
+        // the marching kernels of the preconditioner matrix write the snapshot of a pass themselves (KParams::snapTab)
+        bool snapInMarch = false;
+        if (!rc) {
+            const KParams kq = ad_kparams(level, resFlags);
+            const bool viscApproxA = (resFlags & ADFLOW_RES_VISC_APPROX) != 0 && !(flags & ADFLOW_JAC_VISC_PC);
+            snapInMarch = g_jac_snap && (!(resFlags & ADFLOW_RES_FLOW) || ad_pc_march_applies(kq, viscApproxA)) &&
+                          (!(resFlags & ADFLOW_RES_TURB) || (g_sa_march && g_pc_fused));
+            if (snapInMarch) rc = snap_request_begin(level, J, 0.0);
+        }
         for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
             for (int col = 0; col < J.cn && !rc; ++col) {
+                g_snapreq.col = col;
                 const KParams kps = ad_kparams(level, resFlags);
                 rc = for_level(level, [&](Block* b) {
                     ad_launch_seed_closures(b->v, g_ad[b].v, l, col, J, kps, g_stream);
                     return 0;
                 });
                 if (!rc) rc = ad_block_res_state_enqueue(level, resFlags, turbBC, (flags & ADFLOW_JAC_VISC_PC) != 0, true);
-                if (!rc) rc = for_level(level, [&](Block* b) {
+                if (!rc && !snapInMarch) rc = for_level(level, [&](Block* b) {
                     ad_launch_snap(b->v, g_ad[b].v.dw, b->snap + (size_t)col * J.nState * b->v.nbox, J, g_opts.turbResScale, g_stream);
                     return 0;
                 });
@@ -1850,6 +1910,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
                 return 0;
             });
         }
+        g_snapreq.on = false;
         if (!rc) rc = sync_and_check();
         else (void)hipStreamSynchronize(g_stream);
         if (!g_ad_cache || rc) ad_drop();
@@ -1874,14 +1935,26 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
     // the reference loops colours outside and state variables inside; every (colour, variable) evaluation is independent, so the
     // loops are exchanged here: the nColour evaluations of one variable are kept (dense) and scattered into the blocks together
     const KParams kpc = make_kparams(level, 1.0, 0);
+    // the marching kernels of the preconditioner matrix write the snapshot of an evaluation themselves (KParams::snapTab): not with
+    // actuator regions (their sources are added to dw behind the core)
+    bool snapInMarch = false;
+    if (!rc) {
+        bool moving = false;
+        for_level(level, [&](Block* b) { moving = moving || b->v.sFace || b->v.moving; return 0; });
+        snapInMarch = g_jac_snap && g_act.empty() &&
+                      (!(resFlags & ADFLOW_RES_FLOW) || pc_march_applies(level, kpc, (resFlags & ADFLOW_RES_VISC_APPROX) != 0)) &&
+                      (!(resFlags & ADFLOW_RES_TURB) || (g_sa_march && !moving));
+        if (snapInMarch) rc = snap_request_begin(level, J, deltaInv);
+    }
     for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
         for (int col = 0; col < J.cn && !rc; ++col) {
+            g_snapreq.col = col;
             rc = for_level(level, [&](Block* b) {
                 launch_fd_state_closures(b->v, b->wref, l, col, J, delta, kpc, g_stream);
                 return 0;
             });
             if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC, true);
-            if (!rc) rc = for_level(level, [&](Block* b) {
+            if (!rc && !snapInMarch) rc = for_level(level, [&](Block* b) {
                 launch_fd_snap(b->v, b->dwref, b->snap + (size_t)col * J.nState * b->v.nbox, J, deltaInv, g_opts.turbResScale, g_stream);
                 return 0;
             });
@@ -1891,6 +1964,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
             return 0;
         });
     }
+    g_snapreq.on = false;
     // resetFDReference (adjointUtils.F90:2026-2058): w back, dw = the (scaled) reference residual
     if (!rc) rc = for_level(level, [&](Block* b) {
         launch_fd_state(b->v, b->wref, 0, -1, J, 0.0, g_stream);
@@ -3901,6 +3975,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "front_overlap")) { g_front_overlap = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "test_fault")) { g_test_fault = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
+    if (!strcmp(key, "jac_snap")) { g_jac_snap = value; return 0; }
     if (!strcmp(key, "pc_fused")) { g_pc_fused = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_prefetch")) { g_gf_prefetch = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_waves")) {
@@ -3974,6 +4049,8 @@ static void free_side_buffers(void)
     g_norm_dev = nullptr;
     if (g_floor_flag_dev) (void)hipFree(g_floor_flag_dev);
     g_floor_flag_dev = nullptr;
+    if (g_snapreq.dev) (void)hipFree(g_snapreq.dev);
+    g_snapreq = SnapReq();
 #ifndef ADFLOW_NO_RCCL
     if (g_nccl) (void)ncclCommDestroy(g_nccl);
     g_nccl = nullptr;

@@ -285,7 +285,21 @@ struct KParams {
     // (NKSolvers.F90:1262-1376) of the PETSc-ordered residual vector (block offset BlkView::vecOff); NULL otherwise
     double* rvec;
     double rvecTurbScale;
+    // Jacobian assembly (adflow_gpu_fd_jacobian on the marching kernels of the preconditioner matrix): the kernels that complete the
+    // residual write the dense snapshot of the coloured evaluation -- (resScale(dw) - dwref) / delta, or the derivative part in forward
+    // mode -- INSTEAD of dw (k_fd_snap / k_ad_snap read dw back and wrote the same numbers); NULL otherwise.  snapTab: per block slot
+    // the snapshot array and the scaled reference residual; component m of colour snapCol at ((snapCol snapN + m) nbox); state variable
+    // l is component l - snapL0
+    const struct SnapSlot* snapTab;
+    int snapCol, snapL0, snapN;
+    double snapDeltaInv, snapTurbScale;
 };
+struct SnapSlot { double* snap; const double* dwref; };
+// plain build: the finite difference of one entry (kernels_ad.hip holds the form on dual numbers)
+__device__ __forceinline__ void snap_put(GPTR(double) sn, GPTR(const double) ref, unsigned c, double val, double deltaInv)
+{
+    stg(sn, c, (val - ldg(ref, c)) * deltaInv);
+}
 
 // ---- face normals of a cell from its eight corner nodes, the formulas (and operand order) of metric_block
 // (adjointExtra.F90:176-268, k_metric in kernels_geom.hip): a marching thread loads the two nodes (i, j, k) and (i, j-1, k) of

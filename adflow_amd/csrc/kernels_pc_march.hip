@@ -207,8 +207,18 @@ __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march(const BlkView
         for (int l = 0; l < 5; ++l) acc[l] += gk[l];
         if (out) {
             const adf_real8 blank = (flag0 & 64) ? 1.0 : 0.0;
-            stg(dw0, c, acc[0] * blank); stg(dw1, c, acc[1] * blank); stg(dw2, c, acc[2] * blank); stg(dw3, c, acc[3] * blank);
-            stg(dw4, c, acc[4] * blank);
+            if (kp.snapTab) {
+                // Jacobian assembly: resScale + the snapshot entry of this coloured evaluation instead of dw (KParams::snapTab)
+                const SnapSlot ss = kp.snapTab[t.x];
+                const adf_real8 ovol = 1.0 / ldg((GPTR(const adf_real8))b.volRef, c);
+                GPTR(adf_real8) sn = (GPTR(adf_real8))ss.snap + ((long)kp.snapCol * kp.snapN - kp.snapL0) * nb;
+                GPTR(const adf_real8) rf = (GPTR(const adf_real8))ss.dwref - (long)kp.snapL0 * nb;
+#pragma unroll
+                for (int l = 0; l < 5; ++l) snap_put(sn + l * nb, rf + l * nb, c, (acc[l] * blank) * ovol, kp.snapDeltaInv);
+            } else {
+                stg(dw0, c, acc[0] * blank); stg(dw1, c, acc[1] * blank); stg(dw2, c, acc[2] * blank); stg(dw3, c, acc[3] * blank);
+                stg(dw4, c, acc[4] * blank);
+            }
         }
         q0 = qp1;
         c += sk;

@@ -586,8 +586,14 @@ def test_pc_march_pair_of_kernels(hostsim_engine):
         e.set_tuning("pc_fused", 0)
         checks.check_fd_jacobian(e, (6, 5, 4), rans, tj.WALL, stretch_k=2.0)
         checks.check_ad_jacobian(e, (6, 5, 4), rans, tj.WALL, stretch_k=2.0)
+        # ... and the marches of the default path leaving dw to k_fd_snap / k_ad_snap (jac_snap = 0; 1 runs in the tests above)
+        e.set_tuning("pc_fused", 1)
+        e.set_tuning("jac_snap", 0)
+        checks.check_fd_jacobian(e, (6, 5, 4), rans, tj.WALL, stretch_k=2.0)
+        checks.check_ad_jacobian(e, (6, 5, 4), rans, tj.WALL, stretch_k=2.0)
     finally:
         e.set_tuning("pc_fused", 1)
+        e.set_tuning("jac_snap", 1)
 
 
 def test_update_wall_distances_quickly(hostsim_engine):
