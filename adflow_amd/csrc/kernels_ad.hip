@@ -20,16 +20,18 @@
 
 // ---- the helpers of internal.h for dual arguments (the fast reciprocal / root forms are plain operations here)
 // (round 5: value by the same fast form as the plain build, derivative from it -- the IEEE divisions and roots of `1.0 / b` cost the
-//  dual kernels 3.5 x the transcendental seeds of the plain ones)
+//  dual kernels 3.5 x the transcendental seeds of the plain ones.  The derivative is formed factor by factor, never through r^2 or
+//  r^3 alone: the entropy fix of roe_face.h takes the reciprocal of (z1l + z1r) max(eta, 1e-290), whose square overflows where the
+//  two states of a face are equal -- found by tests/fuzz_parity.py --jac on an extrapolated halo)
 __device__ __forceinline__ Dual rcp_nr(const Dual& b)
 {
     const double r = rcp_nr(b.v);
-    return Dual(r, -(r * r) * b.d);
+    return Dual(r, -(r * b.d) * r);
 }
 __device__ __forceinline__ Dual rsq_nr(const Dual& x)
 {
     const double r = rsq_nr(x.v);
-    return Dual(r, (-0.5 * r) * (r * r) * x.d);
+    return Dual(r, (((-0.5 * r) * x.d) * r) * r);
 }
 __device__ __forceinline__ Dual fastdiv(const Dual& a, const Dual& b)
 {
@@ -39,7 +41,7 @@ __device__ __forceinline__ Dual fastdiv(const Dual& a, const Dual& b)
 __device__ __forceinline__ Dual fastdiv(double a, const Dual& b)
 {
     const double r = rcp_nr(b.v), q = a * r;
-    return Dual(q, -(q * r) * b.d);
+    return Dual(q, -(q * b.d) * r);
 }
 __device__ __forceinline__ Dual fastdiv(const Dual& a, double b)
 {

@@ -149,6 +149,37 @@ def draw_case(rng, huge=False):
     return (nx, ny, nz), kw, mk, entry
 
 
+def draw_jac_case(rng):
+    """--jac (late round 5): the two assemblies of setupStateResidualMatrix only -- forward mode and finite differences, mostly the
+    preconditioner matrix on the upwind scheme (the marching kernels k_pc_march / k_sa_march, plain and dual), blocks of one to three
+    tiles per direction with partial tiles, random boundary kinds, frozenTurb / useTurbOnly"""
+    eq = int(rng.choice([EulerEquations, NSEquations, RANSEquations], p=[0.1, 0.3, 0.6]))
+    sd = int(rng.choice([dissScalar, dissMatrix, upwind], p=[0.1, 0.1, 0.8]))
+    kw = dict(equations=eq, spaceDiscr=sd)
+    if sd == upwind:
+        kw["limiter"] = int(rng.choice([noLimiter, vanAlbeda, minmod]))
+    else:
+        kw["vis4"] = float(rng.choice([0.0156, 0.1]))
+    if eq == RANSEquations:
+        kw["orderTurb"] = int(rng.choice([firstOrder, secondOrder]))
+        kw["useft2SA"] = bool(rng.random() < 0.7)
+    if eq != EulerEquations and rng.random() < 0.3:
+        kw["muSuthDim"] = 1.0          # viscous-dominated
+    entry = "ad" if rng.random() < 0.5 else "pc"
+    usePC = bool(rng.random() < 0.85)
+    kinds = ([-1, -5, -6] if eq == EulerEquations else [-1, -3, -4, -6]) + ([-15, -9] if usePC else [])
+    turb = float(rng.random())
+    mk = dict(seed=int(rng.integers(1, 10 ** 6)), spec={f: int(rng.choice(kinds)) for f in range(1, 7)}, usePC=usePC,
+              frozenTurb=bool(eq == RANSEquations and turb < 0.2), useTurbOnly=bool(eq == RANSEquations and usePC and 0.2 <= turb < 0.35))
+    wide = rng.random() < 0.2
+    nx = int(rng.choice([58, 60, 61, 64, 121])) if wide else int(rng.integers(3, 12))
+    ny = int(rng.integers(3, 11))
+    nz = int(rng.integers(3, 8)) if wide else int(rng.choice([3, 4, 5, 6, 7, 20, 33]))
+    if eq != EulerEquations:
+        mk["stretch_k"] = 2.0
+    return (nx, ny, nz), kw, mk, entry
+
+
 def run_case(engine, dims, kw, mk, entry):
     prm = FlowParams(**kw)
     mk = dict(mk)
@@ -167,6 +198,8 @@ def run_case(engine, dims, kw, mk, entry):
                                            allow_degenerate=mk.get("floor_p", False), **mk)
     elif entry == "ad":
         checks.check_ad_jacobian(engine, dims, prm, mk.pop("spec"), usePC=mk.pop("usePC"), frozenTurb=mk.pop("frozenTurb"), seed=seed, **mk)
+    elif entry == "pc":
+        checks.check_fd_jacobian(engine, dims, prm, mk.pop("spec"), usePC=mk.pop("usePC"), frozenTurb=mk.pop("frozenTurb"), seed=seed, **mk)
     elif entry == "mg":
         nlev, d3 = mk.pop("nlev"), mk.pop("dims3")
         cyc = [0, 1, 0, -1] if nlev == 2 else [0, 1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1]
@@ -221,14 +254,14 @@ def run_case(engine, dims, kw, mk, entry):
         checks.check_block_res_vs_blockette(engine, dims, prm, update_intermed=(entry == "blockette_intermed"), seed=seed, **mk)
 
 
-def sweep(engine, cases, seed, only=-1, quiet=False, big=False):
+def sweep(engine, cases, seed, only=-1, quiet=False, big=False, jac=False):
     """Run `cases` random cases; returns (number run, description of the first failure or None)."""
     rng = np.random.default_rng(seed)
     for n in range(cases):
-        dims, kw, mk, entry = draw_case(rng, big)
+        dims, kw, mk, entry = draw_jac_case(rng) if jac else draw_case(rng, big)
         # round 5: the tuning keys of the new code paths at random (results never depend on them)
         tune = {"bc_merge": int(rng.choice([0, 1, 2])), "front_overlap": int(rng.integers(0, 2)), "gf_waves": int(rng.choice([4, 8])),
-                "gf_prefetch": int(rng.integers(0, 2)), "pc_fused": n % 2}      # (pc_fused without a draw: earlier seeds replay as they were)
+                "gf_prefetch": int(rng.integers(0, 2)), "pc_fused": n % 2, "jac_snap": (n // 2) % 2}      # (pc_fused, jac_snap without a draw: earlier seeds replay as they were)
         if only >= 0 and n != only:
             continue
         try:
@@ -240,7 +273,7 @@ def sweep(engine, cases, seed, only=-1, quiet=False, big=False):
         except AssertionError as ex:
             return n + 1, f"case {n} (seed {seed}): {dims} {entry} {kw} {mk} {tune}: {ex}"
         finally:
-            for k_, v_ in {"bc_merge": 1, "front_overlap": 0, "gf_waves": 4, "gf_prefetch": 0, "split_eval": 1, "pc_fused": 1}.items():
+            for k_, v_ in {"bc_merge": 1, "front_overlap": 0, "gf_waves": 4, "gf_prefetch": 0, "split_eval": 1, "pc_fused": 1, "jac_snap": 1}.items():
                 engine.set_tuning(k_, v_)
     return cases, None
 
@@ -252,6 +285,7 @@ def main():
     ap.add_argument("--gpu", action="store_true", help="the HIP library on cuda:0 instead of the emulator")
     ap.add_argument("--only", type=int, default=-1, help="run this case index only")
     ap.add_argument("--big", action="store_true", help="blocks of 100-200 x 5-40 x 40-100 cells (residual entry points only; for --gpu)")
+    ap.add_argument("--jac", action="store_true", help="the Jacobian assemblies only (draw_jac_case)")
     a = ap.parse_args()
     from adflow_amd.engine import Engine
     if a.gpu:
@@ -260,11 +294,11 @@ def main():
         from hostsim.build import build
         eng = Engine(0, _lib_path=build())
     t0 = time.time()
-    n, failure = sweep(eng, a.cases, a.seed, a.only, big=a.big)
+    n, failure = sweep(eng, a.cases, a.seed, a.only, big=a.big, jac=a.jac)
     if failure:
         print("FAIL", failure)
         print(f"reproduce: python tests/fuzz_parity.py --seed {a.seed} --cases {a.cases} --only {n - 1}" + (" --gpu" if a.gpu else "")
-              + (" --big" if a.big else ""))
+              + (" --big" if a.big else "") + (" --jac" if a.jac else ""))
     print(f"{n} cases, {1 if failure else 0} failures, {time.time() - t0:.0f} s")
     nfail = 1 if failure else 0
     eng.close()

@@ -119,6 +119,16 @@ def test_pc_march_fused_and_pair(engine, fused, snap):
         engine.set_tuning("jac_snap", 1)
 
 
+def test_ad_pc_equal_states_across_a_face(engine):
+    """extrapolated halos (supersonic outflow, -9) hold the state of the cell behind them: both states of the boundary face are EQUAL,
+    eta of the Roe entropy fix is exactly zero and its reciprocal is taken of (z1l + z1r) 1e-290 -- the derivative of the fast dual
+    reciprocal must not pass through r^2 (1e580).  Found by tests/fuzz_parity.py --jac (seed 3, case 1): NaN in every block"""
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=minmod, orderTurb=secondOrder, useft2SA=True)
+    spec = {1: -9, 2: -3, 3: -1, 4: -3, 5: -1, 6: -9}
+    checks.check_ad_jacobian(engine, (5, 6, 4), rans, spec, seed=284201, stretch_k=2.0)
+    checks.check_fd_jacobian(engine, (5, 6, 4), rans, spec, seed=284201, stretch_k=2.0)
+
+
 def test_reference_step(engine):
     """delta = 1e-9 as the reference: rounding differences of two correct residuals are amplified by 1e9, so only ~1e-6 of the
     largest entry is resolvable by ANY implementation (the reference against itself with another compiler flag included)"""

@@ -576,6 +576,11 @@ def test_ad_jacobian(hostsim_engine):
     checks.check_ad_jacobian(e, (7, 6, 5), rm.replace(limiter=vanAlbeda, useQCR=True), tj.OPEN, usePC=False, stretch_k=2.0)
 
 
+def test_ad_pc_equal_states_across_a_face(hostsim_engine):
+    import test_gpu_jacobian as tj
+    tj.test_ad_pc_equal_states_across_a_face(hostsim_engine)
+
+
 def test_pc_march_pair_of_kernels(hostsim_engine):
     """tuning pc_fused = 0: the kernels k_pc_march replaced in the preconditioner assembly (the default, 1, runs in the tests above)"""
     import test_gpu_jacobian as tj
