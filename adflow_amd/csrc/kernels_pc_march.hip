@@ -111,6 +111,9 @@ __device__ __forceinline__ void pc_ld3(GPTR(const adf_real8) a, unsigned o, unsi
     v[0] = ldg(a, o); v[1] = ldg(a, o + nb8); v[2] = ldg(a, o + 2u * nb8);
 }
 
+// SNAP: the Jacobian assembly's snapshot entry instead of dw (KParams::snapTab) -- a compile-time switch: in the dual build only the
+// derivative part of the result is stored then, and the value-only arithmetic behind it goes away
+template <bool SNAP>
 __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                             int kch)
 {
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march(const BlkView
         for (int l = 0; l < 5; ++l) acc[l] += gk[l];
         if (out) {
             const adf_real8 blank = (flag0 & 64) ? 1.0 : 0.0;
-            if (kp.snapTab) {
+            if (SNAP) {
                 // Jacobian assembly: resScale + the snapshot entry of this coloured evaluation instead of dw (KParams::snapTab)
                 const SnapSlot ss = kp.snapTab[t.x];
                 const adf_real8 ovol = 1.0 / ldg((GPTR(const adf_real8))b.volRef, c);
@@ -228,5 +231,6 @@ __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march(const BlkView
 void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)
 {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_pc_march, dim3(ntiles), dim3(64, PM_BY, 1), 0, s, tab, tiles, kp, kch);
+    if (kp.snapTab) hipLaunchKernelGGL(k_pc_march<true>, dim3(ntiles), dim3(64, PM_BY, 1), 0, s, tab, tiles, kp, kch);
+    else hipLaunchKernelGGL(k_pc_march<false>, dim3(ntiles), dim3(64, PM_BY, 1), 0, s, tab, tiles, kp, kch);
 }

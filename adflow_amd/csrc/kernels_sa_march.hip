@@ -100,7 +100,9 @@ __device__ __forceinline__ GsNbr gs_dn1(const GsNbr& q)
 // SOLVE (saSolve): also stores the right-hand side (scratch 0) and the central jacobian qq (scratch 1) of the DDADI line solves,
 // as k_sa_residual<true> (kernels_sa.hip)
 // RV: the residual also goes to the matrix-free residual vector kp.rvec (setRVec: dw / volRef * turbResScale)
-template <bool SOLVE, bool RV = false>
+// SNAP: the Jacobian assembly's snapshot entry instead of dw (KParams::snapTab; compile-time: in the dual build the value-only
+// arithmetic behind the stored derivative goes away)
+template <bool SOLVE, bool RV = false, bool SNAP = false>
 __global__ __launch_bounds__(64 * GS_BY, GS_MINWG) void k_sa_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
     const int4 tl = tiles[blockIdx.x];
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(64 * GS_BY, GS_MINWG) void k_sa_march(const BlkView
             if (outC) {
                 const adf_real8 blank = flg_blank((uint8_t)flag0);
                 const double d5 = -volRef0 * dvt * blank;
-                if (!SOLVE && !RV && kp.snapTab) {
+                if (SNAP) {
                     // Jacobian assembly: resScale + the snapshot entry of this coloured evaluation instead of dw (KParams::snapTab)
                     const SnapSlot ss = kp.snapTab[tl.x];
                     const long m = (long)kp.snapCol * kp.snapN + (5 - kp.snapL0);
@@ -281,6 +283,7 @@ void launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KP
         adf_note_rvec(2);
     } else
 #endif
-        hipLaunchKernelGGL((k_sa_march<false>), grd, blk, 0, s, tab, tiles, kp);     // (the dual build: the residual alone)
+        if (kp.snapTab) hipLaunchKernelGGL((k_sa_march<false, false, true>), grd, blk, 0, s, tab, tiles, kp);
+        else hipLaunchKernelGGL((k_sa_march<false>), grd, blk, 0, s, tab, tiles, kp);     // (the dual build: the residual alone, or its snapshot)
 }
 
