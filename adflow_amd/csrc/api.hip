@@ -20,6 +20,7 @@ int visc_gf_rows();
 int g_test_fault = 0;        // tuning "test_fault" (tests only): bit 0 = the hipGraph capture of a multigrid cycle reports failure, bit 1 = the
                              // split evaluation fails behind its fork -- the error paths must leave the library usable
 int g_front_overlap = 0;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions (off: measured no gain at N = 1, profiles/r05_e_ab.txt)
+int g_pc_handover = 3;       // tuning "pc_handover": k_pc_march_h (every j face once, the flux handed to the row above) -- bit 0: in the dual build, bit 1: in the plain one (both on: forward mode 152.6 -> 144.1 ms, finite differences 94.6 -> 91.4 ms, profiles/r05_x_ab.txt)
 int g_pc_fused = 1;          // tuning "pc_fused": first-order Roe + thin-layer viscous flux of the preconditioner matrix as ONE march (kernels_pc_march.hip), plain and dual
 int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
 
@@ -1137,7 +1138,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         if (approxFirst && pc_march_scheme(kp)) {
             // first-order upwind + thin-layer viscous flux: both are functions of the two cells of a face -- one march, dw written once
             phase_mark(4);
-            launch_pc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream);
+            launch_pc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream, (g_pc_handover & 2) != 0);
             phase_mark(5);
         } else if (approxFirst) {
             KParams kv = kp;
@@ -1758,7 +1759,7 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
             return 0;
         });
         if (rc || ensure_tiles(level)) return 1;
-        ad_launch_pc_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream);
+        ad_launch_pc_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream, (g_pc_handover & 1) != 0);
     } else if (resFlags & ADFLOW_RES_FLOW) {
         ad_launch_inviscid_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
         if (kp.viscous && fabs(kp.rFil) >= 1.e-10) {
@@ -3975,6 +3976,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "front_overlap")) { g_front_overlap = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "test_fault")) { g_test_fault = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
+    if (!strcmp(key, "pc_handover")) { g_pc_handover = value; return 0; }
     if (!strcmp(key, "jac_snap")) { g_jac_snap = value; return 0; }
     if (!strcmp(key, "pc_fused")) { g_pc_fused = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_prefetch")) { g_gf_prefetch = value; mg_graph_drop(); return 0; }

@@ -431,7 +431,7 @@ void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, co
 int inviscid_march_enabled();
 bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 // kernels_pc_march.hip: first-order Roe + thin-layer viscous flux in one march (the mean-flow residual of the preconditioner matrix)
-void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s);
+void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s, bool handover);
 bool roe_march_takes(const KParams& kp);
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
@@ -494,5 +494,5 @@ void ad_launch_inviscid_level(const BlkView* tab, int n, int nx, int ny, int nz,
 void ad_launch_viscous(const BlkView& adv, const KParams& kp, hipStream_t s);
 void ad_launch_viscous_approx(const BlkView& adv, const KParams& kp, hipStream_t s);
 void ad_launch_seed_closures(const BlkView& real, const BlkView& adv, int l, int col, const JacSpec& J, const KParams& kp, hipStream_t s);
-void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s);
+void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s, bool handover);
 void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);

@@ -228,9 +228,163 @@ __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march(const BlkView
     }
 }
 
-void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)
+// The same march with every j face evaluated ONCE (tuning "pc_handover"): a wave evaluates the j face ABOVE its cell and hands the flux
+// to the row above through LDS; the cell is completed one plane later, behind the next barrier, with the flux that arrived through its
+// lower j face.  The face below row 0 of the tile has no wave: wave (k mod 4) takes it in plane k (row j0-1 loaded by that wave, row
+// j0 from the LDS slot of wave 0).  3.25 instead of 4 face evaluations per cell -- what the dual build, bound by FP64 issue, is short of.
+template <bool SNAP>
+__global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march_h(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
+                                                            int kch)
+{
+    __shared__ double qx[2 * PM_BY * PM_NV * 64];       // state of the own cell of every row, by the parity of the plane
+    __shared__ double fj[2 * PM_BY * 5 * 64];           // flux handed to every row through its lower j face, by the parity of the plane
+    const int4 t = tiles[blockIdx.x];
+    if (t.x < 0) return;
+    const BlkView& b = tab[t.x];
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int i = t.y * PM_OUT + lane;          // columns i0-2 .. i0+61
+    const int j = 2 + t.z * PM_BY + row;
+    const int k0 = 2 + t.w * kch;
+    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
+    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
+    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.je) ? j : b.je;
+    const long nb = b.nbox;
+    // byte offsets of 8-byte elements, for the geometry and the state alike (the dual forms of ldg / stg double them, kernels_ad.hip)
+    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
+    const unsigned sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk, nb8 = 8u * (unsigned)nb;
+    PcPtrs m;
+    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w4 = m.w3 + nb;
+    m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.rev = (GPTR(const double))b.rev;
+    GPTR(const adf_real8) sI = (GPTR(const adf_real8))b.sI; GPTR(const adf_real8) sJ = (GPTR(const adf_real8))b.sJ;
+    GPTR(const adf_real8) sK = (GPTR(const adf_real8))b.sK;
+    GPTR(const adf_real8) dI = (GPTR(const adf_real8))b.dI; GPTR(const adf_real8) dJ = (GPTR(const adf_real8))b.dJ;
+    GPTR(const adf_real8) dK = (GPTR(const adf_real8))b.dK;
+    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
+    GPTR(double) dw0 = (GPTR(double))b.dw;
+    GPTR(double) dw1 = dw0 + nb; GPTR(double) dw2 = dw1 + nb; GPTR(double) dw3 = dw2 + nb; GPTR(double) dw4 = dw3 + nb;
+
+    RmK K;
+    K.doDiss = fabs(kp.rFil) >= 1.e-10;
+    K.omk = 0.0; K.opk = 0.0; K.factMinmod = 0.0;
+    K.gam = kp.gammaConstant; K.gm1 = kp.gammaConstant - 1.0; K.ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
+    K.porDiss = 0.5 * kp.rFil;
+    PcK V;
+    V.porV = 0.5 * kp.rFil; V.eddy = kp.eddyModel != 0; V.gam = kp.gammaConstant;
+    V.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); V.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
+
+    PcCell q0 = pc_ld(m, c, V);
+    double gk[5];               // what enters the cell through its lower k face
+    {
+        const PcCell qm1 = pc_ld(m, c - sk, V);
+        adf_real8 nK[3], dKv[3];
+        pc_ld3(sK, c - sk, nb8, nK); pc_ld3(dK, c - sk, nb8, dKv);
+        pc_face(K, V, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), gk);
+    }
+    // row j0 of the tile in plane k0 (the fifth j face lies below it; not c - row sj: rows beyond the block are clamped)
+    const unsigned cE = 8u * (unsigned)(ic + (2 + t.z * PM_BY) * b.ldi + k0 * b.ldk);
+    double accP[5] = {0, 0, 0, 0, 0};                   // cell k-1: everything but the flux through its lower j face
+    int flagm = 0;
+    auto row_state = [&](const double* __restrict__ qb, int r) {
+        const double* __restrict__ qi = qb + r * (PM_NV * 64) + lane;
+        PcCell q;
+        q.rho = qi[0]; q.u = qi[64]; q.v = qi[128]; q.w = qi[192]; q.p = qi[256]; q.e = qi[320]; q.na = qi[384];
+        q.rlv = qi[448]; q.rev = qi[512];
+        return q;
+    };
+    // completes the cell of the plane below c with the flux handed over in that plane, and writes it
+    auto finish = [&](int kdone) {
+        const double* __restrict__ fi = fj + (kdone & 1) * (PM_BY * 5 * 64) + row * (5 * 64) + lane;
+        if (out) {
+            const unsigned cw = c - sk;
+            const adf_real8 blank = (flagm & 64) ? 1.0 : 0.0;
+            if (SNAP) {
+                const SnapSlot ss = kp.snapTab[t.x];
+                const adf_real8 ovol = 1.0 / ldg((GPTR(const adf_real8))b.volRef, cw);
+                GPTR(adf_real8) sn = (GPTR(adf_real8))ss.snap + ((long)kp.snapCol * kp.snapN - kp.snapL0) * nb;
+                GPTR(const adf_real8) rf = (GPTR(const adf_real8))ss.dwref - (long)kp.snapL0 * nb;
+#pragma unroll
+                for (int l = 0; l < 5; ++l) snap_put(sn + l * nb, rf + l * nb, cw, ((accP[l] - fi[l * 64]) * blank) * ovol, kp.snapDeltaInv);
+            } else {
+                stg(dw0, cw, (accP[0] - fi[0]) * blank); stg(dw1, cw, (accP[1] - fi[64]) * blank); stg(dw2, cw, (accP[2] - fi[128]) * blank);
+                stg(dw3, cw, (accP[3] - fi[192]) * blank); stg(dw4, cw, (accP[4] - fi[256]) * blank);
+            }
+        }
+    };
+    for (int k = k0; k <= k1; ++k) {
+        double* __restrict__ qb = qx + (k & 1) * (PM_BY * PM_NV * 64);
+        double* __restrict__ fb = fj + (k & 1) * (PM_BY * 5 * 64);
+        {
+            double* __restrict__ qo = qb + row * (PM_NV * 64) + lane;
+            qo[0] = q0.rho; qo[64] = q0.u; qo[128] = q0.v; qo[192] = q0.w; qo[256] = q0.p; qo[320] = q0.e; qo[384] = q0.na;
+            qo[448] = q0.rlv; qo[512] = q0.rev;
+        }
+        const bool fifth = (wave_uniform(row) == (k & 3));      // this wave evaluates the face below row 0 in this plane
+        // ---- request: the next plane, the geometry of the three faces, the row above the tile; the fifth face: row j0-1 and its geometry
+        const PcCell qp1 = pc_ld(m, c + sk, V);
+        const int flag0 = flags[c >> 3];
+        adf_real8 nI[3], dIv[3], nJ[3], dJv[3], nK[3], dKv[3], nE[3], dE[3];
+        pc_ld3(sI, c, nb8, nI); pc_ld3(dI, c, nb8, dIv);
+        pc_ld3(sJ, c, nb8, nJ); pc_ld3(dJ, c, nb8, dJv);
+        pc_ld3(sK, c, nb8, nK); pc_ld3(dK, c, nb8, dKv);
+        PcCell qjp, qE;
+        int flagE = 0;
+        if (row == PM_BY - 1) qjp = pc_ld(m, c + sj, V);
+        if (fifth) {
+            const unsigned ce = cE + (unsigned)(k - k0) * sk - sj;
+            qE = pc_ld(m, ce, V);
+            pc_ld3(sJ, ce, nb8, nE); pc_ld3(dJ, ce, nb8, dE);
+            flagE = flags[ce >> 3];
+        }
+        __syncthreads();
+        if (k > k0) finish(k - 1);
+        double acc[5], G[5];
+        // ---- i face (i | i+1); the face (i-1 | i) comes from lane-1
+        {
+            const PcCell qR = pc_dn1(q0);
+            pc_face(K, V, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), G);
+#pragma unroll
+            for (int l = 0; l < 5; ++l) acc[l] = (G[l] - lane_up1(G[l])) - gk[l];
+        }
+        // ---- j face (j | j+1): its flux leaves this cell and is handed to the row above
+        if (row < PM_BY - 1) qjp = row_state(qb, row + 1);
+        pc_face(K, V, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), G);
+#pragma unroll
+        for (int l = 0; l < 5; ++l) acc[l] += G[l];
+        if (row < PM_BY - 1) {
+            double* __restrict__ fo = fb + (row + 1) * (5 * 64) + lane;
+#pragma unroll
+            for (int l = 0; l < 5; ++l) fo[l * 64] = G[l];
+        }
+        // ---- the fifth j face (j0-1 | j0)
+        if (fifth) {
+            const PcCell qE0 = row_state(qb, 0);
+            pc_face(K, V, qE, qE0, nE, dE, flg_porJ((uint8_t)flagE), G);
+            double* __restrict__ fo = fb + lane;
+#pragma unroll
+            for (int l = 0; l < 5; ++l) fo[l * 64] = G[l];
+        }
+        // ---- k face above the cell
+        pc_face(K, V, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), gk);
+#pragma unroll
+        for (int l = 0; l < 5; ++l) accP[l] = acc[l] + gk[l];
+        flagm = flag0;
+        q0 = qp1;
+        c += sk;
+    }
+    __syncthreads();
+    finish(k1);
+}
+
+
+void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s, bool handover)
 {
     if (ntiles <= 0) return;
-    if (kp.snapTab) hipLaunchKernelGGL(k_pc_march<true>, dim3(ntiles), dim3(64, PM_BY, 1), 0, s, tab, tiles, kp, kch);
-    else hipLaunchKernelGGL(k_pc_march<false>, dim3(ntiles), dim3(64, PM_BY, 1), 0, s, tab, tiles, kp, kch);
+    const dim3 grd(ntiles), blk(64, PM_BY, 1);
+    if (handover) {
+        if (kp.snapTab) hipLaunchKernelGGL(k_pc_march_h<true>, grd, blk, 0, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL(k_pc_march_h<false>, grd, blk, 0, s, tab, tiles, kp, kch);
+    } else {
+        if (kp.snapTab) hipLaunchKernelGGL(k_pc_march<true>, grd, blk, 0, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL(k_pc_march<false>, grd, blk, 0, s, tab, tiles, kp, kch);
+    }
 }

@@ -596,9 +596,18 @@ def test_pc_march_pair_of_kernels(hostsim_engine):
         e.set_tuning("jac_snap", 0)
         checks.check_fd_jacobian(e, (6, 5, 4), rans, tj.WALL, stretch_k=2.0)
         checks.check_ad_jacobian(e, (6, 5, 4), rans, tj.WALL, stretch_k=2.0)
+        # ... and k_pc_march (both j faces per cell) instead of k_pc_march_h (pc_handover = 0; 3 runs in the tests above); ny = 10: a
+        # tile whose last rows lie beyond the block
+        e.set_tuning("jac_snap", 1)
+        e.set_tuning("pc_handover", 0)
+        checks.check_fd_jacobian(e, (5, 10, 4), rans, tj.OPEN, stretch_k=2.0)
+        checks.check_ad_jacobian(e, (5, 6, 4), rans, tj.WALL, stretch_k=2.0)
+        e.set_tuning("pc_handover", 3)
+        checks.check_fd_jacobian(e, (5, 10, 4), rans, tj.OPEN, stretch_k=2.0)
     finally:
         e.set_tuning("pc_fused", 1)
         e.set_tuning("jac_snap", 1)
+        e.set_tuning("pc_handover", 3)
 
 
 def test_update_wall_distances_quickly(hostsim_engine):
