@@ -363,6 +363,38 @@ def check_ad_jacobian(engine, dims, prm, spec, usePC=True, frozenTurb=False, use
     return Jg, Jr, st
 
 
+def check_jacobian_several_blocks(engine, prm, blocks_spec, seed=91, **mk):
+    """The preconditioner matrix of a LEVEL of several blocks of different sizes (slot numbers with a gap), by finite differences and
+    by forward mode: the marching path of round 5 -- k_pc_march_h + k_sa_march over the level's tile tables, the snapshot entries
+    written by the marches through the per-slot table KParams::snapTab at offsets that depend on the block's own box -- against the
+    same path with the snapshot kernels, against k_pc_march, and against the kernels it replaced (one launch per block, each of them
+    checked against the reference on single blocks in check_fd_jacobian / check_ad_jacobian).  Between two correct assemblies the
+    blocks differ by rounding x 1 / delta (finite differences) or by rounding (forward mode)."""
+    blocks, rblocks, prm = setup_blocks_with_bc(engine, prm, blocks_spec, seed=seed, **mk)
+    keys = {"pc_fused": 1, "jac_snap": 1, "pc_handover": 3}
+
+    def assemble(useAD, **tune):
+        for k_, v_ in {**keys, **tune}.items():
+            engine.set_tuning(k_, v_)
+        engine.setupStateResidualMatrix(1, True, delta=1e-6, useAD=useAD)
+        return {nn: engine.jacobianBlocks(nn).copy() for nn in blocks}
+
+    try:
+        for useAD, tol in ((False, 1e-7), (True, 2e-10)):
+            new = assemble(useAD)
+            others = {"snapshot kernels": assemble(useAD, jac_snap=0), "k_pc_march": assemble(useAD, pc_handover=0),
+                      "replaced kernels": assemble(useAD, pc_fused=0, jac_snap=0)}
+            for nn in blocks:
+                scale = np.abs(others["replaced kernels"][nn]).max()
+                assert scale > 0.0
+                for what, J in others.items():
+                    err = np.abs(new[nn] - J[nn]).max() / scale
+                    assert err <= tol, (("forward mode" if useAD else "finite differences"), what, nn, err, tol)
+    finally:
+        for k_, v_ in keys.items():
+            engine.set_tuning(k_, v_)
+
+
 def check_rk_residual_sequence(engine, dims, prm, seed=3, **mk):
     """residual() inside the RK smoother: rFil = cdisRK(stage+1) with the
     dissipation residual fw PERSISTENT between stages (residuals.F90:61-65,

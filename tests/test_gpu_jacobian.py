@@ -123,6 +123,16 @@ def test_pc_march_fused_and_pair(engine, fused, snap, handover):
         engine.set_tuning("pc_handover", 3)
 
 
+def test_pc_assemblies_on_a_level_of_several_blocks(engine):
+    """three blocks of different sizes in the slots 1, 2, 4: the level-batched marches of the preconditioner assemblies and the
+    per-slot snapshot table (checks.check_jacobian_several_blocks)"""
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda)
+    checks.check_jacobian_several_blocks(engine, rans, {
+        1: ((24, 8, 6), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, {5: -6}),
+        2: ((66, 6, 5), {1: -6, 2: -6, 3: -3, 4: -6, 5: -1, 6: -6}, ()),
+        4: ((10, 13, 9), {1: -6, 2: -15, 3: -3, 4: -6, 5: -1, 6: -1}, ())}, stretch_k=2.0)
+
+
 def test_ad_pc_equal_states_across_a_face(engine):
     """extrapolated halos (supersonic outflow, -9) hold the state of the cell behind them: both states of the boundary face are EQUAL,
     eta of the Roe entropy fix is exactly zero and its reciprocal is taken of (z1l + z1r) 1e-290 -- the derivative of the fast dual
