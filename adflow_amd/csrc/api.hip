@@ -1319,7 +1319,9 @@ static int block_res_enqueue(int level, unsigned flags)
         if (level_tab(level, &tc)) return 1;
         // when the whalo2 of this call follows (mean-flow variables incl. the energy), the energy it would recompute on the owned
         // cells is written by the same pass wherever the pressure kept its value (as FormFunction_mf does, kernels_nk.hip
-        // closures_body): a floored cell raises the device flag and whalo2's closing pass runs only then
+        // closures_body): a floored cell raises the device flag and whalo2's closing pass runs only then.  (The reference sends the old
+        // energy and recomputes afterwards, haloExchange.F90:154-196: a neighbour's halo energy differs by the rounding of p -> E -> p,
+        // DESIGN 4 round 4 (c))
         etotInClosures = (flags & ADFLOW_RES_HALO) && (flags & ADFLOW_RES_FLOW) && g_comm.count(std::make_pair(level, 2)) > 0;
         if (etotInClosures) {
             if (!g_floor_flag_dev) HIPCHK(hipMalloc((void**)&g_floor_flag_dev, sizeof(int)));
