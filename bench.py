@@ -727,9 +727,11 @@ def main():
                 eng.set_tuning("ad_cache", 1)
                 extra["pc_matrix_assembly_forward_ad"] = {
                     "ms": sad * 1e3, "forward_evaluations": 42, "ms_per_evaluation": sad * 1e3 / 42.0,
-                    "what": "adflow_gpu_fd_jacobian(PC | USE_AD): seed = 1 on one state variable of one colour per pass, dual-number "
-                            "twins of the gather kernels incl. closures and boundary conditions; the dual copies of the level's arrays "
-                            "(1 KB per box cell, one slab kept between calls) are refreshed from the library's arrays inside the call"}
+                    "what": "adflow_gpu_fd_jacobian(PC | USE_AD): seed = 1 on one state variable of one colour per pass; the marching "
+                            "kernels of the approximate residual on dual numbers (k_pc_march_h: first-order Roe + thin-layer viscous flux, "
+                            "k_sa_march), dual closures and boundary conditions, snapshots written by the marches; the dual copies of the "
+                            "level's arrays (640 B per box cell, one slab kept between calls) are refreshed from the library's arrays "
+                            "inside the call"}
                 log(f"PC matrix assembly, forward AD: {sad * 1e3:.1f} ms")
             if want("config3"):
                 # ---- config 3: one solver iteration = D-ADI x3 sub-iterations + SA DDADI x3 (test_functionals.py:136-160)
