@@ -292,7 +292,7 @@ int g_metric_from_x = 7;   // tuning "metric_from_x": bit 0 the SA march, bit 1 
                            // bit 3 the Roe march too (off: that kernel is bound by FP64 issue, the cross products cost more than the 6 loads saved - profiles/r02_ba_variants.txt)
 
 // the snapshot request of a Jacobian assembly (KParams::snapTab): set around the coloured evaluations of adflow_gpu_fd_jacobian
-struct SnapReq { bool on = false; SnapSlot* dev = nullptr; int devSlots = 0; int level = 0, col = 0, l0 = 0, n = 0; double deltaInv = 0.0, turbScale = 1.0; };
+struct SnapReq { bool on = false; SnapSlot* dev = nullptr; int devSlots = 0; int level = 0, col = 0, l0 = 0, n = 0; double turbScale = 1.0; };
 static SnapReq g_snapreq;
 int g_jac_snap = 1;         // tuning "jac_snap": the marching kernels of the preconditioner matrix write the snapshots themselves (0: k_fd_snap / k_ad_snap)
 
@@ -342,7 +342,7 @@ KParams make_kparams(int level, double rFil, int fwMode)
     for (int i = 0; i < 10; ++i) k.wInf[i] = o.wInf[i];
     if (g_snapreq.on && level == g_snapreq.level) {
         k.snapTab = g_snapreq.dev; k.snapCol = g_snapreq.col; k.snapL0 = g_snapreq.l0; k.snapN = g_snapreq.n;
-        k.snapDeltaInv = g_snapreq.deltaInv; k.snapTurbScale = g_snapreq.turbScale;
+        k.snapTurbScale = g_snapreq.turbScale;
     }
     return k;
 }
@@ -1777,13 +1777,13 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
 }
 
 // the device table of the snapshot request: per block slot of the level its snapshot array and its scaled reference residual
-static int snap_request_begin(int level, const JacSpec& J, double deltaInv)
+static int snap_request_begin(int level, const JacSpec& J)
 {
     if (ensure_table(level)) return 1;
     const int n = g_tab_size[level] + 1;
-    std::vector<SnapSlot> h((size_t)n, SnapSlot{nullptr, nullptr});
+    std::vector<SnapSlot> h((size_t)n, SnapSlot{nullptr});
     for (auto& kv : g_blocks)
-        if (std::get<0>(kv.first) == level && std::get<1>(kv.first) == 1) h[std::get<2>(kv.first)] = SnapSlot{kv.second->snap, kv.second->dwref};
+        if (std::get<0>(kv.first) == level && std::get<1>(kv.first) == 1) h[std::get<2>(kv.first)] = SnapSlot{kv.second->snap};
     if (g_snapreq.devSlots < n) {
         if (g_snapreq.dev) (void)hipFree(g_snapreq.dev);
         g_snapreq.dev = nullptr; g_snapreq.devSlots = 0;
@@ -1793,7 +1793,7 @@ static int snap_request_begin(int level, const JacSpec& J, double deltaInv)
     HIPCHK(hipStreamSynchronize(g_stream));
     HIPCHK(hipMemcpy(g_snapreq.dev, h.data(), sizeof(SnapSlot) * (size_t)n, hipMemcpyHostToDevice));
     g_snapreq.level = level; g_snapreq.col = 0; g_snapreq.l0 = J.lStart; g_snapreq.n = J.nState;
-    g_snapreq.deltaInv = deltaInv; g_snapreq.turbScale = g_opts.turbResScale;
+    g_snapreq.turbScale = g_opts.turbResScale;
     g_snapreq.on = true;
     return 0;
 }
@@ -1892,7 +1892,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
             const bool viscApproxA = (resFlags & ADFLOW_RES_VISC_APPROX) != 0 && !(flags & ADFLOW_JAC_VISC_PC);
             snapInMarch = g_jac_snap && (!(resFlags & ADFLOW_RES_FLOW) || ad_pc_march_applies(kq, viscApproxA)) &&
                           (!(resFlags & ADFLOW_RES_TURB) || (g_sa_march && g_pc_fused));
-            if (snapInMarch) rc = snap_request_begin(level, J, 0.0);
+            if (snapInMarch) rc = snap_request_begin(level, J);
         }
         for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
             for (int col = 0; col < J.cn && !rc; ++col) {
@@ -1909,7 +1909,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
                 });
             }
             if (!rc) rc = for_level(level, [&](Block* b) {
-                launch_fd_scatter(b->v, b->snap, b->jac, l, J, g_stream);
+                launch_fd_scatter(b->v, b->snap, b->jac, l, J, nullptr, 0.0, g_stream);
                 return 0;
             });
         }
@@ -1947,13 +1947,13 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
         snapInMarch = g_jac_snap && g_act.empty() &&
                       (!(resFlags & ADFLOW_RES_FLOW) || pc_march_applies(level, kpc, (resFlags & ADFLOW_RES_VISC_APPROX) != 0)) &&
                       (!(resFlags & ADFLOW_RES_TURB) || (g_sa_march && !moving));
-        if (snapInMarch) rc = snap_request_begin(level, J, deltaInv);
+        if (snapInMarch) rc = snap_request_begin(level, J);
     }
     for (int l = J.lStart; l < J.lStart + J.nState && !rc; ++l) {
         for (int col = 0; col < J.cn && !rc; ++col) {
             g_snapreq.col = col;
             rc = for_level(level, [&](Block* b) {
-                launch_fd_state_closures(b->v, b->wref, l, col, J, delta, kpc, g_stream);
+                launch_fd_state_closures(b->v, b->wref, l, col, J, delta, kpc, g_stream, col > 0 && !g_bc_callback);
                 return 0;
             });
             if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC, true);
@@ -1963,7 +1963,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
             });
         }
         if (!rc) rc = for_level(level, [&](Block* b) {
-            launch_fd_scatter(b->v, b->snap, b->jac, l, J, g_stream);
+            launch_fd_scatter(b->v, b->snap, b->jac, l, J, b->dwref, deltaInv, g_stream);
             return 0;
         });
     }

@@ -286,20 +286,16 @@ struct KParams {
     double* rvec;
     double rvecTurbScale;
     // Jacobian assembly (adflow_gpu_fd_jacobian on the marching kernels of the preconditioner matrix): the kernels that complete the
-    // residual write the dense snapshot of the coloured evaluation -- (resScale(dw) - dwref) / delta, or the derivative part in forward
-    // mode -- INSTEAD of dw (k_fd_snap / k_ad_snap read dw back and wrote the same numbers); NULL otherwise.  snapTab: per block slot
-    // the snapshot array and the scaled reference residual; component m of colour snapCol at ((snapCol snapN + m) nbox); state variable
-    // l is component l - snapL0
+    // residual write the dense snapshot of the coloured evaluation -- resScale(dw), or its derivative part in forward mode -- INSTEAD
+    // of dw (k_fd_snap / k_ad_snap read dw back and wrote the same numbers); NULL otherwise.  snapTab: per block slot the snapshot
+    // array; component m of colour snapCol at ((snapCol snapN + m) nbox); state variable l is component l - snapL0
     const struct SnapSlot* snapTab;
     int snapCol, snapL0, snapN;
-    double snapDeltaInv, snapTurbScale;
+    double snapTurbScale;
 };
-struct SnapSlot { double* snap; const double* dwref; };
-// plain build: the finite difference of one entry (kernels_ad.hip holds the form on dual numbers)
-__device__ __forceinline__ void snap_put(GPTR(double) sn, GPTR(const double) ref, unsigned c, double val, double deltaInv)
-{
-    stg(sn, c, (val - ldg(ref, c)) * deltaInv);
-}
+struct SnapSlot { double* snap; };
+// plain build: the scaled residual itself (k_fd_scatter forms the finite difference; kernels_ad.hip holds the form on dual numbers)
+__device__ __forceinline__ void snap_put(GPTR(double) sn, unsigned c, double val) { stg(sn, c, val); }
 
 // ---- face normals of a cell from its eight corner nodes, the formulas (and operand order) of metric_block
 // (adjointExtra.F90:176-268, k_metric in kernels_geom.hip): a marching thread loads the two nodes (i, j, k) and (i, j-1, k) of
@@ -354,9 +350,10 @@ struct JacSpec {
 };
 void launch_fd_state(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, hipStream_t s);
 void launch_fd_state_closures(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, const KParams& kp,
-                              hipStream_t s);
+                              hipStream_t s, bool onlyL = false);
 void launch_fd_snap(const BlkView& b, const double* dwref, double* snap, const JacSpec& J, double deltaInv, double turbResScale, hipStream_t s);
-void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, hipStream_t s);
+void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, const double* dwref, double deltaInv,
+                       hipStream_t s);
 void launch_jac_rows(const BlkView& b, const double* jac, double* out, int nState, int nStencil, int k0, int nk, hipStream_t s);
 void launch_fd_copy(const BlkView& b, double* dst, const double* src, int ncomp, hipStream_t s);
 void launch_closures_halo(const BlkView& b, const KParams& kp, hipStream_t s);

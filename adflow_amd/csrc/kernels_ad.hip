@@ -72,7 +72,7 @@ __device__ __forceinline__ void stg(GPTR(Dual) base, unsigned byteoff8, const Du
     *(GPTR(adf_v2))((GPTR(char))base + 2u * byteoff8) = t;
 }
 // the snapshot entry of a forward-mode pass: the derivative part (k_ad_snap; no reference residual, no step)
-__device__ __forceinline__ void snap_put(GPTR(double) sn, GPTR(const double), unsigned c, const Dual& val, double) { stg(sn, c, val.d); }
+__device__ __forceinline__ void snap_put(GPTR(double) sn, unsigned c, const Dual& val) { stg(sn, c, val.d); }
 __device__ __forceinline__ Dual lane_up1(const Dual& a) { return Dual(lane_up1(a.v), lane_up1(a.d)); }
 __device__ __forceinline__ Dual lane_dn1(const Dual& a) { return Dual(lane_dn1(a.v), lane_dn1(a.d)); }
 

@@ -31,9 +31,12 @@ __device__ __forceinline__ void closures_halo_at(const BlkView& b, const KParams
 
 // w <- wref (+ delta on component l of the cells of colour `col`); col < 0: plain restore.  CLOS: also the closures of
 // block_res_state from the new state (pressure on 0..ib, laminar / eddy viscosity on 1..ie) -- one pass instead of two
+// onlyL: the other components hold wref already (the sweep of ONE state variable over the colours changes component l alone: every
+// component is written at its first colour, afterwards 8 instead of 48 B per cell go out; the boundary conditions of an evaluation
+// write halos they own from the interior, whatever stood there)
 template <bool CLOS>
 __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_state(BlkView b, const double* __restrict__ wref, int l, int col, JacSpec J,
-                                                           double delta, KParams kp)
+                                                           double delta, KParams kp, int onlyL)
 {
     const int i = blockIdx.x * JC_BX + threadIdx.x - 14;     // aligned rows (the box origin is shifted by ADF_PAD0)
     const int j = blockIdx.y * JC_BY + threadIdx.y;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_state(BlkView b, const doub
     for (int m = 0; m < b.nw; ++m) {
         double v = wref[c + m * b.nbox];
         if (hit && m == l) v += delta;
-        b.w[c + m * b.nbox] = v;
+        if (!onlyL || m == l) b.w[c + m * b.nbox] = v;
         wv[m] = v;
     }
     if (CLOS) closures_halo_at(b, kp, i, j, k, c, wv);
@@ -123,7 +126,9 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_extract(BlkView b, double* 
     }
 }
 
-// finite differences of ONE coloured evaluation, stored densely: snap[m] = (resScale(dw)[m] - dwref[m]) / delta on the owned cells.
+// ONE coloured evaluation, stored densely: snap[m] = resScale(dw)[m] on the owned cells (late round 5: the difference against the
+// reference residual and the division by delta happen in k_fd_scatter, once per state variable and cell instead of once per
+// evaluation -- 42 x 48 B per cell of dwref reads less in an assembly).
 // The scatter into the stencil blocks happens once per state variable (k_fd_scatter): written per evaluation, every cell has ONE
 // matching stencil entry and consecutive lanes hit different entries -- 1/nColour-dense 8-byte stores into nStencil separate
 // streams ran at 0.3 TB/s (200 us per 1.3 M-cell block and evaluation, profiles/r02_ah)
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_snap(BlkView b, const doubl
     for (int m = 0; m < J.nState; ++m) {
         const int ll = J.lStart + m;
         const double val = b.dw[c + ll * nb] * ovol * (ll >= 5 ? turbResScale : 1.0);
-        snap[c + m * nb] = (val - dwref[c + m * nb]) * deltaInv;
+        snap[c + m * nb] = val;
     }
 }
 
@@ -151,9 +156,11 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_snap(BlkView b, const doubl
 // texture path).  So the snapshots of a cell pass through a lane-private LDS column: nColour coalesced loads, then nStencil
 // coalesced stores that pick their value from the column.
 // NC: capacity of the column (7 colours: 14 KB of LDS per workgroup; 35: 70 KB)
+// dwref (finite differences): the snapshots hold the scaled residuals of the evaluations, the entry is (snapshot - dwref) / delta;
+// NULL (forward mode): the snapshots hold the derivatives themselves
 template <int NC>
 __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_scatter(BlkView b, const double* __restrict__ snap, double* __restrict__ jac, int l,
-                                                             JacSpec J)
+                                                             JacSpec J, const double* __restrict__ dwref, double deltaInv)
 {
     __shared__ double col[JC_BY][NC][JC_BX];
     const int i = blockIdx.x * JC_BX + threadIdx.x + 2;
@@ -167,7 +174,11 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_scatter(BlkView b, const do
     double (*mine)[JC_BX] = col[threadIdx.y];
     const int lane = threadIdx.x;
     for (int m = 0; m < J.nState; ++m) {
-        for (int d = 0; d < J.cn; ++d) mine[d][lane] = snap[((long)d * J.nState + m) * nb + c];
+        if (dwref) {
+            const double ref = dwref[c + m * nb];
+            for (int d = 0; d < J.cn; ++d) mine[d][lane] = (snap[((long)d * J.nState + m) * nb + c] - ref) * deltaInv;
+        } else
+            for (int d = 0; d < J.cn; ++d) mine[d][lane] = snap[((long)d * J.nState + m) * nb + c];
         for (int s = 0; s < J.nStencil; ++s) {
             const int pi = i - J.st[s][0], pj = j - J.st[s][1], pk = k - J.st[s][2];      // the perturbed cell
             if (pi < 0 || pi > b.ib || pj < 0 || pj > b.jb || pk < 0 || pk > b.kb) continue;
@@ -222,13 +233,13 @@ static dim3 own_grid(const BlkView& b) { return dim3((b.nx + JC_BX - 1) / JC_BX,
 void launch_fd_state(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, hipStream_t s)
 {
     KParams kp = KParams();
-    hipLaunchKernelGGL((k_fd_state<false>), box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, wref, l, col, J, delta, kp);
+    hipLaunchKernelGGL((k_fd_state<false>), box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, wref, l, col, J, delta, kp, 0);
 }
 // state of one coloured evaluation and the closures of block_res_state in one pass
 void launch_fd_state_closures(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, const KParams& kp,
-                              hipStream_t s)
+                              hipStream_t s, bool onlyL)
 {
-    hipLaunchKernelGGL((k_fd_state<true>), box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, wref, l, col, J, delta, kp);
+    hipLaunchKernelGGL((k_fd_state<true>), box_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, wref, l, col, J, delta, kp, onlyL ? 1 : 0);
 }
 void launch_fd_copy(const BlkView& b, double* dst, const double* src, int ncomp, hipStream_t s)
 {
@@ -248,11 +259,12 @@ void launch_fd_snap(const BlkView& b, const double* dwref, double* snap, const J
 {
     hipLaunchKernelGGL(k_fd_snap, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, dwref, snap, J, deltaInv, turbResScale);
 }
-void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, hipStream_t s)
+void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, const double* dwref, double deltaInv,
+                       hipStream_t s)
 {
     const dim3 g = own_grid(b), t(JC_BX, JC_BY, 1);
-    if (J.cn <= 7) hipLaunchKernelGGL(k_fd_scatter<7>, g, t, 0, s, b, snap, jac, l, J);
-    else if (J.cn <= 13) hipLaunchKernelGGL(k_fd_scatter<13>, g, t, 0, s, b, snap, jac, l, J);
-    else if (J.cn <= 27) hipLaunchKernelGGL(k_fd_scatter<27>, g, t, 0, s, b, snap, jac, l, J);
-    else hipLaunchKernelGGL(k_fd_scatter<35>, g, t, 0, s, b, snap, jac, l, J);
+    if (J.cn <= 7) hipLaunchKernelGGL(k_fd_scatter<7>, g, t, 0, s, b, snap, jac, l, J, dwref, deltaInv);
+    else if (J.cn <= 13) hipLaunchKernelGGL(k_fd_scatter<13>, g, t, 0, s, b, snap, jac, l, J, dwref, deltaInv);
+    else if (J.cn <= 27) hipLaunchKernelGGL(k_fd_scatter<27>, g, t, 0, s, b, snap, jac, l, J, dwref, deltaInv);
+    else hipLaunchKernelGGL(k_fd_scatter<35>, g, t, 0, s, b, snap, jac, l, J, dwref, deltaInv);
 }

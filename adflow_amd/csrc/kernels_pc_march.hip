@@ -211,13 +211,12 @@ __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march(const BlkView
         if (out) {
             const adf_real8 blank = (flag0 & 64) ? 1.0 : 0.0;
             if (SNAP) {
-                // Jacobian assembly: resScale + the snapshot entry of this coloured evaluation instead of dw (KParams::snapTab)
+                // Jacobian assembly: resScale, the snapshot entry of this coloured evaluation instead of dw (KParams::snapTab)
                 const SnapSlot ss = kp.snapTab[t.x];
                 const adf_real8 ovol = 1.0 / ldg((GPTR(const adf_real8))b.volRef, c);
                 GPTR(adf_real8) sn = (GPTR(adf_real8))ss.snap + ((long)kp.snapCol * kp.snapN - kp.snapL0) * nb;
-                GPTR(const adf_real8) rf = (GPTR(const adf_real8))ss.dwref - (long)kp.snapL0 * nb;
 #pragma unroll
-                for (int l = 0; l < 5; ++l) snap_put(sn + l * nb, rf + l * nb, c, (acc[l] * blank) * ovol, kp.snapDeltaInv);
+                for (int l = 0; l < 5; ++l) snap_put(sn + l * nb, c, (acc[l] * blank) * ovol);
             } else {
                 stg(dw0, c, acc[0] * blank); stg(dw1, c, acc[1] * blank); stg(dw2, c, acc[2] * blank); stg(dw3, c, acc[3] * blank);
                 stg(dw4, c, acc[4] * blank);
@@ -301,9 +300,8 @@ __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march_h(const BlkVi
                 const SnapSlot ss = kp.snapTab[t.x];
                 const adf_real8 ovol = 1.0 / ldg((GPTR(const adf_real8))b.volRef, cw);
                 GPTR(adf_real8) sn = (GPTR(adf_real8))ss.snap + ((long)kp.snapCol * kp.snapN - kp.snapL0) * nb;
-                GPTR(const adf_real8) rf = (GPTR(const adf_real8))ss.dwref - (long)kp.snapL0 * nb;
 #pragma unroll
-                for (int l = 0; l < 5; ++l) snap_put(sn + l * nb, rf + l * nb, cw, ((accP[l] - fi[l * 64]) * blank) * ovol, kp.snapDeltaInv);
+                for (int l = 0; l < 5; ++l) snap_put(sn + l * nb, cw, ((accP[l] - fi[l * 64]) * blank) * ovol);
             } else {
                 stg(dw0, cw, (accP[0] - fi[0]) * blank); stg(dw1, cw, (accP[1] - fi[64]) * blank); stg(dw2, cw, (accP[2] - fi[128]) * blank);
                 stg(dw3, cw, (accP[3] - fi[192]) * blank); stg(dw4, cw, (accP[4] - fi[256]) * blank);

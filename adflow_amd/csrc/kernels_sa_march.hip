@@ -249,8 +249,7 @@ __global__ __launch_bounds__(64 * GS_BY, GS_MINWG) void k_sa_march(const BlkView
                     // Jacobian assembly: resScale + the snapshot entry of this coloured evaluation instead of dw (KParams::snapTab)
                     const SnapSlot ss = kp.snapTab[tl.x];
                     const long m = (long)kp.snapCol * kp.snapN + (5 - kp.snapL0);
-                    snap_put((GPTR(adf_real8))ss.snap + m * nb, (GPTR(const adf_real8))ss.dwref + (long)(5 - kp.snapL0) * nb, c,
-                             d5 * (1.0 / volRef0) * kp.snapTurbScale, kp.snapDeltaInv);
+                    snap_put((GPTR(adf_real8))ss.snap + m * nb, c, d5 * (1.0 / volRef0) * kp.snapTurbScale);
                 } else
                     stg(dw5, c, d5);
                 // setRVec of the matrix-free matvec: dw / volRef * turbResScale

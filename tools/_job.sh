@@ -1,2 +1,2 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_jacobian.py -m gpu -x -q 2>&1 | tail -6
+TAG=r05_z EXTRAS=pc ROWS=16 bash tools/_gpu_job_extras.sh
