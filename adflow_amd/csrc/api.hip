@@ -1899,7 +1899,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
                 g_snapreq.col = col;
                 const KParams kps = ad_kparams(level, resFlags);
                 rc = for_level(level, [&](Block* b) {
-                    ad_launch_seed_closures(b->v, g_ad[b].v, l, col, J, kps, g_stream);
+                    ad_launch_seed_closures(b->v, g_ad[b].v, l, col, J, kps, g_stream, col > 0);
                     return 0;
                 });
                 if (!rc) rc = ad_block_res_state_enqueue(level, resFlags, turbBC, (flags & ADFLOW_JAC_VISC_PC) != 0, true);

@@ -490,6 +490,7 @@ void ad_launch_sa_residual_level(const BlkView* tab, int n, int nx, int ny, int 
 void ad_launch_inviscid_level(const BlkView* tab, int n, int nx, int ny, int nz, const KParams& kp, hipStream_t s);
 void ad_launch_viscous(const BlkView& adv, const KParams& kp, hipStream_t s);
 void ad_launch_viscous_approx(const BlkView& adv, const KParams& kp, hipStream_t s);
-void ad_launch_seed_closures(const BlkView& real, const BlkView& adv, int l, int col, const JacSpec& J, const KParams& kp, hipStream_t s);
+void ad_launch_seed_closures(const BlkView& real, const BlkView& adv, int l, int col, const JacSpec& J, const KParams& kp, hipStream_t s,
+                             bool onlyL);
 void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s, bool handover);
 void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
