@@ -21,6 +21,7 @@ int g_test_fault = 0;        // tuning "test_fault" (tests only): bit 0 = the hi
                              // split evaluation fails behind its fork -- the error paths must leave the library usable
 int g_front_overlap = 0;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions (off: measured no gain at N = 1, profiles/r05_e_ab.txt)
 int g_pc_handover = 3;       // tuning "pc_handover": k_pc_march_h (every j face once, the flux handed to the row above) -- bit 0: in the dual build, bit 1: in the plain one (both on: forward mode 152.6 -> 144.1 ms, finite differences 94.6 -> 91.4 ms, profiles/r05_x_ab.txt)
+int g_rvec_joint = 1;        // tuning "rvec_joint": the six entries of a cell of the matrix-free residual vector written by ONE kernel (KParams::rvecTurbFromDw)
 int g_pc_fused = 1;          // tuning "pc_fused": first-order Roe + thin-layer viscous flux of the preconditioner matrix as ONE march (kernels_pc_march.hip), plain and dual
 int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
 
@@ -1021,6 +1022,15 @@ static bool pc_march_applies(int level, const KParams& kp, bool viscApprox)
     return viscApprox && viscous_is_tiled() >= 2 && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !kp.fwMode && inviscid_march_enabled() &&
            !anyMoving && pc_march_scheme(kp);
 }
+// the exact viscous residual on the upwind scheme ends in k_roe_march<.., ADDV, RV> when a matrix-free vector is the target
+// (enqueue_flow_residual: viscFirst): that kernel can write all six entries of a cell (KParams::rvecTurbFromDw)
+static bool roe_rv_completes(int level, const KParams& kp, bool viscApprox)
+{
+    bool anyMoving = false;
+    for_level(level, [&](Block* b) { anyMoving = anyMoving || b->v.sFace || b->v.moving; return 0; });
+    return kp.rvec && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !viscApprox && viscous_is_tiled() >= 2 && !kp.fwMode && inviscid_march_enabled() &&
+           !kp.dissApprox && !kp.lumpedDiss && !anyMoving && roe_march_takes(kp);
+}
 static bool ad_pc_march_applies(const KParams& kp, bool viscApprox)
 {
     return viscApprox && viscous_is_tiled() >= 2 && kp.viscous && fabs(kp.rFil) >= 1.e-10 && pc_march_scheme(kp);
@@ -1418,6 +1428,9 @@ static int block_res_enqueue(int level, unsigned flags)
             }
             if (g_sa_march && !moving) {
                 if (ensure_sa_tiles(level)) return 1;
+                // the matrix-free vector: the Roe march that follows in the same queue writes the turbulence entry with its own five
+                // (tuning "rvec_joint"; every block holds six variables here: checked above)
+                if (kp.rvec && g_rvec_joint && !saForked && (flags & ADFLOW_RES_FLOW) && roe_rv_completes(level, kp, viscApprox)) kp.rvecTurbFromDw = 1;
                 launch_sa_march(t.tab, g_sa_tiles[level].first, g_sa_tiles[level].second, kp, ss, false);
             } else launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, ss);
             if (saForked) HIPCHK(hipEventRecord(g_evB, g_streamB));
@@ -3978,6 +3991,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "front_overlap")) { g_front_overlap = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "test_fault")) { g_test_fault = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
+    if (!strcmp(key, "rvec_joint")) { g_rvec_joint = value; return 0; }
     if (!strcmp(key, "pc_handover")) { g_pc_handover = value; return 0; }
     if (!strcmp(key, "jac_snap")) { g_jac_snap = value; return 0; }
     if (!strcmp(key, "pc_fused")) { g_pc_fused = value; mg_graph_drop(); return 0; }

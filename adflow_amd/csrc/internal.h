@@ -285,6 +285,9 @@ struct KParams {
     // (NKSolvers.F90:1262-1376) of the PETSc-ordered residual vector (block offset BlkView::vecOff); NULL otherwise
     double* rvec;
     double rvecTurbScale;
+    // the turbulence entry of rvec is written by the Roe march from the dw(itu1) the SA march left (both run in one queue, SA first):
+    // the six entries of a cell go out together -- 48 contiguous bytes per cell instead of 40 + 8 from two kernels
+    int rvecTurbFromDw;
     // Jacobian assembly (adflow_gpu_fd_jacobian on the marching kernels of the preconditioner matrix): the kernels that complete the
     // residual write the dense snapshot of the coloured evaluation -- resScale(dw), or its derivative part in forward mode -- INSTEAD
     // of dw (k_fd_snap / k_ad_snap read dw back and wrote the same numbers); NULL otherwise.  snapTab: per block slot the snapshot

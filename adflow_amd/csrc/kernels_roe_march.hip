@@ -228,6 +228,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         rm_face(K, qm1, q0, ULk, URk0, nKx, nKy, nKz, flg_porK((uint8_t)flagm), fc, fd);    // normal and porosity stored at cell k-1
     };
     // finish cell k-1 with the flux through its lower j face (handed over in the plane before) and write it
+    double turbDw = 0.0;          // RV with rvecTurbFromDw: dw(itu1) of the cell finished in this step (requested with the viscous sums)
     auto finish = [&](int k, const double vsum[4]) {
         const double* __restrict__ xf = xj + ((k - 1) & 1) * RM_XJ(FW) + RM_UR;   // fluxes handed over in the plane before
         double fl[NF];
@@ -259,6 +260,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
                     if (RV) rv[l] = (d * blank) * ovv;
                 }
             }
+            if (RV && !FW && kp.rvecTurbFromDw) rv[5] = turbDw * ovv * kp.rvecTurbScale;
         }
     };
 
@@ -334,6 +336,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
 #pragma unroll
             for (int l = 0; l < 4; ++l) vsum[l] = ldg((GPTR(const double))dw + (l + 1) * nb, c - sk);
         }
+        if (RV && kp.rvecTurbFromDw && k > k0 && out) turbDw = ldg((GPTR(const double))dw + 5 * nb, c - sk);
         nJ[0] = ldg(sJx, c); nJ[1] = ldg(sJy, c); nJ[2] = ldg(sJz, c);
         nIn[0] = ldg(sIx, c + sk - 8u); nIn[1] = ldg(sIy, c + sk - 8u); nIn[2] = ldg(sIz, c + sk - 8u);
         const int flagp = flags[(c + sk) >> 3];
@@ -413,6 +416,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
 #pragma unroll
             for (int l = 0; l < 4; ++l) vsum[l] = ldg((GPTR(const double))dw + (l + 1) * nb, c - sk);
         }
+        if (RV && kp.rvecTurbFromDw && out) turbDw = ldg((GPTR(const double))dw + 5 * nb, c - sk);
         double ULk0[5];
         kface(qp1, nKx, nKy, nKz, ULk0, []() {});
         __syncthreads();
@@ -445,13 +449,13 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
     } else if (kp.viscFirst) {
         if (kp.rvec) {
             hipLaunchKernelGGL((k_roe_march<LIM, false, true, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
-            adf_note_rvec(1);
+            adf_note_rvec(kp.rvecTurbFromDw ? 3 : 1);
         } else
             hipLaunchKernelGGL((k_roe_march<LIM, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
         if (final_ && kp.rvec) {
             hipLaunchKernelGGL((k_roe_march<LIM, false, true, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
-            adf_note_rvec(1);
+            adf_note_rvec(kp.rvecTurbFromDw ? 3 : 1);
         } else if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
     }

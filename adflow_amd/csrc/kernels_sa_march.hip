@@ -277,7 +277,7 @@ void launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KP
     const dim3 grd(ntiles), blk(64, GS_BY, 1);
 #ifndef ADF_AD_BUILD
     if (solve) hipLaunchKernelGGL((k_sa_march<true>), grd, blk, 0, s, tab, tiles, kp);
-    else if (kp.rvec) {
+    else if (kp.rvec && !kp.rvecTurbFromDw) {
         hipLaunchKernelGGL((k_sa_march<false, true>), grd, blk, 0, s, tab, tiles, kp);
         adf_note_rvec(2);
     } else

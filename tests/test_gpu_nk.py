@@ -32,6 +32,21 @@ def test_nk_residual_vector_stores_of_the_marches(engine):
     checks.check_nk_residual(engine, BrickTopology(1, 2, 1, 63, 5, 4), FlowParams(spaceDiscr=upwind))
 
 
+@pytest.mark.parametrize("joint", [0, 1])
+def test_nk_residual_vector_entries_of_a_cell_by_one_kernel(engine, joint):
+    """tuning rvec_joint: the Roe march writes the turbulence entry of the matrix-free vector with its own five, from the dw(itu1) the
+    SA march left (1, the default: 48 contiguous bytes per cell), or the SA march writes it itself (0).  A periodic brick of two blocks
+    with several tiles and k chunks, and one block with six boundary subfaces (the wall-bounded whole evaluation)"""
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
+    try:
+        engine.set_tuning("rvec_joint", joint)
+        checks.check_nk_residual(engine, BrickTopology(2, 1, 1, 70, 9, 37), rans, stretch_k=2.0)
+        checks.check_nk_residual(engine, BrickTopology(1, 1, 1, 13, 9, 6), rans,
+                                 bc_spec={1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}, stretch_k=2.0)
+    finally:
+        engine.set_tuning("rvec_joint", 1)
+
+
 def test_nk_residual_with_floored_pressures(engine):
     """every fifth cell of the vector has less total than kinetic energy: computePressureSimple floors p, whalo2 exchanges the vector's
     energy and recomputes the owned one afterwards (the device pass that does it runs only in this case)"""

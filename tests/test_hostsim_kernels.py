@@ -216,6 +216,13 @@ def test_nk_residual(hostsim_engine):
     checks.check_nk_residual(hostsim_engine, BrickTopology(1, 1, 1, 61, 3, 3), FlowParams(spaceDiscr=upwind))
     # pressures at the floor: the halos take the energy of the vector, the owned cells the recomputed one
     checks.check_nk_residual(hostsim_engine, BrickTopology(2, 2, 1, 6, 5, 4), FlowParams(), floor_p=True)
+    # tuning rvec_joint = 0: the SA march writes the turbulence entry of the vector itself (1, the default, ran above)
+    try:
+        hostsim_engine.set_tuning("rvec_joint", 0)
+        checks.check_nk_residual(hostsim_engine, BrickTopology(1, 2, 1, 6, 5, 4),
+                                 FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
+    finally:
+        hostsim_engine.set_tuning("rvec_joint", 1)
 
 
 def test_sa_ddadi_solve(hostsim_engine):
