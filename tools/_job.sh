@@ -1,4 +1,7 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_nk.py tests/test_gpu_bc.py -m gpu -x -q 2>&1 | tail -3
-for J in 0 1 0 1; do echo "rvec_joint=$J"; python bench.py --no-cpu-baseline --steps 5 --warmup 2 --min-seconds 0.2 --only-extras matvec --force-extras --tuning rvec_joint=$J 2>&1 | grep -a "config 5"; done | tee $O/r05_za_ab.txt
+export GIT=c67b1d3
+TAG=r05_fin3 bash tools/_gpu_job_full.sh
+TAG=r05_fin3 EXTRAS="pc config3 config2 matvec" ROWS=10 bash tools/_gpu_job_extras.sh
+cd $GRAFT_REPO_ROOT
+O=gpurun_out
+( timeout 300 python tests/fuzz_parity.py --gpu --cases 2000 --seed 91 2>&1 | tail -1; timeout 200 python tests/fuzz_parity.py --gpu --big --cases 100 --seed 92 2>&1 | tail -1; timeout 300 python tests/fuzz_parity.py --gpu --jac --cases 2500 --seed 93 2>&1 | tail -1 ) | cut -c1-300 | tee $O/r05_fin3_fuzz.txt
+TAG=r05_fin3 bash tools/_gpu_job_sq.sh 2>&1 | tail -6
