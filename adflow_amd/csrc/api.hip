@@ -1850,7 +1850,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
             b->jac = (double*)b->jac_raw + ADF_PAD0;
             b->jac_ncomp = ncomp;
         }
-        HIPCHK(hipMemsetAsync(b->jac_raw, 0, (size_t)b->v.nbox * ncomp * sizeof(double) + 256, g_stream));
+        // (no memset of the blocks: k_fd_scatter stores every entry of every owned row, and only owned rows are ever read)
         // the finite differences of the nColour evaluations of one state variable, scattered into the blocks once per variable
         const int nsnap = J.cn * J.nState;
         if (b->snap_ncomp != nsnap) {

@@ -181,7 +181,12 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_scatter(BlkView b, const do
             for (int d = 0; d < J.cn; ++d) mine[d][lane] = snap[((long)d * J.nState + m) * nb + c];
         for (int s = 0; s < J.nStencil; ++s) {
             const int pi = i - J.st[s][0], pj = j - J.st[s][1], pk = k - J.st[s][2];      // the perturbed cell
-            if (pi < 0 || pi > b.ib || pj < 0 || pj > b.jb || pk < 0 || pk > b.kb) continue;
+            // (a column outside the box does not exist: its entry is written as zero -- every entry of every owned row is stored by the
+            //  sweep, the 2 KB per cell of the matrix need no memset in front of an assembly)
+            if (pi < 0 || pi > b.ib || pj < 0 || pj > b.jb || pk < 0 || pk > b.kb) {
+                jac[c + ((long)(s * J.nState + (l - J.lStart)) * J.nState + m) * nb] = 0.0;
+                continue;
+            }
             int d;
             if (linear) {
                 d = c0 - J.sc[s];
