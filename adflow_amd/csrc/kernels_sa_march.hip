@@ -37,12 +37,12 @@ __device__ __forceinline__ void gs_ld3(GPTR(const adf_real8) a, unsigned o, unsi
 
 
 
-struct GsCell { double u, v, w, rho, p, rlv; adf_real8 vol; };      // own column, one plane
+struct GsCell { double u, v, w, rho, rlv; adf_real8 vol; };      // own column, one plane
 struct GsNbr { double u, v, w, nu, nut; adf_real8 vol; };           // what a neighbour contributes to the SA terms
 
 struct GsPtrs {
     GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) w5;
-    GPTR(const double) p; GPTR(const double) rlv; GPTR(const adf_real8) vol;
+    GPTR(const double) rlv; GPTR(const adf_real8) vol;
     GPTR(const adf_real8) sI; GPTR(const adf_real8) sJ; GPTR(const adf_real8) sK;
     GPTR(const adf_real8) d2wall; GPTR(const adf_real8) volRef;
     unsigned nb8, sj;
@@ -52,7 +52,7 @@ __device__ __forceinline__ GsCell gs_ld(const GsPtrs& m, unsigned c)
 {
     GsCell q;
     q.rho = ldg(m.w0, c); q.u = ldg(m.w1, c); q.v = ldg(m.w2, c); q.w = ldg(m.w3, c);
-    q.p = ldg(m.p, c); q.vol = ldg(m.vol, c); q.rlv = ldg(m.rlv, c);
+    q.vol = ldg(m.vol, c); q.rlv = ldg(m.rlv, c);
     return q;
 }
 
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * GS_BY, GS_MINWG) void k_sa_march(const BlkView
     const long nb = b.nbox;
     GsPtrs m;
     m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w5 = m.w3 + 2 * nb;
-    m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.vol = (GPTR(const adf_real8))b.vol;
+    m.rlv = (GPTR(const double))b.rlv; m.vol = (GPTR(const adf_real8))b.vol;
     m.sI = (GPTR(const adf_real8))b.sI; m.sJ = (GPTR(const adf_real8))b.sJ; m.sK = (GPTR(const adf_real8))b.sK;
     m.d2wall = (GPTR(const adf_real8))b.d2wall; m.volRef = (GPTR(const adf_real8))b.volRef;
     m.nb8 = 8u * (unsigned)nb; m.sj = 8u * (unsigned)b.ldi;
