@@ -1893,6 +1893,12 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
     // viscosity is still recomputed from nuTilde because eddyModel stays set (turbUtils.F90:604-612)
     const bool turbBC = rans && !(flags & ADFLOW_JAC_FROZEN_TURB);
     auto restore = [&]() { g_opts = saved; g_lumped = savedLumped; };
+    // Inside the sweep of one state variable over the colours only that component of the state changes; the others are written at its
+    // first colour only.  What then differs from a full rewrite is the content of halos BEFORE the boundary conditions of the
+    // evaluation overwrite them (the output of the previous evaluation instead of the reference state): face halos are functions of
+    // the interior alone, but the halo cells along block EDGES are written by one subface from what another left there, in an order
+    // -- so the shortcut is taken for the preconditioner matrix, whose 7-point stencils never reach an edge halo, and not with a host hook
+    const bool oneComponent = (flags & ADFLOW_JAC_PC) && !g_bc_callback && !g_turb_bc_callback;
 
     if (useAD) {
         // one forward-mode evaluation per (colour, state variable): seed = 1 on component l of the cells of the colour (halos
@@ -1912,7 +1918,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
                 g_snapreq.col = col;
                 const KParams kps = ad_kparams(level, resFlags);
                 rc = for_level(level, [&](Block* b) {
-                    ad_launch_seed_closures(b->v, g_ad[b].v, l, col, J, kps, g_stream, col > 0);
+                    ad_launch_seed_closures(b->v, g_ad[b].v, l, col, J, kps, g_stream, oneComponent && col > 0);
                     return 0;
                 });
                 if (!rc) rc = ad_block_res_state_enqueue(level, resFlags, turbBC, (flags & ADFLOW_JAC_VISC_PC) != 0, true);
@@ -1966,7 +1972,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
         for (int col = 0; col < J.cn && !rc; ++col) {
             g_snapreq.col = col;
             rc = for_level(level, [&](Block* b) {
-                launch_fd_state_closures(b->v, b->wref, l, col, J, delta, kpc, g_stream, col > 0 && !g_bc_callback);
+                launch_fd_state_closures(b->v, b->wref, l, col, J, delta, kpc, g_stream, oneComponent && col > 0);
                 return 0;
             });
             if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC, true);

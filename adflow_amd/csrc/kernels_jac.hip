@@ -32,8 +32,8 @@ __device__ __forceinline__ void closures_halo_at(const BlkView& b, const KParams
 // w <- wref (+ delta on component l of the cells of colour `col`); col < 0: plain restore.  CLOS: also the closures of
 // block_res_state from the new state (pressure on 0..ib, laminar / eddy viscosity on 1..ie) -- one pass instead of two
 // onlyL: the other components hold wref already (the sweep of ONE state variable over the colours changes component l alone: every
-// component is written at its first colour, afterwards 8 instead of 48 B per cell go out; the boundary conditions of an evaluation
-// write halos they own from the interior, whatever stood there)
+// component is written at its first colour, afterwards 8 instead of 48 B per cell go out.  Taken for the preconditioner matrix only:
+// api.hip adflow_gpu_fd_jacobian says why)
 template <bool CLOS>
 __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_state(BlkView b, const double* __restrict__ wref, int l, int col, JacSpec J,
                                                            double delta, KParams kp, int onlyL)
