@@ -587,7 +587,7 @@ def test_pc_assemblies_on_a_level_of_several_blocks(hostsim_engine):
     rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
     checks.check_jacobian_several_blocks(hostsim_engine, rans, {
         1: ((6, 5, 4), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, ()),
-        3: ((4, 6, 5), {1: -6, 2: -15, 3: -3, 4: -6, 5: -1, 6: -1}, ())}, stretch_k=2.0)
+        3: ((4, 6, 5), {1: -6, 2: -15, 3: -3, 4: -6, 5: -1, 6: -1}, ())}, quick=True, stretch_k=2.0)
 
 
 def test_ad_pc_equal_states_across_a_face(hostsim_engine):
