@@ -12,8 +12,12 @@
 // number (dual.h) -- state, fluxes and residual carry value + derivative, geometry and options (adf_real8) stay plain.
 //
 // Mapping: the level's tile table (60 of 64 lanes produce, 4 rows, chunks of kch planes).  k face carried, i face once (its flux
-// comes back from the neighbouring lane by DPP), BOTH j faces per cell; the states of the rows above and below through LDS (double
-// buffered by the parity of the plane: one barrier per plane), the rows outside the tile loaded by the waves next to them.
+// comes back from the neighbouring lane by DPP); the states of the neighbouring rows through LDS (double buffered by the parity of
+// the plane: one barrier per plane), the rows outside the tile loaded by the waves next to them.  Two forms: k_pc_march evaluates
+// BOTH j faces of a cell (4 faces per cell); k_pc_march_h, the default, every j face ONCE (the flux handed to the row above, the
+// cell completed a plane later: 3.25 faces per cell; see there).  SNAP: the result goes to the snapshot of the Jacobian sweep.
+// Measured (north-star mesh, profiles/r05_fin6_pc_pmc_bytes.md, r05_fin4_pc_trace.md): plain 0.70 ms, 329 B per cell counted =
+// 4.9 TB/s; dual 1.52 ms (one wave per SIMD, bound by FP64 issue).
 #ifndef ADF_AD_BUILD
 #include "internal.h"
 #endif
