@@ -1977,7 +1977,7 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
             });
             if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC, true);
             if (!rc && !snapInMarch) rc = for_level(level, [&](Block* b) {
-                launch_fd_snap(b->v, b->dwref, b->snap + (size_t)col * J.nState * b->v.nbox, J, deltaInv, g_opts.turbResScale, g_stream);
+                launch_fd_snap(b->v, b->snap + (size_t)col * J.nState * b->v.nbox, J, g_opts.turbResScale, g_stream);
                 return 0;
             });
         }

@@ -354,7 +354,7 @@ struct JacSpec {
 void launch_fd_state(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, hipStream_t s);
 void launch_fd_state_closures(const BlkView& b, const double* wref, int l, int col, const JacSpec& J, double delta, const KParams& kp,
                               hipStream_t s, bool onlyL = false);
-void launch_fd_snap(const BlkView& b, const double* dwref, double* snap, const JacSpec& J, double deltaInv, double turbResScale, hipStream_t s);
+void launch_fd_snap(const BlkView& b, double* snap, const JacSpec& J, double turbResScale, hipStream_t s);
 void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, const double* dwref, double deltaInv,
                        hipStream_t s);
 void launch_jac_rows(const BlkView& b, const double* jac, double* out, int nState, int nStencil, int k0, int nk, hipStream_t s);

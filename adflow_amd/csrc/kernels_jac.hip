@@ -132,8 +132,7 @@ __global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_extract(BlkView b, double* 
 // The scatter into the stencil blocks happens once per state variable (k_fd_scatter): written per evaluation, every cell has ONE
 // matching stencil entry and consecutive lanes hit different entries -- 1/nColour-dense 8-byte stores into nStencil separate
 // streams ran at 0.3 TB/s (200 us per 1.3 M-cell block and evaluation, profiles/r02_ah)
-__global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_snap(BlkView b, const double* __restrict__ dwref, double* __restrict__ snap, JacSpec J,
-                                                          double deltaInv, double turbResScale)
+__global__ __launch_bounds__(JC_BX* JC_BY) void k_fd_snap(BlkView b, double* __restrict__ snap, JacSpec J, double turbResScale)
 {
     const int i = blockIdx.x * JC_BX + threadIdx.x + 2;
     const int j = blockIdx.y * JC_BY + threadIdx.y + 2;
@@ -260,9 +259,9 @@ void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int 
     hipLaunchKernelGGL(k_fd_extract, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, dwref, jac, l, col, J, deltaInv, turbResScale);
 }
 
-void launch_fd_snap(const BlkView& b, const double* dwref, double* snap, const JacSpec& J, double deltaInv, double turbResScale, hipStream_t s)
+void launch_fd_snap(const BlkView& b, double* snap, const JacSpec& J, double turbResScale, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fd_snap, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, dwref, snap, J, deltaInv, turbResScale);
+    hipLaunchKernelGGL(k_fd_snap, own_grid(b), dim3(JC_BX, JC_BY, 1), 0, s, b, snap, J, turbResScale);
 }
 void launch_fd_scatter(const BlkView& b, const double* snap, double* jac, int l, const JacSpec& J, const double* dwref, double deltaInv,
                        hipStream_t s)
