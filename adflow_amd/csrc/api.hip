@@ -15,11 +15,9 @@
 
 #include "internal.h"
 
-extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_gf_prefetch, g_gf_waves;
-int visc_gf_rows();
+extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march;
 int g_test_fault = 0;        // tuning "test_fault" (tests only): bit 0 = the hipGraph capture of a multigrid cycle reports failure, bit 1 = the
                              // split evaluation fails behind its fork -- the error paths must leave the library usable
-int g_front_overlap = 0;     // tuning "front_overlap": derived values of blocketteRes as shell + core, the core beside the boundary conditions (off: measured no gain at N = 1, profiles/r05_e_ab.txt)
 int g_pc_handover = 3;       // tuning "pc_handover": k_pc_march_h (every j face once, the flux handed to the row above) -- bit 0: in the dual build, bit 1: in the plain one (both on: forward mode 152.6 -> 144.1 ms, finite differences 94.6 -> 91.4 ms, profiles/r05_x_ab.txt)
 int g_rvec_joint = 1;        // tuning "rvec_joint": the six entries of a cell of the matrix-free residual vector written by ONE kernel (KParams::rvecTurbFromDw)
 int g_pc_fused = 1;          // tuning "pc_fused": first-order Roe + thin-layer viscous flux of the preconditioner matrix as ONE march (kernels_pc_march.hip), plain and dual
@@ -1003,7 +1001,6 @@ static int wall_stress_enqueue(int level, const KParams& kp, bool formGrad);
 // stage0: the reference's rkStage is 0 at this call -> on the ground level viscousFlux also stores the wall stress tensor
 // and heat flux of the viscous subfaces (storeWallTensor, fluxes.F90:2586-2592)
 static bool has_wall_subfaces(int level);
-static bool level_has_subfaces(int level);
 
 // needGradHbm: the caller wants the nodal gradients in the block arrays (updateIntermed copy-out, blockette.F90:706-750)
 // the scheme of the preconditioner matrix that k_pc_march serves: first-order upwind (lumpedDiss, or the user's first-order limiter) on
@@ -1317,12 +1314,7 @@ static int block_res_enqueue(int level, unsigned flags)
     if (kp.dissApprox && (flags & ADFLOW_RES_UPWIND_FIRST_ORDER)) kp.lumpedDiss = 1;   // blockette.F90:643
     const bool viscApprox = (flags & ADFLOW_RES_VISC_APPROX) != 0;
     int rc = 0;
-    bool etotInClosures = false, closForked = false;
-    // (every exit below the fork joins the side queue first)
-    struct Joiner {
-        bool* f;
-        ~Joiner() { if (*f) { (void)hipStreamWaitEvent(g_stream, g_evB, 0); *f = false; } }
-    } joiner{&closForked};
+    bool etotInClosures = false;
     if (flags & ADFLOW_RES_CLOSURES) {
         // computePressureSimple / computeLamViscosity / computeEddyViscosity (blockette.F90:199-203)
         LevelTab tc;
@@ -1337,19 +1329,7 @@ static int block_res_enqueue(int level, unsigned flags)
             if (!g_floor_flag_dev) HIPCHK(hipMalloc((void**)&g_floor_flag_dev, sizeof(int)));
             HIPCHK(hipMemsetAsync(g_floor_flag_dev, 0, sizeof(int), g_stream));
         }
-        // tuning front_overlap: with boundary subfaces on the level the derived values of the SHELL (the two cell layers behind every
-        // block face: all the boundary conditions and the exchange read) come first, the core follows on the side queue beside the
-        // boundary-condition launches and is joined behind them (kernels_nk.hip k_closures_shell / k_closures_core)
-        closForked = g_front_overlap && g_overlap && (flags & ADFLOW_RES_HALO) && !g_bc_callback && !g_turb_bc_callback && g_phase_base <= 0 &&
-                     level_has_subfaces(level);
-        if (closForked) {
-            launch_closures_part(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream, etotInClosures ? g_floor_flag_dev : nullptr, 0);
-            HIPCHK(hipEventRecord(g_evFork, g_stream));
-            HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
-            launch_closures_part(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_streamB, etotInClosures ? g_floor_flag_dev : nullptr, 1);
-            HIPCHK(hipEventRecord(g_evB, g_streamB));
-        } else
-            launch_closures_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream, etotInClosures ? g_floor_flag_dev : nullptr);
+        launch_closures_level(tc.tab, tc.n, tc.nx, tc.ny, tc.nz, kp, g_stream, etotInClosures ? g_floor_flag_dev : nullptr);
         rc = for_level(level, [&](Block* b) {
             b->ss_valid = false;
             b->etot_consistent = false;
@@ -1361,7 +1341,6 @@ static int block_res_enqueue(int level, unsigned flags)
         // BCTurbTreatment + applyAllTurbBCThisBlock(.true.) before applyAllBC_block(.true.) (blockette.F90:220-226)
         auto frontBCs = [&]() -> int {
             if (apply_turb_and_flow_bc_enqueue(level, 1, (flags & ADFLOW_RES_TURB) != 0)) return 1;
-            if (closForked) { HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0)); closForked = false; }      // join: the core's derived values
             if (g_bc_callback) {
                 HIPCHK(hipStreamSynchronize(g_stream));
                 g_bc_callback(level, 1);
@@ -2358,7 +2337,7 @@ int ensure_gf_tiles(int level)
 {
     if (g_gf_tiles.count(level)) return 0;
     std::pair<int4*, int> a, i, b;
-    if (build_chunk_tables(level, visc_gf_rows(), 1.5, 1, &a, &i, &b, visc_gf_rows() == 7 ? 1 : 2)) return 1;
+    if (build_chunk_tables(level, 3, 1.5, 1, &a, &i, &b, 2)) return 1;
     g_gf_tiles[level] = a; g_gf_tiles_int[level] = i; g_gf_tiles_bnd[level] = b;
     return 0;
 }
@@ -2650,21 +2629,8 @@ struct BcPlan {
     long maxFace = 0;
     bool anyEulerWall = false;
     int nent = 0;
-    // merged application (kernels_bc.hip: k_bc_faces + k_bc_edges): mean-flow kind per entry, per block the (entry, action) steps in
-    // the reference's order, the largest subface
-    int* d_kinds = nullptr;
-    int2* d_steps = nullptr;
-    int* d_stepOff = nullptr;
-    int nblk = 0;
-    long maxCells = 0;
 };
 static std::map<int, BcPlan> g_bcplan;
-// tuning "bc_merge": 2 launches per application instead of one per kind and ordinal.  1 (default): on levels whose largest subface
-// has at most g_bc_merge_cells cells -- the coarse multigrid levels and meshes of small blocks, where an application is a chain of
-// 5 us launches; on fat blocks the ordered edge pass (ONE workgroup per block walking ~13 steps) costs more than the launches it
-// replaces: measured on 8 x 160x128x64, k_bc_faces 94 + k_bc_edges 155 us against 132 us (profiles/r05_b_*).  2: always, 0: never
-int g_bc_merge = 1;
-long g_bc_merge_cells = 6000;
 
 static void bc_plan_drop(int level)
 {
@@ -2672,9 +2638,6 @@ static void bc_plan_drop(int level)
     if (it == g_bcplan.end()) return;
     if (it->second.d_ent) (void)hipFree(it->second.d_ent);
     if (it->second.d_order) (void)hipFree(it->second.d_order);
-    if (it->second.d_kinds) (void)hipFree(it->second.d_kinds);
-    if (it->second.d_steps) (void)hipFree(it->second.d_steps);
-    if (it->second.d_stepOff) (void)hipFree(it->second.d_stepOff);
     g_bcplan.erase(it);
 }
 
@@ -2755,35 +2718,7 @@ static int bc_plan(int level, BcPlan** out)
             const BcFaceDev& f = ent[e].f;
             pl.wall.maxCells = std::max(pl.wall.maxCells, (long)(f.icEnd - f.icBeg + 2) * (f.jcEnd - f.jcBeg + 2));
         }
-    // merged application: kind of every entry; per block its steps -- the turbulence boundary condition of every subface in index
-    // order (applyAllTurbBCThisBlock), then the mean-flow kinds in the order of `flow` (one entry per block and phase)
-    std::vector<int> kinds(ent.size(), -1), blkOf(ent.size(), -1);
-    std::vector<std::vector<int2>> steps(blocks.size());
-    for (size_t q = 0; q < blocks.size(); ++q)
-        for (int m = 0; m < blocks[q].n; ++m) {
-            blkOf[blocks[q].first + m] = (int)q;
-            int2 st; st.x = blocks[q].first + m; st.y = 100;      // BCP_TURB (kernels_bc.hip)
-            steps[q].push_back(st);
-            pl.maxCells = std::max(pl.maxCells, cells(blocks[q].first + m));
-        }
-    for (const BcPhase& ph : pl.flow)
-        for (int t = 0; t < ph.count; ++t) {
-            const int e = order[ph.first + t];
-            int2 st; st.x = e; st.y = ph.kind;
-            steps[blkOf[e]].push_back(st);
-            if (ph.kind != BCP_SYMM2 && ph.kind != BCP_SYMMPOLAR2) kinds[e] = ph.kind;
-        }
-    pl.nblk = (int)blocks.size();
     if (pl.nent > 0) {
-        std::vector<int2> flat;
-        std::vector<int> off(1, 0);
-        for (auto& v : steps) { flat.insert(flat.end(), v.begin(), v.end()); off.push_back((int)flat.size()); }
-        HIPCHK(hipMalloc((void**)&pl.d_kinds, sizeof(int) * kinds.size()));
-        HIPCHK(hipMemcpy(pl.d_kinds, kinds.data(), sizeof(int) * kinds.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMalloc((void**)&pl.d_steps, sizeof(int2) * flat.size()));
-        HIPCHK(hipMemcpy(pl.d_steps, flat.data(), sizeof(int2) * flat.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMalloc((void**)&pl.d_stepOff, sizeof(int) * off.size()));
-        HIPCHK(hipMemcpy(pl.d_stepOff, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMalloc((void**)&pl.d_ent, sizeof(BcEntry) * ent.size()));
         HIPCHK(hipMemcpy(pl.d_ent, ent.data(), sizeof(BcEntry) * ent.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMalloc((void**)&pl.d_order, sizeof(int) * order.size()));
@@ -2802,9 +2737,7 @@ static int turb_bc_treatment_enqueue(int level, const KParams& kp)
     if (pl->nent == 0) return 0;
     LevelTab t;
     if (level_tab(level, &t)) return 1;
-    if (g_bc_merge == 2 || (g_bc_merge == 1 && pl->maxCells <= g_bc_merge_cells))
-        launch_turb_bc_treatment_all(t.tab, pl->d_ent, pl->nent, pl->maxCells, kp, g_stream);   // (face arrays zeroed at registration)
-    else launch_turb_bc_treatment(t.tab, t.n, pl->maxFace, pl->d_ent, pl->d_order, pl->ordinal, kp, g_stream);
+    launch_turb_bc_treatment(t.tab, t.n, pl->maxFace, pl->d_ent, pl->d_order, pl->ordinal, kp, g_stream);
     return 0;
 }
 
@@ -2820,47 +2753,10 @@ static int turb_bc_apply_enqueue(int level, const KParams& kp, int secondHalo)
     return 0;
 }
 
-// Merged application (kernels_bc.hip): [bcTurbTreatment + applyAllTurbBCThisBlock] and / or applyAllBC of every block of the level
-// in two launches.  *taken = false: not applicable here (tuning off; Euler walls with the normal-momentum pressure gradient, which
-// differentiate along the wall and therefore read beyond the edge cells) -- the caller takes the launches per kind and ordinal.
-static int bc_merged_enqueue(int level, int secondHalo, bool turb, bool flow, bool* taken)
-{
-    *taken = false;
-    if (!g_bc_merge) return 0;
-    BcPlan* pl;
-    if (bc_plan(level, &pl)) return 1;
-    if (g_bc_merge == 1 && pl->maxCells > g_bc_merge_cells) return 0;
-    *taken = true;
-    if (pl->nent == 0) return 0;
-    turb = turb && g_opts.equations == ADFLOW_RANS;
-    if (!turb && !flow) return 0;
-    KParams kp = make_kparams(level, 1.0, 0);
-    if (flow && pl->anyEulerWall) {
-        if (g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_QUADRATIC || (g_opts.eulerWallBCTreatment == ADFLOW_WALLBC_NORMAL_MOMENTUM && kp.fineGrid)) {
-            *taken = false;
-            return 0;
-        }
-    }
-    LevelTab t;
-    if (level_tab(level, &t)) return 1;
-    launch_bc_merged(t.tab, pl->d_ent, pl->nent, pl->d_kinds, pl->maxCells, pl->d_steps, pl->d_stepOff, pl->nblk, kp, secondHalo,
-                     g_opts.eulerWallBCTreatment, g_opts.viscWallBCTreatment, g_opts.outflowTreatment, g_opts.hScalingInlet, turb ? 1 : 0,
-                     flow ? 1 : 0, g_stream);
-    if (flow)
-        return for_level(level, [&](Block* b) {
-            if (!b->bc.empty()) b->ss_valid = false;
-            return 0;
-        });
-    return 0;
-}
-
 // bcTurbTreatment + applyAllTurbBCThisBlock(secondHalo) for the blocks of `level` with registered subfaces
 static int apply_turb_bc_enqueue(int level, int secondHalo)
 {
     if (g_opts.equations != ADFLOW_RANS) return 0;
-    bool taken;
-    if (bc_merged_enqueue(level, secondHalo, true, false, &taken)) return 1;
-    if (taken) return 0;
     KParams kp = make_kparams(level, 1.0, 0);
     if (turb_bc_treatment_enqueue(level, kp)) return 1;
     return turb_bc_apply_enqueue(level, kp, secondHalo);
@@ -2869,9 +2765,6 @@ static int apply_turb_bc_enqueue(int level, int secondHalo)
 // both, in the order of blocketteRes (blockette.F90:228-244): turbulence first
 static int apply_turb_and_flow_bc_enqueue(int level, int secondHalo, bool turbBC)
 {
-    bool taken;
-    if (bc_merged_enqueue(level, secondHalo, turbBC, true, &taken)) return 1;
-    if (taken) return 0;
     if (turbBC && apply_turb_bc_enqueue(level, secondHalo)) return 1;
     return apply_bc_enqueue(level, secondHalo);
 }
@@ -2879,9 +2772,6 @@ static int apply_turb_and_flow_bc_enqueue(int level, int secondHalo, bool turbBC
 // applyAllBC (BCRoutines.F90:15-54) for the blocks of `level` that registered subfaces
 static int apply_bc_enqueue(int level, int secondHalo)
 {
-    bool taken;
-    if (bc_merged_enqueue(level, secondHalo, false, true, &taken)) return 1;
-    if (taken) return 0;
     BcPlan* pl;
     if (bc_plan(level, &pl)) return 1;
     if (pl->nent == 0) return 0;
@@ -2924,13 +2814,6 @@ static int ad_apply_bc_enqueue(int level, const KParams& kp, bool turbBC)
     ad_launch_apply_all_bc(g_ad_tab, pl->d_ent, pl->d_order, flow, kp, 1, g_opts.eulerWallBCTreatment, g_opts.viscWallBCTreatment,
                            g_opts.outflowTreatment, g_opts.hScalingInlet, g_stream);
     return 0;
-}
-
-static bool level_has_subfaces(int level)
-{
-    BcPlan* pl;
-    if (bc_plan(level, &pl)) return false;
-    return pl->nent > 0;
 }
 
 static bool has_wall_subfaces(int level)
@@ -3993,26 +3876,12 @@ int adflow_gpu_set_tuning(const char* key, int value)
         return 0;
     }
     if (!strcmp(key, "split_eval")) { g_split_eval = value; return 0; }
-    if (!strcmp(key, "bc_merge")) { g_bc_merge = value; mg_graph_drop(); return 0; }
-    if (!strcmp(key, "front_overlap")) { g_front_overlap = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "test_fault")) { g_test_fault = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
     if (!strcmp(key, "rvec_joint")) { g_rvec_joint = value; return 0; }
     if (!strcmp(key, "pc_handover")) { g_pc_handover = value; return 0; }
     if (!strcmp(key, "jac_snap")) { g_jac_snap = value; return 0; }
     if (!strcmp(key, "pc_fused")) { g_pc_fused = value; mg_graph_drop(); return 0; }
-    if (!strcmp(key, "gf_prefetch")) { g_gf_prefetch = value; mg_graph_drop(); return 0; }
-    if (!strcmp(key, "gf_waves")) {
-        if (value != 4 && value != 8) return fail("gf_waves must be 4 or 8");
-        g_gf_waves = value;
-        if (g_stream) (void)hipStreamSynchronize(g_stream);
-        mg_graph_drop();
-        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd}) {
-            for (auto& kv : *mp) (void)hipFree(kv.second.first);
-            mp->clear();
-        }
-        return 0;
-    }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);

@@ -447,7 +447,6 @@ void launch_closures(const BlkView& b, const KParams& kp, hipStream_t s);
 // level-batched forms (blockIdx.z = slot * planes + plane): one launch for every block of a level
 void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s,
                            int* floored = nullptr);
-void launch_closures_part(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s, int* floored, int part);
 void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
                                  const KParams& kp, int* floored, hipStream_t s);
 void launch_set_w_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor, hipStream_t s);
@@ -465,11 +464,6 @@ void launch_turb_bc_treatment(const BlkView* tab, int nslots, long maxFace, cons
                               const std::vector<BcPhase>& ordinal, const KParams& kp, hipStream_t s);
 void launch_apply_turb_bc(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& ordinal,
                           const KParams& kp, int second, hipStream_t s);
-void launch_bc_merged(const BlkView* tab, const BcEntry* ent, int nent, const int* kinds, long maxCells, const int2* steps, const int* stepOff,
-                      int nblk, const KParams& kp, int second, int eulerWallTreatment, int viscWallTreatment, int outflowTreatment,
-                      int hScalingInlet, int turb, int flow, hipStream_t s);
-void launch_turb_bc_zero(const BlkView* tab, int nslots, long maxFace, hipStream_t s);
-void launch_turb_bc_treatment_all(const BlkView* tab, const BcEntry* ent, int nent, long maxCells, const KParams& kp, hipStream_t s);
 void launch_bc_coarse_corrections(const BlkView* tab, const BcEntry* ent, const int* order, const std::vector<BcPhase>& ordinal,
                                   double fact, hipStream_t s);
 void launch_corner_row_halos_level(const BlkView* tab, int nslots, const KParams& kp, hipStream_t s);

@@ -643,163 +643,6 @@ __global__ __launch_bounds__(256) void k_apply_turb_bc(BC_ARGS, KParams kp, int 
     bcc_turb_apply(b, f, s, kp, second);
 }
 
-#ifndef ADF_AD_BUILD
-// ---------------------------------------------------------------------------
-// Merged application (round 5; tuning "bc_merge", default on).  Subfaces of one block depend on each other ONLY along the block
-// edges: a subface's range includes the first halo ring of the faces around it, so its cells with a transverse index <= 1 or
-// >= ie / je / ke write halos (c1, c0) that the neighbouring faces' subfaces write as well, and they read (slabs c2, c3 along the
-// normal) the halo cells of the neighbouring face at ITS transverse indices 2, 3 / il-1, il -- the reference's order decides who
-// reads what there.  "Edge cells" = transverse index <= 3 or >= ie-2 (je-2, ke-2): three rings.  Every other cell of a subface
-// reads owned cells only, is written by nobody else and read by nobody else.  So:
-//   phase A  ONE launch over every subface of the level (blockIdx.y = entry), all kinds: the cells off the edges -- turbulence
-//            boundary condition (bmt / bvt formed on the fly and stored), then the mean-flow kind of the subface;
-//   phase B  ONE launch, one workgroup per block: the EDGE cells only, subface by subface in the reference's order
-//            (applyAllTurbBCThisBlock turbBCRoutines.F90:49-236 over the subfaces in index order, then applyAllBC_block
-//            BCRoutines.F90:57-221 kind by kind), a workgroup barrier between two steps.
-// 2 launches instead of 13-16 dependent ones that each fill an eighth of the chip (profiles/r04_fin_front_part_dispatches.txt).
-// A block thinner than two cells along a subface's normal has all cells of that subface in phase B (c3 is the opposite halo).
-// Not taken (api.hip): Euler walls with the normal-momentum pressure gradient, which differentiate ALONG the wall.
-// ---------------------------------------------------------------------------
-struct BcAllArgs { int second, eulerWall, viscWall, outflow, hScaling, turb, flow; };
-
-// transverse extents of the face's halo-inclusive cell range, cells along the normal
-__device__ __forceinline__ void bc_face_dims(const BlkView& b, const BcFaceDev& f, int& A, int& B, int& nn)
-{
-    A = (f.faceID <= ADFLOW_IMAX) ? b.je : b.ie;
-    B = (f.faceID <= ADFLOW_JMAX) ? b.ke : b.je;
-    nn = (f.faceID <= ADFLOW_IMAX) ? b.nx : (f.faceID <= ADFLOW_JMAX) ? b.ny : b.nz;
-}
-
-__device__ __forceinline__ bool bc_is_edge(const BlkView& b, const BcFaceDev& f, long t)
-{
-    int A, B, nn;
-    bc_face_dims(b, f, A, B, nn);
-    const int isize = f.icEnd - f.icBeg + 1;
-    const int i = f.icBeg + (int)(t % isize), j = f.jcBeg + (int)(t / isize);
-    return nn < 2 || i <= 3 || i >= A - 2 || j <= 3 || j >= B - 2;
-}
-
-// one cell of one subface: action = BCP_* kind, or BCP_TURB (bcTurbTreatment + the turbulence halo)
-#define BCP_TURB 100
-__device__ __forceinline__ void bc_cell_action(const BlkView& b, const BcFaceDev& f, const BcSlab& s, const KParams& kp, const BcAllArgs& a,
-                                               int action)
-{
-    switch (action) {
-    case BCP_TURB:
-        if (!b.bmt[0]) break;
-        bcc_turb_treatment(b, f, s.f, kp);
-        bcc_turb_apply(b, f, s, kp, a.second);
-        break;
-    case BCP_SYMM1: bcc_symm(b, f, s, kp, 0); break;
-    case BCP_SYMM2: if (a.second) bcc_symm(b, f, s, kp, 1); break;
-    case BCP_SYMMPOLAR1: bcc_symm_polar(b, f, s, kp, 0); break;
-    case BCP_SYMMPOLAR2: if (a.second) bcc_symm_polar(b, f, s, kp, 1); break;
-    case BCP_WALL_ADIABATIC: bcc_nswall<false>(b, f, s, kp, a.second, a.viscWall); break;
-    case BCP_WALL_ISOTHERMAL: bcc_nswall<true>(b, f, s, kp, a.second, a.viscWall); break;
-    case BCP_FARFIELD: bcc_farfield(b, f, s, kp, a.second); break;
-    case BCP_SUBSONIC_OUTFLOW: bcc_subsonic_outflow(b, f, s, kp, a.second); break;
-    case BCP_SUBSONIC_INFLOW: bcc_subsonic_inflow(b, f, s, kp, a.second, a.hScaling); break;
-    case BCP_EXTRAP: bcc_extrap(b, f, s, kp, a.second, a.outflow); break;
-    case BCP_EULERWALL: bcc_eulerwall(b, f, s, kp, a.second, a.eulerWall); break;
-    case BCP_SUPERSONIC_INFLOW: bcc_supersonic_inflow(b, f, s, kp, a.second); break;
-    default: break;
-    }
-}
-
-// phase A: kinds[e] = the mean-flow kind of entry e (-1: none of the kinds applyAllBC_block dispatches; a wall outside the first
-// nViscBocos subfaces is such a case)
-__global__ __launch_bounds__(256) void k_bc_faces(const BlkView* __restrict__ tab, const BcEntry* __restrict__ ent, const int* __restrict__ kinds,
-                                                  KParams kp, BcAllArgs a)
-{
-    const BcEntry& e_ = ent[blockIdx.y];
-    const BlkView& b = tab[e_.slot];
-    const BcFaceDev& f = e_.f;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    BcSlab s;
-    if (!bc_slab_t(b, f, t, s) || bc_is_edge(b, f, t)) return;
-    if (a.turb) bc_cell_action(b, f, s, kp, a, BCP_TURB);
-    if (!a.flow) return;
-    const int kind = kinds[blockIdx.y];
-    if (kind == BCP_SYMM1) { bcc_symm(b, f, s, kp, 0); if (a.second) bcc_symm(b, f, s, kp, 1); }
-    else if (kind == BCP_SYMMPOLAR1) { bcc_symm_polar(b, f, s, kp, 0); if (a.second) bcc_symm_polar(b, f, s, kp, 1); }
-    else if (kind >= 0) bc_cell_action(b, f, s, kp, a, kind);
-}
-
-// phase B: steps[stepOff[w] .. stepOff[w+1]) = (entry, action) of the block of workgroup w in the reference's order
-__global__ __launch_bounds__(512) void k_bc_edges(const BlkView* __restrict__ tab, const BcEntry* __restrict__ ent, const int2* __restrict__ steps,
-                                                  const int* __restrict__ stepOff, KParams kp, BcAllArgs a)
-{
-    const int q0 = stepOff[blockIdx.x], q1 = stepOff[blockIdx.x + 1];
-    for (int q = q0; q < q1; ++q) {
-        const int2 st = steps[q];
-        if (st.y == BCP_TURB ? !a.turb : !a.flow) continue;                    // uniform over the workgroup
-        if (!a.second && (st.y == BCP_SYMM2 || st.y == BCP_SYMMPOLAR2)) continue;
-        const BcEntry& e_ = ent[st.x];
-        const BlkView& b = tab[e_.slot];
-        const BcFaceDev& f = e_.f;
-        int A, B, nn;
-        bc_face_dims(b, f, A, B, nn);
-        const int ni = f.icEnd - f.icBeg + 1, nj = f.jcEnd - f.jcBeg + 1;
-        // the edge cells of the range: whole rows j <= 3 and j >= B - 2, in the rows between them the columns i <= 3 and i >= A - 2
-        int jlo = 4 - f.jcBeg; jlo = jlo < 0 ? 0 : (jlo > nj ? nj : jlo);
-        int jhi = f.jcEnd - (B - 2) + 1; jhi = jhi < 0 ? 0 : (jhi > nj - jlo ? nj - jlo : jhi);
-        int ilo = 4 - f.icBeg; ilo = ilo < 0 ? 0 : (ilo > ni ? ni : ilo);
-        int ihi = f.icEnd - (A - 2) + 1; ihi = ihi < 0 ? 0 : (ihi > ni - ilo ? ni - ilo : ihi);
-        if (nn < 2) { jlo = nj; jhi = 0; ilo = ihi = 0; }
-        const int nmid = nj - jlo - jhi, ncol = ilo + ihi;
-        const long nrow = (long)(jlo + jhi) * ni, nring = nrow + (long)ncol * nmid;
-        for (long r = threadIdx.x; r < nring; r += blockDim.x) {
-            int i, j;
-            if (r < (long)jlo * ni) { j = f.jcBeg + (int)(r / ni); i = f.icBeg + (int)(r % ni); }
-            else if (r < nrow) { const long r2 = r - (long)jlo * ni; j = f.jcEnd - jhi + 1 + (int)(r2 / ni); i = f.icBeg + (int)(r2 % ni); }
-            else {
-                const long r3 = r - nrow;
-                const int c = (int)(r3 % ncol);
-                j = f.jcBeg + jlo + (int)(r3 / ncol);
-                i = c < ilo ? f.icBeg + c : f.icEnd - ihi + 1 + (c - ilo);
-            }
-            BcSlab s;
-            if (bc_slab_t(b, f, (long)(i - f.icBeg) + (long)ni * (j - f.jcBeg), s)) bc_cell_action(b, f, s, kp, a, st.y);
-        }
-        __syncthreads();
-    }
-}
-
-void launch_bc_merged(const BlkView* tab, const BcEntry* ent, int nent, const int* kinds, long maxCells, const int2* steps, const int* stepOff,
-                      int nblk, const KParams& kp, int second, int eulerWallTreatment, int viscWallTreatment, int outflowTreatment,
-                      int hScalingInlet, int turb, int flow, hipStream_t s)
-{
-    if (nent <= 0) return;
-    BcAllArgs a;
-    a.second = second; a.eulerWall = eulerWallTreatment; a.viscWall = viscWallTreatment; a.outflow = outflowTreatment;
-    a.hScaling = hScalingInlet; a.turb = turb; a.flow = flow;
-    // coarse levels force the constant-pressure wall treatment (BCRoutines.F90:552-553, 1098-1099)
-    if (!kp.fineGrid) { a.eulerWall = ADFLOW_WALLBC_CONSTANT; a.viscWall = ADFLOW_WALLBC_CONSTANT; }
-    hipLaunchKernelGGL(k_bc_faces, dim3((unsigned)((maxCells + 255) / 256), (unsigned)nent), dim3(256), 0, s, tab, ent, kinds, kp, a);
-    hipLaunchKernelGGL(k_bc_edges, dim3((unsigned)nblk), dim3(512), 0, s, tab, ent, steps, stepOff, kp, a);
-}
-
-// bcTurbTreatment alone (the SA solve needs bmt / bvt before its march): every subface in one launch; the face arrays were zeroed
-// when the plan was built (k_turb_bc_zero) and a subface only ever writes its own cells
-__global__ __launch_bounds__(256) void k_turb_bc_treatment_all(const BlkView* __restrict__ tab, const BcEntry* __restrict__ ent, KParams kp)
-{
-    const BcEntry& e_ = ent[blockIdx.y];
-    const BlkView& b = tab[e_.slot];
-    const BcFaceDev& f = e_.f;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n = (long)(f.icEnd - f.icBeg + 1) * (f.jcEnd - f.jcBeg + 1);
-    if (t >= n || !b.bmt[0]) return;
-    bcc_turb_treatment(b, f, t, kp);
-}
-void launch_turb_bc_zero(const BlkView* tab, int nslots, long maxFace, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_turb_bc_zero, dim3((unsigned)((maxFace + 255) / 256), nslots), dim3(256), 0, s, tab);
-}
-void launch_turb_bc_treatment_all(const BlkView* tab, const BcEntry* ent, int nent, long maxCells, const KParams& kp, hipStream_t s)
-{
-    if (nent > 0) hipLaunchKernelGGL(k_turb_bc_treatment_all, dim3((unsigned)((maxCells + 255) / 256), (unsigned)nent), dim3(256), 0, s, tab, ent, kp);
-}
-#endif
 
 // `ordinal`: one launch per ordinal of a subface within its block (the r-th subfaces of all blocks together)
 void launch_turb_bc_treatment(const BlkView* tab, int nslots, long maxFace, const BcEntry* ent, const int* order,

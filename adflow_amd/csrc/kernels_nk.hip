@@ -165,59 +165,6 @@ __global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_level(const BlkView* 
     closures_body<ETOT>(tab[blockIdx.z / nzb + 1], (int)(blockIdx.z % nzb), kp, floored);
 }
 
-// The derived values in two parts (tuning "front_overlap"): the SHELL -- the owned cells within two layers of a block face, all the
-// boundary conditions and the halo exchange read -- and the CORE, which runs on a side queue beside the boundary-condition launches
-// (a dozen dependent 5-40 us kernels that fill an eighth of the chip, profiles/r04_fin_front_part_dispatches.txt).
-// shell: blockIdx.y = 0: the planes k = 2, 3, kl-1, kl; 1: the rows j = 2, 3, jl-1, jl of the other planes; 2: the columns
-// i = 2, 3, il-1, il of the other rows and planes (4 columns x 64 rows per workgroup).
-__device__ __forceinline__ int shell_index(int p, int n)      // p-th shell index of a direction with n cells (min(n, 4) of them)
-{
-    const int np = n < 4 ? n : 4;
-    return (p < (np + 1) / 2) ? 2 + p : (n + 1) - (np - 1 - p);
-}
-__device__ __forceinline__ bool in_shell(const BlkView& b, int i, int j, int k)
-{
-    return i < 4 || i > b.il - 2 || j < 4 || j > b.jl - 2 || k < 4 || k > b.kl - 2;
-}
-template <bool ETOT>
-__global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_shell(const BlkView* __restrict__ tab, KParams kp, int* __restrict__ floored)
-{
-    const BlkView& b = tab[blockIdx.z + 1];
-    if (b.nx == 0) return;
-    const int gx = (b.nx + NK_BX - 1) / NK_BX, gy = (b.ny + NK_BY - 1) / NK_BY;
-    const int nkp = b.nz < 4 ? b.nz : 4, njp = b.ny < 4 ? b.ny : 4, nip = b.nx < 4 ? b.nx : 4;
-    const int nkI = b.nz - nkp, njI = b.ny - njp;        // planes / rows outside the k / j slabs: k = 4 .. kl-2, j = 4 .. jl-2
-    int x = blockIdx.x;
-    if (blockIdx.y == 0) {
-        if (x >= gx * gy * nkp) return;
-        const int tx = x % gx, ty = (x / gx) % gy, p = x / (gx * gy);
-        const int i = tx * NK_BX + threadIdx.x + 2, j = ty * NK_BY + threadIdx.y + 2, k = shell_index(p, b.nz);
-        if (i <= b.il && j <= b.jl) closures_cell<ETOT>(b, i, j, k, kp, floored);
-    } else if (blockIdx.y == 1) {
-        if (x >= gx * nkI) return;
-        const int tx = x % gx, kI = x / gx;
-        const int i = tx * NK_BX + threadIdx.x + 2, k = 4 + kI;
-        if ((int)threadIdx.y < njp && i <= b.il) closures_cell<ETOT>(b, i, shell_index(threadIdx.y, b.ny), k, kp, floored);
-    } else {
-        const int gr = (njI + 63) / 64;
-        if (x >= gr * nkI) return;
-        const int tr = x % gr, kI = x / gr;
-        const int t = threadIdx.y * NK_BX + threadIdx.x;
-        const int c = t & 3, j = 4 + tr * 64 + (t >> 2), k = 4 + kI;
-        if (c < nip && j <= b.jl - 2) closures_cell<ETOT>(b, shell_index(c, b.nx), j, k, kp, floored);
-    }
-}
-template <bool ETOT>
-__global__ __launch_bounds__(NK_BX* NK_BY) void k_closures_core(const BlkView* __restrict__ tab, int nzb, KParams kp, int* __restrict__ floored)
-{
-    const BlkView& b = tab[blockIdx.z / nzb + 1];
-    const int i = blockIdx.x * NK_BX + threadIdx.x + 2;
-    const int j = blockIdx.y * NK_BY + threadIdx.y + 2;
-    const int k = (int)(blockIdx.z % nzb) + 2;
-    if (i > b.il || j > b.jl || k > b.kl || in_shell(b, i, j, k)) return;
-    closures_cell<ETOT>(b, i, j, k, kp, floored);
-}
-
 static dim3 nk_grid(const BlkView& b) { return dim3((b.nx + NK_BX - 1) / NK_BX, (b.ny + NK_BY - 1) / NK_BY, b.nz); }
 static dim3 nk_level_grid(int nslots, int maxnx, int maxny, int maxnz)
 {
@@ -233,22 +180,6 @@ void launch_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny,
     else
         hipLaunchKernelGGL(k_closures_level<false>, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp,
                            (int*)nullptr);
-}
-// part 0: the shell, 1: the core (see k_closures_shell)
-void launch_closures_part(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const KParams& kp, hipStream_t s, int* floored, int part)
-{
-    LEVEL_SPLIT(nslots, maxnz + 4, launch_closures_part(tab + s0_, n_, maxnx, maxny, maxnz, kp, s, floored, part));
-    if (nslots <= 0) return;
-    if (part == 0) {
-        const int gx = (maxnx + NK_BX - 1) / NK_BX, gy = (maxny + NK_BY - 1) / NK_BY;
-        const int nk = std::max(gx * gy * 4, std::max(gx * std::max(maxnz - 4, 0), ((std::max(maxny - 4, 0) + 63) / 64) * std::max(maxnz - 4, 0)));
-        const dim3 grd(std::max(nk, 1), 3, nslots);
-        if (floored) hipLaunchKernelGGL(k_closures_shell<true>, grd, dim3(NK_BX, NK_BY, 1), 0, s, tab, kp, floored);
-        else hipLaunchKernelGGL(k_closures_shell<false>, grd, dim3(NK_BX, NK_BY, 1), 0, s, tab, kp, (int*)nullptr);
-    } else {
-        if (floored) hipLaunchKernelGGL(k_closures_core<true>, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp, floored);
-        else hipLaunchKernelGGL(k_closures_core<false>, nk_level_grid(nslots, maxnx, maxny, maxnz), dim3(NK_BX, NK_BY, 1), 0, s, tab, maxnz, kp, (int*)nullptr);
-    }
 }
 void launch_set_w_closures_level(const BlkView* tab, int nslots, int maxnx, int maxny, int maxnz, const double* vec, double turbFloor,
                                  const KParams& kp, int* floored, hipStream_t s)

@@ -650,11 +650,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
 #define GF_G (12 * GF_NL)         // doubles of one node row of one plane
 #define GF_RING (3 * 4 * GF_G)
 #define GF_FJ (3 * GF_OUT * 4)    // doubles of one parity of the j-flux hand-over: rows 0..2, lanes 2..61, 4 components
-// NW waves per workgroup (template parameter; tuning "gf_waves"): 4 = the form above; 8 = ONE workgroup of eight waves per CU -- eight
-// node rows, SEVEN produced cell rows for nine loaded (1.29 instead of 1.67 rows of the gradient part's 17 arrays per produced row,
-// one idle face part in eight waves instead of one in four), the ring at two slots (93.7 KB + 26.9 KB of hand-over) and a second
-// barrier at the end of the step in exchange (the slot written in step m+1 was read in step m)
-#define GF_NSLOT(NW) ((NW) == 4 ? 3 : 2)
+#define GF_NW 4                   // waves (node rows) of a workgroup
 
 struct GfPtrs {
     GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) p;
@@ -684,16 +680,30 @@ struct GfMet { double Pt[3], Q0t[3], Q1t[3], RIt[3], V; };
 struct __attribute__((aligned(16))) Dbl2 { double x, y; };
 __device__ __forceinline__ Dbl2 mk2(double x, double y) { Dbl2 v; v.x = x; v.y = y; return v; }
 
-// one cell plane of the rows jn, jn+1 as loaded (the prefetching form keeps it a whole step before it is used)
-struct GfReq { double au, av, aw, ap, ar, alv, aev, avol, bu, bv, bw, bp, br, blv, bev, bvol, aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3]; };
+// one cell plane of the rows jn, jn+1 as loaded: state and volume ...
+struct GfReq { double au, av, aw, ap, ar, alv, aev, avol, bu, bv, bw, bp, br, blv, bev, bvol; };
+// ... and its face normals sI, sJ(jn-1), sJ, sK (row jn: a, row jn+1: b), loaded or formed from the nodes
+struct GfNrm { double aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3]; };
+// the nodes (i, jn-1 | jn | jn+1, plane) of the thread's column
+struct GfNod { double r0[3], r1[3], r2[3]; };
 
-// PF (tuning "gf_prefetch"): ONE workgroup per CU -- one wavefront per SIMD with the whole 512-entry register file -- and the 37 values
-// of cell plane mm+1 requested at the top of step mm: the request that stood fully exposed in front of the gradient part (a third of
-// the wave cycles waiting, profiles/r04_fin_pmc_sq.txt) has a whole step to land.
-template <bool QCR, bool FIRST, bool STG, bool PF = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
+// XN (round 6; KParams::metricFromX bit 1, the default wherever the stored normals ARE metric_block(x)): the geometry comes from the
+// NODE coordinates, as the reference's default path forms it (blocketteResCore: metrics blockette.F90:854-960; the centre-to-centre
+// vectors inside viscousFlux, fluxes.F90:2673-2690, 2966-2983, 3260-3277).  Per plane a thread loads the three nodes (i, jn-1 .. jn+1,
+// mm) -- 9 values -- instead of the 21 normal components of its two cell rows + 15 values of the face part (dI, dJ, dK and sI, sJ
+// again): 24 unique bytes per cell instead of 144.  Node plane mm-1 is carried; the column i-1 comes by DPP.
+//   normals of cell plane mm      : cross products of the face diagonals, metric_block's formulas and operand order (ngx_cross);
+//   normals of the face part      : sI, sJ of cell row jn at plane mm-1 are carried from the step before (as sK always was);
+//   centre-to-centre vectors      : with H_k = x(jn-1) + x(jn), E_k = x(jn+1) - x(jn-1) of node plane k (per lane),
+//       dK(mm-1 | mm)   = ((H_mm - H_mm-2)(i) + (H_mm - H_mm-2)(i-1)) / 8
+//       dJ(jn | jn+1)   = ((E_mm-2 + E_mm-1)(i) + (E_mm-2 + E_mm-1)(i-1)) / 8
+//       dI(i | i+1)     = ((H_mm-2 + H_mm-1)(i+1) - (H_mm-2 + H_mm-1)(i-1)) / 8
+//     i.e. the reference's eight-term sums in another order (differences of node sums): they agree to the rounding of the
+//     reference's own sum, a few ulp of |x|.  H_mm-2 and E_mm-2 are carried (6 values).
+template <bool QCR, bool FIRST, bool STG, bool XN>
+__global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
-    constexpr int NSLOT = GF_NSLOT(NW);
+    constexpr int NW = GF_NW, NSLOT = 3;
     __shared__ __attribute__((aligned(16))) double ring[NSLOT * NW * GF_G];   // [slot][node row 0..NW-1 = rows j0-1 .. j0+NW-2][component pair][lane-1][2]
     __shared__ __attribute__((aligned(16))) double fjx[2 * (NW - 1) * GF_OUT * 4];  // [parity][row][lane-2][component]
     constexpr int FJ = (NW - 1) * GF_OUT * 4;
@@ -723,6 +733,8 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
     m.nb8 = nb8;
     GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
     GPTR(const double) dK = (GPTR(const double))b.dK;
+    GPTR(const double) xnod = (GPTR(const double))b.x;
+    const double mfact = b.mfact;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     GPTR(double) dw = (GPTR(double))b.dw;
     GPTR(double) fw = (GPTR(double))b.fw;
@@ -736,13 +748,31 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
     const unsigned dB = 8u * (unsigned)((jB - jA) * b.ldi);          // row jn+1 relative to row jn (0 at the upper end of the box)
     const unsigned dM = (jA >= 1) ? sj : 0u;                          // row jn-1
     // carried: state of the rows jn, jn+1 at the previous plane, metric sums and normals of that plane, the k-face flux, the own
-    // part of the flux sum of the plane before
+    // part of the flux sum of the plane before; XN: the nodes of the previous plane, sI / sJ of cell row jn there, H and E (see above)
+    // of the plane before it
     VmCell qA, qB;
     GfMet S;
     double sKA[3], sKB[3], fk[4], pend[4];
+    GfNod P;
+    double cIA[3], cJA[3], Hp2[3], Ep2[3];
     int flagP = 0;
+    auto ld_nodes = [&](unsigned c, GfNod& n) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { sKA[d] = ldg(m.sK, cA - sk + d * nb8); sKB[d] = ldg(m.sK, cA + dB - sk + d * nb8); }
+        for (int d = 0; d < 3; ++d) { n.r0[d] = ldg(xnod, c - dM + d * nb8); n.r1[d] = ldg(xnod, c + d * nb8); n.r2[d] = ldg(xnod, c + dB + d * nb8); }
+    };
+    if (XN) {
+        ld_nodes(cA - sk, P);
+        double P0u[3], P1u[3], P2u[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { P0u[d] = lane_up1(P.r0[d]); P1u[d] = lane_up1(P.r1[d]); P2u[d] = lane_up1(P.r2[d]); }
+        ngx_cross(mfact, P.r1, P0u, P1u, P.r0, sKA);
+        ngx_cross(mfact, P.r2, P1u, P2u, P.r1, sKB);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) cIA[d] = cJA[d] = Hp2[d] = Ep2[d] = 0.0;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sKA[d] = ldg(m.sK, cA - sk + d * nb8); sKB[d] = ldg(m.sK, cA + dB - sk + d * nb8); }
+    }
 #pragma unroll
     for (int l = 0; l < 4; ++l) { fk[l] = 0.0; pend[l] = 0.0; }
     qA.u = qA.v = qA.w = qA.na = qA.rlv = qA.rev = 0.0;
@@ -776,12 +806,8 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
         const unsigned cb = c + dB;
         q.bu = ldg(m.w1, cb); q.bv = ldg(m.w2, cb); q.bw = ldg(m.w3, cb); q.bp = ldg(m.p, cb); q.br = ldg(m.w0, cb);
         q.blv = ldg(m.rlv, cb); q.bev = K.eddy ? ldg(m.rev, cb) : 0.0; q.bvol = ldg(m.vol, cb);
-        vm_ld3(m.sI, c, nb8, q.aI); vm_ld3(m.sJ, c - dM, nb8, q.aJm); vm_ld3(m.sJ, c, nb8, q.aJ); vm_ld3(m.sK, c, nb8, q.aK);
-        vm_ld3(m.sI, cb, nb8, q.bI); vm_ld3(m.sJ, cb, nb8, q.bJ); vm_ld3(m.sK, cb, nb8, q.bK);
         return q;
     };
-    GfReq cur;
-    if (PF) cur = request(cA);
     for (int mm = k0 - 1; mm <= k1 + 1; ++mm) {
         const unsigned cF = cA - sk;
         const bool facePlane = (mm >= k0);
@@ -790,8 +816,9 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
         int flag0 = 0;
         auto face_loads = [&]() {
             if (!facePlane) return;
-            if (r >= 1) vm_ld3(dK, cF, nb8, dKv);
             flag0 = flags[cF >> 3];
+            if (XN) return;
+            if (r >= 1) vm_ld3(dK, cF, nb8, dKv);
             if (full) {
                 if (r >= 1) vm_ld3(dI, cF, nb8, dIv);
                 vm_ld3(dJ, cF, nb8, dJv);
@@ -799,42 +826,54 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
                 vm_ld3(m.sJ, cF, nb8, sJA);
             }
         };
-        // ---- cell plane mm of the rows jn and jn+1: state, normals, volume; centre-to-centre vectors and flags of plane mm-1
-        GfReq nxt;
-        if (PF) {
-            // plane mm+1 (the face part's loads follow behind the gradient part as in the plain form: requested up here the compiler
-            // parks them in AGPRs at once, i.e. waits for them in front of the gradient part)
-            nxt = request(cA + (mm <= k1 ? sk : 0u));
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            cur = request(cA);
+        // ---- cell plane mm of the rows jn and jn+1: state, volume, normals (or the nodes they are formed from); centre-to-centre
+        //      vectors and flags of plane mm-1
+        const GfReq cur = request(cA);
+        GfNrm nr;
+        GfNod N;
+        if (XN) ld_nodes(cA, N);
+        else {
+            const unsigned cb = cA + dB;
+            vm_ld3(m.sI, cA, nb8, nr.aI); vm_ld3(m.sJ, cA - dM, nb8, nr.aJm); vm_ld3(m.sJ, cA, nb8, nr.aJ); vm_ld3(m.sK, cA, nb8, nr.aK);
+            vm_ld3(m.sI, cb, nb8, nr.bI); vm_ld3(m.sJ, cb, nb8, nr.bJ); vm_ld3(m.sK, cb, nb8, nr.bK);
         }
         GfRaw a, bq;
         a.q.u = cur.au; a.q.v = cur.av; a.q.w = cur.aw; a.q.na = -(gam * cur.ap) * rcp_nr(cur.ar); a.q.rlv = cur.alv; a.q.rev = cur.aev; a.vol = cur.avol;
         bq.q.u = cur.bu; bq.q.v = cur.bv; bq.q.w = cur.bw; bq.q.na = -(gam * cur.bp) * rcp_nr(cur.br); bq.q.rlv = cur.blv; bq.q.rev = cur.bev; bq.vol = cur.bvol;
-        double aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3];
+        if (XN) {
+            // normals of cell plane mm from the node planes mm-1 (P) and mm (N): metric_block's diagonals
+            double N0u[3], N1u[3], N2u[3], P0u[3], P1u[3], P2u[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            aI[d] = cur.aI[d]; aJm[d] = cur.aJm[d]; aJ[d] = cur.aJ[d]; aK[d] = cur.aK[d]; bI[d] = cur.bI[d]; bJ[d] = cur.bJ[d]; bK[d] = cur.bK[d];
+            for (int d = 0; d < 3; ++d) {
+                N0u[d] = lane_up1(N.r0[d]); N1u[d] = lane_up1(N.r1[d]); N2u[d] = lane_up1(N.r2[d]);
+                P0u[d] = lane_up1(P.r0[d]); P1u[d] = lane_up1(P.r1[d]); P2u[d] = lane_up1(P.r2[d]);
+            }
+            ngx_cross(mfact, P.r1, N.r0, N.r1, P.r0, nr.aI);           // sI: v1 = x(i,j,n) - x(i,m,k) ; v2 = x(i,j,k) - x(i,m,n)
+            ngx_cross(mfact, P.r2, N.r1, N.r2, P.r1, nr.bI);
+            ngx_cross(mfact, P.r0, N0u, P0u, N.r0, nr.aJm);            // sJ: v1 = x(i,j,n) - x(l,j,k) ; v2 = x(l,j,n) - x(i,j,k)
+            ngx_cross(mfact, P.r1, N1u, P1u, N.r1, nr.aJ);
+            ngx_cross(mfact, P.r2, N2u, P2u, N.r2, nr.bJ);
+            ngx_cross(mfact, N.r1, N0u, N1u, N.r0, nr.aK);             // sK: v1 = x(i,j,k) - x(l,m,k) ; v2 = x(l,j,k) - x(i,m,k)
+            ngx_cross(mfact, N.r2, N1u, N2u, N.r1, nr.bK);
         }
         // ---- metric sums of this plane (ng_finish for both rows; the row above takes sJ(j-1) from the own row)
-        GfMet N;
+        GfMet Nm;
         {
             double tJa[3], tKa[3], tJb[3], tKb[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const double tIa = lane_up1(aI[d]) + aI[d], tIb = lane_up1(bI[d]) + bI[d];
-                N.RIt[d] = tIa + tIb;
-                tJa[d] = aJm[d] + aJ[d]; tJb[d] = aJ[d] + bJ[d];
-                tKa[d] = sKA[d] + aK[d]; tKb[d] = sKB[d] + bK[d];
+                const double tIa = lane_up1(nr.aI[d]) + nr.aI[d], tIb = lane_up1(nr.bI[d]) + nr.bI[d];
+                Nm.RIt[d] = tIa + tIb;
+                tJa[d] = nr.aJm[d] + nr.aJ[d]; tJb[d] = nr.aJ[d] + nr.bJ[d];
+                tKa[d] = sKA[d] + nr.aK[d]; tKb[d] = sKB[d] + nr.bK[d];
             }
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                N.Q0t[d] = tJa[d] + lane_dn1(tJa[d]);
-                N.Q1t[d] = tJb[d] + lane_dn1(tJb[d]);
-                N.Pt[d] = (tKa[d] + lane_dn1(tKa[d])) + (tKb[d] + lane_dn1(tKb[d]));
+                Nm.Q0t[d] = tJa[d] + lane_dn1(tJa[d]);
+                Nm.Q1t[d] = tJb[d] + lane_dn1(tJb[d]);
+                Nm.Pt[d] = (tKa[d] + lane_dn1(tKa[d])) + (tKb[d] + lane_dn1(tKb[d]));
             }
-            N.V = (a.vol + lane_dn1(a.vol)) + (bq.vol + lane_dn1(bq.vol));
+            Nm.V = (a.vol + lane_dn1(a.vol)) + (bq.vol + lane_dn1(bq.vol));
         }
         // ---- gradient of node (i, jn, mm-1) from the cell planes mm-1 (qA, qB, S) and mm -> ring
         if (mm >= k0) {
@@ -854,19 +893,19 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
             ng_outer<true>(g, ph, S.Pt);                          // k direction: below the node -, above +
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = NQ0[v] + NQ1[v];
-            ng_outer<false>(g, ph, N.Pt);
+            ng_outer<false>(g, ph, Nm.Pt);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) t3[d] = S.Q0t[d] + N.Q0t[d];
+            for (int d = 0; d < 3; ++d) t3[d] = S.Q0t[d] + Nm.Q0t[d];
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = SQ0[v] + NQ0[v];
             ng_outer<true>(g, ph, t3);                            // j direction: own row -, row above +
 #pragma unroll
-            for (int d = 0; d < 3; ++d) t3[d] = S.Q1t[d] + N.Q1t[d];
+            for (int d = 0; d < 3; ++d) t3[d] = S.Q1t[d] + Nm.Q1t[d];
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = SQ1[v] + NQ1[v];
             ng_outer<false>(g, ph, t3);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) t3[d] = S.RIt[d] + N.RIt[d];
+            for (int d = 0; d < 3; ++d) t3[d] = S.RIt[d] + Nm.RIt[d];
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = (sA[v] + sB[v]) + (nA[v] + nB[v]);
             ng_outer<true>(g, ph, t3);                            // i direction: own column -, column i+1 +
@@ -878,7 +917,7 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
             ng_outer<false>(g, ph1, t1);
             // a QUARTER of the gradient goes to the ring (the faces then average four nodes by adding); with the 0.25 of the surface
             // integral: 1 / (16 V).  Powers of two: the face gradients are bitwise what 0.25 (g0 + g1 + g2 + g3) gives
-            const double oneOverV = 0.0625 * rcp_nr(S.V + N.V);
+            const double oneOverV = 0.0625 * rcp_nr(S.V + Nm.V);
 #pragma unroll
             for (int q = 0; q < 12; ++q) g[q] *= oneOverV;
             if (ringLane) {
@@ -893,6 +932,29 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
         }
         // ---- loads of the face part (cell plane mm-1), requested above the barrier; sI / sJ of that plane again (carried they spill)
         face_loads();          // requested above the barrier (at the top of the step: no faster, profiles/r03_f)
+        if (XN && facePlane) {
+            // geometry of the faces of cell plane mm-1 from the node planes mm-2 (Hp2, Ep2), mm-1 (P) and mm (N)
+            if (r >= 1) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const double t = (N.r0[d] + N.r1[d]) - Hp2[d];
+                    dKv[d] = 0.125 * (t + lane_up1(t));
+                }
+            }
+            if (full) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    if (r >= 1) {
+                        const double c4 = Hp2[d] + (P.r0[d] + P.r1[d]);
+                        dIv[d] = 0.125 * (lane_dn1(c4) - lane_up1(c4));
+                        sIA[d] = cIA[d];
+                    }
+                    const double f2 = Ep2[d] + (P.r2[d] - P.r0[d]);
+                    dJv[d] = 0.125 * (f2 + lane_up1(f2));
+                    sJA[d] = cJA[d];
+                }
+            }
+        }
         __syncthreads();
         if (facePlane) {
             const double* __restrict__ xb = ring + (((mm - k0) % NSLOT) * NW) * GF_G + nl * 2;                    // node plane mm-1
@@ -954,14 +1016,20 @@ __global__ __launch_bounds__(64 * NW, (PF || NW == 8) ? 1 : 2) void k_visc_gf(co
         }
         // ---- advance
         qA = a.q; qB = bq.q;
-        S = N;
+        S = Nm;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            sKA[d] = aK[d]; sKB[d] = bK[d];
+            sKA[d] = nr.aK[d]; sKB[d] = nr.bK[d];
+        }
+        if (XN) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                Hp2[d] = P.r0[d] + P.r1[d]; Ep2[d] = P.r2[d] - P.r0[d];
+                cIA[d] = nr.aI[d]; cJA[d] = nr.aJ[d];
+            }
+            P = N;
         }
         cA += sk;
-        if (PF) cur = nxt;
-        if (NSLOT == 2) __syncthreads();       // the slot the next step writes was read in this one
     }
     // ---- the last plane of the chunk: its j flux was handed over in the last step
     __syncthreads();
@@ -1078,38 +1146,22 @@ void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles,
 }
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
-int g_gf_prefetch = 0;      // tuning "gf_prefetch": k_visc_gf<.., PF>: one workgroup per CU, cell plane mm+1 requested a step ahead
-int g_gf_waves = 4;         // tuning "gf_waves": 8 = eight waves per workgroup, seven produced rows (the chunk tables follow: api.hip)
-int visc_gf_rows() { return g_gf_waves == 8 ? 7 : 3; }
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)
 {
     if (ntiles <= 0) return;
-    const dim3 grd(ntiles), blk(64, 4, 1);
-    if (g_gf_waves == 8) {
-        const dim3 blk8(64, 8, 1);
-#define GF_LAUNCH8(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G, false, 8>), grd, blk8, 0, s, tab, tiles, kp)
-        if (kp.useQCR) {
-            if (kp.viscFirst) { if (storeGrad) GF_LAUNCH8(true, true, true); else GF_LAUNCH8(true, true, false); }
-            else { if (storeGrad) GF_LAUNCH8(true, false, true); else GF_LAUNCH8(true, false, false); }
-        } else {
-            if (kp.viscFirst) { if (storeGrad) GF_LAUNCH8(false, true, true); else GF_LAUNCH8(false, true, false); }
-            else { if (storeGrad) GF_LAUNCH8(false, false, true); else GF_LAUNCH8(false, false, false); }
-        }
-#undef GF_LAUNCH8
-        return;
+    const dim3 grd(ntiles), blk(64, GF_NW, 1);
+    // geometry from the node coordinates wherever the stored normals are metric_block(x) (KParams::metricFromX bit 1)
+#define GF_LAUNCH(Q, F, G)                                                                                     \
+    {                                                                                                          \
+        if (kp.metricFromX & 2) hipLaunchKernelGGL((k_visc_gf<Q, F, G, true>), grd, blk, 0, s, tab, tiles, kp); \
+        else hipLaunchKernelGGL((k_visc_gf<Q, F, G, false>), grd, blk, 0, s, tab, tiles, kp);                  \
     }
-    if (g_gf_prefetch && !storeGrad && kp.viscFirst) {
-        if (kp.useQCR) hipLaunchKernelGGL((k_visc_gf<true, true, false, true>), grd, blk, 0, s, tab, tiles, kp);
-        else hipLaunchKernelGGL((k_visc_gf<false, true, false, true>), grd, blk, 0, s, tab, tiles, kp);
-        return;
-    }
-#define GF_LAUNCH(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, tiles, kp)
     if (kp.useQCR) {
-        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, true, false); }
-        else { if (storeGrad) GF_LAUNCH(true, false, true); else GF_LAUNCH(true, false, false); }
+        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true) else GF_LAUNCH(true, true, false) }
+        else { if (storeGrad) GF_LAUNCH(true, false, true) else GF_LAUNCH(true, false, false) }
     } else {
-        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(false, true, true); else GF_LAUNCH(false, true, false); }
-        else { if (storeGrad) GF_LAUNCH(false, false, true); else GF_LAUNCH(false, false, false); }
+        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(false, true, true) else GF_LAUNCH(false, true, false) }
+        else { if (storeGrad) GF_LAUNCH(false, false, true) else GF_LAUNCH(false, false, false) }
     }
 #undef GF_LAUNCH
 }

@@ -177,27 +177,20 @@ def test_coordinate_halos(engine):
     checks.check_coarse_level_geometry(engine, BrickTopology(2, 1, 1, 17, 13, 9), FlowParams())
 
 
-@pytest.mark.parametrize("merge", [0, 2])
-def test_bc_merged_application(engine, merge):
-    """tuning bc_merge (round 5): 2 = every application as k_bc_faces (cells off the block edges, all subfaces and kinds in one launch)
-    + k_bc_edges (the three edge rings, one workgroup per block walking the subfaces in the reference's order); 0 = one launch per
-    kind and ordinal; the default picks by subface size.  Faces large enough to have cells off the edges, every kind, split faces,
-    turbulence + mean flow together inside blocketteRes, smoothers, SA solve, multigrid with boundary subfaces"""
-    try:
-        engine.set_tuning("bc_merge", merge)
-        for spec in EULER_SPECS:
-            checks.check_apply_bc(engine, (70, 19, 11), FlowParams(), spec)
-        checks.check_apply_bc(engine, (30, 22, 14), FlowParams(), EULER_SPECS[0], secondHalo=False)
-        for spec in VISC_SPECS:
-            checks.check_apply_bc(engine, (26, 20, 12), FlowParams(equations=RANSEquations), spec, stretch_k=2.0)
-        checks.check_apply_bc(engine, (24, 18, 12), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5})
-        checks.check_apply_bc(engine, (14, 11, 9), FlowParams(outflowTreatment=2, hScalingInlet=True), {1: -8, 2: -8, 3: -10, 4: -12, 5: -2, 6: -6})
-        rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=2)
-        wall = {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}
-        checks.check_smoother_with_bc(engine, (24, 16, 12), rans, wall, stretch_k=2.0)
-        checks.check_sa_solve_with_bc(engine, (20, 14, 10), rans.replace(orderTurb=secondOrder), {1: -6, 2: -15, 3: -1, 4: -4, 5: -3, 6: -9}, stretch_k=2.0)
-        checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 2, 24, 16, 12, periodic=(False, False, False)),
-                                           FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}, stretch_k=2.0)
-        checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 32, 24, 16), FlowParams(), [0, 1, 0, -1], bc_spec={1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})
-    finally:
-        engine.set_tuning("bc_merge", 1)
+def test_bc_on_large_faces(engine):
+    """faces large enough to need several workgroups per launch: every kind, split faces, turbulence + mean flow together inside
+    blocketteRes, smoothers, SA solve, multigrid with boundary subfaces"""
+    for spec in EULER_SPECS:
+        checks.check_apply_bc(engine, (70, 19, 11), FlowParams(), spec)
+    checks.check_apply_bc(engine, (30, 22, 14), FlowParams(), EULER_SPECS[0], secondHalo=False)
+    for spec in VISC_SPECS:
+        checks.check_apply_bc(engine, (26, 20, 12), FlowParams(equations=RANSEquations), spec, stretch_k=2.0)
+    checks.check_apply_bc(engine, (24, 18, 12), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5})
+    checks.check_apply_bc(engine, (14, 11, 9), FlowParams(outflowTreatment=2, hScalingInlet=True), {1: -8, 2: -8, 3: -10, 4: -12, 5: -2, 6: -6})
+    rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=2)
+    wall = {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}
+    checks.check_smoother_with_bc(engine, (24, 16, 12), rans, wall, stretch_k=2.0)
+    checks.check_sa_solve_with_bc(engine, (20, 14, 10), rans.replace(orderTurb=secondOrder), {1: -6, 2: -15, 3: -1, 4: -4, 5: -3, 6: -9}, stretch_k=2.0)
+    checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 2, 24, 16, 12, periodic=(False, False, False)),
+                                       FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}, stretch_k=2.0)
+    checks.check_mg_cycle(engine, BrickTopology(1, 1, 1, 32, 24, 16), FlowParams(), [0, 1, 0, -1], bc_spec={1: -6, 2: -6, 3: -5, 4: -6, 5: -1, 6: -1})

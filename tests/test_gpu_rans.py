@@ -262,12 +262,16 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("inviscid_march", 2)
 
 
-def test_visc_gradient_fused(engine):
+@pytest.mark.parametrize("mfx", [7, 5])
+def test_visc_gradient_fused(engine, mfx):
     """k_visc_gf: nodal gradients and viscous fluxes in one kernel, the gradients stay in an LDS ring.
+    mfx (tuning metric_from_x): 7 = the geometry formed from the node coordinates (k_visc_gf<.., XN>, round 6, the default), 5 = the
+    stored normals and centre-to-centre vectors.
     Partial tiles in i (60 columns) / j (3 rows) / the k chunk, blanked cells, QCR, laminar NS, matrix / scalar dissipation, the
     kernel completing dw itself (persistent fw of the RK stages), the stored-gradient variant (wall stress, updateIntermed), k chunks
     of march_kch planes (gf_cus = -1) and chunks fitted to rounds of 2 x CUs workgroups as on a device with 1 / 3 CUs."""
     try:
+        engine.set_tuning("metric_from_x", mfx)
         prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
         checks.check_block_res(engine, (63, 7, 35), prm, seed=5, stretch_k=2.0, holes=0.05)
         checks.check_block_res(engine, (61, 9, 33), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
@@ -287,6 +291,7 @@ def test_visc_gradient_fused(engine):
     finally:
         engine.set_tuning("march_kch", 32)
         engine.set_tuning("gf_cus", 0)
+        engine.set_tuning("metric_from_x", 7)
 
 
 def test_block_res_without_intermediates(engine):
@@ -323,34 +328,15 @@ def test_foreign_normals_then_own_nodes(engine):
     checks.check_foreign_normals_then_own_nodes(engine, (63, 11, 35), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
 
 
-def test_visc_gf_prefetch_variant(engine):
-    """tuning gf_prefetch: k_visc_gf<.., PF> (one workgroup per CU, the cell plane mm+1 requested a step ahead): partial tiles, QCR, RK
-    stages with persistent fw, walls"""
-    try:
-        engine.set_tuning("gf_prefetch", 1)
-        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
-        checks.check_block_res(engine, (63, 11, 35), prm, seed=71, stretch_k=2.0, holes=0.05)
-        checks.check_block_res(engine, (130, 7, 9), prm.replace(useQCR=True), seed=72, stretch_k=2.0)
-        checks.check_block_res_vs_blockette(engine, (24, 16, 8), prm, seed=73, stretch_k=2.0)
-        checks.check_rk_residual_sequence(engine, (20, 9, 12), FlowParams(equations=NSEquations), stretch_k=2.0)
-    finally:
-        engine.set_tuning("gf_prefetch", 0)
-
-
-@pytest.mark.parametrize("overlap", [0, 1])
-def test_front_overlap_shell_and_core(engine, overlap):
-    """tuning front_overlap: derived values as shell + core (the core on the side queue beside the boundary-condition launches)"""
+def test_blockette_res_with_bc_on_thin_blocks(engine):
+    """the whole blocketteRes with boundary subfaces on blocks that are thin in one or several directions; floored pressures"""
     from adflow_amd.topology import BrickTopology
     spec = {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}
     rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
-    try:
-        engine.set_tuning("front_overlap", overlap)
-        for dims in ((70, 9, 11), (130, 5, 3), (3, 2, 1), (24, 16, 2)):
-            checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 1, *dims, periodic=(False, False, False)), rans, spec, stretch_k=2.0)
-        checks.check_blockette_res_with_bc(engine, BrickTopology(2, 2, 2, 64, 48, 32, periodic=(False, False, False)), rans, spec, floor_p=True,
-                                           stretch_k=2.0)
-    finally:
-        engine.set_tuning("front_overlap", 0)
+    for dims in ((70, 9, 11), (130, 5, 3), (3, 2, 1), (24, 16, 2)):
+        checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 1, *dims, periodic=(False, False, False)), rans, spec, stretch_k=2.0)
+    checks.check_blockette_res_with_bc(engine, BrickTopology(2, 2, 2, 64, 48, 32, periodic=(False, False, False)), rans, spec, floor_p=True,
+                                       stretch_k=2.0)
 
 
 def test_split_evaluation_error_exit_joins_the_side_queue(engine):
@@ -386,19 +372,3 @@ def test_wall_bounded_brick_through_rccl_self_and_split(engine):
             assert n == 4
     finally:
         engine.set_tuning("comm_self", 0)
-
-
-def test_visc_gf_eight_waves(engine):
-    """tuning gf_waves = 8: k_visc_gf<.., NW = 8>, one workgroup of eight waves per CU, seven produced rows per nine loaded, two ring slots
-    and two barriers per plane: the cases of test_visc_gradient_fused (partial tiles in i / j / k, QCR, persistent fw, stored
-    gradients, chunk tables of small devices), the split evaluation and a wall-bounded brick"""
-    from adflow_amd.topology import BrickTopology
-    try:
-        engine.set_tuning("gf_waves", 8)
-        test_visc_gradient_fused(engine)
-        engine.set_tuning("gf_waves", 8)
-        rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
-        checks.check_blockette_res_with_bc(engine, BrickTopology(2, 1, 2, 70, 19, 11, periodic=(False, False, False)), rans,
-                                           {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}, split_eval=2, stretch_k=2.0)
-    finally:
-        engine.set_tuning("gf_waves", 4)

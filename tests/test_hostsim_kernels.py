@@ -141,49 +141,26 @@ def test_foreign_normals_then_own_nodes(hostsim_engine):
     checks.check_foreign_normals_then_own_nodes(hostsim_engine, (9, 7, 6), FlowParams(equations=RANSEquations, spaceDiscr=upwind), stretch_k=2.0)
 
 
-@pytest.mark.parametrize("merge", [0, 2])
-def test_bc_merged_application(hostsim_engine, merge):
-    """tuning bc_merge: one launch over the cells off the block edges + one ordered pass over the edge rings (2), one launch per kind
-    and ordinal (0); faces with cells off the edges (more than 6 cells wide)"""
+def test_bc_faces_wider_than_the_edge_rings(hostsim_engine):
+    """faces with cells off the block edges (more than 6 cells wide): every kind, split faces, smoother and blocketteRes with subfaces"""
     e = hostsim_engine
-    try:
-        e.set_tuning("bc_merge", merge)
-        checks.check_apply_bc(e, (12, 10, 9), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9})
-        checks.check_apply_bc(e, (12, 10, 9), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, stretch_k=2.0)
-        checks.check_apply_bc(e, (14, 10, 9), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5}, secondHalo=False)
-        rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=2)
-        checks.check_smoother_with_bc(e, (10, 9, 8), rans, {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}, stretch_k=2.0)
-        checks.check_blockette_res_with_bc(e, BrickTopology(2, 1, 1, 10, 9, 8, periodic=(False, False, False)),
-                                           FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}, stretch_k=2.0)
-    finally:
-        e.set_tuning("bc_merge", 1)
+    checks.check_apply_bc(e, (12, 10, 9), FlowParams(), {1: -1, 2: -6, 3: -5, 4: -15, 5: -1, 6: -9})
+    checks.check_apply_bc(e, (12, 10, 9), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -4, 5: -3, 6: -6}, stretch_k=2.0)
+    checks.check_apply_bc(e, (14, 10, 9), FlowParams(), {1: -1, 2: -1, 3: -1, 4: -6, 5: -6, 6: -1}, split={3: -6, 6: -5}, secondHalo=False)
+    rans = FlowParams(equations=RANSEquations, smoother=DADI, resAveraging=noResAveraging, cfl=1.5, nSubiterations=2, nSubIterTurb=2)
+    checks.check_smoother_with_bc(e, (10, 9, 8), rans, {1: -6, 2: -6, 3: -1, 4: -1, 5: -3, 6: -6}, stretch_k=2.0)
+    checks.check_blockette_res_with_bc(e, BrickTopology(2, 1, 1, 10, 9, 8, periodic=(False, False, False)),
+                                       FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}, stretch_k=2.0)
 
 
-@pytest.mark.parametrize("overlap", [0, 1])
-def test_front_overlap_shell_and_core(hostsim_engine, overlap):
-    """tuning front_overlap: the derived values of blocketteRes as shell (two layers behind the block faces) + core on a side queue
-    beside the boundary conditions; blocks thinner than the shell in one or several directions"""
+def test_blockette_res_with_bc_on_thin_blocks(hostsim_engine):
+    """the whole blocketteRes with boundary subfaces on blocks of one to a few cells in one or several directions; floored pressures"""
     e = hostsim_engine
     spec = {1: -6, 2: -6, 3: -1, 4: -6, 5: -3, 6: -6}
     rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
-    try:
-        e.set_tuning("front_overlap", overlap)
-        for dims in ((9, 7, 6), (5, 4, 3), (3, 2, 1), (70, 5, 2), (4, 9, 8)):
-            checks.check_blockette_res_with_bc(e, BrickTopology(2, 1, 1, *dims, periodic=(False, False, False)), rans, spec, stretch_k=2.0)
-        checks.check_blockette_res_with_bc(e, BrickTopology(1, 2, 1, 8, 6, 5, periodic=(False, False, False)), rans, spec, floor_p=True, stretch_k=2.0)
-    finally:
-        e.set_tuning("front_overlap", 0)
-
-
-def test_visc_gf_prefetch_variant(hostsim_engine):
-    e = hostsim_engine
-    try:
-        e.set_tuning("gf_prefetch", 1)
-        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
-        checks.check_block_res(e, (63, 5, 9), prm, seed=71, stretch_k=2.0, holes=0.05)
-        checks.check_block_res(e, (10, 7, 6), prm.replace(useQCR=True), seed=72, stretch_k=2.0)
-    finally:
-        e.set_tuning("gf_prefetch", 0)
+    for dims in ((9, 7, 6), (5, 4, 3), (3, 2, 1), (70, 5, 2), (4, 9, 8)):
+        checks.check_blockette_res_with_bc(e, BrickTopology(2, 1, 1, *dims, periodic=(False, False, False)), rans, spec, stretch_k=2.0)
+    checks.check_blockette_res_with_bc(e, BrickTopology(1, 2, 1, 8, 6, 5, periodic=(False, False, False)), rans, spec, floor_p=True, stretch_k=2.0)
 
 
 def test_rotated_interfaces(hostsim_engine):
@@ -457,22 +434,10 @@ def test_viscous_kernel_variants(hostsim_engine):
         else test_gpu_rans.test_viscous_kernel_variants(hostsim_engine)
 
 
-def test_visc_gradient_fused(hostsim_engine):
+@pytest.mark.parametrize("mfx", [7, 5])
+def test_visc_gradient_fused(hostsim_engine, mfx):
     import test_gpu_rans
-    test_gpu_rans.test_visc_gradient_fused(hostsim_engine)
-
-
-def test_visc_gf_eight_waves(hostsim_engine):
-    e = hostsim_engine
-    try:
-        e.set_tuning("gf_waves", 8)
-        prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
-        checks.check_block_res(e, (63, 9, 7), prm, seed=5, stretch_k=2.0, holes=0.05)
-        checks.check_block_res(e, (9, 16, 5), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
-        checks.check_rk_residual_sequence(e, (6, 8, 5), FlowParams(equations=NSEquations, muSuthDim=1.0), stretch_k=2.0)
-        checks.check_wall_stress(e, (9, 8, 7), FlowParams(equations=RANSEquations), {1: -6, 2: -6, 3: -3, 4: -4, 5: -3, 6: -6}, stretch_k=2.0)
-    finally:
-        e.set_tuning("gf_waves", 4)
+    test_gpu_rans.test_visc_gradient_fused(hostsim_engine, mfx)
 
 
 def test_multiblock_brick_block_res(hostsim_engine):
