@@ -15,7 +15,7 @@
 
 #include "internal.h"
 
-extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march;
+extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_gf_ws;
 int g_test_fault = 0;        // tuning "test_fault" (tests only): bit 0 = the hipGraph capture of a multigrid cycle reports failure, bit 1 = the
                              // split evaluation fails behind its fork -- the error paths must leave the library usable
 int g_pc_handover = 3;       // tuning "pc_handover": k_pc_march_h (every j face once, the flux handed to the row above) -- bit 0: in the dual build, bit 1: in the plain one (both on: forward mode 152.6 -> 144.1 ms, finite differences 94.6 -> 91.4 ms, profiles/r05_x_ab.txt)
@@ -141,6 +141,7 @@ std::map<int, int> g_tab_size;
 std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
 std::map<int, std::pair<int4*, int>> g_gf_tiles;       // level -> round-fitted chunk table of k_visc_gf
 std::map<int, std::pair<int4*, int>> g_gf_tiles_int, g_gf_tiles_bnd;   // the same chunks: those that read no halo cell / the others
+std::map<int, int> g_gf_tiles_ws;     // level -> the tables were fitted to rounds of ONE workgroup per CU (k_visc_gfw) / of two (k_visc_gf)
 std::map<int, std::pair<int4*, int>> g_sa_tiles, g_sa_tiles_int, g_sa_tiles_bnd;   // the same three for k_sa_march
 int g_num_cus = 0;
 int g_gf_nofit = 0;         // tuning gf_cus = -1 (tests): chunks of march_kch planes instead of the round fit
@@ -2333,12 +2334,34 @@ static int build_chunk_tables(int level, int R, double warm, int reach, std::pai
     return 0;
 }
 
+// k_visc_gfw serves the level: tuning gf_ws and the geometry of every block re-formable from its nodes (make_kparams: metricFromX bit 1)
+static int level_gf_ws(int level)
+{
+    if (!g_gf_ws || !(g_metric_from_x & 2)) return 0;
+    for (auto& kv : g_blocks)
+        if (std::get<0>(kv.first) == level && !kv.second->normals_from_x_ok) return 0;
+    return 1;
+}
+
 int ensure_gf_tiles(int level)
 {
-    if (g_gf_tiles.count(level)) return 0;
+    const int ws = level_gf_ws(level);
+    if (g_gf_tiles.count(level)) {
+        if (g_gf_tiles_ws[level] == ws) return 0;
+        // the kernel that serves the level changed (an upload of foreign normals, a tuning key): fit the chunks to its rounds
+        if (g_stream) HIPCHK(hipStreamSynchronize(g_stream));
+        if (g_streamB) HIPCHK(hipStreamSynchronize(g_streamB));
+        ++g_state_gen;         // a captured multigrid cycle holds the device pointer of the old table
+        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd}) {
+            (void)hipFree((*mp)[level].first);
+            mp->erase(level);
+        }
+    }
     std::pair<int4*, int> a, i, b;
-    if (build_chunk_tables(level, 3, 1.5, 1, &a, &i, &b, 2)) return 1;
+    // k_visc_gfw: one workgroup per CU, len + 3 iterations per chunk; k_visc_gf: two per CU, len + 2
+    if (build_chunk_tables(level, 3, ws ? 2.5 : 1.5, 1, &a, &i, &b, ws ? 1 : 2)) return 1;
     g_gf_tiles[level] = a; g_gf_tiles_int[level] = i; g_gf_tiles_bnd[level] = b;
+    g_gf_tiles_ws[level] = ws;
     return 0;
 }
 
@@ -3882,6 +3905,7 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "pc_handover")) { g_pc_handover = value; return 0; }
     if (!strcmp(key, "jac_snap")) { g_jac_snap = value; return 0; }
     if (!strcmp(key, "pc_fused")) { g_pc_fused = value; mg_graph_drop(); return 0; }
+    if (!strcmp(key, "gf_ws")) { g_gf_ws = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);

@@ -256,22 +256,22 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("roe_march", 1)
         engine.set_tuning("sa_march", 1)
         engine.set_tuning("sa_side", 0)
-        engine.set_tuning("metric_from_x", 7)
+        engine.set_tuning("gf_ws", 1)
         engine.set_tuning("xcd_tiles", 2)
         engine.set_tuning("gf_cus", 0)
         engine.set_tuning("inviscid_march", 2)
 
 
-@pytest.mark.parametrize("mfx", [7, 5])
-def test_visc_gradient_fused(engine, mfx):
+@pytest.mark.parametrize("ws", [1, 0])
+def test_visc_gradient_fused(engine, ws):
     """k_visc_gf: nodal gradients and viscous fluxes in one kernel, the gradients stay in an LDS ring.
-    mfx (tuning metric_from_x): 7 = the geometry formed from the node coordinates (k_visc_gf<.., XN>, round 6, the default), 5 = the
-    stored normals and centre-to-centre vectors.
+    ws (tuning gf_ws): 1 = k_visc_gfw (round 6, the default): the geometry formed from the node coordinates, producer and consumer
+    waves in one workgroup of eight; 0 = k_visc_gf on the stored normals and centre-to-centre vectors.
     Partial tiles in i (60 columns) / j (3 rows) / the k chunk, blanked cells, QCR, laminar NS, matrix / scalar dissipation, the
     kernel completing dw itself (persistent fw of the RK stages), the stored-gradient variant (wall stress, updateIntermed), k chunks
     of march_kch planes (gf_cus = -1) and chunks fitted to rounds of 2 x CUs workgroups as on a device with 1 / 3 CUs."""
     try:
-        engine.set_tuning("metric_from_x", mfx)
+        engine.set_tuning("gf_ws", ws)
         prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
         checks.check_block_res(engine, (63, 7, 35), prm, seed=5, stretch_k=2.0, holes=0.05)
         checks.check_block_res(engine, (61, 9, 33), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
@@ -291,7 +291,7 @@ def test_visc_gradient_fused(engine, mfx):
     finally:
         engine.set_tuning("march_kch", 32)
         engine.set_tuning("gf_cus", 0)
-        engine.set_tuning("metric_from_x", 7)
+        engine.set_tuning("gf_ws", 1)
 
 
 def test_block_res_without_intermediates(engine):

@@ -434,10 +434,10 @@ def test_viscous_kernel_variants(hostsim_engine):
         else test_gpu_rans.test_viscous_kernel_variants(hostsim_engine)
 
 
-@pytest.mark.parametrize("mfx", [7, 5])
-def test_visc_gradient_fused(hostsim_engine, mfx):
+@pytest.mark.parametrize("ws", [1, 0])
+def test_visc_gradient_fused(hostsim_engine, ws):
     import test_gpu_rans
-    test_gpu_rans.test_visc_gradient_fused(hostsim_engine, mfx)
+    test_gpu_rans.test_visc_gradient_fused(hostsim_engine, ws)
 
 
 def test_multiblock_brick_block_res(hostsim_engine):
