@@ -173,6 +173,16 @@ __device__ __forceinline__ double fast_exp_neg(double x)
 }
 #endif
 
+// Workgroup barrier that orders the LDS traffic of the workgroup only.  __syncthreads() is also a fence over GLOBAL memory: the compiler
+// puts s_waitcnt vmcnt(0) in front of the s_barrier, i.e. a wave waits for the acknowledgement of its global stores (and for every load it
+// has requested ahead) at every barrier.  The marching kernels exchange data between waves through LDS alone -- what a wave stores to
+// global memory is never read by another wave of the launch -- so their per-plane barrier only has to drain the LDS queue.
+#ifdef HOSTSIM
+#define lds_barrier() __syncthreads()
+#else
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
 // binary exponent of a finite x > 0 (frexp: x = f 2^e, 0.5 <= f < 1)
 #ifdef HOSTSIM
 __device__ __forceinline__ int exponent_of(double x) { int e; (void)frexp(x, &e); return e; }
@@ -270,6 +280,7 @@ struct KParams {
     int viscFirst;         // the viscous march runs BEFORE the Roe march: it writes its flux sums into dw(2:5), the Roe march adds them and completes dw
     int radiiInMarch;      // the Euler march forms the spectral radii itself (no k_time_step pass in front)
     int metricFromX;       // marching kernels re-form the face normals from the node coordinates (as blocketteResCore, blockette.F90:854-960)
+    int dbg;               // (experiments: ablation bits of k_visc_gfw, tuning gf_dbg)
     int lumpedDiss;        // inputDiscretization::lumpedDiss (preconditioner assembly): first-order Roe upwind (fluxes.F90:1536)
     double sigma;
     double rFil, sfil;

@@ -1041,18 +1041,33 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
             ngx_cross(mfact, P.r1, P0u, P1u, P.r0, sKA);
             ngx_cross(mfact, P.r2, P1u, P2u, P.r1, sKB);
         }
-        for (int mm = k0 - 1; mm <= k1 + 2; ++mm) {
+        // what a step loads: cell plane of the rows jn and jn+1 (state, volume) and the nodes of that plane.  Requested ONE STEP AHEAD: the
+        // values of plane mm+1 are in flight while plane mm is worked on (a producer has the registers for it; with the request at the
+        // top of its own step a step lasted load latency + arithmetic, 1.00 against 0.86 ms: profiles/r06_b_ab.txt)
+        struct Req { double au, av, aw, ap, ar, alv, aev, avol, bu, bv, bw, bp, br, bvol, blv, bev; GfNod N; };
+        auto request = [&](unsigned c) {
+            Req q;
+            const unsigned cb = c + dB;
+            q.au = ldg(m.w1, c); q.av = ldg(m.w2, c); q.aw = ldg(m.w3, c); q.ap = ldg(m.p, c); q.ar = ldg(m.w0, c);
+            q.alv = ldg(m.rlv, c); q.aev = eddy ? ldg(m.rev, c) : 0.0; q.avol = ldg(m.vol, c);
+            q.bu = ldg(m.w1, cb); q.bv = ldg(m.w2, cb); q.bw = ldg(m.w3, cb); q.bp = ldg(m.p, cb); q.br = ldg(m.w0, cb);
+            q.bvol = ldg(m.vol, cb);
+            q.blv = 0.0; q.bev = 0.0;
+            if (top) { q.blv = ldg(m.rlv, cb); q.bev = eddy ? ldg(m.rev, cb) : 0.0; }
+            ld_nodes(c, q.N);
+            return q;
+        };
+        const unsigned cA0 = cA;
+        // (two request buffers used in turn -- the loop below is unrolled by two: a single pair nxt -> cur is copied at the loop
+        // latch, i.e. waited for in front of the barrier of the step that requested it)
+        auto pstep = [&](const int mm, const Req& cur, Req& nxt) {
             if (mm <= k1 + 1) {
-                const unsigned cF = cA - sk, cb = cA + dB;
-                // ---- cell plane mm of the rows jn and jn+1: state and volume; the nodes of plane mm
-                const double au = ldg(m.w1, cA), av = ldg(m.w2, cA), aw = ldg(m.w3, cA), ap = ldg(m.p, cA), ar = ldg(m.w0, cA);
-                const double alv = ldg(m.rlv, cA), aev = eddy ? ldg(m.rev, cA) : 0.0, avol = ldg(m.vol, cA);
-                const double bu = ldg(m.w1, cb), bv = ldg(m.w2, cb), bw = ldg(m.w3, cb), bp = ldg(m.p, cb), br = ldg(m.w0, cb);
-                const double bvol = ldg(m.vol, cb);
-                double blv = 0.0, bev = 0.0;
-                if (top) { blv = ldg(m.rlv, cb); bev = eddy ? ldg(m.rev, cb) : 0.0; }
-                GfNod N;
-                ld_nodes(cA, N);
+                const unsigned cF = cA - sk;
+                nxt = request((kp.dbg & 4) ? cA0 : cA + (mm <= k1 ? sk : 0u));          // plane mm+1 (the last step asks for its own plane again)
+                __builtin_amdgcn_sched_barrier(0);
+                const double au = cur.au, av = cur.av, aw = cur.aw, ap = cur.ap, ar = cur.ar, alv = cur.alv, aev = cur.aev, avol = cur.avol;
+                const double bu = cur.bu, bv = cur.bv, bw = cur.bw, bp = cur.bp, br = cur.br, bvol = cur.bvol, blv = cur.blv, bev = cur.bev;
+                const GfNod N = cur.N;
                 const double ana = -(gam * ap) * rcp_nr(ar), bna = -(gam * bp) * rcp_nr(br);
                 // ---- publish the state of cell (i, jn, mm) (wave 3: also of row jn+1)
                 {
@@ -1113,7 +1128,7 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
                 }
                 const double nA[4] = {au, av, aw, ana}, nB[4] = {bu, bv, bw, bna};
                 // ---- gradient of node (i, jn, mm-1) from the cell planes mm-1 (sA, sB, S) and mm -> ring
-                if (mm >= k0) {
+                if (mm >= k0 && !(kp.dbg & 1)) {
                     double g[12];
 #pragma unroll
                     for (int q = 0; q < 12; ++q) g[q] = 0.0;
@@ -1173,7 +1188,15 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
                 P = N;
                 cA += sk;
             }
-            __syncthreads();
+        };
+        Req qa = request(cA), qb;
+        for (int mm = k0 - 1; mm <= k1 + 2; mm += 2) {
+            pstep(mm, qa, qb);
+            lds_barrier();
+            if (mm + 1 <= k1 + 2) {
+                pstep(mm + 1, qb, qa);
+                lds_barrier();
+            }
         }
         return;
     }
@@ -1203,15 +1226,17 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
 #pragma unroll
     for (int d = 0; d < 3; ++d) Hp1[d] = ldg(xnod, cC - sk - dM + d * nb8) + ldg(xnod, cC - sk + d * nb8);      // H of node plane k0-2
     // completes the flux sum of cell plane kc (byte offset c) with the j flux handed over by the wave below and stores it
-    auto finish = [&](unsigned c, const double* __restrict__ fjr, int flg) {
+    auto finish_sum = [&](const double* __restrict__ fjr, double fs[4]) {
         const Dbl2 f01 = *reinterpret_cast<const Dbl2*>(fjr), f23 = *reinterpret_cast<const Dbl2*>(fjr + 2);
-        const double fl4[4] = {f01.x, f01.y, f23.x, f23.y};
+        fs[0] = pend[0] + f01.x; fs[1] = pend[1] + f01.y; fs[2] = pend[2] + f23.x; fs[3] = pend[3] + f23.y;
+    };
+    auto finish_store = [&](unsigned c, const double fs[4], int flg) {
         if (!outC) return;
         const double blank = flg_blank((uint8_t)flg);
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const unsigned o = c + (l + 1) * nb8;
-            double fwn = pend[l] + fl4[l];
+            double fwn = fs[l];
             if (FIRST) { stg(dw, o, fwn); continue; }
             if (kp.fwMode) {
                 fwn += ldg(fw, o);
@@ -1221,17 +1246,21 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
         }
         if (!FIRST && kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
     };
-    for (int mm = k0 - 1; mm <= k1 + 2; ++mm) {
+    auto cstep = [&](const int mm, const GfNod& N, const int flagW, GfNod& Nn, int& flagN) {
         if (mm >= k0) {
             const int cs = mm - 1;
             const unsigned cF = cC - sk;                              // cell plane cs-1: the plane of the faces
+            const int flag0 = ((unsigned)flagW >> (8u * ((cF >> 3) & 3u))) & 0xffu;
             const bool facePlane = (cs >= k0);
             const bool full = (cs > k0);                              // all faces (first face step: the k face below plane k0 only)
-            // ---- requests: nodes of plane cs (H, E), flags of the face plane
-            GfNod N;
-            ld_nodes(cC, N);
-            int flag0 = 0;
-            if (facePlane) flag0 = flags[cF >> 3];
+            double fsum[4] = {0.0, 0.0, 0.0, 0.0};
+            bool finNow = false;
+            int finFlag = 0;
+            // ---- nodes of plane cs (H, E) and flags of the face plane: requested a step ahead
+            ld_nodes(cC + (cs <= k1 ? sk : 0u), Nn);
+            // (the flag byte as the aligned 32-bit word around it: a byte load is zero-extended where the loop carries it, i.e. waited for
+            // in front of the barrier of the step that requested it)
+            flagN = (int)*(GPTR(const uint32_t))((GPTR(const char))flags + ((cC >> 3) & ~3u));
             // ---- records of plane cs: state of the rows jn, jn+1, normals of cell (i, jn, cs)
             VmCell a, bq;
             double nI[3], nJ[3], nK[3];
@@ -1251,10 +1280,12 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
                 const double* __restrict__ xb = ring + (((cs - k0) % NSLOT) * NW) * GF_G + nl * 2;                    // node plane cs-1
                 const double* __restrict__ xp = ring + (((cs - k0 + NSLOT - 1) % NSLOT) * NW) * GF_G + nl * 2;        // node plane cs-2
                 const int oM = (r >= 1 ? r - 1 : 0) * GF_G, o0 = r * GF_G;                                // node rows jn-1 and jn
-                if (full && r >= 1 && cs - 2 >= k0) {
-                    // cell plane cs-2: the j flux from the wave below has arrived (written in step cs-1)
-                    finish(cF - sk, fjx + ((cs - 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
-                }
+                // cell plane cs-2: the j flux from the wave below has arrived (written in step cs-1).  The sum is formed here (pend is
+                // renewed below) and STORED at the end of the step: the wait for the nodes requested at the top of the step then stands
+                // in front of the stores of the same step and covers the acknowledged stores of the step before only
+                const bool fin = (full && r >= 1 && cs - 2 >= k0);
+                if (fin) finish_sum(fjx + ((cs - 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, fsum);
+                finNow = fin; finFlag = flagP;
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
                 if (full) {
                     // ---- j face (jn | jn+1): nodes (i-1..i, jn, cs-2..cs-1); handed to the wave above
@@ -1270,7 +1301,7 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
                         const double s0 = u.x + v.x, s1 = u.y + v.y;
                         gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                     }
-                    vm_face<QCR>(K, gs, qA, qB, sJA, dJv, flg_porJ((uint8_t)flag0), f);
+                    if (kp.dbg & 2) { f[0] = gs[0]; f[1] = gs[1]; f[2] = gs[2]; f[3] = gs[3]; } else vm_face<QCR>(K, gs, qA, qB, sJA, dJv, flg_porJ((uint8_t)flag0), f);
 #pragma unroll
                     for (int l = 0; l < 4; ++l) acc[l] = -f[l];
                     if (r < NW - 1 && lane >= 2 && lane <= 61) {
@@ -1295,7 +1326,7 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
                             gs[q] = (u.x + v.x) + (w.x + z.x); gs[q + 1] = (u.y + v.y) + (w.y + z.y);
                         }
                         const VmCell qR = vm_dn1(qA);
-                        vm_face<QCR>(K, gs, qA, qR, sIA, dIv, flg_porI((uint8_t)flag0), f);
+                        if (kp.dbg & 2) { f[0] = gs[0]; f[1] = gs[1]; f[2] = gs[2]; f[3] = gs[3]; } else vm_face<QCR>(K, gs, qA, qR, sIA, dIv, flg_porI((uint8_t)flag0), f);
 #pragma unroll
                         for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
                     }
@@ -1313,7 +1344,7 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
                             const double s0 = w.x + z.x, s1 = w.y + z.y;
                             gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                         }
-                        vm_face<QCR>(K, gs, qA, a, sKA, dKv, flg_porK((uint8_t)flag0), f);
+                        if (kp.dbg & 2) { f[0] = gs[0]; f[1] = gs[1]; f[2] = gs[2]; f[3] = gs[3]; } else vm_face<QCR>(K, gs, qA, a, sKA, dKv, flg_porK((uint8_t)flag0), f);
 #pragma unroll
                         for (int l = 0; l < 4; ++l) { pend[l] = (acc[l] + fk[l]) - f[l]; fk[l] = f[l]; }
                     }
@@ -1328,12 +1359,29 @@ __global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__
                 Hp2[d] = Hp1[d]; Hp1[d] = N.r0[d] + N.r1[d];
                 Ep2[d] = Ep1[d]; Ep1[d] = N.r2[d] - N.r0[d];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (finNow) finish_store(cF - sk, fsum, finFlag);
             cC += sk;
         }
-        __syncthreads();
+    };
+    GfNod Na, Nb;
+    int fa = 0, fb = 0;
+    ld_nodes(cC, Nb);                       // the first working step is the second of the pair (mm = k0)
+    Na = Nb;
+    for (int mm = k0 - 1; mm <= k1 + 2; mm += 2) {
+        cstep(mm, Na, fa, Nb, fb);
+        lds_barrier();
+        if (mm + 1 <= k1 + 2) {
+            cstep(mm + 1, Nb, fb, Na, fa);
+            lds_barrier();
+        }
     }
     // ---- the last plane of the chunk: its j flux was handed over in the last step
-    if (r >= 1 && k1 >= k0) finish(cC - 2 * sk, fjx + ((k1 + 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
+    if (r >= 1 && k1 >= k0) {
+        double fsum[4];
+        finish_sum(fjx + ((k1 + 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, fsum);
+        finish_store(cC - 2 * sk, fsum, flagP);
+    }
 }
 
 #endif
@@ -1446,6 +1494,7 @@ void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles,
 }
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
+int g_gf_dbg = 0;
 int g_gf_ws = 1;            // tuning "gf_ws": k_visc_gfw (geometry from the nodes, producer / consumer waves) wherever metricFromX bit 1 holds
 bool visc_gf_ws(const KParams& kp) { return g_gf_ws && (kp.metricFromX & 2); }
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)
@@ -1453,9 +1502,10 @@ void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KPa
     if (ntiles <= 0) return;
     const dim3 grd(ntiles), blk(64, GF_NW, 1), blkw(64, 2 * GF_NW, 1);
     const bool ws = visc_gf_ws(kp);
+    KParams kd = kp; kd.dbg = g_gf_dbg;
 #define GF_LAUNCH(Q, F, G)                                                                              \
     {                                                                                                   \
-        if (ws) hipLaunchKernelGGL((k_visc_gfw<Q, F, G>), grd, blkw, 0, s, tab, tiles, kp);             \
+        if (ws) hipLaunchKernelGGL((k_visc_gfw<Q, F, G>), grd, blkw, 0, s, tab, tiles, kd);             \
         else hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, tiles, kp);                  \
     }
     if (kp.useQCR) {
