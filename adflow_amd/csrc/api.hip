@@ -15,10 +15,9 @@
 
 #include "internal.h"
 
-extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march, g_gf_ws, g_gf_dbg;
+extern int g_march_kch, g_viscous_tiled, g_inviscid_march, g_roe_march, g_sa_march;
 int g_test_fault = 0;        // tuning "test_fault" (tests only): bit 0 = the hipGraph capture of a multigrid cycle reports failure, bit 1 = the
                              // split evaluation fails behind its fork -- the error paths must leave the library usable
-int g_pc_handover = 3;       // tuning "pc_handover": k_pc_march_h (every j face once, the flux handed to the row above) -- bit 0: in the dual build, bit 1: in the plain one (both on: forward mode 152.6 -> 144.1 ms, finite differences 94.6 -> 91.4 ms, profiles/r05_x_ab.txt)
 int g_rvec_joint = 1;        // tuning "rvec_joint": the six entries of a cell of the matrix-free residual vector written by ONE kernel (KParams::rvecTurbFromDw)
 int g_pc_fused = 1;          // tuning "pc_fused": first-order Roe + thin-layer viscous flux of the preconditioner matrix as ONE march (kernels_pc_march.hip), plain and dual
 int g_xcd_tiles = 2;        // tuning "xcd_tiles": 0 = tiles in launch order, 1 = XCD x owns the x-th eighth of the launch, 2 = of every round
@@ -35,8 +34,6 @@ hipEvent_t g_evFork = nullptr, g_evB = nullptr, g_evC = nullptr, g_evB1 = nullpt
 hipStream_t g_streamX = nullptr;                 // the RCCL send / recv group of a halo exchange
 hipEvent_t g_evPack = nullptr, g_evComm = nullptr;
 int g_overlap = 1;
-int g_sa_side = 0;         // tuning "sa_side": SA residual on a side queue beside the mean-flow kernels.  Round 4: with every march laid out
-                           // for two resident waves per SIMD the kernels no longer fill each other's gaps (2.26 beside, 2.21 ms in a row)
 adflow_opts g_opts;
 bool g_have_opts = false;
 hipEvent_t g_events[64];
@@ -131,6 +128,7 @@ std::vector<ActRegion> g_act;
 std::map<std::pair<int, int>, CommPattern> g_comm;   // (level, nLayers)
 double* g_rvec_target = nullptr;     // residual vector the kernels of the evaluation in flight write (nk_residual_dev)
 int g_rvec_done = 0;                  // bit 0: flow entries written, bit 1: turbulence entry written
+int g_snap_done = 0;                  // the same for the snapshot entries of a coloured Jacobian evaluation (KParams::snapTab)
 long g_state_gen = 0;        // bumped by every call that changes what a multigrid cycle enqueues (options, tuning, blocks, patterns, subfaces)
 int g_split_eval = 1;       // tuning "split_eval": whalo2 + blocketteRes with the halo-free tiles inside the exchange: 1 = when the pattern has messages, 2 = always, 0 = never
 int g_mg_graph = 1;         // tuning "mg_graph": a repeated adflow_gpu_mg_cycle is captured once into a hipGraph and replayed
@@ -141,7 +139,6 @@ std::map<int, int> g_tab_size;
 std::map<int, std::pair<int4*, int>> g_tiles;          // level -> XCD-ordered tile table of the marching kernel
 std::map<int, std::pair<int4*, int>> g_gf_tiles;       // level -> round-fitted chunk table of k_visc_gf
 std::map<int, std::pair<int4*, int>> g_gf_tiles_int, g_gf_tiles_bnd;   // the same chunks: those that read no halo cell / the others
-std::map<int, int> g_gf_tiles_ws;     // level -> the tables were fitted to rounds of ONE workgroup per CU (k_visc_gfw) / of two (k_visc_gf)
 std::map<int, std::pair<int4*, int>> g_sa_tiles, g_sa_tiles_int, g_sa_tiles_bnd;   // the same three for k_sa_march
 int g_num_cus = 0;
 int g_gf_nofit = 0;         // tuning gf_cus = -1 (tests): chunks of march_kch planes instead of the round fit
@@ -288,8 +285,9 @@ int copy_box(Block* b, double* dev, const double* host_c, int ncomp, int lo_i, i
 }
 
 int g_lumped = 0;       // inputDiscretization::lumpedDiss while a preconditioner matrix is assembled
-int g_metric_from_x = 7;   // tuning "metric_from_x": bit 0 the SA march, bit 1 the nodal-gradient march, bit 2 the time-step kernel re-form the face normals from the node coordinates;
-                           // bit 3 the Roe march too (off: that kernel is bound by FP64 issue, the cross products cost more than the 6 loads saved - profiles/r02_ba_variants.txt)
+int g_metric_from_x = 5;   // tuning "metric_from_x": bit 0 the SA march, bit 2 the time-step kernel re-form the face normals from the node coordinates.
+                           // (k_visc_gf and k_roe_march keep the stored normals: the node form costs more registers than either has --
+                           // profiles/r06_a_xn_2wg_*, r02_ba_variants.txt)
 
 // the snapshot request of a Jacobian assembly (KParams::snapTab): set around the coloured evaluations of adflow_gpu_fd_jacobian
 struct SnapReq { bool on = false; SnapSlot* dev = nullptr; int devSlots = 0; int level = 0, col = 0, l0 = 0, n = 0; double turbScale = 1.0; };
@@ -524,6 +522,7 @@ int adflow_gpu_block_register(int nn, int level, int sps, const adflow_block_des
     rc |= alloc_arr(b, &v.dI, 3);
     rc |= alloc_arr(b, &v.dJ, 3);
     rc |= alloc_arr(b, &v.dK, 3);
+    rc |= alloc_arr(b, &v.xc, 3);
     rc |= alloc_arr(b, &v.dw, v.nw);
     rc |= alloc_arr(b, &v.fw, 5);
     rc |= alloc_arr(b, &v.dtl, 1);
@@ -1146,7 +1145,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
         if (approxFirst && pc_march_scheme(kp)) {
             // first-order upwind + thin-layer viscous flux: both are functions of the two cells of a face -- one march, dw written once
             phase_mark(4);
-            launch_pc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream, (g_pc_handover & 2) != 0);
+            launch_pc_march(g_tab[level], g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream);
             phase_mark(5);
         } else if (approxFirst) {
             KParams kv = kp;
@@ -1386,7 +1385,6 @@ static int block_res_enqueue(int level, unsigned flags)
     }
     phase_mark(2);
     // blockResCore order: SA residual first, then the mean-flow fluxes (blockette.F90:806-851)
-    bool saForked = false;
     if ((flags & ADFLOW_RES_TURB) && g_opts.equations == ADFLOW_RANS) {
         bool moving = false;
         rc = for_level(level, [&](Block* b) {
@@ -1398,33 +1396,23 @@ static int block_res_enqueue(int level, unsigned flags)
         {
             LevelTab t;
             if (level_tab(level, &t)) return 1;
+            // (on a side queue beside the mean-flow kernels -- the default of rounds 2-3 -- the march gains nothing since every march fills
+            // the device: 2.26 against 2.21 ms, round 4)
             hipStream_t ss = g_stream;
-            if (g_overlap && g_sa_side && g_phase_base <= 0 && (flags & ADFLOW_RES_FLOW)) {
-                // fork: the SA residual (writes dw(:,:,:,itu1) only) runs beside the mean-flow kernels; joined below
-                HIPCHK(hipEventRecord(g_evFork, g_stream));
-                HIPCHK(hipStreamWaitEvent(g_streamB, g_evFork, 0));
-                ss = g_streamB;
-                saForked = true;
-            }
             if (g_sa_march && !moving) {
                 if (ensure_sa_tiles(level)) return 1;
                 // the matrix-free vector: the Roe march that follows in the same queue writes the turbulence entry with its own five
                 // (tuning "rvec_joint"; every block holds six variables here: checked above)
-                if (kp.rvec && g_rvec_joint && !saForked && (flags & ADFLOW_RES_FLOW) && roe_rv_completes(level, kp, viscApprox)) kp.rvecTurbFromDw = 1;
+                if (kp.rvec && g_rvec_joint && (flags & ADFLOW_RES_FLOW) && roe_rv_completes(level, kp, viscApprox)) kp.rvecTurbFromDw = 1;
                 launch_sa_march(t.tab, g_sa_tiles[level].first, g_sa_tiles[level].second, kp, ss, false);
             } else launch_sa_residual_level(t.tab, t.n, t.nx, t.ny, t.nz, kp, ss);
-            if (saForked) HIPCHK(hipEventRecord(g_evB, g_streamB));
         }
     }
     phase_mark(3);
     if (flags & ADFLOW_RES_FLOW) {
         rc = enqueue_flow_residual(level, kp, viscApprox, false, true, (flags & ADFLOW_RES_UPDATE_INTERMED) != 0);
-        if (rc) {
-            if (saForked) (void)hipStreamWaitEvent(g_stream, g_evB, 0);      // never leave the side queue unjoined
-            return rc;
-        }
+        if (rc) return rc;
     }
-    if (saForked) HIPCHK(hipStreamWaitEvent(g_stream, g_evB, 0));      // join
     phase_mark(6);
     // actuator-region sources after the core, fine level only and without the iblank factor (blockette.F90:276-281)
     if (level == 1 && source_terms_enqueue(0)) return 1;
@@ -1754,7 +1742,7 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
             return 0;
         });
         if (rc || ensure_tiles(level)) return 1;
-        ad_launch_pc_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream, (g_pc_handover & 1) != 0);
+        ad_launch_pc_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream);
     } else if (resFlags & ADFLOW_RES_FLOW) {
         ad_launch_inviscid_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
         if (kp.viscous && fabs(kp.rFil) >= 1.e-10) {
@@ -1878,8 +1866,17 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
     // evaluation overwrite them (the output of the previous evaluation instead of the reference state): face halos are functions of
     // the interior alone, but the halo cells along block EDGES are written by one subface from what another left there, in an order
     // -- so the shortcut is taken for the preconditioner matrix, whose 7-point stencils never reach an edge halo, and not with a host hook
-    const bool oneComponent = (flags & ADFLOW_JAC_PC) && !g_bc_callback && !g_turb_bc_callback;
+    // (... nor for viscPC, whose full viscous flux reads edge and corner halos through its 27-point stencil: round-5 advisor)
+    const bool oneComponent = (flags & ADFLOW_JAC_PC) && !(flags & ADFLOW_JAC_VISC_PC) && !g_bc_callback && !g_turb_bc_callback;
 
+    // the snapshot entries of an evaluation come from the marches only when the host's prediction of the kernel dispatch was right:
+    // the launchers report what they wrote (adf_note_snap) and a mismatch is an error instead of a matrix built from stale memory
+    auto snap_written = [&](int resFlags_) -> int {
+        const int need = ((resFlags_ & ADFLOW_RES_FLOW) ? 1 : 0) | ((resFlags_ & ADFLOW_RES_TURB) ? 2 : 0);
+        if ((g_snap_done & need) != need)
+            return fail("fd_jacobian: the marching kernels were expected to write the snapshot of the evaluation (need %d, written %d)", need, g_snap_done);
+        return 0;
+    };
     if (useAD) {
         // one forward-mode evaluation per (colour, state variable): seed = 1 on component l of the cells of the colour (halos
         // included), block_res_state_d, the derivative of the scaled residual is the column of every stencil block
@@ -1901,7 +1898,9 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
                     ad_launch_seed_closures(b->v, g_ad[b].v, l, col, J, kps, g_stream, oneComponent && col > 0);
                     return 0;
                 });
+                g_snap_done = 0;
                 if (!rc) rc = ad_block_res_state_enqueue(level, resFlags, turbBC, (flags & ADFLOW_JAC_VISC_PC) != 0, true);
+                if (!rc && snapInMarch) rc = snap_written(resFlags);
                 if (!rc && !snapInMarch) rc = for_level(level, [&](Block* b) {
                     ad_launch_snap(b->v, g_ad[b].v.dw, b->snap + (size_t)col * J.nState * b->v.nbox, J, g_opts.turbResScale, g_stream);
                     return 0;
@@ -1955,7 +1954,9 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
                 launch_fd_state_closures(b->v, b->wref, l, col, J, delta, kpc, g_stream, oneComponent && col > 0);
                 return 0;
             });
+            g_snap_done = 0;
             if (!rc) rc = block_res_state_enqueue(level, resFlags, turbBC, true);
+            if (!rc && snapInMarch) rc = snap_written(resFlags);
             if (!rc && !snapInMarch) rc = for_level(level, [&](Block* b) {
                 launch_fd_snap(b->v, b->snap + (size_t)col * J.nState * b->v.nbox, J, g_opts.turbResScale, g_stream);
                 return 0;
@@ -1990,6 +1991,15 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta)
     g_jac = J;
     g_jac_valid = true;
     return sync_and_check();
+}
+
+int adflow_gpu_release_workspace(int64_t* bytes)
+{
+    if (need_ready()) return 1;
+    if (g_stream) HIPCHK(hipStreamSynchronize(g_stream));
+    if (bytes) *bytes = (int64_t)g_ad_slab_bytes;
+    ad_drop();
+    return 0;
 }
 
 int adflow_gpu_jacobian_info(int32_t* nState, int32_t* nStencil, int32_t* stencil)
@@ -2121,6 +2131,7 @@ int res_averaging_level(int level, const KParams& kp, double scaleDtl)
 
 // workgroups of a marching kernel resident at a time: two per CU (256 VGPRs, <= 80 KB of LDS each)
 void adf_note_rvec(int bits) { g_rvec_done |= bits; }
+void adf_note_snap(int bits) { g_snap_done |= bits; }
 
 int adf_round_size()
 {
@@ -2334,34 +2345,12 @@ static int build_chunk_tables(int level, int R, double warm, int reach, std::pai
     return 0;
 }
 
-// k_visc_gfw serves the level: tuning gf_ws and the geometry of every block re-formable from its nodes (make_kparams: metricFromX bit 1)
-static int level_gf_ws(int level)
-{
-    if (!g_gf_ws || !(g_metric_from_x & 2)) return 0;
-    for (auto& kv : g_blocks)
-        if (std::get<0>(kv.first) == level && !kv.second->normals_from_x_ok) return 0;
-    return 1;
-}
-
 int ensure_gf_tiles(int level)
 {
-    const int ws = level_gf_ws(level);
-    if (g_gf_tiles.count(level)) {
-        if (g_gf_tiles_ws[level] == ws) return 0;
-        // the kernel that serves the level changed (an upload of foreign normals, a tuning key): fit the chunks to its rounds
-        if (g_stream) HIPCHK(hipStreamSynchronize(g_stream));
-        if (g_streamB) HIPCHK(hipStreamSynchronize(g_streamB));
-        ++g_state_gen;         // a captured multigrid cycle holds the device pointer of the old table
-        for (auto* mp : {&g_gf_tiles, &g_gf_tiles_int, &g_gf_tiles_bnd}) {
-            (void)hipFree((*mp)[level].first);
-            mp->erase(level);
-        }
-    }
+    if (g_gf_tiles.count(level)) return 0;
     std::pair<int4*, int> a, i, b;
-    // k_visc_gfw: one workgroup per CU, len + 3 iterations per chunk; k_visc_gf: two per CU, len + 2
-    if (build_chunk_tables(level, 3, ws ? 2.5 : 1.5, 1, &a, &i, &b, ws ? 1 : 2)) return 1;
+    if (build_chunk_tables(level, 3, 1.5, 1, &a, &i, &b, 2)) return 1;
     g_gf_tiles[level] = a; g_gf_tiles_int[level] = i; g_gf_tiles_bnd[level] = b;
-    g_gf_tiles_ws[level] = ws;
     return 0;
 }
 
@@ -3871,7 +3860,6 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "roe_march")) { g_roe_march = value; return 0; }
     if (!strcmp(key, "sa_march")) { g_sa_march = value; return 0; }
     if (!strcmp(key, "overlap")) { g_overlap = value; return 0; }
-    if (!strcmp(key, "sa_side")) { g_sa_side = value; return 0; }
     if (!strcmp(key, "max_grid_z")) { g_max_grid_z = (value > 0) ? value : 65535; return 0; }
     if (!strcmp(key, "metric_from_x")) { g_metric_from_x = value; return 0; }
     if (!strcmp(key, "xcd_tiles")) {
@@ -3902,11 +3890,8 @@ int adflow_gpu_set_tuning(const char* key, int value)
     if (!strcmp(key, "test_fault")) { g_test_fault = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ad_cache")) { g_ad_cache = value; if (!value) { if (g_stream) (void)hipStreamSynchronize(g_stream); ad_drop(); } return 0; }
     if (!strcmp(key, "rvec_joint")) { g_rvec_joint = value; return 0; }
-    if (!strcmp(key, "pc_handover")) { g_pc_handover = value; return 0; }
     if (!strcmp(key, "jac_snap")) { g_jac_snap = value; return 0; }
     if (!strcmp(key, "pc_fused")) { g_pc_fused = value; mg_graph_drop(); return 0; }
-    if (!strcmp(key, "gf_dbg")) { g_gf_dbg = value; return 0; }
-    if (!strcmp(key, "gf_ws")) { g_gf_ws = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "mg_graph")) { g_mg_graph = value; g_mgg.failed = false; mg_graph_drop(); return 0; }
     if (!strcmp(key, "comm_self")) {
         if (g_stream) (void)hipStreamSynchronize(g_stream);
@@ -3915,8 +3900,6 @@ int adflow_gpu_set_tuning(const char* key, int value)
         return 0;
     }
     if (!strcmp(key, "dadi_pcr")) { g_dadi_pcr = value; mg_graph_drop(); return 0; }
-    if (!strcmp(key, "dadi_kpipe")) { g_dadi_kpipe = value; mg_graph_drop(); return 0; }
-    if (!strcmp(key, "dadi_jpipe")) { g_dadi_jpipe = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "ra_pcr")) { g_ra_pcr = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "dadi_upd")) { g_dadi_upd = value; mg_graph_drop(); return 0; }
     if (!strcmp(key, "gf_cus")) {

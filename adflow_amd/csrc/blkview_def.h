@@ -18,6 +18,7 @@ struct ADF_BLKVIEW {
     int moving;             // blockIsMoving: rotational source with rot = cgnsDoms%rotRate (fluxes.F90:372-397)
     adf_real8 rot[3];
     ADF_GEOM *dI, *dJ, *dK; // derived geometry: vector between the two cell centres of a face (viscous normal correction)
+    ADF_GEOM* xc;           // derived geometry: the cell centres (mean of the eight corner nodes), cells 1..ie x 1..je x 1..ke (k_visc_gf)
     // implicit turbulence boundary treatment of Spalart-Allmaras (turbBCRoutines.F90:662-798): halo = bvt - bmt * interior.
     // Index 0..5 = iMin,iMax,jMin,jMax,kMin,kMax; entry (a,b) at (a-1) + A*(b-1), A = je (i faces) or ie (j,k faces).
     // NULL until a block registers boundary subfaces (= all zero, the periodic / internal case).

@@ -173,16 +173,6 @@ __device__ __forceinline__ double fast_exp_neg(double x)
 }
 #endif
 
-// Workgroup barrier that orders the LDS traffic of the workgroup only.  __syncthreads() is also a fence over GLOBAL memory: the compiler
-// puts s_waitcnt vmcnt(0) in front of the s_barrier, i.e. a wave waits for the acknowledgement of its global stores (and for every load it
-// has requested ahead) at every barrier.  The marching kernels exchange data between waves through LDS alone -- what a wave stores to
-// global memory is never read by another wave of the launch -- so their per-plane barrier only has to drain the LDS queue.
-#ifdef HOSTSIM
-#define lds_barrier() __syncthreads()
-#else
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
-
 // binary exponent of a finite x > 0 (frexp: x = f 2^e, 0.5 <= f < 1)
 #ifdef HOSTSIM
 __device__ __forceinline__ int exponent_of(double x) { int e; (void)frexp(x, &e); return e; }
@@ -280,7 +270,6 @@ struct KParams {
     int viscFirst;         // the viscous march runs BEFORE the Roe march: it writes its flux sums into dw(2:5), the Roe march adds them and completes dw
     int radiiInMarch;      // the Euler march forms the spectral radii itself (no k_time_step pass in front)
     int metricFromX;       // marching kernels re-form the face normals from the node coordinates (as blocketteResCore, blockette.F90:854-960)
-    int dbg;               // (experiments: ablation bits of k_visc_gfw, tuning gf_dbg)
     int lumpedDiss;        // inputDiscretization::lumpedDiss (preconditioner assembly): first-order Roe upwind (fluxes.F90:1536)
     double sigma;
     double rFil, sfil;
@@ -378,7 +367,6 @@ void launch_fd_extract(const BlkView& b, double* dwref, double* jac, int l, int 
 // slots than fit calls itself on consecutive slot ranges (the kernels index the table relative to the pointer they get).
 extern int g_max_grid_z;          // 65535; tuning "max_grid_z" lowers it for the tests
 extern int g_ra_pcr;              // kernels_smooth.hip, tuning "ra_pcr"
-extern int g_dadi_jpipe, g_dadi_kpipe;
 extern int g_dadi_pcr;            // kernels_smooth.hip, tuning "dadi_pcr"
 inline int level_slots_per_launch(int planes)
 {
@@ -408,6 +396,7 @@ void launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KP
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 bool euler_march_radii_capable(const KParams& kp);
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s);
+void adf_note_snap(int bits);   // api.hip: a launcher reports that its kernel wrote the flow (1) / turbulence (2) snapshot entries (KParams::snapTab)
 void adf_note_rvec(int bits);   // api.hip: a launcher reports that its kernel wrote the flow (1) / turbulence (2) part of kp.rvec
 int adf_round_size();          // api.hip: workgroups of a marching kernel resident at a time (2 x CUs)
 void adf_phase_mark(int i);    // api.hip: optional HIP event between the phases of blocketteRes
@@ -442,7 +431,7 @@ void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, co
 int inviscid_march_enabled();
 bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 // kernels_pc_march.hip: first-order Roe + thin-layer viscous flux in one march (the mean-flow residual of the preconditioner matrix)
-void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s, bool handover);
+void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s);
 bool roe_march_takes(const KParams& kp);
 void launch_euler_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void euler_march_tiles(const BlkView& b, int* ntx, int* nty, int* ntz);
@@ -500,5 +489,5 @@ void ad_launch_viscous(const BlkView& adv, const KParams& kp, hipStream_t s);
 void ad_launch_viscous_approx(const BlkView& adv, const KParams& kp, hipStream_t s);
 void ad_launch_seed_closures(const BlkView& real, const BlkView& adv, int l, int col, const JacSpec& J, const KParams& kp, hipStream_t s,
                              bool onlyL);
-void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s, bool handover);
+void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s);
 void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);

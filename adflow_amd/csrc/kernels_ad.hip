@@ -234,9 +234,9 @@ void ad_launch_inviscid_level(const BlkView* tab, int n, int nx, int ny, int nz,
 }
 void ad_launch_viscous(const BlkView& adv, const KParams& kp, hipStream_t s) { adj::launch_viscous(*ADV(&adv), kp, s); }
 void ad_launch_viscous_approx(const BlkView& adv, const KParams& kp, hipStream_t s) { adj::launch_viscous_approx(*ADV(&adv), kp, s); }
-void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s, bool handover)
+void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)
 {
-    adj::launch_pc_march(ADV(tab), tiles, ntiles, kp, kch, s, handover);
+    adj::launch_pc_march(ADV(tab), tiles, ntiles, kp, kch, s);
 }
 void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {

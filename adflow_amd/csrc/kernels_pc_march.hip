@@ -13,9 +13,9 @@
 //
 // Mapping: the level's tile table (60 of 64 lanes produce, 4 rows, chunks of kch planes).  k face carried, i face once (its flux
 // comes back from the neighbouring lane by DPP); the states of the neighbouring rows through LDS (double buffered by the parity of
-// the plane: one barrier per plane), the rows outside the tile loaded by the waves next to them.  Two forms: k_pc_march evaluates
-// BOTH j faces of a cell (4 faces per cell); k_pc_march_h, the default, every j face ONCE (the flux handed to the row above, the
-// cell completed a plane later: 3.25 faces per cell; see there).  SNAP: the result goes to the snapshot of the Jacobian sweep.
+// the plane: one barrier per plane), the rows outside the tile loaded by the waves next to them.  Every j face ONCE (the flux handed to
+// the row above, the cell completed a plane later: 3.25 faces per cell; see there).  SNAP: the result goes to the snapshot of the
+// Jacobian sweep.
 // Measured (north-star mesh, profiles/r05_fin6_pc_pmc_bytes.md, r05_fin4_pc_trace.md): plain 0.70 ms, 329 B per cell counted =
 // 4.9 TB/s; dual 1.52 ms (one wave per SIMD, bound by FP64 issue).
 #ifndef ADF_AD_BUILD
@@ -116,127 +116,13 @@ __device__ __forceinline__ void pc_ld3(GPTR(const adf_real8) a, unsigned o, unsi
 }
 
 // SNAP: the Jacobian assembly's snapshot entry instead of dw (KParams::snapTab) -- a compile-time switch: in the dual build only the
-// derivative part of the result is stored then, and the value-only arithmetic behind it goes away
-template <bool SNAP>
-__global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
-                                                            int kch)
-{
-    __shared__ double qx[2 * PM_BY * PM_NV * 64];       // state of the own cell of every row, by the parity of the plane
-    const int4 t = tiles[blockIdx.x];
-    if (t.x < 0) return;
-    const BlkView& b = tab[t.x];
-    const int lane = threadIdx.x, row = threadIdx.y;
-    const int i = t.y * PM_OUT + lane;          // columns i0-2 .. i0+61
-    const int j = 2 + t.z * PM_BY + row;
-    const int k0 = 2 + t.w * kch;
-    const int k1 = (k0 + kch - 1 < b.kl) ? k0 + kch - 1 : b.kl;
-    const bool out = (lane >= 2 && lane <= 61 && i <= b.il && j <= b.jl);
-    const int ic = (i < b.ib) ? i : b.ib, jc = (j < b.je) ? j : b.je;
-    const long nb = b.nbox;
-    // byte offsets of 8-byte elements, for the geometry and the state alike (the dual forms of ldg / stg double them, kernels_ad.hip)
-    unsigned c = 8u * (unsigned)(ic + jc * b.ldi + k0 * b.ldk);
-    const unsigned sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk, nb8 = 8u * (unsigned)nb;
-    PcPtrs m;
-    m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w4 = m.w3 + nb;
-    m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.rev = (GPTR(const double))b.rev;
-    GPTR(const adf_real8) sI = (GPTR(const adf_real8))b.sI; GPTR(const adf_real8) sJ = (GPTR(const adf_real8))b.sJ;
-    GPTR(const adf_real8) sK = (GPTR(const adf_real8))b.sK;
-    GPTR(const adf_real8) dI = (GPTR(const adf_real8))b.dI; GPTR(const adf_real8) dJ = (GPTR(const adf_real8))b.dJ;
-    GPTR(const adf_real8) dK = (GPTR(const adf_real8))b.dK;
-    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
-    GPTR(double) dw0 = (GPTR(double))b.dw;
-    GPTR(double) dw1 = dw0 + nb; GPTR(double) dw2 = dw1 + nb; GPTR(double) dw3 = dw2 + nb; GPTR(double) dw4 = dw3 + nb;
-
-    RmK K;
-    K.doDiss = fabs(kp.rFil) >= 1.e-10;
-    K.omk = 0.0; K.opk = 0.0; K.factMinmod = 0.0;
-    K.gam = kp.gammaConstant; K.gm1 = kp.gammaConstant - 1.0; K.ovgm1 = 1.0 / (kp.gammaConstant - 1.0);
-    K.porDiss = 0.5 * kp.rFil;
-    PcK V;
-    V.porV = 0.5 * kp.rFil; V.eddy = kp.eddyModel != 0; V.gam = kp.gammaConstant;
-    V.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); V.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
-
-    PcCell q0 = pc_ld(m, c, V);
-    double gk[5];               // what enters the cell through its lower k face
-    {
-        const PcCell qm1 = pc_ld(m, c - sk, V);
-        adf_real8 nK[3], dKv[3];
-        pc_ld3(sK, c - sk, nb8, nK); pc_ld3(dK, c - sk, nb8, dKv);
-        pc_face(K, V, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), gk);
-    }
-    for (int k = k0; k <= k1; ++k) {
-        double* __restrict__ qb = qx + (k & 1) * (PM_BY * PM_NV * 64);
-        {
-            double* __restrict__ qo = qb + row * (PM_NV * 64) + lane;
-            qo[0] = q0.rho; qo[64] = q0.u; qo[128] = q0.v; qo[192] = q0.w; qo[256] = q0.p; qo[320] = q0.e; qo[384] = q0.na;
-            qo[448] = q0.rlv; qo[512] = q0.rev;
-        }
-        // ---- request: the next plane, the geometry of the four faces, the rows outside the tile
-        const PcCell qp1 = pc_ld(m, c + sk, V);
-        const int flag0 = flags[c >> 3], flagJm = flags[(c - sj) >> 3];
-        adf_real8 nI[3], dIv[3], nJ[3], dJv[3], nJm[3], dJm[3], nK[3], dKv[3];
-        pc_ld3(sJ, c - sj, nb8, nJm); pc_ld3(dJ, c - sj, nb8, dJm);
-        pc_ld3(sI, c, nb8, nI); pc_ld3(dI, c, nb8, dIv);
-        pc_ld3(sJ, c, nb8, nJ); pc_ld3(dJ, c, nb8, dJv);
-        pc_ld3(sK, c, nb8, nK); pc_ld3(dK, c, nb8, dKv);
-        PcCell qjm, qjp;
-        if (row == 0) qjm = pc_ld(m, c - sj, V);
-        if (row == PM_BY - 1) qjp = pc_ld(m, c + sj, V);
-        __syncthreads();
-        auto row_state = [&](int r) {
-            const double* __restrict__ qi = qb + r * (PM_NV * 64) + lane;
-            PcCell q;
-            q.rho = qi[0]; q.u = qi[64]; q.v = qi[128]; q.w = qi[192]; q.p = qi[256]; q.e = qi[320]; q.na = qi[384];
-            q.rlv = qi[448]; q.rev = qi[512];
-            return q;
-        };
-        double acc[5], G[5];
-        // ---- j face (j-1 | j)
-        if (row > 0) qjm = row_state(row - 1);
-        pc_face(K, V, qjm, q0, nJm, dJm, flg_porJ((uint8_t)flagJm), G);
-#pragma unroll
-        for (int l = 0; l < 5; ++l) acc[l] = -(gk[l] + G[l]);
-        // ---- i face (i | i+1); the face (i-1 | i) comes from lane-1
-        {
-            const PcCell qR = pc_dn1(q0);
-            pc_face(K, V, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), G);
-#pragma unroll
-            for (int l = 0; l < 5; ++l) acc[l] += G[l] - lane_up1(G[l]);
-        }
-        // ---- j face (j | j+1)
-        if (row < PM_BY - 1) qjp = row_state(row + 1);
-        pc_face(K, V, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), G);
-#pragma unroll
-        for (int l = 0; l < 5; ++l) acc[l] += G[l];
-        // ---- k face above the cell
-        pc_face(K, V, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), gk);
-#pragma unroll
-        for (int l = 0; l < 5; ++l) acc[l] += gk[l];
-        if (out) {
-            const adf_real8 blank = (flag0 & 64) ? 1.0 : 0.0;
-            if (SNAP) {
-                // Jacobian assembly: resScale, the snapshot entry of this coloured evaluation instead of dw (KParams::snapTab)
-                const SnapSlot ss = kp.snapTab[t.x];
-                const adf_real8 ovol = 1.0 / ldg((GPTR(const adf_real8))b.volRef, c);
-                GPTR(adf_real8) sn = (GPTR(adf_real8))ss.snap + ((long)kp.snapCol * kp.snapN - kp.snapL0) * nb;
-#pragma unroll
-                for (int l = 0; l < 5; ++l) snap_put(sn + l * nb, c, (acc[l] * blank) * ovol);
-            } else {
-                stg(dw0, c, acc[0] * blank); stg(dw1, c, acc[1] * blank); stg(dw2, c, acc[2] * blank); stg(dw3, c, acc[3] * blank);
-                stg(dw4, c, acc[4] * blank);
-            }
-        }
-        q0 = qp1;
-        c += sk;
-    }
-}
-
-// The same march with every j face evaluated ONCE (tuning "pc_handover"): a wave evaluates the j face ABOVE its cell and hands the flux
-// to the row above through LDS; the cell is completed one plane later, behind the next barrier, with the flux that arrived through its
-// lower j face.  The face below row 0 of the tile has no wave: wave (k mod 4) takes it in plane k (row j0-1 loaded by that wave, row
+// derivative part of the result is stored then, and the value-only arithmetic behind it goes away.
+// Every j face is evaluated ONCE: a wave evaluates the j face ABOVE its cell and hands the flux to the row above through LDS; the cell
+// is completed one plane later, behind the next barrier, with the flux that arrived through its lower j face (round 5: 3.25 instead of
+// the 4 face evaluations of the form with both j faces per cell, which round 6 removed: profiles/r05_x_ab.txt).  The face below row 0 of the tile has no wave: wave (k mod 4) takes it in plane k (row j0-1 loaded by that wave, row
 // j0 from the LDS slot of wave 0).  3.25 instead of 4 face evaluations per cell -- what the dual build, bound by FP64 issue, is short of.
 template <bool SNAP>
-__global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march_h(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
+__global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                             int kch)
 {
     __shared__ double qx[2 * PM_BY * PM_NV * 64];       // state of the own cell of every row, by the parity of the plane
@@ -324,6 +210,8 @@ __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march_h(const BlkVi
         // ---- request: the next plane, the geometry of the three faces, the row above the tile; the fifth face: row j0-1 and its geometry
         const PcCell qp1 = pc_ld(m, c + sk, V);
         const int flag0 = flags[c >> 3];
+        // (the cell centres k_visc_gf forms its vectors from -- 3 values per cell where dI / dJ / dK are 9 -- cost this kernel 36 B of
+        // scratch per lane, carried or requested every step: it keeps the stored vectors)
         adf_real8 nI[3], dIv[3], nJ[3], dJv[3], nK[3], dKv[3], nE[3], dE[3];
         pc_ld3(sI, c, nb8, nI); pc_ld3(dI, c, nb8, dIv);
         pc_ld3(sJ, c, nb8, nJ); pc_ld3(dJ, c, nb8, dJv);
@@ -378,15 +266,13 @@ __global__ __launch_bounds__(64 * PM_BY, PM_MINWG) void k_pc_march_h(const BlkVi
 }
 
 
-void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s, bool handover)
+void launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)
 {
     if (ntiles <= 0) return;
     const dim3 grd(ntiles), blk(64, PM_BY, 1);
-    if (handover) {
-        if (kp.snapTab) hipLaunchKernelGGL(k_pc_march_h<true>, grd, blk, 0, s, tab, tiles, kp, kch);
-        else hipLaunchKernelGGL(k_pc_march_h<false>, grd, blk, 0, s, tab, tiles, kp, kch);
-    } else {
-        if (kp.snapTab) hipLaunchKernelGGL(k_pc_march<true>, grd, blk, 0, s, tab, tiles, kp, kch);
-        else hipLaunchKernelGGL(k_pc_march<false>, grd, blk, 0, s, tab, tiles, kp, kch);
-    }
+    if (kp.snapTab) {
+        adf_note_snap(1);
+        hipLaunchKernelGGL(k_pc_march<true>, grd, blk, 0, s, tab, tiles, kp, kch);
+    } else
+        hipLaunchKernelGGL(k_pc_march<false>, grd, blk, 0, s, tab, tiles, kp, kch);
 }

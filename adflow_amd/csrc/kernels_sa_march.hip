@@ -282,7 +282,7 @@ void launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KP
         adf_note_rvec(2);
     } else
 #endif
-        if (kp.snapTab) hipLaunchKernelGGL((k_sa_march<false, false, true>), grd, blk, 0, s, tab, tiles, kp);
+        if (kp.snapTab) { hipLaunchKernelGGL((k_sa_march<false, false, true>), grd, blk, 0, s, tab, tiles, kp); adf_note_snap(2); }
         else hipLaunchKernelGGL((k_sa_march<false>), grd, blk, 0, s, tab, tiles, kp);     // (the dual build: the residual alone, or its snapshot)
 }
 

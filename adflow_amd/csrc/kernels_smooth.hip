@@ -1545,8 +1545,8 @@ static void launch_dadi_i_pcr(const BlkView* tab, int nslots, int ny, int nz, co
     hipLaunchKernelGGL((k_dadi_i_pcr<NW>), dim3((ny + PI_JL - 1) / PI_JL, nz, nslots), dim3(64 * NW, 1, 1), 0, s, tab, kp);
 }
 
-int g_dadi_kpipe = 1;    // tuning "dadi_kpipe": the same for the k sweep
-int g_dadi_jpipe = 0;    // tuning "dadi_jpipe": 1 = the j sweep as a software pipeline too (322 registers: one wavefront per SIMD, its 1536 wavefronts run as two rounds: 0.90 ms); 0 = plain with the reciprocal forms (208 registers, every wavefront resident: 0.73 ms)
+// (the k sweep runs as a software pipeline, the j sweep plain with the reciprocal forms: pipelined it needs 322 registers -- one wavefront
+// per SIMD, its 1536 wavefronts in two rounds: 0.90 against 0.73 ms, round 4)
 int g_dadi_pcr = 1;      // tuning "dadi_pcr": the i direction of D-ADI by cyclic reduction along the lanes (0: rows + tiled Thomas)
 
 // computedwDADI incl. the -cfl*dtl*vol scaling of executeDADIStep
@@ -1556,8 +1556,7 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
     LEVEL_SPLIT(nslots, nz + 4, launch_dadi_level(tab + s0_, n_, nx, ny, nz, kp, s, withUpdate));
     if (nslots <= 0) return;
     dim3 blk(64, 1, 1);
-    if (g_dadi_jpipe) hipLaunchKernelGGL((k_dadi_sweep<1>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
-    else hipLaunchKernelGGL((k_dadi_sweep<1, false, false, false>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
+    hipLaunchKernelGGL((k_dadi_sweep<1, false, false, false>), dim3((nx + 63) / 64, nz, nslots), blk, 0, s, tab, kp, 0);
     if (g_dadi_pcr && nx <= 256) {
         // i direction: cyclic reduction along the lanes with its transform applied (k_dadi_i_pcr); nx = the widest block of the level
         if (nx <= 64) launch_dadi_i_pcr<1>(tab, nslots, ny, nz, kp, s);
@@ -1565,13 +1564,8 @@ void launch_dadi_level(const BlkView* tab, int nslots, int nx, int ny, int nz, c
         else if (nx <= 192) launch_dadi_i_pcr<3>(tab, nslots, ny, nz, kp, s);
         else launch_dadi_i_pcr<4>(tab, nslots, ny, nz, kp, s);
         const dim3 gk((nx + 63) / 64, ny, nslots);
-        if (g_dadi_kpipe) {
-            if (withUpdate) hipLaunchKernelGGL((k_dadi_sweep<2, false, true>), gk, blk, 0, s, tab, kp, 0);
-            else hipLaunchKernelGGL((k_dadi_sweep<2, false>), gk, blk, 0, s, tab, kp, 0);
-        } else {
-            if (withUpdate) hipLaunchKernelGGL((k_dadi_sweep<2, false, true, false>), gk, blk, 0, s, tab, kp, 0);
-            else hipLaunchKernelGGL((k_dadi_sweep<2, false, false, false>), gk, blk, 0, s, tab, kp, 0);
-        }
+        if (withUpdate) hipLaunchKernelGGL((k_dadi_sweep<2, false, true>), gk, blk, 0, s, tab, kp, 0);
+        else hipLaunchKernelGGL((k_dadi_sweep<2, false>), gk, blk, 0, s, tab, kp, 0);
         return;
     }
     // i direction: rows pointwise, Thomas per (line, equation) through LDS tiles; the transform behind the i-solve is applied

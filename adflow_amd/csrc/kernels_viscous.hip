@@ -369,10 +369,23 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_face_vectors(BlkView b)
     const int i = blockIdx.x * VS_BX + threadIdx.x + 1;
     const int j = blockIdx.y * VS_BY + threadIdx.y + 1;
     const int k = blockIdx.z + 1;
-    if (i > b.il || j > b.jl) return;
+    if (i > b.ie || j > b.je) return;
     const long c = b.idx(i, j, k);
     const long nb = b.nbox;
     const long si = 1, sj = b.ldi, sk = b.ldk;
+    // cell centre: the mean of the eight corner nodes.  k_visc_gf takes the vector between the centres of two neighbouring cells as
+    // the difference of two of these (3 values per cell instead of the 9 of dI / dJ / dK); against the eight-term sum of
+    // fluxes.F90:2673-2690 the difference carries the rounding of |x| a few times more -- the same order as that sum's own
+    {
+        const long n0 = c - si - sj - sk;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const adf_real8* xx = b.x + m * nb;
+            b.xc[c + m * nb] = 0.125 * (((xx[n0] + xx[n0 + si]) + (xx[n0 + sj] + xx[n0 + si + sj])) +
+                                        ((xx[n0 + sk] + xx[n0 + si + sk]) + (xx[n0 + sj + sk] + xx[c])));
+        }
+    }
+    if (i > b.il || j > b.jl || k > b.kl) return;
     const long sd3[3] = {si, sj, sk};
     const long s13[3] = {sj, si, si};
     const long s23[3] = {sk, sk, sj};
@@ -390,11 +403,11 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_face_vectors(BlkView b)
     }
 }
 
-// derived static geometry of the viscous path: the face vectors dI / dJ / dK
+// derived static geometry of the viscous path: the face vectors dI / dJ / dK and the cell centres
 void launch_face_vectors(const BlkView& b, hipStream_t s)
 {
     dim3 blk(VS_BX, VS_BY, 1);
-    dim3 g((b.il + VS_BX - 1) / VS_BX, (b.jl + VS_BY - 1) / VS_BY, b.kl);
+    dim3 g((b.ie + VS_BX - 1) / VS_BX, (b.je + VS_BY - 1) / VS_BY, b.ke);
     hipLaunchKernelGGL(k_face_vectors, g, blk, 0, s, b);
 }
 struct VCell { double u, v, w, aa, rlv, rev, gam; };
@@ -714,8 +727,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
     m.vol = (GPTR(const double))b.vol;
     m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
     m.nb8 = nb8;
-    GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
-    GPTR(const double) dK = (GPTR(const double))b.dK;
+    GPTR(const double) xcen = (GPTR(const double))b.xc;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     GPTR(double) dw = (GPTR(double))b.dw;
     GPTR(double) fw = (GPTR(double))b.fw;
@@ -733,6 +745,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
     VmCell qA, qB;
     GfMet S;
     double sKA[3], sKB[3], fk[4], pend[4];
+    double xcP[3] = {0.0, 0.0, 0.0};        // centre of cell (i, jn, mm-1)
     int flagP = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { sKA[d] = ldg(m.sK, cA - sk + d * nb8); sKB[d] = ldg(m.sK, cA + dB - sk + d * nb8); }
@@ -777,16 +790,18 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
         const unsigned cF = cA - sk;
         const bool facePlane = (mm >= k0);
         const bool full = (mm > k0);                           // all faces (first step of the march: the k face below plane k0 only)
-        double dIv[3], dJv[3], dKv[3], sIA[3], sJA[3];
+        // the vectors between cell centres (fluxes.F90:2673-2690, 2966-2983, 3260-3277) are differences of the stored centres: of the
+        // own cell at this plane (kept for the next step) and of the row above at the plane of the faces -- 24 unique bytes per cell
+        // where dI / dJ / dK were 72
+        double xcN[3], xcB[3], sIA[3], sJA[3];
         int flag0 = 0;
         auto face_loads = [&]() {
+            vm_ld3(xcen, cA, nb8, xcN);
             if (!facePlane) return;
-            if (r >= 1) vm_ld3(dK, cF, nb8, dKv);
             flag0 = flags[cF >> 3];
             if (full) {
-                if (r >= 1) vm_ld3(dI, cF, nb8, dIv);
-                vm_ld3(dJ, cF, nb8, dJv);
-                if (r >= 1) vm_ld3(m.sI, cF, nb8, sIA);
+                vm_ld3(xcen, cF + dB, nb8, xcB);
+                if (r >= 1) vm_ld3(m.sI, cF, nb8, sIA);       // (sI / sJ of that plane again: carried they spill -- 16 B of scratch cost 0.02 ms, profiles/r06_g_ab.txt)
                 vm_ld3(m.sJ, cF, nb8, sJA);
             }
         };
@@ -895,6 +910,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
                     const double s0 = u.x + v.x, s1 = u.y + v.y;
                     gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                 }
+                const double dJv[3] = {xcB[0] - xcP[0], xcB[1] - xcP[1], xcB[2] - xcP[2]};
                 vm_face<QCR>(K, gs, qA, qB, sJA, dJv, flg_porJ((uint8_t)flag0), f);
 #pragma unroll
                 for (int l = 0; l < 4; ++l) acc[l] = -f[l];
@@ -915,6 +931,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
                         gs[q] = (u.x + v.x) + (w.x + z.x); gs[q + 1] = (u.y + v.y) + (w.y + z.y);
                     }
                     const VmCell qR = vm_dn1(qA);
+                    const double dIv[3] = {lane_dn1(xcP[0]) - xcP[0], lane_dn1(xcP[1]) - xcP[1], lane_dn1(xcP[2]) - xcP[2]};
                     vm_face<QCR>(K, gs, qA, qR, sIA, dIv, flg_porI((uint8_t)flag0), f);
 #pragma unroll
                     for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
@@ -928,6 +945,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
                         const double s0 = w.x + z.x, s1 = w.y + z.y;
                         gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                     }
+                    const double dKv[3] = {xcN[0] - xcP[0], xcN[1] - xcP[1], xcN[2] - xcP[2]};
                     vm_face<QCR>(K, gs, qA, a.q, sKA, dKv, flg_porK((uint8_t)flag0), f);
 #pragma unroll
                     for (int l = 0; l < 4; ++l) { pend[l] = (acc[l] + fk[l]) - f[l]; fk[l] = f[l]; }
@@ -941,447 +959,13 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             sKA[d] = aK[d]; sKB[d] = bK[d];
+            xcP[d] = xcN[d];
         }
         cA += sk;
     }
     // ---- the last plane of the chunk: its j flux was handed over in the last step
     __syncthreads();
     if (r >= 1 && k1 >= k0) finish(cA - 2 * sk, fjx + ((k1 + 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
-}
-
-// face normals sI, sJ(jn-1), sJ, sK of the cell rows jn (a) and jn+1 (b) of one plane; the nodes (i, jn-1 | jn | jn+1, plane)
-struct GfNrm { double aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3]; };
-struct GfNod { double r0[3], r1[3], r2[3]; };
-
-// ---------------------------------------------------------------------------
-// k_visc_gfw (round 6; tuning "gf_ws", the default wherever the stored normals ARE metric_block(x): KParams::metricFromX bit 1).
-// The fused kernel with its geometry formed from the NODE coordinates, as the reference's default path forms it (blocketteResCore:
-// metrics blockette.F90:854-960; the centre-to-centre vectors inside viscousFlux, fluxes.F90:2673-2690, 2966-2983, 3260-3277): 24
-// unique bytes of nodes per cell instead of 144 of sI / sJ / sK / dI / dJ / dK.  Formed inside k_visc_gf the node planes, the normals
-// carried to the face part and the node sums of the centre-to-centre vectors are ~20 more live values than that kernel has registers
-// for at two waves per SIMD: 252 B of scratch per lane, 1.97 against 0.865 ms (profiles/r06_a_xn_2wg_*).  So the two halves of a step
-// become two ROLES of ONE workgroup of eight waves per CU -- a producer and a consumer wave per SIMD, each with its own 256 registers:
-//   * PRODUCER r (waves 0..3; node row jn = j0-1+r): per plane loads the state of the cell rows jn, jn+1 and the nodes (i, jn-1..jn+1),
-//     forms the seven face normals (metric_block's diagonals, ngx_cross), the metric sums and the gradient of node (i, jn, mm-1) ->
-//     ring (as k_visc_gf), and PUBLISHES what the faces of its cell row need: the state (u, v, w, -a^2, rlv, rev) and sI, sJ, sK of
-//     cell (i, jn, mm) (wave 3 also the state of row jn+1) in double-buffered LDS records;
-//   * CONSUMER r (waves 4..7; cell row jn) runs ONE plane behind: in the iteration the producers work on plane mm it reads the
-//     records of plane mm-1, evaluates the j face above, the i face and the k face of cell (i, jn, mm-2) with the ring's node
-//     planes mm-3, mm-2 (3.25 faces per cell, j flux handed to the consumer above, finish one step later: as k_visc_gf) and forms
-//     the centre-to-centre vectors from node sums of its own: with H_k = x(jn-1) + x(jn), E_k = x(jn+1) - x(jn-1) of node plane k
-//       dK = ((H_k+1 - H_k-1)(i) + (..)(i-1)) / 8,  dJ = ((E_k-1 + E_k)(i) + (..)(i-1)) / 8,  dI = ((H_k-1 + H_k)(i+1) - (..)(i-1)) / 8
-//     -- the reference's eight-term sums in another order: equal to the rounding of the reference's own sum, a few ulp of |x|
-//     (DESIGN 4, round 6); its nine node loads per plane hit the lines the producers fetched.
-// ONE barrier per iteration orders ring (three slots: the consumers read planes mm-3, mm-2 while mm-1 is written), records (two
-// slots) and the j-flux hand-over.  While a producer waits for its loads the consumer of its SIMD computes.
-// LDS: ring 70 272 + hand-over 11 520 + state records 30 720 + normal records 40 960 = 153 472 B.
-// ---------------------------------------------------------------------------
-#define GW_RS (5 * 3 * 128)      // doubles of one slot of the state records: rows 0..4 (4 = the row above the tile), 3 pairs, 64 lanes x 2
-#define GW_RN (4 * 5 * 128)      // ... of the normal records: rows 0..3, 5 pairs (sI, sJ, sK; the tenth value is padding)
-
-template <bool QCR, bool FIRST, bool STG>
-__global__ __launch_bounds__(512, 2) void k_visc_gfw(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
-{
-    constexpr int NW = GF_NW, NSLOT = 3;
-    __shared__ __attribute__((aligned(16))) double ring[NSLOT * NW * GF_G];   // [slot][node row][component pair][lane-1][2]
-    __shared__ __attribute__((aligned(16))) double fjx[2 * (NW - 1) * GF_OUT * 4];  // [parity][row][lane-2][component]
-    __shared__ __attribute__((aligned(16))) double recS[2 * GW_RS];           // [parity][row][pair][lane][2]
-    __shared__ __attribute__((aligned(16))) double recN[2 * GW_RN];
-    constexpr int FJ = (NW - 1) * GF_OUT * 4;
-    const int4 tl = tiles[blockIdx.x];
-    if (tl.x < 0) return;
-    const BlkView& b = tab[tl.x];
-    const int lane = threadIdx.x, r = threadIdx.y & 3;
-    const bool producer = wave_uniform((int)threadIdx.y) < 4;
-    const int bx = tl.y & 0xffff, by = tl.y >> 16;
-    const int i = bx * GF_OUT + lane;             // cells i0-2 .. i0+61, i0 = 2 + 60 bx
-    const int j0 = 2 + by * (NW - 1);             // first produced cell row
-    const int k0 = tl.z, k1 = tl.w;               // planes of the chunk
-    const int jn = j0 - 1 + r;                    // node row of the wave pair; waves 1..3: also its cell row
-    const int ic = (i < b.ib) ? i : b.ib;
-    const int jA = (jn < b.jb) ? jn : b.jb, jB = (jn + 1 < b.jb) ? jn + 1 : b.jb;
-    const long nb = b.nbox;
-    const unsigned nb8 = 8u * (unsigned)nb, sj = 8u * (unsigned)b.ldi, sk = 8u * (unsigned)b.ldk;
-    const unsigned dB = 8u * (unsigned)((jB - jA) * b.ldi);          // row jn+1 relative to row jn (0 at the upper end of the box)
-    const unsigned dM = (jA >= 1) ? sj : 0u;                          // row jn-1
-    GPTR(const double) xnod = (GPTR(const double))b.x;
-    const double gam = kp.gammaConstant;
-    auto ld_nodes = [&](unsigned c, GfNod& n) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { n.r0[d] = ldg(xnod, c - dM + d * nb8); n.r1[d] = ldg(xnod, c + d * nb8); n.r2[d] = ldg(xnod, c + dB + d * nb8); }
-    };
-    if (producer) {
-        // ================================================================ producer: state + nodes -> gradients, records
-        const bool outN = (lane >= 1 && lane <= 61 && i <= b.il && jn <= b.jl);
-        const bool ringLane = (lane >= 1 && lane <= GF_NL);
-        const int nl = ringLane ? lane - 1 : 0;
-        GfPtrs m;
-        m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
-        m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.rev = (GPTR(const double))b.rev;
-        m.vol = (GPTR(const double))b.vol;
-        m.nb8 = nb8;
-        GPTR(double) grad = (GPTR(double))b.grad;
-        const double mfact = b.mfact;
-        const bool eddy = kp.eddyModel != 0;
-        const bool top = (r == NW - 1);                  // wave 3 also publishes the state of the row above the tile
-        unsigned cA = 8u * (unsigned)(ic + jA * b.ldi + (k0 - 1) * b.ldk);
-        // carried: u, v, w, -a^2 of the rows jn, jn+1 at the previous plane, its metric sums, its nodes, sK of the node plane
-        double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
-        GfMet S;
-        GfNod P;
-        double sKA[3], sKB[3];
-        S.V = 0.0;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) S.Pt[d] = S.Q0t[d] = S.Q1t[d] = S.RIt[d] = 0.0;
-        {
-            ld_nodes(cA - sk, P);
-            double P0u[3], P1u[3], P2u[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { P0u[d] = lane_up1(P.r0[d]); P1u[d] = lane_up1(P.r1[d]); P2u[d] = lane_up1(P.r2[d]); }
-            ngx_cross(mfact, P.r1, P0u, P1u, P.r0, sKA);
-            ngx_cross(mfact, P.r2, P1u, P2u, P.r1, sKB);
-        }
-        // what a step loads: cell plane of the rows jn and jn+1 (state, volume) and the nodes of that plane.  Requested ONE STEP AHEAD: the
-        // values of plane mm+1 are in flight while plane mm is worked on (a producer has the registers for it; with the request at the
-        // top of its own step a step lasted load latency + arithmetic, 1.00 against 0.86 ms: profiles/r06_b_ab.txt)
-        struct Req { double au, av, aw, ap, ar, alv, aev, avol, bu, bv, bw, bp, br, bvol, blv, bev; GfNod N; };
-        auto request = [&](unsigned c) {
-            Req q;
-            const unsigned cb = c + dB;
-            q.au = ldg(m.w1, c); q.av = ldg(m.w2, c); q.aw = ldg(m.w3, c); q.ap = ldg(m.p, c); q.ar = ldg(m.w0, c);
-            q.alv = ldg(m.rlv, c); q.aev = eddy ? ldg(m.rev, c) : 0.0; q.avol = ldg(m.vol, c);
-            q.bu = ldg(m.w1, cb); q.bv = ldg(m.w2, cb); q.bw = ldg(m.w3, cb); q.bp = ldg(m.p, cb); q.br = ldg(m.w0, cb);
-            q.bvol = ldg(m.vol, cb);
-            q.blv = 0.0; q.bev = 0.0;
-            if (top) { q.blv = ldg(m.rlv, cb); q.bev = eddy ? ldg(m.rev, cb) : 0.0; }
-            ld_nodes(c, q.N);
-            return q;
-        };
-        const unsigned cA0 = cA;
-        // (two request buffers used in turn -- the loop below is unrolled by two: a single pair nxt -> cur is copied at the loop
-        // latch, i.e. waited for in front of the barrier of the step that requested it)
-        auto pstep = [&](const int mm, const Req& cur, Req& nxt) {
-            if (mm <= k1 + 1) {
-                const unsigned cF = cA - sk;
-                nxt = request((kp.dbg & 4) ? cA0 : cA + (mm <= k1 ? sk : 0u));          // plane mm+1 (the last step asks for its own plane again)
-                __builtin_amdgcn_sched_barrier(0);
-                const double au = cur.au, av = cur.av, aw = cur.aw, ap = cur.ap, ar = cur.ar, alv = cur.alv, aev = cur.aev, avol = cur.avol;
-                const double bu = cur.bu, bv = cur.bv, bw = cur.bw, bp = cur.bp, br = cur.br, bvol = cur.bvol, blv = cur.blv, bev = cur.bev;
-                const GfNod N = cur.N;
-                const double ana = -(gam * ap) * rcp_nr(ar), bna = -(gam * bp) * rcp_nr(br);
-                // ---- publish the state of cell (i, jn, mm) (wave 3: also of row jn+1)
-                {
-                    double* __restrict__ ro = recS + ((mm & 1) * 5 + r) * (3 * 128) + lane * 2;
-                    *reinterpret_cast<Dbl2*>(ro) = mk2(au, av);
-                    *reinterpret_cast<Dbl2*>(ro + 128) = mk2(aw, ana);
-                    *reinterpret_cast<Dbl2*>(ro + 256) = mk2(alv, aev);
-                    if (top) {
-                        ro += 3 * 128;
-                        *reinterpret_cast<Dbl2*>(ro) = mk2(bu, bv);
-                        *reinterpret_cast<Dbl2*>(ro + 128) = mk2(bw, bna);
-                        *reinterpret_cast<Dbl2*>(ro + 256) = mk2(blv, bev);
-                    }
-                }
-                // ---- normals of cell plane mm from the node planes mm-1 (P) and mm (N): metric_block's diagonals
-                GfNrm nr;
-                {
-                    double N0u[3], N1u[3], N2u[3], P0u[3], P1u[3], P2u[3];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        N0u[d] = lane_up1(N.r0[d]); N1u[d] = lane_up1(N.r1[d]); N2u[d] = lane_up1(N.r2[d]);
-                        P0u[d] = lane_up1(P.r0[d]); P1u[d] = lane_up1(P.r1[d]); P2u[d] = lane_up1(P.r2[d]);
-                    }
-                    ngx_cross(mfact, P.r1, N.r0, N.r1, P.r0, nr.aI);           // sI: v1 = x(i,j,n) - x(i,m,k) ; v2 = x(i,j,k) - x(i,m,n)
-                    ngx_cross(mfact, P.r2, N.r1, N.r2, P.r1, nr.bI);
-                    ngx_cross(mfact, P.r0, N0u, P0u, N.r0, nr.aJm);            // sJ: v1 = x(i,j,n) - x(l,j,k) ; v2 = x(l,j,n) - x(i,j,k)
-                    ngx_cross(mfact, P.r1, N1u, P1u, N.r1, nr.aJ);
-                    ngx_cross(mfact, P.r2, N2u, P2u, N.r2, nr.bJ);
-                    ngx_cross(mfact, N.r1, N0u, N1u, N.r0, nr.aK);             // sK: v1 = x(i,j,k) - x(l,m,k) ; v2 = x(l,j,k) - x(i,m,k)
-                    ngx_cross(mfact, N.r2, N1u, N2u, N.r1, nr.bK);
-                }
-                {
-                    double* __restrict__ ro = recN + ((mm & 1) * 4 + r) * (5 * 128) + lane * 2;
-                    *reinterpret_cast<Dbl2*>(ro) = mk2(nr.aI[0], nr.aI[1]);
-                    *reinterpret_cast<Dbl2*>(ro + 128) = mk2(nr.aI[2], nr.aJ[0]);
-                    *reinterpret_cast<Dbl2*>(ro + 256) = mk2(nr.aJ[1], nr.aJ[2]);
-                    *reinterpret_cast<Dbl2*>(ro + 384) = mk2(nr.aK[0], nr.aK[1]);
-                    *reinterpret_cast<Dbl2*>(ro + 512) = mk2(nr.aK[2], 0.0);
-                }
-                // ---- metric sums of this plane
-                GfMet Nm;
-                {
-                    double tJa[3], tKa[3], tJb[3], tKb[3];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const double tIa = lane_up1(nr.aI[d]) + nr.aI[d], tIb = lane_up1(nr.bI[d]) + nr.bI[d];
-                        Nm.RIt[d] = tIa + tIb;
-                        tJa[d] = nr.aJm[d] + nr.aJ[d]; tJb[d] = nr.aJ[d] + nr.bJ[d];
-                        tKa[d] = sKA[d] + nr.aK[d]; tKb[d] = sKB[d] + nr.bK[d];
-                    }
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        Nm.Q0t[d] = tJa[d] + lane_dn1(tJa[d]);
-                        Nm.Q1t[d] = tJb[d] + lane_dn1(tJb[d]);
-                        Nm.Pt[d] = (tKa[d] + lane_dn1(tKa[d])) + (tKb[d] + lane_dn1(tKb[d]));
-                    }
-                    Nm.V = (avol + lane_dn1(avol)) + (bvol + lane_dn1(bvol));
-                }
-                const double nA[4] = {au, av, aw, ana}, nB[4] = {bu, bv, bw, bna};
-                // ---- gradient of node (i, jn, mm-1) from the cell planes mm-1 (sA, sB, S) and mm -> ring
-                if (mm >= k0 && !(kp.dbg & 1)) {
-                    double g[12];
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) g[q] = 0.0;
-                    double SQ0[4], SQ1[4], NQ0[4], NQ1[4], ph[4], t3[3];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        SQ0[v] = sA[v] + lane_dn1(sA[v]); SQ1[v] = sB[v] + lane_dn1(sB[v]);
-                        NQ0[v] = nA[v] + lane_dn1(nA[v]); NQ1[v] = nB[v] + lane_dn1(nB[v]);
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) ph[v] = SQ0[v] + SQ1[v];
-                    ng_outer<true>(g, ph, S.Pt);                          // k direction: below the node -, above +
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) ph[v] = NQ0[v] + NQ1[v];
-                    ng_outer<false>(g, ph, Nm.Pt);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) t3[d] = S.Q0t[d] + Nm.Q0t[d];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) ph[v] = SQ0[v] + NQ0[v];
-                    ng_outer<true>(g, ph, t3);                            // j direction: own row -, row above +
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) t3[d] = S.Q1t[d] + Nm.Q1t[d];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) ph[v] = SQ1[v] + NQ1[v];
-                    ng_outer<false>(g, ph, t3);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) t3[d] = S.RIt[d] + Nm.RIt[d];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) ph[v] = (sA[v] + sB[v]) + (nA[v] + nB[v]);
-                    ng_outer<true>(g, ph, t3);                            // i direction: own column -, column i+1 +
-                    double t1[3], ph1[4];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t3[d]);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) ph1[v] = lane_dn1(ph[v]);
-                    ng_outer<false>(g, ph1, t1);
-                    // a QUARTER of the gradient goes to the ring (see k_visc_gf): 1 / (16 V)
-                    const double oneOverV = 0.0625 * rcp_nr(S.V + Nm.V);
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) g[q] *= oneOverV;
-                    if (ringLane) {
-                        double* __restrict__ xo = ring + (((mm - k0) % NSLOT) * NW + r) * GF_G + nl * 2;     // node plane mm-1 -> slot (mm-k0) % NSLOT
-#pragma unroll
-                        for (int q = 0; q < 12; q += 2) *reinterpret_cast<Dbl2*>(xo + q * GF_NL) = mk2(g[q], g[q + 1]);
-                    }
-                    if (STG && outN) {
-#pragma unroll
-                        for (int q = 0; q < 12; ++q) stg(grad + q * nb, cF, 4.0 * g[q]);
-                    }
-                }
-                // ---- advance
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { sA[v] = nA[v]; sB[v] = nB[v]; }
-                S = Nm;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) { sKA[d] = nr.aK[d]; sKB[d] = nr.bK[d]; }
-                P = N;
-                cA += sk;
-            }
-        };
-        Req qa = request(cA), qb;
-        for (int mm = k0 - 1; mm <= k1 + 2; mm += 2) {
-            pstep(mm, qa, qb);
-            lds_barrier();
-            if (mm + 1 <= k1 + 2) {
-                pstep(mm + 1, qb, qa);
-                lds_barrier();
-            }
-        }
-        return;
-    }
-    // ==================================================================== consumer: records + ring -> face fluxes, residual
-    const bool outC = (r >= 1 && lane >= 2 && lane <= 61 && i <= b.il && jn <= b.jl);
-    const bool ringLane = (lane >= 1 && lane <= GF_NL);
-    const int nl = ringLane ? lane - 1 : 0;       // ring column of the thread (clamped: the lanes outside read entry 0 and drop it)
-    const int fl = (lane >= 2 && lane <= 61) ? lane - 2 : 0;
-    GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
-    GPTR(double) dw = (GPTR(double))b.dw;
-    GPTR(double) fw = (GPTR(double))b.fw;
-    VmK K;
-    K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
-    K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
-    // cell (ic, jA, cs) of the consumer's step cs = mm-1 (the plane whose records it reads); its faces are those of plane cs-1
-    unsigned cC = 8u * (unsigned)(ic + jA * b.ldi + (k0 - 1) * b.ldk);
-    // carried: state of the rows jn, jn+1 and sI, sJ, sK of cell row jn at plane cs-1; H of the node planes cs-2, cs-1 and E of cs-2,
-    // cs-1 (see the header); the k-face flux; the own part of the flux sum of the plane before
-    VmCell qA, qB;
-    double sIA[3] = {0.0, 0.0, 0.0}, sJA[3] = {0.0, 0.0, 0.0}, sKA[3] = {0.0, 0.0, 0.0};
-    double Hp2[3] = {0.0, 0.0, 0.0}, Hp1[3], Ep2[3] = {0.0, 0.0, 0.0}, Ep1[3] = {0.0, 0.0, 0.0}, fk[4], pend[4];
-    int flagP = 0;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) { fk[l] = 0.0; pend[l] = 0.0; }
-    qA.u = qA.v = qA.w = qA.na = qA.rlv = qA.rev = 0.0;
-    qB = qA;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) Hp1[d] = ldg(xnod, cC - sk - dM + d * nb8) + ldg(xnod, cC - sk + d * nb8);      // H of node plane k0-2
-    // completes the flux sum of cell plane kc (byte offset c) with the j flux handed over by the wave below and stores it
-    auto finish_sum = [&](const double* __restrict__ fjr, double fs[4]) {
-        const Dbl2 f01 = *reinterpret_cast<const Dbl2*>(fjr), f23 = *reinterpret_cast<const Dbl2*>(fjr + 2);
-        fs[0] = pend[0] + f01.x; fs[1] = pend[1] + f01.y; fs[2] = pend[2] + f23.x; fs[3] = pend[3] + f23.y;
-    };
-    auto finish_store = [&](unsigned c, const double fs[4], int flg) {
-        if (!outC) return;
-        const double blank = flg_blank((uint8_t)flg);
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            const unsigned o = c + (l + 1) * nb8;
-            double fwn = fs[l];
-            if (FIRST) { stg(dw, o, fwn); continue; }
-            if (kp.fwMode) {
-                fwn += ldg(fw, o);
-                stg(fw, o, fwn);
-            }
-            stg(dw, o, (ldg(dw, o) + fwn) * blank);
-        }
-        if (!FIRST && kp.fwMode) stg(dw, c, (ldg(dw, c) + ldg(fw, c)) * blank);    // the density residual has no viscous part
-    };
-    auto cstep = [&](const int mm, const GfNod& N, const int flagW, GfNod& Nn, int& flagN) {
-        if (mm >= k0) {
-            const int cs = mm - 1;
-            const unsigned cF = cC - sk;                              // cell plane cs-1: the plane of the faces
-            const int flag0 = ((unsigned)flagW >> (8u * ((cF >> 3) & 3u))) & 0xffu;
-            const bool facePlane = (cs >= k0);
-            const bool full = (cs > k0);                              // all faces (first face step: the k face below plane k0 only)
-            double fsum[4] = {0.0, 0.0, 0.0, 0.0};
-            bool finNow = false;
-            int finFlag = 0;
-            // ---- nodes of plane cs (H, E) and flags of the face plane: requested a step ahead
-            ld_nodes(cC + (cs <= k1 ? sk : 0u), Nn);
-            // (the flag byte as the aligned 32-bit word around it: a byte load is zero-extended where the loop carries it, i.e. waited for
-            // in front of the barrier of the step that requested it)
-            flagN = (int)*(GPTR(const uint32_t))((GPTR(const char))flags + ((cC >> 3) & ~3u));
-            // ---- records of plane cs: state of the rows jn, jn+1, normals of cell (i, jn, cs)
-            VmCell a, bq;
-            double nI[3], nJ[3], nK[3];
-            {
-                const double* __restrict__ ra = recS + ((cs & 1) * 5 + r) * (3 * 128) + lane * 2;
-                const Dbl2 s0 = *reinterpret_cast<const Dbl2*>(ra), s1 = *reinterpret_cast<const Dbl2*>(ra + 128), s2 = *reinterpret_cast<const Dbl2*>(ra + 256);
-                a.u = s0.x; a.v = s0.y; a.w = s1.x; a.na = s1.y; a.rlv = s2.x; a.rev = s2.y;
-                const double* __restrict__ rb = ra + 3 * 128;
-                const Dbl2 t0 = *reinterpret_cast<const Dbl2*>(rb), t1 = *reinterpret_cast<const Dbl2*>(rb + 128), t2 = *reinterpret_cast<const Dbl2*>(rb + 256);
-                bq.u = t0.x; bq.v = t0.y; bq.w = t1.x; bq.na = t1.y; bq.rlv = t2.x; bq.rev = t2.y;
-                const double* __restrict__ rn = recN + ((cs & 1) * 4 + r) * (5 * 128) + lane * 2;
-                const Dbl2 n0 = *reinterpret_cast<const Dbl2*>(rn), n1 = *reinterpret_cast<const Dbl2*>(rn + 128), n2 = *reinterpret_cast<const Dbl2*>(rn + 256);
-                const Dbl2 n3 = *reinterpret_cast<const Dbl2*>(rn + 384), n4 = *reinterpret_cast<const Dbl2*>(rn + 512);
-                nI[0] = n0.x; nI[1] = n0.y; nI[2] = n1.x; nJ[0] = n1.y; nJ[1] = n2.x; nJ[2] = n2.y; nK[0] = n3.x; nK[1] = n3.y; nK[2] = n4.x;
-            }
-            if (facePlane) {
-                const double* __restrict__ xb = ring + (((cs - k0) % NSLOT) * NW) * GF_G + nl * 2;                    // node plane cs-1
-                const double* __restrict__ xp = ring + (((cs - k0 + NSLOT - 1) % NSLOT) * NW) * GF_G + nl * 2;        // node plane cs-2
-                const int oM = (r >= 1 ? r - 1 : 0) * GF_G, o0 = r * GF_G;                                // node rows jn-1 and jn
-                // cell plane cs-2: the j flux from the wave below has arrived (written in step cs-1).  The sum is formed here (pend is
-                // renewed below) and STORED at the end of the step: the wait for the nodes requested at the top of the step then stands
-                // in front of the stores of the same step and covers the acknowledged stores of the step before only
-                const bool fin = (full && r >= 1 && cs - 2 >= k0);
-                if (fin) finish_sum(fjx + ((cs - 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, fsum);
-                finNow = fin; finFlag = flagP;
-                double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                if (full) {
-                    // ---- j face (jn | jn+1): nodes (i-1..i, jn, cs-2..cs-1); handed to the wave above
-                    double gs[12], f[4], dJv[3];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const double f2 = Ep2[d] + Ep1[d];
-                        dJv[d] = 0.125 * (f2 + lane_up1(f2));
-                    }
-#pragma unroll
-                    for (int q = 0; q < 12; q += 2) {
-                        const Dbl2 u = *reinterpret_cast<const Dbl2*>(xp + o0 + q * GF_NL), v = *reinterpret_cast<const Dbl2*>(xb + o0 + q * GF_NL);
-                        const double s0 = u.x + v.x, s1 = u.y + v.y;
-                        gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
-                    }
-                    if (kp.dbg & 2) { f[0] = gs[0]; f[1] = gs[1]; f[2] = gs[2]; f[3] = gs[3]; } else vm_face<QCR>(K, gs, qA, qB, sJA, dJv, flg_porJ((uint8_t)flag0), f);
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) acc[l] = -f[l];
-                    if (r < NW - 1 && lane >= 2 && lane <= 61) {
-                        double* __restrict__ fo = fjx + (cs & 1) * FJ + (r * GF_OUT + fl) * 4;
-                        *reinterpret_cast<Dbl2*>(fo) = mk2(f[0], f[1]);
-                        *reinterpret_cast<Dbl2*>(fo + 2) = mk2(f[2], f[3]);
-                    }
-                }
-                if (r >= 1) {
-                    if (full) {
-                        // ---- i face (i | i+1): nodes (i, jn-1..jn, cs-2..cs-1); the face (i-1 | i) comes from lane-1
-                        double gs[12], f[4], dIv[3];
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            const double c4 = Hp2[d] + Hp1[d];
-                            dIv[d] = 0.125 * (lane_dn1(c4) - lane_up1(c4));
-                        }
-#pragma unroll
-                        for (int q = 0; q < 12; q += 2) {
-                            const Dbl2 u = *reinterpret_cast<const Dbl2*>(xp + oM + q * GF_NL), v = *reinterpret_cast<const Dbl2*>(xp + o0 + q * GF_NL);
-                            const Dbl2 w = *reinterpret_cast<const Dbl2*>(xb + oM + q * GF_NL), z = *reinterpret_cast<const Dbl2*>(xb + o0 + q * GF_NL);
-                            gs[q] = (u.x + v.x) + (w.x + z.x); gs[q + 1] = (u.y + v.y) + (w.y + z.y);
-                        }
-                        const VmCell qR = vm_dn1(qA);
-                        if (kp.dbg & 2) { f[0] = gs[0]; f[1] = gs[1]; f[2] = gs[2]; f[3] = gs[3]; } else vm_face<QCR>(K, gs, qA, qR, sIA, dIv, flg_porI((uint8_t)flag0), f);
-#pragma unroll
-                        for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
-                    }
-                    // ---- k face above cell plane cs-1: nodes (i-1..i, jn-1..jn, cs-1); sKA holds sK of plane cs-1
-                    {
-                        double gs[12], f[4], dKv[3];
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            const double t = (N.r0[d] + N.r1[d]) - Hp2[d];
-                            dKv[d] = 0.125 * (t + lane_up1(t));
-                        }
-#pragma unroll
-                        for (int q = 0; q < 12; q += 2) {
-                            const Dbl2 w = *reinterpret_cast<const Dbl2*>(xb + oM + q * GF_NL), z = *reinterpret_cast<const Dbl2*>(xb + o0 + q * GF_NL);
-                            const double s0 = w.x + z.x, s1 = w.y + z.y;
-                            gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
-                        }
-                        if (kp.dbg & 2) { f[0] = gs[0]; f[1] = gs[1]; f[2] = gs[2]; f[3] = gs[3]; } else vm_face<QCR>(K, gs, qA, a, sKA, dKv, flg_porK((uint8_t)flag0), f);
-#pragma unroll
-                        for (int l = 0; l < 4; ++l) { pend[l] = (acc[l] + fk[l]) - f[l]; fk[l] = f[l]; }
-                    }
-                    flagP = flag0;
-                }
-            }
-            // ---- advance
-            qA = a; qB = bq;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                sIA[d] = nI[d]; sJA[d] = nJ[d]; sKA[d] = nK[d];
-                Hp2[d] = Hp1[d]; Hp1[d] = N.r0[d] + N.r1[d];
-                Ep2[d] = Ep1[d]; Ep1[d] = N.r2[d] - N.r0[d];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (finNow) finish_store(cF - sk, fsum, finFlag);
-            cC += sk;
-        }
-    };
-    GfNod Na, Nb;
-    int fa = 0, fb = 0;
-    ld_nodes(cC, Nb);                       // the first working step is the second of the pair (mm = k0)
-    Na = Nb;
-    for (int mm = k0 - 1; mm <= k1 + 2; mm += 2) {
-        cstep(mm, Na, fa, Nb, fb);
-        lds_barrier();
-        if (mm + 1 <= k1 + 2) {
-            cstep(mm + 1, Nb, fb, Na, fa);
-            lds_barrier();
-        }
-    }
-    // ---- the last plane of the chunk: its j flux was handed over in the last step
-    if (r >= 1 && k1 >= k0) {
-        double fsum[4];
-        finish_sum(fjx + ((k1 + 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, fsum);
-        finish_store(cC - 2 * sk, fsum, flagP);
-    }
 }
 
 #endif
@@ -1494,26 +1078,17 @@ void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles,
 }
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
-int g_gf_dbg = 0;
-int g_gf_ws = 1;            // tuning "gf_ws": k_visc_gfw (geometry from the nodes, producer / consumer waves) wherever metricFromX bit 1 holds
-bool visc_gf_ws(const KParams& kp) { return g_gf_ws && (kp.metricFromX & 2); }
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)
 {
     if (ntiles <= 0) return;
-    const dim3 grd(ntiles), blk(64, GF_NW, 1), blkw(64, 2 * GF_NW, 1);
-    const bool ws = visc_gf_ws(kp);
-    KParams kd = kp; kd.dbg = g_gf_dbg;
-#define GF_LAUNCH(Q, F, G)                                                                              \
-    {                                                                                                   \
-        if (ws) hipLaunchKernelGGL((k_visc_gfw<Q, F, G>), grd, blkw, 0, s, tab, tiles, kd);             \
-        else hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, tiles, kp);                  \
-    }
+    const dim3 grd(ntiles), blk(64, GF_NW, 1);
+#define GF_LAUNCH(Q, F, G) hipLaunchKernelGGL((k_visc_gf<Q, F, G>), grd, blk, 0, s, tab, tiles, kp)
     if (kp.useQCR) {
-        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true) else GF_LAUNCH(true, true, false) }
-        else { if (storeGrad) GF_LAUNCH(true, false, true) else GF_LAUNCH(true, false, false) }
+        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, true, false); }
+        else { if (storeGrad) GF_LAUNCH(true, false, true); else GF_LAUNCH(true, false, false); }
     } else {
-        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(false, true, true) else GF_LAUNCH(false, true, false) }
-        else { if (storeGrad) GF_LAUNCH(false, false, true) else GF_LAUNCH(false, false, false) }
+        if (kp.viscFirst) { if (storeGrad) GF_LAUNCH(false, true, true); else GF_LAUNCH(false, true, false); }
+        else { if (storeGrad) GF_LAUNCH(false, false, true); else GF_LAUNCH(false, false, false); }
     }
 #undef GF_LAUNCH
 }

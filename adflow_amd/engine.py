@@ -123,6 +123,12 @@ class Engine:
             | (capi.JAC_TURB_ONLY if useTurbOnly else 0) | (capi.JAC_VISC_PC if viscPC else 0) | (capi.JAC_USE_AD if useAD else 0)
         self._chk(self.lib.adflow_gpu_fd_jacobian(level, flags, float(delta)))
 
+    def releaseWorkspace(self) -> int:
+        """gives the dual-number slab a forward-mode assembly keeps between calls back to the device; returns the bytes released"""
+        n = ctypes.c_int64(0)
+        self._chk(self.lib.adflow_gpu_release_workspace(ctypes.byref(n)))
+        return int(n.value)
+
     def jacobianInfo(self):
         ns, nst = ctypes.c_int32(), ctypes.c_int32()
         self._chk(self.lib.adflow_gpu_jacobian_info(ctypes.byref(ns), ctypes.byref(nst), None))

@@ -288,6 +288,11 @@ module adflowGpuShim
             integer(c_int), value :: level, flags
             real(c_double), value :: delta
         end function
+        ! the work space a forward-mode assembly keeps between calls (the slab of dual arrays) back to the device allocator
+        integer(c_int) function adflow_gpu_release_workspace(bytes) bind(C, name="adflow_gpu_release_workspace")
+            import :: c_int, c_ptr
+            type(c_ptr), value :: bytes
+        end function
         integer(c_int) function adflow_gpu_jacobian_info(nState, nStencil, stencil) bind(C, name="adflow_gpu_jacobian_info")
             import :: c_int, c_ptr
             integer(c_int), intent(out) :: nState, nStencil

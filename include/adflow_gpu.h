@@ -434,6 +434,12 @@ int adflow_gpu_abi_sizes2(int* bc_subface_bytes, int* comm_pattern_bytes);
  */
 enum { ADFLOW_JAC_PC = 1u, ADFLOW_JAC_FROZEN_TURB = 2u, ADFLOW_JAC_TURB_ONLY = 4u, ADFLOW_JAC_VISC_PC = 8u, ADFLOW_JAC_USE_AD = 16u };
 int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta);
+/* Hands back the work space an assembly keeps between calls -- the slab of dual arrays of ADFLOW_JAC_USE_AD (about 640 B per box cell:
+ * 8.4 GB on the 8 x 160x128x64 mesh) -- to the device allocator: what the host calls when the matrix is assembled and the memory is
+ * wanted elsewhere (PETSc objects, further multigrid levels).  *bytes (may be NULL): what was released.  The next forward-mode
+ * assembly lays the slab out again.  Mirrors nothing in the reference, whose Tapenade derivative arrays live in flowDomsd for the
+ * whole run (adjointUtils.F90:87-99 allocDerivativeValues). */
+int adflow_gpu_release_workspace(int64_t* bytes);
 /* nState, nStencil and the stencil offsets (nStencil,3) column-major as src/modules/stencils.f90 of the last assembly:
  * block (ll, l) of stencil entry s at row cell (i,j,k) is  d dw(i,j,k,ll) / d w(i-di(s), j-dj(s), k-dk(s), l)  (after resScale) */
 int adflow_gpu_jacobian_info(int32_t* nState, int32_t* nStencil, int32_t* stencil);

@@ -365,13 +365,13 @@ def check_ad_jacobian(engine, dims, prm, spec, usePC=True, frozenTurb=False, use
 
 def check_jacobian_several_blocks(engine, prm, blocks_spec, seed=91, quick=False, **mk):
     """The preconditioner matrix of a LEVEL of several blocks of different sizes (slot numbers with a gap), by finite differences and
-    by forward mode: the marching path of round 5 -- k_pc_march_h + k_sa_march over the level's tile tables, the snapshot entries
+    by forward mode: the marching path of round 5 -- k_pc_march + k_sa_march over the level's tile tables, the snapshot entries
     written by the marches through the per-slot table KParams::snapTab at offsets that depend on the block's own box -- against the
-    same path with the snapshot kernels, against k_pc_march, and against the kernels it replaced (one launch per block, each of them
+    same path with the snapshot kernels and against the kernels it replaced (one launch per block, each of them
     checked against the reference on single blocks in check_fd_jacobian / check_ad_jacobian).  Between two correct assemblies the
     blocks differ by rounding x 1 / delta (finite differences) or by rounding (forward mode)."""
     blocks, rblocks, prm = setup_blocks_with_bc(engine, prm, blocks_spec, seed=seed, **mk)
-    keys = {"pc_fused": 1, "jac_snap": 1, "pc_handover": 3}
+    keys = {"pc_fused": 1, "jac_snap": 1}
 
     def assemble(useAD, **tune):
         for k_, v_ in {**keys, **tune}.items():
@@ -384,7 +384,7 @@ def check_jacobian_several_blocks(engine, prm, blocks_spec, seed=91, quick=False
             new = assemble(useAD)
             others = {"replaced kernels": assemble(useAD, pc_fused=0, jac_snap=0)}
             if not quick:         # (the emulator twin of the test: the two variants below run on single blocks there)
-                others.update({"snapshot kernels": assemble(useAD, jac_snap=0), "k_pc_march": assemble(useAD, pc_handover=0)})
+                others.update({"snapshot kernels": assemble(useAD, jac_snap=0)})
             for nn in blocks:
                 scale = np.abs(others["replaced kernels"][nn]).max()
                 assert scale > 0.0

@@ -262,7 +262,7 @@ def sweep(engine, cases, seed, only=-1, quiet=False, big=False, jac=False):
         # round 5: the tuning keys of the new code paths at random (results never depend on them)
         # (four draws of keys that round 6 removed stay, so that earlier seeds replay as they were)
         rng.choice([0, 1, 2]); rng.integers(0, 2); rng.choice([4, 8]); rng.integers(0, 2)
-        tune = {"pc_fused": n % 2, "jac_snap": (n // 2) % 2, "pc_handover": (n // 4) % 4}      # (pc_fused, jac_snap without a draw: earlier seeds replay as they were)
+        tune = {"pc_fused": n % 2, "jac_snap": (n // 2) % 2}      # (pc_fused, jac_snap without a draw: earlier seeds replay as they were)
         if only >= 0 and n != only:
             continue
         try:
@@ -274,7 +274,7 @@ def sweep(engine, cases, seed, only=-1, quiet=False, big=False, jac=False):
         except AssertionError as ex:
             return n + 1, f"case {n} (seed {seed}): {dims} {entry} {kw} {mk} {tune}: {ex}"
         finally:
-            for k_, v_ in {"split_eval": 1, "pc_fused": 1, "jac_snap": 1, "pc_handover": 3}.items():
+            for k_, v_ in {"split_eval": 1, "pc_fused": 1, "jac_snap": 1}.items():
                 engine.set_tuning(k_, v_)
     return cases, None
 

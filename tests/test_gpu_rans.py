@@ -225,9 +225,6 @@ def test_viscous_kernel_variants(engine):
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, orderTurb=secondOrder)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=10 + sm, stretch_k=2.0, holes=0.05)
         engine.set_tuning("sa_march", 1)
-        engine.set_tuning("sa_side", 1)     # the SA march on its side queue beside the mean-flow kernels (the default of rounds 2-3)
-        checks.check_block_res(engine, (63, 11, 35), FlowParams(equations=RANSEquations, spaceDiscr=upwind), seed=12, stretch_k=2.0)
-        engine.set_tuning("sa_side", 0)
         # the viscous march in front of each inviscid march over the tile table (Roe, matrix dissipation, scalar JST), QCR, minmod
         for prm in (FlowParams(equations=RANSEquations, spaceDiscr=upwind, useQCR=True, muSuthDim=1.0),
                     FlowParams(equations=NSEquations, spaceDiscr=upwind, limiter=minmod, muSuthDim=1.0),
@@ -247,7 +244,7 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("xcd_tiles", 2)
         engine.set_tuning("gf_cus", 0)
         for mx in (0, 1):           # face normals from the arrays everywhere / re-formed from the nodes in the SA march only;
-                                    # the default 7 = SA + gradient marches + time step
+                                    # the default 5 = SA march + time step
             engine.set_tuning("metric_from_x", mx)
             prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind)
             checks.check_block_res(engine, (63, 11, 35), prm, seed=20 + mx, stretch_k=2.0, holes=0.05)
@@ -255,23 +252,18 @@ def test_viscous_kernel_variants(engine):
         engine.set_tuning("viscous_tiled", 2)
         engine.set_tuning("roe_march", 1)
         engine.set_tuning("sa_march", 1)
-        engine.set_tuning("sa_side", 0)
-        engine.set_tuning("gf_ws", 1)
         engine.set_tuning("xcd_tiles", 2)
         engine.set_tuning("gf_cus", 0)
         engine.set_tuning("inviscid_march", 2)
+        engine.set_tuning("metric_from_x", 5)
 
 
-@pytest.mark.parametrize("ws", [1, 0])
-def test_visc_gradient_fused(engine, ws):
+def test_visc_gradient_fused(engine):
     """k_visc_gf: nodal gradients and viscous fluxes in one kernel, the gradients stay in an LDS ring.
-    ws (tuning gf_ws): 1 = k_visc_gfw (round 6, the default): the geometry formed from the node coordinates, producer and consumer
-    waves in one workgroup of eight; 0 = k_visc_gf on the stored normals and centre-to-centre vectors.
     Partial tiles in i (60 columns) / j (3 rows) / the k chunk, blanked cells, QCR, laminar NS, matrix / scalar dissipation, the
     kernel completing dw itself (persistent fw of the RK stages), the stored-gradient variant (wall stress, updateIntermed), k chunks
     of march_kch planes (gf_cus = -1) and chunks fitted to rounds of 2 x CUs workgroups as on a device with 1 / 3 CUs."""
     try:
-        engine.set_tuning("gf_ws", ws)
         prm = FlowParams(equations=RANSEquations, spaceDiscr=upwind, muSuthDim=1.0)
         checks.check_block_res(engine, (63, 7, 35), prm, seed=5, stretch_k=2.0, holes=0.05)
         checks.check_block_res(engine, (61, 9, 33), prm.replace(useQCR=True), seed=6, stretch_k=2.0)
@@ -291,7 +283,6 @@ def test_visc_gradient_fused(engine, ws):
     finally:
         engine.set_tuning("march_kch", 32)
         engine.set_tuning("gf_cus", 0)
-        engine.set_tuning("gf_ws", 1)
 
 
 def test_block_res_without_intermediates(engine):

@@ -133,16 +133,11 @@ def test_dadi_i_direction_by_cyclic_reduction(engine):
         engine.set_tuning("dadi_pcr", 0)
         checks.check_dadi_smoother(engine, BrickTopology(1, 1, 1, 130, 9, 3), prm, stretch_k=2.0)
         engine.set_tuning("dadi_pcr", 1)
-        # the j / k sweeps in their other forms (software pipeline for j, plain for k, the update as its own pass)
-        engine.set_tuning("dadi_jpipe", 1)
-        engine.set_tuning("dadi_kpipe", 0)
-        checks.check_dadi_smoother(engine, BrickTopology(1, 2, 1, 20, 9, 7), prm, stretch_k=2.0)
+        # the update as its own pass
         engine.set_tuning("dadi_upd", 0)
         checks.check_dadi_smoother(engine, BrickTopology(1, 2, 1, 20, 9, 7), prm, stretch_k=2.0)
     finally:
         engine.set_tuning("dadi_pcr", 1)
-        engine.set_tuning("dadi_jpipe", 0)
-        engine.set_tuning("dadi_kpipe", 1)
         engine.set_tuning("dadi_upd", 1)
 
 

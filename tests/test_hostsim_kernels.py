@@ -434,10 +434,9 @@ def test_viscous_kernel_variants(hostsim_engine):
         else test_gpu_rans.test_viscous_kernel_variants(hostsim_engine)
 
 
-@pytest.mark.parametrize("ws", [1, 0])
-def test_visc_gradient_fused(hostsim_engine, ws):
+def test_visc_gradient_fused(hostsim_engine):
     import test_gpu_rans
-    test_gpu_rans.test_visc_gradient_fused(hostsim_engine, ws)
+    test_gpu_rans.test_visc_gradient_fused(hostsim_engine)
 
 
 def test_multiblock_brick_block_res(hostsim_engine):
@@ -575,18 +574,12 @@ def test_pc_march_pair_of_kernels(hostsim_engine):
         e.set_tuning("jac_snap", 0)
         checks.check_fd_jacobian(e, (6, 5, 4), rans, tj.WALL, stretch_k=2.0)
         checks.check_ad_jacobian(e, (6, 5, 4), rans, tj.WALL, stretch_k=2.0)
-        # ... and k_pc_march (both j faces per cell) instead of k_pc_march_h (pc_handover = 0; 3 runs in the tests above); ny = 10: a
-        # tile whose last rows lie beyond the block
+        # ... ny = 10: a tile whose last rows lie beyond the block
         e.set_tuning("jac_snap", 1)
-        e.set_tuning("pc_handover", 0)
-        checks.check_fd_jacobian(e, (5, 10, 4), rans, tj.OPEN, stretch_k=2.0)
-        checks.check_ad_jacobian(e, (5, 6, 4), rans, tj.WALL, stretch_k=2.0)
-        e.set_tuning("pc_handover", 3)
         checks.check_fd_jacobian(e, (5, 10, 4), rans, tj.OPEN, stretch_k=2.0)
     finally:
         e.set_tuning("pc_fused", 1)
         e.set_tuning("jac_snap", 1)
-        e.set_tuning("pc_handover", 3)
 
 
 def test_update_wall_distances_quickly(hostsim_engine):

@@ -18,13 +18,13 @@ from isa_count import main_loop  # noqa: E402
 
 KERNELS = {
     # key of adflow_gpu_march_stats : (source, regex of the mangled name, what)
-    "sa_march": ("kernels_sa_march.hip", r"k_sa_marchILb0ELb0ELb0E", "k_sa_march<false>: Spalart-Allmaras residual"),
-    "visc_gf": ("kernels_viscous.hip", r"k_visc_gfILb0ELb1ELb0ELb0E", "k_visc_gf<false,true,false>: nodal gradients + viscous fluxes"),
-    "visc_gf_qcr": ("kernels_viscous.hip", r"k_visc_gfILb1ELb1ELb0ELb0E", "k_visc_gf<true,true,false>: the same with QCR"),
-    "roe_march": ("kernels_roe_march.hip", r"k_roe_marchILi3ELb0ELb1ELb1ELb0E", "k_roe_march<vanAlbada,.,FINAL,ADDV>: central + Roe upwind"),
+    "sa_march": ("kernels_sa_march.hip", r"k_sa_marchILb0ELb0ELb0EEv", "k_sa_march<false>: Spalart-Allmaras residual"),
+    "visc_gf": ("kernels_viscous.hip", r"k_visc_gfILb0ELb1ELb0EEv", "k_visc_gf<false,true,false>: nodal gradients + viscous fluxes"),
+    "visc_gf_qcr": ("kernels_viscous.hip", r"k_visc_gfILb1ELb1ELb0EEv", "k_visc_gf<true,true,false>: the same with QCR"),
+    "roe_march": ("kernels_roe_march.hip", r"k_roe_marchILi3ELb0ELb1ELb1ELb0EEv", "k_roe_march<vanAlbada,.,FINAL,ADDV>: central + Roe upwind"),
     "matrix_march": ("kernels_inviscid_march.hip", r"k_inviscid_marchILi2E", "k_inviscid_march<matrix,...> (first instantiation found)"),
     "euler_march": ("kernels_euler_march.hip", r"k_euler_march_p", "k_euler_march_p (first instantiation found)"),
-    "pc_march": ("kernels_pc_march.hip", r"k_pc_march_hILb1E", "k_pc_march_h<SNAP>: first-order Roe + thin-layer viscous flux of the preconditioner matrix (static count: the fifth-face block a wave executes in one plane of four included)"),
+    "pc_march": ("kernels_pc_march.hip", r"k_pc_marchILb1EEv", "k_pc_march<SNAP>: first-order Roe + thin-layer viscous flux of the preconditioner matrix (static count: the fifth-face block a wave executes in one plane of four included)"),
 }
 
 
