@@ -1,4 +1,4 @@
-"""Worker of tests/test_multirank_cpu.py: one rank of a 2-rank halo exchange with
+"""Worker of tests/test_multirank_cpu.py: one rank of an N-rank halo exchange with
 the inter-rank transport done by torch.distributed (gloo) between the library's
 pack and unpack entry points.  The kernel side runs on the tests/hostsim
 emulator (CPU-only CI); the product transport (RCCL inside
@@ -36,6 +36,27 @@ def main():
         shape = (4, 2, 2)     # 4x2x2 brick physical boundaries (no pattern entry beyond them), 1-to-1 interfaces inside
         periodic = (False, False, False)
         topo = BrickTopology(*shape, *dims, owner=lambda g: (g % 4) // 2, periodic=periodic)
+    elif mode in ("weak", "weakwall"):
+        # bench.py's weak layout at any N (Job.__init__): the ranks form an rx x ry x rz grid (rank_grid: 8 -> 2x2x2), every rank owns a
+        # 2x2x2 brick of blocks; "weak": periodic in all three directions (the periodic twin), "weakwall": the ends of the whole brick are
+        # physical boundaries (the default, wall-bounded workload).  At N = 8 a rank has three face peers and edge / corner peers: 7
+        g3, d, n = [1, 1, 1], 0, world
+        while n > 1:
+            f = 2 if n % 2 == 0 else n
+            g3[d % 3] *= f
+            n //= f
+            d += 1
+        rx, ry, rz = g3
+        e = 2
+        dims = (4, 3, 3)
+        shape = (e * rx, e * ry, e * rz)
+        if mode == "weakwall":
+            periodic = (False, False, False)
+
+        def owner(g, Bi=e * rx, Bj=e * ry):
+            bi, bj, bk = g % Bi, (g // Bi) % Bj, g // (Bi * Bj)
+            return (bi // e) + rx * ((bj // e) + ry * (bk // e))
+        topo = BrickTopology(*shape, *dims, owner=owner, periodic=periodic)
     else:
         shape = (2, 2, 1)
         topo = BrickTopology(*shape, *dims, owner=lambda g: g % world)
@@ -100,6 +121,7 @@ def main():
     dist.barrier()
     eng.close()
     dist.destroy_process_group()
+    print(f"rank {rank} peers {len(cp.sendProc)}")
     print(f"rank {rank} OK" if bad == 0 else f"rank {rank} FAIL")
     sys.exit(0 if bad == 0 else 1)
 
