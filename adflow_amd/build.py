@@ -44,8 +44,13 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + CFLAGS + ["-c", s, "-o", o]
+        tmp = f"{o}.tmp.{os.getpid()}"
+        cmd = [HIPCC] + CFLAGS + ["-c", s, "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            os.replace(tmp, o)
+        elif os.path.exists(tmp):
+            os.remove(tmp)
         return s, r.returncode, r.stdout + r.stderr
 
     if jobs:
@@ -59,10 +64,15 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if jobs or force or _stale(LIB, objs):
         # -Bsymbolic-functions: calls between the library's own entry points (adflow_gpu_mg_cycle -> adflow_gpu_rk_smooth ...) bind
         # inside the library and cannot be interposed by another definition of the same name in the process
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+        # (linked under another name and renamed: a process that loads the library never sees a half-written file)
+        tmp = f"{LIB}.tmp.{os.getpid()}"
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-o", tmp] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        os.replace(tmp, LIB)
     return LIB
 
 

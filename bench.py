@@ -740,7 +740,7 @@ def main():
                 extra["pc_matrix_assembly_forward_ad"] = {
                     "ms": sad * 1e3, "forward_evaluations": 42, "ms_per_evaluation": sad * 1e3 / 42.0,
                     "what": "adflow_gpu_fd_jacobian(PC | USE_AD): seed = 1 on one state variable of one colour per pass; the marching "
-                            "kernels of the approximate residual on dual numbers (k_pc_march_h: first-order Roe + thin-layer viscous flux, "
+                            "kernels of the approximate residual on dual numbers (k_pc_march: first-order Roe + thin-layer viscous flux, "
                             "k_sa_march), dual closures and boundary conditions, snapshots written by the marches; the dual copies of the "
                             "level's arrays (640 B per box cell, one slab kept between calls) are refreshed from the library's arrays "
                             "inside the call"}

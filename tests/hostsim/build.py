@@ -19,13 +19,19 @@ def build(force=False):
         [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "adflow_gpu.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
+    # (linked into a file of its own and renamed: several pytest-xdist workers may find the library stale at the same time, and a
+    # reader must never see a half-written one)
+    tmp = f"{LIB}.tmp.{os.getpid()}"
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-Wl,-Bsymbolic-functions", "-I", HERE,
-           "-DADFLOW_NO_RCCL", "-Wno-unknown-pragmas", "-o", LIB]
+           "-DADFLOW_NO_RCCL", "-Wno-unknown-pragmas", "-o", tmp]
     for s in srcs:
         cmd += ["-x", "c++", s]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hostsim build failed:\n" + r.stdout + r.stderr)
+    os.replace(tmp, LIB)
     return LIB
 
 
