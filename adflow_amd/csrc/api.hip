@@ -1744,7 +1744,41 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
         if (rc || ensure_tiles(level)) return 1;
         ad_launch_pc_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, kp, g_march_kch, g_stream);
     } else if (resFlags & ADFLOW_RES_FLOW) {
-        ad_launch_inviscid_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        // the Roe upwind scheme of the exact linearisation (second order, the user's limiter): the marching kernel on dual numbers
+        // (kernels_roe_march.hip compiled a second time, round 6) instead of the cell-gather kernel -- 3.25 instead of 6 face
+        // evaluations and 3.5 instead of 12 reconstructions per cell; it leaves dw + fw in dw for the viscous kernel that follows
+        // ... and the full viscous flux as the fused gradient + flux march on dual numbers (k_visc_gf compiled a second time: the metric
+        // sums and face geometry stay plain, the ring holds dual gradients -- 160 KB of LDS, one workgroup per CU) instead of the dual
+        // gather pair k_nodal_gradients + k_viscous (1.01 ms per pass and 1.3 M cells): in front of the Roe march, which adds its sums
+        // (viscFirst), or behind the gather inviscid kernel of the other schemes, completing dw itself
+        const bool viscous = kp.viscous && fabs(kp.rFil) >= 1.e-10;
+        const bool gfDual = viscous && !viscApprox && g_pc_fused && viscous_is_tiled() >= 2 && kp.fineGrid;
+        if (gfDual) {
+            rc = for_level(level, [&](Block* b) {
+                if (!b->face_vectors_valid) {
+                    launch_face_vectors(b->v, g_stream);
+                    b->face_vectors_valid = true;
+                }
+                return 0;
+            });
+            if (rc || ensure_gf_tiles(level)) return 1;
+        }
+        bool marched = false;
+        if (g_pc_fused && roe_march_takes(kp)) {
+            if (ensure_tiles(level)) return 1;
+            KParams kr = kp;
+            if (gfDual) {
+                kr.viscFirst = 1;
+                ad_launch_visc_gf(g_ad_tab, g_gf_tiles[level].first, g_gf_tiles[level].second, kr, g_stream);
+            }
+            marched = ad_launch_roe_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, kr, g_stream);
+            if (marched && gfDual) return 0;
+        }
+        if (!marched) ad_launch_inviscid_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
+        if (gfDual) {
+            ad_launch_visc_gf(g_ad_tab, g_gf_tiles[level].first, g_gf_tiles[level].second, kp, g_stream);
+            return 0;
+        }
         if (kp.viscous && fabs(kp.rFil) >= 1.e-10) {
             rc = for_level(level, [&](Block* b) {
                 if (viscApprox) ad_launch_viscous_approx(g_ad[b].v, kp, g_stream);

@@ -180,6 +180,11 @@ __device__ __forceinline__ int exponent_of(double x) { int e; (void)frexp(x, &e)
 __device__ __forceinline__ int exponent_of(double x) { return __builtin_amdgcn_frexp_exp(x); }
 #endif
 
+// a b + c in one rounding (the dual form, kernels_ad.hip, is the plain product and sum)
+__device__ __forceinline__ double adf_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// high 32 bits of a double (the exponent test of the limiter's clamp, kernels_roe_march.hip; kernels_ad.hip holds the dual form)
+__device__ __forceinline__ int adf_hiword(double x) { return __double2hiint(x); }
+
 // a value that is the same in every lane of the wavefront, moved to a scalar register so that branches on it are scalar branches
 #ifdef HOSTSIM
 __device__ __forceinline__ int wave_uniform(int v) { return v; }
@@ -491,3 +496,5 @@ void ad_launch_seed_closures(const BlkView& real, const BlkView& adv, int l, int
                              bool onlyL);
 void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s);
 void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+void ad_launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+bool ad_launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);

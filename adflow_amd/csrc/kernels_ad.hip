@@ -73,6 +73,9 @@ __device__ __forceinline__ void stg(GPTR(Dual) base, unsigned byteoff8, const Du
 }
 // the snapshot entry of a forward-mode pass: the derivative part (k_ad_snap; no reference residual, no step)
 __device__ __forceinline__ void snap_put(GPTR(double) sn, unsigned c, const Dual& val) { stg(sn, c, val.d); }
+__device__ __forceinline__ int adf_hiword(const Dual& a) { return adf_hiword(a.v); }
+__device__ __forceinline__ Dual adf_fma(const Dual& a, const Dual& b, const Dual& c) { return a * b + c; }
+__device__ __forceinline__ Dual adf_fma(const Dual& a, const Dual& b, double c) { return a * b + c; }
 __device__ __forceinline__ Dual lane_up1(const Dual& a) { return Dual(lane_up1(a.v), lane_up1(a.d)); }
 __device__ __forceinline__ Dual lane_dn1(const Dual& a) { return Dual(lane_dn1(a.v), lane_dn1(a.d)); }
 
@@ -103,6 +106,7 @@ __global__ void k_ad_value(const Dual* __restrict__ src, double* __restrict__ ds
     if (t < n) dst[t] = deriv ? src[t].d : src[t].v;
 }
 
+extern int g_march_kch, g_roe_march;
 namespace adj {
 #define ADF_AD_BUILD 1
 #define double Dual
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(256) void k_seed_closures(BlkView b, const adf_real
 #include "kernels_viscous.hip"
 #include "kernels_pc_march.hip"
 #include "kernels_sa_march.hip"
+#include "kernels_roe_march.hip"
 
 #undef BlkView
 #undef double
@@ -241,5 +246,13 @@ void ad_launch_pc_march(const BlkView* tab, const int4* tiles, int ntiles, const
 void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     adj::launch_sa_march(ADV(tab), tiles, ntiles, kp, s, false);
+}
+void ad_launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    adj::launch_visc_gf(ADV(tab), tiles, ntiles, kp, false, s);
+}
+bool ad_launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    return adj::launch_roe_march(ADV(tab), tiles, ntiles, kp, s);
 }
 #undef ADV

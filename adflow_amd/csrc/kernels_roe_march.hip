@@ -24,11 +24,22 @@
 //
 // gamma: calorically perfect gas (cpConstant, the only cp model of the path): gamma(i,j,k) = gammaConstant.
 // Roofline: FP64 VALU issue (~1500 slots per cell), then HBM.
+// The source is compiled twice (round 6): as it stands, and inside namespace adj of kernels_ad.hip with `double` standing for the dual
+// number -- the exact linearisation of the adjoint (adjointUtils.F90:227-409, inviscidUpwindFlux_d) ran the cell-GATHER Roe kernel on
+// dual numbers (six faces and twelve reconstructions per cell: 0.77 ms per forward pass and 1.3 M cells).  Geometry and options are
+// adf_real8 and stay plain there; the dual build takes one workgroup per CU (the whole register file).
+#ifndef ADF_AD_BUILD
 #include "internal.h"
+#endif
 #include "roe_face.h"
 
 #define RM_OUT 60          // must match EM_OUT / EM_BY of kernels_euler_march.hip: the tile table is shared
 #define RM_BY 4
+#ifdef ADF_AD_BUILD
+#define RM_MINWG 1
+#else
+#define RM_MINWG 2
+#endif
 
 struct RmPtrs {
     GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) w4;
@@ -102,11 +113,11 @@ __device__ __forceinline__ void rm_recon1(const RmK& K, double qm, double q0, do
 __device__ __forceinline__ void rm_va_sym(double qm, double q0, double qp, double& plus, double& minus, unsigned& range)
 {
     const double dm = q0 - qm, dp = qp - q0;
-    const double den = __builtin_fma(dp, dp, __builtin_fma(dm, dm, 1.e-300));
+    const double den = adf_fma(dp, dp, adf_fma(dm, dm, 1.e-300));
     const double h = (0.5 * fmax(dp * dm, 0.0)) * rcp_nr(den) * (dp + dm);
     plus = q0 + h;
     minus = q0 - h;
-    const unsigned u = (unsigned)__double2hiint(fmin(fabs(dm), fabs(dp))) - 1u;
+    const unsigned u = (unsigned)adf_hiword(fmin(fabs(dm), fabs(dp))) - 1u;
     range = (u < range) ? u : range;
 }
 
@@ -180,9 +191,9 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     RmPtrs m;
     m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb; m.w4 = m.w3 + nb;
     m.p = (GPTR(const double))b.p;
-    GPTR(const double) sIx = (GPTR(const double))b.sI; GPTR(const double) sIy = sIx + nb; GPTR(const double) sIz = sIy + nb;
-    GPTR(const double) sJx = (GPTR(const double))b.sJ; GPTR(const double) sJy = sJx + nb; GPTR(const double) sJz = sJy + nb;
-    GPTR(const double) sKx = (GPTR(const double))b.sK; GPTR(const double) sKy = sKx + nb; GPTR(const double) sKz = sKy + nb;
+    GPTR(const adf_real8) sIx = (GPTR(const adf_real8))b.sI; GPTR(const adf_real8) sIy = sIx + nb; GPTR(const adf_real8) sIz = sIy + nb;
+    GPTR(const adf_real8) sJx = (GPTR(const adf_real8))b.sJ; GPTR(const adf_real8) sJy = sJx + nb; GPTR(const adf_real8) sJz = sJy + nb;
+    GPTR(const adf_real8) sKx = (GPTR(const adf_real8))b.sK; GPTR(const adf_real8) sKy = sKx + nb; GPTR(const adf_real8) sKz = sKy + nb;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     GPTR(double) dw = (GPTR(double))b.dw;
     GPTR(double) fw = (GPTR(double))b.fw;
@@ -208,7 +219,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     }
     int flagm = flags[(c - sk) >> 3];
     int flag0 = flags[c >> 3];
-    double nI[3] = {ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u)};     // face (i-1 | i) of the plane the step works on
+    adf_real8 nI[3] = {ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u)};     // face (i-1 | i) of the plane the step works on
     double acc[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};   // accD: dissipation part, kept apart only when FW
 
     // A wave is resident with ONE other per SIMD: what a step loads has to be in flight while it computes.  The step is laid out as
@@ -221,7 +232,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     // The step that only finishes the last cell stands behind the loop: inside it, its path around the j reconstruction would make
     // every wait behind that point count as if the loads of the top were still pending.
     double fc[5], fd[5];
-    auto kface = [&](const RCell& qp1, double nKx, double nKy, double nKz, double ULk0[5], auto&& between) {
+    auto kface = [&](const RCell& qp1, adf_real8 nKx, adf_real8 nKy, adf_real8 nKz, double ULk0[5], auto&& between) {
         double URk0[5];
         rm_recon<LIM>(K, qm1, q0, qp1, ULk0, URk0);
         between();
@@ -237,12 +248,14 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
         if (out) {
             const unsigned cw = c - sk;
             const double blank = flg_blank((uint8_t)flagm);
+#ifndef ADF_AD_BUILD
             double ovv = 0.0;
             double* __restrict__ rv = nullptr;
             if (RV) {
                 ovv = 1.0 / ldg((GPTR(const double))b.volRef, cw);
                 rv = kp.rvec + b.vecOff + ((((long)(k - 3) * b.ny + (j - 2)) * b.nx + (i - 2)) * b.nw);
             }
+#endif
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 double d = (acc[l] - fl[l]) + fc[l];
@@ -257,10 +270,14 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
                     d += fd[l];
                     if (ADDV && l > 0) d += vsum[l - 1];
                     stg(dw + l * nb, cw, d * blank);      // not FINAL: the viscous kernel adds its part to dw(2:5) and re-applies iblank
+#ifndef ADF_AD_BUILD
                     if (RV) rv[l] = (d * blank) * ovv;
+#endif
                 }
             }
+#ifndef ADF_AD_BUILD
             if (RV && !FW && kp.rvecTurbFromDw) rv[5] = turbDw * ovv * kp.rvecTurbScale;
+#endif
         }
     };
 
@@ -273,7 +290,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
 #endif
         // ---- request
         const RCell qp1 = rm_ld(m, c + sk);
-        const double nKx = ldg(sKx, c - sk), nKy = ldg(sKy, c - sk), nKz = ldg(sKz, c - sk);
+        const adf_real8 nKx = ldg(sKx, c - sk), nKy = ldg(sKy, c - sk), nKz = ldg(sKz, c - sk);
         const RCell qjm = rm_ld(m, c - sj);
         const RCell qjp = rm_ld(m, c + sj);
         RCell qjp2;
@@ -330,7 +347,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
             for (int l = 0; l < 5; ++l) xb[(4 * 5 + l) * 64 + lane] = mi[l];
         }
         // request what the part behind the barrier and phase A of the next step consume
-        double nJ[3], nIn[3], nE[3];
+        adf_real8 nJ[3], nIn[3], nE[3];
         double vsum[4] = {0, 0, 0, 0};       // ADDV: viscous flux sums of the cell finished in this step
         if (ADDV && k > k0 && out) {
 #pragma unroll
@@ -410,7 +427,7 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
     // ---- the k face above the last cell of the chunk, and that cell
     {
         const RCell qp1 = rm_ld(m, c + sk);
-        const double nKx = ldg(sKx, c - sk), nKy = ldg(sKy, c - sk), nKz = ldg(sKz, c - sk);
+        const adf_real8 nKx = ldg(sKx, c - sk), nKy = ldg(sKy, c - sk), nKz = ldg(sKz, c - sk);
         double vsum[4] = {0, 0, 0, 0};
         if (ADDV && out) {
 #pragma unroll
@@ -425,16 +442,18 @@ __device__ __forceinline__ void roe_march_body(const BlkView* __restrict__ tab, 
 }
 
 template <int LIM, bool FW, bool FINAL, bool ADDV = false, bool RV = false>
-__global__ __launch_bounds__(64 * RM_BY, 2) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
+__global__ __launch_bounds__(64 * RM_BY, RM_MINWG) void k_roe_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp,
                                                              int kch)
 {
     __shared__ double xj[2 * RM_XJ(FW) + 2 * RM_XQ];
     roe_march_body<LIM, FW, FINAL, ADDV, RV>(tab, tiles, kp, kch, (int)blockIdx.x, xj);
 }
 
+#ifndef ADF_AD_BUILD
 int g_roe_march = 1;       // tuning "roe_march": 0 = k_inviscid_march<upwind> (reconstruction per face) on the fine level too
 
 extern int g_march_kch;
+#endif
 
 template <int LIM>
 static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
@@ -442,7 +461,15 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
     const dim3 blk(64, RM_BY, 1), grd(ntiles);
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
     const bool final_ = !(kp.viscous && doDiss);
-    const int kch = g_march_kch;
+    const int kch = ::g_march_kch;
+#ifdef ADF_AD_BUILD
+    // forward mode (the exact dR/dw of the adjoint): no persistent fw, no matrix-free vector; the dual gather viscous kernel follows
+    // and completes dw where the equations are viscous
+    // (viscFirst: the dual form of k_visc_gf ran in front and left its flux sums in dw(2:5))
+    if (kp.viscFirst) hipLaunchKernelGGL((k_roe_march<LIM, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+    else if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+    else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
+#else
     if (kp.fwMode) {
         if (final_) hipLaunchKernelGGL((k_roe_march<LIM, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
@@ -459,11 +486,12 @@ static void launch_rm(const BlkView* tab, const int4* tiles, int ntiles, const K
         } else if (final_) hipLaunchKernelGGL((k_roe_march<LIM, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_roe_march<LIM, false, false>), grd, blk, 0, s, tab, tiles, kp, kch);
     }
+#endif
 }
 
 bool roe_march_takes(const KParams& kp)
 {
-    if (!g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid) return false;
+    if (!::g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid) return false;
     const int lim = kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter;
     return lim == ADFLOW_LIM_FIRST_ORDER || lim == ADFLOW_LIM_NONE || lim == ADFLOW_LIM_VANALBADA || lim == ADFLOW_LIM_MINMOD;
 }
@@ -472,7 +500,7 @@ bool roe_march_takes(const KParams& kp)
 bool launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     // (the approximate residual changes the Roe scheme only through the limiter: lumpedDiss = first order)
-    if (!g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid) return false;
+    if (!::g_roe_march || kp.spaceDiscr != ADFLOW_UPWIND || !kp.fineGrid) return false;
     if (ntiles <= 0) return true;
     switch (kp.lumpedDiss ? ADFLOW_LIM_FIRST_ORDER : kp.limiter) {
     case ADFLOW_LIM_FIRST_ORDER: launch_rm<ADFLOW_LIM_FIRST_ORDER>(tab, tiles, ntiles, kp, s); return true;

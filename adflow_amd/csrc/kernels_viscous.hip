@@ -111,7 +111,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
     node_gradient(b, b.idx(i, j, k));
 }
 
-#ifndef ADF_AD_BUILD      // (kernels_ad.hip compiles the gather kernels only: no lane exchange, no LDS)
+// (the marching forms below compile in the forward-mode build too: round 6, k_visc_gf on dual numbers)
 // ---------------------------------------------------------------------------
 // The dual-cell surface integral of allNodalGradients (flowUtils.F90:1712-1979) factorises: with the per-CELL vectors
 // tI = sI(i-1) + sI(i), tJ = sJ(j-1) + sJ(j), tK = sK(k-1) + sK(k) the normal of the integration point of direction k at cell plane m is
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(VS_BX* VS_BY) void k_nodal_gradients(BlkView b)
 
 // g += (NEG ? -1 : +1) phi (x) t   (the factor 0.25 of the surface integral rides on 1 / volume in the caller)
 template <bool NEG>
-__device__ __forceinline__ void ng_outer(double g[12], const double ph[4], const double t[3])
+__device__ __forceinline__ void ng_outer(double g[12], const double ph[4], const adf_real8 t[3])
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -137,12 +137,12 @@ __device__ __forceinline__ void ng_outer(double g[12], const double ph[4], const
     }
 }
 
-__device__ __forceinline__ void vm_ld3(GPTR(const double) a, unsigned o, unsigned nb8, double v[3])
+__device__ __forceinline__ void vm_ld3(GPTR(const adf_real8) a, unsigned o, unsigned nb8, adf_real8 v[3])
 {
     v[0] = ldg(a, o); v[1] = ldg(a, o + nb8); v[2] = ldg(a, o + 2 * nb8);
 }
 
-#endif
+
 // viscous flux through the face between cells cL and cL+sd (fluxes.F90:2610-2860);
 // the four face nodes are cL, cL-s1, cL-s2, cL-s1-s2.
 __device__ __forceinline__ void visc_face(const BlkView& b, const KParams& kp, long cL, long sd, long s1, long s2,
@@ -424,7 +424,6 @@ __device__ __forceinline__ VCell vcell_at(const BlkView& b, const KParams& kp, l
     return c;
 }
 
-#ifndef ADF_AD_BUILD
 // ---------------------------------------------------------------------------
 // Face arithmetic of the marching viscous kernels (k_visc_gf, k_visc_approx_march): vm_face = fluxes.F90:2610-2860 with the SUM of
 // the gradients of the four face nodes handed in (the 4-node average is formed from pair sums: rounding only), the constant gamma
@@ -457,23 +456,23 @@ __device__ __forceinline__ VmCell vm_dn1(const VmCell& q)
     return r;
 }
 
-struct VmK { double porV, hl, ht; bool eddy; };       // 0.5 rFil; 1 / (prandtl (gamma-1)); 1 / (prandtlTurb (gamma-1))
+struct VmK { adf_real8 porV, hl, ht; bool eddy; };       // 0.5 rFil; 1 / (prandtl (gamma-1)); 1 / (prandtlTurb (gamma-1))
 
 // viscous flux through the face between L and R (normal fN pointing from L to R, centre-to-centre vector dN); gr: AVERAGE of the
 // gradients of the four face nodes (k_visc_gf keeps a QUARTER of every nodal gradient in its ring -- the factor rides on 1 / volume --
 // so the average is the plain sum of four ring entries: exact, powers of two)
 template <bool QCR>
-__device__ __forceinline__ void vm_face(const VmK& K, const double gr[12], const VmCell& L, const VmCell& R, const double fN[3],
-                                        const double dN[3], int por_code, double f[4])
+__device__ __forceinline__ void vm_face(const VmK& K, const double gr[12], const VmCell& L, const VmCell& R, const adf_real8 fN[3],
+                                        const adf_real8 dN[3], int por_code, double f[4])
 {
-    double por = K.porV;
+    adf_real8 por = K.porV;
     if (por_code == ADF_POR_NOFLUX) por = 0.0;
     const double mul = por * (L.rlv + R.rlv);
     const double mue = K.eddy ? por * (L.rev + R.rev) : 0.0;
     const double mut = mul + mue;
     const double heatCoef = mul * K.hl + mue * K.ht;
-    const double ss = rsq_nr(dN[0] * dN[0] + dN[1] * dN[1] + dN[2] * dN[2]);
-    const double ssx = ss * dN[0], ssy = ss * dN[1], ssz = ss * dN[2];
+    const adf_real8 ss = rsq_nr(dN[0] * dN[0] + dN[1] * dN[1] + dN[2] * dN[2]);
+    const adf_real8 ssx = ss * dN[0], ssy = ss * dN[1], ssz = ss * dN[2];
     double corr;
     corr = gr[0] * ssx + gr[1] * ssy + gr[2] * ssz - (R.u - L.u) * ss;
     const double u_x = gr[0] - corr * ssx, u_y = gr[1] - corr * ssy, u_z = gr[2] - corr * ssz;
@@ -503,7 +502,7 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gr[12], const
         tauyz -= fact * (Wyx * tauxzS + Wyz * tauzzS + Wzx * tauxyS + Wzy * tauyyS);
     }
     const double ubar = 0.5 * (L.u + R.u), vbar = 0.5 * (L.v + R.v), wbar = 0.5 * (L.w + R.w);
-    const double nx = fN[0], ny = fN[1], nz = fN[2];
+    const adf_real8 nx = fN[0], ny = fN[1], nz = fN[2];
     f[0] = tauxx * nx + tauxy * ny + tauxz * nz;
     f[1] = tauxy * nx + tauyy * ny + tauyz * nz;
     f[2] = tauxz * nx + tauyz * ny + tauzz * nz;
@@ -513,6 +512,7 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gr[12], const
     f[3] = frhoE - q_x * nx - q_y * ny - q_z * nz;
 }
 
+#ifndef ADF_AD_BUILD
 // viscousFluxApprox (fluxes.F90:3487-3859), the thin-layer form of the preconditioner assembly, as a k-march over the level's tile
 // table: the face gradient is the difference of the two cell values along the centre-to-centre vector, i.e. vm_face with the nodal
 // gradients set to zero -- no gradients, no LDS ring.  k faces carried, i faces once (DPP hand-over of the flux), both j faces per
@@ -635,6 +635,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
     }
 }
 
+#endif
 // ---------------------------------------------------------------------------
 // FUSED nodal gradients + viscous fluxes, two workgroups per CU (tuning "viscous_tiled" = 2, the default).  The pair of round 2,
 // k_node_grad_march and k_visc_march, exchanged the 12 nodal gradients through HBM (103 B per cell written, 125 B read back) and
@@ -664,16 +665,21 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
 #define GF_RING (3 * 4 * GF_G)
 #define GF_FJ (3 * GF_OUT * 4)    // doubles of one parity of the j-flux hand-over: rows 0..2, lanes 2..61, 4 components
 #define GF_NW 4                   // waves (node rows) of a workgroup
+#ifdef ADF_AD_BUILD
+#define GF_MINWG 1                // dual numbers: the ring alone is 140 KB, the whole register file
+#else
+#define GF_MINWG 2
+#endif
 
 struct GfPtrs {
     GPTR(const double) w0; GPTR(const double) w1; GPTR(const double) w2; GPTR(const double) w3; GPTR(const double) p;
-    GPTR(const double) rlv; GPTR(const double) rev; GPTR(const double) vol;
-    GPTR(const double) sI; GPTR(const double) sJ; GPTR(const double) sK;
+    GPTR(const double) rlv; GPTR(const double) rev; GPTR(const adf_real8) vol;
+    GPTR(const adf_real8) sI; GPTR(const adf_real8) sJ; GPTR(const adf_real8) sK;
     unsigned nb8;
 };
 
 // state + volume of one cell
-struct GfRaw { VmCell q; double vol; };
+struct GfRaw { VmCell q; adf_real8 vol; };
 
 __device__ __forceinline__ GfRaw gf_ld(const GfPtrs& m, unsigned o, double gam, bool eddy)
 {
@@ -687,17 +693,17 @@ __device__ __forceinline__ GfRaw gf_ld(const GfPtrs& m, unsigned o, double gam, 
 }
 
 // metric sums of one cell plane around the node column of the thread (the t-part of NgPlane)
-struct GfMet { double Pt[3], Q0t[3], Q1t[3], RIt[3], V; };
+struct GfMet { adf_real8 Pt[3], Q0t[3], Q1t[3], RIt[3], V; };
 
 // two doubles moved as one 16-byte LDS access
 struct __attribute__((aligned(16))) Dbl2 { double x, y; };
 __device__ __forceinline__ Dbl2 mk2(double x, double y) { Dbl2 v; v.x = x; v.y = y; return v; }
 
 // one cell plane of the rows jn, jn+1 as loaded
-struct GfReq { double au, av, aw, ap, ar, alv, aev, avol, bu, bv, bw, bp, br, blv, bev, bvol, aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3]; };
+struct GfReq { double au, av, aw, ap, ar, alv, aev, bu, bv, bw, bp, br, blv, bev; adf_real8 avol, bvol, aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3]; };
 
 template <bool QCR, bool FIRST, bool STG>
-__global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
+__global__ __launch_bounds__(64 * GF_NW, GF_MINWG) void k_visc_gf(const BlkView* __restrict__ tab, const int4* __restrict__ tiles, KParams kp)
 {
     constexpr int NW = GF_NW, NSLOT = 3;
     __shared__ __attribute__((aligned(16))) double ring[NSLOT * NW * GF_G];   // [slot][node row 0..NW-1 = rows j0-1 .. j0+NW-2][component pair][lane-1][2]
@@ -724,10 +730,10 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
     GfPtrs m;
     m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
     m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.rev = (GPTR(const double))b.rev;
-    m.vol = (GPTR(const double))b.vol;
-    m.sI = (GPTR(const double))b.sI; m.sJ = (GPTR(const double))b.sJ; m.sK = (GPTR(const double))b.sK;
+    m.vol = (GPTR(const adf_real8))b.vol;
+    m.sI = (GPTR(const adf_real8))b.sI; m.sJ = (GPTR(const adf_real8))b.sJ; m.sK = (GPTR(const adf_real8))b.sK;
     m.nb8 = nb8;
-    GPTR(const double) xcen = (GPTR(const double))b.xc;
+    GPTR(const adf_real8) xcen = (GPTR(const adf_real8))b.xc;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     GPTR(double) dw = (GPTR(double))b.dw;
     GPTR(double) fw = (GPTR(double))b.fw;
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
     VmK K;
     K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
     K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
-    const double gam = kp.gammaConstant;
+    const adf_real8 gam = kp.gammaConstant;
     // byte offsets of the cells (ic, jA, m) and (ic, jB, m); the row below the own one (jn >= 1)
     unsigned cA = 8u * (unsigned)(ic + jA * b.ldi + (k0 - 1) * b.ldk);
     const unsigned dB = 8u * (unsigned)((jB - jA) * b.ldi);          // row jn+1 relative to row jn (0 at the upper end of the box)
@@ -744,8 +750,9 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
     // part of the flux sum of the plane before
     VmCell qA, qB;
     GfMet S;
-    double sKA[3], sKB[3], fk[4], pend[4];
-    double xcP[3] = {0.0, 0.0, 0.0};        // centre of cell (i, jn, mm-1)
+    adf_real8 sKA[3], sKB[3];
+    double fk[4], pend[4];
+    adf_real8 xcP[3] = {0.0, 0.0, 0.0};        // centre of cell (i, jn, mm-1)
     int flagP = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { sKA[d] = ldg(m.sK, cA - sk + d * nb8); sKB[d] = ldg(m.sK, cA + dB - sk + d * nb8); }
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
         const Dbl2 f01 = *reinterpret_cast<const Dbl2*>(fjr), f23 = *reinterpret_cast<const Dbl2*>(fjr + 2);
         const double fl4[4] = {f01.x, f01.y, f23.x, f23.y};
         if (!outC) return;
-        const double blank = flg_blank((uint8_t)flg);
+        const adf_real8 blank = flg_blank((uint8_t)flg);
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const unsigned o = c + (l + 1) * nb8;
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
         // the vectors between cell centres (fluxes.F90:2673-2690, 2966-2983, 3260-3277) are differences of the stored centres: of the
         // own cell at this plane (kept for the next step) and of the row above at the plane of the faces -- 24 unique bytes per cell
         // where dI / dJ / dK were 72
-        double xcN[3], xcB[3], sIA[3], sJA[3];
+        adf_real8 xcN[3], xcB[3], sIA[3], sJA[3];
         int flag0 = 0;
         auto face_loads = [&]() {
             vm_ld3(xcen, cA, nb8, xcN);
@@ -810,7 +817,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
         GfRaw a, bq;
         a.q.u = cur.au; a.q.v = cur.av; a.q.w = cur.aw; a.q.na = -(gam * cur.ap) * rcp_nr(cur.ar); a.q.rlv = cur.alv; a.q.rev = cur.aev; a.vol = cur.avol;
         bq.q.u = cur.bu; bq.q.v = cur.bv; bq.q.w = cur.bw; bq.q.na = -(gam * cur.bp) * rcp_nr(cur.br); bq.q.rlv = cur.blv; bq.q.rev = cur.bev; bq.vol = cur.bvol;
-        double aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3];
+        adf_real8 aI[3], aJm[3], aJ[3], aK[3], bI[3], bJ[3], bK[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             aI[d] = cur.aI[d]; aJm[d] = cur.aJm[d]; aJ[d] = cur.aJ[d]; aK[d] = cur.aK[d]; bI[d] = cur.bI[d]; bJ[d] = cur.bJ[d]; bK[d] = cur.bK[d];
@@ -818,10 +825,10 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
         // ---- metric sums of this plane (ng_finish for both rows; the row above takes sJ(j-1) from the own row)
         GfMet N;
         {
-            double tJa[3], tKa[3], tJb[3], tKb[3];
+            adf_real8 tJa[3], tKa[3], tJb[3], tKb[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const double tIa = lane_up1(aI[d]) + aI[d], tIb = lane_up1(bI[d]) + bI[d];
+                const adf_real8 tIa = lane_up1(aI[d]) + aI[d], tIb = lane_up1(bI[d]) + bI[d];
                 N.RIt[d] = tIa + tIb;
                 tJa[d] = aJm[d] + aJ[d]; tJb[d] = aJ[d] + bJ[d];
                 tKa[d] = sKA[d] + aK[d]; tKb[d] = sKB[d] + bK[d];
@@ -841,7 +848,8 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
             double g[12];
 #pragma unroll
             for (int q = 0; q < 12; ++q) g[q] = 0.0;
-            double SQ0[4], SQ1[4], NQ0[4], NQ1[4], ph[4], t3[3];
+            double SQ0[4], SQ1[4], NQ0[4], NQ1[4], ph[4];
+            adf_real8 t3[3];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 SQ0[v] = sA[v] + lane_dn1(sA[v]); SQ1[v] = sB[v] + lane_dn1(sB[v]);
@@ -868,7 +876,8 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
 #pragma unroll
             for (int v = 0; v < 4; ++v) ph[v] = (sA[v] + sB[v]) + (nA[v] + nB[v]);
             ng_outer<true>(g, ph, t3);                            // i direction: own column -, column i+1 +
-            double t1[3], ph1[4];
+            adf_real8 t1[3];
+            double ph1[4];
 #pragma unroll
             for (int d = 0; d < 3; ++d) t1[d] = lane_dn1(t3[d]);
 #pragma unroll
@@ -876,7 +885,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
             ng_outer<false>(g, ph1, t1);
             // a QUARTER of the gradient goes to the ring (the faces then average four nodes by adding); with the 0.25 of the surface
             // integral: 1 / (16 V).  Powers of two: the face gradients are bitwise what 0.25 (g0 + g1 + g2 + g3) gives
-            const double oneOverV = 0.0625 * rcp_nr(S.V + N.V);
+            const adf_real8 oneOverV = 0.0625 * rcp_nr(S.V + N.V);
 #pragma unroll
             for (int q = 0; q < 12; ++q) g[q] *= oneOverV;
             if (ringLane) {
@@ -910,7 +919,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
                     const double s0 = u.x + v.x, s1 = u.y + v.y;
                     gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                 }
-                const double dJv[3] = {xcB[0] - xcP[0], xcB[1] - xcP[1], xcB[2] - xcP[2]};
+                const adf_real8 dJv[3] = {xcB[0] - xcP[0], xcB[1] - xcP[1], xcB[2] - xcP[2]};
                 vm_face<QCR>(K, gs, qA, qB, sJA, dJv, flg_porJ((uint8_t)flag0), f);
 #pragma unroll
                 for (int l = 0; l < 4; ++l) acc[l] = -f[l];
@@ -931,7 +940,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
                         gs[q] = (u.x + v.x) + (w.x + z.x); gs[q + 1] = (u.y + v.y) + (w.y + z.y);
                     }
                     const VmCell qR = vm_dn1(qA);
-                    const double dIv[3] = {lane_dn1(xcP[0]) - xcP[0], lane_dn1(xcP[1]) - xcP[1], lane_dn1(xcP[2]) - xcP[2]};
+                    const adf_real8 dIv[3] = {lane_dn1(xcP[0]) - xcP[0], lane_dn1(xcP[1]) - xcP[1], lane_dn1(xcP[2]) - xcP[2]};
                     vm_face<QCR>(K, gs, qA, qR, sIA, dIv, flg_porI((uint8_t)flag0), f);
 #pragma unroll
                     for (int l = 0; l < 4; ++l) acc[l] += lane_up1(f[l]) - f[l];
@@ -945,7 +954,7 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
                         const double s0 = w.x + z.x, s1 = w.y + z.y;
                         gs[q] = s0 + lane_up1(s0); gs[q + 1] = s1 + lane_up1(s1);
                     }
-                    const double dKv[3] = {xcN[0] - xcP[0], xcN[1] - xcP[1], xcN[2] - xcP[2]};
+                    const adf_real8 dKv[3] = {xcN[0] - xcP[0], xcN[1] - xcP[1], xcN[2] - xcP[2]};
                     vm_face<QCR>(K, gs, qA, a.q, sKA, dKv, flg_porK((uint8_t)flag0), f);
 #pragma unroll
                     for (int l = 0; l < 4; ++l) { pend[l] = (acc[l] + fk[l]) - f[l]; fk[l] = f[l]; }
@@ -968,7 +977,6 @@ __global__ __launch_bounds__(64 * GF_NW, 2) void k_visc_gf(const BlkView* __rest
     if (r >= 1 && k1 >= k0) finish(cA - 2 * sk, fjx + ((k1 + 1) & 1) * FJ + ((r - 1) * GF_OUT + fl) * 4, flagP);
 }
 
-#endif
 // ---------------------------------------------------------------------------
 // viscousFluxApprox (fluxes.F90:3487-3859): thin-layer form for the preconditioner assembly.  The gradient on a
 // face is the difference of the two cell values along the centre-to-centre vector d (no nodal gradients):
@@ -1067,7 +1075,7 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
     hipLaunchKernelGGL(k_viscous, gc, blk, 0, s, b, kp);
 }
 
-#ifndef ADF_AD_BUILD      // (kernels_ad.hip compiles the gather kernels only)
+#ifndef ADF_AD_BUILD
 // marching face-flux kernel over the tile table of the level (tuning viscous_tiled >= 2)
 // viscousFluxApprox of every block of the level (thin-layer form, no nodal gradients)
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
@@ -1076,6 +1084,7 @@ void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles,
     if (kp.viscFirst) hipLaunchKernelGGL((k_visc_approx_march<true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
     else hipLaunchKernelGGL((k_visc_approx_march<false>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
 }
+#endif
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)
@@ -1093,6 +1102,7 @@ void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KPa
 #undef GF_LAUNCH
 }
 
+#ifndef ADF_AD_BUILD
 int g_sa_march = 1;         // tuning "sa_march": 0 = gather kernel (k_sa_residual), 1 = k-march (kernels_sa_march.hip)
 
 int viscous_is_tiled() { return g_viscous_tiled; }

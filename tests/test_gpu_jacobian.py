@@ -81,6 +81,33 @@ def test_ad_variants(engine):
     checks.check_ad_jacobian(engine, (9, 8, 6), rans.replace(limiter=vanAlbeda, useQCR=True), OPEN, usePC=False, stretch_k=2.0)
 
 
+@pytest.mark.parametrize("sd", [upwind, dissMatrix])
+def test_ad_exact_drdw_marches_against_gather_kernels(engine, sd):
+    """round 6: the exact linearisation on the MARCHING kernels compiled for dual numbers -- k_visc_gf (gradients + full viscous flux,
+    QCR) in front of k_roe_march (second order, van Albada / minmod), or behind the gather inviscid kernel of the other schemes -- against
+    the dual gather kernels it replaces (tuning pc_fused = 0; those are checked against the reference's Tapenade routines on small blocks
+    in test_ad_exact_drdw): a block of several tiles in i, partial tiles in j and k, several k chunks.  Both are exact derivatives:
+    they agree to rounding"""
+    import numpy as np
+    from adflow_amd.params import minmod
+    for lim, qcr, dims in ((vanAlbeda, False, (70, 10, 21)), (minmod, True, (63, 7, 9))):
+        rans = FlowParams(equations=RANSEquations, spaceDiscr=sd, limiter=lim, useQCR=qcr, vis4=0.1 if sd == dissMatrix else 0.0156)
+        checks.setup_block_with_bc(engine, dims, rans, WALL, 107, stretch_k=2.0)
+        try:
+            engine.set_tuning("pc_fused", 0)
+            engine.setupStateResidualMatrix(1, False, useAD=True)
+            Jg = engine.jacobianBlocks(1, 1).copy()
+        finally:
+            engine.set_tuning("pc_fused", 1)
+        engine.setupStateResidualMatrix(1, False, useAD=True)
+        Jm = engine.jacobianBlocks(1, 1)
+        scale = np.abs(Jg).max()
+        assert scale > 0.0
+        err = np.abs(Jm - Jg).max() / scale
+        assert err <= 2e-10, (lim, qcr, dims, err)
+        engine.releaseWorkspace()
+
+
 def test_ad_agrees_with_finite_differences(engine):
     """the two assemblies of the library against each other on a 24 x 16 x 12 RANS block (several workgroups per direction): the
     forward-mode blocks equal the finite-difference ones to the truncation error of the difference"""
