@@ -7,12 +7,10 @@
 // no CPU path and fails loudly without the HIP library) and is never timed.
 //
 // Model: one OS thread runs the blocks of a grid (OpenMP across blocks); the
-// threads of a block are ucontext fibers scheduled round-robin, so
+// threads of a block are fibers (hostsim.cpp) scheduled round-robin, so
 // __syncthreads() and the wave shuffles (which are modelled as block-convergent
 // exchanges) behave deterministically.
 #pragma once
-#include <ucontext.h>
-
 #include <cmath>
 #include <cstddef>
 #include <cstdint>

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdint>
+#include <cstdlib>
 
 thread_local uint3_ threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
@@ -21,15 +23,46 @@ namespace hostsim {
 
 namespace {
 constexpr size_t STACK = 256 * 1024;
+
+// Switch between fibers of one OS thread: callee-saved integer registers and the stack pointer only (x86-64 System V; the
+// kernels change neither the x87 control word nor MXCSR).  ucontext's swapcontext makes a signal-mask system call per
+// switch, which was most of the emulation's run time: a lane shift is two rendezvous of 64 fibers.
+#if !defined(__x86_64__)
+#error "the host emulation's fiber switch is written for x86-64"
+#endif
+struct Ctx { void* sp = nullptr; };
+extern "C" void hostsim_swap(Ctx* from, Ctx* to);
+asm(R"(
+    .text
+    .globl hostsim_swap
+    .type hostsim_swap,@function
+hostsim_swap:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hostsim_swap,.-hostsim_swap
+)");
+
 struct Fiber {
-    ucontext_t ctx;
-    char* stack = nullptr;
+    Ctx ctx;
     bool done = false;
     uint3_ tid;
 };
 struct BlockRun {
     std::vector<Fiber> fibers;
-    ucontext_t sched;
+    Ctx sched;
     int current = -1;
     const std::function<void()>* body = nullptr;
     std::vector<double> xchg;
@@ -43,18 +76,42 @@ struct BlockRun {
 };
 thread_local BlockRun* g_run = nullptr;
 
+// the stacks of a worker thread live as long as the thread: a launch reuses them
+struct StackPool {
+    std::vector<char*> s;
+    ~StackPool() { for (char* p : s) std::free(p); }
+    char* get(size_t i)
+    {
+        while (s.size() <= i) s.push_back((char*)std::malloc(STACK));
+        return s[i];
+    }
+};
+thread_local StackPool g_stacks;
+
 void fiber_entry()
 {
     BlockRun* r = g_run;
     (*r->body)();
     r->fibers[r->current].done = true;
-    swapcontext(&r->fibers[r->current].ctx, &r->sched);
+    hostsim_swap(&r->fibers[r->current].ctx, &r->sched);
+    __builtin_trap();   // a finished fiber is never resumed
+}
+
+void fiber_prepare(Fiber& f, char* stack)
+{
+    // as hostsim_swap leaves it: six saved registers, then the address it returns to; the entry sees the alignment of a call
+    uintptr_t top = ((uintptr_t)stack + STACK) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                 // the entry's (unused) return address
+    *--sp = (void*)&fiber_entry;
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    f.ctx.sp = sp;
 }
 
 void yield_to_sched()
 {
     BlockRun* r = g_run;
-    swapcontext(&r->fibers[r->current].ctx, &r->sched);
+    hostsim_swap(&r->fibers[r->current].ctx, &r->sched);
     threadIdx = r->fibers[r->current].tid;   // restored by the scheduler as well
 }
 }  // namespace
@@ -103,7 +160,6 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
         BlockRun run;
         run.fibers.resize(nthreads);
         run.xchg.resize(nthreads);
-        for (auto& f : run.fibers) f.stack = (char*)std::malloc(STACK);
         run.body = &body;
         g_run = &run;
 #pragma omp for schedule(dynamic)
@@ -119,11 +175,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
                 f.tid.x = t % block.x;
                 f.tid.y = (t / block.x) % block.y;
                 f.tid.z = t / (block.x * block.y);
-                getcontext(&f.ctx);
-                f.ctx.uc_stack.ss_sp = f.stack;
-                f.ctx.uc_stack.ss_size = STACK;
-                f.ctx.uc_link = nullptr;
-                makecontext(&f.ctx, fiber_entry, 0);
+                fiber_prepare(f, g_stacks.get((size_t)t));
             }
             const int nwaves = (nthreads + 63) / 64;
             run.alive = nthreads;
@@ -138,12 +190,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
                     if (f.done) continue;
                     run.current = t;
                     threadIdx = f.tid;
-                    swapcontext(&run.sched, &f.ctx);
+                    hostsim_swap(&run.sched, &f.ctx);
                     if (f.done) { run.alive--; run.wave_alive[t / 64]--; }
                 }
             }
         }
-        for (auto& f : run.fibers) std::free(f.stack);
         g_run = nullptr;
     }
 }
