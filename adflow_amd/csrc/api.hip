@@ -1706,6 +1706,16 @@ static KParams ad_kparams(int level, unsigned resFlags)
     return kp;
 }
 // closuresDone: the seed launch of the caller formed pressure and viscosities already (k_seed_closures)
+// the schemes the dual per-face march takes in the exact linearisation (as the plain evaluation chooses, api.hip residual_enqueue:
+// scalar JST only with the entropy sensor of NS / RANS on the fine level -- Euler + scalar JST has its own pipelined kernel, which has
+// no dual form)
+static bool ad_inviscid_march_takes(const KParams& kp)
+{
+    if (!inviscid_march_enabled() || kp.dissApprox || kp.lumpedDiss || kp.fwMode) return false;
+    if (kp.spaceDiscr == ADFLOW_DISS_SCALAR) return inviscid_march_enabled() >= 2 && kp.viscous && kp.fineGrid;
+    return kp.spaceDiscr == ADFLOW_DISS_MATRIX;       // (upwind: k_roe_march on dual numbers, or the gather kernel)
+}
+
 static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC, bool viscPC, bool closuresDone = false)
 {
     KParams kp = ad_kparams(level, resFlags);
@@ -1773,6 +1783,20 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
             }
             marched = ad_launch_roe_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, kr, g_stream);
             if (marched && gfDual) return 0;
+        }
+        if (!marched && g_pc_fused && ad_inviscid_march_takes(kp)) {
+            // scalar JST with the entropy sensor, matrix dissipation: the per-face march on dual numbers
+            // (kernels_inviscid_march.hip compiled a second time) -- four face evaluations per cell instead of the gather kernel's six;
+            // behind the viscous march it adds the sums it finds in dw(2:5), as in the plain evaluation
+            if (ensure_tiles(level)) return 1;
+            KParams ki = kp;
+            if (gfDual) {
+                ki.viscFirst = 1;
+                ad_launch_visc_gf(g_ad_tab, g_gf_tiles[level].first, g_gf_tiles[level].second, ki, g_stream);
+            }
+            ad_launch_inviscid_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, ki, g_stream);
+            if (gfDual) return 0;
+            marched = true;
         }
         if (!marched) ad_launch_inviscid_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);
         if (gfDual) {

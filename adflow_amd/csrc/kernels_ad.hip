@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void k_seed_closures(BlkView b, const adf_real
 #include "kernels_pc_march.hip"
 #include "kernels_sa_march.hip"
 #include "kernels_roe_march.hip"
+#include "kernels_inviscid_march.hip"
 
 #undef BlkView
 #undef double
@@ -254,5 +255,9 @@ void ad_launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const 
 bool ad_launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     return adj::launch_roe_march(ADV(tab), tiles, ntiles, kp, s);
+}
+void ad_launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    adj::launch_inviscid_march(ADV(tab), tiles, ntiles, kp, s);
 }
 #undef ADV

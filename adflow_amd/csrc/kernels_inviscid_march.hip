@@ -19,10 +19,19 @@
 //
 // Reference semantics: fluxes.F90:4-401 (central), :403-1047 (matrix), :1438-2532 (upwind), :5205-5430 (matrix,
 // coarse levels), residuals.F90:334-344 (final sum).  Roofline: FP64 VALU for upwind, HBM for matrix.
+//
+// The file compiles a second time for dual numbers (kernels_ad.hip, namespace adj: the exact linearisation of the adjoint with the
+// scalar / matrix dissipation): state, sensor, spectral radii and residual are `double` (dual
+// there), the face normals adf_real8 (plain in both builds).
 #include "flux_faces.h"
 
 #define IM_OUT 60          // must match EM_OUT / EM_BY of kernels_euler_march.hip: the tile table is shared
 #define IM_BY 4
+#ifdef ADF_AD_BUILD
+#define IM_MINWG 1         // dual numbers: twice the registers
+#else
+#define IM_MINWG 2
+#endif
 
 struct MCell { double rho, u, v, w, e, p, s; };     // s: sensor variable of the scalar JST scheme (entropy for NS / RANS)
 
@@ -106,7 +115,7 @@ __device__ __forceinline__ void im_face(const ImFace& F, const MCell& a, const M
 // fw are left for the viscous kernel to complete (residual_block, residuals.F90:334-344)
 // ADDV (without FW and FINAL): the viscous march ran first and left its flux sums in dw(2:5); they are added here, before iblank
 template <int SCHEME, bool FW, bool FINAL, bool ADDV = false>
-__global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
+__global__ __launch_bounds__(64 * IM_BY, IM_MINWG) void k_inviscid_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
                                                                   KParams kp, int kch)
 {
     const int4 t = tiles[blockIdx.x];
@@ -131,9 +140,9 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
     GPTR(const double) radI = (GPTR(const double))b.radI;
     GPTR(const double) radJ = (GPTR(const double))b.radJ;
     GPTR(const double) radK = (GPTR(const double))b.radK;
-    GPTR(const double) sIx = (GPTR(const double))b.sI; GPTR(const double) sIy = sIx + nb; GPTR(const double) sIz = sIy + nb;
-    GPTR(const double) sJx = (GPTR(const double))b.sJ; GPTR(const double) sJy = sJx + nb; GPTR(const double) sJz = sJy + nb;
-    GPTR(const double) sKx = (GPTR(const double))b.sK; GPTR(const double) sKy = sKx + nb; GPTR(const double) sKz = sKy + nb;
+    GPTR(const adf_real8) sIx = (GPTR(const adf_real8))b.sI; GPTR(const adf_real8) sIy = sIx + nb; GPTR(const adf_real8) sIz = sIy + nb;
+    GPTR(const adf_real8) sJx = (GPTR(const adf_real8))b.sJ; GPTR(const adf_real8) sJy = sJx + nb; GPTR(const adf_real8) sJz = sJy + nb;
+    GPTR(const adf_real8) sKx = (GPTR(const adf_real8))b.sK; GPTR(const adf_real8) sKy = sKx + nb; GPTR(const adf_real8) sKz = sKy + nb;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     GPTR(double) dw = (GPTR(double))b.dw;
     GPTR(double) fw = (GPTR(double))b.fw;
@@ -172,14 +181,14 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
         }
         // ---- everything else the step reads, requested HERE: the wave shares its SIMD with one other, and every request that stands
         //      in front of its own use is a latency nobody covers (round 4; the k and the i face below run on what has arrived)
-        const double nK[3] = {ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk)};
-        const double nI[3] = {ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u)};
+        const adf_real8 nK[3] = {ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk)};
+        const adf_real8 nI[3] = {ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u)};
         const double radI0 = SCAL ? ldg(radI, c) : 0.0;
         const MCell qa = im_ld<SCAL>(m, c - 2 * sj), qb = im_ld<SCAL>(m, c - sj), qc = im_ld<SCAL>(m, c + sj), qd = im_ld<SCAL>(m, c + 2 * sj);
         const int flagJm = flags[(c - sj) >> 3];
         const double radJ0 = SCAL ? ldg(radJ, c) : 0.0, radJm = SCAL ? ldg(radJ, c - sj) : 0.0, radJp = SCAL ? ldg(radJ, c + sj) : 0.0;
-        const double nJm[3] = {ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj)};
-        const double nJ[3] = {ldg(sJx, c), ldg(sJy, c), ldg(sJz, c)};
+        const adf_real8 nJm[3] = {ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj)};
+        const adf_real8 nJ[3] = {ldg(sJx, c), ldg(sJy, c), ldg(sJz, c)};
         __builtin_amdgcn_sched_barrier(0);
         // ---- k-face between cells k-1 and k (normal and porosity stored at cell k-1)
         double fc[5], fd[5];
@@ -265,7 +274,9 @@ __global__ __launch_bounds__(64 * IM_BY, 2) void k_inviscid_march(const BlkView*
     }
 }
 
+#ifndef ADF_AD_BUILD
 int g_inviscid_march = 2;      // tuning "inviscid_march": 0 = cell-gather kernel for matrix / upwind too, 1 = gather kernel for NS / RANS scalar JST only, 2 = marching form there as well (3.07 vs 3.33 ms per scalar-JST RANS evaluation, profiles/r02_as_ab_config3.txt)
+#endif
 
 template <int SCHEME>
 static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, int kch, hipStream_t s)
@@ -273,10 +284,15 @@ static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const K
     const dim3 blk(64, IM_BY, 1), grd(ntiles);
     const bool doDiss = fabs(kp.rFil) >= 1.e-10;
     const bool final_ = !(kp.viscous && doDiss);       // as launch_scheme of the gather kernel
+#ifndef ADF_AD_BUILD
     if (kp.fwMode) {
         if (final_) hipLaunchKernelGGL((k_inviscid_march<SCHEME, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else hipLaunchKernelGGL((k_inviscid_march<SCHEME, true, false>), grd, blk, 0, s, tab, tiles, kp, kch);
-    } else if (kp.viscFirst) {
+        return;
+    }
+#endif
+    // (the forward-mode passes have no persistent fw: block_res_state_d evaluates the whole residual)
+    if (kp.viscFirst) {
         hipLaunchKernelGGL((k_inviscid_march<SCHEME, false, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {
         if (final_) hipLaunchKernelGGL((k_inviscid_march<SCHEME, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
@@ -284,16 +300,24 @@ static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const K
     }
 }
 
+#ifndef ADF_AD_BUILD
 extern int g_march_kch;
+#endif
 
 // matrix dissipation / Roe upwind over the tile table of the level (the table of the Euler marching kernel)
 void launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;
-    if (kp.spaceDiscr == ADFLOW_DISS_MATRIX) launch_im<ADFLOW_DISS_MATRIX>(tab, tiles, ntiles, kp, g_march_kch, s);
-    else if (kp.spaceDiscr == ADFLOW_UPWIND) launch_im<ADFLOW_UPWIND>(tab, tiles, ntiles, kp, g_march_kch, s);
-    else launch_im<ADFLOW_DISS_SCALAR>(tab, tiles, ntiles, kp, g_march_kch, s);     // NS / RANS on the fine level only (caller)
+    if (kp.spaceDiscr == ADFLOW_DISS_MATRIX) launch_im<ADFLOW_DISS_MATRIX>(tab, tiles, ntiles, kp, ::g_march_kch, s);
+#ifndef ADF_AD_BUILD
+    else if (kp.spaceDiscr == ADFLOW_UPWIND) launch_im<ADFLOW_UPWIND>(tab, tiles, ntiles, kp, ::g_march_kch, s);
+#else
+    else if (kp.spaceDiscr == ADFLOW_UPWIND) return;      // (forward mode: the upwind scheme is k_roe_march's or the gather kernel's)
+#endif
+    else launch_im<ADFLOW_DISS_SCALAR>(tab, tiles, ntiles, kp, ::g_march_kch, s);     // NS / RANS on the fine level only (caller)
 }
 
+#ifndef ADF_AD_BUILD
 // the shared tile table has IM_BY rows per tile unless the Euler kernel was switched to 8 rows (tuning march_by)
 int inviscid_march_enabled() { return g_inviscid_march; }
+#endif

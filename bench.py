@@ -992,6 +992,20 @@ def main():
                                 "evaluation of 8 such blocks"}
                     log(f"exact dR/dw, forward mode, one block: {sdr * 1e3:.1f} ms ({sdr * 1e3 / nev:.2f} ms per evaluation)")
                     eng.releaseWorkspace()
+                    if "drdw_jst" in only:
+                        # the same with the central scheme + scalar JST dissipation (on request: --only-extras drdw_jst)
+                        eng.set_options(js.prm.replace(spaceDiscr=1))
+                        eng.setupStateResidualMatrix(1, usePC=False, useAD=True)
+                        barrier()
+                        t0 = time.perf_counter()
+                        eng.setupStateResidualMatrix(1, usePC=False, useAD=True)
+                        barrier()
+                        sdj = time.perf_counter() - t0
+                        extra["exact_drdw_forward_ad_jst_1x160x128x64"] = {"ms": sdj * 1e3, "forward_evaluations": nev,
+                                                                           "ms_per_evaluation": sdj * 1e3 / nev}
+                        log(f"exact dR/dw, forward mode, scalar JST, one block: {sdj * 1e3:.1f} ms")
+                        eng.releaseWorkspace()
+                        eng.set_options(js.prm)
                 except Exception as ex:
                     extra["error_exact_drdw"] = str(ex)
                     log("exact dR/dw extra failed: " + str(ex))

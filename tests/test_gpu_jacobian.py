@@ -81,10 +81,10 @@ def test_ad_variants(engine):
     checks.check_ad_jacobian(engine, (9, 8, 6), rans.replace(limiter=vanAlbeda, useQCR=True), OPEN, usePC=False, stretch_k=2.0)
 
 
-@pytest.mark.parametrize("sd", [upwind, dissMatrix])
+@pytest.mark.parametrize("sd", [upwind, dissMatrix, dissScalar])
 def test_ad_exact_drdw_marches_against_gather_kernels(engine, sd):
     """round 6: the exact linearisation on the MARCHING kernels compiled for dual numbers -- k_visc_gf (gradients + full viscous flux,
-    QCR) in front of k_roe_march (second order, van Albada / minmod), or behind the gather inviscid kernel of the other schemes -- against
+    QCR) in front of k_roe_march (second order, van Albada / minmod) or of k_inviscid_march (matrix dissipation, scalar JST) -- against
     the dual gather kernels it replaces (tuning pc_fused = 0; those are checked against the reference's Tapenade routines on small blocks
     in test_ad_exact_drdw): a block of several tiles in i, partial tiles in j and k, several k chunks.  Both are exact derivatives:
     they agree to rounding"""

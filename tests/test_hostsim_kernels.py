@@ -545,6 +545,8 @@ def test_ad_jacobian(hostsim_engine):
     checks.check_ad_jacobian(e, (7, 5, 4), rm, tj.WALL, useTurbOnly=True, stretch_k=2.0)
     checks.check_ad_jacobian(e, (6, 5, 4), rm.replace(spaceDiscr=dissScalar), tj.WALL, viscPC=True, stretch_k=2.0)
     checks.check_ad_jacobian(e, (7, 6, 5), rm.replace(limiter=vanAlbeda, useQCR=True), tj.OPEN, usePC=False, stretch_k=2.0)
+    # matrix dissipation of the exact linearisation: k_inviscid_march on dual numbers behind the dual k_visc_gf (round 6)
+    checks.check_ad_jacobian(e, (6, 5, 4), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, vis4=0.1), tj.WALL, usePC=False, stretch_k=2.0)
 
 
 def test_pc_assemblies_on_a_level_of_several_blocks(hostsim_engine):
