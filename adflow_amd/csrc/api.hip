@@ -1101,20 +1101,23 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
     // viscous march first, inviscid march last: the inviscid kernel (Roe: bound by FP64 issue) adds the viscous sums it finds in
     // dw(2:5) instead of the viscous kernel reading dw back.  Any inviscid kernel over the tile table can take that role (Roe,
     // matrix dissipation, scalar JST of NS / RANS); not with the persistent fw of the Runge-Kutta stages.
-    const bool scalarViscM = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
-    const bool tileInviscid = inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarViscM) &&
-                              (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving;
+    // (scalar JST: the marching form reads its sensor from b.ss -- the entropy sensor of NS / RANS, or the frozen sensor of the
+    //  approximate residual, which Euler has too)
+    const bool scalarViscM = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && (kp.viscous || kp.dissApprox) &&
+                              kp.fineGrid);
+    // the approximate residual of the preconditioner matrix: the lumped scalar / matrix dissipation has a marching form on the fine
+    // level (k_inviscid_march<.., APX>, round 6); the upwind scheme changes through its limiter only
+    const bool approxOk = !kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND || (kp.fineGrid && g_pc_fused);
+    const bool tileInviscid = inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarViscM) && approxOk && !anyMoving;
     const bool viscFirst = viscMarch && !kp.fwMode && tileInviscid && !kp.dissApprox && !kp.lumpedDiss;
     // the same order for the thin-layer viscous march of the preconditioner assembly (no gradients)
     const bool approxFirst = viscApprox && viscous_is_tiled() >= 2 && kp.viscous && fabs(kp.rFil) >= 1.e-10 && !kp.fwMode &&
                              tileInviscid;
     // scalar JST with the entropy sensor (NS / RANS, fine level) also has a marching form, but it is bound by memory like
     // the gather form (1.06 vs 1.10 ms on 8 x 128x128x96): only with tuning inviscid_march = 2
-    const bool scalarVisc = (inviscid_march_enabled() >= 2 && kp.spaceDiscr == ADFLOW_DISS_SCALAR && kp.viscous && kp.fineGrid);
     if (viscFirst || approxFirst) {
         // enqueued behind the viscous march below
-    } else if (inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarVisc) &&
-               (!kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND) && !anyMoving) {
+    } else if (tileInviscid) {
         // (the approximate residual changes the Roe scheme only through the limiter: inviscidUpwindFlux is called either way)
         // matrix dissipation / Roe upwind: k-marching kernel over the level's tile table (every face once in k and i)
         if (ensure_tiles(level)) return 1;
@@ -1711,8 +1714,9 @@ static KParams ad_kparams(int level, unsigned resFlags)
 // no dual form)
 static bool ad_inviscid_march_takes(const KParams& kp)
 {
-    if (!inviscid_march_enabled() || kp.dissApprox || kp.lumpedDiss || kp.fwMode) return false;
-    if (kp.spaceDiscr == ADFLOW_DISS_SCALAR) return inviscid_march_enabled() >= 2 && kp.viscous && kp.fineGrid;
+    if (!inviscid_march_enabled() || kp.fwMode) return false;
+    if (kp.dissApprox && !kp.fineGrid) return false;
+    if (kp.spaceDiscr == ADFLOW_DISS_SCALAR) return inviscid_march_enabled() >= 2 && (kp.viscous || kp.dissApprox) && kp.fineGrid;
     return kp.spaceDiscr == ADFLOW_DISS_MATRIX;       // (upwind: k_roe_march on dual numbers, or the gather kernel)
 }
 
@@ -1790,12 +1794,28 @@ static int ad_block_res_state_enqueue(int level, unsigned resFlags, bool turbBC,
             // behind the viscous march it adds the sums it finds in dw(2:5), as in the plain evaluation
             if (ensure_tiles(level)) return 1;
             KParams ki = kp;
+            // the thin-layer viscous flux of the preconditioner matrix marches in front of it as well (k_visc_approx_march on dual
+            // numbers), as in the plain approximate residual
+            const bool vaDual = viscous && viscApprox && viscous_is_tiled() >= 2 && kp.fineGrid;
+            if (vaDual) {
+                rc = for_level(level, [&](Block* b) {
+                    if (!b->face_vectors_valid) {
+                        launch_face_vectors(b->v, g_stream);
+                        b->face_vectors_valid = true;
+                    }
+                    return 0;
+                });
+                if (rc) return rc;
+            }
             if (gfDual) {
                 ki.viscFirst = 1;
                 ad_launch_visc_gf(g_ad_tab, g_gf_tiles[level].first, g_gf_tiles[level].second, ki, g_stream);
+            } else if (vaDual) {
+                ki.viscFirst = 1;
+                ad_launch_visc_march_approx(g_ad_tab, g_tiles[level].first, g_tiles[level].second, ki, g_stream);
             }
             ad_launch_inviscid_march(g_ad_tab, g_tiles[level].first, g_tiles[level].second, ki, g_stream);
-            if (gfDual) return 0;
+            if (gfDual || vaDual) return 0;
             marched = true;
         }
         if (!marched) ad_launch_inviscid_level(g_ad_tab, t.n, t.nx, t.ny, t.nz, kp, g_stream);

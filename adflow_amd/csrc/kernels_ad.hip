@@ -256,6 +256,10 @@ bool ad_launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, cons
 {
     return adj::launch_roe_march(ADV(tab), tiles, ntiles, kp, s);
 }
+void ad_launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
+{
+    adj::launch_visc_march_approx(ADV(tab), tiles, ntiles, kp, s);
+}
 void ad_launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     adj::launch_inviscid_march(ADV(tab), tiles, ntiles, kp, s);

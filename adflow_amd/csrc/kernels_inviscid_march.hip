@@ -82,11 +82,13 @@ struct ImFace {          // scalars of the dissipation shared by all faces of a 
     double fis2, fis4, plim, gam;
     int lim, coarse, doDiss;
     double kappaCoef, rFil, gammaConstant;
+    double sigma;        // APX: weight of the fourth-difference coefficient lumped onto the first difference
 };
 
 // fluxes through the face between b and c (stencil a b | c d) with normal (sx,sy,sz): central fc (dw(b) += fc,
 // dw(c) -= fc) and dissipation fd in the convention fw(c) += fd, fw(b) -= fd.  dssB / dssC: matrix sensors of b and c.
-template <int SCHEME>
+// APX: the lumped dissipation of the preconditioner matrix (inviscidDissFluxScalarApprox / MatrixApprox, fluxes.F90:3861-4967)
+template <int SCHEME, bool APX = false>
 __device__ __forceinline__ void im_face(const ImFace& F, const MCell& a, const MCell& b, const MCell& c, const MCell& d, double sx,
                                         double sy, double sz, int por, double dssB, double dssC, double fc[5], double fd[5],
                                         double radSum = 0.0)
@@ -101,10 +103,10 @@ __device__ __forceinline__ void im_face(const ImFace& F, const MCell& a, const M
     if (SCHEME == ADFLOW_DISS_SCALAR) {
         // scalar JST on the fine level: radSum = spectral radii of b and c in the direction of the face (fluxes.F90:1204-1272)
         const double rrad = (por == ADF_POR_NORMAL ? 0.5 : 0.0) * radSum;
-        jst_scalar_face(L, 1, rrad, dssB, dssC, F.fis2, F.fis4, +1.0, fd);
+        jst_scalar_face(L, 1, rrad, dssB, dssC, F.fis2, F.fis4, +1.0, fd, APX, F.sigma);
     } else if (SCHEME == ADFLOW_DISS_MATRIX) {
         if (F.coarse) jst_matrix_face(L, gam, 1, sx, sy, sz, por, 0.0, 0.0, F.fis2, 0.0, +1.0, fd, true);
-        else jst_matrix_face(L, gam, 1, sx, sy, sz, por, dssB, dssC, F.fis2, F.fis4, +1.0, fd);
+        else jst_matrix_face(L, gam, 1, sx, sy, sz, por, dssB, dssC, F.fis2, F.fis4, +1.0, fd, false, APX, F.sigma);
     } else {
         // roe_face: fw(left) += flux, fw(right) -= flux with flux = -porFlux |A| dW; sign -1 gives the (right += ) form
         roe_face(L, gam, 1, sx, sy, sz, por, F.lim, F.kappaCoef, F.rFil, F.gammaConstant, -1.0, fd);
@@ -114,7 +116,10 @@ __device__ __forceinline__ void im_face(const ImFace& F, const MCell& a, const M
 // FW: persistent dissipation residual of the Runge-Kutta scheme; FINAL: dw = (dw + fw) iblank written here, otherwise dw and
 // fw are left for the viscous kernel to complete (residual_block, residuals.F90:334-344)
 // ADDV (without FW and FINAL): the viscous march ran first and left its flux sums in dw(2:5); they are added here, before iblank
-template <int SCHEME, bool FW, bool FINAL, bool ADDV = false>
+// APX (scalar / matrix, fine level, without FW): the approximate residual of the preconditioner matrix -- the sensor of both schemes
+// from the FROZEN values of referenceShockSensor in b.ss (entropy or pressure for the scalar scheme, pressure for the matrix scheme),
+// the fourth-difference coefficient lumped onto the first difference
+template <int SCHEME, bool FW, bool FINAL, bool ADDV = false, bool APX = false>
 __global__ __launch_bounds__(64 * IM_BY, IM_MINWG) void k_inviscid_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
                                                                   KParams kp, int kch)
 {
@@ -137,6 +142,7 @@ __global__ __launch_bounds__(64 * IM_BY, IM_MINWG) void k_inviscid_march(const B
     m.p = (GPTR(const double))b.p;
     m.ss = (GPTR(const double))b.ss;
     constexpr bool SCAL = (SCHEME == ADFLOW_DISS_SCALAR);       // NS / RANS, fine level: entropy sensor from b.ss, radii from the time step
+    constexpr bool LDS_ = SCAL || APX;                           // the cells carry a sensor value from b.ss
     GPTR(const double) radI = (GPTR(const double))b.radI;
     GPTR(const double) radJ = (GPTR(const double))b.radJ;
     GPTR(const double) radK = (GPTR(const double))b.radK;
@@ -153,24 +159,27 @@ __global__ __launch_bounds__(64 * IM_BY, IM_MINWG) void k_inviscid_march(const B
     F.coarse = !kp.fineGrid;
     F.fis2 = F.coarse ? kp.rFil * kp.vis2Coarse : kp.rFil * kp.vis2;     // coarse: dis0 of inviscidDissFluxMatrixCoarse
     F.fis4 = kp.rFil * kp.vis4;
-    F.plim = SCAL ? 0.001 * kp.pInfCorr / pow(kp.rhoInf, kp.gammaInf) : 0.001 * kp.pInfCorr;   // sslim of the entropy sensor / plim
+    // sslim of the entropy sensor (scalar JST of NS / RANS) / plim of the pressure sensor (matrix; scalar JST of Euler, APX only)
+    F.plim = (SCAL && kp.viscous) ? 0.001 * kp.pInfCorr / pow(kp.rhoInf, kp.gammaInf) : 0.001 * kp.pInfCorr;
+    F.sigma = kp.sigma;
     F.gam = kp.gammaConstant;
     F.lim = (kp.fineGrid && !kp.lumpedDiss) ? kp.limiter : ADFLOW_LIM_FIRST_ORDER;           // fluxes.F90:1531-1538
     F.kappaCoef = kp.kappaCoef; F.rFil = kp.rFil; F.gammaConstant = kp.gammaConstant;
     const bool sens = (SCHEME != ADFLOW_UPWIND) && F.doDiss && !F.coarse;
     auto sensor = [&](const MCell& a, const MCell& q, const MCell& d) {
-        return SCAL ? jst_sensor(a.s, q.s, d.s, F.plim) : mat_sensor(a.p, q.p, d.p, F.plim);
+        if (SCAL) return jst_sensor(a.s, q.s, d.s, F.plim);
+        return APX ? mat_sensor(a.s, q.s, d.s, F.plim) : mat_sensor(a.p, q.p, d.p, F.plim);
     };
 
     // window k-2 .. k+1 of the own column
-    MCell qm2 = im_ld<SCAL>(m, c - 2 * sk), qm1 = im_ld<SCAL>(m, c - sk), q0 = im_ld<SCAL>(m, c);
+    MCell qm2 = im_ld<LDS_>(m, c - 2 * sk), qm1 = im_ld<LDS_>(m, c - sk), q0 = im_ld<LDS_>(m, c);
     int flagm = flags[(c - sk) >> 3];
     double dssKm = sens ? sensor(qm2, qm1, q0) : 0.0;
     double radKm = SCAL ? ldg(radK, c - sk) : 0.0;
     double accC[5] = {0, 0, 0, 0, 0}, accD[5] = {0, 0, 0, 0, 0};
 
     for (int k = k0; k <= k1 + 1; ++k) {
-        const MCell qp1 = im_ld<SCAL>(m, c + sk);
+        const MCell qp1 = im_ld<LDS_>(m, c + sk);
         const int flag0 = flags[c >> 3];
         const double dssK0 = sens ? sensor(qm1, q0, qp1) : 0.0;
         const double radK0 = SCAL ? ldg(radK, c) : 0.0;
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(64 * IM_BY, IM_MINWG) void k_inviscid_march(const B
         const adf_real8 nK[3] = {ldg(sKx, c - sk), ldg(sKy, c - sk), ldg(sKz, c - sk)};
         const adf_real8 nI[3] = {ldg(sIx, c - 8u), ldg(sIy, c - 8u), ldg(sIz, c - 8u)};
         const double radI0 = SCAL ? ldg(radI, c) : 0.0;
-        const MCell qa = im_ld<SCAL>(m, c - 2 * sj), qb = im_ld<SCAL>(m, c - sj), qc = im_ld<SCAL>(m, c + sj), qd = im_ld<SCAL>(m, c + 2 * sj);
+        const MCell qa = im_ld<LDS_>(m, c - 2 * sj), qb = im_ld<LDS_>(m, c - sj), qc = im_ld<LDS_>(m, c + sj), qd = im_ld<LDS_>(m, c + 2 * sj);
         const int flagJm = flags[(c - sj) >> 3];
         const double radJ0 = SCAL ? ldg(radJ, c) : 0.0, radJm = SCAL ? ldg(radJ, c - sj) : 0.0, radJp = SCAL ? ldg(radJ, c + sj) : 0.0;
         const adf_real8 nJm[3] = {ldg(sJx, c - sj), ldg(sJy, c - sj), ldg(sJz, c - sj)};
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(64 * IM_BY, IM_MINWG) void k_inviscid_march(const B
         __builtin_amdgcn_sched_barrier(0);
         // ---- k-face between cells k-1 and k (normal and porosity stored at cell k-1)
         double fc[5], fd[5];
-        im_face<SCHEME>(F, qm2, qm1, q0, qp1, nK[0], nK[1], nK[2], flg_porK((uint8_t)flagm), dssKm, dssK0, fc, fd, radKm + radK0);
+        im_face<SCHEME, APX>(F, qm2, qm1, q0, qp1, nK[0], nK[1], nK[2], flg_porK((uint8_t)flagm), dssKm, dssK0, fc, fd, radKm + radK0);
         // ---- finish cell k-1 and write it
         if (k > k0 && out) {
             const unsigned cw = c - sk;
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(64 * IM_BY, IM_MINWG) void k_inviscid_march(const B
             double radSum = 0.0;
             if (SCAL) radSum = lane_up1(radI0) + radI0;
             double gc[5], gd[5];
-            im_face<SCHEME>(F, qLL, qL, q0, qR, nI[0], nI[1], nI[2], por, dL, d0, gc, gd, radSum);
+            im_face<SCHEME, APX>(F, qLL, qL, q0, qR, nI[0], nI[1], nI[2], por, dL, d0, gc, gd, radSum);
 #pragma unroll
             for (int l = 0; l < 5; ++l) {
                 accC[l] += lane_dn1(gc[l]) - gc[l];     // + plus face, - minus face
@@ -258,10 +267,10 @@ __global__ __launch_bounds__(64 * IM_BY, IM_MINWG) void k_inviscid_march(const B
                 rP = radJ0 + radJp;
             }
             double hc[5], hd[5];
-            im_face<SCHEME>(F, qa, qb, q0, qc, nJm[0], nJm[1], nJm[2], porM, dm, d0, hc, hd, rM);
+            im_face<SCHEME, APX>(F, qa, qb, q0, qc, nJm[0], nJm[1], nJm[2], porM, dm, d0, hc, hd, rM);
 #pragma unroll
             for (int l = 0; l < 5; ++l) { accC[l] -= hc[l]; accD[l] += hd[l]; }
-            im_face<SCHEME>(F, qb, q0, qc, qd, nJ[0], nJ[1], nJ[2], porP, d0, dp, hc, hd, rP);
+            im_face<SCHEME, APX>(F, qb, q0, qc, qd, nJ[0], nJ[1], nJ[2], porP, d0, dp, hc, hd, rP);
 #pragma unroll
             for (int l = 0; l < 5; ++l) { accC[l] += hc[l]; accD[l] -= hd[l]; }
         }
@@ -292,6 +301,14 @@ static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const K
     }
 #endif
     // (the forward-mode passes have no persistent fw: block_res_state_d evaluates the whole residual)
+    if (kp.dissApprox) {
+        if (SCHEME == ADFLOW_UPWIND) return;        // (the approximate upwind residual is the first-order limiter: the caller's business)
+        constexpr int S2 = (SCHEME == ADFLOW_UPWIND) ? ADFLOW_DISS_SCALAR : SCHEME;
+        if (kp.viscFirst) hipLaunchKernelGGL((k_inviscid_march<S2, false, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        else if (final_) hipLaunchKernelGGL((k_inviscid_march<S2, false, true, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        else hipLaunchKernelGGL((k_inviscid_march<S2, false, false, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
+        return;
+    }
     if (kp.viscFirst) {
         hipLaunchKernelGGL((k_inviscid_march<SCHEME, false, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);
     } else {

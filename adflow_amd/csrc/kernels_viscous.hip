@@ -13,7 +13,9 @@
 // Roofline: HBM (255 B/cell RANS); no MFMA.
 #include "sa_core.h"
 
+#ifndef ADF_AD_BUILD
 extern int g_march_kch;
+#endif
 
 #define VS_BX 64
 #define VS_BY 4
@@ -512,7 +514,13 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gr[12], const
     f[3] = frhoE - q_x * nx - q_y * ny - q_z * nz;
 }
 
-#ifndef ADF_AD_BUILD
+#ifdef ADF_AD_BUILD
+#define VMA_MINWG 1
+#else
+#define VMA_MINWG 2
+#endif
+// (compiles for dual numbers too -- the preconditioner matrix of the scalar / matrix schemes by forward mode: state, LDS rows and
+//  fluxes dual, normals and centre-to-centre vectors plain)
 // viscousFluxApprox (fluxes.F90:3487-3859), the thin-layer form of the preconditioner assembly, as a k-march over the level's tile
 // table: the face gradient is the difference of the two cell values along the centre-to-centre vector, i.e. vm_face with the nodal
 // gradients set to zero -- no gradients, no LDS ring.  k faces carried, i faces once (DPP hand-over of the flux), both j faces per
@@ -520,7 +528,7 @@ __device__ __forceinline__ void vm_face(const VmK& K, const double gr[12], const
 // FIRST: the kernel runs before the inviscid march: its flux sums are stored to dw(2:5) as they are, the inviscid march (ADDV) adds
 // them to its own sums and applies iblank
 template <bool FIRST>
-__global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
+__global__ __launch_bounds__(64 * VM_BY, VMA_MINWG) void k_visc_approx_march(const BlkView* __restrict__ tab, const int4* __restrict__ tiles,
                                                                      KParams kp, int kch)
 {
     __shared__ double qx[VM_BY * 6 * 64];               // state of the own cell of every row, for the rows above and below
@@ -540,17 +548,17 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
     VmPtrs m;
     m.w0 = (GPTR(const double))b.w; m.w1 = m.w0 + nb; m.w2 = m.w1 + nb; m.w3 = m.w2 + nb;
     m.p = (GPTR(const double))b.p; m.rlv = (GPTR(const double))b.rlv; m.rev = (GPTR(const double))b.rev;
-    GPTR(const double) sI = (GPTR(const double))b.sI; GPTR(const double) sJ = (GPTR(const double))b.sJ;
-    GPTR(const double) sK = (GPTR(const double))b.sK;
-    GPTR(const double) dI = (GPTR(const double))b.dI; GPTR(const double) dJ = (GPTR(const double))b.dJ;
-    GPTR(const double) dK = (GPTR(const double))b.dK;
+    GPTR(const adf_real8) sI = (GPTR(const adf_real8))b.sI; GPTR(const adf_real8) sJ = (GPTR(const adf_real8))b.sJ;
+    GPTR(const adf_real8) sK = (GPTR(const adf_real8))b.sK;
+    GPTR(const adf_real8) dI = (GPTR(const adf_real8))b.dI; GPTR(const adf_real8) dJ = (GPTR(const adf_real8))b.dJ;
+    GPTR(const adf_real8) dK = (GPTR(const adf_real8))b.dK;
     GPTR(const uint8_t) flags = (GPTR(const uint8_t))b.flags;
     GPTR(double) dw = (GPTR(double))b.dw;
     GPTR(double) fw = (GPTR(double))b.fw;
     VmK K;
     K.porV = 0.5 * kp.rFil; K.eddy = kp.eddyModel != 0;
     K.hl = 1.0 / (kp.prandtl * (kp.gammaConstant - 1.0)); K.ht = 1.0 / (kp.prandtlTurb * (kp.gammaConstant - 1.0));
-    const double gam = kp.gammaConstant;
+    const adf_real8 gam = kp.gammaConstant;
     double gs[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) gs[q] = 0.0;
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
     double fk[4];
     {
         // k face below the first plane of the march
-        double nK[3], dKv[3];
+        adf_real8 nK[3], dKv[3];
         vm_ld3(sK, c - sk, nb8, nK); vm_ld3(dK, c - sk, nb8, dKv);
         vm_face<false>(K, gs, qm1, q0, nK, dKv, flg_porK(flags[(c - sk) >> 3]), fk);
     }
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
         };
         // ---- j face (j-1 | j)
         {
-            double nJ[3], dJv[3], f[4];
+            adf_real8 nJ[3], dJv[3]; double f[4];
             const VmCell qjm = (row > 0) ? row_state(row - 1) : vm_ld(m, c - sj, gam, K.eddy);
             vm_ld3(sJ, c - sj, nb8, nJ); vm_ld3(dJ, c - sj, nb8, dJv);
             vm_face<false>(K, gs, qjm, q0, nJ, dJv, flg_porJ(flags[(c - sj) >> 3]), f);
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
         }
         // ---- i face (i | i+1); the face (i-1 | i) comes from lane-1
         {
-            double nI[3], dIv[3], f[4];
+            adf_real8 nI[3], dIv[3]; double f[4];
             vm_ld3(sI, c, nb8, nI); vm_ld3(dI, c, nb8, dIv);
             const VmCell qR = vm_dn1(q0);
             vm_face<false>(K, gs, q0, qR, nI, dIv, flg_porI((uint8_t)flag0), f);
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
         }
         // ---- j face (j | j+1)
         {
-            double nJ[3], dJv[3], f[4];
+            adf_real8 nJ[3], dJv[3]; double f[4];
             const VmCell qjp = (row < VM_BY - 1) ? row_state(row + 1) : vm_ld(m, c + sj, gam, K.eddy);
             vm_ld3(sJ, c, nb8, nJ); vm_ld3(dJ, c, nb8, dJv);
             vm_face<false>(K, gs, q0, qjp, nJ, dJv, flg_porJ((uint8_t)flag0), f);
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
         }
         // ---- k face above the cell
         {
-            double nK[3], dKv[3], f[4];
+            adf_real8 nK[3], dKv[3]; double f[4];
             vm_ld3(sK, c, nb8, nK); vm_ld3(dK, c, nb8, dKv);
             vm_face<false>(K, gs, q0, qp1, nK, dKv, flg_porK((uint8_t)flag0), f);
 #pragma unroll
@@ -635,7 +643,6 @@ __global__ __launch_bounds__(64 * VM_BY, 2) void k_visc_approx_march(const BlkVi
     }
 }
 
-#endif
 // ---------------------------------------------------------------------------
 // FUSED nodal gradients + viscous fluxes, two workgroups per CU (tuning "viscous_tiled" = 2, the default).  The pair of round 2,
 // k_node_grad_march and k_visc_march, exchanged the 12 nodal gradients through HBM (103 B per cell written, 125 B read back) and
@@ -1075,16 +1082,14 @@ void launch_viscous(const BlkView& b, const KParams& kp, hipStream_t s)
     hipLaunchKernelGGL(k_viscous, gc, blk, 0, s, b, kp);
 }
 
-#ifndef ADF_AD_BUILD
 // marching face-flux kernel over the tile table of the level (tuning viscous_tiled >= 2)
 // viscousFluxApprox of every block of the level (thin-layer form, no nodal gradients)
 void launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s)
 {
     if (ntiles <= 0) return;
-    if (kp.viscFirst) hipLaunchKernelGGL((k_visc_approx_march<true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
-    else hipLaunchKernelGGL((k_visc_approx_march<false>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, g_march_kch);
+    if (kp.viscFirst) hipLaunchKernelGGL((k_visc_approx_march<true>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, ::g_march_kch);
+    else hipLaunchKernelGGL((k_visc_approx_march<false>), dim3(ntiles), dim3(64, VM_BY, 1), 0, s, tab, tiles, kp, ::g_march_kch);
 }
-#endif
 
 // fused nodal gradients + viscous fluxes over the level's round-fitted chunk table (api.hip ensure_gf_tiles)
 void launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, bool storeGrad, hipStream_t s)

@@ -535,7 +535,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported under 'extra' (N=1)")
     ap.add_argument("--force-extras", action="store_true", help="run the extras although --tuning is given (A/B runs of a tuning key)")
     ap.add_argument("--no-mg", action="store_true", help="skip the config-2 multigrid cycle measurement")
-    ap.add_argument("--only-extras", default="", help="comma list out of 4b,matvec,pc,config3,periodic,config2,config1,shard,drdw,small (drdw8 on request only): time only these extras (kernel traces)")
+    ap.add_argument("--only-extras", default="", help="comma list out of 4b,matvec,pc,config3,periodic,config2,config1,shard,drdw,small (drdw8, drdw_jst, pc_jst on request only): time only these extras (kernel traces)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K steps until the region lasts this long")
     ap.add_argument("--tuning", action="append", default=[], help="key=value knobs of adflow_gpu_set_tuning")
     ap.add_argument("--separate-halo", action="store_true",
@@ -745,6 +745,22 @@ def main():
                             "level's arrays (640 B per box cell, one slab kept between calls) are refreshed from the library's arrays "
                             "inside the call"}
                 log(f"PC matrix assembly, forward AD: {sad * 1e3:.1f} ms")
+            if "pc_jst" in only:
+                # (only on request) the same two assemblies with the central scheme + scalar JST: lumped scalar dissipation with the
+                # frozen sensor (inviscidDissFluxScalarApprox, fluxes.F90:3861-4342) + thin-layer viscous flux
+                eng.set_options(prm.replace(spaceDiscr=1))
+                res_j = {}
+                for label, ad in (("finite_differences", False), ("forward_ad", True)):
+                    eng.setupStateResidualMatrix(1, usePC=True, useAD=ad)
+                    barrier()
+                    t0 = time.perf_counter()
+                    eng.setupStateResidualMatrix(1, usePC=True, useAD=ad)
+                    barrier()
+                    res_j[label + "_ms"] = (time.perf_counter() - t0) * 1e3
+                eng.releaseWorkspace()
+                eng.set_options(prm)
+                extra["pc_matrix_assembly_scalar_jst"] = res_j
+                log("PC matrix assembly, scalar JST: " + ", ".join(f"{k} {v:.1f}" for k, v in res_j.items()))
             if "drdw8" in only:
                 # (only on request: 112 GB of stencil blocks) the exact dR/dw of the adjoint by forward mode on the whole 8-block mesh
                 eng.setupStateResidualMatrix(1, usePC=False, useAD=True)

@@ -545,6 +545,11 @@ def test_ad_jacobian(hostsim_engine):
     checks.check_ad_jacobian(e, (7, 5, 4), rm, tj.WALL, useTurbOnly=True, stretch_k=2.0)
     checks.check_ad_jacobian(e, (6, 5, 4), rm.replace(spaceDiscr=dissScalar), tj.WALL, viscPC=True, stretch_k=2.0)
     checks.check_ad_jacobian(e, (7, 6, 5), rm.replace(limiter=vanAlbeda, useQCR=True), tj.OPEN, usePC=False, stretch_k=2.0)
+    # the preconditioner matrix of the scalar / matrix schemes by forward mode: the lumped dissipation with the frozen sensor
+    # (k_inviscid_march<.., APX>) behind the thin-layer viscous march, both on dual numbers (round 6)
+    checks.check_ad_jacobian(e, (6, 5, 4), rans.replace(spaceDiscr=dissScalar), tj.WALL, stretch_k=2.0)
+    checks.check_ad_jacobian(e, (6, 5, 4), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, vis4=0.1), tj.WALL, stretch_k=2.0)
+    checks.check_ad_jacobian(e, (6, 5, 4), FlowParams(spaceDiscr=dissScalar), tj.EULER)
     # matrix dissipation of the exact linearisation: k_inviscid_march on dual numbers behind the dual k_visc_gf (round 6)
     checks.check_ad_jacobian(e, (6, 5, 4), FlowParams(equations=NSEquations, spaceDiscr=dissMatrix, vis4=0.1), tj.WALL, usePC=False, stretch_k=2.0)
 
