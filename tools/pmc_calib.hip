@@ -265,17 +265,22 @@ int main(int argc, char** argv)
             CK(hipMemset(s, 0, n2 * 16));
             const int reps = ws == 0 ? 10 : 200;
             for (int which = 0; which < 2; ++which) {
-                for (int it = -2; it < reps; ++it) {
-                    if (it == 0) CK(hipEventRecord(e0, 0));
-                    if (which == 0) hipLaunchKernelGGL(copy16u<8>, dim3((unsigned)(n2 / (8 * 256))), dim3(256), 0, 0, d, s);
-                    else hipLaunchKernelGGL(read16u<8>, dim3((unsigned)(n2 / (8 * 256))), dim3(256), 0, 0, s, o);
+                // best of three rounds: the first timed round of a fresh process has been seen at a third of the rate (r06_fin3)
+                float best = 1e30f;
+                for (int rnd = 0; rnd < 3; ++rnd) {
+                    for (int it = -2; it < reps; ++it) {
+                        if (it == 0) CK(hipEventRecord(e0, 0));
+                        if (which == 0) hipLaunchKernelGGL(copy16u<8>, dim3((unsigned)(n2 / (8 * 256))), dim3(256), 0, 0, d, s);
+                        else hipLaunchKernelGGL(read16u<8>, dim3((unsigned)(n2 / (8 * 256))), dim3(256), 0, 0, s, o);
+                    }
+                    CK(hipEventRecord(e1, 0));
+                    CK(hipEventSynchronize(e1));
+                    float ms = 0;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
                 }
-                CK(hipEventRecord(e1, 0));
-                CK(hipEventSynchronize(e1));
-                float ms = 0;
-                CK(hipEventElapsedTime(&ms, e0, e1));
                 const double bytes = (which == 0 ? 32.0 : 16.0) * n2;
-                printf(", \"%s_%s_gbs\": %.0f", which == 0 ? "copy16u8" : "read16u8", ws == 0 ? "1gib" : "32mib", bytes / (ms / reps * 1e-3) / 1e9);
+                printf(", \"%s_%s_gbs\": %.0f", which == 0 ? "copy16u8" : "read16u8", ws == 0 ? "1gib" : "32mib", bytes / (best / reps * 1e-3) / 1e9);
             }
             CK(hipFree(s)); CK(hipFree(d)); CK(hipFree(o));
         }
