@@ -152,7 +152,7 @@ EXPORTS = [
     "adflow_gpu_halo_local_copy", "adflow_gpu_set_bc_callback", "adflow_gpu_bc_register", "adflow_gpu_apply_all_bc", "adflow_gpu_download_wall_stress", "adflow_gpu_abi_sizes2", "adflow_gpu_xhalo", "adflow_gpu_actuator_register", "adflow_gpu_comm_register_periodic", "adflow_gpu_coarse_coordinates", "adflow_gpu_exchange_coor",
     "adflow_gpu_upload_coordinates", "adflow_gpu_update_geometry", "adflow_gpu_reference_shock_sensor",
     "adflow_gpu_wall_distance_register", "adflow_gpu_update_wall_distances",
-    "adflow_gpu_fd_jacobian", "adflow_gpu_release_workspace", "adflow_gpu_jacobian_info", "adflow_gpu_download_jacobian", "adflow_gpu_download_jacobian_rows",
+    "adflow_gpu_fd_jacobian", "adflow_gpu_release_workspace", "adflow_gpu_selftest_math", "adflow_gpu_jacobian_info", "adflow_gpu_download_jacobian", "adflow_gpu_download_jacobian_rows",
     "adflow_gpu_event_record", "adflow_gpu_event_elapsed_ms", "adflow_gpu_sync", "adflow_gpu_set_async",
     "adflow_gpu_abi_sizes", "adflow_gpu_set_tuning", "adflow_gpu_march_stats",
 ]
@@ -203,6 +203,7 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
     lib.adflow_gpu_update_wall_distances.argtypes = [c_int, c_void_p, ctypes.c_int64]
     lib.adflow_gpu_fd_jacobian.argtypes = [c_int, c_uint, c_double]
     lib.adflow_gpu_release_workspace.argtypes = [ctypes.POINTER(ctypes.c_int64)]
+    lib.adflow_gpu_selftest_math.argtypes = [c_int, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]
     lib.adflow_gpu_jacobian_info.argtypes = [POINTER(ctypes.c_int32), POINTER(ctypes.c_int32), POINTER(ctypes.c_int32)]
     lib.adflow_gpu_download_jacobian.argtypes = [c_int, c_int, c_int, c_void_p]
     lib.adflow_gpu_download_jacobian_rows.argtypes = [c_int, c_int, c_int, c_void_p]

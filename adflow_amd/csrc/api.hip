@@ -2080,6 +2080,27 @@ int adflow_gpu_release_workspace(int64_t* bytes)
     return 0;
 }
 
+int adflow_gpu_selftest_math(int which, const double* x, const double* a, int64_t n, double* y, double* dy)
+{
+    if (g_device < 0) return fail("adflow_gpu_init has not been called");
+    if (which < 0 || which > 7 || n < 0 || !x || !a || !y || !dy) return fail("selftest_math: bad arguments");
+    if (n == 0) return 0;
+    double* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(double) * 5 * (size_t)n));          // x, a, y, (value, derivative)
+    int rc = 0;
+    if (hipMemcpy(d, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + n, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail("selftest_math: upload failed");
+    if (!rc) {
+        ad_launch_selftest_math(which, d, d + n, (long)n, d + 2 * n, d + 3 * n, g_stream);
+        if (hipStreamSynchronize(g_stream) != hipSuccess || hipMemcpy(y, d + 2 * n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(dy, d + 3 * n, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail("selftest_math: kernel or download failed");
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 int adflow_gpu_jacobian_info(int32_t* nState, int32_t* nStencil, int32_t* stencil)
 {
     if (!g_jac_valid) return fail("jacobian_info: no assembled Jacobian (call adflow_gpu_fd_jacobian first)");

@@ -499,4 +499,5 @@ void ad_launch_sa_march(const BlkView* tab, const int4* tiles, int ntiles, const
 void ad_launch_visc_gf(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 bool ad_launch_roe_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
 void ad_launch_inviscid_march(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);
+void ad_launch_selftest_math(int which, const double* x, const double* a, long n, double* y, double* dy, hipStream_t s);
 void ad_launch_visc_march_approx(const BlkView* tab, const int4* tiles, int ntiles, const KParams& kp, hipStream_t s);

@@ -106,6 +106,37 @@ __global__ void k_ad_value(const Dual* __restrict__ src, double* __restrict__ ds
     if (t < n) dst[t] = deriv ? src[t].d : src[t].v;
 }
 
+// adflow_gpu_selftest_math: the fast reciprocal / root / power forms of internal.h and their dual-number forms above, one argument per
+// thread (the kernel-logic emulator replaces them with libm: only a device run sees them)
+__global__ void k_selftest_math(int which, const double* __restrict__ x, const double* __restrict__ a, long n, double* __restrict__ y,
+                                double* __restrict__ dy)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double xv = x[t], av = a[t];
+    const Dual xd(xv, 1.0);
+    double v = 0.0;
+    Dual d(0.0, 0.0);
+    switch (which) {
+    case 0: v = rcp_nr(xv); d = rcp_nr(xd); break;
+    case 1: v = rsq_nr(xv); d = rsq_nr(xd); break;
+    case 2: v = fastsqrt(xv); d = fastsqrt(xd); break;
+    case 3: v = fast_root6(xv); d = fast_root6(xd); break;
+    case 4: v = fast_exp_neg(xv); d = fast_exp_neg(xd); break;
+    case 5: v = fast_powa(xv, av); d = fast_powa(xd, av); break;
+    case 6: v = fastdiv(av, xv); d = fastdiv(av, xd); break;
+    case 7: v = fastdiv(xv, av); d = fastdiv(xd, Dual(av, 0.0)); break;
+    default: break;
+    }
+    y[t] = v;
+    dy[2 * t] = d.v;
+    dy[2 * t + 1] = d.d;
+}
+void ad_launch_selftest_math(int which, const double* x, const double* a, long n, double* y, double* dy, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_selftest_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, which, x, a, n, y, dy);
+}
+
 extern int g_march_kch, g_roe_march;
 namespace adj {
 #define ADF_AD_BUILD 1

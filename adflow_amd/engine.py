@@ -129,6 +129,16 @@ class Engine:
         self._chk(self.lib.adflow_gpu_release_workspace(ctypes.byref(n)))
         return int(n.value)
 
+    def selftestMath(self, which: int, x, a=None):
+        """the kernels' fast division / root / power forms on the arguments x (and exponents / numerators a): returns
+        (plain value, dual value, dual derivative) -- csrc/internal.h, csrc/kernels_ad.hip"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        a = np.ones_like(x) if a is None else np.ascontiguousarray(np.broadcast_to(a, x.shape), dtype=np.float64)
+        y = np.zeros_like(x)
+        dy = np.zeros((x.size, 2))
+        self._chk(self.lib.adflow_gpu_selftest_math(int(which), x.ctypes.data, a.ctypes.data, x.size, y.ctypes.data, dy.ctypes.data))
+        return y, dy[:, 0].reshape(x.shape), dy[:, 1].reshape(x.shape)
+
     def jacobianInfo(self):
         ns, nst = ctypes.c_int32(), ctypes.c_int32()
         self._chk(self.lib.adflow_gpu_jacobian_info(ctypes.byref(ns), ctypes.byref(nst), None))

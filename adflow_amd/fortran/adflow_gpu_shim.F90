@@ -293,6 +293,13 @@ module adflowGpuShim
             import :: c_int, c_ptr
             type(c_ptr), value :: bytes
         end function
+        ! self-test of the fast division / root / power forms of the kernels (plain and dual-number)
+        integer(c_int) function adflow_gpu_selftest_math(which, x, a, n, y, dy) bind(C, name="adflow_gpu_selftest_math")
+            import :: c_int, c_int64_t, c_ptr
+            integer(c_int), value :: which
+            type(c_ptr), value :: x, a, y, dy
+            integer(c_int64_t), value :: n
+        end function
         integer(c_int) function adflow_gpu_jacobian_info(nState, nStencil, stencil) bind(C, name="adflow_gpu_jacobian_info")
             import :: c_int, c_ptr
             integer(c_int), intent(out) :: nState, nStencil

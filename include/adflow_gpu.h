@@ -440,6 +440,13 @@ int adflow_gpu_fd_jacobian(int level, unsigned flags, double delta);
  * assembly lays the slab out again.  Mirrors nothing in the reference, whose Tapenade derivative arrays live in flowDomsd for the
  * whole run (adjointUtils.F90:87-99 allocDerivativeValues). */
 int adflow_gpu_release_workspace(int64_t* bytes);
+/* Self-test of the arithmetic the kernels substitute for the compiler's division, square root, pow and exp (csrc/internal.h: v_rcp_f64 /
+ * v_rsq_f64 seeds + Newton steps, x^(1/6), x^a, exp of a negative argument) and of their dual-number forms (csrc/kernels_ad.hip): for
+ * every i < n   y[i] = f(x[i])  by the plain form and  dy[2i], dy[2i+1] = value and d/dx by the dual form.  which: 0 1/x, 1 1/sqrt(x),
+ * 2 sqrt(x), 3 x^(1/6), 4 exp(x) for x <= 0, 5 x^a[i], 6 a[i]/x, 7 x/a[i].  Host pointers.  Mirrors nothing in the reference (its
+ * compiler's own division and intrinsics, e.g. sa.F90:245-330, solverUtils.F90:292-310): the check that the substitution stays inside
+ * the parity bar on the arguments the flow kernels see, which the CPU emulator of the tests cannot make (it runs libm). */
+int adflow_gpu_selftest_math(int which, const double* x, const double* a, int64_t n, double* y, double* dy);
 /* nState, nStencil and the stencil offsets (nStencil,3) column-major as src/modules/stencils.f90 of the last assembly:
  * block (ll, l) of stencil entry s at row cell (i,j,k) is  d dw(i,j,k,ll) / d w(i-di(s), j-dj(s), k-dk(s), l)  (after resScale) */
 int adflow_gpu_jacobian_info(int32_t* nState, int32_t* nStencil, int32_t* stencil);
