@@ -340,6 +340,24 @@ def rank_grid(n):
     return tuple(g)
 
 
+def weak_owner(e, rx, ry):
+    """owner rank of global block g when every rank of an rx x ry x rz grid owns an e x e x e brick of blocks (blocks numbered with i
+    fastest over the whole (e rx) x (e ry) x (e rz) brick); tests/mp_halo_worker.py runs the same function at 2 / 4 / 8 ranks"""
+    Bi, Bj = e * rx, e * ry
+
+    def owner(g):
+        bi, bj, bk = g % Bi, (g // Bi) % Bj, g // (Bi * Bj)
+        return (bi // e) + rx * ((bj // e) + ry * (bk // e))
+    return owner
+
+
+def strong_owner(nb, world):
+    """owner rank of global block g when ONE mesh of nb equal blocks is farmed over `world` ranks (greedy bin-pack on the cell count,
+    loadBalance.F90:409, on equal blocks: nb / world each, taken in index order so that a rank's blocks are neighbours)"""
+    own = {g: (g * world) // nb for g in range(nb)}
+    return lambda g: own[g]
+
+
 def w_cycle(nlev):
     """cycleStrategy of an `nlev`w cycle (inputParamRoutines.F90:1127-1180 setEntriesWcycle)"""
     if nlev == 2:
@@ -386,21 +404,14 @@ class Job:
             # gets nb / N of them, neighbours in k first): total work fixed, the exchange grows with N
             rx = ry = rz = 1
             self.grid = (1, 1, 1)
-            # (greedy on equal blocks = nb / N each; taken in index order, k slowest, so that a rank's blocks are neighbours)
-            own = {g: (g * world) // nb for g in range(nb)}
-
-            def owner(g):
-                return own[g]
+            owner = strong_owner(nb, world)
         else:
             # weak scaling: every GPU owns an e^3 brick of blocks; the ranks form an rx x ry x rz grid of such bricks, periodic
             # in all three directions, so every evaluation is preceded by the 2-layer exchange of blocketteRes (whalo2,
             # blockette.F90:246): same-GPU copies + RCCL send/recv with up to 7 distinct peers at 8 ranks
             rx, ry, rz = rank_grid(world)
             self.grid = (rx, ry, rz)
-
-            def owner(g, Bi=e * rx, Bj=e * ry):
-                bi, bj, bk = g % Bi, (g // Bi) % Bj, g // (Bi * Bj)
-                return (bi // e) + rx * ((bj // e) + ry * (bk // e))
+            owner = weak_owner(e, rx, ry)
         self.bc = wl.get("bc")
         periodic = (False, False, False) if self.bc else (True, True, True)
         self.topo = [BrickTopology(e * rx, e * ry, e * rz, dims[0] >> l, dims[1] >> l, dims[2] >> l, owner=owner, periodic=periodic)

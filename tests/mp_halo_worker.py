@@ -31,7 +31,8 @@ def main():
     periodic = (True, True, True)
     if mode == "strong":      # bench.py --scaling strong: ONE 2x2x2 brick, nb / N blocks per rank, contiguous in k
         shape = (2, 2, 2)
-        topo = BrickTopology(*shape, *dims, owner=lambda g: (g * world) // 8)
+        import bench
+        topo = BrickTopology(*shape, *dims, owner=bench.strong_owner(8, world))
     elif mode == "wall":      # bench.py's default workload at N = 2 (weak): 2 x 1 x 1 ranks, each a 2x2x2 brick, the ends of the whole
         shape = (4, 2, 2)     # 4x2x2 brick physical boundaries (no pattern entry beyond them), 1-to-1 interfaces inside
         periodic = (False, False, False)
@@ -40,23 +41,15 @@ def main():
         # bench.py's weak layout at any N (Job.__init__): the ranks form an rx x ry x rz grid (rank_grid: 8 -> 2x2x2), every rank owns a
         # 2x2x2 brick of blocks; "weak": periodic in all three directions (the periodic twin), "weakwall": the ends of the whole brick are
         # physical boundaries (the default, wall-bounded workload).  At N = 8 a rank has three face peers and edge / corner peers: 7
-        g3, d, n = [1, 1, 1], 0, world
-        while n > 1:
-            f = 2 if n % 2 == 0 else n
-            g3[d % 3] *= f
-            n //= f
-            d += 1
-        rx, ry, rz = g3
+        # (bench.py's own rank_grid / weak_owner: the layout under test IS the driver's)
+        import bench
+        rx, ry, rz = bench.rank_grid(world)
         e = 2
         dims = (4, 3, 3)
         shape = (e * rx, e * ry, e * rz)
         if mode == "weakwall":
             periodic = (False, False, False)
-
-        def owner(g, Bi=e * rx, Bj=e * ry):
-            bi, bj, bk = g % Bi, (g // Bi) % Bj, g // (Bi * Bj)
-            return (bi // e) + rx * ((bj // e) + ry * (bk // e))
-        topo = BrickTopology(*shape, *dims, owner=owner, periodic=periodic)
+        topo = BrickTopology(*shape, *dims, owner=bench.weak_owner(e, rx, ry), periodic=periodic)
     else:
         shape = (2, 2, 1)
         topo = BrickTopology(*shape, *dims, owner=lambda g: g % world)
