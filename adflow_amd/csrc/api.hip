@@ -1107,7 +1107,7 @@ static int enqueue_flow_fluxes(int level, const KParams& kp, bool viscApprox, bo
                               kp.fineGrid);
     // the approximate residual of the preconditioner matrix: the lumped scalar / matrix dissipation has a marching form on the fine
     // level (k_inviscid_march<.., APX>, round 6); the upwind scheme changes through its limiter only
-    const bool approxOk = !kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND || (kp.fineGrid && g_pc_fused);
+    const bool approxOk = !kp.dissApprox || kp.spaceDiscr == ADFLOW_UPWIND || (kp.fineGrid && g_pc_fused && !kp.fwMode);
     const bool tileInviscid = inviscid_march_enabled() && (kp.spaceDiscr != ADFLOW_DISS_SCALAR || scalarViscM) && approxOk && !anyMoving;
     const bool viscFirst = viscMarch && !kp.fwMode && tileInviscid && !kp.dissApprox && !kp.lumpedDiss;
     // the same order for the thin-layer viscous march of the preconditioner assembly (no gradients)

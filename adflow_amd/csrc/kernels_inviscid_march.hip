@@ -301,8 +301,8 @@ static void launch_im(const BlkView* tab, const int4* tiles, int ntiles, const K
     }
 #endif
     // (the forward-mode passes have no persistent fw: block_res_state_d evaluates the whole residual)
-    if (kp.dissApprox) {
-        if (SCHEME == ADFLOW_UPWIND) return;        // (the approximate upwind residual is the first-order limiter: the caller's business)
+    if (kp.dissApprox && SCHEME != ADFLOW_UPWIND) {
+        // (the approximate upwind residual differs through its limiter only -- F.lim below -- and takes the kernels of the exact one)
         constexpr int S2 = (SCHEME == ADFLOW_UPWIND) ? ADFLOW_DISS_SCALAR : SCHEME;
         if (kp.viscFirst) hipLaunchKernelGGL((k_inviscid_march<S2, false, false, true, true>), grd, blk, 0, s, tab, tiles, kp, kch);
         else if (final_) hipLaunchKernelGGL((k_inviscid_march<S2, false, true, false, true>), grd, blk, 0, s, tab, tiles, kp, kch);

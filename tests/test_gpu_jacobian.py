@@ -36,6 +36,26 @@ def test_pc_rans_variants(engine):
     checks.check_fd_jacobian(engine, (10, 7, 6), rans, WALL, blockettes=True, stretch_k=2.0)       # blocketteResCore as the evaluator
 
 
+def test_pc_on_the_kernels_behind_the_marches(engine):
+    """the preconditioner matrices again with the marching kernels of the approximate residual switched off one layer at a time
+    (tuning pc_fused / roe_march / inviscid_march): k_visc_approx_march + k_roe_march<first order>, then k_inviscid_march<upwind>
+    with the first-order limiter, then the gather kernels -- the code paths blocks outside the tile table, moving blocks and coarse
+    levels take"""
+    rans = FlowParams(equations=RANSEquations, spaceDiscr=upwind, limiter=vanAlbeda)
+    steps = (("pc_fused", 0), ("roe_march", 0), ("inviscid_march", 0))
+    try:
+        for key, val in steps:
+            engine.set_tuning(key, val)
+            checks.check_fd_jacobian(engine, (10, 7, 6), rans, WALL, stretch_k=2.0)
+            checks.check_ad_jacobian(engine, (8, 6, 5), rans, WALL, stretch_k=2.0)
+        for sd in (dissScalar, dissMatrix):       # their marches are off now: the gather forms of the lumped dissipation
+            checks.check_fd_jacobian(engine, (8, 7, 6), rans.replace(spaceDiscr=sd, vis4=0.1 if sd == dissMatrix else 0.0156), WALL, stretch_k=2.0)
+    finally:
+        engine.set_tuning("pc_fused", 1)
+        engine.set_tuning("roe_march", 1)
+        engine.set_tuning("inviscid_march", 2)
+
+
 def test_exact_drdw(engine):
     """usePC = F: 13 colours (Euler) / 35 colours (viscous), 13- and 33-point stencils"""
     checks.check_fd_jacobian(engine, (9, 8, 7), FlowParams(spaceDiscr=dissScalar), EULER, usePC=False)

@@ -561,6 +561,11 @@ def test_pc_assemblies_on_a_level_of_several_blocks(hostsim_engine):
         3: ((4, 6, 5), {1: -6, 2: -15, 3: -3, 4: -6, 5: -1, 6: -1}, ())}, quick=True, stretch_k=2.0)
 
 
+def test_pc_on_the_kernels_behind_the_marches(hostsim_engine):
+    import test_gpu_jacobian as tj
+    tj.test_pc_on_the_kernels_behind_the_marches(hostsim_engine)
+
+
 def test_ad_pc_equal_states_across_a_face(hostsim_engine):
     import test_gpu_jacobian as tj
     tj.test_ad_pc_equal_states_across_a_face(hostsim_engine)
