@@ -254,6 +254,13 @@ def run_case(engine, dims, kw, mk, entry):
         checks.check_block_res_vs_blockette(engine, dims, prm, update_intermed=(entry == "blockette_intermed"), seed=seed, **mk)
 
 
+# tuning keys that select between kernels: key, the non-default settings drawn
+KERNEL_KEYS = [("roe_march", [0]), ("inviscid_march", [0, 1]), ("viscous_tiled", [0]), ("sa_march", [0]), ("euler_march", [0]),
+               ("dadi_pcr", [0]), ("dadi_upd", [0]), ("ra_pcr", [0]), ("rvec_joint", [0]), ("metric_from_x", [0, 1, 4])]
+KERNEL_DEFAULTS = {"roe_march": 1, "inviscid_march": 2, "viscous_tiled": 2, "sa_march": 1, "euler_march": 1, "dadi_pcr": 1, "dadi_upd": 1,
+                   "ra_pcr": 1, "rvec_joint": 1, "metric_from_x": 5}
+
+
 def sweep(engine, cases, seed, only=-1, quiet=False, big=False, jac=False):
     """Run `cases` random cases; returns (number run, description of the first failure or None)."""
     rng = np.random.default_rng(seed)
@@ -263,6 +270,14 @@ def sweep(engine, cases, seed, only=-1, quiet=False, big=False, jac=False):
         # (four draws of keys that round 6 removed stay, so that earlier seeds replay as they were)
         rng.choice([0, 1, 2]); rng.integers(0, 2); rng.choice([4, 8]); rng.integers(0, 2)
         tune = {"pc_fused": n % 2, "jac_snap": (n // 2) % 2}      # (pc_fused, jac_snap without a draw: earlier seeds replay as they were)
+        # round 6: the kernel-selection keys too -- in one case of three, one or two of the marching kernels are switched off, so that the
+        # kernels behind them (gather forms, the per-face march under the Roe march) meet every scheme / boundary / size the sweep draws
+        # (their own stream of random numbers: the cases of a seed stay what they were)
+        trng = np.random.default_rng([seed, n, 6])
+        if trng.random() < 1.0 / 3.0:
+            for _ in range(int(trng.integers(1, 3))):
+                k_, vals = KERNEL_KEYS[int(trng.integers(0, len(KERNEL_KEYS)))]
+                tune[k_] = int(trng.choice(vals))
         if only >= 0 and n != only:
             continue
         try:
@@ -274,7 +289,7 @@ def sweep(engine, cases, seed, only=-1, quiet=False, big=False, jac=False):
         except AssertionError as ex:
             return n + 1, f"case {n} (seed {seed}): {dims} {entry} {kw} {mk} {tune}: {ex}"
         finally:
-            for k_, v_ in {"split_eval": 1, "pc_fused": 1, "jac_snap": 1}.items():
+            for k_, v_ in {"split_eval": 1, "pc_fused": 1, "jac_snap": 1, **KERNEL_DEFAULTS}.items():
                 engine.set_tuning(k_, v_)
     return cases, None
 
